@@ -1,0 +1,183 @@
+/*
+ * mvgx.h — C ABI of libmvgx_hip.so: MI355X (gfx950) accelerators behind two openMVG interfaces.
+ *
+ *   matching : exhaustive brute-force L2 2-NN + Lowe ratio on 128-D uint8 descriptors
+ *              (drop-in for openMVG::matching_image_collection::Matcher_Regions(ratio, BRUTE_FORCE_L2))
+ *   ba       : Levenberg-Marquardt bundle adjustment (Jacobians -> Schur -> reduced solve -> back-substitution)
+ *              (drop-in for openMVG::sfm::Bundle_Adjustment_Ceres::Adjust)
+ *
+ * Plain C: pointers + sizes only, no C++/torch types. Every entry point returns an int status
+ * (MVGX_OK == 0) and never throws. `mvgx_last_error()` returns a thread-local message.
+ *
+ * Reference interfaces each entry point replaces are cited as  <path under /root/reference/src>:<line>.
+ */
+#ifndef MVGX_H_
+#define MVGX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVGX_OK 0
+#define MVGX_ERR_ARG 1      /* bad argument (null pointer, dim != 128, index out of range ...)   */
+#define MVGX_ERR_HIP 2      /* a HIP runtime call failed; see mvgx_last_error()                  */
+#define MVGX_ERR_NODEV 3    /* no gfx950 device visible                                          */
+#define MVGX_ERR_STATE 4    /* call order violated (e.g. run before set_regions)                 */
+#define MVGX_ERR_UNSUPPORTED 5 /* semantics the device path does not reproduce (ratio > 1, camera model) */
+#define MVGX_ERR_NUMERIC 6  /* BA: linear solve failed / non-finite cost                         */
+
+const char* mvgx_last_error(void);
+int mvgx_device_count(int* count);
+/* abi version, bumped on any signature change */
+int mvgx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * MATCHING
+ * replaces: matching_image_collection/Matcher_Regions.cpp:32-107 (Matcher_Regions::Match),
+ *           matching/regions_matcher.hpp:162-207 (RegionsMatcherT::MatchDistanceRatio),
+ *           matching/matcher_brute_force.hpp:100-200 (ArrayMatcherBruteForce::SearchNeighbours),
+ *           matching/metric.hpp:55-93 (L2<uint8_t>), matching/matching_filters.hpp:39-60 (NNdistanceRatio)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mvgx_match_ctx mvgx_match_ctx;
+
+/* Called serially on the calling thread, once per image pair that has >= 1 putative match
+ * (Matcher_Regions.cpp:95-103 inserts only non-empty vectors). `ij` holds n (i_in_I, j_in_J) uint32
+ * pairs in ascending j, exactly the IndMatch(i_, j_) order of regions_matcher.hpp:198-204. */
+typedef void (*mvgx_match_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
+
+typedef struct mvgx_match_stats {
+  uint64_t n_pairs;            /* image pairs processed on the device                              */
+  uint64_t n_desc_pairs;       /* sum over processed pairs of nI * nJ distance evaluations          */
+  uint64_t n_matches;          /* putative matches emitted                                          */
+  uint64_t n_kernel_launches;  /* launches of the dominant kernel (l2_top2_ratio)                   */
+  double   kernel_ms;          /* HIP-event time summed over those launches (profile mode only)     */
+  double   total_ms;           /* HIP-event time of the whole device pass (match + compaction)      */
+  uint32_t kernel_vgprs;       /* informational                                                     */
+  uint32_t variant;            /* kernel variant actually used                                      */
+} mvgx_match_stats;
+
+/* device < 0: use the current HIP device. */
+int mvgx_match_create(int device, mvgx_match_ctx** out);
+int mvgx_match_destroy(mvgx_match_ctx* ctx);
+
+/* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch),
+ * "batch_pairs" (pairs per device batch), "keep_host_results" (0: skip D2H of the match lists). */
+int mvgx_match_set_option(mvgx_match_ctx* ctx, const char* key, int64_t value);
+
+/* Load the descriptor arrays of n_images images into HBM (replaces Regions_Provider::get +
+ * RegionsMatcherT ctor/Build, sfm_regions_provider.hpp:76-85, regions_matcher.hpp:119-132).
+ * desc_rows[k] -> n_desc[k] x dim row-major uint8 (Scalar_Regions::DescriptorRawData, scalar_regions.hpp:93);
+ * may be NULL when n_desc[k] == 0. dim must be 128. The arrays are copied; the caller keeps ownership. */
+int mvgx_match_set_regions(mvgx_match_ctx* ctx, const uint8_t* const* desc_rows, const uint32_t* n_desc,
+                           uint32_t n_images, uint32_t dim);
+
+/* Same, descriptors already resident on the device: one concatenated (sum n_desc) x 128 row-major uint8
+ * buffer (device pointer), image k starting at row sum_{m<k} n_desc[m]. */
+int mvgx_match_set_regions_device(mvgx_match_ctx* ctx, const void* d_desc_concat, const uint32_t* n_desc,
+                                  uint32_t n_images, uint32_t dim);
+
+/* Match `n_pairs` image pairs. pairs_IJ = 2*n_pairs uint32 (I = database image, J = query image, as
+ * Matcher_Regions.cpp:57-93). ratio_sq = Square(dist_ratio) computed in float by the caller
+ * (regions_matcher.hpp:196, numeric.h:56). ratio_sq > 1 -> MVGX_ERR_UNSUPPORTED (tie order would be
+ * libstdc++-specific, stl/indexed_sort.hpp:48-63). Pairs whose I has < 2 descriptors or whose J is
+ * empty produce no matches (matcher_brute_force.hpp:108-113, Matcher_Regions.cpp:65-69,85-90).
+ * Results stay valid until the next run/destroy. */
+int mvgx_match_run(mvgx_match_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                   mvgx_match_stats* stats /* may be NULL */);
+
+/* Host view of the last run: offsets[n_pairs+1] into ij (in units of matches); ij = 2 uint32 per match. */
+int mvgx_match_results(mvgx_match_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
+
+/* One-shot convenience with the exact shape of Matcher_Regions::Match: upload, run, and feed `sink`
+ * pair by pair in ascending (I, J) order of the input list. */
+int mvgx_match_pairs_u8_l2(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                           uint32_t dim, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                           int device, mvgx_match_sink sink, void* user);
+
+/* ------------------------------------------------------------------------------------------------
+ * BUNDLE ADJUSTMENT
+ * replaces: sfm/sfm_data_BA_ceres.cpp:165-608 (Bundle_Adjustment_Ceres::Adjust) and, underneath it,
+ *           vendored Ceres 1.13: program_evaluator.h:138-285, residual_block.cc:68-196, corrector.cc:41-155,
+ *           schur_eliminator_impl.h:176-410, schur_complement_solver.cc:120-224,
+ *           levenberg_marquardt_strategy.cc:65-160, trust_region_minimizer.cc:66-786
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mvgx_ba_ctx mvgx_ba_ctx;
+
+/* camera models, numeric values of cameras::EINTRINSIC (cameras/Camera_Common.hpp:39-50) */
+#define MVGX_CAM_PINHOLE 1          /* PINHOLE_CAMERA          params {f, ppx, ppy}              */
+#define MVGX_CAM_PINHOLE_RADIAL1 2  /* PINHOLE_CAMERA_RADIAL1  params {f, ppx, ppy, k1}          */
+#define MVGX_CAM_PINHOLE_RADIAL3 3  /* PINHOLE_CAMERA_RADIAL3  params {f, ppx, ppy, k1, k2, k3}  */
+#define MVGX_BA_MAX_INTR_PARAMS 8
+
+typedef struct mvgx_ba_problem {
+  uint32_t n_poses, n_intrinsics, n_points;
+  uint64_t n_obs;
+  /* parameter blocks, layouts of sfm_data_BA_ceres.cpp:260-351 */
+  const double* poses;        /* n_poses x 6: angle-axis(3), translation(3) with t = -R*C          */
+  const double* intrinsics;   /* n_intrinsics x MVGX_BA_MAX_INTR_PARAMS (unused tail ignored)      */
+  const int32_t* intr_model;  /* n_intrinsics: MVGX_CAM_*                                          */
+  const double* points;       /* n_points x 3                                                      */
+  /* observations (one residual block each, sfm_data_BA_ceres.cpp:354-396) */
+  const uint32_t* obs_pose;   /* n_obs */
+  const uint32_t* obs_intr;   /* n_obs */
+  const uint32_t* obs_point;  /* n_obs */
+  const double* obs_xy;       /* n_obs x 2 */
+  /* constant-parameter masks (bit k set = component k of the block held constant;
+   * all bits of the block set = SetParameterBlockConstant). NULL = everything free. */
+  const uint8_t* pose_const_mask;   /* n_poses, bits 0..5   (Extrinsic_Parameter_Type, sfm_data_BA.hpp:28-34) */
+  const uint8_t* intr_const_mask;   /* n_intrinsics, bits 0..7 (subsetParameterization, Camera_Intrinsics.hpp) */
+  uint8_t points_constant;          /* Structure_Parameter_Type::NONE (sfm_data_BA.hpp:38-42)      */
+  double huber_a;                   /* HuberLoss(a): sfm_data_BA_ceres.cpp:249 uses Square(4.0)=16; <=0: no loss */
+} mvgx_ba_problem;
+
+typedef struct mvgx_ba_options {
+  int32_t max_num_iterations;   /* 50  (sfm_data_BA_ceres.cpp:120,478)           */
+  double function_tolerance;    /* 1e-6 (ceres solver.h:91)                       */
+  double gradient_tolerance;    /* 1e-10 (sfm_data_BA_ceres.cpp:117)              */
+  double parameter_tolerance;   /* 1e-8  (sfm_data_BA_ceres.cpp:118)              */
+  double initial_radius;        /* 1e4  (solver.h:84)                             */
+  double max_radius;            /* 1e16                                           */
+  double min_radius;            /* 1e-32                                          */
+  double min_relative_decrease; /* 1e-3                                           */
+  double min_lm_diagonal;       /* 1e-6                                           */
+  double max_lm_diagonal;       /* 1e32                                           */
+  int32_t max_consecutive_invalid_steps; /* 5                                     */
+  int32_t jacobi_scaling;       /* 1                                              */
+  int32_t verbose;              /* 0                                              */
+} mvgx_ba_options;
+
+typedef struct mvgx_ba_summary {
+  int32_t num_iterations;         /* LM iterations executed (successful + unsuccessful)            */
+  int32_t num_successful_steps;
+  int32_t termination;            /* 0 convergence, 1 no-convergence (max iters), 2 failure         */
+  double initial_cost, final_cost;      /* 1/2 sum rho(|r|^2), as ceres Solver::Summary             */
+  double initial_rmse, final_rmse;      /* sqrt(sum |x - proj|^2 / (2 n_obs)), sfm_data_BA_test.cpp:310-330 */
+  double total_ms;                /* device wall time of the solve (HIP events)                     */
+  double iter_ms_mean;            /* mean time of one LM iteration                                  */
+  double jacobian_ms, schur_ms, solve_ms, backsub_ms, cost_ms; /* per-phase sums (profile)         */
+} mvgx_ba_summary;
+
+void mvgx_ba_default_options(mvgx_ba_options* opt);
+int mvgx_ba_create(int device, const mvgx_ba_problem* problem, mvgx_ba_ctx** out);
+int mvgx_ba_destroy(mvgx_ba_ctx* ctx);
+/* multi-GPU: the caller shards points/observations per rank and supplies an all-reduce(sum, fp64)
+ * callback for the reduced camera system (RCCL via the host language's binding); NULL = single GPU. */
+typedef int (*mvgx_allreduce_f64)(void* user, void* device_buffer, uint64_t count, void* hip_stream);
+int mvgx_ba_set_allreduce(mvgx_ba_ctx* ctx, mvgx_allreduce_f64 fn, void* user);
+int mvgx_ba_solve(mvgx_ba_ctx* ctx, const mvgx_ba_options* opt, mvgx_ba_summary* summary);
+/* one LM iteration (Jacobian + Schur + reduced solve + back-substitution + candidate cost + accept/reject) */
+int mvgx_ba_lm_iteration(mvgx_ba_ctx* ctx, const mvgx_ba_options* opt, mvgx_ba_summary* summary);
+/* copy the current parameter blocks back (same layouts as mvgx_ba_problem) */
+int mvgx_ba_read_params(mvgx_ba_ctx* ctx, double* poses, double* intrinsics, double* points);
+/* residual-only evaluation at the current parameters: cost (1/2 sum rho) and RMSE (no loss) */
+int mvgx_ba_evaluate(mvgx_ba_ctx* ctx, double* cost, double* rmse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVGX_H_ */

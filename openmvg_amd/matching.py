@@ -1,0 +1,210 @@
+"""Host-side mirror of openMVG's collection-matching interface on top of the mvgx C ABI.
+
+Names, argument meaning and skip/insert behaviour follow the reference (paths under /root/reference/src/openMVG):
+
+  EMatcherType                         matching/matcher_type.hpp:15-24
+  exhaustivePairs / contiguousWithOverlap   matching_image_collection/Pair_Builder.hpp:25-44
+  Regions (Scalar_Regions<.., uint8, 128>)  features/scalar_regions.hpp:28-138, features/regions_factory.hpp:19
+  Regions_Provider.get                 sfm/pipelines/sfm_regions_provider.hpp:76-85
+  PairWiseMatches                      matching/indMatch.hpp:70-96  (map Pair -> IndMatches)
+  Matcher_Regions(distRatio, type).Match(provider, pairs, map_PutativeMatches, progress)
+                                       matching_image_collection/Matcher_Regions.{hpp:28-51,cpp:22-107}
+
+Only the path the MI355X kernel accelerates is implemented: BRUTE_FORCE_L2 on uint8 x 128 descriptors.
+Anything else raises (there is no CPU fallback in this package; unchanged openMVG keeps its own CPU matchers).
+"""
+import ctypes as C
+from enum import IntEnum
+
+import numpy as np
+
+from . import _capi
+
+
+class EMatcherType(IntEnum):
+    BRUTE_FORCE_L2 = 0
+    ANN_L2 = 1
+    CASCADE_HASHING_L2 = 2
+    HNSW_L2 = 3
+    HNSW_L1 = 4
+    BRUTE_FORCE_HAMMING = 5
+    HNSW_HAMMING = 6
+
+
+def exhaustivePairs(N):
+    """All (I, J), I < J, in the sorted order of a std::set<Pair> (Pair_Builder.hpp:25-33)."""
+    return [(i, j) for i in range(N) for j in range(i + 1, N)]
+
+
+def contiguousWithOverlap(N, overlapSize):
+    """Pair_Builder.hpp:37-44."""
+    return [(i, j) for i in range(N) for j in range(i + 1, min(i + 1 + overlapSize, N))]
+
+
+def exhaustive_pairs_array(N):
+    """exhaustivePairs as an (n_pairs, 2) uint32 array, same order, without Python tuples."""
+    i, j = np.triu_indices(N, k=1)
+    return np.ascontiguousarray(np.stack([i, j], axis=1).astype(np.uint32))
+
+
+class Regions:
+    """SIFT_Regions stand-in: an (n, 128) uint8 row-major descriptor array (DescriptorRawData layout)."""
+
+    def __init__(self, descriptors):
+        d = np.ascontiguousarray(descriptors, dtype=np.uint8)
+        if d.ndim != 2:
+            raise ValueError("descriptors must be a 2-D array (n, L)")
+        self._d = d
+
+    def RegionCount(self):
+        return int(self._d.shape[0])
+
+    def DescriptorLength(self):
+        return int(self._d.shape[1])
+
+    def Type_id(self):
+        return "h"  # typeid(unsigned char).name() under the Itanium ABI
+
+    def IsScalar(self):
+        return True
+
+    def IsBinary(self):
+        return False
+
+    def DescriptorRawData(self):
+        return self._d
+
+
+class Regions_Provider:
+    """id_view -> Regions cache, fully loaded up-front like the reference provider."""
+
+    def __init__(self, regions_by_view=None):
+        self.cache_ = dict(regions_by_view or {})
+
+    def get(self, x):
+        return self.cache_.get(x)
+
+
+class PairWiseMatches(dict):
+    """Pair -> (n, 2) uint32 array of IndMatch(i_, j_)."""
+
+    def insert(self, pair, ind_matches):
+        self.setdefault(pair, ind_matches)  # std::map::insert keeps an existing entry
+
+
+class MatchContext:
+    """Device-resident descriptor set + runs over pair lists (thin wrapper over mvgx_match_*)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().mvgx_match_create(int(device), C.byref(self._h)))
+        self.n_images = 0
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            _capi.lib().mvgx_match_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _capi.check(_capi.lib().mvgx_match_set_option(self._h, key.encode(), int(value)))
+
+    def set_regions(self, desc_list):
+        """desc_list: sequence of (n_k, 128) uint8 arrays (n_k may be 0)."""
+        arrs = []
+        dim = 128
+        for d in desc_list:
+            a = np.ascontiguousarray(d, dtype=np.uint8)
+            if a.size == 0:
+                a = np.zeros((0, 128), np.uint8)
+            if a.ndim != 2:
+                raise ValueError("each descriptor array must be 2-D (n, L)")
+            if a.shape[0] and a.shape[1] != 128:
+                dim = a.shape[1]  # rejected by the C side (MVGX_ERR_UNSUPPORTED)
+            arrs.append(a)
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))()
+        cnt = (C.c_uint32 * max(n, 1))()
+        for k, a in enumerate(arrs):
+            ptrs[k] = a.ctypes.data if a.shape[0] else None
+            cnt[k] = a.shape[0]
+        self._keep = arrs
+        _capi.check(_capi.lib().mvgx_match_set_regions(self._h, ptrs, cnt, n, dim))
+        self.n_images = n
+
+    def set_regions_device(self, d_ptr, n_desc):
+        n_desc = np.ascontiguousarray(n_desc, dtype=np.uint32)
+        _capi.check(_capi.lib().mvgx_match_set_regions_device(
+            self._h, C.c_void_p(int(d_ptr)), n_desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(n_desc), 128))
+        self.n_images = len(n_desc)
+
+    def run(self, pairs, ratio_sq, fetch=True):
+        """pairs: (n_pairs, 2) uint32. Returns (stats, offsets[n_pairs+1] uint64, ij[(n_matches, 2)] uint32)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        st = _capi.MatchStats()
+        _capi.check(_capi.lib().mvgx_match_run(self._h, pairs.ctypes.data, pairs.shape[0], np.float32(ratio_sq), C.byref(st)))
+        if not fetch:
+            return st, None, None
+        po = C.POINTER(C.c_uint64)()
+        pij = C.POINTER(C.c_uint32)()
+        _capi.check(_capi.lib().mvgx_match_results(self._h, C.byref(po), C.byref(pij)))
+        n = pairs.shape[0]
+        offsets = np.ctypeslib.as_array(po, shape=(n + 1,)).copy() if n + 1 > 0 else np.zeros(1, np.uint64)
+        total = int(offsets[-1])
+        ij = np.ctypeslib.as_array(pij, shape=(total, 2)).copy() if total else np.zeros((0, 2), np.uint32)
+        return st, offsets, ij
+
+
+class Matcher_Regions:
+    """Drop-in mirror of matching_image_collection::Matcher_Regions for BRUTE_FORCE_L2 (MI355X path)."""
+
+    def __init__(self, distRatio, eMatcherType, device=-1, variant=None):
+        self.f_dist_ratio_ = np.float32(distRatio)
+        self.eMatcherType_ = EMatcherType(eMatcherType)
+        self._device = device
+        self._variant = variant
+
+    def Match(self, regions_provider, pairs, map_PutativeMatches, my_progress_bar=None):
+        if self.eMatcherType_ != EMatcherType.BRUTE_FORCE_L2:
+            raise NotImplementedError(
+                f"{self.eMatcherType_.name}: only BRUTE_FORCE_L2 is accelerated; use openMVG's own matcher for the rest")
+        pairs = sorted(set((int(a), int(b)) for a, b in pairs))  # Pair_Set is an ordered std::set
+        if my_progress_bar is not None:
+            my_progress_bar.Restart(len(pairs), "- Matching -")
+        if not pairs:
+            return
+        ids = sorted({v for p in pairs for v in p})
+        regs = {}
+        for v in ids:
+            r = regions_provider.get(v)
+            if r is None:
+                raise KeyError(f"Regions_Provider has no regions for view {v}")
+            regs[v] = r
+        # Matcher_Regions.cpp:85-90: pairs whose Type_id differ are skipped; regions_matcher.cpp:75-81: uchar only here
+        for v, r in regs.items():
+            if r.RegionCount() and (r.Type_id() != "h" or r.DescriptorLength() != 128 or not r.IsScalar()):
+                raise NotImplementedError("device path handles Scalar_Regions<uint8, 128> (SIFT_Regions) only")
+        local = {v: k for k, v in enumerate(ids)}
+        descs = [regs[v].DescriptorRawData() if regs[v].RegionCount() else np.zeros((0, 128), np.uint8) for v in ids]
+        ctx = MatchContext(self._device)
+        try:
+            if self._variant is not None:
+                ctx.set_option("variant", self._variant)
+            ctx.set_regions(descs)
+            parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
+            ratio_sq = np.float32(self.f_dist_ratio_ * self.f_dist_ratio_)  # Square() in float, numeric.h:56
+            _, offsets, ij = ctx.run(parr, ratio_sq)
+        finally:
+            ctx.close()
+        for k, p in enumerate(pairs):
+            a, b = int(offsets[k]), int(offsets[k + 1])
+            if b > a:  # only non-empty vectors are inserted (Matcher_Regions.cpp:99-102)
+                map_PutativeMatches.insert(p, ij[a:b].copy())
+            if my_progress_bar is not None:
+                my_progress_bar += 1

@@ -1,0 +1,149 @@
+/*
+ * match_oracle.c — TEST INFRASTRUCTURE ONLY (never linked into, imported by, or called from the product path).
+ *
+ * Plain-C restatement of openMVG's brute-force L2 + distance-ratio matching path, used as the parity checker
+ * for libmvgx_hip.so. Every function cites the reference lines (under /root/reference/src/openMVG) it follows.
+ * Pinned against the reference itself: tests/test_oracle_matching.py checks it against the golden values of the
+ * reference's own unit tests (metric_test.cpp:31-39,132-147; matching_test.cpp:26-87) and, when oracle/_ref is
+ * built, against the reference's compiled ArrayMatcherBruteForce / Matcher_Regions on random and adversarial input.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file.
+ */
+#include <limits.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* matching/metric.hpp:55-93 — L2<uint8_t>::operator(): ResultType = int (accumulator_trait.hpp:15-32),
+ * sum of squared differences, 4-way unrolled then tail; integer arithmetic, so order does not matter. */
+int oracle_l2_u8(const uint8_t* a, const uint8_t* b, size_t size) {
+  int result = 0;
+  for (size_t k = 0; k < size; ++k) {
+    const int diff = (int)a[k] - (int)b[k];
+    result += diff * diff;
+  }
+  return result;
+}
+
+/* Same metric for the other integral / floating instantiations exercised by metric_test.cpp:31-39. */
+int oracle_l2_i32(const int32_t* a, const int32_t* b, size_t size) {
+  int result = 0;
+  for (size_t k = 0; k < size; ++k) {
+    const int diff = a[k] - b[k];
+    result += diff * diff;
+  }
+  return result;
+}
+float oracle_l2_f32(const float* a, const float* b, size_t size) {
+  /* metric.hpp:60-92: processes 4 at a time accumulating diff0^2+diff1^2+diff2^2+diff3^2 into result */
+  float result = 0.f;
+  size_t k = 0;
+  for (; k + 4 <= size; k += 4) {
+    const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2], d3 = a[k + 3] - b[k + 3];
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  for (; k < size; ++k) {
+    const float d0 = a[k] - b[k];
+    result += d0 * d0;
+  }
+  return result;
+}
+
+/* matching/matcher_brute_force.hpp:163-200 — SearchNeighbours_func for NN neighbours:
+ * all nI distances, then the NN smallest in ascending order (stl/indexed_sort.hpp:48-63, std::partial_sort on
+ * (val, index) packets comparing val only). Ties between equal distances are implementation-defined in the
+ * reference (heap order); this restatement breaks them by ascending database index. For NN=2 and ratio <= 1
+ * the emitted matches do not depend on that order (an accepted query has d0 < d1 strictly).
+ * Returns 0 (and writes nothing) in the reference's early-out cases, matcher_brute_force.hpp:108-113. */
+int oracle_search_neighbours_u8(const uint8_t* db, int nI, const uint8_t* queries, int nJ, int dim, int NN,
+                                int32_t* out_index /* nJ*NN */, int32_t* out_dist /* nJ*NN */) {
+  if (db == NULL || nI < 1 || NN > nI || nJ < 1) return 0;
+#pragma omp parallel for schedule(static)
+  for (int q = 0; q < nJ; ++q) {
+    int32_t* bi = out_index + (size_t)q * NN;
+    int32_t* bd = out_dist + (size_t)q * NN;
+    int filled = 0;
+    for (int i = 0; i < nI; ++i) {
+      const int d = oracle_l2_u8(queries + (size_t)q * dim, db + (size_t)i * dim, (size_t)dim);
+      /* insertion into the sorted prefix of length <= NN; strict '<' keeps the earlier index first on ties */
+      int pos = filled;
+      while (pos > 0 && d < bd[pos - 1]) --pos;
+      if (pos >= NN) continue;
+      const int last = filled < NN ? filled : NN - 1;
+      for (int k = last; k > pos; --k) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; }
+      bd[pos] = d; bi[pos] = i;
+      if (filled < NN) ++filled;
+    }
+  }
+  return 1;
+}
+
+/* matching/matching_filters.hpp:39-60 — NNdistanceRatio on int distances: `(*iter) < fratio * (*iter2)` is
+ * evaluated as (float)d0 < fratio * (float)d1 in binary32 (usual arithmetic conversions; x86-64 SSE, no x87). */
+static int ratio_ok(int d0, int d1, float fratio) {
+  volatile float rhs = fratio * (float)d1; /* volatile: forbid contraction / excess precision */
+  return (float)d0 < rhs;
+}
+
+/* matching/regions_matcher.hpp:162-207 — RegionsMatcherT::MatchDistanceRatio with b_squared_metric_ = true
+ * (regions_matcher.cpp:75-81): 2-NN search, ratio filter with Square(distance_ratio) (numeric.h:56: x*x in
+ * float), emit IndMatch(i_ = index in I (database), j_ = index in J (query)) in ascending j.
+ * out_ij must hold 2*nJ uint32. Returns the number of matches. */
+uint32_t oracle_match_distance_ratio_u8(const uint8_t* dbI, int nI, const uint8_t* qJ, int nJ, int dim,
+                                        float distance_ratio, uint32_t* out_ij) {
+  if (nJ < 1 || nI < 2) return 0; /* SearchNeighbours returns false -> no matches */
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nJ);
+  int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nJ);
+  uint32_t n = 0;
+  if (oracle_search_neighbours_u8(dbI, nI, qJ, nJ, dim, 2, idx, dist)) {
+    const float fratio = distance_ratio * distance_ratio; /* Square(distance_ratio), float */
+    for (int q = 0; q < nJ; ++q) {
+      if (ratio_ok(dist[2 * q], dist[2 * q + 1], fratio)) {
+        out_ij[2 * n] = (uint32_t)idx[2 * q];
+        out_ij[2 * n + 1] = (uint32_t)q;
+        ++n;
+      }
+    }
+  }
+  free(idx);
+  free(dist);
+  return n;
+}
+
+/* matching_image_collection/Matcher_Regions.cpp:32-107 — Matcher_Regions::Match for BRUTE_FORCE_L2 on uint8
+ * 128-D regions. For every input pair (I, J) (processed grouped by I; the grouping does not change results):
+ *   I empty -> skipped (:65-69); J empty -> skipped (:85-90); otherwise MatchDistanceRatio; the pair is reported
+ *   only if it has matches (:99-102).
+ * Output: offsets[n_pairs+1] (match counts prefix, in input pair order), ij (2 uint32 per match), capacity in
+ * matches; returns total matches or (uint64_t)-1 if capacity is too small. */
+uint64_t oracle_matcher_regions_match_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                         uint32_t dim, const uint32_t* pairs_IJ, uint64_t n_pairs,
+                                         float distance_ratio, uint64_t* offsets, uint32_t* ij, uint64_t capacity) {
+  uint64_t total = 0;
+  offsets[0] = 0;
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    const uint32_t I = pairs_IJ[2 * p], J = pairs_IJ[2 * p + 1];
+    uint32_t n = 0;
+    if (I < n_images && J < n_images && n_desc[I] != 0 && n_desc[J] != 0) {
+      if (total + n_desc[J] > capacity) return (uint64_t)-1;
+      n = oracle_match_distance_ratio_u8(desc_rows[I], (int)n_desc[I], desc_rows[J], (int)n_desc[J], (int)dim,
+                                         distance_ratio, ij + 2 * total);
+    }
+    total += n;
+    offsets[p + 1] = total;
+  }
+  return total;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,108 @@
+// ref_shim_match.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Thin extern "C" wrapper (our code) around the REFERENCE's own matching implementation, compiled in place from
+// /root/reference/src by oracle/Makefile into oracle/_ref/libref_match.so. No reference source is copied into this
+// repository: this file only #includes the reference headers and calls the reference classes:
+//   openMVG::matching::L2<uint8_t>                                   matching/metric.hpp:55-93 (+ metric_simd.hpp AVX2)
+//   openMVG::matching::ArrayMatcherBruteForce<uint8_t, L2<uint8_t>>  matching/matcher_brute_force.hpp:27-201
+//   openMVG::matching_image_collection::Matcher_Regions              matching_image_collection/Matcher_Regions.cpp:22-107
+// fed through an in-memory sfm::Regions_Provider (sfm/pipelines/sfm_regions_provider.hpp:30-144, cache_ is protected).
+// Used to (a) validate oracle/match_oracle.c, (b) serve as the "reference" CPU baseline in bench.py.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "openMVG/features/regions_factory.hpp"
+#include "openMVG/matching/indMatch.hpp"
+#include "openMVG/matching/matcher_brute_force.hpp"
+#include "openMVG/matching/metric.hpp"
+#include "openMVG/matching_image_collection/Matcher_Regions.hpp"
+#include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
+
+using namespace openMVG;
+
+namespace {
+
+struct InMemoryRegionsProvider : public sfm::Regions_Provider {
+  void set(IndexT id, std::shared_ptr<features::Regions> r) { cache_[id] = std::move(r); }
+  void set_type(features::Regions* t) { region_type_.reset(t); }
+};
+
+std::shared_ptr<features::Regions> make_sift_regions(const uint8_t* rows, uint32_t n) {
+  auto r = std::make_shared<features::SIFT_Regions>();
+  r->Features().resize(n);
+  r->Descriptors().resize(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    r->Features()[k] = features::SIOPointFeature(float(k), float(k), 1.f, 0.f);
+    std::memcpy(r->Descriptors()[k].data(), rows + size_t(k) * 128, 128);
+  }
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+typedef void (*ref_match_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
+
+// L2<uint8_t> on `size` elements (the AVX2 path of the reference engages for size == 128 when built with
+// -DOPENMVG_USE_AVX2 and needs 32-byte aligned rows: inputs are copied to aligned storage here).
+int ref_l2_u8(const uint8_t* a, const uint8_t* b, size_t size) {
+  std::vector<uint8_t, Eigen::aligned_allocator<uint8_t>> aa(a, a + size), bb(b, b + size);
+  matching::L2<uint8_t> metric;
+  return metric(aa.data(), bb.data(), size);
+}
+
+int ref_uses_avx2(void) {
+#ifdef OPENMVG_USE_AVX2
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// ArrayMatcherBruteForce<uint8_t>::Build + SearchNeighbours. out arrays sized nJ*NN. Returns 1 on success.
+int ref_search_neighbours_u8(const uint8_t* db, int nI, const uint8_t* queries, int nJ, int dim, int NN,
+                             int32_t* out_index, int32_t* out_dist) {
+  std::vector<uint8_t, Eigen::aligned_allocator<uint8_t>> dbc(db, db + size_t(nI > 0 ? nI : 0) * dim);
+  std::vector<uint8_t, Eigen::aligned_allocator<uint8_t>> qc(queries, queries + size_t(nJ > 0 ? nJ : 0) * dim);
+  matching::ArrayMatcherBruteForce<uint8_t, matching::L2<uint8_t>> m;
+  m.Build(dbc.data(), nI, dim);
+  matching::IndMatches idx;
+  std::vector<int> dist;
+  if (!m.SearchNeighbours(qc.data(), nJ, &idx, &dist, size_t(NN))) return 0;
+  for (size_t k = 0; k < idx.size(); ++k) {
+    out_index[k] = int32_t(idx[k].j_);
+    out_dist[k] = dist[k];
+  }
+  return 1;
+}
+
+// Matcher_Regions(dist_ratio, BRUTE_FORCE_L2).Match on in-memory SIFT_Regions. `sink` is called for every entry of
+// the resulting PairWiseMatches map (sorted by (I, J)). Returns the number of pairs with matches.
+uint64_t ref_matcher_regions_match_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                      const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                      ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::SIFT_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) provider->set(k, make_sift_regions(desc_rows[k], n_desc[k]));
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) {
+      flat[2 * m] = kv.second[m].i_;
+      flat[2 * m + 1] = kv.second[m].j_;
+    }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP path (through the C ABI) must reproduce the reference bit-exactly.
+
+Checkers: the committed golden fixtures (outputs of the reference's Matcher_Regions), the C oracle on seeded inputs,
+and size-independent properties at the full 2000-descriptor size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openmvg_amd import _capi, matching, synth
+from tests import _golden, _oracle
+from tests.test_oracle_matching import _adversarial_set
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, 1, 2, 3]  # 0 naive check kernel, 1..3 MFMA kernel with the three window-staging forms
+
+
+def run_hip(imgs, pairs, ratio, variant, batch_pairs=None):
+    ctx = matching.MatchContext(0)
+    try:
+        ctx.set_option("variant", variant)
+        if batch_pairs:
+            ctx.set_option("batch_pairs", batch_pairs)
+        ctx.set_regions(imgs)
+        r = np.float32(ratio)
+        st, offsets, ij = ctx.run(pairs, r * r)
+    finally:
+        ctx.close()
+    return st, offsets, ij
+
+
+def assert_same(pairs, offsets, ij, ref):
+    got = _oracle.offsets_to_dict(pairs, offsets, ij)
+    assert set(got) == set(ref), (sorted(set(got) ^ set(ref))[:10])
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), (k, got[k][:5], ref[k][:5])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", _golden.CASES)
+def test_golden_fixtures(case, variant):
+    imgs, pairs, ratio, ref = _golden.load_case(case)
+    st, offsets, ij = run_hip(imgs, pairs, ratio, variant)
+    assert_same(pairs, offsets, ij, ref)
+    assert int(st.n_matches) == sum(len(v) for v in ref.values())
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("ratio", [0.8, 0.6, 1.0])
+def test_adversarial_vs_oracle(variant, ratio):
+    imgs = _adversarial_set()
+    n = len(imgs)
+    pairs = np.concatenate([matching.exhaustive_pairs_array(n), matching.exhaustive_pairs_array(n)[:, ::-1]])
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
+    _, offsets, ij = run_hip(imgs, pairs, ratio, variant)
+    assert np.array_equal(offsets, o_off)
+    assert np.array_equal(ij, o_ij)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_ragged_sizes_full_range_bytes(variant):
+    """Tile/window boundaries (31/32/33, 255/256/257, 511/513) on iid uniform bytes (largest norms)."""
+    sizes = [0, 1, 2, 3, 31, 32, 33, 63, 255, 256, 257, 511, 513, 1000]
+    imgs = synth.random_descriptors(len(sizes), sizes, seed=12)
+    # plant near-duplicates so that matches exist across ragged images
+    rng = np.random.default_rng(2)
+    for k in range(4, len(sizes)):
+        m = min(sizes[k], sizes[k - 1])
+        imgs[k][:m] = np.clip(imgs[k - 1][:m].astype(np.int16) + rng.integers(-9, 10, (m, 128)), 0, 255).astype(np.uint8)
+    n = len(imgs)
+    pairs = np.concatenate([matching.exhaustive_pairs_array(n), matching.exhaustive_pairs_array(n)[:, ::-1]])
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    _, offsets, ij = run_hip(imgs, pairs, 0.8, variant)
+    assert int(o_off[-1]) > 500
+    assert np.array_equal(offsets, o_off)
+    assert np.array_equal(ij, o_ij)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_extreme_values_do_not_overflow_packed_keys(variant):
+    """All-0 vs all-255 rows give d = 8 323 200 (the maximum); mixed extremes exercise every key range."""
+    rng = np.random.default_rng(7)
+    a = np.zeros((300, 128), np.uint8); b = np.full((300, 128), 255, np.uint8)
+    a[::3] = rng.integers(0, 2, (100, 128), dtype=np.uint8) * 255
+    b[::5] = rng.integers(0, 2, (60, 128), dtype=np.uint8) * 255
+    c = rng.integers(0, 256, (300, 128), dtype=np.uint8)
+    imgs = [a, b, c]
+    pairs = np.array([[0, 1], [1, 0], [0, 2], [2, 0], [1, 2], [2, 1]], np.uint32)
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 1.0)
+    _, offsets, ij = run_hip(imgs, pairs, 1.0, variant)
+    assert np.array_equal(offsets, o_off) and np.array_equal(ij, o_ij)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_rootsift_like_2000_desc_sampled_vs_oracle_and_batching(variant):
+    """Full-size images (2000 x 128): every pair of 12 images vs the oracle; tiny batches exercise the batch seams."""
+    imgs = synth.image_descriptors(12, n_desc=2000, seed=5)
+    pairs = matching.exhaustive_pairs_array(12)
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    st, offsets, ij = run_hip(imgs, pairs, 0.8, variant, batch_pairs=7)
+    assert int(st.n_desc_pairs) == 66 * 2000 * 2000
+    assert int(o_off[-1]) > 1000
+    assert np.array_equal(offsets, o_off)
+    assert np.array_equal(ij, o_ij)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_properties_at_full_size(variant):
+    """Size-independent properties at 2000 descriptors/image:
+    (1) an image against a row-permuted copy of itself matches every distinct row to its preimage;
+    (2) permuting the database rows permutes the reported i indices and nothing else;
+    (3) the result does not depend on the batch size."""
+    rng = np.random.default_rng(42)
+    base = synth.image_descriptors(3, n_desc=2000, seed=77)
+    A = base[0]
+    _, inv = np.unique(A, axis=0, return_inverse=True)
+    assert len(set(inv.tolist())) == len(A)  # all rows distinct in this fixture
+    perm = rng.permutation(len(A))
+    Ap = A[perm]                                # Ap[k] = A[perm[k]]
+    imgs = [A, Ap, base[1], base[2]]
+    pairs = np.array([[0, 1], [1, 0], [0, 2], [1, 2], [2, 3]], np.uint32)
+    _, off, ij = run_hip(imgs, pairs, 0.8, variant)
+    g = _oracle.offsets_to_dict(pairs, off, ij)
+    # (1) database A, queries Ap: query j matches i = perm[j], all 2000 accepted (d0 = 0 < 0.64 d1)
+    m01 = g[(0, 1)]
+    assert len(m01) == 2000 and np.array_equal(m01[:, 1], np.arange(2000)) and np.array_equal(m01[:, 0], perm)
+    # (2) same queries (image 2) against A and against Ap: j lists equal, i lists related by the permutation
+    m02, m12 = g[(0, 2)], g[(1, 2)]
+    assert np.array_equal(m02[:, 1], m12[:, 1])
+    assert np.array_equal(m02[:, 0], perm[m12[:, 0]])
+    # (3) batch seams
+    _, off2, ij2 = run_hip(imgs, pairs, 0.8, variant, batch_pairs=2)
+    assert np.array_equal(off, off2) and np.array_equal(ij, ij2)
+
+
+def test_oneshot_sink_entry_point_matches_reference_container_semantics():
+    """mvgx_match_pairs_u8_l2 + sink: only non-empty pairs are reported, in input order, ascending j."""
+    imgs, pairs, ratio, ref = _golden.load_case("adv08")
+    arrs = [np.ascontiguousarray(i) for i in imgs]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data if len(a) else None for a in arrs])
+    cnt = (C.c_uint32 * len(arrs))(*[len(a) for a in arrs])
+    seen = []
+
+    def sink(_u, I, J, pij, n):
+        seen.append(((int(I), int(J)), np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()))
+
+    cb = _capi.MATCH_SINK(sink)
+    r = np.float32(ratio)
+    _capi.check(_capi.lib().mvgx_match_pairs_u8_l2(ptrs, cnt, len(arrs), 128, pairs.ctypes.data, len(pairs), r * r, 0, cb, None))
+    assert [k for k, _ in seen] == [tuple(map(int, p)) for p in pairs if tuple(map(int, p)) in ref]
+    for k, v in seen:
+        assert np.array_equal(v, ref[k])
+        assert np.all(np.diff(v[:, 1].astype(np.int64)) > 0)
+
+
+def test_matcher_regions_mirror_drop_in():
+    """The host-side mirror keeps the reference call shape: Matcher_Regions(ratio, BRUTE_FORCE_L2).Match(provider, pairs, map)."""
+    imgs, pairs, ratio, ref = _golden.load_case("sift08")
+    provider = matching.Regions_Provider({k: matching.Regions(d) for k, d in enumerate(imgs)})
+    out = matching.PairWiseMatches()
+    matching.Matcher_Regions(ratio, matching.EMatcherType.BRUTE_FORCE_L2).Match(provider, [tuple(p) for p in pairs], out)
+    assert set(out) == set(ref)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k])
+
+
+def test_error_behaviour():
+    ctx = matching.MatchContext(0)
+    try:
+        with pytest.raises(_capi.MvgxError) as e:
+            ctx.set_regions([np.zeros((4, 64), np.uint8)])
+        assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
+        ctx.set_regions(synth.random_descriptors(2, 40, seed=1))
+        with pytest.raises(_capi.MvgxError) as e:
+            ctx.run(np.array([[0, 1]], np.uint32), 1.5)  # ratio^2 > 1: tie order is libstdc++-specific in the reference
+        assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
+        with pytest.raises(_capi.MvgxError) as e:
+            ctx.run(np.array([[0, 2]], np.uint32), 0.64)
+        assert e.value.code == _capi.MVGX_ERR_ARG
+        st, off, ij = ctx.run(np.zeros((0, 2), np.uint32), 0.64)
+        assert int(st.n_pairs) == 0 and len(ij) == 0
+    finally:
+        ctx.close()
+    with pytest.raises(NotImplementedError):
+        matching.Matcher_Regions(0.8, matching.EMatcherType.ANN_L2).Match(matching.Regions_Provider(), [(0, 1)], {})
