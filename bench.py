@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X matching + BA hot path (contract: see the driver's prompt).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the matching hot path over this rank's shard of the exhaustive pair list (+ one BA LM
+iteration on the BA scene when the BA kernels are built). Workload at N=1: BASELINE.json configs[1]
+("1k images x 2k SIFT/img exhaustive brute-force L2 matching on 1 MI355X" = 499 500 image pairs = 2.0e12
+descriptor pairs). Weak scaling: N ranks match round(1000*sqrt(N)) images, i.e. ~499 500 pairs per GPU; the pair
+list is cut into N contiguous shards, descriptors are replicated, no data-path collective.
+
+`value` = descriptor pairs (distance evaluations) per second over all ranks, inputs resident in HBM when the clock
+starts, result lists delivered to host memory inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+I8_MFMA_DENSE_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: i8 MFMA = 2x the 2.5 PF bf16 dense peak (2xK); ubench 4404 TOPS
+FLOP_PER_DESC_PAIR = 256.0          # 128 MAC
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=0, help="images at N=1 (default 1000 = configs[1])")
+    ap.add_argument("--desc", type=int, default=2000)
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--ratio", type=float, default=0.8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-ba", action="store_true")
+    return ap.parse_args()
+
+
+def shard_pairs(pairs, rank, world):
+    n = len(pairs)
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return pairs[lo:hi]
+
+
+def cpu_baseline(descs, pairs, ratio, budget_s):
+    """Reference CPU path (oracle/_ref: openMVG's own Matcher_Regions, -O3 -mavx2 OpenMP/std::async build) — or the C
+    restatement if the reference build is absent — timed on a bounded random sample of the same pair list."""
+    from tests import _oracle
+    rng = np.random.default_rng(123)
+    kind = "reference" if _oracle.have_ref_match() else "port"
+    fn = _oracle.ref_matcher_regions_match if kind == "reference" else _oracle.port_matcher_regions_match
+    order = rng.permutation(len(pairs))
+    t0 = time.perf_counter()
+    fn(descs, pairs[order[:2]], ratio)
+    t1 = time.perf_counter()
+    per_pair = max((t1 - t0) / 2.0, 1e-4)
+    n = int(max(4, min(len(pairs), budget_s / per_pair)))
+    sample = pairs[order[:n]]
+    dp = float(sum(len(descs[a]) * len(descs[b]) for a, b in sample))
+    t0 = time.perf_counter()
+    fn(descs, sample, ratio)
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    if kind == "port":
+        cores = _oracle.port().oracle_num_threads()
+    return {"value": dp / dt, "unit": "descriptor pairs/s", "cores": int(cores), "kind": kind,
+            "sample": f"{n} random image pairs of the same set ({dp:.3g} descriptor pairs) in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from openmvg_amd import matching, synth
+
+    n_images = args.images if args.images > 0 else 1000
+    n_images = int(round(n_images * np.sqrt(world)))
+    descs = synth.image_descriptors(n_images, n_desc=args.desc, seed=0xC0FFEE00)
+    all_pairs = matching.exhaustive_pairs_array(n_images)
+    pairs = np.ascontiguousarray(shard_pairs(all_pairs, rank, world))
+
+    ctx = matching.MatchContext(local_rank)
+    if args.variant >= 0:
+        ctx.set_option("variant", args.variant)
+    ctx.set_option("profile", 1)
+    ctx.set_regions(descs)  # descriptors resident in HBM (tile layout built here, outside the timed region)
+    ratio_sq = np.float32(args.ratio) * np.float32(args.ratio)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.run(pairs, ratio_sq, fetch=False)
+
+    kernel_ms = 0.0
+    launches = 0
+    desc_pairs = 0
+    matches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, _, _ = ctx.run(pairs, ratio_sq, fetch=False)
+        kernel_ms += st.kernel_ms
+        launches += int(st.n_kernel_launches)
+        desc_pairs += int(st.n_desc_pairs)
+        matches = int(st.n_matches)
+        variant = int(st.variant)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt, float(desc_pairs), kernel_ms, float(launches)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        total_desc_pairs = float(tsum[1])
+    else:
+        total_desc_pairs = float(desc_pairs)
+
+    if rank == 0:
+        value = total_desc_pairs / dt
+        # roofline of the dominant kernel (l2_top2_ratio), this rank: algorithmic flop per launch / mean launch time
+        flop_per_launch = (desc_pairs / max(launches, 1)) * FLOP_PER_DESC_PAIR
+        mean_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
+        achieved = flop_per_launch / mean_launch_s / 1e12 if mean_launch_s > 0 else 0.0
+        out = {
+            "metric": "descriptor pairs/s (brute-force L2 2-NN + ratio matching)",
+            "value": value,
+            "unit": "descriptor pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i8 (int32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": f"{n_images} images x {args.desc} SIFT-like uint8x128 descriptors, exhaustive pairs "
+                                   f"({len(all_pairs)} image pairs, {len(pairs)} on rank 0), ratio {args.ratio}",
+                       "kernel_variant": variant, "matches_rank0": matches,
+                       "parallelism": f"pair-sharded x{world}, no collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "l2_top2_ratio_kernel", "launches": launches,
+                         "mean_launch_ms": kernel_ms / max(launches, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is a reported side figure; never let it kill the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {e!r}"}
+        if not args.no_ba:
+            try:
+                from bench_ba import ba_bench_record
+                out["ba"] = ba_bench_record(local_rank, world)
+            except ImportError:
+                pass
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
