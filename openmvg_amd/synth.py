@@ -39,3 +39,106 @@ def random_descriptors(n_images, n_desc, seed=1):
     if np.isscalar(n_desc):
         n_desc = [int(n_desc)] * n_images
     return [rng.integers(0, 256, size=(int(n), 128), dtype=np.uint8) for n in n_desc]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Bundle-adjustment scenes: cameras on rings looking at the origin (generalised
+# NRealisticCamerasRing, reference multiview/test_data_sets.cpp:45-88: f = 1000, pp = (500, 500)), points in a cube,
+# every point observed by `track_len` consecutive cameras; observations = exact projection + N(0, noise_px);
+# initial state = ground truth perturbed (rotations N(0, rot_deg) angle-axis noise, centres and points N(0, 0.01)).
+# ---------------------------------------------------------------------------------------------------------
+CAM_PINHOLE, CAM_PINHOLE_RADIAL1, CAM_PINHOLE_RADIAL3 = 1, 2, 3
+_NPARAM = {1: 3, 2: 4, 3: 6}
+
+
+def _rodrigues(aa):
+    """angle-axis (n,3) -> rotation matrices (n,3,3)."""
+    aa = np.asarray(aa, np.float64).reshape(-1, 3)
+    th = np.linalg.norm(aa, axis=1)
+    safe = np.where(th > 1e-12, th, 1.0)
+    k = aa / safe[:, None]
+    Kx = np.zeros((len(aa), 3, 3))
+    Kx[:, 0, 1] = -k[:, 2]; Kx[:, 0, 2] = k[:, 1]; Kx[:, 1, 0] = k[:, 2]
+    Kx[:, 1, 2] = -k[:, 0]; Kx[:, 2, 0] = -k[:, 1]; Kx[:, 2, 1] = k[:, 0]
+    s = np.where(th > 1e-12, np.sin(th), th)[:, None, None]
+    c = np.where(th > 1e-12, 1 - np.cos(th), 0.0)[:, None, None]
+    return np.eye(3)[None] + s * Kx + c * np.einsum("nij,njk->nik", Kx, Kx)
+
+
+def _rotmat_to_aa(R):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_matrix(R).as_rotvec()
+
+
+def project(model, intr, pose, X):
+    """numpy restatement of the residual functors' projection (float64), vectorised over observations."""
+    R = _rodrigues(pose[:, :3])
+    p = np.einsum("nij,nj->ni", R, X) + pose[:, 3:6]
+    u, v = p[:, 0] / p[:, 2], p[:, 1] / p[:, 2]
+    r2 = u * u + v * v
+    c = np.ones_like(u)
+    if model >= CAM_PINHOLE_RADIAL1:
+        c = c + intr[:, 3] * r2
+    if model == CAM_PINHOLE_RADIAL3:
+        c = c + intr[:, 4] * r2 * r2 + intr[:, 5] * r2 * r2 * r2
+    return np.stack([intr[:, 1] + intr[:, 0] * u * c, intr[:, 2] + intr[:, 0] * v * c], axis=1)
+
+
+def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1, seed=0xBA5E0000,
+             noise_px=0.5, rot_deg=0.5, center_sigma=0.01, point_sigma=0.01, k_gt=(-0.05, 0.01, 0.0),
+             n_rings=4, outlier_frac=0.0):
+    """Returns a dict with ground truth and the perturbed initial problem (flat arrays, mvgx_ba_problem layout)."""
+    rng = np.random.default_rng(seed)
+    track_len = min(track_len, n_cams)
+    n_rings = max(1, min(n_rings, n_cams // max(1, track_len)))
+    # cameras: ring-major order, radii 1.5..3, small height offsets, looking at the origin
+    per_ring = int(np.ceil(n_cams / n_rings))
+    idx = np.arange(n_cams)
+    ring, k = idx // per_ring, idx % per_ring
+    radius = 1.5 + 1.5 * ring / max(1, n_rings - 1)
+    ang = 2 * np.pi * (k + 0.25 * ring) / per_ring
+    C = np.stack([radius * np.cos(ang), 0.3 * (ring - (n_rings - 1) / 2) + 0.01 * rng.standard_normal(n_cams),
+                  radius * np.sin(ang)], axis=1)
+    z = -C / np.linalg.norm(C, axis=1, keepdims=True)
+    x = np.cross(np.array([0.0, 1.0, 0.0])[None], z); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    Rgt = np.stack([x, y, z], axis=1)          # rows = camera axes: p_cam = R (X - C)
+    aa_gt = _rotmat_to_aa(Rgt)
+    t_gt = -np.einsum("nij,nj->ni", Rgt, C)
+    poses_gt = np.concatenate([aa_gt, t_gt], axis=1)
+    # intrinsics: groups of consecutive cameras share one intrinsic
+    K = _NPARAM[model]
+    intr_gt = np.zeros((n_intr_groups, 8))
+    intr_gt[:, 0] = 1000.0; intr_gt[:, 1] = 500.0; intr_gt[:, 2] = 500.0
+    if model == CAM_PINHOLE_RADIAL1:
+        intr_gt[:, 3] = k_gt[0]
+    if model == CAM_PINHOLE_RADIAL3:
+        intr_gt[:, 3:6] = k_gt
+    cam_group = (np.arange(n_cams) * n_intr_groups) // n_cams
+    X_gt = rng.uniform(-0.3, 0.3, size=(n_points, 3))
+    # visibility: `track_len` consecutive cameras (ring-major order, wrapping) from a random start
+    start = rng.integers(0, n_cams, size=n_points)
+    obs_point = np.repeat(np.arange(n_points, dtype=np.uint32), track_len)
+    obs_pose = ((start[:, None] + np.arange(track_len)[None, :]) % n_cams).astype(np.uint32).reshape(-1)
+    obs_intr = cam_group[obs_pose].astype(np.uint32)
+    xy = project(model, intr_gt[obs_intr], poses_gt[obs_pose], X_gt[obs_point])
+    xy = xy + noise_px * rng.standard_normal(xy.shape)
+    if outlier_frac > 0:
+        bad = rng.random(len(xy)) < outlier_frac
+        xy[bad] += 60.0 * rng.standard_normal((int(bad.sum()), 2))
+    # perturbed initial state
+    Rn = _rodrigues(np.deg2rad(rot_deg) * rng.standard_normal((n_cams, 3)))
+    R0 = np.einsum("nij,njk->nik", Rn, Rgt)
+    C0 = C + center_sigma * rng.standard_normal(C.shape)
+    poses0 = np.concatenate([_rotmat_to_aa(R0), -np.einsum("nij,nj->ni", R0, C0)], axis=1)
+    intr0 = intr_gt.copy()
+    intr0[:, 3:] = 0.0
+    X0 = X_gt + point_sigma * rng.standard_normal(X_gt.shape)
+    return {
+        "n_poses": n_cams, "n_intrinsics": n_intr_groups, "n_points": n_points, "n_obs": len(obs_point),
+        "poses": np.ascontiguousarray(poses0), "intrinsics": np.ascontiguousarray(intr0),
+        "intr_model": np.full(n_intr_groups, model, np.int32), "points": np.ascontiguousarray(X0),
+        "obs_pose": obs_pose, "obs_intr": obs_intr, "obs_point": obs_point, "obs_xy": np.ascontiguousarray(xy),
+        "poses_gt": poses_gt, "intrinsics_gt": intr_gt, "points_gt": X_gt, "n_intr_params": K,
+        "huber_a": 16.0,
+    }

@@ -112,3 +112,115 @@ def offsets_to_dict(pairs, offsets, ij):
         if hi > lo:
             out[(int(a), int(b))] = ij[lo:hi].copy()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bundle adjustment checkers
+# ---------------------------------------------------------------------------------------------------------
+_refba = None
+
+
+def have_ref_ba():
+    return os.path.exists(REF_BA_SO)
+
+
+def ba_problem_struct(scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=None):
+    """Builds a ctypes mvgx_ba_problem (+ the dict of arrays that must stay alive)."""
+    from openmvg_amd import _capi
+    keep = {}
+
+    def arr(name, dtype):
+        a = np.ascontiguousarray(scene[name], dtype=dtype)
+        keep[name] = a
+        return a.ctypes.data
+
+    p = _capi.BaProblem()
+    p.n_poses = int(scene["n_poses"]); p.n_intrinsics = int(scene["n_intrinsics"]); p.n_points = int(scene["n_points"])
+    p.n_obs = int(scene["n_obs"])
+    p.poses = arr("poses", np.float64); p.intrinsics = arr("intrinsics", np.float64)
+    p.intr_model = arr("intr_model", np.int32); p.points = arr("points", np.float64)
+    p.obs_pose = arr("obs_pose", np.uint32); p.obs_intr = arr("obs_intr", np.uint32); p.obs_point = arr("obs_point", np.uint32)
+    p.obs_xy = arr("obs_xy", np.float64)
+    if pose_const_mask is not None:
+        keep["pm"] = np.ascontiguousarray(pose_const_mask, np.uint8); p.pose_const_mask = keep["pm"].ctypes.data
+    if intr_const_mask is not None:
+        keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = keep["im"].ctypes.data
+    p.points_constant = 1 if points_constant else 0
+    p.huber_a = float(scene.get("huber_a", 16.0) if huber_a is None else huber_a)
+    return p, keep
+
+
+def default_ba_options(**kw):
+    from openmvg_amd import _capi
+    o = _capi.BaOptions(50, 1e-6, 1e-10, 1e-8, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 5, 1, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def port_ba_solve(scene, options=None, trace_cap=64, **pk):
+    from openmvg_amd import _capi
+    L = port()
+    L.oracle_ba_solve.restype = C.c_int
+    L.oracle_ba_solve.argtypes = [C.POINTER(_capi.BaProblem), C.POINTER(_capi.BaOptions), C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(_capi.BaSummary), C.c_void_p, C.c_int]
+    prob, keep = ba_problem_struct(scene, **pk)
+    opt = options or default_ba_options()
+    poses = np.zeros_like(keep["poses"]); intr = np.zeros_like(keep["intrinsics"]); pts = np.zeros_like(keep["points"])
+    summ = _capi.BaSummary()
+    trace = np.zeros((trace_cap, 6))
+    rc = L.oracle_ba_solve(C.byref(prob), C.byref(opt), poses.ctypes.data, intr.ctypes.data, pts.ctypes.data, C.byref(summ),
+                           trace.ctypes.data, trace_cap)
+    return rc, summ, poses, intr, pts, trace[: max(0, summ.num_iterations)]
+
+
+def port_ba_evaluate(scene, **pk):
+    from openmvg_amd import _capi
+    L = port()
+    L.oracle_ba_evaluate.restype = C.c_int
+    L.oracle_ba_evaluate.argtypes = [C.POINTER(_capi.BaProblem), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    prob, keep = ba_problem_struct(scene, **pk)
+    cost, rmse = C.c_double(), C.c_double()
+    rc = L.oracle_ba_evaluate(C.byref(prob), C.byref(cost), C.byref(rmse))
+    assert rc == 0
+    return cost.value, rmse.value
+
+
+def port_ba_eval_obs(model, intr, pose, X, obs):
+    L = port()
+    L.oracle_ba_eval_obs.restype = C.c_int
+    L.oracle_ba_eval_obs.argtypes = [C.c_int] + [C.c_void_p] * 8
+    a = [np.ascontiguousarray(v, np.float64) for v in (intr, pose, X, obs)]
+    r = np.zeros(2); Ji = np.zeros((2, 8)); Jc = np.zeros((2, 6)); Jp = np.zeros((2, 3))
+    rc = L.oracle_ba_eval_obs(int(model), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                              r.ctypes.data, Ji.ctypes.data, Jc.ctypes.data, Jp.ctypes.data)
+    assert rc == 0
+    return r, Ji, Jc, Jp
+
+
+def ref_ba_adjust(scene, intrinsics_opt=None, extrinsics_opt=6, structure_opt=1, max_iterations=0, num_threads=0,
+                  linear_solver=0, use_loss=1, print_summary=0):
+    """The reference's Bundle_Adjustment_Ceres::Adjust. Returns (rc, stats[4], poses, intrinsics, points).
+    intrinsics_opt default = ADJUST_ALL (cameras/Camera_Common.hpp:92-100: focal 2 | pp 4 | disto 8 = 14)."""
+    global _refba
+    if _refba is None:
+        _refba = C.CDLL(REF_BA_SO)
+        _refba.ref_ba_adjust.restype = C.c_int
+        _refba.ref_ba_adjust.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    poses = np.ascontiguousarray(scene["poses"], np.float64).copy()
+    intr = np.ascontiguousarray(scene["intrinsics"], np.float64).copy()
+    pts = np.ascontiguousarray(scene["points"], np.float64).copy()
+    model = np.ascontiguousarray(scene["intr_model"], np.int32)
+    op = np.ascontiguousarray(scene["obs_pose"], np.uint32); oi = np.ascontiguousarray(scene["obs_intr"], np.uint32)
+    ox = np.ascontiguousarray(scene["obs_point"], np.uint32); xy = np.ascontiguousarray(scene["obs_xy"], np.float64)
+    stats = np.zeros(4)
+    if intrinsics_opt is None:
+        intrinsics_opt = 14
+    rc = _refba.ref_ba_adjust(int(scene["n_poses"]), int(scene["n_intrinsics"]), int(scene["n_points"]), int(scene["n_obs"]),
+                              poses.ctypes.data, intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data,
+                              oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, int(intrinsics_opt), int(extrinsics_opt),
+                              int(structure_opt), int(max_iterations), int(num_threads), int(linear_solver), int(use_loss),
+                              int(print_summary), stats.ctypes.data)
+    return rc, stats, poses, intr, pts

@@ -1,0 +1,115 @@
+"""CPU tests: pin oracle/ba_oracle.cpp against the reference itself (Bundle_Adjustment_Ceres::Adjust on vendored Ceres 1.13,
+compiled in place into oracle/_ref/libref_ba.so) and against the reference's own unit-test assertions."""
+import numpy as np
+import pytest
+
+from openmvg_amd import ba_options as bo
+from openmvg_amd import synth
+from tests import _oracle
+
+needs_ref = pytest.mark.skipif(not _oracle.have_ref_ba(), reason="oracle/_ref/libref_ba.so not built")
+
+
+def test_autodiff_jacobian_matches_central_differences():
+    rng = np.random.default_rng(0)
+    for model, K in ((1, 3), (2, 4), (3, 6)):
+        for trial in range(5):
+            intr = np.zeros(8); intr[:3] = [1000 + rng.normal(), 500 + rng.normal(), 500 + rng.normal()]
+            intr[3:K] = 0.05 * rng.standard_normal(K - 3)
+            pose = np.concatenate([0.7 * rng.standard_normal(3), rng.standard_normal(3) * 0.2 + [0, 0, 2.5]])
+            if trial == 0:
+                pose[:3] = 1e-9 * rng.standard_normal(3)  # the first-order branch of AngleAxisRotatePoint
+            X = rng.uniform(-0.3, 0.3, 3); obs = rng.uniform(300, 700, 2)
+            r, Ji, Jc, Jp = _oracle.port_ba_eval_obs(model, intr, pose, X, obs)
+
+            def f(i, c, x):
+                return _oracle.port_ba_eval_obs(model, i, c, x, obs)[0]
+            for k in range(K):
+                h = 1e-6 * max(1.0, abs(intr[k])); d = np.zeros(8); d[k] = h
+                assert np.allclose(Ji[:, k], (f(intr + d, pose, X) - f(intr - d, pose, X)) / (2 * h), rtol=2e-5, atol=1e-4)
+            assert np.all(Ji[:, K:] == 0)
+            for k in range(6):
+                d = np.zeros(6); d[k] = 1e-6
+                assert np.allclose(Jc[:, k], (f(intr, pose + d, X) - f(intr, pose - d, X)) / 2e-6, rtol=2e-5, atol=1e-3)
+            for k in range(3):
+                d = np.zeros(3); d[k] = 1e-6
+                assert np.allclose(Jp[:, k], (f(intr, pose, X + d) - f(intr, pose, X - d)) / 2e-6, rtol=2e-5, atol=1e-3)
+
+
+def test_evaluate_matches_numpy_projection():
+    sc = synth.ba_scene(8, 100, track_len=5, model=3, seed=3)
+    cost, rmse = _oracle.port_ba_evaluate(sc, huber_a=0.0)
+    xy = synth.project(3, sc["intrinsics"][sc["obs_intr"]], sc["poses"][sc["obs_pose"]], sc["points"][sc["obs_point"]])
+    res = xy - sc["obs_xy"]
+    assert np.isclose(cost, 0.5 * (res ** 2).sum(), rtol=1e-12)
+    assert np.isclose(rmse, np.sqrt((res ** 2).sum() / res.size), rtol=1e-12)
+
+
+SCENES = {
+    # the shape of sfm_data_BA_test.cpp:47-185 (few views, few points, one shared intrinsic), per camera model
+    "tiny_pinhole": dict(n_cams=3, n_points=6, track_len=3, model=1, seed=11, rot_deg=2.0, noise_px=0.1),
+    "tiny_k1": dict(n_cams=3, n_points=12, track_len=3, model=2, seed=12, rot_deg=2.0, noise_px=0.1),
+    "tiny_k3": dict(n_cams=4, n_points=24, track_len=4, model=3, seed=13, rot_deg=2.0, noise_px=0.1),
+    "ring_pinhole": dict(n_cams=24, n_points=600, track_len=8, model=1, seed=14),
+    "ring_k3_groups": dict(n_cams=24, n_points=600, track_len=8, model=3, n_intr_groups=3, seed=15),
+    "ring_outliers": dict(n_cams=16, n_points=400, track_len=6, model=1, seed=16, outlier_frac=0.05),
+}
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_port_equals_reference_adjust_all(name):
+    sc = synth.ba_scene(**SCENES[name])
+    rc, stats, rp, ri, rx = _oracle.ref_ba_adjust(sc)
+    prc, summ, pp, pi, px, trace = _oracle.port_ba_solve(sc)
+    assert rc == 0 and stats[3] == 1.0 and prc == 0
+    # the reference's own assertion (sfm_data_BA_test.cpp:74-78): RMSE decreases
+    assert stats[1] < stats[0]
+    assert abs(summ.initial_rmse - stats[0]) < 1e-9
+    assert abs(summ.final_rmse - stats[1]) < 1e-7, (summ.final_rmse, stats[1])
+    # parameters agree too (rotations compared as matrices: angle-axis is two-valued near pi)
+    assert np.allclose(synth._rodrigues(pp[:, :3]), synth._rodrigues(rp[:, :3]), rtol=0, atol=1e-6)
+    assert np.allclose(pp[:, 3:], rp[:, 3:], rtol=0, atol=1e-5) and np.allclose(px, rx, rtol=0, atol=1e-5)
+
+
+@needs_ref
+@pytest.mark.parametrize("iopt,eopt,sopt", [
+    (bo.Intrinsic_Parameter_Type.NONE, bo.Extrinsic_Parameter_Type.ADJUST_ALL, 1),
+    (bo.Intrinsic_Parameter_Type.ADJUST_FOCAL_LENGTH, bo.Extrinsic_Parameter_Type.ADJUST_ALL, 1),
+    (bo.Intrinsic_Parameter_Type.ADJUST_FOCAL_LENGTH | bo.Intrinsic_Parameter_Type.ADJUST_DISTORTION, bo.Extrinsic_Parameter_Type.ADJUST_ROTATION, 1),
+    (bo.Intrinsic_Parameter_Type.ADJUST_ALL, bo.Extrinsic_Parameter_Type.ADJUST_TRANSLATION, 1),
+    (bo.Intrinsic_Parameter_Type.ADJUST_ALL, bo.Extrinsic_Parameter_Type.NONE, 1),
+    (bo.Intrinsic_Parameter_Type.ADJUST_ALL, bo.Extrinsic_Parameter_Type.ADJUST_ALL, 0),
+    (bo.Intrinsic_Parameter_Type.NONE, bo.Extrinsic_Parameter_Type.NONE, 1),
+])
+def test_port_equals_reference_subset_parameterizations(iopt, eopt, sopt):
+    sc = synth.ba_scene(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=2, seed=21, rot_deg=0.3)
+    rc, stats, rp, ri, rx = _oracle.ref_ba_adjust(sc, intrinsics_opt=int(iopt), extrinsics_opt=int(eopt), structure_opt=sopt)
+    masks = bo.masks_for(sc, iopt, eopt, sopt)
+    prc, summ, pp, pi, px, trace = _oracle.port_ba_solve(sc, **masks)
+    assert rc == 0 and prc == 0
+    # the reference writes poses back through Pose3(R, C) (ADJUST_ROTATION keeps the old centre, :538-542):
+    # the RMSE of the scene it returns is the RMSE after that write-back
+    sc2 = dict(sc); sc2["poses"] = bo.writeback_poses(sc["poses"], pp, eopt); sc2["intrinsics"] = pi; sc2["points"] = px
+    _, rmse_after = _oracle.port_ba_evaluate(sc2)
+    assert abs(rmse_after - stats[1]) < 1e-7, (rmse_after, summ.final_rmse, stats[1])
+    assert np.allclose(synth._rodrigues(sc2["poses"][:, :3]), synth._rodrigues(rp[:, :3]), rtol=0, atol=1e-6)
+    assert np.allclose(sc2["poses"][:, 3:], rp[:, 3:], rtol=0, atol=1e-5)
+    # constant components really are untouched
+    if int(eopt) == 1:
+        assert np.array_equal(pp, sc["poses"])
+    if sopt == 0:
+        assert np.array_equal(px, sc["points"])
+    if int(iopt) == 1:
+        assert np.array_equal(pi, sc["intrinsics"])
+
+
+@needs_ref
+def test_port_equals_reference_without_loss_and_one_iteration():
+    sc = synth.ba_scene(n_cams=16, n_points=400, track_len=6, model=3, seed=31, outlier_frac=0.03)
+    rc, stats, *_ = _oracle.ref_ba_adjust(sc, use_loss=0)
+    prc, summ, *_ = _oracle.port_ba_solve(sc, huber_a=0.0)
+    assert abs(summ.final_rmse - stats[1]) < 1e-7
+    rc, stats, *_ = _oracle.ref_ba_adjust(sc, max_iterations=1)
+    prc, summ, *_ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(max_num_iterations=1))
+    assert summ.num_iterations == 1 and abs(summ.final_rmse - stats[1]) < 1e-9
