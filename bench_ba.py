@@ -1,0 +1,95 @@
+"""BA leg of bench.py: BASELINE.json configs[2] — synthetic BA, 200 pinhole cameras, 100k points, ~1M observations,
+LM iteration time + final RMSE on 1 MI355X, with the reference's Ceres CPU path timed beside it."""
+import os
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes_per_iteration(n_obs, n_pts, n_cam, n_cols):
+    """fused fp64 LM iteration — observations read twice (Jacobian pass + candidate cost pass), points
+    read + written, camera blocks, dense reduced system accumulated + factored, rhs."""
+    return n_obs * (16 + 12) * 2 + n_pts * (24 + 24) + n_cam * 9 * 8 * 2 + 2 * (n_cols * n_cols * 8) + n_cols * 8
+
+
+def _capture_stderr(fn):
+    """Runs fn() with fd 2 redirected to a temp file (the reference logs Ceres' FullReport through its stderr logger)."""
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        saved = os.dup(2)
+        try:
+            os.dup2(tmp.fileno(), 2)
+            out = fn()
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+        tmp.seek(0)
+        return tmp.read().decode("utf-8", "replace"), out
+
+
+def _parse_report(txt):
+    """Seconds per phase from ceres::Solver::Summary::FullReport()."""
+    import re
+    out = {}
+    for key, pat in (("preprocessor_s", r"Preprocessor\s+([0-9.]+)"), ("residual_eval_s", r"Residual evaluation\s+([0-9.]+)"),
+                     ("jacobian_eval_s", r"Jacobian evaluation\s+([0-9.]+)"), ("linear_solver_s", r"Linear solver\s+([0-9.]+)\n"),
+                     ("minimizer_s", r"Minimizer\s+([0-9.]+)\n"), ("total_s", r"Total\s+([0-9.]+)"),
+                     ("iterations", r"Minimizer iterations\s+([0-9]+)"), ("threads", r"Threads\s+([0-9]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    return out
+
+
+def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
+    from openmvg_amd import ba, synth
+    if world > 1:
+        return {"status": "BA runs on one GPU this round (observation sharding + RCCL all-reduce hook not enabled yet)"}
+    scene = synth.ba_scene(200, 100000, track_len=10, model=synth.CAM_PINHOLE, n_intr_groups=1, seed=0xBA5E0003)
+    ctx = ba.BaContext(scene, device=local_rank)
+    s1 = ctx.lm_iteration(ba.default_options(max_num_iterations=1))   # iteration zero + one LM iteration
+    ctx.close()
+    ctx = ba.BaContext(scene, device=local_rank)
+    t0 = time.perf_counter()
+    s = ctx.solve()
+    wall = time.perf_counter() - t0
+    ctx.close()
+    n_cols = 6 * scene["n_poses"] + 8 * scene["n_intrinsics"]
+    bytes_it = algorithmic_bytes_per_iteration(scene["n_obs"], scene["n_points"], scene["n_poses"], n_cols)
+    rec = {
+        "config": "200 pinhole cams (1 shared intrinsic), 100k points, 1.0M observations, ADJUST_ALL, Huber(16)",
+        "lm_iteration_ms": s.iter_ms_mean,
+        "first_call_ms_iteration_zero_plus_one_iteration": s1.total_ms,
+        "iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "termination": s.termination,
+        "solve_ms": s.total_ms, "solve_wall_ms": wall * 1e3,
+        "initial_rmse": s.initial_rmse, "final_rmse": s.final_rmse, "final_cost": s.final_cost,
+        "roofline": {"bound": "hbm", "achieved": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_iteration": bytes_it},
+    }
+    if cpu:
+        try:
+            from tests import _oracle
+            if _oracle.have_ref_ba():
+                t0 = time.perf_counter()
+                report, (rc, st, *_) = _capture_stderr(lambda: _oracle.ref_ba_adjust(scene, max_iterations=1, print_summary=1))
+                t1 = time.perf_counter() - t0
+                c = {"kind": "reference", "cores": os.cpu_count(), "one_iteration_adjust_s": st[2], "wall_s": t1,
+                     "ceres_full_report": _parse_report(report),
+                     "sample": "Bundle_Adjustment_Ceres::Adjust (vendored Ceres 1.13, SPARSE_SCHUR/EIGEN_SPARSE, OpenMP), "
+                               "same scene, max_num_iterations=1 (problem build + preprocessing + iteration 0 + 1 LM iteration)"}
+                if st[2] * 12 < cpu_budget_s:   # full solve only when it fits the budget
+                    rc, st2, *_ = _oracle.ref_ba_adjust(scene)
+                    c["full_solve_s"] = st2[2]; c["final_rmse"] = st2[1]
+                    c["rmse_diff_vs_gpu"] = abs(st2[1] - s.final_rmse)
+                rec["cpu_baseline"] = c
+        except Exception as e:  # side figure only
+            rec["cpu_baseline"] = {"kind": "reference", "error": repr(e)}
+    return rec
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(ba_bench_record(0, 1)))

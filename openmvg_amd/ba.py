@@ -1,0 +1,147 @@
+"""Host-side mirror of openMVG's bundle-adjustment interface on top of the mvgx C ABI.
+
+  Bundle_Adjustment (abstract: bool Adjust(SfM_Data&, const Optimize_Options&))   sfm/sfm_data_BA.hpp:92-105
+  Bundle_Adjustment_Ceres / BA_Ceres_options                                       sfm/sfm_data_BA_ceres.hpp:31-69
+  Optimize_Options                                                                  sfm/sfm_data_BA.hpp:66-89
+
+The scene is the flat form of SfM_Data the C ABI takes (dict: poses [aa, t], intrinsics, intr_model, points,
+obs_pose / obs_intr / obs_point / obs_xy — layouts of sfm_data_BA_ceres.cpp:260-396). All numerics run in
+libmvgx_hip.so on the GPU; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from . import ba_options as bo
+
+
+class Optimize_Options:
+    def __init__(self, intrinsics_opt=bo.Intrinsic_Parameter_Type.ADJUST_ALL, extrinsics_opt=bo.Extrinsic_Parameter_Type.ADJUST_ALL,
+                 structure_opt=bo.Structure_Parameter_Type.ADJUST_ALL):
+        self.intrinsics_opt = intrinsics_opt
+        self.extrinsics_opt = extrinsics_opt
+        self.structure_opt = structure_opt
+
+
+class BA_Ceres_options:
+    """Field names of Bundle_Adjustment_Ceres::BA_Ceres_options (sfm_data_BA_ceres.cpp:110-149)."""
+
+    def __init__(self, bVerbose=False, bmultithreaded=True):
+        self.bVerbose_ = bVerbose
+        self.parameter_tolerance_ = 1e-8
+        self.gradient_tolerance_ = 1e-10
+        self.bUse_loss_function_ = True
+        self.max_num_iterations_ = 50
+
+
+def default_options(**kw):
+    o = _capi.BaOptions()
+    _capi.lib().mvgx_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class BaContext:
+    """Device-resident BA problem (thin wrapper over mvgx_ba_*)."""
+
+    def __init__(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0, device=-1):
+        self._keep = {}
+
+        def arr(name, dtype):
+            a = np.ascontiguousarray(scene[name], dtype=dtype)
+            self._keep[name] = a
+            return a.ctypes.data
+
+        p = _capi.BaProblem()
+        p.n_poses = int(scene["n_poses"]); p.n_intrinsics = int(scene["n_intrinsics"]); p.n_points = int(scene["n_points"])
+        p.n_obs = int(scene["n_obs"])
+        p.poses = arr("poses", np.float64); p.intrinsics = arr("intrinsics", np.float64)
+        p.intr_model = arr("intr_model", np.int32); p.points = arr("points", np.float64)
+        p.obs_pose = arr("obs_pose", np.uint32); p.obs_intr = arr("obs_intr", np.uint32); p.obs_point = arr("obs_point", np.uint32)
+        p.obs_xy = arr("obs_xy", np.float64)
+        if pose_const_mask is not None:
+            self._keep["pm"] = np.ascontiguousarray(pose_const_mask, np.uint8); p.pose_const_mask = self._keep["pm"].ctypes.data
+        if intr_const_mask is not None:
+            self._keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = self._keep["im"].ctypes.data
+        p.points_constant = 1 if points_constant else 0
+        p.huber_a = float(huber_a)
+        self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().mvgx_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, options=None):
+        s = _capi.BaSummary()
+        _capi.check(_capi.lib().mvgx_ba_solve(self._h, C.byref(options or default_options()), C.byref(s)))
+        return s
+
+    def lm_iteration(self, options=None):
+        s = _capi.BaSummary()
+        _capi.check(_capi.lib().mvgx_ba_lm_iteration(self._h, C.byref(options or default_options()), C.byref(s)))
+        return s
+
+    def evaluate(self):
+        cost, rmse = C.c_double(), C.c_double()
+        _capi.check(_capi.lib().mvgx_ba_evaluate(self._h, C.byref(cost), C.byref(rmse)))
+        return cost.value, rmse.value
+
+    def read_params(self):
+        npz, ni, nx = self.shape
+        poses = np.zeros((npz, 6)); intr = np.zeros((ni, 8)); pts = np.zeros((nx, 3))
+        _capi.check(_capi.lib().mvgx_ba_read_params(self._h, poses.ctypes.data, intr.ctypes.data, pts.ctypes.data))
+        return poses, intr, pts
+
+
+class Bundle_Adjustment_HIP:
+    """Drop-in mirror of sfm::Bundle_Adjustment_Ceres: Adjust(scene, Optimize_Options) -> bool, scene updated in place
+    with the reference's write-back rules (sfm_data_BA_ceres.cpp:527-568)."""
+
+    def __init__(self, options=None, device=-1):
+        self.ceres_options_ = options or BA_Ceres_options()
+        self._device = device
+        self.summary = None
+
+    def ceres_options(self):
+        return self.ceres_options_
+
+    def Adjust(self, scene, options=None):
+        options = options or Optimize_Options()
+        masks = bo.masks_for(scene, options.intrinsics_opt, options.extrinsics_opt, options.structure_opt)
+        co = self.ceres_options_
+        try:
+            ctx = BaContext(scene, huber_a=16.0 if co.bUse_loss_function_ else 0.0, device=self._device, **masks)
+        except _capi.MvgxError as e:
+            if e.code == _capi.MVGX_ERR_UNSUPPORTED:   # "Cannot create a CostFunction for this camera model" -> false
+                return False
+            raise
+        try:
+            opt = default_options(max_num_iterations=co.max_num_iterations_, parameter_tolerance=co.parameter_tolerance_,
+                                  gradient_tolerance=co.gradient_tolerance_)
+            try:
+                self.summary = ctx.solve(opt)
+            except _capi.MvgxError as e:
+                if e.code == _capi.MVGX_ERR_NUMERIC:   # !summary.IsSolutionUsable() -> false, poses/intrinsics untouched
+                    return False
+                raise
+            poses, intr, pts = ctx.read_params()
+        finally:
+            ctx.close()
+        before = np.array(scene["poses"], np.float64)
+        if int(options.extrinsics_opt) != int(bo.Extrinsic_Parameter_Type.NONE):
+            scene["poses"] = bo.writeback_poses(before, poses, options.extrinsics_opt)
+        if int(options.intrinsics_opt) != int(bo.Intrinsic_Parameter_Type.NONE):
+            scene["intrinsics"] = intr
+        scene["points"] = pts
+        return True
