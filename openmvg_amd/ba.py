@@ -118,6 +118,9 @@ class Bundle_Adjustment_HIP:
 
     def Adjust(self, scene, options=None):
         options = options or Optimize_Options()
+        # sfm_data_BA_ceres.cpp:84-108,388-392: a camera model without a cost functor makes Adjust() return false
+        if any(int(m) not in bo.N_INTR_PARAMS for m in scene["intr_model"]):
+            return False
         masks = bo.masks_for(scene, options.intrinsics_opt, options.extrinsics_opt, options.structure_opt)
         co = self.ceres_options_
         try:
