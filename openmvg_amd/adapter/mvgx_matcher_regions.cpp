@@ -1,0 +1,185 @@
+// mvgx_matcher_regions.cpp — link-time replacement for openMVG's
+//   src/openMVG/matching_image_collection/Matcher_Regions.cpp
+//
+// Compile this translation unit INSTEAD of the reference's Matcher_Regions.cpp (same header, same mangled symbols:
+// Matcher_Regions::Matcher_Regions(float, EMatcherType) and Matcher_Regions::Match(...) const) and link
+// libmvgx_hip.so. main_ComputeMatches.cpp:248-252,318 and main_benchANN.cpp:168,186 then run unchanged:
+//
+//   -n BRUTEFORCEL2 on 128-D uint8 regions (SIFT_Regions) with dist_ratio <= 1
+//        -> the MI355X path: every (I, J) of the Pair_Set goes to the C ABI in batches, match lists come back
+//           bit-identical to RegionsMatcherT<ArrayMatcherBruteForce<uchar, L2<uchar>>>::MatchDistanceRatio
+//           (regions_matcher.hpp:162-207) and are inserted in the container in ascending (I, J) order.
+//           A HIP failure on this path throws (no silent CPU fallback).
+//   anything else (other -n values, float/binary regions, dim != 128, ratio > 1 whose tie order is libstdc++'s)
+//        -> the per-pair interface the reference itself uses for them (RegionMatcherFactory, regions_matcher.cpp:54),
+//           which stays in the link; that code is not part of the accelerated path.
+//
+// Contract mirrored from Matcher_Regions.cpp:32-107: progress restart with pairs.size(); pairs whose I (or J) has no
+// regions are skipped but counted; regions of different Type_id are skipped; only non-empty match vectors are
+// inserted; insert() is called from the calling thread only; cancellation is polled between batches.
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+#include <unordered_map>
+#include <vector>
+
+#include "openMVG/features/regions.hpp"
+#include "openMVG/matching/indMatch.hpp"
+#include "openMVG/matching/regions_matcher.hpp"
+#include "openMVG/matching_image_collection/Matcher_Regions.hpp"
+#include "openMVG/numeric/numeric.h"
+#include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
+#include "openMVG/system/logger.hpp"
+#include "openMVG/system/progressinterface.hpp"
+
+#include "mvgx.h"
+
+namespace openMVG {
+namespace matching_image_collection {
+
+namespace {
+
+constexpr uint64_t kPairsPerCall = 1u << 16;  // cancellation / progress granularity of the device path
+
+bool is_sift_u8(const features::Regions& r) {
+  return r.IsScalar() && r.DescriptorLength() == 128 && r.Type_id() == typeid(unsigned char).name();
+}
+
+struct Sink {
+  matching::PairWiseMatchesContainer* out;
+  const std::vector<IndexT>* ids;  // dense image index -> view id
+};
+
+void on_pair(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n) {
+  auto* s = static_cast<Sink*>(user);
+  matching::IndMatches v;
+  v.reserve(n);
+  for (uint32_t k = 0; k < n; ++k) v.emplace_back(ij[2 * k], ij[2 * k + 1]);
+  s->out->insert({{(*s->ids)[I], (*s->ids)[J]}, std::move(v)});
+}
+
+[[noreturn]] void device_failure(const char* what, int rc) {
+  const std::string msg = std::string("mvgx (MI355X matching): ") + what + " failed with status " + std::to_string(rc) +
+                          ": " + mvgx_last_error();
+  OPENMVG_LOG_ERROR << msg;
+  throw std::runtime_error(msg);
+}
+
+// The reference's generic per-pair route for matcher types the device path does not cover.
+void match_generic(matching::EMatcherType type, float ratio, const std::shared_ptr<sfm::Regions_Provider>& provider,
+                   const std::vector<Pair>& pairs, matching::PairWiseMatchesContainer& out,
+                   system::ProgressInterface* progress) {
+  size_t k = 0;
+  while (k < pairs.size()) {
+    const IndexT I = pairs[k].first;
+    size_t end = k;
+    while (end < pairs.size() && pairs[end].first == I) ++end;
+    if (progress->hasBeenCanceled()) { k = end; continue; }
+    const std::shared_ptr<features::Regions> regionsI = provider->get(I);
+    std::unique_ptr<matching::RegionsMatcher> matcher;
+    if (regionsI && regionsI->RegionCount() > 0) matcher = matching::RegionMatcherFactory(type, *regionsI);
+    for (; k < end; ++k) {
+      if (matcher) {
+        const std::shared_ptr<features::Regions> regionsJ = provider->get(pairs[k].second);
+        if (regionsJ && regionsJ->RegionCount() > 0 && regionsI->Type_id() == regionsJ->Type_id()) {
+          matching::IndMatches v;
+          matcher->MatchDistanceRatio(ratio, *regionsJ, v);
+          if (!v.empty()) out.insert({pairs[k], std::move(v)});
+        }
+      }
+      ++(*progress);
+    }
+  }
+}
+
+}  // namespace
+
+Matcher_Regions::Matcher_Regions(float dist_ratio, matching::EMatcherType eMatcherType)
+    : Matcher(), f_dist_ratio_(dist_ratio), eMatcherType_(eMatcherType) {}
+
+void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& regions_provider, const Pair_Set& pairs,
+                            matching::PairWiseMatchesContainer& map_PutativeMatches,
+                            system::ProgressInterface* progress) const {
+  if (!progress) progress = &system::ProgressInterface::dummy();
+  progress->Restart(pairs.size(), "- Matching -");
+
+  const float ratio_sq = Square(f_dist_ratio_);  // regions_matcher.hpp:196 (squared metric), numeric.h:56
+  const bool device_type = (eMatcherType_ == matching::BRUTE_FORCE_L2) && ratio_sq <= 1.0f && ratio_sq >= 0.0f;
+
+  // Pair_Set is ordered by (I, J): the order in which the reference visits and inserts.
+  std::vector<Pair> generic_pairs;
+  std::vector<IndexT> ids;                       // dense index -> view id
+  std::unordered_map<IndexT, uint32_t> dense;    // view id -> dense index
+  std::vector<std::shared_ptr<features::Regions>> keep;  // holds the descriptor memory alive for the whole call
+  std::vector<uint32_t> dev_pairs;               // 2 x n: (dense I, dense J)
+  uint32_t skipped = 0;
+
+  auto dense_id = [&](IndexT view) -> int64_t {
+    auto it = dense.find(view);
+    if (it != dense.end()) return it->second;
+    std::shared_ptr<features::Regions> r = regions_provider->get(view);
+    if (!r || !is_sift_u8(*r)) return -1;
+    const uint32_t k = static_cast<uint32_t>(ids.size());
+    dense.emplace(view, k);
+    ids.push_back(view);
+    keep.push_back(std::move(r));
+    return k;
+  };
+
+  for (const Pair& p : pairs) {
+    if (!device_type) { generic_pairs.push_back(p); continue; }
+    const int64_t a = dense_id(p.first), b = dense_id(p.second);
+    if (a >= 0 && b >= 0) {
+      dev_pairs.push_back(static_cast<uint32_t>(a));
+      dev_pairs.push_back(static_cast<uint32_t>(b));
+      continue;
+    }
+    // one side is not 128-D uint8: the reference skips mismatching Type_id, otherwise uses its own matcher
+    const std::shared_ptr<features::Regions> ri = regions_provider->get(p.first), rj = regions_provider->get(p.second);
+    if (ri && rj && ri->RegionCount() > 0 && rj->RegionCount() > 0 && ri->Type_id() == rj->Type_id())
+      generic_pairs.push_back(p);
+    else
+      ++skipped;
+  }
+  if (skipped) (*progress) += skipped;
+
+  if (!dev_pairs.empty()) {
+    std::vector<const uint8_t*> rows(ids.size());
+    std::vector<uint32_t> n_desc(ids.size());
+    for (size_t k = 0; k < ids.size(); ++k) {
+      n_desc[k] = static_cast<uint32_t>(keep[k]->RegionCount());
+      rows[k] = n_desc[k] ? static_cast<const uint8_t*>(keep[k]->DescriptorRawData()) : nullptr;
+    }
+    mvgx_match_ctx* ctx = nullptr;
+    int rc = mvgx_match_create(-1, &ctx);
+    if (rc != MVGX_OK) device_failure("mvgx_match_create", rc);
+    rc = mvgx_match_set_regions(ctx, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()), 128);
+    if (rc != MVGX_OK) { mvgx_match_destroy(ctx); device_failure("mvgx_match_set_regions", rc); }
+    Sink sink{&map_PutativeMatches, &ids};
+    const uint64_t n_pairs = dev_pairs.size() / 2;
+    for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
+      const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
+      if (progress->hasBeenCanceled()) break;
+      rc = mvgx_match_run(ctx, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+      if (rc != MVGX_OK) { mvgx_match_destroy(ctx); device_failure("mvgx_match_run", rc); }
+      const uint64_t* offsets = nullptr;
+      const uint32_t* ij = nullptr;
+      mvgx_match_results(ctx, &offsets, &ij);
+      for (uint64_t k = 0; k < nb; ++k)
+        if (offsets[k + 1] > offsets[k])
+          on_pair(&sink, dev_pairs[2 * (p0 + k)], dev_pairs[2 * (p0 + k) + 1], ij + 2 * offsets[k],
+                  static_cast<uint32_t>(offsets[k + 1] - offsets[k]));
+      (*progress) += static_cast<uint32_t>(nb);
+    }
+    mvgx_match_destroy(ctx);
+  }
+
+  if (!generic_pairs.empty())
+    match_generic(eMatcherType_, f_dist_ratio_, regions_provider, generic_pairs, map_PutativeMatches, progress);
+}
+
+}  // namespace matching_image_collection
+}  // namespace openMVG

@@ -51,6 +51,15 @@ def have_ref_match():
     return os.path.exists(REF_MATCH_SO)
 
 
+def _bind_match_shim(L):
+    """Prototypes of oracle/ref_shim_match.cpp (the same caller code is linked into oracle/_ref/libref_match.so and,
+    against the MI355X replacements, into openmvg_amd/lib/libmvgx_openmvg_adapter.so)."""
+    L.ref_matcher_regions_match_u8.restype = C.c_uint64
+    L.ref_matcher_regions_match_u8.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
+                                               C.c_uint64, C.c_float, SINK, C.c_void_p]
+    return L
+
+
 def ref_match():
     global _refm
     if _refm is None:
@@ -91,8 +100,9 @@ def port_matcher_regions_match(descs, pairs, dist_ratio):
     return offsets, ij[: int(total)].copy()
 
 
-def ref_matcher_regions_match(descs, pairs, dist_ratio):
-    """The reference's own Matcher_Regions(BRUTE_FORCE_L2).Match. Returns {(I, J): (n,2) uint32}."""
+def ref_matcher_regions_match(descs, pairs, dist_ratio, lib=None):
+    """The reference's own Matcher_Regions(BRUTE_FORCE_L2).Match. Returns {(I, J): (n,2) uint32}.
+    lib: another library exporting the same shim (the adapter build) — default oracle/_ref/libref_match.so."""
     arrs, ptrs, cnt = _desc_tables(descs)
     pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
     out = {}
@@ -101,7 +111,7 @@ def ref_matcher_regions_match(descs, pairs, dist_ratio):
         out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()
 
     cb = SINK(sink)
-    ref_match().ref_matcher_regions_match_u8(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    (lib or ref_match()).ref_matcher_regions_match_u8(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
     return out
 
 
@@ -198,17 +208,21 @@ def port_ba_eval_obs(model, intr, pose, X, obs):
     return r, Ji, Jc, Jp
 
 
+def _bind_ba_shim(L):
+    L.ref_ba_adjust.restype = C.c_int
+    L.ref_ba_adjust.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return L
+
+
 def ref_ba_adjust(scene, intrinsics_opt=None, extrinsics_opt=6, structure_opt=1, max_iterations=0, num_threads=0,
-                  linear_solver=0, use_loss=1, print_summary=0):
+                  linear_solver=0, use_loss=1, print_summary=0, lib=None):
     """The reference's Bundle_Adjustment_Ceres::Adjust. Returns (rc, stats[4], poses, intrinsics, points).
     intrinsics_opt default = ADJUST_ALL (cameras/Camera_Common.hpp:92-100: focal 2 | pp 4 | disto 8 = 14)."""
     global _refba
-    if _refba is None:
-        _refba = C.CDLL(REF_BA_SO)
-        _refba.ref_ba_adjust.restype = C.c_int
-        _refba.ref_ba_adjust.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if lib is None and _refba is None:
+        _refba = _bind_ba_shim(C.CDLL(REF_BA_SO))
     poses = np.ascontiguousarray(scene["poses"], np.float64).copy()
     intr = np.ascontiguousarray(scene["intrinsics"], np.float64).copy()
     pts = np.ascontiguousarray(scene["points"], np.float64).copy()
@@ -218,9 +232,30 @@ def ref_ba_adjust(scene, intrinsics_opt=None, extrinsics_opt=6, structure_opt=1,
     stats = np.zeros(4)
     if intrinsics_opt is None:
         intrinsics_opt = 14
-    rc = _refba.ref_ba_adjust(int(scene["n_poses"]), int(scene["n_intrinsics"]), int(scene["n_points"]), int(scene["n_obs"]),
+    rc = (lib or _refba).ref_ba_adjust(int(scene["n_poses"]), int(scene["n_intrinsics"]), int(scene["n_points"]), int(scene["n_obs"]),
                               poses.ctypes.data, intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data,
                               oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, int(intrinsics_opt), int(extrinsics_opt),
                               int(structure_opt), int(max_iterations), int(num_threads), int(linear_solver), int(use_loss),
                               int(print_summary), stats.ctypes.data)
     return rc, stats, poses, intr, pts
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the openMVG-side adapter build (product code + the same caller shims as oracle/_ref)
+# ---------------------------------------------------------------------------------------------------------
+ADAPTER_SO = os.path.join(ROOT, "openmvg_amd", "lib", "libmvgx_openmvg_adapter.so")
+_adapter = None
+
+
+def have_adapter():
+    return os.path.exists(ADAPTER_SO)
+
+
+def adapter():
+    """libmvgx_openmvg_adapter.so: oracle/ref_shim_{match,ba}.cpp linked against openmvg_amd/adapter/*.cpp (the link-time
+    replacements of Matcher_Regions.cpp / sfm_data_BA_ceres.cpp) and libmvgx_hip.so. RTLD_LOCAL + -Bsymbolic keep its
+    Matcher_Regions / Bundle_Adjustment_Ceres symbols apart from the reference's in oracle/_ref."""
+    global _adapter
+    if _adapter is None:
+        _adapter = _bind_ba_shim(_bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW)))
+    return _adapter
