@@ -43,13 +43,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_pairs(pairs, rank, world):
-    n = len(pairs)
-    lo = (n * rank) // world
-    hi = (n * (rank + 1)) // world
-    return pairs[lo:hi]
-
-
 def cpu_baseline(descs, pairs, ratio, budget_s):
     """Reference CPU path (oracle/_ref: openMVG's own Matcher_Regions, -O3 -mavx2 OpenMP/std::async build) — or the C
     restatement if the reference build is absent — timed on a bounded random sample of the same pair list."""
@@ -58,8 +51,9 @@ def cpu_baseline(descs, pairs, ratio, budget_s):
     kind = "reference" if _oracle.have_ref_match() else "port"
     fn = _oracle.ref_matcher_regions_match if kind == "reference" else _oracle.port_matcher_regions_match
     order = rng.permutation(len(pairs))
+    fn(descs, pairs[order[:2]], ratio)   # first call: thread pool / page-in, not timed
     t0 = time.perf_counter()
-    fn(descs, pairs[order[:2]], ratio)
+    fn(descs, pairs[order[2:4]], ratio)
     t1 = time.perf_counter()
     per_pair = max((t1 - t0) / 2.0, 1e-4)
     n = int(max(4, min(len(pairs), budget_s / per_pair)))
@@ -97,7 +91,8 @@ def main():
     n_images = int(round(n_images * np.sqrt(world)))
     descs = synth.image_descriptors(n_images, n_desc=args.desc, seed=0xC0FFEE00)
     all_pairs = matching.exhaustive_pairs_array(n_images)
-    pairs = np.ascontiguousarray(shard_pairs(all_pairs, rank, world))
+    from openmvg_amd import sharding
+    pairs = np.ascontiguousarray(sharding.shard_pairs(all_pairs, [len(d) for d in descs], rank, world))
 
     ctx = matching.MatchContext(local_rank)
     if args.variant >= 0:
@@ -176,14 +171,18 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
-        if not args.no_ba:
-            try:
-                from bench_ba import ba_bench_record
-                out["ba"] = ba_bench_record(local_rank, world)
-            except ImportError:
-                pass
-        print(json.dumps(out), flush=True)
     ctx.close()
+    ba_rec = None
+    if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
+        try:
+            from bench_ba import ba_bench_record
+            ba_rec = ba_bench_record(local_rank, world)
+        except Exception as e:  # the BA leg is a side record: never lose the matching line
+            ba_rec = {"status": f"failed: {e!r}"}
+    if rank == 0:
+        if ba_rec is not None:
+            out["ba"] = ba_rec
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

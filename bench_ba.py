@@ -43,23 +43,55 @@ def _parse_report(txt):
     return out
 
 
+def ba_config(world):
+    """BASELINE.json configs[2] at 1 GPU (200 pinhole cams / 100k points / 1M obs) growing to configs[4] at 8 GPUs
+    (1k cams pinhole+K3 in 8 intrinsic groups / 500k points / 5M obs); linear in between."""
+    if world <= 1:
+        return dict(n_cams=200, n_points=100000, track_len=10, model=1, n_intr_groups=1, seed=0xBA5E0003)
+    f = min(1.0, (world - 1) / 7.0)
+    return dict(n_cams=int(round(200 + 800 * f)), n_points=int(round(100000 + 400000 * f)), track_len=10, model=3,
+                n_intr_groups=8, seed=0xBA5E0005)
+
+
 def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
-    from openmvg_amd import ba, synth
+    """One BA solve per rank on its point shard; returns the record on every rank (identical numbers: the LM state is
+    replicated). world > 1 needs torch.distributed initialised (used only to hand out the RCCL unique id)."""
+    from openmvg_amd import ba, sharding, synth
+    cfg = ba_config(world)
+    full = synth.ba_scene(**cfg)
+    rank = 0
+    uid = None
     if world > 1:
-        return {"status": "BA runs on one GPU this round (observation sharding + RCCL all-reduce hook not enabled yet)"}
-    scene = synth.ba_scene(200, 100000, track_len=10, model=synth.CAM_PINHOLE, n_intr_groups=1, seed=0xBA5E0003)
-    ctx = ba.BaContext(scene, device=local_rank)
+        import torch.distributed as dist
+        rank = dist.get_rank()
+        box = [ba.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        scene, _mine = sharding.shard_ba_scene(full, rank, world)
+    else:
+        scene = full
+
+    def make():
+        c = ba.BaContext(scene, device=local_rank)
+        if uid is not None:
+            c.comm_init(world, rank, uid)
+        return c
+
+    ctx = make()
     s1 = ctx.lm_iteration(ba.default_options(max_num_iterations=1))   # iteration zero + one LM iteration
     ctx.close()
-    ctx = ba.BaContext(scene, device=local_rank)
+    ctx = make()
     t0 = time.perf_counter()
     s = ctx.solve()
     wall = time.perf_counter() - t0
     ctx.close()
+    scene = full
     n_cols = 6 * scene["n_poses"] + 8 * scene["n_intrinsics"]
     bytes_it = algorithmic_bytes_per_iteration(scene["n_obs"], scene["n_points"], scene["n_poses"], n_cols)
     rec = {
-        "config": "200 pinhole cams (1 shared intrinsic), 100k points, 1.0M observations, ADJUST_ALL, Huber(16)",
+        "config": f"{cfg['n_cams']} cams ({'pinhole' if cfg['model'] == 1 else 'pinhole+K3'}, {cfg['n_intr_groups']} shared "
+                  f"intrinsic group(s)), {cfg['n_points']} points, {full['n_obs']} observations, ADJUST_ALL, Huber(16); "
+                  f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of the reduced camera system" if world > 1 else ""),
         "lm_iteration_ms": s.iter_ms_mean,
         "first_call_ms_iteration_zero_plus_one_iteration": s1.total_ms,
         "iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "termination": s.termination,
@@ -69,7 +101,7 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
                      "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_iteration": bytes_it},
     }
-    if cpu:
+    if cpu and world == 1:
         try:
             from tests import _oracle
             if _oracle.have_ref_ba():

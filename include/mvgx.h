@@ -165,10 +165,21 @@ typedef struct mvgx_ba_summary {
 void mvgx_ba_default_options(mvgx_ba_options* opt);
 int mvgx_ba_create(int device, const mvgx_ba_problem* problem, mvgx_ba_ctx** out);
 int mvgx_ba_destroy(mvgx_ba_ctx* ctx);
-/* multi-GPU: the caller shards points/observations per rank and supplies an all-reduce(sum, fp64)
- * callback for the reduced camera system (RCCL via the host language's binding); NULL = single GPU. */
-typedef int (*mvgx_allreduce_f64)(void* user, void* device_buffer, uint64_t count, void* hip_stream);
+/* ---- multi-GPU (one process per GPU) --------------------------------------------------------------
+ * Every rank creates its context from ITS shard of the problem: all poses and intrinsics (replicated, same
+ * order on every rank) and a disjoint subset of the points together with ALL observations of those points
+ * (a point's rows must be local to be eliminated, ceres schur_eliminator_impl.h:114-151). Per LM iteration
+ * the solver sums across ranks: cost, camera column norms + gradient, the partial reduced camera system
+ * (S, rhs), the model-cost change and the point parts of |step|^2 / |x|^2; max: gradient max-norm and the
+ * failure flag. Every rank then factors the same S (no second exchange) and back-substitutes its points.
+ * Either bind RCCL (mvgx_ba_comm_init: ncclAllReduce on the solver's stream, unique id from
+ * mvgx_comm_unique_id on rank 0, distributed by the caller) or supply a callback transport. */
+#define MVGX_REDUCE_SUM 0
+#define MVGX_REDUCE_MAX 1
+typedef int (*mvgx_allreduce_f64)(void* user, void* device_buffer, uint64_t count, int op, void* hip_stream);
 int mvgx_ba_set_allreduce(mvgx_ba_ctx* ctx, mvgx_allreduce_f64 fn, void* user);
+int mvgx_comm_unique_id(void* out128 /* 128 bytes: ncclUniqueId */);
+int mvgx_ba_comm_init(mvgx_ba_ctx* ctx, int world, int rank, const void* unique_id128);
 int mvgx_ba_solve(mvgx_ba_ctx* ctx, const mvgx_ba_options* opt, mvgx_ba_summary* summary);
 /* one LM iteration (Jacobian + Schur + reduced solve + back-substitution + candidate cost + accept/reject) */
 int mvgx_ba_lm_iteration(mvgx_ba_ctx* ctx, const mvgx_ba_options* opt, mvgx_ba_summary* summary);

@@ -92,7 +92,8 @@ class BaSummary(C.Structure):
 
 
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
-ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
+MVGX_REDUCE_SUM, MVGX_REDUCE_MAX = 0, 1
 
 # name -> (restype, argtypes). tests/test_capi_symbols.py checks every one of these is exported.
 PROTOTYPES = {
@@ -112,6 +113,8 @@ PROTOTYPES = {
     "mvgx_ba_create": (C.c_int, [C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
     "mvgx_ba_destroy": (C.c_int, [C.c_void_p]),
     "mvgx_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_F64, C.c_void_p]),
+    "mvgx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mvgx_ba_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mvgx_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "mvgx_ba_lm_iteration": (C.c_int, [C.c_void_p, C.POINTER(BaOptions), C.POINTER(BaSummary)]),
     "mvgx_ba_read_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -43,6 +43,13 @@ def default_options(**kw):
     return o
 
 
+def comm_unique_id():
+    """128-byte ncclUniqueId (call on rank 0, broadcast to the other ranks)."""
+    buf = (C.c_char * 128)()
+    _capi.check(_capi.lib().mvgx_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf.raw)
+
+
 class BaContext:
     """Device-resident BA problem (thin wrapper over mvgx_ba_*)."""
 
@@ -70,6 +77,16 @@ class BaContext:
         self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
         self._h = C.c_void_p()
         _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
+
+    def comm_init(self, world, rank, unique_id):
+        """Bind this rank's context to an RCCL communicator (unique_id: the 128 bytes of comm_unique_id() of rank 0)."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _capi.check(_capi.lib().mvgx_ba_comm_init(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)))
+
+    def set_allreduce(self, fn):
+        """Callback transport: fn(device_ptr, count, op, hip_stream) -> 0 on success (op: 0 sum, 1 max)."""
+        self._cb = _capi.ALLREDUCE_F64(lambda _u, ptr, count, op, stream: int(fn(ptr, int(count), int(op), stream)))
+        _capi.check(_capi.lib().mvgx_ba_set_allreduce(self._h, self._cb, None))
 
     def close(self):
         if self._h:

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "ba_math.h"
+#include "mvgx_comm.h"
 #include "mvgx_common.h"
 
 namespace {
@@ -48,7 +49,9 @@ constexpr int kNB = 64;        // Cholesky block size
 constexpr int kIntrChunk = 2048;   // intrinsic-row entries per workgroup
 constexpr int kRedBlock = 256;
 
-enum Scalar { kSCost = 0, kSSqErr, kSModel, kSStepSq, kSXSq, kSGmax, kSFail, kSCount = 8 };
+// kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
+// point parts are rank-local and summed across ranks.
+enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSCount = 12 };
 
 struct Dev {
   // sizes
@@ -432,11 +435,9 @@ __global__ __launch_bounds__(512) void ba_schur_pose_rows_kernel(Dev d, double i
     const int rr = k / wcols, col = win0 + (k - rr * wcols);
     const int row = 6 * (int)i + rr;
     if (col < 6 * (int)i) continue;
-    double v = panel[k];
-    if (col == row) v = d.cam_active[row] ? v + d.diag_cam[row] * inv_radius : 1.0;
-    d.S[(size_t)row * d.LD + col] = v;
+    d.S[(size_t)row * d.LD + col] = panel[k];   // raw partial sum; the LM diagonal is added after the cross-rank sum
   }
-  if (last_window && tid < 6) d.S[(size_t)(6 * i + tid) * d.LD + d.N] = d.cam_active[6 * i + tid] ? rhs[tid] : 0.0;
+  if (last_window && tid < 6) d.S[(size_t)(6 * i + tid) * d.LD + d.N] = rhs[tid];
 }
 
 // intrinsic rows: chunk of (point, slot) entries of one intrinsic -> partial panel 8 x (8 n_intr) + rhs(8)
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) void ba_schur_intr_rows_kernel(Dev d) {
   double* out = d.ipanel_part + (size_t)ch * (8 * wi + 8);
   for (int q = tid; q < 8 * wi + 8; q += blockDim.x) out[q] = panel[q];
 }
-__global__ __launch_bounds__(256) void ba_schur_intr_reduce_kernel(Dev d, double inv_radius) {
+__global__ __launch_bounds__(256) void ba_schur_intr_reduce_kernel(Dev d) {
   const uint32_t k = blockIdx.x;
   const int wi = 8 * (int)d.n_intr;
   const int icol0 = 6 * (int)d.n_poses;
@@ -493,14 +494,28 @@ __global__ __launch_bounds__(256) void ba_schur_intr_reduce_kernel(Dev d, double
       const int rr = q / wi, c = q - rr * wi;
       const int row = icol0 + 8 * (int)k + rr, col = icol0 + c;
       if (col < icol0 + 8 * (int)k) continue;
-      if (col == row) v = d.cam_active[row] ? v + d.diag_cam[row] * inv_radius : 1.0;
       d.S[(size_t)row * d.LD + col] = v;
     } else {
       const int row = icol0 + 8 * (int)k + (q - 8 * wi);
-      d.S[(size_t)row * d.LD + d.N] = d.cam_active[row] ? v : 0.0;
+      d.S[(size_t)row * d.LD + d.N] = v;
     }
   }
 }
+
+// After the (cross-rank) sum of the partial systems: S_jj += D_j^2 = diag_j / radius for free components, unit diagonal
+// and zero rhs for constant / unused ones (their off-diagonals are exactly zero: Jacobi scale 0).
+__global__ __launch_bounds__(256) void ba_finish_system_kernel(Dev d, double inv_radius) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= d.N) return;
+  const size_t dd = (size_t)row * d.LD + row;
+  if (d.cam_active[row]) {
+    d.S[dd] += d.diag_cam[row] * inv_radius;
+  } else {
+    d.S[dd] = 1.0;
+    d.S[(size_t)row * d.LD + d.N] = 0.0;
+  }
+}
+__global__ void ba_pack_fail_kernel(Dev d) { d.scalars[kSFail] = (double)*d.fail; }
 
 // ------------------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky of the column-major lower matrix A (n x n, ld = n + 1) whose extra row n carries the
@@ -704,15 +719,15 @@ __global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __res
 __global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __restrict__ part) {
   __shared__ double sh[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double dsq = 0, xsq = 0;
+  double dsq = 0, xsq = 0, cdsq = 0, cxsq = 0;
   if (i < (size_t)d.N) {
     const int np6 = 6 * (int)d.n_poses;
     double* x; double* cx; size_t idx;
     if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
     const double delta = d.step_cam[i] * d.scale_cam[i];
     cx[idx] = x[idx] + delta;
-    dsq += delta * delta;
-    if (d.cam_counts[i]) xsq += x[idx] * x[idx];
+    cdsq = delta * delta;
+    if (d.cam_counts[i]) cxsq = x[idx] * x[idx];
   }
   if (i < (size_t)d.n_pts * 3) {
     const double delta = d.step_pt[i] * d.scale_pt[i];
@@ -720,9 +735,13 @@ __global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __rest
     dsq += delta * delta;
     if (d.scale_pt[i] != 0.0) xsq += d.pts[i] * d.pts[i];
   }
+  const double ca = block_sum(cdsq, sh);
+  const double cb = block_sum(cxsq, sh);
   const double a = block_sum(dsq, sh);
   const double b = block_sum(xsq, sh);
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+  if (threadIdx.x == 0) {
+    part[4 * blockIdx.x] = ca; part[4 * blockIdx.x + 1] = cb; part[4 * blockIdx.x + 2] = a; part[4 * blockIdx.x + 3] = b;
+  }
 }
 
 template <typename T>
@@ -752,6 +771,8 @@ struct mvgx_ba_ctx {
   size_t part_cap = 0;
   mvgx_allreduce_f64 allreduce = nullptr;
   void* allreduce_user = nullptr;
+  mvgx::RcclComm* rccl = nullptr;
+  double n_obs_global = 0;             // observations over all ranks (RMSE denominator)
   // LM state (persists across mvgx_ba_lm_iteration calls)
   bool started = false;
   double x_cost = 0, radius = 0, decrease_factor = 2.0, gradient_max_norm = 0;
@@ -774,9 +795,12 @@ int read_scalars(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
-int all_reduce(mvgx_ba_ctx* c, double* buf, uint64_t count) {
+bool multi_rank(const mvgx_ba_ctx* c) { return c->rccl != nullptr || c->allreduce != nullptr; }
+
+int all_reduce(mvgx_ba_ctx* c, double* buf, uint64_t count, int op = MVGX_REDUCE_SUM) {
+  if (c->rccl) return mvgx::rccl_allreduce_f64(c->rccl, buf, count, op, c->stream);
   if (!c->allreduce) return MVGX_OK;
-  const int rc = c->allreduce(c->allreduce_user, buf, count, c->stream);
+  const int rc = c->allreduce(c->allreduce_user, buf, count, op, c->stream);
   MVGX_REQUIRE(rc == 0, MVGX_ERR_HIP, "all-reduce callback failed (%d)", rc);
   return MVGX_OK;
 }
@@ -813,7 +837,7 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
                      opt->max_lm_diagonal, d.part);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_vec, 1, 1, d.scalars, kSGmax, 1);
   BA_LAUNCH_CHECK();
-  // (multi-GPU: the max over ranks of the point-gradient part is taken on the host by the caller's reduction of scalars)
+  if ((rc = all_reduce(c, d.scalars + kSGmax, 1, MVGX_REDUCE_MAX))) return rc;   // point gradients are rank-local
   if ((rc = read_scalars(c))) return rc;
   c->x_cost = c->h_scalars[kSCost];
   c->gradient_max_norm = c->h_scalars[kSGmax];
@@ -838,10 +862,12 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     const size_t lds = (size_t)(64 * d.n_intr + 8) * sizeof(double);
     hipLaunchKernelGGL(ba_schur_intr_rows_kernel, dim3(d.n_ichunks), dim3(256), lds, c->stream, d);
   }
-  if (d.n_intr) hipLaunchKernelGGL(ba_schur_intr_reduce_kernel, dim3(d.n_intr), dim3(256), 0, c->stream, d, inv_radius);
+  if (d.n_intr) hipLaunchKernelGGL(ba_schur_intr_reduce_kernel, dim3(d.n_intr), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
-  int rc = all_reduce(c, d.S, (uint64_t)d.N * d.LD);
+  int rc = all_reduce(c, d.S, (uint64_t)d.N * d.LD);   // the one bulk exchange of the iteration (RCCL over xGMI)
   if (rc) return rc;
+  if (d.N) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
+  BA_LAUNCH_CHECK();
   // Cholesky (rhs as extra row) + back substitution
   for (int k0 = 0; k0 < d.N; k0 += kNB) {
     const int kb = std::min(kNB, d.N - k0);
@@ -864,9 +890,15 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_obs, 1, 1, d.scalars, kSModel, 0);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.scalars + kSModel, 1))) return rc;
+  if (multi_rank(c)) {   // a point block that failed to invert on one rank fails the step everywhere
+    hipLaunchKernelGGL(ba_pack_fail_kernel, dim3(1), dim3(1), 0, c->stream, d);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, d.scalars + kSFail, 1, MVGX_REDUCE_MAX))) return rc;
+  }
   if ((rc = read_scalars(c))) return rc;
   *model_cost_change = c->h_scalars[kSModel];
-  *ok = (*c->h_fail == 0) && std::isfinite(*model_cost_change);
+  const bool failed = multi_rank(c) ? (c->h_scalars[kSFail] != 0.0) : (*c->h_fail != 0);
+  *ok = !failed && std::isfinite(*model_cost_change);
   return MVGX_OK;
 }
 
@@ -875,13 +907,14 @@ int make_candidate_and_cost(mvgx_ba_ctx* c, double* step_norm, double* x_norm, d
   MVGX_HIP(hipMemcpyAsync(d.cposes, d.poses, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(d.cintr, d.intr, (size_t)d.n_intr * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_vec, 2, 2, d.scalars, kSStepSq, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_vec, 4, 4, d.scalars, kSCamStepSq, 0);
   BA_LAUNCH_CHECK();
-  int rc = eval<false>(c, d.cposes, d.cintr, d.cpts);
+  int rc = all_reduce(c, d.scalars + kSStepSq, 2);   // point parts
   if (rc) return rc;
+  if ((rc = eval<false>(c, d.cposes, d.cintr, d.cpts))) return rc;
   if ((rc = read_scalars(c))) return rc;
-  *step_norm = std::sqrt(c->h_scalars[kSStepSq]);
-  *x_norm = std::sqrt(c->h_scalars[kSXSq]);
+  *step_norm = std::sqrt(c->h_scalars[kSCamStepSq] + c->h_scalars[kSStepSq]);
+  *x_norm = std::sqrt(c->h_scalars[kSCamXSq] + c->h_scalars[kSXSq]);
   *cand_cost = c->h_scalars[kSCost];
   return MVGX_OK;
 }
@@ -894,11 +927,27 @@ int accept_candidate(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
-int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
-  int rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts);
+int global_obs_count(mvgx_ba_ctx* c) {
+  c->n_obs_global = (double)c->d.n_obs;
+  if (!multi_rank(c)) return MVGX_OK;
+  MVGX_HIP(hipMemcpyAsync(c->d.scalars + kSNobs, &c->n_obs_global, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = all_reduce(c, c->d.scalars + kSNobs, 1);
   if (rc) return rc;
   if ((rc = read_scalars(c))) return rc;
-  c->initial_rmse = c->d.n_obs ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * (double)c->d.n_obs)) : 0.0;
+  c->n_obs_global = c->h_scalars[kSNobs];
+  return MVGX_OK;
+}
+
+double rmse_from(const mvgx_ba_ctx* c) {
+  return c->n_obs_global > 0 ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * c->n_obs_global)) : 0.0;
+}
+
+int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
+  int rc = global_obs_count(c);
+  if (rc) return rc;
+  if ((rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts))) return rc;
+  if ((rc = read_scalars(c))) return rc;
+  c->initial_rmse = rmse_from(c);
   c->radius = opt->initial_radius;
   c->decrease_factor = 2.0;
   c->reuse_diagonal = false; c->x_norm_valid = false; c->last_successful = true;
@@ -963,7 +1012,7 @@ int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
   s->initial_cost = c->initial_cost;
   s->final_cost = c->x_cost;
   s->initial_rmse = c->initial_rmse;
-  s->final_rmse = c->d.n_obs ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * (double)c->d.n_obs)) : 0.0;
+  s->final_rmse = rmse_from(c);
   return MVGX_OK;
 }
 
@@ -1109,7 +1158,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
-  AL(part, (size_t)2 * std::max(c->grid_obs, c->grid_vec) + 16);
+  AL(part, (size_t)4 * std::max(c->grid_obs, c->grid_vec) + 16);
   AL(scalars, kSCount); AL(fail, 1);
 #undef UP
 #undef AL
@@ -1149,8 +1198,18 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  mvgx::rccl_destroy(c->rccl);
   delete c;
   return MVGX_OK;
+}
+
+int mvgx_ba_comm_init(mvgx_ba_ctx* c, int world, int rank, const void* unique_id128) {
+  MVGX_REQUIRE(c && unique_id128, MVGX_ERR_ARG, "mvgx_ba_comm_init: NULL argument");
+  MVGX_REQUIRE(!c->started, MVGX_ERR_STATE, "mvgx_ba_comm_init after the solve has started");
+  MVGX_HIP(hipSetDevice(c->device));
+  mvgx::rccl_destroy(c->rccl);
+  c->rccl = nullptr;
+  return mvgx::rccl_init(&c->rccl, world, rank, unique_id128);
 }
 
 int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {
@@ -1213,7 +1272,8 @@ int mvgx_ba_evaluate(mvgx_ba_ctx* c, double* cost, double* rmse) {
   if (rc) return rc;
   if ((rc = read_scalars(c))) return rc;
   if (cost) *cost = c->h_scalars[kSCost];
-  if (rmse) *rmse = c->d.n_obs ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * (double)c->d.n_obs)) : 0.0;
+  if (c->n_obs_global == 0 && (rc = global_obs_count(c))) return rc;
+  if (rmse) *rmse = rmse_from(c);
   return MVGX_OK;
 }
 

@@ -1,0 +1,116 @@
+// libmvgx_hip.so — RCCL communicator for the one exchange step of the BA path: one process per GPU,
+// points (and all their observations) partitioned across ranks, camera blocks replicated; per LM iteration the partial
+// reduced camera system / camera column norms / scalars are summed with ncclAllReduce over xGMI on the solver's stream.
+// RCCL is bound at run time (dlopen) so that single-GPU users need no librccl.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "mvgx_comm.h"
+
+namespace mvgx {
+namespace {
+
+typedef struct { char internal[128]; } UniqueId;  // ncclUniqueId (rccl.h:43, NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* Comm;
+typedef int (*GetUniqueIdFn)(UniqueId*);
+typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
+typedef int (*AllReduceFn)(const void*, void*, size_t, int /*dtype*/, int /*op*/, Comm, hipStream_t);
+typedef int (*CommDestroyFn)(Comm);
+typedef const char* (*GetErrorStringFn)(int);
+
+constexpr int kNcclFloat64 = 8;  // rccl.h:467
+constexpr int kNcclSum = 0, kNcclMax = 2;  // rccl.h:448-450
+
+struct Api {
+  void* handle = nullptr;
+  GetUniqueIdFn get_unique_id = nullptr;
+  CommInitRankFn comm_init_rank = nullptr;
+  AllReduceFn all_reduce = nullptr;
+  CommDestroyFn comm_destroy = nullptr;
+  GetErrorStringFn error_string = nullptr;
+};
+
+Api* api() {
+  static Api a;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (a.handle) {
+      a.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(a.handle, "ncclGetUniqueId"));
+      a.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(a.handle, "ncclCommInitRank"));
+      a.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(a.handle, "ncclAllReduce"));
+      a.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(a.handle, "ncclCommDestroy"));
+      a.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(a.handle, "ncclGetErrorString"));
+    }
+  }
+  if (!a.handle || !a.get_unique_id || !a.comm_init_rank || !a.all_reduce || !a.comm_destroy) {
+    set_error("RCCL not available: %s", a.handle ? "missing symbols in librccl" : dlerror());
+    return nullptr;
+  }
+  return &a;
+}
+
+const char* nccl_err(Api* a, int rc) { return a->error_string ? a->error_string(rc) : "nccl error"; }
+
+}  // namespace
+
+struct RcclComm {
+  Comm comm = nullptr;
+  int world = 1, rank = 0;
+};
+
+int rccl_unique_id(void* out128) {
+  Api* a = api();
+  if (!a) return MVGX_ERR_HIP;
+  UniqueId id;
+  const int rc = a->get_unique_id(&id);
+  MVGX_REQUIRE(rc == 0, MVGX_ERR_HIP, "ncclGetUniqueId: %s", nccl_err(a, rc));
+  memcpy(out128, id.internal, sizeof(id.internal));
+  return MVGX_OK;
+}
+
+int rccl_init(RcclComm** out, int world, int rank, const void* unique_id) {
+  Api* a = api();
+  if (!a) return MVGX_ERR_HIP;
+  MVGX_REQUIRE(out && unique_id && world >= 1 && rank >= 0 && rank < world, MVGX_ERR_ARG, "rccl_init: bad argument");
+  UniqueId id;
+  memcpy(id.internal, unique_id, sizeof(id.internal));
+  auto* c = new RcclComm();
+  c->world = world; c->rank = rank;
+  const int rc = a->comm_init_rank(&c->comm, world, id, rank);
+  if (rc != 0) {
+    set_error("ncclCommInitRank(world %d, rank %d): %s", world, rank, nccl_err(a, rc));
+    delete c;
+    return MVGX_ERR_HIP;
+  }
+  *out = c;
+  return MVGX_OK;
+}
+
+void rccl_destroy(RcclComm* c) {
+  if (!c) return;
+  Api* a = api();
+  if (a && c->comm) a->comm_destroy(c->comm);
+  delete c;
+}
+
+int rccl_allreduce_f64(RcclComm* c, double* device_buffer, uint64_t count, int op, hipStream_t stream) {
+  Api* a = api();
+  if (!a) return MVGX_ERR_HIP;
+  const int rc = a->all_reduce(device_buffer, device_buffer, count, kNcclFloat64, op == MVGX_REDUCE_MAX ? kNcclMax : kNcclSum,
+                               c->comm, stream);
+  MVGX_REQUIRE(rc == 0, MVGX_ERR_HIP, "ncclAllReduce(%llu doubles): %s", (unsigned long long)count, nccl_err(a, rc));
+  return MVGX_OK;
+}
+
+}  // namespace mvgx
+
+extern "C" int mvgx_comm_unique_id(void* out128) {
+  MVGX_REQUIRE(out128 != nullptr, MVGX_ERR_ARG, "mvgx_comm_unique_id: NULL buffer");
+  return mvgx::rccl_unique_id(out128);
+}

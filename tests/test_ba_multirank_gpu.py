@@ -1,0 +1,97 @@
+"""GPU tests of the BA exchange step on ONE device: (1) the RCCL binding with a 1-rank communicator,
+(2) a 2-rank run — two contexts holding the two point shards, driven from two host threads, with a test transport that
+implements all-reduce(sum / max) semantics through host memory. The sharded solve must reproduce the single-context solve
+(same LM trajectory), which checks every cross-rank reduction the solver issues, with the real kernels."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from openmvg_amd import ba, sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_single_rank_communicator():
+    sc = synth.ba_scene(10, 300, track_len=6, model=3, n_intr_groups=2, seed=91)
+    ctx = ba.BaContext(sc); ref = ctx.solve(); ctx.close()
+    ctx = ba.BaContext(sc)
+    ctx.comm_init(1, 0, ba.comm_unique_id())
+    s = ctx.solve()
+    ctx.close()
+    assert s.num_iterations == ref.num_iterations and abs(s.final_rmse - ref.final_rmse) < 1e-12
+
+
+class _HostAllReduce:
+    """all-reduce over `world` threads of one process: D2H, barrier, combine, H2D (test transport only)."""
+
+    def __init__(self, world):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def make(self, rank):
+        def fn(ptr, count, op, stream):
+            self.hip.hipStreamSynchronize(C.c_void_p(stream))
+            host = np.empty(count, np.float64)
+            assert self.hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(8 * count), 2) == 0
+            self.slots[rank] = host
+            self.barrier.wait()
+            tot = np.maximum.reduce(self.slots) if op == 1 else np.sum(self.slots, axis=0)
+            self.barrier.wait()
+            assert self.hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(tot.ctypes.data), C.c_size_t(8 * count), 1) == 0
+            if rank == 0:
+                self.calls += 1
+            return 0
+        return fn
+
+
+@pytest.mark.parametrize("kw,strict", [
+    (dict(n_cams=14, n_points=600, track_len=6, model=3, n_intr_groups=2, seed=92), True),
+    # 40-iteration crawl along a Huber-flattened valley: the per-shard summation order differs from the single-rank one
+    # (fp64 sums are not associative — the reference's own order is unspecified too), so the
+    # function-tolerance test may fire one iteration apart; the result must still agree to the parity tolerance.
+    (dict(n_cams=10, n_points=400, track_len=5, model=1, n_intr_groups=1, seed=93, outlier_frac=0.05), False),
+])
+def test_two_point_shards_reproduce_the_single_rank_solve(kw, strict):
+    sc = synth.ba_scene(**kw)
+    ctx = ba.BaContext(sc); ref = ctx.solve(); rposes, rintr, rpts = ctx.read_params(); ctx.close()
+
+    world = 2
+    tr = _HostAllReduce(world)
+    owner = sharding.assign_points(sc["obs_point"], sc["n_points"], world)
+    out = [None] * world
+
+    def run(rank):
+        shard, mine = sharding.shard_ba_scene(sc, rank, world, owner)
+        c = ba.BaContext(shard)
+        c.set_allreduce(tr.make(rank))
+        s = c.solve()
+        poses, intr, pts = c.read_params()
+        c.close()
+        out[rank] = (s, poses, intr, pts, mine)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert all(o is not None for o in out) and tr.calls > 0
+    pts = np.zeros_like(rpts)
+    for s, poses, intr, p, mine in out:
+        assert abs(s.initial_rmse - ref.initial_rmse) < 1e-9 and abs(s.initial_cost - ref.initial_cost) <= 1e-12 * ref.initial_cost
+        if strict:
+            assert s.num_iterations == ref.num_iterations and s.num_successful_steps == ref.num_successful_steps
+            assert abs(s.final_rmse - ref.final_rmse) < 1e-9
+            assert abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
+            assert np.allclose(poses, rposes, atol=1e-9) and np.allclose(intr, rintr, rtol=1e-9, atol=1e-9)
+        else:
+            assert abs(s.num_iterations - ref.num_iterations) <= 1
+            assert abs(s.final_rmse - ref.final_rmse) < 1e-6
+        pts[mine] = p
+    assert np.allclose(pts, rpts, atol=1e-8 if strict else 1e-3)
+    # camera parameters are bit-identical across ranks (every rank factors the same reduced system)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
