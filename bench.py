@@ -161,7 +161,7 @@ def main():
                        "parallelism": f"pair-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "l2_top2_ratio_kernel", "launches": launches,
+                         "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:

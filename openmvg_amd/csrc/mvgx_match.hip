@@ -11,15 +11,21 @@
 // invariant, so d = |a'|^2 + |b'|^2 - 2 a'.b'. The 128-long dot products run on the i8 matrix cores
 // (v_mfma_i32_32x32x32_i8, exact int32 accumulation), norms are precomputed per descriptor.
 //
-// HBM layout (built once per image set by prep_tiles_kernel):
-//   tiles  : int8, one 4 KiB block per 32 descriptors, "fragment-major": chunk c = s*64 + lane holds the 16
+// HBM layout (built once per image set by the prep kernels):
+//   Rows of an image are PERMUTED into tile slots by the parity of |a'|^2: slot (tile t, row m) with
+//   half(m) = (m >> 2) & 1 and j(m) = (m >> 3) * 4 + (m & 3) holds the (16 t + j)-th row of parity half(m)
+//   (stable order), so the two lane halves of a 32x32 MFMA result (lane >> 5) see even-norm and odd-norm
+//   database rows respectively. Empty slots are pad rows. An image owns ceil(max(n_even, n_odd) / 16) tiles
+//   rounded up to a multiple of 8 (one LDS window = 8 tiles = 256 slots).
+//   tiles  : int8, one 4 KiB block per 32 slots, "fragment-major": chunk c = s*64 + lane holds the 16
 //            bytes lane `lane` feeds to MFMA k-step s (row = lane&31, k-half = lane>>5). A straight 1 KiB
 //            coalesced read per wave-instruction therefore IS an MFMA operand; the same image serves as
 //            A (database, through LDS) or B (queries, register-resident) operand.
-//   rconst : int32 per descriptor, R = -(|a'|^2 << 8) - (row index within its 256-row window); pad rows hold
-//            INT_MIN + 512 so they never win.
-//   qnorm  : int32 per descriptor, |a'|^2.
-// Each image owns ceil(n/32) tiles rounded up to a multiple of 8 (one LDS window = 8 tiles = 256 rows).
+//   rconst : int32 per slot, R = -(|a'|^2 << 8) - (slot index within its 256-slot window); pad slots hold
+//            INT_MIN + 512 so they never win                                  (exact kernel, variants 1-3)
+//   cinit  : int32 per slot, C = -floor(|a'|^2 / 2); pad slots hold kCPad     (filter kernel, variant 4)
+//   qnorm  : int32 per slot, |a'|^2.
+//   perm   : uint32 per slot, original row index (kNoMatch for pad slots); rowpos: slot of each original row.
 //
 // Kernel l2_top2_ratio: one 256-thread workgroup = 4 waves = 512 queries of image J against all of image I.
 // Each wave keeps 4 query tiles (128 queries, 64 VGPRs) resident as MFMA B operands for its whole life and
@@ -55,79 +61,149 @@ constexpr int kNQ = 4;                        // query tiles per wave (register-
 constexpr int kBlockQTiles = kWaves * kNQ;    // 16 tiles = 512 queries per workgroup
 constexpr int kStageBytes = kWinTiles * kTileBytes + kWinTiles * kTileRows * 4;  // 32768 + 1024
 constexpr int kRPad = INT_MIN + 512;
+constexpr int kCPad = -(1 << 27);             // accumulator init of pad slots (real values are > -2^22)
+constexpr int kNegInit = -(1 << 28);          // "no value yet" for running maxima; 2 * kNegInit - 1 fits int32
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 constexpr int kTailTiles = 16;                // slack tiles after the last image (query over-read)
 
 struct MatchParams {
   const int8_t* tiles;
+  const int8_t* rows_slot;         // int8 rows, row-major in slot order
   const int* rconst;
+  const int* cinit;
   const int* qnorm;
+  const uint32_t* perm;            // slot -> original row (kNoMatch: pad)
+  const uint32_t* rowpos;          // original row (global numbering) -> slot within its image
   const uint8_t* rows_u8;          // original row-major descriptors (naive check kernel only)
   const uint64_t* img_row_off;     // first row of each image in rows_u8
-  const uint32_t* img_tile_off;    // first tile of each image
+  const uint32_t* img_tile_off;    // first tile of each image (padded tile counts)
   const uint32_t* img_n;           // descriptors per image
+  const uint32_t* img_ntiles;      // occupied tiles per image
+  const uint32_t* img_neven;       // rows of even squared norm per image (slots of a parity half are filled in rank order)
   const uint2* pairs;              // batch-local (I, J)
   const uint2* work;               // (batch-local pair index, first query tile)
   uint32_t n_work;
-  uint32_t* best;                  // [batch pairs][qstride]: index in I of the accepted match or kNoMatch
+  uint32_t* best;                  // [batch pairs][qstride], indexed by query SLOT: original index in I or kNoMatch
+  int2* cd;                        // filter -> verify: (d0, upper bound of d1) of a candidate query slot
   uint32_t* count;                 // [batch pairs]: accepted matches
+  uint32_t* errflag;               // internal-consistency violations seen by the verify kernel (must stay 0)
   uint32_t qstride;
   float ratio_sq;
 };
 
 // ------------------------------------------------------------------------------------------------
-// prep: row-major uint8 descriptors -> fragment-major int8 tiles + rconst + qnorm
-// grid = (max padded tiles per image, n_images), block = 256
+// prep 1/3: |a'|^2 of every original row + number of even-norm rows per image
+// grid = (ceil(max n / 256), n_images), block = 256, one thread per row
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_tiles_kernel(const uint8_t* __restrict__ rows,
-                                                         const uint64_t* __restrict__ img_row_off,
-                                                         const uint32_t* __restrict__ img_tile_off,
-                                                         const uint32_t* __restrict__ img_n,
-                                                         int8_t* __restrict__ tiles, int* __restrict__ rconst,
-                                                         int* __restrict__ qnorm) {
+__global__ __launch_bounds__(256) void row_norms_kernel(const uint8_t* __restrict__ rows,
+                                                        const uint64_t* __restrict__ img_row_off,
+                                                        const uint32_t* __restrict__ img_n, int* __restrict__ rownorm,
+                                                        uint32_t* __restrict__ n_even) {
   const uint32_t img = blockIdx.y;
   const uint32_t n = img_n[img];
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool even = false;
+  if (r < n) {
+    const uint4* src = reinterpret_cast<const uint4*>(rows + (img_row_off[img] + r) * kDim);
+    int nn = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint4 v = src[c];
+      const uint32_t w[4] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nn = __builtin_amdgcn_sdot4((int)w[i], (int)w[i], nn, false);
+    }
+    rownorm[img_row_off[img] + r] = nn;
+    even = (nn & 1) == 0;
+  }
+  const unsigned long long m = __ballot(even);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_even[img], (uint32_t)__popcll(m));
+}
+
+// in-tile row of the j-th (0..15) slot of parity half h: matches the 32x32 MFMA result layout, where lane half h
+// holds rows (r / 4) * 8 + h * 4 + r % 4 in accumulator register r
+__device__ __host__ __forceinline__ int slot_row(int j, int h) { return (j >> 2) * 8 + h * 4 + (j & 3); }
+
+// ------------------------------------------------------------------------------------------------
+// prep 2/3: stable partition of an image's rows by norm parity into tile slots; per-slot constants
+// grid = n_images, block = 1024 (one workgroup walks the image's rows in order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void assign_slots_kernel(const uint64_t* __restrict__ img_row_off,
+                                                            const uint32_t* __restrict__ img_tile_off,
+                                                            const uint32_t* __restrict__ img_n,
+                                                            const int* __restrict__ rownorm, uint32_t* __restrict__ rowpos,
+                                                            uint32_t* __restrict__ perm, int* __restrict__ rconst,
+                                                            int* __restrict__ cinit, int* __restrict__ qnorm) {
+  __shared__ uint32_t s_cnt[16][2];
+  __shared__ uint32_t s_base[2];
+  const uint32_t img = blockIdx.x;
+  const uint32_t n = img_n[img];
+  const uint64_t row0 = img_row_off[img];
+  const size_t slot0 = (size_t)img_tile_off[img] * kTileRows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 2) s_base[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < n; c0 += blockDim.x) {
+    const uint32_t r = c0 + threadIdx.x;
+    const bool valid = r < n;
+    const int nn = valid ? rownorm[row0 + r] : 0;
+    const int par = nn & 1;
+    const unsigned long long m_even = __ballot(valid && par == 0), m_odd = __ballot(valid && par == 1);
+    if (lane == 0) { s_cnt[wave][0] = (uint32_t)__popcll(m_even); s_cnt[wave][1] = (uint32_t)__popcll(m_odd); }
+    __syncthreads();
+    if (valid) {
+      uint32_t rank = s_base[par];
+      for (int w = 0; w < wave; ++w) rank += s_cnt[w][par];
+      rank += (uint32_t)__popcll((par ? m_odd : m_even) & ((1ull << lane) - 1ull));
+      const uint32_t t = rank >> 4;
+      const uint32_t pos = t * kTileRows + (uint32_t)slot_row((int)(rank & 15u), par);
+      rowpos[row0 + r] = pos;
+      perm[slot0 + pos] = r;
+      rconst[slot0 + pos] = -(nn << 8) - (int)((t % kWinTiles) * kTileRows + (pos & 31u));
+      cinit[slot0 + pos] = -(nn >> 1);
+      qnorm[slot0 + pos] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t e = 0, o = 0;
+      for (int w = 0; w < 16; ++w) { e += s_cnt[w][0]; o += s_cnt[w][1]; }
+      s_base[0] += e; s_base[1] += o;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep 3/3: gather the permuted rows into fragment-major int8 tiles
+// grid = (max padded tiles per image, n_images), block = 256 (one 16-byte chunk per thread)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_tiles_kernel(const uint8_t* __restrict__ rows,
+                                                          const uint64_t* __restrict__ img_row_off,
+                                                          const uint32_t* __restrict__ img_tile_off,
+                                                          const uint32_t* __restrict__ perm, int8_t* __restrict__ tiles,
+                                                          int8_t* __restrict__ rows_slot) {
+  const uint32_t img = blockIdx.y;
   const uint32_t ntiles_pad = img_tile_off[img + 1] - img_tile_off[img];
   const uint32_t t = blockIdx.x;
   if (t >= ntiles_pad) return;
   const uint32_t gt = img_tile_off[img] + t;
-  const uint8_t* src = rows + img_row_off[img] * kDim;
-  __shared__ int s_norm[kTileRows][8];
-
   const int c = threadIdx.x;        // chunk id = s*64 + lane
   const int s = c >> 6, lane = c & 63;
   const int m = lane & 31, h = lane >> 5;
-  const uint32_t row = t * kTileRows + m;
-  const int kchunk = s * 2 + h;     // source bytes [16*kchunk, 16*kchunk + 16)
+  const uint32_t src_row = perm[(size_t)gt * kTileRows + m];
   uint4 v = make_uint4(0, 0, 0, 0);
-  int part = 0;
-  if (row < n) {
-    v = *reinterpret_cast<const uint4*>(src + (size_t)row * kDim + kchunk * 16);
+  if (src_row != kNoMatch) {
+    v = *reinterpret_cast<const uint4*>(rows + (img_row_off[img] + src_row) * kDim + (s * 2 + h) * 16);
     v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int a = (int)(int8_t)((w[i] >> (8 * b)) & 0xFF);
-        part += a * a;
-      }
-    }
   }
   *reinterpret_cast<uint4*>(tiles + (size_t)gt * kTileBytes + c * 16) = v;
-  s_norm[m][kchunk] = part;
-  __syncthreads();
-  if (threadIdx.x < kTileRows) {
-    const int mm = threadIdx.x;
-    const uint32_t r = t * kTileRows + mm;
-    int nn = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) nn += s_norm[mm][i];
-    const bool valid = r < n;
-    const int idx8 = (int)((t % kWinTiles) * kTileRows + mm);
-    rconst[(size_t)gt * kTileRows + mm] = valid ? (-(nn << 8) - idx8) : kRPad;
-    qnorm[(size_t)gt * kTileRows + mm] = valid ? nn : 0;
-  }
+  // the same int8 bytes once more, row-major in slot order (128 contiguous bytes per slot): what the verify stage reads
+  *reinterpret_cast<uint4*>(rows_slot + ((size_t)gt * kTileRows + m) * kDim + (s * 2 + h) * 16) = v;
+}
+
+__global__ __launch_bounds__(256) void fill_i32_kernel(int* __restrict__ p, size_t n, int value) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = value;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void l2_top2_ratio_kernel(MatchParams p) {
   const uint2 wk = p.work[w];
   const uint2 ij = p.pairs[wk.x];
   const uint32_t I = ij.x, J = ij.y;
-  const uint32_t nI = p.img_n[I], nJ = p.img_n[J];
   const uint32_t tileI0 = p.img_tile_off[I], tileJ0 = p.img_tile_off[J];
-  const int ntI = (int)((nI + kTileRows - 1) / kTileRows);
+  const uint32_t ntJpad = p.img_tile_off[J + 1] - tileJ0;
+  const int ntI = (int)p.img_ntiles[I];
   const int nwin = (ntI + kWinTiles - 1) / kWinTiles;
   const uint32_t qt0 = wk.y + (uint32_t)wave * kNQ;
 
@@ -345,21 +421,367 @@ __global__ __launch_bounds__(256, 2) void l2_top2_ratio_kernel(MatchParams p) {
     G2[n] = g2;
   }
 
-  // ratio test + output (lanes 0..31 own one query each per tile)
+  // ratio test + output (lanes 0..31 own one query slot each per tile); indices go back to original rows
 #pragma unroll
   for (int n = 0; n < kNQ; ++n) {
-    const uint32_t q = (qt0 + n) * kTileRows + (lane & 31);
-    const bool inb = (lane < 32) && (q < nJ);
+    const uint32_t q = (qt0 + n) * kTileRows + (lane & 31);   // query slot within J
+    const bool inb = (lane < 32) && (qt0 + n < ntJpad);
     bool ok = false;
     if (inb) {
+      const bool valid = p.perm[(size_t)tileJ0 * kTileRows + q] != kNoMatch;
       const int nq = p.qnorm[(size_t)tileJ0 * kTileRows + q];
       const int d0 = G1[n] + nq, d1 = G2[n] + nq;
-      ok = __int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1));
-      p.best[(size_t)wk.x * p.qstride + q] = ok ? (uint32_t)Gi[n] : kNoMatch;
+      ok = valid && (__int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1)));
+      p.best[(size_t)wk.x * p.qstride + q] = ok ? p.perm[(size_t)tileI0 * kTileRows + (uint32_t)Gi[n]] : kNoMatch;
     }
     const unsigned long long m = __ballot(ok);
     if (lane == 0 && m) atomicAdd(&p.count[wk.x], (uint32_t)__popcll(m));
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// l2_filter (variant 4, stage 1): the same MFMA stream with a ONE-VALU-per-distance epilogue.
+//
+// The accumulator starts at C_i = -floor(|a'_i|^2 / 2), so a finished 32x32 tile holds v = a'.b' - floor(|a'|^2 / 2)
+// and, because lane half h only sees rows of norm parity h,  w = 2 v - h = |b'|^2 - d  exactly (larger = nearer).
+// Instead of a running top-2 (3 VALU per distance) each lane keeps running MAXIMA of two partitions of the rows it sees
+// (2 x v_max3_i32 per two distances):
+//   P-classes: accumulator register pair s = r / 2  (8 per lane)   -> rows at two fixed in-tile positions, all tiles
+//   Q-classes: LDS window g (8 tiles)               (folded into a running top-2 over windows with argmax)
+// Let x* be the nearest row, in P-class s1 and window g1 of half hw. Every other row is in a different P-class, a
+// different window, or the other half, unless it shares (s1, g1, hw) with x* — at most 15 rows. Hence
+//   V2 = max(second-best P-class, second-best window, best of the other half)   (all in w units, all exact)
+// is the exact nearest distance among the rows OUTSIDE that 16-row cell and d1 <= d1_ub = |b'|^2 - V2.
+//   * (float)d0 >= ratio_sq * (float)d1_ub  =>  the reference's test fails for the true d1 <= d1_ub too: REJECT, exactly.
+//   * otherwise the query is a CANDIDATE: stage 2 recomputes the 16 rows of the cell exactly and finishes the test.
+// Nothing is approximated; ties (equal maxima in two classes) make d1_ub <= d0 and are rejected like the reference does.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int kMode>
+__global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x kStageBytes
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5;
+
+  const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const uint2 wk = p.work[w];
+  const uint2 ij = p.pairs[wk.x];
+  const uint32_t I = ij.x, J = ij.y;
+  const uint32_t tileI0 = p.img_tile_off[I], tileJ0 = p.img_tile_off[J];
+  const uint32_t ntJpad = p.img_tile_off[J + 1] - tileJ0;
+  const int ntI = (int)p.img_ntiles[I];
+  const int nwin = (ntI + kWinTiles - 1) / kWinTiles;
+  const uint32_t qt0 = wk.y + (uint32_t)wave * kNQ;
+
+  v4i b[kNQ][4];
+  {
+    const int8_t* qsrc = p.tiles + (size_t)(tileJ0 + qt0) * kTileBytes + lane * 16;
+#pragma unroll
+    for (int n = 0; n < kNQ; ++n)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[n][s] = *reinterpret_cast<const v4i*>(qsrc + n * kTileBytes + s * 1024);
+  }
+
+  const int8_t* gI = p.tiles + (size_t)tileI0 * kTileBytes;
+  const int* gC = p.cinit + (size_t)tileI0 * kTileRows;
+
+  int TP[kNQ][8];                      // P-class maxima
+  int Q1[kNQ], Q2[kNQ], Qg[kNQ];       // best / second-best window maximum, best window
+#pragma unroll
+  for (int n = 0; n < kNQ; ++n) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) TP[n][s] = kNegInit;
+    Q1[n] = kNegInit; Q2[n] = kNegInit; Qg[n] = 0;
+  }
+
+  StageRegs sr;
+  if constexpr (kMode == kStageGlds) {
+    stage_window_glds(smem, gI, gC, wave, lane);
+  } else if constexpr (kMode == kStageGldsAsm) {
+    stage_window_glds_asm(smem, gI, gC, wave, lane);
+  } else {
+    stage_issue(sr, gI, gC, wave, lane);
+    stage_commit(smem, sr, wave, lane);
+  }
+#pragma unroll
+  for (int n = 0; n < kNQ; ++n)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(b[n][s]));
+
+  for (int win = 0; win < nwin; ++win) {
+    if constexpr (kMode == kStageGldsAsm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    char* buf = smem + (win & 1) * kStageBytes;
+    char* nbuf = smem + ((win + 1) & 1) * kStageBytes;
+    if constexpr (kMode == kStageRegs) {
+      const int wn = (win + 1 < nwin) ? win + 1 : win;
+      stage_issue(sr, gI + (size_t)wn * kWinTiles * kTileBytes, gC + wn * kWinRows, wave, lane);
+    } else if (win + 1 < nwin) {
+      const int8_t* gt = gI + (size_t)(win + 1) * kWinTiles * kTileBytes;
+      const int* gc = gC + (win + 1) * kWinRows;
+      if constexpr (kMode == kStageGlds) stage_window_glds(nbuf, gt, gc, wave, lane);
+      else stage_window_glds_asm(nbuf, gt, gc, wave, lane);
+    }
+
+    int TQ[kNQ];
+#pragma unroll
+    for (int n = 0; n < kNQ; ++n) TQ[n] = kNegInit;
+
+    // Software pipeline over the (tile, query tile) chains of the window: the 4-MFMA chain of step k is issued, then
+    // the 16 v_max3 of step k-1 run in its shadow (two accumulator sets ping-pong); the LDS fragments of tile t+1 are
+    // fetched while tile t computes. The pipeline is drained at the end of every window (once per 32 chains).
+    const int nt = min(kWinTiles, ntI - win * kWinTiles);
+    const char* wb = buf + lane * 16;
+    const char* wc = buf + kWinTiles * kTileBytes + h * 16;
+    v4i a[4];
+    v16i cv;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const v4i*>(wb + s * 1024);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 c4 = *reinterpret_cast<const int4*>(wc + g * 32);
+      cv[g * 4 + 0] = c4.x; cv[g * 4 + 1] = c4.y; cv[g * 4 + 2] = c4.z; cv[g * 4 + 3] = c4.w;
+    }
+    v16i accA, accB;   // accB starts as the neutral element of max: its first epilogue is a no-op
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = kNegInit;
+
+#define MVGX_EPILOGUE(ACC, N)                                          \
+  {                                                                    \
+    int tq = TQ[N];                                                    \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                    \
+      TP[N][s] = max(max(TP[N][s], ACC[2 * s]), ACC[2 * s + 1]);       \
+      tq = max(max(tq, ACC[2 * s + 1]), ACC[2 * s]);                   \
+    }                                                                  \
+    TQ[N] = tq;                                                        \
+  }
+#define MVGX_CHAIN(ACC, N, A, CV)                                                            \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], b[N][0], CV, 0, 0, 0);                   \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1], b[N][1], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2], b[N][2], ACC, 0, 0, 0);                  \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[3], b[N][3], ACC, 0, 0, 0);
+#define MVGX_INTERLEAVE()                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);                                         \
+  }
+
+#define MVGX_TILE(A, CV, AN, CN, TN)                                                              \
+  {                                                                                                \
+    const int tn_ = (TN);                                                                          \
+    MVGX_CHAIN(accA, 0, A, CV)                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
+        AN[s] = *reinterpret_cast<const v4i*>(wb + tn_ * kTileBytes + s * 1024);                   \
+    MVGX_EPILOGUE(accB, 3)                                                                         \
+    MVGX_INTERLEAVE()                                                                              \
+    MVGX_CHAIN(accB, 1, A, CV)                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
+      const int4 c4 = *reinterpret_cast<const int4*>(wc + tn_ * (kTileRows * 4) + g * 32);        \
+      CN[g * 4 + 0] = c4.x; CN[g * 4 + 1] = c4.y; CN[g * 4 + 2] = c4.z; CN[g * 4 + 3] = c4.w;     \
+    }                                                                                              \
+    MVGX_EPILOGUE(accA, 0)                                                                         \
+    MVGX_INTERLEAVE()                                                                              \
+    MVGX_CHAIN(accA, 2, A, CV)                                                                     \
+    MVGX_EPILOGUE(accB, 1)                                                                         \
+    MVGX_INTERLEAVE()                                                                              \
+    MVGX_CHAIN(accB, 3, A, CV)                                                                     \
+    MVGX_EPILOGUE(accA, 2)                                                                         \
+    MVGX_INTERLEAVE()                                                                              \
+  }
+    // two tiles per trip so that the fragment registers ping-pong (a, cv) <-> (an, cn) without copies; the fetch of a
+    // tile past the end of the window re-reads the last tile (no branch around the loads)
+    v4i an[4];
+    v16i cn;
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+      MVGX_TILE(a, cv, an, cn, t + 1)
+      MVGX_TILE(an, cn, a, cv, min(t + 2, nt - 1))
+    }
+    if (t < nt) MVGX_TILE(a, cv, an, cn, t)
+    MVGX_EPILOGUE(accB, 3)   // drain
+#undef MVGX_EPILOGUE
+#undef MVGX_CHAIN
+#undef MVGX_TILE
+#undef MVGX_INTERLEAVE
+    if constexpr (kMode == kStageRegs) stage_commit(nbuf, sr, wave, lane);
+    // fold the window maximum into the running (best, best window, second best) over windows
+#pragma unroll
+    for (int n = 0; n < kNQ; ++n) {
+      const int v = TQ[n];
+      const bool better = v > Q1[n];
+      Q2[n] = better ? Q1[n] : max(Q2[n], v);
+      Qg[n] = better ? win : Qg[n];
+      Q1[n] = better ? v : Q1[n];
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < kNQ; ++n) {
+    // best / second-best P-class of this lane half
+    int p1 = kNegInit, p2 = kNegInit, ps = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int v = TP[n][s];
+      const bool better = v > p1;
+      p2 = better ? p1 : max(p2, v);
+      ps = better ? s : ps;
+      p1 = better ? v : p1;
+    }
+    // exact w = |b'|^2 - d of: the half's best row, its runner-up outside the best P-class, outside the best window
+    const int w1 = 2 * p1 - h, w2p = 2 * p2 - h, w2q = 2 * Q2[n] - h;
+    const int o1 = __shfl_xor(w1, 32), o2p = __shfl_xor(w2p, 32), o2q = __shfl_xor(w2q, 32);
+    const int os = __shfl_xor(ps, 32), og = __shfl_xor(Qg[n], 32);
+    const bool mine = w1 > o1;   // parities differ between the halves, so w1 != o1
+    const int W1 = mine ? w1 : o1;
+    const int V2 = mine ? max3i(w2p, w2q, o1) : max3i(o2p, o2q, w1);
+    const int s1 = mine ? ps : os, g1 = mine ? Qg[n] : og, hw = mine ? h : (h ^ 1);
+
+    const uint32_t q = (qt0 + n) * kTileRows + (lane & 31);   // query slot within J
+    if (lane < 32 && qt0 + n < ntJpad) {
+      const bool valid = p.perm[(size_t)tileJ0 * kTileRows + q] != kNoMatch;
+      const int nq = p.qnorm[(size_t)tileJ0 * kTileRows + q];
+      const int d0 = nq - W1, d1ub = nq - V2;
+      const bool cand = valid && (__int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1ub)));
+      const size_t o = (size_t)wk.x * p.qstride + q;
+      p.best[o] = cand ? ((uint32_t)s1 | ((uint32_t)hw << 3) | ((uint32_t)g1 << 4)) : kNoMatch;
+      if (cand) p.cd[o] = make_int2(d0, d1ub);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// l2_verify (variant 4, stage 2): finishes the candidates of the filter. Same work items as the filter (a workgroup
+// owns 512 query slots of one pair). 16 lanes per candidate recompute the exact distances of the 16 slots of its
+// (P-class, window, half) cell with v_dot4_i32_i8 on the tile bytes, take the cell's best (must equal d0) and its
+// runner-up, d1 = min(d1_ub, runner-up), and evaluate the reference's fp32 ratio test. best[] receives the ORIGINAL
+// index in I or kNoMatch; count[] the accepted queries of the pair.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_verify_kernel(MatchParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint2 wk = p.work[blockIdx.x];
+  const uint2 ij = p.pairs[wk.x];
+  const uint32_t I = ij.x, J = ij.y;
+  const uint32_t tileI0 = p.img_tile_off[I], tileJ0 = p.img_tile_off[J];
+  const uint32_t ntJpad = p.img_tile_off[J + 1] - tileJ0;
+  const uint32_t nEvenI = p.img_neven[I], nOddI = p.img_n[I] - nEvenI;
+  const int l16 = lane & 15, sub = lane >> 4;
+  uint32_t accepted = 0;
+  for (int part = 0; part < 2; ++part) {
+    const uint32_t q0 = (wk.y + (uint32_t)wave * kNQ) * kTileRows + (uint32_t)part * 64;
+    const uint32_t q = q0 + lane;
+    const bool inb = q < ntJpad * kTileRows;
+    const uint32_t code = inb ? p.best[(size_t)wk.x * p.qstride + q] : kNoMatch;
+    unsigned long long todo = __ballot(code != kNoMatch);
+    while (todo) {
+      // the sub-th pending candidate of this round goes to lane group `sub`
+      unsigned long long m = todo;
+      for (int i = 0; i < sub; ++i) m &= m - 1;
+      const bool active = m != 0;
+      const int src = active ? __builtin_ctzll(m) : 0;
+      for (int i = 0; i < 4; ++i) todo &= todo - 1;
+      const uint32_t cc = (uint32_t)__shfl((int)code, src);
+      const uint32_t qs = q0 + (uint32_t)src;                      // query slot
+      const int s1 = cc & 7, hw = (cc >> 3) & 1, g1 = (int)(cc >> 4);
+      // Row rho (0..15) of the cell sits in tile g1*8 + (rho >> 1), in-tile row slot_row(2*s1 + (rho & 1), hw); rows
+      // 2c and 2c+1 are adjacent slots = 256 contiguous bytes of rows_slot. Load c (0..7) of the group therefore reads
+      // exactly those two rows, lane l16 taking 16-byte piece (l16 & 7) of row 2c + (l16 >> 3): 2-4 cache lines per
+      // group and instruction instead of 16. Each lane needs only ONE piece of the query.
+      const int piece = l16 & 7, rsel = l16 >> 3;
+      const int mrow = slot_row(2 * s1 + rsel, hw);
+      const size_t slot0 = (size_t)tileI0 * kTileRows + (active ? (size_t)g1 * kWinTiles * kTileRows + mrow : 0);
+      const size_t slotQ = (size_t)tileJ0 * kTileRows + (active ? qs : 0);
+      const size_t o = (size_t)wk.x * p.qstride + (active ? qs : 0);
+      // the row this lane finally owns: rho = 2 * (l16 & 7) + (l16 >> 3)  (a permutation of 0..15)
+      const uint32_t tt = (uint32_t)g1 * kWinTiles + (uint32_t)piece;
+      const size_t slotI = active ? slot0 + (size_t)piece * kTileRows : slot0;
+      // slots of a parity half are filled in rank order: slot (tile tt, j = 2*s1 + rsel) holds rank 16*tt + j
+      const bool valid = active && (tt * 16u + (uint32_t)(2 * s1 + rsel)) < (hw ? nOddI : nEvenI);
+      int4 va[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        va[c] = *reinterpret_cast<const int4*>(p.rows_slot + (slot0 + (active ? (size_t)c * kTileRows : 0)) * kDim + piece * 16);
+      const int4 vb = *reinterpret_cast<const int4*>(p.rows_slot + slotQ * kDim + piece * 16);
+      const int2 f = p.cd[o];
+      const int f_d0 = f.x, f_d1 = f.y;
+      // |b'|^2 from the query piece itself (sum over the 8 lanes holding its pieces)
+      int nb = __builtin_amdgcn_sdot4(vb.x, vb.x, 0, false);
+      nb = __builtin_amdgcn_sdot4(vb.y, vb.y, nb, false);
+      nb = __builtin_amdgcn_sdot4(vb.z, vb.z, nb, false);
+      nb = __builtin_amdgcn_sdot4(vb.w, vb.w, nb, false);
+      nb += __builtin_amdgcn_update_dpp(0, nb, 0xB1, 0xF, 0xF, true);
+      nb += __builtin_amdgcn_update_dpp(0, nb, 0x4E, 0xF, 0xF, true);
+      nb += __builtin_amdgcn_update_dpp(0, nb, 0x141, 0xF, 0xF, true);
+      int dot = 0, na = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int part = __builtin_amdgcn_sdot4(va[c].x, vb.x, 0, false);
+        part = __builtin_amdgcn_sdot4(va[c].y, vb.y, part, false);
+        part = __builtin_amdgcn_sdot4(va[c].z, vb.z, part, false);
+        part = __builtin_amdgcn_sdot4(va[c].w, vb.w, part, false);
+        // sum over the 8 lanes holding the 8 pieces of this row (DPP butterfly: xor 1, xor 2, half-row mirror)
+        part += __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xF, 0xF, true);
+        part += __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xF, 0xF, true);
+        part += __builtin_amdgcn_update_dpp(0, part, 0x141, 0xF, 0xF, true);
+        dot = (c == piece) ? part : dot;   // lane keeps the row whose tile index equals its piece index
+        // |a'|^2 of the same row, same way (cheaper than a scattered load of the per-slot norm)
+        int sq = __builtin_amdgcn_sdot4(va[c].x, va[c].x, 0, false);
+        sq = __builtin_amdgcn_sdot4(va[c].y, va[c].y, sq, false);
+        sq = __builtin_amdgcn_sdot4(va[c].z, va[c].z, sq, false);
+        sq = __builtin_amdgcn_sdot4(va[c].w, va[c].w, sq, false);
+        sq += __builtin_amdgcn_update_dpp(0, sq, 0xB1, 0xF, 0xF, true);
+        sq += __builtin_amdgcn_update_dpp(0, sq, 0x4E, 0xF, 0xF, true);
+        sq += __builtin_amdgcn_update_dpp(0, sq, 0x141, 0xF, 0xF, true);
+        na = (c == piece) ? sq : na;
+      }
+      const int d = valid ? na + nb - 2 * dot : INT_MAX;
+      // best of the cell (key = distance, lane) and runner-up over the 16 lanes of the group (DPP min butterfly)
+      int key = valid ? ((d << 4) | l16) : INT_MAX;
+      key = min(key, __builtin_amdgcn_update_dpp(INT_MAX, key, 0xB1, 0xF, 0xF, false));
+      key = min(key, __builtin_amdgcn_update_dpp(INT_MAX, key, 0x4E, 0xF, 0xF, false));
+      key = min(key, __builtin_amdgcn_update_dpp(INT_MAX, key, 0x141, 0xF, 0xF, false));
+      key = min(key, __builtin_amdgcn_update_dpp(INT_MAX, key, 0x140, 0xF, 0xF, false));
+      const int wl = key & 15, dbest = key >> 4;
+      int second = (l16 == wl) ? INT_MAX : d;
+      second = min(second, __builtin_amdgcn_update_dpp(INT_MAX, second, 0xB1, 0xF, 0xF, false));
+      second = min(second, __builtin_amdgcn_update_dpp(INT_MAX, second, 0x4E, 0xF, 0xF, false));
+      second = min(second, __builtin_amdgcn_update_dpp(INT_MAX, second, 0x141, 0xF, 0xF, false));
+      second = min(second, __builtin_amdgcn_update_dpp(INT_MAX, second, 0x140, 0xF, 0xF, false));
+      bool ok = false;
+      if (active && l16 == wl) {   // the winner's lane finishes the test and translates its slot to the original row
+        if (key == INT_MAX || dbest != f_d0) atomicAdd(p.errflag, 1u);
+        const int d1 = min(f_d1, second);
+        ok = __int2float_rn(dbest) < __fmul_rn(p.ratio_sq, __int2float_rn(d1));
+        p.best[o] = ok ? p.perm[slotI] : kNoMatch;
+      }
+      accepted += (uint32_t)__popcll(__ballot(ok));
+    }
+  }
+  if (lane == 0 && accepted) atomicAdd(&p.count[wk.x], accepted);
+}
+
+// statistics (profile mode only): candidates the filter hands to the verify stage. One atomic per 16 K slots — a single
+// counter word saturates at ~90 atomics/us on this chip, which is why the verify kernel itself does not count.
+__global__ __launch_bounds__(256) void count_candidates_kernel(const uint32_t* __restrict__ best, size_t n,
+                                                               uint32_t* __restrict__ counter) {
+  __shared__ uint32_t s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  uint32_t c = 0;
+  const size_t base = (size_t)blockIdx.x * 16384;
+  for (int k = 0; k < 64; ++k) {
+    const size_t i = base + (size_t)k * 256 + threadIdx.x;
+    if (i < n && best[i] != kNoMatch) ++c;
+  }
+  const unsigned long long m = __ballot(c != 0);
+  (void)m;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_sum, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum) atomicAdd(counter, s_sum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +818,7 @@ __global__ __launch_bounds__(256) void l2_top2_ratio_naive_kernel(MatchParams p)
       else if (d < d1) { d1 = d; }
     }
     const bool ok = __int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1));
-    p.best[(size_t)wk.x * p.qstride + q] = ok ? i0 : kNoMatch;
+    p.best[(size_t)wk.x * p.qstride + p.rowpos[p.img_row_off[J] + q]] = ok ? i0 : kNoMatch;
     if (ok) atomicAdd(&p.count[wk.x], 1u);
   }
 }
@@ -429,6 +851,8 @@ __global__ __launch_bounds__(256) void compact_matches_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ offsets,
                                                               const uint2* __restrict__ pairs,
                                                               const uint32_t* __restrict__ img_n,
+                                                              const uint64_t* __restrict__ img_row_off,
+                                                              const uint32_t* __restrict__ rowpos,
                                                               uint32_t n_pairs, uint32_t qstride,
                                                               uint2* __restrict__ out_ij) {
   const uint32_t pidx = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per image pair
@@ -436,11 +860,13 @@ __global__ __launch_bounds__(256) void compact_matches_kernel(const uint32_t* __
   const int lane = threadIdx.x & 63;
   const uint32_t off = offsets[pidx];
   if (offsets[pidx + 1] == off) return;
-  const uint32_t nJ = img_n[pairs[pidx].y];
+  const uint32_t J = pairs[pidx].y;
+  const uint32_t nJ = img_n[J];
+  const uint32_t* pos = rowpos + img_row_off[J];   // original query row -> slot (best[] is slot-indexed)
   uint32_t run = off;
   for (uint32_t q0 = 0; q0 < nJ; q0 += 64) {
     const uint32_t q = q0 + lane;
-    const uint32_t v = (q < nJ) ? best[(size_t)pidx * qstride + q] : kNoMatch;
+    const uint32_t v = (q < nJ) ? best[(size_t)pidx * qstride + pos[q]] : kNoMatch;
     const bool ok = v != kNoMatch;
     const unsigned long long m = __ballot(ok);
     if (ok) {
@@ -488,7 +914,9 @@ struct mvgx_match_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
   // options
-  int variant = 1;          // 0 naive, 1 MFMA + register-staged LDS, 2 MFMA + LDS-DMA builtin, 3 MFMA + LDS-DMA asm
+  int variant = 4;          // 0 naive; exact top-2 kernel: 1 register-staged LDS, 2 LDS-DMA builtin, 3 LDS-DMA asm;
+                            // 4 = filter (1 VALU / distance) + verify, LDS staging mode in `stage`
+  int stage = 3;            // staging mode of variant 4 (1 / 2 / 3 as above); 3 measured fastest (sweep call 5)
   int profile = 0;
   int64_t batch_pairs = 1 << 17;
   int keep_host_results = 1;
@@ -497,15 +925,16 @@ struct mvgx_match_ctx {
   uint32_t total_tiles = 0;
   uint32_t max_tiles_pad = 0;
   uint32_t qstride = 0;
-  std::vector<uint32_t> h_n, h_tile_off;
+  std::vector<uint32_t> h_n, h_tile_off, h_ntiles;
   std::vector<uint64_t> h_row_off;
   DevBuf<uint8_t> d_rows;
   bool rows_owned = true;
   const uint8_t* d_rows_view = nullptr;
-  DevBuf<int8_t> d_tiles;
-  DevBuf<int> d_rconst, d_qnorm;
+  DevBuf<int8_t> d_tiles, d_rows_slot;
+  DevBuf<int> d_rconst, d_cinit, d_qnorm, d_rownorm;
   DevBuf<uint64_t> d_row_off;
-  DevBuf<uint32_t> d_tile_off, d_n;
+  DevBuf<uint32_t> d_tile_off, d_n, d_ntiles, d_perm, d_rowpos, d_neven, d_err;
+  DevBuf<int2> d_cd;
   // batch scratch
   DevBuf<uint2> d_pairs, d_work, d_ij;
   DevBuf<uint32_t> d_best, d_count, d_offsets;
@@ -523,39 +952,79 @@ int prep_regions(mvgx_match_ctx* c) {
   const uint32_t n_images = c->n_images;
   c->h_tile_off.assign(n_images + 1, 0);
   c->h_row_off.assign(n_images + 1, 0);
-  uint32_t max_pad = 0, max_n = 0;
+  c->h_ntiles.assign(n_images + 1, 0);
+  uint32_t max_n = 0;
   for (uint32_t k = 0; k < n_images; ++k) {
-    const uint32_t nt = (c->h_n[k] + kTileRows - 1) / kTileRows;
-    const uint32_t pad = (nt + kWinTiles - 1) / kWinTiles * kWinTiles;
-    c->h_tile_off[k + 1] = c->h_tile_off[k] + pad;
     c->h_row_off[k + 1] = c->h_row_off[k] + c->h_n[k];
-    max_pad = std::max(max_pad, pad);
     max_n = std::max(max_n, c->h_n[k]);
   }
-  c->total_tiles = c->h_tile_off[n_images];
-  c->max_tiles_pad = max_pad;
-  c->qstride = (max_n + kTileRows - 1) / kTileRows * kTileRows;
-  const size_t alloc_tiles = (size_t)c->total_tiles + kTailTiles;
+  const uint64_t total_rows = c->h_row_off[n_images];
   int rc;
-  if ((rc = c->d_tiles.ensure(alloc_tiles * kTileBytes))) return rc;
-  if ((rc = c->d_rconst.ensure(alloc_tiles * kTileRows))) return rc;
-  if ((rc = c->d_qnorm.ensure(alloc_tiles * kTileRows))) return rc;
   if ((rc = c->d_row_off.ensure(n_images + 1))) return rc;
   if ((rc = c->d_tile_off.ensure(n_images + 1))) return rc;
   if ((rc = c->d_n.ensure(n_images + 1))) return rc;
+  if ((rc = c->d_ntiles.ensure(n_images + 1))) return rc;
+  if ((rc = c->d_neven.ensure(n_images + 1))) return rc;
+  if ((rc = c->d_err.ensure(2))) return rc;
+  if ((rc = c->d_rownorm.ensure(std::max<uint64_t>(total_rows, 1)))) return rc;
+  if ((rc = c->d_rowpos.ensure(std::max<uint64_t>(total_rows, 1)))) return rc;
   MVGX_HIP(hipMemcpyAsync(c->d_row_off.p, c->h_row_off.data(), (n_images + 1) * sizeof(uint64_t),
                           hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_n.p, c->h_n.data(), n_images * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemsetAsync(c->d_neven.p, 0, (n_images + 1) * sizeof(uint32_t), c->stream));
+  MVGX_HIP(hipMemsetAsync(c->d_err.p, 0, 2 * sizeof(uint32_t), c->stream));
+  // 1/3: row norms + even-norm counts (the tile count of an image depends on its parity split)
+  std::vector<uint32_t> h_even(n_images + 1, 0);
+  if (total_rows > 0) {
+    dim3 grid((max_n + 255) / 256, n_images);
+    hipLaunchKernelGGL(row_norms_kernel, grid, dim3(256), 0, c->stream, c->d_rows_view, c->d_row_off.p, c->d_n.p,
+                       c->d_rownorm.p, c->d_neven.p);
+    MVGX_HIP(hipGetLastError());
+    MVGX_HIP(hipMemcpyAsync(h_even.data(), c->d_neven.p, n_images * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  uint32_t max_pad = 0;
+  for (uint32_t k = 0; k < n_images; ++k) {
+    const uint32_t ne = h_even[k], no = c->h_n[k] - h_even[k];
+    const uint32_t nt = (std::max(ne, no) + 15) / 16;
+    const uint32_t pad = (nt + kWinTiles - 1) / kWinTiles * kWinTiles;
+    c->h_ntiles[k] = nt;
+    c->h_tile_off[k + 1] = c->h_tile_off[k] + pad;
+    max_pad = std::max(max_pad, pad);
+  }
+  c->total_tiles = c->h_tile_off[n_images];
+  c->max_tiles_pad = max_pad;
+  c->qstride = max_pad * kTileRows;
+  const size_t alloc_tiles = (size_t)c->total_tiles + kTailTiles;
+  const size_t alloc_slots = alloc_tiles * kTileRows;
+  if ((rc = c->d_tiles.ensure(alloc_tiles * kTileBytes))) return rc;
+  if ((rc = c->d_rows_slot.ensure(alloc_tiles * kTileBytes))) return rc;
+  if ((rc = c->d_rconst.ensure(alloc_slots))) return rc;
+  if ((rc = c->d_cinit.ensure(alloc_slots))) return rc;
+  if ((rc = c->d_qnorm.ensure(alloc_slots))) return rc;
+  if ((rc = c->d_perm.ensure(alloc_slots))) return rc;
   MVGX_HIP(hipMemcpyAsync(c->d_tile_off.p, c->h_tile_off.data(), (n_images + 1) * sizeof(uint32_t),
                           hipMemcpyHostToDevice, c->stream));
-  MVGX_HIP(hipMemcpyAsync(c->d_n.p, c->h_n.data(), n_images * sizeof(uint32_t), hipMemcpyHostToDevice,
-                          c->stream));
-  // slack tiles: zero data (their results are never written)
+  MVGX_HIP(hipMemcpyAsync(c->d_ntiles.p, c->h_ntiles.data(), (n_images + 1) * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, c->stream));
+  // every slot starts as a pad slot; slack tiles after the last image are zero data (their results are never used)
+  const int fill_grid = (int)((alloc_slots + 255) / 256);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fill_grid), dim3(256), 0, c->stream, c->d_rconst.p, alloc_slots, kRPad);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fill_grid), dim3(256), 0, c->stream, c->d_cinit.p, alloc_slots, kCPad);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fill_grid), dim3(256), 0, c->stream, c->d_qnorm.p, alloc_slots, 0);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(fill_grid), dim3(256), 0, c->stream, reinterpret_cast<int*>(c->d_perm.p),
+                     alloc_slots, (int)kNoMatch);
+  MVGX_HIP(hipGetLastError());
   MVGX_HIP(hipMemsetAsync(c->d_tiles.p + (size_t)c->total_tiles * kTileBytes, 0, (size_t)kTailTiles * kTileBytes,
                           c->stream));
-  if (c->total_tiles > 0 && max_pad > 0) {
+  if (total_rows > 0 && max_pad > 0) {
+    // 2/3: slots, 3/3: tiles
+    hipLaunchKernelGGL(assign_slots_kernel, dim3(n_images), dim3(1024), 0, c->stream, c->d_row_off.p, c->d_tile_off.p,
+                       c->d_n.p, c->d_rownorm.p, c->d_rowpos.p, c->d_perm.p, c->d_rconst.p, c->d_cinit.p, c->d_qnorm.p);
+    MVGX_HIP(hipGetLastError());
     dim3 grid(max_pad, n_images);
-    hipLaunchKernelGGL(prep_tiles_kernel, grid, dim3(256), 0, c->stream, c->d_rows_view, c->d_row_off.p,
-                       c->d_tile_off.p, c->d_n.p, c->d_tiles.p, c->d_rconst.p, c->d_qnorm.p);
+    hipLaunchKernelGGL(build_tiles_kernel, grid, dim3(256), 0, c->stream, c->d_rows_view, c->d_row_off.p,
+                       c->d_tile_off.p, c->d_perm.p, c->d_tiles.p, c->d_rows_slot.p);
     MVGX_HIP(hipGetLastError());
   }
   MVGX_HIP(hipStreamSynchronize(c->stream));
@@ -591,6 +1060,12 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_top2_ratio_kernel<kStageGldsAsm>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageRegs>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGlds>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   *out = c;
   return MVGX_OK;
 }
@@ -600,6 +1075,8 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_rows.release(); c->d_tiles.release(); c->d_rconst.release(); c->d_qnorm.release();
+  c->d_rows_slot.release(); c->d_cinit.release(); c->d_rownorm.release(); c->d_ntiles.release(); c->d_perm.release(); c->d_rowpos.release();
+  c->d_neven.release(); c->d_err.release(); c->d_cd.release();
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
   c->d_pairs.release(); c->d_work.release(); c->d_ij.release();
   c->d_best.release(); c->d_count.release(); c->d_offsets.release();
@@ -615,8 +1092,11 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
 int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
   MVGX_REQUIRE(c && key, MVGX_ERR_ARG, "mvgx_match_set_option: NULL argument");
   if (!strcmp(key, "variant")) {
-    MVGX_REQUIRE(value >= 0 && value <= 3, MVGX_ERR_ARG, "variant must be 0..3");
+    MVGX_REQUIRE(value >= 0 && value <= 4, MVGX_ERR_ARG, "variant must be 0..4");
     c->variant = (int)value;
+  } else if (!strcmp(key, "stage")) {
+    MVGX_REQUIRE(value >= 1 && value <= 3, MVGX_ERR_ARG, "stage must be 1..3");
+    c->stage = (int)value;
   } else if (!strcmp(key, "profile")) {
     c->profile = value != 0;
   } else if (!strcmp(key, "batch_pairs")) {
@@ -705,7 +1185,7 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
       const uint32_t nI = c->h_n[I], nJ = c->h_n[J];
       // matcher_brute_force.hpp:108-113: NN(=2) > rows  -> no result; Matcher_Regions.cpp:65-69,85-90: empty regions skipped
       if (nI < 2 || nJ == 0) continue;
-      const uint32_t ntJ = (nJ + kTileRows - 1) / kTileRows;
+      const uint32_t ntJ = c->h_ntiles[J];   // occupied tiles of the query image
       for (uint32_t qt = 0; qt < ntJ; qt += kBlockQTiles) c->hp_work.p[n_work++] = make_uint2(k, qt);
       st.n_pairs += 1;
       st.n_desc_pairs += (uint64_t)nI * nJ;
@@ -713,6 +1193,9 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     if ((rc = c->d_pairs.ensure(nb))) return rc;
     if ((rc = c->d_work.ensure(std::max<uint32_t>(n_work, 1)))) return rc;
     if ((rc = c->d_best.ensure((size_t)nb * c->qstride))) return rc;
+    if (c->variant == 4) {
+      if ((rc = c->d_cd.ensure((size_t)nb * c->qstride))) return rc;
+    }
     if ((rc = c->d_count.ensure(nb))) return rc;
     if ((rc = c->d_offsets.ensure((size_t)nb + 1))) return rc;
     if ((rc = c->hp_offsets.ensure((size_t)nb + 1))) return rc;
@@ -722,9 +1205,11 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     MVGX_HIP(hipMemsetAsync(c->d_count.p, 0, nb * sizeof(uint32_t), c->stream));
 
     MatchParams mp;
-    mp.tiles = c->d_tiles.p; mp.rconst = c->d_rconst.p; mp.qnorm = c->d_qnorm.p;
+    mp.tiles = c->d_tiles.p; mp.rows_slot = c->d_rows_slot.p; mp.rconst = c->d_rconst.p; mp.cinit = c->d_cinit.p; mp.qnorm = c->d_qnorm.p;
+    mp.perm = c->d_perm.p; mp.rowpos = c->d_rowpos.p;
     mp.rows_u8 = c->d_rows_view; mp.img_row_off = c->d_row_off.p;
-    mp.img_tile_off = c->d_tile_off.p; mp.img_n = c->d_n.p;
+    mp.img_tile_off = c->d_tile_off.p; mp.img_n = c->d_n.p; mp.img_ntiles = c->d_ntiles.p;
+    mp.cd = c->d_cd.p; mp.img_neven = c->d_neven.p; mp.errflag = c->d_err.p;
     mp.pairs = c->d_pairs.p; mp.work = c->d_work.p; mp.n_work = n_work;
     mp.best = c->d_best.p; mp.count = c->d_count.p; mp.qstride = c->qstride; mp.ratio_sq = ratio_sq;
 
@@ -741,12 +1226,27 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
       } else if (c->variant == 2) {
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
-      } else {
+      } else if (c->variant == 3) {
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+      } else if (c->stage == 1) {
+        hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+      } else if (c->stage == 2) {
+        hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+      } else {
+        hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
       }
       MVGX_HIP(hipGetLastError());
       if (c->profile) MVGX_HIP(hipEventRecord(e1, c->stream));
       st.n_kernel_launches += 1;
+      if (c->variant == 4) {
+        if (c->profile) {
+          const size_t nslots = (size_t)nb * c->qstride;
+          hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, c->stream,
+                             c->d_best.p, nslots, c->d_err.p + 1);
+        }
+        hipLaunchKernelGGL(l2_verify_kernel, dim3(n_work), dim3(256), 0, c->stream, mp);
+        MVGX_HIP(hipGetLastError());
+      }
     }
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_count.p, nb, c->d_offsets.p);
     MVGX_HIP(hipGetLastError());
@@ -760,7 +1260,8 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     if (total) {
       if ((rc = c->d_ij.ensure(total))) return rc;
       hipLaunchKernelGGL(compact_matches_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->d_best.p,
-                         c->d_offsets.p, c->d_pairs.p, c->d_n.p, nb, c->qstride, c->d_ij.p);
+                         c->d_offsets.p, c->d_pairs.p, c->d_n.p, c->d_row_off.p, c->d_rowpos.p, nb, c->qstride,
+                         c->d_ij.p);
       MVGX_HIP(hipGetLastError());
       if (c->keep_host_results) {
         const size_t old = c->res_ij.size();
@@ -776,6 +1277,17 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
   float ms = 0.f;
   MVGX_HIP(hipEventElapsedTime(&ms, c->ev_total0, c->ev_total1));
   st.total_ms = ms;
+  if (c->variant == 4) {   // the verify kernel cross-checks the filter's d0 against its own exact recomputation
+    uint32_t flags[2] = {0, 0};
+    MVGX_HIP(hipMemcpy(flags, c->d_err.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipMemset(c->d_err.p, 0, 2 * sizeof(uint32_t));
+    const uint32_t nerr = flags[0];
+    st.kernel_vgprs = flags[1];   // (field reused) candidates verified in this run, modulo 2^32
+    if (nerr) {
+      set_error("matching filter/verify disagreement on %u candidates (internal error)", nerr);
+      return MVGX_ERR_NUMERIC;
+    }
+  }
   if (c->profile) {
     for (size_t i = 0; i + 1 < n_ev; i += 2) {
       float k = 0.f;

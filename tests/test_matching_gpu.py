@@ -13,13 +13,19 @@ from tests.test_oracle_matching import _adversarial_set
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 3]  # 0 naive check kernel, 1..3 MFMA kernel with the three window-staging forms
+# 0 naive check kernel; 1..3 exact top-2 MFMA kernel with the three window-staging forms;
+# 41..43 = variant 4 (filter + verify, the default) with staging form 1..3
+VARIANTS = [0, 1, 2, 3, 41, 42, 43]
 
 
 def run_hip(imgs, pairs, ratio, variant, batch_pairs=None):
     ctx = matching.MatchContext(0)
     try:
-        ctx.set_option("variant", variant)
+        if variant >= 40:
+            ctx.set_option("variant", 4)
+            ctx.set_option("stage", variant - 40)
+        else:
+            ctx.set_option("variant", variant)
         if batch_pairs:
             ctx.set_option("batch_pairs", batch_pairs)
         ctx.set_regions(imgs)
@@ -77,7 +83,7 @@ def test_ragged_sizes_full_range_bytes(variant):
     assert np.array_equal(ij, o_ij)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 41, 43])
 def test_extreme_values_do_not_overflow_packed_keys(variant):
     """All-0 vs all-255 rows give d = 8 323 200 (the maximum); mixed extremes exercise every key range."""
     rng = np.random.default_rng(7)
@@ -92,7 +98,7 @@ def test_extreme_values_do_not_overflow_packed_keys(variant):
     assert np.array_equal(offsets, o_off) and np.array_equal(ij, o_ij)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 41, 43])
 def test_rootsift_like_2000_desc_sampled_vs_oracle_and_batching(variant):
     """Full-size images (2000 x 128): every pair of 12 images vs the oracle; tiny batches exercise the batch seams."""
     imgs = synth.image_descriptors(12, n_desc=2000, seed=5)
@@ -105,7 +111,7 @@ def test_rootsift_like_2000_desc_sampled_vs_oracle_and_batching(variant):
     assert np.array_equal(ij, o_ij)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 41, 43])
 def test_properties_at_full_size(variant):
     """Size-independent properties at 2000 descriptors/image:
     (1) an image against a row-permuted copy of itself matches every distinct row to its preimage;
@@ -132,6 +138,38 @@ def test_properties_at_full_size(variant):
     # (3) batch seams
     _, off2, ij2 = run_hip(imgs, pairs, 0.8, variant, batch_pairs=2)
     assert np.array_equal(off, off2) and np.array_equal(ij, ij2)
+
+
+def _force_norm_parity(d, parity):
+    """Flip the LSB of byte 0 where needed so that every row's sum (a - 128)^2 has the given parity."""
+    d = d.copy()
+    odd = (((d.astype(np.int64) - 128) ** 2).sum(axis=1) & 1).astype(bool)
+    d[odd != bool(parity), 0] ^= 1
+    return d
+
+
+@pytest.mark.parametrize("variant", [1, 41, 42, 43])
+def test_norm_parity_skew_and_cell_collisions(variant):
+    """The tile layout partitions rows by the parity of their squared norm: all-even / all-odd / lopsided images double
+    the tile count of one half and leave the other half all pad slots. Near-duplicate rows placed in consecutive
+    original positions fall into the same (P-class, window) cell and exercise the verify stage's runner-up search."""
+    rng = np.random.default_rng(99)
+    base = synth.image_descriptors(4, n_desc=700, seed=31)
+    even = _force_norm_parity(base[0], 0)
+    odd = _force_norm_parity(base[1], 1)
+    lop = base[2].copy(); lop[:600] = _force_norm_parity(lop[:600], 0)
+    near = base[3].copy()
+    for k in range(0, 600, 2):                      # row k+1 = row k with a few +-1 / +-2 nudges: d(k, k+1) small
+        near[k + 1] = near[k]
+        idx = rng.integers(0, 128, 3)
+        near[k + 1, idx] = np.clip(near[k + 1, idx].astype(np.int64) + rng.integers(-2, 3, 3), 0, 255)
+    tiny = [base[0][:2], base[1][:3], base[2][:17], base[3][:33]]
+    imgs = [even, odd, lop, near, base[0]] + tiny
+    pairs = np.array([(i, j) for i in range(len(imgs)) for j in range(len(imgs)) if i != j], np.uint32)
+    for ratio in (0.8, 1.0, 0.95):
+        o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
+        _, offsets, ij = run_hip(imgs, pairs, ratio, variant)
+        assert np.array_equal(offsets, o_off) and np.array_equal(ij, o_ij), ratio
 
 
 def test_oneshot_sink_entry_point_matches_reference_container_semantics():

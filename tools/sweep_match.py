@@ -24,7 +24,11 @@ def main():
     ctxs = {}
     for v in [int(x) for x in a.variants.split(",")]:
         c = matching.MatchContext(0)
-        c.set_option("variant", v)
+        if v >= 40:
+            c.set_option("variant", 4)
+            c.set_option("stage", v - 40)
+        else:
+            c.set_option("variant", v)
         c.set_option("profile", 1)
         c.set_regions(descs)
         c.run(pairs[:1000], 0.64, fetch=False)
@@ -42,7 +46,7 @@ def main():
         rows.append({"variant": v, "kernel_dpps_median": float(np.median(r[:, 0])), "kernel_dpps_best": float(r[:, 0].max()),
                      "e2e_dpps_median": float(np.median(r[:, 1])), "kernel_ms_median": float(np.median(r[:, 2])),
                      "e2e_ms_median": float(np.median(r[:, 3])),
-                     "mfma_frac_of_5PF": float(np.median(r[:, 0]) * 256 / 5e15)})
+                     "mfma_frac_of_5PF": float(np.median(r[:, 0]) * 256 / 5e15), "candidates_last_run": int(st.kernel_vgprs), "queries_last_run": int(st.n_pairs) * a.desc})
         print(json.dumps(rows[-1]), flush=True)
     if a.out:
         with open(a.out, "w") as f:
