@@ -43,9 +43,11 @@ def _parse_report(txt):
     return out
 
 
-def ba_config(world):
+def ba_config(world, name=None):
     """BASELINE.json configs[2] at 1 GPU (200 pinhole cams / 100k points / 1M obs) growing to configs[4] at 8 GPUs
-    (1k cams pinhole+K3 in 8 intrinsic groups / 500k points / 5M obs); linear in between."""
+    (1k cams pinhole+K3 in 8 intrinsic groups / 500k points / 5M obs); linear in between. name="c5": configs[4] as is."""
+    if name == "c5":
+        return dict(n_cams=1000, n_points=500000, track_len=10, model=3, n_intr_groups=8, seed=0xBA5E0005)
     if world <= 1:
         return dict(n_cams=200, n_points=100000, track_len=10, model=1, n_intr_groups=1, seed=0xBA5E0003)
     f = min(1.0, (world - 1) / 7.0)
@@ -53,11 +55,11 @@ def ba_config(world):
                 n_intr_groups=8, seed=0xBA5E0005)
 
 
-def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
+def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0, name=None):
     """One BA solve per rank on its point shard; returns the record on every rank (identical numbers: the LM state is
     replicated). world > 1 needs torch.distributed initialised (used only to hand out the RCCL unique id)."""
     from openmvg_amd import ba, sharding, synth
-    cfg = ba_config(world)
+    cfg = ba_config(world, name)
     full = synth.ba_scene(**cfg)
     rank = 0
     uid = None
@@ -77,7 +79,9 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
             c.comm_init(world, rank, uid)
         return c
 
+    t0 = time.perf_counter()
     ctx = make()
+    create_s = time.perf_counter() - t0
     s1 = ctx.lm_iteration(ba.default_options(max_num_iterations=1))   # iteration zero + one LM iteration
     ctx.close()
     ctx = make()
@@ -95,7 +99,7 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
         "lm_iteration_ms": s.iter_ms_mean,
         "first_call_ms_iteration_zero_plus_one_iteration": s1.total_ms,
         "iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "termination": s.termination,
-        "solve_ms": s.total_ms, "solve_wall_ms": wall * 1e3,
+        "solve_ms": s.total_ms, "solve_wall_ms": wall * 1e3, "create_s_host_structure_plus_upload": create_s,
         "initial_rmse": s.initial_rmse, "final_rmse": s.final_rmse, "final_cost": s.final_cost,
         "roofline": {"bound": "hbm", "achieved": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -124,4 +128,6 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0):
 
 if __name__ == "__main__":
     import json
-    print(json.dumps(ba_bench_record(0, 1)))
+    import sys
+    name = sys.argv[1] if len(sys.argv) > 1 else None
+    print(json.dumps(ba_bench_record(0, 1, cpu=(name is None and "--no-cpu" not in sys.argv), name=name)))

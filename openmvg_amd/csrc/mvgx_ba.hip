@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -48,6 +49,27 @@ constexpr int kJr = 0, kJE = 2, kJFc = 8, kJFi = 20;
 constexpr int kNB = 64;        // Cholesky block size
 constexpr int kIntrChunk = 2048;   // intrinsic-row entries per workgroup
 constexpr int kRedBlock = 256;
+constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave in the Schur-product kernel
+constexpr int kPoseGram = 27;      // per pose: Fc^T Fc upper triangle (21) | Fc^T r (6)
+constexpr int kPiGram = 75;        // per (pose, intrinsic) pair: the 27 above | Fc^T Fi (6 x 8)
+constexpr int kIntrGram = 44;      // per intrinsic: Fi^T Fi upper triangle (36) | Fi^T r (8)
+// legacy-path switches (env MVGX_BA_LEGACY, debugging / A-B measurement only)
+constexpr int kLegacySchur = 1, kLegacyChol = 2;
+
+// One list of Schur products -T_a^T Y_b, sorted by the (row block, column block) of S they add into. Entities are
+// observations (pose blocks, width 6) or (point, intrinsic) slots (intrinsic blocks, width 8).
+struct TripList {
+  uint32_t n_trips = 0, n_chunks = 0, n_blocks = 0;
+  uint2* trips = nullptr;             // (a, b)
+  uint32_t* chunk_lo = nullptr;       // n_chunks: first product
+  uint32_t* chunk_hi = nullptr;       // n_chunks: one past the last
+  uint8_t* chunk_diag = nullptr;      // n_chunks: chunk of a diagonal block (carries the rhs)
+  uint32_t* block_row = nullptr;      // n_blocks: camera block index (pose i -> i, intrinsic k -> n_poses + k)
+  uint32_t* block_col = nullptr;
+  uint32_t* block_chunk0 = nullptr;   // n_blocks + 1
+  int32_t* block_own = nullptr;       // n_blocks: PI lists: index of the (pose, intrinsic) pair whose Fc^T Fi adds in; else unused
+  double* part = nullptr;             // n_chunks x (WA * WB + WA)
+};
 
 // kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
 // point parts are rank-local and summed across ranks.
@@ -95,6 +117,15 @@ struct Dev {
   double* S = nullptr;                // N x LD
   double* ipanel_part = nullptr;      // n_ichunks x 8 x (8 n_intr + 1)
   double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
+  // v2 assembly: per-entity T = V^-1 Y, Gram blocks of the camera columns, sorted product lists
+  double *Tpose = nullptr, *Tint = nullptr;         // n_obs x 18, n_islots x 24
+  int n_pi = 0, n_igchunks = 0;
+  uint32_t *pi_start = nullptr, *pi_obs = nullptr, *pi_pose = nullptr, *pi_intr = nullptr, *pose_pi_start = nullptr;
+  uint32_t *iobs_start = nullptr, *iobs = nullptr;  // observations by intrinsic
+  uint32_t *igchunk_intr = nullptr, *igchunk_lo = nullptr, *igchunk_hi = nullptr, *igchunk_start = nullptr;
+  double *pi_gram = nullptr, *pose_gram = nullptr, *igram_part = nullptr, *igram = nullptr;
+  TripList tpp, tpi, tii;
+  double* linv = nullptr;             // inverses of the Cholesky diagonal blocks: nblk x 64 x 64, row-major
   double* part = nullptr;             // partial sums (reductions)
   double* scalars = nullptr;          // kSCount
   int* fail = nullptr;
@@ -744,6 +775,542 @@ __global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __rest
   }
 }
 
+// ======================================================================================================
+// v2 assembly path (default). The reduced camera system is S = G - sum_p Y_p^T V_p^-1 Y_p with
+//   G   = Fs^T Fs, the Gram blocks of the (scaled) camera columns: depends on the Jacobian only, so it is
+//         accumulated once per Jacobian evaluation (ba_pi_gram / ba_intr_gram) and reused when the LM radius changes;
+//   Y_p = Es^T Fs per point, one 3 x 6 block per observation (pose columns) and one 3 x 8 block per (point, intrinsic)
+//         slot (intrinsic columns); T = V^-1 Y is stored beside it.
+// Every product -T_a^T Y_b lands in the block (camera block of a, camera block of b). The products are listed once
+// at create time, sorted by destination block and cut into chunks; one wave per chunk accumulates its products in
+// registers (no atomics, fixed order), a second kernel sums the chunks of each block and writes it into S.
+// ======================================================================================================
+__device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
+__device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r * (r - 1)) / 2 + (c - r); }
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// one workgroup per (pose, intrinsic) pair: Fc^T Fc (upper, 21), Fc^T r (6), Fc^T Fi (6 x 8), all UNscaled
+__global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
+  __shared__ double sh[4][kPiGram];
+  const uint32_t q = blockIdx.x;
+  const size_t n = d.n_obs;
+  const double* __restrict__ J = d.J;
+  double acc[kPiGram];
+#pragma unroll
+  for (int k = 0; k < kPiGram; ++k) acc[k] = 0.0;
+  for (uint32_t e = d.pi_start[q] + threadIdx.x; e < d.pi_start[q + 1]; e += 256) {
+    const uint32_t o = d.pi_obs[e];
+    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
+    double f0[6], f1[6], h0[8], h1[8];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { f0[c] = J[(kJFc + c) * n + o]; f1[c] = J[(kJFc + 6 + c) * n + o]; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { h0[c] = J[(kJFi + c) * n + o]; h1[c] = J[(kJFi + 8 + c) * n + o]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = r; c < 6; ++c) acc[tri6(r, c)] += f0[r] * f0[c] + f1[r] * f1[c];
+      acc[21 + r] += f0[r] * r0 + f1[r] * r1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[kPoseGram + r * 8 + c] += f0[r] * h0[c] + f1[r] * h1[c];
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kPiGram; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) sh[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kPiGram)
+    d.pi_gram[(size_t)q * kPiGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// per pose: sum its (pose, intrinsic) pairs -> pose_gram (27), column norms and gradient of the pose columns
+__global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
+  const uint32_t i = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= kPoseGram) return;
+  double v = 0;
+  for (uint32_t q = d.pose_pi_start[i]; q < d.pose_pi_start[i + 1]; ++q) v += d.pi_gram[(size_t)q * kPiGram + t];
+  d.pose_gram[(size_t)i * kPoseGram + t] = v;
+  if (t >= 21) d.g_cam[6 * i + (t - 21)] = v;
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+    if (t == tri6(c, c)) d.cn_cam[6 * i + c] = v;
+}
+
+// chunk of the observations of one intrinsic: Fi^T Fi (upper, 36), Fi^T r (8), UNscaled
+__global__ __launch_bounds__(256) void ba_intr_gram_kernel(Dev d) {
+  __shared__ double sh[4][kIntrGram];
+  const uint32_t ch = blockIdx.x;
+  const size_t n = d.n_obs;
+  const double* __restrict__ J = d.J;
+  double acc[kIntrGram];
+#pragma unroll
+  for (int k = 0; k < kIntrGram; ++k) acc[k] = 0.0;
+  for (uint32_t e = d.igchunk_lo[ch] + threadIdx.x; e < d.igchunk_hi[ch]; e += 256) {
+    const uint32_t o = d.iobs[e];
+    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
+    double h0[8], h1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { h0[c] = J[(kJFi + c) * n + o]; h1[c] = J[(kJFi + 8 + c) * n + o]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+      for (int c = r; c < 8; ++c) acc[tri8(r, c)] += h0[r] * h0[c] + h1[r] * h1[c];
+      acc[36 + r] += h0[r] * r0 + h1[r] * r1;
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kIntrGram; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) sh[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kIntrGram)
+    d.igram_part[(size_t)ch * kIntrGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void ba_intr_finish_kernel(Dev d) {
+  const uint32_t k = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= kIntrGram) return;
+  double v = 0;
+  for (uint32_t ch = d.igchunk_start[k]; ch < d.igchunk_start[k + 1]; ++ch) v += d.igram_part[(size_t)ch * kIntrGram + t];
+  d.igram[(size_t)k * kIntrGram + t] = v;
+  const int col0 = 6 * (int)d.n_poses + 8 * (int)k;
+  if (t >= 36) d.g_cam[col0 + (t - 36)] = v;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (t == tri8(c, c)) d.cn_cam[col0 + c] = v;
+}
+
+// per point: V = Es^T Es + D^2, V^-1, gs = Es^T r, e = V^-1 gs
+__global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_radius) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.n_pts) return;
+  const uint32_t o0 = d.pt_start[p], o1 = d.pt_start[p + 1];
+  const size_t n = d.n_obs;
+  const double* __restrict__ J = d.J;
+  const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
+  double V[6] = {d.diag_pt[(size_t)p * 3] * inv_radius, 0, 0, d.diag_pt[(size_t)p * 3 + 1] * inv_radius, 0,
+                 d.diag_pt[(size_t)p * 3 + 2] * inv_radius};
+  double g[3] = {0, 0, 0};
+  for (uint32_t o = o0; o < o1; ++o) {
+    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
+    double e0[3], e1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e0[c] = J[(kJE + c) * n + o] * sp[c]; e1[c] = J[(kJE + 3 + c) * n + o] * sp[c]; }
+    V[0] += e0[0] * e0[0] + e1[0] * e1[0]; V[1] += e0[0] * e0[1] + e1[0] * e1[1]; V[2] += e0[0] * e0[2] + e1[0] * e1[2];
+    V[3] += e0[1] * e0[1] + e1[1] * e1[1]; V[4] += e0[1] * e0[2] + e1[1] * e1[2]; V[5] += e0[2] * e0[2] + e1[2] * e1[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] += e0[c] * r0 + e1[c] * r1;
+  }
+  double Vi[6] = {0, 0, 0, 0, 0, 0};
+  const bool eliminate = sp[0] != 0.0;  // scale 0 <=> structure constant / point unused: no e-block
+  if (eliminate && o1 > o0) {
+    if (!invert_spd3(V, Vi)) { atomicExch(d.fail, 1); }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) d.Vinv[(size_t)p * 6 + c] = Vi[c];
+  const double ep[3] = {Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2], Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2],
+                        Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { d.ep[(size_t)p * 3 + c] = ep[c]; d.gs_pt[(size_t)p * 3 + c] = g[c]; }
+}
+
+__device__ __forceinline__ void apply_vinv(const double* Vi, double y0, double y1, double y2, double& t0, double& t1, double& t2) {
+  t0 = Vi[0] * y0 + Vi[1] * y1 + Vi[2] * y2;
+  t1 = Vi[1] * y0 + Vi[3] * y1 + Vi[4] * y2;
+  t2 = Vi[2] * y0 + Vi[4] * y1 + Vi[5] * y2;
+}
+
+// per observation: Y = Es^T Fc_s (3 x 6) and T = V^-1 Y
+__global__ __launch_bounds__(256) void ba_obs_yt_kernel(Dev d) {
+  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= d.n_obs) return;
+  const size_t n = d.n_obs;
+  const double* __restrict__ J = d.J;
+  const uint32_t p = d.opt[o], ip = d.opose[o];
+  double e0[3], e1[3], Vi[6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double s = d.scale_pt[(size_t)p * 3 + c];
+    e0[c] = J[(kJE + c) * n + o] * s; e1[c] = J[(kJE + 3 + c) * n + o] * s;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
+  double Y[18], T[18];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double sc = d.scale_cam[6 * ip + c];
+    const double f0 = J[(kJFc + c) * n + o] * sc, f1 = J[(kJFc + 6 + c) * n + o] * sc;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) Y[e * 6 + c] = e0[e] * f0 + e1[e] * f1;
+    apply_vinv(Vi, Y[c], Y[6 + c], Y[12 + c], T[c], T[6 + c], T[12 + c]);
+  }
+  double2* __restrict__ yo = reinterpret_cast<double2*>(d.Ypose + (size_t)o * 18);
+  double2* __restrict__ to = reinterpret_cast<double2*>(d.Tpose + (size_t)o * 18);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { yo[k] = make_double2(Y[2 * k], Y[2 * k + 1]); to[k] = make_double2(T[2 * k], T[2 * k + 1]); }
+}
+
+// per (point, intrinsic) slot: Y = sum over the slot's observations of Es^T Fi_s (3 x 8) and T = V^-1 Y
+__global__ __launch_bounds__(256) void ba_slot_yt_kernel(Dev d) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= (uint32_t)d.n_islots) return;
+  const size_t n = d.n_obs;
+  const double* __restrict__ J = d.J;
+  const uint32_t p = d.slot_point[s], ik = d.slot_intr[s];
+  const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
+  double sc[8], Y[24], T[24], Vi[6];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sc[c] = d.scale_cam[6 * d.n_poses + 8 * ik + c];
+#pragma unroll
+  for (int c = 0; c < 24; ++c) Y[c] = 0.0;
+  for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+    if (d.ointr[o] != ik) continue;
+    double e0[3], e1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e0[c] = J[(kJE + c) * n + o] * sp[c]; e1[c] = J[(kJE + 3 + c) * n + o] * sp[c]; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double f0 = J[(kJFi + c) * n + o] * sc[c], f1 = J[(kJFi + 8 + c) * n + o] * sc[c];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) Y[e * 8 + c] += e0[e] * f0 + e1[e] * f1;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) apply_vinv(Vi, Y[c], Y[8 + c], Y[16 + c], T[c], T[8 + c], T[16 + c]);
+  double2* __restrict__ yo = reinterpret_cast<double2*>(d.Yint + (size_t)s * 24);
+  double2* __restrict__ to = reinterpret_cast<double2*>(d.Tint + (size_t)s * 24);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { yo[k] = make_double2(Y[2 * k], Y[2 * k + 1]); to[k] = make_double2(T[2 * k], T[2 * k + 1]); }
+}
+
+// One wave per chunk of products of one destination block: acc += T_a^T Y_b (WA x WB), and for the (a, a) products of a
+// diagonal block rhs += T_a^T gs_p (= Y_a^T e_p). Lanes stride the chunk; the 64 per-lane partial blocks are summed
+// through LDS in a fixed order.
+template <int WA, int WB>
+__global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const double* __restrict__ Ta, const double* __restrict__ Yb,
+                                                               const double* __restrict__ gs_pt, const uint32_t* __restrict__ a_point) {
+  constexpr int NV = WA * WB + WA;
+  __shared__ double red[64][NV + 1];
+  const uint32_t ch = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t lo = L.chunk_lo[ch], hi = L.chunk_hi[ch];
+  const bool diag = L.chunk_diag[ch] != 0;
+  double acc[WA * WB], rhs[WA];
+#pragma unroll
+  for (int k = 0; k < WA * WB; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < WA; ++k) rhs[k] = 0.0;
+  for (uint32_t t = lo + lane; t < hi; t += 64) {
+    const uint2 ab = L.trips[t];
+    double ta[3 * WA], yb[3 * WB];
+    const double2* __restrict__ pa = reinterpret_cast<const double2*>(Ta + (size_t)ab.x * (3 * WA));
+    const double2* __restrict__ pb = reinterpret_cast<const double2*>(Yb + (size_t)ab.y * (3 * WB));
+#pragma unroll
+    for (int k = 0; k < 3 * WA / 2; ++k) { const double2 v = pa[k]; ta[2 * k] = v.x; ta[2 * k + 1] = v.y; }
+#pragma unroll
+    for (int k = 0; k < 3 * WB / 2; ++k) { const double2 v = pb[k]; yb[2 * k] = v.x; yb[2 * k + 1] = v.y; }
+#pragma unroll
+    for (int r = 0; r < WA; ++r)
+#pragma unroll
+      for (int c = 0; c < WB; ++c)
+        acc[r * WB + c] += ta[r] * yb[c] + ta[WA + r] * yb[WB + c] + ta[2 * WA + r] * yb[2 * WB + c];
+    if (diag && ab.x == ab.y) {
+      const uint32_t p = a_point[ab.x];
+      const double g0 = gs_pt[(size_t)p * 3], g1 = gs_pt[(size_t)p * 3 + 1], g2 = gs_pt[(size_t)p * 3 + 2];
+#pragma unroll
+      for (int r = 0; r < WA; ++r) rhs[r] += ta[r] * g0 + ta[WA + r] * g1 + ta[2 * WA + r] * g2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < WA * WB; ++k) red[lane][k] = acc[k];
+#pragma unroll
+  for (int k = 0; k < WA; ++k) red[lane][WA * WB + k] = rhs[k];
+  __syncthreads();
+  for (int idx = lane; idx < NV; idx += 64) {
+    double v = 0;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) v += red[l][idx];
+    L.part[(size_t)ch * NV + idx] = v;
+  }
+}
+
+// KIND 0: pose x pose, 1: pose x intrinsic, 2: intrinsic x intrinsic. Sums the chunks of one destination block, adds the
+// scaled Gram block that belongs there, writes the block (and, for diagonal blocks, the rhs entries) into S.
+template <int WA, int WB, int KIND>
+__global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList L) {
+  constexpr int NV = WA * WB + WA;
+  const uint32_t b = blockIdx.x;
+  const int e = threadIdx.x;
+  if (e >= NV) return;
+  const uint32_t rcb = L.block_row[b], ccb = L.block_col[b];
+  const bool diag = rcb == ccb;
+  if (e >= WA * WB && !diag) return;
+  double sum = 0;
+  for (uint32_t ch = L.block_chunk0[b]; ch < L.block_chunk0[b + 1]; ++ch) sum += L.part[(size_t)ch * NV + e];
+  const uint32_t np = d.n_poses;
+  const int row0 = rcb < np ? 6 * (int)rcb : 6 * (int)np + 8 * (int)(rcb - np);
+  const int col0 = ccb < np ? 6 * (int)ccb : 6 * (int)np + 8 * (int)(ccb - np);
+  if (e < WA * WB) {
+    const int r = e / WB, c = e - r * WB;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    double own = 0;
+    if (KIND == 0) {
+      if (diag) own = d.pose_gram[(size_t)rcb * kPoseGram + tri6(lo, hi)];
+    } else if (KIND == 1) {
+      const int q = L.block_own[b];
+      if (q >= 0) own = d.pi_gram[(size_t)q * kPiGram + kPoseGram + r * 8 + c];
+    } else {
+      if (diag) own = d.igram[(size_t)(rcb - np) * kIntrGram + tri8(lo, hi)];
+    }
+    d.S[(size_t)(row0 + r) * d.LD + (col0 + c)] = own * d.scale_cam[row0 + r] * d.scale_cam[col0 + c] - sum;
+  } else {
+    const int r = e - WA * WB;
+    const double g = KIND == 0 ? d.pose_gram[(size_t)rcb * kPoseGram + 21 + r] : d.igram[(size_t)(rcb - np) * kIntrGram + 36 + r];
+    d.S[(size_t)(row0 + r) * d.LD + d.N] = g * d.scale_cam[row0 + r] - sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// v2 Cholesky: per 64-column block step  (1) chol_diag_inv: factor the diagonal block and invert its factor (one
+// workgroup, 16-wide sub-blocks in LDS), (2) chol_panel_mfma: L21 = A21 L11^-T as a GEMM with the inverse (the rhs row n
+// rides along: forward substitution for free), (3) chol_update_mfma: A22 -= L21 L21^T on 64 x 64 tiles with
+// v_mfma_f64_16x16x4_f64. Back substitution: one launch per block step, z_b = L_bb^-T y_b, then y_c -= L_bc^T z_b for
+// all columns c left of the block.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLS = 65;    // LDS row stride of the 64 x 64 factor / inverse
+constexpr int kTS = 80;    // LDS row stride of a k-major 64-wide MFMA operand tile (rows k, k+1 land 32 banks apart)
+constexpr int kDiagLds = (2 * 64 * kLS + 64 * 17) * (int)sizeof(double);
+
+__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb,
+                                                            double* __restrict__ linvT /* [k][c] = Linv[c][k] */, int* fail) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double (*L)[kLS] = reinterpret_cast<double (*)[kLS]>(lds);
+  double (*Li)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 64 * kLS);
+  double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  for (int q = tid; q < 4096; q += 256) {
+    const int c = q >> 6, r = q & 63;
+    double v = (r == c) ? 1.0 : 0.0;   // identity padding of a partial last block
+    if (r < kb && c < kb) v = (r >= c) ? A[(size_t)(k0 + c) * ld + (k0 + r)] : 0.0;
+    L[r][c] = v;
+    Li[r][c] = 0.0;
+  }
+  __syncthreads();
+  for (int jb = 0; jb < 4; ++jb) {
+    const int j0 = jb * 16;
+    // 16 x 16 diagonal sub-block, thread (ty, tx) owns element (j0 + ty, j0 + tx)
+    for (int j = 0; j < 16; ++j) {
+      const double dj = L[j0 + j][j0 + j];
+      if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform
+      const double sj = sqrt(dj);
+      __syncthreads();
+      if (tx == j && ty >= j) L[j0 + ty][j0 + j] = (ty == j) ? sj : L[j0 + ty][j0 + j] / sj;
+      __syncthreads();
+      if (ty > j && tx > j && tx <= ty) L[j0 + ty][j0 + tx] -= L[j0 + ty][j0 + j] * L[j0 + tx][j0 + j];
+      __syncthreads();
+    }
+    // rows below inside the 64-block: x D^T = a, one row per thread
+    const int nrows = 48 - j0;
+    if (tid < nrows) {
+      const int r = j0 + 16 + tid;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double v = L[r][j0 + c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) v -= x[q] * L[j0 + c][j0 + q];
+        x[c] = v / L[j0 + c][j0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) L[r][j0 + c] = x[c];
+    }
+    __syncthreads();
+    // trailing update inside the 64-block
+    for (int q = tid; q < 4096; q += 256) {
+      const int r = q >> 6, c = q & 63;
+      if (c >= j0 + 16 && r >= c) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += L[r][j0 + k] * L[c][j0 + k];
+        L[r][c] -= v;
+      }
+    }
+    __syncthreads();
+  }
+  // inverse of the factor: 16 x 16 diagonal blocks by forward substitution (one column per thread) ...
+  if (tid < 64) {
+    const int b0 = (tid >> 4) * 16, c = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) v -= L[b0 + r][b0 + q] * x[q];
+      x[r] = v / L[b0 + r][b0 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Li[b0 + r][b0 + c] = x[r];
+  }
+  __syncthreads();
+  // ... then the blocks below the diagonal, by block distance: Linv[I][J] = -Linv[I][I] sum_{K=J}^{I-1} L[I][K] Linv[K][J]
+  for (int dist = 1; dist < 4; ++dist) {
+    for (int I = dist; I < 4; ++I) {
+      const int Jb = I - dist;
+      double v = 0;
+      for (int K = Jb; K < I; ++K)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += L[16 * I + ty][16 * K + q] * Li[16 * K + q][16 * Jb + tx];
+      Tmp[16 * I + ty][tx] = v;
+    }
+    __syncthreads();
+    for (int I = dist; I < 4; ++I) {
+      const int Jb = I - dist;
+      double v = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += Li[16 * I + ty][16 * I + q] * Tmp[16 * I + q][tx];
+      Li[16 * I + ty][16 * Jb + tx] = -v;
+    }
+    __syncthreads();
+  }
+  for (int q = tid; q < 4096; q += 256) {
+    const int c = q >> 6, r = q & 63;
+    if (r < kb && c < kb && r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
+    linvT[q] = Li[r][c];   // q = c * 64 + r  ->  linvT[k = c][col = r] = Linv[r][c]
+  }
+}
+
+using d4_t = __attribute__((ext_vector_type(4))) double;
+
+// 32 x 32 sub-tile of D[c][r] = sum_k Q[k][c] P[k][r] on one wave: 2 x 2 MFMA blocks, MFMA row index = c, column = r.
+// Lane l feeds A[i = l & 15][k = l >> 4] = Q[k][cbase + i] and B[k = l >> 4][j = l & 15] = P[k][rbase + j]; it receives
+// D[i = (l >> 4) + 4 reg][j = l & 15].
+__device__ __forceinline__ void mfma_tile_32x32(const double (*P)[kTS], const double (*Q)[kTS], int kc, int rbase, int cbase,
+                                                d4_t acc[2][2]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  for (int k = 0; k < kc; k += 4) {
+    const double q0 = Q[k + lk][cbase + li], q1 = Q[k + lk][cbase + 16 + li];
+    const double p0 = P[k + lk][rbase + li], p1 = P[k + lk][rbase + 16 + li];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, p1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, p1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// rows k0 + kb .. n (row n = rhs) of block column k0: X = A21 Linv^T, 64 rows per workgroup
+__global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb,
+                                                              const double* __restrict__ linvT) {
+  __shared__ double P[32][kTS];
+  __shared__ double Q[32][kTS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row0 = k0 + kb + (int)blockIdx.x * 64;
+  const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+  for (int kc0 = 0; kc0 < kb; kc0 += 32) {
+    if (kc0) __syncthreads();
+    for (int q = tid; q < 32 * 64; q += 256) {
+      const int k = q >> 6, r = q & 63, kk = kc0 + k;
+      P[k][r] = (kk < kb && row0 + r <= n) ? A[(size_t)(k0 + kk) * ld + (row0 + r)] : 0.0;
+      Q[k][r] = linvT[kk * 64 + r];   // zero beyond the factor's triangle, identity padding beyond kb
+    }
+    __syncthreads();
+    mfma_tile_32x32(P, Q, 32, rbase, cbase, acc);
+  }
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = cbase + 16 * ci + (lane >> 4) + 4 * reg, r = row0 + rbase + 16 * ri + (lane & 15);
+        if (c < kb && r <= n) A[(size_t)(k0 + c) * ld + r] = acc[ci][ri][reg];
+      }
+}
+
+// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive)
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
+  __shared__ double P[32][kTS];   // rows of tile I, k-major
+  __shared__ double Q[32][kTS];   // rows of tile J (= columns of the destination tile)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r0 = k0 + kb;
+  int t = blockIdx.x, ti = 0;
+  while (t > ti) { t -= ti + 1; ++ti; }
+  const int tj = t;
+  const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
+  const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+  for (int kc0 = 0; kc0 < kb; kc0 += 32) {
+    if (kc0) __syncthreads();
+    for (int q = tid; q < 32 * 64; q += 256) {
+      const int k = q >> 6, r = q & 63, kk = kc0 + k;
+      P[k][r] = (kk < kb && i0 + r <= n) ? A[(size_t)(k0 + kk) * ld + (i0 + r)] : 0.0;
+      Q[k][r] = (kk < kb && j0 + r < n) ? A[(size_t)(k0 + kk) * ld + (j0 + r)] : 0.0;
+    }
+    __syncthreads();
+    mfma_tile_32x32(P, Q, 32, rbase, cbase, acc);
+  }
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = j0 + cbase + 16 * ci + (lane >> 4) + 4 * reg, r = i0 + rbase + 16 * ri + (lane & 15);
+        if (r <= n && c < n && r >= c) A[(size_t)c * ld + r] -= acc[ci][ri][reg];
+      }
+}
+
+// back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
+// y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 64 columns c < b0 (one wave per 16 columns).
+__global__ __launch_bounds__(256) void chol_backsolve_step_kernel(double* __restrict__ A, int n, int ld, int b0, int kb,
+                                                                  const double* __restrict__ linvT, double* __restrict__ z) {
+  __shared__ double yb[64];
+  __shared__ double zp[4][64];
+  __shared__ double zb[64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 64) yb[tid] = (tid < kb) ? A[(size_t)(b0 + tid) * ld + n] : 0.0;
+  __syncthreads();
+  {  // z[c] = sum_r Linv[r][c] y[r] = sum_r linvT[c][r] y[r]; wave w takes r = w, w + 4, ...
+    double v = 0;
+    for (int r = wave; r < 64; r += 4) v += linvT[lane * 64 + r] * yb[r];
+    zp[wave][lane] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double v = (zp[0][tid] + zp[1][tid]) + (zp[2][tid] + zp[3][tid]);
+    zb[tid] = v;
+    if (blockIdx.x == 0 && tid < kb) z[b0 + tid] = v;
+  }
+  __syncthreads();
+  const int cbase = (int)blockIdx.x * 64 + wave * 16;
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cbase + cc;
+    if (c >= b0) break;   // wave-uniform
+    double v = (lane < kb) ? A[(size_t)c * ld + (b0 + lane)] * zb[lane] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) A[(size_t)c * ld + n] -= v;
+  }
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t n) {
   MVGX_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
@@ -755,6 +1322,53 @@ int dev_upload(T** p, const std::vector<T>& v, hipStream_t s) {
   if (rc) return rc;
   if (!v.empty()) MVGX_HIP(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return MVGX_OK;
+}
+
+
+// ---- host side of the v2 assembly: product lists sorted by destination block ----
+struct TripHost {
+  std::vector<uint2> trips;
+  std::vector<uint32_t> chunk_lo, chunk_hi, block_row, block_col, block_chunk0;
+  std::vector<uint8_t> chunk_diag;
+  std::vector<int32_t> block_own;
+};
+
+// rows/cols: camera block of a / of b for every product; stable two-level counting sort by (row, col), then blocks and
+// chunks of at most kTripChunk products. O(n) time, no comparison sort over the products.
+void build_trip_list(size_t n_cb, const std::vector<uint32_t>& row, const std::vector<uint32_t>& col, const std::vector<uint2>& ab,
+                     TripHost& out) {
+  const size_t n = ab.size();
+  std::vector<uint64_t> rstart(n_cb + 1, 0);
+  for (size_t t = 0; t < n; ++t) rstart[row[t] + 1]++;
+  for (size_t r = 0; r < n_cb; ++r) rstart[r + 1] += rstart[r];
+  std::vector<uint32_t> order(n);
+  { std::vector<uint64_t> fill(rstart.begin(), rstart.end() - 1);
+    for (size_t t = 0; t < n; ++t) order[fill[row[t]]++] = (uint32_t)t; }
+  out.trips.resize(n);
+  std::vector<uint32_t> cnt(n_cb, 0), touched;
+  std::vector<uint64_t> off(n_cb, 0);
+  out.block_chunk0.push_back(0);
+  for (size_t r = 0; r < n_cb; ++r) {
+    const uint64_t lo = rstart[r], hi = rstart[r + 1];
+    if (lo == hi) continue;
+    touched.clear();
+    for (uint64_t q = lo; q < hi; ++q) { const uint32_t cb = col[order[q]]; if (cnt[cb]++ == 0) touched.push_back(cb); }
+    std::sort(touched.begin(), touched.end());
+    uint64_t pos = lo;
+    for (uint32_t cb : touched) {
+      off[cb] = pos;
+      out.block_row.push_back((uint32_t)r); out.block_col.push_back(cb); out.block_own.push_back(-1);
+      for (uint64_t a = pos; a < pos + cnt[cb]; a += kTripChunk) {
+        out.chunk_lo.push_back((uint32_t)a);
+        out.chunk_hi.push_back((uint32_t)std::min<uint64_t>(a + kTripChunk, pos + cnt[cb]));
+        out.chunk_diag.push_back(cb == (uint32_t)r ? 1 : 0);
+      }
+      out.block_chunk0.push_back((uint32_t)out.chunk_lo.size());
+      pos += cnt[cb];
+    }
+    for (uint64_t q = lo; q < hi; ++q) { const uint32_t t = order[q]; out.trips[off[col[t]]++] = ab[t]; }
+    for (uint32_t cb : touched) cnt[cb] = 0;
+  }
 }
 
 }  // namespace
@@ -782,6 +1396,8 @@ struct mvgx_ba_ctx {
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
   int max_pose_win = 0;
+  int legacy = 0;                      // kLegacySchur | kLegacyChol (env MVGX_BA_LEGACY)
+  std::vector<void*> extra;            // device allocations of the v2 path (freed in destroy)
 };
 
 namespace {
@@ -823,9 +1439,16 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   int rc = eval<true>(c, d.poses, d.intr, d.pts);
   if (rc) return rc;
   if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
-  if (d.n_poses) hipLaunchKernelGGL(ba_pose_norms_kernel, dim3(d.n_poses), dim3(256), 0, c->stream, d);
-  if (d.n_ichunks) hipLaunchKernelGGL(ba_intr_norms_kernel, dim3(d.n_ichunks), dim3(256), 0, c->stream, d);
-  if (d.n_intr) hipLaunchKernelGGL(ba_intr_norms_reduce_kernel, dim3(d.n_intr), dim3(16), 0, c->stream, d);
+  if (c->legacy & kLegacySchur) {
+    if (d.n_poses) hipLaunchKernelGGL(ba_pose_norms_kernel, dim3(d.n_poses), dim3(256), 0, c->stream, d);
+    if (d.n_ichunks) hipLaunchKernelGGL(ba_intr_norms_kernel, dim3(d.n_ichunks), dim3(256), 0, c->stream, d);
+    if (d.n_intr) hipLaunchKernelGGL(ba_intr_norms_reduce_kernel, dim3(d.n_intr), dim3(16), 0, c->stream, d);
+  } else {   // Gram blocks of the camera columns (their diagonals are the column norms, their r-products the gradient)
+    if (d.n_pi) hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pi), dim3(256), 0, c->stream, d);
+    if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
+    if (d.n_igchunks) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
+    if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(64), 0, c->stream, d);
+  }
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
   if ((rc = all_reduce(c, d.g_cam, d.N))) return rc;
@@ -844,47 +1467,99 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   return MVGX_OK;
 }
 
+// Partial reduced camera system of this rank at the current radius (raw sums: LM diagonal not yet added)
+int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
+  Dev& d = c->d;
+  MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
+  if (c->legacy & kLegacySchur) {
+    if (d.n_pts) hipLaunchKernelGGL(ba_point_eliminate_kernel, dim3((d.n_pts + 127) / 128), dim3(128), 0, c->stream, d, inv_radius);
+    BA_LAUNCH_CHECK();
+    const int maxw = c->max_pose_win;
+    for (int win0 = 0; win0 < d.N && d.n_poses; win0 += maxw) {
+      const int wcols = std::min(maxw, d.N - win0);
+      hipLaunchKernelGGL(ba_schur_pose_rows_kernel, dim3(d.n_poses), dim3(512), (size_t)(6 * wcols + 6) * sizeof(double), c->stream, d,
+                         inv_radius, win0, wcols);
+    }
+    if (d.n_ichunks) {
+      const size_t lds = (size_t)(64 * d.n_intr + 8) * sizeof(double);
+      hipLaunchKernelGGL(ba_schur_intr_rows_kernel, dim3(d.n_ichunks), dim3(256), lds, c->stream, d);
+    }
+    if (d.n_intr) hipLaunchKernelGGL(ba_schur_intr_reduce_kernel, dim3(d.n_intr), dim3(256), 0, c->stream, d);
+    BA_LAUNCH_CHECK();
+    return MVGX_OK;
+  }
+  if (d.n_pts) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
+  if (d.n_obs) hipLaunchKernelGGL(ba_obs_yt_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d);
+  if (d.n_islots) hipLaunchKernelGGL(ba_slot_yt_kernel, dim3((d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
+  BA_LAUNCH_CHECK();
+  MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
+  if (d.tpp.n_chunks)
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(d.tpp.n_chunks), dim3(64), 0, c->stream, d.tpp, d.Tpose, d.Ypose, d.gs_pt, d.opt);
+  if (d.tpi.n_chunks)
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(d.tpi.n_chunks), dim3(64), 0, c->stream, d.tpi, d.Tpose, d.Yint, d.gs_pt, d.opt);
+  if (d.tii.n_chunks)
+    hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(d.tii.n_chunks), dim3(64), 0, c->stream, d.tii, d.Tint, d.Yint, d.gs_pt, d.slot_point);
+  BA_LAUNCH_CHECK();
+  if (d.tpp.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 6, 0>), dim3(d.tpp.n_blocks), dim3(128), 0, c->stream, d, d.tpp);
+  if (d.tpi.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 8, 1>), dim3(d.tpi.n_blocks), dim3(128), 0, c->stream, d, d.tpi);
+  if (d.tii.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<8, 8, 2>), dim3(d.tii.n_blocks), dim3(128), 0, c->stream, d, d.tii);
+  BA_LAUNCH_CHECK();
+  return MVGX_OK;
+}
+
+// Cholesky of the summed system (rhs as extra row -> forward substitution) + back substitution -> zsol
+int factor_and_solve(mvgx_ba_ctx* c) {
+  Dev& d = c->d;
+  if (!d.N) return MVGX_OK;
+  if (c->legacy & kLegacyChol) {
+    for (int k0 = 0; k0 < d.N; k0 += kNB) {
+      const int kb = std::min(kNB, d.N - k0);
+      const int rows_below = d.N + 1 - (k0 + kb);  // includes the rhs row
+      const int gp = std::max(1, (rows_below + kPanelRows - 1) / kPanelRows);
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, d.S, d.LD, k0, kb, d.fail);
+      hipLaunchKernelGGL(chol_panel_kernel, dim3(gp), dim3(kPanelRows), 0, c->stream, d.S, d.N, d.LD, k0, kb);
+      const int rem = d.N + 1 - (k0 + kb);
+      if (rem > 0 && k0 + kb < d.N) {
+        const int nt = (rem + kNB - 1) / kNB;
+        hipLaunchKernelGGL(chol_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
+      }
+    }
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)(d.N + kNB) * sizeof(double), c->stream, d.S, d.N, d.LD,
+                       d.zsol);
+    BA_LAUNCH_CHECK();
+    return MVGX_OK;
+  }
+  for (int k0 = 0; k0 < d.N; k0 += 64) {
+    const int kb = std::min(64, d.N - k0);
+    double* linvT = d.linv + (size_t)(k0 / 64) * 4096;
+    hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linvT, d.fail);
+    const int rows_below = d.N + 1 - (k0 + kb);   // >= 1: the rhs row
+    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, linvT);
+    if (k0 + kb < d.N) {
+      const int nt = (rows_below + 63) / 64;
+      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
+    }
+  }
+  BA_LAUNCH_CHECK();
+  for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
+    const int kb = std::min(64, d.N - b0);
+    hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(std::max(1, b0 / 64)), dim3(256), 0, c->stream, d.S, d.N, d.LD, b0, kb,
+                       d.linv + (size_t)(b0 / 64) * 4096, d.zsol);
+  }
+  BA_LAUNCH_CHECK();
+  return MVGX_OK;
+}
+
 // LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver::SolveImpl. ok=false <=> LINEAR_SOLVER_FAILURE.
 int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   Dev& d = c->d;
   const double inv_radius = 1.0 / c->radius;
-  MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
-  if (d.n_pts) hipLaunchKernelGGL(ba_point_eliminate_kernel, dim3((d.n_pts + 127) / 128), dim3(128), 0, c->stream, d, inv_radius);
-  BA_LAUNCH_CHECK();
-  // S assembly
-  const int maxw = c->max_pose_win;
-  for (int win0 = 0; win0 < d.N && d.n_poses; win0 += maxw) {
-    const int wcols = std::min(maxw, d.N - win0);
-    hipLaunchKernelGGL(ba_schur_pose_rows_kernel, dim3(d.n_poses), dim3(512), (size_t)(6 * wcols + 6) * sizeof(double), c->stream, d,
-                       inv_radius, win0, wcols);
-  }
-  if (d.n_ichunks) {
-    const size_t lds = (size_t)(64 * d.n_intr + 8) * sizeof(double);
-    hipLaunchKernelGGL(ba_schur_intr_rows_kernel, dim3(d.n_ichunks), dim3(256), lds, c->stream, d);
-  }
-  if (d.n_intr) hipLaunchKernelGGL(ba_schur_intr_reduce_kernel, dim3(d.n_intr), dim3(256), 0, c->stream, d);
-  BA_LAUNCH_CHECK();
-  int rc = all_reduce(c, d.S, (uint64_t)d.N * d.LD);   // the one bulk exchange of the iteration (RCCL over xGMI)
+  int rc = assemble_system(c, inv_radius);
   if (rc) return rc;
+  if ((rc = all_reduce(c, d.S, (uint64_t)d.N * d.LD))) return rc;   // the one bulk exchange of the iteration (RCCL over xGMI)
   if (d.N) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
   BA_LAUNCH_CHECK();
-  // Cholesky (rhs as extra row) + back substitution
-  for (int k0 = 0; k0 < d.N; k0 += kNB) {
-    const int kb = std::min(kNB, d.N - k0);
-    const int rows_below = d.N + 1 - (k0 + kb);  // includes the rhs row
-    const int gp = std::max(1, (rows_below + kPanelRows - 1) / kPanelRows);
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, d.S, d.LD, k0, kb, d.fail);
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(gp), dim3(kPanelRows), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-    const int rem = d.N + 1 - (k0 + kb);
-    if (rem > 0 && k0 + kb < d.N) {
-      const int nt = (rem + kNB - 1) / kNB;
-      hipLaunchKernelGGL(chol_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-    }
-  }
-  if (d.N)
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)(d.N + kNB) * sizeof(double), c->stream, d.S, d.N, d.LD,
-                       d.zsol);
-  BA_LAUNCH_CHECK();
+  if ((rc = factor_and_solve(c))) return rc;
   hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);
   if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_obs, 1, 1, d.scalars, kSModel, 0);
@@ -1113,6 +1788,71 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     ichunk_start[k + 1] = (uint32_t)ichunk_intr.size();
   }
   d.n_ichunks = (int)ichunk_intr.size();
+  // ---- v2 assembly structures ----
+  // (pose, intrinsic) pairs: observations sorted by pose, then intrinsic
+  std::vector<uint32_t> pi_obs(prow_obs), pi_start, pi_pose, pi_intr, pose_pi_start(d.n_poses + 1, 0);
+  for (uint32_t i = 0; i < d.n_poses; ++i) {
+    auto b = pi_obs.begin() + prow_start[i], e = pi_obs.begin() + prow_start[i + 1];
+    std::stable_sort(b, e, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
+    for (uint32_t q = prow_start[i]; q < prow_start[i + 1]; ++q)
+      if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) { pi_start.push_back(q); pi_pose.push_back(i); pi_intr.push_back(ointr[pi_obs[q]]); }
+    pose_pi_start[i + 1] = (uint32_t)pi_start.size();
+  }
+  d.n_pi = (int)pi_start.size();
+  pi_start.push_back((uint32_t)no);
+  // observations by intrinsic, cut into chunks
+  std::vector<uint32_t> iobs_start(d.n_intr + 1, 0), iobs(no), igchunk_intr, igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
+  for (uint64_t k = 0; k < no; ++k) iobs_start[ointr[k] + 1]++;
+  for (uint32_t i = 0; i < d.n_intr; ++i) iobs_start[i + 1] += iobs_start[i];
+  { std::vector<uint32_t> fill(iobs_start.begin(), iobs_start.end() - 1);
+    for (uint64_t k = 0; k < no; ++k) iobs[fill[ointr[k]]++] = (uint32_t)k; }
+  for (uint32_t k = 0; k < d.n_intr; ++k) {
+    for (uint32_t lo = iobs_start[k]; lo < iobs_start[k + 1]; lo += kIntrChunk) {
+      igchunk_intr.push_back(k); igchunk_lo.push_back(lo); igchunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, iobs_start[k + 1]));
+    }
+    igchunk_start[k + 1] = (uint32_t)igchunk_intr.size();
+  }
+  d.n_igchunks = (int)igchunk_intr.size();
+  // Schur products by destination block
+  TripHost hpp, hpi, hii;
+  {
+    const size_t n_cb = (size_t)d.n_poses + d.n_intr;
+    std::vector<uint32_t> row, col;
+    std::vector<uint2> ab;
+    size_t npp = 0, npi = 0, nii = 0;
+    for (uint32_t j = 0; j < d.n_pts; ++j) {
+      const size_t L = pt_start[j + 1] - pt_start[j], K = ptk_start[j + 1] - ptk_start[j];
+      npp += L * L; npi += L * K; nii += K * K;
+    }
+    MVGX_REQUIRE(npp < (1ull << 32) && npi < (1ull << 32), MVGX_ERR_ARG, "mvgx_ba_create: too many co-visibility products for one device shard");
+    row.reserve(npp); col.reserve(npp); ab.reserve(npp);
+    for (uint32_t j = 0; j < d.n_pts; ++j)
+      for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
+        for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
+          if (opose[a] <= opose[b]) { row.push_back(opose[a]); col.push_back(opose[b]); ab.push_back(make_uint2(a, b)); }
+    build_trip_list(n_cb, row, col, ab, hpp);
+    row.clear(); col.clear(); ab.clear();
+    for (uint32_t j = 0; j < d.n_pts; ++j)
+      for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
+        for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl) {
+          row.push_back(opose[a]); col.push_back(d.n_poses + slot_intr[sl]); ab.push_back(make_uint2(a, sl));
+        }
+    build_trip_list(n_cb, row, col, ab, hpi);
+    for (size_t b = 0; b < hpi.block_row.size(); ++b) {   // the (pose, intrinsic) pair whose Fc^T Fi belongs to the block
+      const uint32_t i = hpi.block_row[b], k = hpi.block_col[b] - d.n_poses;
+      for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
+        if (pi_intr[q] == k) hpi.block_own[b] = (int32_t)q;
+    }
+    row.clear(); col.clear(); ab.clear();
+    for (uint32_t j = 0; j < d.n_pts; ++j)
+      for (uint32_t sa = ptk_start[j]; sa < ptk_start[j + 1]; ++sa)
+        for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
+          if (slot_intr[sa] <= slot_intr[sb]) {
+            row.push_back(d.n_poses + slot_intr[sa]); col.push_back(d.n_poses + slot_intr[sb]); ab.push_back(make_uint2(sa, sb));
+          }
+    build_trip_list(n_cb, row, col, ab, hii);
+  }
+  if (const char* env = getenv("MVGX_BA_LEGACY")) c->legacy = atoi(env);
   // active / counted camera components
   std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
   for (uint32_t i = 0; i < d.n_poses; ++i) {
@@ -1156,6 +1896,38 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(S, (size_t)d.N * d.LD);
   AL(ipanel_part, (size_t)d.n_ichunks * (64 * d.n_intr + 8));
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
+  AL(Tpose, (size_t)no * 18); AL(Tint, (size_t)d.n_islots * 24);
+  UP(pi_start, pi_start); UP(pi_obs, pi_obs); UP(pi_pose, pi_pose); UP(pi_intr, pi_intr); UP(pose_pi_start, pose_pi_start);
+  UP(iobs_start, iobs_start); UP(iobs, iobs);
+  UP(igchunk_intr, igchunk_intr); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
+  AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
+  AL(igram_part, (size_t)d.n_igchunks * kIntrGram); AL(igram, (size_t)d.n_intr * kIntrGram);
+  AL(linv, (size_t)((d.N + 63) / 64) * 4096);
+  {
+    struct { TripHost* h; TripList* l; int nv; } lists[3] = {{&hpp, &d.tpp, 6 * 6 + 6}, {&hpi, &d.tpi, 6 * 8 + 6}, {&hii, &d.tii, 8 * 8 + 8}};
+    for (auto& e : lists) {
+      TripHost& h = *e.h; TripList& l = *e.l;
+      l.n_trips = (uint32_t)h.trips.size(); l.n_chunks = (uint32_t)h.chunk_lo.size(); l.n_blocks = (uint32_t)h.block_row.size();
+      if ((rc = dev_upload(&l.trips, h.trips, c->stream))) return rc;
+      if ((rc = dev_upload(&l.chunk_lo, h.chunk_lo, c->stream))) return rc;
+      if ((rc = dev_upload(&l.chunk_hi, h.chunk_hi, c->stream))) return rc;
+      if ((rc = dev_upload(&l.chunk_diag, h.chunk_diag, c->stream))) return rc;
+      if ((rc = dev_upload(&l.block_row, h.block_row, c->stream))) return rc;
+      if ((rc = dev_upload(&l.block_col, h.block_col, c->stream))) return rc;
+      if ((rc = dev_upload(&l.block_chunk0, h.block_chunk0, c->stream))) return rc;
+      if ((rc = dev_upload(&l.block_own, h.block_own, c->stream))) return rc;
+      if ((rc = dev_alloc(&l.part, (size_t)l.n_chunks * e.nv))) return rc;
+      for (void* q : {(void*)l.trips, (void*)l.chunk_lo, (void*)l.chunk_hi, (void*)l.chunk_diag, (void*)l.block_row, (void*)l.block_col,
+                      (void*)l.block_chunk0, (void*)l.block_own, (void*)l.part})
+        c->extra.push_back(q);
+    }
+    for (void* q : {(void*)d.Tpose, (void*)d.Tint, (void*)d.pi_start, (void*)d.pi_obs, (void*)d.pi_pose, (void*)d.pi_intr,
+                    (void*)d.pose_pi_start, (void*)d.iobs_start, (void*)d.iobs, (void*)d.igchunk_intr, (void*)d.igchunk_lo,
+                    (void*)d.igchunk_hi, (void*)d.igchunk_start, (void*)d.pi_gram, (void*)d.pose_gram, (void*)d.igram_part,
+                    (void*)d.igram, (void*)d.linv})
+      c->extra.push_back(q);
+  }
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
   AL(part, (size_t)4 * std::max(c->grid_obs, c->grid_vec) + 16);
@@ -1193,6 +1965,7 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
                   d.scale_cam, d.diag_cam, d.cn_pt, d.g_pt, d.scale_pt, d.diag_pt, d.inorm_part, d.Vinv, d.ep, d.gs_pt, d.Ypose,
                   d.Yint, d.FtF, d.Ftr, d.S, d.ipanel_part, d.zsol, d.step_cam, d.step_pt, d.part, d.scalars, d.fail};
   for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (void* q : c->extra) if (q) (void)hipFree(q);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -1,0 +1,94 @@
+// hipemu — TEST INFRASTRUCTURE ONLY. A minimal single-threaded emulation of the HIP execution model (workgroups of
+// fibers, 64-lane waves, LDS, barriers, shuffles, the f64 MFMA) so that the device code of the BA solver
+// (openmvg_amd/csrc/mvgx_ba.hip) can be compiled for the host and exercised by the CPU test-suite, where no GPU
+// exists. It is never part of libmvgx_hip.so and nothing in openmvg_amd/ loads it: the product has no CPU path.
+//
+// Semantics: the workgroups of a launch run one after the other; the threads of a workgroup are ucontext fibers on one
+// OS thread, switched only at __syncthreads() and at wave-collective operations (__shfl*, MFMA), which wait for all
+// live lanes of the wave. "Device memory" is host memory.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct double2 { double x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+namespace hipemu {
+extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void block_barrier();
+double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);
+typedef double d4 __attribute__((ext_vector_type(4)));
+d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int);
+int lane_xor(int lane, int m);
+int lane_down(int lane, int d);
+int lane_abs(int lane, int s);
+}  // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ thread_local   // one workgroup at a time on one OS thread: a per-thread static is the workgroup's LDS
+
+#define __syncthreads() hipemu::block_barrier()
+static inline double __shfl_xor(double v, int m) { return hipemu::shfl_f64(v, hipemu::lane_xor, m); }
+static inline double __shfl_down(double v, int d) { return hipemu::shfl_f64(v, hipemu::lane_down, d); }
+static inline double __shfl(double v, int s) { return hipemu::shfl_f64(v, hipemu::lane_abs, s); }
+#define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
+
+static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
+static inline double atomicAdd(double* p, double v) { const double o = *p; *p += v; return o; }
+using std::max;
+using std::min;
+
+// ---- runtime API subset used by the BA solver ----
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

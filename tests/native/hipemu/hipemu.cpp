@@ -1,0 +1,177 @@
+// hipemu runtime (TEST INFRASTRUCTURE ONLY — see hip/hip_runtime.h): fiber scheduler + wave collectives, and the
+// translation unit that compiles the BA solver's HIP source for the host.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <cstdio>
+#include <vector>
+
+namespace hipemu {
+
+dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+namespace {
+enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
+constexpr size_t kStack = 512 * 1024;
+struct Fiber {
+  ucontext_t ctx;
+  State st = DONE;
+  char* stack = nullptr;
+};
+std::vector<Fiber> g_fibers;
+ucontext_t g_sched;
+int g_cur = -1, g_n = 0;
+const std::function<void()>* g_body = nullptr;
+// wave-collective exchange slots, double-buffered: a lane may run ahead to its next collective (other buffer) while
+// slower lanes still read this one; the buffer is reused only after another wave-wide rendezvous
+double g_slot[2][1024];
+double g_slot_b[2][1024];
+unsigned char g_parity[1024];
+
+void trampoline() {
+  (*g_body)();
+  g_fibers[g_cur].st = DONE;
+  swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+void yield(State s) {
+  g_fibers[g_cur].st = s;
+  swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+void run_block(unsigned nthreads) {
+  if (g_fibers.size() < nthreads) {
+    const size_t old = g_fibers.size();
+    g_fibers.resize(nthreads);
+    for (size_t i = old; i < nthreads; ++i) g_fibers[i].stack = static_cast<char*>(malloc(kStack));
+  }
+  g_n = (int)nthreads;
+  for (int i = 0; i < g_n; ++i) {
+    Fiber& f = g_fibers[i];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &g_sched;
+    makecontext(&f.ctx, trampoline, 0);
+    f.st = RUNNABLE;
+    g_parity[i] = 0;
+  }
+  for (;;) {
+    bool progressed = false;
+    for (int i = 0; i < g_n; ++i) {
+      if (g_fibers[i].st != RUNNABLE) continue;
+      g_cur = i;
+      g_threadIdx = dim3((unsigned)i, 0, 0);
+      swapcontext(&g_sched, &g_fibers[i].ctx);
+      progressed = true;
+    }
+    // release waves whose live lanes all wait at a wave collective
+    bool all_done = true, all_block = true;
+    for (int w0 = 0; w0 < g_n; w0 += 64) {
+      bool any = false, ok = true;
+      for (int i = w0; i < std::min(g_n, w0 + 64); ++i) {
+        if (g_fibers[i].st == DONE) continue;
+        any = true;
+        if (g_fibers[i].st != WAIT_WAVE) ok = false;
+      }
+      if (any && ok) {
+        for (int i = w0; i < std::min(g_n, w0 + 64); ++i)
+          if (g_fibers[i].st == WAIT_WAVE) g_fibers[i].st = RUNNABLE;
+        progressed = true;
+      }
+    }
+    for (int i = 0; i < g_n; ++i) {
+      if (g_fibers[i].st != DONE) all_done = false;
+      if (g_fibers[i].st != DONE && g_fibers[i].st != WAIT_BLOCK) all_block = false;
+    }
+    if (all_done) break;
+    if (all_block) {
+      for (int i = 0; i < g_n; ++i)
+        if (g_fibers[i].st == WAIT_BLOCK) g_fibers[i].st = RUNNABLE;
+      progressed = true;
+    }
+    if (!progressed) {
+      fprintf(stderr, "hipemu: deadlock (divergent barrier / wave collective) in block %u\n", g_blockIdx.x);
+      abort();
+    }
+  }
+}
+}  // namespace
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  g_body = &body;
+  g_gridDim = grid;
+  g_blockDim = block;
+  for (unsigned b = 0; b < grid.x; ++b) {
+    g_blockIdx = dim3(b, 0, 0);
+    run_block(block.x);
+  }
+  g_body = nullptr;
+}
+
+void block_barrier() {
+  const int me = g_cur;
+  yield(WAIT_BLOCK);
+  g_cur = me;
+  g_threadIdx = dim3((unsigned)me, 0, 0);
+}
+
+static void wave_sync() {
+  const int me = g_cur;
+  yield(WAIT_WAVE);
+  g_cur = me;
+  g_threadIdx = dim3((unsigned)me, 0, 0);
+}
+
+int lane_xor(int lane, int m) { return lane ^ m; }
+int lane_down(int lane, int d) { return lane + d; }
+int lane_abs(int, int s) { return s; }
+
+double shfl_f64(double v, int src_lane_of(int, int), int arg) {
+  const int me = g_cur, w0 = me & ~63, lane = me & 63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  g_slot[par][me] = v;
+  wave_sync();
+  const int src = src_lane_of(lane, arg);
+  double r = v;
+  if (src >= 0 && src < 64 && w0 + src < g_n) r = g_slot[par][w0 + src];
+  return r;
+}
+
+// v_mfma_f64_16x16x4_f64: lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; receives
+// D[i = (l >> 4) + 4 reg][j = l & 15], reg = 0..3   (cdna_hip_programming.md, "f64 MFMA does NOT use these maps")
+d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int) {
+  const int me = g_cur, w0 = me & ~63, lane = me & 63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  g_slot[par][me] = a;
+  g_slot_b[par][me] = b;
+  wave_sync();
+  d4 out = c;
+  const int j = lane & 15;
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = (lane >> 4) + 4 * reg;
+    double s = 0;
+    for (int k = 0; k < 4; ++k) s += g_slot[par][w0 + k * 16 + i] * g_slot_b[par][w0 + k * 16 + j];
+    out[reg] += s;
+  }
+  return out;
+}
+
+}  // namespace hipemu
+
+// ---- the product's device + host code, compiled for the host against the shim ----
+namespace {   // the kernels' `extern __shared__` arrays (same unnamed namespace as the kernels below)
+thread_local __attribute__((aligned(16))) double panel[32768];
+thread_local __attribute__((aligned(16))) double zs[32768];
+thread_local __attribute__((aligned(16))) double lds[32768];
+}  // namespace
+#include "mvgx_common.hip"
+namespace mvgx {   // no RCCL in the emulation: the callback transport of mvgx_ba_set_allreduce covers multi-rank tests
+struct RcclComm {};
+int rccl_unique_id(void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPPORTED; }
+int rccl_init(RcclComm**, int, int, const void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPPORTED; }
+void rccl_destroy(RcclComm*) {}
+int rccl_allreduce_f64(RcclComm*, double*, uint64_t, int, hipStream_t) { return MVGX_ERR_UNSUPPORTED; }
+}  // namespace mvgx
+extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out); }
+#include "mvgx_ba.hip"
