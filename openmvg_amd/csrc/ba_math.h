@@ -18,10 +18,14 @@
 namespace mvgx_ba {
 
 constexpr int kMaxIntr = 8;
-constexpr int kCamPinhole = 1, kCamRadial1 = 2, kCamRadial3 = 3;
+// numeric values of cameras::EINTRINSIC (cameras/Camera_Common.hpp:39-50)
+constexpr int kCamPinhole = 1, kCamRadial1 = 2, kCamRadial3 = 3, kCamBrown = 4, kCamFisheye = 5, kCamSpherical = 7;
 
+// size of the intrinsic parameter block (IntrinsicBase::getParams): -1 = no functor for the model
+// (sfm_data_BA_ceres.cpp:84-108). The spherical camera has no parameter block; its intrinsics row carries {w, h} as data.
 MVGX_HD int intr_param_count(int model) {
-  return model == kCamPinhole ? 3 : model == kCamRadial1 ? 4 : model == kCamRadial3 ? 6 : -1;
+  return model == kCamPinhole ? 3 : model == kCamRadial1 ? 4 : model == kCamRadial3 ? 6 : model == kCamBrown ? 8 :
+         model == kCamFisheye ? 7 : model == kCamSpherical ? 0 : -1;
 }
 
 // p = R(aa) X + t. When kJac: R = dp/dX (row-major 3x3) and A = dp/d(aa) (row-major 3x3).
@@ -82,37 +86,98 @@ MVGX_HD void transform_point(const double* pose, const double* X, double p[3], d
 
 // Residual r = project(intr, pose, X) - obs and, when kJac, the row-major Jacobians
 //   Ji (2 x 8, columns beyond the model's parameter count are 0), Jc (2 x 6: angle-axis | t), Jp (2 x 3).
+// Functors of sfm_data_BA_ceres_camera_functor.hpp: pinhole :103-194, radial K1 :207-300, radial K3 :313-412,
+// Brown T2 :425-545, fisheye :548-660, spherical :662-760.
 template <bool kJac>
 MVGX_HD void eval_observation(int model, const double* intr, const double* pose, const double* X, const double* obs,
                               double r[2], double* Ji, double* Jc, double* Jp) {
   double p[3], R[9], A[9];
   transform_point<kJac>(pose, X, p, R, A);
-  const double iz = 1.0 / p[2];
-  const double u = p[0] * iz, v = p[1] * iz;
-  const double f = intr[0];
-  double coeff = 1.0, dc = 0.0, r2 = 0.0, r4 = 0.0, r6 = 0.0;
-  if (model != kCamPinhole) {
-    r2 = u * u + v * v;
-    if (model == kCamRadial1) {
-      coeff = 1.0 + intr[3] * r2;
-      dc = intr[3];
-    } else {
-      r4 = r2 * r2;
-      r6 = r4 * r2;
-      coeff = 1.0 + intr[3] * r2 + intr[4] * r4 + intr[5] * r6;
-      dc = intr[3] + 2.0 * intr[4] * r2 + 3.0 * intr[5] * r4;
+  double g00, g01, g02, g10, g11, g12;   // G = d r / d p (2 x 3)
+  if (kJac)
+    for (int c = 0; c < 16; ++c) Ji[c] = 0.0;
+  if (model == kCamSpherical) {
+    // lon = atan2(x, z), lat = atan2(-y, |(x, z)|); r = (lon, -lat) size / 2pi + (w, h) / 2 - obs, size = max(w, h)
+    const double w = intr[0], h = intr[1];
+    const double size = w > h ? w : h;
+    const double k = size / (2.0 * 3.14159265358979323846);
+    const double rho2 = p[0] * p[0] + p[2] * p[2];
+    const double rho = sqrt(rho2);
+    const double lon = atan2(p[0], p[2]);
+    const double lat = atan2(-p[1], rho);
+    r[0] = lon * k + w / 2.0 - obs[0];
+    r[1] = -lat * k + h / 2.0 - obs[1];
+    if (kJac) {
+      const double n2 = p[1] * p[1] + rho2;
+      g00 = k * p[2] / rho2; g01 = 0.0; g02 = -k * p[0] / rho2;
+      // d lat / d p = (y x / (rho n2), -rho / n2, y z / (rho n2));  r1 = -k lat
+      g10 = -k * (p[1] * p[0] / (rho * n2)); g11 = k * rho / n2; g12 = -k * (p[1] * p[2] / (rho * n2));
+    }
+  } else {
+    const double iz = 1.0 / p[2];
+    const double u = p[0] * iz, v = p[1] * iz;
+    const double f = intr[0];
+    const double r2 = u * u + v * v;
+    double xd = u, yd = v;                       // distorted normalised coordinates
+    double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;   // d (xd, yd) / d (u, v)
+    if (model == kCamRadial1 || model == kCamRadial3 || model == kCamBrown) {
+      const double k1 = intr[3], k2 = model == kCamRadial1 ? 0.0 : intr[4], k3 = model == kCamRadial1 ? 0.0 : intr[5];
+      const double r4 = r2 * r2, r6 = r4 * r2;
+      const double coeff = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+      const double dc = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+      xd = u * coeff; yd = v * coeff;
+      if (kJac) {
+        m00 = coeff + 2.0 * u * u * dc; m01 = 2.0 * u * v * dc; m10 = m01; m11 = coeff + 2.0 * v * v * dc;
+        Ji[3] = f * u * r2; Ji[8 + 3] = f * v * r2;
+        if (model != kCamRadial1) {
+          Ji[4] = f * u * r4; Ji[8 + 4] = f * v * r4;
+          Ji[5] = f * u * r6; Ji[8 + 5] = f * v * r6;
+        }
+      }
+      if (model == kCamBrown) {
+        const double t1 = intr[6], t2 = intr[7];
+        xd += t2 * (r2 + 2.0 * u * u) + 2.0 * t1 * u * v;
+        yd += t1 * (r2 + 2.0 * v * v) + 2.0 * t2 * u * v;
+        if (kJac) {
+          m00 += 6.0 * t2 * u + 2.0 * t1 * v; m01 += 2.0 * t2 * v + 2.0 * t1 * u;
+          m10 += 2.0 * t1 * u + 2.0 * t2 * v; m11 += 6.0 * t1 * v + 2.0 * t2 * u;
+          Ji[6] = f * 2.0 * u * v;            Ji[8 + 6] = f * (r2 + 2.0 * v * v);
+          Ji[7] = f * (r2 + 2.0 * u * u);     Ji[8 + 7] = f * 2.0 * u * v;
+        }
+      }
+    } else if (model == kCamFisheye) {
+      const double rr = sqrt(r2);
+      if (rr > 1e-8) {   // else cdist = 1 (a constant in the reference's functor: zero derivative)
+        const double th = atan(rr);
+        const double th2 = th * th, th3 = th2 * th, th5 = th3 * th2, th7 = th5 * th2, th9 = th7 * th2;
+        const double thd = th + intr[3] * th3 + intr[4] * th5 + intr[5] * th7 + intr[6] * th9;
+        const double ir = 1.0 / rr;
+        const double cdist = thd * ir;
+        xd = u * cdist; yd = v * cdist;
+        if (kJac) {
+          const double dthd = 1.0 + 3.0 * intr[3] * th2 + 5.0 * intr[4] * th2 * th2 + 7.0 * intr[5] * th3 * th3 + 9.0 * intr[6] * th5 * th3;
+          const double dcd = (dthd / (1.0 + r2) - cdist) * ir;      // d cdist / d r
+          const double cu = dcd * u * ir, cv = dcd * v * ir;        // d cdist / d u, d v
+          m00 = cdist + u * cu; m01 = u * cv; m10 = v * cu; m11 = cdist + v * cv;
+          Ji[3] = f * u * th3 * ir; Ji[8 + 3] = f * v * th3 * ir;
+          Ji[4] = f * u * th5 * ir; Ji[8 + 4] = f * v * th5 * ir;
+          Ji[5] = f * u * th7 * ir; Ji[8 + 5] = f * v * th7 * ir;
+          Ji[6] = f * u * th9 * ir; Ji[8 + 6] = f * v * th9 * ir;
+        }
+      }
+    }
+    r[0] = intr[1] + xd * f - obs[0];
+    r[1] = intr[2] + yd * f - obs[1];
+    if (kJac) {
+      Ji[0] = xd; Ji[8] = yd;        // d/d focal
+      Ji[1] = 1.0; Ji[8 + 2] = 1.0;  // d/d ppx, d/d ppy
+      const double j00 = f * m00, j01 = f * m01, j10 = f * m10, j11 = f * m11;
+      // d(u,v)/dp = [[iz, 0, -u iz], [0, iz, -v iz]]
+      g00 = j00 * iz; g01 = j01 * iz; g02 = -(j00 * u + j01 * v) * iz;
+      g10 = j10 * iz; g11 = j11 * iz; g12 = -(j10 * u + j11 * v) * iz;
     }
   }
-  const double xd = u * coeff, yd = v * coeff;
-  r[0] = intr[1] + xd * f - obs[0];
-  r[1] = intr[2] + yd * f - obs[1];
   if (kJac) {
-    // d(res)/d(u,v)
-    const double j00 = f * (coeff + 2.0 * u * u * dc), j01 = f * (2.0 * u * v * dc);
-    const double j10 = j01, j11 = f * (coeff + 2.0 * v * v * dc);
-    // d(u,v)/dp = [[iz, 0, -u iz], [0, iz, -v iz]]
-    const double g00 = j00 * iz, g01 = j01 * iz, g02 = -(j00 * u + j01 * v) * iz;
-    const double g10 = j10 * iz, g11 = j11 * iz, g12 = -(j10 * u + j11 * v) * iz;
     for (int c = 0; c < 3; ++c) {
       Jp[c] = g00 * R[c] + g01 * R[3 + c] + g02 * R[6 + c];
       Jp[3 + c] = g10 * R[c] + g11 * R[3 + c] + g12 * R[6 + c];
@@ -121,23 +186,30 @@ MVGX_HD void eval_observation(int model, const double* intr, const double* pose,
     }
     Jc[3] = g00; Jc[4] = g01; Jc[5] = g02;
     Jc[9] = g10; Jc[10] = g11; Jc[11] = g12;
-    for (int c = 0; c < 16; ++c) Ji[c] = 0.0;
-    Ji[0] = xd; Ji[8] = yd;        // d/d focal
-    Ji[1] = 1.0; Ji[8 + 2] = 1.0;  // d/d ppx, d/d ppy
-    if (model != kCamPinhole) {
-      Ji[3] = f * u * r2; Ji[8 + 3] = f * v * r2;
-      if (model == kCamRadial3) {
-        Ji[4] = f * u * r4; Ji[8 + 4] = f * v * r4;
-        Ji[5] = f * u * r6; Ji[8 + 5] = f * v * r6;
-      }
-    }
   }
 }
 
-// HuberLoss::Evaluate (a <= 0: TrivialLoss). rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s).
-MVGX_HD void huber_rho(double a, double s, double rho[3]) {
+// PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): r = weight o (C(pose) - prior), C = -R(-aa) t.
+// When kJac: Jc (3 x 6, row-major) = [d r / d aa | d r / d t].
+template <bool kJac>
+MVGX_HD void eval_pose_center_prior(const double* pose, const double* center, const double* weight, double r[3], double* Jc) {
+  const double neg[6] = {-pose[0], -pose[1], -pose[2], 0.0, 0.0, 0.0};
+  double p[3], R[9], A[9];
+  transform_point<kJac>(neg, pose + 3, p, R, A);   // p = R(-aa) t, R = dp/dt, A = dp/dw at w = -aa
+  for (int k = 0; k < 3; ++k) r[k] = weight[k] * (-p[k] - center[k]);
+  if (kJac)
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) {
+        Jc[k * 6 + c] = weight[k] * A[k * 3 + c];        // C = -p(w(aa)), dw/daa = -1
+        Jc[k * 6 + 3 + c] = -weight[k] * R[k * 3 + c];
+      }
+}
+
+// HuberLoss::Evaluate. rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s). a = 0 is a legal (degenerate) scale the
+// pose-centre priors can produce, so "no loss function" is a separate switch.
+MVGX_HD void huber_rho_on(bool loss, double a, double s, double rho[3]) {
   const double b = a * a;
-  if (a > 0.0 && s > b) {
+  if (loss && s > b) {
     const double rr = sqrt(s);
     rho[0] = 2.0 * a * rr - b;
     const double r1 = a / rr;
@@ -147,6 +219,8 @@ MVGX_HD void huber_rho(double a, double s, double rho[3]) {
     rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
   }
 }
+// observation residuals: a <= 0 means the problem was built without a loss function (TrivialLoss)
+MVGX_HD void huber_rho(double a, double s, double rho[3]) { huber_rho_on(a > 0.0, a, s, rho); }
 
 // Corrector for rho'' <= 0 (always the case for Huber / trivial loss): residual and Jacobian scale by sqrt(rho').
 MVGX_HD double corrector_scale(const double rho[3]) { return sqrt(rho[1]); }

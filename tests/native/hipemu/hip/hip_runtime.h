@@ -27,7 +27,7 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 namespace hipemu {
-extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void block_barrier();
 double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);

@@ -8,7 +8,7 @@
 
 namespace hipemu {
 
-dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;   // one emulated device per OS thread
 
 namespace {
 enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
@@ -18,15 +18,15 @@ struct Fiber {
   State st = DONE;
   char* stack = nullptr;
 };
-std::vector<Fiber> g_fibers;
-ucontext_t g_sched;
-int g_cur = -1, g_n = 0;
-const std::function<void()>* g_body = nullptr;
+thread_local std::vector<Fiber> g_fibers;
+thread_local ucontext_t g_sched;
+thread_local int g_cur = -1, g_n = 0;
+thread_local const std::function<void()>* g_body = nullptr;
 // wave-collective exchange slots, double-buffered: a lane may run ahead to its next collective (other buffer) while
 // slower lanes still read this one; the buffer is reused only after another wave-wide rendezvous
-double g_slot[2][1024];
-double g_slot_b[2][1024];
-unsigned char g_parity[1024];
+thread_local double g_slot[2][1024];
+thread_local double g_slot_b[2][1024];
+thread_local unsigned char g_parity[1024];
 
 void trampoline() {
   (*g_body)();
