@@ -31,7 +31,7 @@ extern "C" {
 
 const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
-/* abi version, bumped on any signature change */
+/* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -112,6 +112,10 @@ typedef struct mvgx_ba_ctx mvgx_ba_ctx;
 #define MVGX_CAM_PINHOLE 1          /* PINHOLE_CAMERA          params {f, ppx, ppy}              */
 #define MVGX_CAM_PINHOLE_RADIAL1 2  /* PINHOLE_CAMERA_RADIAL1  params {f, ppx, ppy, k1}          */
 #define MVGX_CAM_PINHOLE_RADIAL3 3  /* PINHOLE_CAMERA_RADIAL3  params {f, ppx, ppy, k1, k2, k3}  */
+#define MVGX_CAM_PINHOLE_BROWN 4    /* PINHOLE_CAMERA_BROWN    params {f, ppx, ppy, k1, k2, k3, t1, t2} */
+#define MVGX_CAM_PINHOLE_FISHEYE 5  /* PINHOLE_CAMERA_FISHEYE  params {f, ppx, ppy, k1, k2, k3, k4} */
+#define MVGX_CAM_SPHERICAL 7        /* CAMERA_SPHERICAL: no parameter block (getParams() is empty, sfm_data_BA_ceres.cpp:366-383);
+                                       the intrinsics row carries the image size {w, h} the functor needs           */
 #define MVGX_BA_MAX_INTR_PARAMS 8
 
 typedef struct mvgx_ba_problem {
@@ -133,6 +137,17 @@ typedef struct mvgx_ba_problem {
   const uint8_t* intr_const_mask;   /* n_intrinsics, bits 0..7 (subsetParameterization, Camera_Intrinsics.hpp) */
   uint8_t points_constant;          /* Structure_Parameter_Type::NONE (sfm_data_BA.hpp:38-42)      */
   double huber_a;                   /* HuberLoss(a): sfm_data_BA_ceres.cpp:249 uses Square(4.0)=16; <=0: no loss */
+  /* ---- optional (NULL / 0 = absent): ground control points and pose-centre priors ---- */
+  const double* obs_weight;         /* n_obs: residual weight of WeightedCostFunction (camera_functor.hpp:35-90);
+                                       0 = the unweighted functor (IntrinsicsToCostFunction's weight == 0.0 case)          */
+  const uint8_t* obs_is_control;    /* n_obs: 1 = residual block of a control point: added WITHOUT loss function
+                                       (sfm_data_BA_ceres.cpp:421-435) and not part of the RMSE (not a Landmark)          */
+  const uint8_t* point_const_mask;  /* n_points: 1 = SetParameterBlockConstant on this point (control points, :447)       */
+  uint32_t n_pose_priors;           /* PoseCenterConstraintCostFunction residuals (sfm_data_BA_ceres.cpp:44-80,454-473)   */
+  const uint32_t* prior_pose;       /* n_pose_priors: pose block index                                                    */
+  const double* prior_center;       /* n_pose_priors x 3: ViewPriors::pose_center_                                        */
+  const double* prior_weight;       /* n_pose_priors x 3: ViewPriors::center_weight_                                      */
+  double prior_huber_a;             /* HuberLoss(a) of the priors: Square(pose_center_robust_fitting_error); may be 0     */
 } mvgx_ba_problem;
 
 typedef struct mvgx_ba_options {

@@ -51,6 +51,14 @@ class BaProblem(C.Structure):
         ("intr_const_mask", C.c_void_p),
         ("points_constant", C.c_uint8),
         ("huber_a", C.c_double),
+        ("obs_weight", C.c_void_p),
+        ("obs_is_control", C.c_void_p),
+        ("point_const_mask", C.c_void_p),
+        ("n_pose_priors", C.c_uint32),
+        ("prior_pose", C.c_void_p),
+        ("prior_center", C.c_void_p),
+        ("prior_weight", C.c_void_p),
+        ("prior_huber_a", C.c_double),
     ]
 
 

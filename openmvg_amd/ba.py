@@ -74,6 +74,19 @@ class BaContext:
             self._keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = self._keep["im"].ctypes.data
         p.points_constant = 1 if points_constant else 0
         p.huber_a = float(huber_a)
+        # optional: ground control points (weighted, loss-free residuals on constant points) and pose-centre priors
+        if scene.get("obs_weight") is not None:
+            p.obs_weight = arr("obs_weight", np.float64)
+        if scene.get("obs_is_control") is not None:
+            p.obs_is_control = arr("obs_is_control", np.uint8)
+        if scene.get("point_const_mask") is not None:
+            p.point_const_mask = arr("point_const_mask", np.uint8)
+        if scene.get("prior_pose") is not None and len(scene["prior_pose"]):
+            p.n_pose_priors = len(scene["prior_pose"])
+            p.prior_pose = arr("prior_pose", np.uint32)
+            p.prior_center = arr("prior_center", np.float64)
+            p.prior_weight = arr("prior_weight", np.float64)
+            p.prior_huber_a = float(scene.get("prior_huber_a", 0.0))
         self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
         self._h = C.c_void_p()
         _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))

@@ -251,4 +251,26 @@ MVGX_HD bool invert_spd3(const double v[6], double inv[6]) {
   return true;
 }
 
+// Inverse of the Cholesky factor of a symmetric positive definite 3x3 (v = {a00, a01, a02, a11, a12, a22}):
+// V = L L^T, li = {i00, i10, i11, i20, i21, i22} = the lower-triangular L^-1, so that V^-1 = L^-T L^-1
+// (what invert_psd_matrix.h:49-72 computes through Eigen's LLT). Returns false if not positive definite.
+MVGX_HD bool chol_inv3(const double v[6], double li[6]) {
+  if (!(v[0] > 0.0)) return false;
+  const double l00 = sqrt(v[0]);
+  const double l10 = v[1] / l00, l20 = v[2] / l00;
+  const double d1 = v[3] - l10 * l10;
+  if (!(d1 > 0.0)) return false;
+  const double l11 = sqrt(d1);
+  const double l21 = (v[4] - l20 * l10) / l11;
+  const double d2 = v[5] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0.0)) return false;
+  const double l22 = sqrt(d2);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
+  return true;
+}
+
 }  // namespace mvgx_ba

@@ -1,8 +1,10 @@
 // libmvgx_hip.so — Levenberg-Marquardt bundle adjustment on gfx950 (fp64), no Ceres / no Eigen on the device.
 //
 // Reference path reproduced (paths under /root/reference/src; "ceres/" = third_party/ceres-solver/internal/ceres):
-//   openMVG/sfm/sfm_data_BA_ceres.cpp:242-473      problem: one residual block per observation (intrinsic, pose, point)
-//   openMVG/sfm/sfm_data_BA_ceres_camera_functor.hpp  pinhole / radial K1 / radial K3 reprojection residuals
+//   openMVG/sfm/sfm_data_BA_ceres.cpp:242-473      problem: one residual block per observation (intrinsic, pose, point),
+//                                                   weighted loss-free residuals of ground control points (:398-451),
+//                                                   pose-centre priors (:44-80, :454-473)
+//   openMVG/sfm/sfm_data_BA_ceres_camera_functor.hpp  pinhole / radial K1 / radial K3 / Brown T2 / fisheye / spherical residuals
 //   ceres/residual_block.cc:68-196, corrector.cc     Huber loss correction of residuals and Jacobians
 //   ceres/trust_region_minimizer.cc:66-786           LM loop (Jacobi scaling frozen at iteration 0, step acceptance,
 //                                                     parameter / function / gradient tolerances, invalid steps)
@@ -12,18 +14,24 @@
 //
 // Device data layout (all fp64):
 //   observations sorted by 3-D point (CSR pt_start), so a point's rows are contiguous like Ceres' chunks;
-//   Jacobian kept structure-of-arrays, component-major: J[c * n_obs + o], c = 0..35 =
+//   Jacobian structure-of-arrays, component-major: J[c * n_obs + o], c = 0..35 =
 //     r(2) | E = d r/d point (2x3) | Fc = d r/d pose (2x6) | Fi = d r/d intrinsic (2x8), loss-corrected, UNscaled;
 //   reduced camera system S: n = 6 n_poses + 8 n_intr columns (pose blocks first, then intrinsic blocks), leading
 //     dimension n + 1; memory is simultaneously "row-major upper + rhs in column n" (how the assembly kernels write it)
 //     and "column-major lower + rhs in row n" (how the Cholesky kernels read it). Constant / unused parameter
 //     components keep their slot with Jacobi scale 0, unit diagonal and zero rhs, so they decouple exactly.
 //
-// Kernels: ba_linearize (per observation: residual + closed-form Jacobian + Huber), ba_point_norms / ba_pose_norms /
-// ba_intr_norms (column norms + gradient, segmented by owner — no global atomics), ba_point_eliminate (per point:
-// V = E^T E + D^2, V^-1, E^T F blocks), ba_schur_pose_rows / ba_schur_intr_rows (row-owner assembly of S in LDS panels),
-// chol_panel / chol_update (blocked right-looking Cholesky, the rhs rides along as an extra row), chol_backsolve,
-// ba_backsub, ba_model_cost, ba_candidate. The host loop mirrors TrustRegionMinimizer::Minimize.
+// The reduced system is S = G - Z^T Z with
+//   G = Fs^T Fs, the Gram blocks of the scaled camera columns. They depend on the Jacobian only: accumulated once per
+//       Jacobian evaluation (ba_pi_gram / ba_intr_gram), reused when only the LM radius changes;
+//   Z = L_p^-1 Es^T Fs per point, V_p = Es^T Es + D_p^2 = L_p L_p^T: one 3 x 6 block per observation (pose columns) and
+//       one 3 x 8 block per (point, intrinsic) slot (intrinsic columns). V^-1 never appears: Z^T Z = Y^T V^-1 Y.
+// Every product -Z_a^T Z_b lands in the block (camera block of a, camera block of b). The products are listed once at
+// create time, sorted by destination block and cut into chunks; one wave per chunk accumulates its products in
+// registers (no atomics, fixed order), a second kernel sums the chunks of each block and writes it into S.
+// Cholesky: per 64-column block step chol_diag_inv (factor the diagonal block, invert its factor), chol_panel_mfma
+// (L21 = A21 L11^-T as a GEMM; the rhs row rides along = forward substitution), chol_update_mfma (A22 -= L21 L21^T,
+// v_mfma_f64_16x16x4_f64); back substitution one launch per block step.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -46,17 +54,19 @@ using namespace mvgx_ba;
 
 constexpr int kJC = 36;        // Jacobian components per observation
 constexpr int kJr = 0, kJE = 2, kJFc = 8, kJFi = 20;
-constexpr int kNB = 64;        // Cholesky block size
-constexpr int kIntrChunk = 2048;   // intrinsic-row entries per workgroup
-constexpr int kRedBlock = 256;
-constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave in the Schur-product kernel
+constexpr int kIntrChunk = 2048;   // observations per workgroup of the intrinsic Gram kernel
+constexpr int kPiChunk = 512;      // observations per workgroup of the (pose, intrinsic) Gram kernel
+constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave of the Schur-product kernel
 constexpr int kPoseGram = 27;      // per pose: Fc^T Fc upper triangle (21) | Fc^T r (6)
 constexpr int kPiGram = 75;        // per (pose, intrinsic) pair: the 27 above | Fc^T Fi (6 x 8)
 constexpr int kIntrGram = 44;      // per intrinsic: Fi^T Fi upper triangle (36) | Fi^T r (8)
-// legacy-path switches (env MVGX_BA_LEGACY, debugging / A-B measurement only)
-constexpr int kLegacySchur = 1, kLegacyChol = 2;
+constexpr int kPriorJ = 21;        // per pose-centre prior: corrected r (3) | corrected d r / d pose (3 x 6)
 
-// One list of Schur products -T_a^T Y_b, sorted by the (row block, column block) of S they add into. Entities are
+// kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
+// point parts are rank-local and summed across ranks.
+enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSCount = 12 };
+
+// One list of Schur products -Z_a^T Z_b, sorted by the (row block, column block) of S they add into. Entities are
 // observations (pose blocks, width 6) or (point, intrinsic) slots (intrinsic blocks, width 8).
 struct TripList {
   uint32_t n_trips = 0, n_chunks = 0, n_blocks = 0;
@@ -67,65 +77,51 @@ struct TripList {
   uint32_t* block_row = nullptr;      // n_blocks: camera block index (pose i -> i, intrinsic k -> n_poses + k)
   uint32_t* block_col = nullptr;
   uint32_t* block_chunk0 = nullptr;   // n_blocks + 1
-  int32_t* block_own = nullptr;       // n_blocks: PI lists: index of the (pose, intrinsic) pair whose Fc^T Fi adds in; else unused
+  int32_t* block_own = nullptr;       // pose x intrinsic lists: the (pose, intrinsic) pair whose Fc^T Fi adds in, or -1
   double* part = nullptr;             // n_chunks x (WA * WB + WA)
 };
 
-// kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
-// point parts are rank-local and summed across ranks.
-enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSCount = 12 };
-
 struct Dev {
   // sizes
-  uint32_t n_poses = 0, n_intr = 0, n_pts = 0;
+  uint32_t n_poses = 0, n_intr = 0, n_pts = 0, n_priors = 0;
   uint64_t n_obs = 0;
   int N = 0, LD = 0;             // camera system size and leading dimension
   int n_islots = 0;              // (point, intrinsic) slots
-  int n_ichunks = 0;
-  int points_constant = 0;
-  double huber_a = 0;
+  int n_pi = 0, n_pichunks = 0, n_igchunks = 0;
+  double huber_a = 0, prior_huber_a = 0;
   // parameters
   double *poses = nullptr, *intr = nullptr, *pts = nullptr;      // x_
   double *cposes = nullptr, *cintr = nullptr, *cpts = nullptr;   // candidate_x_
   int* model = nullptr;
   // observations (sorted by point)
-  uint32_t *opose = nullptr, *ointr = nullptr, *opt = nullptr, *oslot = nullptr;  // oslot: intrinsic slot of the obs
+  uint32_t *opose = nullptr, *ointr = nullptr, *opt = nullptr;
   double* oxy = nullptr;
+  double* oweight = nullptr;          // n_obs or null
+  uint8_t* octrl = nullptr;           // n_obs or null
   uint32_t* pt_start = nullptr;       // n_pts + 1
   uint32_t* ptk_start = nullptr;      // n_pts + 1 -> intrinsic slots of a point
   uint32_t* slot_intr = nullptr;      // n_islots
   uint32_t* slot_point = nullptr;     // n_islots
-  uint32_t* prow_start = nullptr;     // n_poses + 1 -> observations of a pose
-  uint32_t* prow_obs = nullptr;       // n_obs
-  uint32_t* irow_start = nullptr;     // n_intr + 1 -> slots of an intrinsic
-  uint32_t* irow_slot = nullptr;      // n_islots
-  uint32_t* ichunk_intr = nullptr;    // n_ichunks: owning intrinsic
-  uint32_t* ichunk_lo = nullptr;      // n_ichunks: first entry (index into irow_slot)
-  uint32_t* ichunk_hi = nullptr;
-  uint32_t* ichunk_start = nullptr;   // n_intr + 1 -> chunks of an intrinsic
   uint8_t* cam_active = nullptr;      // N: free component of a block that has residuals
   uint8_t* cam_counts = nullptr;      // N: component belongs to a block that is in the reduced program (x-norm)
-  uint8_t* pt_used = nullptr;         // n_pts
+  uint8_t* pt_free = nullptr;         // n_pts: point is a free parameter block with residuals
+  // (pose, intrinsic) pairs and intrinsics: observation lists for the Gram kernels
+  uint32_t *pi_obs = nullptr, *pichunk_lo = nullptr, *pichunk_hi = nullptr, *pi_chunk0 = nullptr, *pose_pi_start = nullptr;
+  uint32_t *iobs = nullptr, *igchunk_lo = nullptr, *igchunk_hi = nullptr, *igchunk_start = nullptr;
+  // pose-centre priors
+  uint32_t *prior_pose = nullptr, *pose_prior_start = nullptr, *pose_prior_idx = nullptr;
+  double *prior_center = nullptr, *prior_weight = nullptr, *Jprior = nullptr;
   // Jacobian and derived
   double* J = nullptr;                // kJC x n_obs
   double *cn_cam = nullptr, *g_cam = nullptr, *scale_cam = nullptr, *diag_cam = nullptr;   // N
   double *cn_pt = nullptr, *g_pt = nullptr, *scale_pt = nullptr, *diag_pt = nullptr;       // 3 n_pts
-  double* inorm_part = nullptr;       // n_ichunks x 16
-  double *Vinv = nullptr, *ep = nullptr, *gs_pt = nullptr;   // 6 / 3 / 3 per point (scaled-space gradient E_s^T r)
-  double* Ypose = nullptr;            // n_obs x 18
-  double *Yint = nullptr, *FtF = nullptr, *Ftr = nullptr;   // per islot: 24 / 64 / 8
-  double* S = nullptr;                // N x LD
-  double* ipanel_part = nullptr;      // n_ichunks x 8 x (8 n_intr + 1)
-  double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
-  // v2 assembly: per-entity T = V^-1 Y, Gram blocks of the camera columns, sorted product lists
-  double *Tpose = nullptr, *Tint = nullptr;         // n_obs x 18, n_islots x 24
-  int n_pi = 0, n_igchunks = 0;
-  uint32_t *pi_start = nullptr, *pi_obs = nullptr, *pi_pose = nullptr, *pi_intr = nullptr, *pose_pi_start = nullptr;
-  uint32_t *iobs_start = nullptr, *iobs = nullptr;  // observations by intrinsic
-  uint32_t *igchunk_intr = nullptr, *igchunk_lo = nullptr, *igchunk_hi = nullptr, *igchunk_start = nullptr;
-  double *pi_gram = nullptr, *pose_gram = nullptr, *igram_part = nullptr, *igram = nullptr;
+  double *pichunk_part = nullptr, *pi_gram = nullptr, *pose_gram = nullptr, *igram_part = nullptr, *igram = nullptr;
+  double *Linv3 = nullptr, *hp = nullptr;   // per point: L_p^-1 (6, lower) and h_p = L_p^-1 Es^T r (3)
+  double *Zpose = nullptr, *Zint = nullptr; // n_obs x 18, n_islots x 24
   TripList tpp, tpi, tii;
-  double* linv = nullptr;             // inverses of the Cholesky diagonal blocks: nblk x 64 x 64, row-major
+  double* S = nullptr;                // N x LD
+  double* linv = nullptr;             // per Cholesky block step: L11^-1 k-major (64 x 64), then row-major (64 x 64)
+  double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
   double* part = nullptr;             // partial sums (reductions)
   double* scalars = nullptr;          // kSCount
   int* fail = nullptr;
@@ -156,6 +152,10 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) t = fmax(t, sh[i]);
   return t;
 }
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
 // out[k] = sum_i part[i * stride + k], k < nk (single block; deterministic order)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ part, int n, int stride, int nk,
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------------------------------------------
-// linearize: residual (+ Jacobian) per observation, Huber loss correction, cost partial sums
+// linearize: residual (+ Jacobian) per observation, weight, Huber loss correction, cost partial sums
 // ------------------------------------------------------------------------------------------------------
 template <bool kJac>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* __restrict__ poses,
@@ -192,17 +192,23 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
     for (int k = 0; k < 3; ++k) px[k] = pts[(size_t)ix * 3 + k];
     obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
     eval_observation<kJac>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp);
+    // WeightedCostFunction (camera_functor.hpp:35-90): weight 0 selects the unweighted functor
+    double w = 1.0;
+    if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
+    const bool ctrl = d.octrl && d.octrl[o];   // control point: no loss function, not in the RMSE
+    r[0] *= w; r[1] *= w;
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3];
-    huber_rho(d.huber_a, s, rho);
+    huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s, rho);
     cost = 0.5 * rho[0];
-    sq = s;
+    sq = ctrl ? 0.0 : s;
     if (kJac) {
-      const double sc = corrector_scale(rho);
+      const double sr = corrector_scale(rho);
+      const double sc = sr * w;
       double* J = d.J;
       const size_t n = d.n_obs;
-      J[(kJr + 0) * n + o] = r[0] * sc;
-      J[(kJr + 1) * n + o] = r[1] * sc;
+      J[(kJr + 0) * n + o] = r[0] * sr;
+      J[(kJr + 1) * n + o] = r[1] * sr;
 #pragma unroll
       for (int k = 0; k < 6; ++k) J[(kJE + k) * n + o] = Jp[k] * sc;
 #pragma unroll
@@ -216,8 +222,32 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = c; part[2 * blockIdx.x + 1] = q; }
 }
 
+// pose-centre priors (one workgroup): cost added onto scalars[kSCost]; with kJac the loss-corrected residual and
+// Jacobian rows are kept for the Gram / gradient / model-cost kernels
+template <bool kJac>
+__global__ __launch_bounds__(256) void ba_prior_kernel(Dev d, const double* __restrict__ poses) {
+  __shared__ double sh[4];
+  double cost = 0;
+  for (uint32_t q = threadIdx.x; q < d.n_priors; q += blockDim.x) {
+    double r[3], Jc[18];
+    eval_pose_center_prior<kJac>(poses + (size_t)d.prior_pose[q] * 6, d.prior_center + 3 * (size_t)q, d.prior_weight + 3 * (size_t)q, r, Jc);
+    const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double rho[3];
+    huber_rho_on(true, d.prior_huber_a, s, rho);
+    cost += 0.5 * rho[0];
+    if (kJac) {
+      const double sr = corrector_scale(rho);
+      double* out = d.Jprior + (size_t)q * kPriorJ;
+      for (int k = 0; k < 3; ++k) out[k] = r[k] * sr;
+      for (int k = 0; k < 18; ++k) out[3 + k] = Jc[k] * sr;
+    }
+  }
+  const double c = block_sum(cost, sh);
+  if (threadIdx.x == 0) d.scalars[kSCost] += c;
+}
+
 // ------------------------------------------------------------------------------------------------------
-// column norms (unscaled) and gradient J^T r, segmented by owner
+// column norms (unscaled) and gradient J^T r
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_point_norms_kernel(Dev d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,571 +267,20 @@ __global__ __launch_bounds__(256) void ba_point_norms_kernel(Dev d) {
   for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = cn[c]; d.g_pt[(size_t)p * 3 + c] = g[c]; }
 }
 
-// one workgroup per pose: 6 column norms + 6 gradient entries over the pose's observations
-__global__ __launch_bounds__(256) void ba_pose_norms_kernel(Dev d) {
-  __shared__ double sh[4];
-  const uint32_t i = blockIdx.x;
-  double cn[6] = {0, 0, 0, 0, 0, 0}, g[6] = {0, 0, 0, 0, 0, 0};
-  const size_t n = d.n_obs;
-  for (uint32_t e = d.prow_start[i] + threadIdx.x; e < d.prow_start[i + 1]; e += blockDim.x) {
-    const uint32_t o = d.prow_obs[e];
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double f0 = d.J[(kJFc + c) * n + o], f1 = d.J[(kJFc + 6 + c) * n + o];
-      cn[c] += f0 * f0 + f1 * f1;
-      g[c] += f0 * r0 + f1 * r1;
-    }
-  }
-  for (int c = 0; c < 6; ++c) {
-    const double a = block_sum(cn[c], sh);
-    const double b = block_sum(g[c], sh);
-    if (threadIdx.x == 0) { d.cn_cam[6 * i + c] = a; d.g_cam[6 * i + c] = b; }
-  }
-}
-
-// intrinsic columns: chunked partial sums over (point, intrinsic) slots, then a sequential per-intrinsic reduce
-__global__ __launch_bounds__(256) void ba_intr_norms_kernel(Dev d) {
-  __shared__ double sh[4];
-  const uint32_t ch = blockIdx.x;
-  double cn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const size_t n = d.n_obs;
-  const uint32_t k = d.ichunk_intr[ch];
-  for (uint32_t e = d.ichunk_lo[ch] + threadIdx.x; e < d.ichunk_hi[ch]; e += blockDim.x) {
-    const uint32_t s = d.irow_slot[e];
-    const uint32_t p = d.slot_point[s];
-    for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-      if (d.ointr[o] != k) continue;
-      const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double f0 = d.J[(kJFi + c) * n + o], f1 = d.J[(kJFi + 8 + c) * n + o];
-        cn[c] += f0 * f0 + f1 * f1;
-        g[c] += f0 * r0 + f1 * r1;
-      }
-    }
-  }
-  for (int c = 0; c < 8; ++c) {
-    const double a = block_sum(cn[c], sh);
-    const double b = block_sum(g[c], sh);
-    if (threadIdx.x == 0) { d.inorm_part[(size_t)ch * 16 + c] = a; d.inorm_part[(size_t)ch * 16 + 8 + c] = b; }
-  }
-}
-__global__ void ba_intr_norms_reduce_kernel(Dev d) {
-  const uint32_t k = blockIdx.x;
-  const int c = threadIdx.x;  // 16 threads: 8 norms + 8 gradient entries
-  if (c >= 16) return;
-  double v = 0;
-  for (uint32_t ch = d.ichunk_start[k]; ch < d.ichunk_start[k + 1]; ++ch) v += d.inorm_part[(size_t)ch * 16 + c];
-  const int col = 6 * d.n_poses + 8 * k + (c & 7);
-  if (c < 8) d.cn_cam[col] = v; else d.g_cam[col] = v;
-}
-
-// jacobian_scaling_ = 1 / (1 + sqrt(|col|^2)) at iteration 0 (trust_region_minimizer.cc:239-254); 0 for inactive columns
-__global__ void ba_make_scaling_kernel(Dev d, int jacobi) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)d.N) d.scale_cam[i] = d.cam_active[i] ? (jacobi ? 1.0 / (1.0 + sqrt(d.cn_cam[i])) : 1.0) : 0.0;
-  if (i < (size_t)d.n_pts * 3) {
-    const bool act = !d.points_constant && d.pt_used[i / 3];
-    d.scale_pt[i] = act ? (jacobi ? 1.0 / (1.0 + sqrt(d.cn_pt[i])) : 1.0) : 0.0;
-  }
-}
-
-// LM diagonal = clamp(diag(Js^T Js), min, max) (levenberg_marquardt_strategy.cc:75-87) + max |gradient| partials
-__global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, double dmax, double* __restrict__ part) {
-  __shared__ double sh[4];
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double gm = 0;
-  if (i < (size_t)d.N) {
-    const double s = d.scale_cam[i];
-    d.diag_cam[i] = fmin(fmax(d.cn_cam[i] * s * s, dmin), dmax);
-    if (d.cam_active[i]) gm = fabs(d.g_cam[i]);
-  }
-  if (i < (size_t)d.n_pts * 3) {
-    const double s = d.scale_pt[i];
-    d.diag_pt[i] = fmin(fmax(d.cn_pt[i] * s * s, dmin), dmax);
-    if (s != 0.0) gm = fmax(gm, fabs(d.g_pt[i]));
-  }
-  const double t = block_max(gm, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// per-point elimination: V = Es^T Es + D^2, V^-1, e = V^-1 Es^T r, Y blocks = Es^T Fs
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void ba_point_eliminate_kernel(Dev d, double inv_radius) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.n_pts) return;
-  const uint32_t o0 = d.pt_start[p], o1 = d.pt_start[p + 1];
-  const uint32_t s0 = d.ptk_start[p], s1 = d.ptk_start[p + 1];
-  const size_t n = d.n_obs;
-  const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
-  double V[6] = {d.diag_pt[(size_t)p * 3] * inv_radius, 0, 0, d.diag_pt[(size_t)p * 3 + 1] * inv_radius, 0,
-                 d.diag_pt[(size_t)p * 3 + 2] * inv_radius};
-  double g[3] = {0, 0, 0};
-  for (uint32_t o = o0; o < o1; ++o) {
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-    double e0[3], e1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { e0[c] = d.J[(kJE + c) * n + o] * sp[c]; e1[c] = d.J[(kJE + 3 + c) * n + o] * sp[c]; }
-    V[0] += e0[0] * e0[0] + e1[0] * e1[0]; V[1] += e0[0] * e0[1] + e1[0] * e1[1]; V[2] += e0[0] * e0[2] + e1[0] * e1[2];
-    V[3] += e0[1] * e0[1] + e1[1] * e1[1]; V[4] += e0[1] * e0[2] + e1[1] * e1[2]; V[5] += e0[2] * e0[2] + e1[2] * e1[2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] += e0[c] * r0 + e1[c] * r1;
-  }
-  double Vi[6] = {0, 0, 0, 0, 0, 0};
-  const bool eliminate = sp[0] != 0.0;  // scale 0 <=> structure constant / point unused: no e-block
-  if (eliminate && o1 > o0) {
-    if (!invert_spd3(V, Vi)) { atomicExch(d.fail, 1); }
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) d.Vinv[(size_t)p * 6 + c] = Vi[c];
-  const double ep[3] = {Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2], Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2],
-                        Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { d.ep[(size_t)p * 3 + c] = ep[c]; d.gs_pt[(size_t)p * 3 + c] = g[c]; }
-  for (uint32_t s = s0; s < s1; ++s) {
-    for (int c = 0; c < 24; ++c) d.Yint[(size_t)s * 24 + c] = 0;
-    for (int c = 0; c < 64; ++c) d.FtF[(size_t)s * 64 + c] = 0;
-    for (int c = 0; c < 8; ++c) d.Ftr[(size_t)s * 8 + c] = 0;
-  }
-  for (uint32_t o = o0; o < o1; ++o) {
-    const uint32_t ip = d.opose[o], ik = d.ointr[o], s = d.oslot[o];
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-    double e0[3], e1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { e0[c] = d.J[(kJE + c) * n + o] * sp[c]; e1[c] = d.J[(kJE + 3 + c) * n + o] * sp[c]; }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double sc = d.scale_cam[6 * ip + c];
-      const double f0 = d.J[(kJFc + c) * n + o] * sc, f1 = d.J[(kJFc + 6 + c) * n + o] * sc;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) d.Ypose[(size_t)o * 18 + e * 6 + c] = e0[e] * f0 + e1[e] * f1;
-    }
-    double f0[8], f1[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double sc = d.scale_cam[6 * d.n_poses + 8 * ik + c];
-      f0[c] = d.J[(kJFi + c) * n + o] * sc; f1[c] = d.J[(kJFi + 8 + c) * n + o] * sc;
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-      for (int e = 0; e < 3; ++e) d.Yint[(size_t)s * 24 + e * 8 + c] += e0[e] * f0[c] + e1[e] * f1[c];
-      d.Ftr[(size_t)s * 8 + c] += f0[c] * r0 + f1[c] * r1;
-#pragma unroll
-      for (int c2 = 0; c2 < 8; ++c2) d.FtF[(size_t)s * 64 + c * 8 + c2] += f0[c] * f0[c2] + f1[c] * f1[c2];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Schur complement rows. LDS panel = the row block's rows x [win0, win0 + wcols) columns (+ rhs accumulators).
-// Each wave walks entries; lanes spread over (slot b, row rr, col cc) outputs of the entry.
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void ba_schur_pose_rows_kernel(Dev d, double inv_radius, int win0, int wcols) {
-  extern __shared__ __attribute__((aligned(16))) double panel[];  // 6 x wcols, then rhs[6]
-  const uint32_t i = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  double* rhs = panel + (size_t)6 * wcols;
-  for (int k = tid; k < 6 * wcols + 6; k += blockDim.x) panel[k] = 0.0;
-  __syncthreads();
-  const size_t n = d.n_obs;
-  const int icol0 = 6 * (int)d.n_poses;
-  const bool last_window = (win0 + wcols >= d.N);
-  for (uint32_t e = d.prow_start[i] + wave; e < d.prow_start[i + 1]; e += nwaves) {
-    const uint32_t o = d.prow_obs[e];
-    const uint32_t p = d.opt[o];
-    const uint32_t o0 = d.pt_start[p], o1 = d.pt_start[p + 1];
-    const uint32_t s0 = d.ptk_start[p], s1 = d.ptk_start[p + 1];
-    const uint32_t my_islot = d.oslot[o], my_intr = d.ointr[o];
-    const int nb = (int)(o1 - o0) + (int)(s1 - s0);
-    double Vi[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
-    const double* Ya = d.Ypose + (size_t)o * 18;           // 3 x 6, L1-resident for the whole wave
-    const double* Jo = d.J + o;                            // component c of this observation: Jo[c * n]
-    const double* sci = d.scale_cam + 6 * i;
-    for (int item = lane; item < nb * 48; item += 64) {
-      const int b = item / 48, rc = item - b * 48, rr = rc >> 3, cc = rc & 7;
-      if (rr >= 6) continue;
-      int col0; const double* Yb; int wb; bool own_pose = false, own_intr = false;
-      if (b < (int)(o1 - o0)) {
-        const uint32_t ob = o0 + b;
-        col0 = 6 * (int)d.opose[ob]; Yb = d.Ypose + (size_t)ob * 18; wb = 6; own_pose = (ob == o);
-      } else {
-        const uint32_t sb = s0 + (b - (o1 - o0));
-        col0 = icol0 + 8 * (int)d.slot_intr[sb]; Yb = d.Yint + (size_t)sb * 24; wb = 8; own_intr = (sb == my_islot);
-      }
-      if (cc >= wb || col0 < 6 * (int)i) continue;            // upper block triangle only
-      const int col = col0 + cc;
-      if (col < win0 || col >= win0 + wcols) continue;
-      // T[:, rr] = V^-1 Ya[:, rr]
-      const double y0 = Ya[rr], y1 = Ya[6 + rr], y2 = Ya[12 + rr];
-      const double t0 = Vi[0] * y0 + Vi[1] * y1 + Vi[2] * y2;
-      const double t1 = Vi[1] * y0 + Vi[3] * y1 + Vi[4] * y2;
-      const double t2 = Vi[2] * y0 + Vi[4] * y1 + Vi[5] * y2;
-      double v = -(t0 * Yb[cc] + t1 * Yb[wb + cc] + t2 * Yb[2 * wb + cc]);
-      if (own_pose || own_intr) {
-        const double fr0 = Jo[(size_t)(kJFc + rr) * n] * sci[rr], fr1 = Jo[(size_t)(kJFc + 6 + rr) * n] * sci[rr];
-        if (own_pose) v += fr0 * (Jo[(size_t)(kJFc + cc) * n] * sci[cc]) + fr1 * (Jo[(size_t)(kJFc + 6 + cc) * n] * sci[cc]);
-        if (own_intr) {
-          const double sc = d.scale_cam[icol0 + 8 * my_intr + cc];
-          v += fr0 * (Jo[(size_t)(kJFi + cc) * n] * sc) + fr1 * (Jo[(size_t)(kJFi + 8 + cc) * n] * sc);
-        }
-      }
-      atomicAdd(&panel[(size_t)rr * wcols + (col - win0)], v);
-    }
-    if (last_window && lane < 6) {
-      const double r0 = Jo[(size_t)(kJr + 0) * n], r1 = Jo[(size_t)(kJr + 1) * n];
-      const double f0 = Jo[(size_t)(kJFc + lane) * n] * sci[lane], f1 = Jo[(size_t)(kJFc + 6 + lane) * n] * sci[lane];
-      const double v = f0 * r0 + f1 * r1 -
-                       (Ya[lane] * d.ep[(size_t)p * 3] + Ya[6 + lane] * d.ep[(size_t)p * 3 + 1] + Ya[12 + lane] * d.ep[(size_t)p * 3 + 2]);
-      atomicAdd(&rhs[lane], v);
-    }
-  }
-  __syncthreads();
-  // write the panel: rows 6i..6i+5, columns >= 6i within the window; LM diagonal / unit diagonal for inactive columns
-  for (int k = tid; k < 6 * wcols; k += blockDim.x) {
-    const int rr = k / wcols, col = win0 + (k - rr * wcols);
-    const int row = 6 * (int)i + rr;
-    if (col < 6 * (int)i) continue;
-    d.S[(size_t)row * d.LD + col] = panel[k];   // raw partial sum; the LM diagonal is added after the cross-rank sum
-  }
-  if (last_window && tid < 6) d.S[(size_t)(6 * i + tid) * d.LD + d.N] = rhs[tid];
-}
-
-// intrinsic rows: chunk of (point, slot) entries of one intrinsic -> partial panel 8 x (8 n_intr) + rhs(8)
-__global__ __launch_bounds__(256) void ba_schur_intr_rows_kernel(Dev d) {
-  extern __shared__ __attribute__((aligned(16))) double panel[];  // 8 x wi, then rhs[8]
-  const uint32_t ch = blockIdx.x;
-  const uint32_t k = d.ichunk_intr[ch];
-  const int wi = 8 * (int)d.n_intr;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  double* rhs = panel + (size_t)8 * wi;
-  for (int q = tid; q < 8 * wi + 8; q += blockDim.x) panel[q] = 0.0;
-  __syncthreads();
-  for (uint32_t e = d.ichunk_lo[ch] + wave; e < d.ichunk_hi[ch]; e += nwaves) {
-    const uint32_t s = d.irow_slot[e];
-    const uint32_t p = d.slot_point[s];
-    const uint32_t s0 = d.ptk_start[p], s1 = d.ptk_start[p + 1];
-    double Vi[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
-    const double* Ya = d.Yint + (size_t)s * 24;
-    const int nb = (int)(s1 - s0);
-    for (int item = lane; item < nb * 64; item += 64) {
-      const int b = item >> 6, rr = (item >> 3) & 7, cc = item & 7;
-      const uint32_t sb = s0 + b;
-      const uint32_t kb = d.slot_intr[sb];
-      if (kb < k) continue;
-      const double* Yb = d.Yint + (size_t)sb * 24;
-      const double y0 = Ya[rr], y1 = Ya[8 + rr], y2 = Ya[16 + rr];
-      const double t0 = Vi[0] * y0 + Vi[1] * y1 + Vi[2] * y2;
-      const double t1 = Vi[1] * y0 + Vi[3] * y1 + Vi[4] * y2;
-      const double t2 = Vi[2] * y0 + Vi[4] * y1 + Vi[5] * y2;
-      double v = -(t0 * Yb[cc] + t1 * Yb[8 + cc] + t2 * Yb[16 + cc]);
-      if (sb == s) v += d.FtF[(size_t)s * 64 + rr * 8 + cc];
-      atomicAdd(&panel[(size_t)rr * wi + 8 * kb + cc], v);
-    }
-    if (lane < 8) {
-      const double v = d.Ftr[(size_t)s * 8 + lane] -
-                       (Ya[lane] * d.ep[(size_t)p * 3] + Ya[8 + lane] * d.ep[(size_t)p * 3 + 1] + Ya[16 + lane] * d.ep[(size_t)p * 3 + 2]);
-      atomicAdd(&rhs[lane], v);
-    }
-  }
-  __syncthreads();
-  double* out = d.ipanel_part + (size_t)ch * (8 * wi + 8);
-  for (int q = tid; q < 8 * wi + 8; q += blockDim.x) out[q] = panel[q];
-}
-__global__ __launch_bounds__(256) void ba_schur_intr_reduce_kernel(Dev d) {
-  const uint32_t k = blockIdx.x;
-  const int wi = 8 * (int)d.n_intr;
-  const int icol0 = 6 * (int)d.n_poses;
-  for (int q = threadIdx.x; q < 8 * wi + 8; q += blockDim.x) {
-    double v = 0;
-    for (uint32_t ch = d.ichunk_start[k]; ch < d.ichunk_start[k + 1]; ++ch) v += d.ipanel_part[(size_t)ch * (8 * wi + 8) + q];
-    if (q < 8 * wi) {
-      const int rr = q / wi, c = q - rr * wi;
-      const int row = icol0 + 8 * (int)k + rr, col = icol0 + c;
-      if (col < icol0 + 8 * (int)k) continue;
-      d.S[(size_t)row * d.LD + col] = v;
-    } else {
-      const int row = icol0 + 8 * (int)k + (q - 8 * wi);
-      d.S[(size_t)row * d.LD + d.N] = v;
-    }
-  }
-}
-
-// After the (cross-rank) sum of the partial systems: S_jj += D_j^2 = diag_j / radius for free components, unit diagonal
-// and zero rhs for constant / unused ones (their off-diagonals are exactly zero: Jacobi scale 0).
-__global__ __launch_bounds__(256) void ba_finish_system_kernel(Dev d, double inv_radius) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= d.N) return;
-  const size_t dd = (size_t)row * d.LD + row;
-  if (d.cam_active[row]) {
-    d.S[dd] += d.diag_cam[row] * inv_radius;
-  } else {
-    d.S[dd] = 1.0;
-    d.S[(size_t)row * d.LD + d.N] = 0.0;
-  }
-}
-__global__ void ba_pack_fail_kernel(Dev d) { d.scalars[kSFail] = (double)*d.fail; }
-
-// ------------------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky of the column-major lower matrix A (n x n, ld = n + 1) whose extra row n carries the
-// rhs: after the sweep, row n holds y = L^-1 rhs. A(i, j) = S[j * ld + i].
-// ------------------------------------------------------------------------------------------------------
-// chol_diag: factor the kb x kb diagonal block in place (one workgroup, LDS).
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, int ld, int k0, int kb, int* fail) {
-  __shared__ double L[kNB][kNB + 1];
-  const int tid = threadIdx.x;
-  for (int q = tid; q < kb * kb; q += blockDim.x) {
-    const int c = q / kb, r = q - c * kb;
-    L[r][c] = (r >= c) ? A[(size_t)(k0 + c) * ld + (k0 + r)] : 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < kb; ++j) {
-    const double dj = L[j][j];
-    if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) atomicExch(fail, 2); return; }  // uniform: every thread reads the same dj
-    const double sj = sqrt(dj);
-    __syncthreads();
-    if (tid == 0) L[j][j] = sj;
-    for (int r = j + 1 + tid; r < kb; r += blockDim.x) L[r][j] /= sj;
-    __syncthreads();
-    const int m = kb - j - 1;  // trailing update inside the block: L[r][c] -= L[r][j] L[c][j], j < c <= r
-    for (int q = tid; q < m * m; q += blockDim.x) {
-      const int r = j + 1 + q / m, c = j + 1 + (q - (q / m) * m);
-      if (c <= r) L[r][c] -= L[r][j] * L[c][j];
-    }
-    __syncthreads();
-  }
-  for (int q = tid; q < kb * kb; q += blockDim.x) {
-    const int c = q / kb, r = q - c * kb;
-    if (r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
-  }
-}
-
-// chol_panel: rows below the diagonal block (and the rhs row n): x L11^T = a, one row per thread (128 rows per
-// workgroup); the row's solved entries live in LDS (X[c][thread], conflict-free) so nothing is indexed dynamically
-// in registers.
-constexpr int kPanelRows = 128;
-__global__ __launch_bounds__(kPanelRows) void chol_panel_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
-  __shared__ double L[kNB][kNB + 1];
-  __shared__ double X[kNB][kPanelRows];
-  const int tid = threadIdx.x;
-  for (int q = tid; q < kb * kb; q += blockDim.x) {
-    const int c = q / kb, r = q - c * kb;
-    L[r][c] = (r >= c) ? A[(size_t)(k0 + c) * ld + (k0 + r)] : 0.0;
-  }
-  __syncthreads();
-  const int row = k0 + kb + blockIdx.x * kPanelRows + tid;
-  if (row <= n) {
-    for (int c = 0; c < kb; ++c) {
-      double v = A[(size_t)(k0 + c) * ld + row];
-      for (int q = 0; q < c; ++q) v -= X[q][tid] * L[c][q];
-      v /= L[c][c];
-      X[c][tid] = v;
-      A[(size_t)(k0 + c) * ld + row] = v;
-    }
-  }
-}
-
-// chol_update: A22 -= L21 L21^T on 64 x 64 tiles of the lower triangle (rows up to n inclusive: the rhs row rides along)
-__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
-  __shared__ double Li[kNB][kNB + 1];  // [row in tile I][k]
-  __shared__ double Lj[kNB][kNB + 1];  // [row in tile J][k]
-  const int r0 = k0 + kb;
-  // linear tile index -> (ti >= tj)
-  int t = blockIdx.x, ti = 0;
-  while (t > ti) { t -= ti + 1; ++ti; }
-  const int tj = t;
-  const int i0 = r0 + ti * kNB, j0 = r0 + tj * kNB;
-  const int tid = threadIdx.x;
-  for (int q = tid; q < kNB * kb; q += blockDim.x) {
-    const int c = q / kNB, r = q - c * kNB;  // consecutive threads -> consecutive rows (coalesced in column-major)
-    Li[r][c] = (i0 + r <= n) ? A[(size_t)(k0 + c) * ld + (i0 + r)] : 0.0;
-    Lj[r][c] = (j0 + r < n) ? A[(size_t)(k0 + c) * ld + (j0 + r)] : 0.0;
-  }
-  __syncthreads();
-  // 256 threads: thread -> 4 x 4 outputs (rows ty*4.., cols tx*4..)
-  const int ty = tid >> 4, tx = tid & 15;
-  double acc[4][4] = {{0}};
-  for (int k = 0; k < kb; ++k) {
-    double a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = Li[ty * 4 + u][k]; b[u] = Lj[tx * 4 + u][k]; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = i0 + ty * 4 + u, col = j0 + tx * 4 + v;
-      if (row <= n && col < n && row >= col) A[(size_t)col * ld + row] -= acc[u][v];
-    }
-}
-
-// Back substitution L^T z = y (y in row n), single workgroup, block columns from last to first; z lives in LDS.
-__global__ __launch_bounds__(1024) void chol_backsolve_kernel(const double* __restrict__ A, int n, int ld, double* __restrict__ z) {
-  extern __shared__ __attribute__((aligned(16))) double zs[];  // n doubles, then kNB partial sums
-  __shared__ double Lb[kNB][kNB + 1];
-  double* red = zs + n;
-  const int tid = threadIdx.x, nw = blockDim.x >> 6, lane = tid & 63, wave = tid >> 6;
-  const int nblk = (n + kNB - 1) / kNB;
-  for (int b = nblk - 1; b >= 0; --b) {
-    const int c0 = b * kNB, kb = min(kNB, n - c0);
-    // red[c] = sum_{i >= c0 + kb} L(i, c0 + c) z_i : waves take columns, lanes stride rows (contiguous in memory)
-    for (int c = wave; c < kb; c += nw) {
-      double v = 0;
-      for (int i = c0 + kb + lane; i < n; i += 64) v += A[(size_t)(c0 + c) * ld + i] * zs[i];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if (lane == 0) red[c] = v;
-    }
-    for (int q = tid; q < kb * kb; q += blockDim.x) {
-      const int c = q / kb, r = q - c * kb;
-      Lb[r][c] = (r >= c) ? A[(size_t)(c0 + c) * ld + (c0 + r)] : 0.0;
-    }
-    __syncthreads();
-    if (wave == 0) {  // L11^T z = y_b - red, unknowns held one per lane
-      double myz = (lane < kb) ? A[(size_t)(c0 + lane) * ld + n] - red[lane] : 0.0;
-      for (int c = kb - 1; c >= 0; --c) {
-        double term = (lane > c && lane < kb) ? Lb[lane][c] * myz : 0.0;
-        for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off);
-        const double zc = (__shfl(myz, c) - term) / Lb[c][c];
-        if (lane == c) myz = zc;
-      }
-      if (lane < kb) zs[c0 + lane] = myz;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < n; i += blockDim.x) z[i] = zs[i];
-}
-
-// ------------------------------------------------------------------------------------------------------
-// back-substitution of the points, steps, model cost, candidate
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_backsub_kernel(Dev d) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)d.N) d.step_cam[i] = d.cam_active[i] ? -d.zsol[i] : 0.0;   // step = -solution
-  if (p >= d.n_pts) return;
-  double t[3] = {d.gs_pt[(size_t)p * 3], d.gs_pt[(size_t)p * 3 + 1], d.gs_pt[(size_t)p * 3 + 2]};
-  for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-    const uint32_t ip = d.opose[o];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double z = d.zsol[6 * ip + c];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) t[e] -= d.Ypose[(size_t)o * 18 + e * 6 + c] * z;
-    }
-  }
-  for (uint32_t s = d.ptk_start[p]; s < d.ptk_start[p + 1]; ++s) {
-    const int col0 = 6 * (int)d.n_poses + 8 * (int)d.slot_intr[s];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double z = d.zsol[col0 + c];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) t[e] -= d.Yint[(size_t)s * 24 + e * 8 + c] * z;
-    }
-  }
-  const double* Vi = d.Vinv + (size_t)p * 6;
-  d.step_pt[(size_t)p * 3 + 0] = -(Vi[0] * t[0] + Vi[1] * t[1] + Vi[2] * t[2]);
-  d.step_pt[(size_t)p * 3 + 1] = -(Vi[1] * t[0] + Vi[3] * t[1] + Vi[4] * t[2]);
-  d.step_pt[(size_t)p * 3 + 2] = -(Vi[2] * t[0] + Vi[4] * t[1] + Vi[5] * t[2]);
-}
-
-// model_cost_change = -(Js step)^T (r + Js step / 2)  (trust_region_minimizer.cc:402-405)
-__global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __restrict__ part) {
-  __shared__ double sh[4];
-  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double v = 0;
-  if (o < d.n_obs) {
-    const size_t n = d.n_obs;
-    const uint32_t ip = d.opose[o], ik = d.ointr[o], p = d.opt[o];
-    double m0 = 0, m1 = 0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const double s = d.scale_cam[6 * ip + c] * d.step_cam[6 * ip + c];
-      m0 += d.J[(kJFc + c) * n + o] * s; m1 += d.J[(kJFc + 6 + c) * n + o] * s;
-    }
-    const int col0 = 6 * (int)d.n_poses + 8 * (int)ik;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double s = d.scale_cam[col0 + c] * d.step_cam[col0 + c];
-      m0 += d.J[(kJFi + c) * n + o] * s; m1 += d.J[(kJFi + 8 + c) * n + o] * s;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double s = d.scale_pt[(size_t)p * 3 + c] * d.step_pt[(size_t)p * 3 + c];
-      m0 += d.J[(kJE + c) * n + o] * s; m1 += d.J[(kJE + 3 + c) * n + o] * s;
-    }
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-    v = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
-  }
-  const double t = block_sum(v, sh);
-  if (threadIdx.x == 0) part[blockIdx.x] = t;
-}
-
-// candidate_x = x + step o scaling; partial sums of |delta|^2 and |x|^2 (over the blocks of the reduced program)
-__global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __restrict__ part) {
-  __shared__ double sh[4];
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double dsq = 0, xsq = 0, cdsq = 0, cxsq = 0;
-  if (i < (size_t)d.N) {
-    const int np6 = 6 * (int)d.n_poses;
-    double* x; double* cx; size_t idx;
-    if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
-    const double delta = d.step_cam[i] * d.scale_cam[i];
-    cx[idx] = x[idx] + delta;
-    cdsq = delta * delta;
-    if (d.cam_counts[i]) cxsq = x[idx] * x[idx];
-  }
-  if (i < (size_t)d.n_pts * 3) {
-    const double delta = d.step_pt[i] * d.scale_pt[i];
-    d.cpts[i] = d.pts[i] + delta;
-    dsq += delta * delta;
-    if (d.scale_pt[i] != 0.0) xsq += d.pts[i] * d.pts[i];
-  }
-  const double ca = block_sum(cdsq, sh);
-  const double cb = block_sum(cxsq, sh);
-  const double a = block_sum(dsq, sh);
-  const double b = block_sum(xsq, sh);
-  if (threadIdx.x == 0) {
-    part[4 * blockIdx.x] = ca; part[4 * blockIdx.x + 1] = cb; part[4 * blockIdx.x + 2] = a; part[4 * blockIdx.x + 3] = b;
-  }
-}
-
-// ======================================================================================================
-// v2 assembly path (default). The reduced camera system is S = G - sum_p Y_p^T V_p^-1 Y_p with
-//   G   = Fs^T Fs, the Gram blocks of the (scaled) camera columns: depends on the Jacobian only, so it is
-//         accumulated once per Jacobian evaluation (ba_pi_gram / ba_intr_gram) and reused when the LM radius changes;
-//   Y_p = Es^T Fs per point, one 3 x 6 block per observation (pose columns) and one 3 x 8 block per (point, intrinsic)
-//         slot (intrinsic columns); T = V^-1 Y is stored beside it.
-// Every product -T_a^T Y_b lands in the block (camera block of a, camera block of b). The products are listed once
-// at create time, sorted by destination block and cut into chunks; one wave per chunk accumulates its products in
-// registers (no atomics, fixed order), a second kernel sums the chunks of each block and writes it into S.
-// ======================================================================================================
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
 __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r * (r - 1)) / 2 + (c - r); }
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
-// one workgroup per (pose, intrinsic) pair: Fc^T Fc (upper, 21), Fc^T r (6), Fc^T Fi (6 x 8), all UNscaled
+// one workgroup per chunk of the observations of a (pose, intrinsic) pair: Fc^T Fc (upper, 21), Fc^T r (6),
+// Fc^T Fi (6 x 8), all UNscaled
 __global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
   __shared__ double sh[4][kPiGram];
-  const uint32_t q = blockIdx.x;
+  const uint32_t ch = blockIdx.x;
   const size_t n = d.n_obs;
   const double* __restrict__ J = d.J;
   double acc[kPiGram];
 #pragma unroll
   for (int k = 0; k < kPiGram; ++k) acc[k] = 0.0;
-  for (uint32_t e = d.pi_start[q] + threadIdx.x; e < d.pi_start[q + 1]; e += 256) {
+  for (uint32_t e = d.pichunk_lo[ch] + threadIdx.x; e < d.pichunk_hi[ch]; e += 256) {
     const uint32_t o = d.pi_obs[e];
     const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
     double f0[6], f1[6], h0[8], h1[8];
@@ -826,16 +305,33 @@ __global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
   }
   __syncthreads();
   if (threadIdx.x < kPiGram)
-    d.pi_gram[(size_t)q * kPiGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    d.pichunk_part[(size_t)ch * kPiGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
-
-// per pose: sum its (pose, intrinsic) pairs -> pose_gram (27), column norms and gradient of the pose columns
+// per (pose, intrinsic) pair: sum of its chunks
+__global__ __launch_bounds__(128) void ba_pi_finish_kernel(Dev d) {
+  const uint32_t q = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= kPiGram) return;
+  double v = 0;
+  for (uint32_t ch = d.pi_chunk0[q]; ch < d.pi_chunk0[q + 1]; ++ch) v += d.pichunk_part[(size_t)ch * kPiGram + t];
+  d.pi_gram[(size_t)q * kPiGram + t] = v;
+}
+// per pose: sum of its (pose, intrinsic) pairs and of its pose-centre priors -> pose_gram (27), column norms, gradient
 __global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
   const uint32_t i = blockIdx.x;
   const int t = threadIdx.x;
   if (t >= kPoseGram) return;
   double v = 0;
   for (uint32_t q = d.pose_pi_start[i]; q < d.pose_pi_start[i + 1]; ++q) v += d.pi_gram[(size_t)q * kPiGram + t];
+  if (d.n_priors) {
+    int r = 0, c = 0;   // (r, c) of upper-triangle index t < 21
+    if (t < 21) { int k = t; while (k >= 6 - r) { k -= 6 - r; ++r; } c = r + k; }
+    for (uint32_t e = d.pose_prior_start[i]; e < d.pose_prior_start[i + 1]; ++e) {
+      const double* jp = d.Jprior + (size_t)d.pose_prior_idx[e] * kPriorJ;
+      if (t < 21) { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + r] * jp[3 + k * 6 + c]; }
+      else { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + (t - 21)] * jp[k]; }
+    }
+  }
   d.pose_gram[(size_t)i * kPoseGram + t] = v;
   if (t >= 21) d.g_cam[6 * i + (t - 21)] = v;
 #pragma unroll
@@ -875,12 +371,21 @@ __global__ __launch_bounds__(256) void ba_intr_gram_kernel(Dev d) {
   if (threadIdx.x < kIntrGram)
     d.igram_part[(size_t)ch * kIntrGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(64) void ba_intr_finish_kernel(Dev d) {
+// per intrinsic: 16 groups of threads stride its chunks, fixed-order combine
+__global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
+  __shared__ double sh[16][kIntrGram];
   const uint32_t k = blockIdx.x;
-  const int t = threadIdx.x;
-  if (t >= kIntrGram) return;
+  const int g = threadIdx.x >> 6, t = threadIdx.x & 63;
+  if (t < kIntrGram) {
+    double v = 0;
+    for (uint32_t ch = d.igchunk_start[k] + g; ch < d.igchunk_start[k + 1]; ch += 16) v += d.igram_part[(size_t)ch * kIntrGram + t];
+    sh[g][t] = v;
+  }
+  __syncthreads();
+  if (g != 0 || t >= kIntrGram) return;
   double v = 0;
-  for (uint32_t ch = d.igchunk_start[k]; ch < d.igchunk_start[k + 1]; ++ch) v += d.igram_part[(size_t)ch * kIntrGram + t];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v += sh[q][t];
   d.igram[(size_t)k * kIntrGram + t] = v;
   const int col0 = 6 * (int)d.n_poses + 8 * (int)k;
   if (t >= 36) d.g_cam[col0 + (t - 36)] = v;
@@ -889,7 +394,36 @@ __global__ __launch_bounds__(64) void ba_intr_finish_kernel(Dev d) {
     if (t == tri8(c, c)) d.cn_cam[col0 + c] = v;
 }
 
-// per point: V = Es^T Es + D^2, V^-1, gs = Es^T r, e = V^-1 gs
+// jacobian_scaling_ = 1 / (1 + sqrt(|col|^2)) at iteration 0 (trust_region_minimizer.cc:239-254); 0 for inactive columns
+__global__ void ba_make_scaling_kernel(Dev d, int jacobi) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)d.N) d.scale_cam[i] = d.cam_active[i] ? (jacobi ? 1.0 / (1.0 + sqrt(d.cn_cam[i])) : 1.0) : 0.0;
+  if (i < (size_t)d.n_pts * 3) d.scale_pt[i] = d.pt_free[i / 3] ? (jacobi ? 1.0 / (1.0 + sqrt(d.cn_pt[i])) : 1.0) : 0.0;
+}
+
+// LM diagonal = clamp(diag(Js^T Js), min, max) (levenberg_marquardt_strategy.cc:75-87) + max |gradient| partials
+__global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, double dmax, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double gm = 0;
+  if (i < (size_t)d.N) {
+    const double s = d.scale_cam[i];
+    d.diag_cam[i] = fmin(fmax(d.cn_cam[i] * s * s, dmin), dmax);
+    if (d.cam_active[i]) gm = fabs(d.g_cam[i]);
+  }
+  if (i < (size_t)d.n_pts * 3) {
+    const double s = d.scale_pt[i];
+    d.diag_pt[i] = fmin(fmax(d.cn_pt[i] * s * s, dmin), dmax);
+    if (s != 0.0) gm = fmax(gm, fabs(d.g_pt[i]));
+  }
+  const double t = block_max(gm, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-point elimination
+// ------------------------------------------------------------------------------------------------------
+// per point: V = Es^T Es + D^2 = L L^T, L^-1, h = L^-1 Es^T r
 __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_radius) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.n_pts) return;
@@ -910,96 +444,79 @@ __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_r
 #pragma unroll
     for (int c = 0; c < 3; ++c) g[c] += e0[c] * r0 + e1[c] * r1;
   }
-  double Vi[6] = {0, 0, 0, 0, 0, 0};
-  const bool eliminate = sp[0] != 0.0;  // scale 0 <=> structure constant / point unused: no e-block
+  double li[6] = {0, 0, 0, 0, 0, 0};
+  const bool eliminate = sp[0] != 0.0;  // scale 0 <=> point constant / unused: no e-block (Z = 0, the rows stay in G)
   if (eliminate && o1 > o0) {
-    if (!invert_spd3(V, Vi)) { atomicExch(d.fail, 1); }
+    if (!chol_inv3(V, li)) { atomicExch(d.fail, 1); for (int c = 0; c < 6; ++c) li[c] = 0.0; }
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) d.Vinv[(size_t)p * 6 + c] = Vi[c];
-  const double ep[3] = {Vi[0] * g[0] + Vi[1] * g[1] + Vi[2] * g[2], Vi[1] * g[0] + Vi[3] * g[1] + Vi[4] * g[2],
-                        Vi[2] * g[0] + Vi[4] * g[1] + Vi[5] * g[2]};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { d.ep[(size_t)p * 3 + c] = ep[c]; d.gs_pt[(size_t)p * 3 + c] = g[c]; }
+  for (int c = 0; c < 6; ++c) d.Linv3[(size_t)p * 6 + c] = li[c];
+  d.hp[(size_t)p * 3 + 0] = li[0] * g[0];
+  d.hp[(size_t)p * 3 + 1] = li[1] * g[0] + li[2] * g[1];
+  d.hp[(size_t)p * 3 + 2] = li[3] * g[0] + li[4] * g[1] + li[5] * g[2];
 }
 
-__device__ __forceinline__ void apply_vinv(const double* Vi, double y0, double y1, double y2, double& t0, double& t1, double& t2) {
-  t0 = Vi[0] * y0 + Vi[1] * y1 + Vi[2] * y2;
-  t1 = Vi[1] * y0 + Vi[3] * y1 + Vi[4] * y2;
-  t2 = Vi[2] * y0 + Vi[4] * y1 + Vi[5] * y2;
-}
-
-// per observation: Y = Es^T Fc_s (3 x 6) and T = V^-1 Y
-__global__ __launch_bounds__(256) void ba_obs_yt_kernel(Dev d) {
+// per observation: Z = L_p^-1 Es^T Fc_s (3 x 6)
+__global__ __launch_bounds__(256) void ba_obs_z_kernel(Dev d) {
   const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= d.n_obs) return;
   const size_t n = d.n_obs;
   const double* __restrict__ J = d.J;
   const uint32_t p = d.opt[o], ip = d.opose[o];
-  double e0[3], e1[3], Vi[6];
+  double e0[3], e1[3], li[6];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const double s = d.scale_pt[(size_t)p * 3 + c];
     e0[c] = J[(kJE + c) * n + o] * s; e1[c] = J[(kJE + 3 + c) * n + o] * s;
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
-  double Y[18], T[18];
+  for (int c = 0; c < 6; ++c) li[c] = d.Linv3[(size_t)p * 6 + c];
+  double Z[18];
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const double sc = d.scale_cam[6 * ip + c];
     const double f0 = J[(kJFc + c) * n + o] * sc, f1 = J[(kJFc + 6 + c) * n + o] * sc;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) Y[e * 6 + c] = e0[e] * f0 + e1[e] * f1;
-    apply_vinv(Vi, Y[c], Y[6 + c], Y[12 + c], T[c], T[6 + c], T[12 + c]);
+    const double y0 = e0[0] * f0 + e1[0] * f1, y1 = e0[1] * f0 + e1[1] * f1, y2 = e0[2] * f0 + e1[2] * f1;
+    Z[c] = li[0] * y0;
+    Z[6 + c] = li[1] * y0 + li[2] * y1;
+    Z[12 + c] = li[3] * y0 + li[4] * y1 + li[5] * y2;
   }
-  double2* __restrict__ yo = reinterpret_cast<double2*>(d.Ypose + (size_t)o * 18);
-  double2* __restrict__ to = reinterpret_cast<double2*>(d.Tpose + (size_t)o * 18);
+  double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)o * 18);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { yo[k] = make_double2(Y[2 * k], Y[2 * k + 1]); to[k] = make_double2(T[2 * k], T[2 * k + 1]); }
+  for (int k = 0; k < 9; ++k) zo[k] = make_double2(Z[2 * k], Z[2 * k + 1]);
 }
 
-// per (point, intrinsic) slot: Y = sum over the slot's observations of Es^T Fi_s (3 x 8) and T = V^-1 Y
-__global__ __launch_bounds__(256) void ba_slot_yt_kernel(Dev d) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// per (point, intrinsic) slot and intrinsic column: Z[:, c] = L_p^-1 sum over the slot's observations of Es^T Fi_s[:, c]
+__global__ __launch_bounds__(256) void ba_slot_z_kernel(Dev d) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t s = idx >> 3;
+  const int c = idx & 7;
   if (s >= (uint32_t)d.n_islots) return;
   const size_t n = d.n_obs;
   const double* __restrict__ J = d.J;
   const uint32_t p = d.slot_point[s], ik = d.slot_intr[s];
   const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
-  double sc[8], Y[24], T[24], Vi[6];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) sc[c] = d.scale_cam[6 * d.n_poses + 8 * ik + c];
-#pragma unroll
-  for (int c = 0; c < 24; ++c) Y[c] = 0.0;
+  const double sc = d.scale_cam[6 * d.n_poses + 8 * ik + c];
+  double y0 = 0, y1 = 0, y2 = 0;
   for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
     if (d.ointr[o] != ik) continue;
-    double e0[3], e1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { e0[c] = J[(kJE + c) * n + o] * sp[c]; e1[c] = J[(kJE + 3 + c) * n + o] * sp[c]; }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double f0 = J[(kJFi + c) * n + o] * sc[c], f1 = J[(kJFi + 8 + c) * n + o] * sc[c];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) Y[e * 8 + c] += e0[e] * f0 + e1[e] * f1;
-    }
+    const double f0 = J[(kJFi + c) * n + o] * sc, f1 = J[(kJFi + 8 + c) * n + o] * sc;
+    y0 += (J[(kJE + 0) * n + o] * f0 + J[(kJE + 3) * n + o] * f1) * sp[0];
+    y1 += (J[(kJE + 1) * n + o] * f0 + J[(kJE + 4) * n + o] * f1) * sp[1];
+    y2 += (J[(kJE + 2) * n + o] * f0 + J[(kJE + 5) * n + o] * f1) * sp[2];
   }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) Vi[c] = d.Vinv[(size_t)p * 6 + c];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) apply_vinv(Vi, Y[c], Y[8 + c], Y[16 + c], T[c], T[8 + c], T[16 + c]);
-  double2* __restrict__ yo = reinterpret_cast<double2*>(d.Yint + (size_t)s * 24);
-  double2* __restrict__ to = reinterpret_cast<double2*>(d.Tint + (size_t)s * 24);
-#pragma unroll
-  for (int k = 0; k < 12; ++k) { yo[k] = make_double2(Y[2 * k], Y[2 * k + 1]); to[k] = make_double2(T[2 * k], T[2 * k + 1]); }
+  const double* li = d.Linv3 + (size_t)p * 6;
+  d.Zint[(size_t)s * 24 + c] = li[0] * y0;
+  d.Zint[(size_t)s * 24 + 8 + c] = li[1] * y0 + li[2] * y1;
+  d.Zint[(size_t)s * 24 + 16 + c] = li[3] * y0 + li[4] * y1 + li[5] * y2;
 }
 
-// One wave per chunk of products of one destination block: acc += T_a^T Y_b (WA x WB), and for the (a, a) products of a
-// diagonal block rhs += T_a^T gs_p (= Y_a^T e_p). Lanes stride the chunk; the 64 per-lane partial blocks are summed
-// through LDS in a fixed order.
+// One wave per chunk of products of one destination block: acc += Z_a^T Z_b (WA x WB), and for the (a, a) products of a
+// diagonal block rhs += Z_a^T h_p. Lanes stride the chunk; the 64 per-lane partial blocks are summed through LDS in a
+// fixed order.
 template <int WA, int WB>
-__global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const double* __restrict__ Ta, const double* __restrict__ Yb,
-                                                               const double* __restrict__ gs_pt, const uint32_t* __restrict__ a_point) {
+__global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const double* __restrict__ Za, const double* __restrict__ Zb,
+                                                               const double* __restrict__ hp, const uint32_t* __restrict__ a_point) {
   constexpr int NV = WA * WB + WA;
   __shared__ double red[64][NV + 1];
   const uint32_t ch = blockIdx.x;
@@ -1013,23 +530,23 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
   for (int k = 0; k < WA; ++k) rhs[k] = 0.0;
   for (uint32_t t = lo + lane; t < hi; t += 64) {
     const uint2 ab = L.trips[t];
-    double ta[3 * WA], yb[3 * WB];
-    const double2* __restrict__ pa = reinterpret_cast<const double2*>(Ta + (size_t)ab.x * (3 * WA));
-    const double2* __restrict__ pb = reinterpret_cast<const double2*>(Yb + (size_t)ab.y * (3 * WB));
+    double za[3 * WA], zb[3 * WB];
+    const double2* __restrict__ pa = reinterpret_cast<const double2*>(Za + (size_t)ab.x * (3 * WA));
+    const double2* __restrict__ pb = reinterpret_cast<const double2*>(Zb + (size_t)ab.y * (3 * WB));
 #pragma unroll
-    for (int k = 0; k < 3 * WA / 2; ++k) { const double2 v = pa[k]; ta[2 * k] = v.x; ta[2 * k + 1] = v.y; }
+    for (int k = 0; k < 3 * WA / 2; ++k) { const double2 v = pa[k]; za[2 * k] = v.x; za[2 * k + 1] = v.y; }
 #pragma unroll
-    for (int k = 0; k < 3 * WB / 2; ++k) { const double2 v = pb[k]; yb[2 * k] = v.x; yb[2 * k + 1] = v.y; }
+    for (int k = 0; k < 3 * WB / 2; ++k) { const double2 v = pb[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
 #pragma unroll
     for (int r = 0; r < WA; ++r)
 #pragma unroll
       for (int c = 0; c < WB; ++c)
-        acc[r * WB + c] += ta[r] * yb[c] + ta[WA + r] * yb[WB + c] + ta[2 * WA + r] * yb[2 * WB + c];
+        acc[r * WB + c] += za[r] * zb[c] + za[WA + r] * zb[WB + c] + za[2 * WA + r] * zb[2 * WB + c];
     if (diag && ab.x == ab.y) {
       const uint32_t p = a_point[ab.x];
-      const double g0 = gs_pt[(size_t)p * 3], g1 = gs_pt[(size_t)p * 3 + 1], g2 = gs_pt[(size_t)p * 3 + 2];
+      const double h0 = hp[(size_t)p * 3], h1 = hp[(size_t)p * 3 + 1], h2 = hp[(size_t)p * 3 + 2];
 #pragma unroll
-      for (int r = 0; r < WA; ++r) rhs[r] += ta[r] * g0 + ta[WA + r] * g1 + ta[2 * WA + r] * g2;
+      for (int r = 0; r < WA; ++r) rhs[r] += za[r] * h0 + za[WA + r] * h1 + za[2 * WA + r] * h2;
     }
   }
 #pragma unroll
@@ -1081,23 +598,48 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
   }
 }
 
+// After the (cross-rank) sum of the partial systems: S_jj += D_j^2 = diag_j / radius for free components, unit diagonal
+// and zero rhs for constant / unused ones (their off-diagonals are exactly zero: Jacobi scale 0).
+__global__ __launch_bounds__(256) void ba_finish_system_kernel(Dev d, double inv_radius) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= d.N) return;
+  const size_t dd = (size_t)row * d.LD + row;
+  if (d.cam_active[row]) {
+    d.S[dd] += d.diag_cam[row] * inv_radius;
+  } else {
+    d.S[dd] = 1.0;
+    d.S[(size_t)row * d.LD + d.N] = 0.0;
+  }
+}
+__global__ void ba_pack_fail_kernel(Dev d) { d.scalars[kSFail] = (double)*d.fail; }
+
 // ------------------------------------------------------------------------------------------------------
-// v2 Cholesky: per 64-column block step  (1) chol_diag_inv: factor the diagonal block and invert its factor (one
-// workgroup, 16-wide sub-blocks in LDS), (2) chol_panel_mfma: L21 = A21 L11^-T as a GEMM with the inverse (the rhs row n
-// rides along: forward substitution for free), (3) chol_update_mfma: A22 -= L21 L21^T on 64 x 64 tiles with
-// v_mfma_f64_16x16x4_f64. Back substitution: one launch per block step, z_b = L_bb^-T y_b, then y_c -= L_bc^T z_b for
-// all columns c left of the block.
+// Blocked Cholesky of the column-major lower matrix A (n x n, ld = n + 1) whose extra row n carries the rhs: after the
+// sweep, row n holds y = L^-1 rhs. A(i, j) = S[j * ld + i].
 // ------------------------------------------------------------------------------------------------------
 constexpr int kLS = 65;    // LDS row stride of the 64 x 64 factor / inverse
 constexpr int kTS = 80;    // LDS row stride of a k-major 64-wide MFMA operand tile (rows k, k+1 land 32 banks apart)
-constexpr int kDiagLds = (2 * 64 * kLS + 64 * 17) * (int)sizeof(double);
+constexpr int kDiagLds = (2 * 64 * kLS + 64 * 17 + 64) * (int)sizeof(double);
 
+__device__ __forceinline__ double fast_rcp(double x) {   // v_rcp_f64 + two Newton steps (full precision for finite x > 0)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
+// processed as four 64 x 16 column panels: a right-looking panel factorisation on UNscaled columns (one barrier per
+// pivot: a_rc -= a_rj a_cj / d_j, the 1 / sqrt(d) scaling applied once at the end of the panel), then a rank-16 update
+// of the remaining columns. The inverse is built from the 16 x 16 diagonal blocks outwards.
 __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb,
-                                                            double* __restrict__ linvT /* [k][c] = Linv[c][k] */, int* fail) {
+                                                            double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double (*L)[kLS] = reinterpret_cast<double (*)[kLS]>(lds);
   double (*Li)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 64 * kLS);
   double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);
+  double (*col)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 2 * 64 * kLS);   // aliases Tmp: 16 pivot columns of the panel
+  double* rd = lds + 2 * 64 * kLS + 64 * 17;                                      // 1 / L[r][r]
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   for (int q = tid; q < 4096; q += 256) {
     const int c = q >> 6, r = q & 63;
@@ -1108,36 +650,35 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
   }
   __syncthreads();
   for (int jb = 0; jb < 4; ++jb) {
-    const int j0 = jb * 16;
-    // 16 x 16 diagonal sub-block, thread (ty, tx) owns element (j0 + ty, j0 + tx)
+    const int j0 = jb * 16, nm = 4 - jb;
+    double a[4];   // thread (ty, tx) owns rows j0 + ty + 16 m of panel column j0 + tx
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = (m < nm) ? L[j0 + ty + 16 * m][j0 + tx] : 0.0;
     for (int j = 0; j < 16; ++j) {
-      const double dj = L[j0 + j][j0 + j];
-      if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform
-      const double sj = sqrt(dj);
-      __syncthreads();
-      if (tx == j && ty >= j) L[j0 + ty][j0 + j] = (ty == j) ? sj : L[j0 + ty][j0 + j] / sj;
-      __syncthreads();
-      if (ty > j && tx > j && tx <= ty) L[j0 + ty][j0 + tx] -= L[j0 + ty][j0 + j] * L[j0 + tx][j0 + j];
-      __syncthreads();
-    }
-    // rows below inside the 64-block: x D^T = a, one row per thread
-    const int nrows = 48 - j0;
-    if (tid < nrows) {
-      const int r = j0 + 16 + tid;
-      double x[16];
+      if (tx == j) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double v = L[r][j0 + c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) v -= x[q] * L[j0 + c][j0 + q];
-        x[c] = v / L[j0 + c][j0 + c];
+        for (int m = 0; m < 4; ++m)
+          if (m < nm) col[j][j0 + ty + 16 * m] = a[m];
       }
+      __syncthreads();
+      const double dj = col[j][j0 + j];
+      if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform
+      if (tx > j) {
+        const double cj = col[j][j0 + tx] * fast_rcp(dj);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) L[r][j0 + c] = x[c];
+        for (int m = 0; m < 4; ++m)
+          if (m < nm) a[m] -= col[j][j0 + ty + 16 * m] * cj;
+      }
     }
+    const double rs = 1.0 / sqrt(col[tx][j0 + tx]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < nm) {
+        const int r = j0 + ty + 16 * m;
+        L[r][j0 + tx] = (r >= j0 + tx) ? a[m] * rs : 0.0;
+      }
     __syncthreads();
-    // trailing update inside the 64-block
-    for (int q = tid; q < 4096; q += 256) {
+    for (int q = tid; q < 4096; q += 256) {   // L[r][c] -= sum_k L[r][j0 + k] L[c][j0 + k] for the columns right of the panel
       const int r = q >> 6, c = q & 63;
       if (c >= j0 + 16 && r >= c) {
         double v = 0;
@@ -1149,6 +690,8 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     __syncthreads();
   }
   // inverse of the factor: 16 x 16 diagonal blocks by forward substitution (one column per thread) ...
+  if (tid < 64) rd[tid] = 1.0 / L[tid][tid];
+  __syncthreads();
   if (tid < 64) {
     const int b0 = (tid >> 4) * 16, c = tid & 15;
     double x[16];
@@ -1157,7 +700,7 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
       double v = (r == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int q = 0; q < r; ++q) v -= L[b0 + r][b0 + q] * x[q];
-      x[r] = v / L[b0 + r][b0 + r];
+      x[r] = v * rd[b0 + r];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) Li[b0 + r][b0 + c] = x[r];
@@ -1186,7 +729,8 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
   for (int q = tid; q < 4096; q += 256) {
     const int c = q >> 6, r = q & 63;
     if (r < kb && c < kb && r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
-    linvT[q] = Li[r][c];   // q = c * 64 + r  ->  linvT[k = c][col = r] = Linv[r][c]
+    linv[q] = Li[r][c];                  // k-major: linv[k = c][col = r] = Linv[r][c]
+    linv[4096 + q] = Li[q >> 6][q & 63]; // row-major
   }
 }
 
@@ -1280,18 +824,19 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
 }
 
 // back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
-// y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 64 columns c < b0 (one wave per 16 columns).
+// y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 256 columns c < b0: four lanes per column, 16 contiguous rows
+// (one cache line) each.
 __global__ __launch_bounds__(256) void chol_backsolve_step_kernel(double* __restrict__ A, int n, int ld, int b0, int kb,
-                                                                  const double* __restrict__ linvT, double* __restrict__ z) {
+                                                                  const double* __restrict__ linv_rm, double* __restrict__ z) {
   __shared__ double yb[64];
   __shared__ double zp[4][64];
   __shared__ double zb[64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid < 64) yb[tid] = (tid < kb) ? A[(size_t)(b0 + tid) * ld + n] : 0.0;
   __syncthreads();
-  {  // z[c] = sum_r Linv[r][c] y[r] = sum_r linvT[c][r] y[r]; wave w takes r = w, w + 4, ...
+  {  // z[c] = sum_r Linv[r][c] y[r]; wave w takes r = w, w + 4, ...
     double v = 0;
-    for (int r = wave; r < 64; r += 4) v += linvT[lane * 64 + r] * yb[r];
+    for (int r = wave; r < 64; r += 4) v += linv_rm[r * 64 + lane] * yb[r];
     zp[wave][lane] = v;
   }
   __syncthreads();
@@ -1301,31 +846,134 @@ __global__ __launch_bounds__(256) void chol_backsolve_step_kernel(double* __rest
     if (blockIdx.x == 0 && tid < kb) z[b0 + tid] = v;
   }
   __syncthreads();
-  const int cbase = (int)blockIdx.x * 64 + wave * 16;
-  for (int cc = 0; cc < 16; ++cc) {
-    const int c = cbase + cc;
-    if (c >= b0) break;   // wave-uniform
-    double v = (lane < kb) ? A[(size_t)c * ld + (b0 + lane)] * zb[lane] : 0.0;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if (lane == 0) A[(size_t)c * ld + n] -= v;
+  const int part = lane & 3;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int c = (int)blockIdx.x * 256 + wave * 64 + pass * 16 + (lane >> 2);
+    double v = 0;
+    if (c < b0) {
+      const double* __restrict__ colp = A + (size_t)c * ld + (b0 + part * 16);
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (part * 16 + k < kb) v += colp[k] * zb[part * 16 + k];
+    }
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    if (c < b0 && part == 0) A[(size_t)c * ld + n] -= v;
   }
 }
 
-template <typename T>
-int dev_alloc(T** p, size_t n) {
-  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
-  return MVGX_OK;
-}
-template <typename T>
-int dev_upload(T** p, const std::vector<T>& v, hipStream_t s) {
-  int rc = dev_alloc(p, v.size());
-  if (rc) return rc;
-  if (!v.empty()) MVGX_HIP(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-  return MVGX_OK;
+// ------------------------------------------------------------------------------------------------------
+// back-substitution of the points, steps, model cost, candidate
+// ------------------------------------------------------------------------------------------------------
+// step_pt = -L^-T (h - sum Z z)  ( = -V^-1 (Es^T r - sum Y z), schur_eliminator_impl.h:303-366 )
+__global__ __launch_bounds__(256) void ba_backsub_kernel(Dev d) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)d.N) d.step_cam[i] = d.cam_active[i] ? -d.zsol[i] : 0.0;   // step = -solution
+  if (p >= d.n_pts) return;
+  double t[3] = {d.hp[(size_t)p * 3], d.hp[(size_t)p * 3 + 1], d.hp[(size_t)p * 3 + 2]};
+  for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+    const uint32_t ip = d.opose[o];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double z = d.zsol[6 * ip + c];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) t[e] -= d.Zpose[(size_t)o * 18 + e * 6 + c] * z;
+    }
+  }
+  for (uint32_t s = d.ptk_start[p]; s < d.ptk_start[p + 1]; ++s) {
+    const int col0 = 6 * (int)d.n_poses + 8 * (int)d.slot_intr[s];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double z = d.zsol[col0 + c];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) t[e] -= d.Zint[(size_t)s * 24 + e * 8 + c] * z;
+    }
+  }
+  const double* li = d.Linv3 + (size_t)p * 6;
+  d.step_pt[(size_t)p * 3 + 0] = -(li[0] * t[0] + li[1] * t[1] + li[3] * t[2]);
+  d.step_pt[(size_t)p * 3 + 1] = -(li[2] * t[1] + li[4] * t[2]);
+  d.step_pt[(size_t)p * 3 + 2] = -(li[5] * t[2]);
 }
 
+// model_cost_change = -(Js step)^T (r + Js step / 2)  (trust_region_minimizer.cc:402-405)
+__global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double v = 0;
+  if (o < d.n_obs) {
+    const size_t n = d.n_obs;
+    const uint32_t ip = d.opose[o], ik = d.ointr[o], p = d.opt[o];
+    double m0 = 0, m1 = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double s = d.scale_cam[6 * ip + c] * d.step_cam[6 * ip + c];
+      m0 += d.J[(kJFc + c) * n + o] * s; m1 += d.J[(kJFc + 6 + c) * n + o] * s;
+    }
+    const int col0 = 6 * (int)d.n_poses + 8 * (int)ik;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double s = d.scale_cam[col0 + c] * d.step_cam[col0 + c];
+      m0 += d.J[(kJFi + c) * n + o] * s; m1 += d.J[(kJFi + 8 + c) * n + o] * s;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double s = d.scale_pt[(size_t)p * 3 + c] * d.step_pt[(size_t)p * 3 + c];
+      m0 += d.J[(kJE + c) * n + o] * s; m1 += d.J[(kJE + 3 + c) * n + o] * s;
+    }
+    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
+    v = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
+  }
+  const double t = block_sum(v, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// the prior rows' share of the model cost change, added onto scalars[kSModel] (one workgroup)
+__global__ __launch_bounds__(256) void ba_prior_model_kernel(Dev d) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (uint32_t q = threadIdx.x; q < d.n_priors; q += blockDim.x) {
+    const double* jp = d.Jprior + (size_t)q * kPriorJ;
+    const uint32_t ip = d.prior_pose[q];
+    for (int k = 0; k < 3; ++k) {
+      double m = 0;
+      for (int c = 0; c < 6; ++c) m += jp[3 + k * 6 + c] * d.scale_cam[6 * ip + c] * d.step_cam[6 * ip + c];
+      v -= m * (jp[k] + m / 2.0);
+    }
+  }
+  const double t = block_sum(v, sh);
+  if (threadIdx.x == 0) d.scalars[kSModel] += t;
+}
 
-// ---- host side of the v2 assembly: product lists sorted by destination block ----
+// candidate_x = x + step o scaling; partial sums of |delta|^2 and |x|^2 (over the blocks of the reduced program)
+__global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double dsq = 0, xsq = 0, cdsq = 0, cxsq = 0;
+  if (i < (size_t)d.N) {
+    const int np6 = 6 * (int)d.n_poses;
+    double* x; double* cx; size_t idx;
+    if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
+    const double delta = d.step_cam[i] * d.scale_cam[i];
+    cx[idx] = x[idx] + delta;
+    cdsq = delta * delta;
+    if (d.cam_counts[i]) cxsq = x[idx] * x[idx];
+  }
+  if (i < (size_t)d.n_pts * 3) {
+    const double delta = d.step_pt[i] * d.scale_pt[i];
+    d.cpts[i] = d.pts[i] + delta;
+    dsq += delta * delta;
+    if (d.scale_pt[i] != 0.0) xsq += d.pts[i] * d.pts[i];
+  }
+  const double ca = block_sum(cdsq, sh);
+  const double cb = block_sum(cxsq, sh);
+  const double a = block_sum(dsq, sh);
+  const double b = block_sum(xsq, sh);
+  if (threadIdx.x == 0) {
+    part[4 * blockIdx.x] = ca; part[4 * blockIdx.x + 1] = cb; part[4 * blockIdx.x + 2] = a; part[4 * blockIdx.x + 3] = b;
+  }
+}
+
+// ---- host side of the assembly: product lists sorted by destination block ----
 struct TripHost {
   std::vector<uint2> trips;
   std::vector<uint32_t> chunk_lo, chunk_hi, block_row, block_col, block_chunk0;
@@ -1371,6 +1019,20 @@ void build_trip_list(size_t n_cb, const std::vector<uint32_t>& row, const std::v
   }
 }
 
+template <typename T>
+int dev_alloc(std::vector<void*>& pool, T** p, size_t n) {
+  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
+  pool.push_back(*p);
+  return MVGX_OK;
+}
+template <typename T>
+int dev_upload(std::vector<void*>& pool, T** p, const std::vector<T>& v, hipStream_t s) {
+  int rc = dev_alloc(pool, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) MVGX_HIP(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return MVGX_OK;
+}
+
 }  // namespace
 
 struct mvgx_ba_ctx {
@@ -1378,15 +1040,14 @@ struct mvgx_ba_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Dev d;
-  std::vector<void*> allocs;
-  std::vector<uint64_t> perm;          // sorted observation -> original index
+  std::vector<void*> pool;             // every device allocation (freed in destroy)
   double* h_scalars = nullptr;         // pinned
   int* h_fail = nullptr;               // pinned
-  size_t part_cap = 0;
   mvgx_allreduce_f64 allreduce = nullptr;
   void* allreduce_user = nullptr;
   mvgx::RcclComm* rccl = nullptr;
-  double n_obs_global = 0;             // observations over all ranks (RMSE denominator)
+  double n_obs_rmse_local = 0;         // observations of this rank that count in the RMSE (not control points)
+  double n_obs_global = 0;             // ... over all ranks
   // LM state (persists across mvgx_ba_lm_iteration calls)
   bool started = false;
   double x_cost = 0, radius = 0, decrease_factor = 2.0, gradient_max_norm = 0;
@@ -1395,9 +1056,6 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
-  int max_pose_win = 0;
-  int legacy = 0;                      // kLegacySchur | kLegacyChol (env MVGX_BA_LEGACY)
-  std::vector<void*> extra;            // device allocations of the v2 path (freed in destroy)
 };
 
 namespace {
@@ -1428,27 +1086,24 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
   if (d.n_obs)
     hipLaunchKernelGGL(ba_linearize_kernel<kJac>, dim3(c->grid_obs), dim3(256), 0, c->stream, d, poses, intr, pts, d.part);
   BA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_obs, 2, 2, d.scalars, kSCost, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 2, 2, d.scalars,
+                     kSCost, 0);
+  if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<kJac>, dim3(1), dim3(256), 0, c->stream, d, poses);
   BA_LAUNCH_CHECK();
   return all_reduce(c, d.scalars + kSCost, 2);
 }
 
-// TrustRegionMinimizer::EvaluateGradientAndJacobian: J, cost, column norms, gradient (+ scaling at iteration 0)
+// TrustRegionMinimizer::EvaluateGradientAndJacobian: J, cost, Gram blocks / column norms, gradient (+ scaling at iteration 0)
 int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, bool iteration_zero) {
   Dev& d = c->d;
   int rc = eval<true>(c, d.poses, d.intr, d.pts);
   if (rc) return rc;
   if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
-  if (c->legacy & kLegacySchur) {
-    if (d.n_poses) hipLaunchKernelGGL(ba_pose_norms_kernel, dim3(d.n_poses), dim3(256), 0, c->stream, d);
-    if (d.n_ichunks) hipLaunchKernelGGL(ba_intr_norms_kernel, dim3(d.n_ichunks), dim3(256), 0, c->stream, d);
-    if (d.n_intr) hipLaunchKernelGGL(ba_intr_norms_reduce_kernel, dim3(d.n_intr), dim3(16), 0, c->stream, d);
-  } else {   // Gram blocks of the camera columns (their diagonals are the column norms, their r-products the gradient)
-    if (d.n_pi) hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pi), dim3(256), 0, c->stream, d);
-    if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
-    if (d.n_igchunks) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
-    if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(64), 0, c->stream, d);
-  }
+  if (d.n_pichunks) hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
+  if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
+  if (d.n_igchunks) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
+  if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(1024), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
   if ((rc = all_reduce(c, d.g_cam, d.N))) return rc;
@@ -1471,34 +1126,17 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
 int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   Dev& d = c->d;
   MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
-  if (c->legacy & kLegacySchur) {
-    if (d.n_pts) hipLaunchKernelGGL(ba_point_eliminate_kernel, dim3((d.n_pts + 127) / 128), dim3(128), 0, c->stream, d, inv_radius);
-    BA_LAUNCH_CHECK();
-    const int maxw = c->max_pose_win;
-    for (int win0 = 0; win0 < d.N && d.n_poses; win0 += maxw) {
-      const int wcols = std::min(maxw, d.N - win0);
-      hipLaunchKernelGGL(ba_schur_pose_rows_kernel, dim3(d.n_poses), dim3(512), (size_t)(6 * wcols + 6) * sizeof(double), c->stream, d,
-                         inv_radius, win0, wcols);
-    }
-    if (d.n_ichunks) {
-      const size_t lds = (size_t)(64 * d.n_intr + 8) * sizeof(double);
-      hipLaunchKernelGGL(ba_schur_intr_rows_kernel, dim3(d.n_ichunks), dim3(256), lds, c->stream, d);
-    }
-    if (d.n_intr) hipLaunchKernelGGL(ba_schur_intr_reduce_kernel, dim3(d.n_intr), dim3(256), 0, c->stream, d);
-    BA_LAUNCH_CHECK();
-    return MVGX_OK;
-  }
   if (d.n_pts) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
-  if (d.n_obs) hipLaunchKernelGGL(ba_obs_yt_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d);
-  if (d.n_islots) hipLaunchKernelGGL(ba_slot_yt_kernel, dim3((d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
+  if (d.n_obs) hipLaunchKernelGGL(ba_obs_z_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d);
+  if (d.n_islots) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   if (d.tpp.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(d.tpp.n_chunks), dim3(64), 0, c->stream, d.tpp, d.Tpose, d.Ypose, d.gs_pt, d.opt);
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(d.tpp.n_chunks), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
   if (d.tpi.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(d.tpi.n_chunks), dim3(64), 0, c->stream, d.tpi, d.Tpose, d.Yint, d.gs_pt, d.opt);
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(d.tpi.n_chunks), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
   if (d.tii.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(d.tii.n_chunks), dim3(64), 0, c->stream, d.tii, d.Tint, d.Yint, d.gs_pt, d.slot_point);
+    hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(d.tii.n_chunks), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
   BA_LAUNCH_CHECK();
   if (d.tpp.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 6, 0>), dim3(d.tpp.n_blocks), dim3(128), 0, c->stream, d, d.tpp);
   if (d.tpi.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 8, 1>), dim3(d.tpi.n_blocks), dim3(128), 0, c->stream, d, d.tpi);
@@ -1511,30 +1149,12 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 int factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   if (!d.N) return MVGX_OK;
-  if (c->legacy & kLegacyChol) {
-    for (int k0 = 0; k0 < d.N; k0 += kNB) {
-      const int kb = std::min(kNB, d.N - k0);
-      const int rows_below = d.N + 1 - (k0 + kb);  // includes the rhs row
-      const int gp = std::max(1, (rows_below + kPanelRows - 1) / kPanelRows);
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, d.S, d.LD, k0, kb, d.fail);
-      hipLaunchKernelGGL(chol_panel_kernel, dim3(gp), dim3(kPanelRows), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-      const int rem = d.N + 1 - (k0 + kb);
-      if (rem > 0 && k0 + kb < d.N) {
-        const int nt = (rem + kNB - 1) / kNB;
-        hipLaunchKernelGGL(chol_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-      }
-    }
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)(d.N + kNB) * sizeof(double), c->stream, d.S, d.N, d.LD,
-                       d.zsol);
-    BA_LAUNCH_CHECK();
-    return MVGX_OK;
-  }
   for (int k0 = 0; k0 < d.N; k0 += 64) {
     const int kb = std::min(64, d.N - k0);
-    double* linvT = d.linv + (size_t)(k0 / 64) * 4096;
-    hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linvT, d.fail);
+    double* linv = d.linv + (size_t)(k0 / 64) * 8192;
+    hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linv, d.fail);
     const int rows_below = d.N + 1 - (k0 + kb);   // >= 1: the rhs row
-    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, linvT);
+    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, linv);
     if (k0 + kb < d.N) {
       const int nt = (rows_below + 63) / 64;
       hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
@@ -1543,8 +1163,8 @@ int factor_and_solve(mvgx_ba_ctx* c) {
   BA_LAUNCH_CHECK();
   for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
     const int kb = std::min(64, d.N - b0);
-    hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(std::max(1, b0 / 64)), dim3(256), 0, c->stream, d.S, d.N, d.LD, b0, kb,
-                       d.linv + (size_t)(b0 / 64) * 4096, d.zsol);
+    hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(std::max(1, (b0 + 255) / 256)), dim3(256), 0, c->stream, d.S, d.N, d.LD, b0, kb,
+                       d.linv + (size_t)(b0 / 64) * 8192 + 4096, d.zsol);
   }
   BA_LAUNCH_CHECK();
   return MVGX_OK;
@@ -1562,7 +1182,9 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   if ((rc = factor_and_solve(c))) return rc;
   hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);
   if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_obs, 1, 1, d.scalars, kSModel, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
+                     kSModel, 0);
+  if (d.n_priors) hipLaunchKernelGGL(ba_prior_model_kernel, dim3(1), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.scalars + kSModel, 1))) return rc;
   if (multi_rank(c)) {   // a point block that failed to invert on one rank fails the step everywhere
@@ -1603,7 +1225,7 @@ int accept_candidate(mvgx_ba_ctx* c) {
 }
 
 int global_obs_count(mvgx_ba_ctx* c) {
-  c->n_obs_global = (double)c->d.n_obs;
+  c->n_obs_global = c->n_obs_rmse_local;
   if (!multi_rank(c)) return MVGX_OK;
   MVGX_HIP(hipMemcpyAsync(c->d.scalars + kSNobs, &c->n_obs_global, sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = all_reduce(c, c->d.scalars + kSNobs, 1);
@@ -1719,12 +1341,16 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(!p->n_obs || (p->obs_pose && p->obs_intr && p->obs_point && p->obs_xy), MVGX_ERR_ARG,
                "mvgx_ba_create: NULL observation array");
   MVGX_REQUIRE(p->n_obs < (1ull << 31), MVGX_ERR_ARG, "mvgx_ba_create: too many observations for one device shard");
+  MVGX_REQUIRE(!p->n_pose_priors || (p->prior_pose && p->prior_center && p->prior_weight), MVGX_ERR_ARG,
+               "mvgx_ba_create: NULL pose-prior array");
   for (uint32_t k = 0; k < p->n_intrinsics; ++k)
-    MVGX_REQUIRE(intr_param_count(p->intr_model[k]) > 0, MVGX_ERR_UNSUPPORTED,
-                 "intrinsic %u: camera model %d has no device functor (pinhole, radial K1, radial K3 only)", k, p->intr_model[k]);
+    MVGX_REQUIRE(intr_param_count(p->intr_model[k]) >= 0, MVGX_ERR_UNSUPPORTED,
+                 "intrinsic %u: camera model %d has no cost functor (sfm_data_BA_ceres.cpp:84-108)", k, p->intr_model[k]);
   for (uint64_t k = 0; k < p->n_obs; ++k)
     MVGX_REQUIRE(p->obs_pose[k] < p->n_poses && p->obs_intr[k] < p->n_intrinsics && p->obs_point[k] < p->n_points, MVGX_ERR_ARG,
                  "observation %llu references a block out of range", (unsigned long long)k);
+  for (uint32_t k = 0; k < p->n_pose_priors; ++k)
+    MVGX_REQUIRE(p->prior_pose[k] < p->n_poses, MVGX_ERR_ARG, "pose prior %u references a pose out of range", k);
   int rc = mvgx::select_device(device);
   if (rc) return rc;
   auto* c = new mvgx_ba_ctx();
@@ -1735,28 +1361,38 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), kSCount * sizeof(double), hipHostMallocDefault));
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_fail), sizeof(int), hipHostMallocDefault));
   Dev& d = c->d;
-  d.n_poses = p->n_poses; d.n_intr = p->n_intrinsics; d.n_pts = p->n_points; d.n_obs = p->n_obs;
+  d.n_poses = p->n_poses; d.n_intr = p->n_intrinsics; d.n_pts = p->n_points; d.n_obs = p->n_obs; d.n_priors = p->n_pose_priors;
   d.N = 6 * (int)d.n_poses + 8 * (int)d.n_intr; d.LD = d.N + 1;
-  d.points_constant = p->points_constant ? 1 : 0;
   d.huber_a = p->huber_a;
+  d.prior_huber_a = p->prior_huber_a;
   const uint64_t no = d.n_obs;
 
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----
-  std::vector<uint64_t>& perm = c->perm;
-  perm.resize(no);
+  std::vector<uint64_t> perm(no);
   std::iota(perm.begin(), perm.end(), 0ull);
   std::stable_sort(perm.begin(), perm.end(), [&](uint64_t a, uint64_t b) { return p->obs_point[a] < p->obs_point[b]; });
   std::vector<uint32_t> opose(no), ointr(no), opt_(no), oslot(no), pt_start(d.n_pts + 1, 0);
-  std::vector<double> oxy(2 * no);
+  std::vector<double> oxy(2 * no), oweight;
+  std::vector<uint8_t> octrl;
+  if (p->obs_weight) oweight.resize(no);
+  if (p->obs_is_control) octrl.resize(no);
+  double n_rmse = 0;
   for (uint64_t k = 0; k < no; ++k) {
     const uint64_t s = perm[k];
     opose[k] = p->obs_pose[s]; ointr[k] = p->obs_intr[s]; opt_[k] = p->obs_point[s];
     oxy[2 * k] = p->obs_xy[2 * s]; oxy[2 * k + 1] = p->obs_xy[2 * s + 1];
+    if (p->obs_weight) oweight[k] = p->obs_weight[s];
+    if (p->obs_is_control) octrl[k] = p->obs_is_control[s] ? 1 : 0;
+    if (!(p->obs_is_control && p->obs_is_control[s])) n_rmse += 1.0;
     pt_start[opt_[k] + 1]++;
   }
+  c->n_obs_rmse_local = n_rmse;
   for (uint32_t j = 0; j < d.n_pts; ++j) pt_start[j + 1] += pt_start[j];
-  std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_used(d.n_pts, 0);
-  for (uint64_t k = 0; k < no; ++k) { pose_used[opose[k]] = 1; intr_used[ointr[k]] = 1; pt_used[opt_[k]] = 1; }
+  std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_free(d.n_pts, 0);
+  for (uint64_t k = 0; k < no; ++k) { pose_used[opose[k]] = 1; intr_used[ointr[k]] = 1; pt_free[opt_[k]] = 1; }
+  for (uint32_t k = 0; k < d.n_priors; ++k) pose_used[p->prior_pose[k]] = 1;
+  for (uint32_t j = 0; j < d.n_pts; ++j)
+    if (p->points_constant || (p->point_const_mask && p->point_const_mask[j])) pt_free[j] = 0;
   // (point, intrinsic) slots
   std::vector<uint32_t> ptk_start(d.n_pts + 1, 0), slot_intr, slot_point;
   for (uint32_t j = 0; j < d.n_pts; ++j) {
@@ -1770,73 +1406,75 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     ptk_start[j + 1] = (uint32_t)slot_intr.size();
   }
   d.n_islots = (int)slot_intr.size();
-  // rows of the pose blocks (observations by pose) and of the intrinsic blocks (slots by intrinsic)
-  std::vector<uint32_t> prow_start(d.n_poses + 1, 0), prow_obs(no), irow_start(d.n_intr + 1, 0), irow_slot(slot_intr.size());
+  // (pose, intrinsic) pairs: observations sorted by pose, then intrinsic; chunks of kPiChunk observations
+  std::vector<uint32_t> prow_start(d.n_poses + 1, 0), pi_obs(no);
   for (uint64_t k = 0; k < no; ++k) prow_start[opose[k] + 1]++;
   for (uint32_t i = 0; i < d.n_poses; ++i) prow_start[i + 1] += prow_start[i];
   { std::vector<uint32_t> fill(prow_start.begin(), prow_start.end() - 1);
-    for (uint64_t k = 0; k < no; ++k) prow_obs[fill[opose[k]]++] = (uint32_t)k; }
-  for (size_t s = 0; s < slot_intr.size(); ++s) irow_start[slot_intr[s] + 1]++;
-  for (uint32_t i = 0; i < d.n_intr; ++i) irow_start[i + 1] += irow_start[i];
-  { std::vector<uint32_t> fill(irow_start.begin(), irow_start.end() - 1);
-    for (size_t s = 0; s < slot_intr.size(); ++s) irow_slot[fill[slot_intr[s]]++] = (uint32_t)s; }
-  std::vector<uint32_t> ichunk_intr, ichunk_lo, ichunk_hi, ichunk_start(d.n_intr + 1, 0);
-  for (uint32_t k = 0; k < d.n_intr; ++k) {
-    for (uint32_t lo = irow_start[k]; lo < irow_start[k + 1]; lo += kIntrChunk) {
-      ichunk_intr.push_back(k); ichunk_lo.push_back(lo); ichunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, irow_start[k + 1]));
-    }
-    ichunk_start[k + 1] = (uint32_t)ichunk_intr.size();
-  }
-  d.n_ichunks = (int)ichunk_intr.size();
-  // ---- v2 assembly structures ----
-  // (pose, intrinsic) pairs: observations sorted by pose, then intrinsic
-  std::vector<uint32_t> pi_obs(prow_obs), pi_start, pi_pose, pi_intr, pose_pi_start(d.n_poses + 1, 0);
+    for (uint64_t k = 0; k < no; ++k) pi_obs[fill[opose[k]]++] = (uint32_t)k; }
+  std::vector<uint32_t> pi_start, pi_intr, pose_pi_start(d.n_poses + 1, 0), pichunk_lo, pichunk_hi, pi_chunk0;
   for (uint32_t i = 0; i < d.n_poses; ++i) {
     auto b = pi_obs.begin() + prow_start[i], e = pi_obs.begin() + prow_start[i + 1];
     std::stable_sort(b, e, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
     for (uint32_t q = prow_start[i]; q < prow_start[i + 1]; ++q)
-      if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) { pi_start.push_back(q); pi_pose.push_back(i); pi_intr.push_back(ointr[pi_obs[q]]); }
+      if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) { pi_start.push_back(q); pi_intr.push_back(ointr[pi_obs[q]]); }
     pose_pi_start[i + 1] = (uint32_t)pi_start.size();
   }
   d.n_pi = (int)pi_start.size();
   pi_start.push_back((uint32_t)no);
+  for (int q = 0; q < d.n_pi; ++q) {
+    pi_chunk0.push_back((uint32_t)pichunk_lo.size());
+    for (uint32_t lo = pi_start[q]; lo < pi_start[q + 1]; lo += kPiChunk) {
+      pichunk_lo.push_back(lo); pichunk_hi.push_back(std::min<uint32_t>(lo + kPiChunk, pi_start[q + 1]));
+    }
+  }
+  pi_chunk0.push_back((uint32_t)pichunk_lo.size());
+  d.n_pichunks = (int)pichunk_lo.size();
   // observations by intrinsic, cut into chunks
-  std::vector<uint32_t> iobs_start(d.n_intr + 1, 0), iobs(no), igchunk_intr, igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
+  std::vector<uint32_t> iobs_start(d.n_intr + 1, 0), iobs(no), igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
   for (uint64_t k = 0; k < no; ++k) iobs_start[ointr[k] + 1]++;
   for (uint32_t i = 0; i < d.n_intr; ++i) iobs_start[i + 1] += iobs_start[i];
   { std::vector<uint32_t> fill(iobs_start.begin(), iobs_start.end() - 1);
     for (uint64_t k = 0; k < no; ++k) iobs[fill[ointr[k]]++] = (uint32_t)k; }
   for (uint32_t k = 0; k < d.n_intr; ++k) {
     for (uint32_t lo = iobs_start[k]; lo < iobs_start[k + 1]; lo += kIntrChunk) {
-      igchunk_intr.push_back(k); igchunk_lo.push_back(lo); igchunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, iobs_start[k + 1]));
+      igchunk_lo.push_back(lo); igchunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, iobs_start[k + 1]));
     }
-    igchunk_start[k + 1] = (uint32_t)igchunk_intr.size();
+    igchunk_start[k + 1] = (uint32_t)igchunk_lo.size();
   }
-  d.n_igchunks = (int)igchunk_intr.size();
+  d.n_igchunks = (int)igchunk_lo.size();
+  // pose-centre priors by pose
+  std::vector<uint32_t> prior_pose(p->prior_pose, p->prior_pose + d.n_priors), pose_prior_start(d.n_poses + 1, 0), pose_prior_idx(d.n_priors);
+  for (uint32_t k = 0; k < d.n_priors; ++k) pose_prior_start[prior_pose[k] + 1]++;
+  for (uint32_t i = 0; i < d.n_poses; ++i) pose_prior_start[i + 1] += pose_prior_start[i];
+  { std::vector<uint32_t> fill(pose_prior_start.begin(), pose_prior_start.end() - 1);
+    for (uint32_t k = 0; k < d.n_priors; ++k) pose_prior_idx[fill[prior_pose[k]]++] = k; }
   // Schur products by destination block
   TripHost hpp, hpi, hii;
   {
     const size_t n_cb = (size_t)d.n_poses + d.n_intr;
     std::vector<uint32_t> row, col;
     std::vector<uint2> ab;
-    size_t npp = 0, npi = 0, nii = 0;
+    size_t npp = 0, npi = 0;
     for (uint32_t j = 0; j < d.n_pts; ++j) {
+      if (!pt_free[j]) continue;
       const size_t L = pt_start[j + 1] - pt_start[j], K = ptk_start[j + 1] - ptk_start[j];
-      npp += L * L; npi += L * K; nii += K * K;
+      npp += L * L; npi += L * K;
     }
     MVGX_REQUIRE(npp < (1ull << 32) && npi < (1ull << 32), MVGX_ERR_ARG, "mvgx_ba_create: too many co-visibility products for one device shard");
     row.reserve(npp); col.reserve(npp); ab.reserve(npp);
+    // Constant / unused points have Z = 0: only the (a, a) products are listed, so that every diagonal block exists
+    // (it carries the Gram block and the rhs).
     for (uint32_t j = 0; j < d.n_pts; ++j)
       for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
         for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
-          if (opose[a] <= opose[b]) { row.push_back(opose[a]); col.push_back(opose[b]); ab.push_back(make_uint2(a, b)); }
+          if (opose[a] <= opose[b] && (pt_free[j] || a == b)) { row.push_back(opose[a]); col.push_back(opose[b]); ab.push_back(make_uint2(a, b)); }
     build_trip_list(n_cb, row, col, ab, hpp);
     row.clear(); col.clear(); ab.clear();
     for (uint32_t j = 0; j < d.n_pts; ++j)
       for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
-        for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl) {
-          row.push_back(opose[a]); col.push_back(d.n_poses + slot_intr[sl]); ab.push_back(make_uint2(a, sl));
-        }
+        for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
+          if (pt_free[j] || sl == oslot[a]) { row.push_back(opose[a]); col.push_back(d.n_poses + slot_intr[sl]); ab.push_back(make_uint2(a, sl)); }
     build_trip_list(n_cb, row, col, ab, hpi);
     for (size_t b = 0; b < hpi.block_row.size(); ++b) {   // the (pose, intrinsic) pair whose Fc^T Fi belongs to the block
       const uint32_t i = hpi.block_row[b], k = hpi.block_col[b] - d.n_poses;
@@ -1847,12 +1485,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     for (uint32_t j = 0; j < d.n_pts; ++j)
       for (uint32_t sa = ptk_start[j]; sa < ptk_start[j + 1]; ++sa)
         for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
-          if (slot_intr[sa] <= slot_intr[sb]) {
+          if (slot_intr[sa] <= slot_intr[sb] && (pt_free[j] || sa == sb)) {
             row.push_back(d.n_poses + slot_intr[sa]); col.push_back(d.n_poses + slot_intr[sb]); ab.push_back(make_uint2(sa, sb));
           }
     build_trip_list(n_cb, row, col, ab, hii);
   }
-  if (const char* env = getenv("MVGX_BA_LEGACY")) c->legacy = atoi(env);
   // active / counted camera components
   std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
   for (uint32_t i = 0; i < d.n_poses; ++i) {
@@ -1867,7 +1504,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     const int K = intr_param_count(p->intr_model[k]);
     const uint8_t m = p->intr_const_mask ? p->intr_const_mask[k] : 0;
     const uint8_t full = (uint8_t)((1u << K) - 1u);
-    const bool in_program = intr_used[k] && ((m & full) != full);
+    const bool in_program = intr_used[k] && K > 0 && ((m & full) != full);
     for (int cpt = 0; cpt < 8; ++cpt) {
       cam_active[6 * d.n_poses + 8 * k + cpt] = in_program && cpt < K && !((m >> cpt) & 1);
       cam_counts[6 * d.n_poses + 8 * k + cpt] = in_program && cpt < K;
@@ -1876,58 +1513,47 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   std::vector<double> h_poses(p->poses, p->poses + (size_t)d.n_poses * 6), h_intr(p->intrinsics, p->intrinsics + (size_t)d.n_intr * 8),
       h_pts(p->points, p->points + (size_t)d.n_pts * 3);
   std::vector<int> h_model(p->intr_model, p->intr_model + d.n_intr);
+  std::vector<double> h_pc(p->prior_center, p->prior_center + (size_t)d.n_priors * 3), h_pw(p->prior_weight, p->prior_weight + (size_t)d.n_priors * 3);
 
-#define UP(field, vec) if ((rc = dev_upload(&d.field, vec, c->stream))) return rc
-#define AL(field, n) if ((rc = dev_alloc(&d.field, (size_t)(n)))) return rc
+#define UP(field, vec) if ((rc = dev_upload(c->pool, &d.field, vec, c->stream))) return rc
+#define AL(field, n) if ((rc = dev_alloc(c->pool, &d.field, (size_t)(n)))) return rc
   UP(poses, h_poses); UP(intr, h_intr); UP(pts, h_pts); UP(model, h_model);
   AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
-  UP(opose, opose); UP(ointr, ointr); UP(opt, opt_); UP(oslot, oslot); UP(oxy, oxy);
+  UP(opose, opose); UP(ointr, ointr); UP(opt, opt_); UP(oxy, oxy);
+  if (p->obs_weight) { UP(oweight, oweight); }
+  if (p->obs_is_control) { UP(octrl, octrl); }
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
-  UP(prow_start, prow_start); UP(prow_obs, prow_obs); UP(irow_start, irow_start); UP(irow_slot, irow_slot);
-  UP(ichunk_intr, ichunk_intr); UP(ichunk_lo, ichunk_lo); UP(ichunk_hi, ichunk_hi); UP(ichunk_start, ichunk_start);
-  UP(cam_active, cam_active); UP(cam_counts, cam_counts); UP(pt_used, pt_used);
+  UP(cam_active, cam_active); UP(cam_counts, cam_counts); UP(pt_free, pt_free);
+  UP(pi_obs, pi_obs); UP(pichunk_lo, pichunk_lo); UP(pichunk_hi, pichunk_hi); UP(pi_chunk0, pi_chunk0); UP(pose_pi_start, pose_pi_start);
+  UP(iobs, iobs); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
+  UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
+  UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
   AL(J, (size_t)kJC * no);
   AL(cn_cam, d.N); AL(g_cam, d.N); AL(scale_cam, d.N); AL(diag_cam, d.N);
   AL(cn_pt, (size_t)d.n_pts * 3); AL(g_pt, (size_t)d.n_pts * 3); AL(scale_pt, (size_t)d.n_pts * 3); AL(diag_pt, (size_t)d.n_pts * 3);
-  AL(inorm_part, (size_t)d.n_ichunks * 16);
-  AL(Vinv, (size_t)d.n_pts * 6); AL(ep, (size_t)d.n_pts * 3); AL(gs_pt, (size_t)d.n_pts * 3);
-  AL(Ypose, (size_t)no * 18);
-  AL(Yint, (size_t)d.n_islots * 24); AL(FtF, (size_t)d.n_islots * 64); AL(Ftr, (size_t)d.n_islots * 8);
-  AL(S, (size_t)d.N * d.LD);
-  AL(ipanel_part, (size_t)d.n_ichunks * (64 * d.n_intr + 8));
-  AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
-  AL(Tpose, (size_t)no * 18); AL(Tint, (size_t)d.n_islots * 24);
-  UP(pi_start, pi_start); UP(pi_obs, pi_obs); UP(pi_pose, pi_pose); UP(pi_intr, pi_intr); UP(pose_pi_start, pose_pi_start);
-  UP(iobs_start, iobs_start); UP(iobs, iobs);
-  UP(igchunk_intr, igchunk_intr); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
-  AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
+  AL(pichunk_part, (size_t)d.n_pichunks * kPiGram); AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
   AL(igram_part, (size_t)d.n_igchunks * kIntrGram); AL(igram, (size_t)d.n_intr * kIntrGram);
-  AL(linv, (size_t)((d.N + 63) / 64) * 4096);
+  AL(Linv3, (size_t)d.n_pts * 6); AL(hp, (size_t)d.n_pts * 3);
+  AL(Zpose, (size_t)no * 18); AL(Zint, (size_t)d.n_islots * 24);
+  AL(S, (size_t)d.N * d.LD);
+  AL(linv, (size_t)((d.N + 63) / 64) * 8192);
+  AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
   {
     struct { TripHost* h; TripList* l; int nv; } lists[3] = {{&hpp, &d.tpp, 6 * 6 + 6}, {&hpi, &d.tpi, 6 * 8 + 6}, {&hii, &d.tii, 8 * 8 + 8}};
     for (auto& e : lists) {
       TripHost& h = *e.h; TripList& l = *e.l;
       l.n_trips = (uint32_t)h.trips.size(); l.n_chunks = (uint32_t)h.chunk_lo.size(); l.n_blocks = (uint32_t)h.block_row.size();
-      if ((rc = dev_upload(&l.trips, h.trips, c->stream))) return rc;
-      if ((rc = dev_upload(&l.chunk_lo, h.chunk_lo, c->stream))) return rc;
-      if ((rc = dev_upload(&l.chunk_hi, h.chunk_hi, c->stream))) return rc;
-      if ((rc = dev_upload(&l.chunk_diag, h.chunk_diag, c->stream))) return rc;
-      if ((rc = dev_upload(&l.block_row, h.block_row, c->stream))) return rc;
-      if ((rc = dev_upload(&l.block_col, h.block_col, c->stream))) return rc;
-      if ((rc = dev_upload(&l.block_chunk0, h.block_chunk0, c->stream))) return rc;
-      if ((rc = dev_upload(&l.block_own, h.block_own, c->stream))) return rc;
-      if ((rc = dev_alloc(&l.part, (size_t)l.n_chunks * e.nv))) return rc;
-      for (void* q : {(void*)l.trips, (void*)l.chunk_lo, (void*)l.chunk_hi, (void*)l.chunk_diag, (void*)l.block_row, (void*)l.block_col,
-                      (void*)l.block_chunk0, (void*)l.block_own, (void*)l.part})
-        c->extra.push_back(q);
+      if ((rc = dev_upload(c->pool, &l.trips, h.trips, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.chunk_lo, h.chunk_lo, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.chunk_hi, h.chunk_hi, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.chunk_diag, h.chunk_diag, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.block_row, h.block_row, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.block_col, h.block_col, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.block_chunk0, h.block_chunk0, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &l.block_own, h.block_own, c->stream))) return rc;
+      if ((rc = dev_alloc(c->pool, &l.part, (size_t)l.n_chunks * e.nv))) return rc;
     }
-    for (void* q : {(void*)d.Tpose, (void*)d.Tint, (void*)d.pi_start, (void*)d.pi_obs, (void*)d.pi_pose, (void*)d.pi_intr,
-                    (void*)d.pose_pi_start, (void*)d.iobs_start, (void*)d.iobs, (void*)d.igchunk_intr, (void*)d.igchunk_lo,
-                    (void*)d.igchunk_hi, (void*)d.igchunk_start, (void*)d.pi_gram, (void*)d.pose_gram, (void*)d.igram_part,
-                    (void*)d.igram, (void*)d.linv})
-      c->extra.push_back(q);
   }
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
   AL(part, (size_t)4 * std::max(c->grid_obs, c->grid_vec) + 16);
@@ -1937,18 +1563,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
-  // LDS window of the pose-row panels: 6 x wcols doubles, at most ~120 KiB
-  c->max_pose_win = std::max(8, std::min(d.N, 2500));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_pose_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((6 * c->max_pose_win + 6) * sizeof(double))));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_intr_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((64 * std::max<int>(d.n_intr, 1) + 8) * sizeof(double))));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((d.N + kNB) * sizeof(double))));
-  MVGX_REQUIRE((size_t)(d.N + kNB) * sizeof(double) <= 120 * 1024, MVGX_ERR_UNSUPPORTED,
-               "reduced camera system of %d columns exceeds the LDS-resident back substitution", d.N);
-  MVGX_REQUIRE((64 * (size_t)d.n_intr + 8) * sizeof(double) <= 150 * 1024, MVGX_ERR_UNSUPPORTED,
-               "%u intrinsic groups exceed the LDS panel of the intrinsic rows", d.n_intr);
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   *out = c;
   return MVGX_OK;
@@ -1958,14 +1573,7 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (!c) return MVGX_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  Dev& d = c->d;
-  void* ptrs[] = {d.poses, d.intr, d.pts, d.cposes, d.cintr, d.cpts, d.model, d.opose, d.ointr, d.opt, d.oslot, d.oxy, d.pt_start,
-                  d.ptk_start, d.slot_intr, d.slot_point, d.prow_start, d.prow_obs, d.irow_start, d.irow_slot, d.ichunk_intr,
-                  d.ichunk_lo, d.ichunk_hi, d.ichunk_start, d.cam_active, d.cam_counts, d.pt_used, d.J, d.cn_cam, d.g_cam,
-                  d.scale_cam, d.diag_cam, d.cn_pt, d.g_pt, d.scale_pt, d.diag_pt, d.inorm_part, d.Vinv, d.ep, d.gs_pt, d.Ypose,
-                  d.Yint, d.FtF, d.Ftr, d.S, d.ipanel_part, d.zsol, d.step_cam, d.step_pt, d.part, d.scalars, d.fail};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
-  for (void* q : c->extra) if (q) (void)hipFree(q);
+  for (void* q : c->pool) if (q) (void)hipFree(q);
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -51,16 +51,11 @@ def handle():
 
 
 @contextlib.contextmanager
-def emulated(legacy=0):
+def emulated():
     """Routes openmvg_amd._capi to the emulation library inside the block (tests only)."""
-    saved, saved_env = _capi._lib, os.environ.get("MVGX_BA_LEGACY")
+    saved = _capi._lib
     _capi._lib = handle()
-    os.environ["MVGX_BA_LEGACY"] = str(int(legacy))
     try:
         yield
     finally:
         _capi._lib = saved
-        if saved_env is None:
-            os.environ.pop("MVGX_BA_LEGACY", None)
-        else:
-            os.environ["MVGX_BA_LEGACY"] = saved_env

@@ -55,6 +55,7 @@ static inline double __shfl_xor(double v, int m) { return hipemu::shfl_f64(v, hi
 static inline double __shfl_down(double v, int d) { return hipemu::shfl_f64(v, hipemu::lane_down, d); }
 static inline double __shfl(double v, int s) { return hipemu::shfl_f64(v, hipemu::lane_abs, s); }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
 
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p += v; return o; }

@@ -19,8 +19,8 @@ from tests import _emu, _oracle
 RMSE_TOL = 1e-6
 
 
-def _solve_emu(sc, legacy=0, options=None, **masks):
-    with _emu.emulated(legacy):
+def _solve_emu(sc, options=None, **masks):
+    with _emu.emulated():
         ctx = ba.BaContext(sc, **masks)
         s = ctx.solve(options)
         poses, intr, pts = ctx.read_params()
@@ -28,12 +28,11 @@ def _solve_emu(sc, legacy=0, options=None, **masks):
     return s, poses, intr, pts
 
 
-@pytest.mark.parametrize("legacy", [0, 3])
-def test_lm_trajectory_equals_oracle(legacy):
-    """default (v2) path and the legacy path: same iteration count, costs and parameters as the oracle"""
+def test_lm_trajectory_equals_oracle():
+    """same iteration count, costs and parameters as the oracle"""
     sc = synth.ba_scene(n_cams=9, n_points=120, track_len=5, model=3, n_intr_groups=2, seed=21, rot_deg=0.3)
     rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc)
-    s, poses, intr, pts = _solve_emu(sc, legacy)
+    s, poses, intr, pts = _solve_emu(sc)
     assert rc == 0 and s.num_iterations == osum.num_iterations and s.num_successful_steps == osum.num_successful_steps
     assert s.termination == osum.termination
     assert abs(s.initial_cost - osum.initial_cost) <= 1e-10 * osum.initial_cost
@@ -48,7 +47,7 @@ def test_multi_block_cholesky_and_wide_intrinsics():
     sc = synth.ba_scene(n_cams=12, n_points=150, track_len=4, model=2, n_intr_groups=12, seed=33)
     opt = dict(max_num_iterations=2)
     rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
-    s, poses, intr, pts = _solve_emu(sc, 0, ba.default_options(**opt))
+    s, poses, intr, pts = _solve_emu(sc, ba.default_options(**opt))
     assert 6 * 12 + 8 * 12 > 128
     assert s.num_iterations == osum.num_iterations == 2
     assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
@@ -60,7 +59,7 @@ def test_subset_parameterizations(iopt, eopt, sopt):
     sc = synth.ba_scene(n_cams=8, n_points=100, track_len=5, model=3, n_intr_groups=2, seed=22, rot_deg=0.3)
     masks = bo.masks_for(sc, iopt, eopt, sopt)
     rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, **masks)
-    s, poses, intr, pts = _solve_emu(sc, 0, **masks)
+    s, poses, intr, pts = _solve_emu(sc, **masks)
     assert s.num_iterations == osum.num_iterations
     assert abs(s.final_rmse - osum.final_rmse) < RMSE_TOL * max(1.0, osum.final_rmse)
     if eopt == 1:
@@ -96,7 +95,7 @@ def test_two_point_shards_reproduce_the_single_rank_solve():
     transport; every cross-rank reduction the solver issues is exercised"""
     sc = synth.ba_scene(n_cams=8, n_points=160, track_len=5, model=3, n_intr_groups=2, seed=92)
     opt = dict(max_num_iterations=3)
-    ref, rposes, rintr, rpts = _solve_emu(sc, 0, ba.default_options(**opt))
+    ref, rposes, rintr, rpts = _solve_emu(sc, ba.default_options(**opt))
     world = 2
     tr = _HostAllReduce(world)
     owner = sharding.assign_points(sc["obs_point"], sc["n_points"], world)
@@ -111,7 +110,7 @@ def test_two_point_shards_reproduce_the_single_rank_solve():
         c.close()
         out[rank] = (s, poses, intr, pts, mine)
 
-    with _emu.emulated(0):
+    with _emu.emulated():
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         for t in th:
             t.start()

