@@ -31,7 +31,8 @@ class Structure_Parameter_Type(IntFlag):
     ADJUST_ALL = 1
 
 
-N_INTR_PARAMS = {1: 3, 2: 4, 3: 6}  # PINHOLE_CAMERA, PINHOLE_CAMERA_RADIAL1, PINHOLE_CAMERA_RADIAL3
+# PINHOLE_CAMERA, _RADIAL1, _RADIAL3, _BROWN, _FISHEYE, CAMERA_SPHERICAL (no parameter block)
+N_INTR_PARAMS = {1: 3, 2: 4, 3: 6, 4: 8, 5: 7, 7: 0}
 
 
 def pose_const_mask(extrinsics_opt):

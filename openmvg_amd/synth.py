@@ -47,8 +47,8 @@ def random_descriptors(n_images, n_desc, seed=1):
 # every point observed by `track_len` consecutive cameras; observations = exact projection + N(0, noise_px);
 # initial state = ground truth perturbed (rotations N(0, rot_deg) angle-axis noise, centres and points N(0, 0.01)).
 # ---------------------------------------------------------------------------------------------------------
-CAM_PINHOLE, CAM_PINHOLE_RADIAL1, CAM_PINHOLE_RADIAL3 = 1, 2, 3
-_NPARAM = {1: 3, 2: 4, 3: 6}
+CAM_PINHOLE, CAM_PINHOLE_RADIAL1, CAM_PINHOLE_RADIAL3, CAM_PINHOLE_BROWN, CAM_PINHOLE_FISHEYE, CAM_SPHERICAL = 1, 2, 3, 4, 5, 7
+_NPARAM = {1: 3, 2: 4, 3: 6, 4: 8, 5: 7, 7: 0}
 
 
 def _rodrigues(aa):
@@ -71,17 +71,34 @@ def _rotmat_to_aa(R):
 
 
 def project(model, intr, pose, X):
-    """numpy restatement of the residual functors' projection (float64), vectorised over observations."""
+    """numpy restatement of the residual functors' projection (float64), vectorised over observations
+    (sfm_data_BA_ceres_camera_functor.hpp: pinhole, radial K1/K3, Brown T2, fisheye, spherical)."""
     R = _rodrigues(pose[:, :3])
     p = np.einsum("nij,nj->ni", R, X) + pose[:, 3:6]
+    if model == CAM_SPHERICAL:   # intr = {w, h}
+        lon = np.arctan2(p[:, 0], p[:, 2])
+        lat = np.arctan2(-p[:, 1], np.hypot(p[:, 0], p[:, 2]))
+        size = np.maximum(intr[:, 0], intr[:, 1])
+        return np.stack([lon / (2 * np.pi) * size + intr[:, 0] / 2, -lat / (2 * np.pi) * size + intr[:, 1] / 2], axis=1)
     u, v = p[:, 0] / p[:, 2], p[:, 1] / p[:, 2]
     r2 = u * u + v * v
-    c = np.ones_like(u)
-    if model >= CAM_PINHOLE_RADIAL1:
-        c = c + intr[:, 3] * r2
-    if model == CAM_PINHOLE_RADIAL3:
-        c = c + intr[:, 4] * r2 * r2 + intr[:, 5] * r2 * r2 * r2
-    return np.stack([intr[:, 1] + intr[:, 0] * u * c, intr[:, 2] + intr[:, 0] * v * c], axis=1)
+    xd, yd = u, v
+    if model in (CAM_PINHOLE_RADIAL1, CAM_PINHOLE_RADIAL3, CAM_PINHOLE_BROWN):
+        c = 1 + intr[:, 3] * r2
+        if model != CAM_PINHOLE_RADIAL1:
+            c = c + intr[:, 4] * r2 * r2 + intr[:, 5] * r2 * r2 * r2
+        xd, yd = u * c, v * c
+        if model == CAM_PINHOLE_BROWN:
+            t1, t2 = intr[:, 6], intr[:, 7]
+            xd = xd + t2 * (r2 + 2 * u * u) + 2 * t1 * u * v
+            yd = yd + t1 * (r2 + 2 * v * v) + 2 * t2 * u * v
+    elif model == CAM_PINHOLE_FISHEYE:
+        r = np.sqrt(r2)
+        th = np.arctan(r)
+        thd = th + intr[:, 3] * th ** 3 + intr[:, 4] * th ** 5 + intr[:, 5] * th ** 7 + intr[:, 6] * th ** 9
+        cd = np.where(r > 1e-8, thd / np.where(r > 1e-8, r, 1.0), 1.0)
+        xd, yd = u * cd, v * cd
+    return np.stack([intr[:, 1] + intr[:, 0] * xd, intr[:, 2] + intr[:, 0] * yd], axis=1)
 
 
 def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1, seed=0xBA5E0000,
@@ -112,8 +129,15 @@ def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1,
     intr_gt[:, 0] = 1000.0; intr_gt[:, 1] = 500.0; intr_gt[:, 2] = 500.0
     if model == CAM_PINHOLE_RADIAL1:
         intr_gt[:, 3] = k_gt[0]
-    if model == CAM_PINHOLE_RADIAL3:
+    if model in (CAM_PINHOLE_RADIAL3, CAM_PINHOLE_BROWN):
         intr_gt[:, 3:6] = k_gt
+    if model == CAM_PINHOLE_BROWN:
+        intr_gt[:, 6:8] = (0.002, -0.001)
+    if model == CAM_PINHOLE_FISHEYE:
+        intr_gt[:, 3:7] = (0.02, -0.004, 0.001, 0.0)
+    if model == CAM_SPHERICAL:       # no parameter block: the row carries the image size {w, h}
+        intr_gt[:, :] = 0.0
+        intr_gt[:, 0] = 2000.0; intr_gt[:, 1] = 1000.0
     cam_group = (np.arange(n_cams) * n_intr_groups) // n_cams
     X_gt = rng.uniform(-0.3, 0.3, size=(n_points, 3))
     # visibility: `track_len` consecutive cameras (ring-major order, wrapping) from a random start
@@ -132,7 +156,8 @@ def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1,
     C0 = C + center_sigma * rng.standard_normal(C.shape)
     poses0 = np.concatenate([_rotmat_to_aa(R0), -np.einsum("nij,nj->ni", R0, C0)], axis=1)
     intr0 = intr_gt.copy()
-    intr0[:, 3:] = 0.0
+    if model != CAM_SPHERICAL:
+        intr0[:, 3:] = 0.0
     X0 = X_gt + point_sigma * rng.standard_normal(X_gt.shape)
     return {
         "n_poses": n_cams, "n_intrinsics": n_intr_groups, "n_points": n_points, "n_obs": len(obs_point),
@@ -142,3 +167,47 @@ def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1,
         "poses_gt": poses_gt, "intrinsics_gt": intr_gt, "points_gt": X_gt, "n_intr_params": K,
         "huber_a": 16.0,
     }
+
+
+def add_control_points(scene, n_ctrl=6, views_per_point=4, weight=20.0, noise_px=0.0, seed=7):
+    """Ground control points (SfM_Data::control_points + Control_Point_Parameter(weight, true), sfm_data_BA.hpp:44-64,
+    sfm_data_BA_ceres.cpp:398-451): known 3-D positions, constant in the solve, observed in `views_per_point` images with
+    weighted, loss-free residuals. Appended to the flat problem as extra points / observations. Returns a new dict."""
+    rng = np.random.default_rng(seed)
+    sc = dict(scene)
+    n_poses, n_pts = int(scene["n_poses"]), int(scene["n_points"])
+    Xc = rng.uniform(-0.3, 0.3, size=(n_ctrl, 3))
+    cam_group = np.zeros(n_poses, np.uint32)
+    cam_group[scene["obs_pose"]] = scene["obs_intr"]
+    op = np.concatenate([rng.choice(n_poses, size=min(views_per_point, n_poses), replace=False) for _ in range(n_ctrl)]).astype(np.uint32)
+    ox = np.repeat(np.arange(n_ctrl, dtype=np.uint32), min(views_per_point, n_poses))
+    oi = cam_group[op]
+    model = int(scene["intr_model"][0])
+    xy = project(model, scene["intrinsics_gt"][oi], scene["poses_gt"][op], Xc[ox]) + noise_px * rng.standard_normal((len(op), 2))
+    sc["points"] = np.concatenate([scene["points"], Xc]); sc["points_gt"] = np.concatenate([scene["points_gt"], Xc])
+    sc["n_points"] = n_pts + n_ctrl
+    sc["obs_pose"] = np.concatenate([scene["obs_pose"], op]); sc["obs_intr"] = np.concatenate([scene["obs_intr"], oi])
+    sc["obs_point"] = np.concatenate([scene["obs_point"], ox + n_pts]).astype(np.uint32)
+    sc["obs_xy"] = np.concatenate([scene["obs_xy"], xy]); sc["n_obs"] = len(sc["obs_pose"])
+    n_old = int(scene["n_obs"])
+    sc["obs_weight"] = np.concatenate([np.zeros(n_old), np.full(len(op), float(weight))])
+    sc["obs_is_control"] = np.concatenate([np.zeros(n_old, np.uint8), np.ones(len(op), np.uint8)])
+    sc["point_const_mask"] = np.concatenate([np.zeros(n_pts, np.uint8), np.ones(n_ctrl, np.uint8)])
+    sc["n_structure_points"] = n_pts
+    sc["control_weight"] = float(weight)
+    return sc
+
+
+def add_pose_priors(scene, weight=(1.0, 1.0, 1.0), sigma=0.0, huber_a=0.0, seed=11, every=1):
+    """Pose-centre priors (ViewPriors::SetPoseCenterPrior, sfm_view_priors.hpp:55-63): prior centre = ground-truth centre
+    (+ N(0, sigma)), one per `every`-th pose. `huber_a` = Square(pose_center_robust_fitting_error) of the reference."""
+    rng = np.random.default_rng(seed)
+    sc = dict(scene)
+    Rgt = _rodrigues(scene["poses_gt"][:, :3])
+    Cgt = -np.einsum("nji,nj->ni", Rgt, scene["poses_gt"][:, 3:6])
+    idx = np.arange(0, int(scene["n_poses"]), every, dtype=np.uint32)
+    sc["prior_pose"] = idx
+    sc["prior_center"] = np.ascontiguousarray(Cgt[idx] + sigma * rng.standard_normal((len(idx), 3)))
+    sc["prior_weight"] = np.tile(np.asarray(weight, np.float64), (len(idx), 1))
+    sc["prior_huber_a"] = float(huber_a)
+    return sc

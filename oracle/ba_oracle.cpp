@@ -57,12 +57,22 @@ template <int N> Jet<N> operator-(double s, const Jet<N>& f) { return Jet<N>(s) 
 template <int N> Jet<N> operator*(const Jet<N>& f, double s) { Jet<N> h; h.a = f.a * s; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * s; return h; }
 template <int N> Jet<N> operator*(double s, const Jet<N>& f) { return f * s; }
 template <int N> Jet<N> operator/(double s, const Jet<N>& g) { return Jet<N>(s) / g; }
+template <int N> Jet<N> operator/(const Jet<N>& f, double s) { return f * (1.0 / s); }
 template <int N> bool operator>(const Jet<N>& f, const Jet<N>& g) { return f.a > g.a; }
 template <int N> Jet<N> sqrt(const Jet<N>& f) { Jet<N> h; h.a = std::sqrt(f.a); const double d = 1.0 / (2.0 * h.a); for (int i = 0; i < N; ++i) h.v[i] = f.v[i] * d; return h; }
 template <int N> Jet<N> sin(const Jet<N>& f) { Jet<N> h; h.a = std::sin(f.a); const double c = std::cos(f.a); for (int i = 0; i < N; ++i) h.v[i] = c * f.v[i]; return h; }
 template <int N> Jet<N> cos(const Jet<N>& f) { Jet<N> h; h.a = std::cos(f.a); const double s = -std::sin(f.a); for (int i = 0; i < N; ++i) h.v[i] = s * f.v[i]; return h; }
+// jet.h: atan, atan2(g, f) = atan(g / f) with the quadrant of (f, g)
+template <int N> Jet<N> atan(const Jet<N>& f) { Jet<N> h; h.a = std::atan(f.a); const double d = 1.0 / (1.0 + f.a * f.a); for (int i = 0; i < N; ++i) h.v[i] = d * f.v[i]; return h; }
+template <int N> Jet<N> atan2(const Jet<N>& g, const Jet<N>& f) {
+  Jet<N> h; h.a = std::atan2(g.a, f.a); const double t = 1.0 / (f.a * f.a + g.a * g.a);
+  for (int i = 0; i < N; ++i) h.v[i] = t * (-g.a * f.v[i] + f.a * g.v[i]);
+  return h;
+}
 inline double value_of(double x) { return x; }
 template <int N> double value_of(const Jet<N>& x) { return x.a; }
+using std::atan;
+using std::atan2;
 using std::cos;
 using std::sin;
 using std::sqrt;
@@ -95,17 +105,32 @@ int intr_param_count(int model) {
     case MVGX_CAM_PINHOLE: return 3;          // cameras/Camera_Pinhole.hpp:215-223 getParams {f, ppx, ppy}
     case MVGX_CAM_PINHOLE_RADIAL1: return 4;  // cameras/Camera_Pinhole_Radial.hpp K1: + k1
     case MVGX_CAM_PINHOLE_RADIAL3: return 6;  // cameras/Camera_Pinhole_Radial.hpp:340-348 K3: + k1 k2 k3
+    case MVGX_CAM_PINHOLE_BROWN: return 8;    // cameras/Camera_Pinhole_Brown.hpp getParams: + k1 k2 k3 t1 t2
+    case MVGX_CAM_PINHOLE_FISHEYE: return 7;  // cameras/Camera_Pinhole_Fisheye.hpp getParams: + k1 k2 k3 k4
+    case MVGX_CAM_SPHERICAL: return 0;        // cameras/Camera_Spherical.hpp: getParams() is empty; {w, h} are data
     default: return -1;
   }
 }
 
-// sfm/sfm_data_BA_ceres_camera_functor.hpp:124-164 (pinhole), :228-270 (radial K1), :337-382 (radial K3):
-// x_u = hnormalized(R(aa) X + t); r = pp + f * d(x_u) * x_u - obs, d = 1 + k1 r2 (+ k2 r4 + k3 r6)
+// sfm/sfm_data_BA_ceres_camera_functor.hpp:124-164 (pinhole), :228-270 (radial K1), :337-382 (radial K3),
+// :446-500 (Brown T2), :569-618 (fisheye), :681-711 (spherical):
+// x_u = hnormalized(R(aa) X + t); r = pp + f * distort(x_u) - obs
 template <typename T>
 void reprojection_residual(int model, const T* intr, const T* pose, const T* X, const double obs[2], T r[2]) {
   T p[3];
   angle_axis_rotate_point(pose, X, p);
   p[0] = p[0] + pose[3]; p[1] = p[1] + pose[4]; p[2] = p[2] + pose[5];
+  if (model == MVGX_CAM_SPHERICAL) {
+    // intr = {w, h} (image size, data): lon/lat of the bearing vector, normalised by 2 pi, scaled by max(w, h)
+    const double w = value_of(intr[0]), h = value_of(intr[1]);
+    const T lon = atan2(p[0], p[2]);
+    const T lat = atan2(-p[1], sqrt(p[0] * p[0] + p[2] * p[2]));
+    const T c0 = lon / (2 * M_PI), c1 = -lat / (2 * M_PI);
+    const double size = std::max(w, h);
+    r[0] = c0 * size + w / 2.0 - obs[0];
+    r[1] = c1 * size + h / 2.0 - obs[1];
+    return;
+  }
   const T u = p[0] / p[2], v = p[1] / p[2];
   const T& focal = intr[0];
   const T& ppx = intr[1];
@@ -118,14 +143,44 @@ void reprojection_residual(int model, const T* intr, const T* pose, const T* X, 
     const T coeff = T(1.0) + intr[3] * r2;
     r[0] = ppx + (u * coeff) * focal - obs[0];
     r[1] = ppy + (v * coeff) * focal - obs[1];
-  } else {
+  } else if (model == MVGX_CAM_PINHOLE_RADIAL3) {
     const T r2 = u * u + v * v;
     const T r4 = r2 * r2;
     const T r6 = r4 * r2;
     const T coeff = T(1.0) + intr[3] * r2 + intr[4] * r4 + intr[5] * r6;
     r[0] = ppx + (u * coeff) * focal - obs[0];
     r[1] = ppy + (v * coeff) * focal - obs[1];
+  } else if (model == MVGX_CAM_PINHOLE_BROWN) {
+    const T& k1 = intr[3]; const T& k2 = intr[4]; const T& k3 = intr[5]; const T& t1 = intr[6]; const T& t2 = intr[7];
+    const T r2 = u * u + v * v;
+    const T r4 = r2 * r2;
+    const T r6 = r4 * r2;
+    const T r_coeff = T(1.0) + k1 * r2 + k2 * r4 + k3 * r6;
+    const T t_x = t2 * (r2 + 2.0 * u * u) + 2.0 * t1 * u * v;
+    const T t_y = t1 * (r2 + 2.0 * v * v) + 2.0 * t2 * u * v;
+    r[0] = ppx + (u * r_coeff + t_x) * focal - obs[0];
+    r[1] = ppy + (v * r_coeff + t_y) * focal - obs[1];
+  } else {  // MVGX_CAM_PINHOLE_FISHEYE
+    const T& k1 = intr[3]; const T& k2 = intr[4]; const T& k3 = intr[5]; const T& k4 = intr[6];
+    const T r2 = u * u + v * v;
+    const T rr = sqrt(r2);
+    const T theta = atan(rr), theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta,
+            theta7 = theta3 * theta3 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+    const T theta_dist = theta + k1 * theta3 + k2 * theta5 + k3 * theta7 + k4 * theta9;
+    const T inv_r = rr > T(1e-8) ? T(1.0) / rr : T(1.0);
+    const T cdist = rr > T(1e-8) ? theta_dist * inv_r : T(1.0);
+    r[0] = ppx + (u * cdist) * focal - obs[0];
+    r[1] = ppy + (v * cdist) * focal - obs[1];
   }
+}
+
+// PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): weight o (-(R(-aa) t) - prior centre)
+template <typename T>
+void pose_center_residual(const T* pose, const double center[3], const double weight[3], T r[3]) {
+  const T neg[3] = {-pose[0], -pose[1], -pose[2]};
+  T c[3];
+  angle_axis_rotate_point(neg, pose + 3, c);
+  for (int k = 0; k < 3; ++k) r[k] = (c[k] * -1.0 - center[k]) * weight[k];
 }
 
 constexpr int kJetN = 8 + 6 + 3;  // intrinsics (<= 8) | pose (6) | point (3)
@@ -136,7 +191,7 @@ void eval_obs_autodiff(int model, const double* intr, const double* pose, const 
   typedef Jet<kJetN> J;
   J ji[8], jc[6], jx[3], jr[2];
   const int K = intr_param_count(model);
-  for (int k = 0; k < 8; ++k) ji[k] = (k < K) ? J(intr[k], k) : J(0.0);
+  for (int k = 0; k < 8; ++k) ji[k] = (k < K) ? J(intr[k], k) : J(intr[k]);   // beyond K: data (spherical {w, h}), no partials
   for (int k = 0; k < 6; ++k) jc[k] = J(pose[k], 8 + k);
   for (int k = 0; k < 3; ++k) jx[k] = J(X[k], 14 + k);
   reprojection_residual<J>(model, ji, jc, jx, obs, jr);
@@ -149,9 +204,9 @@ void eval_obs_autodiff(int model, const double* intr, const double* pose, const 
 }
 
 // ceres/internal/ceres/loss_function.cc:47-61 — HuberLoss(a): b = a^2
-void huber(double a, double s, double rho[3]) {
+void huber_on(bool loss, double a, double s, double rho[3]) {
   const double b = a * a;
-  if (a > 0.0 && s > b) {
+  if (loss && s > b) {
     const double r = std::sqrt(s);
     rho[0] = 2.0 * a * r - b;
     rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
@@ -160,6 +215,7 @@ void huber(double a, double s, double rho[3]) {
     rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
   }
 }
+void huber(double a, double s, double rho[3]) { huber_on(a > 0.0, a, s, rho); }   // a <= 0: problem built without a loss function
 
 struct Problem {
   uint32_t n_poses = 0, n_intr = 0, n_points = 0;
@@ -171,6 +227,16 @@ struct Problem {
   std::vector<uint8_t> pose_mask, intr_mask;
   bool points_constant = false;
   double huber_a = 0;
+  std::vector<double> oweight;          // per observation (empty: all unweighted)
+  std::vector<uint8_t> octrl;           // per observation: control-point residual (no loss, not in the RMSE)
+  std::vector<uint8_t> point_const;     // per point: SetParameterBlockConstant
+  std::vector<uint32_t> prior_pose;     // pose-centre priors
+  std::vector<double> prior_center, prior_weight;
+  double prior_huber_a = 0;
+  uint64_t n_obs_rmse = 0;
+  bool is_const(uint32_t j) const { return points_constant || (!point_const.empty() && point_const[j]); }
+  double weight(uint64_t k) const { return (!oweight.empty() && oweight[k] != 0.0) ? oweight[k] : 1.0; }
+  bool ctrl(uint64_t k) const { return !octrl.empty() && octrl[k]; }
   // derived: local columns
   std::vector<int> pose_col, intr_col;             // first reduced-system column of the block or -1 (constant / unused)
   std::vector<std::vector<int>> pose_free, intr_free;  // free component indices of each block
@@ -195,6 +261,17 @@ bool load(const mvgx_ba_problem* p, Problem& P) {
   if (p->intr_const_mask) P.intr_mask.assign(p->intr_const_mask, p->intr_const_mask + P.n_intr);
   P.points_constant = p->points_constant != 0;
   P.huber_a = p->huber_a;
+  if (p->obs_weight) P.oweight.assign(p->obs_weight, p->obs_weight + P.n_obs);
+  if (p->obs_is_control) P.octrl.assign(p->obs_is_control, p->obs_is_control + P.n_obs);
+  if (p->point_const_mask) P.point_const.assign(p->point_const_mask, p->point_const_mask + P.n_points);
+  if (p->n_pose_priors) {
+    P.prior_pose.assign(p->prior_pose, p->prior_pose + p->n_pose_priors);
+    P.prior_center.assign(p->prior_center, p->prior_center + 3 * size_t(p->n_pose_priors));
+    P.prior_weight.assign(p->prior_weight, p->prior_weight + 3 * size_t(p->n_pose_priors));
+    P.prior_huber_a = p->prior_huber_a;
+  }
+  P.n_obs_rmse = 0;
+  for (uint64_t k = 0; k < P.n_obs; ++k) if (!P.ctrl(k)) ++P.n_obs_rmse;
   for (uint32_t i = 0; i < P.n_intr; ++i) if (intr_param_count(P.model[i]) < 0) return false;
   // Blocks no residual references are dropped by Ceres' preprocessor (program.cc RemoveFixedBlocks), like constants.
   std::vector<uint8_t> pose_used(P.n_poses, 0), intr_used(P.n_intr, 0);
@@ -205,6 +282,7 @@ bool load(const mvgx_ba_problem* p, Problem& P) {
     pose_used[P.op[k]] = 1; intr_used[P.oi[k]] = 1; P.point_used[P.ox[k]] = 1;
     P.obs_of_point[P.ox[k]].push_back(k);
   }
+  for (uint32_t q : P.prior_pose) { if (q >= P.n_poses) return false; pose_used[q] = 1; }
   // reduced camera system column layout: poses in index order, then intrinsics
   P.pose_col.assign(P.n_poses, -1); P.intr_col.assign(P.n_intr, -1);
   P.pose_free.assign(P.n_poses, {}); P.intr_free.assign(P.n_intr, {});
@@ -219,7 +297,7 @@ bool load(const mvgx_ba_problem* p, Problem& P) {
     if (!intr_used[i]) continue;
     const int K = intr_param_count(P.model[i]);
     for (int c = 0; c < K; ++c) if (!((P.intr_mask[i] >> c) & 1)) P.intr_free[i].push_back(c);
-    if (P.intr_free[i].empty()) continue;
+    if (P.intr_free[i].empty()) continue;   // constant, or no parameter block at all (spherical)
     P.intr_col[i] = col; col += int(P.intr_free[i].size());
   }
   P.ncols = col;
@@ -233,6 +311,42 @@ struct ObsLin {           // one residual block after ResidualBlock::Evaluate (c
   double Fi[16];          // 2 x 8 intrinsic Jacobian
 };
 
+struct PriorLin { double r[3]; double Fc[18]; };   // pose-centre prior: corrected residual and 3 x 6 pose Jacobian
+
+double prior_cost(const Problem& P, const std::vector<double>& poses) {
+  double c = 0;
+  for (size_t q = 0; q < P.prior_pose.size(); ++q) {
+    double r[3];
+    pose_center_residual<double>(&poses[size_t(P.prior_pose[q]) * 6], &P.prior_center[3 * q], &P.prior_weight[3 * q], r);
+    double rho[3];
+    huber_on(true, P.prior_huber_a, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho);
+    c += 0.5 * rho[0];
+  }
+  return c;
+}
+
+double linearize_priors(const Problem& P, const std::vector<double>& poses, std::vector<PriorLin>& L) {
+  typedef Jet<6> J;
+  L.resize(P.prior_pose.size());
+  double c = 0;
+  for (size_t q = 0; q < P.prior_pose.size(); ++q) {
+    const double* pose = &poses[size_t(P.prior_pose[q]) * 6];
+    J jp[6], jr[3];
+    for (int k = 0; k < 6; ++k) jp[k] = J(pose[k], k);
+    pose_center_residual<J>(jp, &P.prior_center[3 * q], &P.prior_weight[3 * q], jr);
+    PriorLin& o = L[q];
+    double s = 0;
+    for (int k = 0; k < 3; ++k) { o.r[k] = jr[k].a; s += o.r[k] * o.r[k]; for (int cc = 0; cc < 6; ++cc) o.Fc[k * 6 + cc] = jr[k].v[cc]; }
+    double rho[3];
+    huber_on(true, P.prior_huber_a, s, rho);
+    c += 0.5 * rho[0];
+    const double sr = std::sqrt(rho[1]);   // rho'' <= 0: Corrector scales residual and Jacobian by sqrt(rho') (corrector.cc:81-85)
+    for (int k = 0; k < 3; ++k) o.r[k] *= sr;
+    for (int k = 0; k < 18; ++k) o.Fc[k] *= sr;
+  }
+  return c;
+}
+
 // Cost only: 0.5 * rho(|r|^2) summed (residual_block.cc:168-176); also the loss-free squared error for the RMSE.
 void evaluate_cost(const Problem& P, const std::vector<double>& poses, const std::vector<double>& intr,
                    const std::vector<double>& points, double* cost, double* sq_err) {
@@ -241,12 +355,15 @@ void evaluate_cost(const Problem& P, const std::vector<double>& poses, const std
     double r[2];
     reprojection_residual<double>(P.model[P.oi[k]], &intr[size_t(P.oi[k]) * 8], &poses[size_t(P.op[k]) * 6],
                                   &points[size_t(P.ox[k]) * 3], &P.oxy[2 * k], r);
+    const double w = P.weight(k);   // WeightedCostFunction (camera_functor.hpp:35-90)
+    r[0] *= w; r[1] *= w;
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3];
-    huber(P.huber_a, s, rho);
+    huber_on(!P.ctrl(k) && P.huber_a > 0.0, P.huber_a, s, rho);   // control-point blocks carry no loss (:421-435)
     c += 0.5 * rho[0];
-    se += s;
+    if (!P.ctrl(k)) se += s;
   }
+  c += prior_cost(P, poses);
   *cost = c; *sq_err = se;
 }
 
@@ -259,9 +376,16 @@ void linearize(const Problem& P, const std::vector<double>& poses, const std::ve
     ObsLin& o = L[k];
     eval_obs_autodiff(P.model[P.oi[k]], &intr[size_t(P.oi[k]) * 8], &poses[size_t(P.op[k]) * 6],
                       &points[size_t(P.ox[k]) * 3], &P.oxy[2 * k], o.r, o.Fi, o.Fc, o.E);
+    const double w = P.weight(k);
+    if (w != 1.0) {
+      o.r[0] *= w; o.r[1] *= w;
+      for (double& v : o.E) v *= w;
+      for (double& v : o.Fc) v *= w;
+      for (double& v : o.Fi) v *= w;
+    }
     const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
     double rho[3];
-    huber(P.huber_a, s, rho);
+    huber_on(!P.ctrl(k) && P.huber_a > 0.0, P.huber_a, s, rho);
     c += 0.5 * rho[0];
     const double sqrt_rho1 = std::sqrt(rho[1]);
     double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
@@ -344,6 +468,7 @@ struct Solver {
   std::vector<double> poses, intr, points;       // x_
   std::vector<double> cposes, cintr, cpoints;    // candidate_x_
   std::vector<ObsLin> L;                         // Jacobian at x_ (unscaled, loss-corrected)
+  std::vector<PriorLin> LP;                      // rows of the pose-centre priors
   std::vector<double> scale_cam, scale_pt;       // jacobian_scaling_ (trust_region_minimizer.cc:239-254)
   std::vector<double> diag_cam, diag_pt;         // LM `diagonal_` (levenberg_marquardt_strategy.cc:75-87), already clamped
   std::vector<double> step_cam, step_pt;         // trust_region_step_ (scaled space)
@@ -374,18 +499,28 @@ struct Solver {
           const double j0 = o.Fi[gc] * s, j1 = o.Fi[8 + gc] * s;
           n_cam[col] += j0 * j0 + j1 * j1; g_cam[col] += j0 * o.r[0] + j1 * o.r[1];
         }
-      if (!P.points_constant)
+      if (!P.is_const(ix))
         for (int c = 0; c < 3; ++c) {
           const double s = scaled ? scale_pt[size_t(ix) * 3 + c] : 1.0;
           const double j0 = o.E[c] * s, j1 = o.E[3 + c] * s;
           n_pt[size_t(ix) * 3 + c] += j0 * j0 + j1 * j1; g_pt[size_t(ix) * 3 + c] += j0 * o.r[0] + j1 * o.r[1];
         }
     }
+    for (size_t q = 0; q < LP.size(); ++q) {   // prior rows: 3 residuals on one pose block
+      const uint32_t ip = P.prior_pose[q];
+      if (P.pose_col[ip] < 0) continue;
+      for (size_t c = 0; c < P.pose_free[ip].size(); ++c) {
+        const int gc = P.pose_free[ip][c], col = P.pose_col[ip] + int(c);
+        const double s = scaled ? scale_cam[col] : 1.0;
+        for (int k = 0; k < 3; ++k) { const double j = LP[q].Fc[k * 6 + gc] * s; n_cam[col] += j * j; g_cam[col] += j * LP[q].r[k]; }
+      }
+    }
   }
 
   // TrustRegionMinimizer::EvaluateGradientAndJacobian (trust_region_minimizer.cc:226-279)
   void evaluate_gradient_and_jacobian(bool iteration_zero) {
     linearize(P, poses, intr, points, L, &x_cost);
+    x_cost += linearize_priors(P, poses, LP);
     std::vector<double> n_cam, n_pt, g_cam, g_pt;
     column_norms_and_gradient(false, n_cam, n_pt, g_cam, g_pt);
     if (iteration_zero) {
@@ -397,9 +532,8 @@ struct Solver {
     }
     gradient_max_norm = 0;  // |Plus(x,-g) - x|_inf = max |g| over the free components
     for (double g : g_cam) gradient_max_norm = std::max(gradient_max_norm, std::fabs(g));
-    if (!P.points_constant)
-      for (uint32_t j = 0; j < P.n_points; ++j)
-        if (P.point_used[j]) for (int c = 0; c < 3; ++c) gradient_max_norm = std::max(gradient_max_norm, std::fabs(g_pt[size_t(j) * 3 + c]));
+    for (uint32_t j = 0; j < P.n_points; ++j)
+      if (P.point_used[j] && !P.is_const(j)) for (int c = 0; c < 3; ++c) gradient_max_norm = std::max(gradient_max_norm, std::fabs(g_pt[size_t(j) * 3 + c]));
   }
 
   // LevenbergMarquardtStrategy::ComputeStep (levenberg_marquardt_strategy.cc:65-145) with the Schur-complement solver
@@ -436,7 +570,7 @@ struct Solver {
     for (uint32_t j = 0; j < P.n_points; ++j) {
       const auto& obs = P.obs_of_point[j];
       if (obs.empty()) continue;
-      if (P.points_constant) {  // no e-block: NoEBlockRowsUpdate (:556-576): S += F^T F, rhs += F^T b
+      if (P.is_const(j)) {  // no e-block: NoEBlockRowsUpdate (:556-576): S += F^T F, rhs += F^T b
         for (uint64_t k : obs) {
           double Fs[32]; int cols[16]; int nl;
           scaled_row(L[k], k, Fs, cols, nl);
@@ -483,6 +617,18 @@ struct Solver {
           S[size_t(ycols[b]) * n + ycols[a]] -= Y[b * 3] * T[0] + Y[b * 3 + 1] * T[1] + Y[b * 3 + 2] * T[2];
       }
     }
+    for (size_t q = 0; q < LP.size(); ++q) {   // prior rows have no e-block either: S += F^T F, rhs += F^T b
+      const uint32_t ip = P.prior_pose[q];
+      if (P.pose_col[ip] < 0) continue;
+      for (size_t a = 0; a < P.pose_free[ip].size(); ++a) {
+        const int ca = P.pose_col[ip] + int(a), ga = P.pose_free[ip][a];
+        for (int k = 0; k < 3; ++k) rhs[ca] += LP[q].Fc[k * 6 + ga] * scale_cam[ca] * LP[q].r[k];
+        for (size_t b = 0; b < P.pose_free[ip].size(); ++b) {
+          const int cb = P.pose_col[ip] + int(b), gb = P.pose_free[ip][b];
+          for (int k = 0; k < 3; ++k) S[size_t(ca) * n + cb] += LP[q].Fc[k * 6 + ga] * scale_cam[ca] * LP[q].Fc[k * 6 + gb] * scale_cam[cb];
+        }
+      }
+    }
     step_cam.assign(n, 0.0);
     if (n > 0) {
       std::vector<double> z = rhs;
@@ -491,10 +637,9 @@ struct Solver {
     }
     // BackSubstitute (:303-366): y_p = (E^T E + D^2)^-1 (E^T b - E^T F z)
     step_pt.assign(size_t(P.n_points) * 3, 0.0);
-    if (!P.points_constant)
       for (uint32_t j = 0; j < P.n_points; ++j) {
         const auto& obs = P.obs_of_point[j];
-        if (obs.empty()) continue;
+        if (obs.empty() || P.is_const(j)) continue;
         double t[3] = {gpt[size_t(j) * 3], gpt[size_t(j) * 3 + 1], gpt[size_t(j) * 3 + 2]};
         for (uint64_t k : obs) {
           const ObsLin& o = L[k];
@@ -520,7 +665,7 @@ struct Solver {
       scaled_row(o, k, Fs, cols, nl);
       double m0 = 0, m1 = 0;
       for (int a = 0; a < nl; ++a) { m0 += Fs[a] * step_cam[cols[a]]; m1 += Fs[16 + a] * step_cam[cols[a]]; }
-      if (!P.points_constant) {
+      if (!P.is_const(P.ox[k])) {
         const uint32_t j = P.ox[k];
         for (int c = 0; c < 3; ++c) {
           const double s = scale_pt[size_t(j) * 3 + c] * step_pt[size_t(j) * 3 + c];
@@ -528,6 +673,18 @@ struct Solver {
         }
       }
       mc -= m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0);
+    }
+    for (size_t q = 0; q < LP.size(); ++q) {
+      const uint32_t ip = P.prior_pose[q];
+      if (P.pose_col[ip] < 0) continue;
+      for (int k = 0; k < 3; ++k) {
+        double m = 0;
+        for (size_t a = 0; a < P.pose_free[ip].size(); ++a) {
+          const int ca = P.pose_col[ip] + int(a);
+          m += LP[q].Fc[k * 6 + P.pose_free[ip][a]] * scale_cam[ca] * step_cam[ca];
+        }
+        mc -= m * (LP[q].r[k] + m / 2.0);
+      }
     }
     model_cost_change = mc;
     return true;
@@ -555,9 +712,8 @@ struct Solver {
       }
       for (int c = 0; c < intr_param_count(P.model[i]); ++c) xn += intr[size_t(i) * 8 + c] * intr[size_t(i) * 8 + c];
     }
-    if (!P.points_constant)
       for (uint32_t j = 0; j < P.n_points; ++j) {
-        if (!P.point_used[j]) continue;
+        if (!P.point_used[j] || P.is_const(j)) continue;
         for (int c = 0; c < 3; ++c) {
           const double d = step_pt[size_t(j) * 3 + c] * scale_pt[size_t(j) * 3 + c];
           cpoints[size_t(j) * 3 + c] += d; sn += d * d;
@@ -579,6 +735,15 @@ int oracle_ba_eval_obs(int model, const double* intr, const double* pose, const 
   return 0;
 }
 
+int oracle_ba_eval_prior(const double* pose, const double* center, const double* weight, double* r, double* Jc) {
+  typedef Jet<6> J;
+  J jp[6], jr[3];
+  for (int k = 0; k < 6; ++k) jp[k] = J(pose[k], k);
+  pose_center_residual<J>(jp, center, weight, jr);
+  for (int k = 0; k < 3; ++k) { r[k] = jr[k].a; for (int c = 0; c < 6; ++c) Jc[k * 6 + c] = jr[k].v[c]; }
+  return 0;
+}
+
 // cost = 1/2 sum rho(|r|^2) (Ceres cost), rmse = sqrt(sum |r|^2 / (2 n_obs)) (sfm_data_BA_test.cpp:310-330)
 int oracle_ba_evaluate(const mvgx_ba_problem* prob, double* cost, double* rmse) {
   Problem P;
@@ -586,7 +751,7 @@ int oracle_ba_evaluate(const mvgx_ba_problem* prob, double* cost, double* rmse) 
   double c, se;
   evaluate_cost(P, P.poses, P.intr, P.points, &c, &se);
   *cost = c;
-  *rmse = P.n_obs ? std::sqrt(se / (2.0 * double(P.n_obs))) : 0.0;
+  *rmse = P.n_obs_rmse ? std::sqrt(se / (2.0 * double(P.n_obs_rmse))) : 0.0;
   return 0;
 }
 
@@ -602,7 +767,7 @@ int oracle_ba_solve(const mvgx_ba_problem* prob, const mvgx_ba_options* options,
   std::memset(sum, 0, sizeof(*sum));
   double c0, se0;
   evaluate_cost(P, S.poses, S.intr, S.points, &c0, &se0);
-  sum->initial_rmse = P.n_obs ? std::sqrt(se0 / (2.0 * double(P.n_obs))) : 0.0;
+  sum->initial_rmse = P.n_obs_rmse ? std::sqrt(se0 / (2.0 * double(P.n_obs_rmse))) : 0.0;
   S.evaluate_gradient_and_jacobian(true);  // IterationZero (:177-212)
   sum->initial_cost = S.x_cost;
   sum->termination = 1;  // NO_CONVERGENCE until proven otherwise
@@ -658,7 +823,7 @@ int oracle_ba_solve(const mvgx_ba_problem* prob, const mvgx_ba_options* options,
   sum->final_cost = S.x_cost;
   double c1, se1;
   evaluate_cost(P, S.poses, S.intr, S.points, &c1, &se1);
-  sum->final_rmse = P.n_obs ? std::sqrt(se1 / (2.0 * double(P.n_obs))) : 0.0;
+  sum->final_rmse = P.n_obs_rmse ? std::sqrt(se1 / (2.0 * double(P.n_obs_rmse))) : 0.0;
   if (poses_out) std::memcpy(poses_out, S.poses.data(), S.poses.size() * sizeof(double));
   if (intr_out) std::memcpy(intr_out, S.intr.data(), S.intr.size() * sizeof(double));
   if (points_out) std::memcpy(points_out, S.points.data(), S.points.size() * sizeof(double));

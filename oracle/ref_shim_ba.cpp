@@ -7,7 +7,9 @@
 // The RMSE helper restates sfm_data_BA_test.cpp:310-330 using the reference's own IntrinsicBase::residual.
 #include <chrono>
 #include <cmath>
+#include <algorithm>
 #include <cstdint>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -16,11 +18,20 @@
 
 #include "openMVG/cameras/Camera_Common.hpp"
 #include "openMVG/cameras/Camera_Pinhole.hpp"
+#include "openMVG/cameras/Camera_Pinhole_Brown.hpp"
+#include "openMVG/cameras/Camera_Pinhole_Fisheye.hpp"
 #include "openMVG/cameras/Camera_Pinhole_Radial.hpp"
+#include "openMVG/cameras/Camera_Spherical.hpp"
+#include "openMVG/geometry/Similarity3.hpp"
+#include "openMVG/geometry/Similarity3_Kernel.hpp"
 #include "openMVG/geometry/pose3.hpp"
+#include "openMVG/robust_estimation/robust_estimator_LMeds.hpp"
 #include "openMVG/sfm/sfm_data.hpp"
 #include "openMVG/sfm/sfm_data_BA.hpp"
 #include "openMVG/sfm/sfm_data_BA_ceres.hpp"
+#include "openMVG/sfm/sfm_data_transform.hpp"
+#include "openMVG/sfm/sfm_view.hpp"
+#include "openMVG/sfm/sfm_view_priors.hpp"
 
 using namespace openMVG;
 using namespace openMVG::sfm;
@@ -45,37 +56,41 @@ double rmse_of(const SfM_Data& sfm_data) {
   return n ? std::sqrt(ss / double(n)) : 0.0;
 }
 
-}  // namespace
+// ---- flat arrays <-> SfM_Data (layout of mvgx_ba_problem in include/mvgx.h) ----
+struct Extras {          // optional inputs of ref_ba_adjust_ex; all pointers may be null
+  uint32_t n_ctrl_points = 0;         // control points (SfM_Data::control_points): constant 3-D points ...
+  const double* ctrl_X = nullptr;     // n_ctrl_points x 3
+  uint64_t n_ctrl_obs = 0;            // ... with weighted image observations
+  const uint32_t* ctrl_obs_pose = nullptr;
+  const uint32_t* ctrl_obs_point = nullptr;
+  const double* ctrl_obs_xy = nullptr;
+  double ctrl_weight = 0.0;
+  int use_control_points = 0;
+  const uint8_t* prior_flag = nullptr;   // n_poses: the view is a ViewPriors with a pose-centre prior
+  const double* prior_center = nullptr;  // n_poses x 3
+  const double* prior_weight = nullptr;  // n_poses x 3
+  int use_motion_priors = 0;
+};
 
-extern "C" {
-
-// poses: n_poses x 6 (angle-axis, t = -R C), intrinsics: n_intr x 8, points: n_points x 3 — all updated in place.
-// Each pose becomes one View (view id = pose id) using the intrinsic of its first observation.
-// intrinsics_opt / extrinsics_opt / structure_opt: numeric values of the openMVG option enums.
-// linear_solver: 0 = reference default (SPARSE_SCHUR + EIGEN_SPARSE here), 1 = DENSE_SCHUR, 2 = SPARSE_SCHUR.
-// out_stats[0..3] = {rmse_before, rmse_after, seconds in Adjust(), Adjust() return value}.
-int ref_ba_adjust(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, double* poses,
-                  double* intrinsics, const int32_t* intr_model, double* points, const uint32_t* obs_pose,
-                  const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, int intrinsics_opt,
-                  int extrinsics_opt, int structure_opt, int max_iterations, int num_threads, int linear_solver,
-                  int use_loss, int print_summary, double* out_stats) {
-  SfM_Data scene;
+int build_scene(SfM_Data& scene, uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, const Extras& ex) {
   std::vector<int64_t> pose_intr(n_poses, -1);
   for (uint64_t k = 0; k < n_obs; ++k)
     if (pose_intr[obs_pose[k]] < 0) pose_intr[obs_pose[k]] = obs_intr[k];
   for (uint64_t k = 0; k < n_obs; ++k)
     if (pose_intr[obs_pose[k]] != int64_t(obs_intr[k])) return -2;  // a pose seen through two intrinsics: not a View
-
   for (uint32_t i = 0; i < n_intr; ++i) {
     const double* p = intrinsics + size_t(i) * 8;
-    if (intr_model[i] == PINHOLE_CAMERA)
-      scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic>(1000, 1000, p[0], p[1], p[2]);
-    else if (intr_model[i] == PINHOLE_CAMERA_RADIAL1)
-      scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Radial_K1>(1000, 1000, p[0], p[1], p[2], p[3]);
-    else if (intr_model[i] == PINHOLE_CAMERA_RADIAL3)
-      scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Radial_K3>(1000, 1000, p[0], p[1], p[2], p[3], p[4], p[5]);
-    else
-      return -3;
+    switch (intr_model[i]) {
+      case PINHOLE_CAMERA: scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic>(1000, 1000, p[0], p[1], p[2]); break;
+      case PINHOLE_CAMERA_RADIAL1: scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Radial_K1>(1000, 1000, p[0], p[1], p[2], p[3]); break;
+      case PINHOLE_CAMERA_RADIAL3: scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Radial_K3>(1000, 1000, p[0], p[1], p[2], p[3], p[4], p[5]); break;
+      case PINHOLE_CAMERA_BROWN: scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Brown_T2>(1000, 1000, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]); break;
+      case PINHOLE_CAMERA_FISHEYE: scene.intrinsics[i] = std::make_shared<Pinhole_Intrinsic_Fisheye>(1000, 1000, p[0], p[1], p[2], p[3], p[4], p[5], p[6]); break;
+      case CAMERA_SPHERICAL: scene.intrinsics[i] = std::make_shared<Intrinsic_Spherical>(static_cast<unsigned>(p[0]), static_cast<unsigned>(p[1])); break;
+      default: return -3;
+    }
   }
   for (uint32_t i = 0; i < n_poses; ++i) {
     const double* p = poses + size_t(i) * 6;
@@ -85,33 +100,29 @@ int ref_ba_adjust(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t
     const Vec3 C = -R.transpose() * t;
     scene.poses[i] = Pose3(R, C);
     const IndexT intr_id = pose_intr[i] < 0 ? 0 : IndexT(pose_intr[i]);
-    scene.views[i] = std::make_shared<View>("", i, intr_id, i, 1000, 1000);
+    if (ex.prior_flag && ex.prior_flag[i]) {
+      auto v = std::make_shared<ViewPriors>("", i, intr_id, i, 1000, 1000);
+      v->SetPoseCenterPrior(Vec3(ex.prior_center[3 * i], ex.prior_center[3 * i + 1], ex.prior_center[3 * i + 2]),
+                            Vec3(ex.prior_weight[3 * i], ex.prior_weight[3 * i + 1], ex.prior_weight[3 * i + 2]));
+      scene.views[i] = v;
+    } else {
+      scene.views[i] = std::make_shared<View>("", i, intr_id, i, 1000, 1000);
+    }
   }
   for (uint32_t j = 0; j < n_points; ++j)
     scene.structure[j].X = Vec3(points[3 * size_t(j)], points[3 * size_t(j) + 1], points[3 * size_t(j) + 2]);
   for (uint64_t k = 0; k < n_obs; ++k)
     scene.structure[obs_point[k]].obs[obs_pose[k]] = Observation(Vec2(obs_xy[2 * k], obs_xy[2 * k + 1]), IndexT(k));
+  for (uint32_t j = 0; j < ex.n_ctrl_points; ++j)
+    scene.control_points[j].X = Vec3(ex.ctrl_X[3 * size_t(j)], ex.ctrl_X[3 * size_t(j) + 1], ex.ctrl_X[3 * size_t(j) + 2]);
+  for (uint64_t k = 0; k < ex.n_ctrl_obs; ++k)
+    scene.control_points[ex.ctrl_obs_point[k]].obs[ex.ctrl_obs_pose[k]] =
+        Observation(Vec2(ex.ctrl_obs_xy[2 * k], ex.ctrl_obs_xy[2 * k + 1]), IndexT(k));
+  return 0;
+}
 
-  out_stats[0] = rmse_of(scene);
-
-  Bundle_Adjustment_Ceres::BA_Ceres_options opt(false, num_threads != 1);
-  if (num_threads > 0) opt.nb_threads_ = unsigned(num_threads);
-  opt.bCeres_summary_ = print_summary != 0;
-  opt.bUse_loss_function_ = use_loss != 0;
-  if (max_iterations > 0) opt.max_num_iterations_ = max_iterations;
-  if (linear_solver == 1) opt.linear_solver_type_ = ceres::DENSE_SCHUR;
-  if (linear_solver == 2) opt.linear_solver_type_ = ceres::SPARSE_SCHUR;
-  Bundle_Adjustment_Ceres ba(opt);
-  const Optimize_Options oo(static_cast<Intrinsic_Parameter_Type>(intrinsics_opt),
-                            static_cast<Extrinsic_Parameter_Type>(extrinsics_opt),
-                            static_cast<Structure_Parameter_Type>(structure_opt != 0));
-  const auto t0 = std::chrono::steady_clock::now();
-  const bool ok = ba.Adjust(scene, oo);
-  const auto t1 = std::chrono::steady_clock::now();
-  out_stats[2] = std::chrono::duration<double>(t1 - t0).count();
-  out_stats[3] = ok ? 1.0 : 0.0;
-  out_stats[1] = rmse_of(scene);
-
+void flatten_scene(const SfM_Data& scene, uint32_t n_poses, uint32_t n_intr, uint32_t n_points, double* poses, double* intrinsics,
+                   double* points) {
   for (uint32_t i = 0; i < n_poses; ++i) {
     const Pose3& pose = scene.poses.at(i);
     const Mat3 R = pose.rotation();
@@ -128,7 +139,113 @@ int ref_ba_adjust(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t
     const Vec3& X = scene.structure.at(j).X;
     points[3 * size_t(j)] = X(0); points[3 * size_t(j) + 1] = X(1); points[3 * size_t(j) + 2] = X(2);
   }
+}
+
+}  // namespace
+
+extern "C" {
+
+// poses: n_poses x 6 (angle-axis, t = -R C), intrinsics: n_intr x 8, points: n_points x 3 — all updated in place.
+// Each pose becomes one View (view id = pose id) using the intrinsic of its first observation.
+// intrinsics_opt / extrinsics_opt / structure_opt: numeric values of the openMVG option enums.
+// linear_solver: 0 = reference default (SPARSE_SCHUR + EIGEN_SPARSE here), 1 = DENSE_SCHUR, 2 = SPARSE_SCHUR.
+// ex (may be null): control points / pose-centre priors, see struct Extras above (same layout on the Python side).
+// out_stats[0..3] = {rmse_before, rmse_after, seconds in Adjust(), Adjust() return value}.
+int ref_ba_adjust_ex(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, double* poses,
+                     double* intrinsics, const int32_t* intr_model, double* points, const uint32_t* obs_pose,
+                     const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, int intrinsics_opt,
+                     int extrinsics_opt, int structure_opt, int max_iterations, int num_threads, int linear_solver,
+                     int use_loss, int print_summary, const Extras* exp, double* out_stats) {
+  const Extras ex = exp ? *exp : Extras();
+  SfM_Data scene;
+  const int rc0 = build_scene(scene, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
+                              obs_point, obs_xy, ex);
+  if (rc0) return rc0;
+  out_stats[0] = rmse_of(scene);
+
+  Bundle_Adjustment_Ceres::BA_Ceres_options opt(false, num_threads != 1);
+  if (num_threads > 0) opt.nb_threads_ = unsigned(num_threads);
+  opt.bCeres_summary_ = print_summary != 0;
+  opt.bUse_loss_function_ = use_loss != 0;
+  if (max_iterations > 0) opt.max_num_iterations_ = max_iterations;
+  if (linear_solver == 1) opt.linear_solver_type_ = ceres::DENSE_SCHUR;
+  if (linear_solver == 2) opt.linear_solver_type_ = ceres::SPARSE_SCHUR;
+  Bundle_Adjustment_Ceres ba(opt);
+  const Optimize_Options oo(static_cast<Intrinsic_Parameter_Type>(intrinsics_opt),
+                            static_cast<Extrinsic_Parameter_Type>(extrinsics_opt),
+                            static_cast<Structure_Parameter_Type>(structure_opt != 0),
+                            Control_Point_Parameter(ex.ctrl_weight, ex.use_control_points != 0), ex.use_motion_priors != 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool ok = ba.Adjust(scene, oo);
+  const auto t1 = std::chrono::steady_clock::now();
+  out_stats[2] = std::chrono::duration<double>(t1 - t0).count();
+  out_stats[3] = ok ? 1.0 : 0.0;
+  out_stats[1] = rmse_of(scene);
+  flatten_scene(scene, n_poses, n_intr, n_points, poses, intrinsics, points);
   return ok ? 0 : 1;
+}
+
+int ref_ba_adjust(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, double* poses,
+                  double* intrinsics, const int32_t* intr_model, double* points, const uint32_t* obs_pose,
+                  const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, int intrinsics_opt,
+                  int extrinsics_opt, int structure_opt, int max_iterations, int num_threads, int linear_solver,
+                  int use_loss, int print_summary, double* out_stats) {
+  return ref_ba_adjust_ex(n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr, obs_point,
+                          obs_xy, intrinsics_opt, extrinsics_opt, structure_opt, max_iterations, num_threads, linear_solver,
+                          use_loss, print_summary, nullptr, out_stats);
+}
+
+// The scene transformation Adjust() applies BEFORE it builds the problem when motion priors are used
+// (sfm_data_BA_ceres.cpp:180-240), restated with the reference's own library calls (Similarity3_Kernel,
+// LeastMedianOfSquares - deterministic: std::mt19937::default_seed -, ApplySimilarity): robust registration of the pose
+// centres onto the prior centres, then a shift of the whole scene (priors included) to the pose centroid. Lets the
+// tests hand the oracle exactly the problem the reference solves. poses / points / prior_center are updated in place;
+// out[0] = usable (0/1), out[1] = pose_center_robust_fitting_error, out[2..4] = the centroid that was subtracted.
+int ref_ba_prior_prepare(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, double* poses, double* intrinsics,
+                         const int32_t* intr_model, double* points, const uint32_t* obs_pose, const uint32_t* obs_intr,
+                         const uint32_t* obs_point, const double* obs_xy, const uint8_t* prior_flag, double* prior_center,
+                         const double* prior_weight, double* out) {
+  Extras ex;
+  ex.prior_flag = prior_flag; ex.prior_center = prior_center; ex.prior_weight = prior_weight;
+  SfM_Data sfm_data;
+  const int rc0 = build_scene(sfm_data, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
+                              obs_point, obs_xy, ex);
+  if (rc0) return rc0;
+  out[0] = out[1] = out[2] = out[3] = out[4] = 0.0;
+  if (sfm_data.GetViews().size() <= 3) return 0;
+  std::vector<Vec3> X_SfM, X_GPS;
+  for (const auto& view_it : sfm_data.GetViews()) {
+    const ViewPriors* prior = dynamic_cast<ViewPriors*>(view_it.second.get());
+    if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
+      X_SfM.push_back(sfm_data.GetPoses().at(prior->id_pose).center());
+      X_GPS.push_back(prior->pose_center_);
+    }
+  }
+  if (X_GPS.size() <= 3) return 0;
+  openMVG::geometry::Similarity3 sim;
+  const Mat X_SfM_Mat = Eigen::Map<Mat>(X_SfM[0].data(), 3, X_SfM.size());
+  const Mat X_GPS_Mat = Eigen::Map<Mat>(X_GPS[0].data(), 3, X_GPS.size());
+  geometry::kernel::Similarity3_Kernel kernel(X_SfM_Mat, X_GPS_Mat);
+  const double lmeds_median = openMVG::robust::LeastMedianOfSquares(kernel, &sim);
+  if (lmeds_median == std::numeric_limits<double>::max()) return 0;
+  for (Vec3& pos : X_SfM) pos = sim(pos);
+  Vec residual = (Eigen::Map<Mat3X>(X_SfM[0].data(), 3, X_SfM.size()) - Eigen::Map<Mat3X>(X_GPS[0].data(), 3, X_GPS.size())).colwise().norm();
+  std::sort(residual.data(), residual.data() + residual.size());
+  out[0] = 1.0;
+  out[1] = residual(residual.size() / 2);
+  openMVG::sfm::ApplySimilarity(sim, sfm_data);
+  Vec3 pose_centroid = Vec3::Zero();
+  for (const auto& pose_it : sfm_data.poses) pose_centroid += (pose_it.second.center() / (double)sfm_data.poses.size());
+  const openMVG::geometry::Similarity3 sim_to_center(openMVG::sfm::Pose3(Mat3::Identity(), pose_centroid), 1.0);
+  openMVG::sfm::ApplySimilarity(sim_to_center, sfm_data, true);
+  out[2] = pose_centroid(0); out[3] = pose_centroid(1); out[4] = pose_centroid(2);
+  flatten_scene(sfm_data, n_poses, n_intr, n_points, poses, intrinsics, points);
+  for (const auto& view_it : sfm_data.GetViews()) {
+    const ViewPriors* prior = dynamic_cast<ViewPriors*>(view_it.second.get());
+    if (prior != nullptr && prior->b_use_pose_center_)
+      for (int k = 0; k < 3; ++k) prior_center[3 * size_t(prior->id_pose) + k] = prior->pose_center_(k);
+  }
+  return 0;
 }
 
 int ref_ba_default_linear_solver_is_sparse(void) {

@@ -157,6 +157,18 @@ def ba_problem_struct(scene, pose_const_mask=None, intr_const_mask=None, points_
         keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = keep["im"].ctypes.data
     p.points_constant = 1 if points_constant else 0
     p.huber_a = float(scene.get("huber_a", 16.0) if huber_a is None else huber_a)
+    if scene.get("obs_weight") is not None:
+        p.obs_weight = arr("obs_weight", np.float64)
+    if scene.get("obs_is_control") is not None:
+        p.obs_is_control = arr("obs_is_control", np.uint8)
+    if scene.get("point_const_mask") is not None:
+        p.point_const_mask = arr("point_const_mask", np.uint8)
+    if scene.get("prior_pose") is not None and len(scene["prior_pose"]):
+        p.n_pose_priors = len(scene["prior_pose"])
+        p.prior_pose = arr("prior_pose", np.uint32)
+        p.prior_center = arr("prior_center", np.float64)
+        p.prior_weight = arr("prior_weight", np.float64)
+        p.prior_huber_a = float(scene.get("prior_huber_a", 0.0))
     return p, keep
 
 
@@ -208,7 +220,31 @@ def port_ba_eval_obs(model, intr, pose, X, obs):
     return r, Ji, Jc, Jp
 
 
+class ShimExtras(C.Structure):
+    """struct Extras of oracle/ref_shim_ba.cpp"""
+    _fields_ = [("n_ctrl_points", C.c_uint32), ("ctrl_X", C.c_void_p), ("n_ctrl_obs", C.c_uint64), ("ctrl_obs_pose", C.c_void_p),
+                ("ctrl_obs_point", C.c_void_p), ("ctrl_obs_xy", C.c_void_p), ("ctrl_weight", C.c_double),
+                ("use_control_points", C.c_int), ("prior_flag", C.c_void_p), ("prior_center", C.c_void_p),
+                ("prior_weight", C.c_void_p), ("use_motion_priors", C.c_int)]
+
+
+def port_ba_eval_prior(pose, center, weight):
+    L = port()
+    L.oracle_ba_eval_prior.restype = C.c_int
+    L.oracle_ba_eval_prior.argtypes = [C.c_void_p] * 5
+    a = [np.ascontiguousarray(v, np.float64) for v in (pose, center, weight)]
+    r = np.zeros(3); Jc = np.zeros((3, 6))
+    assert L.oracle_ba_eval_prior(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, r.ctypes.data, Jc.ctypes.data) == 0
+    return r, Jc
+
+
 def _bind_ba_shim(L):
+    L.ref_ba_adjust_ex.restype = C.c_int
+    L.ref_ba_adjust_ex.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ShimExtras), C.c_void_p]
+    L.ref_ba_prior_prepare.restype = C.c_int
+    L.ref_ba_prior_prepare.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 12
     L.ref_ba_adjust.restype = C.c_int
     L.ref_ba_adjust.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -238,6 +274,82 @@ def ref_ba_adjust(scene, intrinsics_opt=None, extrinsics_opt=6, structure_opt=1,
                               int(structure_opt), int(max_iterations), int(num_threads), int(linear_solver), int(use_loss),
                               int(print_summary), stats.ctypes.data)
     return rc, stats, poses, intr, pts
+
+
+def _structure_part(scene):
+    """Splits a flat problem into the Landmark part and the control-point part (appended by synth.add_control_points)."""
+    ns = int(scene.get("n_structure_points", scene["n_points"]))
+    ctrl = np.asarray(scene["obs_is_control"], bool) if scene.get("obs_is_control") is not None else np.zeros(int(scene["n_obs"]), bool)
+    return ns, ctrl
+
+
+def ref_ba_adjust_ex(scene, intrinsics_opt=14, extrinsics_opt=6, structure_opt=1, max_iterations=0, num_threads=0, linear_solver=0,
+                     use_loss=1, use_control_points=None, use_motion_priors=None, lib=None):
+    """Bundle_Adjustment_Ceres::Adjust on a flat problem that may carry control points (synth.add_control_points) and pose-centre
+    priors (synth.add_pose_priors; the reference derives the priors' Huber scale itself). Returns (rc, stats, poses, intr, points)
+    with `points` in the flat layout (control points unchanged at the end)."""
+    global _refba
+    if lib is None and _refba is None:
+        _refba = _bind_ba_shim(C.CDLL(REF_BA_SO))
+    L = lib or _refba
+    ns, ctrl = _structure_part(scene)
+    poses = np.ascontiguousarray(scene["poses"], np.float64).copy()
+    intr = np.ascontiguousarray(scene["intrinsics"], np.float64).copy()
+    pts_all = np.ascontiguousarray(scene["points"], np.float64).copy()
+    pts = np.ascontiguousarray(pts_all[:ns])
+    model = np.ascontiguousarray(scene["intr_model"], np.int32)
+    op = np.ascontiguousarray(np.asarray(scene["obs_pose"])[~ctrl], np.uint32); oi = np.ascontiguousarray(np.asarray(scene["obs_intr"])[~ctrl], np.uint32)
+    ox = np.ascontiguousarray(np.asarray(scene["obs_point"])[~ctrl], np.uint32); xy = np.ascontiguousarray(np.asarray(scene["obs_xy"])[~ctrl], np.float64)
+    ex = ShimExtras()
+    keep = []
+    if ctrl.any():
+        cX = np.ascontiguousarray(pts_all[ns:]); cop = np.ascontiguousarray(np.asarray(scene["obs_pose"])[ctrl], np.uint32)
+        cox = np.ascontiguousarray(np.asarray(scene["obs_point"])[ctrl] - ns, np.uint32); cxy = np.ascontiguousarray(np.asarray(scene["obs_xy"])[ctrl], np.float64)
+        keep += [cX, cop, cox, cxy]
+        ex.n_ctrl_points = len(cX); ex.ctrl_X = cX.ctypes.data; ex.n_ctrl_obs = len(cop); ex.ctrl_obs_pose = cop.ctypes.data
+        ex.ctrl_obs_point = cox.ctypes.data; ex.ctrl_obs_xy = cxy.ctypes.data; ex.ctrl_weight = float(scene.get("control_weight", 20.0))
+        ex.use_control_points = 1 if use_control_points is None else int(use_control_points)
+    if scene.get("prior_pose") is not None and len(scene["prior_pose"]):
+        n = int(scene["n_poses"])
+        flag = np.zeros(n, np.uint8); pc = np.zeros((n, 3)); pw = np.zeros((n, 3))
+        flag[scene["prior_pose"]] = 1; pc[scene["prior_pose"]] = scene["prior_center"]; pw[scene["prior_pose"]] = scene["prior_weight"]
+        keep += [flag, pc, pw]
+        ex.prior_flag = flag.ctypes.data; ex.prior_center = pc.ctypes.data; ex.prior_weight = pw.ctypes.data
+        ex.use_motion_priors = 1 if use_motion_priors is None else int(use_motion_priors)
+    stats = np.zeros(4)
+    rc = L.ref_ba_adjust_ex(int(scene["n_poses"]), int(scene["n_intrinsics"]), ns, len(op), poses.ctypes.data, intr.ctypes.data,
+                            model.ctypes.data, pts.ctypes.data, op.ctypes.data, oi.ctypes.data, ox.ctypes.data, xy.ctypes.data,
+                            int(intrinsics_opt), int(extrinsics_opt), int(structure_opt), int(max_iterations), int(num_threads),
+                            int(linear_solver), int(use_loss), 0, C.byref(ex), stats.ctypes.data)
+    pts_all[:ns] = pts
+    return rc, stats, poses, intr, pts_all
+
+
+def ref_ba_prior_prepare(scene, lib=None):
+    """The scene transformation the reference applies before building the problem when motion priors are on
+    (oracle/ref_shim_ba.cpp::ref_ba_prior_prepare). Returns (usable, new_scene, centroid): new_scene carries the transformed
+    poses / points / prior centres and prior_huber_a = Square(pose_center_robust_fitting_error)."""
+    global _refba
+    if lib is None and _refba is None:
+        _refba = _bind_ba_shim(C.CDLL(REF_BA_SO))
+    L = lib or _refba
+    n = int(scene["n_poses"])
+    poses = np.ascontiguousarray(scene["poses"], np.float64).copy(); intr = np.ascontiguousarray(scene["intrinsics"], np.float64).copy()
+    pts = np.ascontiguousarray(scene["points"], np.float64).copy(); model = np.ascontiguousarray(scene["intr_model"], np.int32)
+    op = np.ascontiguousarray(scene["obs_pose"], np.uint32); oi = np.ascontiguousarray(scene["obs_intr"], np.uint32)
+    ox = np.ascontiguousarray(scene["obs_point"], np.uint32); xy = np.ascontiguousarray(scene["obs_xy"], np.float64)
+    flag = np.zeros(n, np.uint8); pc = np.zeros((n, 3)); pw = np.zeros((n, 3))
+    flag[scene["prior_pose"]] = 1; pc[scene["prior_pose"]] = scene["prior_center"]; pw[scene["prior_pose"]] = scene["prior_weight"]
+    out = np.zeros(5)
+    rc = L.ref_ba_prior_prepare(n, int(scene["n_intrinsics"]), int(scene["n_points"]), int(scene["n_obs"]), poses.ctypes.data,
+                                intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data, oi.ctypes.data, ox.ctypes.data,
+                                xy.ctypes.data, flag.ctypes.data, pc.ctypes.data, pw.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    sc = dict(scene)
+    sc["poses"] = poses; sc["points"] = pts
+    sc["prior_center"] = np.ascontiguousarray(pc[scene["prior_pose"]])
+    sc["prior_huber_a"] = float(out[1]) ** 2
+    return bool(out[0]), sc, out[2:5].copy()
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -124,3 +124,28 @@ def test_two_point_shards_reproduce_the_single_rank_solve():
         pts[mine] = p
     assert np.allclose(pts, rpts, atol=1e-8)
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("model", [4, 5, 7])
+def test_brown_fisheye_spherical_functors(model):
+    sc = synth.ba_scene(n_cams=6, n_points=60, track_len=4, model=model, n_intr_groups=2, seed=70 + model, rot_deg=0.3)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc)
+    s, poses, intr, pts = _solve_emu(sc)
+    assert rc == 0 and s.num_iterations == osum.num_iterations and s.termination == osum.termination
+    assert abs(s.final_cost - osum.final_cost) <= 1e-8 * osum.final_cost and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+    assert np.allclose(pts, opx, atol=1e-7) and np.allclose(intr, opi, rtol=1e-7, atol=1e-7) and np.allclose(poses, opp, atol=1e-7)
+
+
+def test_control_points_and_pose_priors():
+    """weighted loss-free residuals on constant points + PoseCenterConstraintCostFunction rows, together"""
+    sc = synth.ba_scene(n_cams=8, n_points=80, track_len=5, model=3, n_intr_groups=2, seed=81, rot_deg=0.3)
+    sc = synth.add_pose_priors(synth.add_control_points(sc, n_ctrl=5, weight=20.0), sigma=0.005, huber_a=2e-4, every=2)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc)
+    s, poses, intr, pts = _solve_emu(sc)
+    assert rc == 0 and s.num_iterations == osum.num_iterations and s.num_successful_steps == osum.num_successful_steps
+    assert abs(s.initial_cost - osum.initial_cost) <= 1e-10 * osum.initial_cost
+    assert abs(s.final_cost - osum.final_cost) <= 1e-8 * osum.final_cost
+    assert abs(s.initial_rmse - osum.initial_rmse) < 1e-9 and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+    assert np.allclose(pts, opx, atol=1e-7) and np.allclose(poses, opp, atol=1e-7)
+    ns = sc["n_structure_points"]
+    assert np.array_equal(pts[ns:], sc["points"][ns:])

@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from openmvg_amd import synth
 from tests import _oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,7 @@ def hostlib():
     L = C.CDLL(out)
     L.host_eval_observation.argtypes = [C.c_int] + [C.c_void_p] * 8
     L.host_eval_residual.argtypes = [C.c_int] + [C.c_void_p] * 5
+    L.host_eval_prior.argtypes = [C.c_void_p] * 5
     L.host_huber.argtypes = [C.c_double, C.c_double, C.c_void_p]
     L.host_invert_spd3.argtypes = [C.c_void_p, C.c_void_p]
     return L
@@ -30,10 +32,12 @@ def hostlib():
 
 def _cases(rng, n):
     for trial in range(n):
-        model = (1, 2, 3)[trial % 3]
-        K = {1: 3, 2: 4, 3: 6}[model]
+        model = (1, 2, 3, 4, 5, 7)[trial % 6]
+        K = {1: 3, 2: 4, 3: 6, 4: 8, 5: 7, 7: 0}[model]
         intr = np.zeros(8); intr[:3] = [1000 + 30 * rng.normal(), 500 + 5 * rng.normal(), 500 + 5 * rng.normal()]
-        intr[3:K] = 0.1 * rng.standard_normal(K - 3)
+        intr[3:K] = 0.1 * rng.standard_normal(max(K - 3, 0))
+        if model == 7:
+            intr[:] = 0; intr[0] = 2000 + trial; intr[1] = 1000
         pose = np.concatenate([rng.standard_normal(3) * (3.0 if trial % 5 == 0 else 0.5), 0.2 * rng.standard_normal(3) + [0, 0, 2.5]])
         if trial % 7 == 0:
             pose[:3] = 1e-9 * rng.standard_normal(3)     # first-order branch of AngleAxisRotatePoint
@@ -47,7 +51,7 @@ def _cases(rng, n):
 def test_closed_form_jacobians_equal_autodiff(hostlib):
     rng = np.random.default_rng(1)
     worst = 0.0
-    for model, intr, pose, X, obs in _cases(rng, 300):
+    for model, intr, pose, X, obs in _cases(rng, 600):
         r0, Ji0, Jc0, Jp0 = _oracle.port_ba_eval_obs(model, intr, pose, X, obs)
         r = np.zeros(2); Ji = np.zeros((2, 8)); Jc = np.zeros((2, 6)); Jp = np.zeros((2, 3))
         hostlib.host_eval_observation(model, intr.ctypes.data, pose.ctypes.data, X.ctypes.data, obs.ctypes.data,
@@ -80,3 +84,22 @@ def test_huber_and_spd3(hostlib):
         assert np.allclose(Ai @ A, np.eye(3), atol=1e-8)
     bad = np.array([1.0, 2.0, 0.0, 1.0, 0.0, 1.0]); inv = np.zeros(6)
     assert hostlib.host_invert_spd3(bad.ctypes.data, inv.ctypes.data) == 0
+
+
+def test_pose_center_prior_closed_form_equals_autodiff(hostlib):
+    """PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): closed form vs the oracle's Jets, both branches of
+    AngleAxisRotatePoint"""
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        pose = np.concatenate([rng.standard_normal(3) * (2.5 if trial % 4 == 0 else 0.4), rng.standard_normal(3)])
+        if trial % 9 == 0:
+            pose[:3] = 1e-9 * rng.standard_normal(3)
+        if trial % 13 == 0:
+            pose[:3] = 0.0
+        center = rng.standard_normal(3); weight = rng.uniform(0.1, 3.0, 3)
+        r0, J0 = _oracle.port_ba_eval_prior(pose, center, weight)
+        r = np.zeros(3); J = np.zeros((3, 6))
+        hostlib.host_eval_prior(pose.ctypes.data, center.ctypes.data, weight.ctypes.data, r.ctypes.data, J.ctypes.data)
+        assert np.abs(r - r0).max() < 1e-12 and np.abs(J - J0).max() < 1e-11, (pose, J, J0)
+        R = synth._rodrigues(pose[None, :3])[0]
+        assert np.allclose(r, weight * (-R.T @ pose[3:] - center), atol=1e-12)   # C = -R^T t

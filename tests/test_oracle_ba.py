@@ -12,7 +12,7 @@ needs_ref = pytest.mark.skipif(not _oracle.have_ref_ba(), reason="oracle/_ref/li
 
 def test_autodiff_jacobian_matches_central_differences():
     rng = np.random.default_rng(0)
-    for model, K in ((1, 3), (2, 4), (3, 6)):
+    for model, K in ((1, 3), (2, 4), (3, 6), (4, 8), (5, 7)):
         for trial in range(5):
             intr = np.zeros(8); intr[:3] = [1000 + rng.normal(), 500 + rng.normal(), 500 + rng.normal()]
             intr[3:K] = 0.05 * rng.standard_normal(K - 3)
@@ -113,3 +113,80 @@ def test_port_equals_reference_without_loss_and_one_iteration():
     rc, stats, *_ = _oracle.ref_ba_adjust(sc, max_iterations=1)
     prc, summ, *_ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(max_num_iterations=1))
     assert summ.num_iterations == 1 and abs(summ.final_rmse - stats[1]) < 1e-9
+
+
+@needs_ref
+@pytest.mark.parametrize("model", [4, 5, 7])
+def test_port_equals_reference_brown_fisheye_spherical(model):
+    """the remaining functors of IntrinsicsToCostFunction (sfm_data_BA_ceres.cpp:84-108); mirrors the reference's own
+    EffectiveMinimization_Pinhole_Intrinsic_Brown_T2 / _Fisheye / Intrinsic_Spherical tests (sfm_data_BA_test.cpp:128-185)"""
+    sc = synth.ba_scene(n_cams=8, n_points=100, track_len=5, model=model, n_intr_groups=2, seed=30 + model, rot_deg=0.3)
+    rc, stats, rp, ri, rx = _oracle.ref_ba_adjust_ex(sc)
+    prc, summ, pp, pi, px, _ = _oracle.port_ba_solve(sc)
+    assert rc == 0 and prc == 0 and stats[1] < stats[0]
+    assert abs(summ.initial_rmse - stats[0]) < 1e-9 and abs(summ.final_rmse - stats[1]) < 1e-9
+    assert np.allclose(pp[:, 3:], rp[:, 3:], atol=1e-7) and np.allclose(px, rx, atol=1e-7)
+    if model != 7:
+        assert np.allclose(pi, ri, rtol=1e-7, atol=1e-7)
+    else:
+        assert np.array_equal(pi, sc["intrinsics"])   # no parameter block: the {w, h} row is data
+
+
+@needs_ref
+@pytest.mark.parametrize("iopt", [1, 14])
+def test_port_equals_reference_with_control_points(iopt):
+    """Control_Point_Parameter(20, true) (sfm_data_BA_ceres.cpp:398-451; the reference's EffectiveMinimization_Pinhole_GCP
+    test runs iopt = NONE): weighted loss-free residuals on constant points"""
+    sc = synth.add_control_points(synth.ba_scene(n_cams=8, n_points=100, track_len=5, model=1, seed=50, rot_deg=0.3), n_ctrl=6, weight=20.0)
+    rc, stats, rp, ri, rx = _oracle.ref_ba_adjust_ex(sc, intrinsics_opt=iopt)
+    prc, summ, pp, pi, px, _ = _oracle.port_ba_solve(sc, **bo.masks_for(sc, iopt, 6, 1))
+    assert rc == 0 and prc == 0
+    assert abs(summ.initial_rmse - stats[0]) < 1e-9 and abs(summ.final_rmse - stats[1]) < 1e-9   # RMSE over Landmarks only
+    assert np.allclose(synth._rodrigues(pp[:, :3]), synth._rodrigues(rp[:, :3]), atol=1e-9)
+    assert np.allclose(pp[:, 3:], rp[:, 3:], atol=1e-8) and np.allclose(px, rx, atol=1e-8)
+    assert np.array_equal(px[sc["n_structure_points"]:], sc["points"][sc["n_structure_points"]:])   # control points stay put
+    # the reference's own assertion: with control points the camera centres land on the ground truth (1e-4)
+    if iopt == 1:
+        C = -np.einsum("nji,nj->ni", synth._rodrigues(pp[:, :3]), pp[:, 3:])
+        Cgt = -np.einsum("nji,nj->ni", synth._rodrigues(sc["poses_gt"][:, :3]), sc["poses_gt"][:, 3:])
+        assert np.abs(C - Cgt).max() < 5e-3   # noisy observations here (0.5 px), unlike the reference's noise-free test
+    # without the option the control residuals are not part of the problem
+    rc2, stats2, *_ = _oracle.ref_ba_adjust_ex(sc, intrinsics_opt=iopt, use_control_points=0)
+    plain = {k: v for k, v in sc.items() if k not in ("obs_weight", "obs_is_control", "point_const_mask")}
+    ns, keep = sc["n_structure_points"], ~sc["obs_is_control"].astype(bool)
+    plain.update(n_points=ns, points=sc["points"][:ns], n_obs=int(keep.sum()), obs_pose=sc["obs_pose"][keep], obs_intr=sc["obs_intr"][keep],
+                 obs_point=sc["obs_point"][keep], obs_xy=sc["obs_xy"][keep])
+    prc2, summ2, *_ = _oracle.port_ba_solve(plain, **bo.masks_for(plain, iopt, 6, 1))
+    assert abs(summ2.final_rmse - stats2[1]) < 1e-9 and abs(stats2[1] - stats[1]) > 1e-9
+
+
+def _uncentre(poses, points, centroid):
+    R = synth._rodrigues(poses[:, :3])
+    C = -np.einsum("nji,nj->ni", R, poses[:, 3:6]) + centroid
+    out = poses.copy(); out[:, 3:6] = -np.einsum("nij,nj->ni", R, C)
+    return out, points + centroid
+
+
+@needs_ref
+@pytest.mark.parametrize("sigma", [0.01, 0.0])
+def test_port_equals_reference_with_pose_center_priors(sigma):
+    """use_motion_priors_opt (sfm_data_BA_ceres.cpp:180-240, 454-473, 575-606): the reference registers the scene on the
+    priors (LMedS, deterministic), centres it, solves with PoseCenterConstraintCostFunction + HuberLoss(fit error^2) and moves
+    the centroid back. The oracle gets the same prepared problem (ref_ba_prior_prepare: the reference's own library calls)."""
+    sc = synth.add_pose_priors(synth.ba_scene(n_cams=12, n_points=120, track_len=6, model=1, seed=60, rot_deg=0.3), sigma=sigma)
+    rc, stats, rp, ri, rx = _oracle.ref_ba_adjust_ex(sc)
+    usable, prep, centroid = _oracle.ref_ba_prior_prepare(sc)
+    assert rc == 0 and usable
+    prc, summ, pp, pi, px, _ = _oracle.port_ba_solve(prep)
+    pp, px = _uncentre(pp, px, centroid)
+    assert prc == 0 and abs(summ.final_rmse - stats[1]) < 1e-9
+    assert np.allclose(pp[:, 3:], rp[:, 3:], atol=1e-8) and np.allclose(px, rx, atol=1e-8) and np.allclose(pi, ri, rtol=1e-9)
+    # the reference's own assertion (sfm_data_BA_test.cpp:298-305, there with noise-free observations and 1e-8): the
+    # centres end near the priors (0.5 px observation noise and unit prior weights here)
+    C = -np.einsum("nji,nj->ni", synth._rodrigues(pp[:, :3]), pp[:, 3:])
+    assert np.abs(C - sc["prior_center"]).max() < 0.05
+    # and without the option the priors are ignored
+    rc0, stats0, rp0, *_ = _oracle.ref_ba_adjust_ex(sc, use_motion_priors=0)
+    plain = {k: v for k, v in sc.items() if not k.startswith("prior_")}
+    _, summ0, pp0, *_ = _oracle.port_ba_solve(plain)
+    assert abs(summ0.final_rmse - stats0[1]) < 1e-9 and np.allclose(pp0[:, 3:], rp0[:, 3:], atol=1e-8)
