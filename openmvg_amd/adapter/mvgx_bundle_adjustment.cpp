@@ -3,11 +3,16 @@
 // (sfm/sfm_data_BA_ceres.cpp): pose block = [angle-axis(3), t(3)] with t = -R*C (:260-271); intrinsic block =
 // getParams() (:310-320); one residual per observation with blocks (intrinsic, pose, landmark) (:354-396); Huber
 // loss with a = Square(4.0) (:249); constant blocks / subsets from Optimize_Options (:274-306, :321-344, :394-395);
-// write-back :527-568. No Ceres and no Eigen solver is used: Eigen only as the reference's value types, and
+// ground control points as weighted, loss-free residuals on constant points (:398-451); pose-centre priors with the
+// robust pre-registration of the scene onto them (:180-240, :454-473, :575-606); write-back :527-568.
+// No Ceres and no Eigen solver is used: Eigen only as the reference's value types, and
 // ceres/rotation.h (header-only templates vendored with openMVG) for the exact angle-axis conversions the reference
 // performs on the host.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <limits>
+#include <sstream>
 #include <unordered_map>
 #include <vector>
 
@@ -15,9 +20,16 @@
 
 #include "openMVG/cameras/Camera_Common.hpp"
 #include "openMVG/cameras/Camera_Intrinsics.hpp"
+#include "openMVG/geometry/Similarity3.hpp"
+#include "openMVG/geometry/Similarity3_Kernel.hpp"
 #include "openMVG/geometry/pose3.hpp"
+#include "openMVG/numeric/eigen_alias_definition.hpp"
+#include "openMVG/robust_estimation/robust_estimator_LMeds.hpp"
 #include "openMVG/sfm/sfm_data.hpp"
+#include "openMVG/sfm/sfm_data_transform.hpp"
+#include "openMVG/sfm/sfm_view.hpp"
 #include "openMVG/sfm/sfm_view_priors.hpp"
+#include "openMVG/stl/stlMap.hpp"
 #include "openMVG/system/logger.hpp"
 #include "openMVG/types.hpp"
 
@@ -31,18 +43,41 @@ using cameras::Intrinsic_Parameter_Type;
 using geometry::Pose3;
 
 bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& options) {
-  // --- parts of Adjust() the device path does not implement yet are refused loudly, never approximated ---
-  if (options.control_point_opt.bUse_control_points && !sfm_data.control_points.empty()) {
-    OPENMVG_LOG_ERROR << "mvgx BA: ground-control-point residuals (sfm_data_BA_ceres.cpp:398-451) are not on the device path.";
-    return false;
-  }
-  if (options.use_motion_priors_opt) {
-    for (const auto& v : sfm_data.GetViews()) {
-      const auto* prior = dynamic_cast<const ViewPriors*>(v.second.get());
-      if (prior && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
-        OPENMVG_LOG_ERROR << "mvgx BA: pose-centre priors (sfm_data_BA_ceres.cpp:184-240,454-473) are not on the device path.";
-        return false;
+  // --- motion priors: robust registration of the pose centres onto the prior centres, then the whole scene (priors
+  // included) is moved to the pose centroid for conditioning (sfm_data_BA_ceres.cpp:180-240). Host work on a handful of
+  // 3-vectors, done with the same library calls as the reference (LeastMedianOfSquares is seeded deterministically). ---
+  double pose_center_robust_fitting_error = 0.0;
+  openMVG::geometry::Similarity3 sim_to_center;
+  bool b_usable_prior = false;
+  if (options.use_motion_priors_opt && sfm_data.GetViews().size() > 3) {
+    std::vector<Vec3> X_SfM, X_GPS;
+    for (const auto& view_it : sfm_data.GetViews()) {
+      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
+      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
+        X_SfM.push_back(sfm_data.GetPoses().at(prior->id_pose).center());
+        X_GPS.push_back(prior->pose_center_);
       }
+    }
+    openMVG::geometry::Similarity3 sim;
+    if (X_GPS.size() > 3) {
+      const Mat X_SfM_Mat = Eigen::Map<Mat>(X_SfM[0].data(), 3, X_SfM.size());
+      const Mat X_GPS_Mat = Eigen::Map<Mat>(X_GPS[0].data(), 3, X_GPS.size());
+      geometry::kernel::Similarity3_Kernel kernel(X_SfM_Mat, X_GPS_Mat);
+      const double lmeds_median = openMVG::robust::LeastMedianOfSquares(kernel, &sim);
+      if (lmeds_median != std::numeric_limits<double>::max()) {
+        b_usable_prior = true;
+        for (Vec3& pos : X_SfM) pos = sim(pos);
+        Vec residual = (Eigen::Map<Mat3X>(X_SfM[0].data(), 3, X_SfM.size()) - Eigen::Map<Mat3X>(X_GPS[0].data(), 3, X_GPS.size())).colwise().norm();
+        std::sort(residual.data(), residual.data() + residual.size());
+        pose_center_robust_fitting_error = residual(residual.size() / 2);
+        openMVG::sfm::ApplySimilarity(sim, sfm_data);
+        Vec3 pose_centroid = Vec3::Zero();
+        for (const auto& pose_it : sfm_data.poses) pose_centroid += (pose_it.second.center() / (double)sfm_data.poses.size());
+        sim_to_center = openMVG::geometry::Similarity3(openMVG::sfm::Pose3(Mat3::Identity(), pose_centroid), 1.0);
+        openMVG::sfm::ApplySimilarity(sim_to_center, sfm_data, true);
+      }
+    } else {
+      OPENMVG_LOG_WARNING << "Cannot used the motion prior, insufficient number of motion priors/poses";
     }
   }
 
@@ -75,13 +110,17 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
       OPENMVG_LOG_ERROR << "Unsupported camera type.";
       continue;
     }
-    const std::vector<double> prm = it.second->getParams();
-    if (prm.empty() || prm.size() > MVGX_BA_MAX_INTR_PARAMS) {
+    std::vector<double> prm = it.second->getParams();
+    if (prm.size() > MVGX_BA_MAX_INTR_PARAMS) {
       OPENMVG_LOG_ERROR << "mvgx BA: camera model " << static_cast<int>(it.second->getType()) << " has no device functor.";
       return false;
     }
+    const bool no_block = prm.empty();   // CAMERA_SPHERICAL: residual blocks take (pose, point) only (:366-383)
+    if (no_block) prm = {static_cast<double>(it.second->w()), static_cast<double>(it.second->h())};   // data of the functor
     uint8_t m = 0;
-    if (options.intrinsics_opt == Intrinsic_Parameter_Type::NONE) {
+    if (no_block) {
+      m = 0;
+    } else if (options.intrinsics_opt == Intrinsic_Parameter_Type::NONE) {
       m = static_cast<uint8_t>((1u << prm.size()) - 1u);
     } else {
       for (int c : it.second->subsetParameterization(options.intrinsics_opt)) m |= static_cast<uint8_t>(1u << c);
@@ -116,10 +155,59 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
     }
   }
 
+  // --- ground control points: constant points, weighted residuals without loss function (:398-451) ---
+  const size_t n_structure_obs = obs_pose.size();
+  std::vector<double> obs_weight;
+  std::vector<uint8_t> obs_is_control, point_const;
+  size_t n_points_total = lm_of_point.size();
+  if (options.control_point_opt.bUse_control_points) {
+    for (auto& gcp : sfm_data.control_points) {
+      if (gcp.second.obs.empty()) {
+        OPENMVG_LOG_ERROR << "Cannot use this GCP id: " << gcp.first << ". There is not linked image observation.";
+        continue;
+      }
+      const uint32_t j = static_cast<uint32_t>(n_points_total++);
+      points.insert(points.end(), {gcp.second.X(0), gcp.second.X(1), gcp.second.X(2)});
+      for (const auto& ob : gcp.second.obs) {
+        const View* view = sfm_data.views.at(ob.first).get();
+        const auto ii = intr_idx.find(view->id_intrinsic);
+        if (ii == intr_idx.end()) continue;   // IntrinsicsToCostFunction returned null: the reference skips the block
+        obs_pose.push_back(pose_idx.at(view->id_pose));
+        obs_intr.push_back(ii->second);
+        obs_point.push_back(j);
+        obs_xy.push_back(ob.second.x(0));
+        obs_xy.push_back(ob.second.x(1));
+      }
+    }
+    if (n_points_total > lm_of_point.size()) {
+      obs_weight.assign(obs_pose.size(), 0.0);
+      obs_is_control.assign(obs_pose.size(), 0);
+      for (size_t k = n_structure_obs; k < obs_pose.size(); ++k) { obs_weight[k] = options.control_point_opt.weight; obs_is_control[k] = 1; }
+      point_const.assign(n_points_total, 0);
+      for (size_t j = lm_of_point.size(); j < n_points_total; ++j) point_const[j] = 1;
+    }
+  }
+  // --- pose-centre priors (:454-473); the reference indexes the pose block with prior->id_view ---
+  std::vector<uint32_t> prior_pose;
+  std::vector<double> prior_center, prior_weight;
+  if (b_usable_prior) {
+    for (const auto& view_it : sfm_data.GetViews()) {
+      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
+      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
+        prior_pose.push_back(pose_idx.at(prior->id_view));
+        for (int k = 0; k < 3; ++k) { prior_center.push_back(prior->pose_center_(k)); prior_weight.push_back(prior->center_weight_(k)); }
+      }
+    }
+  }
+
   mvgx_ba_problem prob{};
+  if (!obs_weight.empty()) { prob.obs_weight = obs_weight.data(); prob.obs_is_control = obs_is_control.data(); prob.point_const_mask = point_const.data(); }
+  prob.n_pose_priors = static_cast<uint32_t>(prior_pose.size());
+  prob.prior_pose = prior_pose.data(); prob.prior_center = prior_center.data(); prob.prior_weight = prior_weight.data();
+  prob.prior_huber_a = Square(pose_center_robust_fitting_error);
   prob.n_poses = static_cast<uint32_t>(pose_ids.size());
   prob.n_intrinsics = static_cast<uint32_t>(intr_ids.size());
-  prob.n_points = static_cast<uint32_t>(lm_of_point.size());
+  prob.n_points = static_cast<uint32_t>(n_points_total);
   prob.n_obs = obs_pose.size();
   prob.poses = poses.data(); prob.intrinsics = intrinsics.data(); prob.intr_model = intr_model.data();
   prob.points = points.data();
@@ -173,7 +261,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
                      << " Initial RMSE: " << std::sqrt(summary.initial_cost / nres) << "\n"
                      << " Final RMSE: " << std::sqrt(summary.final_cost / nres) << "\n"
                      << " Time (s): " << summary.total_ms * 1e-3 << " (MI355X, " << summary.num_iterations
-                     << " LM iterations)\n--\n Used motion prior: 0";
+                     << " LM iterations)\n--\n Used motion prior: " << static_cast<int>(b_usable_prior);
   }
 
   if (options.extrinsics_opt != Extrinsic_Parameter_Type::NONE) {
@@ -196,6 +284,26 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
       auto& cam = sfm_data.intrinsics.at(intr_ids[k]);
       const size_t np = cam->getParams().size();
       cam->updateFromParams(std::vector<double>(&intrinsics[8 * k], &intrinsics[8 * k] + np));
+    }
+  }
+  if (b_usable_prior) {   // set back to the original scene centroid + fitting statistics (:575-606)
+    openMVG::sfm::ApplySimilarity(sim_to_center.inverse(), sfm_data, true);
+    std::vector<Vec3> X_SfM, X_GPS;
+    for (const auto& view_it : sfm_data.GetViews()) {
+      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
+      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
+        X_SfM.push_back(sfm_data.GetPoses().at(prior->id_pose).center());
+        X_GPS.push_back(prior->pose_center_);
+      }
+    }
+    if (X_GPS.size() > 3) {
+      const Vec residual = (Eigen::Map<Mat3X>(X_SfM[0].data(), 3, X_SfM.size()) - Eigen::Map<Mat3X>(X_GPS[0].data(), 3, X_GPS.size())).colwise().norm();
+      std::ostringstream os;
+      os << "Pose prior statistics (user units):\n"
+         << " - Starting median fitting error: " << pose_center_robust_fitting_error << "\n"
+         << " - Final fitting error:\n";
+      minMaxMeanMedian<Vec::Scalar>(residual.data(), residual.data() + residual.size(), os);
+      OPENMVG_LOG_INFO << os.str();
     }
   }
   return true;

@@ -67,4 +67,15 @@ def shard_ba_scene(scene, rank, world, owner=None):
         out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
     out["obs_xy"] = np.ascontiguousarray(np.asarray(scene["obs_xy"], np.float64).reshape(-1, 2)[keep])
     out["n_obs"] = int(keep.sum())
+    # control points shard like any other point (their residual rows only touch camera blocks, which are summed)
+    for k in ("obs_weight", "obs_is_control"):
+        if scene.get(k) is not None:
+            out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
+    if scene.get("point_const_mask") is not None:
+        out["point_const_mask"] = np.ascontiguousarray(np.asarray(scene["point_const_mask"])[mine])
+    # pose-centre priors are residuals on replicated blocks: exactly one rank may hold them, or the summed reduced system
+    # and cost would count them `world` times
+    if rank != 0:
+        for k in ("prior_pose", "prior_center", "prior_weight"):
+            out.pop(k, None)
     return out, mine

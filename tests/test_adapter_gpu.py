@@ -63,6 +63,23 @@ def test_bundle_adjustment_ceres_replacement_equals_golden(tag):
         assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-4)
 
 
+@pytest.mark.parametrize("name", list(_golden()["ex_case_names"]))
+def test_bundle_adjustment_ceres_replacement_functors_control_points_priors(name):
+    """Brown / fisheye / spherical cameras, Control_Point_Parameter(20, true) and use_motion_priors_opt through the
+    replacement Bundle_Adjustment_Ceres::Adjust, against the reference's outputs on the same SfM_Data"""
+    from tests.test_ba_gpu import _ex_case
+    z = _golden()
+    tag, sc = _ex_case(z, name)
+    iopt = int(name.split("|")[1])
+    ref_stats = z[f"{tag}/ref_stats"]
+    rc, stats, poses, intr, pts = _oracle.ref_ba_adjust_ex(sc, intrinsics_opt=iopt, lib=_oracle.adapter())
+    assert rc == 0 and stats[3] == ref_stats[3] == 1.0
+    assert abs(stats[0] - ref_stats[0]) < 1e-9
+    assert abs(stats[1] - ref_stats[1]) < 1e-6, (stats[1], ref_stats[1])
+    assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-5)
+    assert np.allclose(poses[:, 3:], z[f"{tag}/ref_poses"][:, 3:], atol=1e-5)
+
+
 def test_bundle_adjustment_unsupported_model_returns_false():
     sc = synth.ba_scene(4, 30, track_len=3, model=1, seed=3)
     # the shim only builds pinhole / K1 / K3 cameras (-3 otherwise); an unsupported Adjust() is covered through the C ABI

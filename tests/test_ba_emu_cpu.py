@@ -149,3 +149,36 @@ def test_control_points_and_pose_priors():
     assert np.allclose(pts, opx, atol=1e-7) and np.allclose(poses, opp, atol=1e-7)
     ns = sc["n_structure_points"]
     assert np.array_equal(pts[ns:], sc["points"][ns:])
+
+
+def test_two_shards_with_control_points_and_priors():
+    """control points shard with the points; the pose priors live on rank 0 only (sharding.shard_ba_scene)"""
+    sc = synth.ba_scene(n_cams=8, n_points=120, track_len=5, model=1, n_intr_groups=1, seed=95, rot_deg=0.3)
+    sc = synth.add_pose_priors(synth.add_control_points(sc, n_ctrl=6, weight=20.0), sigma=0.005, huber_a=2e-4)
+    opt = dict(max_num_iterations=3)
+    ref, rposes, rintr, rpts = _solve_emu(sc, ba.default_options(**opt))
+    world = 2
+    tr = _HostAllReduce(world)
+    owner = sharding.assign_points(sc["obs_point"], sc["n_points"], world)
+    out = [None] * world
+
+    def run(rank):
+        shard, mine = sharding.shard_ba_scene(sc, rank, world, owner)
+        c = ba.BaContext(shard)
+        c.set_allreduce(tr.make(rank))
+        s = c.solve(ba.default_options(**opt))
+        poses, intr, pts = c.read_params()
+        c.close()
+        out[rank] = (s, poses, intr, pts, mine)
+
+    with _emu.emulated():
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(600)
+    assert all(o is not None for o in out)
+    for s, poses, intr, p, mine in out:
+        assert s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
+        assert abs(s.final_rmse - ref.final_rmse) < 1e-9 and abs(s.initial_rmse - ref.initial_rmse) < 1e-9
+        assert np.allclose(poses, rposes, atol=1e-9)
