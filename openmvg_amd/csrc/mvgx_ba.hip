@@ -14,8 +14,10 @@
 //
 // Device data layout (all fp64):
 //   observations sorted by 3-D point (CSR pt_start), so a point's rows are contiguous like Ceres' chunks;
-//   Jacobian structure-of-arrays, component-major: J[c * n_obs + o], c = 0..35 =
-//     r(2) | E = d r/d point (2x3) | Fc = d r/d pose (2x6) | Fi = d r/d intrinsic (2x8), loss-corrected, UNscaled;
+//   Jacobian as three arrays of per-observation records (loss-corrected, UNscaled), so that both the point-ordered
+//     kernels and the gathers by pose / intrinsic read whole cache lines:
+//     JA[o] = {r(2), E = d r/d point (2x3)} (64 B), JB[o] = {r(2), Fc = d r/d pose (2x6), pad} (128 B),
+//     JC[o] = {Fi = d r/d intrinsic (2x8)} (128 B);
 //   reduced camera system S: n = 6 n_poses + 8 n_intr columns (pose blocks first, then intrinsic blocks), leading
 //     dimension n + 1; memory is simultaneously "row-major upper + rhs in column n" (how the assembly kernels write it)
 //     and "column-major lower + rhs in row n" (how the Cholesky kernels read it). Constant / unused parameter
@@ -52,8 +54,7 @@ namespace {
 using mvgx::set_error;
 using namespace mvgx_ba;
 
-constexpr int kJC = 36;        // Jacobian components per observation
-constexpr int kJr = 0, kJE = 2, kJFc = 8, kJFi = 20;
+constexpr int kJA = 8, kJB = 16, kJC = 16;   // doubles per observation record: {r, E} | {r, Fc, pad} | {Fi}
 constexpr int kIntrChunk = 2048;   // observations per workgroup of the intrinsic Gram kernel
 constexpr int kPiChunk = 512;      // observations per workgroup of the (pose, intrinsic) Gram kernel
 constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave of the Schur-product kernel
@@ -112,7 +113,7 @@ struct Dev {
   uint32_t *prior_pose = nullptr, *pose_prior_start = nullptr, *pose_prior_idx = nullptr;
   double *prior_center = nullptr, *prior_weight = nullptr, *Jprior = nullptr;
   // Jacobian and derived
-  double* J = nullptr;                // kJC x n_obs
+  double *JA = nullptr, *JB = nullptr, *JC = nullptr;   // n_obs records each
   double *cn_cam = nullptr, *g_cam = nullptr, *scale_cam = nullptr, *diag_cam = nullptr;   // N
   double *cn_pt = nullptr, *g_pt = nullptr, *scale_pt = nullptr, *diag_pt = nullptr;       // 3 n_pts
   double *pichunk_part = nullptr, *pi_gram = nullptr, *pose_gram = nullptr, *igram_part = nullptr, *igram = nullptr;
@@ -155,6 +156,13 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+template <int N>
+__device__ __forceinline__ void load_rec(const double* __restrict__ p, double* v) {   // N doubles, 16-byte aligned
+  const double2* __restrict__ q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) { const double2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
 }
 
 // out[k] = sum_i part[i * stride + k], k < nk (single block; deterministic order)
@@ -205,16 +213,19 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
     if (kJac) {
       const double sr = corrector_scale(rho);
       const double sc = sr * w;
-      double* J = d.J;
-      const size_t n = d.n_obs;
-      J[(kJr + 0) * n + o] = r[0] * sr;
-      J[(kJr + 1) * n + o] = r[1] * sr;
+      const double r0 = r[0] * sr, r1 = r[1] * sr;
+      double2* __restrict__ a = reinterpret_cast<double2*>(d.JA + (size_t)o * kJA);
+      a[0] = make_double2(r0, r1);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) J[(kJE + k) * n + o] = Jp[k] * sc;
+      for (int k = 0; k < 3; ++k) a[1 + k] = make_double2(Jp[2 * k] * sc, Jp[2 * k + 1] * sc);
+      double2* __restrict__ b = reinterpret_cast<double2*>(d.JB + (size_t)o * kJB);
+      b[0] = make_double2(r0, r1);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) J[(kJFc + k) * n + o] = Jc[k] * sc;
+      for (int k = 0; k < 6; ++k) b[1 + k] = make_double2(Jc[2 * k] * sc, Jc[2 * k + 1] * sc);
+      b[7] = make_double2(0.0, 0.0);
+      double2* __restrict__ cc = reinterpret_cast<double2*>(d.JC + (size_t)o * kJC);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) J[(kJFi + k) * n + o] = Ji[k] * sc;
+      for (int k = 0; k < 8; ++k) cc[k] = make_double2(Ji[2 * k] * sc, Ji[2 * k + 1] * sc);
     }
   }
   const double c = block_sum(cost, sh);
@@ -253,14 +264,13 @@ __global__ __launch_bounds__(256) void ba_point_norms_kernel(Dev d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.n_pts) return;
   double cn[3] = {0, 0, 0}, g[3] = {0, 0, 0};
-  const size_t n = d.n_obs;
   for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
+    double a[8];
+    load_rec<8>(d.JA + (size_t)o * kJA, a);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double e0 = d.J[(kJE + c) * n + o], e1 = d.J[(kJE + 3 + c) * n + o];
-      cn[c] += e0 * e0 + e1 * e1;
-      g[c] += e0 * r0 + e1 * r1;
+      cn[c] += a[2 + c] * a[2 + c] + a[5 + c] * a[5 + c];
+      g[c] += a[2 + c] * a[0] + a[5 + c] * a[1];
     }
   }
 #pragma unroll
@@ -275,19 +285,16 @@ __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r 
 __global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
   __shared__ double sh[4][kPiGram];
   const uint32_t ch = blockIdx.x;
-  const size_t n = d.n_obs;
-  const double* __restrict__ J = d.J;
   double acc[kPiGram];
 #pragma unroll
   for (int k = 0; k < kPiGram; ++k) acc[k] = 0.0;
   for (uint32_t e = d.pichunk_lo[ch] + threadIdx.x; e < d.pichunk_hi[ch]; e += 256) {
     const uint32_t o = d.pi_obs[e];
-    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
-    double f0[6], f1[6], h0[8], h1[8];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { f0[c] = J[(kJFc + c) * n + o]; f1[c] = J[(kJFc + 6 + c) * n + o]; }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { h0[c] = J[(kJFi + c) * n + o]; h1[c] = J[(kJFi + 8 + c) * n + o]; }
+    double b[16], h[16];
+    load_rec<16>(d.JB + (size_t)o * kJB, b);
+    load_rec<16>(d.JC + (size_t)o * kJC, h);
+    const double r0 = b[0], r1 = b[1];
+    const double* f0 = b + 2; const double* f1 = b + 8; const double* h0 = h; const double* h1 = h + 8;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
 #pragma unroll
@@ -343,17 +350,16 @@ __global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
 __global__ __launch_bounds__(256) void ba_intr_gram_kernel(Dev d) {
   __shared__ double sh[4][kIntrGram];
   const uint32_t ch = blockIdx.x;
-  const size_t n = d.n_obs;
-  const double* __restrict__ J = d.J;
   double acc[kIntrGram];
 #pragma unroll
   for (int k = 0; k < kIntrGram; ++k) acc[k] = 0.0;
   for (uint32_t e = d.igchunk_lo[ch] + threadIdx.x; e < d.igchunk_hi[ch]; e += 256) {
     const uint32_t o = d.iobs[e];
-    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
-    double h0[8], h1[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { h0[c] = J[(kJFi + c) * n + o]; h1[c] = J[(kJFi + 8 + c) * n + o]; }
+    double h[16];
+    load_rec<16>(d.JC + (size_t)o * kJC, h);
+    const double2 rr = *reinterpret_cast<const double2*>(d.JA + (size_t)o * kJA);
+    const double r0 = rr.x, r1 = rr.y;
+    const double* h0 = h; const double* h1 = h + 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
 #pragma unroll
@@ -428,17 +434,17 @@ __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_r
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= d.n_pts) return;
   const uint32_t o0 = d.pt_start[p], o1 = d.pt_start[p + 1];
-  const size_t n = d.n_obs;
-  const double* __restrict__ J = d.J;
   const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
   double V[6] = {d.diag_pt[(size_t)p * 3] * inv_radius, 0, 0, d.diag_pt[(size_t)p * 3 + 1] * inv_radius, 0,
                  d.diag_pt[(size_t)p * 3 + 2] * inv_radius};
   double g[3] = {0, 0, 0};
   for (uint32_t o = o0; o < o1; ++o) {
-    const double r0 = J[(kJr + 0) * n + o], r1 = J[(kJr + 1) * n + o];
+    double a[8];
+    load_rec<8>(d.JA + (size_t)o * kJA, a);
+    const double r0 = a[0], r1 = a[1];
     double e0[3], e1[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { e0[c] = J[(kJE + c) * n + o] * sp[c]; e1[c] = J[(kJE + 3 + c) * n + o] * sp[c]; }
+    for (int c = 0; c < 3; ++c) { e0[c] = a[2 + c] * sp[c]; e1[c] = a[5 + c] * sp[c]; }
     V[0] += e0[0] * e0[0] + e1[0] * e1[0]; V[1] += e0[0] * e0[1] + e1[0] * e1[1]; V[2] += e0[0] * e0[2] + e1[0] * e1[2];
     V[3] += e0[1] * e0[1] + e1[1] * e1[1]; V[4] += e0[1] * e0[2] + e1[1] * e1[2]; V[5] += e0[2] * e0[2] + e1[2] * e1[2];
 #pragma unroll
@@ -460,14 +466,14 @@ __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_r
 __global__ __launch_bounds__(256) void ba_obs_z_kernel(Dev d) {
   const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= d.n_obs) return;
-  const size_t n = d.n_obs;
-  const double* __restrict__ J = d.J;
   const uint32_t p = d.opt[o], ip = d.opose[o];
-  double e0[3], e1[3], li[6];
+  double a[8], b[16], e0[3], e1[3], li[6];
+  load_rec<8>(d.JA + (size_t)o * kJA, a);
+  load_rec<16>(d.JB + (size_t)o * kJB, b);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const double s = d.scale_pt[(size_t)p * 3 + c];
-    e0[c] = J[(kJE + c) * n + o] * s; e1[c] = J[(kJE + 3 + c) * n + o] * s;
+    e0[c] = a[2 + c] * s; e1[c] = a[5 + c] * s;
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) li[c] = d.Linv3[(size_t)p * 6 + c];
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256) void ba_obs_z_kernel(Dev d) {
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const double sc = d.scale_cam[6 * ip + c];
-    const double f0 = J[(kJFc + c) * n + o] * sc, f1 = J[(kJFc + 6 + c) * n + o] * sc;
+    const double f0 = b[2 + c] * sc, f1 = b[8 + c] * sc;
     const double y0 = e0[0] * f0 + e1[0] * f1, y1 = e0[1] * f0 + e1[1] * f1, y2 = e0[2] * f0 + e1[2] * f1;
     Z[c] = li[0] * y0;
     Z[6 + c] = li[1] * y0 + li[2] * y1;
@@ -492,18 +498,18 @@ __global__ __launch_bounds__(256) void ba_slot_z_kernel(Dev d) {
   const uint32_t s = idx >> 3;
   const int c = idx & 7;
   if (s >= (uint32_t)d.n_islots) return;
-  const size_t n = d.n_obs;
-  const double* __restrict__ J = d.J;
   const uint32_t p = d.slot_point[s], ik = d.slot_intr[s];
   const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
   const double sc = d.scale_cam[6 * d.n_poses + 8 * ik + c];
   double y0 = 0, y1 = 0, y2 = 0;
   for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
     if (d.ointr[o] != ik) continue;
-    const double f0 = J[(kJFi + c) * n + o] * sc, f1 = J[(kJFi + 8 + c) * n + o] * sc;
-    y0 += (J[(kJE + 0) * n + o] * f0 + J[(kJE + 3) * n + o] * f1) * sp[0];
-    y1 += (J[(kJE + 1) * n + o] * f0 + J[(kJE + 4) * n + o] * f1) * sp[1];
-    y2 += (J[(kJE + 2) * n + o] * f0 + J[(kJE + 5) * n + o] * f1) * sp[2];
+    double a[8];
+    load_rec<8>(d.JA + (size_t)o * kJA, a);   // the 8 lanes of a slot read the same record (broadcast)
+    const double f0 = d.JC[(size_t)o * kJC + c] * sc, f1 = d.JC[(size_t)o * kJC + 8 + c] * sc;
+    y0 += (a[2] * f0 + a[5] * f1) * sp[0];
+    y1 += (a[3] * f0 + a[6] * f1) * sp[1];
+    y2 += (a[4] * f0 + a[7] * f1) * sp[2];
   }
   const double* li = d.Linv3 + (size_t)p * 6;
   d.Zint[(size_t)s * 24 + c] = li[0] * y0;
@@ -902,27 +908,29 @@ __global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __res
   const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double v = 0;
   if (o < d.n_obs) {
-    const size_t n = d.n_obs;
     const uint32_t ip = d.opose[o], ik = d.ointr[o], p = d.opt[o];
+    double a[8], b[16], h[16];
+    load_rec<8>(d.JA + (size_t)o * kJA, a);
+    load_rec<16>(d.JB + (size_t)o * kJB, b);
+    load_rec<16>(d.JC + (size_t)o * kJC, h);
     double m0 = 0, m1 = 0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const double s = d.scale_cam[6 * ip + c] * d.step_cam[6 * ip + c];
-      m0 += d.J[(kJFc + c) * n + o] * s; m1 += d.J[(kJFc + 6 + c) * n + o] * s;
+      m0 += b[2 + c] * s; m1 += b[8 + c] * s;
     }
     const int col0 = 6 * (int)d.n_poses + 8 * (int)ik;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const double s = d.scale_cam[col0 + c] * d.step_cam[col0 + c];
-      m0 += d.J[(kJFi + c) * n + o] * s; m1 += d.J[(kJFi + 8 + c) * n + o] * s;
+      m0 += h[c] * s; m1 += h[8 + c] * s;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double s = d.scale_pt[(size_t)p * 3 + c] * d.step_pt[(size_t)p * 3 + c];
-      m0 += d.J[(kJE + c) * n + o] * s; m1 += d.J[(kJE + 3 + c) * n + o] * s;
+      m0 += a[2 + c] * s; m1 += a[5 + c] * s;
     }
-    const double r0 = d.J[(kJr + 0) * n + o], r1 = d.J[(kJr + 1) * n + o];
-    v = -(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0));
+    v = -(m0 * (a[0] + m0 / 2.0) + m1 * (a[1] + m1 / 2.0));
   }
   const double t = block_sum(v, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
@@ -1528,7 +1536,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   UP(iobs, iobs); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
   UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
   UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
-  AL(J, (size_t)kJC * no);
+  AL(JA, (size_t)kJA * no); AL(JB, (size_t)kJB * no); AL(JC, (size_t)kJC * no);
   AL(cn_cam, d.N); AL(g_cam, d.N); AL(scale_cam, d.N); AL(diag_cam, d.N);
   AL(cn_pt, (size_t)d.n_pts * 3); AL(g_pt, (size_t)d.n_pts * 3); AL(scale_pt, (size_t)d.n_pts * 3); AL(diag_pt, (size_t)d.n_pts * 3);
   AL(pichunk_part, (size_t)d.n_pichunks * kPiGram); AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);

@@ -356,11 +356,12 @@ def ref_ba_prior_prepare(scene, lib=None):
 # the openMVG-side adapter build (product code + the same caller shims as oracle/_ref)
 # ---------------------------------------------------------------------------------------------------------
 ADAPTER_SO = os.path.join(ROOT, "openmvg_amd", "lib", "libmvgx_openmvg_adapter.so")
+ADAPTER_BA_SO = os.path.join(ROOT, "openmvg_amd", "lib", "libmvgx_openmvg_adapter_ba.so")
 _adapter = None
 
 
 def have_adapter():
-    return os.path.exists(ADAPTER_SO)
+    return os.path.exists(ADAPTER_SO) and os.path.exists(ADAPTER_BA_SO)
 
 
 def adapter():
@@ -369,5 +370,13 @@ def adapter():
     Matcher_Regions / Bundle_Adjustment_Ceres symbols apart from the reference's in oracle/_ref."""
     global _adapter
     if _adapter is None:
-        _adapter = _bind_ba_shim(_bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW)))
+        class _Both:   # the two adapter libraries behind one handle (matcher half / BA half: different Eigen ABIs)
+            pass
+        both = _Both()
+        m = _bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+        b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+        both.ref_matcher_regions_match_u8 = m.ref_matcher_regions_match_u8
+        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare"):
+            setattr(both, name, getattr(b, name))
+        _adapter = both
     return _adapter
