@@ -33,7 +33,7 @@
 // registers (no atomics, fixed order), a second kernel sums the chunks of each block and writes it into S.
 // Cholesky: per 64-column block step chol_diag_inv (factor the diagonal block, invert its factor), chol_panel_mfma
 // (L21 = A21 L11^-T as a GEMM; the rhs row rides along = forward substitution), chol_update_mfma (A22 -= L21 L21^T,
-// v_mfma_f64_16x16x4_f64); back substitution one launch per block step.
+// v_mfma_f64_16x16x4_f64); back substitution one launch per group of four block steps.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -525,7 +525,11 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
                                                                const double* __restrict__ hp, const uint32_t* __restrict__ a_point) {
   constexpr int NV = WA * WB + WA;
   __shared__ double red[64][NV + 1];
-  const uint32_t ch = blockIdx.x;
+  // Workgroup ids are dealt round-robin to the 8 XCDs: give each XCD one contiguous eighth of the (row, column)-sorted
+  // chunk list, so that the products that share Z records of a camera row meet in one 4 MiB L2.
+  const uint32_t per = (L.n_chunks + 7) / 8;
+  const uint32_t ch = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (ch >= L.n_chunks) return;
   const int lane = threadIdx.x;
   const uint32_t lo = L.chunk_lo[ch], hi = L.chunk_hi[ch];
   const bool diag = L.chunk_diag[ch] != 0;
@@ -829,42 +833,57 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
       }
 }
 
-// back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
-// y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 256 columns c < b0: four lanes per column, 16 contiguous rows
-// (one cache line) each.
-__global__ __launch_bounds__(256) void chol_backsolve_step_kernel(double* __restrict__ A, int n, int ld, int b0, int kb,
-                                                                  const double* __restrict__ linv_rm, double* __restrict__ z) {
-  __shared__ double yb[64];
-  __shared__ double zp[4][64];
-  __shared__ double zb[64];
+// Back substitution L^T z = y, one launch per group of up to four 64-row block steps (g0 = first row of the group, a
+// multiple of 256; gr = rows in the group). Every workgroup solves the group's own triangular system in LDS (block steps
+// from last to first: z_k = L_kk^-T y_k, then y_j -= L_kj^T z_k for the group's blocks j < k), workgroup 0 stores z; then
+// each workgroup updates y_c -= sum_r L(g0 + r, c) z[r] for its 256 columns c < g0: four lanes per column, gr / 4
+// contiguous rows each.
+__global__ __launch_bounds__(256) void chol_backsolve_group_kernel(double* __restrict__ A, int n, int ld, int g0, int gr,
+                                                                   const double* __restrict__ linv_all, double* __restrict__ z) {
+  __shared__ double yg[256];
+  __shared__ double zg[256];
+  __shared__ double part[4][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid < 64) yb[tid] = (tid < kb) ? A[(size_t)(b0 + tid) * ld + n] : 0.0;
+  yg[tid] = (tid < gr) ? A[(size_t)(g0 + tid) * ld + n] : 0.0;
+  zg[tid] = 0.0;
   __syncthreads();
-  {  // z[c] = sum_r Linv[r][c] y[r]; wave w takes r = w, w + 4, ...
-    double v = 0;
-    for (int r = wave; r < 64; r += 4) v += linv_rm[r * 64 + lane] * yb[r];
-    zp[wave][lane] = v;
+  const int nb = (gr + 63) >> 6;
+  for (int k = nb - 1; k >= 0; --k) {
+    const int k0 = 64 * k, kb = min(64, gr - k0);
+    const double* __restrict__ linv_rm = linv_all + (size_t)((g0 + k0) >> 6) * 8192 + 4096;
+    {  // z_k[c] = sum_r Linv[r][c] y_k[r]; wave w takes r = w, w + 4, ...
+      double v = 0;
+      for (int r = wave; r < 64; r += 4) v += linv_rm[r * 64 + lane] * yg[k0 + r];
+      part[wave][lane] = v;
+    }
+    __syncthreads();
+    if (tid < 64) zg[k0 + tid] = (tid < kb) ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.0;
+    __syncthreads();
+    for (int j = k - 1; j >= 0; --j) {   // y_j[c] -= sum_r L(g0 + k0 + r, g0 + 64 j + c) z_k[r]; wave w takes 16 rows
+      const double* __restrict__ colp = A + (size_t)(g0 + 64 * j + lane) * ld + (g0 + k0 + wave * 16);
+      double v = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (wave * 16 + r < kb) v += colp[r] * zg[k0 + wave * 16 + r];
+      part[wave][lane] = v;
+      __syncthreads();
+      if (tid < 64) yg[64 * j + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  if (tid < 64) {
-    const double v = (zp[0][tid] + zp[1][tid]) + (zp[2][tid] + zp[3][tid]);
-    zb[tid] = v;
-    if (blockIdx.x == 0 && tid < kb) z[b0 + tid] = v;
-  }
-  __syncthreads();
-  const int part = lane & 3;
+  if (blockIdx.x == 0 && tid < gr) z[g0 + tid] = zg[tid];
+  const int q = lane & 3, rq = (gr + 3) >> 2;   // rows [q rq, q rq + rq) of the group for this lane
   for (int pass = 0; pass < 4; ++pass) {
     const int c = (int)blockIdx.x * 256 + wave * 64 + pass * 16 + (lane >> 2);
     double v = 0;
-    if (c < b0) {
-      const double* __restrict__ colp = A + (size_t)c * ld + (b0 + part * 16);
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (part * 16 + k < kb) v += colp[k] * zb[part * 16 + k];
+    if (c < g0) {
+      const double* __restrict__ colp = A + (size_t)c * ld + g0;
+      const int r1 = min(gr, q * rq + rq);
+      for (int r = q * rq; r < r1; ++r) v += colp[r] * zg[r];
     }
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
-    if (c < b0 && part == 0) A[(size_t)c * ld + n] -= v;
+    if (c < g0 && q == 0) A[(size_t)c * ld + n] -= v;
   }
 }
 
@@ -1140,11 +1159,11 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   BA_LAUNCH_CHECK();
   MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   if (d.tpp.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(d.tpp.n_chunks), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
   if (d.tpi.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(d.tpi.n_chunks), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
+    hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(8 * ((d.tpi.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
   if (d.tii.n_chunks)
-    hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(d.tii.n_chunks), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
+    hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(8 * ((d.tii.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
   BA_LAUNCH_CHECK();
   if (d.tpp.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 6, 0>), dim3(d.tpp.n_blocks), dim3(128), 0, c->stream, d, d.tpp);
   if (d.tpi.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 8, 1>), dim3(d.tpi.n_blocks), dim3(128), 0, c->stream, d, d.tpi);
@@ -1169,10 +1188,10 @@ int factor_and_solve(mvgx_ba_ctx* c) {
     }
   }
   BA_LAUNCH_CHECK();
-  for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
-    const int kb = std::min(64, d.N - b0);
-    hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(std::max(1, (b0 + 255) / 256)), dim3(256), 0, c->stream, d.S, d.N, d.LD, b0, kb,
-                       d.linv + (size_t)(b0 / 64) * 8192 + 4096, d.zsol);
+  for (int g0 = ((d.N - 1) / 256) * 256; g0 >= 0; g0 -= 256) {
+    const int gr = std::min(256, d.N - g0);
+    hipLaunchKernelGGL(chol_backsolve_group_kernel, dim3(std::max(1, (g0 + 255) / 256)), dim3(256), 0, c->stream, d.S, d.N, d.LD, g0, gr,
+                       d.linv, d.zsol);
   }
   BA_LAUNCH_CHECK();
   return MVGX_OK;

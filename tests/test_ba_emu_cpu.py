@@ -182,3 +182,14 @@ def test_two_shards_with_control_points_and_priors():
         assert s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
         assert abs(s.final_rmse - ref.final_rmse) < 1e-9 and abs(s.initial_rmse - ref.initial_rmse) < 1e-9
         assert np.allclose(poses, rposes, atol=1e-9)
+
+
+def test_reduced_system_beyond_one_backsolve_group():
+    """N = 6 * 42 + 8 * 3 = 276 > 256 columns: five Cholesky block steps (partial last one) and two back-substitution groups"""
+    sc = synth.ba_scene(n_cams=42, n_points=260, track_len=4, model=3, n_intr_groups=3, seed=37)
+    opt = dict(max_num_iterations=1)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
+    s, poses, intr, pts = _solve_emu(sc, ba.default_options(**opt))
+    assert s.num_iterations == osum.num_iterations == 1
+    assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
