@@ -33,7 +33,7 @@
 // registers (no atomics, fixed order), a second kernel sums the chunks of each block and writes it into S.
 // Cholesky: per 64-column block step chol_diag_inv (factor the diagonal block, invert its factor), chol_panel_mfma
 // (L21 = A21 L11^-T as a GEMM; the rhs row rides along = forward substitution), chol_update_mfma (A22 -= L21 L21^T,
-// v_mfma_f64_16x16x4_f64); back substitution one launch per group of four block steps.
+// v_mfma_f64_16x16x4_f64); back substitution one launch per block step.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -638,10 +638,15 @@ __device__ __forceinline__ double fast_rcp(double x) {   // v_rcp_f64 + two Newt
   return r;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 // Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
-// processed as four 64 x 16 column panels: a right-looking panel factorisation on UNscaled columns (one barrier per
-// pivot: a_rc -= a_rj a_cj / d_j, the 1 / sqrt(d) scaling applied once at the end of the panel), then a rank-16 update
-// of the remaining columns. The inverse is built from the 16 x 16 diagonal blocks outwards.
+// processed as four 64 x 16 column panels: a register-resident panel factorisation by one wave, then a rank-16 update
+// of the remaining columns by all four. The inverse is built from the 16 x 16 diagonal blocks outwards.
 __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb,
                                                             double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -659,35 +664,35 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     Li[r][c] = 0.0;
   }
   __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
   for (int jb = 0; jb < 4; ++jb) {
-    const int j0 = jb * 16, nm = 4 - jb;
-    double a[4];   // thread (ty, tx) owns rows j0 + ty + 16 m of panel column j0 + tx
+    const int j0 = jb * 16;
+    // Panel of 16 columns, factored by wave 0 alone with lane = row and the row's 16 panel entries in registers: the pivot
+    // column reaches the other lanes through v_readlane (scalar operands), so the 16 pivots cost neither LDS traffic nor
+    // barriers. Right-looking on UNscaled columns: a_rt -= (a_rj / d_j) a_pt for t > j, p = j0 + j; the 1 / sqrt(d)
+    // scaling is applied when the panel is written back. Rows above the pivot compute garbage that is never stored.
+    if (wave == 0) {
+      double a[16], rs[16];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = (m < nm) ? L[j0 + ty + 16 * m][j0 + tx] : 0.0;
-    for (int j = 0; j < 16; ++j) {
-      if (tx == j) {
+      for (int t = 0; t < 16; ++t) a[t] = L[lane][j0 + t];
+      bool ok = true;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (m < nm) col[j][j0 + ty + 16 * m] = a[m];
+      for (int j = 0; j < 16; ++j) {
+        const double dj = readlane_f64(a[j], j0 + j);
+        ok = ok && (dj > 0.0) && isfinite(dj);
+        const double dsafe = ok ? dj : 1.0;
+        rs[j] = 1.0 / sqrt(dsafe);
+        const double lj = a[j] * fast_rcp(dsafe);
+#pragma unroll
+        for (int t = j + 1; t < 16; ++t) a[t] -= lj * readlane_f64(a[j], j0 + t);   // a(j0 + t, j): lower triangle
       }
-      __syncthreads();
-      const double dj = col[j][j0 + j];
-      if (!(dj > 0.0) || !isfinite(dj)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform
-      if (tx > j) {
-        const double cj = col[j][j0 + tx] * fast_rcp(dj);
+      if (!ok && lane == 0) col[0][0] = -1.0;   // flag for the uniform exit below
+      if (ok && lane == 0) col[0][0] = 1.0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (m < nm) a[m] -= col[j][j0 + ty + 16 * m] * cj;
-      }
+      for (int t = 0; t < 16; ++t) L[lane][j0 + t] = (lane >= j0 + t) ? a[t] * rs[t] : 0.0;
     }
-    const double rs = 1.0 / sqrt(col[tx][j0 + tx]);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      if (m < nm) {
-        const int r = j0 + ty + 16 * m;
-        L[r][j0 + tx] = (r >= j0 + tx) ? a[m] * rs : 0.0;
-      }
     __syncthreads();
+    if (!(col[0][0] > 0.0)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform: not positive definite
     for (int q = tid; q < 4096; q += 256) {   // L[r][c] -= sum_k L[r][j0 + k] L[c][j0 + k] for the columns right of the panel
       const int r = q >> 6, c = q & 63;
       if (c >= j0 + 16 && r >= c) {
@@ -762,11 +767,14 @@ __device__ __forceinline__ void mfma_tile_32x32(const double (*P)[kTS], const do
   }
 }
 
-// rows k0 + kb .. n (row n = rhs) of block column k0: X = A21 Linv^T, 64 rows per workgroup
+// rows k0 + kb .. n (row n = rhs) of block column k0: X = A21 Linv^T, 64 rows per workgroup. Latency-bound (few
+// workgroups per launch): both operands are fetched in one go (2 x 40 KiB of LDS) so the launch costs one memory round trip.
+constexpr int kPanelLds = 2 * 64 * kTS * (int)sizeof(double);
 __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb,
                                                               const double* __restrict__ linvT) {
-  __shared__ double P[32][kTS];
-  __shared__ double Q[32][kTS];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double (*P)[kTS] = reinterpret_cast<double (*)[kTS]>(lds);
+  double (*Q)[kTS] = reinterpret_cast<double (*)[kTS]>(lds + 64 * kTS);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = k0 + kb + (int)blockIdx.x * 64;
   const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
@@ -775,16 +783,13 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kc0 = 0; kc0 < kb; kc0 += 32) {
-    if (kc0) __syncthreads();
-    for (int q = tid; q < 32 * 64; q += 256) {
-      const int k = q >> 6, r = q & 63, kk = kc0 + k;
-      P[k][r] = (kk < kb && row0 + r <= n) ? A[(size_t)(k0 + kk) * ld + (row0 + r)] : 0.0;
-      Q[k][r] = linvT[kk * 64 + r];   // zero beyond the factor's triangle, identity padding beyond kb
-    }
-    __syncthreads();
-    mfma_tile_32x32(P, Q, 32, rbase, cbase, acc);
+  for (int q = tid; q < 64 * 64; q += 256) {
+    const int k = q >> 6, r = q & 63;
+    P[k][r] = (k < kb && row0 + r <= n) ? A[(size_t)(k0 + k) * ld + (row0 + r)] : 0.0;
+    Q[k][r] = linvT[k * 64 + r];   // zero beyond the factor's triangle, identity padding beyond kb
   }
+  __syncthreads();
+  mfma_tile_32x32(P, Q, 64, rbase, cbase, acc);
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -807,11 +812,17 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
   const int tj = t;
   const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
   const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
-  d4_t acc[2][2];
+  d4_t acc[2][2], dst[2][2];   // dst: the destination tile, requested before anything else (one round trip less)
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = j0 + cbase + 16 * ci + (lane >> 4) + 4 * reg, r = i0 + rbase + 16 * ri + (lane & 15);
+        dst[ci][ri][reg] = (r <= n && c < n && r >= c) ? A[(size_t)c * ld + r] : 0.0;
+        acc[ci][ri][reg] = 0.0;
+      }
   for (int kc0 = 0; kc0 < kb; kc0 += 32) {
     if (kc0) __syncthreads();
     for (int q = tid; q < 32 * 64; q += 256) {
@@ -829,61 +840,60 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int c = j0 + cbase + 16 * ci + (lane >> 4) + 4 * reg, r = i0 + rbase + 16 * ri + (lane & 15);
-        if (r <= n && c < n && r >= c) A[(size_t)c * ld + r] -= acc[ci][ri][reg];
+        if (r <= n && c < n && r >= c) A[(size_t)c * ld + r] = dst[ci][ri][reg] - acc[ci][ri][reg];
       }
 }
 
-// Back substitution L^T z = y, one launch per group of up to four 64-row block steps (g0 = first row of the group, a
-// multiple of 256; gr = rows in the group). Every workgroup solves the group's own triangular system in LDS (block steps
-// from last to first: z_k = L_kk^-T y_k, then y_j -= L_kj^T z_k for the group's blocks j < k), workgroup 0 stores z; then
-// each workgroup updates y_c -= sum_r L(g0 + r, c) z[r] for its 256 columns c < g0: four lanes per column, gr / 4
-// contiguous rows each.
-__global__ __launch_bounds__(256) void chol_backsolve_group_kernel(double* __restrict__ A, int n, int ld, int g0, int gr,
-                                                                   const double* __restrict__ linv_all, double* __restrict__ z) {
-  __shared__ double yg[256];
-  __shared__ double zg[256];
-  __shared__ double part[4][64];
+// Back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
+// y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 256 columns c < b0: four lanes per column, 16 contiguous rows
+// (one cache line) each. The step is a chain of tiny dependent phases, so every global load it needs (y_b, the inverse
+// block, the 64 x 256 slab of L, the y_c to update) is issued up front, before the first barrier: one memory round trip
+// per launch instead of four. (A variant that fused four block steps per launch measured slower: its in-workgroup
+// triangular solve added dependent round trips.)
+__global__ __launch_bounds__(256) void chol_backsolve_step_kernel(double* __restrict__ A, int n, int ld, int b0, int kb,
+                                                                  const double* __restrict__ linv_rm, double* __restrict__ z) {
+  __shared__ double yb[64];
+  __shared__ double zp[4][64];
+  __shared__ double zb[64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  yg[tid] = (tid < gr) ? A[(size_t)(g0 + tid) * ld + n] : 0.0;
-  zg[tid] = 0.0;
-  __syncthreads();
-  const int nb = (gr + 63) >> 6;
-  for (int k = nb - 1; k >= 0; --k) {
-    const int k0 = 64 * k, kb = min(64, gr - k0);
-    const double* __restrict__ linv_rm = linv_all + (size_t)((g0 + k0) >> 6) * 8192 + 4096;
-    {  // z_k[c] = sum_r Linv[r][c] y_k[r]; wave w takes r = w, w + 4, ...
-      double v = 0;
-      for (int r = wave; r < 64; r += 4) v += linv_rm[r * 64 + lane] * yg[k0 + r];
-      part[wave][lane] = v;
-    }
-    __syncthreads();
-    if (tid < 64) zg[k0 + tid] = (tid < kb) ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.0;
-    __syncthreads();
-    for (int j = k - 1; j >= 0; --j) {   // y_j[c] -= sum_r L(g0 + k0 + r, g0 + 64 j + c) z_k[r]; wave w takes 16 rows
-      const double* __restrict__ colp = A + (size_t)(g0 + 64 * j + lane) * ld + (g0 + k0 + wave * 16);
-      double v = 0;
+  const int part = lane & 3, cq = (int)blockIdx.x * 256 + wave * 64 + (lane >> 2);
+  const double yv = (tid < kb) ? A[(size_t)(b0 + tid) * ld + n] : 0.0;   // tid < kb <= 64
+  double lv[16], cv[4][16], yc[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (wave * 16 + r < kb) v += colp[r] * zg[k0 + wave * 16 + r];
-      part[wave][lane] = v;
-      __syncthreads();
-      if (tid < 64) yg[64 * j + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-      __syncthreads();
-    }
-  }
-  if (blockIdx.x == 0 && tid < gr) z[g0 + tid] = zg[tid];
-  const int q = lane & 3, rq = (gr + 3) >> 2;   // rows [q rq, q rq + rq) of the group for this lane
+  for (int i = 0; i < 16; ++i) lv[i] = linv_rm[(wave + 4 * i) * 64 + lane];
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
-    const int c = (int)blockIdx.x * 256 + wave * 64 + pass * 16 + (lane >> 2);
+    const int c = cq + pass * 16;
+    const bool on = c < b0;
+    const double* __restrict__ colp = A + (size_t)(on ? c : 0) * ld + (b0 + part * 16);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cv[pass][k] = (on && part * 16 + k < kb) ? colp[k] : 0.0;
+    yc[pass] = (on && part == 0) ? A[(size_t)c * ld + n] : 0.0;
+  }
+  if (tid < 64) yb[tid] = yv;
+  __syncthreads();
+  {  // z[c] = sum_r Linv[r][c] y[r]; wave w takes r = w, w + 4, ...
     double v = 0;
-    if (c < g0) {
-      const double* __restrict__ colp = A + (size_t)c * ld + g0;
-      const int r1 = min(gr, q * rq + rq);
-      for (int r = q * rq; r < r1; ++r) v += colp[r] * zg[r];
-    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += lv[i] * yb[wave + 4 * i];
+    zp[wave][lane] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double v = (zp[0][tid] + zp[1][tid]) + (zp[2][tid] + zp[3][tid]);
+    zb[tid] = v;
+    if (blockIdx.x == 0 && tid < kb) z[b0 + tid] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int c = cq + pass * 16;
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += cv[pass][k] * zb[part * 16 + k];
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
-    if (c < g0 && q == 0) A[(size_t)c * ld + n] -= v;
+    if (c < b0 && part == 0) A[(size_t)c * ld + n] = yc[pass] - v;
   }
 }
 
@@ -1181,17 +1191,17 @@ int factor_and_solve(mvgx_ba_ctx* c) {
     double* linv = d.linv + (size_t)(k0 / 64) * 8192;
     hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linv, d.fail);
     const int rows_below = d.N + 1 - (k0 + kb);   // >= 1: the rhs row
-    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, linv);
+    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
     if (k0 + kb < d.N) {
       const int nt = (rows_below + 63) / 64;
       hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
     }
   }
   BA_LAUNCH_CHECK();
-  for (int g0 = ((d.N - 1) / 256) * 256; g0 >= 0; g0 -= 256) {
-    const int gr = std::min(256, d.N - g0);
-    hipLaunchKernelGGL(chol_backsolve_group_kernel, dim3(std::max(1, (g0 + 255) / 256)), dim3(256), 0, c->stream, d.S, d.N, d.LD, g0, gr,
-                       d.linv, d.zsol);
+  for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
+    const int kb = std::min(64, d.N - b0);
+    hipLaunchKernelGGL(chol_backsolve_step_kernel, dim3(std::max(1, (b0 + 255) / 256)), dim3(256), 0, c->stream, d.S, d.N, d.LD, b0, kb,
+                       d.linv + (size_t)(b0 / 64) * 8192 + 4096, d.zsol);
   }
   BA_LAUNCH_CHECK();
   return MVGX_OK;
@@ -1591,6 +1601,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   *out = c;
   return MVGX_OK;

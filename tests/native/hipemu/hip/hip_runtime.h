@@ -33,6 +33,7 @@ void block_barrier();
 double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);
 typedef double d4 __attribute__((ext_vector_type(4)));
 d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int);
+int readlane_i32(int v, int src_lane);
 int lane_xor(int lane, int m);
 int lane_down(int lane, int d);
 int lane_abs(int lane, int s);
@@ -55,6 +56,10 @@ static inline double __shfl_xor(double v, int m) { return hipemu::shfl_f64(v, hi
 static inline double __shfl_down(double v, int d) { return hipemu::shfl_f64(v, hipemu::lane_down, d); }
 static inline double __shfl(double v, int s) { return hipemu::shfl_f64(v, hipemu::lane_abs, s); }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
+#define __builtin_amdgcn_readlane(v, l) hipemu::readlane_i32((v), (l))
+static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
+static inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &b, 8); return d; }
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
 
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }

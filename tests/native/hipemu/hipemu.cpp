@@ -138,6 +138,15 @@ double shfl_f64(double v, int src_lane_of(int, int), int arg) {
   return r;
 }
 
+int readlane_i32(int v, int src_lane) {
+  double d = 0;
+  memcpy(&d, &v, sizeof(int));
+  d = shfl_f64(d, lane_abs, src_lane);
+  int r;
+  memcpy(&r, &d, sizeof(int));
+  return r;
+}
+
 // v_mfma_f64_16x16x4_f64: lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; receives
 // D[i = (l >> 4) + 4 reg][j = l & 15], reg = 0..3   (cdna_hip_programming.md, "f64 MFMA does NOT use these maps")
 d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int) {
