@@ -638,6 +638,8 @@ __device__ __forceinline__ double fast_rcp(double x) {   // v_rcp_f64 + two Newt
   return r;
 }
 
+using d4_t = __attribute__((ext_vector_type(4))) double;
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -672,34 +674,45 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     // barriers. Right-looking on UNscaled columns: a_rt -= (a_rj / d_j) a_pt for t > j, p = j0 + j; the 1 / sqrt(d)
     // scaling is applied when the panel is written back. Rows above the pivot compute garbage that is never stored.
     if (wave == 0) {
-      double a[16], rs[16];
+      double a[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = L[lane][j0 + t];
       bool ok = true;
+      double dmine = 1.0;   // lane j keeps pivot j: the 16 square roots are taken once, in parallel, after the chain
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double dj = readlane_f64(a[j], j0 + j);
         ok = ok && (dj > 0.0) && isfinite(dj);
         const double dsafe = ok ? dj : 1.0;
-        rs[j] = 1.0 / sqrt(dsafe);
+        if (lane == j) dmine = dsafe;
         const double lj = a[j] * fast_rcp(dsafe);
 #pragma unroll
         for (int t = j + 1; t < 16; ++t) a[t] -= lj * readlane_f64(a[j], j0 + t);   // a(j0 + t, j): lower triangle
       }
-      if (!ok && lane == 0) col[0][0] = -1.0;   // flag for the uniform exit below
-      if (ok && lane == 0) col[0][0] = 1.0;
+      const double rsm = 1.0 / sqrt(dmine);
+      if (lane == 0) col[0][0] = ok ? 1.0 : -1.0;   // flag for the uniform exit below
 #pragma unroll
-      for (int t = 0; t < 16; ++t) L[lane][j0 + t] = (lane >= j0 + t) ? a[t] * rs[t] : 0.0;
+      for (int t = 0; t < 16; ++t) {
+        const double rst = readlane_f64(rsm, t);   // wave collective: outside the lane-dependent select
+        L[lane][j0 + t] = (lane >= j0 + t) ? a[t] * rst : 0.0;
+      }
     }
     __syncthreads();
     if (!(col[0][0] > 0.0)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform: not positive definite
-    for (int q = tid; q < 4096; q += 256) {   // L[r][c] -= sum_k L[r][j0 + k] L[c][j0 + k] for the columns right of the panel
-      const int r = q >> 6, c = q & 63;
-      if (c >= j0 + 16 && r >= c) {
-        double v = 0;
+    // rank-16 update of the columns right of the panel, one 16 x 16 block (I, J), I >= J > jb, per wave and turn:
+    // D = P_I P_J^T with P_X = L[16 X .. 16 X + 15][j0 .. j0 + 15] on the f64 matrix core (4 k-steps of 4)
+    {
+      const int li = lane & 15, lk = lane >> 4, nbk = 3 - jb, ntile = nbk * (nbk + 1) / 2;
+      for (int tile = wave; tile < ntile; tile += 4) {
+        int bi = 0, bj = tile;
+        while (bj > bi) { bj -= bi + 1; ++bi; }
+        const int r0 = j0 + 16 + 16 * bi, c0 = j0 + 16 + 16 * bj;
+        d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += L[r][j0 + k] * L[c][j0 + k];
-        L[r][c] -= v;
+        for (int ks = 0; ks < 4; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[r0 + li][j0 + 4 * ks + lk], L[c0 + li][j0 + 4 * ks + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) L[r0 + lk + 4 * reg][c0 + li] -= acc[reg];
       }
     }
     __syncthreads();
@@ -748,8 +761,6 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
     linv[4096 + q] = Li[q >> 6][q & 63]; // row-major
   }
 }
-
-using d4_t = __attribute__((ext_vector_type(4))) double;
 
 // 32 x 32 sub-tile of D[c][r] = sum_k Q[k][c] P[k][r] on one wave: 2 x 2 MFMA blocks, MFMA row index = c, column = r.
 // Lane l feeds A[i = l & 15][k = l >> 4] = Q[k][cbase + i] and B[k = l >> 4][j = l & 15] = P[k][rbase + j]; it receives

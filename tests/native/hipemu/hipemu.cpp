@@ -91,7 +91,13 @@ void run_block(unsigned nthreads) {
       progressed = true;
     }
     if (!progressed) {
-      fprintf(stderr, "hipemu: deadlock (divergent barrier / wave collective) in block %u\n", g_blockIdx.x);
+      fprintf(stderr, "hipemu: deadlock (divergent barrier / wave collective) in block %u of %u x %u threads; fiber states"
+              " (R runnable, w wave collective, B block barrier, . done):\n", g_blockIdx.x, g_gridDim.x, g_blockDim.x);
+      for (int i = 0; i < g_n; ++i) {
+        fputc("RwB."[g_fibers[i].st], stderr);
+        if ((i & 63) == 63) fputc('\n', stderr);
+      }
+      fputc('\n', stderr);
       abort();
     }
   }
