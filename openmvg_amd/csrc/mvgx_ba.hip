@@ -812,15 +812,22 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict
       }
 }
 
-// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive)
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
+// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive). first_col: only the tiles of the
+// first block column of A22 (what the next block step needs); otherwise the tiles of all the other block columns.
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb, int first_col) {
   __shared__ double P[32][kTS];   // rows of tile I, k-major
   __shared__ double Q[32][kTS];   // rows of tile J (= columns of the destination tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r0 = k0 + kb;
-  int t = blockIdx.x, ti = 0;
-  while (t > ti) { t -= ti + 1; ++ti; }
-  const int tj = t;
+  int ti, tj;
+  if (first_col) {
+    ti = blockIdx.x; tj = 0;
+  } else {   // linear index -> (ti' >= tj') of the triangle without its first column; ti = ti' + 1, tj = tj' + 1
+    int t = blockIdx.x;
+    ti = 0;
+    while (t > ti) { t -= ti + 1; ++ti; }
+    tj = t + 1; ti += 1;
+  }
   const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
   const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
   d4_t acc[2][2], dst[2][2];   // dst: the destination tile, requested before anything else (one round trip less)
@@ -1104,6 +1111,10 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
+  // the Cholesky + back substitution as a captured HIP graph (built on first use): its launch sequence depends on N only
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipGraphExec_t chol_exec = nullptr;
 };
 
 namespace {
@@ -1193,10 +1204,13 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   return MVGX_OK;
 }
 
-// Cholesky of the summed system (rhs as extra row -> forward substitution) + back substitution -> zsol
-int factor_and_solve(mvgx_ba_ctx* c) {
+// Cholesky of the summed system (rhs as extra row -> forward substitution) + back substitution -> zsol.
+// Issued once under stream capture and replayed as a HIP graph: ~4 launches per 64-column block step, all tiny, with a
+// one-step look-ahead expressed as graph edges - the update of the NEXT block column (what the next diagonal / panel
+// kernels need) stays on the main branch, the update of all other columns runs on a side branch concurrently with them.
+int enqueue_factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
-  if (!d.N) return MVGX_OK;
+  bool side_pending = false;
   for (int k0 = 0; k0 < d.N; k0 += 64) {
     const int kb = std::min(64, d.N - k0);
     double* linv = d.linv + (size_t)(k0 / 64) * 8192;
@@ -1205,9 +1219,20 @@ int factor_and_solve(mvgx_ba_ctx* c) {
     hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
     if (k0 + kb < d.N) {
       const int nt = (rows_below + 63) / 64;
-      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
+      if (nt > 1) {   // fork: the block columns the next step does not touch
+        MVGX_HIP(hipEventRecord(c->ev_fork, c->stream));
+        MVGX_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      }
+      if (side_pending) { MVGX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0)); side_pending = false; }   // join the previous step's side update
+      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, 1);
+      if (nt > 1) {
+        hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt - 1) / 2), dim3(256), 0, c->side, d.S, d.N, d.LD, k0, kb, 0);
+        MVGX_HIP(hipEventRecord(c->ev_join, c->side));
+        side_pending = true;
+      }
     }
   }
+  if (side_pending) MVGX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   BA_LAUNCH_CHECK();
   for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
     const int kb = std::min(64, d.N - b0);
@@ -1215,6 +1240,22 @@ int factor_and_solve(mvgx_ba_ctx* c) {
                        d.linv + (size_t)(b0 / 64) * 8192 + 4096, d.zsol);
   }
   BA_LAUNCH_CHECK();
+  return MVGX_OK;
+}
+
+int factor_and_solve(mvgx_ba_ctx* c) {
+  if (!c->d.N) return MVGX_OK;
+  if (!c->chol_exec) {
+    hipGraph_t graph = nullptr;
+    MVGX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_factor_and_solve(c);
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    MVGX_HIP(e);
+    MVGX_HIP(hipGraphInstantiate(&c->chol_exec, graph, nullptr, nullptr, 0));
+    MVGX_HIP(hipGraphDestroy(graph));
+  }
+  MVGX_HIP(hipGraphLaunch(c->chol_exec, c->stream));
   return MVGX_OK;
 }
 
@@ -1406,6 +1447,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
+  MVGX_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  MVGX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  MVGX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), kSCount * sizeof(double), hipHostMallocDefault));
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_fail), sizeof(int), hipHostMallocDefault));
   Dev& d = c->d;
@@ -1627,6 +1671,10 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->chol_exec) (void)hipGraphExecDestroy(c->chol_exec);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   mvgx::rccl_destroy(c->rccl);
   delete c;

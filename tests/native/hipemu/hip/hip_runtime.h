@@ -96,5 +96,21 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
+// ---- stream capture / graphs: a captured launch is recorded (arguments by value) and replayed by hipGraphLaunch in
+// issue order, which is a topological order of the fork / join structure the capture describes ----
+struct hipemuGraph;
+typedef hipemuGraph* hipGraph_t;
+typedef hipemuGraph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+enum { hipEventDisableTiming = 2 };
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode);
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*);
+hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t);
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
+hipError_t hipGraphDestroy(hipGraph_t);
+hipError_t hipGraphExecDestroy(hipGraphExec_t);
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+  hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

@@ -104,7 +104,19 @@ void run_block(unsigned nthreads) {
 }
 }  // namespace
 
+}  // namespace hipemu
+
+struct hipemuGraph {
+  struct Node { dim3 grid, block; std::function<void()> body; };
+  std::vector<Node> nodes;
+  int refs = 1;
+};
+
+namespace hipemu {
+namespace { thread_local hipemuGraph* g_capture = nullptr; }
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  if (g_capture) { g_capture->nodes.push_back({grid, block, body}); return; }
   g_body = &body;
   g_gridDim = grid;
   g_blockDim = block;
@@ -173,6 +185,16 @@ d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int) {
 }
 
 }  // namespace hipemu
+
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { hipemu::g_capture = new hipemuGraph(); return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = hipemu::g_capture; hipemu::g_capture = nullptr; return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { ++g->refs; *e = g; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  for (auto& n : e->nodes) hipemu::launch(n.grid, n.block, n.body);
+  return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) { if (g && --g->refs == 0) delete g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { return hipGraphDestroy(e); }
 
 // ---- the product's device + host code, compiled for the host against the shim ----
 namespace {   // the kernels' `extern __shared__` arrays (same unnamed namespace as the kernels below)
