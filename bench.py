@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
     return ap.parse_args()
 
 
@@ -51,12 +52,11 @@ def cpu_baseline(descs, pairs, ratio, budget_s):
     kind = "reference" if _oracle.have_ref_match() else "port"
     fn = _oracle.ref_matcher_regions_match if kind == "reference" else _oracle.port_matcher_regions_match
     order = rng.permutation(len(pairs))
-    fn(descs, pairs[order[:2]], ratio)   # first call: thread pool / page-in, not timed
+    fn(descs, pairs[order[:8]], ratio)   # first call: thread pool / page-in, not timed
     t0 = time.perf_counter()
-    fn(descs, pairs[order[2:4]], ratio)
-    t1 = time.perf_counter()
-    per_pair = max((t1 - t0) / 2.0, 1e-4)
-    n = int(max(4, min(len(pairs), budget_s / per_pair)))
+    fn(descs, pairs[order[8:40]], ratio)
+    per_pair = max((time.perf_counter() - t0) / 32.0, 1e-5)
+    n = int(max(32, min(len(pairs), budget_s / per_pair)))   # sized for ~budget_s seconds of host work
     sample = pairs[order[:n]]
     dp = float(sum(len(descs[a]) * len(descs[b]) for a, b in sample))
     t0 = time.perf_counter()
@@ -172,16 +172,20 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
     ctx.close()
-    ba_rec = None
+    ba_rec = ba_c5 = None
     if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
         try:
             from bench_ba import ba_bench_record
             ba_rec = ba_bench_record(local_rank, world)
+            if world == 1 and not args.no_ba_c5:   # configs[4] fits one GPU: reported beside its sharded runs at N > 1
+                ba_c5 = ba_bench_record(local_rank, 1, cpu=False, name="c5")
         except Exception as e:  # the BA leg is a side record: never lose the matching line
-            ba_rec = {"status": f"failed: {e!r}"}
+            ba_rec = ba_rec or {"status": f"failed: {e!r}"}
     if rank == 0:
         if ba_rec is not None:
             out["ba"] = ba_rec
+        if ba_c5 is not None:
+            out["ba_c5_single_gpu"] = ba_c5
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -202,6 +202,10 @@ int mvgx_ba_lm_iteration(mvgx_ba_ctx* ctx, const mvgx_ba_options* opt, mvgx_ba_s
 int mvgx_ba_read_params(mvgx_ba_ctx* ctx, double* poses, double* intrinsics, double* points);
 /* residual-only evaluation at the current parameters: cost (1/2 sum rho) and RMSE (no loss) */
 int mvgx_ba_evaluate(mvgx_ba_ctx* ctx, double* cost, double* rmse);
+/* |x - project(pose(X))| in pixels for every observation at the current parameters (unweighted, no loss), in the order
+ * of the problem's observation arrays: the quantity RemoveOutliers_PixelResidualError (sfm/sfm_data_filters.cpp:40-73)
+ * compares with its threshold in the "do { BA } while (badTrackRejector)" loops (sequential_SfM.cpp:206-210,1226-1232). */
+int mvgx_ba_residuals(mvgx_ba_ctx* ctx, double* residual_norm /* n_obs */);
 
 #ifdef __cplusplus
 }

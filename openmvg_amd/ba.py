@@ -127,6 +127,12 @@ class BaContext:
         _capi.check(_capi.lib().mvgx_ba_evaluate(self._h, C.byref(cost), C.byref(rmse)))
         return cost.value, rmse.value
 
+    def residuals(self):
+        """per-observation pixel residual norms at the current parameters (order of the scene's observation arrays)"""
+        out = np.zeros(int(self._keep["obs_pose"].shape[0]))
+        _capi.check(_capi.lib().mvgx_ba_residuals(self._h, out.ctypes.data))
+        return out
+
     def read_params(self):
         npz, ni, nx = self.shape
         poses = np.zeros((npz, 6)); intr = np.zeros((ni, 8)); pts = np.zeros((nx, 3))
@@ -178,3 +184,26 @@ class Bundle_Adjustment_HIP:
             scene["intrinsics"] = intr
         scene["points"] = pts
         return True
+
+
+def RemoveOutliers_PixelResidualError(scene, dThresholdPixel, minTrackLength=2, device=-1):
+    """Mirror of sfm::RemoveOutliers_PixelResidualError (sfm/sfm_data_filters.cpp:40-73) on the flat scene: observations
+    whose reprojection residual norm exceeds the threshold are erased, then tracks with fewer than minTrackLength
+    observations. The residuals come from the device (mvgx_ba_residuals). Returns (outlier_count, filtered scene); point
+    ids are kept (erased tracks simply lose all their observations), as the reference keeps landmark ids."""
+    ctx = BaContext(scene, device=device)
+    try:
+        res = ctx.residuals()
+    finally:
+        ctx.close()
+    keep = ~(res > float(dThresholdPixel))
+    outlier_count = int((~keep).sum())
+    cnt = np.bincount(np.asarray(scene["obs_point"])[keep], minlength=int(scene["n_points"]))
+    keep &= cnt[np.asarray(scene["obs_point"])] >= max(int(minTrackLength), 1)
+    out = dict(scene)
+    for k in ("obs_pose", "obs_intr", "obs_point", "obs_weight", "obs_is_control"):
+        if scene.get(k) is not None:
+            out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
+    out["obs_xy"] = np.ascontiguousarray(np.asarray(scene["obs_xy"], np.float64).reshape(-1, 2)[keep])
+    out["n_obs"] = int(keep.sum())
+    return outlier_count, out

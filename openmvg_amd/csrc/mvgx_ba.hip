@@ -99,6 +99,7 @@ struct Dev {
   double* oxy = nullptr;
   double* oweight = nullptr;          // n_obs or null
   uint8_t* octrl = nullptr;           // n_obs or null
+  uint32_t* oorig = nullptr;          // n_obs: index of the observation in the caller's arrays
   uint32_t* pt_start = nullptr;       // n_pts + 1
   uint32_t* ptk_start = nullptr;      // n_pts + 1 -> intrinsic slots of a point
   uint32_t* slot_intr = nullptr;      // n_islots
@@ -231,6 +232,24 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
   const double c = block_sum(cost, sh);
   const double q = block_sum(sq, sh);
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = c; part[2 * blockIdx.x + 1] = q; }
+}
+
+// |x - project(X)| per observation at the given parameters, unweighted, no loss: what RemoveOutliers_PixelResidualError
+// (sfm/sfm_data_filters.cpp:40-73) thresholds. out is indexed by the caller's observation order.
+__global__ __launch_bounds__(256) void ba_residual_norm_kernel(Dev d, const uint32_t* __restrict__ orig_index, double* __restrict__ out) {
+  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= d.n_obs) return;
+  const uint32_t ip = d.opose[o], ii = d.ointr[o], ix = d.opt[o];
+  double pin[8], pp[6], px[3], obs[2], r[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)ii * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+  obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
+  eval_observation<false>(d.model[ii], pin, pp, px, obs, r, nullptr, nullptr, nullptr);
+  out[orig_index[o]] = sqrt(r[0] * r[0] + r[1] * r[1]);
 }
 
 // pose-centre priors (one workgroup): cost added onto scalars[kSCost]; with kJac the loss-corrected residual and
@@ -812,22 +831,15 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict
       }
 }
 
-// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive). first_col: only the tiles of the
-// first block column of A22 (what the next block step needs); otherwise the tiles of all the other block columns.
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb, int first_col) {
+// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive)
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
   __shared__ double P[32][kTS];   // rows of tile I, k-major
   __shared__ double Q[32][kTS];   // rows of tile J (= columns of the destination tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r0 = k0 + kb;
-  int ti, tj;
-  if (first_col) {
-    ti = blockIdx.x; tj = 0;
-  } else {   // linear index -> (ti' >= tj') of the triangle without its first column; ti = ti' + 1, tj = tj' + 1
-    int t = blockIdx.x;
-    ti = 0;
-    while (t > ti) { t -= ti + 1; ++ti; }
-    tj = t + 1; ti += 1;
-  }
+  int t = blockIdx.x, ti = 0;
+  while (t > ti) { t -= ti + 1; ++ti; }
+  const int tj = t;
   const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
   const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
   d4_t acc[2][2], dst[2][2];   // dst: the destination tile, requested before anything else (one round trip less)
@@ -1111,10 +1123,6 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
-  // the Cholesky + back substitution as a captured HIP graph (built on first use): its launch sequence depends on N only
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipGraphExec_t chol_exec = nullptr;
 };
 
 namespace {
@@ -1204,13 +1212,15 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   return MVGX_OK;
 }
 
-// Cholesky of the summed system (rhs as extra row -> forward substitution) + back substitution -> zsol.
-// Issued once under stream capture and replayed as a HIP graph: ~4 launches per 64-column block step, all tiny, with a
-// one-step look-ahead expressed as graph edges - the update of the NEXT block column (what the next diagonal / panel
-// kernels need) stays on the main branch, the update of all other columns runs on a side branch concurrently with them.
-int enqueue_factor_and_solve(mvgx_ba_ctx* c) {
+// Cholesky of the summed system (rhs as extra row -> forward substitution) + back substitution -> zsol: three launches
+// per 64-column block step plus one per back-substitution step, all on the solver's stream.
+// Measured and rejected (profiles/round1_ba_chol_modes_call16.json): a one-step look-ahead that updates the next block
+// column on the main stream and the remaining columns on a side stream (fork / join through events) was 8 % slower on
+// C3 and 1.5 % faster on C5 - the cross-stream dependencies cost what the overlap gains; replaying the same sequence
+// as a captured HIP graph cost 4-16 ms of instantiation per context, more than a whole small solve.
+int factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
-  bool side_pending = false;
+  if (!d.N) return MVGX_OK;
   for (int k0 = 0; k0 < d.N; k0 += 64) {
     const int kb = std::min(64, d.N - k0);
     double* linv = d.linv + (size_t)(k0 / 64) * 8192;
@@ -1219,20 +1229,9 @@ int enqueue_factor_and_solve(mvgx_ba_ctx* c) {
     hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
     if (k0 + kb < d.N) {
       const int nt = (rows_below + 63) / 64;
-      if (nt > 1) {   // fork: the block columns the next step does not touch
-        MVGX_HIP(hipEventRecord(c->ev_fork, c->stream));
-        MVGX_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-      }
-      if (side_pending) { MVGX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0)); side_pending = false; }   // join the previous step's side update
-      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, 1);
-      if (nt > 1) {
-        hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt - 1) / 2), dim3(256), 0, c->side, d.S, d.N, d.LD, k0, kb, 0);
-        MVGX_HIP(hipEventRecord(c->ev_join, c->side));
-        side_pending = true;
-      }
+      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
     }
   }
-  if (side_pending) MVGX_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   BA_LAUNCH_CHECK();
   for (int b0 = ((d.N - 1) / 64) * 64; b0 >= 0; b0 -= 64) {
     const int kb = std::min(64, d.N - b0);
@@ -1240,22 +1239,6 @@ int enqueue_factor_and_solve(mvgx_ba_ctx* c) {
                        d.linv + (size_t)(b0 / 64) * 8192 + 4096, d.zsol);
   }
   BA_LAUNCH_CHECK();
-  return MVGX_OK;
-}
-
-int factor_and_solve(mvgx_ba_ctx* c) {
-  if (!c->d.N) return MVGX_OK;
-  if (!c->chol_exec) {
-    hipGraph_t graph = nullptr;
-    MVGX_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_factor_and_solve(c);
-    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    MVGX_HIP(e);
-    MVGX_HIP(hipGraphInstantiate(&c->chol_exec, graph, nullptr, nullptr, 0));
-    MVGX_HIP(hipGraphDestroy(graph));
-  }
-  MVGX_HIP(hipGraphLaunch(c->chol_exec, c->stream));
   return MVGX_OK;
 }
 
@@ -1447,9 +1430,6 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
-  MVGX_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  MVGX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  MVGX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), kSCount * sizeof(double), hipHostMallocDefault));
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_fail), sizeof(int), hipHostMallocDefault));
   Dev& d = c->d;
@@ -1612,6 +1592,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   UP(poses, h_poses); UP(intr, h_intr); UP(pts, h_pts); UP(model, h_model);
   AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
   UP(opose, opose); UP(ointr, ointr); UP(opt, opt_); UP(oxy, oxy);
+  { std::vector<uint32_t> oorig(perm.begin(), perm.end()); UP(oorig, oorig); }
   if (p->obs_weight) { UP(oweight, oweight); }
   if (p->obs_is_control) { UP(octrl, octrl); }
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
@@ -1671,10 +1652,6 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->chol_exec) (void)hipGraphExecDestroy(c->chol_exec);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   mvgx::rccl_destroy(c->rccl);
   delete c;
@@ -1739,6 +1716,20 @@ int mvgx_ba_read_params(mvgx_ba_ctx* c, double* poses, double* intrinsics, doubl
   if (poses) MVGX_HIP(hipMemcpyAsync(poses, d.poses, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (intrinsics) MVGX_HIP(hipMemcpyAsync(intrinsics, d.intr, (size_t)d.n_intr * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (points) MVGX_HIP(hipMemcpyAsync(points, d.pts, (size_t)d.n_pts * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+int mvgx_ba_residuals(mvgx_ba_ctx* c, double* residual_norm) {
+  MVGX_REQUIRE(c && residual_norm, MVGX_ERR_ARG, "mvgx_ba_residuals: NULL argument");
+  MVGX_HIP(hipSetDevice(c->device));
+  Dev& d = c->d;
+  if (!d.n_obs) return MVGX_OK;
+  double* out = nullptr;   // the Z array is free between LM iterations: borrow its first n_obs doubles
+  out = d.Zpose;
+  hipLaunchKernelGGL(ba_residual_norm_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.oorig, out);
+  BA_LAUNCH_CHECK();
+  MVGX_HIP(hipMemcpyAsync(residual_norm, out, (size_t)d.n_obs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   return MVGX_OK;
 }

@@ -193,3 +193,26 @@ def test_reduced_system_beyond_one_backsolve_group():
     assert s.num_iterations == osum.num_iterations == 1
     assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
     assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
+
+
+def test_pixel_residual_outlier_filter():
+    """mvgx_ba_residuals + the mirror of RemoveOutliers_PixelResidualError (sfm_data_filters.cpp:40-73) against a numpy
+    restatement that uses the projection of synth.project"""
+    sc = synth.ba_scene(n_cams=7, n_points=90, track_len=4, model=3, n_intr_groups=2, seed=55, outlier_frac=0.1, rot_deg=0.0,
+                        center_sigma=0.0, point_sigma=0.0)
+    sc["intrinsics"] = sc["intrinsics_gt"].copy()
+    perm = np.random.default_rng(1).permutation(sc["n_obs"])        # the caller's order is not the device's point order
+    for k in ("obs_pose", "obs_intr", "obs_point"):
+        sc[k] = sc[k][perm]
+    sc["obs_xy"] = sc["obs_xy"][perm]
+    xy = synth.project(3, sc["intrinsics"][sc["obs_intr"]], sc["poses"][sc["obs_pose"]], sc["points"][sc["obs_point"]])
+    want = np.linalg.norm(xy - sc["obs_xy"], axis=1)
+    with _emu.emulated():
+        ctx = ba.BaContext(sc); got = ctx.residuals(); ctx.close()
+        n_out, filtered = ba.RemoveOutliers_PixelResidualError(sc, 4.0, 3)
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-9)
+    keep = want <= 4.0
+    assert n_out == int((~keep).sum()) and n_out > 0
+    cnt = np.bincount(sc["obs_point"][keep], minlength=sc["n_points"])
+    keep &= cnt[sc["obs_point"]] >= 3
+    assert filtered["n_obs"] == int(keep.sum()) and np.array_equal(filtered["obs_point"], sc["obs_point"][keep])

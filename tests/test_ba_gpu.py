@@ -184,3 +184,27 @@ def test_error_behaviour():
     with pytest.raises(_capi.MvgxError) as e:
         ba.BaContext(bad2)
     assert e.value.code == _capi.MVGX_ERR_ARG
+
+
+def test_pixel_residual_outlier_filter():
+    """mvgx_ba_residuals + the mirror of RemoveOutliers_PixelResidualError (sfm_data_filters.cpp:40-73): the loop
+    `do { BA } while (badTrackRejector)` of the sequential pipeline (sequential_SfM.cpp:206-210), on the device"""
+    sc = synth.ba_scene(n_cams=30, n_points=3000, track_len=6, model=3, n_intr_groups=3, seed=56, outlier_frac=0.05)
+    perm = np.random.default_rng(1).permutation(sc["n_obs"])
+    for k in ("obs_pose", "obs_intr", "obs_point"):
+        sc[k] = sc[k][perm]
+    sc["obs_xy"] = sc["obs_xy"][perm]
+    adj = ba.Bundle_Adjustment_HIP()
+    assert adj.Adjust(sc)
+    xy = synth.project(3, sc["intrinsics"][sc["obs_intr"]], sc["poses"][sc["obs_pose"]], sc["points"][sc["obs_point"]])
+    want = np.linalg.norm(xy - sc["obs_xy"], axis=1)
+    ctx = ba.BaContext(sc); got = ctx.residuals(); ctx.close()
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    n_out, filtered = ba.RemoveOutliers_PixelResidualError(sc, 4.0, 2)
+    keep = want <= 4.0
+    assert n_out == int((~keep).sum()) and 0 < n_out < 0.2 * sc["n_obs"]
+    cnt = np.bincount(sc["obs_point"][keep], minlength=sc["n_points"])
+    keep &= cnt[sc["obs_point"]] >= 2
+    assert filtered["n_obs"] == int(keep.sum())
+    # a second BA on the filtered scene ends at the noise floor (the outliers are gone)
+    assert adj.Adjust(filtered) and adj.summary.final_rmse < 0.6
