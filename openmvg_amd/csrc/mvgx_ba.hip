@@ -874,54 +874,6 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
       }
 }
 
-// The same update on 128 x 128 tiles (each wave a 64 x 64 sub-tile = 4 x 4 MFMA blocks: half the LDS reads per MFMA),
-// used while the trailing matrix is large enough to fill the chip with them.
-constexpr int kTS2 = 144;   // LDS row stride of a k-major 128-wide operand tile
-constexpr int kBigUpdateTiles = 24;   // trailing matrix of >= 24 x 24 64-tiles (1536 rows): use the 128 x 128 kernel (default)
-__global__ __launch_bounds__(256) void chol_update_mfma128_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
-  __shared__ double P[16][kTS2];
-  __shared__ double Q[16][kTS2];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int r0 = k0 + kb;
-  int t = blockIdx.x, ti = 0;
-  while (t > ti) { t -= ti + 1; ++ti; }
-  const int tj = t;
-  const int i0 = r0 + ti * 128, j0 = r0 + tj * 128;
-  const int rbase = (wave & 1) * 64, cbase = (wave >> 1) * 64;
-  d4_t acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kc0 = 0; kc0 < kb; kc0 += 16) {
-    if (kc0) __syncthreads();
-    for (int q = tid; q < 16 * 128; q += 256) {
-      const int k = q >> 7, r = q & 127, kk = kc0 + k;
-      P[k][r] = (kk < kb && i0 + r <= n) ? A[(size_t)(k0 + kk) * ld + (i0 + r)] : 0.0;
-      Q[k][r] = (kk < kb && j0 + r < n) ? A[(size_t)(k0 + kk) * ld + (j0 + r)] : 0.0;
-    }
-    __syncthreads();
-    for (int k = 0; k < 16; k += 4) {
-      double qv[4], pv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { qv[u] = Q[k + lk][cbase + 16 * u + li]; pv[u] = P[k + lk][rbase + 16 * u + li]; }
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[ci], pv[ri], acc[ci][ri], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-    for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c = j0 + cbase + 16 * ci + lk + 4 * reg, r = i0 + rbase + 16 * ri + li;
-        if (r <= n && c < n && r >= c) A[(size_t)c * ld + r] -= acc[ci][ri][reg];
-      }
-}
-
 // Back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
 // y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 256 columns c < b0: four lanes per column, 16 contiguous rows
 // (one cache line) each. The step is a chain of tiny dependent phases, so every global load it needs (y_b, the inverse
@@ -1171,7 +1123,6 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
-  int big_update_tiles = kBigUpdateTiles;   // tuning: MVGX_BA_BIG_UPDATE_TILES (the tests lower it to reach the 128-tile kernel on small systems)
 };
 
 namespace {
@@ -1266,7 +1217,8 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 // Measured and rejected (profiles/round1_ba_chol_modes_call16.json): a one-step look-ahead that updates the next block
 // column on the main stream and the remaining columns on a side stream (fork / join through events) was 8 % slower on
 // C3 and 1.5 % faster on C5 - the cross-stream dependencies cost what the overlap gains; replaying the same sequence
-// as a captured HIP graph cost 4-16 ms of instantiation per context, more than a whole small solve.
+// as a captured HIP graph cost 4-16 ms of instantiation per context, more than a whole small solve. An update kernel on
+// 128 x 128 tiles (64 x 64 per wave) was 2.1x slower per launch than the 64 x 64 one at C5 (profiles/round1_ba_c5_update128_call18.json).
 int factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   if (!d.N) return MVGX_OK;
@@ -1278,12 +1230,7 @@ int factor_and_solve(mvgx_ba_ctx* c) {
     hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
     if (k0 + kb < d.N) {
       const int nt = (rows_below + 63) / 64;
-      if (nt >= c->big_update_tiles) {
-        const int nt2 = (rows_below + 127) / 128;
-        hipLaunchKernelGGL(chol_update_mfma128_kernel, dim3(nt2 * (nt2 + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-      } else {
-        hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
-      }
+      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
     }
   }
   BA_LAUNCH_CHECK();
@@ -1491,7 +1438,6 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.N = 6 * (int)d.n_poses + 8 * (int)d.n_intr; d.LD = d.N + 1;
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
-  if (const char* env = getenv("MVGX_BA_BIG_UPDATE_TILES")) c->big_update_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
 
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----

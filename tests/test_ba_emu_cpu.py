@@ -217,13 +217,3 @@ def test_pixel_residual_outlier_filter():
     keep &= cnt[sc["obs_point"]] >= 3
     assert filtered["n_obs"] == int(keep.sum()) and np.array_equal(filtered["obs_point"], sc["obs_point"][keep])
 
-
-def test_128_tile_update_kernel(monkeypatch):
-    """the Cholesky update on 128 x 128 tiles (used for trailing matrices of >= 1536 rows) forced onto a small system"""
-    monkeypatch.setenv("MVGX_BA_BIG_UPDATE_TILES", "1")
-    sc = synth.ba_scene(n_cams=42, n_points=260, track_len=4, model=3, n_intr_groups=3, seed=37)
-    opt = dict(max_num_iterations=1)
-    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
-    s, poses, intr, pts = _solve_emu(sc, ba.default_options(**opt))
-    assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
-    assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
