@@ -831,16 +831,17 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict
       }
 }
 
-// A22 -= L21 L21^T on the 64 x 64 tiles of the lower triangle (rows up to n inclusive)
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int k0, int kb) {
+// Trailing update A(r, c) -= sum_{q in [ks, ks + klen)} L(r, q) L(c, q) on the 64 x 64 tiles (ti >= tj) of the lower
+// triangle whose first row / column is t0, for columns c < col_end and rows r <= n (the rhs row rides along). Two uses per
+// outer panel of the two-level factorisation: the inner step (klen = 64, columns up to the end of the panel only) and the
+// panel's deferred update of everything to its right (klen = panel width: K-times fewer passes over the trailing matrix).
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restrict__ A, int n, int ld, int ks, int klen, int t0, int col_end) {
   __shared__ double P[32][kTS];   // rows of tile I, k-major
   __shared__ double Q[32][kTS];   // rows of tile J (= columns of the destination tile)
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti < tj) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r0 = k0 + kb;
-  int t = blockIdx.x, ti = 0;
-  while (t > ti) { t -= ti + 1; ++ti; }
-  const int tj = t;
-  const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
+  const int i0 = t0 + ti * 64, j0 = t0 + tj * 64;
   const int rbase = (wave & 1) * 32, cbase = (wave >> 1) * 32;
   d4_t acc[2][2], dst[2][2];   // dst: the destination tile, requested before anything else (one round trip less)
 #pragma unroll
@@ -850,15 +851,15 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int c = j0 + cbase + 16 * ci + (lane >> 4) + 4 * reg, r = i0 + rbase + 16 * ri + (lane & 15);
-        dst[ci][ri][reg] = (r <= n && c < n && r >= c) ? A[(size_t)c * ld + r] : 0.0;
+        dst[ci][ri][reg] = (r <= n && c < col_end && r >= c) ? A[(size_t)c * ld + r] : 0.0;
         acc[ci][ri][reg] = 0.0;
       }
-  for (int kc0 = 0; kc0 < kb; kc0 += 32) {
+  for (int kc0 = 0; kc0 < klen; kc0 += 32) {
     if (kc0) __syncthreads();
     for (int q = tid; q < 32 * 64; q += 256) {
       const int k = q >> 6, r = q & 63, kk = kc0 + k;
-      P[k][r] = (kk < kb && i0 + r <= n) ? A[(size_t)(k0 + kk) * ld + (i0 + r)] : 0.0;
-      Q[k][r] = (kk < kb && j0 + r < n) ? A[(size_t)(k0 + kk) * ld + (j0 + r)] : 0.0;
+      P[k][r] = (kk < klen && i0 + r <= n) ? A[(size_t)(ks + kk) * ld + (i0 + r)] : 0.0;
+      Q[k][r] = (kk < klen && j0 + r < col_end) ? A[(size_t)(ks + kk) * ld + (j0 + r)] : 0.0;
     }
     __syncthreads();
     mfma_tile_32x32(P, Q, 32, rbase, cbase, acc);
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int c = j0 + cbase + 16 * ci + (lane >> 4) + 4 * reg, r = i0 + rbase + 16 * ri + (lane & 15);
-        if (r <= n && c < n && r >= c) A[(size_t)c * ld + r] = dst[ci][ri][reg] - acc[ci][ri][reg];
+        if (r <= n && c < col_end && r >= c) A[(size_t)c * ld + r] = dst[ci][ri][reg] - acc[ci][ri][reg];
       }
 }
 
@@ -1123,6 +1124,7 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
+  int two_level_min_n = 2048;   // tuning (MVGX_BA_TWO_LEVEL_MIN_N): reduced systems at least this wide factor with 256-column outer panels
 };
 
 namespace {
@@ -1222,15 +1224,27 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 int factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   if (!d.N) return MVGX_OK;
-  for (int k0 = 0; k0 < d.N; k0 += 64) {
-    const int kb = std::min(64, d.N - k0);
-    double* linv = d.linv + (size_t)(k0 / 64) * 8192;
-    hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linv, d.fail);
-    const int rows_below = d.N + 1 - (k0 + kb);   // >= 1: the rhs row
-    hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
-    if (k0 + kb < d.N) {
-      const int nt = (rows_below + 63) / 64;
-      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb);
+  // two-level blocking: outer panels of pw columns; inside a panel the classic 64-column steps update only the panel's
+  // own columns, the rest of the trailing matrix gets one update per panel with K = pw. The trailing matrix is read and
+  // written N / pw times instead of N / 64 (C5: the update is bound by that traffic). Small systems are launch-latency
+  // bound instead and keep pw = 64 (= the classic right-looking sweep: no inner update, one full update per step).
+  const int pw_cfg = d.N >= c->two_level_min_n ? 256 : 64;
+  for (int p0 = 0; p0 < d.N; p0 += pw_cfg) {
+    const int pend = std::min(d.N, p0 + pw_cfg);
+    for (int k0 = p0; k0 < pend; k0 += 64) {
+      const int kb = std::min(64, pend - k0);
+      double* linv = d.linv + (size_t)(k0 / 64) * 8192;
+      hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, c->stream, d.S, d.LD, k0, kb, linv, d.fail);
+      const int rows_below = d.N + 1 - (k0 + kb);   // >= 1: the rhs row
+      hipLaunchKernelGGL(chol_panel_mfma_kernel, dim3((rows_below + 63) / 64), dim3(256), kPanelLds, c->stream, d.S, d.N, d.LD, k0, kb, linv);
+      if (k0 + kb < pend) {   // columns of this panel right of the block
+        const int ntr = (rows_below + 63) / 64, ntc = (pend - (k0 + kb) + 63) / 64;
+        hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(ntr, ntc), dim3(256), 0, c->stream, d.S, d.N, d.LD, k0, kb, k0 + kb, pend);
+      }
+    }
+    if (pend < d.N) {   // everything right of the panel, K = panel width
+      const int nt = (d.N + 1 - pend + 63) / 64;
+      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt, nt), dim3(256), 0, c->stream, d.S, d.N, d.LD, p0, pend - p0, pend, d.N);
     }
   }
   BA_LAUNCH_CHECK();
@@ -1438,6 +1452,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.N = 6 * (int)d.n_poses + 8 * (int)d.n_intr; d.LD = d.N + 1;
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
+  if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
 
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----

@@ -120,10 +120,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = &body;
   g_gridDim = grid;
   g_blockDim = block;
-  for (unsigned b = 0; b < grid.x; ++b) {
-    g_blockIdx = dim3(b, 0, 0);
-    run_block(block.x);
-  }
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_blockIdx = dim3(bx, by, bz);
+        run_block(block.x);   // one-dimensional workgroups only (all the solver uses)
+      }
   g_body = nullptr;
 }
 

@@ -217,3 +217,15 @@ def test_pixel_residual_outlier_filter():
     keep &= cnt[sc["obs_point"]] >= 3
     assert filtered["n_obs"] == int(keep.sum()) and np.array_equal(filtered["obs_point"], sc["obs_point"][keep])
 
+
+
+def test_two_level_cholesky(monkeypatch):
+    """256-column outer panels (used for reduced systems of >= 2048 columns) forced onto a 276-column system: inner steps
+    update the panel's own columns, one deferred K = 256 update covers the rest, the last panel is partial"""
+    monkeypatch.setenv("MVGX_BA_TWO_LEVEL_MIN_N", "1")
+    sc = synth.ba_scene(n_cams=42, n_points=260, track_len=4, model=3, n_intr_groups=3, seed=37)
+    opt = dict(max_num_iterations=1)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
+    s, poses, intr, pts = _solve_emu(sc, ba.default_options(**opt))
+    assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
