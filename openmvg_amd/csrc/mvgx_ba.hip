@@ -875,6 +875,66 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double* __restric
       }
 }
 
+// The deferred panel update on 128 x 128 tiles (each wave a 64 x 64 sub-tile = 4 x 4 MFMA blocks), software-pipelined:
+// the next 32-deep slice of both operands is fetched into registers while the current one is multiplied out of LDS.
+// PMC counters place the 64 x 64 kernel at C5 on the L2 / Infinity-cache line-traffic limit (~3.7 TB/s x 4 flop/B = 15
+// TFLOP/s: S does not fit the 32 MiB of L2); a 128 x 128 tile with K = 256 moves 2.7x fewer bytes per flop.
+constexpr int kTS2 = 144;   // LDS row stride of a k-major 128-wide operand tile (rows k, k + 1 land 32 banks apart)
+constexpr int kUpd128Lds = 2 * 32 * kTS2 * (int)sizeof(double);
+__global__ __launch_bounds__(256, 2) void chol_update128_kernel(double* __restrict__ A, int n, int ld, int ks, int klen, int t0, int col_end) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double (*P)[kTS2] = reinterpret_cast<double (*)[kTS2]>(lds);
+  double (*Q)[kTS2] = reinterpret_cast<double (*)[kTS2]>(lds + 32 * kTS2);
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti < tj) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int i0 = t0 + ti * 128, j0 = t0 + tj * 128;
+  const int rbase = (wave & 1) * 64, cbase = (wave >> 1) * 64;
+  d4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double pr[16], qr[16];
+  const int lr = tid & 127, lk0 = tid >> 7;   // this thread's row of the slice and its first k (k = lk0, lk0 + 2, ...)
+  const bool pin = i0 + lr <= n, qin = j0 + lr < col_end;
+  auto fetch = [&](int kc0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = kc0 + lk0 + 2 * i;
+      const size_t colbase = (size_t)(ks + kk) * ld;
+      pr[i] = (kk < klen && pin) ? A[colbase + (i0 + lr)] : 0.0;
+      qr[i] = (kk < klen && qin) ? A[colbase + (j0 + lr)] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int kc0 = 0; kc0 < klen; kc0 += 32) {
+    if (kc0) __syncthreads();   // everyone is done reading the previous slice
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { P[lk0 + 2 * i][lr] = pr[i]; Q[lk0 + 2 * i][lr] = qr[i]; }
+    __syncthreads();
+    if (kc0 + 32 < klen) fetch(kc0 + 32);   // in flight during the MFMA work below
+    for (int k = 0; k < 32; k += 4) {
+      double qv[4], pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { qv[u] = Q[k + lk][cbase + 16 * u + li]; pv[u] = P[k + lk][rbase + 16 * u + li]; }
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[ci], pv[ri], acc[ci][ri], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c = j0 + cbase + 16 * ci + lk + 4 * reg, r = i0 + rbase + 16 * ri + li;
+        if (r <= n && c < col_end && r >= c) A[(size_t)c * ld + r] -= acc[ci][ri][reg];
+      }
+}
+
 // Back substitution, block step b0: z_b = L_bb^-T y_b (every workgroup, in LDS; workgroup 0 stores it), then
 // y_c -= sum_r L(b0 + r, c) z_b[r] for this workgroup's 256 columns c < b0: four lanes per column, 16 contiguous rows
 // (one cache line) each. The step is a chain of tiny dependent phases, so every global load it needs (y_b, the inverse
@@ -1124,6 +1184,7 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
+  int update128_min_tiles = 128;   // tuning (MVGX_BA_UPDATE128_MIN_TILES): deferred updates with at least this many 128 x 128 tiles use them
   int two_level_min_n = 2048;   // tuning (MVGX_BA_TWO_LEVEL_MIN_N): reduced systems at least this wide factor with 256-column outer panels
 };
 
@@ -1243,8 +1304,11 @@ int factor_and_solve(mvgx_ba_ctx* c) {
       }
     }
     if (pend < d.N) {   // everything right of the panel, K = panel width
-      const int nt = (d.N + 1 - pend + 63) / 64;
-      hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt, nt), dim3(256), 0, c->stream, d.S, d.N, d.LD, p0, pend - p0, pend, d.N);
+      const int nt = (d.N + 1 - pend + 63) / 64, nt2 = (d.N + 1 - pend + 127) / 128;
+      if (pw_cfg > 64 && nt2 * (nt2 + 1) / 2 >= c->update128_min_tiles)
+        hipLaunchKernelGGL(chol_update128_kernel, dim3(nt2, nt2), dim3(256), kUpd128Lds, c->stream, d.S, d.N, d.LD, p0, pend - p0, pend, d.N);
+      else
+        hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(nt, nt), dim3(256), 0, c->stream, d.S, d.N, d.LD, p0, pend - p0, pend, d.N);
     }
   }
   BA_LAUNCH_CHECK();
@@ -1453,6 +1517,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
+  if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
 
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----
@@ -1654,6 +1719,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kUpd128Lds));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   *out = c;
   return MVGX_OK;

@@ -219,10 +219,13 @@ def test_pixel_residual_outlier_filter():
 
 
 
-def test_two_level_cholesky(monkeypatch):
+@pytest.mark.parametrize("tiles128", [1, 1000])
+def test_two_level_cholesky(monkeypatch, tiles128):
     """256-column outer panels (used for reduced systems of >= 2048 columns) forced onto a 276-column system: inner steps
-    update the panel's own columns, one deferred K = 256 update covers the rest, the last panel is partial"""
+    update the panel's own columns, one deferred K = 256 update covers the rest (on 128 x 128 or on 64 x 64 tiles), the last
+    panel is partial"""
     monkeypatch.setenv("MVGX_BA_TWO_LEVEL_MIN_N", "1")
+    monkeypatch.setenv("MVGX_BA_UPDATE128_MIN_TILES", str(tiles128))
     sc = synth.ba_scene(n_cams=42, n_points=260, track_len=4, model=3, n_intr_groups=3, seed=37)
     opt = dict(max_num_iterations=1)
     rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
