@@ -122,6 +122,13 @@ struct Dev {
   double *Zpose = nullptr, *Zint = nullptr; // n_obs x 18, n_islots x 24
   TripList tpp, tpi, tii;
   double* S = nullptr;                // N x LD
+  // multi-rank exchange of S: the union over ranks of the non-zero camera blocks, packed contiguously (+ the rhs column)
+  uint32_t n_ublocks = 0;
+  uint64_t n_packed = 0;
+  uint32_t *ublk_row = nullptr, *ublk_col = nullptr;   // first row / column of the block in S
+  uint8_t *ublk_h = nullptr, *ublk_w = nullptr;        // 6 or 8
+  uint64_t* ublk_off = nullptr;
+  double* packed = nullptr;
   double* linv = nullptr;             // per Cholesky block step: L11^-1 k-major (64 x 64), then row-major (64 x 64)
   double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
   double* part = nullptr;             // partial sums (reductions)
@@ -625,6 +632,35 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
     const double g = KIND == 0 ? d.pose_gram[(size_t)rcb * kPoseGram + 21 + r] : d.igram[(size_t)(rcb - np) * kIntrGram + 36 + r];
     d.S[(size_t)(row0 + r) * d.LD + d.N] = g * d.scale_cam[row0 + r] - sum;
   }
+}
+
+// ---- multi-rank exchange of the reduced system --------------------------------------------------------------------
+// S is block sparse (a pair of cameras shares a block only if some point sees both). Only the blocks that are non-zero
+// on at least one rank travel: every rank marks its own blocks in an n_cb x n_cb flag matrix (upper triangle), one
+// all-reduce(max) of the flags at the start of the solve gives all ranks the same union and the same packed layout.
+template <int KIND>
+__global__ void ba_mark_blocks_kernel(Dev d, TripList L, double* __restrict__ flags, int n_cb) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < L.n_blocks) flags[(size_t)L.block_row[b] * n_cb + L.block_col[b]] = 1.0;
+}
+// one workgroup per union block: S block -> packed (dir 0) or packed -> S block (dir 1); the last workgroup moves the rhs
+__global__ __launch_bounds__(64) void ba_pack_system_kernel(Dev d, int dir) {
+  const uint32_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  if (b == d.n_ublocks) {
+    double* pk = d.packed + (d.n_packed - (uint64_t)d.N);
+    for (int i = t; i < d.N; i += 64) {
+      double* sp = d.S + (size_t)i * d.LD + d.N;
+      if (dir == 0) pk[i] = *sp; else *sp = pk[i];
+    }
+    return;
+  }
+  const int h = d.ublk_h[b], w = d.ublk_w[b];
+  if (t >= h * w) return;
+  const int r = t / w, c = t - r * w;
+  double* sp = d.S + (size_t)(d.ublk_row[b] + r) * d.LD + (d.ublk_col[b] + c);
+  double* pk = d.packed + d.ublk_off[b] + t;
+  if (dir == 0) *pk = *sp; else *sp = *pk;
 }
 
 // After the (cross-rank) sum of the partial systems: S_jj += D_j^2 = diag_j / radius for free components, unit diagonal
@@ -1321,13 +1357,70 @@ int factor_and_solve(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
+// One-time (per solve) agreement on the union of non-zero camera blocks across ranks; see ba_mark_blocks_kernel.
+int setup_block_exchange(mvgx_ba_ctx* c) {
+  Dev& d = c->d;
+  if (!multi_rank(c) || d.ublk_off) return MVGX_OK;
+  const int n_cb = (int)d.n_poses + (int)d.n_intr;
+  double* flags = nullptr;
+  int rc = dev_alloc(c->pool, &flags, (size_t)n_cb * n_cb);
+  if (rc) return rc;
+  MVGX_HIP(hipMemsetAsync(flags, 0, (size_t)n_cb * n_cb * sizeof(double), c->stream));
+  if (d.tpp.n_blocks) hipLaunchKernelGGL(ba_mark_blocks_kernel<0>, dim3((d.tpp.n_blocks + 255) / 256), dim3(256), 0, c->stream, d, d.tpp, flags, n_cb);
+  if (d.tpi.n_blocks) hipLaunchKernelGGL(ba_mark_blocks_kernel<1>, dim3((d.tpi.n_blocks + 255) / 256), dim3(256), 0, c->stream, d, d.tpi, flags, n_cb);
+  if (d.tii.n_blocks) hipLaunchKernelGGL(ba_mark_blocks_kernel<2>, dim3((d.tii.n_blocks + 255) / 256), dim3(256), 0, c->stream, d, d.tii, flags, n_cb);
+  BA_LAUNCH_CHECK();
+  if ((rc = all_reduce(c, flags, (uint64_t)n_cb * n_cb, MVGX_REDUCE_MAX))) return rc;
+  std::vector<double> h((size_t)n_cb * n_cb);
+  MVGX_HIP(hipMemcpyAsync(h.data(), flags, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> brow, bcol;
+  std::vector<uint8_t> bh, bw;
+  std::vector<uint64_t> boff;
+  uint64_t off = 0;
+  auto first = [&](int cb) { return cb < (int)d.n_poses ? 6 * cb : 6 * (int)d.n_poses + 8 * (cb - (int)d.n_poses); };
+  auto width = [&](int cb) { return cb < (int)d.n_poses ? 6 : 8; };
+  for (int r = 0; r < n_cb; ++r)
+    for (int q = r; q < n_cb; ++q)
+      if (h[(size_t)r * n_cb + q] != 0.0) {
+        brow.push_back((uint32_t)first(r)); bcol.push_back((uint32_t)first(q));
+        bh.push_back((uint8_t)width(r)); bw.push_back((uint8_t)width(q));
+        boff.push_back(off);
+        off += (uint64_t)width(r) * width(q);
+      }
+  d.n_ublocks = (uint32_t)brow.size();
+  d.n_packed = off + (uint64_t)d.N;   // + the rhs column
+  boff.push_back(off);
+  if ((rc = dev_upload(c->pool, &d.ublk_row, brow, c->stream))) return rc;
+  if ((rc = dev_upload(c->pool, &d.ublk_col, bcol, c->stream))) return rc;
+  if ((rc = dev_upload(c->pool, &d.ublk_h, bh, c->stream))) return rc;
+  if ((rc = dev_upload(c->pool, &d.ublk_w, bw, c->stream))) return rc;
+  if ((rc = dev_upload(c->pool, &d.ublk_off, boff, c->stream))) return rc;
+  if ((rc = dev_alloc(c->pool, &d.packed, (size_t)d.n_packed))) return rc;
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+// sum of the partial reduced systems over the ranks: the one bulk exchange of the iteration (RCCL over xGMI)
+int exchange_system(mvgx_ba_ctx* c) {
+  Dev& d = c->d;
+  if (!multi_rank(c) || !d.N) return MVGX_OK;
+  hipLaunchKernelGGL(ba_pack_system_kernel, dim3(d.n_ublocks + 1), dim3(64), 0, c->stream, d, 0);
+  BA_LAUNCH_CHECK();
+  const int rc = all_reduce(c, d.packed, d.n_packed);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ba_pack_system_kernel, dim3(d.n_ublocks + 1), dim3(64), 0, c->stream, d, 1);
+  BA_LAUNCH_CHECK();
+  return MVGX_OK;
+}
+
 // LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver::SolveImpl. ok=false <=> LINEAR_SOLVER_FAILURE.
 int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   Dev& d = c->d;
   const double inv_radius = 1.0 / c->radius;
   int rc = assemble_system(c, inv_radius);
   if (rc) return rc;
-  if ((rc = all_reduce(c, d.S, (uint64_t)d.N * d.LD))) return rc;   // the one bulk exchange of the iteration (RCCL over xGMI)
+  if ((rc = exchange_system(c))) return rc;
   if (d.N) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
   BA_LAUNCH_CHECK();
   if ((rc = factor_and_solve(c))) return rc;
@@ -1393,6 +1486,7 @@ double rmse_from(const mvgx_ba_ctx* c) {
 int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   int rc = global_obs_count(c);
   if (rc) return rc;
+  if ((rc = setup_block_exchange(c))) return rc;
   if ((rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts))) return rc;
   if ((rc = read_scalars(c))) return rc;
   c->initial_rmse = rmse_from(c);

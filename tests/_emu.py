@@ -28,7 +28,9 @@ def build(force=False):
         return _OUT
     os.makedirs(os.path.dirname(_OUT), exist_ok=True)
     cxx = _CLANG if os.path.exists(_CLANG) else "clang++"
-    subprocess.run([cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-psabi", "-I" + _SRC,
+    subprocess.run([cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-psabi",
+                    "-Wl,-Bsymbolic",   # never bind to same-named (weak, inline) symbols of libmvgx_hip.so loaded earlier
+                    "-I" + _SRC,
                     "-I" + os.path.join(_ROOT, "include"), "-I" + csrc, os.path.join(_SRC, "hipemu.cpp"), "-o", _OUT], check=True)
     return _OUT
 
