@@ -65,7 +65,8 @@ int mvgx_match_create(int device, mvgx_match_ctx** out);
 int mvgx_match_destroy(mvgx_match_ctx* ctx);
 
 /* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch),
- * "batch_pairs" (pairs per device batch), "keep_host_results" (0: skip D2H of the match lists). */
+ * "batch_pairs" (pairs per device batch), "keep_host_results" (0: skip D2H of the match lists),
+ * "overlap" (default 1: two batch slots, batch b filters while batch b-1 is verified/compacted/copied; 0: one at a time). */
 int mvgx_match_set_option(mvgx_match_ctx* ctx, const char* key, int64_t value);
 
 /* Load the descriptor arrays of n_images images into HBM (replaces Regions_Provider::get +

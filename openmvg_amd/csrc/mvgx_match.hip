@@ -920,6 +920,7 @@ struct mvgx_match_ctx {
   int profile = 0;
   int64_t batch_pairs = 1 << 17;
   int keep_host_results = 1;
+  int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
   // regions
   uint32_t n_images = 0;
   uint32_t total_tiles = 0;
@@ -934,12 +935,20 @@ struct mvgx_match_ctx {
   DevBuf<int> d_rconst, d_cinit, d_qnorm, d_rownorm;
   DevBuf<uint64_t> d_row_off;
   DevBuf<uint32_t> d_tile_off, d_n, d_ntiles, d_perm, d_rowpos, d_neven, d_err;
-  DevBuf<int2> d_cd;
-  // batch scratch
-  DevBuf<uint2> d_pairs, d_work, d_ij;
-  DevBuf<uint32_t> d_best, d_count, d_offsets;
-  PinnedBuf<uint2> hp_pairs, hp_work;
-  PinnedBuf<uint32_t> hp_offsets;
+  // batch scratch, two slots: while the filter kernel of batch b runs, batch b-1 is verified, scanned, compacted and
+  // copied out on the other slot's stream
+  struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_scan = nullptr;     // offsets of the batch are on the host
+    hipEvent_t ev_filter = nullptr;   // filter kernel of the batch has finished
+    DevBuf<uint2> d_pairs, d_work, d_ij;
+    DevBuf<uint32_t> d_best, d_count, d_offsets;
+    DevBuf<int2> d_cd;
+    PinnedBuf<uint2> hp_pairs, hp_work;
+    PinnedBuf<uint32_t> hp_offsets;
+    uint64_t p0 = 0;
+    uint32_t nb = 0;
+  } slot[2];
   // results of the last run
   std::vector<uint64_t> res_offsets;
   std::vector<uint32_t> res_ij;
@@ -1053,6 +1062,11 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev_total0));
   MVGX_HIP(hipEventCreate(&c->ev_total1));
+  for (auto& sl : c->slot) {
+    MVGX_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    MVGX_HIP(hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
+    MVGX_HIP(hipEventCreateWithFlags(&sl.ev_filter, hipEventDisableTiming));
+  }
   // 2 x 33 KiB dynamic LDS for both MFMA variants
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_top2_ratio_kernel<kStageRegs>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
@@ -1076,11 +1090,16 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_rows.release(); c->d_tiles.release(); c->d_rconst.release(); c->d_qnorm.release();
   c->d_rows_slot.release(); c->d_cinit.release(); c->d_rownorm.release(); c->d_ntiles.release(); c->d_perm.release(); c->d_rowpos.release();
-  c->d_neven.release(); c->d_err.release(); c->d_cd.release();
+  c->d_neven.release(); c->d_err.release();
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
-  c->d_pairs.release(); c->d_work.release(); c->d_ij.release();
-  c->d_best.release(); c->d_count.release(); c->d_offsets.release();
-  c->hp_pairs.release(); c->hp_work.release(); c->hp_offsets.release();
+  for (auto& sl : c->slot) {
+    sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
+    sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
+    sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release();
+    if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
+    if (sl.ev_filter) (void)hipEventDestroy(sl.ev_filter);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_total0) (void)hipEventDestroy(c->ev_total0);
   if (c->ev_total1) (void)hipEventDestroy(c->ev_total1);
@@ -1104,6 +1123,8 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->batch_pairs = value;
   } else if (!strcmp(key, "keep_host_results")) {
     c->keep_host_results = value != 0;
+  } else if (!strcmp(key, "overlap")) {
+    c->overlap = value != 0;
   } else {
     set_error("unknown option '%s'", key);
     return MVGX_ERR_ARG;
@@ -1170,109 +1191,139 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
   size_t n_ev = 0;
   int rc;
 
-  MVGX_HIP(hipEventRecord(c->ev_total0, c->stream));
+  MVGX_HIP(hipEventRecord(c->ev_total0, c->slot[0].stream));
   const uint64_t B = (uint64_t)c->batch_pairs;
-  for (uint64_t p0 = 0; p0 < n_pairs; p0 += B) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
-    if ((rc = c->hp_pairs.ensure(nb))) return rc;
+
+  // Stage 1 of a batch on its slot's stream: work list -> filter (+ verify) -> per-pair counts -> exclusive scan -> offsets to host
+  auto issue = [&](mvgx_match_ctx::Slot& sl, mvgx_match_ctx::Slot* prev, uint64_t p0, uint32_t nb) -> int {
+    int rc;
+    hipStream_t stream = sl.stream;
+    sl.p0 = p0; sl.nb = nb;
+    if ((rc = sl.hp_pairs.ensure(nb))) return rc;
     // worst-case work items: ceil(max tiles / 16) per pair
     const uint32_t max_blocks_per_pair = std::max<uint32_t>(1, (c->max_tiles_pad + kBlockQTiles - 1) / kBlockQTiles);
-    if ((rc = c->hp_work.ensure((size_t)nb * max_blocks_per_pair))) return rc;
+    if ((rc = sl.hp_work.ensure((size_t)nb * max_blocks_per_pair))) return rc;
     uint32_t n_work = 0;
     for (uint32_t k = 0; k < nb; ++k) {
       const uint32_t I = pairs_IJ[2 * (p0 + k)], J = pairs_IJ[2 * (p0 + k) + 1];
-      c->hp_pairs.p[k] = make_uint2(I, J);
+      sl.hp_pairs.p[k] = make_uint2(I, J);
       const uint32_t nI = c->h_n[I], nJ = c->h_n[J];
       // matcher_brute_force.hpp:108-113: NN(=2) > rows  -> no result; Matcher_Regions.cpp:65-69,85-90: empty regions skipped
       if (nI < 2 || nJ == 0) continue;
       const uint32_t ntJ = c->h_ntiles[J];   // occupied tiles of the query image
-      for (uint32_t qt = 0; qt < ntJ; qt += kBlockQTiles) c->hp_work.p[n_work++] = make_uint2(k, qt);
+      for (uint32_t qt = 0; qt < ntJ; qt += kBlockQTiles) sl.hp_work.p[n_work++] = make_uint2(k, qt);
       st.n_pairs += 1;
       st.n_desc_pairs += (uint64_t)nI * nJ;
     }
-    if ((rc = c->d_pairs.ensure(nb))) return rc;
-    if ((rc = c->d_work.ensure(std::max<uint32_t>(n_work, 1)))) return rc;
-    if ((rc = c->d_best.ensure((size_t)nb * c->qstride))) return rc;
+    if ((rc = sl.d_pairs.ensure(nb))) return rc;
+    if ((rc = sl.d_work.ensure(std::max<uint32_t>(n_work, 1)))) return rc;
+    if ((rc = sl.d_best.ensure((size_t)nb * c->qstride))) return rc;
     if (c->variant == 4) {
-      if ((rc = c->d_cd.ensure((size_t)nb * c->qstride))) return rc;
+      if ((rc = sl.d_cd.ensure((size_t)nb * c->qstride))) return rc;
     }
-    if ((rc = c->d_count.ensure(nb))) return rc;
-    if ((rc = c->d_offsets.ensure((size_t)nb + 1))) return rc;
-    if ((rc = c->hp_offsets.ensure((size_t)nb + 1))) return rc;
-    MVGX_HIP(hipMemcpyAsync(c->d_pairs.p, c->hp_pairs.p, nb * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    if ((rc = sl.d_count.ensure(nb))) return rc;
+    if ((rc = sl.d_offsets.ensure((size_t)nb + 1))) return rc;
+    if ((rc = sl.hp_offsets.ensure((size_t)nb + 1))) return rc;
+    MVGX_HIP(hipMemcpyAsync(sl.d_pairs.p, sl.hp_pairs.p, nb * sizeof(uint2), hipMemcpyHostToDevice, stream));
     if (n_work)
-      MVGX_HIP(hipMemcpyAsync(c->d_work.p, c->hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-    MVGX_HIP(hipMemsetAsync(c->d_count.p, 0, nb * sizeof(uint32_t), c->stream));
+      MVGX_HIP(hipMemcpyAsync(sl.d_work.p, sl.hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemsetAsync(sl.d_count.p, 0, nb * sizeof(uint32_t), stream));
 
     MatchParams mp;
     mp.tiles = c->d_tiles.p; mp.rows_slot = c->d_rows_slot.p; mp.rconst = c->d_rconst.p; mp.cinit = c->d_cinit.p; mp.qnorm = c->d_qnorm.p;
     mp.perm = c->d_perm.p; mp.rowpos = c->d_rowpos.p;
     mp.rows_u8 = c->d_rows_view; mp.img_row_off = c->d_row_off.p;
     mp.img_tile_off = c->d_tile_off.p; mp.img_n = c->d_n.p; mp.img_ntiles = c->d_ntiles.p;
-    mp.cd = c->d_cd.p; mp.img_neven = c->d_neven.p; mp.errflag = c->d_err.p;
-    mp.pairs = c->d_pairs.p; mp.work = c->d_work.p; mp.n_work = n_work;
-    mp.best = c->d_best.p; mp.count = c->d_count.p; mp.qstride = c->qstride; mp.ratio_sq = ratio_sq;
+    mp.cd = sl.d_cd.p; mp.img_neven = c->d_neven.p; mp.errflag = c->d_err.p;
+    mp.pairs = sl.d_pairs.p; mp.work = sl.d_work.p; mp.n_work = n_work;
+    mp.best = sl.d_best.p; mp.count = sl.d_count.p; mp.qstride = c->qstride; mp.ratio_sq = ratio_sq;
 
+    // filter kernels run one after the other (each fills the device); everything else of batch b-1 runs beside filter b
+    if (prev) MVGX_HIP(hipStreamWaitEvent(stream, prev->ev_filter, 0));
     if (n_work) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (c->profile) {
         e0 = get_event(c, n_ev++); e1 = get_event(c, n_ev++);
         MVGX_REQUIRE(e0 && e1, MVGX_ERR_HIP, "hipEventCreate failed");
-        MVGX_HIP(hipEventRecord(e0, c->stream));
+        MVGX_HIP(hipEventRecord(e0, stream));
       }
       if (c->variant == 0) {
-        hipLaunchKernelGGL(l2_top2_ratio_naive_kernel, dim3(n_work), dim3(256), 0, c->stream, mp);
+        hipLaunchKernelGGL(l2_top2_ratio_naive_kernel, dim3(n_work), dim3(256), 0, stream, mp);
       } else if (c->variant == 1) {
-        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->variant == 2) {
-        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->variant == 3) {
-        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 1) {
-        hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 2) {
-        hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else {
-        hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, c->stream, mp);
+        hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       }
       MVGX_HIP(hipGetLastError());
-      if (c->profile) MVGX_HIP(hipEventRecord(e1, c->stream));
+      if (c->profile) MVGX_HIP(hipEventRecord(e1, stream));
+      MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
       st.n_kernel_launches += 1;
       if (c->variant == 4) {
         if (c->profile) {
           const size_t nslots = (size_t)nb * c->qstride;
-          hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, c->stream,
-                             c->d_best.p, nslots, c->d_err.p + 1);
+          hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, stream,
+                             sl.d_best.p, nslots, c->d_err.p + 1);
         }
-        hipLaunchKernelGGL(l2_verify_kernel, dim3(n_work), dim3(256), 0, c->stream, mp);
+        hipLaunchKernelGGL(l2_verify_kernel, dim3(n_work), dim3(256), 0, stream, mp);
         MVGX_HIP(hipGetLastError());
       }
     }
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_count.p, nb, c->d_offsets.p);
+    if (!n_work) MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sl.d_count.p, nb, sl.d_offsets.p);
     MVGX_HIP(hipGetLastError());
-    MVGX_HIP(hipMemcpyAsync(c->hp_offsets.p, c->d_offsets.p, ((size_t)nb + 1) * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost, c->stream));
-    MVGX_HIP(hipStreamSynchronize(c->stream));
-    const uint32_t total = c->hp_offsets.p[nb];
+    MVGX_HIP(hipMemcpyAsync(sl.hp_offsets.p, sl.d_offsets.p, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    MVGX_HIP(hipEventRecord(sl.ev_scan, stream));
+    return MVGX_OK;
+  };
+  // Stage 2, in batch order: totals -> ordered compaction -> (optional) copy of the match lists to the host
+  auto finish = [&](mvgx_match_ctx::Slot& sl) -> int {
+    int rc;
+    MVGX_HIP(hipEventSynchronize(sl.ev_scan));
+    const uint32_t nb = sl.nb;
+    const uint64_t p0 = sl.p0;
+    const uint32_t total = sl.hp_offsets.p[nb];
     const uint64_t base = c->res_offsets[p0];
-    for (uint32_t k = 0; k <= nb; ++k) c->res_offsets[p0 + k] = base + c->hp_offsets.p[k];
+    for (uint32_t k = 0; k <= nb; ++k) c->res_offsets[p0 + k] = base + sl.hp_offsets.p[k];
     st.n_matches += total;
     if (total) {
-      if ((rc = c->d_ij.ensure(total))) return rc;
-      hipLaunchKernelGGL(compact_matches_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->d_best.p,
-                         c->d_offsets.p, c->d_pairs.p, c->d_n.p, c->d_row_off.p, c->d_rowpos.p, nb, c->qstride,
-                         c->d_ij.p);
+      if ((rc = sl.d_ij.ensure(total))) return rc;
+      hipLaunchKernelGGL(compact_matches_kernel, dim3((nb + 3) / 4), dim3(256), 0, sl.stream, sl.d_best.p,
+                         sl.d_offsets.p, sl.d_pairs.p, c->d_n.p, c->d_row_off.p, c->d_rowpos.p, nb, c->qstride,
+                         sl.d_ij.p);
       MVGX_HIP(hipGetLastError());
       if (c->keep_host_results) {
         const size_t old = c->res_ij.size();
         c->res_ij.resize(old + (size_t)total * 2);
-        MVGX_HIP(hipMemcpyAsync(c->res_ij.data() + old, c->d_ij.p, (size_t)total * sizeof(uint2),
-                                hipMemcpyDeviceToHost, c->stream));
+        MVGX_HIP(hipMemcpyAsync(c->res_ij.data() + old, sl.d_ij.p, (size_t)total * sizeof(uint2),
+                                hipMemcpyDeviceToHost, sl.stream));
       }
-      MVGX_HIP(hipStreamSynchronize(c->stream));
+      MVGX_HIP(hipStreamSynchronize(sl.stream));
     }
+    return MVGX_OK;
+  };
+  uint64_t nbatch = 0;
+  for (uint64_t p0 = 0; p0 < n_pairs; p0 += B, ++nbatch) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
+    mvgx_match_ctx::Slot& cur = c->slot[nbatch & 1];
+    mvgx_match_ctx::Slot* prev = nbatch ? &c->slot[(nbatch - 1) & 1] : nullptr;
+    if (!c->overlap) {
+      if ((rc = issue(cur, nullptr, p0, nb)) || (rc = finish(cur))) return rc;
+      continue;
+    }
+    if ((rc = issue(cur, prev, p0, nb))) return rc;   // batch b: filter on the device ...
+    if (prev && (rc = finish(*prev))) return rc;      // ... while batch b-1 is compacted and copied out
   }
-  MVGX_HIP(hipEventRecord(c->ev_total1, c->stream));
+  if (c->overlap && nbatch && (rc = finish(c->slot[(nbatch - 1) & 1]))) return rc;
+  for (auto& sl : c->slot) MVGX_HIP(hipStreamSynchronize(sl.stream));
+  MVGX_HIP(hipEventRecord(c->ev_total1, c->slot[0].stream));
   MVGX_HIP(hipEventSynchronize(c->ev_total1));
   float ms = 0.f;
   MVGX_HIP(hipEventElapsedTime(&ms, c->ev_total0, c->ev_total1));
