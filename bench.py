@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--desc", type=int, default=2000)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--ratio", type=float, default=0.8)
+    ap.add_argument("--batch-pairs", type=int, default=0, help="image pairs per device batch (default: library default)")
     ap.add_argument("--overlap", type=int, default=-1, help="0: one batch at a time (isolated kernel timings); default: library default (1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -105,6 +106,8 @@ def main():
         ctx.set_option("variant", args.variant)
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
+    if args.batch_pairs > 0:
+        ctx.set_option("batch_pairs", args.batch_pairs)
     ctx.set_option("profile", 1)
     ctx.set_regions(descs)  # descriptors resident in HBM (tile layout built here, outside the timed region)
     ratio_sq = np.float32(args.ratio) * np.float32(args.ratio)

@@ -904,6 +904,20 @@ struct PinnedBuf {
     cap = want;
     return MVGX_OK;
   }
+  // grow to at least n elements, keeping the first `used` (geometric growth: the caller appends batch after batch)
+  int grow_keep(size_t n, size_t used) {
+    if (n <= cap) return MVGX_OK;
+    const size_t want = std::max<size_t>(std::max<size_t>(n, cap + cap / 2), 16);
+    T* q = nullptr;
+    MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&q), want * sizeof(T), hipHostMallocDefault));
+    if (p) {
+      if (used) memcpy(q, p, used * sizeof(T));
+      (void)hipHostFree(p);
+    }
+    p = q;
+    cap = want;
+    return MVGX_OK;
+  }
   void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
 };
 
@@ -918,7 +932,7 @@ struct mvgx_match_ctx {
                             // 4 = filter (1 VALU / distance) + verify, LDS staging mode in `stage`
   int stage = 3;            // staging mode of variant 4 (1 / 2 / 3 as above); 3 measured fastest (sweep call 5)
   int profile = 0;
-  int64_t batch_pairs = 1 << 17;
+  int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
   int keep_host_results = 1;
   int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
   // regions
@@ -951,7 +965,8 @@ struct mvgx_match_ctx {
   } slot[2];
   // results of the last run
   std::vector<uint64_t> res_offsets;
-  std::vector<uint32_t> res_ij;
+  PinnedBuf<uint32_t> res_ij;   // match lists of the last run, pinned: the D2H copies are plain DMA, nothing is zero-filled
+  size_t res_ij_n = 0;
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -1092,6 +1107,7 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   c->d_rows_slot.release(); c->d_cinit.release(); c->d_rownorm.release(); c->d_ntiles.release(); c->d_perm.release(); c->d_rowpos.release();
   c->d_neven.release(); c->d_err.release();
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
+  c->res_ij.release();
   for (auto& sl : c->slot) {
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
@@ -1184,7 +1200,7 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
                  "pair %llu references image out of range", (unsigned long long)k);
 
   c->res_offsets.assign(n_pairs + 1, 0);
-  c->res_ij.clear();
+  c->res_ij_n = 0;
   mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
   st.variant = (uint32_t)c->variant;
@@ -1300,12 +1316,14 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
                          sl.d_ij.p);
       MVGX_HIP(hipGetLastError());
       if (c->keep_host_results) {
-        const size_t old = c->res_ij.size();
-        c->res_ij.resize(old + (size_t)total * 2);
-        MVGX_HIP(hipMemcpyAsync(c->res_ij.data() + old, sl.d_ij.p, (size_t)total * sizeof(uint2),
-                                hipMemcpyDeviceToHost, sl.stream));
+        const size_t old = c->res_ij_n;
+        if (old + (size_t)total * 2 > c->res_ij.cap)   // growth moves the lists: no copy into them may be in flight
+          for (auto& o : c->slot) MVGX_HIP(hipStreamSynchronize(o.stream));
+        if ((rc = c->res_ij.grow_keep(old + (size_t)total * 2, old))) return rc;
+        c->res_ij_n = old + (size_t)total * 2;
+        MVGX_HIP(hipMemcpyAsync(c->res_ij.p + old, sl.d_ij.p, (size_t)total * sizeof(uint2),
+                                hipMemcpyDeviceToHost, sl.stream));   // completes before the run returns
       }
-      MVGX_HIP(hipStreamSynchronize(sl.stream));
     }
     return MVGX_OK;
   };
@@ -1316,6 +1334,7 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     mvgx_match_ctx::Slot* prev = nbatch ? &c->slot[(nbatch - 1) & 1] : nullptr;
     if (!c->overlap) {
       if ((rc = issue(cur, nullptr, p0, nb)) || (rc = finish(cur))) return rc;
+      MVGX_HIP(hipStreamSynchronize(cur.stream));
       continue;
     }
     if ((rc = issue(cur, prev, p0, nb))) return rc;   // batch b: filter on the device ...
@@ -1353,7 +1372,7 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
 int mvgx_match_results(mvgx_match_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
   MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_match_results: NULL argument");
   *offsets = c->res_offsets.data();
-  *ij = c->res_ij.data();
+  *ij = c->res_ij.p;
   return MVGX_OK;
 }
 
@@ -1368,7 +1387,7 @@ int mvgx_match_pairs_u8_l2(const uint8_t* const* desc_rows, const uint32_t* n_de
   if (!rc && sink) {
     for (uint64_t k = 0; k < n_pairs; ++k) {
       const uint64_t a = c->res_offsets[k], b = c->res_offsets[k + 1];
-      if (b > a) sink(user, pairs_IJ[2 * k], pairs_IJ[2 * k + 1], c->res_ij.data() + 2 * a, (uint32_t)(b - a));
+      if (b > a) sink(user, pairs_IJ[2 * k], pairs_IJ[2 * k + 1], c->res_ij.p + 2 * a, (uint32_t)(b - a));
     }
   }
   mvgx_match_destroy(c);

@@ -8,6 +8,11 @@ driven from an openMVG matches directory:
   matches.*.txt  putative matches     matching/indMatch_utils.cpp:85-131 (Save, "txt" branch) / :28-83 (Load):
                  per pair "I J\n#matches\n" then one "i j" line per IndMatch (matching/indMatch.hpp:58-64)
 
+  <scene>.baf    BA problem export    sfm/sfm_data_io_baf.hpp:38-147 (Save_BAF; the reference has no BAF reader): header counts,
+                 one line per intrinsic (getParams()), per view (R column-major 3x3 + centre; identity / 0 when the pose
+                 is missing), per landmark (X, #obs, then "id_intrinsic id_pose x y" per observation), plus
+                 <scene>_imgList.txt ("filename id_intrinsic id_pose" per view)
+
 Host-side plumbing only (numpy); the .bin variants of the reference are cereal archives and are out of scope (the cereal
 submodule is absent from the reference tree).
 """
@@ -77,3 +82,65 @@ def load_matches_txt(path):
         out[(I, J)] = np.array(tok[p:p + 2 * n], np.uint32).reshape(n, 2)
         p += 2 * n
     return out
+
+
+def _g(x):
+    """default std::ostream formatting of a double / unsigned (precision 6, %g)."""
+    return f"{float(x):g}"
+
+
+def save_baf(path, poses, intrinsics, intr_model, points, obs_pose, obs_intr, obs_point, obs_xy, image_names=None,
+             root_path=""):
+    """Save_BAF (sfm/sfm_data_io_baf.hpp:38-147) for a flat BA scene (the layout of mvgx_ba_problem): poses n x 6
+    (angle-axis, t = -R C; one view per pose, view id = pose id, using the intrinsic of its first observation),
+    intrinsics n x 8 + model ids, points n x 3, observations. The reference iterates its std::unordered_map containers,
+    so its line order inside a section is libstdc++'s bucket order; this writer emits ascending ids (the multiset of lines
+    is what tests/test_io_cpu.py pins against the reference)."""
+    from .ba_options import N_INTR_PARAMS
+    poses = np.asarray(poses, np.float64).reshape(-1, 6)
+    intrinsics = np.asarray(intrinsics, np.float64).reshape(-1, 8)
+    points = np.asarray(points, np.float64).reshape(-1, 3)
+    obs_pose = np.asarray(obs_pose, np.int64)
+    obs_intr = np.asarray(obs_intr, np.int64)
+    obs_point = np.asarray(obs_point, np.int64)
+    obs_xy = np.asarray(obs_xy, np.float64).reshape(-1, 2)
+    n_poses = len(poses)
+    pose_intr = np.zeros(n_poses, np.int64)
+    seen = np.zeros(n_poses, bool)
+    for p, i in zip(obs_pose, obs_intr):
+        if not seen[p]:
+            seen[p] = True
+            pose_intr[p] = i
+    lines = [str(len(intrinsics)), str(n_poses), str(len(points))]
+    for prm, model in zip(intrinsics, np.asarray(intr_model).reshape(-1)):
+        n = N_INTR_PARAMS[int(model)]
+        if int(model) == 7:   # Intrinsic_Spherical::getParams() is empty (Camera_Spherical.hpp)
+            n = 0
+        lines.append("".join(_g(v) + " " for v in prm[:n]))
+    for p in poses:
+        w = p[:3]
+        th = float(np.linalg.norm(w))
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        if th > 0:
+            R = np.eye(3) + (np.sin(th) / th) * K + ((1 - np.cos(th)) / (th * th)) * (K @ K)
+        else:
+            R = np.eye(3) + K
+        C = -R.T @ p[3:6]
+        lines.append("".join(_g(v) + " " for v in R.T.reshape(-1)) + "".join(_g(v) + " " for v in C))
+    order = np.lexsort((obs_pose, obs_point))
+    starts = np.searchsorted(obs_point[order], np.arange(len(points) + 1))
+    for j, X in enumerate(points):
+        ks = order[starts[j]:starts[j + 1]]
+        line = "".join(_g(v) + " " for v in X) + f"{len(ks)} "
+        for k in ks:
+            line += f"{pose_intr[obs_pose[k]]} {obs_pose[k]} {_g(obs_xy[k, 0])} {_g(obs_xy[k, 1])} "
+        lines.append(line)
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    import os
+    stem, _ = os.path.splitext(path)
+    with open(stem + "_imgList.txt", "w") as f:
+        for v in range(n_poses):
+            name = image_names[v] if image_names is not None else ""
+            full = name if not root_path else (root_path.rstrip("/") + "/" + name)
+            f.write(f"{full} {pose_intr[v]} {v}\n")

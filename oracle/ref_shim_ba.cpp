@@ -29,6 +29,7 @@
 #include "openMVG/sfm/sfm_data.hpp"
 #include "openMVG/sfm/sfm_data_BA.hpp"
 #include "openMVG/sfm/sfm_data_BA_ceres.hpp"
+#include "openMVG/sfm/sfm_data_io_baf.hpp"
 #include "openMVG/sfm/sfm_data_transform.hpp"
 #include "openMVG/sfm/sfm_view.hpp"
 #include "openMVG/sfm/sfm_view_priors.hpp"
@@ -246,6 +247,17 @@ int ref_ba_prior_prepare(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, u
       for (int k = 0; k < 3; ++k) prior_center[3 * size_t(prior->id_pose) + k] = prior->pose_center_(k);
   }
   return 0;
+}
+
+// The reference's BAF export (sfm/sfm_data_io_baf.hpp:38-147) of the same flat scene: pins openmvg_amd.io.save_baf.
+int ref_save_baf(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                 const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                 const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, const char* path) {
+  SfM_Data scene;
+  const int rc0 = build_scene(scene, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
+                              obs_point, obs_xy, Extras());
+  if (rc0) return rc0;
+  return Save_BAF(scene, path, ESfM_Data(ALL)) ? 0 : 1;
 }
 
 int ref_ba_default_linear_solver_is_sparse(void) {

@@ -352,6 +352,18 @@ def ref_ba_prior_prepare(scene, lib=None):
     return bool(out[0]), sc, out[2:5].copy()
 
 
+def ref_save_baf(scene, path):
+    """The reference's Save_BAF (sfm/sfm_data_io_baf.hpp) on the flat scene (oracle/ref_shim_ba.cpp::ref_save_baf)."""
+    L = C.CDLL(REF_BA_SO)
+    L.ref_save_baf.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 + [C.c_char_p]
+    poses = np.ascontiguousarray(scene["poses"], np.float64); intr = np.ascontiguousarray(scene["intrinsics"], np.float64)
+    pts = np.ascontiguousarray(scene["points"], np.float64); model = np.ascontiguousarray(scene["intr_model"], np.int32)
+    op = np.ascontiguousarray(scene["obs_pose"], np.uint32); oi = np.ascontiguousarray(scene["obs_intr"], np.uint32)
+    ox = np.ascontiguousarray(scene["obs_point"], np.uint32); xy = np.ascontiguousarray(scene["obs_xy"], np.float64)
+    return L.ref_save_baf(len(poses), len(intr), len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data,
+                          pts.ctypes.data, op.ctypes.data, oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, path.encode())
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the openMVG-side adapter build (product code + the same caller shims as oracle/_ref)
 # ---------------------------------------------------------------------------------------------------------

@@ -96,3 +96,65 @@ def test_error_and_empty_cases(tmp_path):
     q = str(tmp_path / "e.txt")
     io.save_matches_txt(q, np.zeros((0, 2), np.uint32), np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32))
     assert io.load_matches_txt(q) == {}
+
+
+# ---- BAF export (sfm/sfm_data_io_baf.hpp:38-147) ----
+REF_BA_SO = os.path.join(ROOT, "oracle", "_ref", "libref_ba.so")
+
+
+def _baf_scene():
+    from openmvg_amd import synth
+    sc = synth.ba_scene(5, 23, track_len=3, model=3, n_intr_groups=2, seed=11, noise_px=0.3)
+    sc["intr_model"] = np.array([3, 1], np.int32)      # radial-3 and pinhole in one file: 6 and 3 parameters per line
+    return sc
+
+
+def _baf_sections(path):
+    """-> (header, sorted intrinsic lines, sorted view lines, sorted landmark lines); inside a section the reference's line
+    order is the iteration order of std::unordered_map (types.hpp:67), so sections are compared as multisets."""
+    lines = open(path).read().split("\n")
+    assert lines[-1] == ""
+    ni, nv, nl = (int(x) for x in lines[:3])
+    body = lines[3:-1]
+    assert len(body) == ni + nv + nl
+    return lines[:3], sorted(body[:ni]), sorted(body[ni:ni + nv]), sorted(body[ni + nv:])
+
+
+def _baf_landmark_canonical(line):
+    """observations of one landmark sorted by id_pose (the reference emits them in hash-map order)."""
+    t = line.split()
+    n = int(t[3])
+    obs = sorted(tuple(t[4 + 4 * k:8 + 4 * k]) for k in range(n))
+    return tuple(t[:4]), tuple(obs)
+
+
+def _write_ours(path, sc):
+    io.save_baf(path, sc["poses"], sc["intrinsics"], sc["intr_model"], sc["points"], sc["obs_pose"], sc["obs_intr"],
+                sc["obs_point"], sc["obs_xy"])
+
+
+def _compare_baf(ours, ref):
+    ho, io_, vo, lo = _baf_sections(ours)
+    hr, ir, vr, lr = _baf_sections(ref)
+    assert ho == hr and io_ == ir and vo == vr
+    assert sorted(map(_baf_landmark_canonical, lo)) == sorted(map(_baf_landmark_canonical, lr))
+    a = sorted(open(os.path.splitext(ours)[0] + "_imgList.txt").read().split("\n"))
+    b = sorted(open(os.path.splitext(ref)[0] + "_imgList.txt").read().split("\n"))
+    assert a == b
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BA_SO), reason="oracle/_ref/libref_ba.so not built")
+def test_baf_export_matches_the_reference_writer(tmp_path):
+    from tests import _oracle
+    sc = _baf_scene()
+    ours, ref = str(tmp_path / "ours.baf"), str(tmp_path / "ref.baf")
+    _write_ours(ours, sc)
+    assert _oracle.ref_save_baf(sc, ref) == 0
+    _compare_baf(ours, ref)
+
+
+def test_baf_export_against_committed_reference_file(tmp_path):
+    sc = _baf_scene()
+    ours = str(tmp_path / "ours.baf")
+    _write_ours(ours, sc)
+    _compare_baf(ours, os.path.join(GOLD, "scene.baf"))
