@@ -124,20 +124,35 @@ uint32_t oracle_match_distance_ratio_u8(const uint8_t* dbI, int nI, const uint8_
 uint64_t oracle_matcher_regions_match_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
                                          uint32_t dim, const uint32_t* pairs_IJ, uint64_t n_pairs,
                                          float distance_ratio, uint64_t* offsets, uint32_t* ij, uint64_t capacity) {
+  /* pairs are independent (the reference itself runs the J loop under OpenMP, Matcher_Regions.cpp:80): evaluate them in
+   * parallel into per-pair lists (the 2-NN search called from inside a parallel region runs single-threaded), then
+   * concatenate in input order. */
+  uint32_t** lists = (uint32_t**)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t*));
+  uint32_t* counts = (uint32_t*)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t));
+  if (!lists || !counts) { free(lists); free(counts); return (uint64_t)-1; }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint32_t I = pairs_IJ[2 * p], J = pairs_IJ[2 * p + 1];
+    if (I < n_images && J < n_images && n_desc[I] != 0 && n_desc[J] != 0) {
+      lists[p] = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)n_desc[J]);
+      if (lists[p])
+        counts[p] = oracle_match_distance_ratio_u8(desc_rows[I], (int)n_desc[I], desc_rows[J], (int)n_desc[J], (int)dim,
+                                                   distance_ratio, lists[p]);
+    }
+  }
   uint64_t total = 0;
+  int overflow = 0;
   offsets[0] = 0;
   for (uint64_t p = 0; p < n_pairs; ++p) {
-    const uint32_t I = pairs_IJ[2 * p], J = pairs_IJ[2 * p + 1];
-    uint32_t n = 0;
-    if (I < n_images && J < n_images && n_desc[I] != 0 && n_desc[J] != 0) {
-      if (total + n_desc[J] > capacity) return (uint64_t)-1;
-      n = oracle_match_distance_ratio_u8(desc_rows[I], (int)n_desc[I], desc_rows[J], (int)n_desc[J], (int)dim,
-                                         distance_ratio, ij + 2 * total);
-    }
-    total += n;
+    if (!overflow && total + counts[p] > capacity) overflow = 1;
+    if (!overflow && counts[p]) memcpy(ij + 2 * total, lists[p], sizeof(uint32_t) * 2 * (size_t)counts[p]);
+    total += counts[p];
     offsets[p + 1] = total;
+    free(lists[p]);
   }
-  return total;
+  free(lists);
+  free(counts);
+  return overflow ? (uint64_t)-1 : total;
 }
 
 int oracle_num_threads(void) {

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The CPU checkers (oracle/) use OpenMP; on a shared GPU box spinning barriers of 256 threads cost far more than the work
+# of the small parity cases. Must be set before libgomp is first loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
