@@ -232,3 +232,16 @@ def test_two_level_cholesky(monkeypatch, tiles128):
     s, poses, intr, pts = _solve_emu(sc, ba.default_options(**opt))
     assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
     assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
+
+
+from tests._ba_cases import edge_scenes as _edge_scenes  # noqa: E402
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_degenerate_problems_follow_the_oracle(case):
+    name, sc, masks = _edge_scenes()[case]
+    rc, osum, *_ = _oracle.port_ba_solve(sc, **masks)
+    s, *_ = _solve_emu(sc, **masks)
+    assert rc == 0, name
+    assert (s.num_iterations, s.termination) == (osum.num_iterations, osum.termination), name
+    assert abs(s.final_cost - osum.final_cost) <= 1e-8 * max(osum.final_cost, 1e-12) + 1e-18, name

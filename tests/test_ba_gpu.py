@@ -208,3 +208,17 @@ def test_pixel_residual_outlier_filter():
     assert filtered["n_obs"] == int(keep.sum())
     # a second BA on the filtered scene ends at the noise floor (the outliers are gone)
     assert adj.Adjust(filtered) and adj.summary.final_rmse < 0.6
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_degenerate_problems_follow_the_oracle(case):
+    """unused blocks, empty problem, everything constant, rank-deficient V_p, a wild point (tests/_ba_cases.py)"""
+    from tests._ba_cases import edge_scenes
+    name, sc, masks = edge_scenes()[case]
+    rc, osum, *_ = _oracle.port_ba_solve(sc, **masks)
+    ctx = ba.BaContext(sc, **masks)
+    s = ctx.solve()
+    ctx.close()
+    assert rc == 0, name
+    assert (s.num_iterations, s.termination) == (osum.num_iterations, osum.termination), name
+    assert abs(s.final_cost - osum.final_cost) <= 1e-8 * max(osum.final_cost, 1e-12) + 1e-18, name
