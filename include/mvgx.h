@@ -207,6 +207,11 @@ int mvgx_ba_evaluate(mvgx_ba_ctx* ctx, double* cost, double* rmse);
  * of the problem's observation arrays: the quantity RemoveOutliers_PixelResidualError (sfm/sfm_data_filters.cpp:40-73)
  * compares with its threshold in the "do { BA } while (badTrackRejector)" loops (sequential_SfM.cpp:206-210,1226-1232). */
 int mvgx_ba_residuals(mvgx_ba_ctx* ctx, double* residual_norm /* n_obs */);
+/* per point (track): the largest angle in degrees between the world rays of two of its observations at the current
+ * poses / intrinsics (undistorted pixel -> bearing -> R^T, cameras/Camera_Intrinsics.hpp:263-280), 0 for tracks with fewer
+ * than two observations: the quantity RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp:77-121) compares with
+ * dMinAcceptedAngle - the second half of badTrackRejector (sequential_SfM.cpp:1226-1232). */
+int mvgx_ba_track_angles(mvgx_ba_ctx* ctx, double* max_angle_deg /* n_points */);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,7 @@ PROTOTYPES = {
     "mvgx_ba_read_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvgx_ba_evaluate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mvgx_ba_residuals": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mvgx_ba_track_angles": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

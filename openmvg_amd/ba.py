@@ -133,6 +133,12 @@ class BaContext:
         _capi.check(_capi.lib().mvgx_ba_residuals(self._h, out.ctypes.data))
         return out
 
+    def track_angles(self):
+        """per point: largest angle (degrees) between the world rays of two of its observations (mvgx_ba_track_angles)"""
+        out = np.zeros(int(self.shape[2]))
+        _capi.check(_capi.lib().mvgx_ba_track_angles(self._h, out.ctypes.data))
+        return out
+
     def read_params(self):
         npz, ni, nx = self.shape
         poses = np.zeros((npz, 6)); intr = np.zeros((ni, 8)); pts = np.zeros((nx, 3))
@@ -207,3 +213,39 @@ def RemoveOutliers_PixelResidualError(scene, dThresholdPixel, minTrackLength=2, 
     out["obs_xy"] = np.ascontiguousarray(np.asarray(scene["obs_xy"], np.float64).reshape(-1, 2)[keep])
     out["n_obs"] = int(keep.sum())
     return outlier_count, out
+
+
+def _drop_observations(scene, keep):
+    out = dict(scene)
+    for k in ("obs_pose", "obs_intr", "obs_point", "obs_weight", "obs_is_control"):
+        if scene.get(k) is not None:
+            out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
+    out["obs_xy"] = np.ascontiguousarray(np.asarray(scene["obs_xy"], np.float64).reshape(-1, 2)[keep])
+    out["n_obs"] = int(keep.sum())
+    return out
+
+
+def RemoveOutliers_AngleError(scene, dMinAcceptedAngle, device=-1):
+    """Mirror of sfm::RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp:77-121) on the flat scene: tracks whose largest
+    pairwise ray angle (device: mvgx_ba_track_angles) is below dMinAcceptedAngle degrees are erased - they lose all their
+    observations, the point id stays. Tracks that are already empty do not exist in the reference's landmark map and are
+    not counted. Returns (removed_track_count, filtered scene)."""
+    ctx = BaContext(scene, device=device)
+    try:
+        ang = ctx.track_angles()
+    finally:
+        ctx.close()
+    obs_point = np.asarray(scene["obs_point"])
+    alive = np.bincount(obs_point, minlength=int(scene["n_points"])) > 0
+    bad = alive & (ang < float(dMinAcceptedAngle))
+    return int(bad.sum()), _drop_observations(scene, ~bad[obs_point])
+
+
+def badTrackRejector(scene, dPrecision, count=0, device=-1):
+    """SequentialSfMReconstructionEngine::badTrackRejector (sfm/pipelines/sequential/sequential_SfM.cpp:1226-1232):
+    RemoveOutliers_PixelResidualError(dPrecision, 2) then RemoveOutliers_AngleError(2.0); True when more than `count`
+    outliers were removed, i.e. when the caller's `do { BA } while (badTrackRejector(...))` loop runs again
+    (:206-210). Returns (again, filtered scene)."""
+    n_res, scene = RemoveOutliers_PixelResidualError(scene, dPrecision, 2, device=device)
+    n_ang, scene = RemoveOutliers_AngleError(scene, 2.0, device=device)
+    return (n_res + n_ang) > int(count), scene

@@ -191,6 +191,100 @@ MVGX_HD void eval_observation(int model, const double* intr, const double* pose,
 
 // PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): r = weight o (C(pose) - prior), C = -R(-aa) t.
 // When kJac: Jc (3 x 6, row-major) = [d r / d aa | d r / d t].
+// Unit ray of an image observation in world coordinates: R^T * bearing(get_ud_pixel(x)), normalised — the two vectors
+// AngleBetweenRay (cameras/Camera_Intrinsics.hpp:263-280) compares, as RemoveOutliers_AngleError
+// (sfm/sfm_data_filters.cpp:77-121) calls it. Undistortion per model:
+//   pinhole / spherical: identity (Camera_Pinhole.hpp:268-271, Camera_Spherical.hpp:175)
+//   radial K1 / K3: bisection on r^2 (Camera_Pinhole_Radial.hpp:37-70, :148-158, :273-277, :357-367, :482-486)
+//   Brown T2: fixed-point iteration, Manhattan stop 1e-10 (Camera_Pinhole_Brown.hpp:97-110, :226-236); the reference loop
+//             is unbounded — here it gives up after kBrownMaxIter rounds (a diverging model has no meaningful ray anyway)
+//   fisheye: 10 fixed-point rounds on theta, then tan (Camera_Pinhole_Fisheye.hpp:112-136)
+// Bearing: Kinv (x, y, 1) normalised (Camera_Pinhole.hpp:136-139); spherical lon/lat (Camera_Spherical.hpp:115-132).
+constexpr int kBrownMaxIter = 10000;
+
+MVGX_HD double radial_disto_r2(int model, const double* intr, double r2) {
+  const double k1 = intr[3];
+  if (model == kCamRadial1) {
+    const double c = 1.0 + r2 * k1;
+    return r2 * (c * c);
+  }
+  const double c = 1.0 + r2 * (k1 + r2 * (intr[4] + r2 * intr[5]));
+  return r2 * (c * c);
+}
+
+MVGX_HD void observation_ray(int model, const double* intr, const double* pose, const double* obs, double ray[3]) {
+  double b0, b1, b2;
+  if (model == kCamSpherical) {
+    const double w = intr[0], h = intr[1];
+    const double size = w > h ? w : h;
+    const double ux = (obs[0] - w / 2.0) / size, uy = (obs[1] - h / 2.0) / size;
+    const double lon = ux * 2 * 3.14159265358979323846, lat = -uy * 2 * 3.14159265358979323846;
+    b0 = cos(lat) * sin(lon); b1 = -sin(lat); b2 = cos(lat) * cos(lon);
+  } else {
+    const double f = intr[0], cx = intr[1], cy = intr[2];
+    double px = (obs[0] - cx) / f, py = (obs[1] - cy) / f;   // ima2cam
+    if (model == kCamRadial1 || model == kCamRadial3) {
+      const double r2 = px * px + py * py;
+      double radius = 1.0;
+      if (r2 != 0.0) {
+        double lo = r2, up = r2;
+        while (radial_disto_r2(model, intr, lo) > r2) lo /= 1.05;
+        while (radial_disto_r2(model, intr, up) < r2) up *= 1.05;
+        while (1e-10 < up - lo) {
+          const double mid = .5 * (lo + up);
+          if (radial_disto_r2(model, intr, mid) > r2) up = mid; else lo = mid;
+        }
+        radius = sqrt(.5 * (lo + up) / r2);
+      }
+      px *= radius; py *= radius;
+    } else if (model == kCamBrown) {
+      const double k1 = intr[3], k2 = intr[4], k3 = intr[5], t1 = intr[6], t2 = intr[7];
+      double ux = px, uy = py, dx, dy;
+      for (int it = 0;; ++it) {
+        const double r2 = ux * ux + uy * uy, r4 = r2 * r2, r6 = r4 * r2;
+        const double kd = k1 * r2 + k2 * r4 + k3 * r6;
+        dx = ux * kd + (t2 * (r2 + 2 * ux * ux) + 2 * t1 * ux * uy);
+        dy = uy * kd + (t1 * (r2 + 2 * uy * uy) + 2 * t2 * ux * uy);
+        if (!(fabs(ux + dx - px) + fabs(uy + dy - py) > 1e-10) || it >= kBrownMaxIter) break;
+        ux = px - dx; uy = py - dy;
+      }
+      px = ux; py = uy;
+    } else if (model == kCamFisheye) {
+      const double td = hypot(px, py);
+      double scale = 1.0;
+      if (td > 1e-8) {
+        double th = td;
+        for (int j = 0; j < 10; ++j) {
+          const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+          th = td / (1 + intr[3] * t2 + intr[4] * t4 + intr[5] * t6 + intr[6] * t8);
+        }
+        scale = tan(th) / td;
+      }
+      px *= scale; py *= scale;
+    }
+    const double xu = f * px + cx, yu = f * py + cy;   // cam2ima: the undistorted pixel ...
+    b0 = (xu - cx) / f; b1 = (yu - cy) / f; b2 = 1.0;  // ... and its bearing
+    const double n = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
+    b0 /= n; b1 /= n; b2 /= n;
+  }
+  double p[3], R[9], A[9];
+  const double zero[3] = {0.0, 0.0, 0.0};
+  transform_point<true>(pose, zero, p, R, A);   // R row-major
+  const double r0 = R[0] * b0 + R[3] * b1 + R[6] * b2;
+  const double r1 = R[1] * b0 + R[4] * b1 + R[7] * b2;
+  const double r2_ = R[2] * b0 + R[5] * b1 + R[8] * b2;
+  const double n = sqrt(r0 * r0 + r1 * r1 + r2_ * r2_);
+  ray[0] = r0 / n; ray[1] = r1 / n; ray[2] = r2_ / n;
+}
+
+// R2D(acos(clamp(dot, -1 + 1e-8, 1 - 1e-8))) (Camera_Intrinsics.hpp:278-279, numeric.h:72-75,135-138)
+MVGX_HD double ray_angle_deg(const double a[3], const double b[3]) {
+  double dt = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  dt = dt < 1.0 - 1.e-8 ? dt : 1.0 - 1.e-8;
+  dt = dt > -1.0 + 1.e-8 ? dt : -1.0 + 1.e-8;
+  return acos(dt) / 3.14159265358979323846 * 180.0;
+}
+
 template <bool kJac>
 MVGX_HD void eval_pose_center_prior(const double* pose, const double* center, const double* weight, double r[3], double* Jc) {
   const double neg[6] = {-pose[0], -pose[1], -pose[2], 0.0, 0.0, 0.0};

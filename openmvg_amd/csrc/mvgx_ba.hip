@@ -259,6 +259,39 @@ __global__ __launch_bounds__(256) void ba_residual_norm_kernel(Dev d, const uint
   out[orig_index[o]] = sqrt(r[0] * r[0] + r[1] * r[1]);
 }
 
+// world ray of every observation (3 doubles each, point-sorted order) at the current parameters
+__global__ __launch_bounds__(256) void ba_obs_ray_kernel(Dev d, double* __restrict__ rays) {
+  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= d.n_obs) return;
+  const uint32_t ip = d.opose[o], ii = d.ointr[o];
+  double pin[8], pp[6], obs[2], ray[3];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)ii * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
+  obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
+  observation_ray(d.model[ii], pin, pp, obs, ray);
+  rays[3 * o] = ray[0]; rays[3 * o + 1] = ray[1]; rays[3 * o + 2] = ray[2];
+}
+
+// per track: the largest angle (degrees) between the rays of two of its observations — what RemoveOutliers_AngleError
+// (sfm/sfm_data_filters.cpp:77-121) compares with dMinAcceptedAngle; 0 for tracks with fewer than two observations
+__global__ __launch_bounds__(256) void ba_track_angle_kernel(Dev d, const double* __restrict__ rays, double* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.n_pts) return;
+  const uint32_t lo = d.pt_start[p], hi = d.pt_start[p + 1];
+  double best = 0.0;
+  for (uint32_t a = lo; a < hi; ++a) {
+    const double ra[3] = {rays[3 * (size_t)a], rays[3 * (size_t)a + 1], rays[3 * (size_t)a + 2]};
+    for (uint32_t b = a + 1; b < hi; ++b) {
+      const double rb[3] = {rays[3 * (size_t)b], rays[3 * (size_t)b + 1], rays[3 * (size_t)b + 2]};
+      const double ang = ray_angle_deg(ra, rb);
+      best = ang > best ? ang : best;   // std::max(angle, max_angle): a NaN angle never replaces the maximum
+    }
+  }
+  out[p] = best;
+}
+
 // pose-centre priors (one workgroup): cost added onto scalars[kSCost]; with kJac the loss-corrected residual and
 // Jacobian rows are kept for the Gram / gradient / model-cost kernels
 template <bool kJac>
@@ -1906,6 +1939,27 @@ int mvgx_ba_residuals(mvgx_ba_ctx* c, double* residual_norm) {
   hipLaunchKernelGGL(ba_residual_norm_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.oorig, out);
   BA_LAUNCH_CHECK();
   MVGX_HIP(hipMemcpyAsync(residual_norm, out, (size_t)d.n_obs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
+  MVGX_REQUIRE(c && max_angle_deg, MVGX_ERR_ARG, "mvgx_ba_track_angles: NULL argument");
+  MVGX_HIP(hipSetDevice(c->device));
+  Dev& d = c->d;
+  if (!d.n_pts) return MVGX_OK;
+  if (!d.n_obs) {
+    for (uint32_t p = 0; p < d.n_pts; ++p) max_angle_deg[p] = 0.0;
+    return MVGX_OK;
+  }
+  // scratch that is free between LM iterations: rays in the Z array (18 doubles per observation), angles in h_p (3 per point)
+  double* rays = d.Zpose;
+  double* out = d.hp;
+  hipLaunchKernelGGL(ba_obs_ray_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, rays);
+  BA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ba_track_angle_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, rays, out);
+  BA_LAUNCH_CHECK();
+  MVGX_HIP(hipMemcpyAsync(max_angle_deg, out, (size_t)d.n_pts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   return MVGX_OK;
 }

@@ -744,6 +744,120 @@ int oracle_ba_eval_prior(const double* pose, const double* center, const double*
   return 0;
 }
 
+// RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp:77-121): per track the maximum over observation pairs of
+// AngleBetweenRay (cameras/Camera_Intrinsics.hpp:263-280) on get_ud_pixel'd observations. Flat arrays in the layout of
+// mvgx_ba_problem; observations in any order. out[n_points] in degrees (0 for tracks with < 2 observations).
+namespace {
+struct UdModel {
+  int model;
+  const double* q;   // intrinsics row (8)
+  double radial(double r2) const {   // Camera_Pinhole_Radial.hpp:273-277 (K1), :482-486 (K3): distoFunctor
+    if (model == MVGX_CAM_PINHOLE_RADIAL1) { const double c = 1. + r2 * q[3]; return r2 * (c * c); }
+    const double c = 1. + r2 * (q[3] + r2 * (q[4] + r2 * q[5]));
+    return r2 * (c * c);
+  }
+  void remove_disto(double p[2]) const {
+    switch (model) {
+      case MVGX_CAM_PINHOLE_RADIAL1:
+      case MVGX_CAM_PINHOLE_RADIAL3: {   // Camera_Pinhole_Radial.hpp:148-158 / :357-367 + bisection :37-70
+        const double r2 = p[0] * p[0] + p[1] * p[1];
+        if (r2 == 0) return;
+        double lowerbound = r2, upbound = r2;
+        while (radial(lowerbound) > r2) lowerbound /= 1.05;
+        while (radial(upbound) < r2) upbound *= 1.05;
+        while (1e-10 < upbound - lowerbound) {
+          const double mid = .5 * (lowerbound + upbound);
+          if (radial(mid) > r2) upbound = mid; else lowerbound = mid;
+        }
+        const double radius = std::sqrt(.5 * (lowerbound + upbound) / r2);
+        p[0] *= radius; p[1] *= radius;
+        return;
+      }
+      case MVGX_CAM_PINHOLE_BROWN: {     // Camera_Pinhole_Brown.hpp:97-110, distoFunction :226-236
+        auto disto = [&](const double u[2], double d[2]) {
+          const double r2 = u[0] * u[0] + u[1] * u[1], r4 = r2 * r2, r6 = r4 * r2;
+          const double k_diff = q[3] * r2 + q[4] * r4 + q[5] * r6;
+          const double t_x = q[7] * (r2 + 2 * u[0] * u[0]) + 2 * q[6] * u[0] * u[1];
+          const double t_y = q[6] * (r2 + 2 * u[1] * u[1]) + 2 * q[7] * u[0] * u[1];
+          d[0] = u[0] * k_diff + t_x; d[1] = u[1] * k_diff + t_y;
+        };
+        double u[2] = {p[0], p[1]}, d[2];
+        disto(u, d);
+        int guard = 0;
+        while (std::fabs(u[0] + d[0] - p[0]) + std::fabs(u[1] + d[1] - p[1]) > 1e-10 && guard++ < 10000) {
+          u[0] = p[0] - d[0]; u[1] = p[1] - d[1];
+          disto(u, d);
+        }
+        p[0] = u[0]; p[1] = u[1];
+        return;
+      }
+      case MVGX_CAM_PINHOLE_FISHEYE: {   // Camera_Pinhole_Fisheye.hpp:112-136
+        const double theta_dist = std::hypot(p[0], p[1]);
+        if (theta_dist > 1e-8) {
+          double theta = theta_dist;
+          for (int j = 0; j < 10; ++j) {
+            const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+            theta = theta_dist / (1 + q[3] * t2 + q[4] * t4 + q[5] * t6 + q[6] * t8);
+          }
+          const double scale = std::tan(theta) / theta_dist;
+          p[0] *= scale; p[1] *= scale;
+        }
+        return;
+      }
+      default: return;   // pinhole: Camera_Pinhole.hpp:268-271
+    }
+  }
+  void bearing(const double x[2], double b[3]) const {
+    if (model == MVGX_CAM_SPHERICAL) {   // Camera_Spherical.hpp:103-132
+      const double size = std::max(q[0], q[1]);
+      const double ux = (x[0] - q[0] / 2.0) / size, uy = (x[1] - q[1] / 2.0) / size;
+      const double lon = ux * 2 * M_PI, lat = -uy * 2 * M_PI;
+      b[0] = std::cos(lat) * std::sin(lon); b[1] = -std::sin(lat); b[2] = std::cos(lat) * std::cos(lon);
+      return;
+    }
+    double p[2] = {(x[0] - q[1]) / q[0], (x[1] - q[2]) / q[0]};        // ima2cam
+    remove_disto(p);
+    const double xu[2] = {q[0] * p[0] + q[1], q[0] * p[1] + q[2]};     // cam2ima: get_ud_pixel
+    b[0] = (xu[0] - q[1]) / q[0]; b[1] = (xu[1] - q[2]) / q[0]; b[2] = 1.0;   // Kinv * homogeneous (Camera_Pinhole.hpp:136-139)
+    const double n = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    b[0] /= n; b[1] /= n; b[2] /= n;
+  }
+};
+}  // namespace
+
+int oracle_ba_track_angles(uint32_t n_points, uint64_t n_obs, const double* poses, const double* intrinsics,
+                           const int32_t* intr_model, const uint32_t* obs_pose, const uint32_t* obs_intr,
+                           const uint32_t* obs_point, const double* obs_xy, double* out) {
+  std::vector<double> rays(3 * n_obs);
+  std::vector<std::vector<uint64_t>> track(n_points);
+  for (uint64_t o = 0; o < n_obs; ++o) {
+    const UdModel m{intr_model[obs_intr[o]], intrinsics + 8 * size_t(obs_intr[o])};
+    if (intr_param_count(m.model) < 0) return 1;
+    double b[3], w[3];
+    m.bearing(obs_xy + 2 * o, b);
+    const double* aa = poses + 6 * size_t(obs_pose[o]);
+    const double inv[3] = {-aa[0], -aa[1], -aa[2]};   // R^T = R(-aa)
+    angle_axis_rotate_point<double>(inv, b, w);
+    const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int k = 0; k < 3; ++k) rays[3 * o + k] = w[k] / n;
+    track[obs_point[o]].push_back(o);
+  }
+  for (uint32_t p = 0; p < n_points; ++p) {
+    double max_angle = 0.0;
+    const auto& t = track[p];
+    for (size_t a = 0; a < t.size(); ++a)
+      for (size_t b = a + 1; b < t.size(); ++b) {
+        const double* r1 = &rays[3 * t[a]];
+        const double* r2 = &rays[3 * t[b]];
+        const double dt = r1[0] * r2[0] + r1[1] * r2[1] + r1[2] * r2[2];
+        const double angle = std::acos(std::max(-1.0 + 1.e-8, std::min(dt, 1.0 - 1.e-8))) / M_PI * 180.0;
+        max_angle = std::max(angle, max_angle);
+      }
+    out[p] = max_angle;
+  }
+  return 0;
+}
+
 // cost = 1/2 sum rho(|r|^2) (Ceres cost), rmse = sqrt(sum |r|^2 / (2 n_obs)) (sfm_data_BA_test.cpp:310-330)
 int oracle_ba_evaluate(const mvgx_ba_problem* prob, double* cost, double* rmse) {
   Problem P;

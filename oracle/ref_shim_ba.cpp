@@ -29,6 +29,7 @@
 #include "openMVG/sfm/sfm_data.hpp"
 #include "openMVG/sfm/sfm_data_BA.hpp"
 #include "openMVG/sfm/sfm_data_BA_ceres.hpp"
+#include "openMVG/sfm/sfm_data_filters.hpp"
 #include "openMVG/sfm/sfm_data_io_baf.hpp"
 #include "openMVG/sfm/sfm_data_transform.hpp"
 #include "openMVG/sfm/sfm_view.hpp"
@@ -245,6 +246,49 @@ int ref_ba_prior_prepare(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, u
     const ViewPriors* prior = dynamic_cast<ViewPriors*>(view_it.second.get());
     if (prior != nullptr && prior->b_use_pose_center_)
       for (int k = 0; k < 3; ++k) prior_center[3 * size_t(prior->id_pose) + k] = prior->pose_center_(k);
+  }
+  return 0;
+}
+
+// The reference's post-BA track filters on the flat scene (sfm/sfm_data_filters.cpp:40-121), in the order
+// SequentialSfMReconstructionEngine::badTrackRejector applies them (sequential_SfM.cpp:1226-1232):
+//   RemoveOutliers_PixelResidualError(px_threshold, min_track_length), then RemoveOutliers_AngleError(min_angle_deg).
+// A negative threshold skips that filter. obs_keep[n_obs] = 1 for the observations that survive; counts[0..1] = the two
+// return values. max_angle (optional, n_points): the per-track maximum of the reference's own AngleBetweenRay over
+// get_ud_pixel'd observation pairs, evaluated BEFORE any filtering (the loop of :84-110 around the library calls).
+int ref_ba_filters(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                   const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                   const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, double px_threshold,
+                   uint32_t min_track_length, double min_angle_deg, uint8_t* obs_keep, uint64_t* counts, double* max_angle) {
+  SfM_Data scene;
+  const int rc0 = build_scene(scene, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
+                              obs_point, obs_xy, Extras());
+  if (rc0) return rc0;
+  if (max_angle) {
+    for (uint32_t j = 0; j < n_points; ++j) max_angle[j] = 0.0;
+    for (const auto& lm : scene.structure) {
+      const Observations& obs = lm.second.obs;
+      double best = 0.0;
+      for (auto it1 = obs.begin(); it1 != obs.end(); ++it1) {
+        const View* v1 = scene.views.at(it1->first).get();
+        const Pose3 pose1 = scene.GetPoseOrDie(v1);
+        const IntrinsicBase* i1 = scene.intrinsics.at(v1->id_intrinsic).get();
+        auto it2 = it1;
+        for (++it2; it2 != obs.end(); ++it2) {
+          const View* v2 = scene.views.at(it2->first).get();
+          const Pose3 pose2 = scene.GetPoseOrDie(v2);
+          const IntrinsicBase* i2 = scene.intrinsics.at(v2->id_intrinsic).get();
+          best = std::max(AngleBetweenRay(pose1, i1, pose2, i2, i1->get_ud_pixel(it1->second.x), i2->get_ud_pixel(it2->second.x)), best);
+        }
+      }
+      max_angle[lm.first] = best;
+    }
+  }
+  counts[0] = px_threshold >= 0 ? RemoveOutliers_PixelResidualError(scene, px_threshold, min_track_length) : 0;
+  counts[1] = min_angle_deg >= 0 ? RemoveOutliers_AngleError(scene, min_angle_deg) : 0;
+  for (uint64_t k = 0; k < n_obs; ++k) {
+    const auto lm = scene.structure.find(obs_point[k]);
+    obs_keep[k] = (lm != scene.structure.end() && lm->second.obs.count(obs_pose[k])) ? 1 : 0;
   }
   return 0;
 }

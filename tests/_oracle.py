@@ -352,6 +352,42 @@ def ref_ba_prior_prepare(scene, lib=None):
     return bool(out[0]), sc, out[2:5].copy()
 
 
+def _flat(scene):
+    return (np.ascontiguousarray(scene["poses"], np.float64), np.ascontiguousarray(scene["intrinsics"], np.float64),
+            np.ascontiguousarray(scene["intr_model"], np.int32), np.ascontiguousarray(scene["points"], np.float64),
+            np.ascontiguousarray(scene["obs_pose"], np.uint32), np.ascontiguousarray(scene["obs_intr"], np.uint32),
+            np.ascontiguousarray(scene["obs_point"], np.uint32), np.ascontiguousarray(scene["obs_xy"], np.float64))
+
+
+def port_ba_track_angles(scene):
+    """oracle/ba_oracle.cpp::oracle_ba_track_angles: per-track maximum ray angle (degrees)."""
+    L = port()
+    L.oracle_ba_track_angles.restype = C.c_int
+    L.oracle_ba_track_angles.argtypes = [C.c_uint32, C.c_uint64] + [C.c_void_p] * 8
+    poses, intr, model, pts, op, oi, ox, xy = _flat(scene)
+    out = np.zeros(len(pts))
+    rc = L.oracle_ba_track_angles(len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data, op.ctypes.data,
+                                  oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def ref_ba_filters(scene, px_threshold=4.0, min_track_length=2, min_angle_deg=2.0, lib_path=None):
+    """The reference's RemoveOutliers_PixelResidualError + RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp) on the flat
+    scene (oracle/ref_shim_ba.cpp::ref_ba_filters). -> (obs_keep bool[n_obs], (n_residual, n_angle), max_angle[n_points])"""
+    L = C.CDLL(lib_path or REF_BA_SO)
+    L.ref_ba_filters.restype = C.c_int
+    L.ref_ba_filters.argtypes = ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 +
+                                 [C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])
+    poses, intr, model, pts, op, oi, ox, xy = _flat(scene)
+    keep = np.zeros(len(op), np.uint8); counts = np.zeros(2, np.uint64); ang = np.zeros(len(pts))
+    rc = L.ref_ba_filters(len(poses), len(intr), len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data,
+                          pts.ctypes.data, op.ctypes.data, oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, float(px_threshold),
+                          int(min_track_length), float(min_angle_deg), keep.ctypes.data, counts.ctypes.data, ang.ctypes.data)
+    assert rc == 0, rc
+    return keep.astype(bool), (int(counts[0]), int(counts[1])), ang
+
+
 def ref_save_baf(scene, path):
     """The reference's Save_BAF (sfm/sfm_data_io_baf.hpp) on the flat scene (oracle/ref_shim_ba.cpp::ref_save_baf)."""
     L = C.CDLL(REF_BA_SO)

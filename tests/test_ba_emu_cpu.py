@@ -245,3 +245,31 @@ def test_degenerate_problems_follow_the_oracle(case):
     assert rc == 0, name
     assert (s.num_iterations, s.termination) == (osum.num_iterations, osum.termination), name
     assert abs(s.final_cost - osum.final_cost) <= 1e-8 * max(osum.final_cost, 1e-12) + 1e-18, name
+
+
+@pytest.mark.parametrize("model", [3, 4, 5, 7])
+def test_track_filters_follow_the_reference(model):
+    """mvgx_ba_track_angles + the mirrors of RemoveOutliers_AngleError / badTrackRejector (device kernels under emulation)
+    against the oracle and the reference's committed output (tests/golden/ba_filters.npz, make_filter_golden.py)"""
+    import os
+    from tests import _ba_cases
+    sc = _ba_cases.filter_scene(model, n_cams=12, n_points=150) if model != 3 else _ba_cases.filter_scene(model)
+    want = _oracle.port_ba_track_angles(sc)
+    with _emu.emulated():
+        ctx = ba.BaContext(sc); got = ctx.track_angles(); ctx.close()
+        n_ang, f_ang = ba.RemoveOutliers_AngleError(sc, 2.0)
+        again, f_both = ba.badTrackRejector(sc, 4.0, 50)
+    assert np.abs(got - want).max() < 1e-9
+    alive = np.bincount(sc["obs_point"], minlength=sc["n_points"]) > 0
+    assert n_ang == int((alive & (want < 2.0)).sum()) > 0
+    if model == 3:   # the scene of the committed reference output
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_filters.npz"))
+        assert n_ang == int(gold["m3_count_angle_only"]) and f_ang["n_obs"] == int(gold["m3_keep_angle_only"].sum())
+        keep = gold["m3_keep"]
+        assert again == (int(gold["m3_counts"].sum()) > 50)
+        for k in ("obs_pose", "obs_point"):
+            assert np.array_equal(f_both[k], sc[k][keep])
+        assert np.array_equal(f_both["obs_xy"], sc["obs_xy"][keep])
+    elif _oracle.have_ref_ba():
+        keep, counts, _ = _oracle.ref_ba_filters(sc, 4.0, 2, 2.0)
+        assert again == (sum(counts) > 50) and np.array_equal(f_both["obs_xy"], sc["obs_xy"][keep])

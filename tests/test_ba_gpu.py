@@ -222,3 +222,24 @@ def test_degenerate_problems_follow_the_oracle(case):
     assert rc == 0, name
     assert (s.num_iterations, s.termination) == (osum.num_iterations, osum.termination), name
     assert abs(s.final_cost - osum.final_cost) <= 1e-8 * max(osum.final_cost, 1e-12) + 1e-18, name
+
+
+@pytest.mark.parametrize("model", [1, 2, 3, 4, 5, 7])
+def test_track_filters_follow_the_reference(model):
+    """mvgx_ba_track_angles + the mirrors of RemoveOutliers_AngleError / badTrackRejector (sfm_data_filters.cpp:40-121,
+    sequential_SfM.cpp:1226-1232) against the oracle and the reference's committed output (tests/golden/ba_filters.npz)"""
+    import os
+    from tests import _ba_cases
+    sc = _ba_cases.filter_scene(model)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_filters.npz"))
+    ctx = ba.BaContext(sc); got = ctx.track_angles(); ctx.close()
+    assert np.abs(got - _oracle.port_ba_track_angles(sc)).max() < 1e-9
+    assert np.abs(got - gold[f"m{model}_angles"]).max() < 1e-9
+    n_ang, f_ang = ba.RemoveOutliers_AngleError(sc, 2.0)
+    assert n_ang == int(gold[f"m{model}_count_angle_only"]) and f_ang["n_obs"] == int(gold[f"m{model}_keep_angle_only"].sum())
+    again, f_both = ba.badTrackRejector(sc, 4.0, 50)
+    keep = gold[f"m{model}_keep"]
+    assert again == (int(gold[f"m{model}_counts"].sum()) > 50)
+    for k in ("obs_pose", "obs_point"):
+        assert np.array_equal(f_both[k], sc[k][keep])
+    assert np.array_equal(f_both["obs_xy"], sc["obs_xy"][keep])

@@ -190,3 +190,23 @@ def test_port_equals_reference_with_pose_center_priors(sigma):
     plain = {k: v for k, v in sc.items() if not k.startswith("prior_")}
     _, summ0, pp0, *_ = _oracle.port_ba_solve(plain)
     assert abs(summ0.final_rmse - stats0[1]) < 1e-9 and np.allclose(pp0[:, 3:], rp0[:, 3:], atol=1e-8)
+
+
+# ---- track filters (sfm/sfm_data_filters.cpp:40-121) ----
+@pytest.mark.parametrize("model", [1, 2, 3, 4, 5, 7])
+def test_track_angles_oracle_equals_reference_and_golden(model):
+    """oracle_ba_track_angles (get_ud_pixel of every camera model, bearing, R^T, max over pairs) against the reference's own
+    AngleBetweenRay / get_ud_pixel (compiled in place) and against the committed reference output."""
+    import os
+    from tests import _ba_cases
+    sc = _ba_cases.filter_scene(model)
+    ang = _oracle.port_ba_track_angles(sc)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_filters.npz"))
+    assert np.abs(ang - gold[f"m{model}_angles"]).max() < 1e-9
+    alive = np.bincount(sc["obs_point"], minlength=sc["n_points"]) > 0
+    bad = alive & (ang < 2.0)
+    assert int(bad.sum()) == int(gold[f"m{model}_count_angle_only"]) > 20
+    assert np.array_equal(~bad[sc["obs_point"]], gold[f"m{model}_keep_angle_only"])
+    if _oracle.have_ref_ba():
+        keep, counts, ref = _oracle.ref_ba_filters(sc, -1.0, 2, 2.0)
+        assert np.abs(ang - ref).max() < 1e-9 and counts[1] == int(bad.sum()) and np.array_equal(keep, ~bad[sc["obs_point"]])
