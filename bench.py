@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
     return ap.parse_args()
 
@@ -195,6 +196,12 @@ def main():
                 ba_c5 = ba_bench_record(local_rank, 1, cpu=False, name="c5")
         except Exception as e:  # the BA leg is a side record: never lose the matching line
             ba_rec = ba_rec or {"status": f"failed: {e!r}"}
+    if rank == 0 and world == 1 and not args.no_hamming:
+        try:
+            from bench_hamming import hamming_bench_record
+            out["hamming"] = hamming_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+        except Exception as e:  # side record only
+            out["hamming"] = {"status": f"failed: {e!r}"}
     if rank == 0:
         if ba_rec is not None:
             out["ba"] = ba_rec

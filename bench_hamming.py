@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Side record of bench.py: BRUTE_FORCE_HAMMING on AKAZE-like 64-byte binary descriptors on one MI355X.
+
+Workload: 300 images x 2000 descriptors, exhaustive pairs (44 850 image pairs = 1.79e11 descriptor pairs). The kernel is
+VALU-bound: 2 x 16 + 3 = 35 32-bit integer lane operations per descriptor pair (xor + popcount-accumulate per dword, packed
+key, min, max/min); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s (MI355X_MICROARCH.md)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
+LANE_OPS_PER_DESC_PAIR = 35.0
+
+
+def hamming_bench_record(device=0, n_images=300, n_desc=2000, steps=3, cpu_seconds=8.0, cpu=True):
+    from openmvg_amd import matching, synth
+    imgs = synth.binary_descriptors(n_images, n_desc, seed=0xA4A2E)
+    pairs = matching.exhaustive_pairs_array(n_images)
+    ctx = matching.HammingContext(device)
+    ctx.set_regions(imgs, 64)
+    ctx.run(pairs[:2000], 0.8)   # warm-up
+    kernel_ms = 0.0; launches = 0; desc_pairs = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st, off, _ = ctx.run(pairs, 0.8)
+        kernel_ms += st.kernel_ms; launches += int(st.n_kernel_launches); desc_pairs += int(st.n_desc_pairs)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    ach = desc_pairs * LANE_OPS_PER_DESC_PAIR / max(kernel_ms * 1e-3, 1e-12)
+    rec = {
+        "metric": "descriptor pairs/s (brute-force Hamming 2-NN + ratio matching)", "value": desc_pairs / dt,
+        "unit": "descriptor pairs/s", "dtype": "u32 popcount",
+        "config": {"workload": f"{n_images} images x {n_desc} 64-byte binary descriptors, exhaustive pairs ({len(pairs)} image pairs), ratio 0.8",
+                   "matches": int(off[-1])},
+        "ms_per_step": dt / steps * 1e3,
+        "roofline": {"bound": "valu", "achieved": ach / 1e12, "peak": VALU_LANE_OPS_PEAK / 1e12, "unit": "T lane-ops/s",
+                     "frac": ach / VALU_LANE_OPS_PEAK, "traffic": None, "kernel": "hamming_top2_ratio_kernel<16>",
+                     "launches": launches, "mean_launch_ms": kernel_ms / max(launches, 1)},
+    }
+    if cpu:
+        try:
+            from tests import _oracle
+            kind = "reference" if _oracle.have_ref_match() else "port"
+            fn = (_oracle.ref_matcher_regions_match_binary64 if kind == "reference"
+                  else lambda d, p, r: _oracle.port_matcher_regions_match_hamming(d, p, r))
+            order = np.random.default_rng(1).permutation(len(pairs))
+            fn(imgs, pairs[order[:8]], 0.8)
+            t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
+            per = max((time.perf_counter() - t0) / 32.0, 1e-5)
+            n = int(max(32, min(len(pairs), cpu_seconds / per)))
+            t0 = time.perf_counter(); fn(imgs, pairs[order[:n]], 0.8); cdt = time.perf_counter() - t0
+            rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
+                                   "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, BRUTE_FORCE_HAMMING)"}
+            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+    return rec
+
+
+if __name__ == "__main__":
+    print(json.dumps(hamming_bench_record(cpu="--no-cpu" not in sys.argv)))

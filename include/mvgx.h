@@ -100,6 +100,27 @@ int mvgx_match_pairs_u8_l2(const uint8_t* const* desc_rows, const uint32_t* n_de
                            int device, mvgx_match_sink sink, void* user);
 
 /* ------------------------------------------------------------------------------------------------
+ * MATCHING OF BINARY DESCRIPTORS (BRUTE_FORCE_HAMMING)
+ * replaces, behind the same factory as the L2 path (matching/regions_matcher.cpp:184-191):
+ *   RegionsMatcherT<ArrayMatcherBruteForce<unsigned char, Hamming<unsigned char>>>(regions, false) on binary regions
+ *   (features::Binary_Regions<SIOPointFeature, 64> = AKAZE_Binary_Regions, features/regions_factory.hpp:26):
+ *   matching/metric_hamming.hpp:36-107 (popcount of the XOR, unsigned int), matching/matcher_brute_force.hpp:95-200,
+ *   MatchDistanceRatio with the ratio as given (regions_matcher.hpp:162-207), inside the I/J loops of
+ *   Matcher_Regions::Match (Matcher_Regions.cpp:57-105). Same call shapes as mvgx_match_*; the ratio is dist_ratio itself
+ *   (the metric is not squared), accepted range 0 <= dist_ratio <= 1. desc_bytes: 1..64 (AKAZE MLDB: 64).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mvgx_hamming_ctx mvgx_hamming_ctx;
+int mvgx_hamming_create(int device, mvgx_hamming_ctx** out);
+int mvgx_hamming_destroy(mvgx_hamming_ctx* ctx);
+int mvgx_hamming_set_option(mvgx_hamming_ctx* ctx, const char* key /* "batch_pairs" */, int64_t value);
+/* desc_rows[k] -> n_desc[k] x desc_bytes row-major bytes (Binary_Regions::DescriptorRawData, binary_regions.hpp) */
+int mvgx_hamming_set_regions(mvgx_hamming_ctx* ctx, const uint8_t* const* desc_rows, const uint32_t* n_desc,
+                             uint32_t n_images, uint32_t desc_bytes);
+int mvgx_hamming_run(mvgx_hamming_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                     mvgx_match_stats* stats /* may be NULL */);
+int mvgx_hamming_results(mvgx_hamming_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
+
+/* ------------------------------------------------------------------------------------------------
  * BUNDLE ADJUSTMENT
  * replaces: sfm/sfm_data_BA_ceres.cpp:165-608 (Bundle_Adjustment_Ceres::Adjust) and, underneath it,
  *           vendored Ceres 1.13: program_evaluator.h:138-285, residual_block.cc:68-196, corrector.cc:41-155,

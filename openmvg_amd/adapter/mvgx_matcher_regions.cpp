@@ -10,7 +10,10 @@
 //           bit-identical to RegionsMatcherT<ArrayMatcherBruteForce<uchar, L2<uchar>>>::MatchDistanceRatio
 //           (regions_matcher.hpp:162-207) and are inserted in the container in ascending (I, J) order.
 //           A HIP failure on this path throws (no silent CPU fallback).
-//   anything else (other -n values, float/binary regions, dim != 128, ratio > 1 whose tie order is libstdc++'s)
+//   -n BRUTEFORCEHAMMING on binary uint8 regions of <= 64 bytes (AKAZE_Binary_Regions) with dist_ratio <= 1
+//        -> the MI355X popcount path (mvgx_hamming_*), bit-identical to
+//           RegionsMatcherT<ArrayMatcherBruteForce<uchar, Hamming<uchar>>>::MatchDistanceRatio (regions_matcher.cpp:184-191)
+//   anything else (other -n values, float regions, dim != 128, ratio > 1 whose tie order is libstdc++'s)
 //        -> the per-pair interface the reference itself uses for them (RegionMatcherFactory, regions_matcher.cpp:54),
 //           which stays in the link; that code is not part of the accelerated path.
 //
@@ -46,6 +49,10 @@ constexpr uint64_t kPairsPerCall = 1u << 16;  // cancellation / progress granula
 
 bool is_sift_u8(const features::Regions& r) {
   return r.IsScalar() && r.DescriptorLength() == 128 && r.Type_id() == typeid(unsigned char).name();
+}
+
+bool is_binary_u8(const features::Regions& r) {
+  return r.IsBinary() && r.DescriptorLength() >= 1 && r.DescriptorLength() <= 64 && r.Type_id() == typeid(unsigned char).name();
 }
 
 struct Sink {
@@ -107,7 +114,10 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
   progress->Restart(pairs.size(), "- Matching -");
 
   const float ratio_sq = Square(f_dist_ratio_);  // regions_matcher.hpp:196 (squared metric), numeric.h:56
-  const bool device_type = (eMatcherType_ == matching::BRUTE_FORCE_L2) && ratio_sq <= 1.0f && ratio_sq >= 0.0f;
+  const bool hamming = eMatcherType_ == matching::BRUTE_FORCE_HAMMING;   // metric not squared: the ratio is used as given
+  const bool device_type = (eMatcherType_ == matching::BRUTE_FORCE_L2 && ratio_sq <= 1.0f && ratio_sq >= 0.0f) ||
+                           (hamming && f_dist_ratio_ <= 1.0f && f_dist_ratio_ >= 0.0f);
+  size_t binary_len = 0;   // one descriptor length per device run (a Regions_Provider holds one region type)
 
   // Pair_Set is ordered by (I, J): the order in which the reference visits and inserts.
   std::vector<Pair> generic_pairs;
@@ -121,7 +131,14 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     auto it = dense.find(view);
     if (it != dense.end()) return it->second;
     std::shared_ptr<features::Regions> r = regions_provider->get(view);
-    if (!r || !is_sift_u8(*r)) return -1;
+    if (!r) return -1;
+    if (hamming) {
+      if (!is_binary_u8(*r)) return -1;
+      if (!binary_len) binary_len = r->DescriptorLength();
+      if (r->DescriptorLength() != binary_len) return -1;
+    } else if (!is_sift_u8(*r)) {
+      return -1;
+    }
     const uint32_t k = static_cast<uint32_t>(ids.size());
     dense.emplace(view, k);
     ids.push_back(view);
@@ -153,28 +170,34 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       n_desc[k] = static_cast<uint32_t>(keep[k]->RegionCount());
       rows[k] = n_desc[k] ? static_cast<const uint8_t*>(keep[k]->DescriptorRawData()) : nullptr;
     }
-    mvgx_match_ctx* ctx = nullptr;
-    int rc = mvgx_match_create(-1, &ctx);
-    if (rc != MVGX_OK) device_failure("mvgx_match_create", rc);
-    rc = mvgx_match_set_regions(ctx, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()), 128);
-    if (rc != MVGX_OK) { mvgx_match_destroy(ctx); device_failure("mvgx_match_set_regions", rc); }
     Sink sink{&map_PutativeMatches, &ids};
     const uint64_t n_pairs = dev_pairs.size() / 2;
+    // the two device paths have the same call shapes (include/mvgx.h): bind them once
+    mvgx_match_ctx* l2 = nullptr;
+    mvgx_hamming_ctx* hm = nullptr;
+    int rc = hamming ? mvgx_hamming_create(-1, &hm) : mvgx_match_create(-1, &l2);
+    if (rc != MVGX_OK) device_failure(hamming ? "mvgx_hamming_create" : "mvgx_match_create", rc);
+    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (l2) mvgx_match_destroy(l2); };
+    rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()),
+                                            static_cast<uint32_t>(binary_len ? binary_len : 64))
+                 : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()), 128);
+    if (rc != MVGX_OK) { destroy(); device_failure("set_regions", rc); }
     for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
       const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
       if (progress->hasBeenCanceled()) break;
-      rc = mvgx_match_run(ctx, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
-      if (rc != MVGX_OK) { mvgx_match_destroy(ctx); device_failure("mvgx_match_run", rc); }
+      rc = hamming ? mvgx_hamming_run(hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
+                   : mvgx_match_run(l2, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+      if (rc != MVGX_OK) { destroy(); device_failure("run", rc); }
       const uint64_t* offsets = nullptr;
       const uint32_t* ij = nullptr;
-      mvgx_match_results(ctx, &offsets, &ij);
+      if (hamming) mvgx_hamming_results(hm, &offsets, &ij); else mvgx_match_results(l2, &offsets, &ij);
       for (uint64_t k = 0; k < nb; ++k)
         if (offsets[k + 1] > offsets[k])
           on_pair(&sink, dev_pairs[2 * (p0 + k)], dev_pairs[2 * (p0 + k) + 1], ij + 2 * offsets[k],
                   static_cast<uint32_t>(offsets[k + 1] - offsets[k]));
       (*progress) += static_cast<uint32_t>(nb);
     }
-    mvgx_match_destroy(ctx);
+    destroy();
   }
 
   if (!generic_pairs.empty())

@@ -1,0 +1,346 @@
+// mvgx_hamming.hip — brute-force Hamming 2-NN + distance-ratio matching of binary descriptors on gfx950.
+//
+// Replaces, for binary regions (features::Binary_Regions<SIOPointFeature, 64> = AKAZE_Binary_Regions,
+// features/regions_factory.hpp:26) behind the same factory as the L2 path:
+//   matching/regions_matcher.cpp:184-191   BRUTE_FORCE_HAMMING -> RegionsMatcherT<ArrayMatcherBruteForce<uchar, Hamming<uchar>>>(regions, false)
+//   matching/metric_hamming.hpp:36-107     Hamming<T>: ResultType unsigned int, popcount of the XOR
+//   matching/matcher_brute_force.hpp:95-200 SearchNeighbours (all distances, the NN smallest)
+//   matching/regions_matcher.hpp:162-207   MatchDistanceRatio with b_squared_metric_ == false: the ratio is used as given
+//   matching/matching_filters.hpp:39-60    NNdistanceRatio: (float)d0 < ratio * (float)d1
+//
+// Formulation. Every lane owns one query descriptor of image J in registers (NW dwords). The database image I is not staged
+// at all: the row index is wave-uniform, so the rows arrive through the scalar data path (s_load_dwordx8/16 from the
+// constant cache) and are XORed as SGPR operands; per row and lane NW x (v_xor + v_bcnt accumulate) and three VALU for the
+// running top-2 on packed keys (distance << 22 | row): best0 = min(best0, key), best1 = med3(best0, best1, key).
+// Keys order equal distances by row, so best0 is the first minimum; for ratio <= 1 an accepted query has d0 < d1 strictly
+// and the emitted index is the unique argmin (the reference's partial_sort tie order cannot matter).
+// Bound: VALU issue (2 NW + 3 instructions per descriptor pair and lane); HBM traffic is negligible (every image is read
+// once per work item from L2 / the scalar cache).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "mvgx_common.h"
+
+namespace {
+
+using mvgx::set_error;
+
+constexpr int kQBlock = 256;                 // queries per workgroup
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kRowBits = 22;            // rows per image < 2^22 (distance <= 512 fits the upper 10 bits)
+
+struct HamParams {
+  const uint32_t* words;        // all descriptors, NW dwords each (zero padded), image-major
+  const uint64_t* img_row_off;  // first row of image k
+  const uint32_t* img_n;        // rows of image k
+  const uint2* pairs;           // (I, J) per pair of the batch
+  const uint2* work;            // (pair in batch, first query)
+  uint32_t* best;               // [pair][query] -> database row or kInvalid
+  uint32_t* count;              // matches per pair
+  uint32_t qstride;
+  float ratio;
+};
+
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+template <int NW>
+__global__ __launch_bounds__(kQBlock) void hamming_top2_ratio_kernel(HamParams p) {
+  __shared__ uint32_t sh_count;
+  const uint2 w = p.work[blockIdx.x];
+  const uint2 ij = p.pairs[w.x];
+  const uint32_t nI = p.img_n[ij.x], nJ = p.img_n[ij.y];
+  const uint32_t q = w.y + threadIdx.x;
+  const bool active = q < nJ;
+  if (threadIdx.x == 0) sh_count = 0;
+  __syncthreads();
+  uint32_t qv[NW];
+  {
+    const uint32_t* src = p.words + (p.img_row_off[ij.y] + (active ? q : 0)) * NW;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) qv[k] = src[k];
+  }
+  const uint32_t* __restrict__ db = p.words + p.img_row_off[ij.x] * NW;   // wave-uniform: scalar loads
+  uint32_t b0 = kInvalid, b1 = kInvalid;
+  // rows in groups of four: the scalar loads of a group are issued back to back and their latency is hidden by the VALU work
+  // of the other waves on the SIMD (35 VGPRs: the occupancy is bounded by the workgroup size, not by registers)
+#pragma unroll 4
+  for (uint32_t i = 0; i < nI; ++i) {
+    const uint32_t* __restrict__ row = db + (size_t)i * NW;
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) d += __popc(row[k] ^ qv[k]);
+    const uint32_t key = (d << kRowBits) | i;
+    const uint32_t lo = umin32(b0, key), hi = umax32(b0, key);
+    b1 = umin32(b1, hi);   // = med3(b0, b1, key) for b0 <= b1
+    b0 = lo;
+  }
+  uint32_t out = kInvalid;
+  if (active && nI >= 2) {   // matcher_brute_force.hpp:108-113: NN (= 2) > rows -> no result
+    const float d0 = (float)(b0 >> kRowBits), d1 = (float)(b1 >> kRowBits);
+    if (d0 < __fmul_rn(p.ratio, d1)) out = b0 & ((1u << kRowBits) - 1u);
+  }
+  if (active) p.best[(size_t)w.x * p.qstride + q] = out;
+  if (out != kInvalid) atomicAdd(&sh_count, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
+}
+
+// exclusive scan of the per-pair counts (one workgroup)
+__global__ __launch_bounds__(1024) void hamming_scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = umin32(threadIdx.x * per, n), hi = umin32(lo + per, n);
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += count[k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (uint32_t k = lo; k < hi; ++k) { offsets[k] = run; run += count[k]; }
+  if (threadIdx.x == 1023) offsets[n] = part[1023];
+}
+
+// ordered gather: matches of a pair in ascending query index (regions_matcher.hpp:198-205 emits them in that order)
+__global__ __launch_bounds__(256) void hamming_compact_kernel(const uint32_t* __restrict__ best, const uint32_t* __restrict__ offsets,
+                                                              const uint2* __restrict__ pairs, const uint32_t* __restrict__ img_n,
+                                                              uint32_t qstride, uint2* __restrict__ out) {
+  __shared__ uint32_t sh[256];
+  const uint32_t k = blockIdx.x;
+  const uint32_t nJ = img_n[pairs[k].y];
+  uint32_t base = offsets[k];
+  if (offsets[k + 1] == base) return;
+  for (uint32_t q0 = 0; q0 < nJ; q0 += 256) {
+    const uint32_t q = q0 + threadIdx.x;
+    const uint32_t b = q < nJ ? best[(size_t)k * qstride + q] : kInvalid;
+    const uint32_t f = b != kInvalid ? 1u : 0u;
+    sh[threadIdx.x] = f;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t v = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (f) out[base + sh[threadIdx.x] - 1] = make_uint2(b, q);
+    base += sh[255];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+struct Buf {
+  T* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  int ensure(size_t n) {
+    if (n <= cap) return MVGX_OK;
+    release();
+    const size_t want = std::max<size_t>(n + n / 4, 16);
+    if (pinned) MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), 0));
+    else MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
+    cap = want;
+    return MVGX_OK;
+  }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+    p = nullptr; cap = 0;
+  }
+};
+
+}  // namespace
+
+struct mvgx_hamming_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+  int64_t batch_pairs = 1 << 15;
+  uint32_t n_images = 0, nw = 0, desc_bytes = 0, max_n = 0, qstride = 0;
+  std::vector<uint32_t> h_n;
+  Buf<uint32_t> d_words, d_n, d_best, d_count, d_offsets;
+  Buf<uint64_t> d_row_off;
+  Buf<uint2> d_pairs, d_work, d_ij;
+  Buf<uint2> hp_pairs, hp_work;
+  Buf<uint32_t> hp_offsets;
+  std::vector<uint64_t> res_offsets;
+  std::vector<uint32_t> res_ij;
+  mvgx_hamming_ctx() { hp_pairs.pinned = hp_work.pinned = hp_offsets.pinned = true; }
+};
+
+extern "C" {
+
+int mvgx_hamming_create(int device, mvgx_hamming_ctx** out) {
+  MVGX_REQUIRE(out, MVGX_ERR_ARG, "mvgx_hamming_create: NULL out");
+  *out = nullptr;
+  const int rc = mvgx::select_device(device);
+  if (rc) return rc;
+  mvgx_hamming_ctx* c = new mvgx_hamming_ctx();
+  MVGX_HIP(hipGetDevice(&c->device));
+  MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MVGX_HIP(hipEventCreate(&c->ev0)); MVGX_HIP(hipEventCreate(&c->ev1));
+  MVGX_HIP(hipEventCreate(&c->evk0)); MVGX_HIP(hipEventCreate(&c->evk1));
+  *out = c;
+  return MVGX_OK;
+}
+
+int mvgx_hamming_destroy(mvgx_hamming_ctx* c) {
+  if (!c) return MVGX_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_words.release(); c->d_n.release(); c->d_best.release(); c->d_count.release(); c->d_offsets.release();
+  c->d_row_off.release(); c->d_pairs.release(); c->d_work.release(); c->d_ij.release();
+  c->hp_pairs.release(); c->hp_work.release(); c->hp_offsets.release();
+  for (hipEvent_t e : {c->ev0, c->ev1, c->evk0, c->evk1}) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MVGX_OK;
+}
+
+int mvgx_hamming_set_option(mvgx_hamming_ctx* c, const char* key, int64_t value) {
+  MVGX_REQUIRE(c && key, MVGX_ERR_ARG, "mvgx_hamming_set_option: NULL argument");
+  if (!strcmp(key, "batch_pairs")) {
+    MVGX_REQUIRE(value >= 1 && value <= (1 << 20), MVGX_ERR_ARG, "batch_pairs must be in [1, 2^20]");
+    c->batch_pairs = value;
+    return MVGX_OK;
+  }
+  set_error("mvgx_hamming_set_option: unknown key '%s'", key);
+  return MVGX_ERR_ARG;
+}
+
+int mvgx_hamming_set_regions(mvgx_hamming_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                             uint32_t desc_bytes) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_hamming_set_regions: NULL argument");
+  MVGX_REQUIRE(desc_bytes >= 1 && desc_bytes <= 64, MVGX_ERR_UNSUPPORTED,
+               "binary descriptor of %u bytes unsupported (device path: 1..64 bytes; AKAZE MLDB is 64)", desc_bytes);
+  MVGX_HIP(hipSetDevice(c->device));
+  c->n_images = n_images;
+  c->desc_bytes = desc_bytes;
+  c->nw = desc_bytes <= 32 ? 8 : 16;
+  c->h_n.assign(n_desc, n_desc + n_images);
+  std::vector<uint64_t> off(n_images + 1, 0);
+  c->max_n = 0;
+  for (uint32_t k = 0; k < n_images; ++k) {
+    MVGX_REQUIRE(n_desc[k] == 0 || desc_rows[k] != nullptr, MVGX_ERR_ARG, "image %u: NULL descriptor array", k);
+    MVGX_REQUIRE(n_desc[k] < (1u << kRowBits), MVGX_ERR_UNSUPPORTED, "image %u: %u descriptors (limit 2^22 - 1)", k, n_desc[k]);
+    off[k + 1] = off[k] + n_desc[k];
+    c->max_n = std::max(c->max_n, n_desc[k]);
+  }
+  c->qstride = (c->max_n + kQBlock - 1) / kQBlock * kQBlock;
+  const uint64_t rows = off[n_images];
+  // zero-padded copy: bytes beyond desc_bytes are equal (0) in every row and add nothing to a distance
+  std::vector<uint32_t> words((size_t)std::max<uint64_t>(rows, 1) * c->nw, 0u);
+  for (uint32_t k = 0; k < n_images; ++k)
+    for (uint32_t r = 0; r < n_desc[k]; ++r)
+      memcpy(reinterpret_cast<uint8_t*>(words.data() + (off[k] + r) * c->nw), desc_rows[k] + (size_t)r * desc_bytes, desc_bytes);
+  int rc;
+  if ((rc = c->d_words.ensure(words.size())) || (rc = c->d_row_off.ensure(n_images + 1)) || (rc = c->d_n.ensure(std::max(n_images, 1u))))
+    return rc;
+  MVGX_HIP(hipMemcpyAsync(c->d_words.p, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_row_off.p, off.data(), (n_images + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  if (n_images)
+    MVGX_HIP(hipMemcpyAsync(c->d_n.p, c->h_n.data(), n_images * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio, mvgx_match_stats* stats) {
+  MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "mvgx_hamming_run: NULL argument");
+  MVGX_REQUIRE(c->nw != 0 || c->n_images == 0, MVGX_ERR_STATE, "mvgx_hamming_run before set_regions");
+  MVGX_REQUIRE(dist_ratio <= 1.0f && dist_ratio >= 0.0f, MVGX_ERR_UNSUPPORTED,
+               "dist_ratio = %g: the device path reproduces the reference only for 0 <= ratio <= 1 "
+               "(ties are libstdc++ partial_sort order beyond that)", (double)dist_ratio);
+  MVGX_HIP(hipSetDevice(c->device));
+  for (uint64_t k = 0; k < n_pairs; ++k)
+    MVGX_REQUIRE(pairs_IJ[2 * k] < c->n_images && pairs_IJ[2 * k + 1] < c->n_images, MVGX_ERR_ARG,
+                 "pair %llu references image out of range", (unsigned long long)k);
+  c->res_offsets.assign(n_pairs + 1, 0);
+  c->res_ij.clear();
+  mvgx_match_stats st;
+  memset(&st, 0, sizeof(st));
+  st.variant = 100 + c->nw;
+  int rc;
+  float kernel_ms = 0.f;
+  MVGX_HIP(hipEventRecord(c->ev0, c->stream));
+  const uint64_t B = (uint64_t)c->batch_pairs;
+  for (uint64_t p0 = 0; p0 < n_pairs; p0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
+    const uint32_t blocks_per_pair = std::max<uint32_t>(1, c->qstride / kQBlock);
+    if ((rc = c->hp_pairs.ensure(nb)) || (rc = c->hp_work.ensure((size_t)nb * blocks_per_pair))) return rc;
+    uint32_t n_work = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+      const uint32_t I = pairs_IJ[2 * (p0 + k)], J = pairs_IJ[2 * (p0 + k) + 1];
+      c->hp_pairs.p[k] = make_uint2(I, J);
+      const uint32_t nI = c->h_n[I], nJ = c->h_n[J];
+      if (nI < 2 || nJ == 0) continue;   // matcher_brute_force.hpp:108-113, Matcher_Regions.cpp:65-69,85-90
+      for (uint32_t q0 = 0; q0 < nJ; q0 += kQBlock) c->hp_work.p[n_work++] = make_uint2(k, q0);
+      st.n_pairs += 1;
+      st.n_desc_pairs += (uint64_t)nI * nJ;
+    }
+    if ((rc = c->d_pairs.ensure(nb)) || (rc = c->d_work.ensure(std::max<uint32_t>(n_work, 1))) ||
+        (rc = c->d_best.ensure((size_t)nb * std::max<uint32_t>(c->qstride, 1))) || (rc = c->d_count.ensure(nb)) ||
+        (rc = c->d_offsets.ensure((size_t)nb + 1)) || (rc = c->hp_offsets.ensure((size_t)nb + 1)))
+      return rc;
+    MVGX_HIP(hipMemcpyAsync(c->d_pairs.p, c->hp_pairs.p, nb * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    if (n_work) MVGX_HIP(hipMemcpyAsync(c->d_work.p, c->hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+    MVGX_HIP(hipMemsetAsync(c->d_count.p, 0, nb * sizeof(uint32_t), c->stream));
+    if (n_work) {
+      HamParams hp;
+      hp.words = c->d_words.p; hp.img_row_off = c->d_row_off.p; hp.img_n = c->d_n.p; hp.pairs = c->d_pairs.p; hp.work = c->d_work.p;
+      hp.best = c->d_best.p; hp.count = c->d_count.p; hp.qstride = c->qstride; hp.ratio = dist_ratio;
+      MVGX_HIP(hipEventRecord(c->evk0, c->stream));
+      if (c->nw == 8) hipLaunchKernelGGL(hamming_top2_ratio_kernel<8>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+      else hipLaunchKernelGGL(hamming_top2_ratio_kernel<16>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+      MVGX_HIP(hipGetLastError());
+      MVGX_HIP(hipEventRecord(c->evk1, c->stream));
+      st.n_kernel_launches += 1;
+    }
+    hipLaunchKernelGGL(hamming_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_count.p, nb, c->d_offsets.p);
+    MVGX_HIP(hipGetLastError());
+    MVGX_HIP(hipMemcpyAsync(c->hp_offsets.p, c->d_offsets.p, ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    MVGX_HIP(hipStreamSynchronize(c->stream));
+    if (n_work) {
+      float ms = 0.f;
+      MVGX_HIP(hipEventElapsedTime(&ms, c->evk0, c->evk1));
+      kernel_ms += ms;
+    }
+    const uint32_t total = c->hp_offsets.p[nb];
+    const uint64_t base = c->res_offsets[p0];
+    for (uint32_t k = 0; k <= nb; ++k) c->res_offsets[p0 + k] = base + c->hp_offsets.p[k];
+    st.n_matches += total;
+    if (total) {
+      if ((rc = c->d_ij.ensure(total))) return rc;
+      hipLaunchKernelGGL(hamming_compact_kernel, dim3(nb), dim3(256), 0, c->stream, c->d_best.p, c->d_offsets.p, c->d_pairs.p,
+                         c->d_n.p, c->qstride, c->d_ij.p);
+      MVGX_HIP(hipGetLastError());
+      const size_t old = c->res_ij.size();
+      c->res_ij.resize(old + (size_t)total * 2);
+      MVGX_HIP(hipMemcpyAsync(c->res_ij.data() + old, c->d_ij.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+      MVGX_HIP(hipStreamSynchronize(c->stream));
+    }
+  }
+  MVGX_HIP(hipEventRecord(c->ev1, c->stream));
+  MVGX_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  MVGX_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  st.total_ms = ms;
+  st.kernel_ms = kernel_ms;
+  if (stats) *stats = st;
+  return MVGX_OK;
+}
+
+int mvgx_hamming_results(mvgx_hamming_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
+  MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_hamming_results: NULL argument");
+  *offsets = c->res_offsets.data();
+  *ij = c->res_ij.data();
+  return MVGX_OK;
+}
+
+}  // extern "C"

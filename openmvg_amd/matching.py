@@ -75,6 +75,17 @@ class Regions:
         return self._d
 
 
+class Binary_Regions(Regions):
+    """Binary_Regions<SIOPointFeature, L> stand-in (features/binary_regions.hpp; AKAZE_Binary_Regions: L = 64): an (n, L)
+    uint8 array of packed bits."""
+
+    def IsScalar(self):
+        return False
+
+    def IsBinary(self):
+        return True
+
+
 class Regions_Provider:
     """id_view -> Regions cache, fully loaded up-front like the reference provider."""
 
@@ -161,8 +172,63 @@ class MatchContext:
         return st, offsets, ij
 
 
+class HammingContext:
+    """Device-resident binary descriptor set + runs over pair lists (thin wrapper over mvgx_hamming_*)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        _capi.check(_capi.lib().mvgx_hamming_create(int(device), C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            _capi.lib().mvgx_hamming_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _capi.check(_capi.lib().mvgx_hamming_set_option(self._h, key.encode(), int(value)))
+
+    def set_regions(self, desc_list, desc_bytes=None):
+        """desc_list: sequence of (n_k, L) uint8 arrays of packed bits (n_k may be 0), one L for all."""
+        arrs = [np.ascontiguousarray(d, dtype=np.uint8) for d in desc_list]
+        if desc_bytes is None:
+            lens = {a.shape[1] for a in arrs if a.ndim == 2 and a.shape[0]}
+            if len(lens) > 1:
+                raise ValueError("all binary descriptors must have one length")
+            desc_bytes = lens.pop() if lens else 64
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))()
+        cnt = (C.c_uint32 * max(n, 1))()
+        for k, a in enumerate(arrs):
+            ptrs[k] = a.ctypes.data if a.size else None
+            cnt[k] = a.shape[0] if a.size else 0
+        self._keep = arrs
+        _capi.check(_capi.lib().mvgx_hamming_set_regions(self._h, ptrs, cnt, n, int(desc_bytes)))
+
+    def run(self, pairs, dist_ratio):
+        """pairs: (n_pairs, 2) uint32. Returns (stats, offsets[n_pairs+1] uint64, ij[(n_matches, 2)] uint32)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        st = _capi.MatchStats()
+        _capi.check(_capi.lib().mvgx_hamming_run(self._h, pairs.ctypes.data, pairs.shape[0], np.float32(dist_ratio), C.byref(st)))
+        po = C.POINTER(C.c_uint64)()
+        pij = C.POINTER(C.c_uint32)()
+        _capi.check(_capi.lib().mvgx_hamming_results(self._h, C.byref(po), C.byref(pij)))
+        n = pairs.shape[0]
+        offsets = np.ctypeslib.as_array(po, shape=(n + 1,)).copy()
+        total = int(offsets[-1])
+        ij = np.ctypeslib.as_array(pij, shape=(total, 2)).copy() if total else np.zeros((0, 2), np.uint32)
+        return st, offsets, ij
+
+
 class Matcher_Regions:
-    """Drop-in mirror of matching_image_collection::Matcher_Regions for BRUTE_FORCE_L2 (MI355X path)."""
+    """Drop-in mirror of matching_image_collection::Matcher_Regions for BRUTE_FORCE_L2 on SIFT-like regions and
+    BRUTE_FORCE_HAMMING on binary regions (MI355X paths)."""
 
     def __init__(self, distRatio, eMatcherType, device=-1, variant=None):
         self.f_dist_ratio_ = np.float32(distRatio)
@@ -171,9 +237,12 @@ class Matcher_Regions:
         self._variant = variant
 
     def Match(self, regions_provider, pairs, map_PutativeMatches, my_progress_bar=None):
+        if self.eMatcherType_ == EMatcherType.BRUTE_FORCE_HAMMING:
+            return self._match_hamming(regions_provider, pairs, map_PutativeMatches, my_progress_bar)
         if self.eMatcherType_ != EMatcherType.BRUTE_FORCE_L2:
             raise NotImplementedError(
-                f"{self.eMatcherType_.name}: only BRUTE_FORCE_L2 is accelerated; use openMVG's own matcher for the rest")
+                f"{self.eMatcherType_.name}: only BRUTE_FORCE_L2 / BRUTE_FORCE_HAMMING are accelerated; use openMVG's own "
+                "matcher for the rest")
         pairs = sorted(set((int(a), int(b)) for a, b in pairs))  # Pair_Set is an ordered std::set
         if my_progress_bar is not None:
             my_progress_bar.Restart(len(pairs), "- Matching -")
@@ -205,6 +274,40 @@ class Matcher_Regions:
         for k, p in enumerate(pairs):
             a, b = int(offsets[k]), int(offsets[k + 1])
             if b > a:  # only non-empty vectors are inserted (Matcher_Regions.cpp:99-102)
+                map_PutativeMatches.insert(p, ij[a:b].copy())
+            if my_progress_bar is not None:
+                my_progress_bar += 1
+
+    def _match_hamming(self, regions_provider, pairs, map_PutativeMatches, my_progress_bar=None):
+        """regions_matcher.cpp:184-191: binary regions, Hamming<unsigned char>, ratio not squared."""
+        pairs = sorted(set((int(a), int(b)) for a, b in pairs))
+        if my_progress_bar is not None:
+            my_progress_bar.Restart(len(pairs), "- Matching -")
+        if not pairs:
+            return
+        ids = sorted({v for p in pairs for v in p})
+        regs = {}
+        for v in ids:
+            r = regions_provider.get(v)
+            if r is None:
+                raise KeyError(f"Regions_Provider has no regions for view {v}")
+            if r.RegionCount() and (not r.IsBinary() or r.Type_id() != "h"):
+                # RegionMatcherFactory returns no matcher for scalar regions + BRUTE_FORCE_HAMMING (regions_matcher.cpp:60-64)
+                raise NotImplementedError("BRUTE_FORCE_HAMMING needs binary uint8 regions")
+            regs[v] = r
+        local = {v: k for k, v in enumerate(ids)}
+        L = next((regs[v].DescriptorLength() for v in ids if regs[v].RegionCount()), 64)
+        descs = [regs[v].DescriptorRawData() if regs[v].RegionCount() else np.zeros((0, L), np.uint8) for v in ids]
+        ctx = HammingContext(self._device)
+        try:
+            ctx.set_regions(descs, L)
+            parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
+            _, offsets, ij = ctx.run(parr, self.f_dist_ratio_)
+        finally:
+            ctx.close()
+        for k, p in enumerate(pairs):
+            a, b = int(offsets[k]), int(offsets[k + 1])
+            if b > a:
                 map_PutativeMatches.insert(p, ij[a:b].copy())
             if my_progress_bar is not None:
                 my_progress_bar += 1

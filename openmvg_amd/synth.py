@@ -211,3 +211,28 @@ def add_pose_priors(scene, weight=(1.0, 1.0, 1.0), sigma=0.0, huber_a=0.0, seed=
     sc["prior_weight"] = np.tile(np.asarray(weight, np.float64), (len(idx), 1))
     sc["prior_huber_a"] = float(huber_a)
     return sc
+
+
+def binary_descriptors(n_images, n_desc=300, n_bytes=64, seed=0, n_world=None, flip_bits=40):
+    """AKAZE-MLDB-like packed binary descriptors: every image sees a window of shared 'world' bit strings with `flip_bits`
+    random bit flips (true correspondences: small Hamming distance) plus unrelated rows. n_desc: int or per-image list."""
+    rng = np.random.default_rng(seed)
+    sizes = [int(n_desc)] * n_images if np.isscalar(n_desc) else [int(v) for v in n_desc]
+    n_world = n_world or max(4 * max(sizes + [1]), 16)
+    world = rng.integers(0, 256, (n_world, n_bytes), dtype=np.uint8)
+    out = []
+    for k, n in enumerate(sizes):
+        if n == 0:
+            out.append(np.zeros((0, n_bytes), np.uint8))
+            continue
+        idx = (rng.integers(0, max(n_world // 2, 1)) + rng.permutation(max(n_world // 2, 1))[:n]) % n_world
+        if len(idx) < n:
+            idx = np.concatenate([idx, rng.integers(0, n_world, n - len(idx))])
+        d = world[idx].copy()
+        bits = rng.integers(0, n_bytes * 8, (n, flip_bits))
+        for j in range(flip_bits):
+            d[np.arange(n), bits[:, j] >> 3] ^= (1 << (bits[:, j] & 7)).astype(np.uint8)
+        fresh = rng.random(n) < 0.3
+        d[fresh] = rng.integers(0, 256, (int(fresh.sum()), n_bytes), dtype=np.uint8)
+        out.append(np.ascontiguousarray(d))
+    return out

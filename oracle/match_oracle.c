@@ -155,6 +155,77 @@ uint64_t oracle_matcher_regions_match_u8(const uint8_t* const* desc_rows, const 
   return overflow ? (uint64_t)-1 : total;
 }
 
+/* ---- binary descriptors: BRUTE_FORCE_HAMMING (matching/regions_matcher.cpp:184-191) ----
+ * matching/metric_hamming.hpp:36-107 — Hamming<unsigned char>::operator(): ResultType = unsigned int, popcount of the XOR
+ * over `size` bytes (the reference walks 8-, 4- or 1-byte words depending on size; the sum is the same). */
+unsigned int oracle_hamming_u8(const uint8_t* a, const uint8_t* b, size_t size) {
+  unsigned int result = 0;
+  for (size_t k = 0; k < size; ++k) {
+    unsigned int x = (unsigned int)(a[k] ^ b[k]);
+    while (x) { result += x & 1u; x >>= 1; }
+  }
+  return result;
+}
+
+/* matching/regions_matcher.hpp:162-207 with b_squared_metric_ == false (regions_matcher.cpp:189): 2-NN search
+ * (matcher_brute_force.hpp:95-200), then NNdistanceRatio (matching_filters.hpp:39-60) with the ratio as given:
+ * `(*iter) < fratio * (*iter2)` on unsigned int distances = (float)d0 < fratio * (float)d1 in binary32.
+ * Ties in the 2-NN are broken by ascending database index (irrelevant for ratio <= 1, see oracle_search_neighbours_u8). */
+uint32_t oracle_match_distance_ratio_hamming(const uint8_t* dbI, int nI, const uint8_t* qJ, int nJ, int bytes,
+                                             float distance_ratio, uint32_t* out_ij) {
+  if (nJ < 1 || nI < 2) return 0;
+  uint32_t n = 0;
+  for (int q = 0; q < nJ; ++q) {
+    unsigned int d0 = 0xFFFFFFFFu, d1 = 0xFFFFFFFFu;
+    int i0 = -1;
+    for (int i = 0; i < nI; ++i) {
+      const unsigned int d = oracle_hamming_u8(qJ + (size_t)q * bytes, dbI + (size_t)i * bytes, (size_t)bytes);
+      if (d < d0) { d1 = d0; d0 = d; i0 = i; }
+      else if (d < d1) { d1 = d; }
+    }
+    volatile float rhs = distance_ratio * (float)d1;
+    if ((float)d0 < rhs) {
+      out_ij[2 * n] = (uint32_t)i0;
+      out_ij[2 * n + 1] = (uint32_t)q;
+      ++n;
+    }
+  }
+  return n;
+}
+
+/* matching_image_collection/Matcher_Regions.cpp:32-107 for BRUTE_FORCE_HAMMING on binary regions of `bytes` bytes; same
+ * output convention as oracle_matcher_regions_match_u8. */
+uint64_t oracle_matcher_regions_match_hamming(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                              uint32_t bytes, const uint32_t* pairs_IJ, uint64_t n_pairs,
+                                              float distance_ratio, uint64_t* offsets, uint32_t* ij, uint64_t capacity) {
+  uint32_t** lists = (uint32_t**)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t*));
+  uint32_t* counts = (uint32_t*)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t));
+  if (!lists || !counts) { free(lists); free(counts); return (uint64_t)-1; }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint32_t I = pairs_IJ[2 * p], J = pairs_IJ[2 * p + 1];
+    if (I < n_images && J < n_images && n_desc[I] != 0 && n_desc[J] != 0) {
+      lists[p] = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)n_desc[J]);
+      if (lists[p])
+        counts[p] = oracle_match_distance_ratio_hamming(desc_rows[I], (int)n_desc[I], desc_rows[J], (int)n_desc[J], (int)bytes,
+                                                        distance_ratio, lists[p]);
+    }
+  }
+  uint64_t total = 0;
+  int overflow = 0;
+  offsets[0] = 0;
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    if (!overflow && total + counts[p] > capacity) overflow = 1;
+    if (!overflow && counts[p]) memcpy(ij + 2 * total, lists[p], sizeof(uint32_t) * 2 * (size_t)counts[p]);
+    total += counts[p];
+    offsets[p + 1] = total;
+    free(lists[p]);
+  }
+  free(lists);
+  free(counts);
+  return overflow ? (uint64_t)-1 : total;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

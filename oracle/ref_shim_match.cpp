@@ -17,6 +17,7 @@
 #include "openMVG/matching/indMatch.hpp"
 #include "openMVG/matching/matcher_brute_force.hpp"
 #include "openMVG/matching/metric.hpp"
+#include "openMVG/matching/metric_hamming.hpp"
 #include "openMVG/matching_image_collection/Matcher_Regions.hpp"
 #include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
 
@@ -36,6 +37,17 @@ std::shared_ptr<features::Regions> make_sift_regions(const uint8_t* rows, uint32
   for (uint32_t k = 0; k < n; ++k) {
     r->Features()[k] = features::SIOPointFeature(float(k), float(k), 1.f, 0.f);
     std::memcpy(r->Descriptors()[k].data(), rows + size_t(k) * 128, 128);
+  }
+  return r;
+}
+
+std::shared_ptr<features::Regions> make_binary64_regions(const uint8_t* rows, uint32_t n) {
+  auto r = std::make_shared<features::AKAZE_Binary_Regions>();   // Binary_Regions<SIOPointFeature, 64>, regions_factory.hpp:26
+  r->Features().resize(n);
+  r->Descriptors().resize(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    r->Features()[k] = features::SIOPointFeature(float(k), float(k), 1.f, 0.f);
+    std::memcpy(r->Descriptors()[k].data(), rows + size_t(k) * 64, 64);
   }
   return r;
 }
@@ -91,6 +103,39 @@ uint64_t ref_matcher_regions_match_u8(const uint8_t* const* desc_rows, const uin
   for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
   matching::PairWiseMatches out;
   matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) {
+      flat[2 * m] = kv.second[m].i_;
+      flat[2 * m + 1] = kv.second[m].j_;
+    }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
+}
+
+// Hamming<unsigned char> on `size` bytes (matching/metric_hamming.hpp:36-107).
+unsigned int ref_hamming_u8(const uint8_t* a, const uint8_t* b, size_t size) {
+  std::vector<uint8_t, Eigen::aligned_allocator<uint8_t>> aa(a, a + size), bb(b, b + size);
+  matching::Hamming<uint8_t> metric;
+  return metric(aa.data(), bb.data(), size);
+}
+
+// Matcher_Regions(dist_ratio, BRUTE_FORCE_HAMMING).Match on in-memory AKAZE_Binary_Regions (64-byte descriptors); same
+// output convention as ref_matcher_regions_match_u8.
+uint64_t ref_matcher_regions_match_binary64(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                            const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                            ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::AKAZE_Binary_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) provider->set(k, make_binary64_regions(desc_rows[k], n_desc[k]));
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_HAMMING);
   std::shared_ptr<sfm::Regions_Provider> base = provider;
   matcher.Match(base, pairs, out, nullptr);
   std::vector<uint32_t> flat;

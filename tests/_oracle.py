@@ -115,6 +115,52 @@ def ref_matcher_regions_match(descs, pairs, dist_ratio, lib=None):
     return out
 
 
+def _bin_tables(descs, L):
+    arrs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, L) for d in descs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = (C.c_uint32 * max(n, 1))()
+    for k, a in enumerate(arrs):
+        ptrs[k] = a.ctypes.data if a.shape[0] else None
+        cnt[k] = a.shape[0]
+    return arrs, ptrs, cnt
+
+
+def port_matcher_regions_match_hamming(descs, pairs, dist_ratio, L=64):
+    """C-restatement oracle of Matcher_Regions::Match for BRUTE_FORCE_HAMMING on L-byte binary descriptors."""
+    Lb = port()
+    Lb.oracle_matcher_regions_match_hamming.restype = C.c_uint64
+    Lb.oracle_matcher_regions_match_hamming.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                                        C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
+    arrs, ptrs, cnt = _bin_tables(descs, L)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    cap = int(sum(int(arrs[j].shape[0]) for j in pairs[:, 1])) + 1 if len(pairs) else 1
+    offsets = np.zeros(len(pairs) + 1, np.uint64)
+    ij = np.zeros((cap, 2), np.uint32)
+    total = Lb.oracle_matcher_regions_match_hamming(ptrs, cnt, len(arrs), L, pairs.ctypes.data, len(pairs),
+                                                    np.float32(dist_ratio), offsets.ctypes.data, ij.ctypes.data, cap)
+    assert total != 2 ** 64 - 1
+    return offsets, ij[: int(total)].copy()
+
+
+def ref_matcher_regions_match_binary64(descs, pairs, dist_ratio, lib=None):
+    """The reference's own Matcher_Regions(BRUTE_FORCE_HAMMING).Match on AKAZE_Binary_Regions. -> {(I, J): (n,2) uint32}"""
+    Lr = lib or ref_match()
+    Lr.ref_matcher_regions_match_binary64.restype = C.c_uint64
+    Lr.ref_matcher_regions_match_binary64.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
+                                                      C.c_uint64, C.c_float, SINK, C.c_void_p]
+    arrs, ptrs, cnt = _bin_tables(descs, 64)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = {}
+
+    def sink(_user, I, J, pij, n):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()
+
+    cb = SINK(sink)
+    Lr.ref_matcher_regions_match_binary64(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    return out
+
+
 def offsets_to_dict(pairs, offsets, ij):
     out = {}
     for k, (a, b) in enumerate(np.asarray(pairs).reshape(-1, 2)):
