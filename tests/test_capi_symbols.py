@@ -39,3 +39,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("missing extension must raise")
+
+
+def test_every_built_shared_library_resolves_all_its_symbols():
+    """dlopen(RTLD_NOW) of the product, the adapter and the reference checker libraries: a missing link dependency must
+    show up here, not as a lazy-binding failure on the GPU box."""
+    import ctypes
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = glob.glob(os.path.join(root, "openmvg_amd", "lib", "*.so")) + glob.glob(os.path.join(root, "oracle", "_ref", "*.so")) + \
+        glob.glob(os.path.join(root, "oracle", "_build", "*.so"))
+    assert any(p.endswith("libmvgx_hip.so") for p in libs)
+    for p in sorted(libs):
+        ctypes.CDLL(p, mode=os.RTLD_NOW)
