@@ -198,8 +198,9 @@ def main():
             ba_rec = ba_rec or {"status": f"failed: {e!r}"}
     if rank == 0 and world == 1 and not args.no_hamming:
         try:
-            from bench_hamming import hamming_bench_record
+            from bench_hamming import hamming_bench_record, l2f_bench_record
             out["hamming"] = hamming_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+            out["l2_float"] = l2f_bench_record(local_rank, cpu=not args.no_cpu_baseline)
         except Exception as e:  # side record only
             out["hamming"] = {"status": f"failed: {e!r}"}
     if rank == 0:

@@ -64,5 +64,59 @@ def hamming_bench_record(device=0, n_images=300, n_desc=2000, steps=3, cpu_secon
     return rec
 
 
+PK_F32_OPS_PEAK = 256 * 4 * 16 * 2 * 2.4e9     # packed fp32, one operation per half and lane and cycle (no FMA allowed here)
+F32_OPS_PER_DESC_PAIR = 3.0 * 64                # sub, mul, add per element, in the reference's order
+
+
+def l2f_bench_record(device=0, n_images=200, n_desc=2000, steps=3, cpu_seconds=8.0, cpu=True):
+    """BRUTE_FORCE_L2 on AKAZE_Float_Regions-like 64-float descriptors: 200 images x 2000, exhaustive pairs."""
+    from openmvg_amd import matching, synth
+    imgs = synth.float_descriptors(n_images, n_desc, seed=0xF10A7)
+    pairs = matching.exhaustive_pairs_array(n_images)
+    rsq = np.float32(0.8) * np.float32(0.8)
+    ctx = matching.L2fContext(device)
+    ctx.set_regions(imgs, 64)
+    ctx.run(pairs[:1000], rsq)
+    kernel_ms = 0.0; launches = 0; desc_pairs = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st, off, _ = ctx.run(pairs, rsq)
+        kernel_ms += st.kernel_ms; launches += int(st.n_kernel_launches); desc_pairs += int(st.n_desc_pairs)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    ach = desc_pairs * F32_OPS_PER_DESC_PAIR / max(kernel_ms * 1e-3, 1e-12)
+    rec = {
+        "metric": "descriptor pairs/s (brute-force L2<float> 2-NN + ratio matching, reference summation order)",
+        "value": desc_pairs / dt, "unit": "descriptor pairs/s", "dtype": "f32 (separate mul/add, no contraction)",
+        "config": {"workload": f"{n_images} images x {n_desc} 64-float descriptors, exhaustive pairs ({len(pairs)} image pairs), ratio 0.8",
+                   "matches": int(off[-1])},
+        "ms_per_step": dt / steps * 1e3,
+        "roofline": {"bound": "valu", "achieved": ach / 1e12, "peak": PK_F32_OPS_PEAK / 1e12, "unit": "T fp32 ops/s",
+                     "frac": ach / PK_F32_OPS_PEAK, "traffic": None, "kernel": "l2f_top2_ratio_kernel<64>",
+                     "launches": launches, "mean_launch_ms": kernel_ms / max(launches, 1)},
+    }
+    if cpu:
+        try:
+            from tests import _oracle
+            kind = "reference" if _oracle.have_ref_match() else "port"
+            fn = (_oracle.ref_matcher_regions_match_float64 if kind == "reference"
+                  else lambda d, p, r: _oracle.port_matcher_regions_match_f32(d, p, r))
+            order = np.random.default_rng(1).permutation(len(pairs))
+            fn(imgs, pairs[order[:8]], 0.8)
+            t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
+            per = max((time.perf_counter() - t0) / 32.0, 1e-5)
+            n = int(max(32, min(len(pairs), cpu_seconds / per)))
+            t0 = time.perf_counter(); fn(imgs, pairs[order[:n]], 0.8); cdt = time.perf_counter() - t0
+            rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
+                                   "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, BRUTE_FORCE_L2, float)"}
+            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+    return rec
+
+
 if __name__ == "__main__":
+    if "l2f" in sys.argv:
+        print(json.dumps(l2f_bench_record(cpu="--no-cpu" not in sys.argv)))
+        sys.exit(0)
     print(json.dumps(hamming_bench_record(cpu="--no-cpu" not in sys.argv)))

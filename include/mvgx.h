@@ -121,6 +121,24 @@ int mvgx_hamming_run(mvgx_hamming_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n
 int mvgx_hamming_results(mvgx_hamming_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
 
 /* ------------------------------------------------------------------------------------------------
+ * MATCHING OF FLOAT DESCRIPTORS (BRUTE_FORCE_L2 on Scalar_Regions<SIOPointFeature, float, 64> = AKAZE_Float_Regions)
+ * replaces matching/regions_matcher.cpp:119-124: RegionsMatcherT<ArrayMatcherBruteForce<float, L2<float>>>(regions, true);
+ * L2<float> (matching/metric.hpp:98-135) is evaluated with the reference's own operation order in IEEE binary32 without
+ * contraction, so distances - and therefore the match lists - are bit-identical, not merely close.
+ * Same call shapes as mvgx_match_*; ratio_sq = Square(dist_ratio) in float, accepted range 0 <= ratio_sq <= 1; dim must be 64.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mvgx_l2f_ctx mvgx_l2f_ctx;
+int mvgx_l2f_create(int device, mvgx_l2f_ctx** out);
+int mvgx_l2f_destroy(mvgx_l2f_ctx* ctx);
+int mvgx_l2f_set_option(mvgx_l2f_ctx* ctx, const char* key /* "batch_pairs" */, int64_t value);
+/* desc_rows[k] -> n_desc[k] x dim row-major floats (Scalar_Regions::DescriptorRawData, scalar_regions.hpp:93) */
+int mvgx_l2f_set_regions(mvgx_l2f_ctx* ctx, const float* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                         uint32_t dim);
+int mvgx_l2f_run(mvgx_l2f_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                 mvgx_match_stats* stats /* may be NULL */);
+int mvgx_l2f_results(mvgx_l2f_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
+
+/* ------------------------------------------------------------------------------------------------
  * BUNDLE ADJUSTMENT
  * replaces: sfm/sfm_data_BA_ceres.cpp:165-608 (Bundle_Adjustment_Ceres::Adjust) and, underneath it,
  *           vendored Ceres 1.13: program_evaluator.h:138-285, residual_block.cc:68-196, corrector.cc:41-155,

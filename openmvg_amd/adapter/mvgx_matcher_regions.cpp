@@ -13,7 +13,9 @@
 //   -n BRUTEFORCEHAMMING on binary uint8 regions of <= 64 bytes (AKAZE_Binary_Regions) with dist_ratio <= 1
 //        -> the MI355X popcount path (mvgx_hamming_*), bit-identical to
 //           RegionsMatcherT<ArrayMatcherBruteForce<uchar, Hamming<uchar>>>::MatchDistanceRatio (regions_matcher.cpp:184-191)
-//   anything else (other -n values, float regions, dim != 128, ratio > 1 whose tie order is libstdc++'s)
+//   -n BRUTEFORCEL2 on 64-D float regions (AKAZE_Float_Regions) with dist_ratio <= 1
+//        -> the MI355X packed-fp32 path (mvgx_l2f_*): L2<float> in the reference's own summation order, bit-identical lists
+//   anything else (other -n values, other float lengths, uint8 dim != 128, ratio > 1 whose tie order is libstdc++'s)
 //        -> the per-pair interface the reference itself uses for them (RegionMatcherFactory, regions_matcher.cpp:54),
 //           which stays in the link; that code is not part of the accelerated path.
 //
@@ -49,6 +51,10 @@ constexpr uint64_t kPairsPerCall = 1u << 16;  // cancellation / progress granula
 
 bool is_sift_u8(const features::Regions& r) {
   return r.IsScalar() && r.DescriptorLength() == 128 && r.Type_id() == typeid(unsigned char).name();
+}
+
+bool is_float64(const features::Regions& r) {
+  return r.IsScalar() && r.DescriptorLength() == 64 && r.Type_id() == typeid(float).name();
 }
 
 bool is_binary_u8(const features::Regions& r) {
@@ -118,6 +124,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
   const bool device_type = (eMatcherType_ == matching::BRUTE_FORCE_L2 && ratio_sq <= 1.0f && ratio_sq >= 0.0f) ||
                            (hamming && f_dist_ratio_ <= 1.0f && f_dist_ratio_ >= 0.0f);
   size_t binary_len = 0;   // one descriptor length per device run (a Regions_Provider holds one region type)
+  int l2_kind = -1;        // BRUTE_FORCE_L2: 0 = 128-D uint8, 1 = 64-D float, decided by the first usable regions
 
   // Pair_Set is ordered by (I, J): the order in which the reference visits and inserts.
   std::vector<Pair> generic_pairs;
@@ -136,8 +143,9 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       if (!is_binary_u8(*r)) return -1;
       if (!binary_len) binary_len = r->DescriptorLength();
       if (r->DescriptorLength() != binary_len) return -1;
-    } else if (!is_sift_u8(*r)) {
-      return -1;
+    } else {
+      if (l2_kind < 0) l2_kind = is_float64(*r) ? 1 : 0;
+      if (l2_kind == 1 ? !is_float64(*r) : !is_sift_u8(*r)) return -1;
     }
     const uint32_t k = static_cast<uint32_t>(ids.size());
     dense.emplace(view, k);
@@ -172,25 +180,31 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     }
     Sink sink{&map_PutativeMatches, &ids};
     const uint64_t n_pairs = dev_pairs.size() / 2;
-    // the two device paths have the same call shapes (include/mvgx.h): bind them once
+    // the device paths have the same call shapes (include/mvgx.h)
+    const bool f32 = !hamming && l2_kind == 1;
     mvgx_match_ctx* l2 = nullptr;
     mvgx_hamming_ctx* hm = nullptr;
-    int rc = hamming ? mvgx_hamming_create(-1, &hm) : mvgx_match_create(-1, &l2);
-    if (rc != MVGX_OK) device_failure(hamming ? "mvgx_hamming_create" : "mvgx_match_create", rc);
-    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (l2) mvgx_match_destroy(l2); };
-    rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()),
-                                            static_cast<uint32_t>(binary_len ? binary_len : 64))
-                 : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), static_cast<uint32_t>(ids.size()), 128);
+    mvgx_l2f_ctx* lf = nullptr;
+    int rc = hamming ? mvgx_hamming_create(-1, &hm) : f32 ? mvgx_l2f_create(-1, &lf) : mvgx_match_create(-1, &l2);
+    if (rc != MVGX_OK) device_failure("create", rc);
+    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (l2) mvgx_match_destroy(l2); };
+    const uint32_t n_img = static_cast<uint32_t>(ids.size());
+    rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
+         : f32   ? mvgx_l2f_set_regions(lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
+                 : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), n_img, 128);
     if (rc != MVGX_OK) { destroy(); device_failure("set_regions", rc); }
     for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
       const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
       if (progress->hasBeenCanceled()) break;
       rc = hamming ? mvgx_hamming_run(hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
+           : f32   ? mvgx_l2f_run(lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
                    : mvgx_match_run(l2, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
       if (rc != MVGX_OK) { destroy(); device_failure("run", rc); }
       const uint64_t* offsets = nullptr;
       const uint32_t* ij = nullptr;
-      if (hamming) mvgx_hamming_results(hm, &offsets, &ij); else mvgx_match_results(l2, &offsets, &ij);
+      if (hamming) mvgx_hamming_results(hm, &offsets, &ij);
+      else if (f32) mvgx_l2f_results(lf, &offsets, &ij);
+      else mvgx_match_results(l2, &offsets, &ij);
       for (uint64_t k = 0; k < nb; ++k)
         if (offsets[k + 1] > offsets[k])
           on_pair(&sink, dev_pairs[2 * (p0 + k)], dev_pairs[2 * (p0 + k) + 1], ij + 2 * offsets[k],

@@ -1,4 +1,5 @@
-// mvgx_hamming.hip — brute-force Hamming 2-NN + distance-ratio matching of binary descriptors on gfx950.
+// mvgx_bruteforce.hip — the other brute-force instantiations behind RegionMatcherFactory on gfx950:
+//   Hamming 2-NN + distance-ratio matching of binary descriptors, and L2<float> on float descriptors (second half of the file).
 //
 // Replaces, for binary regions (features::Binary_Regions<SIOPointFeature, 64> = AKAZE_Binary_Regions,
 // features/regions_factory.hpp:26) behind the same factory as the L2 path:
@@ -89,6 +90,84 @@ __global__ __launch_bounds__(kQBlock) void hamming_top2_ratio_kernel(HamParams p
   if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
 }
 
+// ---- L2<float> (matching/metric.hpp:98-135) on Scalar_Regions<SIOPointFeature, float, DIM> (AKAZE_Float_Regions: 64) ----
+// regions_matcher.cpp:119-124: ArrayMatcherBruteForce<float, L2<float>>, squared metric -> ratio test with Square(ratio).
+// Bit-exactness: float addition is not associative, so the kernel performs the reference's operations in the reference's
+// order - per group of four elements ((d0 d0 + d1 d1) + d2 d2) + d3 d3, then result += group - with separate IEEE
+// multiplies and adds (fp contraction off: an FMA would round differently). The reference takes this scalar route for every
+// dimension that is a multiple of 8 (metric.hpp:107-112 sends only `size % 8 != 0` to its AVX variant); other dimensions
+// are refused by the C ABI. Same structure as the Hamming kernel: query in registers, database rows through the scalar
+// path, two rows per step in the two halves of packed-fp32 instructions (rows stored pairwise interleaved). Top-2 on 64-bit keys (distance bits << 32 | row):
+// a sum of squares is >= +0, and non-negative floats order like their bit patterns.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct L2fParams {
+  const float* rows;            // all descriptors, DIM floats each, image-major
+  const uint64_t* img_row_off;
+  const uint32_t* img_n;
+  const uint2* pairs;
+  const uint2* work;
+  uint32_t* best;
+  uint32_t* count;
+  uint32_t qstride;
+  float ratio_sq;
+};
+
+__device__ __forceinline__ void top2_u64(uint64_t key, uint64_t& b0, uint64_t& b1) {
+  const uint64_t lo = key < b0 ? key : b0, hi = key < b0 ? b0 : key;
+  b1 = hi < b1 ? hi : b1;
+  b0 = lo;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kQBlock) void l2f_top2_ratio_kernel(L2fParams p) {
+#pragma clang fp contract(off)
+  __shared__ uint32_t sh_count;
+  const uint2 w = p.work[blockIdx.x];
+  const uint2 ij = p.pairs[w.x];
+  const uint32_t nI = p.img_n[ij.x], nJ = p.img_n[ij.y];
+  const uint32_t q = w.y + threadIdx.x;
+  const bool active = q < nJ;
+  if (threadIdx.x == 0) sh_count = 0;
+  __syncthreads();
+  // layout: rows of an image in pairs, element k of rows 2m and 2m+1 adjacent (an image holds an even number of rows, the
+  // pad row is zero): one 64-bit scalar operand feeds both halves of a packed-fp32 instruction
+  float qv[DIM];
+  {
+    const uint32_t qq = active ? q : 0;
+    const float* src = p.rows + (p.img_row_off[ij.y] + (qq & ~1u)) * DIM + (qq & 1u);
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) qv[k] = src[2 * k];
+  }
+  const f2* __restrict__ db = reinterpret_cast<const f2*>(p.rows + p.img_row_off[ij.x] * DIM);   // wave-uniform: scalar loads
+  uint64_t b0 = ~0ull, b1 = ~0ull;
+  for (uint32_t i = 0; i < nI; i += 2) {   // rows i (x half) and i + 1 (y half)
+    const f2* __restrict__ rp = db + (size_t)(i >> 1) * DIM;
+    f2 result = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < DIM; k += 4) {
+      const f2 d0 = (f2){qv[k], qv[k]} - rp[k];
+      const f2 d1 = (f2){qv[k + 1], qv[k + 1]} - rp[k + 1];
+      const f2 d2 = (f2){qv[k + 2], qv[k + 2]} - rp[k + 2];
+      const f2 d3 = (f2){qv[k + 3], qv[k + 3]} - rp[k + 3];
+      const f2 g = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+      result = result + g;
+    }
+    top2_u64(((uint64_t)__float_as_uint(result.x) << 32) | i, b0, b1);
+    const uint64_t k1 = i + 1 < nI ? (((uint64_t)__float_as_uint(result.y) << 32) | (i + 1)) : ~0ull;   // pad row: never a neighbour
+    top2_u64(k1, b0, b1);
+  }
+  uint32_t out = kInvalid;
+  if (active && nI >= 2) {
+    const float d0 = __uint_as_float((uint32_t)(b0 >> 32)), d1 = __uint_as_float((uint32_t)(b1 >> 32));
+    if (d0 < p.ratio_sq * d1) out = (uint32_t)b0;   // matching_filters.hpp:39-60 on float distances
+  }
+  if (active) p.best[(size_t)w.x * p.qstride + q] = out;
+  if (out != kInvalid) atomicAdd(&sh_count, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
+}
+
 // exclusive scan of the per-pair counts (one workgroup)
 __global__ __launch_bounds__(1024) void hamming_scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offsets) {
   __shared__ uint32_t part[1024];
@@ -158,7 +237,8 @@ struct Buf {
 
 }  // namespace
 
-struct mvgx_hamming_ctx {
+struct BfCtx {
+  int kind = 0;   // 0: Hamming on packed bits (nw dwords per row), 1: L2<float> (nw floats per row)
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
@@ -172,27 +252,25 @@ struct mvgx_hamming_ctx {
   Buf<uint32_t> hp_offsets;
   std::vector<uint64_t> res_offsets;
   std::vector<uint32_t> res_ij;
-  mvgx_hamming_ctx() { hp_pairs.pinned = hp_work.pinned = hp_offsets.pinned = true; }
+  BfCtx() { hp_pairs.pinned = hp_work.pinned = hp_offsets.pinned = true; }
 };
+struct mvgx_hamming_ctx : BfCtx {};
+struct mvgx_l2f_ctx : BfCtx {};
 
-extern "C" {
+namespace {
 
-int mvgx_hamming_create(int device, mvgx_hamming_ctx** out) {
-  MVGX_REQUIRE(out, MVGX_ERR_ARG, "mvgx_hamming_create: NULL out");
-  *out = nullptr;
+int bf_create(int kind, int device, BfCtx* c) {
+  c->kind = kind;
   const int rc = mvgx::select_device(device);
   if (rc) return rc;
-  mvgx_hamming_ctx* c = new mvgx_hamming_ctx();
   MVGX_HIP(hipGetDevice(&c->device));
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev0)); MVGX_HIP(hipEventCreate(&c->ev1));
   MVGX_HIP(hipEventCreate(&c->evk0)); MVGX_HIP(hipEventCreate(&c->evk1));
-  *out = c;
   return MVGX_OK;
 }
 
-int mvgx_hamming_destroy(mvgx_hamming_ctx* c) {
-  if (!c) return MVGX_OK;
+void bf_release(BfCtx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_words.release(); c->d_n.release(); c->d_best.release(); c->d_count.release(); c->d_offsets.release();
@@ -200,46 +278,48 @@ int mvgx_hamming_destroy(mvgx_hamming_ctx* c) {
   c->hp_pairs.release(); c->hp_work.release(); c->hp_offsets.release();
   for (hipEvent_t e : {c->ev0, c->ev1, c->evk0, c->evk1}) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  delete c;
-  return MVGX_OK;
 }
 
-int mvgx_hamming_set_option(mvgx_hamming_ctx* c, const char* key, int64_t value) {
-  MVGX_REQUIRE(c && key, MVGX_ERR_ARG, "mvgx_hamming_set_option: NULL argument");
+int bf_set_option(BfCtx* c, const char* key, int64_t value) {
+  MVGX_REQUIRE(c && key, MVGX_ERR_ARG, "set_option: NULL argument");
   if (!strcmp(key, "batch_pairs")) {
     MVGX_REQUIRE(value >= 1 && value <= (1 << 20), MVGX_ERR_ARG, "batch_pairs must be in [1, 2^20]");
     c->batch_pairs = value;
     return MVGX_OK;
   }
-  set_error("mvgx_hamming_set_option: unknown key '%s'", key);
+  set_error("set_option: unknown key '%s'", key);
   return MVGX_ERR_ARG;
 }
 
-int mvgx_hamming_set_regions(mvgx_hamming_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
-                             uint32_t desc_bytes) {
-  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_hamming_set_regions: NULL argument");
-  MVGX_REQUIRE(desc_bytes >= 1 && desc_bytes <= 64, MVGX_ERR_UNSUPPORTED,
-               "binary descriptor of %u bytes unsupported (device path: 1..64 bytes; AKAZE MLDB is 64)", desc_bytes);
+// rows of row_bytes bytes each -> device rows of nw dwords (zero padded: padding is equal in every row and adds nothing)
+int bf_set_regions(BfCtx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t row_bytes,
+                   uint32_t nw) {
   MVGX_HIP(hipSetDevice(c->device));
   c->n_images = n_images;
-  c->desc_bytes = desc_bytes;
-  c->nw = desc_bytes <= 32 ? 8 : 16;
+  c->desc_bytes = row_bytes;
+  c->nw = nw;
   c->h_n.assign(n_desc, n_desc + n_images);
   std::vector<uint64_t> off(n_images + 1, 0);
   c->max_n = 0;
   for (uint32_t k = 0; k < n_images; ++k) {
     MVGX_REQUIRE(n_desc[k] == 0 || desc_rows[k] != nullptr, MVGX_ERR_ARG, "image %u: NULL descriptor array", k);
     MVGX_REQUIRE(n_desc[k] < (1u << kRowBits), MVGX_ERR_UNSUPPORTED, "image %u: %u descriptors (limit 2^22 - 1)", k, n_desc[k]);
-    off[k + 1] = off[k] + n_desc[k];
+    off[k + 1] = off[k] + (c->kind == 1 ? (n_desc[k] + 1u) / 2u * 2u : n_desc[k]);   // float path: whole row pairs
     c->max_n = std::max(c->max_n, n_desc[k]);
   }
   c->qstride = (c->max_n + kQBlock - 1) / kQBlock * kQBlock;
   const uint64_t rows = off[n_images];
-  // zero-padded copy: bytes beyond desc_bytes are equal (0) in every row and add nothing to a distance
-  std::vector<uint32_t> words((size_t)std::max<uint64_t>(rows, 1) * c->nw, 0u);
+  std::vector<uint32_t> words((size_t)std::max<uint64_t>(rows, 1) * nw, 0u);
   for (uint32_t k = 0; k < n_images; ++k)
-    for (uint32_t r = 0; r < n_desc[k]; ++r)
-      memcpy(reinterpret_cast<uint8_t*>(words.data() + (off[k] + r) * c->nw), desc_rows[k] + (size_t)r * desc_bytes, desc_bytes);
+    for (uint32_t r = 0; r < n_desc[k]; ++r) {
+      if (c->kind == 1) {   // element e of row r -> pair (r / 2), slot 2 e + (r & 1)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_rows[k] + (size_t)r * row_bytes);
+        uint32_t* dst = words.data() + (off[k] + (r & ~1u)) * nw + (r & 1u);
+        for (uint32_t e = 0; e < nw; ++e) dst[2 * e] = src[e];
+      } else {
+        memcpy(reinterpret_cast<uint8_t*>(words.data() + (off[k] + r) * nw), desc_rows[k] + (size_t)r * row_bytes, row_bytes);
+      }
+    }
   int rc;
   if ((rc = c->d_words.ensure(words.size())) || (rc = c->d_row_off.ensure(n_images + 1)) || (rc = c->d_n.ensure(std::max(n_images, 1u))))
     return rc;
@@ -251,12 +331,14 @@ int mvgx_hamming_set_regions(mvgx_hamming_ctx* c, const uint8_t* const* desc_row
   return MVGX_OK;
 }
 
-int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio, mvgx_match_stats* stats) {
-  MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "mvgx_hamming_run: NULL argument");
-  MVGX_REQUIRE(c->nw != 0 || c->n_images == 0, MVGX_ERR_STATE, "mvgx_hamming_run before set_regions");
-  MVGX_REQUIRE(dist_ratio <= 1.0f && dist_ratio >= 0.0f, MVGX_ERR_UNSUPPORTED,
-               "dist_ratio = %g: the device path reproduces the reference only for 0 <= ratio <= 1 "
-               "(ties are libstdc++ partial_sort order beyond that)", (double)dist_ratio);
+// the I/J loops of Matcher_Regions::Match (Matcher_Regions.cpp:57-105) in batches: work list -> top-2 + ratio kernel ->
+// per-pair counts -> exclusive scan -> ordered compaction -> host lists
+int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mvgx_match_stats* stats) {
+  MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "run: NULL argument");
+  MVGX_REQUIRE(c->nw != 0 || c->n_images == 0, MVGX_ERR_STATE, "run before set_regions");
+  MVGX_REQUIRE(ratio <= 1.0f && ratio >= 0.0f, MVGX_ERR_UNSUPPORTED,
+               "ratio = %g: the device path reproduces the reference only for 0 <= ratio <= 1 "
+               "(ties are libstdc++ partial_sort order beyond that)", (double)ratio);
   MVGX_HIP(hipSetDevice(c->device));
   for (uint64_t k = 0; k < n_pairs; ++k)
     MVGX_REQUIRE(pairs_IJ[2 * k] < c->n_images && pairs_IJ[2 * k + 1] < c->n_images, MVGX_ERR_ARG,
@@ -265,7 +347,7 @@ int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_p
   c->res_ij.clear();
   mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
-  st.variant = 100 + c->nw;
+  st.variant = (c->kind ? 200 : 100) + c->nw;
   int rc;
   float kernel_ms = 0.f;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -292,12 +374,20 @@ int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_p
     if (n_work) MVGX_HIP(hipMemcpyAsync(c->d_work.p, c->hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
     MVGX_HIP(hipMemsetAsync(c->d_count.p, 0, nb * sizeof(uint32_t), c->stream));
     if (n_work) {
-      HamParams hp;
-      hp.words = c->d_words.p; hp.img_row_off = c->d_row_off.p; hp.img_n = c->d_n.p; hp.pairs = c->d_pairs.p; hp.work = c->d_work.p;
-      hp.best = c->d_best.p; hp.count = c->d_count.p; hp.qstride = c->qstride; hp.ratio = dist_ratio;
       MVGX_HIP(hipEventRecord(c->evk0, c->stream));
-      if (c->nw == 8) hipLaunchKernelGGL(hamming_top2_ratio_kernel<8>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
-      else hipLaunchKernelGGL(hamming_top2_ratio_kernel<16>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+      if (c->kind == 0) {
+        HamParams hp;
+        hp.words = c->d_words.p; hp.img_row_off = c->d_row_off.p; hp.img_n = c->d_n.p; hp.pairs = c->d_pairs.p; hp.work = c->d_work.p;
+        hp.best = c->d_best.p; hp.count = c->d_count.p; hp.qstride = c->qstride; hp.ratio = ratio;
+        if (c->nw == 8) hipLaunchKernelGGL(hamming_top2_ratio_kernel<8>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+        else hipLaunchKernelGGL(hamming_top2_ratio_kernel<16>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+      } else {
+        L2fParams fp;
+        fp.rows = reinterpret_cast<const float*>(c->d_words.p); fp.img_row_off = c->d_row_off.p; fp.img_n = c->d_n.p;
+        fp.pairs = c->d_pairs.p; fp.work = c->d_work.p; fp.best = c->d_best.p; fp.count = c->d_count.p; fp.qstride = c->qstride;
+        fp.ratio_sq = ratio;
+        hipLaunchKernelGGL(l2f_top2_ratio_kernel<64>, dim3(n_work), dim3(kQBlock), 0, c->stream, fp);
+      }
       MVGX_HIP(hipGetLastError());
       MVGX_HIP(hipEventRecord(c->evk1, c->stream));
       st.n_kernel_launches += 1;
@@ -336,8 +426,61 @@ int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_p
   return MVGX_OK;
 }
 
+template <typename Ctx>
+int bf_create_as(int kind, int device, Ctx** out) {
+  MVGX_REQUIRE(out, MVGX_ERR_ARG, "create: NULL out");
+  *out = nullptr;
+  Ctx* c = new Ctx();
+  const int rc = bf_create(kind, device, c);
+  if (rc) { bf_release(c); delete c; return rc; }
+  *out = c;
+  return MVGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvgx_hamming_create(int device, mvgx_hamming_ctx** out) { return bf_create_as(0, device, out); }
+int mvgx_hamming_destroy(mvgx_hamming_ctx* c) { if (c) { bf_release(c); delete c; } return MVGX_OK; }
+int mvgx_hamming_set_option(mvgx_hamming_ctx* c, const char* key, int64_t value) { return bf_set_option(c, key, value); }
+
+int mvgx_hamming_set_regions(mvgx_hamming_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                             uint32_t desc_bytes) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_hamming_set_regions: NULL argument");
+  MVGX_REQUIRE(desc_bytes >= 1 && desc_bytes <= 64, MVGX_ERR_UNSUPPORTED,
+               "binary descriptor of %u bytes unsupported (device path: 1..64 bytes; AKAZE MLDB is 64)", desc_bytes);
+  return bf_set_regions(c, desc_rows, n_desc, n_images, desc_bytes, desc_bytes <= 32 ? 8 : 16);
+}
+
+int mvgx_hamming_run(mvgx_hamming_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio, mvgx_match_stats* stats) {
+  return bf_run(c, pairs_IJ, n_pairs, dist_ratio, stats);
+}
+
 int mvgx_hamming_results(mvgx_hamming_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
   MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_hamming_results: NULL argument");
+  *offsets = c->res_offsets.data();
+  *ij = c->res_ij.data();
+  return MVGX_OK;
+}
+
+int mvgx_l2f_create(int device, mvgx_l2f_ctx** out) { return bf_create_as(1, device, out); }
+int mvgx_l2f_destroy(mvgx_l2f_ctx* c) { if (c) { bf_release(c); delete c; } return MVGX_OK; }
+int mvgx_l2f_set_option(mvgx_l2f_ctx* c, const char* key, int64_t value) { return bf_set_option(c, key, value); }
+
+int mvgx_l2f_set_regions(mvgx_l2f_ctx* c, const float* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_l2f_set_regions: NULL argument");
+  MVGX_REQUIRE(dim == 64, MVGX_ERR_UNSUPPORTED,
+               "float descriptors of length %u unsupported (device path: 64 = AKAZE_Float_Regions)", dim);
+  return bf_set_regions(c, reinterpret_cast<const uint8_t* const*>(desc_rows), n_desc, n_images, dim * 4, dim);
+}
+
+int mvgx_l2f_run(mvgx_l2f_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, mvgx_match_stats* stats) {
+  return bf_run(c, pairs_IJ, n_pairs, ratio_sq, stats);
+}
+
+int mvgx_l2f_results(mvgx_l2f_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
+  MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_l2f_results: NULL argument");
   *offsets = c->res_offsets.data();
   *ij = c->res_ij.data();
   return MVGX_OK;

@@ -174,15 +174,20 @@ class MatchContext:
 
 class HammingContext:
     """Device-resident binary descriptor set + runs over pair lists (thin wrapper over mvgx_hamming_*)."""
+    _prefix = "mvgx_hamming"
+    _dtype = np.uint8
+
+    def _fn(self, name):
+        return getattr(_capi.lib(), f"{self._prefix}_{name}")
 
     def __init__(self, device=-1):
         self._h = C.c_void_p()
-        _capi.check(_capi.lib().mvgx_hamming_create(int(device), C.byref(self._h)))
+        _capi.check(self._fn("create")(int(device), C.byref(self._h)))
         self._keep = None
 
     def close(self):
         if self._h:
-            _capi.lib().mvgx_hamming_destroy(self._h)
+            self._fn("destroy")(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -192,11 +197,11 @@ class HammingContext:
             pass
 
     def set_option(self, key, value):
-        _capi.check(_capi.lib().mvgx_hamming_set_option(self._h, key.encode(), int(value)))
+        _capi.check(self._fn("set_option")(self._h, key.encode(), int(value)))
 
     def set_regions(self, desc_list, desc_bytes=None):
-        """desc_list: sequence of (n_k, L) uint8 arrays of packed bits (n_k may be 0), one L for all."""
-        arrs = [np.ascontiguousarray(d, dtype=np.uint8) for d in desc_list]
+        """desc_list: sequence of (n_k, L) arrays (uint8 packed bits / float32 for L2fContext; n_k may be 0), one L for all."""
+        arrs = [np.ascontiguousarray(d, dtype=self._dtype) for d in desc_list]
         if desc_bytes is None:
             lens = {a.shape[1] for a in arrs if a.ndim == 2 and a.shape[0]}
             if len(lens) > 1:
@@ -209,16 +214,16 @@ class HammingContext:
             ptrs[k] = a.ctypes.data if a.size else None
             cnt[k] = a.shape[0] if a.size else 0
         self._keep = arrs
-        _capi.check(_capi.lib().mvgx_hamming_set_regions(self._h, ptrs, cnt, n, int(desc_bytes)))
+        _capi.check(self._fn("set_regions")(self._h, ptrs, cnt, n, int(desc_bytes)))
 
     def run(self, pairs, dist_ratio):
         """pairs: (n_pairs, 2) uint32. Returns (stats, offsets[n_pairs+1] uint64, ij[(n_matches, 2)] uint32)."""
         pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
         st = _capi.MatchStats()
-        _capi.check(_capi.lib().mvgx_hamming_run(self._h, pairs.ctypes.data, pairs.shape[0], np.float32(dist_ratio), C.byref(st)))
+        _capi.check(self._fn("run")(self._h, pairs.ctypes.data, pairs.shape[0], np.float32(dist_ratio), C.byref(st)))
         po = C.POINTER(C.c_uint64)()
         pij = C.POINTER(C.c_uint32)()
-        _capi.check(_capi.lib().mvgx_hamming_results(self._h, C.byref(po), C.byref(pij)))
+        _capi.check(self._fn("results")(self._h, C.byref(po), C.byref(pij)))
         n = pairs.shape[0]
         offsets = np.ctypeslib.as_array(po, shape=(n + 1,)).copy()
         total = int(offsets[-1])
@@ -226,9 +231,29 @@ class HammingContext:
         return st, offsets, ij
 
 
+class L2fContext(HammingContext):
+    """Float descriptors (AKAZE_Float_Regions: 64 floats), BRUTE_FORCE_L2 (thin wrapper over mvgx_l2f_*); run() takes the
+    squared ratio like MatchContext.run()."""
+    _prefix = "mvgx_l2f"
+    _dtype = np.float32
+
+
+class Float_Regions(Regions):
+    """Scalar_Regions<SIOPointFeature, float, L> stand-in (AKAZE_Float_Regions: L = 64): an (n, L) float32 array."""
+
+    def __init__(self, descriptors):
+        d = np.ascontiguousarray(descriptors, dtype=np.float32)
+        if d.ndim != 2:
+            raise ValueError("descriptors must be a 2-D array (n, L)")
+        self._d = d
+
+    def Type_id(self):
+        return "f"  # typeid(float).name()
+
+
 class Matcher_Regions:
-    """Drop-in mirror of matching_image_collection::Matcher_Regions for BRUTE_FORCE_L2 on SIFT-like regions and
-    BRUTE_FORCE_HAMMING on binary regions (MI355X paths)."""
+    """Drop-in mirror of matching_image_collection::Matcher_Regions for BRUTE_FORCE_L2 on SIFT-like uint8 regions and on
+    64-D float regions, and BRUTE_FORCE_HAMMING on binary regions (MI355X paths)."""
 
     def __init__(self, distRatio, eMatcherType, device=-1, variant=None):
         self.f_dist_ratio_ = np.float32(distRatio)
@@ -255,6 +280,8 @@ class Matcher_Regions:
             if r is None:
                 raise KeyError(f"Regions_Provider has no regions for view {v}")
             regs[v] = r
+        if any(r.RegionCount() and r.Type_id() == "f" for r in regs.values()):
+            return self._match_float(regs, ids, pairs, map_PutativeMatches, my_progress_bar)
         # Matcher_Regions.cpp:85-90: pairs whose Type_id differ are skipped; regions_matcher.cpp:75-81: uchar only here
         for v, r in regs.items():
             if r.RegionCount() and (r.Type_id() != "h" or r.DescriptorLength() != 128 or not r.IsScalar()):
@@ -303,6 +330,29 @@ class Matcher_Regions:
             ctx.set_regions(descs, L)
             parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
             _, offsets, ij = ctx.run(parr, self.f_dist_ratio_)
+        finally:
+            ctx.close()
+        for k, p in enumerate(pairs):
+            a, b = int(offsets[k]), int(offsets[k + 1])
+            if b > a:
+                map_PutativeMatches.insert(p, ij[a:b].copy())
+            if my_progress_bar is not None:
+                my_progress_bar += 1
+
+
+    def _match_float(self, regs, ids, pairs, map_PutativeMatches, my_progress_bar=None):
+        """regions_matcher.cpp:119-124: float regions, L2<float>, squared metric."""
+        for v in ids:
+            r = regs[v]
+            if r.RegionCount() and (r.Type_id() != "f" or not r.IsScalar() or r.DescriptorLength() != 64):
+                raise NotImplementedError("device path handles Scalar_Regions<float, 64> (AKAZE_Float_Regions) only")
+        local = {v: k for k, v in enumerate(ids)}
+        descs = [regs[v].DescriptorRawData() if regs[v].RegionCount() else np.zeros((0, 64), np.float32) for v in ids]
+        ctx = L2fContext(self._device)
+        try:
+            ctx.set_regions(descs, 64)
+            parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
+            _, offsets, ij = ctx.run(parr, np.float32(self.f_dist_ratio_ * self.f_dist_ratio_))
         finally:
             ctx.close()
         for k, p in enumerate(pairs):

@@ -236,3 +236,26 @@ def binary_descriptors(n_images, n_desc=300, n_bytes=64, seed=0, n_world=None, f
         d[fresh] = rng.integers(0, 256, (int(fresh.sum()), n_bytes), dtype=np.uint8)
         out.append(np.ascontiguousarray(d))
     return out
+
+
+def float_descriptors(n_images, n_desc=300, dim=64, seed=0, noise=0.05):
+    """AKAZE-MSURF-like float descriptors: unit-norm rows drawn from a shared set of 'world' vectors plus noise (true
+    correspondences) and unrelated rows. n_desc: int or per-image list. float32, C-contiguous."""
+    rng = np.random.default_rng(seed)
+    sizes = [int(n_desc)] * n_images if np.isscalar(n_desc) else [int(v) for v in n_desc]
+    n_world = max(4 * max(sizes + [1]), 16)
+    world = rng.standard_normal((n_world, dim)).astype(np.float32)
+    out = []
+    for n in sizes:
+        if n == 0:
+            out.append(np.zeros((0, dim), np.float32))
+            continue
+        idx = rng.permutation(n_world // 2)[:n]
+        if len(idx) < n:
+            idx = np.concatenate([idx, rng.integers(0, n_world, n - len(idx))])
+        d = world[idx] + noise * rng.standard_normal((n, dim)).astype(np.float32)
+        fresh = rng.random(n) < 0.3
+        d[fresh] = rng.standard_normal((int(fresh.sum()), dim)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        out.append(np.ascontiguousarray(d.astype(np.float32)))
+    return out

@@ -226,6 +226,65 @@ uint64_t oracle_matcher_regions_match_hamming(const uint8_t* const* desc_rows, c
   return overflow ? (uint64_t)-1 : total;
 }
 
+/* ---- float descriptors: BRUTE_FORCE_L2 on Scalar_Regions<float> (matching/regions_matcher.cpp:119-124) ----
+ * L2<float> is oracle_l2_f32 above (metric.hpp:98-135; dimensions that are a multiple of 8 take its scalar loop). 2-NN +
+ * NNdistanceRatio with Square(distance_ratio) on float distances (regions_matcher.hpp:162-207, matching_filters.hpp:39-60).
+ * This translation unit must be compiled without floating-point contraction and without -ffast-math (oracle/Makefile). */
+uint32_t oracle_match_distance_ratio_f32(const float* dbI, int nI, const float* qJ, int nJ, int dim, float distance_ratio,
+                                         uint32_t* out_ij) {
+  if (nJ < 1 || nI < 2) return 0;
+  const float fratio = distance_ratio * distance_ratio;
+  uint32_t n = 0;
+  for (int q = 0; q < nJ; ++q) {
+    float d0 = 0.f, d1 = 0.f;
+    int i0 = -1, have = 0;
+    for (int i = 0; i < nI; ++i) {
+      const float d = oracle_l2_f32(qJ + (size_t)q * dim, dbI + (size_t)i * dim, (size_t)dim);
+      if (have == 0) { d0 = d; i0 = i; have = 1; }
+      else if (d < d0) { d1 = d0; d0 = d; i0 = i; have = 2; }
+      else if (have == 1 || d < d1) { d1 = d; have = 2; }
+    }
+    volatile float rhs = fratio * d1;
+    if (d0 < rhs) {
+      out_ij[2 * n] = (uint32_t)i0;
+      out_ij[2 * n + 1] = (uint32_t)q;
+      ++n;
+    }
+  }
+  return n;
+}
+
+uint64_t oracle_matcher_regions_match_f32(const float* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                          uint32_t dim, const uint32_t* pairs_IJ, uint64_t n_pairs, float distance_ratio,
+                                          uint64_t* offsets, uint32_t* ij, uint64_t capacity) {
+  uint32_t** lists = (uint32_t**)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t*));
+  uint32_t* counts = (uint32_t*)calloc(n_pairs ? n_pairs : 1, sizeof(uint32_t));
+  if (!lists || !counts) { free(lists); free(counts); return (uint64_t)-1; }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint32_t I = pairs_IJ[2 * p], J = pairs_IJ[2 * p + 1];
+    if (I < n_images && J < n_images && n_desc[I] != 0 && n_desc[J] != 0) {
+      lists[p] = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)n_desc[J]);
+      if (lists[p])
+        counts[p] = oracle_match_distance_ratio_f32(desc_rows[I], (int)n_desc[I], desc_rows[J], (int)n_desc[J], (int)dim,
+                                                    distance_ratio, lists[p]);
+    }
+  }
+  uint64_t total = 0;
+  int overflow = 0;
+  offsets[0] = 0;
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    if (!overflow && total + counts[p] > capacity) overflow = 1;
+    if (!overflow && counts[p]) memcpy(ij + 2 * total, lists[p], sizeof(uint32_t) * 2 * (size_t)counts[p]);
+    total += counts[p];
+    offsets[p + 1] = total;
+    free(lists[p]);
+  }
+  free(lists);
+  free(counts);
+  return overflow ? (uint64_t)-1 : total;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

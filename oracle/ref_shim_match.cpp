@@ -52,6 +52,17 @@ std::shared_ptr<features::Regions> make_binary64_regions(const uint8_t* rows, ui
   return r;
 }
 
+std::shared_ptr<features::Regions> make_float64_regions(const float* rows, uint32_t n) {
+  auto r = std::make_shared<features::AKAZE_Float_Regions>();   // Scalar_Regions<SIOPointFeature, float, 64>, regions_factory.hpp:22
+  r->Features().resize(n);
+  r->Descriptors().resize(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    r->Features()[k] = features::SIOPointFeature(float(k), float(k), 1.f, 0.f);
+    std::memcpy(r->Descriptors()[k].data(), rows + size_t(k) * 64, 64 * sizeof(float));
+  }
+  return r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,6 +147,38 @@ uint64_t ref_matcher_regions_match_binary64(const uint8_t* const* desc_rows, con
   for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
   matching::PairWiseMatches out;
   matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_HAMMING);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) {
+      flat[2 * m] = kv.second[m].i_;
+      flat[2 * m + 1] = kv.second[m].j_;
+    }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
+}
+
+// L2<float> on `size` elements (matching/metric.hpp:98-135).
+float ref_l2_f32(const float* a, const float* b, size_t size) {
+  std::vector<float, Eigen::aligned_allocator<float>> aa(a, a + size), bb(b, b + size);
+  matching::L2<float> metric;
+  return metric(aa.data(), bb.data(), size);
+}
+
+// Matcher_Regions(dist_ratio, BRUTE_FORCE_L2).Match on in-memory AKAZE_Float_Regions (64 floats); same output convention.
+uint64_t ref_matcher_regions_match_float64(const float* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                           const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                           ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::AKAZE_Float_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) provider->set(k, make_float64_regions(desc_rows[k], n_desc[k]));
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
   std::shared_ptr<sfm::Regions_Provider> base = provider;
   matcher.Match(base, pairs, out, nullptr);
   std::vector<uint32_t> flat;

@@ -161,6 +161,52 @@ def ref_matcher_regions_match_binary64(descs, pairs, dist_ratio, lib=None):
     return out
 
 
+def _f32_tables(descs, dim):
+    arrs = [np.ascontiguousarray(d, dtype=np.float32).reshape(-1, dim) for d in descs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = (C.c_uint32 * max(n, 1))()
+    for k, a in enumerate(arrs):
+        ptrs[k] = a.ctypes.data if a.shape[0] else None
+        cnt[k] = a.shape[0]
+    return arrs, ptrs, cnt
+
+
+def port_matcher_regions_match_f32(descs, pairs, dist_ratio, dim=64):
+    """C-restatement oracle of Matcher_Regions::Match for BRUTE_FORCE_L2 on float descriptors."""
+    Lb = port()
+    Lb.oracle_matcher_regions_match_f32.restype = C.c_uint64
+    Lb.oracle_matcher_regions_match_f32.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                                    C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64]
+    arrs, ptrs, cnt = _f32_tables(descs, dim)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    cap = int(sum(int(arrs[j].shape[0]) for j in pairs[:, 1])) + 1 if len(pairs) else 1
+    offsets = np.zeros(len(pairs) + 1, np.uint64)
+    ij = np.zeros((cap, 2), np.uint32)
+    total = Lb.oracle_matcher_regions_match_f32(ptrs, cnt, len(arrs), dim, pairs.ctypes.data, len(pairs),
+                                                np.float32(dist_ratio), offsets.ctypes.data, ij.ctypes.data, cap)
+    assert total != 2 ** 64 - 1
+    return offsets, ij[: int(total)].copy()
+
+
+def ref_matcher_regions_match_float64(descs, pairs, dist_ratio, lib=None):
+    """The reference's own Matcher_Regions(BRUTE_FORCE_L2).Match on AKAZE_Float_Regions. -> {(I, J): (n,2) uint32}"""
+    Lr = lib or ref_match()
+    Lr.ref_matcher_regions_match_float64.restype = C.c_uint64
+    Lr.ref_matcher_regions_match_float64.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
+                                                     C.c_uint64, C.c_float, SINK, C.c_void_p]
+    arrs, ptrs, cnt = _f32_tables(descs, 64)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = {}
+
+    def sink(_user, I, J, pij, n):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()
+
+    cb = SINK(sink)
+    Lr.ref_matcher_regions_match_float64(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    return out
+
+
 def offsets_to_dict(pairs, offsets, ij):
     out = {}
     for k, (a, b) in enumerate(np.asarray(pairs).reshape(-1, 2)):
@@ -469,7 +515,8 @@ def adapter():
         both = _Both()
         m = _bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
-        both.ref_matcher_regions_match_u8 = m.ref_matcher_regions_match_u8
+        for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64"):
+            setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare"):
             setattr(both, name, getattr(b, name))
         _adapter = both

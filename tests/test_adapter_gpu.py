@@ -58,6 +58,22 @@ def test_matcher_regions_replacement_hamming_equals_reference():
         _same(got, _oracle.ref_matcher_regions_match_binary64(imgs, pairs, 0.8))
 
 
+def test_matcher_regions_replacement_float_equals_reference():
+    """-n BRUTEFORCEL2 on AKAZE_Float_Regions (64 floats): same caller shim, reference TUs vs the MI355X replacement;
+    the lists are identical because the device sums in the reference's order"""
+    from openmvg_amd import matching, synth
+    sizes = [300, 0, 257, 64, 1, 2, 500]
+    imgs = synth.float_descriptors(len(sizes), sizes, seed=9)
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    got = _oracle.ref_matcher_regions_match_float64(imgs, pairs, 0.8, lib=_oracle.adapter())
+    o_off, o_ij = _oracle.port_matcher_regions_match_f32(imgs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, o_off, o_ij)
+    assert sum(len(v) for v in want.values()) > 100
+    _same(got, want)
+    if _oracle.have_ref_match():
+        _same(got, _oracle.ref_matcher_regions_match_float64(imgs, pairs, 0.8))
+
+
 def _golden():
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_golden.npz"))
 

@@ -1,6 +1,6 @@
 """CPU tests of the binary-descriptor path (BRUTE_FORCE_HAMMING, matching/regions_matcher.cpp:184-191):
 the C restatement against the reference's own Matcher_Regions on AKAZE_Binary_Regions (compiled in place) and against
-committed reference output; the device code of openmvg_amd/csrc/mvgx_hamming.hip under the HIP execution-model emulation
+committed reference output; the device code of openmvg_amd/csrc/mvgx_bruteforce.hip under the HIP execution-model emulation
 (tests/_emu.py) against the restatement."""
 import os
 

@@ -1,4 +1,4 @@
-"""MI355X parity tests of the binary-descriptor path (mvgx_hamming_*, openmvg_amd/csrc/mvgx_hamming.hip) through the C ABI:
+"""MI355X parity tests of the binary-descriptor path (mvgx_hamming_*, openmvg_amd/csrc/mvgx_bruteforce.hip) through the C ABI:
 bit-exact against the C restatement of the reference (oracle/match_oracle.c), the reference's committed output
 (tests/golden/hamming_golden.npz) and, when its build travelled, the reference itself."""
 import numpy as np
