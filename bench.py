@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--side-deadline", type=float, default=420.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
     return ap.parse_args()
@@ -188,6 +189,19 @@ def main():
                                        "kind": "port", "sample": f"failed: {e!r}"}
     ctx.close()
     ba_rec = ba_c5 = None
+    # The side records below must never cost the headline line: if one of them stalls (the BA leg has collectives; a rank
+    # that fails alone would leave the others waiting), every rank gives up after a deadline and rank 0 prints what it has.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            out.setdefault("ba", {"status": f"no result within {args.side_deadline:.0f} s"})
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.side_deadline, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
         try:
             from bench_ba import ba_bench_record
@@ -209,6 +223,7 @@ def main():
         if ba_c5 is not None:
             out["ba_c5_single_gpu"] = ba_c5
         print(json.dumps(out), flush=True)
+    watchdog.cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
