@@ -37,12 +37,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "ba_math.h"
@@ -1178,42 +1181,86 @@ struct TripHost {
   std::vector<int32_t> block_own;
 };
 
-// rows/cols: camera block of a / of b for every product; stable two-level counting sort by (row, col), then blocks and
-// chunks of at most kTripChunk products. O(n) time, no comparison sort over the products.
-void build_trip_list(size_t n_cb, const std::vector<uint32_t>& row, const std::vector<uint32_t>& col, const std::vector<uint2>& ab,
-                     TripHost& out) {
-  const size_t n = ab.size();
+// Host threads for the structure build (the analogue of Ceres' preprocessor). f(index, thread) is called for every index
+// in [0, n), indices handed out dynamically; results must not depend on which thread ran an index.
+inline unsigned host_threads(size_t work_items) {
+  if (work_items < 2048) return 1;
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* env = getenv("MVGX_HOST_THREADS")) t = (unsigned)std::max(1, atoi(env));
+  return std::max(1u, std::min(t, 32u));
+}
+template <class F>
+void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
+  if (threads <= 1 || n <= grain) { for (size_t i = 0; i < n; ++i) f(i, 0u); return; }
+  std::atomic<size_t> next{0};
+  auto body = [&](unsigned tix) {
+    for (;;) {
+      const size_t lo = next.fetch_add(grain);
+      if (lo >= n) return;
+      const size_t hi = std::min(n, lo + grain);
+      for (size_t i = lo; i < hi; ++i) f(i, tix);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body, t);
+  body(0);
+  for (auto& th : pool) th.join();
+}
+
+// Product list of one family, generated row by row (row = camera block of the first factor). gen(r, emit) must call
+// emit(col, a, b) for every product of row r in the canonical order (point, then first factor, then second factor); the
+// products of a row are grouped by column with a stable counting sort, cut into blocks (one per (row, col)) and chunks of
+// at most kTripChunk products. Rows are independent: they are generated by host threads and stitched in row order, so the
+// list does not depend on the thread count. O(products) time, no comparison sort over the products.
+template <class Gen>
+int build_trip_list(size_t n_cb, Gen gen, TripHost& out) {
+  struct RowMeta { std::vector<uint32_t> col, cnt; };
   std::vector<uint64_t> rstart(n_cb + 1, 0);
-  for (size_t t = 0; t < n; ++t) rstart[row[t] + 1]++;
+  const unsigned threads = host_threads(n_cb * 64);
+  parallel_for_dynamic(n_cb, 1, threads, [&](size_t r, unsigned) {
+    uint64_t n = 0;
+    gen((uint32_t)r, [&](uint32_t, uint32_t, uint32_t) { ++n; });
+    rstart[r + 1] = n;
+  });
   for (size_t r = 0; r < n_cb; ++r) rstart[r + 1] += rstart[r];
-  std::vector<uint32_t> order(n);
-  { std::vector<uint64_t> fill(rstart.begin(), rstart.end() - 1);
-    for (size_t t = 0; t < n; ++t) order[fill[row[t]]++] = (uint32_t)t; }
-  out.trips.resize(n);
-  std::vector<uint32_t> cnt(n_cb, 0), touched;
-  std::vector<uint64_t> off(n_cb, 0);
+  MVGX_REQUIRE(rstart[n_cb] < (1ull << 32), MVGX_ERR_ARG, "mvgx_ba_create: too many co-visibility products for one device shard");
+  out.trips.resize(rstart[n_cb]);
+  std::vector<RowMeta> meta(n_cb);
+  struct Scratch { std::vector<uint32_t> cnt, touched, cols; std::vector<uint64_t> off; std::vector<uint2> ab; };
+  std::vector<Scratch> scratch(threads);
+  for (auto& sc : scratch) { sc.cnt.assign(n_cb, 0); sc.off.assign(n_cb, 0); }
+  parallel_for_dynamic(n_cb, 1, threads, [&](size_t r, unsigned tix) {
+    const uint64_t lo = rstart[r], hi = rstart[r + 1];
+    if (lo == hi) return;
+    Scratch& sc = scratch[tix];
+    sc.touched.clear(); sc.cols.clear(); sc.ab.clear();
+    gen((uint32_t)r, [&](uint32_t cb, uint32_t a, uint32_t b) {
+      if (sc.cnt[cb]++ == 0) sc.touched.push_back(cb);
+      sc.cols.push_back(cb); sc.ab.push_back(make_uint2(a, b));
+    });
+    std::sort(sc.touched.begin(), sc.touched.end());
+    uint64_t pos = lo;
+    RowMeta& m = meta[r];
+    for (uint32_t cb : sc.touched) { sc.off[cb] = pos; m.col.push_back(cb); m.cnt.push_back(sc.cnt[cb]); pos += sc.cnt[cb]; sc.cnt[cb] = 0; }
+    for (size_t q = 0; q < sc.cols.size(); ++q) out.trips[sc.off[sc.cols[q]]++] = sc.ab[q];
+  });
   out.block_chunk0.push_back(0);
   for (size_t r = 0; r < n_cb; ++r) {
-    const uint64_t lo = rstart[r], hi = rstart[r + 1];
-    if (lo == hi) continue;
-    touched.clear();
-    for (uint64_t q = lo; q < hi; ++q) { const uint32_t cb = col[order[q]]; if (cnt[cb]++ == 0) touched.push_back(cb); }
-    std::sort(touched.begin(), touched.end());
-    uint64_t pos = lo;
-    for (uint32_t cb : touched) {
-      off[cb] = pos;
+    uint64_t pos = rstart[r];
+    const RowMeta& m = meta[r];
+    for (size_t k = 0; k < m.col.size(); ++k) {
+      const uint32_t cb = m.col[k], cnt = m.cnt[k];
       out.block_row.push_back((uint32_t)r); out.block_col.push_back(cb); out.block_own.push_back(-1);
-      for (uint64_t a = pos; a < pos + cnt[cb]; a += kTripChunk) {
+      for (uint64_t a = pos; a < pos + cnt; a += kTripChunk) {
         out.chunk_lo.push_back((uint32_t)a);
-        out.chunk_hi.push_back((uint32_t)std::min<uint64_t>(a + kTripChunk, pos + cnt[cb]));
+        out.chunk_hi.push_back((uint32_t)std::min<uint64_t>(a + kTripChunk, pos + cnt));
         out.chunk_diag.push_back(cb == (uint32_t)r ? 1 : 0);
       }
       out.block_chunk0.push_back((uint32_t)out.chunk_lo.size());
-      pos += cnt[cb];
+      pos += cnt;
     }
-    for (uint64_t q = lo; q < hi; ++q) { const uint32_t t = order[q]; out.trips[off[col[t]]++] = ab[t]; }
-    for (uint32_t cb : touched) cnt[cb] = 0;
   }
+  return MVGX_OK;
 }
 
 template <typename T>
@@ -1646,56 +1693,105 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
+  // MVGX_BA_CREATE_TIMING=1: phase times of this function on stderr (host structure vs allocation vs upload)
+  const bool timing = getenv("MVGX_BA_CREATE_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mvgx_ba_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
 
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----
+  const unsigned T = host_threads(no);
+  // observations sorted by point (stable): identity when the caller's list already is (a landmark-by-landmark export of an
+  // SfM_Data scene), else one counting sort
   std::vector<uint64_t> perm(no);
-  std::iota(perm.begin(), perm.end(), 0ull);
-  std::stable_sort(perm.begin(), perm.end(), [&](uint64_t a, uint64_t b) { return p->obs_point[a] < p->obs_point[b]; });
-  std::vector<uint32_t> opose(no), ointr(no), opt_(no), oslot(no), pt_start(d.n_pts + 1, 0);
+  std::vector<uint32_t> pt_start(d.n_pts + 1, 0);
+  for (uint64_t k = 0; k < no; ++k) pt_start[p->obs_point[k] + 1]++;
+  for (uint32_t j = 0; j < d.n_pts; ++j) pt_start[j + 1] += pt_start[j];
+  {
+    bool sorted = true;
+    for (uint64_t k = 1; k < no && sorted; ++k) sorted = p->obs_point[k - 1] <= p->obs_point[k];
+    if (sorted) {
+      std::iota(perm.begin(), perm.end(), 0ull);
+    } else {
+      std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
+      for (uint64_t k = 0; k < no; ++k) perm[fill[p->obs_point[k]]++] = k;
+    }
+  }
+  std::vector<uint32_t> opose(no), ointr(no), opt_(no), oslot(no);
   std::vector<double> oxy(2 * no), oweight;
   std::vector<uint8_t> octrl;
   if (p->obs_weight) oweight.resize(no);
   if (p->obs_is_control) octrl.resize(no);
-  double n_rmse = 0;
-  for (uint64_t k = 0; k < no; ++k) {
-    const uint64_t s = perm[k];
-    opose[k] = p->obs_pose[s]; ointr[k] = p->obs_intr[s]; opt_[k] = p->obs_point[s];
-    oxy[2 * k] = p->obs_xy[2 * s]; oxy[2 * k + 1] = p->obs_xy[2 * s + 1];
-    if (p->obs_weight) oweight[k] = p->obs_weight[s];
-    if (p->obs_is_control) octrl[k] = p->obs_is_control[s] ? 1 : 0;
-    if (!(p->obs_is_control && p->obs_is_control[s])) n_rmse += 1.0;
-    pt_start[opt_[k] + 1]++;
-  }
+  constexpr size_t kGrain = 16384;
+  const size_t n_grains = (size_t)((no + kGrain - 1) / kGrain);
+  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+    for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+      const uint64_t s_ = perm[k];
+      opose[k] = p->obs_pose[s_]; ointr[k] = p->obs_intr[s_]; opt_[k] = p->obs_point[s_];
+      oxy[2 * k] = p->obs_xy[2 * s_]; oxy[2 * k + 1] = p->obs_xy[2 * s_ + 1];
+      if (p->obs_weight) oweight[k] = p->obs_weight[s_];
+      if (p->obs_is_control) octrl[k] = p->obs_is_control[s_] ? 1 : 0;
+    }
+  });
+  double n_rmse = (double)no;
+  if (p->obs_is_control)
+    for (uint64_t k = 0; k < no; ++k) if (p->obs_is_control[k]) n_rmse -= 1.0;
   c->n_obs_rmse_local = n_rmse;
-  for (uint32_t j = 0; j < d.n_pts; ++j) pt_start[j + 1] += pt_start[j];
+  tick("sort by point + gather");
   std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_free(d.n_pts, 0);
   for (uint64_t k = 0; k < no; ++k) { pose_used[opose[k]] = 1; intr_used[ointr[k]] = 1; pt_free[opt_[k]] = 1; }
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_used[p->prior_pose[k]] = 1;
   for (uint32_t j = 0; j < d.n_pts; ++j)
     if (p->points_constant || (p->point_const_mask && p->point_const_mask[j])) pt_free[j] = 0;
-  // (point, intrinsic) slots
-  std::vector<uint32_t> ptk_start(d.n_pts + 1, 0), slot_intr, slot_point;
-  for (uint32_t j = 0; j < d.n_pts; ++j) {
-    const size_t first = slot_intr.size();
-    for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
-      size_t s = first;
-      while (s < slot_intr.size() && slot_intr[s] != ointr[o]) ++s;
-      if (s == slot_intr.size()) { slot_intr.push_back(ointr[o]); slot_point.push_back(j); }
-      oslot[o] = (uint32_t)s;
+  // (point, intrinsic) slots: the distinct intrinsics of a point in order of first appearance; counted, then filled
+  std::vector<uint32_t> ptk_start(d.n_pts + 1, 0);
+  const size_t n_pgrains = ((size_t)d.n_pts + 4095) / 4096;
+  parallel_for_dynamic(n_pgrains, 1, T, [&](size_t g, unsigned) {
+    for (uint32_t j = (uint32_t)(g * 4096), e = (uint32_t)std::min<size_t>(d.n_pts, (g + 1) * 4096); j < e; ++j) {
+      uint32_t n = 0;
+      for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+        bool seen = false;
+        for (uint32_t q = pt_start[j]; q < o && !seen; ++q) seen = ointr[q] == ointr[o];
+        n += seen ? 0u : 1u;
+      }
+      ptk_start[j + 1] = n;
     }
-    ptk_start[j + 1] = (uint32_t)slot_intr.size();
-  }
+  });
+  for (uint32_t j = 0; j < d.n_pts; ++j) ptk_start[j + 1] += ptk_start[j];
+  std::vector<uint32_t> slot_intr(ptk_start[d.n_pts]), slot_point(ptk_start[d.n_pts]);
+  parallel_for_dynamic(n_pgrains, 1, T, [&](size_t g, unsigned) {
+    for (uint32_t j = (uint32_t)(g * 4096), e = (uint32_t)std::min<size_t>(d.n_pts, (g + 1) * 4096); j < e; ++j) {
+      const uint32_t first = ptk_start[j];
+      uint32_t used = first;
+      for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+        uint32_t s_ = first;
+        while (s_ < used && slot_intr[s_] != ointr[o]) ++s_;
+        if (s_ == used) { slot_intr[used] = ointr[o]; slot_point[used] = j; ++used; }
+        oslot[o] = s_;
+      }
+    }
+  });
   d.n_islots = (int)slot_intr.size();
-  // (pose, intrinsic) pairs: observations sorted by pose, then intrinsic; chunks of kPiChunk observations
-  std::vector<uint32_t> prow_start(d.n_poses + 1, 0), pi_obs(no);
+  // observations by pose (ascending observation index inside a pose): the rows of the product lists; then, inside a pose,
+  // stably by intrinsic: the (pose, intrinsic) pairs of the Gram kernels, cut into chunks of kPiChunk observations
+  std::vector<uint32_t> prow_start(d.n_poses + 1, 0), pose_obs(no);
   for (uint64_t k = 0; k < no; ++k) prow_start[opose[k] + 1]++;
   for (uint32_t i = 0; i < d.n_poses; ++i) prow_start[i + 1] += prow_start[i];
   { std::vector<uint32_t> fill(prow_start.begin(), prow_start.end() - 1);
-    for (uint64_t k = 0; k < no; ++k) pi_obs[fill[opose[k]]++] = (uint32_t)k; }
+    for (uint64_t k = 0; k < no; ++k) pose_obs[fill[opose[k]]++] = (uint32_t)k; }
+  std::vector<uint32_t> pi_obs(pose_obs);
+  parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
+    auto b_ = pi_obs.begin() + prow_start[i], e_ = pi_obs.begin() + prow_start[i + 1];
+    bool one = true;   // the usual case: a view has one intrinsic
+    for (auto it = b_; it != e_ && one; ++it) one = ointr[*it] == ointr[*b_];
+    if (!one) std::stable_sort(b_, e_, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
+  });
   std::vector<uint32_t> pi_start, pi_intr, pose_pi_start(d.n_poses + 1, 0), pichunk_lo, pichunk_hi, pi_chunk0;
   for (uint32_t i = 0; i < d.n_poses; ++i) {
-    auto b = pi_obs.begin() + prow_start[i], e = pi_obs.begin() + prow_start[i + 1];
-    std::stable_sort(b, e, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
     for (uint32_t q = prow_start[i]; q < prow_start[i + 1]; ++q)
       if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) { pi_start.push_back(q); pi_intr.push_back(ointr[pi_obs[q]]); }
     pose_pi_start[i + 1] = (uint32_t)pi_start.size();
@@ -1723,53 +1819,58 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     igchunk_start[k + 1] = (uint32_t)igchunk_lo.size();
   }
   d.n_igchunks = (int)igchunk_lo.size();
+  // slots by intrinsic (ascending slot index): the rows of the intrinsic-intrinsic products
+  std::vector<uint32_t> islot_start(d.n_intr + 1, 0), islot(slot_intr.size());
+  for (uint32_t s_ : slot_intr) islot_start[s_ + 1]++;
+  for (uint32_t i = 0; i < d.n_intr; ++i) islot_start[i + 1] += islot_start[i];
+  { std::vector<uint32_t> fill(islot_start.begin(), islot_start.end() - 1);
+    for (uint32_t q = 0; q < (uint32_t)slot_intr.size(); ++q) islot[fill[slot_intr[q]]++] = q; }
   // pose-centre priors by pose
   std::vector<uint32_t> prior_pose(p->prior_pose, p->prior_pose + d.n_priors), pose_prior_start(d.n_poses + 1, 0), pose_prior_idx(d.n_priors);
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_prior_start[prior_pose[k] + 1]++;
   for (uint32_t i = 0; i < d.n_poses; ++i) pose_prior_start[i + 1] += pose_prior_start[i];
   { std::vector<uint32_t> fill(pose_prior_start.begin(), pose_prior_start.end() - 1);
     for (uint32_t k = 0; k < d.n_priors; ++k) pose_prior_idx[fill[prior_pose[k]]++] = k; }
-  // Schur products by destination block
+  tick("slots, pose / intrinsic lists");
+  // Schur products by destination block, generated row by row on host threads. Constant / unused points have Z = 0: only
+  // their (a, a) products are listed, so that every diagonal block exists (it carries the Gram block and the rhs).
   TripHost hpp, hpi, hii;
   {
     const size_t n_cb = (size_t)d.n_poses + d.n_intr;
-    std::vector<uint32_t> row, col;
-    std::vector<uint2> ab;
-    size_t npp = 0, npi = 0;
-    for (uint32_t j = 0; j < d.n_pts; ++j) {
-      if (!pt_free[j]) continue;
-      const size_t L = pt_start[j + 1] - pt_start[j], K = ptk_start[j + 1] - ptk_start[j];
-      npp += L * L; npi += L * K;
-    }
-    MVGX_REQUIRE(npp < (1ull << 32) && npi < (1ull << 32), MVGX_ERR_ARG, "mvgx_ba_create: too many co-visibility products for one device shard");
-    row.reserve(npp); col.reserve(npp); ab.reserve(npp);
-    // Constant / unused points have Z = 0: only the (a, a) products are listed, so that every diagonal block exists
-    // (it carries the Gram block and the rhs).
-    for (uint32_t j = 0; j < d.n_pts; ++j)
-      for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
-        for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
-          if (opose[a] <= opose[b] && (pt_free[j] || a == b)) { row.push_back(opose[a]); col.push_back(opose[b]); ab.push_back(make_uint2(a, b)); }
-    build_trip_list(n_cb, row, col, ab, hpp);
-    row.clear(); col.clear(); ab.clear();
-    for (uint32_t j = 0; j < d.n_pts; ++j)
-      for (uint32_t a = pt_start[j]; a < pt_start[j + 1]; ++a)
-        for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
-          if (pt_free[j] || sl == oslot[a]) { row.push_back(opose[a]); col.push_back(d.n_poses + slot_intr[sl]); ab.push_back(make_uint2(a, sl)); }
-    build_trip_list(n_cb, row, col, ab, hpi);
+    const uint32_t np = d.n_poses;
+    if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-pose: Z_a^T Z_b, pose(a) <= pose(b), same point
+          if (r >= np) return;
+          for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
+            const uint32_t a = pose_obs[q], j = opt_[a];
+            for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
+              if (r <= opose[b] && (pt_free[j] || a == b)) emit(opose[b], a, b);
+          }
+        }, hpp))) return rc;
+    tick("pose-pose products");
+    if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-intrinsic: Z_a^T Zint_slot
+          if (r >= np) return;
+          for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
+            const uint32_t a = pose_obs[q], j = opt_[a];
+            for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
+              if (pt_free[j] || sl == oslot[a]) emit(np + slot_intr[sl], a, sl);
+          }
+        }, hpi))) return rc;
     for (size_t b = 0; b < hpi.block_row.size(); ++b) {   // the (pose, intrinsic) pair whose Fc^T Fi belongs to the block
       const uint32_t i = hpi.block_row[b], k = hpi.block_col[b] - d.n_poses;
       for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
         if (pi_intr[q] == k) hpi.block_own[b] = (int32_t)q;
     }
-    row.clear(); col.clear(); ab.clear();
-    for (uint32_t j = 0; j < d.n_pts; ++j)
-      for (uint32_t sa = ptk_start[j]; sa < ptk_start[j + 1]; ++sa)
-        for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
-          if (slot_intr[sa] <= slot_intr[sb] && (pt_free[j] || sa == sb)) {
-            row.push_back(d.n_poses + slot_intr[sa]); col.push_back(d.n_poses + slot_intr[sb]); ab.push_back(make_uint2(sa, sb));
+    if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // intrinsic-intrinsic
+          if (r < np) return;
+          const uint32_t k = r - np;
+          for (uint32_t q = islot_start[k]; q < islot_start[k + 1]; ++q) {
+            const uint32_t sa = islot[q], j = slot_point[sa];
+            for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
+              if (k <= slot_intr[sb] && (pt_free[j] || sa == sb)) emit(np + slot_intr[sb], sa, sb);
           }
-    build_trip_list(n_cb, row, col, ab, hii);
+        }, hii))) return rc;
   }
+  tick("pose-intr / intr-intr products");
   // active / counted camera components
   std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
   for (uint32_t i = 0; i < d.n_poses; ++i) {
@@ -1797,6 +1898,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 
 #define UP(field, vec) if ((rc = dev_upload(c->pool, &d.field, vec, c->stream))) return rc
 #define AL(field, n) if ((rc = dev_alloc(c->pool, &d.field, (size_t)(n)))) return rc
+  tick("masks, parameter copies");
   UP(poses, h_poses); UP(intr, h_intr); UP(pts, h_pts); UP(model, h_model);
   AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
   UP(opose, opose); UP(ointr, ointr); UP(opt, opt_); UP(oxy, oxy);
@@ -1809,6 +1911,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   UP(iobs, iobs); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
   UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
   UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
+  tick("small allocations + uploads");
   AL(JA, (size_t)kJA * no); AL(JB, (size_t)kJB * no); AL(JC, (size_t)kJC * no);
   AL(cn_cam, d.N); AL(g_cam, d.N); AL(scale_cam, d.N); AL(diag_cam, d.N);
   AL(cn_pt, (size_t)d.n_pts * 3); AL(g_pt, (size_t)d.n_pts * 3); AL(scale_pt, (size_t)d.n_pts * 3); AL(diag_pt, (size_t)d.n_pts * 3);
@@ -1819,6 +1922,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(S, (size_t)d.N * d.LD);
   AL(linv, (size_t)((d.N + 63) / 64) * 8192);
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
+  tick("large scratch allocations");
   {
     struct { TripHost* h; TripList* l; int nv; } lists[3] = {{&hpp, &d.tpp, 6 * 6 + 6}, {&hpi, &d.tpi, 6 * 8 + 6}, {&hii, &d.tii, 8 * 8 + 8}};
     for (auto& e : lists) {
@@ -1847,7 +1951,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kUpd128Lds));
+  tick("product lists upload (enqueue)");
   MVGX_HIP(hipStreamSynchronize(c->stream));
+  tick("stream drain");
   *out = c;
   return MVGX_OK;
 }
