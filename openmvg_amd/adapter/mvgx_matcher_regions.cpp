@@ -25,8 +25,14 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <future>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <typeinfo>
 #include <unordered_map>
 #include <vector>
@@ -47,7 +53,7 @@ namespace matching_image_collection {
 
 namespace {
 
-constexpr uint64_t kPairsPerCall = 1u << 16;  // cancellation / progress granularity of the device path
+constexpr uint64_t kPairsPerCall = 1u << 17;  // cancellation / progress granularity of the device path (~60 ms of device work)
 
 bool is_sift_u8(const features::Regions& r) {
   return r.IsScalar() && r.DescriptorLength() == 128 && r.Type_id() == typeid(unsigned char).name();
@@ -66,12 +72,39 @@ struct Sink {
   const std::vector<IndexT>* ids;  // dense image index -> view id
 };
 
-void on_pair(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n) {
-  auto* s = static_cast<Sink*>(user);
-  matching::IndMatches v;
-  v.reserve(n);
-  for (uint32_t k = 0; k < n; ++k) v.emplace_back(ij[2 * k], ij[2 * k + 1]);
-  s->out->insert({{(*s->ids)[I], (*s->ids)[J]}, std::move(v)});
+// The match lists of one device call become IndMatches vectors on host threads (allocation + copy of up to a gigabyte is
+// the host-side cost of a large run); the container itself is filled from the calling thread only, in ascending (I, J),
+// as PairWiseMatchesContainer requires (indMatch.hpp:70-75: not thread safe).
+void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const uint64_t* offsets, const uint32_t* ij) {
+  std::vector<matching::IndMatches> lists(nb);
+  auto build = [&](uint64_t k) {
+    const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
+    if (!n) return;
+    matching::IndMatches& v = lists[k];
+    v.reserve(n);
+    for (uint64_t m = 0; m < n; ++m) v.emplace_back(ij[2 * (lo + m)], ij[2 * (lo + m) + 1]);
+  };
+  const uint64_t total = offsets[nb] - offsets[0];
+  unsigned threads = total < (1u << 16) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (threads <= 1) {
+    for (uint64_t k = 0; k < nb; ++k) build(k);
+  } else {
+    std::atomic<uint64_t> next{0};
+    auto body = [&]() {
+      for (;;) {
+        const uint64_t lo = next.fetch_add(256);
+        if (lo >= nb) return;
+        for (uint64_t k = lo, hi = std::min(nb, lo + 256); k < hi; ++k) build(k);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body);
+    body();
+    for (auto& th : pool) th.join();
+  }
+  for (uint64_t k = 0; k < nb; ++k)
+    if (!lists[k].empty())
+      sink.out->insert({{(*sink.ids)[pairs_IJ[2 * k]], (*sink.ids)[pairs_IJ[2 * k + 1]]}, std::move(lists[k])});
 }
 
 [[noreturn]] void device_failure(const char* what, int rc) {
@@ -118,6 +151,16 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
                             system::ProgressInterface* progress) const {
   if (!progress) progress = &system::ProgressInterface::dummy();
   progress->Restart(pairs.size(), "- Matching -");
+  // MVGX_ADAPTER_TIMING=1: phase times of this call on stderr
+  const bool timing = std::getenv("MVGX_ADAPTER_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[mvgx Matcher_Regions::Match] %-32s %8.2f ms\n", what,
+                 std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
 
   const float ratio_sq = Square(f_dist_ratio_);  // regions_matcher.hpp:196 (squared metric), numeric.h:56
   const bool hamming = eMatcherType_ == matching::BRUTE_FORCE_HAMMING;   // metric not squared: the ratio is used as given
@@ -170,6 +213,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       ++skipped;
   }
   if (skipped) (*progress) += skipped;
+  tick("pair list + regions lookup");
 
   if (!dev_pairs.empty()) {
     std::vector<const uint8_t*> rows(ids.size());
@@ -187,31 +231,45 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     mvgx_l2f_ctx* lf = nullptr;
     int rc = hamming ? mvgx_hamming_create(-1, &hm) : f32 ? mvgx_l2f_create(-1, &lf) : mvgx_match_create(-1, &l2);
     if (rc != MVGX_OK) device_failure("create", rc);
+    if (l2) {
+      const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the lists rarely pays
+      mvgx_match_set_option(l2, "pinned_results", env ? std::atoi(env) : 0);
+    }
     auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (l2) mvgx_match_destroy(l2); };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());
     rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
          : f32   ? mvgx_l2f_set_regions(lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
                  : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), n_img, 128);
     if (rc != MVGX_OK) { destroy(); device_failure("set_regions", rc); }
+    tick("context + upload + tile build");
+    // device call k + 1 runs while the lists of call k are turned into IndMatches and inserted (one worker at a time, in
+    // (I, J) order); the uint8 context keeps the previous call's results alive for exactly that (include/mvgx.h)
+    std::future<void> pending;
+    auto drain = [&]() { if (pending.valid()) pending.get(); };
     for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
       const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
       if (progress->hasBeenCanceled()) break;
+      if (hamming || f32) drain();   // those contexts hold one result buffer
       rc = hamming ? mvgx_hamming_run(hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
            : f32   ? mvgx_l2f_run(lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
                    : mvgx_match_run(l2, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+      tick("device run");
+      drain();
+      tick("wait for previous delivery");
       if (rc != MVGX_OK) { destroy(); device_failure("run", rc); }
       const uint64_t* offsets = nullptr;
       const uint32_t* ij = nullptr;
       if (hamming) mvgx_hamming_results(hm, &offsets, &ij);
       else if (f32) mvgx_l2f_results(lf, &offsets, &ij);
       else mvgx_match_results(l2, &offsets, &ij);
-      for (uint64_t k = 0; k < nb; ++k)
-        if (offsets[k + 1] > offsets[k])
-          on_pair(&sink, dev_pairs[2 * (p0 + k)], dev_pairs[2 * (p0 + k) + 1], ij + 2 * offsets[k],
-                  static_cast<uint32_t>(offsets[k + 1] - offsets[k]));
+      const uint32_t* batch_pairs = dev_pairs.data() + 2 * p0;
+      pending = std::async(std::launch::async, [=, &sink]() { deliver(sink, batch_pairs, nb, offsets, ij); });
       (*progress) += static_cast<uint32_t>(nb);
     }
+    drain();
+    tick("last delivery");
     destroy();
+    tick("context destroy");
   }
 
   if (!generic_pairs.empty())

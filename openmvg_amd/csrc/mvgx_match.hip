@@ -904,10 +904,18 @@ struct PinnedBuf {
     cap = want;
     return MVGX_OK;
   }
+  bool pageable = false;   // true: plain malloc'd memory (cheap to obtain; D2H copies are staged by the runtime)
   // grow to at least n elements, keeping the first `used` (geometric growth: the caller appends batch after batch)
   int grow_keep(size_t n, size_t used) {
     if (n <= cap) return MVGX_OK;
     const size_t want = std::max<size_t>(std::max<size_t>(n, cap + cap / 2), 16);
+    if (pageable) {
+      T* q = static_cast<T*>(realloc(p, want * sizeof(T)));
+      MVGX_REQUIRE(q != nullptr, MVGX_ERR_HIP, "out of host memory (%zu bytes)", want * sizeof(T));
+      p = q;
+      cap = want;
+      return MVGX_OK;
+    }
     T* q = nullptr;
     MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&q), want * sizeof(T), hipHostMallocDefault));
     if (p) {
@@ -918,7 +926,7 @@ struct PinnedBuf {
     cap = want;
     return MVGX_OK;
   }
-  void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+  void release() { if (p) { if (pageable) free(p); else (void)hipHostFree(p); p = nullptr; cap = 0; } }
 };
 
 }  // namespace
@@ -964,9 +972,13 @@ struct mvgx_match_ctx {
     uint32_t nb = 0;
   } slot[2];
   // results of the last run
-  std::vector<uint64_t> res_offsets;
-  PinnedBuf<uint32_t> res_ij;   // match lists of the last run, pinned: the D2H copies are plain DMA, nothing is zero-filled
-  size_t res_ij_n = 0;
+  // results of the last two runs (alternating): a caller may consume run k on another thread while run k + 1 executes
+  struct Results {
+    std::vector<uint64_t> offsets;
+    PinnedBuf<uint32_t> ij;   // pinned: the D2H copies are plain DMA, nothing is zero-filled
+    size_t ij_n = 0;
+  } results[2];
+  int cur = 0;
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -1107,7 +1119,7 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   c->d_rows_slot.release(); c->d_cinit.release(); c->d_rownorm.release(); c->d_ntiles.release(); c->d_perm.release(); c->d_rowpos.release();
   c->d_neven.release(); c->d_err.release();
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
-  c->res_ij.release();
+  for (auto& r : c->results) r.ij.release();
   for (auto& sl : c->slot) {
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
@@ -1141,6 +1153,11 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->keep_host_results = value != 0;
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
+  } else if (!strcmp(key, "pinned_results")) {
+    for (auto& r : c->results) {
+      MVGX_REQUIRE(r.ij.p == nullptr || r.ij.pageable == (value == 0), MVGX_ERR_STATE, "pinned_results must be set before the first run");
+      r.ij.pageable = value == 0;
+    }
   } else {
     set_error("unknown option '%s'", key);
     return MVGX_ERR_ARG;
@@ -1199,8 +1216,10 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     MVGX_REQUIRE(pairs_IJ[2 * k] < c->n_images && pairs_IJ[2 * k + 1] < c->n_images, MVGX_ERR_ARG,
                  "pair %llu references image out of range", (unsigned long long)k);
 
-  c->res_offsets.assign(n_pairs + 1, 0);
-  c->res_ij_n = 0;
+  c->cur ^= 1;
+  mvgx_match_ctx::Results& res = c->results[c->cur];
+  res.offsets.assign(n_pairs + 1, 0);
+  res.ij_n = 0;
   mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
   st.variant = (uint32_t)c->variant;
@@ -1306,8 +1325,8 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     const uint32_t nb = sl.nb;
     const uint64_t p0 = sl.p0;
     const uint32_t total = sl.hp_offsets.p[nb];
-    const uint64_t base = c->res_offsets[p0];
-    for (uint32_t k = 0; k <= nb; ++k) c->res_offsets[p0 + k] = base + sl.hp_offsets.p[k];
+    const uint64_t base = res.offsets[p0];
+    for (uint32_t k = 0; k <= nb; ++k) res.offsets[p0 + k] = base + sl.hp_offsets.p[k];
     st.n_matches += total;
     if (total) {
       if ((rc = sl.d_ij.ensure(total))) return rc;
@@ -1316,12 +1335,12 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
                          sl.d_ij.p);
       MVGX_HIP(hipGetLastError());
       if (c->keep_host_results) {
-        const size_t old = c->res_ij_n;
-        if (old + (size_t)total * 2 > c->res_ij.cap)   // growth moves the lists: no copy into them may be in flight
+        const size_t old = res.ij_n;
+        if (old + (size_t)total * 2 > res.ij.cap)   // growth moves the lists: no copy into them may be in flight
           for (auto& o : c->slot) MVGX_HIP(hipStreamSynchronize(o.stream));
-        if ((rc = c->res_ij.grow_keep(old + (size_t)total * 2, old))) return rc;
-        c->res_ij_n = old + (size_t)total * 2;
-        MVGX_HIP(hipMemcpyAsync(c->res_ij.p + old, sl.d_ij.p, (size_t)total * sizeof(uint2),
+        if ((rc = res.ij.grow_keep(old + (size_t)total * 2, old))) return rc;
+        res.ij_n = old + (size_t)total * 2;
+        MVGX_HIP(hipMemcpyAsync(res.ij.p + old, sl.d_ij.p, (size_t)total * sizeof(uint2),
                                 hipMemcpyDeviceToHost, sl.stream));   // completes before the run returns
       }
     }
@@ -1371,8 +1390,8 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
 
 int mvgx_match_results(mvgx_match_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
   MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_match_results: NULL argument");
-  *offsets = c->res_offsets.data();
-  *ij = c->res_ij.p;
+  *offsets = c->results[c->cur].offsets.data();
+  *ij = c->results[c->cur].ij.p;
   return MVGX_OK;
 }
 
@@ -1386,8 +1405,8 @@ int mvgx_match_pairs_u8_l2(const uint8_t* const* desc_rows, const uint32_t* n_de
   if (!rc) rc = mvgx_match_run(c, pairs_IJ, n_pairs, ratio_sq, nullptr);
   if (!rc && sink) {
     for (uint64_t k = 0; k < n_pairs; ++k) {
-      const uint64_t a = c->res_offsets[k], b = c->res_offsets[k + 1];
-      if (b > a) sink(user, pairs_IJ[2 * k], pairs_IJ[2 * k + 1], c->res_ij.p + 2 * a, (uint32_t)(b - a));
+      const uint64_t a = c->results[c->cur].offsets[k], b = c->results[c->cur].offsets[k + 1];
+      if (b > a) sink(user, pairs_IJ[2 * k], pairs_IJ[2 * k + 1], c->results[c->cur].ij.p + 2 * a, (uint32_t)(b - a));
     }
   }
   mvgx_match_destroy(c);

@@ -8,6 +8,7 @@
 //   openMVG::matching_image_collection::Matcher_Regions              matching_image_collection/Matcher_Regions.cpp:22-107
 // fed through an in-memory sfm::Regions_Provider (sfm/pipelines/sfm_regions_provider.hpp:30-144, cache_ is protected).
 // Used to (a) validate oracle/match_oracle.c, (b) serve as the "reference" CPU baseline in bench.py.
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -191,6 +192,30 @@ uint64_t ref_matcher_regions_match_float64(const float* const* desc_rows, const 
     if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
   }
   return out.size();
+}
+
+// Wall time of Matcher_Regions::Match itself (exhaustive pairs over n_images SIFT_Regions), container included, without the
+// per-pair callback: the end-to-end figure a caller of main_ComputeMatches sees. out[0] = seconds, out[1] = matches,
+// out[2] = pairs with matches.
+int ref_matcher_regions_match_u8_timed(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                       float dist_ratio, double* out) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::SIFT_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) provider->set(k, make_sift_regions(desc_rows[k], n_desc[k]));
+  Pair_Set pairs;
+  for (uint32_t i = 0; i < n_images; ++i)
+    for (uint32_t j = i + 1; j < n_images; ++j) pairs.insert({i, j});
+  matching::PairWiseMatches res;
+  matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  const auto t0 = std::chrono::steady_clock::now();
+  matcher.Match(base, pairs, res, nullptr);
+  out[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  uint64_t n = 0;
+  for (const auto& kv : res) n += kv.second.size();
+  out[1] = double(n);
+  out[2] = double(res.size());
+  return 0;
 }
 
 }  // extern "C"
