@@ -222,3 +222,38 @@ def test_error_behaviour():
         ctx.close()
     with pytest.raises(NotImplementedError):
         matching.Matcher_Regions(0.8, matching.EMatcherType.ANN_L2).Match(matching.Regions_Provider(), [(0, 1)], {})
+
+
+@pytest.mark.parametrize("pinned", [1, 0])
+def test_results_of_a_run_survive_the_next_run(pinned):
+    """include/mvgx.h: the context alternates between two result buffers, so the lists of run k stay valid while run k + 1
+    executes (the adapter fills the match container from them on another thread); both pinned and plain result memory"""
+    import ctypes as C
+    from openmvg_amd import _capi
+    imgs = synth.image_descriptors(5, n_desc=400, seed=77)
+    pa = matching.exhaustive_pairs_array(5)
+    pb = np.ascontiguousarray(pa[::-1, ::-1])
+    ctx = matching.MatchContext(0)
+    try:
+        ctx.set_option("pinned_results", pinned)
+        ctx.set_regions(imgs)
+        L = _capi.lib()
+
+        def run(pairs):
+            st = _capi.MatchStats()
+            _capi.check(L.mvgx_match_run(ctx._h, pairs.ctypes.data, len(pairs), np.float32(0.64), C.byref(st)))
+            po, pij = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+            _capi.check(L.mvgx_match_results(ctx._h, C.byref(po), C.byref(pij)))
+            off = np.ctypeslib.as_array(po, shape=(len(pairs) + 1,))
+            return off, np.ctypeslib.as_array(pij, shape=(int(off[-1]), 2))   # views, not copies
+
+        off_a, ij_a = run(pa)
+        keep_off, keep_ij = off_a.copy(), ij_a.copy()
+        off_b, ij_b = run(pb)
+        assert np.array_equal(off_a, keep_off) and np.array_equal(ij_a, keep_ij)      # run k still readable after run k + 1
+        o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pa, 0.8)
+        assert np.array_equal(keep_off, o_off) and np.array_equal(keep_ij, o_ij)
+        o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pb, 0.8)
+        assert np.array_equal(off_b, o_off) and np.array_equal(ij_b, o_ij)
+    finally:
+        ctx.close()
