@@ -53,11 +53,10 @@ def build_oracle(ref=True, verbose=False):
 
 
 def build_adapter(verbose=False):
-    """openMVG-side adapters (openmvg_amd/adapter/*.cpp: link-time replacements of Matcher_Regions.cpp and
-    sfm_data_BA_ceres.cpp) compiled against the openMVG tree when it is present; needs libmvgx_hip.so and the openMVG
-    objects oracle/Makefile builds. Output: openmvg_amd/lib/libmvgx_openmvg_adapter{,_ba}.so (travel to the GPU box)."""
+    """openMVG-side adapter TUs (openmvg_amd/adapter/*.cpp: link-time replacements of Matcher_Regions.cpp and
+    sfm_data_BA_ceres.cpp) compiled against the openMVG tree when it is present -> openmvg_amd/lib/adapter_obj/*.o."""
     if not os.path.isdir("/root/reference/src"):
         return None
     out = None if verbose else subprocess.DEVNULL
     subprocess.run(["make", "-C", os.path.join(_HERE, "adapter")], check=True, stdout=out)
-    return os.path.join(LIBDIR, "libmvgx_openmvg_adapter.so")
+    return os.path.join(LIBDIR, "adapter_obj")

@@ -53,7 +53,7 @@ def have_ref_match():
 
 def _bind_match_shim(L):
     """Prototypes of oracle/ref_shim_match.cpp (the same caller code is linked into oracle/_ref/libref_match.so and,
-    against the MI355X replacements, into openmvg_amd/lib/libmvgx_openmvg_adapter.so)."""
+    against the MI355X replacements, into tests/native/_build/libmvgx_openmvg_adapter.so)."""
     L.ref_matcher_regions_match_u8.restype = C.c_uint64
     L.ref_matcher_regions_match_u8.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
                                                C.c_uint64, C.c_float, SINK, C.c_void_p]
@@ -495,9 +495,20 @@ def ref_save_baf(scene, path):
 # ---------------------------------------------------------------------------------------------------------
 # the openMVG-side adapter build (product code + the same caller shims as oracle/_ref)
 # ---------------------------------------------------------------------------------------------------------
-ADAPTER_SO = os.path.join(ROOT, "openmvg_amd", "lib", "libmvgx_openmvg_adapter.so")
-ADAPTER_BA_SO = os.path.join(ROOT, "openmvg_amd", "lib", "libmvgx_openmvg_adapter_ba.so")
+ADAPTER_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter.so")
+ADAPTER_BA_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_ba.so")
 _adapter = None
+
+
+def build_adapter_harness(verbose=False):
+    """tests/native/adapter_harness.mk: the product's adapter objects + the reference's caller shims (needs the openMVG tree
+    and the objects of oracle/Makefile; a no-op elsewhere - the GPU box uses the prebuilt libraries)."""
+    import subprocess
+    if not os.path.isdir("/root/reference/src"):
+        return None
+    subprocess.run(["make", "-f", os.path.join(ROOT, "tests", "native", "adapter_harness.mk")], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+    return ADAPTER_SO
 
 
 def have_adapter():

@@ -1,0 +1,51 @@
+# tests/native/adapter_harness.mk — TEST INFRASTRUCTURE ONLY.
+# Links the product's adapter objects (openmvg_amd/adapter/Makefile -> openmvg_amd/lib/adapter_obj/*.o) with the UNCHANGED
+# caller-side shims of oracle/ (ref_shim_{match,ba}.cpp: the same code that drives the reference in oracle/_ref), the
+# openMVG objects those callers and adapters still need (taken from oracle/_ref/obj, built by oracle/Makefile from the sources
+# under $(REF)) and libmvgx_hip.so. The parity tests then call identical entry points in oracle/_ref/libref_*.so (reference
+# TUs) and in tests/native/_build/libmvgx_openmvg_adapter{,_ba}.so (replacement TUs).
+# Two libraries, because the two halves are compiled with different Eigen ABIs (AVX2 for the matching objects, none for the
+# sfm / geometry objects) and must not share inline Eigen allocation code.
+REF ?= /root/reference/src
+HERE := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+ROOT := $(abspath $(HERE)/../..)
+OUT := $(ROOT)/tests/native/_build
+LIBDIR := $(ROOT)/openmvg_amd/lib
+AOBJ := $(LIBDIR)/adapter_obj
+REFOBJ := $(ROOT)/oracle/_ref/obj
+CXX ?= g++
+INC := -I$(ROOT)/include -I$(REF) -I$(REF)/third_party/eigen -I$(REF)/third_party \
+       -I$(REF)/third_party/flann/src/cpp -I$(REF)/third_party/hnswlib -I$(REF)/dependencies/cereal/include \
+       -I$(ROOT)/oracle/ceres_config -I$(REF)/third_party/ceres-solver/include \
+       -I$(REF)/third_party/ceres-solver/internal/ceres/miniglog
+BASEFLAGS := -std=c++11 -O3 -fPIC -fopenmp -DOPENMVG_USE_OPENMP -DEIGEN_MPL2_ONLY -w $(INC)
+REF_MATCH_OBJS := $(REFOBJ)/openMVG/matching/regions_matcher.o $(REFOBJ)/openMVG/features/feature.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/file_system.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/portability_fixes.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/wildcard.o
+REF_BA_OBJS := $(REFOBJ)/ba/openMVG/numeric/numeric.o $(REFOBJ)/ba/openMVG/sfm/sfm_data_transform.o \
+            $(REFOBJ)/ba/openMVG/geometry/Similarity3.o $(REFOBJ)/ba/openMVG/geometry/Similarity3_Kernel.o \
+            $(REFOBJ)/ba/openMVG/geometry/rigid_transformation3D_srt.o \
+            $(REFOBJ)/ba/openMVG/sfm/sfm_data_filters.o $(REFOBJ)/ba/openMVG/multiview/projection.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/file_system.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/portability_fixes.o \
+            $(REFOBJ)/third_party/stlplus3/filesystemSimplified/wildcard.o
+RPATH := -Wl,-rpath,'$$ORIGIN/../../../openmvg_amd/lib'
+
+all: $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so
+
+$(OUT)/ref_shim_match.o: $(ROOT)/oracle/ref_shim_match.cpp
+	@mkdir -p $(OUT)
+	$(CXX) $(BASEFLAGS) -DOPENMVG_USE_AVX2 -DOPENMVG_USE_AVX -mavx2 -c $< -o $@
+$(OUT)/ref_shim_ba.o: $(ROOT)/oracle/ref_shim_ba.cpp
+	@mkdir -p $(OUT)
+	$(CXX) $(BASEFLAGS) -c $< -o $@
+
+$(OUT)/libmvgx_openmvg_adapter.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
+
+$(OUT)/libmvgx_openmvg_adapter_ba.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
+
+clean:
+	rm -f $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so $(OUT)/ref_shim_match.o $(OUT)/ref_shim_ba.o

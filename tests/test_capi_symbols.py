@@ -49,7 +49,7 @@ def test_every_built_shared_library_resolves_all_its_symbols():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libs = glob.glob(os.path.join(root, "openmvg_amd", "lib", "*.so")) + glob.glob(os.path.join(root, "oracle", "_ref", "*.so")) + \
-        glob.glob(os.path.join(root, "oracle", "_build", "*.so"))
+        glob.glob(os.path.join(root, "oracle", "_build", "*.so")) + glob.glob(os.path.join(root, "tests", "native", "_build", "libmvgx_openmvg_adapter*.so"))
     assert any(p.endswith("libmvgx_hip.so") for p in libs)
     for p in sorted(libs):
         ctypes.CDLL(p, mode=os.RTLD_NOW)
