@@ -89,6 +89,19 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0, name=None):
     s = ctx.solve()
     wall = time.perf_counter() - t0
     ctx.close()
+    # one more solve with HIP events around the phases of every iteration (kept out of the timed solve above)
+    phases = None
+    try:
+        os.environ["MVGX_BA_PHASE_TIMING"] = "1"
+        ctx = make()
+        sp = ctx.solve()
+        ctx.close()
+        it = max(sp.num_iterations, 1)
+        phases = {"jacobian_ms": sp.jacobian_ms / (sp.num_successful_steps + 1), "schur_ms": sp.schur_ms / it, "solve_ms": sp.solve_ms / it,
+                  "backsub_ms": sp.backsub_ms / it, "cost_ms": sp.cost_ms / it,
+                  "note": "device time per LM iteration (jacobian: per Jacobian evaluation); the rest of an iteration is host round trips"}
+    finally:
+        os.environ.pop("MVGX_BA_PHASE_TIMING", None)
     scene = full
     n_cols = 6 * scene["n_poses"] + 8 * scene["n_intrinsics"]
     bytes_it = algorithmic_bytes_per_iteration(scene["n_obs"], scene["n_points"], scene["n_poses"], n_cols)
@@ -100,6 +113,10 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0, name=None):
         "first_call_ms_iteration_zero_plus_one_iteration": s1.total_ms,
         "iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "termination": s.termination,
         "solve_ms": s.total_ms, "solve_wall_ms": wall * 1e3, "create_s_host_structure_plus_upload": create_s,
+        "phases": phases,
+        "reduced_solve": (None if not phases or not phases["solve_ms"] else
+                          {"n": n_cols, "flop": n_cols ** 3 / 3.0, "ms": phases["solve_ms"],
+                           "achieved_tflops": n_cols ** 3 / 3.0 / (phases["solve_ms"] * 1e-3) / 1e12, "peak_tflops_fp64_mfma": 78.6}),
         "initial_rmse": s.initial_rmse, "final_rmse": s.final_rmse, "final_cost": s.final_cost,
         "roofline": {"bound": "hbm", "achieved": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

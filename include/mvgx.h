@@ -217,7 +217,8 @@ typedef struct mvgx_ba_summary {
   double initial_rmse, final_rmse;      /* sqrt(sum |x - proj|^2 / (2 n_obs)), sfm_data_BA_test.cpp:310-330 */
   double total_ms;                /* device wall time of the solve (HIP events)                     */
   double iter_ms_mean;            /* mean time of one LM iteration                                  */
-  double jacobian_ms, schur_ms, solve_ms, backsub_ms, cost_ms; /* per-phase sums (profile)         */
+  double jacobian_ms, schur_ms, solve_ms, backsub_ms, cost_ms; /* per-phase device time summed over the context's life
+                                   * when MVGX_BA_PHASE_TIMING=1 was set at create (HIP events), else 0            */
 } mvgx_ba_summary;
 
 void mvgx_ba_default_options(mvgx_ba_options* opt);

@@ -1302,6 +1302,14 @@ struct mvgx_ba_ctx {
   int grid_obs = 0, grid_vec = 0;
   int update128_min_tiles = 128;   // tuning (MVGX_BA_UPDATE128_MIN_TILES): deferred updates with at least this many 128 x 128 tiles use them
   int two_level_min_n = 2048;   // tuning (MVGX_BA_TWO_LEVEL_MIN_N): reduced systems at least this wide factor with 256-column outer panels
+  // phase timing (MVGX_BA_PHASE_TIMING=1 at create): HIP events around the five phases of an iteration, summed into phase_ms
+  bool phase_timing = false;
+  struct Mark { int id; hipEvent_t a, b; };
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<Mark> marks;
+  hipEvent_t ph_a = nullptr;
+  double phase_ms[5] = {0, 0, 0, 0, 0};   // jacobian, schur, solve, backsub, cost
 };
 
 namespace {
@@ -1316,6 +1324,33 @@ int read_scalars(mvgx_ba_ctx* c) {
 }
 
 bool multi_rank(const mvgx_ba_ctx* c) { return c->rccl != nullptr || c->allreduce != nullptr; }
+
+enum { kPhJacobian = 0, kPhSchur, kPhSolve, kPhBacksub, kPhCost };
+hipEvent_t phase_event(mvgx_ba_ctx* c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(e);
+  }
+  hipEvent_t e = c->ev_pool[c->ev_used++];
+  (void)hipEventRecord(e, c->stream);
+  return e;
+}
+void phase_begin(mvgx_ba_ctx* c) { if (c->phase_timing) c->ph_a = phase_event(c); }
+void phase_end(mvgx_ba_ctx* c, int id) {
+  if (!c->phase_timing || !c->ph_a) return;
+  hipEvent_t b = phase_event(c);
+  if (b) c->marks.push_back({id, c->ph_a, b});
+  c->ph_a = nullptr;
+}
+void phase_collect(mvgx_ba_ctx* c) {   // after a stream synchronisation
+  for (const auto& m : c->marks) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) c->phase_ms[m.id] += ms;
+  }
+  c->marks.clear();
+  c->ev_used = 0;
+}
 
 int all_reduce(mvgx_ba_ctx* c, double* buf, uint64_t count, int op = MVGX_REDUCE_SUM) {
   if (c->rccl) return mvgx::rccl_allreduce_f64(c->rccl, buf, count, op, c->stream);
@@ -1342,6 +1377,7 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
 // TrustRegionMinimizer::EvaluateGradientAndJacobian: J, cost, Gram blocks / column norms, gradient (+ scaling at iteration 0)
 int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, bool iteration_zero) {
   Dev& d = c->d;
+  phase_begin(c);
   int rc = eval<true>(c, d.poses, d.intr, d.pts);
   if (rc) return rc;
   if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
@@ -1362,6 +1398,7 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_vec, 1, 1, d.scalars, kSGmax, 1);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.scalars + kSGmax, 1, MVGX_REDUCE_MAX))) return rc;   // point gradients are rank-local
+  phase_end(c, kPhJacobian);
   if ((rc = read_scalars(c))) return rc;
   c->x_cost = c->h_scalars[kSCost];
   c->gradient_max_norm = c->h_scalars[kSGmax];
@@ -1498,12 +1535,17 @@ int exchange_system(mvgx_ba_ctx* c) {
 int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   Dev& d = c->d;
   const double inv_radius = 1.0 / c->radius;
+  phase_begin(c);
   int rc = assemble_system(c, inv_radius);
   if (rc) return rc;
   if ((rc = exchange_system(c))) return rc;
   if (d.N) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
   BA_LAUNCH_CHECK();
+  phase_end(c, kPhSchur);
+  phase_begin(c);
   if ((rc = factor_and_solve(c))) return rc;
+  phase_end(c, kPhSolve);
+  phase_begin(c);
   hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);
   if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
@@ -1516,6 +1558,7 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     BA_LAUNCH_CHECK();
     if ((rc = all_reduce(c, d.scalars + kSFail, 1, MVGX_REDUCE_MAX))) return rc;
   }
+  phase_end(c, kPhBacksub);
   if ((rc = read_scalars(c))) return rc;
   *model_cost_change = c->h_scalars[kSModel];
   const bool failed = multi_rank(c) ? (c->h_scalars[kSFail] != 0.0) : (*c->h_fail != 0);
@@ -1525,6 +1568,7 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
 
 int make_candidate_and_cost(mvgx_ba_ctx* c, double* step_norm, double* x_norm, double* cand_cost) {
   Dev& d = c->d;
+  phase_begin(c);
   MVGX_HIP(hipMemcpyAsync(d.cposes, d.poses, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(d.cintr, d.intr, (size_t)d.n_intr * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
@@ -1533,6 +1577,7 @@ int make_candidate_and_cost(mvgx_ba_ctx* c, double* step_norm, double* x_norm, d
   int rc = all_reduce(c, d.scalars + kSStepSq, 2);   // point parts
   if (rc) return rc;
   if ((rc = eval<false>(c, d.cposes, d.cintr, d.cpts))) return rc;
+  phase_end(c, kPhCost);
   if ((rc = read_scalars(c))) return rc;
   *step_norm = std::sqrt(c->h_scalars[kSCamStepSq] + c->h_scalars[kSStepSq]);
   *x_norm = std::sqrt(c->h_scalars[kSCamXSq] + c->h_scalars[kSXSq]);
@@ -1635,6 +1680,9 @@ int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
   s->final_cost = c->x_cost;
   s->initial_rmse = c->initial_rmse;
   s->final_rmse = rmse_from(c);
+  phase_collect(c);   // read_scalars above synchronised the stream
+  s->jacobian_ms = c->phase_ms[kPhJacobian]; s->schur_ms = c->phase_ms[kPhSchur]; s->solve_ms = c->phase_ms[kPhSolve];
+  s->backsub_ms = c->phase_ms[kPhBacksub]; s->cost_ms = c->phase_ms[kPhCost];
   return MVGX_OK;
 }
 
@@ -1690,6 +1738,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.N = 6 * (int)d.n_poses + 8 * (int)d.n_intr; d.LD = d.N + 1;
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
+  c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
@@ -1967,6 +2016,7 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   mvgx::rccl_destroy(c->rccl);
   delete c;
