@@ -67,6 +67,7 @@ int mvgx_match_destroy(mvgx_match_ctx* ctx);
 /* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch),
  * "batch_pairs" (pairs per device batch), "keep_host_results" (0: skip D2H of the match lists),
  * "overlap" (default 1: two batch slots, batch b filters while batch b-1 is verified/compacted/copied; 0: one at a time),
+ * "double_buffer_results" (default 0, see mvgx_match_run),
  * "pinned_results" (default 1: the host match lists live in pinned memory - fastest when a context is run many times;
  * 0: plain memory, for one-shot use where pinning a gigabyte costs more than the staged copies; set before the first run). */
 int mvgx_match_set_option(mvgx_match_ctx* ctx, const char* key, int64_t value);
@@ -88,8 +89,9 @@ int mvgx_match_set_regions_device(mvgx_match_ctx* ctx, const void* d_desc_concat
  * (regions_matcher.hpp:196, numeric.h:56). ratio_sq > 1 -> MVGX_ERR_UNSUPPORTED (tie order would be
  * libstdc++-specific, stl/indexed_sort.hpp:48-63). Pairs whose I has < 2 descriptors or whose J is
  * empty produce no matches (matcher_brute_force.hpp:108-113, Matcher_Regions.cpp:65-69,85-90).
- * Results stay valid until the run AFTER the next one (or destroy): the context alternates between two result buffers, so a
- * caller may consume run k on another thread while run k + 1 executes (the adapter fills the match container that way). */
+ * Results stay valid until the next run/destroy; with the option "double_buffer_results" = 1 until the run AFTER the next
+ * one: the context then alternates between two result buffers, so a caller may consume run k on another thread while
+ * run k + 1 executes (the adapter fills the match container that way). */
 int mvgx_match_run(mvgx_match_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
                    mvgx_match_stats* stats /* may be NULL */);
 

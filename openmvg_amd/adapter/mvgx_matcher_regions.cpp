@@ -234,6 +234,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     if (l2) {
       const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the lists rarely pays
       mvgx_match_set_option(l2, "pinned_results", env ? std::atoi(env) : 0);
+      mvgx_match_set_option(l2, "double_buffer_results", 1);   // run k + 1 overlaps the delivery of run k
     }
     auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (l2) mvgx_match_destroy(l2); };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());

@@ -972,13 +972,15 @@ struct mvgx_match_ctx {
     uint32_t nb = 0;
   } slot[2];
   // results of the last run
-  // results of the last two runs (alternating): a caller may consume run k on another thread while run k + 1 executes
+  // results of the last run - or, with "double_buffer_results", of the last two runs (alternating): a caller may then
+  // consume run k on another thread while run k + 1 executes
   struct Results {
     std::vector<uint64_t> offsets;
     PinnedBuf<uint32_t> ij;   // pinned: the D2H copies are plain DMA, nothing is zero-filled
     size_t ij_n = 0;
   } results[2];
   int cur = 0;
+  int double_buffer = 0;
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -1153,6 +1155,8 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->keep_host_results = value != 0;
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
+  } else if (!strcmp(key, "double_buffer_results")) {
+    c->double_buffer = value != 0;
   } else if (!strcmp(key, "pinned_results")) {
     for (auto& r : c->results) {
       MVGX_REQUIRE(r.ij.p == nullptr || r.ij.pageable == (value == 0), MVGX_ERR_STATE, "pinned_results must be set before the first run");
@@ -1216,7 +1220,7 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     MVGX_REQUIRE(pairs_IJ[2 * k] < c->n_images && pairs_IJ[2 * k + 1] < c->n_images, MVGX_ERR_ARG,
                  "pair %llu references image out of range", (unsigned long long)k);
 
-  c->cur ^= 1;
+  if (c->double_buffer) c->cur ^= 1;
   mvgx_match_ctx::Results& res = c->results[c->cur];
   res.offsets.assign(n_pairs + 1, 0);
   res.ij_n = 0;

@@ -226,7 +226,7 @@ def test_error_behaviour():
 
 @pytest.mark.parametrize("pinned", [1, 0])
 def test_results_of_a_run_survive_the_next_run(pinned):
-    """include/mvgx.h: the context alternates between two result buffers, so the lists of run k stay valid while run k + 1
+    """include/mvgx.h, "double_buffer_results": the context alternates between two result buffers, so the lists of run k stay valid while run k + 1
     executes (the adapter fills the match container from them on another thread); both pinned and plain result memory"""
     import ctypes as C
     from openmvg_amd import _capi
@@ -236,6 +236,7 @@ def test_results_of_a_run_survive_the_next_run(pinned):
     ctx = matching.MatchContext(0)
     try:
         ctx.set_option("pinned_results", pinned)
+        ctx.set_option("double_buffer_results", 1)
         ctx.set_regions(imgs)
         L = _capi.lib()
 
