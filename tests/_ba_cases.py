@@ -63,3 +63,16 @@ def filter_scene(model, seed=5, n_cams=24, n_points=600, track_len=3):
     sc["obs_xy"] = np.ascontiguousarray(sc["obs_xy"][keep][perm])
     sc["n_obs"] = len(perm)
     return sc
+
+
+def rejector_loop(adjust, rejector, scene, dPrecision=4.0, count=0, max_rounds=5):
+    """The pipeline loop `do { BA } while (badTrackRejector(dPrecision, count))` (sequential_SfM.cpp:206-210) over the flat
+    scene: adjust(scene) -> scene', rejector(scene', dPrecision, count) -> (again, scene''). Returns the final scene and the
+    number of bundle adjustments run."""
+    rounds = 0
+    while True:
+        scene = adjust(scene)
+        rounds += 1
+        again, scene = rejector(scene, dPrecision, count)
+        if not again or rounds >= max_rounds:
+            return scene, rounds

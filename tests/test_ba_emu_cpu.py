@@ -273,3 +273,36 @@ def test_track_filters_follow_the_reference(model):
     elif _oracle.have_ref_ba():
         keep, counts, _ = _oracle.ref_ba_filters(sc, 4.0, 2, 2.0)
         assert again == (sum(counts) > 50) and np.array_equal(f_both["obs_xy"], sc["obs_xy"][keep])
+
+
+@pytest.mark.skipif(not _oracle.have_ref_ba(), reason="oracle/_ref/libref_ba.so not built")
+def test_bundle_then_reject_loop_equals_the_reference_pipeline():
+    """`do { BA } while (badTrackRejector(4.0, 0))` (sequential_SfM.cpp:206-210,1226-1232), emulated device code against the
+    reference's Bundle_Adjustment_Ceres + sfm_data_filters.cpp driven by the same loop"""
+    from tests import _ba_cases
+    sc0 = synth.ba_scene(n_cams=10, n_points=160, track_len=4, model=3, n_intr_groups=2, seed=91, outlier_frac=0.05, n_rings=1)
+
+    def ours_adjust(sc):
+        sc = dict(sc)
+        assert ba.Bundle_Adjustment_HIP().Adjust(sc)
+        return sc
+
+    def ref_adjust(sc):
+        rc, st, poses, intr, pts = _oracle.ref_ba_adjust(sc)
+        assert rc == 0
+        out = dict(sc); out["poses"] = poses; out["intrinsics"] = intr; out["points"] = pts
+        return out
+
+    def ref_rejector(sc, prec, count):
+        keep, counts, _ = _oracle.ref_ba_filters(sc, prec, 2, 2.0)
+        return sum(counts) > count, ba._drop_observations(sc, keep)
+
+    with _emu.emulated():
+        ours, n_ours = _ba_cases.rejector_loop(ours_adjust, ba.badTrackRejector, sc0)
+        ref, n_ref = _ba_cases.rejector_loop(ref_adjust, ref_rejector, sc0)
+        assert n_ours == n_ref >= 2
+        assert ours["n_obs"] == ref["n_obs"] < sc0["n_obs"]
+        assert np.array_equal(ours["obs_xy"], ref["obs_xy"])
+        c1 = ba.BaContext(ours); r1 = c1.evaluate()[1]; c1.close()
+        c2 = ba.BaContext(ref); r2 = c2.evaluate()[1]; c2.close()
+    assert abs(r1 - r2) < 1e-6
