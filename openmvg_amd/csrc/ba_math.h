@@ -201,6 +201,7 @@ MVGX_HD void eval_observation(int model, const double* intr, const double* pose,
 //   fisheye: 10 fixed-point rounds on theta, then tan (Camera_Pinhole_Fisheye.hpp:112-136)
 // Bearing: Kinv (x, y, 1) normalised (Camera_Pinhole.hpp:136-139); spherical lon/lat (Camera_Spherical.hpp:115-132).
 constexpr int kBrownMaxIter = 10000;
+constexpr int kBisectMaxIter = 40000;   // bracket search (ratio 1.05: < 30 000 rounds across the double range) + bisection together
 
 MVGX_HD double radial_disto_r2(int model, const double* intr, double r2) {
   const double k1 = intr[3];
@@ -227,10 +228,13 @@ MVGX_HD void observation_ray(int model, const double* intr, const double* pose, 
       const double r2 = px * px + py * py;
       double radius = 1.0;
       if (r2 != 0.0) {
+        // the reference's loops are unbounded; they end within a few hundred rounds for every finite input whose interval
+        // can shrink below 1e-10 in double precision - a device thread must not spin on garbage (|x| ~ 1e300), hence the cap
         double lo = r2, up = r2;
-        while (radial_disto_r2(model, intr, lo) > r2) lo /= 1.05;
-        while (radial_disto_r2(model, intr, up) < r2) up *= 1.05;
-        while (1e-10 < up - lo) {
+        int guard = 0;
+        while (radial_disto_r2(model, intr, lo) > r2 && guard++ < kBisectMaxIter) lo /= 1.05;
+        while (radial_disto_r2(model, intr, up) < r2 && guard++ < kBisectMaxIter) up *= 1.05;
+        while (1e-10 < up - lo && guard++ < kBisectMaxIter) {
           const double mid = .5 * (lo + up);
           if (radial_disto_r2(model, intr, mid) > r2) up = mid; else lo = mid;
         }
