@@ -1184,10 +1184,9 @@ struct TripHost {
 // Host threads for the structure build (the analogue of Ceres' preprocessor). f(index, thread) is called for every index
 // in [0, n), indices handed out dynamically; results must not depend on which thread ran an index.
 inline unsigned host_threads(size_t work_items) {
+  if (const char* env = getenv("MVGX_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(env)));   // as told
   if (work_items < 2048) return 1;
-  unsigned t = std::thread::hardware_concurrency();
-  if (const char* env = getenv("MVGX_HOST_THREADS")) t = (unsigned)std::max(1, atoi(env));
-  return std::max(1u, std::min(t, 32u));
+  return std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
 }
 template <class F>
 void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
@@ -1205,6 +1204,35 @@ void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
   for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body, t);
   body(0);
   for (auto& th : pool) th.join();
+}
+
+// Stable counting sort of the indices 0..n-1 by key(i) in [0, n_keys): start[n_keys + 1] and order[n] (ascending index inside a
+// key), with per-thread histograms over contiguous index ranges; the result does not depend on the thread count.
+template <class Key>
+void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key key, std::vector<uint32_t>& start, std::vector<uint32_t>& order) {
+  start.assign((size_t)n_keys + 1, 0);
+  order.resize(n);
+  if (threads <= 1 || n < 4096 || (uint64_t)threads * n_keys > (1u << 24)) {
+    for (uint64_t i = 0; i < n; ++i) start[key(i) + 1]++;
+    for (uint32_t k = 0; k < n_keys; ++k) start[k + 1] += start[k];
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (uint64_t i = 0; i < n; ++i) order[fill[key(i)]++] = (uint32_t)i;
+    return;
+  }
+  const uint64_t per = (n + threads - 1) / threads;
+  std::vector<std::vector<uint32_t>> hist(threads, std::vector<uint32_t>(n_keys, 0));
+  parallel_for_dynamic(threads, 1, threads, [&](size_t t, unsigned) {
+    for (uint64_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) hist[t][key(i)]++;
+  });
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < n_keys; ++k) {
+    start[k] = run;
+    for (unsigned t = 0; t < threads; ++t) { const uint32_t c_ = hist[t][k]; hist[t][k] = run; run += c_; }
+  }
+  start[n_keys] = run;
+  parallel_for_dynamic(threads, 1, threads, [&](size_t t, unsigned) {
+    for (uint64_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) order[hist[t][key(i)]++] = (uint32_t)i;
+  });
 }
 
 // Product list of one family, generated row by row (row = camera block of the first factor). gen(r, emit) must call
@@ -1827,11 +1855,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.n_islots = (int)slot_intr.size();
   // observations by pose (ascending observation index inside a pose): the rows of the product lists; then, inside a pose,
   // stably by intrinsic: the (pose, intrinsic) pairs of the Gram kernels, cut into chunks of kPiChunk observations
-  std::vector<uint32_t> prow_start(d.n_poses + 1, 0), pose_obs(no);
-  for (uint64_t k = 0; k < no; ++k) prow_start[opose[k] + 1]++;
-  for (uint32_t i = 0; i < d.n_poses; ++i) prow_start[i + 1] += prow_start[i];
-  { std::vector<uint32_t> fill(prow_start.begin(), prow_start.end() - 1);
-    for (uint64_t k = 0; k < no; ++k) pose_obs[fill[opose[k]]++] = (uint32_t)k; }
+  std::vector<uint32_t> prow_start, pose_obs;
+  counting_sort_indices(no, d.n_poses, T, [&](uint64_t k) { return opose[k]; }, prow_start, pose_obs);
   std::vector<uint32_t> pi_obs(pose_obs);
   parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
     auto b_ = pi_obs.begin() + prow_start[i], e_ = pi_obs.begin() + prow_start[i + 1];
@@ -1856,11 +1881,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   pi_chunk0.push_back((uint32_t)pichunk_lo.size());
   d.n_pichunks = (int)pichunk_lo.size();
   // observations by intrinsic, cut into chunks
-  std::vector<uint32_t> iobs_start(d.n_intr + 1, 0), iobs(no), igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
-  for (uint64_t k = 0; k < no; ++k) iobs_start[ointr[k] + 1]++;
-  for (uint32_t i = 0; i < d.n_intr; ++i) iobs_start[i + 1] += iobs_start[i];
-  { std::vector<uint32_t> fill(iobs_start.begin(), iobs_start.end() - 1);
-    for (uint64_t k = 0; k < no; ++k) iobs[fill[ointr[k]]++] = (uint32_t)k; }
+  std::vector<uint32_t> iobs_start, iobs, igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
+  counting_sort_indices(no, d.n_intr, T, [&](uint64_t k) { return ointr[k]; }, iobs_start, iobs);
   for (uint32_t k = 0; k < d.n_intr; ++k) {
     for (uint32_t lo = iobs_start[k]; lo < iobs_start[k + 1]; lo += kIntrChunk) {
       igchunk_lo.push_back(lo); igchunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, iobs_start[k + 1]));

@@ -306,3 +306,26 @@ def test_bundle_then_reject_loop_equals_the_reference_pipeline():
         c1 = ba.BaContext(ours); r1 = c1.evaluate()[1]; c1.close()
         c2 = ba.BaContext(ref); r2 = c2.evaluate()[1]; c2.close()
     assert abs(r1 - r2) < 1e-6
+
+
+def test_structure_build_is_independent_of_the_host_thread_count(monkeypatch):
+    """mvgx_ba_create builds the observation order, the slot lists and the three product lists on host threads (row-wise
+    generation, per-thread histograms): the device sees the same arrays - bitwise equal costs after an LM iteration - for 1
+    and 8 threads (MVGX_HOST_THREADS forces the parallel paths), for point-sorted and for shuffled observation lists"""
+    sc = synth.ba_scene(n_cams=40, n_points=1500, track_len=6, model=3, n_intr_groups=3, seed=5)
+    perm = np.random.default_rng(0).permutation(sc["n_obs"])
+    shuffled = dict(sc)
+    for k in ("obs_pose", "obs_intr", "obs_point"):
+        shuffled[k] = sc[k][perm]
+    shuffled["obs_xy"] = sc["obs_xy"][perm]
+    assert sc["n_obs"] >= 4096   # counting_sort_indices' threshold for per-thread histograms
+    for scene in (sc, shuffled):
+        got = []
+        for threads in ("1", "8"):
+            monkeypatch.setenv("MVGX_HOST_THREADS", threads)
+            with _emu.emulated():
+                ctx = ba.BaContext(scene)
+                s = ctx.lm_iteration()
+                ctx.close()
+            got.append((s.initial_cost, s.final_cost, s.final_rmse))
+        assert got[0] == got[1]
