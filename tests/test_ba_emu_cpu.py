@@ -280,7 +280,7 @@ def test_bundle_then_reject_loop_equals_the_reference_pipeline():
     """`do { BA } while (badTrackRejector(4.0, 0))` (sequential_SfM.cpp:206-210,1226-1232), emulated device code against the
     reference's Bundle_Adjustment_Ceres + sfm_data_filters.cpp driven by the same loop"""
     from tests import _ba_cases
-    sc0 = synth.ba_scene(n_cams=10, n_points=160, track_len=4, model=3, n_intr_groups=2, seed=91, outlier_frac=0.05, n_rings=1)
+    sc0 = synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=3, n_intr_groups=2, seed=91, outlier_frac=0.05, n_rings=1)
 
     def ours_adjust(sc):
         sc = dict(sc)
