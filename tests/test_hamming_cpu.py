@@ -121,3 +121,25 @@ def test_emulated_error_behaviour():
         with pytest.raises(Exception):
             ctx.run(np.array([[0, 2]], np.uint32), 0.8)               # image out of range
         ctx.close()
+
+
+def test_reference_known_answer_vectors():
+    """matching/metric_test.cpp:41-129 (Metric.HAMMING_BITSET, ..._RAW_MEMORY_64BITS, ..._32BITS): the reference's own
+    ground-truth Hamming distances, on the C restatement of Hamming<unsigned char>"""
+    import ctypes as C
+    P = _oracle.port()
+    P.oracle_hamming_u8.restype = C.c_uint; P.oracle_hamming_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+
+    def ham(a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        return P.oracle_hamming_u8(a.ctypes.data, b.ctypes.data, len(a))
+
+    a, b, c = (np.array([int(s, 2)], np.uint8) for s in ("01010101", "10101010", "11010100"))
+    assert (ham(a, b), ham(a, a), ham(a, c)) == (8, 0, 2)
+    for nbits, gt in ((64, [0, 32, 32, 33, 32, 0, 32, 21, 32, 32, 0, 31, 33, 21, 31, 0]),
+                      (32, [0, 16, 16, 17, 16, 0, 16, 11, 16, 16, 0, 17, 17, 11, 17, 0])):
+        i = np.arange(nbits)
+        tab = [np.zeros(nbits, bool), i % 2 == 0, (i // 2) % 2 == 0, (i // 3) % 2 == 0]
+        packed = [np.packbits(t, bitorder="little") for t in tab]   # std::bitset bit i = bit i of the little-endian word
+        got = [ham(packed[r], packed[q]) for r in range(4) for q in range(4)]
+        assert got == gt and got == [ham(packed[q], packed[r]) for r in range(4) for q in range(4)]
