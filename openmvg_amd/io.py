@@ -21,21 +21,24 @@ import numpy as np
 DESC_DIM = 128
 
 
-def load_desc_bin(path, dim=DESC_DIM):
-    """-> (n, dim) uint8, C-contiguous (what mvgx_match_set_regions takes)."""
+def load_desc_bin(path, dim=DESC_DIM, dtype=np.uint8):
+    """-> (n, dim) array of `dtype`, C-contiguous. SIFT_Regions: (128, uint8) - what mvgx_match_set_regions takes;
+    AKAZE_Binary_Regions: (64, uint8); AKAZE_Float_Regions: (64, float32). The file is `std::size_t count` followed by
+    count x dim elements of the descriptor's bin_type (descriptor.hpp:182-203)."""
+    dtype = np.dtype(dtype)
     with open(path, "rb") as f:
         head = f.read(8)
         if len(head) != 8:
             raise ValueError(f"{path}: truncated header")
         n = int(np.frombuffer(head, "<u8")[0])
-        data = np.frombuffer(f.read(n * dim), np.uint8)
+        data = np.frombuffer(f.read(n * dim * dtype.itemsize), dtype)
     if data.size != n * dim:
-        raise ValueError(f"{path}: expected {n} x {dim} bytes, found {data.size}")
+        raise ValueError(f"{path}: expected {n} x {dim} elements, found {data.size}")
     return data.reshape(n, dim).copy()
 
 
-def save_desc_bin(path, desc):
-    desc = np.ascontiguousarray(desc, np.uint8)
+def save_desc_bin(path, desc, dtype=np.uint8):
+    desc = np.ascontiguousarray(desc, dtype)
     with open(path, "wb") as f:
         f.write(np.array([desc.shape[0]], "<u8").tobytes())
         f.write(desc.tobytes())
@@ -144,3 +147,30 @@ def save_baf(path, poses, intrinsics, intr_model, points, obs_pose, obs_intr, ob
             name = image_names[v] if image_names is not None else ""
             full = name if not root_path else (root_path.rstrip("/") + "/" + name)
             f.write(f"{full} {pose_intr[v]} {v}\n")
+
+
+def match_directory(match_dir, stems, ratio=0.8, kind="sift", pairs=None, out_name="matches.putative.txt", device=-1):
+    """File-level pipeline either side of the matching path (main_ComputeMatches without the cereal formats): reads
+    `<match_dir>/<stem>.desc` for the ordered list `stems` (view id = position in the list, as main_ComputeMatches takes it
+    from the views of sfm_data), matches the pairs (default: exhaustivePairs, Pair_Builder.hpp:25-33) on the device and
+    writes `<match_dir>/<out_name>` in the reference's text format. kind: "sift" (uint8 x 128, BRUTE_FORCE_L2), "binary"
+    (uint8 x 64, BRUTE_FORCE_HAMMING) or "float" (float32 x 64, BRUTE_FORCE_L2). Returns {(I, J): (n, 2) uint32}."""
+    import os
+    from . import matching
+    spec = {"sift": (128, np.uint8, matching.Regions, matching.EMatcherType.BRUTE_FORCE_L2),
+            "binary": (64, np.uint8, matching.Binary_Regions, matching.EMatcherType.BRUTE_FORCE_HAMMING),
+            "float": (64, np.float32, matching.Float_Regions, matching.EMatcherType.BRUTE_FORCE_L2)}[kind]
+    dim, dtype, cls, mtype = spec
+    regions = {k: cls(load_desc_bin(os.path.join(match_dir, stem + ".desc"), dim, dtype)) for k, stem in enumerate(stems)}
+    provider = matching.Regions_Provider(regions)
+    if pairs is None:
+        pairs = matching.exhaustivePairs(len(stems))
+    out = matching.PairWiseMatches()
+    matching.Matcher_Regions(ratio, mtype, device=device).Match(provider, pairs, out)
+    keys = sorted(out)
+    offsets = np.zeros(len(keys) + 1, np.uint64)
+    for k, key in enumerate(keys):
+        offsets[k + 1] = offsets[k] + len(out[key])
+    ij = np.concatenate([out[k] for k in keys]) if keys else np.zeros((0, 2), np.uint32)
+    save_matches_txt(os.path.join(match_dir, out_name), np.array(keys, np.uint32).reshape(-1, 2), offsets, ij)
+    return dict(out)

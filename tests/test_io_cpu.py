@@ -158,3 +158,38 @@ def test_baf_export_against_committed_reference_file(tmp_path):
     ours = str(tmp_path / "ours.baf")
     _write_ours(ours, sc)
     _compare_baf(ours, os.path.join(GOLD, "scene.baf"))
+
+
+# ---- file-level pipeline: <stem>.desc in, matches.putative.txt out ----
+def test_match_directory_binary_descriptors_under_emulation(tmp_path):
+    """io.match_directory on AKAZE-like binary descriptor files: the device code (emulated) behind the Matcher_Regions
+    mirror, the written matches file read back and compared with the oracle - and with the reference's own
+    Matcher_Regions(BRUTE_FORCE_HAMMING) when its build is present"""
+    from openmvg_amd import matching, synth
+    from tests import _emu, _oracle
+    sizes = [120, 0, 300, 64, 257]
+    imgs = synth.binary_descriptors(len(sizes), sizes, seed=41)
+    stems = [f"img_{k:03d}" for k in range(len(sizes))]
+    for stem, d in zip(stems, imgs):
+        io.save_desc_bin(str(tmp_path / (stem + ".desc")), d)
+    with _emu.emulated():
+        got = io.match_directory(str(tmp_path), stems, ratio=0.8, kind="binary")
+    back = io.load_matches_txt(str(tmp_path / "matches.putative.txt"))
+    assert back.keys() == got.keys() and all(np.array_equal(back[k], got[k]) for k in got)
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    off, ij = _oracle.port_matcher_regions_match_hamming(imgs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    assert len(want) >= 3 and back.keys() == want.keys() and all(np.array_equal(back[k], want[k]) for k in want)
+    if _oracle.have_ref_match():
+        ref = _oracle.ref_matcher_regions_match_binary64(imgs, pairs, 0.8)
+        assert back.keys() == ref.keys() and all(np.array_equal(back[k], ref[k]) for k in ref)
+
+
+def test_desc_files_of_the_other_region_types_round_trip(tmp_path):
+    rng = np.random.default_rng(2)
+    f = rng.standard_normal((17, 64)).astype(np.float32)
+    b = rng.integers(0, 256, (9, 64), dtype=np.uint8)
+    io.save_desc_bin(str(tmp_path / "f.desc"), f, np.float32); io.save_desc_bin(str(tmp_path / "b.desc"), b)
+    assert np.array_equal(io.load_desc_bin(str(tmp_path / "f.desc"), 64, np.float32), f)
+    assert np.array_equal(io.load_desc_bin(str(tmp_path / "b.desc"), 64), b)
+    assert os.path.getsize(tmp_path / "f.desc") == 8 + 17 * 64 * 4

@@ -258,3 +258,25 @@ def test_results_of_a_run_survive_the_next_run(pinned):
         assert np.array_equal(off_b, o_off) and np.array_equal(ij_b, o_ij)
     finally:
         ctx.close()
+
+
+def test_match_directory_file_level_pipeline(tmp_path):
+    """io.match_directory: <stem>.desc files in, matches.putative.txt out, through the Matcher_Regions
+    mirror on the device; the file read back equals the oracle's lists"""
+    from openmvg_amd import io
+    sizes = [400, 0, 300, 1, 257, 2]
+    imgs = synth.random_descriptors(len(sizes), sizes, seed=5)
+    rng = np.random.default_rng(1)
+    for k in (2, 4):      # near-duplicates of image 0 so that matches exist
+        m = min(sizes[k], sizes[0])
+        imgs[k][:m] = np.clip(imgs[0][:m].astype(np.int16) + rng.integers(-6, 7, (m, 128)), 0, 255).astype(np.uint8)
+    stems = [f"view_{k}" for k in range(len(sizes))]
+    for stem, d in zip(stems, imgs):
+        io.save_desc_bin(str(tmp_path / (stem + ".desc")), d)
+    got = io.match_directory(str(tmp_path), stems, ratio=0.8, kind="sift", device=0)
+    back = io.load_matches_txt(str(tmp_path / "matches.putative.txt"))
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    off, ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    assert len(want) >= 2 and back.keys() == want.keys() == got.keys()
+    assert all(np.array_equal(back[k], want[k]) for k in want)
