@@ -1231,7 +1231,9 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
   int rc;
 
   MVGX_HIP(hipEventRecord(c->ev_total0, c->slot[0].stream));
-  const uint64_t B = (uint64_t)c->batch_pairs;
+  // pairs per batch: the option, capped so that the per-slot scratch (12 B per pair and query slot) stays near 6 GB when the
+  // images carry tens of thousands of descriptors
+  const uint64_t B = std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)c->batch_pairs, (1ull << 29) / std::max<uint32_t>(c->qstride, 1)));
 
   // Stage 1 of a batch on its slot's stream: work list -> filter (+ verify) -> per-pair counts -> exclusive scan -> offsets to host
   auto issue = [&](mvgx_match_ctx::Slot& sl, mvgx_match_ctx::Slot* prev, uint64_t p0, uint32_t nb) -> int {
