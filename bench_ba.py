@@ -62,21 +62,19 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=40.0, name=None):
     cfg = ba_config(world, name)
     full = synth.ba_scene(**cfg)
     rank = 0
-    uid = None
     if world > 1:
         import torch.distributed as dist
         rank = dist.get_rank()
-        box = [ba.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
         scene, _mine = sharding.shard_ba_scene(full, rank, world)
     else:
         scene = full
 
     def make():
         c = ba.BaContext(scene, device=local_rank)
-        if uid is not None:
-            c.comm_init(world, rank, uid)
+        if world > 1:   # a unique id creates exactly one communicator: every context gets its own
+            box = [ba.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            c.comm_init(world, rank, box[0])
         return c
 
     t0 = time.perf_counter()
