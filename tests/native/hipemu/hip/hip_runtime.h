@@ -1,7 +1,8 @@
 // hipemu — TEST INFRASTRUCTURE ONLY. A minimal single-threaded emulation of the HIP execution model (workgroups of
-// fibers, 64-lane waves, LDS, barriers, shuffles, the f64 MFMA) so that the device code of the BA solver
-// (openmvg_amd/csrc/mvgx_ba.hip) can be compiled for the host and exercised by the CPU test-suite, where no GPU
-// exists. It is never part of libmvgx_hip.so and nothing in openmvg_amd/ loads it: the product has no CPU path.
+// fibers, 64-lane waves, LDS, barriers, shuffles, ballots, DPP row permutations, the f64 and i8 MFMAs) so that the
+// device code of the product (openmvg_amd/csrc/mvgx_ba.hip, mvgx_bruteforce.hip unchanged; mvgx_match.hip with its
+// asynchronous staging helpers substituted, see tests/_emu.py) can be compiled for the host and exercised by the CPU
+// test-suite, where no GPU exists. It is never part of libmvgx_hip.so and nothing in openmvg_amd/ loads it: the product has no CPU path.
 //
 // Semantics: the workgroups of a launch run one after the other; the threads of a workgroup are ucontext fibers on one
 // OS thread, switched only at __syncthreads() and at wave-collective operations (__shfl*, MFMA), which wait for all
@@ -22,8 +23,13 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
 struct double2 { double x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 namespace hipemu {
@@ -34,6 +40,11 @@ double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);
 typedef double d4 __attribute__((ext_vector_type(4)));
 d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int);
 int readlane_i32(int v, int src_lane);
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+v16i_t mfma_i32_32x32x32_i8(v4i_t a, v4i_t b, v16i_t c, int, int, int);
+unsigned long long ballot(bool pred);
+int update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl);
 int lane_xor(int lane, int m);
 int lane_down(int lane, int d);
 int lane_abs(int lane, int s);
@@ -55,6 +66,25 @@ int lane_abs(int lane, int s);
 static inline double __shfl_xor(double v, int m) { return hipemu::shfl_f64(v, hipemu::lane_xor, m); }
 static inline double __shfl_down(double v, int d) { return hipemu::shfl_f64(v, hipemu::lane_down, d); }
 static inline double __shfl(double v, int s) { return hipemu::shfl_f64(v, hipemu::lane_abs, s); }
+static inline int __shfl_xor(int v, int m) { return hipemu::readlane_i32(v, (int)(hipemu::g_threadIdx.x & 63) ^ m); }
+static inline int __shfl(int v, int s) { return hipemu::readlane_i32(v, s); }
+static inline int __shfl_down(int v, int d) {
+  const int lane = (int)(hipemu::g_threadIdx.x & 63);
+  const int r = hipemu::readlane_i32(v, lane + d < 64 ? lane + d : lane);   // every lane takes part in the exchange
+  return lane + d < 64 ? r : v;
+}
+static inline unsigned __shfl_down(unsigned v, int d) { return (unsigned)__shfl_down((int)v, d); }
+#define __ballot(p) hipemu::ballot((p))
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline float __int2float_rn(int v) { return (float)v; }
+#define __builtin_amdgcn_readfirstlane(v) hipemu::readlane_i32((int)(v), 0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_update_dpp hipemu::update_dpp
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8 hipemu::mfma_i32_32x32x32_i8
+static inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool) {   // v_dot4_i32_i8: signed bytes
+  for (int k = 0; k < 4; ++k) c += (int)(signed char)(a >> (8 * k)) * (int)(signed char)(b >> (8 * k));
+  return c;
+}
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
 #define __builtin_amdgcn_readlane(v, l) hipemu::readlane_i32((v), (l))
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
@@ -91,6 +121,7 @@ static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

@@ -27,6 +27,9 @@ thread_local const std::function<void()>* g_body = nullptr;
 thread_local double g_slot[2][1024];
 thread_local double g_slot_b[2][1024];
 thread_local unsigned char g_parity[1024];
+// ballots: a lane that has already left the kernel must not vote, and a lane that runs ahead and finishes must still be
+// counted by the slower lanes of the same ballot: votes are tagged with the lane's ballot sequence number
+thread_local unsigned g_ballot_seq[1024], g_ballot_tag[2][1024];
 
 void trampoline() {
   (*g_body)();
@@ -55,6 +58,8 @@ void run_block(unsigned nthreads) {
     makecontext(&f.ctx, trampoline, 0);
     f.st = RUNNABLE;
     g_parity[i] = 0;
+    g_ballot_seq[i] = 0;
+    g_ballot_tag[0][i] = g_ballot_tag[1][i] = 0;
   }
   for (;;) {
     bool progressed = false;
@@ -186,6 +191,54 @@ d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int) {
   return out;
 }
 
+// v_mfma_i32_32x32x32_i8 (gfx950): lane l feeds 16 bytes of A row i = l & 31 and of B column j = l & 31, covering
+// k = 16 (l >> 5) .. + 15; it receives D[i = 8 (r >> 2) + 4 (l >> 5) + (r & 3)][j = l & 31], r = 0..15
+// (MI355X_MICROARCH.md, 32x32 accumulator layout; the matching kernels were validated bit for bit on the device with it)
+thread_local unsigned char g_a16[2][1024][16], g_b16[2][1024][16];
+v16i_t mfma_i32_32x32x32_i8(v4i_t a, v4i_t b, v16i_t c, int, int, int) {
+  const int me = g_cur, w0 = me & ~63, lane = me & 63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  memcpy(g_a16[par][me], &a, 16);
+  memcpy(g_b16[par][me], &b, 16);
+  wave_sync();
+  v16i_t out = c;
+  const int j = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int i = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+    int s = 0;
+    for (int k = 0; k < 32; ++k)
+      s += (int)(signed char)g_a16[par][w0 + i + 32 * (k >> 4)][k & 15] * (int)(signed char)g_b16[par][w0 + j + 32 * (k >> 4)][k & 15];
+    out[r] += s;
+  }
+  return out;
+}
+
+unsigned long long ballot(bool pred) {
+  const int me = g_cur, w0 = me & ~63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  const unsigned seq = ++g_ballot_seq[me];
+  g_slot[par][me] = pred ? 1.0 : 0.0;
+  g_ballot_tag[par][me] = seq;
+  wave_sync();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64 && w0 + l < g_n; ++l)
+    if (g_ballot_tag[par][w0 + l] == seq && g_slot[par][w0 + l] != 0.0) m |= 1ull << l;
+  return m;
+}
+
+// DPP with full row / bank masks for the controls the kernels use: quad_perm (0x00-0xFF), row_mirror (0x140),
+// row_half_mirror (0x141) - permutations inside a row of 16 lanes, so `old` / bound_ctrl never apply
+int update_dpp(int old, int src, int dpp_ctrl, int, int, bool) {
+  const int lane = g_cur & 63;
+  int from;
+  if (dpp_ctrl >= 0 && dpp_ctrl <= 0xFF) from = (lane & ~3) + ((dpp_ctrl >> (2 * (lane & 3))) & 3);
+  else if (dpp_ctrl == 0x140) from = (lane & ~15) + (15 - (lane & 15));
+  else if (dpp_ctrl == 0x141) from = (lane & ~7) + (7 - (lane & 7));
+  else { fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", dpp_ctrl); abort(); }
+  (void)old;
+  return readlane_i32(src, from);
+}
+
 }  // namespace hipemu
 
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { hipemu::g_capture = new hipemuGraph(); return hipSuccess; }
@@ -198,6 +251,7 @@ hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
 hipError_t hipGraphDestroy(hipGraph_t g) { if (g && --g->refs == 0) delete g; return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t e) { return hipGraphDestroy(e); }
 
+#ifndef HIPEMU_NO_PRODUCT
 // ---- the product's device + host code, compiled for the host against the shim ----
 namespace {   // the kernels' `extern __shared__` arrays (same unnamed namespace as the kernels below)
 thread_local __attribute__((aligned(16))) double panel[32768];
@@ -215,3 +269,4 @@ int rccl_allreduce_f64(RcclComm*, double*, uint64_t, int, hipStream_t) { return 
 extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out); }
 #include "mvgx_ba.hip"
 #include "mvgx_bruteforce.hip"
+#endif  // HIPEMU_NO_PRODUCT

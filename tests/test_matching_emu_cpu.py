@@ -1,0 +1,133 @@
+"""CPU tests of the uint8 matching path's DEVICE code under the HIP execution-model emulation (tests/native/hipemu,
+tests/_emu.py: second library, built from openmvg_amd/csrc/mvgx_match.hip with the LDS-DMA staging helpers replaced by per-lane
+copies). The emulation implements v_mfma_i32_32x32x32_i8 with the gfx950 fragment maps, v_dot4_i32_i8, the DPP row
+permutations, ballots and shuffles; tile layout, parity partition, the max3 filter epilogue, the verify stage, the ordered
+compaction and the two-slot batch pipeline are the product's code. What this cannot check is gfx950 code generation, the
+hand-placed waitcnt of the asynchronous staging and timing - the `-m gpu` tests run the real thing on the MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openmvg_amd import _capi, matching, synth
+from tests import _emu, _golden, _oracle
+from tests.test_matching_gpu import VARIANTS, assert_same, run_hip
+from tests.test_oracle_matching import _adversarial_set
+
+
+def _both_directions(n):
+    p = matching.exhaustive_pairs_array(n)
+    return np.concatenate([p, p[:, ::-1]])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_ragged_sizes_all_kernel_variants(variant):
+    """tile / window boundaries (31 / 33 rows, 255 / 257: one LDS window more, 600: three windows per parity half) on
+    full-range bytes, every kernel variant and staging form, against the C restatement"""
+    sizes = [0, 1, 2, 3, 31, 33, 255, 257, 600]
+    imgs = synth.random_descriptors(len(sizes), sizes, seed=12)
+    rng = np.random.default_rng(2)
+    for k in range(4, len(sizes)):
+        m = min(sizes[k], sizes[k - 1])
+        imgs[k][:m] = np.clip(imgs[k - 1][:m].astype(np.int16) + rng.integers(-9, 10, (m, 128)), 0, 255).astype(np.uint8)
+    pairs = _both_directions(len(sizes))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    with _emu.emulated():
+        _, off, ij = run_hip(imgs, pairs, 0.8, variant)
+    assert int(o_off[-1]) > 1000 and np.array_equal(off, o_off) and np.array_equal(ij, o_ij)
+
+
+@pytest.mark.parametrize("case", _golden.CASES)
+def test_golden_fixtures_of_the_reference(case):
+    imgs, pairs, ratio, ref = _golden.load_case(case)
+    with _emu.emulated():
+        st, off, ij = run_hip(imgs, pairs, ratio, 41)
+    assert_same(pairs, off, ij, ref)
+    assert int(st.n_matches) == sum(len(v) for v in ref.values())
+
+
+@pytest.mark.parametrize("ratio", [0.8, 1.0])
+def test_adversarial_set(ratio):
+    """all-zero rows, exact duplicates, duplicate nearest neighbours, nI in {0, 1, 2}, nJ = 0"""
+    imgs = _adversarial_set()
+    pairs = _both_directions(len(imgs))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
+    with _emu.emulated():
+        for variant in (43, 1):
+            _, off, ij = run_hip(imgs, pairs, ratio, variant)
+            assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), variant
+
+
+def test_extreme_values_and_parity_skew():
+    """d = 8 323 200 (all-0 vs all-255), images whose rows all have even / odd squared norm (one parity half stays empty),
+    near-duplicates inside one 16-row cell (the verify stage's runner-up search)"""
+    rng = np.random.default_rng(7)
+    a = np.zeros((150, 128), np.uint8); b = np.full((150, 128), 255, np.uint8)
+    a[::3] = rng.integers(0, 2, (50, 128), dtype=np.uint8) * 255
+    b[::5] = rng.integers(0, 2, (30, 128), dtype=np.uint8) * 255
+    base = synth.image_descriptors(2, n_desc=300, seed=31)
+    from tests.test_matching_gpu import _force_norm_parity
+    even = _force_norm_parity(base[0], 0)
+    near = base[1].copy()
+    for k in range(0, 280, 2):
+        near[k + 1] = near[k]
+        idx = rng.integers(0, 128, 3)
+        near[k + 1, idx] = np.clip(near[k + 1, idx].astype(np.int64) + rng.integers(-2, 3, 3), 0, 255)
+    imgs = [a, b, even, near, base[0]]
+    pairs = np.array([(i, j) for i in range(5) for j in range(5) if i != j], np.uint32)
+    with _emu.emulated():
+        for ratio in (1.0, 0.8):
+            o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
+            _, off, ij = run_hip(imgs, pairs, ratio, 41)
+            assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), ratio
+
+
+def test_batch_pipeline_options_and_result_buffers():
+    """tiny batches through the two-slot pipeline, serial mode, plain-memory and double-buffered results: the lists are
+    independent of all of them; run k stays readable after run k + 1 with "double_buffer_results" """
+    imgs = synth.image_descriptors(5, n_desc=120, seed=77)
+    pa = matching.exhaustive_pairs_array(5)
+    pb = np.ascontiguousarray(pa[::-1, ::-1])
+    oa = _oracle.port_matcher_regions_match(imgs, pa, 0.8)
+    ob = _oracle.port_matcher_regions_match(imgs, pb, 0.8)
+    with _emu.emulated():
+        for opts in ({"batch_pairs": 3}, {"batch_pairs": 2, "overlap": 0}, {"batch_pairs": 4, "pinned_results": 0}):
+            ctx = matching.MatchContext(0)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.set_regions(imgs)
+            _, off, ij = ctx.run(pa, np.float32(0.64))
+            ctx.close()
+            assert np.array_equal(off, oa[0]) and np.array_equal(ij, oa[1]), opts
+        ctx = matching.MatchContext(0)
+        ctx.set_option("double_buffer_results", 1); ctx.set_option("batch_pairs", 3)
+        ctx.set_regions(imgs)
+        L = _capi.lib()
+
+        def run(pairs):
+            st = _capi.MatchStats()
+            _capi.check(L.mvgx_match_run(ctx._h, pairs.ctypes.data, len(pairs), np.float32(0.64), C.byref(st)))
+            po, pij = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+            _capi.check(L.mvgx_match_results(ctx._h, C.byref(po), C.byref(pij)))
+            off = np.ctypeslib.as_array(po, shape=(len(pairs) + 1,))
+            return off, np.ctypeslib.as_array(pij, shape=(int(off[-1]), 2))
+
+        off_a, ij_a = run(pa)
+        off_b, ij_b = run(pb)
+        assert np.array_equal(off_a, oa[0]) and np.array_equal(ij_a, oa[1])      # still valid after the next run
+        assert np.array_equal(off_b, ob[0]) and np.array_equal(ij_b, ob[1])
+        ctx.close()
+
+
+def test_oneshot_sink_and_mirror():
+    """mvgx_match_pairs_u8_l2 (serial callback, ascending input order) and the Matcher_Regions mirror"""
+    imgs = synth.image_descriptors(4, n_desc=90, seed=3)
+    imgs[2] = imgs[2][:0]
+    pairs = matching.exhaustive_pairs_array(4)
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, o_off, o_ij)
+    with _emu.emulated():
+        prov = matching.Regions_Provider({k: matching.Regions(d) for k, d in enumerate(imgs)})
+        out = matching.PairWiseMatches()
+        matching.Matcher_Regions(0.8, matching.EMatcherType.BRUTE_FORCE_L2).Match(prov, [tuple(p) for p in pairs], out)
+    assert dict(out).keys() == want.keys() and all(np.array_equal(out[k], want[k]) for k in want)
