@@ -144,6 +144,23 @@ int mvgx_l2f_run(mvgx_l2f_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, 
 int mvgx_l2f_results(mvgx_l2f_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
 
 /* ------------------------------------------------------------------------------------------------
+ * MATCHING OF uint8 DESCRIPTORS OF OTHER LENGTHS (BRUTE_FORCE_L2 on Scalar_Regions<SIOPointFeature, unsigned char, N>,
+ * N = 144: AKAZE_Liop_Regions, features/regions_factory.hpp:24)
+ * replaces matching/regions_matcher.cpp:75-81 for those region types; L2<uint8_t> (matching/metric.hpp:55-93) in exact integer
+ * arithmetic (v_dot4_u32_u8), so the lists are bit-identical. Same call shapes as mvgx_match_* (ratio_sq = Square(dist_ratio));
+ * dim must be 64, 128 or 144 - SIFT's 128 is better served by mvgx_match_* (the MFMA path) and accepted here as a cross-check.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mvgx_l2u8_ctx mvgx_l2u8_ctx;
+int mvgx_l2u8_create(int device, mvgx_l2u8_ctx** out);
+int mvgx_l2u8_destroy(mvgx_l2u8_ctx* ctx);
+int mvgx_l2u8_set_option(mvgx_l2u8_ctx* ctx, const char* key /* "batch_pairs" */, int64_t value);
+int mvgx_l2u8_set_regions(mvgx_l2u8_ctx* ctx, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                          uint32_t dim);
+int mvgx_l2u8_run(mvgx_l2u8_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                  mvgx_match_stats* stats /* may be NULL */);
+int mvgx_l2u8_results(mvgx_l2u8_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
+
+/* ------------------------------------------------------------------------------------------------
  * BUNDLE ADJUSTMENT
  * replaces: sfm/sfm_data_BA_ceres.cpp:165-608 (Bundle_Adjustment_Ceres::Adjust) and, underneath it,
  *           vendored Ceres 1.13: program_evaluator.h:138-285, residual_block.cc:68-196, corrector.cc:41-155,

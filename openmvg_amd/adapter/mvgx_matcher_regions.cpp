@@ -15,7 +15,9 @@
 //           RegionsMatcherT<ArrayMatcherBruteForce<uchar, Hamming<uchar>>>::MatchDistanceRatio (regions_matcher.cpp:184-191)
 //   -n BRUTEFORCEL2 on 64-D float regions (AKAZE_Float_Regions) with dist_ratio <= 1
 //        -> the MI355X packed-fp32 path (mvgx_l2f_*): L2<float> in the reference's own summation order, bit-identical lists
-//   anything else (other -n values, other float lengths, uint8 dim != 128, ratio > 1 whose tie order is libstdc++'s)
+//   -n BRUTEFORCEL2 on uint8 regions of 64 or 144 bytes (AKAZE_Liop_Regions) with dist_ratio <= 1
+//        -> the MI355X integer dot-product path (mvgx_l2u8_*), bit-identical lists
+//   anything else (other -n values, other descriptor lengths, ratio > 1 whose tie order is libstdc++'s)
 //        -> the per-pair interface the reference itself uses for them (RegionMatcherFactory, regions_matcher.cpp:54),
 //           which stays in the link; that code is not part of the accelerated path.
 //
@@ -57,6 +59,10 @@ constexpr uint64_t kPairsPerCall = 1u << 17;  // cancellation / progress granula
 
 bool is_sift_u8(const features::Regions& r) {
   return r.IsScalar() && r.DescriptorLength() == 128 && r.Type_id() == typeid(unsigned char).name();
+}
+
+bool is_u8_other(const features::Regions& r) {   // uint8 scalar regions of the other supported lengths (AKAZE_Liop_Regions: 144)
+  return r.IsScalar() && (r.DescriptorLength() == 64 || r.DescriptorLength() == 144) && r.Type_id() == typeid(unsigned char).name();
 }
 
 bool is_float64(const features::Regions& r) {
@@ -167,7 +173,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
   const bool device_type = (eMatcherType_ == matching::BRUTE_FORCE_L2 && ratio_sq <= 1.0f && ratio_sq >= 0.0f) ||
                            (hamming && f_dist_ratio_ <= 1.0f && f_dist_ratio_ >= 0.0f);
   size_t binary_len = 0;   // one descriptor length per device run (a Regions_Provider holds one region type)
-  int l2_kind = -1;        // BRUTE_FORCE_L2: 0 = 128-D uint8, 1 = 64-D float, decided by the first usable regions
+  int l2_kind = -1;        // BRUTE_FORCE_L2: 0 = 128-D uint8, 1 = 64-D float, 2 = uint8 of another length; first usable regions decide
 
   // Pair_Set is ordered by (I, J): the order in which the reference visits and inserts.
   std::vector<Pair> generic_pairs;
@@ -187,8 +193,8 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       if (!binary_len) binary_len = r->DescriptorLength();
       if (r->DescriptorLength() != binary_len) return -1;
     } else {
-      if (l2_kind < 0) l2_kind = is_float64(*r) ? 1 : 0;
-      if (l2_kind == 1 ? !is_float64(*r) : !is_sift_u8(*r)) return -1;
+      if (l2_kind < 0) { l2_kind = is_float64(*r) ? 1 : is_u8_other(*r) ? 2 : 0; if (l2_kind == 2) binary_len = r->DescriptorLength(); }
+      if (l2_kind == 1 ? !is_float64(*r) : l2_kind == 2 ? !(is_u8_other(*r) && r->DescriptorLength() == binary_len) : !is_sift_u8(*r)) return -1;
     }
     const uint32_t k = static_cast<uint32_t>(ids.size());
     dense.emplace(view, k);
@@ -225,21 +231,23 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     Sink sink{&map_PutativeMatches, &ids};
     const uint64_t n_pairs = dev_pairs.size() / 2;
     // the device paths have the same call shapes (include/mvgx.h)
-    const bool f32 = !hamming && l2_kind == 1;
+    const bool f32 = !hamming && l2_kind == 1, u8o = !hamming && l2_kind == 2;
     mvgx_match_ctx* l2 = nullptr;
     mvgx_hamming_ctx* hm = nullptr;
     mvgx_l2f_ctx* lf = nullptr;
-    int rc = hamming ? mvgx_hamming_create(-1, &hm) : f32 ? mvgx_l2f_create(-1, &lf) : mvgx_match_create(-1, &l2);
+    mvgx_l2u8_ctx* lu = nullptr;
+    int rc = hamming ? mvgx_hamming_create(-1, &hm) : f32 ? mvgx_l2f_create(-1, &lf) : u8o ? mvgx_l2u8_create(-1, &lu) : mvgx_match_create(-1, &l2);
     if (rc != MVGX_OK) device_failure("create", rc);
     if (l2) {
       const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the lists rarely pays
       mvgx_match_set_option(l2, "pinned_results", env ? std::atoi(env) : 0);
       mvgx_match_set_option(l2, "double_buffer_results", 1);   // run k + 1 overlaps the delivery of run k
     }
-    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (l2) mvgx_match_destroy(l2); };
+    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (lu) mvgx_l2u8_destroy(lu); if (l2) mvgx_match_destroy(l2); };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());
     rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
          : f32   ? mvgx_l2f_set_regions(lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
+         : u8o   ? mvgx_l2u8_set_regions(lu, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len))
                  : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), n_img, 128);
     if (rc != MVGX_OK) { destroy(); device_failure("set_regions", rc); }
     tick("context + upload + tile build");
@@ -250,9 +258,10 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
       const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
       if (progress->hasBeenCanceled()) break;
-      if (hamming || f32) drain();   // those contexts hold one result buffer
+      if (hamming || f32 || u8o) drain();   // those contexts hold one result buffer
       rc = hamming ? mvgx_hamming_run(hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
            : f32   ? mvgx_l2f_run(lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
+           : u8o   ? mvgx_l2u8_run(lu, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
                    : mvgx_match_run(l2, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
       tick("device run");
       drain();
@@ -262,6 +271,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       const uint32_t* ij = nullptr;
       if (hamming) mvgx_hamming_results(hm, &offsets, &ij);
       else if (f32) mvgx_l2f_results(lf, &offsets, &ij);
+      else if (u8o) mvgx_l2u8_results(lu, &offsets, &ij);
       else mvgx_match_results(l2, &offsets, &ij);
       const uint32_t* batch_pairs = dev_pairs.data() + 2 * p0;
       pending = std::async(std::launch::async, [=, &sink]() { deliver(sink, batch_pairs, nb, offsets, ij); });

@@ -168,6 +168,66 @@ __global__ __launch_bounds__(kQBlock) void l2f_top2_ratio_kernel(L2fParams p) {
   if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
 }
 
+// ---- L2<unsigned char> for descriptor lengths other than 128 (AKAZE_Liop_Regions: 144, regions_factory.hpp:24) ----
+// regions_matcher.cpp:75-81: ArrayMatcherBruteForce<unsigned char, L2<unsigned char>>, squared metric. L2<uint8_t>
+// (metric.hpp:55-93) accumulates int: d = |a|^2 + |b|^2 - 2 a.b exactly, with a.b from v_dot4_u32_u8 on the raw bytes and
+// the squared norms precomputed per row. Same structure as the kernels above (query in registers, database rows and their
+// norms through the scalar path); the 128-byte SIFT case keeps its own MFMA path (mvgx_match.hip) - this one exists so that
+// the other uint8 region types do not fall back to the host.
+struct L2uParams {
+  const uint32_t* words;        // all descriptors, NW dwords each (zero padded), image-major
+  const uint32_t* norms;        // |a|^2 per row
+  const uint64_t* img_row_off;
+  const uint32_t* img_n;
+  const uint2* pairs;
+  const uint2* work;
+  uint32_t* best;
+  uint32_t* count;
+  uint32_t qstride;
+  float ratio_sq;
+};
+
+template <int NW>
+__global__ __launch_bounds__(kQBlock) void l2u8_top2_ratio_kernel(L2uParams p) {
+  __shared__ uint32_t sh_count;
+  const uint2 w = p.work[blockIdx.x];
+  const uint2 ij = p.pairs[w.x];
+  const uint32_t nI = p.img_n[ij.x], nJ = p.img_n[ij.y];
+  const uint32_t q = w.y + threadIdx.x;
+  const bool active = q < nJ;
+  if (threadIdx.x == 0) sh_count = 0;
+  __syncthreads();
+  uint32_t qv[NW];
+  const uint64_t qrow = p.img_row_off[ij.y] + (active ? q : 0);
+  {
+    const uint32_t* src = p.words + qrow * NW;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) qv[k] = src[k];
+  }
+  const uint32_t qn = p.norms[qrow];
+  const uint32_t* __restrict__ db = p.words + p.img_row_off[ij.x] * NW;   // wave-uniform: scalar loads
+  const uint32_t* __restrict__ dn = p.norms + p.img_row_off[ij.x];
+  uint64_t b0 = ~0ull, b1 = ~0ull;
+#pragma unroll 2
+  for (uint32_t i = 0; i < nI; ++i) {
+    const uint32_t* __restrict__ row = db + (size_t)i * NW;
+    uint32_t dot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dot = __builtin_amdgcn_udot4(row[k], qv[k], dot, false);
+    const uint32_t d = dn[i] + qn - 2u * dot;   // exact: every term < 2^24 for lengths up to 256
+    top2_u64(((uint64_t)d << 32) | i, b0, b1);
+  }
+  uint32_t out = kInvalid;
+  if (active && nI >= 2) {
+    const float d0 = (float)(uint32_t)(b0 >> 32), d1 = (float)(uint32_t)(b1 >> 32);
+    if (d0 < __fmul_rn(p.ratio_sq, d1)) out = (uint32_t)b0;
+  }
+  if (active) p.best[(size_t)w.x * p.qstride + q] = out;
+  if (out != kInvalid) atomicAdd(&sh_count, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
+}
+
 // exclusive scan of the per-pair counts (one workgroup)
 __global__ __launch_bounds__(1024) void hamming_scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offsets) {
   __shared__ uint32_t part[1024];
@@ -238,14 +298,14 @@ struct Buf {
 }  // namespace
 
 struct BfCtx {
-  int kind = 0;   // 0: Hamming on packed bits (nw dwords per row), 1: L2<float> (nw floats per row)
+  int kind = 0;   // 0: Hamming on packed bits (nw dwords per row), 1: L2<float> (nw floats per row), 2: L2<uint8> (nw dwords per row)
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
   int64_t batch_pairs = 1 << 15;
   uint32_t n_images = 0, nw = 0, desc_bytes = 0, max_n = 0, qstride = 0;
   std::vector<uint32_t> h_n;
-  Buf<uint32_t> d_words, d_n, d_best, d_count, d_offsets;
+  Buf<uint32_t> d_words, d_n, d_best, d_count, d_offsets, d_norms;
   Buf<uint64_t> d_row_off;
   Buf<uint2> d_pairs, d_work, d_ij;
   Buf<uint2> hp_pairs, hp_work;
@@ -256,6 +316,7 @@ struct BfCtx {
 };
 struct mvgx_hamming_ctx : BfCtx {};
 struct mvgx_l2f_ctx : BfCtx {};
+struct mvgx_l2u8_ctx : BfCtx {};
 
 namespace {
 
@@ -273,7 +334,7 @@ int bf_create(int kind, int device, BfCtx* c) {
 void bf_release(BfCtx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->d_words.release(); c->d_n.release(); c->d_best.release(); c->d_count.release(); c->d_offsets.release();
+  c->d_words.release(); c->d_norms.release(); c->d_n.release(); c->d_best.release(); c->d_count.release(); c->d_offsets.release();
   c->d_row_off.release(); c->d_pairs.release(); c->d_work.release(); c->d_ij.release();
   c->hp_pairs.release(); c->hp_work.release(); c->hp_offsets.release();
   for (hipEvent_t e : {c->ev0, c->ev1, c->evk0, c->evk1}) if (e) (void)hipEventDestroy(e);
@@ -325,6 +386,18 @@ int bf_set_regions(BfCtx* c, const uint8_t* const* desc_rows, const uint32_t* n_
     return rc;
   MVGX_HIP(hipMemcpyAsync(c->d_words.p, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(c->d_row_off.p, off.data(), (n_images + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  std::vector<uint32_t> norms;
+  if (c->kind == 2) {   // |a|^2 per row (metric.hpp:55-93 accumulates int; < 2^24 here)
+    norms.assign((size_t)std::max<uint64_t>(rows, 1), 0u);
+    for (uint64_t r = 0; r < rows; ++r) {
+      const uint8_t* b = reinterpret_cast<const uint8_t*>(words.data() + r * nw);
+      uint32_t nn = 0;
+      for (uint32_t e = 0; e < row_bytes; ++e) nn += (uint32_t)b[e] * b[e];
+      norms[r] = nn;
+    }
+    if ((rc = c->d_norms.ensure(norms.size()))) return rc;
+    MVGX_HIP(hipMemcpyAsync(c->d_norms.p, norms.data(), norms.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  }
   if (n_images)
     MVGX_HIP(hipMemcpyAsync(c->d_n.p, c->h_n.data(), n_images * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
@@ -347,7 +420,7 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
   c->res_ij.clear();
   mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
-  st.variant = (c->kind ? 200 : 100) + c->nw;
+  st.variant = (c->kind == 0 ? 100 : c->kind == 1 ? 200 : 300) + c->nw;
   int rc;
   float kernel_ms = 0.f;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -381,6 +454,13 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
         hp.best = c->d_best.p; hp.count = c->d_count.p; hp.qstride = c->qstride; hp.ratio = ratio;
         if (c->nw == 8) hipLaunchKernelGGL(hamming_top2_ratio_kernel<8>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
         else hipLaunchKernelGGL(hamming_top2_ratio_kernel<16>, dim3(n_work), dim3(kQBlock), 0, c->stream, hp);
+      } else if (c->kind == 2) {
+        L2uParams up;
+        up.words = c->d_words.p; up.norms = c->d_norms.p; up.img_row_off = c->d_row_off.p; up.img_n = c->d_n.p; up.pairs = c->d_pairs.p;
+        up.work = c->d_work.p; up.best = c->d_best.p; up.count = c->d_count.p; up.qstride = c->qstride; up.ratio_sq = ratio;
+        if (c->nw == 16) hipLaunchKernelGGL(l2u8_top2_ratio_kernel<16>, dim3(n_work), dim3(kQBlock), 0, c->stream, up);
+        else if (c->nw == 32) hipLaunchKernelGGL(l2u8_top2_ratio_kernel<32>, dim3(n_work), dim3(kQBlock), 0, c->stream, up);
+        else hipLaunchKernelGGL(l2u8_top2_ratio_kernel<36>, dim3(n_work), dim3(kQBlock), 0, c->stream, up);
       } else {
         L2fParams fp;
         fp.rows = reinterpret_cast<const float*>(c->d_words.p); fp.img_row_off = c->d_row_off.p; fp.img_n = c->d_n.p;
@@ -481,6 +561,29 @@ int mvgx_l2f_run(mvgx_l2f_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, fl
 
 int mvgx_l2f_results(mvgx_l2f_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
   MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_l2f_results: NULL argument");
+  *offsets = c->res_offsets.data();
+  *ij = c->res_ij.data();
+  return MVGX_OK;
+}
+
+int mvgx_l2u8_create(int device, mvgx_l2u8_ctx** out) { return bf_create_as(2, device, out); }
+int mvgx_l2u8_destroy(mvgx_l2u8_ctx* c) { if (c) { bf_release(c); delete c; } return MVGX_OK; }
+int mvgx_l2u8_set_option(mvgx_l2u8_ctx* c, const char* key, int64_t value) { return bf_set_option(c, key, value); }
+
+int mvgx_l2u8_set_regions(mvgx_l2u8_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_l2u8_set_regions: NULL argument");
+  MVGX_REQUIRE(dim == 64 || dim == 128 || dim == 144, MVGX_ERR_UNSUPPORTED,
+               "uint8 descriptors of length %u unsupported (this path: 64, 128 or 144 = AKAZE_Liop_Regions; SIFT's 128 has "
+               "its own MFMA path, mvgx_match_*)", dim);
+  return bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4);
+}
+
+int mvgx_l2u8_run(mvgx_l2u8_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, mvgx_match_stats* stats) {
+  return bf_run(c, pairs_IJ, n_pairs, ratio_sq, stats);
+}
+
+int mvgx_l2u8_results(mvgx_l2u8_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
+  MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_l2u8_results: NULL argument");
   *offsets = c->res_offsets.data();
   *ij = c->res_ij.data();
   return MVGX_OK;

@@ -238,6 +238,13 @@ class L2fContext(HammingContext):
     _dtype = np.float32
 
 
+class L2u8Context(HammingContext):
+    """uint8 descriptors of length 64 / 128 / 144 (AKAZE_Liop_Regions), BRUTE_FORCE_L2 in exact integers (mvgx_l2u8_*);
+    run() takes the squared ratio like MatchContext.run()."""
+    _prefix = "mvgx_l2u8"
+    _dtype = np.uint8
+
+
 class Float_Regions(Regions):
     """Scalar_Regions<SIOPointFeature, float, L> stand-in (AKAZE_Float_Regions: L = 64): an (n, L) float32 array."""
 
@@ -282,6 +289,9 @@ class Matcher_Regions:
             regs[v] = r
         if any(r.RegionCount() and r.Type_id() == "f" for r in regs.values()):
             return self._match_float(regs, ids, pairs, map_PutativeMatches, my_progress_bar)
+        lens = {r.DescriptorLength() for r in regs.values() if r.RegionCount() and r.Type_id() == "h" and r.IsScalar()}
+        if lens and lens <= {64, 144} and len(lens) == 1:   # e.g. AKAZE_Liop_Regions: the integer VALU path
+            return self._match_u8_other(regs, ids, pairs, lens.pop(), map_PutativeMatches, my_progress_bar)
         # Matcher_Regions.cpp:85-90: pairs whose Type_id differ are skipped; regions_matcher.cpp:75-81: uchar only here
         for v, r in regs.items():
             if r.RegionCount() and (r.Type_id() != "h" or r.DescriptorLength() != 128 or not r.IsScalar()):
@@ -351,6 +361,28 @@ class Matcher_Regions:
         ctx = L2fContext(self._device)
         try:
             ctx.set_regions(descs, 64)
+            parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
+            _, offsets, ij = ctx.run(parr, np.float32(self.f_dist_ratio_ * self.f_dist_ratio_))
+        finally:
+            ctx.close()
+        for k, p in enumerate(pairs):
+            a, b = int(offsets[k]), int(offsets[k + 1])
+            if b > a:
+                map_PutativeMatches.insert(p, ij[a:b].copy())
+            if my_progress_bar is not None:
+                my_progress_bar += 1
+
+    def _match_u8_other(self, regs, ids, pairs, dim, map_PutativeMatches, my_progress_bar=None):
+        """regions_matcher.cpp:75-81 on Scalar_Regions<uint8, dim != 128> (AKAZE_Liop_Regions: 144)."""
+        for v in ids:
+            r = regs[v]
+            if r.RegionCount() and (r.Type_id() != "h" or not r.IsScalar() or r.DescriptorLength() != dim):
+                raise NotImplementedError("one uint8 descriptor length per provider")
+        local = {v: k for k, v in enumerate(ids)}
+        descs = [regs[v].DescriptorRawData() if regs[v].RegionCount() else np.zeros((0, dim), np.uint8) for v in ids]
+        ctx = L2u8Context(self._device)
+        try:
+            ctx.set_regions(descs, dim)
             parr = np.array([(local[a], local[b]) for a, b in pairs], dtype=np.uint32).reshape(-1, 2)
             _, offsets, ij = ctx.run(parr, np.float32(self.f_dist_ratio_ * self.f_dist_ratio_))
         finally:

@@ -64,6 +64,17 @@ std::shared_ptr<features::Regions> make_float64_regions(const float* rows, uint3
   return r;
 }
 
+std::shared_ptr<features::Regions> make_liop144_regions(const uint8_t* rows, uint32_t n) {
+  auto r = std::make_shared<features::AKAZE_Liop_Regions>();   // Scalar_Regions<SIOPointFeature, unsigned char, 144>
+  r->Features().resize(n);
+  r->Descriptors().resize(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    r->Features()[k] = features::SIOPointFeature(float(k), float(k), 1.f, 0.f);
+    std::memcpy(r->Descriptors()[k].data(), rows + size_t(k) * 144, 144);
+  }
+  return r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,6 +227,31 @@ int ref_matcher_regions_match_u8_timed(const uint8_t* const* desc_rows, const ui
   out[1] = double(n);
   out[2] = double(res.size());
   return 0;
+}
+
+// Matcher_Regions(dist_ratio, BRUTE_FORCE_L2).Match on in-memory AKAZE_Liop_Regions (144 x uint8); same output convention.
+uint64_t ref_matcher_regions_match_liop144(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images,
+                                           const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                           ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::AKAZE_Liop_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) provider->set(k, make_liop144_regions(desc_rows[k], n_desc[k]));
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) {
+      flat[2 * m] = kv.second[m].i_;
+      flat[2 * m + 1] = kv.second[m].j_;
+    }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
 }
 
 }  // extern "C"

@@ -76,8 +76,8 @@ def ref_match():
     return _refm
 
 
-def _desc_tables(descs):
-    arrs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 128) for d in descs]
+def _desc_tables(descs, dim=128):
+    arrs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, dim) for d in descs]
     n = len(arrs)
     ptrs = (C.c_void_p * max(n, 1))()
     cnt = (C.c_uint32 * max(n, 1))()
@@ -87,14 +87,14 @@ def _desc_tables(descs):
     return arrs, ptrs, cnt
 
 
-def port_matcher_regions_match(descs, pairs, dist_ratio):
+def port_matcher_regions_match(descs, pairs, dist_ratio, dim=128):
     """C-restatement oracle of Matcher_Regions::Match. Returns (offsets uint64[n_pairs+1], ij uint32[(n,2)])."""
-    arrs, ptrs, cnt = _desc_tables(descs)
+    arrs, ptrs, cnt = _desc_tables(descs, dim)
     pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
     cap = int(sum(int(arrs[j].shape[0]) for j in pairs[:, 1])) + 1 if len(pairs) else 1
     offsets = np.zeros(len(pairs) + 1, np.uint64)
     ij = np.zeros((cap, 2), np.uint32)
-    total = port().oracle_matcher_regions_match_u8(ptrs, cnt, len(arrs), 128, pairs.ctypes.data, len(pairs),
+    total = port().oracle_matcher_regions_match_u8(ptrs, cnt, len(arrs), dim, pairs.ctypes.data, len(pairs),
                                                    np.float32(dist_ratio), offsets.ctypes.data, ij.ctypes.data, cap)
     assert total != 2 ** 64 - 1
     return offsets, ij[: int(total)].copy()
@@ -204,6 +204,24 @@ def ref_matcher_regions_match_float64(descs, pairs, dist_ratio, lib=None):
 
     cb = SINK(sink)
     Lr.ref_matcher_regions_match_float64(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    return out
+
+
+def ref_matcher_regions_match_liop144(descs, pairs, dist_ratio, lib=None):
+    """The reference's own Matcher_Regions(BRUTE_FORCE_L2).Match on AKAZE_Liop_Regions (144 x uint8). -> {(I, J): (n,2)}"""
+    Lr = lib or ref_match()
+    Lr.ref_matcher_regions_match_liop144.restype = C.c_uint64
+    Lr.ref_matcher_regions_match_liop144.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p,
+                                                     C.c_uint64, C.c_float, SINK, C.c_void_p]
+    arrs, ptrs, cnt = _desc_tables(descs, 144)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = {}
+
+    def sink(_user, I, J, pij, n):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()
+
+    cb = SINK(sink)
+    Lr.ref_matcher_regions_match_liop144(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
     return out
 
 
@@ -511,6 +529,25 @@ def build_adapter_harness(verbose=False):
     return ADAPTER_SO
 
 
+ADAPTER_EMU_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_emu.so")
+_adapter_emu = None
+
+
+def adapter_emu():
+    """The matcher adapter linked against the HIP emulation libraries (tests/native/adapter_harness.mk, target `emu`): the
+    adapter's C++ code on the CPU. None where the openMVG tree / reference objects are absent."""
+    global _adapter_emu
+    if _adapter_emu is None:
+        import subprocess
+        from tests import _emu
+        if not os.path.isdir("/root/reference/src") or not os.path.exists(os.path.join(ROOT, "openmvg_amd", "lib", "adapter_obj", "mvgx_matcher_regions.o")):
+            return None
+        _emu.build(); _emu.build_match()
+        subprocess.run(["make", "-f", os.path.join(ROOT, "tests", "native", "adapter_harness.mk"), "emu"], check=True, stdout=subprocess.DEVNULL)
+        _adapter_emu = _bind_match_shim(C.CDLL(ADAPTER_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+    return _adapter_emu
+
+
 def have_adapter():
     return os.path.exists(ADAPTER_SO) and os.path.exists(ADAPTER_BA_SO)
 
@@ -526,7 +563,8 @@ def adapter():
         both = _Both()
         m = _bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
-        for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64"):
+        for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64",
+                     "ref_matcher_regions_match_liop144"):
             setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare"):
             setattr(both, name, getattr(b, name))

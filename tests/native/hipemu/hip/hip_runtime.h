@@ -85,6 +85,10 @@ static inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool) {   // v_dot
   for (int k = 0; k < 4; ++k) c += (int)(signed char)(a >> (8 * k)) * (int)(signed char)(b >> (8 * k));
   return c;
 }
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {   // v_dot4_u32_u8
+  for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
+  return c;
+}
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
 #define __builtin_amdgcn_readlane(v, l) hipemu::readlane_i32((v), (l))
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }

@@ -1,0 +1,65 @@
+"""CPU test of the matcher adapter's C++ code (openmvg_amd/adapter/mvgx_matcher_regions.cpp: region-type dispatch, pair
+batching, delivery threads, container fill): the replacement TU, driven by the reference's caller code
+(oracle/ref_shim_match.cpp), linked against the HIP emulation libraries instead of libmvgx_hip.so. Same entry points as
+tests/test_adapter_gpu.py; needs the openMVG tree (build container)."""
+import numpy as np
+import pytest
+
+from openmvg_amd import matching, synth
+from tests import _oracle
+from tests.test_l2u8_cpu import liop_like
+
+pytestmark = pytest.mark.skipif(_oracle.adapter_emu() is None, reason="openMVG tree / adapter objects not present")
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_sift_uint8_route():
+    descs = synth.image_descriptors(5, n_desc=150, seed=11)
+    descs[3] = descs[3][:0]; descs[4] = descs[4][:1]
+    pairs = matching.exhaustive_pairs_array(5)
+    got = _oracle.ref_matcher_regions_match(descs, pairs, 0.8, lib=_oracle.adapter_emu())
+    off, ij = _oracle.port_matcher_regions_match(descs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    assert sum(len(v) for v in want.values()) > 20
+    _same(got, want)
+
+
+def test_liop_uint8_144_route():
+    sizes = [120, 0, 130, 64, 1, 2]
+    imgs = liop_like(sizes, 144, seed=21)
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    got = _oracle.ref_matcher_regions_match_liop144(imgs, pairs, 0.8, lib=_oracle.adapter_emu())
+    off, ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8, dim=144)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    assert sum(len(v) for v in want.values()) > 20
+    _same(got, want)
+    if _oracle.have_ref_match():
+        _same(got, _oracle.ref_matcher_regions_match_liop144(imgs, pairs, 0.8))
+
+
+def test_binary_and_float_routes():
+    sizes = [100, 0, 90, 1, 2]
+    b = synth.binary_descriptors(len(sizes), sizes, seed=9)
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    got = _oracle.ref_matcher_regions_match_binary64(b, pairs, 0.8, lib=_oracle.adapter_emu())
+    off, ij = _oracle.port_matcher_regions_match_hamming(b, pairs, 0.8)
+    _same(got, _oracle.offsets_to_dict(pairs, off, ij))
+    f = synth.float_descriptors(len(sizes), sizes, seed=9)
+    got = _oracle.ref_matcher_regions_match_float64(f, pairs, 0.8, lib=_oracle.adapter_emu())
+    off, ij = _oracle.port_matcher_regions_match_f32(f, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    assert sum(len(v) for v in want.values()) > 10
+    _same(got, want)
+
+
+def test_ratio_above_one_uses_the_reference_route():
+    descs = synth.image_descriptors(3, n_desc=60, seed=5)
+    pairs = matching.exhaustive_pairs_array(3)
+    got = _oracle.ref_matcher_regions_match(descs, pairs, 1.05, lib=_oracle.adapter_emu())
+    if _oracle.have_ref_match():
+        _same(got, _oracle.ref_matcher_regions_match(descs, pairs, 1.05))

@@ -74,6 +74,21 @@ def test_matcher_regions_replacement_float_equals_reference():
         _same(got, _oracle.ref_matcher_regions_match_float64(imgs, pairs, 0.8))
 
 
+def test_matcher_regions_replacement_liop_equals_reference():
+    """-n BRUTEFORCEL2 on AKAZE_Liop_Regions (144 x uint8): same caller shim, reference TUs vs the MI355X replacement"""
+    from tests.test_l2u8_cpu import liop_like
+    sizes = [300, 0, 257, 64, 1, 2, 500]
+    imgs = liop_like(sizes, 144, seed=21)
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    got = _oracle.ref_matcher_regions_match_liop144(imgs, pairs, 0.8, lib=_oracle.adapter())
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8, dim=144)
+    want = _oracle.offsets_to_dict(pairs, o_off, o_ij)
+    assert sum(len(v) for v in want.values()) > 50
+    _same(got, want)
+    if _oracle.have_ref_match():
+        _same(got, _oracle.ref_matcher_regions_match_liop144(imgs, pairs, 0.8))
+
+
 def _golden():
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_golden.npz"))
 
