@@ -548,6 +548,20 @@ def adapter_emu():
     return _adapter_emu
 
 
+ADAPTER_BA_EMU_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_ba_emu.so")
+_adapter_ba_emu = None
+
+
+def adapter_ba_emu():
+    """The BA adapter (Bundle_Adjustment_Ceres replacement TU + Bundle_Adjustment_HIP) linked against the HIP emulation."""
+    global _adapter_ba_emu
+    if _adapter_ba_emu is None:
+        if adapter_emu() is None:   # builds the `emu` targets
+            return None
+        _adapter_ba_emu = _bind_ba_shim(C.CDLL(ADAPTER_BA_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+    return _adapter_ba_emu
+
+
 def have_adapter():
     return os.path.exists(ADAPTER_SO) and os.path.exists(ADAPTER_BA_SO)
 

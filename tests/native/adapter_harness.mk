@@ -53,5 +53,9 @@ emu: $(OUT)/libmvgx_openmvg_adapter_emu.so
 $(OUT)/libmvgx_openmvg_adapter_emu.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) $(OUT)/libmvgx_ba_emu.so $(OUT)/libmvgx_match_emu.so $(lastword $(MAKEFILE_LIST))
 	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) -L$(OUT) -lmvgx_match_emu -lmvgx_ba_emu -lpthread
 
+$(OUT)/libmvgx_openmvg_adapter_ba_emu.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(OUT)/libmvgx_ba_emu.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(OUT) -lmvgx_ba_emu -lpthread
+emu: $(OUT)/libmvgx_openmvg_adapter_ba_emu.so
+
 clean:
 	rm -f $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so $(OUT)/ref_shim_match.o $(OUT)/ref_shim_ba.o

@@ -1,0 +1,49 @@
+"""CPU test of the BA adapter's C++ code (openmvg_amd/adapter/mvgx_bundle_adjustment{,_ceres}.cpp: SfM_Data -> mvgx_ba_problem,
+Optimize_Options -> masks, control points, the prior registration through the reference's own Similarity3 / LMedS code,
+write-back rules): the replacement Bundle_Adjustment_Ceres, driven by the reference's caller code (oracle/ref_shim_ba.cpp),
+linked against the HIP emulation instead of libmvgx_hip.so; compared with the outputs of the reference stored in
+tests/golden/ba_golden.npz. Same entry points as tests/test_adapter_gpu.py; needs the openMVG tree (build container)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+
+pytestmark = pytest.mark.skipif(_oracle.adapter_ba_emu() is None, reason="openMVG tree / adapter objects not present")
+
+
+def _golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", ["tiny_pinhole|14|6|1", "tiny_k1|14|6|1", "tiny_k3|14|6|1", "ring_outliers|14|6|1", "ring_pinhole|1|6|1"])
+def test_bundle_adjustment_ceres_replacement_equals_golden(tag):
+    z = _golden()
+    keys = ("poses", "intrinsics", "intr_model", "points", "obs_pose", "obs_intr", "obs_point", "obs_xy")
+    sc = {k: z[f"{tag}/{k}"].copy() for k in keys}
+    sc["n_poses"] = len(sc["poses"]); sc["n_intrinsics"] = len(sc["intrinsics"]); sc["n_points"] = len(sc["points"])
+    sc["n_obs"] = len(sc["obs_pose"])
+    _, iopt, eopt, sopt = tag.split("|")
+    ref_stats = z[f"{tag}/ref_stats"]
+    rc, stats, poses, intr, pts = _oracle.ref_ba_adjust(sc, int(iopt), int(eopt), int(sopt), lib=_oracle.adapter_ba_emu())
+    assert rc == 0 and stats[3] == ref_stats[3] == 1.0
+    assert abs(stats[0] - ref_stats[0]) < 1e-9
+    assert abs(stats[1] - ref_stats[1]) < 1e-6 * max(1.0, ref_stats[1]), (stats[1], ref_stats[1])
+    if ref_stats[1] < 100:
+        assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(_golden()["ex_case_names"]))
+def test_functors_control_points_priors(name):
+    from tests.test_ba_gpu import _ex_case
+    z = _golden()
+    tag, sc = _ex_case(z, name)
+    iopt = int(name.split("|")[1])
+    ref_stats = z[f"{tag}/ref_stats"]
+    rc, stats, poses, intr, pts = _oracle.ref_ba_adjust_ex(sc, intrinsics_opt=iopt, lib=_oracle.adapter_ba_emu())
+    assert rc == 0 and stats[3] == ref_stats[3] == 1.0
+    assert abs(stats[0] - ref_stats[0]) < 1e-9
+    assert abs(stats[1] - ref_stats[1]) < 1e-6, (stats[1], ref_stats[1])
+    assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-5)
+    assert np.allclose(poses[:, 3:], z[f"{tag}/ref_poses"][:, 3:], atol=1e-5)
