@@ -1,0 +1,31 @@
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from openmvg_amd import matching, synth
+from tests import _emu, _oracle
+from tests.test_matching_gpu import run_hip
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t0=time.time(); n_cases=0; bad=0
+pools = [list(range(0,40)), list(range(250,264)), list(range(505,522)), [767,768,769,1023,1024,1025]]
+while time.time()-t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 240:
+    k = int(rng.integers(2,5))
+    sizes = [int(rng.choice(pools[int(rng.integers(0,len(pools)))])) for _ in range(k)]
+    mode = int(rng.integers(0,3))
+    if mode == 0: imgs = synth.random_descriptors(k, sizes, seed=int(rng.integers(1<<30)))
+    else:
+        imgs = synth.image_descriptors(k, n_desc=max(sizes+[1]), seed=int(rng.integers(1<<30)))
+        imgs = [d[:s] for d, s in zip(imgs, sizes)]
+    if mode == 2 and k >= 2 and min(sizes[0], sizes[1]) > 0:   # duplicates across images and inside one image
+        m = min(sizes[0], sizes[1]); imgs[1] = imgs[1].copy(); imgs[1][:m] = imgs[0][:m]
+        if sizes[1] > 3: imgs[1][1] = imgs[1][3]
+    pairs = np.array([(i,j) for i in range(k) for j in range(k) if i!=j], np.uint32)
+    ratio = float(rng.choice([0.6,0.8,0.95,1.0]))
+    variant = int(rng.choice([41,43,42,1]))
+    bp = int(rng.choice([0,1,3]))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
+    with _emu.emulated():
+        _, off, ij = run_hip(imgs, pairs, ratio, variant, bp or None)
+    ok = np.array_equal(off,o_off) and np.array_equal(ij,o_ij)
+    n_cases += 1
+    if not ok:
+        bad += 1; print("MISMATCH", sizes, mode, ratio, variant, bp, flush=True)
+print("cases", n_cases, "mismatches", bad)
