@@ -1755,6 +1755,10 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   int rc = mvgx::select_device(device);
   if (rc) return rc;
   auto* c = new mvgx_ba_ctx();
+  struct Guard {   // every early return below (allocation failure, bad product list) releases what was built so far
+    mvgx_ba_ctx* c;
+    ~Guard() { if (c) mvgx_ba_destroy(c); }
+  } guard{c};
   MVGX_HIP(hipGetDevice(&c->device));
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev0));
@@ -2025,6 +2029,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   tick("product lists upload (enqueue)");
   MVGX_HIP(hipStreamSynchronize(c->stream));
   tick("stream drain");
+  guard.c = nullptr;
   *out = c;
   return MVGX_OK;
 }

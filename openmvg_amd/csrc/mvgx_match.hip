@@ -1087,6 +1087,10 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
   int rc = mvgx::select_device(device);
   if (rc) return rc;
   auto* c = new mvgx_match_ctx();
+  struct Guard {   // an early return below releases what was created so far
+    mvgx_match_ctx* c;
+    ~Guard() { if (c) mvgx_match_destroy(c); }
+  } guard{c};
   MVGX_HIP(hipGetDevice(&c->device));
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev_total0));
@@ -1109,6 +1113,7 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  guard.c = nullptr;
   *out = c;
   return MVGX_OK;
 }
