@@ -131,3 +131,25 @@ def test_oneshot_sink_and_mirror():
         out = matching.PairWiseMatches()
         matching.Matcher_Regions(0.8, matching.EMatcherType.BRUTE_FORCE_L2).Match(prov, [tuple(p) for p in pairs], out)
     assert dict(out).keys() == want.keys() and all(np.array_equal(out[k], want[k]) for k in want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pair_shards_reproduce_the_single_rank_run(world):
+    """the pair list is cut into per-rank shards (sharding.shard_pairs, balanced by descriptor pairs), every
+    rank holds all descriptors and runs its shard with no collective; the shards' lists concatenated in rank order are the
+    single-rank lists (emulated device code, one context per rank)"""
+    from openmvg_amd import sharding
+    sizes = [90, 40, 0, 130, 75, 20]
+    imgs = synth.image_descriptors(len(sizes), n_desc=max(sizes), seed=19)
+    imgs = [d[:s] for d, s in zip(imgs, sizes)]
+    all_pairs = matching.exhaustive_pairs_array(len(sizes))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, all_pairs, 0.8)
+    got_pairs, got_ij, counts = [], [], []
+    with _emu.emulated():
+        for rank in range(world):
+            mine = np.ascontiguousarray(sharding.shard_pairs(all_pairs, sizes, rank, world))
+            _, off, ij = run_hip(imgs, mine, 0.8, 41)
+            got_pairs.append(mine); got_ij.append(ij); counts.append(np.diff(off))
+    assert np.array_equal(np.concatenate(got_pairs), all_pairs)          # contiguous shards, in order, covering every pair once
+    assert np.array_equal(np.concatenate(counts), np.diff(o_off))
+    assert np.array_equal(np.concatenate(got_ij), o_ij)
