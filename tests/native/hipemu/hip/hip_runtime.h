@@ -118,7 +118,14 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorUnknown; }
+// failure injection for the error paths: HIPEMU_FAIL_MALLOC_AFTER=n makes the (n+1)-th and later device allocations fail
+static inline bool hipemu_malloc_should_fail() {
+  static long seen = 0;
+  const char* env = getenv("HIPEMU_FAIL_MALLOC_AFTER");
+  if (!env) { seen = 0; return false; }
+  return seen++ >= atol(env);
+}
+static inline hipError_t hipMalloc(void** p, size_t n) { if (hipemu_malloc_should_fail()) { *p = nullptr; return hipErrorUnknown; } *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }

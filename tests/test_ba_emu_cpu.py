@@ -329,3 +329,38 @@ def test_structure_build_is_independent_of_the_host_thread_count(monkeypatch):
                 ctx.close()
             got.append((s.initial_cost, s.final_cost, s.final_rmse))
         assert got[0] == got[1]
+
+
+def test_allocation_failures_during_create_are_reported_not_fatal(monkeypatch):
+    """every early return of mvgx_ba_create / mvgx_match_create / the brute-force contexts releases the partially built
+    context (guard objects): with the emulation's allocation-failure injection the calls raise MvgxError - no crash, no
+    double free - wherever the failure lands, and a later healthy call still works"""
+    from openmvg_amd import _capi, matching
+    sc = synth.ba_scene(n_cams=4, n_points=20, track_len=3, model=3, n_intr_groups=2, seed=2)
+    imgs = synth.image_descriptors(3, n_desc=40, seed=1)
+    bins = synth.binary_descriptors(3, 40, seed=1)
+    pairs = matching.exhaustive_pairs_array(3)
+    failures = 0
+    with _emu.emulated():
+        for n in list(range(0, 40, 3)) + [55, 80, 110]:
+            monkeypatch.setenv("HIPEMU_FAIL_MALLOC_AFTER", str(n))
+            try:
+                ctx = ba.BaContext(sc); ctx.solve(); ctx.close()
+            except _capi.MvgxError:
+                failures += 1
+            monkeypatch.setenv("HIPEMU_FAIL_MALLOC_AFTER", str(n))
+            try:
+                m = matching.MatchContext(0); m.set_regions(imgs); m.run(pairs, np.float32(0.64)); m.close()
+            except _capi.MvgxError:
+                failures += 1
+            monkeypatch.setenv("HIPEMU_FAIL_MALLOC_AFTER", str(n))
+            try:
+                h = matching.HammingContext(); h.set_regions(bins, 64); h.run(pairs, 0.8); h.close()
+            except _capi.MvgxError:
+                failures += 1
+        monkeypatch.delenv("HIPEMU_FAIL_MALLOC_AFTER")
+        ctx = ba.BaContext(sc); s = ctx.solve(); ctx.close()
+        m = matching.MatchContext(0); m.set_regions(imgs); _, off, ij = m.run(pairs, np.float32(0.64)); m.close()
+    assert failures >= 20 and s.termination == 0
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij)
