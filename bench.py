@@ -70,13 +70,27 @@ def cpu_baseline(descs, pairs, ratio, budget_s):
     sample = pairs[order[:n]]
     dp = float(sum(len(descs[a]) * len(descs[b]) for a, b in sample))
     t0 = time.perf_counter()
-    fn(descs, sample, ratio)
+    lists = fn(descs, sample, ratio)
     dt = time.perf_counter() - t0
+    if kind == "port":   # (offsets, ij) -> {(I, J): (n, 2)} like the reference shim returns
+        lists = _oracle.offsets_to_dict(sample, *lists)
     cores = os.cpu_count() or 1
     if kind == "port":
         cores = _oracle.port().oracle_num_threads()
     return {"value": dp / dt, "unit": "descriptor pairs/s", "cores": int(cores), "kind": kind,
-            "sample": f"{n} random image pairs of the same set ({dp:.3g} descriptor pairs) in {dt:.1f} s"}
+            "sample": f"{n} random image pairs of the same set ({dp:.3g} descriptor pairs) in {dt:.1f} s"}, sample, lists
+
+
+def parity_on_sample(ctx, ratio_sq, sample, cpu_lists):
+    """"bit-exact comparison is done on the sampled pairs" - the device lists of the very pairs the CPU baseline
+    just matched (same context, same resident descriptors as the timed region) against the CPU lists, entry by entry."""
+    from tests import _oracle
+    _, offsets, ij = ctx.run(sample, ratio_sq, fetch=True)
+    gpu = _oracle.offsets_to_dict(sample, offsets, ij)
+    same = set(gpu) == set(cpu_lists) and all(np.array_equal(gpu[k], cpu_lists[k]) for k in gpu)
+    return {"pairs_checked": int(len(sample)), "non_empty_pairs": int(len(cpu_lists)),
+            "matches_checked": int(sum(len(v) for v in cpu_lists.values())), "identical": bool(same),
+            "against": "cpu_baseline lists (same run, same pairs)"}
 
 
 def main():
@@ -177,14 +191,17 @@ def main():
                          "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS,
                          "traffic": (HBM_BYTES_PER_IMAGE_PAIR_MEASURED * (args.desc / 2000.0) * len(pairs) * args.steps / max(launches, 1)
                                      if variant == 4 else None),
-                         "traffic_note": "HBM bytes per launch, PMC pass profiles/round1_match_traffic_pmc_call42.json scaled by pairs per launch",
+                         "traffic_measured_in_run": False,
+                         "traffic_note": "HBM bytes per launch, PMC pass profiles/round1_match_traffic_pmc_call42.json scaled by pairs per launch "
+                                         "(counters cannot be read inside this process)",
                          "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)
+                out["cpu_baseline"], sample, cpu_lists = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                out["parity"] = parity_on_sample(ctx, ratio_sq, sample, cpu_lists)
             except Exception as e:  # the baseline is a reported side figure; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}

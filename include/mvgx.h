@@ -31,7 +31,8 @@ extern "C" {
 
 const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
-/* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors) */
+/* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors;
+ * 3: mvgx_ba_get_solver_info) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -274,6 +275,24 @@ int mvgx_ba_residuals(mvgx_ba_ctx* ctx, double* residual_norm /* n_obs */);
  * than two observations: the quantity RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp:77-121) compares with
  * dMinAcceptedAngle - the second half of badTrackRejector (sequential_SfM.cpp:1226-1232). */
 int mvgx_ba_track_angles(mvgx_ba_ctx* ctx, double* max_angle_deg /* n_points */);
+
+/* How the reduced camera system of this context is solved (decided at the first iteration, on the union of the ranks'
+ * block patterns): the reference picks SPARSE_SCHUR above 100 poses (sfm/pipelines/sequential/sequential_SfM.cpp:1193-1205,
+ * ceres schur_complement_solver.cc:241-347); here a block-sparse tile Cholesky in a nested-dissection order is used
+ * whenever it needs fewer rounds of dependent launches than the dense sweep and no more tiles, the dense blocked Cholesky otherwise.
+ * MVGX_BA_SOLVER=dense|sparse (environment, read at create) forces either. */
+typedef struct mvgx_ba_solver_info {
+  int32_t sparse;          /* 1: block-sparse tile Cholesky, 0: dense                                              */
+  int32_t n_columns;       /* N = 6 n_poses + 8 n_intrinsics                                                       */
+  int32_t n_padded;        /* sparse: columns after padding every part of the dissection to a multiple of 64      */
+  int32_t n_parts;         /* sparse: parts of the nested dissection (incl. the dense border)                      */
+  int32_t n_border_blocks; /* sparse: camera blocks ordered last as dense border (e.g. shared intrinsics)          */
+  int32_t n_levels;        /* sparse: levels of the tile elimination tree = rounds of dependent launches           */
+  int64_t n_factor_tiles;  /* 64 x 64 tiles of the factor's lower triangle (dense: nt (nt + 1) / 2)                */
+  int64_t n_dense_tiles;   /* nt (nt + 1) / 2 with nt = ceil(N / 64)                                               */
+  double flops;            /* floating-point operations of one factorisation + solve on the stored tiles           */
+} mvgx_ba_solver_info;
+int mvgx_ba_get_solver_info(mvgx_ba_ctx* ctx, mvgx_ba_solver_info* out);   /* MVGX_ERR_STATE before the first iteration */
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,14 @@ class BaSummary(C.Structure):
     ]
 
 
+class BaSolverInfo(C.Structure):
+    _fields_ = [
+        ("sparse", C.c_int32), ("n_columns", C.c_int32), ("n_padded", C.c_int32), ("n_parts", C.c_int32),
+        ("n_border_blocks", C.c_int32), ("n_levels", C.c_int32), ("n_factor_tiles", C.c_int64), ("n_dense_tiles", C.c_int64),
+        ("flops", C.c_double),
+    ]
+
+
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
 ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
 MVGX_REDUCE_SUM, MVGX_REDUCE_MAX = 0, 1
@@ -147,6 +155,7 @@ PROTOTYPES = {
     "mvgx_ba_evaluate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mvgx_ba_residuals": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvgx_ba_track_angles": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mvgx_ba_get_solver_info": (C.c_int, [C.c_void_p, C.POINTER(BaSolverInfo)]),
 }
 
 _lib = None

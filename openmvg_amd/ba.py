@@ -139,6 +139,12 @@ class BaContext:
         _capi.check(_capi.lib().mvgx_ba_track_angles(self._h, out.ctypes.data))
         return out
 
+    def solver_info(self):
+        """how the reduced camera system is solved (mvgx_ba_get_solver_info; valid after the first iteration)"""
+        info = _capi.BaSolverInfo()
+        _capi.check(_capi.lib().mvgx_ba_get_solver_info(self._h, C.byref(info)))
+        return info
+
     def read_params(self):
         npz, ni, nx = self.shape
         poses = np.zeros((npz, 6)); intr = np.zeros((ni, 8)); pts = np.zeros((nx, 3))

@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "ba_math.h"
+#include "ba_sparse_plan.h"
 #include "mvgx_comm.h"
 #include "mvgx_common.h"
 
@@ -83,6 +84,24 @@ struct TripList {
   uint32_t* block_chunk0 = nullptr;   // n_blocks + 1
   int32_t* block_own = nullptr;       // pose x intrinsic lists: the (pose, intrinsic) pair whose Fc^T Fi adds in, or -1
   double* part = nullptr;             // n_chunks x (WA * WB + WA)
+};
+
+// Block-sparse storage of the reduced camera system (ba_sparse_plan.h): 64 x 64 tiles of the permuted, padded matrix,
+// lower triangle, only the tiles that are non-zero in S or fill in its factor; tile row nT carries the rhs (row 0 of each
+// of its tiles). Inside a tile element (r, c) lives at c * 64 + r.
+struct SpSys {
+  int enabled = 0;
+  int nT = 0, n_slots = 0, n_levels = 0;
+  const int32_t* pcol = nullptr;      // N: original scalar column -> padded permuted column
+  const int32_t* tmap = nullptr;      // (nT + 1) x nT: tile (I, J), I >= J -> slot, -1 = structurally zero
+  const int32_t* tile_kb = nullptr;   // nT: valid columns of a diagonal tile (the rest is identity padding)
+  double* A = nullptr;                // n_slots x 4096: S, updated in place by the sweep
+  double* L = nullptr;                // n_slots x 4096: the factor's tiles below the diagonal and the forward-substituted rhs
+  double* Linv = nullptr;             // nT x 4096: inverses of the diagonal factor tiles
+  double* z = nullptr;                // nT x 64: solution in padded order
+  const mvgx_sparse::GemmTask *t_tasks = nullptr, *u_tasks = nullptr;
+  const mvgx_sparse::SlotPair *t_pairs = nullptr, *u_pairs = nullptr;
+  const int32_t *f_cols = nullptr, *bs_start = nullptr, *bs_slot = nullptr, *bs_row = nullptr;
 };
 
 struct Dev {
@@ -124,7 +143,8 @@ struct Dev {
   double *Linv3 = nullptr, *hp = nullptr;   // per point: L_p^-1 (6, lower) and h_p = L_p^-1 Es^T r (3)
   double *Zpose = nullptr, *Zint = nullptr; // n_obs x 18, n_islots x 24
   TripList tpp, tpi, tii;
-  double* S = nullptr;                // N x LD
+  double* S = nullptr;                // N x LD (dense mode only)
+  SpSys sp;                           // block-sparse mode
   // multi-rank exchange of S: the union over ranks of the non-zero camera blocks, packed contiguously (+ the rhs column)
   uint32_t n_ublocks = 0;
   uint64_t n_packed = 0;
@@ -174,6 +194,17 @@ __device__ __forceinline__ void load_rec(const double* __restrict__ p, double* v
   const double2* __restrict__ q = reinterpret_cast<const double2*>(p);
 #pragma unroll
   for (int k = 0; k < N / 2; ++k) { const double2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+}
+
+// Element (row, col) of the reduced system, row <= col in the original numbering, col == N: the rhs. Dense mode: the
+// row-major upper triangle (= column-major lower, what the dense Cholesky reads). Sparse mode: the tile of the permuted matrix.
+__device__ __forceinline__ double* sys_elem(const Dev& d, int row, int col) {
+  if (!d.sp.enabled) return d.S + (size_t)row * d.LD + col;
+  const int pr = d.sp.pcol[row];
+  if (col == d.N) return d.sp.A + (size_t)d.sp.tmap[(size_t)d.sp.nT * d.sp.nT + (pr >> 6)] * 4096 + (size_t)(pr & 63) * 64;
+  const int pc = d.sp.pcol[col];
+  const int hi = pr > pc ? pr : pc, lo = pr > pc ? pc : pr;
+  return d.sp.A + (size_t)d.sp.tmap[(size_t)(hi >> 6) * d.sp.nT + (lo >> 6)] * 4096 + (size_t)(lo & 63) * 64 + (hi & 63);
 }
 
 // out[k] = sum_i part[i * stride + k], k < nk (single block; deterministic order)
@@ -662,11 +693,12 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
     } else {
       if (diag) own = d.igram[(size_t)(rcb - np) * kIntrGram + tri8(lo, hi)];
     }
-    d.S[(size_t)(row0 + r) * d.LD + (col0 + c)] = own * d.scale_cam[row0 + r] * d.scale_cam[col0 + c] - sum;
+    if (diag && r > c) return;   // the upper triangle of a diagonal block is the whole block (sparse mode: one home per element)
+    *sys_elem(d, row0 + r, col0 + c) = own * d.scale_cam[row0 + r] * d.scale_cam[col0 + c] - sum;
   } else {
     const int r = e - WA * WB;
     const double g = KIND == 0 ? d.pose_gram[(size_t)rcb * kPoseGram + 21 + r] : d.igram[(size_t)(rcb - np) * kIntrGram + 36 + r];
-    d.S[(size_t)(row0 + r) * d.LD + d.N] = g * d.scale_cam[row0 + r] - sum;
+    *sys_elem(d, row0 + r, d.N) = g * d.scale_cam[row0 + r] - sum;
   }
 }
 
@@ -686,7 +718,7 @@ __global__ __launch_bounds__(64) void ba_pack_system_kernel(Dev d, int dir) {
   if (b == d.n_ublocks) {
     double* pk = d.packed + (d.n_packed - (uint64_t)d.N);
     for (int i = t; i < d.N; i += 64) {
-      double* sp = d.S + (size_t)i * d.LD + d.N;
+      double* sp = sys_elem(d, i, d.N);
       if (dir == 0) pk[i] = *sp; else *sp = pk[i];
     }
     return;
@@ -694,7 +726,11 @@ __global__ __launch_bounds__(64) void ba_pack_system_kernel(Dev d, int dir) {
   const int h = d.ublk_h[b], w = d.ublk_w[b];
   if (t >= h * w) return;
   const int r = t / w, c = t - r * w;
-  double* sp = d.S + (size_t)(d.ublk_row[b] + r) * d.LD + (d.ublk_col[b] + c);
+  if (d.ublk_row[b] == d.ublk_col[b] && r > c) {   // lower triangle of a diagonal block: not part of the system
+    if (dir == 0) d.packed[d.ublk_off[b] + t] = 0.0;
+    return;
+  }
+  double* sp = sys_elem(d, (int)d.ublk_row[b] + r, (int)d.ublk_col[b] + c);
   double* pk = d.packed + d.ublk_off[b] + t;
   if (dir == 0) *pk = *sp; else *sp = *pk;
 }
@@ -704,12 +740,12 @@ __global__ __launch_bounds__(64) void ba_pack_system_kernel(Dev d, int dir) {
 __global__ __launch_bounds__(256) void ba_finish_system_kernel(Dev d, double inv_radius) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= d.N) return;
-  const size_t dd = (size_t)row * d.LD + row;
+  double* dd = sys_elem(d, row, row);
   if (d.cam_active[row]) {
-    d.S[dd] += d.diag_cam[row] * inv_radius;
+    *dd += d.diag_cam[row] * inv_radius;
   } else {
-    d.S[dd] = 1.0;
-    d.S[(size_t)row * d.LD + d.N] = 0.0;
+    *dd = 1.0;
+    *sys_elem(d, row, d.N) = 0.0;
   }
 }
 __global__ void ba_pack_fail_kernel(Dev d) { d.scalars[kSFail] = (double)*d.fail; }
@@ -740,9 +776,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // sr
 // Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
 // processed as four 64 x 16 column panels: a register-resident panel factorisation by one wave, then a rank-16 update
 // of the remaining columns by all four. The inverse is built from the 16 x 16 diagonal blocks outwards.
-__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb,
-                                                            double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+// kDense: the factor goes back into A and the inverse is stored twice (k-major for the panel GEMM, row-major for the
+// back substitution); otherwise (block-sparse solver) only the k-major inverse is kept.
+template <bool kDense>
+__device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int ld, int k0, int kb,
+                                                   double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail,
+                                                   double* lds) {
   double (*L)[kLS] = reinterpret_cast<double (*)[kLS]>(lds);
   double (*Li)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 64 * kLS);
   double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);
@@ -847,10 +886,90 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
   }
   for (int q = tid; q < 4096; q += 256) {
     const int c = q >> 6, r = q & 63;
-    if (r < kb && c < kb && r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
+    if (kDense && r < kb && c < kb && r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
     linv[q] = Li[r][c];                  // k-major: linv[k = c][col = r] = Linv[r][c]
-    linv[4096 + q] = Li[q >> 6][q & 63]; // row-major
+    if (kDense) linv[4096 + q] = Li[q >> 6][q & 63]; // row-major
   }
+}
+__global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb, double* __restrict__ linv, int* fail) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  chol_diag_inv_body<true>(A, ld, k0, kb, linv, fail, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Block-sparse Cholesky of the reduced camera system (symbolic phase: ba_sparse_plan.h). One level of the elimination
+// tree of the tile columns per round of launches: F factors + inverts the diagonal tiles of the level, T forms the tiles
+// below them, U applies their outer products to the tiles of later columns. A wave owns one 16 x 16 sub-block of a
+// destination tile and walks its contributors in a fixed order: operands go straight from L2 into the f64 MFMA (the
+// tiles are stored so that an operand fragment is 16 consecutive doubles), no LDS, no barriers, no atomics.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_factor_kernel(SpSys s, int f0, int* fail) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int k = s.f_cols[f0 + blockIdx.x];
+  double* A = s.A + (size_t)s.tmap[(size_t)k * s.nT + k] * 4096;
+  chol_diag_inv_body<false>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds);
+}
+
+// kUpdate false: T, dst(L) = X(A) Linv_k^T (only the q <= column part of the triangular inverse is walked);
+// kUpdate true:  U, dst(A) -= sum over contributors X(L) Y(L)^T.
+template <bool kUpdate>
+__global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tasks) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int t = (int)blockIdx.x * 4 + wave;
+  if (t >= n_tasks) return;   // wave-uniform
+  const mvgx_sparse::GemmTask g = (kUpdate ? s.u_tasks : s.t_tasks)[t0 + t];
+  const mvgx_sparse::SlotPair* __restrict__ pairs = kUpdate ? s.u_pairs : s.t_pairs;
+  d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+  const int ksteps = kUpdate ? 16 : 4 * (g.bj + 1);
+  for (int c = g.c0; c < g.c1; ++c) {
+    const mvgx_sparse::SlotPair p = pairs[c];
+    // lane (li, lk) feeds X[16 bi + li][4 ks + lk] and Y[16 bj + li][4 ks + lk]; element (r, q) of a tile sits at q * 64 + r
+    const double* __restrict__ X = (kUpdate ? s.L : s.A) + (size_t)p.a * 4096 + 16 * g.bi + li + lk * 64;
+    const double* __restrict__ Y = (kUpdate ? s.L : s.Linv) + (size_t)p.b * 4096 + 16 * g.bj + li + lk * 64;
+    double xv[16], yv[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      xv[ks] = ks < ksteps ? X[ks * 256] : 0.0;
+      yv[ks] = ks < ksteps ? Y[ks * 256] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[ks], xv[ks], acc, 0, 0, 0);   // D[c][r]: stores coalesce along r
+  }
+  double* __restrict__ dst = (kUpdate ? s.A : s.L) + (size_t)g.dst * 4096 + (size_t)(16 * g.bj + lk) * 64 + 16 * g.bi + li;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    if (kUpdate) dst[reg * 256] -= acc[reg]; else dst[reg * 256] = acc[reg];
+  }
+}
+
+// Reverse sweep, one workgroup per tile column of the level: z_k = Linv_k^T (y_k - sum over the tiles below L_ik^T z_i).
+__global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
+  __shared__ double w[64];
+  const int k = s.f_cols[f0 + blockIdx.x];
+  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
+  double v = 0;
+  for (int e = s.bs_start[k]; e < s.bs_start[k + 1]; ++e) {
+    const double* __restrict__ tile = s.L + (size_t)s.bs_slot[e] * 4096 + c * 64 + part * 16;
+    const double* __restrict__ zi = s.z + (size_t)s.bs_row[e] * 64 + part * 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += tile[q] * zi[q];
+  }
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  if (part == 0) w[c] = s.L[(size_t)s.tmap[(size_t)s.nT * s.nT + k] * 4096 + c * 64] - v;   // y_k[c]: row 0 of the rhs tile
+  __syncthreads();
+  const double* __restrict__ li = s.Linv + (size_t)k * 4096 + c * 64 + part * 16;   // Linv[q][c] at c * 64 + q
+  double u = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) u += li[q] * w[part * 16 + q];
+  u += __shfl_xor(u, 1);
+  u += __shfl_xor(u, 2);
+  if (part == 0) s.z[(size_t)k * 64 + c] = u;
+}
+__global__ void sp_gather_solution_kernel(Dev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.N) d.zsol[i] = d.sp.z[d.sp.pcol[i]];
 }
 
 // 32 x 32 sub-tile of D[c][r] = sum_k Q[k][c] P[k][r] on one wave: 2 x 2 MFMA blocks, MFMA row index = c, column = r.
@@ -1328,6 +1447,11 @@ struct mvgx_ba_ctx {
   bool finished = false;
   double initial_cost = 0, initial_rmse = 0;
   int grid_obs = 0, grid_vec = 0;
+  // reduced-system solver: block-sparse (tile) Cholesky with a nested-dissection order, or the dense one (auto: by fill)
+  std::vector<std::pair<uint32_t, uint32_t>> h_blocks;   // non-zero camera blocks of this rank's S (row block, col block)
+  bool solver_ready = false;
+  int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
+  mvgx_sparse::Plan plan;          // host copy of the schedule (launch geometry per level)
   int update128_min_tiles = 128;   // tuning (MVGX_BA_UPDATE128_MIN_TILES): deferred updates with at least this many 128 x 128 tiles use them
   int two_level_min_n = 2048;   // tuning (MVGX_BA_TWO_LEVEL_MIN_N): reduced systems at least this wide factor with 256-column outer panels
   // phase timing (MVGX_BA_PHASE_TIMING=1 at create): HIP events around the five phases of an iteration, summed into phase_ms
@@ -1441,7 +1565,8 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   if (d.n_obs) hipLaunchKernelGGL(ba_obs_z_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d);
   if (d.n_islots) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
-  MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
+  if (d.sp.enabled) MVGX_HIP(hipMemsetAsync(d.sp.A, 0, (size_t)d.sp.n_slots * 4096 * sizeof(double), c->stream));
+  else MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   if (d.tpp.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
   if (d.tpi.n_chunks)
@@ -1463,9 +1588,27 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 // C3 and 1.5 % faster on C5 - the cross-stream dependencies cost what the overlap gains; replaying the same sequence
 // as a captured HIP graph cost 4-16 ms of instantiation per context, more than a whole small solve. An update kernel on
 // 128 x 128 tiles (64 x 64 per wave) was 2.1x slower per launch than the 64 x 64 one at C5 (profiles/round1_ba_c5_update128_call18.json).
+int factor_and_solve_sparse(mvgx_ba_ctx* c) {
+  Dev& d = c->d;
+  const mvgx_sparse::Plan& pl = c->plan;
+  for (int l = 0; l < pl.n_levels; ++l) {
+    const int nf = pl.f_start[l + 1] - pl.f_start[l], nt = pl.t_start[l + 1] - pl.t_start[l], nu = pl.u_start[l + 1] - pl.u_start[l];
+    hipLaunchKernelGGL(sp_factor_kernel, dim3(nf), dim3(256), kDiagLds, c->stream, d.sp, pl.f_start[l], d.fail);
+    if (nt) hipLaunchKernelGGL(sp_gemm_kernel<false>, dim3((nt + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.t_start[l], nt);
+    if (nu) hipLaunchKernelGGL(sp_gemm_kernel<true>, dim3((nu + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.u_start[l], nu);
+  }
+  BA_LAUNCH_CHECK();
+  for (int l = pl.n_levels - 1; l >= 0; --l)
+    hipLaunchKernelGGL(sp_backsolve_kernel, dim3(pl.f_start[l + 1] - pl.f_start[l]), dim3(256), 0, c->stream, d.sp, pl.f_start[l]);
+  hipLaunchKernelGGL(sp_gather_solution_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d);
+  BA_LAUNCH_CHECK();
+  return MVGX_OK;
+}
+
 int factor_and_solve(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   if (!d.N) return MVGX_OK;
+  if (d.sp.enabled) return factor_and_solve_sparse(c);
   // two-level blocking: outer panels of pw columns; inside a panel the classic 64-column steps update only the panel's
   // own columns, the rest of the trailing matrix gets one update per panel with K = pw. The trailing matrix is read and
   // written N / pw times instead of N / 64 (C5: the update is bound by that traffic). Small systems are launch-latency
@@ -1502,14 +1645,36 @@ int factor_and_solve(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
-// One-time (per solve) agreement on the union of non-zero camera blocks across ranks; see ba_mark_blocks_kernel.
-int setup_block_exchange(mvgx_ba_ctx* c) {
+// One-time agreement across ranks, before the first iteration:
+//  * which camera components are free parameters with residuals SOMEWHERE (a pose or intrinsic whose observations all live
+//    on other ranks is still part of the program: its Jacobi scale, LM diagonal and x-norm share must be the same on
+//    every rank, or the ranks would factor different systems);
+//  * the union of the non-zero camera blocks of S (see ba_mark_blocks_kernel): the packed layout of the per-iteration
+//    exchange and the pattern the block-sparse solver is planned on.
+__global__ void ba_masks_f64_kernel(Dev d, double* __restrict__ buf, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.N) return;
+  if (dir == 0) { buf[i] = d.cam_active[i]; buf[d.N + i] = d.cam_counts[i]; }
+  else { d.cam_active[i] = buf[i] != 0.0; d.cam_counts[i] = buf[d.N + i] != 0.0; }
+}
+
+int setup_block_exchange(mvgx_ba_ctx* c, std::vector<std::pair<uint32_t, uint32_t>>& blocks) {
   Dev& d = c->d;
+  blocks = c->h_blocks;
   if (!multi_rank(c) || d.ublk_off) return MVGX_OK;
+  int rc;
+  if (d.N) {
+    double* masks = nullptr;
+    if ((rc = dev_alloc(c->pool, &masks, (size_t)2 * d.N))) return rc;
+    hipLaunchKernelGGL(ba_masks_f64_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, masks, 0);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, masks, (uint64_t)2 * d.N, MVGX_REDUCE_MAX))) return rc;
+    hipLaunchKernelGGL(ba_masks_f64_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, masks, 1);
+    BA_LAUNCH_CHECK();
+  }
   const int n_cb = (int)d.n_poses + (int)d.n_intr;
   double* flags = nullptr;
-  int rc = dev_alloc(c->pool, &flags, (size_t)n_cb * n_cb);
-  if (rc) return rc;
+  if ((rc = dev_alloc(c->pool, &flags, (size_t)n_cb * n_cb))) return rc;
   MVGX_HIP(hipMemsetAsync(flags, 0, (size_t)n_cb * n_cb * sizeof(double), c->stream));
   if (d.tpp.n_blocks) hipLaunchKernelGGL(ba_mark_blocks_kernel<0>, dim3((d.tpp.n_blocks + 255) / 256), dim3(256), 0, c->stream, d, d.tpp, flags, n_cb);
   if (d.tpi.n_blocks) hipLaunchKernelGGL(ba_mark_blocks_kernel<1>, dim3((d.tpi.n_blocks + 255) / 256), dim3(256), 0, c->stream, d, d.tpi, flags, n_cb);
@@ -1525,9 +1690,11 @@ int setup_block_exchange(mvgx_ba_ctx* c) {
   uint64_t off = 0;
   auto first = [&](int cb) { return cb < (int)d.n_poses ? 6 * cb : 6 * (int)d.n_poses + 8 * (cb - (int)d.n_poses); };
   auto width = [&](int cb) { return cb < (int)d.n_poses ? 6 : 8; };
+  blocks.clear();
   for (int r = 0; r < n_cb; ++r)
     for (int q = r; q < n_cb; ++q)
       if (h[(size_t)r * n_cb + q] != 0.0) {
+        blocks.emplace_back((uint32_t)r, (uint32_t)q);
         brow.push_back((uint32_t)first(r)); bcol.push_back((uint32_t)first(q));
         bh.push_back((uint8_t)width(r)); bw.push_back((uint8_t)width(q));
         boff.push_back(off);
@@ -1543,6 +1710,70 @@ int setup_block_exchange(mvgx_ba_ctx* c) {
   if ((rc = dev_upload(c->pool, &d.ublk_off, boff, c->stream))) return rc;
   if ((rc = dev_alloc(c->pool, &d.packed, (size_t)d.n_packed))) return rc;
   MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+// Reduced-system solver, chosen once per context on the (union) block pattern: block-sparse tile Cholesky in a nested-
+// dissection order when it needs fewer rounds of dependent launches than the dense sweep has block steps and no more tiles
+// than the dense triangle, the dense blocked Cholesky otherwise.
+// MVGX_BA_SOLVER=dense|sparse forces either; MVGX_BA_ND_LEAF_COLS tunes the dissection depth.
+int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& blocks) {
+  Dev& d = c->d;
+  if (c->solver_ready) return MVGX_OK;
+  int rc;
+  bool sparse = false;
+  const uint32_t np = d.n_poses;
+  if (d.N > 0 && c->solver_mode != 1) {
+    mvgx_sparse::PlanParams prm;
+    if (const char* env = getenv("MVGX_BA_ND_LEAF_COLS")) prm.leaf_cols = std::max(64, atoi(env));
+    const bool ok = mvgx_sparse::build_plan(
+        (int)(np + d.n_intr), d.N, blocks, [&](int cb) { return cb < (int)np ? 6 : 8; },
+        [&](int cb) { return cb < (int)np ? 6 * cb : 6 * (int)np + 8 * (cb - (int)np); }, prm, (uint64_t)1 << 25, c->plan);
+    const uint64_t nd = (uint64_t)((d.N + 63) / 64);
+    sparse = ok && (c->solver_mode == 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
+    MVGX_REQUIRE(ok || c->solver_mode != 2, MVGX_ERR_UNSUPPORTED, "MVGX_BA_SOLVER=sparse: the reduced system fills too much for the task lists");
+  }
+  if (sparse) {
+    const mvgx_sparse::Plan& pl = c->plan;
+    SpSys& s = d.sp;
+    s.nT = pl.nT; s.n_slots = pl.n_slots; s.n_levels = pl.n_levels;
+    int32_t *pcol = nullptr, *tmap = nullptr, *tile_kb = nullptr, *f_cols = nullptr, *bs_start = nullptr, *bs_slot = nullptr, *bs_row = nullptr;
+    mvgx_sparse::GemmTask *tt = nullptr, *ut = nullptr;
+    mvgx_sparse::SlotPair *tp = nullptr, *up = nullptr;
+    if ((rc = dev_upload(c->pool, &pcol, pl.pcol, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &tmap, pl.tmap, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &tile_kb, pl.tile_kb, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &f_cols, pl.f_cols, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &bs_start, pl.bs_start, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &bs_slot, pl.bs_slot, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &bs_row, pl.bs_row, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &tt, pl.t_tasks, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &ut, pl.u_tasks, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &tp, pl.t_pairs, c->stream))) return rc;
+    if ((rc = dev_upload(c->pool, &up, pl.u_pairs, c->stream))) return rc;
+    s.pcol = pcol; s.tmap = tmap; s.tile_kb = tile_kb; s.f_cols = f_cols; s.bs_start = bs_start; s.bs_slot = bs_slot; s.bs_row = bs_row;
+    s.t_tasks = tt; s.u_tasks = ut; s.t_pairs = tp; s.u_pairs = up;
+    if ((rc = dev_alloc(c->pool, &s.A, (size_t)pl.n_slots * 4096))) return rc;
+    if ((rc = dev_alloc(c->pool, &s.L, (size_t)pl.n_slots * 4096))) return rc;
+    if ((rc = dev_alloc(c->pool, &s.Linv, (size_t)pl.nT * 4096))) return rc;
+    if ((rc = dev_alloc(c->pool, &s.z, (size_t)pl.nT * 64))) return rc;
+    // rows 1..63 of the rhs tiles and the padding are never written: zero once
+    MVGX_HIP(hipMemsetAsync(s.L, 0, (size_t)pl.n_slots * 4096 * sizeof(double), c->stream));
+    MVGX_HIP(hipMemsetAsync(s.z, 0, (size_t)pl.nT * 64 * sizeof(double), c->stream));
+    MVGX_HIP(hipStreamSynchronize(c->stream));   // the host vectors behind the uploads are the plan's: keep until here anyway
+    s.enabled = 1;
+  } else if (d.N > 0) {
+    const size_t bytes = (size_t)d.N * d.LD * sizeof(double) + (size_t)((d.N + 63) / 64) * 8192 * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    MVGX_HIP(hipMemGetInfo(&free_b, &total_b));
+    MVGX_REQUIRE(bytes < free_b, MVGX_ERR_UNSUPPORTED,
+                 "reduced camera system of %d columns: its factor fills more than half of the dense triangle, and the dense "
+                 "storage (%.1f GB) exceeds the free device memory (%.1f GB); the reference would use an iterative Schur "
+                 "solver here, which this library does not provide", d.N, bytes / 1e9, free_b / 1e9);
+    if ((rc = dev_alloc(c->pool, &d.S, (size_t)d.N * d.LD))) return rc;
+    if ((rc = dev_alloc(c->pool, &d.linv, (size_t)((d.N + 63) / 64) * 8192))) return rc;
+  }
+  c->solver_ready = true;
   return MVGX_OK;
 }
 
@@ -1639,7 +1870,11 @@ double rmse_from(const mvgx_ba_ctx* c) {
 int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   int rc = global_obs_count(c);
   if (rc) return rc;
-  if ((rc = setup_block_exchange(c))) return rc;
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;
+    if ((rc = setup_block_exchange(c, blocks))) return rc;
+    if ((rc = setup_solver(c, blocks))) return rc;
+  }
   if ((rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts))) return rc;
   if ((rc = read_scalars(c))) return rc;
   c->initial_rmse = rmse_from(c);
@@ -1771,6 +2006,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
   c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
+  if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
@@ -1945,6 +2181,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           }
         }, hii))) return rc;
   }
+  for (const TripHost* h : {&hpp, &hpi, &hii})
+    for (size_t b = 0; b < h->block_row.size(); ++b) c->h_blocks.emplace_back(h->block_row[b], h->block_col[b]);
   tick("pose-intr / intr-intr products");
   // active / counted camera components
   std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
@@ -1994,8 +2232,6 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(igram_part, (size_t)d.n_igchunks * kIntrGram); AL(igram, (size_t)d.n_intr * kIntrGram);
   AL(Linv3, (size_t)d.n_pts * 6); AL(hp, (size_t)d.n_pts * 3);
   AL(Zpose, (size_t)no * 18); AL(Zint, (size_t)d.n_islots * 24);
-  AL(S, (size_t)d.N * d.LD);
-  AL(linv, (size_t)((d.N + 63) / 64) * 8192);
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
   tick("large scratch allocations");
   {
@@ -2021,9 +2257,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 #undef UP
 #undef AL
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
-  MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kUpd128Lds));
   tick("product lists upload (enqueue)");
@@ -2144,6 +2380,24 @@ int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
   BA_LAUNCH_CHECK();
   MVGX_HIP(hipMemcpyAsync(max_angle_deg, out, (size_t)d.n_pts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {
+  MVGX_REQUIRE(c && out, MVGX_ERR_ARG, "mvgx_ba_get_solver_info: NULL argument");
+  MVGX_REQUIRE(c->solver_ready, MVGX_ERR_STATE, "mvgx_ba_get_solver_info before the first iteration");
+  memset(out, 0, sizeof(*out));
+  const int64_t nd = (c->d.N + 63) / 64;
+  out->n_columns = c->d.N;
+  out->n_dense_tiles = nd * (nd + 1) / 2;
+  if (c->d.sp.enabled) {
+    const mvgx_sparse::Plan& pl = c->plan;
+    out->sparse = 1; out->n_padded = pl.N_pad; out->n_parts = pl.n_parts; out->n_border_blocks = pl.n_border_blocks;
+    out->n_levels = pl.n_levels; out->n_factor_tiles = (int64_t)pl.n_fill_tiles; out->flops = pl.flops;
+  } else {
+    out->n_padded = c->d.N; out->n_factor_tiles = out->n_dense_tiles; out->n_levels = (int32_t)nd;
+    out->flops = (double)c->d.N * c->d.N * c->d.N / 3.0 + 2.0 * (double)c->d.N * c->d.N;
+  }
   return MVGX_OK;
 }
 

@@ -127,6 +127,7 @@ static inline bool hipemu_malloc_should_fail() {
 }
 static inline hipError_t hipMalloc(void** p, size_t n) { if (hipemu_malloc_should_fail()) { *p = nullptr; return hipErrorUnknown; } *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)64 << 30; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

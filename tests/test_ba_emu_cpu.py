@@ -126,6 +126,50 @@ def test_two_point_shards_reproduce_the_single_rank_solve():
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+def _run_two_ranks(sc, owner, opt):
+    world = 2
+    tr = _HostAllReduce(world)
+    out = [None] * world
+
+    def run(rank):
+        shard, mine = sharding.shard_ba_scene(sc, rank, world, owner)
+        c = ba.BaContext(shard)
+        c.set_allreduce(tr.make(rank))
+        s = c.solve(ba.default_options(**opt))
+        poses, intr, pts = c.read_params()
+        c.close()
+        out[rank] = (s, poses, intr, pts, mine)
+
+    with _emu.emulated():
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(600)
+    assert all(o is not None for o in out)
+    return out
+
+
+def test_a_camera_observed_on_one_rank_only_is_still_in_every_ranks_program():
+    """round-1 advisor finding: every point seen by pose 0 lives on rank 0, so rank 1 has no residual on pose 0 (and none on
+    intrinsic 0's ... pose 0 column block). Its 'free parameter with residuals' masks must come from all ranks, or rank 1
+    overwrites the block's diagonal with 1 and the ranks factor different systems."""
+    sc = synth.ba_scene(n_cams=8, n_points=160, track_len=5, model=3, n_intr_groups=2, seed=92)
+    opt = dict(max_num_iterations=4)
+    ref, rposes, rintr, rpts = _solve_emu(sc, ba.default_options(**opt))
+    sees0 = np.zeros(sc["n_points"], bool)
+    sees0[sc["obs_point"][sc["obs_pose"] == 0]] = True
+    owner = np.where(sees0, 0, 1).astype(np.int32)
+    rest = np.flatnonzero(~sees0)
+    owner[rest[::3]] = 0   # rank 0 also gets a share of the other points
+    assert not np.any(sc["obs_pose"][owner[sc["obs_point"]] == 1] == 0)
+    out = _run_two_ranks(sc, owner, opt)
+    for s, poses, intr, p, mine in out:
+        assert s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
+        assert np.allclose(poses, rposes, atol=1e-9) and np.allclose(intr, rintr, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
 @pytest.mark.parametrize("model", [4, 5, 7])
 def test_brown_fisheye_spherical_functors(model):
     sc = synth.ba_scene(n_cams=6, n_points=60, track_len=4, model=model, n_intr_groups=2, seed=70 + model, rot_deg=0.3)
@@ -364,3 +408,69 @@ def test_allocation_failures_during_create_are_reported_not_fatal(monkeypatch):
     assert failures >= 20 and s.termination == 0
     o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
     assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij)
+
+
+# ---- block-sparse reduced camera system (ba_sparse_plan.h + the sp_* kernels) ---------------------------------------------
+def _solve_emu_info(sc, options=None):
+    with _emu.emulated():
+        ctx = ba.BaContext(sc)
+        s = ctx.solve(options)
+        info = ctx.solver_info()
+        poses, intr, pts = ctx.read_params()
+        ctx.close()
+    return s, info, poses, intr, pts
+
+
+@pytest.mark.parametrize("leaf_cols", [64, 192])
+def test_block_sparse_solver_on_a_ring_equals_dense_and_oracle(monkeypatch, leaf_cols):
+    """72 cameras on rings, tracks of 4 consecutive cameras, 3 shared intrinsics: S is a cyclic band + a dense border. The
+    nested dissection must cut it into several parts (parallel levels), the shared intrinsics must go to the border, and the
+    LM trajectory must equal the dense solver's and the oracle's."""
+    sc = synth.ba_scene(n_cams=72, n_points=500, track_len=4, model=3, n_intr_groups=3, seed=71)
+    opt = dict(max_num_iterations=3)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
+    monkeypatch.setenv("MVGX_BA_SOLVER", "dense")
+    sd, info_d, pd, idn, xd = _solve_emu_info(sc, ba.default_options(**opt))
+    assert info_d.sparse == 0
+    monkeypatch.setenv("MVGX_BA_SOLVER", "sparse")
+    monkeypatch.setenv("MVGX_BA_ND_LEAF_COLS", str(leaf_cols))
+    ss, info, ps, isn, xs = _solve_emu_info(sc, ba.default_options(**opt))
+    assert info.sparse == 1 and info.n_border_blocks == 3 and info.n_columns == 6 * 72 + 8 * 3
+    assert info.n_parts >= (7 if leaf_cols == 64 else 3) and info.n_levels < info.n_padded // 64
+    assert ss.num_iterations == sd.num_iterations == osum.num_iterations == 3
+    for s in (ss, sd):
+        assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert np.allclose(xs, xd, atol=1e-10) and np.allclose(ps, pd, atol=1e-10) and np.allclose(isn, idn, rtol=1e-10, atol=1e-10)
+    assert np.allclose(xs, opx, atol=1e-9) and np.allclose(ps, opp, atol=1e-9) and np.allclose(isn, opi, rtol=1e-9, atol=1e-9)
+
+
+def test_block_sparse_solver_is_the_default_when_the_factor_is_sparse():
+    sc = synth.ba_scene(n_cams=120, n_points=700, track_len=4, model=1, n_intr_groups=1, seed=72)
+    opt = dict(max_num_iterations=1)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
+    s, info, poses, intr, pts = _solve_emu_info(sc, ba.default_options(**opt))
+    assert info.sparse == 1 and info.n_factor_tiles < info.n_dense_tiles and info.n_levels < (info.n_columns + 63) // 64
+    assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9)
+
+
+def test_block_sparse_solver_with_per_camera_intrinsics_and_constant_blocks(monkeypatch):
+    """one intrinsic per camera (intrinsic blocks are NOT border: each couples with a few poses), some poses constant,
+    some cameras unobserved: inactive blocks keep their unit diagonal inside the tiles"""
+    sc = synth.ba_scene(n_cams=40, n_points=300, track_len=4, model=2, n_intr_groups=40, seed=73)
+    keep = sc["obs_pose"] != 7            # camera 7 loses all its observations
+    for k in ("obs_pose", "obs_intr", "obs_point"):
+        sc[k] = sc[k][keep]
+    sc["obs_xy"] = sc["obs_xy"][keep]; sc["n_obs"] = int(keep.sum())
+    pm = np.zeros(40, np.uint8); pm[3] = 0x3F; pm[11] = 0x07
+    opt = dict(max_num_iterations=2)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt), pose_const_mask=pm)
+    monkeypatch.setenv("MVGX_BA_SOLVER", "sparse")
+    monkeypatch.setenv("MVGX_BA_ND_LEAF_COLS", "64")
+    with _emu.emulated():
+        ctx = ba.BaContext(sc, pose_const_mask=pm)
+        s = ctx.solve(ba.default_options(**opt)); info = ctx.solver_info(); poses, intr, pts = ctx.read_params(); ctx.close()
+    assert info.sparse == 1 and info.n_border_blocks == 0 and info.n_parts > 3
+    assert s.num_iterations == osum.num_iterations
+    assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)

@@ -280,3 +280,32 @@ def test_match_directory_file_level_pipeline(tmp_path):
     want = _oracle.offsets_to_dict(pairs, off, ij)
     assert len(want) >= 2 and back.keys() == want.keys() == got.keys()
     assert all(np.array_equal(back[k], want[k]) for k in want)
+
+
+# ---- parity at the benchmarked shape ("bit-exact comparison ... all pairs for n <= 64 images") --------------
+@pytest.mark.skipif(not _oracle.have_ref_match(), reason="oracle/_ref (the compiled reference) not built")
+def test_c2_shape_64_images_all_pairs_vs_reference():
+    """64 images x 2000 descriptors of the bench.py data set (same generator and seed as BASELINE configs[1]), all 2016 pairs,
+    default kernel and batch pipeline, against the reference's own Matcher_Regions::Match compiled in place (oracle/_ref)."""
+    imgs = synth.image_descriptors(64, n_desc=2000, seed=0xC0FFEE00)
+    pairs = matching.exhaustive_pairs_array(64)
+    ref = _oracle.ref_matcher_regions_match(imgs, pairs, 0.8)
+    # 500 pairs per batch: five batches, so the two-slot pipeline and the batch seams are part of what is compared
+    st, offsets, ij = run_hip(imgs, pairs, 0.8, 43, batch_pairs=500)
+    assert_same(pairs, offsets, ij, ref)
+    assert int(st.n_desc_pairs) == 2016 * 2000 * 2000
+    assert int(st.n_matches) == sum(len(v) for v in ref.values()) > 0
+
+
+@pytest.mark.parametrize("n", [9000, 30000, 70001])
+def test_large_images_vs_oracle(n):
+    """Real SIFT gives 10-40 k features per image: query strides beyond one batch slot's default scratch, the batch size
+    shrinks (mvgx_match_run's scratch cap); lists must stay bit-identical to the restatement."""
+    imgs = synth.image_descriptors(3, n_desc=n, seed=11)
+    imgs[2] = imgs[2][: n // 3 + 1]
+    pairs = np.array([[0, 1], [1, 0], [0, 2], [2, 1]], np.uint32)
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    _, offsets, ij = run_hip(imgs, pairs, 0.8, 43)
+    assert np.array_equal(offsets, o_off)
+    assert np.array_equal(ij, o_ij)
+    assert int(o_off[-1]) > 0
