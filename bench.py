@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ba", action="store_true")
-    ap.add_argument("--side-deadline", type=float, default=420.0, help="seconds granted to the side records (BA, Hamming, float L2)")
+    ap.add_argument("--side-deadline", type=float, default=900.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
     return ap.parse_args()
@@ -223,9 +223,9 @@ def main():
     if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
         try:
             from bench_ba import ba_bench_record
-            ba_rec = ba_bench_record(local_rank, world)
+            ba_rec = ba_bench_record(local_rank, world, cpu=not args.no_cpu_baseline)
             if world == 1 and not args.no_ba_c5:   # configs[4] fits one GPU: reported beside its sharded runs at N > 1
-                ba_c5 = ba_bench_record(local_rank, 1, cpu=False, name="c5")
+                ba_c5 = ba_bench_record(local_rank, 1, cpu=not args.no_cpu_baseline, name="c5")
         except Exception as e:  # the BA leg is a side record: never lose the matching line
             ba_rec = ba_rec or {"status": f"failed: {e!r}"}
     if rank == 0 and world == 1 and not args.no_hamming:

@@ -278,3 +278,78 @@ def test_bundle_then_reject_loop_equals_the_reference_pipeline():
     c1 = ba.BaContext(ours); r1 = c1.evaluate()[1]; c1.close()
     c2 = ba.BaContext(ref); r2 = c2.evaluate()[1]; c2.close()
     assert abs(r1 - r2) < 1e-6 and r1 < 0.6
+
+
+def test_huber_plateau_scene_is_inside_the_references_own_spread():
+    """Round-1 open point: on this scene (5 % gross outliers, 40+ LM iterations of ~1e-6 relative cost change) the
+    function-tolerance test fires a few iterations apart for different summation orders. The compiled reference itself,
+    run with 1/2/4/8 threads and three residual-block orders (its containers are hash maps), ends at final RMSEs
+    4.4e-4 apart (tests/golden/ba_plateau_seed93_reference.json, profiles/round2_seed93_reference_spread.json). Parity here
+    = inside the band the reference spans; and against the reference run in THIS process when oracle/_ref is present."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_plateau_seed93_reference.json")))
+    sc = synth.ba_scene(**g["scene"])
+    ctx = ba.BaContext(sc); s = ctx.solve(); ctx.close()
+    ref = [r["final_rmse"] for r in g["runs"]]
+    spread = max(ref) - min(ref)
+    assert 1e-4 < spread < 1e-3                      # the fixture documents a real spread of the reference
+    assert min(ref) - spread <= s.final_rmse <= max(ref) + spread, (s.final_rmse, min(ref), max(ref))
+    assert abs(s.initial_rmse - g["runs"][0]["initial_rmse"]) < 1e-9
+    if _oracle.have_ref_ba():
+        rc, st, *_ = _oracle.ref_ba_adjust(sc, num_threads=1)
+        assert rc == 0 and abs(st[1] - s.final_rmse) <= 2 * spread
+
+
+# ---- block-sparse reduced camera system ------------------------------------------------------------------------------
+def _solve_mode(sc, mode, monkeypatch, options=None, leaf_cols=None):
+    monkeypatch.setenv("MVGX_BA_SOLVER", mode)
+    if leaf_cols:
+        monkeypatch.setenv("MVGX_BA_ND_LEAF_COLS", str(leaf_cols))
+    else:
+        monkeypatch.delenv("MVGX_BA_ND_LEAF_COLS", raising=False)
+    ctx = ba.BaContext(sc)
+    s = ctx.solve(options)
+    info = ctx.solver_info()
+    poses, intr, pts = ctx.read_params()
+    ctx.close()
+    return s, info, poses, intr, pts
+
+
+@pytest.mark.parametrize("kw,leaf", [
+    (dict(n_cams=72, n_points=2000, track_len=4, model=3, n_intr_groups=3, seed=71), 64),
+    (dict(n_cams=150, n_points=8000, track_len=8, model=3, n_intr_groups=5, seed=74), None),
+    (dict(n_cams=60, n_points=3000, track_len=5, model=2, n_intr_groups=60, seed=75), 128),   # one intrinsic per camera: no border
+    (dict(n_cams=200, n_points=12000, track_len=10, model=1, n_intr_groups=1, seed=76), None),   # the shape of bench C3
+])
+def test_block_sparse_solver_equals_dense_and_oracle(kw, leaf, monkeypatch):
+    sc = synth.ba_scene(**kw)
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc)
+    sd, info_d, pd, idn, xd = _solve_mode(sc, "dense", monkeypatch)
+    ss, info, ps, isn, xs = _solve_mode(sc, "sparse", monkeypatch, leaf_cols=leaf)
+    assert info_d.sparse == 0 and info.sparse == 1 and info.n_parts > 2
+    assert info.n_levels < info.n_padded // 64          # the dissection bought concurrency
+    for s in (sd, ss):
+        assert s.num_iterations == osum.num_iterations and s.num_successful_steps == osum.num_successful_steps
+        assert abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+        assert abs(s.final_cost - osum.final_cost) <= 1e-8 * osum.final_cost
+    assert np.allclose(xs, xd, atol=1e-8) and np.allclose(ps, pd, atol=1e-8) and np.allclose(isn, idn, rtol=1e-8, atol=1e-8)
+
+
+def test_block_sparse_solver_is_chosen_for_a_sequential_capture_scene(monkeypatch):
+    monkeypatch.delenv("MVGX_BA_SOLVER", raising=False)
+    monkeypatch.delenv("MVGX_BA_ND_LEAF_COLS", raising=False)
+    sc = synth.ba_scene(n_cams=200, n_points=12000, track_len=10, model=1, n_intr_groups=1, seed=76)
+    ctx = ba.BaContext(sc); s = ctx.solve(); info = ctx.solver_info(); ctx.close()
+    assert info.sparse == 1 and info.n_border_blocks == 1 and 2 * info.n_factor_tiles < info.n_dense_tiles
+    assert s.termination == 0 and s.final_rmse < 0.6
+
+
+def test_dense_visibility_scene_keeps_the_dense_solver(monkeypatch):
+    """every camera sees every point: S is full, nothing to dissect -> the dense blocked Cholesky (the fallback and cross-check)"""
+    monkeypatch.delenv("MVGX_BA_SOLVER", raising=False)
+    sc = synth.ba_scene(n_cams=40, n_points=1500, track_len=40, model=3, n_intr_groups=2, seed=77)
+    rc, osum, *_ = _oracle.port_ba_solve(sc)
+    ctx = ba.BaContext(sc); s = ctx.solve(); info = ctx.solver_info(); ctx.close()
+    assert info.sparse == 0
+    assert s.num_iterations == osum.num_iterations and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
