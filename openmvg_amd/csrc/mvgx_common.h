@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "mvgx.h"
 
@@ -32,5 +33,9 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 int select_device(int device);
+
+// MVGX_DEVICES: "all" or a comma-separated list of device ordinals (an ordinal may repeat: several contexts on one device,
+// used by the single-GPU tests of the multi-device paths). Unset / empty -> `out` stays empty (the current device).
+int devices_from_env(std::vector<int>& out);
 
 }  // namespace mvgx

@@ -1,6 +1,7 @@
 // libmvgx_hip.so — common entry points (error string, device enumeration).
 #include "mvgx_common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace mvgx {
@@ -33,13 +34,40 @@ int select_device(int device) {
   return MVGX_OK;
 }
 
+int devices_from_env(std::vector<int>& out) {
+  out.clear();
+  const char* env = getenv("MVGX_DEVICES");
+  if (!env || !*env) return MVGX_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    set_error("no HIP device visible (libmvgx_hip needs a gfx950 GPU; there is no CPU fallback)");
+    return MVGX_ERR_NODEV;
+  }
+  if (!strcmp(env, "all")) {
+    for (int d = 0; d < count; ++d) out.push_back(d);
+    return MVGX_OK;
+  }
+  for (const char* p = env; *p;) {
+    char* end = nullptr;
+    const long v = strtol(p, &end, 10);
+    if (end == p || v < 0 || v >= count) {
+      set_error("MVGX_DEVICES='%s': expected 'all' or a comma-separated list of ordinals below %d", env, count);
+      return MVGX_ERR_ARG;
+    }
+    out.push_back((int)v);
+    p = end;
+    while (*p == ',' || *p == ' ') ++p;
+  }
+  return MVGX_OK;
+}
+
 }  // namespace mvgx
 
 extern "C" {
 
 const char* mvgx_last_error(void) { return mvgx::last_error_ref().c_str(); }
 
-int mvgx_abi_version(void) { return 3; }
+int mvgx_abi_version(void) { return 4; }
 
 int mvgx_device_count(int* count) {
   if (!count) return MVGX_ERR_ARG;

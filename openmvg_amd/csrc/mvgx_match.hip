@@ -37,9 +37,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "mvgx_common.h"
@@ -970,6 +977,12 @@ struct mvgx_match_ctx {
     PinnedBuf<uint32_t> hp_offsets;
     uint64_t p0 = 0;
     uint32_t nb = 0;
+    // stream mode (mvgx_match_run_stream): the lists of the slot's finished batch wait here for the sink
+    hipEvent_t ev_copy = nullptr;     // match lists of the batch are on the host
+    PinnedBuf<uint32_t> hp_ij;
+    std::vector<uint32_t> h_off_out;
+    uint64_t out_p0 = 0;
+    uint32_t out_nb = 0;
   } slot[2];
   // results of the last run
   // results of the last run - or, with "double_buffer_results", of the last two runs (alternating): a caller may then
@@ -982,6 +995,9 @@ struct mvgx_match_ctx {
   int cur = 0;
   int double_buffer = 0;
   std::vector<hipEvent_t> ev_pool;
+  // a context over several devices (mvgx_match_create_multi / MVGX_DEVICES): it owns one ordinary context per device and
+  // no device state of its own; descriptors are replicated, the batches of a run are shared out dynamically
+  std::vector<mvgx_match_ctx*> children;
 };
 
 namespace {
@@ -1082,8 +1098,31 @@ hipEvent_t get_event(mvgx_match_ctx* c, size_t i) {
 
 extern "C" {
 
+int mvgx_match_create_multi(const int* devices, int n_devices, mvgx_match_ctx** out) {
+  MVGX_REQUIRE(out != nullptr && devices != nullptr && n_devices >= 1, MVGX_ERR_ARG, "mvgx_match_create_multi: bad argument");
+  if (n_devices == 1) return mvgx_match_create(devices[0] < 0 ? -2 : devices[0], out);
+  auto* c = new mvgx_match_ctx();
+  c->device = devices[0];
+  for (int k = 0; k < n_devices; ++k) {
+    mvgx_match_ctx* child = nullptr;
+    const int rc = mvgx_match_create(devices[k] < 0 ? -2 : devices[k], &child);   // -2: current device, MVGX_DEVICES not consulted
+    if (rc) { mvgx_match_destroy(c); return rc; }
+    c->children.push_back(child);
+  }
+  *out = c;
+  return MVGX_OK;
+}
+
 int mvgx_match_create(int device, mvgx_match_ctx** out) {
   MVGX_REQUIRE(out != nullptr, MVGX_ERR_ARG, "mvgx_match_create: out is NULL");
+  if (device == -1) {   // "the caller has no preference": MVGX_DEVICES may name the device(s) to use
+    std::vector<int> devs;
+    int rc = mvgx::devices_from_env(devs);
+    if (rc) return rc;
+    if (devs.size() >= 2) return mvgx_match_create_multi(devs.data(), (int)devs.size(), out);
+    if (devs.size() == 1) device = devs[0];
+  }
+  if (device < 0) device = -1;
   int rc = mvgx::select_device(device);
   if (rc) return rc;
   auto* c = new mvgx_match_ctx();
@@ -1099,6 +1138,7 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
     MVGX_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     MVGX_HIP(hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
     MVGX_HIP(hipEventCreateWithFlags(&sl.ev_filter, hipEventDisableTiming));
+    MVGX_HIP(hipEventCreateWithFlags(&sl.ev_copy, hipEventDisableTiming));
   }
   // 2 x 33 KiB dynamic LDS for both MFMA variants
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_top2_ratio_kernel<kStageRegs>),
@@ -1120,6 +1160,12 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
 
 int mvgx_match_destroy(mvgx_match_ctx* c) {
   if (!c) return MVGX_OK;
+  if (!c->children.empty()) {
+    for (mvgx_match_ctx* child : c->children) mvgx_match_destroy(child);
+    for (auto& r : c->results) r.ij.release();
+    delete c;
+    return MVGX_OK;
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_rows.release(); c->d_tiles.release(); c->d_rconst.release(); c->d_qnorm.release();
@@ -1130,7 +1176,8 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   for (auto& sl : c->slot) {
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
-    sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release();
+    sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release(); sl.hp_ij.release();
+    if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
     if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
     if (sl.ev_filter) (void)hipEventDestroy(sl.ev_filter);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1145,6 +1192,11 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
 
 int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
   MVGX_REQUIRE(c && key, MVGX_ERR_ARG, "mvgx_match_set_option: NULL argument");
+  if (strcmp(key, "pinned_results") && strcmp(key, "double_buffer_results") && strcmp(key, "keep_host_results"))
+    for (mvgx_match_ctx* child : c->children) {   // per-device knobs; the result buffers belong to the parent
+      const int rc = mvgx_match_set_option(child, key, value);
+      if (rc) return rc;
+    }
   if (!strcmp(key, "variant")) {
     MVGX_REQUIRE(value >= 0 && value <= 4, MVGX_ERR_ARG, "variant must be 0..4");
     c->variant = (int)value;
@@ -1178,6 +1230,21 @@ int mvgx_match_set_regions(mvgx_match_ctx* c, const uint8_t* const* desc_rows, c
                            uint32_t n_images, uint32_t dim) {
   MVGX_REQUIRE(c && n_desc && (desc_rows || n_images == 0), MVGX_ERR_ARG, "mvgx_match_set_regions: NULL argument");
   MVGX_REQUIRE(dim == kDim, MVGX_ERR_UNSUPPORTED, "descriptor length %u unsupported (device path is 128-D uint8)", dim);
+  if (!c->children.empty()) {   // replicate the descriptors: one uploading thread per device
+    const size_t nd = c->children.size();
+    std::vector<int> rcs(nd, MVGX_OK);
+    std::vector<std::string> errs(nd);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < nd; ++d)
+      th.emplace_back([&, d]() {
+        rcs[d] = mvgx_match_set_regions(c->children[d], desc_rows, n_desc, n_images, dim);
+        if (rcs[d]) errs[d] = mvgx_last_error();
+      });
+    for (auto& t : th) t.join();
+    for (size_t d = 0; d < nd; ++d)
+      if (rcs[d]) { set_error("device %d: %s", c->children[d]->device, errs[d].c_str()); return rcs[d]; }
+    return MVGX_OK;
+  }
   MVGX_HIP(hipSetDevice(c->device));
   c->n_images = n_images;
   c->h_n.assign(n_desc, n_desc + n_images);
@@ -1205,6 +1272,8 @@ int mvgx_match_set_regions_device(mvgx_match_ctx* c, const void* d_desc_concat, 
   MVGX_REQUIRE(c && n_desc && (d_desc_concat || n_images == 0), MVGX_ERR_ARG,
                "mvgx_match_set_regions_device: NULL argument");
   MVGX_REQUIRE(dim == kDim, MVGX_ERR_UNSUPPORTED, "descriptor length %u unsupported (device path is 128-D uint8)", dim);
+  MVGX_REQUIRE(c->children.empty(), MVGX_ERR_UNSUPPORTED, "mvgx_match_set_regions_device: a device pointer belongs to one device; "
+               "use mvgx_match_set_regions on a multi-device context");
   MVGX_HIP(hipSetDevice(c->device));
   c->n_images = n_images;
   c->h_n.assign(n_desc, n_desc + n_images);
@@ -1213,32 +1282,43 @@ int mvgx_match_set_regions_device(mvgx_match_ctx* c, const void* d_desc_concat, 
   return prep_regions(c);
 }
 
-int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
-                   mvgx_match_stats* stats) {
-  MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "mvgx_match_run: NULL argument");
-  MVGX_REQUIRE(c->d_rows_view != nullptr || c->n_images == 0, MVGX_ERR_STATE, "mvgx_match_run before set_regions");
-  MVGX_REQUIRE(ratio_sq <= 1.0f && ratio_sq >= 0.0f, MVGX_ERR_UNSUPPORTED,
-               "ratio_sq = %g: the device path reproduces the reference only for 0 <= ratio^2 <= 1 "
-               "(ties are libstdc++ partial_sort order beyond that)", (double)ratio_sq);
-  MVGX_HIP(hipSetDevice(c->device));
-  for (uint64_t k = 0; k < n_pairs; ++k)
-    MVGX_REQUIRE(pairs_IJ[2 * k] < c->n_images && pairs_IJ[2 * k + 1] < c->n_images, MVGX_ERR_ARG,
-                 "pair %llu references image out of range", (unsigned long long)k);
+}  // extern "C"
 
-  if (c->double_buffer) c->cur ^= 1;
+namespace {
+
+// The pair list of one run, cut into batches that the devices of the context take one after the other (a single device: in
+// order; several: whoever is free - the lists of a batch do not depend on which device computed them).
+struct BatchFeed {
+  const uint32_t* pairs_IJ = nullptr;
+  uint64_t n_pairs = 0, B = 1;
+  std::atomic<uint64_t> next{0};
+  std::atomic<int> stop{0};   // a sink asked to cancel, or a device failed
+  bool take(uint64_t& p0, uint32_t& nb) {
+    if (stop.load(std::memory_order_relaxed)) return false;
+    p0 = next.fetch_add(B);
+    if (p0 >= n_pairs) return false;
+    nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
+    return true;
+  }
+};
+
+// Called when the lists of a batch are in host memory: pairs [p0, p0 + nb), offsets[nb + 1] relative to the batch (in
+// matches), ij = 2 uint32 per match. Non-zero return = stop the run.
+using BatchSink = std::function<int(uint64_t p0, uint32_t nb, const uint32_t* offsets, const uint32_t* ij)>;
+
+// One device's share of a run. sink == nullptr: the lists are appended to c->results[c->cur] (the feed must then be
+// consumed by this device alone, in order); otherwise every batch is handed to `sink` from this thread as soon as its
+// lists are on the host, and host memory stays O(batch): two pinned buffers per device.
+int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSink* sink, mvgx_match_stats& st) {
+  const uint32_t* pairs_IJ = feed.pairs_IJ;
+  MVGX_HIP(hipSetDevice(c->device));
   mvgx_match_ctx::Results& res = c->results[c->cur];
-  res.offsets.assign(n_pairs + 1, 0);
-  res.ij_n = 0;
-  mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
   st.variant = (uint32_t)c->variant;
   size_t n_ev = 0;
   int rc;
 
   MVGX_HIP(hipEventRecord(c->ev_total0, c->slot[0].stream));
-  // pairs per batch: the option, capped so that the per-slot scratch (12 B per pair and query slot) stays near 6 GB when the
-  // images carry tens of thousands of descriptors
-  const uint64_t B = std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)c->batch_pairs, (1ull << 29) / std::max<uint32_t>(c->qstride, 1)));
 
   // Stage 1 of a batch on its slot's stream: work list -> filter (+ verify) -> per-pair counts -> exclusive scan -> offsets to host
   auto issue = [&](mvgx_match_ctx::Slot& sl, mvgx_match_ctx::Slot* prev, uint64_t p0, uint32_t nb) -> int {
@@ -1329,15 +1409,21 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
     MVGX_HIP(hipEventRecord(sl.ev_scan, stream));
     return MVGX_OK;
   };
-  // Stage 2, in batch order: totals -> ordered compaction -> (optional) copy of the match lists to the host
+  // Stage 2, in batch order: totals -> ordered compaction -> copy of the match lists to the host (collect mode: appended to
+  // the run's result buffer; stream mode: into the slot's own pinned buffer, delivered by stage 3)
   auto finish = [&](mvgx_match_ctx::Slot& sl) -> int {
     int rc;
     MVGX_HIP(hipEventSynchronize(sl.ev_scan));
     const uint32_t nb = sl.nb;
     const uint64_t p0 = sl.p0;
     const uint32_t total = sl.hp_offsets.p[nb];
-    const uint64_t base = res.offsets[p0];
-    for (uint32_t k = 0; k <= nb; ++k) res.offsets[p0 + k] = base + sl.hp_offsets.p[k];
+    if (sink) {
+      sl.h_off_out.assign(sl.hp_offsets.p, sl.hp_offsets.p + nb + 1);   // hp_offsets is rewritten by the slot's next batch
+    } else {
+      const uint64_t base = res.offsets[p0];
+      for (uint32_t k = 0; k <= nb; ++k) res.offsets[p0 + k] = base + sl.hp_offsets.p[k];
+    }
+    sl.out_p0 = p0; sl.out_nb = nb;
     st.n_matches += total;
     if (total) {
       if ((rc = sl.d_ij.ensure(total))) return rc;
@@ -1345,7 +1431,10 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
                          sl.d_offsets.p, sl.d_pairs.p, c->d_n.p, c->d_row_off.p, c->d_rowpos.p, nb, c->qstride,
                          sl.d_ij.p);
       MVGX_HIP(hipGetLastError());
-      if (c->keep_host_results) {
+      if (sink) {
+        if ((rc = sl.hp_ij.ensure((size_t)total * 2))) return rc;
+        MVGX_HIP(hipMemcpyAsync(sl.hp_ij.p, sl.d_ij.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost, sl.stream));
+      } else if (c->keep_host_results) {
         const size_t old = res.ij_n;
         if (old + (size_t)total * 2 > res.ij.cap)   // growth moves the lists: no copy into them may be in flight
           for (auto& o : c->slot) MVGX_HIP(hipStreamSynchronize(o.stream));
@@ -1355,22 +1444,41 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
                                 hipMemcpyDeviceToHost, sl.stream));   // completes before the run returns
       }
     }
+    if (sink) MVGX_HIP(hipEventRecord(sl.ev_copy, sl.stream));
     return MVGX_OK;
   };
-  uint64_t nbatch = 0;
-  for (uint64_t p0 = 0; p0 < n_pairs; p0 += B, ++nbatch) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
+  // Stage 3 (stream mode): the lists of the slot's batch are on the host -> the sink, on this thread
+  auto deliver = [&](mvgx_match_ctx::Slot& sl) -> int {
+    MVGX_HIP(hipEventSynchronize(sl.ev_copy));
+    if (feed.stop.load()) return MVGX_OK;   // cancelled: the sink is not entered again
+    if ((*sink)(sl.out_p0, sl.out_nb, sl.h_off_out.data(), sl.hp_ij.p)) feed.stop.store(1);
+    return MVGX_OK;
+  };
+  // software pipeline over the batches this device takes: issue(b) | finish(b-1) | deliver(b-2)
+  uint64_t nbatch = 0, p0 = 0;
+  uint32_t nb = 0;
+  while (feed.take(p0, nb)) {
     mvgx_match_ctx::Slot& cur = c->slot[nbatch & 1];
     mvgx_match_ctx::Slot* prev = nbatch ? &c->slot[(nbatch - 1) & 1] : nullptr;
     if (!c->overlap) {
       if ((rc = issue(cur, nullptr, p0, nb)) || (rc = finish(cur))) return rc;
       MVGX_HIP(hipStreamSynchronize(cur.stream));
+      if (sink && (rc = deliver(cur))) return rc;
+      ++nbatch;
       continue;
     }
     if ((rc = issue(cur, prev, p0, nb))) return rc;   // batch b: filter on the device ...
-    if (prev && (rc = finish(*prev))) return rc;      // ... while batch b-1 is compacted and copied out
+    if (prev && (rc = finish(*prev))) return rc;      // ... while batch b-1 is compacted and copied out ...
+    if (sink && nbatch >= 2 && (rc = deliver(cur))) return rc;   // ... and batch b-2 (this slot's previous one) is consumed
+    // (deliver(cur) reads the slot's HOST buffers of batch b-2; the device side of the slot already works on batch b)
+    ++nbatch;
   }
-  if (c->overlap && nbatch && (rc = finish(c->slot[(nbatch - 1) & 1]))) return rc;
+  if (c->overlap && nbatch) {
+    mvgx_match_ctx::Slot& last = c->slot[(nbatch - 1) & 1];
+    if (sink && nbatch >= 2 && (rc = deliver(c->slot[nbatch & 1]))) return rc;   // batch nbatch-2
+    if ((rc = finish(last))) return rc;
+    if (sink && (rc = deliver(last))) return rc;
+  }
   for (auto& sl : c->slot) MVGX_HIP(hipStreamSynchronize(sl.stream));
   MVGX_HIP(hipEventRecord(c->ev_total1, c->slot[0].stream));
   MVGX_HIP(hipEventSynchronize(c->ev_total1));
@@ -1395,8 +1503,149 @@ int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
       st.kernel_ms += k;
     }
   }
-  if (stats) *stats = st;
   return MVGX_OK;
+}
+
+void add_stats(mvgx_match_stats& a, const mvgx_match_stats& b) {
+  a.n_pairs += b.n_pairs; a.n_desc_pairs += b.n_desc_pairs; a.n_matches += b.n_matches;
+  a.n_kernel_launches += b.n_kernel_launches; a.kernel_ms += b.kernel_ms;
+  a.total_ms = std::max(a.total_ms, b.total_ms); a.kernel_vgprs += b.kernel_vgprs; a.variant = b.variant;
+}
+
+// Several devices: one host thread per device runs run_device() on the shared feed; finished batches are handed to the
+// CALLING thread through a one-entry mailbox per device, so that `sink` is never entered from two threads nor from a
+// thread the caller does not know (PairWiseMatchesContainer::insert is not thread safe, indMatch.hpp:70-75).
+int run_multi(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSink& sink, mvgx_match_stats& st) {
+  const size_t nd = c->children.size();
+  struct Mail { uint64_t p0; uint32_t nb; const uint32_t* offsets; const uint32_t* ij; int result; bool full, done; };
+  std::mutex mu;
+  std::condition_variable cv_main, cv_dev;
+  std::vector<Mail> mail(nd, Mail{0, 0, nullptr, nullptr, 0, false, false});
+  std::vector<int> rcs(nd, MVGX_OK);
+  std::vector<std::string> errs(nd);
+  std::vector<mvgx_match_stats> sts(nd);
+  size_t running = nd;
+  std::vector<std::thread> workers;
+  for (size_t d = 0; d < nd; ++d) {
+    workers.emplace_back([&, d]() {
+      BatchSink post = [&, d](uint64_t p0, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) -> int {
+        std::unique_lock<std::mutex> lk(mu);
+        mail[d] = Mail{p0, nb, offsets, ij, 0, true, false};
+        cv_main.notify_one();
+        cv_dev.wait(lk, [&]() { return mail[d].done; });   // the buffers stay valid until the caller has consumed them
+        mail[d].full = mail[d].done = false;
+        return mail[d].result;
+      };
+      rcs[d] = run_device(c->children[d], feed, ratio_sq, &post, sts[d]);
+      if (rcs[d] != MVGX_OK) { errs[d] = mvgx_last_error(); feed.stop.store(1); }
+      std::lock_guard<std::mutex> lk(mu);
+      --running;
+      cv_main.notify_one();
+    });
+  }
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      size_t ready = nd;
+      cv_main.wait(lk, [&]() {
+        for (size_t d = 0; d < nd; ++d)
+          if (mail[d].full && !mail[d].done) { ready = d; return true; }
+        return running == 0;
+      });
+      if (ready == nd) break;
+      Mail m = mail[ready];
+      lk.unlock();
+      const int r = sink(m.p0, m.nb, m.offsets, m.ij);
+      lk.lock();
+      mail[ready].result = r;
+      mail[ready].done = true;
+      cv_dev.notify_all();
+    }
+  }
+  for (auto& w : workers) w.join();
+  memset(&st, 0, sizeof(st));
+  int rc = MVGX_OK;
+  for (size_t d = 0; d < nd; ++d) {
+    add_stats(st, sts[d]);
+    if (rcs[d] != MVGX_OK && rc == MVGX_OK) { rc = rcs[d]; set_error("device %d: %s", c->children[d]->device, errs[d].c_str()); }
+  }
+  return rc;
+}
+
+int check_run_args(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, const char* who) {
+  MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "%s: NULL argument", who);
+  const mvgx_match_ctx* r = c->children.empty() ? c : c->children[0];
+  MVGX_REQUIRE(r->d_rows_view != nullptr || r->n_images == 0, MVGX_ERR_STATE, "%s before set_regions", who);
+  MVGX_REQUIRE(ratio_sq <= 1.0f && ratio_sq >= 0.0f, MVGX_ERR_UNSUPPORTED,
+               "ratio_sq = %g: the device path reproduces the reference only for 0 <= ratio^2 <= 1 "
+               "(ties are libstdc++ partial_sort order beyond that)", (double)ratio_sq);
+  for (uint64_t k = 0; k < n_pairs; ++k)
+    MVGX_REQUIRE(pairs_IJ[2 * k] < r->n_images && pairs_IJ[2 * k + 1] < r->n_images, MVGX_ERR_ARG,
+                 "pair %llu references image out of range", (unsigned long long)k);
+  return MVGX_OK;
+}
+
+// pairs per batch: the option, capped so that the per-slot scratch (12 B per pair and query slot) stays near 6 GB when the
+// images carry tens of thousands of descriptors
+uint64_t batch_size(const mvgx_match_ctx* c) {
+  const mvgx_match_ctx* r = c->children.empty() ? c : c->children[0];
+  return std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)c->batch_pairs, (1ull << 29) / std::max<uint32_t>(r->qstride, 1)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvgx_match_run(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                   mvgx_match_stats* stats) {
+  int rc = check_run_args(c, pairs_IJ, n_pairs, ratio_sq, "mvgx_match_run");
+  if (rc) return rc;
+  if (c->double_buffer) c->cur ^= 1;
+  mvgx_match_ctx::Results& res = c->results[c->cur];
+  res.offsets.assign(n_pairs + 1, 0);
+  res.ij_n = 0;
+  BatchFeed feed;
+  feed.pairs_IJ = pairs_IJ; feed.n_pairs = n_pairs; feed.B = batch_size(c);
+  mvgx_match_stats st;
+  if (c->children.empty()) {
+    rc = run_device(c, feed, ratio_sq, nullptr, st);
+  } else {
+    // several devices: batches arrive in any order; per-pair counts first, the lists are put in place once all offsets are known
+    struct Piece { uint64_t p0; std::vector<uint32_t> ij; };
+    std::vector<Piece> pieces;
+    BatchSink collect = [&](uint64_t p0, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) -> int {
+      for (uint32_t k = 0; k < nb; ++k) res.offsets[p0 + k + 1] = offsets[k + 1] - offsets[k];
+      if (c->keep_host_results && offsets[nb]) pieces.push_back(Piece{p0, std::vector<uint32_t>(ij, ij + 2 * (size_t)offsets[nb])});
+      return 0;
+    };
+    rc = run_multi(c, feed, ratio_sq, collect, st);
+    if (rc == MVGX_OK) {
+      for (uint64_t k = 0; k < n_pairs; ++k) res.offsets[k + 1] += res.offsets[k];
+      if (c->keep_host_results) {
+        if ((rc = res.ij.grow_keep(2 * res.offsets[n_pairs], 0))) return rc;
+        res.ij_n = 2 * res.offsets[n_pairs];
+        for (const Piece& p : pieces) memcpy(res.ij.p + 2 * res.offsets[p.p0], p.ij.data(), p.ij.size() * sizeof(uint32_t));
+      }
+    }
+  }
+  if (rc == MVGX_OK && stats) *stats = st;
+  return rc;
+}
+
+int mvgx_match_run_stream(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                          mvgx_match_batch_sink sink, void* user, mvgx_match_stats* stats) {
+  int rc = check_run_args(c, pairs_IJ, n_pairs, ratio_sq, "mvgx_match_run_stream");
+  if (rc) return rc;
+  MVGX_REQUIRE(sink != nullptr, MVGX_ERR_ARG, "mvgx_match_run_stream: sink is NULL");
+  BatchFeed feed;
+  feed.pairs_IJ = pairs_IJ; feed.n_pairs = n_pairs; feed.B = batch_size(c);
+  BatchSink fn = [&](uint64_t p0, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) -> int {
+    return sink(user, p0, nb, offsets, ij);
+  };
+  mvgx_match_stats st;
+  rc = c->children.empty() ? run_device(c, feed, ratio_sq, &fn, st) : run_multi(c, feed, ratio_sq, fn, st);
+  if (rc == MVGX_OK && stats) *stats = st;
+  return rc;
 }
 
 int mvgx_match_results(mvgx_match_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
