@@ -32,7 +32,7 @@ extern "C" {
 const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
 /* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors;
- * 3: mvgx_ba_get_solver_info) */
+ * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -61,8 +61,15 @@ typedef struct mvgx_match_stats {
   uint32_t variant;            /* kernel variant actually used                                      */
 } mvgx_match_stats;
 
-/* device < 0: use the current HIP device. */
+/* device >= 0: that device. device == -1 ("no preference", what the openMVG adapter passes): the devices named by the
+ * environment variable MVGX_DEVICES - "all" or a comma-separated list of ordinals; two or more make a multi-device
+ * context (below) - or, when it is unset, the current HIP device. device <= -2: the current HIP device, environment ignored. */
 int mvgx_match_create(int device, mvgx_match_ctx** out);
+/* One context over several devices of this process (Matcher_Regions.cpp:49-54 fans the pairs of an image I out over host
+ * threads; here the pair list is cut into batches that the devices take in turn, one host thread per device, no
+ * collective): descriptors are replicated by set_regions, every run call shares its batches out dynamically, results are
+ * identical to a single-device run. An ordinal may repeat (several contexts on one device). */
+int mvgx_match_create_multi(const int* devices, int n_devices, mvgx_match_ctx** out);
 int mvgx_match_destroy(mvgx_match_ctx* ctx);
 
 /* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch),
@@ -95,6 +102,18 @@ int mvgx_match_set_regions_device(mvgx_match_ctx* ctx, const void* d_desc_concat
  * run k + 1 executes (the adapter fills the match container that way). */
 int mvgx_match_run(mvgx_match_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
                    mvgx_match_stats* stats /* may be NULL */);
+
+/* Streaming form of mvgx_match_run for runs whose match lists should not be held in host memory at once (10k images:
+ * 5e7 pairs, ~1e10 matches): the lists are handed over batch by batch ("batch_pairs" image pairs each) and host memory
+ * stays O(batch) - two pinned buffers per device. `sink` is entered on the CALLING thread only, one batch at a time:
+ * pairs [first_pair, first_pair + n_pairs) of the input list, offsets[n_pairs + 1] relative to the batch (in matches),
+ * ij = 2 uint32 per match, ascending j within a pair; the pointers are valid during the call only. Batches arrive in
+ * ascending order on a single device and in any order on a multi-device context. A non-zero return stops the run (the
+ * sink is not entered again; the call still returns MVGX_OK). mvgx_match_results is not affected by this call. */
+typedef int (*mvgx_match_batch_sink)(void* user, uint64_t first_pair, uint32_t n_pairs, const uint32_t* offsets,
+                                     const uint32_t* ij);
+int mvgx_match_run_stream(mvgx_match_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                          mvgx_match_batch_sink sink, void* user, mvgx_match_stats* stats /* may be NULL */);
 
 /* Host view of the last run: offsets[n_pairs+1] into ij (in units of matches); ij = 2 uint32 per match. */
 int mvgx_match_results(mvgx_match_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);

@@ -108,6 +108,7 @@ class BaSolverInfo(C.Structure):
 
 
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
+MATCH_BATCH_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
 MVGX_REDUCE_SUM, MVGX_REDUCE_MAX = 0, 1
 
@@ -117,11 +118,14 @@ PROTOTYPES = {
     "mvgx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mvgx_abi_version": (C.c_int, []),
     "mvgx_match_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mvgx_match_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "mvgx_match_destroy": (C.c_int, [C.c_void_p]),
     "mvgx_match_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mvgx_match_set_regions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]),
     "mvgx_match_set_regions_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]),
     "mvgx_match_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.POINTER(MatchStats)]),
+    "mvgx_match_run_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, MATCH_BATCH_SINK, C.c_void_p,
+                                        C.POINTER(MatchStats)]),
     "mvgx_match_results": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]),
     "mvgx_match_pairs_u8_l2": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_uint64, C.c_float, C.c_int, MATCH_SINK, C.c_void_p]),

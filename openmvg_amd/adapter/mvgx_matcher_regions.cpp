@@ -23,7 +23,8 @@
 //
 // Contract mirrored from Matcher_Regions.cpp:32-107: progress restart with pairs.size(); pairs whose I (or J) has no
 // regions are skipped but counted; regions of different Type_id are skipped; only non-empty match vectors are
-// inserted; insert() is called from the calling thread only; cancellation is polled between batches.
+// inserted; insert() is called from the calling thread only; cancellation is polled between device batches.
+// Several GPUs: MVGX_DEVICES=all (or a list of ordinals) in the environment of the unchanged main_ComputeMatches.
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -31,7 +32,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <future>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -78,10 +79,15 @@ struct Sink {
   const std::vector<IndexT>* ids;  // dense image index -> view id
 };
 
-// The match lists of one device call become IndMatches vectors on host threads (allocation + copy of up to a gigabyte is
-// the host-side cost of a large run); the container itself is filled from the calling thread only, in ascending (I, J),
-// as PairWiseMatchesContainer requires (indMatch.hpp:70-75: not thread safe).
-void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const uint64_t* offsets, const uint32_t* ij) {
+// The match lists of one device batch become IndMatches vectors on helper threads (allocation + copy of up to a gigabyte
+// per run is the host-side cost of a large collection) while the CALLING thread - and only it - inserts them into the
+// container in ascending (I, J) as soon as a chunk of lists is ready (indMatch.hpp:70-75: insert is not thread safe;
+// Matcher_Regions.cpp:95-103 inserts from the thread that called Match).
+// offsets: nb + 1 entries (in matches) relative to `ij`.
+template <typename OffT>
+void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const OffT* offsets, const uint32_t* ij) {
+  constexpr uint64_t kChunk = 256;
+  const uint64_t n_chunks = (nb + kChunk - 1) / kChunk;
   std::vector<matching::IndMatches> lists(nb);
   auto build = [&](uint64_t k) {
     const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
@@ -90,27 +96,36 @@ void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const uint
     v.reserve(n);
     for (uint64_t m = 0; m < n; ++m) v.emplace_back(ij[2 * (lo + m)], ij[2 * (lo + m) + 1]);
   };
+  auto insert_chunk = [&](uint64_t c) {
+    for (uint64_t k = c * kChunk, hi = std::min(nb, k + kChunk); k < hi; ++k)
+      if (!lists[k].empty())
+        sink.out->insert({{(*sink.ids)[pairs_IJ[2 * k]], (*sink.ids)[pairs_IJ[2 * k + 1]]}, std::move(lists[k])});
+  };
   const uint64_t total = offsets[nb] - offsets[0];
-  unsigned threads = total < (1u << 16) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (threads <= 1) {
+  const unsigned helpers = total < (1u << 16) ? 0u : std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+  if (!helpers) {
     for (uint64_t k = 0; k < nb; ++k) build(k);
-  } else {
-    std::atomic<uint64_t> next{0};
-    auto body = [&]() {
-      for (;;) {
-        const uint64_t lo = next.fetch_add(256);
-        if (lo >= nb) return;
-        for (uint64_t k = lo, hi = std::min(nb, lo + 256); k < hi; ++k) build(k);
-      }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body);
-    body();
-    for (auto& th : pool) th.join();
+    for (uint64_t c = 0; c < n_chunks; ++c) insert_chunk(c);
+    return;
   }
-  for (uint64_t k = 0; k < nb; ++k)
-    if (!lists[k].empty())
-      sink.out->insert({{(*sink.ids)[pairs_IJ[2 * k]], (*sink.ids)[pairs_IJ[2 * k + 1]]}, std::move(lists[k])});
+  std::atomic<uint64_t> next{0};
+  std::unique_ptr<std::atomic<uint8_t>[]> ready(new std::atomic<uint8_t>[n_chunks]);
+  for (uint64_t c = 0; c < n_chunks; ++c) ready[c].store(0, std::memory_order_relaxed);
+  auto body = [&]() {
+    for (;;) {
+      const uint64_t c = next.fetch_add(1);
+      if (c >= n_chunks) return;
+      for (uint64_t k = c * kChunk, hi = std::min(nb, k + kChunk); k < hi; ++k) build(k);
+      ready[c].store(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  struct Join { std::vector<std::thread>& p; ~Join() { for (auto& t : p) if (t.joinable()) t.join(); } } join{pool};
+  for (unsigned t = 0; t < helpers; ++t) pool.emplace_back(body);
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+    insert_chunk(c);
+  }
 }
 
 [[noreturn]] void device_failure(const char* what, int rc) {
@@ -232,54 +247,75 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     const uint64_t n_pairs = dev_pairs.size() / 2;
     // the device paths have the same call shapes (include/mvgx.h)
     const bool f32 = !hamming && l2_kind == 1, u8o = !hamming && l2_kind == 2;
-    mvgx_match_ctx* l2 = nullptr;
-    mvgx_hamming_ctx* hm = nullptr;
-    mvgx_l2f_ctx* lf = nullptr;
-    mvgx_l2u8_ctx* lu = nullptr;
-    int rc = hamming ? mvgx_hamming_create(-1, &hm) : f32 ? mvgx_l2f_create(-1, &lf) : u8o ? mvgx_l2u8_create(-1, &lu) : mvgx_match_create(-1, &l2);
+    // every exit path - including an exception out of the container or of a list allocation - releases the device context
+    struct Contexts {
+      mvgx_match_ctx* l2 = nullptr;
+      mvgx_hamming_ctx* hm = nullptr;
+      mvgx_l2f_ctx* lf = nullptr;
+      mvgx_l2u8_ctx* lu = nullptr;
+      void release() {
+        if (hm) mvgx_hamming_destroy(hm);
+        if (lf) mvgx_l2f_destroy(lf);
+        if (lu) mvgx_l2u8_destroy(lu);
+        if (l2) mvgx_match_destroy(l2);
+        hm = nullptr; lf = nullptr; lu = nullptr; l2 = nullptr;
+      }
+      ~Contexts() { release(); }
+    } ctx;
+    // device -1 = "no preference": MVGX_DEVICES (e.g. "all") makes the SIFT path one context over several GPUs of the node
+    int rc = hamming ? mvgx_hamming_create(-1, &ctx.hm) : f32 ? mvgx_l2f_create(-1, &ctx.lf) : u8o ? mvgx_l2u8_create(-1, &ctx.lu)
+                                                                                                  : mvgx_match_create(-1, &ctx.l2);
     if (rc != MVGX_OK) device_failure("create", rc);
-    if (l2) {
-      const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the lists rarely pays
-      mvgx_match_set_option(l2, "pinned_results", env ? std::atoi(env) : 0);
-      mvgx_match_set_option(l2, "double_buffer_results", 1);   // run k + 1 overlaps the delivery of run k
-    }
-    auto destroy = [&]() { if (hm) mvgx_hamming_destroy(hm); if (lf) mvgx_l2f_destroy(lf); if (lu) mvgx_l2u8_destroy(lu); if (l2) mvgx_match_destroy(l2); };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());
-    rc = hamming ? mvgx_hamming_set_regions(hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
-         : f32   ? mvgx_l2f_set_regions(lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
-         : u8o   ? mvgx_l2u8_set_regions(lu, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len))
-                 : mvgx_match_set_regions(l2, rows.data(), n_desc.data(), n_img, 128);
-    if (rc != MVGX_OK) { destroy(); device_failure("set_regions", rc); }
+    rc = hamming ? mvgx_hamming_set_regions(ctx.hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
+         : f32   ? mvgx_l2f_set_regions(ctx.lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
+         : u8o   ? mvgx_l2u8_set_regions(ctx.lu, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len))
+                 : mvgx_match_set_regions(ctx.l2, rows.data(), n_desc.data(), n_img, 128);
+    if (rc != MVGX_OK) device_failure("set_regions", rc);
     tick("context + upload + tile build");
-    // device call k + 1 runs while the lists of call k are turned into IndMatches and inserted (one worker at a time, in
-    // (I, J) order); the uint8 context keeps the previous call's results alive for exactly that (include/mvgx.h)
-    std::future<void> pending;
-    auto drain = [&]() { if (pending.valid()) pending.get(); };
-    for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
-      const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
-      if (progress->hasBeenCanceled()) break;
-      if (hamming || f32 || u8o) drain();   // those contexts hold one result buffer
-      rc = hamming ? mvgx_hamming_run(hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
-           : f32   ? mvgx_l2f_run(lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
-           : u8o   ? mvgx_l2u8_run(lu, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
-                   : mvgx_match_run(l2, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
-      tick("device run");
-      drain();
-      tick("wait for previous delivery");
-      if (rc != MVGX_OK) { destroy(); device_failure("run", rc); }
-      const uint64_t* offsets = nullptr;
-      const uint32_t* ij = nullptr;
-      if (hamming) mvgx_hamming_results(hm, &offsets, &ij);
-      else if (f32) mvgx_l2f_results(lf, &offsets, &ij);
-      else if (u8o) mvgx_l2u8_results(lu, &offsets, &ij);
-      else mvgx_match_results(l2, &offsets, &ij);
-      const uint32_t* batch_pairs = dev_pairs.data() + 2 * p0;
-      pending = std::async(std::launch::async, [=, &sink]() { deliver(sink, batch_pairs, nb, offsets, ij); });
-      (*progress) += static_cast<uint32_t>(nb);
+    if (ctx.l2) {
+      // SIFT path: the lists arrive batch by batch on THIS thread (mvgx_match_run_stream) while the device(s) work on the
+      // next batches; host memory beside the container itself is two batches per device. Cancellation is polled per batch.
+      struct Stream {
+        const Sink* sink; const uint32_t* pairs; system::ProgressInterface* progress; std::exception_ptr error;
+        static int on_batch(void* user, uint64_t first_pair, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) {
+          Stream& s = *static_cast<Stream*>(user);
+          try {
+            deliver(*s.sink, s.pairs + 2 * first_pair, nb, offsets, ij);
+            (*s.progress) += nb;
+          } catch (...) {   // never unwind through the C frames: stop the run, rethrow after it has returned
+            s.error = std::current_exception();
+            return 1;
+          }
+          return s.progress->hasBeenCanceled() ? 1 : 0;
+        }
+      } stream{&sink, dev_pairs.data(), progress, nullptr};
+      if (!progress->hasBeenCanceled()) {
+        rc = mvgx_match_run_stream(ctx.l2, dev_pairs.data(), n_pairs, ratio_sq, &Stream::on_batch, &stream, nullptr);
+        if (stream.error) std::rethrow_exception(stream.error);
+        if (rc != MVGX_OK) device_failure("run", rc);
+      }
+      tick("device runs + container fill");
+    } else {
+      for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
+        const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
+        if (progress->hasBeenCanceled()) break;
+        rc = hamming ? mvgx_hamming_run(ctx.hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
+             : f32   ? mvgx_l2f_run(ctx.lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
+                     : mvgx_l2u8_run(ctx.lu, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+        tick("device run");
+        if (rc != MVGX_OK) device_failure("run", rc);
+        const uint64_t* offsets = nullptr;
+        const uint32_t* ij = nullptr;
+        if (hamming) mvgx_hamming_results(ctx.hm, &offsets, &ij);
+        else if (f32) mvgx_l2f_results(ctx.lf, &offsets, &ij);
+        else mvgx_l2u8_results(ctx.lu, &offsets, &ij);
+        deliver(sink, dev_pairs.data() + 2 * p0, nb, offsets, ij);
+        tick("container fill");
+        (*progress) += static_cast<uint32_t>(nb);
+      }
     }
-    drain();
-    tick("last delivery");
-    destroy();
+    ctx.release();
     tick("context destroy");
   }
 

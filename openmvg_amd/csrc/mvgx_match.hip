@@ -1589,7 +1589,7 @@ int check_run_args(mvgx_match_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs
 // images carry tens of thousands of descriptors
 uint64_t batch_size(const mvgx_match_ctx* c) {
   const mvgx_match_ctx* r = c->children.empty() ? c : c->children[0];
-  return std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)c->batch_pairs, (1ull << 29) / std::max<uint32_t>(r->qstride, 1)));
+  return std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->batch_pairs, std::max<uint64_t>(16, (1ull << 29) / std::max<uint32_t>(r->qstride, 1))));
 }
 
 }  // namespace

@@ -106,9 +106,15 @@ class PairWiseMatches(dict):
 class MatchContext:
     """Device-resident descriptor set + runs over pair lists (thin wrapper over mvgx_match_*)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, devices=None):
+        """device: one ordinal (-1: MVGX_DEVICES or the current device). devices: a list of ordinals -> one context over
+        several devices of this process (mvgx_match_create_multi; an ordinal may repeat)."""
         self._h = C.c_void_p()
-        _capi.check(_capi.lib().mvgx_match_create(int(device), C.byref(self._h)))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _capi.check(_capi.lib().mvgx_match_create_multi(arr, len(devices), C.byref(self._h)))
+        else:
+            _capi.check(_capi.lib().mvgx_match_create(int(device), C.byref(self._h)))
         self.n_images = 0
         self._keep = None
 
@@ -170,6 +176,49 @@ class MatchContext:
         total = int(offsets[-1])
         ij = np.ctypeslib.as_array(pij, shape=(total, 2)).copy() if total else np.zeros((0, 2), np.uint32)
         return st, offsets, ij
+
+
+    def run_stream(self, pairs, ratio_sq, on_batch=None):
+        """mvgx_match_run_stream: `on_batch(first_pair, offsets[nb + 1] uint32, ij[(n, 2)] uint32)` is called on this thread
+        for every batch (arrays are views valid during the call; return a true value to stop). Returns the stats."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        st = _capi.MatchStats()
+        err = []
+
+        def sink(_user, first_pair, nb, offsets, ij):
+            if on_batch is None:
+                return 0
+            try:
+                off = np.ctypeslib.as_array(offsets, shape=(nb + 1,))
+                total = int(off[nb])
+                lists = np.ctypeslib.as_array(ij, shape=(total, 2)) if total else np.zeros((0, 2), np.uint32)
+                return 1 if on_batch(int(first_pair), off, lists) else 0
+            except BaseException as e:   # never unwind through the C frames
+                err.append(e)
+                return 1
+
+        cb = _capi.MATCH_BATCH_SINK(sink)
+        _capi.check(_capi.lib().mvgx_match_run_stream(self._h, pairs.ctypes.data, pairs.shape[0], np.float32(ratio_sq), cb, None,
+                                                      C.byref(st)))
+        if err:
+            raise err[0]
+        return st
+
+    def run_collect_stream(self, pairs, ratio_sq):
+        """run_stream assembled into the (stats, offsets, ij) shape of run(): for tests of the streaming path."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        counts = np.zeros(len(pairs) + 1, np.uint64)
+        pieces = {}
+
+        def on_batch(p0, off, lists):
+            counts[p0 + 1:p0 + len(off)] = np.diff(off.astype(np.int64)).astype(np.uint64)
+            pieces[p0] = lists.copy()
+
+        st = self.run_stream(pairs, ratio_sq, on_batch)
+        offsets = np.cumsum(counts, dtype=np.uint64)
+        keys = sorted(pieces)
+        ij = np.concatenate([pieces[k] for k in keys]) if keys else np.zeros((0, 2), np.uint32)
+        return st, offsets, ij, keys
 
 
 class HammingContext:

@@ -16,7 +16,7 @@ REFOBJ := $(ROOT)/oracle/_ref/obj
 CXX ?= g++
 INC := -I$(ROOT)/include -I$(REF) -I$(REF)/third_party/eigen -I$(REF)/third_party \
        -I$(REF)/third_party/flann/src/cpp -I$(REF)/third_party/hnswlib -I$(REF)/dependencies/cereal/include \
-       -I$(ROOT)/oracle/ceres_config -I$(REF)/third_party/ceres-solver/include \
+       -I$(ROOT)/openmvg_amd/adapter/ceres_config -I$(REF)/third_party/ceres-solver/include \
        -I$(REF)/third_party/ceres-solver/internal/ceres/miniglog
 BASEFLAGS := -std=c++11 -O3 -fPIC -fopenmp -DOPENMVG_USE_OPENMP -DEIGEN_MPL2_ONLY -w $(INC)
 REF_MATCH_OBJS := $(REFOBJ)/openMVG/matching/regions_matcher.o $(REFOBJ)/openMVG/features/feature.o \

@@ -29,6 +29,19 @@ def test_sift_uint8_route():
     _same(got, want)
 
 
+def test_sift_route_on_the_devices_of_the_environment(monkeypatch):
+    """MVGX_DEVICES in the caller's environment: Match runs several device contexts (here emulated ones), the lists arrive
+    batch by batch on the calling thread, the container equals the single-context one"""
+    descs = synth.image_descriptors(9, n_desc=110, seed=12)
+    descs[2] = descs[2][:0]
+    pairs = matching.exhaustive_pairs_array(9)
+    off, ij = _oracle.port_matcher_regions_match(descs, pairs, 0.8)
+    want = _oracle.offsets_to_dict(pairs, off, ij)
+    for env in ("0,0", "0,0,0", "all"):
+        monkeypatch.setenv("MVGX_DEVICES", env)
+        _same(_oracle.ref_matcher_regions_match(descs, pairs, 0.8, lib=_oracle.adapter_emu()), want)
+
+
 def test_liop_uint8_144_route():
     sizes = [120, 0, 130, 64, 1, 2]
     imgs = liop_like(sizes, 144, seed=21)

@@ -133,3 +133,17 @@ def test_bundle_adjustment_unsupported_model_returns_false():
     # in test_ba_gpu.py::test_error_behaviour. Here: Adjust on a healthy scene returns true and lowers the RMSE.
     rc, stats, *_ = _oracle.ref_ba_adjust(sc, lib=_oracle.adapter())
     assert rc == 0 and stats[1] < stats[0]
+
+
+def test_matcher_regions_replacement_uses_the_devices_of_the_environment(monkeypatch):
+    """Unchanged callers reach several GPUs through the environment: MVGX_DEVICES=0,0 makes Matcher_Regions::Match of the
+    replacement TU run two device contexts (here on the one GPU of the box) - same container."""
+    descs = synth.image_descriptors(30, n_desc=700, seed=13)
+    descs[4] = descs[4][:0]
+    pairs = matching.exhaustive_pairs_array(30)
+    one = _oracle.ref_matcher_regions_match(descs, pairs, 0.8, lib=_oracle.adapter())
+    monkeypatch.setenv("MVGX_DEVICES", "0,0")
+    two = _oracle.ref_matcher_regions_match(descs, pairs, 0.8, lib=_oracle.adapter())
+    _same(one, two)
+    off, ij = _oracle.port_matcher_regions_match(descs, pairs, 0.8)
+    _same(two, _oracle.offsets_to_dict(pairs, off, ij))

@@ -153,3 +153,53 @@ def test_pair_shards_reproduce_the_single_rank_run(world):
     assert np.array_equal(np.concatenate(got_pairs), all_pairs)          # contiguous shards, in order, covering every pair once
     assert np.array_equal(np.concatenate(counts), np.diff(o_off))
     assert np.array_equal(np.concatenate(got_ij), o_ij)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
+def test_streamed_and_multi_device_runs_equal_the_single_run(devices):
+    """mvgx_match_run_stream (lists handed over batch by batch on the calling thread, host memory O(batch)) and multi-device
+    contexts (mvgx_match_create_multi: one host thread per device, batches shared out dynamically, no collective):
+    every batch carries the lists of the single-device run; several emulated contexts on 'device 0'"""
+    sizes = [90, 40, 0, 130, 75, 20, 1, 64]
+    imgs = synth.image_descriptors(len(sizes), n_desc=max(sizes), seed=23)
+    imgs = [d[:s] for d, s in zip(imgs, sizes)]
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    with _emu.emulated():
+        for opts in ({"batch_pairs": 3}, {"batch_pairs": 5, "overlap": 0}, {"batch_pairs": 64}):
+            ctx = matching.MatchContext(0) if devices is None else matching.MatchContext(devices=devices)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            ctx.set_regions(imgs)
+            st, off, ij, firsts = ctx.run_collect_stream(pairs, np.float32(0.64))
+            assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), (devices, opts)
+            assert st.n_matches == len(o_ij)
+            b = opts["batch_pairs"]
+            assert firsts == list(range(0, len(pairs), b))   # every batch was handed over exactly once
+            # the collecting entry point on the same context
+            _, off2, ij2 = ctx.run(pairs, np.float32(0.64))
+            assert np.array_equal(off2, o_off) and np.array_equal(ij2, o_ij), (devices, opts)
+            # a sink that asks to stop is not entered again
+            seen = []
+            ctx.run_stream(pairs, np.float32(0.64), lambda p0, off_, ij_: seen.append(p0) or True)
+            assert len(seen) == 1
+            ctx.close()
+
+
+def test_devices_from_the_environment(monkeypatch):
+    """mvgx_match_create(-1) consults MVGX_DEVICES ("all", a list of ordinals); a bad list is an argument error"""
+    imgs = synth.image_descriptors(3, n_desc=50, seed=5)
+    pairs = matching.exhaustive_pairs_array(3)
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    with _emu.emulated():
+        for env in ("0,0", "all", "0"):
+            monkeypatch.setenv("MVGX_DEVICES", env)
+            ctx = matching.MatchContext(-1)
+            ctx.set_option("batch_pairs", 2)
+            ctx.set_regions(imgs)
+            _, off, ij = ctx.run(pairs, np.float32(0.64))
+            ctx.close()
+            assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), env
+        monkeypatch.setenv("MVGX_DEVICES", "0,99")
+        with pytest.raises(_capi.MvgxError):
+            matching.MatchContext(-1)

@@ -309,3 +309,56 @@ def test_large_images_vs_oracle(n):
     assert np.array_equal(offsets, o_off)
     assert np.array_equal(ij, o_ij)
     assert int(o_off[-1]) > 0
+
+
+# ---- streaming hand-over and several device contexts in one process ------------------
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
+def test_streamed_and_multi_device_runs_equal_the_single_run(devices):
+    """mvgx_match_run_stream + mvgx_match_create_multi: 48 images x 2000 descriptors, 1128 pairs in batches of 100, two /
+    three contexts on this one GPU (one host thread each, batches shared out dynamically): per-batch lists and the collected
+    run equal the single-context run bit for bit."""
+    imgs = synth.image_descriptors(48, n_desc=2000, seed=0xC0FFEE00)
+    imgs[7] = imgs[7][:0]
+    imgs[11] = imgs[11][:1]
+    pairs = matching.exhaustive_pairs_array(48)
+    _, want_off, want_ij = run_hip(imgs, pairs, 0.8, 43)
+    ctx = matching.MatchContext(0) if devices is None else matching.MatchContext(devices=devices)
+    try:
+        ctx.set_option("batch_pairs", 100)
+        ctx.set_regions(imgs)
+        st, off, ij, firsts = ctx.run_collect_stream(pairs, np.float32(0.8) * np.float32(0.8))
+        assert firsts == list(range(0, len(pairs), 100))
+        assert np.array_equal(off, want_off) and np.array_equal(ij, want_ij)
+        assert int(st.n_matches) == len(want_ij) and int(st.n_desc_pairs) == sum(len(imgs[a]) * len(imgs[b]) for a, b in pairs if len(imgs[a]) >= 2)
+        st2, off2, ij2 = ctx.run(pairs, np.float32(0.8) * np.float32(0.8))
+        assert np.array_equal(off2, want_off) and np.array_equal(ij2, want_ij)
+    finally:
+        ctx.close()
+
+
+def test_streaming_keeps_host_memory_flat():
+    """A 400-image run (79 800 pairs, ~0.16 GB of match lists) streamed in batches of 4096 pairs: the process's resident set
+    grows by the two pinned batch buffers, not by the run's lists (what a 10 000-image run needs: DESIGN 3.2)."""
+    import psutil
+    imgs = synth.image_descriptors(400, n_desc=2000, seed=0xC0FFEE00)
+    pairs = matching.exhaustive_pairs_array(400)
+    ctx = matching.MatchContext(0)
+    try:
+        ctx.set_option("batch_pairs", 4096)
+        ctx.set_regions(imgs)
+        r2 = np.float32(0.8) * np.float32(0.8)
+        tot = [0, 0]
+
+        def on_batch(p0, off, lists):
+            tot[0] += len(lists)
+            tot[1] = max(tot[1], lists.nbytes)
+        ctx.run_stream(pairs[:8192], r2, on_batch)   # first batches: buffers allocated
+        rss0 = psutil.Process().memory_info().rss
+        tot[0] = 0
+        st = ctx.run_stream(pairs, r2, on_batch)
+        rss1 = psutil.Process().memory_info().rss
+        assert tot[0] == int(st.n_matches) > 10_000_000
+        assert rss1 - rss0 < 4 * tot[1] + (32 << 20), (rss0, rss1, tot)
+        assert 8 * tot[0] > 20 * (rss1 - rss0)    # the whole run's lists are >20x what the process grew by
+    finally:
+        ctx.close()
