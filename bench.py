@@ -4,13 +4,16 @@
   python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the matching hot path over this rank's shard of the exhaustive pair list (+ one BA LM
-iteration on the BA scene when the BA kernels are built). Workload at N=1: BASELINE.json configs[1]
-("1k images x 2k SIFT/img exhaustive brute-force L2 matching on 1 MI355X" = 499 500 image pairs = 2.0e12
-descriptor pairs). Weak scaling: N ranks match round(1000*sqrt(N)) images, i.e. ~499 500 pairs per GPU; the pair
-list is cut into N contiguous shards, descriptors are replicated, no data-path collective.
+iteration on the BA scene when the BA kernels are built). Workloads (BASELINE.json):
+  N = 1     configs[1]: 1k images x 2k SIFT (499 500 image pairs = 2.0e12 descriptor pairs) on one MI355X
+  N = 2, 4  the same set, pair list cut into N contiguous shards ("scaling": "strong")
+  N = 8     configs[3]: 10k images x 2k SIFT (49 995 000 image pairs = 2.0e14 descriptor pairs), pair-sharded x8
+Descriptors are replicated, no data-path collective. The BA side record is configs[2] at N = 1 (plus configs[4] on one GPU)
+and configs[4] itself, point-sharded over the N ranks with the RCCL exchange, at N > 1.
 
 `value` = descriptor pairs (distance evaluations) per second over all ranks, inputs resident in HBM when the clock
-starts, result lists delivered to host memory inside the timed region.
+starts, result lists delivered to host memory inside the timed region (streamed batch by batch through two pinned buffers
+per rank - mvgx_match_run_stream - so the host footprint does not depend on the size of the run).
 """
 import argparse
 import json
@@ -45,6 +48,8 @@ def parse():
     ap.add_argument("--ratio", type=float, default=0.8)
     ap.add_argument("--batch-pairs", type=int, default=0, help="image pairs per device batch (default: library default)")
     ap.add_argument("--overlap", type=int, default=-1, help="0: one batch at a time (isolated kernel timings); default: library default (1)")
+    ap.add_argument("--collect", action="store_true", help="keep the run's match lists in one pinned host buffer (mvgx_match_run) "
+                                                           "instead of streaming them (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-ba", action="store_true")
@@ -111,8 +116,7 @@ def main():
 
     from openmvg_amd import matching, synth
 
-    n_images = args.images if args.images > 0 else 1000
-    n_images = int(round(n_images * np.sqrt(world)))
+    n_images = args.images if args.images > 0 else (10000 if world >= 8 else 1000)
     descs = synth.image_descriptors(n_images, n_desc=args.desc, seed=0xC0FFEE00)
     all_pairs = matching.exhaustive_pairs_array(n_images)
     from openmvg_amd import sharding
@@ -125,6 +129,8 @@ def main():
         ctx.set_option("overlap", args.overlap)
     if args.batch_pairs > 0:
         ctx.set_option("batch_pairs", args.batch_pairs)
+    elif len(pairs) < 16 * 32768:   # a shard of the 1k-image set: keep >= 16 batches in the two-slot pipeline (fill / drain)
+        ctx.set_option("batch_pairs", max(4096, len(pairs) // 16))
     ctx.set_option("profile", 1)
     ctx.set_regions(descs)  # descriptors resident in HBM (tile layout built here, outside the timed region)
     ratio_sq = np.float32(args.ratio) * np.float32(args.ratio)
@@ -134,8 +140,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_pass():
+        if args.collect:
+            return ctx.run(pairs, ratio_sq, fetch=False)[0]
+        return ctx.run_stream(pairs, ratio_sq)      # every batch's lists reach host memory; nothing is kept
+
     for _ in range(args.warmup):
-        ctx.run(pairs, ratio_sq, fetch=False)
+        one_pass()
 
     kernel_ms = 0.0
     launches = 0
@@ -144,7 +155,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st, _, _ = ctx.run(pairs, ratio_sq, fetch=False)
+        st = one_pass()
         kernel_ms += st.kernel_ms
         launches += int(st.n_kernel_launches)
         desc_pairs += int(st.n_desc_pairs)
@@ -179,13 +190,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world >= 8 or world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "i8 (int32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{n_images} images x {args.desc} SIFT-like uint8x128 descriptors, exhaustive pairs "
                                    f"({len(all_pairs)} image pairs, {len(pairs)} on rank 0), ratio {args.ratio}",
                        "kernel_variant": variant, "matches_rank0": matches,
+                       "results": "collected (one pinned host buffer)" if args.collect else "streamed (two pinned batch buffers)",
                        "parallelism": f"pair-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS,

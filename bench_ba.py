@@ -78,15 +78,11 @@ def cpu_reference(scene, gpu_summary, budget_s):
 
 
 def ba_config(world, name=None):
-    """BASELINE.json configs[2] at 1 GPU (200 pinhole cams / 100k points / 1M obs) growing to configs[4] at 8 GPUs
-    (1k cams pinhole+K3 in 8 intrinsic groups / 500k points / 5M obs); linear in between. name="c5": configs[4] as is."""
-    if name == "c5":
+    """BASELINE.json configs[2] at 1 GPU (200 pinhole cams / 100k points / 1M obs); configs[4] itself (1k cams pinhole+K3 in 8
+    intrinsic groups / 500k points / 5M obs) point-sharded over the ranks at N > 1 (strong scaling) and, name="c5", on one GPU."""
+    if name == "c5" or world > 1:
         return dict(n_cams=1000, n_points=500000, track_len=10, model=3, n_intr_groups=8, seed=0xBA5E0005)
-    if world <= 1:
-        return dict(n_cams=200, n_points=100000, track_len=10, model=1, n_intr_groups=1, seed=0xBA5E0003)
-    f = min(1.0, (world - 1) / 7.0)
-    return dict(n_cams=int(round(200 + 800 * f)), n_points=int(round(100000 + 400000 * f)), track_len=10, model=3,
-                n_intr_groups=8, seed=0xBA5E0005)
+    return dict(n_cams=200, n_points=100000, track_len=10, model=1, n_intr_groups=1, seed=0xBA5E0003)
 
 
 def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None):

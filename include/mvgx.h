@@ -261,7 +261,18 @@ typedef struct mvgx_ba_summary {
 } mvgx_ba_summary;
 
 void mvgx_ba_default_options(mvgx_ba_options* opt);
+/* device >= 0: that device; -1 ("no preference", what the openMVG adapter passes): MVGX_DEVICES ("all" or a list of
+ * ordinals) names the device(s) - two or more make a multi-device context when the problem has at least
+ * MVGX_BA_MULTI_MIN_OBS observations (default 200 000; smaller problems use the first one) - or, unset, the current
+ * device; <= -2: the current device, environment ignored. */
 int mvgx_ba_create(int device, const mvgx_ba_problem* problem, mvgx_ba_ctx** out);
+/* One context over several devices of THIS process (sfm_data_BA_ceres.cpp:165-608 is one call of one process): the
+ * problem is cut as described under "multi-GPU" below (points + their observations partitioned by sum L_p^2, camera blocks
+ * replicated, priors on the first shard), one single-device context and one host thread per shard, the per-iteration sums
+ * go over RCCL (distinct devices, librccl present) or over peer-mapped device memory (MVGX_BA_TRANSPORT=rccl|peer forces
+ * either; an ordinal may repeat with the peer transport). Every entry point below accepts such a context; results
+ * (parameters, residuals, track angles) come back in the caller's numbering. */
+int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_problem* problem, mvgx_ba_ctx** out);
 int mvgx_ba_destroy(mvgx_ba_ctx* ctx);
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------------------
  * Every rank creates its context from ITS shard of the problem: all poses and intrinsics (replicated, same

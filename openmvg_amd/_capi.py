@@ -149,6 +149,7 @@ PROTOTYPES = {
     "mvgx_l2u8_results": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]),
     "mvgx_ba_default_options": (None, [C.POINTER(BaOptions)]),
     "mvgx_ba_create": (C.c_int, [C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
+    "mvgx_ba_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
     "mvgx_ba_destroy": (C.c_int, [C.c_void_p]),
     "mvgx_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_F64, C.c_void_p]),
     "mvgx_comm_unique_id": (C.c_int, [C.c_void_p]),

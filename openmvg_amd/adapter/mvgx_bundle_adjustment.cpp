@@ -42,44 +42,87 @@ namespace sfm {
 using cameras::Intrinsic_Parameter_Type;
 using geometry::Pose3;
 
-bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& options) {
-  // --- motion priors: robust registration of the pose centres onto the prior centres, then the whole scene (priors
-  // included) is moved to the pose centroid for conditioning (sfm_data_BA_ceres.cpp:180-240). Host work on a handful of
-  // 3-vectors, done with the same library calls as the reference (LeastMedianOfSquares is seeded deterministically). ---
-  double pose_center_robust_fitting_error = 0.0;
-  openMVG::geometry::Similarity3 sim_to_center;
-  bool b_usable_prior = false;
-  if (options.use_motion_priors_opt && sfm_data.GetViews().size() > 3) {
-    std::vector<Vec3> X_SfM, X_GPS;
-    for (const auto& view_it : sfm_data.GetViews()) {
-      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
-      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
-        X_SfM.push_back(sfm_data.GetPoses().at(prior->id_pose).center());
-        X_GPS.push_back(prior->pose_center_);
-      }
+namespace {
+
+// Motion priors (sfm_data_BA_ceres.cpp:180-240 before the solve, :454-473 the residuals, :575-606 after it). The reference
+// walks the views three times with the same test; here the participating views are listed once and everything else reads
+// the current centres through that list. Host work on a handful of 3-vectors, done with the reference's own library
+// calls (Similarity3_Kernel + LeastMedianOfSquares, which seeds its sampler deterministically; ApplySimilarity) and the same
+// arithmetic, so the scene handed to the solver is the reference's bit for bit.
+class PosePriorFrame {
+ public:
+  PosePriorFrame(SfM_Data& scene, bool requested) : scene_(scene) {
+    if (!requested || scene.GetViews().size() <= 3) return;
+    for (const auto& v : scene.GetViews()) {
+      const ViewPriors* p = dynamic_cast<const ViewPriors*>(v.second.get());
+      if (p && p->b_use_pose_center_ && scene.IsPoseAndIntrinsicDefined(p)) views_.push_back(p);
     }
-    openMVG::geometry::Similarity3 sim;
-    if (X_GPS.size() > 3) {
-      const Mat X_SfM_Mat = Eigen::Map<Mat>(X_SfM[0].data(), 3, X_SfM.size());
-      const Mat X_GPS_Mat = Eigen::Map<Mat>(X_GPS[0].data(), 3, X_GPS.size());
-      geometry::kernel::Similarity3_Kernel kernel(X_SfM_Mat, X_GPS_Mat);
-      const double lmeds_median = openMVG::robust::LeastMedianOfSquares(kernel, &sim);
-      if (lmeds_median != std::numeric_limits<double>::max()) {
-        b_usable_prior = true;
-        for (Vec3& pos : X_SfM) pos = sim(pos);
-        Vec residual = (Eigen::Map<Mat3X>(X_SfM[0].data(), 3, X_SfM.size()) - Eigen::Map<Mat3X>(X_GPS[0].data(), 3, X_GPS.size())).colwise().norm();
-        std::sort(residual.data(), residual.data() + residual.size());
-        pose_center_robust_fitting_error = residual(residual.size() / 2);
-        openMVG::sfm::ApplySimilarity(sim, sfm_data);
-        Vec3 pose_centroid = Vec3::Zero();
-        for (const auto& pose_it : sfm_data.poses) pose_centroid += (pose_it.second.center() / (double)sfm_data.poses.size());
-        sim_to_center = openMVG::geometry::Similarity3(openMVG::sfm::Pose3(Mat3::Identity(), pose_centroid), 1.0);
-        openMVG::sfm::ApplySimilarity(sim_to_center, sfm_data, true);
-      }
-    } else {
-      OPENMVG_LOG_WARNING << "Cannot used the motion prior, insufficient number of motion priors/poses";
+    if (views_.size() <= 3) {
+      OPENMVG_LOG_WARNING << "Motion priors ignored: " << views_.size() << " usable pose-centre prior(s), at least 4 are needed";
+      return;
     }
+    // robust similarity pose centres -> prior centres
+    geometry::Similarity3 fit;
+    const Mat from = pose_centres(), to = prior_centres();
+    geometry::kernel::Similarity3_Kernel kernel(from, to);
+    if (robust::LeastMedianOfSquares(kernel, &fit) == std::numeric_limits<double>::max()) return;
+    usable_ = true;
+    // median distance of the registered centres to their priors: the scale of the priors' Huber loss
+    Mat3X moved(3, views_.size());
+    for (size_t k = 0; k < views_.size(); ++k) moved.col(k) = fit(Vec3(from.col(k)));
+    Vec gap = (moved - Mat3X(to)).colwise().norm();
+    std::nth_element(gap.data(), gap.data() + gap.size() / 2, gap.data() + gap.size());
+    median_gap_ = gap(gap.size() / 2);
+    ApplySimilarity(fit, scene_);
+    // conditioning: origin at the centroid of the pose centres, priors moved along
+    Vec3 centroid = Vec3::Zero();
+    const double n_poses = static_cast<double>(scene_.poses.size());
+    for (const auto& pose : scene_.poses) centroid += pose.second.center() / n_poses;
+    to_centroid_ = geometry::Similarity3(Pose3(Mat3::Identity(), centroid), 1.0);
+    ApplySimilarity(to_centroid_, scene_, true);
   }
+
+  bool usable() const { return usable_; }
+  double median_gap() const { return median_gap_; }
+  size_t size() const { return usable_ ? views_.size() : 0; }
+  const ViewPriors& view(size_t k) const { return *views_[k]; }
+
+  // after the solve: back to the caller's origin, then the fitting statistics of the log
+  void leave() {
+    if (!usable_) return;
+    ApplySimilarity(to_centroid_.inverse(), scene_, true);
+    const Vec gap = (Mat3X(pose_centres()) - Mat3X(prior_centres())).colwise().norm();
+    std::ostringstream os;
+    os << "Pose prior statistics (user units):\n"
+       << " - Starting median fitting error: " << median_gap_ << "\n"
+       << " - Final fitting error:\n";
+    minMaxMeanMedian<Vec::Scalar>(gap.data(), gap.data() + gap.size(), os);
+    OPENMVG_LOG_INFO << os.str();
+  }
+
+ private:
+  Mat pose_centres() const {
+    Mat m(3, views_.size());
+    for (size_t k = 0; k < views_.size(); ++k) m.col(k) = scene_.GetPoses().at(views_[k]->id_pose).center();
+    return m;
+  }
+  Mat prior_centres() const {
+    Mat m(3, views_.size());
+    for (size_t k = 0; k < views_.size(); ++k) m.col(k) = views_[k]->pose_center_;
+    return m;
+  }
+  SfM_Data& scene_;
+  std::vector<const ViewPriors*> views_;
+  bool usable_ = false;
+  double median_gap_ = 0.0;
+  geometry::Similarity3 to_centroid_;
+};
+
+}  // namespace
+
+bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& options) {
+  PosePriorFrame priors(sfm_data, options.use_motion_priors_opt);   // may move the whole scene (undone by priors.leave())
+  const bool b_usable_prior = priors.usable();
 
   // --- parameter blocks ---
   std::unordered_map<IndexT, uint32_t> pose_idx, intr_idx;
@@ -190,21 +233,17 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   // --- pose-centre priors (:454-473); the reference indexes the pose block with prior->id_view ---
   std::vector<uint32_t> prior_pose;
   std::vector<double> prior_center, prior_weight;
-  if (b_usable_prior) {
-    for (const auto& view_it : sfm_data.GetViews()) {
-      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
-      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
-        prior_pose.push_back(pose_idx.at(prior->id_view));
-        for (int k = 0; k < 3; ++k) { prior_center.push_back(prior->pose_center_(k)); prior_weight.push_back(prior->center_weight_(k)); }
-      }
-    }
+  for (size_t k = 0; k < priors.size(); ++k) {
+    const ViewPriors& v = priors.view(k);
+    prior_pose.push_back(pose_idx.at(v.id_view));
+    for (int a = 0; a < 3; ++a) { prior_center.push_back(v.pose_center_(a)); prior_weight.push_back(v.center_weight_(a)); }
   }
 
   mvgx_ba_problem prob{};
   if (!obs_weight.empty()) { prob.obs_weight = obs_weight.data(); prob.obs_is_control = obs_is_control.data(); prob.point_const_mask = point_const.data(); }
   prob.n_pose_priors = static_cast<uint32_t>(prior_pose.size());
   prob.prior_pose = prior_pose.data(); prob.prior_center = prior_center.data(); prob.prior_weight = prior_weight.data();
-  prob.prior_huber_a = Square(pose_center_robust_fitting_error);
+  prob.prior_huber_a = Square(priors.median_gap());
   prob.n_poses = static_cast<uint32_t>(pose_ids.size());
   prob.n_intrinsics = static_cast<uint32_t>(intr_ids.size());
   prob.n_points = static_cast<uint32_t>(n_points_total);
@@ -286,26 +325,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
       cam->updateFromParams(std::vector<double>(&intrinsics[8 * k], &intrinsics[8 * k] + np));
     }
   }
-  if (b_usable_prior) {   // set back to the original scene centroid + fitting statistics (:575-606)
-    openMVG::sfm::ApplySimilarity(sim_to_center.inverse(), sfm_data, true);
-    std::vector<Vec3> X_SfM, X_GPS;
-    for (const auto& view_it : sfm_data.GetViews()) {
-      const sfm::ViewPriors* prior = dynamic_cast<sfm::ViewPriors*>(view_it.second.get());
-      if (prior != nullptr && prior->b_use_pose_center_ && sfm_data.IsPoseAndIntrinsicDefined(prior)) {
-        X_SfM.push_back(sfm_data.GetPoses().at(prior->id_pose).center());
-        X_GPS.push_back(prior->pose_center_);
-      }
-    }
-    if (X_GPS.size() > 3) {
-      const Vec residual = (Eigen::Map<Mat3X>(X_SfM[0].data(), 3, X_SfM.size()) - Eigen::Map<Mat3X>(X_GPS[0].data(), 3, X_GPS.size())).colwise().norm();
-      std::ostringstream os;
-      os << "Pose prior statistics (user units):\n"
-         << " - Starting median fitting error: " << pose_center_robust_fitting_error << "\n"
-         << " - Final fitting error:\n";
-      minMaxMeanMedian<Vec::Scalar>(residual.data(), residual.data() + residual.size(), os);
-      OPENMVG_LOG_INFO << os.str();
-    }
-  }
+  priors.leave();
   return true;
 }
 

@@ -53,7 +53,10 @@ def comm_unique_id():
 class BaContext:
     """Device-resident BA problem (thin wrapper over mvgx_ba_*)."""
 
-    def __init__(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0, device=-1):
+    def __init__(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0, device=-1,
+                 devices=None):
+        """device: one ordinal (-1: MVGX_DEVICES or the current device). devices: list of ordinals -> one context over several
+        devices of this process (mvgx_ba_create_multi: the problem is sharded inside the library)."""
         self._keep = {}
 
         def arr(name, dtype):
@@ -89,7 +92,11 @@ class BaContext:
             p.prior_huber_a = float(scene.get("prior_huber_a", 0.0))
         self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
         self._h = C.c_void_p()
-        _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
+        if devices is not None:
+            arr_d = (C.c_int * len(devices))(*[int(x) for x in devices])
+            _capi.check(_capi.lib().mvgx_ba_create_multi(arr_d, len(devices), C.byref(p), C.byref(self._h)))
+        else:
+            _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
 
     def comm_init(self, world, rank, unique_id):
         """Bind this rank's context to an RCCL communicator (unique_id: the 128 bytes of comm_unique_id() of rank 0)."""

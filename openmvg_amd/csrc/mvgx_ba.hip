@@ -50,6 +50,7 @@
 
 #include "ba_math.h"
 #include "ba_sparse_plan.h"
+#include "mvgx_ba_multi.h"
 #include "mvgx_comm.h"
 #include "mvgx_common.h"
 
@@ -1427,6 +1428,7 @@ int dev_upload(std::vector<void*>& pool, T** p, const std::vector<T>& v, hipStre
 }  // namespace
 
 struct mvgx_ba_ctx {
+  mvgx::BaMulti* multi = nullptr;      // a context over several devices (mvgx_ba_create_multi / MVGX_DEVICES): everything below is unused
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1970,8 +1972,33 @@ void mvgx_ba_default_options(mvgx_ba_options* o) {
   o->verbose = 0;
 }
 
+int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
+  MVGX_REQUIRE(devices && p && out && n_devices >= 1, MVGX_ERR_ARG, "mvgx_ba_create_multi: bad argument");
+  // never more shards than points (an empty shard would only add latency)
+  n_devices = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)n_devices, p->n_points));
+  if (n_devices == 1) return mvgx_ba_create(devices[0] < 0 ? -2 : devices[0], p, out);
+  mvgx::BaMulti* m = nullptr;
+  const int rc = mvgx::ba_multi_create(devices, n_devices, p, &m);
+  if (rc) return rc;
+  auto* c = new mvgx_ba_ctx();
+  c->multi = m;
+  c->device = devices[0];
+  *out = c;
+  return MVGX_OK;
+}
+
 int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(p && out, MVGX_ERR_ARG, "mvgx_ba_create: NULL argument");
+  if (device == -1) {   // "no preference": MVGX_DEVICES may name the device(s); small problems stay on one device
+    std::vector<int> devs;
+    const int rc = mvgx::devices_from_env(devs);
+    if (rc) return rc;
+    uint64_t min_obs = 200000;   // below this an LM iteration is a few hundred microseconds of device work: the exchange would dominate
+    if (const char* env = getenv("MVGX_BA_MULTI_MIN_OBS")) min_obs = strtoull(env, nullptr, 10);
+    if (devs.size() >= 2 && p->n_obs >= min_obs) return mvgx_ba_create_multi(devs.data(), (int)devs.size(), p, out);
+    if (!devs.empty()) device = devs[0];
+  }
+  if (device < 0) device = -1;
   MVGX_REQUIRE((p->poses || !p->n_poses) && (p->intrinsics || !p->n_intrinsics) && (p->points || !p->n_points), MVGX_ERR_ARG,
                "mvgx_ba_create: NULL parameter array");
   MVGX_REQUIRE(!p->n_obs || (p->obs_pose && p->obs_intr && p->obs_point && p->obs_xy), MVGX_ERR_ARG,
@@ -2272,6 +2299,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 
 int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (!c) return MVGX_OK;
+  if (c->multi) {
+    mvgx::ba_multi_destroy(c->multi);
+    delete c;
+    return MVGX_OK;
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void* q : c->pool) if (q) (void)hipFree(q);
@@ -2288,6 +2320,7 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
 
 int mvgx_ba_comm_init(mvgx_ba_ctx* c, int world, int rank, const void* unique_id128) {
   MVGX_REQUIRE(c && unique_id128, MVGX_ERR_ARG, "mvgx_ba_comm_init: NULL argument");
+  MVGX_REQUIRE(!c->multi, MVGX_ERR_STATE, "mvgx_ba_comm_init: a multi-device context has its own exchange");
   MVGX_REQUIRE(!c->started, MVGX_ERR_STATE, "mvgx_ba_comm_init after the solve has started");
   MVGX_HIP(hipSetDevice(c->device));
   mvgx::rccl_destroy(c->rccl);
@@ -2297,6 +2330,7 @@ int mvgx_ba_comm_init(mvgx_ba_ctx* c, int world, int rank, const void* unique_id
 
 int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {
   MVGX_REQUIRE(c, MVGX_ERR_ARG, "mvgx_ba_set_allreduce: NULL context");
+  MVGX_REQUIRE(!c->multi, MVGX_ERR_STATE, "mvgx_ba_set_allreduce: a multi-device context has its own exchange");
   c->allreduce = fn;
   c->allreduce_user = user;
   return MVGX_OK;
@@ -2304,6 +2338,7 @@ int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {
 
 int mvgx_ba_lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_summary* summary) {
   MVGX_REQUIRE(c && opt, MVGX_ERR_ARG, "mvgx_ba_lm_iteration: NULL argument");
+  if (c->multi) return mvgx::ba_multi_solve(c->multi, opt, summary, true);
   MVGX_HIP(hipSetDevice(c->device));
   int rc;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -2320,6 +2355,7 @@ int mvgx_ba_lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_sum
 
 int mvgx_ba_solve(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_summary* summary) {
   MVGX_REQUIRE(c && opt, MVGX_ERR_ARG, "mvgx_ba_solve: NULL argument");
+  if (c->multi) return mvgx::ba_multi_solve(c->multi, opt, summary, false);
   MVGX_HIP(hipSetDevice(c->device));
   int rc;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -2339,6 +2375,7 @@ int mvgx_ba_solve(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_summary* s
 
 int mvgx_ba_read_params(mvgx_ba_ctx* c, double* poses, double* intrinsics, double* points) {
   MVGX_REQUIRE(c, MVGX_ERR_ARG, "mvgx_ba_read_params: NULL context");
+  if (c->multi) return mvgx::ba_multi_read_params(c->multi, poses, intrinsics, points);
   MVGX_HIP(hipSetDevice(c->device));
   Dev& d = c->d;
   if (poses) MVGX_HIP(hipMemcpyAsync(poses, d.poses, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2350,6 +2387,7 @@ int mvgx_ba_read_params(mvgx_ba_ctx* c, double* poses, double* intrinsics, doubl
 
 int mvgx_ba_residuals(mvgx_ba_ctx* c, double* residual_norm) {
   MVGX_REQUIRE(c && residual_norm, MVGX_ERR_ARG, "mvgx_ba_residuals: NULL argument");
+  if (c->multi) return mvgx::ba_multi_residuals(c->multi, residual_norm);
   MVGX_HIP(hipSetDevice(c->device));
   Dev& d = c->d;
   if (!d.n_obs) return MVGX_OK;
@@ -2364,6 +2402,7 @@ int mvgx_ba_residuals(mvgx_ba_ctx* c, double* residual_norm) {
 
 int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
   MVGX_REQUIRE(c && max_angle_deg, MVGX_ERR_ARG, "mvgx_ba_track_angles: NULL argument");
+  if (c->multi) return mvgx::ba_multi_track_angles(c->multi, max_angle_deg);
   MVGX_HIP(hipSetDevice(c->device));
   Dev& d = c->d;
   if (!d.n_pts) return MVGX_OK;
@@ -2385,6 +2424,7 @@ int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
 
 int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {
   MVGX_REQUIRE(c && out, MVGX_ERR_ARG, "mvgx_ba_get_solver_info: NULL argument");
+  if (c->multi) return mvgx::ba_multi_solver_info(c->multi, out);
   MVGX_REQUIRE(c->solver_ready, MVGX_ERR_STATE, "mvgx_ba_get_solver_info before the first iteration");
   memset(out, 0, sizeof(*out));
   const int64_t nd = (c->d.N + 63) / 64;
@@ -2403,6 +2443,7 @@ int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {
 
 int mvgx_ba_evaluate(mvgx_ba_ctx* c, double* cost, double* rmse) {
   MVGX_REQUIRE(c, MVGX_ERR_ARG, "mvgx_ba_evaluate: NULL context");
+  if (c->multi) return mvgx::ba_multi_evaluate(c->multi, cost, rmse);
   MVGX_HIP(hipSetDevice(c->device));
   int rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts);
   if (rc) return rc;

@@ -42,9 +42,19 @@ def contiguousWithOverlap(N, overlapSize):
 
 
 def exhaustive_pairs_array(N):
-    """exhaustivePairs as an (n_pairs, 2) uint32 array, same order, without Python tuples."""
-    i, j = np.triu_indices(N, k=1)
-    return np.ascontiguousarray(np.stack([i, j], axis=1).astype(np.uint32))
+    """exhaustivePairs as an (n_pairs, 2) uint32 array, same order, without Python tuples (10 000 images: 5e7 rows, ~1 s)."""
+    N = int(N)
+    if N < 2:
+        return np.zeros((0, 2), np.uint32)
+    out = np.empty((N * (N - 1) // 2, 2), np.uint32)
+    js = np.arange(N, dtype=np.uint32)
+    pos = 0
+    for i in range(N - 1):           # N slice assignments: memory-bound
+        n = N - 1 - i
+        out[pos:pos + n, 0] = i
+        out[pos:pos + n, 1] = js[i + 1:]
+        pos += n
+    return out
 
 
 class Regions:

@@ -108,7 +108,7 @@ using std::min;
 
 // ---- runtime API subset used by the BA solver ----
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -118,6 +118,8 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 // failure injection for the error paths: HIPEMU_FAIL_MALLOC_AFTER=n makes the (n+1)-th and later device allocations fail
 static inline bool hipemu_malloc_should_fail() {
   static long seen = 0;

@@ -268,5 +268,6 @@ int rccl_allreduce_f64(RcclComm*, double*, uint64_t, int, hipStream_t) { return 
 }  // namespace mvgx
 extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out); }
 #include "mvgx_ba.hip"
+#include "mvgx_ba_multi.hip"
 #include "mvgx_bruteforce.hip"
 #endif  // HIPEMU_NO_PRODUCT

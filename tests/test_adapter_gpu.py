@@ -147,3 +147,21 @@ def test_matcher_regions_replacement_uses_the_devices_of_the_environment(monkeyp
     _same(one, two)
     off, ij = _oracle.port_matcher_regions_match(descs, pairs, 0.8)
     _same(two, _oracle.offsets_to_dict(pairs, off, ij))
+
+
+@pytest.mark.parametrize("name", list(_golden()["ex_case_names"])[-3:])
+def test_bundle_adjustment_ceres_replacement_on_the_devices_of_the_environment(name, monkeypatch):
+    """Unchanged callers of Bundle_Adjustment_Ceres::Adjust reach several GPUs through the environment (MVGX_DEVICES; here
+    two shards on the one GPU of the box, threshold lowered so that the small golden scenes are sharded): same outputs as
+    the reference's on control-point / prior scenes."""
+    from tests.test_ba_gpu import _ex_case
+    monkeypatch.setenv("MVGX_DEVICES", "0,0")
+    monkeypatch.setenv("MVGX_BA_MULTI_MIN_OBS", "1")
+    z = _golden()
+    tag, sc = _ex_case(z, name)
+    iopt = int(name.split("|")[1])
+    ref_stats = z[f"{tag}/ref_stats"]
+    rc, stats, poses, intr, pts = _oracle.ref_ba_adjust_ex(sc, intrinsics_opt=iopt, lib=_oracle.adapter())
+    assert rc == 0 and stats[3] == ref_stats[3] == 1.0
+    assert abs(stats[1] - ref_stats[1]) < 1e-6, (stats[1], ref_stats[1])
+    assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-5)

@@ -474,3 +474,50 @@ def test_block_sparse_solver_with_per_camera_intrinsics_and_constant_blocks(monk
     assert s.num_iterations == osum.num_iterations
     assert abs(s.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
     assert np.allclose(pts, opx, atol=1e-9) and np.allclose(poses, opp, atol=1e-9) and np.allclose(intr, opi, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_in_process_multi_device_context_equals_the_single_device_solve(devices):
+    """mvgx_ba_create_multi: the library shards the problem itself (points by sum L_p^2, priors on the first shard), runs one
+    host thread per shard and sums over peer-mapped buffers in rank order - here several emulated contexts of 'device 0'.
+    Solve, read-back, residuals, track angles and evaluate come back in the caller's numbering."""
+    sc = synth.ba_scene(n_cams=9, n_points=170, track_len=5, model=3, n_intr_groups=2, seed=97, rot_deg=0.3)
+    sc = synth.add_pose_priors(synth.add_control_points(sc, n_ctrl=5, weight=20.0), sigma=0.005, huber_a=2e-4)
+    perm = np.random.default_rng(4).permutation(sc["n_obs"])       # observations not sorted by point
+    for k in ("obs_pose", "obs_intr", "obs_point", "obs_weight", "obs_is_control"):
+        sc[k] = np.ascontiguousarray(np.asarray(sc[k])[perm])
+    sc["obs_xy"] = np.ascontiguousarray(np.asarray(sc["obs_xy"]).reshape(-1, 2)[perm])
+    opt = ba.default_options(max_num_iterations=4)
+    with _emu.emulated():
+        one = ba.BaContext(sc)
+        s1 = one.solve(opt)
+        p1, i1, x1 = one.read_params()
+        r1, a1, e1 = one.residuals(), one.track_angles(), one.evaluate()
+        one.close()
+        many = ba.BaContext(sc, devices=devices)
+        s2 = many.solve(opt)
+        p2, i2, x2 = many.read_params()
+        r2, a2, e2 = many.residuals(), many.track_angles(), many.evaluate()
+        info = many.solver_info()
+        many.close()
+    assert s2.num_iterations == s1.num_iterations and s2.num_successful_steps == s1.num_successful_steps
+    assert abs(s2.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost and abs(s2.final_rmse - s1.final_rmse) < 1e-9
+    assert abs(s2.initial_rmse - s1.initial_rmse) < 1e-12
+    assert np.allclose(p2, p1, atol=1e-9) and np.allclose(i2, i1, rtol=1e-9, atol=1e-9) and np.allclose(x2, x1, atol=1e-8)
+    assert np.allclose(r2, r1, atol=1e-8) and np.allclose(a2, a1, atol=1e-7)
+    assert abs(e2[0] - e1[0]) <= 1e-9 * e1[0] and abs(e2[1] - e1[1]) < 1e-9
+    assert info.n_columns == 6 * 9 + 8 * 2
+
+
+def test_multi_device_from_the_environment_only_for_large_problems(monkeypatch):
+    """mvgx_ba_create(-1): MVGX_DEVICES names the devices, MVGX_BA_MULTI_MIN_OBS the size from which a problem is sharded"""
+    sc = synth.ba_scene(n_cams=6, n_points=80, track_len=4, model=1, n_intr_groups=1, seed=98)
+    opt = ba.default_options(max_num_iterations=2)
+    with _emu.emulated():
+        c = ba.BaContext(sc); ref = c.solve(opt); c.close()
+        monkeypatch.setenv("MVGX_DEVICES", "0,0")
+        c = ba.BaContext(sc); s_small = c.solve(opt); c.close()          # below the default threshold: one device
+        monkeypatch.setenv("MVGX_BA_MULTI_MIN_OBS", "10")
+        c = ba.BaContext(sc); s_multi = c.solve(opt); c.close()
+    for s in (s_small, s_multi):
+        assert s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost

@@ -100,3 +100,36 @@ def test_two_point_shards_reproduce_the_single_rank_solve(kw, strict):
         assert np.allclose(pts, rpts, atol=1e-8)
     # camera parameters are bit-identical across ranks (every rank factors the same reduced system)
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+# ---- the in-process form: one context over several device shards, threads + peer-mapped sums inside the library ----
+@pytest.mark.parametrize("devices,kw", [
+    ([0, 0], dict(n_cams=14, n_points=600, track_len=6, model=3, n_intr_groups=2, seed=92)),
+    ([0, 0, 0, 0], dict(n_cams=60, n_points=6000, track_len=8, model=3, n_intr_groups=4, seed=96)),
+])
+def test_in_process_multi_device_context_equals_the_single_device_solve(devices, kw):
+    """mvgx_ba_create_multi with several contexts on this one GPU (peer transport: every rank sums all ranks' buffers in rank
+    order): same LM trajectory as the single context, parameters / residuals / track angles in the caller's numbering."""
+    sc = synth.ba_scene(**kw)
+    one = ba.BaContext(sc); s1 = one.solve(); p1, i1, x1 = one.read_params(); r1, a1 = one.residuals(), one.track_angles(); one.close()
+    many = ba.BaContext(sc, devices=devices)
+    s2 = many.solve()
+    p2, i2, x2 = many.read_params()
+    r2, a2, e2 = many.residuals(), many.track_angles(), many.evaluate()
+    many.close()
+    assert s2.num_iterations == s1.num_iterations and s2.num_successful_steps == s1.num_successful_steps
+    assert abs(s2.final_rmse - s1.final_rmse) < 1e-9 and abs(s2.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost
+    assert abs(e2[1] - s1.final_rmse) < 1e-9
+    assert np.allclose(p2, p1, atol=1e-9) and np.allclose(i2, i1, rtol=1e-9, atol=1e-9) and np.allclose(x2, x1, atol=1e-8)
+    assert np.allclose(r2, r1, atol=1e-8) and np.allclose(a2, a1, atol=1e-7)
+
+
+def test_in_process_multi_device_large_exchange_takes_the_sliced_path(monkeypatch):
+    """dense reduced system of 1.2 M doubles (> 2^20): the reduce-scatter + all-gather form of the peer transport"""
+    monkeypatch.setenv("MVGX_BA_SOLVER", "dense")
+    sc = synth.ba_scene(n_cams=180, n_points=4000, track_len=180, model=1, n_intr_groups=1, seed=99)   # every point sees every camera
+    opt = ba.default_options(max_num_iterations=2)
+    one = ba.BaContext(sc); s1 = one.solve(opt); p1, _, _ = one.read_params(); one.close()
+    many = ba.BaContext(sc, devices=[0, 0, 0]); s2 = many.solve(opt); p2, _, _ = many.read_params(); many.close()
+    assert s2.num_iterations == s1.num_iterations and abs(s2.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost
+    assert np.allclose(p2, p1, atol=1e-9)
