@@ -321,6 +321,10 @@ typedef struct mvgx_ba_solver_info {
   int64_t n_factor_tiles;  /* 64 x 64 tiles of the factor's lower triangle (dense: nt (nt + 1) / 2)                */
   int64_t n_dense_tiles;   /* nt (nt + 1) / 2 with nt = ceil(N / 64)                                               */
   double flops;            /* floating-point operations of one factorisation + solve on the stored tiles           */
+  /* Schur assembly: points whose pose x pose products are formed group-wise on the f64 matrix cores (groups of up to 42
+   * points that share a set of at most 10 poses); the other points go through the flat product list                   */
+  int32_t n_point_groups;
+  int32_t n_grouped_points;
 } mvgx_ba_solver_info;
 int mvgx_ba_get_solver_info(mvgx_ba_ctx* ctx, mvgx_ba_solver_info* out);   /* MVGX_ERR_STATE before the first iteration */
 

@@ -103,7 +103,7 @@ class BaSolverInfo(C.Structure):
     _fields_ = [
         ("sparse", C.c_int32), ("n_columns", C.c_int32), ("n_padded", C.c_int32), ("n_parts", C.c_int32),
         ("n_border_blocks", C.c_int32), ("n_levels", C.c_int32), ("n_factor_tiles", C.c_int64), ("n_dense_tiles", C.c_int64),
-        ("flops", C.c_double),
+        ("flops", C.c_double), ("n_point_groups", C.c_int32), ("n_grouped_points", C.c_int32),
     ]
 
 

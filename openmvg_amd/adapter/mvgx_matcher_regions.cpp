@@ -88,6 +88,8 @@ template <typename OffT>
 void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const OffT* offsets, const uint32_t* ij) {
   constexpr uint64_t kChunk = 256;
   const uint64_t n_chunks = (nb + kChunk - 1) / kChunk;
+  static const int debug_skip = std::getenv("MVGX_ADAPTER_DEBUG_SKIP") ? std::atoi(std::getenv("MVGX_ADAPTER_DEBUG_SKIP")) : 0;
+  if (debug_skip == 1) return;   // measurement only: device + transfers, nothing built
   std::vector<matching::IndMatches> lists(nb);
   auto build = [&](uint64_t k) {
     const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
@@ -97,6 +99,7 @@ void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const OffT
     for (uint64_t m = 0; m < n; ++m) v.emplace_back(ij[2 * (lo + m)], ij[2 * (lo + m) + 1]);
   };
   auto insert_chunk = [&](uint64_t c) {
+    if (debug_skip == 2) return;   // measurement only: lists built, container untouched
     for (uint64_t k = c * kChunk, hi = std::min(nb, k + kChunk); k < hi; ++k)
       if (!lists[k].empty())
         sink.out->insert({{(*sink.ids)[pairs_IJ[2 * k]], (*sink.ids)[pairs_IJ[2 * k + 1]]}, std::move(lists[k])});

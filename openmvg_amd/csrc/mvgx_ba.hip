@@ -62,6 +62,7 @@ using namespace mvgx_ba;
 constexpr int kJA = 8, kJB = 16, kJC = 16;   // doubles per observation record: {r, E} | {r, Fc, pad} | {Fi}
 constexpr int kIntrChunk = 2048;   // observations per workgroup of the intrinsic Gram kernel
 constexpr int kPiChunk = 512;      // observations per workgroup of the (pose, intrinsic) Gram kernel
+using d4_t = __attribute__((ext_vector_type(4))) double;   // accumulator of v_mfma_f64_16x16x4_f64
 constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave of the Schur-product kernel
 constexpr int kPoseGram = 27;      // per pose: Fc^T Fc upper triangle (21) | Fc^T r (6)
 constexpr int kPiGram = 75;        // per (pose, intrinsic) pair: the 27 above | Fc^T Fi (6 x 8)
@@ -84,7 +85,34 @@ struct TripList {
   uint32_t* block_col = nullptr;
   uint32_t* block_chunk0 = nullptr;   // n_blocks + 1
   int32_t* block_own = nullptr;       // pose x intrinsic lists: the (pose, intrinsic) pair whose Fc^T Fi adds in, or -1
-  double* part = nullptr;             // n_chunks x (WA * WB + WA)
+  double* part = nullptr;             // (n_chunks + n_ext) x (WA * WB + WA)
+  // pose x pose list only: partial blocks written by the point-group kernel (GroupList), numbered in block order after
+  // the n_chunks chunks of the flat list
+  uint32_t n_ext = 0;
+  uint32_t* block_ext0 = nullptr;     // n_blocks + 1 (null: none)
+};
+
+// Points whose observations fall on at most kGroupCams poses are processed in groups that share such a camera set: the
+// group's Z blocks are staged once into LDS as a dense (3 n_points) x 64 matrix (6 columns per local camera, column 60 =
+// h_p, zero where a point does not see a camera) and Z^T Z - all Schur products of the group, all destination blocks at
+// once - runs on the f64 matrix cores. Per product this reads 1/11 of what the flat product list reads (each Z block once
+// instead of once per partner) - the list stays for the points that fit no group (long tracks, constant points).
+constexpr int kGroupCams = 10;                                    // local cameras per group: 60 pose columns + h
+constexpr int kGroupPairs = kGroupCams * (kGroupCams + 1) / 2;    // destination blocks of a group
+constexpr int kGroupPts = 42;                                     // 126 rows of K
+constexpr int kGroupRS = 130;                                     // doubles between columns in LDS: = 2 mod 32 -> an MFMA operand read
+                                                                  // (16 columns x 2 rows per half wave) touches every bank pair once
+constexpr int kGroupLds = 64 * kGroupRS * (int)sizeof(double);
+constexpr int kGroupMinPts = 8;                                   // smaller groups go to the flat list
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+struct GroupList {
+  uint32_t n_groups = 0;
+  uint32_t* obs_start = nullptr;   // n_groups + 1 -> entries
+  uint32_t* obs = nullptr;         // entry: observation index
+  uint16_t* obs_qx = nullptr;      // entry: (local point << 8) | local camera
+  uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
+  uint32_t* pts = nullptr;         // local point -> point
+  uint32_t* chunk = nullptr;       // n_groups x kGroupPairs: row of tpp.part for local cameras (x <= y), kNoChunk: no common point
 };
 
 // Block-sparse storage of the reduced camera system (ba_sparse_plan.h): 64 x 64 tiles of the permuted, padded matrix,
@@ -144,6 +172,7 @@ struct Dev {
   double *Linv3 = nullptr, *hp = nullptr;   // per point: L_p^-1 (6, lower) and h_p = L_p^-1 Es^T r (3)
   double *Zpose = nullptr, *Zint = nullptr; // n_obs x 18, n_islots x 24
   TripList tpp, tpi, tii;
+  GroupList grp;
   double* S = nullptr;                // N x LD (dense mode only)
   SpSys sp;                           // block-sparse mode
   // multi-rank exchange of S: the union over ranks of the non-zero camera blocks, packed contiguously (+ the rhs column)
@@ -666,6 +695,98 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
   }
 }
 
+// One workgroup per point group: Z^T Z of the group's dense (rows x 64) matrix on the f64 matrix cores, upper 16 x 16
+// tiles shared out over the four waves; every (local camera x, local camera y >= x) block and the rhs column are written
+// as one partial block of the pose x pose list (fixed slot, no atomics), summed per destination by ba_schur_assemble.
+__device__ __forceinline__ int group_pair_index(int x, int y) { return x * kGroupCams - x * (x - 1) / 2 + (y - x); }
+__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, const uint32_t* __restrict__ chunk, double* __restrict__ part,
+                                                 int li, int lk) {
+  const int J = 16 * tj + li;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int I = 16 * ti + lk + 4 * reg;
+    if (I >= 6 * kGroupCams || J > 6 * kGroupCams || I > J) continue;
+    const int x = I / 6, r = I - 6 * x;
+    if (J == 6 * kGroupCams) {   // column of h_p: the rhs of camera x
+      const uint32_t ch = chunk[group_pair_index(x, x)];
+      if (ch != kNoChunk) part[(size_t)ch * 42 + 36 + r] = acc[reg];
+    } else {
+      const int y = J / 6, c = J - 6 * y;
+      const uint32_t ch = chunk[group_pair_index(x, y)];
+      if (ch != kNoChunk) part[(size_t)ch * 42 + r * 6 + c] = acc[reg];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ba_schur_group_kernel(GroupList G, const double* __restrict__ Z, const double* __restrict__ hp,
+                                                             double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [64 columns][kGroupRS]
+  const int g = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
+  __syncthreads();
+  // one observation per thread and turn: its 144-byte Z record arrives as nine independent 16-byte loads (neighbouring
+  // lanes read neighbouring records: the observations of a point are contiguous), then 18 LDS stores
+  const uint32_t e0 = G.obs_start[g], ne = G.obs_start[g + 1] - e0;
+  const uint32_t p0 = G.pt_start[g], np = G.pt_start[g + 1] - p0;
+  double hv = 0.0;
+  if ((uint32_t)tid < np * 3) hv = hp[(size_t)G.pts[p0 + tid / 3] * 3 + tid % 3];
+  for (uint32_t e = tid; e < ne; e += 256) {
+    const uint32_t qx = G.obs_qx[e0 + e], q = qx >> 8, x = qx & 255u;
+    const double2* __restrict__ zr = reinterpret_cast<const double2*>(Z + (size_t)G.obs[e0 + e] * 18);
+    double2 v[9];
+#pragma unroll
+    for (int w = 0; w < 9; ++w) v[w] = zr[w];
+    double* __restrict__ dst = lds + (6 * x) * kGroupRS + 3 * q;
+#pragma unroll
+    for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
+      const int k = (2 * w) / 6, cc = (2 * w) % 6;
+      dst[cc * kGroupRS + k] = v[w].x;
+      dst[(cc + 1) * kGroupRS + k] = v[w].y;
+    }
+  }
+  if ((uint32_t)tid < np * 3) lds[(6 * kGroupCams) * kGroupRS + tid] = hv;
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int rows = (int)(3 * np + 3) & ~3;
+  const double* __restrict__ col0 = lds + (0 * 16 + li) * kGroupRS + lk;
+  const double* __restrict__ col1 = lds + (1 * 16 + li) * kGroupRS + lk;
+  const double* __restrict__ col2 = lds + (2 * 16 + li) * kGroupRS + lk;
+  const double* __restrict__ col3 = lds + (3 * 16 + li) * kGroupRS + lk;
+  d4_t a0 = d4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
+  const uint32_t* __restrict__ chunk = G.chunk + (size_t)g * kGroupPairs;
+  // tiles (ti, tj), ti <= tj: wave 0: (0,0) (0,1) (0,2); wave 1: (0,3) (1,1) (1,2); wave 2: (1,3) (2,2); wave 3: (2,3) (3,3)
+  if (wave == 0) {
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+      const double f0 = col0[k0], f1 = col1[k0], f2 = col2[k0];
+      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f2, a2, 0, 0, 0);
+    }
+    group_store_tile(a0, 0, 0, chunk, part, li, lk); group_store_tile(a1, 0, 1, chunk, part, li, lk); group_store_tile(a2, 0, 2, chunk, part, li, lk);
+  } else if (wave == 1) {
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+      const double f0 = col0[k0], f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
+      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f3, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f2, a2, 0, 0, 0);
+    }
+    group_store_tile(a0, 0, 3, chunk, part, li, lk); group_store_tile(a1, 1, 1, chunk, part, li, lk); group_store_tile(a2, 1, 2, chunk, part, li, lk);
+  } else if (wave == 2) {
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+      const double f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
+      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f3, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, a1, 0, 0, 0);
+    }
+    group_store_tile(a0, 1, 3, chunk, part, li, lk); group_store_tile(a1, 2, 2, chunk, part, li, lk);
+  } else {
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+      const double f2 = col2[k0], f3 = col3[k0];
+      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f3, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f3, f3, a1, 0, 0, 0);
+    }
+    group_store_tile(a0, 2, 3, chunk, part, li, lk); group_store_tile(a1, 3, 3, chunk, part, li, lk);
+  }
+}
+
 // KIND 0: pose x pose, 1: pose x intrinsic, 2: intrinsic x intrinsic. Sums the chunks of one destination block, adds the
 // scaled Gram block that belongs there, writes the block (and, for diagonal blocks, the rhs entries) into S.
 template <int WA, int WB, int KIND>
@@ -679,6 +800,16 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
   if (e >= WA * WB && !diag) return;
   double sum = 0;
   for (uint32_t ch = L.block_chunk0[b]; ch < L.block_chunk0[b + 1]; ++ch) sum += L.part[(size_t)ch * NV + e];
+  if (KIND == 0 && L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
+    const uint32_t x1 = L.block_ext0[b + 1];
+    uint32_t x = L.block_ext0[b];
+    const double* __restrict__ q = L.part + (size_t)L.n_chunks * NV + e;
+    for (; x + 4 <= x1; x += 4) {
+      const double v0 = q[(size_t)x * NV], v1 = q[(size_t)(x + 1) * NV], v2 = q[(size_t)(x + 2) * NV], v3 = q[(size_t)(x + 3) * NV];
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; x < x1; ++x) sum += q[(size_t)x * NV];
+  }
   const uint32_t np = d.n_poses;
   const int row0 = rcb < np ? 6 * (int)rcb : 6 * (int)np + 8 * (int)(rcb - np);
   const int col0 = ccb < np ? 6 * (int)ccb : 6 * (int)np + 8 * (int)(ccb - np);
@@ -766,7 +897,6 @@ __device__ __forceinline__ double fast_rcp(double x) {   // v_rcp_f64 + two Newt
   return r;
 }
 
-using d4_t = __attribute__((ext_vector_type(4))) double;
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // src_lane wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -1299,6 +1429,15 @@ struct TripHost {
   std::vector<uint32_t> chunk_lo, chunk_hi, block_row, block_col, block_chunk0;
   std::vector<uint8_t> chunk_diag;
   std::vector<int32_t> block_own;
+  // external partial blocks (point groups): per block the range of ext rows, numbered in block order
+  std::vector<uint32_t> block_ext0;
+  uint32_t n_ext = 0;
+};
+// external partial blocks handed to build_trip_list: per row block a list of (column block, ext id), ascending; the list
+// build assigns every ext id its row in the partial-sum buffer (ext_row[id], counted after the flat chunks)
+struct TripExt {
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> rows;
+  std::vector<uint32_t> ext_row;
 };
 
 // Host threads for the structure build (the analogue of Ceres' preprocessor). f(index, thread) is called for every index
@@ -1361,7 +1500,7 @@ void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key ke
 // at most kTripChunk products. Rows are independent: they are generated by host threads and stitched in row order, so the
 // list does not depend on the thread count. O(products) time, no comparison sort over the products.
 template <class Gen>
-int build_trip_list(size_t n_cb, Gen gen, TripHost& out) {
+int build_trip_list(size_t n_cb, Gen gen, TripHost& out, TripExt* ext = nullptr) {
   struct RowMeta { std::vector<uint32_t> col, cnt; };
   std::vector<uint64_t> rstart(n_cb + 1, 0);
   const unsigned threads = host_threads(n_cb * 64);
@@ -1393,19 +1532,31 @@ int build_trip_list(size_t n_cb, Gen gen, TripHost& out) {
     for (size_t q = 0; q < sc.cols.size(); ++q) out.trips[sc.off[sc.cols[q]]++] = sc.ab[q];
   });
   out.block_chunk0.push_back(0);
+  if (ext) out.block_ext0.push_back(0);
   for (size_t r = 0; r < n_cb; ++r) {
     uint64_t pos = rstart[r];
     const RowMeta& m = meta[r];
-    for (size_t k = 0; k < m.col.size(); ++k) {
-      const uint32_t cb = m.col[k], cnt = m.cnt[k];
+    static const std::vector<std::pair<uint32_t, uint32_t>> none;
+    const auto& xr = ext ? ext->rows[r] : none;   // ascending (column, id)
+    size_t k = 0, x = 0;
+    while (k < m.col.size() || x < xr.size()) {   // union of the flat list's columns and the external ones, ascending
+      const uint32_t cb = std::min(k < m.col.size() ? m.col[k] : UINT32_MAX, x < xr.size() ? xr[x].first : UINT32_MAX);
       out.block_row.push_back((uint32_t)r); out.block_col.push_back(cb); out.block_own.push_back(-1);
-      for (uint64_t a = pos; a < pos + cnt; a += kTripChunk) {
-        out.chunk_lo.push_back((uint32_t)a);
-        out.chunk_hi.push_back((uint32_t)std::min<uint64_t>(a + kTripChunk, pos + cnt));
-        out.chunk_diag.push_back(cb == (uint32_t)r ? 1 : 0);
+      if (k < m.col.size() && m.col[k] == cb) {
+        const uint32_t cnt = m.cnt[k];
+        for (uint64_t a = pos; a < pos + cnt; a += kTripChunk) {
+          out.chunk_lo.push_back((uint32_t)a);
+          out.chunk_hi.push_back((uint32_t)std::min<uint64_t>(a + kTripChunk, pos + cnt));
+          out.chunk_diag.push_back(cb == (uint32_t)r ? 1 : 0);
+        }
+        pos += cnt;
+        ++k;
       }
       out.block_chunk0.push_back((uint32_t)out.chunk_lo.size());
-      pos += cnt;
+      if (ext) {
+        for (; x < xr.size() && xr[x].first == cb; ++x) ext->ext_row[xr[x].second] = out.n_ext++;
+        out.block_ext0.push_back(out.n_ext);
+      }
     }
   }
   return MVGX_OK;
@@ -1451,6 +1602,7 @@ struct mvgx_ba_ctx {
   int grid_obs = 0, grid_vec = 0;
   // reduced-system solver: block-sparse (tile) Cholesky with a nested-dissection order, or the dense one (auto: by fill)
   std::vector<std::pair<uint32_t, uint32_t>> h_blocks;   // non-zero camera blocks of this rank's S (row block, col block)
+  uint32_t n_grouped_points = 0;
   bool solver_ready = false;
   int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
   mvgx_sparse::Plan plan;          // host copy of the schedule (launch geometry per level)
@@ -1571,6 +1723,8 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   else MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
   if (d.tpp.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
+  if (d.grp.n_groups)
+    hipLaunchKernelGGL(ba_schur_group_kernel, dim3(d.grp.n_groups), dim3(256), kGroupLds, c->stream, d.grp, d.Zpose, d.hp, d.tpp.part);
   if (d.tpi.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(8 * ((d.tpi.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
   if (d.tii.n_chunks)
@@ -2173,6 +2327,98 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // Schur products by destination block, generated row by row on host threads. Constant / unused points have Z = 0: only
   // their (a, a) products are listed, so that every diagonal block exists (it carries the Gram block and the rhs).
   TripHost hpp, hpi, hii;
+  // Point groups of the pose x pose products (GroupList): free points with at most kGroupCams distinct poses, ordered by
+  // (lowest pose, highest pose, hash of the pose set); consecutive points join a group while the union of their poses stays within kGroupCams
+  // and the group within kGroupPts points. Groups of fewer than kGroupMinPts points are dissolved (their points stay in
+  // the flat list, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups.
+  std::vector<uint8_t> in_group(d.n_pts, 0);
+  std::vector<uint32_t> g_obs_start{0}, g_obs, g_pt_start{0}, g_pts, g_cams;   // g_cams: kGroupCams per group, UINT32_MAX = unused
+  std::vector<uint16_t> g_obs_qx;
+  std::vector<uint8_t> g_pair;   // kGroupPairs per group: some point sees both cameras
+  {
+    const char* env = getenv("MVGX_BA_GROUPS");
+    if (!(env && atoi(env) == 0) && d.n_poses && d.n_pts) {
+      std::vector<uint32_t> lo_pose(d.n_pts, UINT32_MAX), hi_pose(d.n_pts, 0);
+      std::vector<uint64_t> set_key(d.n_pts, 0);   // (highest pose, order-independent hash of the pose set): equal sets become neighbours
+      parallel_for_dynamic(n_pgrains, 1, T, [&](size_t g, unsigned) {
+        for (uint32_t j = (uint32_t)(g * 4096), e = (uint32_t)std::min<size_t>(d.n_pts, (g + 1) * 4096); j < e; ++j) {
+          const uint32_t o0 = pt_start[j], o1 = pt_start[j + 1];
+          bool ok = pt_free[j] && o1 > o0 && o1 - o0 <= (uint32_t)kGroupCams;
+          for (uint32_t o = o0; o < o1 && ok; ++o) {
+            for (uint32_t o2 = o0; o2 < o; ++o2) ok = ok && opose[o2] != opose[o];   // a pose seen twice (shared by two views): flat list
+            lo_pose[j] = std::min(lo_pose[j], opose[o]); hi_pose[j] = std::max(hi_pose[j], opose[o]);
+            uint64_t h = (uint64_t)opose[o] * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            set_key[j] += h * 0xBF58476D1CE4E5B9ull;   // commutative combination
+          }
+          set_key[j] = ((uint64_t)hi_pose[j] << 32) | (uint32_t)(set_key[j] >> 32);
+          if (!ok) lo_pose[j] = UINT32_MAX;
+        }
+      });
+      std::vector<uint32_t> lo_start, order;   // eligible points by lowest pose (bucket n_poses: not eligible)
+      counting_sort_indices(d.n_pts, d.n_poses + 1, T, [&](uint64_t j) { return lo_pose[j] == UINT32_MAX ? d.n_poses : lo_pose[j]; }, lo_start, order);
+      parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
+        std::stable_sort(order.begin() + lo_start[i], order.begin() + lo_start[i + 1], [&](uint32_t x, uint32_t y) { return set_key[x] < set_key[y]; });
+      });
+      std::vector<uint32_t> cams, merged, cur;
+      auto close_group = [&]() {
+        if (cur.size() >= (size_t)kGroupMinPts) {
+          const size_t g = g_pt_start.size() - 1;
+          g_cams.resize((g + 1) * kGroupCams, UINT32_MAX);
+          std::copy(cams.begin(), cams.end(), g_cams.begin() + g * kGroupCams);
+          g_pair.resize((g + 1) * kGroupPairs, 0);
+          for (size_t q = 0; q < cur.size(); ++q) {
+            const uint32_t j = cur[q];
+            in_group[j] = 1;
+            g_pts.push_back(j);
+            uint8_t xs[kGroupCams];
+            int nx = 0;
+            for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+              const int x = (int)(std::lower_bound(cams.begin(), cams.end(), opose[o]) - cams.begin());
+              g_obs.push_back(o);
+              g_obs_qx.push_back((uint16_t)((q << 8) | (unsigned)x));
+              xs[nx++] = (uint8_t)x;
+            }
+            for (int a = 0; a < nx; ++a)
+              for (int b = 0; b < nx; ++b)
+                if (xs[a] <= xs[b]) g_pair[g * kGroupPairs + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b] - xs[a])] = 1;
+          }
+          g_obs_start.push_back((uint32_t)g_obs.size());
+          g_pt_start.push_back((uint32_t)g_pts.size());
+        }
+        cur.clear(); cams.clear();
+      };
+      for (uint32_t q = 0; q < lo_start[d.n_poses]; ++q) {
+        const uint32_t j = order[q];
+        uint32_t pc[kGroupCams];
+        int npc = 0;
+        for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) pc[npc++] = opose[o];
+        std::sort(pc, pc + npc);
+        merged.clear();
+        std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(merged));
+        if (cur.size() == (size_t)kGroupPts || merged.size() > (size_t)kGroupCams) {
+          close_group();
+          merged.assign(pc, pc + npc);
+        }
+        cams = merged;
+        cur.push_back(j);
+      }
+      close_group();
+    }
+  }
+  const uint32_t n_groups = (uint32_t)g_pt_start.size() - 1;
+  TripExt gext;
+  {
+    const size_t n_cb = (size_t)d.n_poses + d.n_intr;
+    gext.rows.resize(n_cb);
+    gext.ext_row.assign((size_t)n_groups * kGroupPairs, kNoChunk);
+    for (uint32_t g = 0; g < n_groups; ++g)
+      for (int x = 0, t = 0; x < kGroupCams; ++x)
+        for (int y = x; y < kGroupCams; ++y, ++t)
+          if (g_pair[(size_t)g * kGroupPairs + t]) gext.rows[g_cams[(size_t)g * kGroupCams + x]].emplace_back(g_cams[(size_t)g * kGroupCams + y], g * kGroupPairs + t);
+    parallel_for_dynamic(n_cb, 16, T, [&](size_t r, unsigned) { std::sort(gext.rows[r].begin(), gext.rows[r].end()); });
+  }
+  tick("point groups");
   {
     const size_t n_cb = (size_t)d.n_poses + d.n_intr;
     const uint32_t np = d.n_poses;
@@ -2180,10 +2426,13 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           if (r >= np) return;
           for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
             const uint32_t a = pose_obs[q], j = opt_[a];
+            if (in_group[j]) continue;   // all products of the point are formed by its group
             for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
               if (r <= opose[b] && (pt_free[j] || a == b)) emit(opose[b], a, b);
           }
-        }, hpp))) return rc;
+        }, hpp, &gext))) return rc;
+    for (uint32_t& e : gext.ext_row)
+      if (e != kNoChunk) e += (uint32_t)hpp.chunk_lo.size();   // rows of the partial-sum buffer: after the flat chunks
     tick("pose-pose products");
     if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-intrinsic: Z_a^T Zint_slot
           if (r >= np) return;
@@ -2274,7 +2523,19 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if ((rc = dev_upload(c->pool, &l.block_col, h.block_col, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &l.block_chunk0, h.block_chunk0, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &l.block_own, h.block_own, c->stream))) return rc;
-      if ((rc = dev_alloc(c->pool, &l.part, (size_t)l.n_chunks * e.nv))) return rc;
+      l.n_ext = h.n_ext;
+      if (h.n_ext && (rc = dev_upload(c->pool, &l.block_ext0, h.block_ext0, c->stream))) return rc;
+      if ((rc = dev_alloc(c->pool, &l.part, ((size_t)l.n_chunks + l.n_ext) * e.nv))) return rc;
+    }
+    d.grp.n_groups = n_groups;
+    c->n_grouped_points = (uint32_t)g_pts.size();
+    if (n_groups) {
+      if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.obs, g_obs, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.obs_qx, g_obs_qx, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.chunk, gext.ext_row, c->stream))) return rc;
     }
   }
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
@@ -2285,6 +2546,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 #undef AL
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
@@ -2430,6 +2692,8 @@ int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {
   const int64_t nd = (c->d.N + 63) / 64;
   out->n_columns = c->d.N;
   out->n_dense_tiles = nd * (nd + 1) / 2;
+  out->n_point_groups = (int32_t)c->d.grp.n_groups;
+  out->n_grouped_points = (int32_t)c->n_grouped_points;
   if (c->d.sp.enabled) {
     const mvgx_sparse::Plan& pl = c->plan;
     out->sparse = 1; out->n_padded = pl.N_pad; out->n_parts = pl.n_parts; out->n_border_blocks = pl.n_border_blocks;

@@ -521,3 +521,34 @@ def test_multi_device_from_the_environment_only_for_large_problems(monkeypatch):
         c = ba.BaContext(sc); s_multi = c.solve(opt); c.close()
     for s in (s_small, s_multi):
         assert s.num_iterations == ref.num_iterations and abs(s.final_cost - ref.final_cost) <= 1e-9 * ref.final_cost
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=2, seed=101),
+    dict(n_cams=30, n_points=700, track_len=10, model=1, n_intr_groups=1, seed=102),      # ten poses per point: full groups
+    dict(n_cams=16, n_points=200, track_len=12, model=1, n_intr_groups=1, seed=103),      # tracks longer than a group: flat list only
+])
+def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkeypatch):
+    """pose x pose Schur products: points that share a set of <= 10 poses are multiplied group-wise (Z^T Z of the group's dense
+    matrix, f64 MFMA, one partial block per destination); the result must equal the flat product list's (MVGX_BA_GROUPS=0)
+    and the oracle's; constant points and a pose seen twice by one point stay on the flat list"""
+    sc = synth.ba_scene(**kw)
+    sc = synth.add_control_points(sc, n_ctrl=4, weight=10.0)                  # constant points with observations
+    sc["obs_pose"] = np.asarray(sc["obs_pose"]).copy()
+    first = int(np.flatnonzero(np.asarray(sc["obs_point"]) == 3)[0])         # point 3: make two of its observations share a pose
+    second = int(np.flatnonzero(np.asarray(sc["obs_point"]) == 3)[1])
+    sc["obs_pose"][second] = sc["obs_pose"][first]
+    opt = ba.default_options(max_num_iterations=3)
+    with _emu.emulated():
+        c = ba.BaContext(sc); s_g = c.solve(opt); pg, ig, xg = c.read_params(); info = c.solver_info(); c.close()
+        monkeypatch.setenv("MVGX_BA_GROUPS", "0")
+        c = ba.BaContext(sc); s_f = c.solve(opt); pf, if_, xf = c.read_params(); info_f = c.solver_info(); c.close()
+    assert info_f.n_point_groups == 0
+    if kw["track_len"] <= 10:
+        assert info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]
+    else:
+        assert info.n_point_groups == 0
+    assert s_g.num_iterations == s_f.num_iterations and abs(s_g.final_cost - s_f.final_cost) <= 1e-10 * s_f.final_cost
+    assert np.allclose(pg, pf, atol=1e-9) and np.allclose(ig, if_, rtol=1e-9, atol=1e-9) and np.allclose(xg, xf, atol=1e-8)
+    rc, osum, *_ = _oracle.port_ba_solve(sc, opt)
+    assert abs(s_g.final_rmse - osum.final_rmse) < 1e-9

@@ -335,7 +335,8 @@ def test_block_sparse_solver_equals_dense_and_oracle(kw, leaf, monkeypatch):
         assert abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
         assert abs(s.final_cost - osum.final_cost) <= 1e-8 * osum.final_cost
     # the two factorisations round differently; weakly determined parameters (one intrinsic per camera) move more than the cost
-    assert np.allclose(xs, xd, atol=1e-6) and np.allclose(ps, pd, atol=1e-6) and np.allclose(isn, idn, rtol=1e-6, atol=1e-6)
+    tol = 1e-4 if kw["n_intr_groups"] == kw["n_cams"] else 1e-6   # an intrinsic per camera: the scale of the scene is barely held
+    assert np.allclose(xs, xd, atol=tol) and np.allclose(ps, pd, atol=tol) and np.allclose(isn, idn, rtol=tol, atol=tol)
 
 
 def test_block_sparse_solver_is_chosen_for_a_sequential_capture_scene(monkeypatch):
@@ -355,3 +356,23 @@ def test_dense_visibility_scene_keeps_the_dense_solver(monkeypatch):
     ctx = ba.BaContext(sc); s = ctx.solve(); info = ctx.solver_info(); ctx.close()
     assert info.sparse == 0
     assert s.num_iterations == osum.num_iterations and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_cams=60, n_points=6000, track_len=10, model=3, n_intr_groups=4, seed=111),
+    dict(n_cams=40, n_points=3000, track_len=6, model=1, n_intr_groups=1, seed=112, outlier_frac=0.02),
+    dict(n_cams=24, n_points=1500, track_len=14, model=1, n_intr_groups=1, seed=113),     # tracks too long for a group
+])
+def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkeypatch):
+    """pose x pose Schur products formed group-wise on the f64 matrix cores (ba_schur_group_kernel) against the flat product
+    list (MVGX_BA_GROUPS=0) and the oracle: same LM trajectory, same parameters"""
+    sc = synth.ba_scene(**kw)
+    c = ba.BaContext(sc); s_g = c.solve(); pg, ig, xg = c.read_params(); info = c.solver_info(); c.close()
+    monkeypatch.setenv("MVGX_BA_GROUPS", "0")
+    c = ba.BaContext(sc); s_f = c.solve(); pf, if_, xf = c.read_params(); info_f = c.solver_info(); c.close()
+    assert info_f.n_point_groups == 0
+    assert (info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]) if kw["track_len"] <= 10 else info.n_point_groups == 0
+    assert s_g.num_iterations == s_f.num_iterations and abs(s_g.final_cost - s_f.final_cost) <= 1e-9 * s_f.final_cost
+    assert np.allclose(pg, pf, atol=1e-8) and np.allclose(ig, if_, rtol=1e-8, atol=1e-8) and np.allclose(xg, xf, atol=1e-7)
+    rc, osum, *_ = _oracle.port_ba_solve(sc)
+    assert s_g.num_iterations == osum.num_iterations and abs(s_g.final_rmse - osum.final_rmse) < RMSE_TOL
