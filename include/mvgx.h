@@ -77,7 +77,11 @@ int mvgx_match_destroy(mvgx_match_ctx* ctx);
  * "overlap" (default 1: two batch slots, batch b filters while batch b-1 is verified/compacted/copied; 0: one at a time),
  * "double_buffer_results" (default 0, see mvgx_match_run),
  * "pinned_results" (default 1: the host match lists live in pinned memory - fastest when a context is run many times;
- * 0: plain memory, for one-shot use where pinning a gigabyte costs more than the staged copies; set before the first run). */
+ * 0: plain memory, for one-shot use where pinning a gigabyte costs more than the staged copies; set before the first run),
+ * "stream_hold" (mvgx_match_run_stream, default 0; 1: the buffers handed to the sink stay valid until TWO further sink
+ * calls have returned or the run has returned - a second set of host buffers per batch slot - so that a caller can
+ * convert batch k on its own threads while batches k + 1 and k + 2 arrive),
+ * "pinned_stream" (default 1: the batch buffers of mvgx_match_run_stream are pinned; 0: plain memory, for one-shot use). */
 int mvgx_match_set_option(mvgx_match_ctx* ctx, const char* key, int64_t value);
 
 /* Load the descriptor arrays of n_images images into HBM (replaces Regions_Provider::get +

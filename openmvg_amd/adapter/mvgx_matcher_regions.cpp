@@ -31,8 +31,10 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <condition_variable>
 #include <cstdlib>
 #include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -79,57 +81,108 @@ struct Sink {
   const std::vector<IndexT>* ids;  // dense image index -> view id
 };
 
-// The match lists of one device batch become IndMatches vectors on helper threads (allocation + copy of up to a gigabyte
-// per run is the host-side cost of a large collection) while the CALLING thread - and only it - inserts them into the
-// container in ascending (I, J) as soon as a chunk of lists is ready (indMatch.hpp:70-75: insert is not thread safe;
-// Matcher_Regions.cpp:95-103 inserts from the thread that called Match).
-// offsets: nb + 1 entries (in matches) relative to `ij`.
-template <typename OffT>
-void deliver(const Sink& sink, const uint32_t* pairs_IJ, uint64_t nb, const OffT* offsets, const uint32_t* ij) {
-  constexpr uint64_t kChunk = 256;
-  const uint64_t n_chunks = (nb + kChunk - 1) / kChunk;
-  static const int debug_skip = std::getenv("MVGX_ADAPTER_DEBUG_SKIP") ? std::atoi(std::getenv("MVGX_ADAPTER_DEBUG_SKIP")) : 0;
-  if (debug_skip == 1) return;   // measurement only: device + transfers, nothing built
-  std::vector<matching::IndMatches> lists(nb);
-  auto build = [&](uint64_t k) {
-    const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
-    if (!n) return;
-    matching::IndMatches& v = lists[k];
-    v.reserve(n);
-    for (uint64_t m = 0; m < n; ++m) v.emplace_back(ij[2 * (lo + m)], ij[2 * (lo + m) + 1]);
+// The match lists of the device batches become IndMatches vectors on helper threads (allocating and first-touching up to a
+// gigabyte per run is the host-side cost of a large collection: the page faults of fresh memory, not the copying) while the
+// CALLING thread - and only it - inserts them into the container (indMatch.hpp:70-75: insert is not thread safe;
+// Matcher_Regions.cpp:95-103 inserts from the thread that called Match). Helper threads live for one Match() call; a batch is
+// a job of 256-pair chunks; jobs are built in submission order and taken out in submission order.
+class ListBuilder {
+ public:
+  struct Job {
+    const uint32_t* pairs_IJ; uint64_t nb;
+    const uint32_t* off32; const uint64_t* off64;   // nb + 1 offsets (in matches) relative to `ij`, one of the two widths
+    const uint32_t* ij;
+    std::vector<matching::IndMatches> lists;
+    uint64_t n_chunks = 0, next = 0, done = 0;       // guarded by the builder's mutex
+    std::exception_ptr error;
+    uint64_t offset(uint64_t k) const { return off32 ? off32[k] : off64[k]; }
   };
-  auto insert_chunk = [&](uint64_t c) {
-    if (debug_skip == 2) return;   // measurement only: lists built, container untouched
-    for (uint64_t k = c * kChunk, hi = std::min(nb, k + kChunk); k < hi; ++k)
-      if (!lists[k].empty())
-        sink.out->insert({{(*sink.ids)[pairs_IJ[2 * k]], (*sink.ids)[pairs_IJ[2 * k + 1]]}, std::move(lists[k])});
-  };
-  const uint64_t total = offsets[nb] - offsets[0];
-  const unsigned helpers = total < (1u << 16) ? 0u : std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
-  if (!helpers) {
-    for (uint64_t k = 0; k < nb; ++k) build(k);
-    for (uint64_t c = 0; c < n_chunks; ++c) insert_chunk(c);
-    return;
+
+  explicit ListBuilder(unsigned helpers) {
+    for (unsigned t = 0; t < helpers; ++t) pool_.emplace_back([this]() { work(); });
   }
-  std::atomic<uint64_t> next{0};
-  std::unique_ptr<std::atomic<uint8_t>[]> ready(new std::atomic<uint8_t>[n_chunks]);
-  for (uint64_t c = 0; c < n_chunks; ++c) ready[c].store(0, std::memory_order_relaxed);
-  auto body = [&]() {
-    for (;;) {
-      const uint64_t c = next.fetch_add(1);
-      if (c >= n_chunks) return;
-      for (uint64_t k = c * kChunk, hi = std::min(nb, k + kChunk); k < hi; ++k) build(k);
-      ready[c].store(1, std::memory_order_release);
+  ~ListBuilder() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_work_.notify_all();
+    for (auto& t : pool_) t.join();
+  }
+  void submit(const uint32_t* pairs_IJ, uint64_t nb, const uint32_t* off32, const uint64_t* off64, const uint32_t* ij) {
+    std::unique_ptr<Job> j(new Job());
+    j->pairs_IJ = pairs_IJ; j->nb = nb; j->off32 = off32; j->off64 = off64; j->ij = ij;
+    j->lists.resize(nb);
+    j->n_chunks = (nb + kChunk - 1) / kChunk;
+    { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(std::move(j)); }
+    cv_work_.notify_all();
+  }
+  size_t pending() const { return jobs_.size() - taken_; }   // calling thread only
+  // waits for the oldest job that has not been taken yet (helping with its chunks meanwhile) and inserts its lists
+  void take_oldest(const Sink& sink) {
+    Job* j;
+    { std::lock_guard<std::mutex> lk(mu_); j = jobs_[taken_].get(); }
+    for (;;) {   // the calling thread builds chunks too instead of sleeping
+      uint64_t c;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (j->next >= j->n_chunks) { cv_done_.wait(lk, [&]() { return j->done == j->n_chunks; }); break; }
+        c = j->next++;
+      }
+      build_chunk(*j, c);
+      std::lock_guard<std::mutex> lk(mu_);
+      ++j->done;
     }
-  };
-  std::vector<std::thread> pool;
-  struct Join { std::vector<std::thread>& p; ~Join() { for (auto& t : p) if (t.joinable()) t.join(); } } join{pool};
-  for (unsigned t = 0; t < helpers; ++t) pool.emplace_back(body);
-  for (uint64_t c = 0; c < n_chunks; ++c) {
-    while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
-    insert_chunk(c);
+    if (j->error) std::rethrow_exception(j->error);
+    static const int debug_skip = std::getenv("MVGX_ADAPTER_DEBUG_SKIP") ? std::atoi(std::getenv("MVGX_ADAPTER_DEBUG_SKIP")) : 0;
+    if (debug_skip != 2)   // (measurement knob: lists built, container untouched)
+      for (uint64_t k = 0; k < j->nb; ++k)
+        if (!j->lists[k].empty())
+          sink.out->insert({{(*sink.ids)[j->pairs_IJ[2 * k]], (*sink.ids)[j->pairs_IJ[2 * k + 1]]}, std::move(j->lists[k])});
+    std::lock_guard<std::mutex> lk(mu_);
+    jobs_[taken_].reset();
+    ++taken_;
   }
-}
+
+ private:
+  static constexpr uint64_t kChunk = 256;
+  static void build_chunk(Job& j, uint64_t c) {
+    try {
+      for (uint64_t k = c * kChunk, hi = std::min(j.nb, k + kChunk); k < hi; ++k) {
+        const uint64_t lo = j.offset(k), n = j.offset(k + 1) - lo;
+        if (!n) continue;
+        matching::IndMatches& v = j.lists[k];
+        v.reserve(n);
+        for (uint64_t m = 0; m < n; ++m) v.emplace_back(j.ij[2 * (lo + m)], j.ij[2 * (lo + m) + 1]);
+      }
+    } catch (...) {
+      j.error = std::current_exception();   // (any chunk's failure fails the job; rethrown on the calling thread)
+    }
+  }
+  void work() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      Job* j = nullptr;
+      for (size_t q = taken_; q < jobs_.size() && !j; ++q)
+        if (jobs_[q] && jobs_[q]->next < jobs_[q]->n_chunks) j = jobs_[q].get();
+      if (!j) {
+        if (stop_) return;
+        cv_work_.wait(lk);
+        continue;
+      }
+      const uint64_t c = j->next++;
+      lk.unlock();
+      build_chunk(*j, c);
+      lk.lock();
+      if (++j->done == j->n_chunks) cv_done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::vector<std::unique_ptr<Job>> jobs_;
+  size_t taken_ = 0;
+  bool stop_ = false;
+  std::vector<std::thread> pool_;
+};
+
+unsigned builder_helpers() { return std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u); }
 
 [[noreturn]] void device_failure(const char* what, int rc) {
   const std::string msg = std::string("mvgx (MI355X matching): ") + what + " failed with status " + std::to_string(rc) +
@@ -279,12 +332,21 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
     if (ctx.l2) {
       // SIFT path: the lists arrive batch by batch on THIS thread (mvgx_match_run_stream) while the device(s) work on the
       // next batches; host memory beside the container itself is two batches per device. Cancellation is polled per batch.
+      // "stream_hold": a batch's buffers outlive two further sink calls, so batch k is converted by the helper threads while
+      // batches k + 1 and k + 2 arrive; the container takes batch k - 2 at call k (and the rest after the run) - on this thread.
+      mvgx_match_set_option(ctx.l2, "stream_hold", 1);
+      { const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the buffers rarely pays
+        mvgx_match_set_option(ctx.l2, "pinned_stream", env ? std::atoi(env) : 0); }
+      ListBuilder list_builder(builder_helpers());
       struct Stream {
-        const Sink* sink; const uint32_t* pairs; system::ProgressInterface* progress; std::exception_ptr error;
+        ListBuilder& builder; const Sink* sink; const uint32_t* pairs; system::ProgressInterface* progress; std::exception_ptr error;
         static int on_batch(void* user, uint64_t first_pair, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) {
           Stream& s = *static_cast<Stream*>(user);
+          static const int debug_skip = std::getenv("MVGX_ADAPTER_DEBUG_SKIP") ? std::atoi(std::getenv("MVGX_ADAPTER_DEBUG_SKIP")) : 0;
+          if (debug_skip == 1) return 0;   // (measurement knob: device + transfers only)
           try {
-            deliver(*s.sink, s.pairs + 2 * first_pair, nb, offsets, ij);
+            s.builder.submit(s.pairs + 2 * first_pair, nb, offsets, nullptr, ij);
+            while (s.builder.pending() > 2) s.builder.take_oldest(*s.sink);
             (*s.progress) += nb;
           } catch (...) {   // never unwind through the C frames: stop the run, rethrow after it has returned
             s.error = std::current_exception();
@@ -292,14 +354,16 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
           }
           return s.progress->hasBeenCanceled() ? 1 : 0;
         }
-      } stream{&sink, dev_pairs.data(), progress, nullptr};
+      } stream{list_builder, &sink, dev_pairs.data(), progress, nullptr};
       if (!progress->hasBeenCanceled()) {
         rc = mvgx_match_run_stream(ctx.l2, dev_pairs.data(), n_pairs, ratio_sq, &Stream::on_batch, &stream, nullptr);
         if (stream.error) std::rethrow_exception(stream.error);
         if (rc != MVGX_OK) device_failure("run", rc);
+        while (stream.builder.pending()) stream.builder.take_oldest(sink);   // the last batches: their buffers live until the next call on the context
       }
       tick("device runs + container fill");
     } else {
+      ListBuilder builder(builder_helpers());
       for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
         const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
         if (progress->hasBeenCanceled()) break;
@@ -313,7 +377,8 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
         if (hamming) mvgx_hamming_results(ctx.hm, &offsets, &ij);
         else if (f32) mvgx_l2f_results(ctx.lf, &offsets, &ij);
         else mvgx_l2u8_results(ctx.lu, &offsets, &ij);
-        deliver(sink, dev_pairs.data() + 2 * p0, nb, offsets, ij);
+        builder.submit(dev_pairs.data() + 2 * p0, nb, nullptr, offsets, ij);
+        builder.take_oldest(sink);
         tick("container fill");
         (*progress) += static_cast<uint32_t>(nb);
       }

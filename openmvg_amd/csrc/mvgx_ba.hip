@@ -1563,13 +1563,11 @@ int build_trip_list(size_t n_cb, Gen gen, TripHost& out, TripExt* ext = nullptr)
 }
 
 template <typename T>
-int dev_alloc(std::vector<void*>& pool, T** p, size_t n) {
-  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
-  pool.push_back(*p);
-  return MVGX_OK;
+int dev_alloc(mvgx::Arena& pool, T** p, size_t n) {
+  return pool.alloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
 }
 template <typename T>
-int dev_upload(std::vector<void*>& pool, T** p, const std::vector<T>& v, hipStream_t s) {
+int dev_upload(mvgx::Arena& pool, T** p, const std::vector<T>& v, hipStream_t s) {
   int rc = dev_alloc(pool, p, v.size());
   if (rc) return rc;
   if (!v.empty()) MVGX_HIP(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
@@ -1584,7 +1582,7 @@ struct mvgx_ba_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Dev d;
-  std::vector<void*> pool;             // every device allocation (freed in destroy)
+  mvgx::Arena pool;                    // every device allocation (slabs go back to the process-wide cache in destroy)
   double* h_scalars = nullptr;         // pinned
   int* h_fail = nullptr;               // pinned
   mvgx_allreduce_f64 allreduce = nullptr;
@@ -2568,7 +2566,7 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (void* q : c->pool) if (q) (void)hipFree(q);
+  c->pool.release();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -38,4 +38,25 @@ int select_device(int device);
 // used by the single-GPU tests of the multi-device paths). Unset / empty -> `out` stays empty (the current device).
 int devices_from_env(std::vector<int>& out);
 
+// Device memory of one context, sub-allocated from a few large slabs that are handed back to a process-wide cache when the
+// context is destroyed: an SfM engine calls Bundle_Adjustment::Adjust hundreds of times (sequential_SfM.cpp:593-596, :1190-1215),
+// and a context makes ~80 allocations - through hipMalloc / hipFree that is several milliseconds per call, from the cache a few
+// microseconds. MVGX_DEVICE_CACHE_MB bounds what the cache keeps per device (default 4096; 0: no caching).
+class Arena {
+ public:
+  Arena() = default;
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  ~Arena() { release(); }
+  int alloc(void** out, size_t bytes);   // 256-byte aligned; MVGX_ERR_HIP when the device is out of memory
+  void release();                        // every slab back to the cache (or to the driver)
+  size_t bytes_reserved() const;
+ private:
+  struct Slab { char* p; size_t size; int device; };
+  std::vector<Slab> slabs_;   // slabs_[bump_] is the one small requests are carved from
+  int bump_ = -1;
+  size_t off_ = 0, next_ = 0;
+  int take_slab(size_t min_bytes, Slab* out);
+};
+
 }  // namespace mvgx

@@ -950,6 +950,8 @@ struct mvgx_match_ctx {
   int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
   int keep_host_results = 1;
   int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
+  int stream_hold = 0;      // mvgx_match_run_stream: 1 = a batch's buffers survive two further sink calls (see Slot)
+  int pinned_stream = 1;    // host buffers of the stream mode: pinned (contexts that are run repeatedly) or plain memory (one-shot)
   // regions
   uint32_t n_images = 0;
   uint32_t total_tiles = 0;
@@ -978,9 +980,13 @@ struct mvgx_match_ctx {
     uint64_t p0 = 0;
     uint32_t nb = 0;
     // stream mode (mvgx_match_run_stream): the lists of the slot's finished batch wait here for the sink
+    // Two sets of host buffers per slot, used alternately: with the option "stream_hold" the lists handed to the sink stay
+    // valid until two further sink calls have returned (a caller can turn them into its own data structures on other threads
+    // while the run goes on); without it only the first set is used
     hipEvent_t ev_copy = nullptr;     // match lists of the batch are on the host
-    PinnedBuf<uint32_t> hp_ij;
-    std::vector<uint32_t> h_off_out;
+    PinnedBuf<uint32_t> hp_ij[2];
+    std::vector<uint32_t> h_off_out[2];
+    int out_set = 0;
     uint64_t out_p0 = 0;
     uint32_t out_nb = 0;
   } slot[2];
@@ -1176,7 +1182,7 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   for (auto& sl : c->slot) {
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
-    sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release(); sl.hp_ij.release();
+    sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release(); sl.hp_ij[0].release(); sl.hp_ij[1].release();
     if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
     if (sl.ev_scan) (void)hipEventDestroy(sl.ev_scan);
     if (sl.ev_filter) (void)hipEventDestroy(sl.ev_filter);
@@ -1212,6 +1218,10 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->keep_host_results = value != 0;
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
+  } else if (!strcmp(key, "stream_hold")) {
+    c->stream_hold = value != 0;
+  } else if (!strcmp(key, "pinned_stream")) {
+    c->pinned_stream = value != 0;
   } else if (!strcmp(key, "double_buffer_results")) {
     c->double_buffer = value != 0;
   } else if (!strcmp(key, "pinned_results")) {
@@ -1418,7 +1428,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     const uint64_t p0 = sl.p0;
     const uint32_t total = sl.hp_offsets.p[nb];
     if (sink) {
-      sl.h_off_out.assign(sl.hp_offsets.p, sl.hp_offsets.p + nb + 1);   // hp_offsets is rewritten by the slot's next batch
+      if (c->stream_hold) sl.out_set ^= 1;
+      sl.h_off_out[sl.out_set].assign(sl.hp_offsets.p, sl.hp_offsets.p + nb + 1);   // hp_offsets is rewritten by the slot's next batch
     } else {
       const uint64_t base = res.offsets[p0];
       for (uint32_t k = 0; k <= nb; ++k) res.offsets[p0 + k] = base + sl.hp_offsets.p[k];
@@ -1432,8 +1443,11 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
                          sl.d_ij.p);
       MVGX_HIP(hipGetLastError());
       if (sink) {
-        if ((rc = sl.hp_ij.ensure((size_t)total * 2))) return rc;
-        MVGX_HIP(hipMemcpyAsync(sl.hp_ij.p, sl.d_ij.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost, sl.stream));
+        PinnedBuf<uint32_t>& hb = sl.hp_ij[sl.out_set];
+        if (!hb.p) hb.pageable = !c->pinned_stream;
+        // batch sizes vary: grow with headroom (re-pinning ~100 MB costs tens of milliseconds); nothing of the old content is kept
+        if ((size_t)total * 2 > hb.cap) { hb.release(); if ((rc = hb.grow_keep(std::max<size_t>((size_t)total * 3, 4u << 20), 0))) return rc; }
+        MVGX_HIP(hipMemcpyAsync(hb.p, sl.d_ij.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost, sl.stream));
       } else if (c->keep_host_results) {
         const size_t old = res.ij_n;
         if (old + (size_t)total * 2 > res.ij.cap)   // growth moves the lists: no copy into them may be in flight
@@ -1451,7 +1465,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
   auto deliver = [&](mvgx_match_ctx::Slot& sl) -> int {
     MVGX_HIP(hipEventSynchronize(sl.ev_copy));
     if (feed.stop.load()) return MVGX_OK;   // cancelled: the sink is not entered again
-    if ((*sink)(sl.out_p0, sl.out_nb, sl.h_off_out.data(), sl.hp_ij.p)) feed.stop.store(1);
+    if ((*sink)(sl.out_p0, sl.out_nb, sl.h_off_out[sl.out_set].data(), sl.hp_ij[sl.out_set].p)) feed.stop.store(1);
     return MVGX_OK;
   };
   // software pipeline over the batches this device takes: issue(b) | finish(b-1) | deliver(b-2)

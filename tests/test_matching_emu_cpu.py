@@ -203,3 +203,36 @@ def test_devices_from_the_environment(monkeypatch):
         monkeypatch.setenv("MVGX_DEVICES", "0,99")
         with pytest.raises(_capi.MvgxError):
             matching.MatchContext(-1)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_stream_hold_keeps_a_batch_valid_for_two_further_sink_calls(devices):
+    """option "stream_hold": the arrays handed to the sink at call k are still intact when calls k + 1 and k + 2 are made (second
+    set of host buffers per slot) - what the openMVG adapter relies on to build its containers off the calling thread"""
+    sizes = [90, 40, 130, 75, 20, 64, 33, 51]
+    imgs = synth.image_descriptors(len(sizes), n_desc=max(sizes), seed=29)
+    imgs = [d[:s] for d, s in zip(imgs, sizes)]
+    pairs = matching.exhaustive_pairs_array(len(sizes))
+    o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, 0.8)
+    with _emu.emulated():
+        ctx = matching.MatchContext(0) if devices is None else matching.MatchContext(devices=devices)
+        ctx.set_option("batch_pairs", 3)
+        ctx.set_option("stream_hold", 1)
+        ctx.set_option("pinned_stream", 0)
+        ctx.set_regions(imgs)
+        held = []     # (first pair, live views, copies taken at hand-over)
+        checked = [0]
+
+        def on_batch(p0, off, lists):
+            for q0, (voff, vij), (coff, cij) in held[-2:]:      # the two previous hand-overs
+                assert np.array_equal(voff, coff) and np.array_equal(vij, cij), (q0, p0)
+                checked[0] += 1
+            held.append((p0, (off, lists), (off.copy(), lists.copy())))
+
+        ctx.run_stream(pairs, np.float32(0.64), on_batch)
+        for q0, (voff, vij), (coff, cij) in held[-2:]:          # ... and the last ones after the run has returned
+            assert np.array_equal(voff, coff) and np.array_equal(vij, cij)
+        ctx.close()
+    assert checked[0] >= 2 * (len(held) - 2)
+    got = np.concatenate([c[2][1] for c in sorted(held, key=lambda h: h[0])])
+    assert np.array_equal(got, o_ij)
