@@ -71,7 +71,7 @@ constexpr int kPriorJ = 21;        // per pose-centre prior: corrected r (3) | c
 
 // kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
 // point parts are rank-local and summed across ranks.
-enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSCount = 12 };
+enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSModelPt, kSModelCam, kSCount = 12 };
 
 // One list of Schur products -Z_a^T Z_b, sorted by the (row block, column block) of S they add into. Entities are
 // observations (pose blocks, width 6) or (point, intrinsic) slots (intrinsic blocks, width 8).
@@ -1377,6 +1377,26 @@ __global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __res
   const double t = block_sum(v, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
+// The same quantity from the normal equations, without a pass over the observations: the step solves
+// (Js^T Js + D^2) s = -gs exactly (direct solver), hence -(Js s)^T (r + Js s / 2) = -s^T gs - s^T Js^T Js s / 2 = (s^T D^2 s - s^T gs) / 2,
+// with gs = scale o g the gradient and D^2 = LM diagonal / radius of the scaled problem. part[2 b] = the workgroup's point
+// components (rank-local in a multi-rank run), part[2 b + 1] = its camera components (replicated).
+__global__ __launch_bounds__(256) void ba_model_cost_vec_kernel(Dev d, double inv_radius, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double vc = 0, vp = 0;
+  if (i < (size_t)d.N) {
+    const double s = d.step_cam[i];
+    vc = 0.5 * s * (s * d.diag_cam[i] * inv_radius - d.g_cam[i] * d.scale_cam[i]);
+  }
+  if (i < (size_t)d.n_pts * 3) {
+    const double s = d.step_pt[i];
+    vp = 0.5 * s * (s * d.diag_pt[i] * inv_radius - d.g_pt[i] * d.scale_pt[i]);
+  }
+  const double tp = block_sum(vp, sh);
+  const double tc = block_sum(vc, sh);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = tp; part[2 * blockIdx.x + 1] = tc; }
+}
 // the prior rows' share of the model cost change, added onto scalars[kSModel] (one workgroup)
 __global__ __launch_bounds__(256) void ba_prior_model_kernel(Dev d) {
   __shared__ double sh[4];
@@ -1601,6 +1621,7 @@ struct mvgx_ba_ctx {
   // reduced-system solver: block-sparse (tile) Cholesky with a nested-dissection order, or the dense one (auto: by fill)
   std::vector<std::pair<uint32_t, uint32_t>> h_blocks;   // non-zero camera blocks of this rank's S (row block, col block)
   uint32_t n_grouped_points = 0;
+  bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
   int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
   mvgx_sparse::Plan plan;          // host copy of the schedule (launch geometry per level)
@@ -1960,12 +1981,19 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   phase_end(c, kPhSolve);
   phase_begin(c);
   hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);
-  if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
-                     kSModel, 0);
-  if (d.n_priors) hipLaunchKernelGGL(ba_prior_model_kernel, dim3(1), dim3(256), 0, c->stream, d);
-  BA_LAUNCH_CHECK();
-  if ((rc = all_reduce(c, d.scalars + kSModel, 1))) return rc;
+  if (c->model_cost_from_jacobian) {   // Ceres' own form (trust_region_minimizer.cc:402-405): one more pass over the Jacobian records
+    if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
+                       kSModel, 0);
+    if (d.n_priors) hipLaunchKernelGGL(ba_prior_model_kernel, dim3(1), dim3(256), 0, c->stream, d);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, d.scalars + kSModel, 1))) return rc;
+  } else {
+    hipLaunchKernelGGL(ba_model_cost_vec_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, inv_radius, d.part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, c->stream, d.part, c->grid_vec, 2, 2, d.scalars, kSModelPt, 0);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, d.scalars + kSModelPt, 1))) return rc;   // point parts; the camera part is the same on every rank
+  }
   if (multi_rank(c)) {   // a point block that failed to invert on one rank fails the step everywhere
     hipLaunchKernelGGL(ba_pack_fail_kernel, dim3(1), dim3(1), 0, c->stream, d);
     BA_LAUNCH_CHECK();
@@ -1973,7 +2001,7 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   }
   phase_end(c, kPhBacksub);
   if ((rc = read_scalars(c))) return rc;
-  *model_cost_change = c->h_scalars[kSModel];
+  *model_cost_change = c->model_cost_from_jacobian ? c->h_scalars[kSModel] : c->h_scalars[kSModelPt] + c->h_scalars[kSModelCam];
   const bool failed = multi_rank(c) ? (c->h_scalars[kSFail] != 0.0) : (*c->h_fail != 0);
   *ok = !failed && std::isfinite(*model_cost_change);
   return MVGX_OK;
@@ -2185,6 +2213,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
   c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
+  if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
   if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));

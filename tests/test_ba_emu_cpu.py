@@ -552,3 +552,27 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert np.allclose(pg, pf, atol=1e-9) and np.allclose(ig, if_, rtol=1e-9, atol=1e-9) and np.allclose(xg, xf, atol=1e-8)
     rc, osum, *_ = _oracle.port_ba_solve(sc, opt)
     assert abs(s_g.final_rmse - osum.final_rmse) < 1e-9
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_model_cost_from_the_normal_equations_equals_the_jacobian_form(devices, monkeypatch):
+    """model_cost_change of trust_region_minimizer.cc:402-405, -(J s)^T (r + J s / 2), is evaluated as (s^T D^2 s - s^T g) / 2 from the
+    quantities the solver already holds (exact for a direct solve) instead of a pass over all observations; same LM trajectory as
+    the Jacobian form (MVGX_BA_MODEL_COST=jacobian), with priors, control points, Huber-active outliers, rejected steps, 2 shards"""
+    sc = synth.ba_scene(n_cams=9, n_points=160, track_len=5, model=3, n_intr_groups=2, seed=131, rot_deg=2.0, outlier_frac=0.05)
+    sc = synth.add_pose_priors(synth.add_control_points(sc, n_ctrl=5, weight=20.0), sigma=0.005, huber_a=2e-4)
+    opt = ba.default_options(max_num_iterations=8, initial_radius=1e7)     # a large first radius: some steps get rejected
+    out = {}
+    with _emu.emulated():
+        for form in ("normal", "jacobian"):
+            if form == "jacobian":
+                monkeypatch.setenv("MVGX_BA_MODEL_COST", "jacobian")
+            c = ba.BaContext(sc) if devices is None else ba.BaContext(sc, devices=devices)
+            s = c.solve(opt)
+            out[form] = (s, c.read_params())
+            c.close()
+    a, b = out["normal"][0], out["jacobian"][0]
+    assert a.num_iterations == b.num_iterations and a.num_successful_steps == b.num_successful_steps
+    assert abs(a.final_cost - b.final_cost) <= 1e-11 * b.final_cost
+    for x, y in zip(out["normal"][1], out["jacobian"][1]):
+        assert np.allclose(x, y, rtol=1e-9, atol=1e-10)
