@@ -1464,8 +1464,10 @@ struct TripExt {
 // in [0, n), indices handed out dynamically; results must not depend on which thread ran an index.
 inline unsigned host_threads(size_t work_items) {
   if (const char* env = getenv("MVGX_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(env)));   // as told
-  if (work_items < 2048) return 1;
-  return std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  // one thread per ~16k items: starting a thread costs tens of microseconds, and the small problems an SfM engine sends most
+  // often (initial pair, local adjustments) are built faster by the calling thread alone
+  const unsigned want = (unsigned)std::min<size_t>(work_items / 16384, 32);
+  return std::max(1u, std::min(std::thread::hardware_concurrency(), want));
 }
 template <class F>
 void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
@@ -1520,10 +1522,9 @@ void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key ke
 // at most kTripChunk products. Rows are independent: they are generated by host threads and stitched in row order, so the
 // list does not depend on the thread count. O(products) time, no comparison sort over the products.
 template <class Gen>
-int build_trip_list(size_t n_cb, Gen gen, TripHost& out, TripExt* ext = nullptr) {
+int build_trip_list(size_t n_cb, Gen gen, TripHost& out, unsigned threads, TripExt* ext = nullptr) {
   struct RowMeta { std::vector<uint32_t> col, cnt; };
   std::vector<uint64_t> rstart(n_cb + 1, 0);
-  const unsigned threads = host_threads(n_cb * 64);
   parallel_for_dynamic(n_cb, 1, threads, [&](size_t r, unsigned) {
     uint64_t n = 0;
     gen((uint32_t)r, [&](uint32_t, uint32_t, uint32_t) { ++n; });
@@ -2387,50 +2388,70 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
         std::stable_sort(order.begin() + lo_start[i], order.begin() + lo_start[i + 1], [&](uint32_t x, uint32_t y) { return set_key[x] < set_key[y]; });
       });
-      std::vector<uint32_t> cams, merged, cur;
-      auto close_group = [&]() {
-        if (cur.size() >= (size_t)kGroupMinPts) {
-          const size_t g = g_pt_start.size() - 1;
-          g_cams.resize((g + 1) * kGroupCams, UINT32_MAX);
-          std::copy(cams.begin(), cams.end(), g_cams.begin() + g * kGroupCams);
-          g_pair.resize((g + 1) * kGroupPairs, 0);
-          for (size_t q = 0; q < cur.size(); ++q) {
-            const uint32_t j = cur[q];
-            in_group[j] = 1;
-            g_pts.push_back(j);
-            uint8_t xs[kGroupCams];
-            int nx = 0;
-            for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
-              const int x = (int)(std::lower_bound(cams.begin(), cams.end(), opose[o]) - cams.begin());
-              g_obs.push_back(o);
-              g_obs_qx.push_back((uint16_t)((q << 8) | (unsigned)x));
-              xs[nx++] = (uint8_t)x;
+      // groups never span two lowest-pose buckets, so the buckets are swept independently (host threads) and their groups
+      // stitched in bucket order: the result does not depend on the thread count
+      struct BucketGroups { std::vector<uint32_t> obs_n, obs, pt_n, pts, cams; std::vector<uint16_t> qx; std::vector<uint8_t> pair; };
+      std::vector<BucketGroups> per_bucket(d.n_poses);
+      parallel_for_dynamic(d.n_poses, 4, T, [&](size_t bucket, unsigned) {
+        BucketGroups& B = per_bucket[bucket];
+        std::vector<uint32_t> cams, merged, cur;
+        auto close_group = [&]() {
+          if (cur.size() >= (size_t)kGroupMinPts) {
+            const size_t g = B.pt_n.size();
+            B.cams.resize((g + 1) * kGroupCams, UINT32_MAX);
+            std::copy(cams.begin(), cams.end(), B.cams.begin() + g * kGroupCams);
+            B.pair.resize((g + 1) * kGroupPairs, 0);
+            uint32_t n_obs_g = 0;
+            for (size_t q = 0; q < cur.size(); ++q) {
+              const uint32_t j = cur[q];
+              in_group[j] = 1;
+              B.pts.push_back(j);
+              uint8_t xs[kGroupCams];
+              int nx = 0;
+              for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+                const int x = (int)(std::lower_bound(cams.begin(), cams.end(), opose[o]) - cams.begin());
+                B.obs.push_back(o);
+                B.qx.push_back((uint16_t)((q << 8) | (unsigned)x));
+                xs[nx++] = (uint8_t)x;
+                ++n_obs_g;
+              }
+              for (int a = 0; a < nx; ++a)
+                for (int b2 = 0; b2 < nx; ++b2)
+                  if (xs[a] <= xs[b2]) B.pair[g * kGroupPairs + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b2] - xs[a])] = 1;
             }
-            for (int a = 0; a < nx; ++a)
-              for (int b = 0; b < nx; ++b)
-                if (xs[a] <= xs[b]) g_pair[g * kGroupPairs + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b] - xs[a])] = 1;
+            B.obs_n.push_back(n_obs_g);
+            B.pt_n.push_back((uint32_t)cur.size());
           }
-          g_obs_start.push_back((uint32_t)g_obs.size());
-          g_pt_start.push_back((uint32_t)g_pts.size());
+          cur.clear(); cams.clear();
+        };
+        for (uint32_t q = lo_start[bucket]; q < lo_start[bucket + 1]; ++q) {
+          const uint32_t j = order[q];
+          uint32_t pc[kGroupCams];
+          int npc = 0;
+          for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) pc[npc++] = opose[o];
+          std::sort(pc, pc + npc);
+          merged.clear();
+          std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(merged));
+          if (cur.size() == (size_t)kGroupPts || merged.size() > (size_t)kGroupCams) {
+            close_group();
+            merged.assign(pc, pc + npc);
+          }
+          cams = merged;
+          cur.push_back(j);
         }
-        cur.clear(); cams.clear();
-      };
-      for (uint32_t q = 0; q < lo_start[d.n_poses]; ++q) {
-        const uint32_t j = order[q];
-        uint32_t pc[kGroupCams];
-        int npc = 0;
-        for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) pc[npc++] = opose[o];
-        std::sort(pc, pc + npc);
-        merged.clear();
-        std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(merged));
-        if (cur.size() == (size_t)kGroupPts || merged.size() > (size_t)kGroupCams) {
-          close_group();
-          merged.assign(pc, pc + npc);
+        close_group();
+      });
+      for (const BucketGroups& B : per_bucket) {
+        for (size_t g = 0; g < B.pt_n.size(); ++g) {
+          g_obs_start.push_back(g_obs_start.back() + B.obs_n[g]);
+          g_pt_start.push_back(g_pt_start.back() + B.pt_n[g]);
         }
-        cams = merged;
-        cur.push_back(j);
+        g_obs.insert(g_obs.end(), B.obs.begin(), B.obs.end());
+        g_obs_qx.insert(g_obs_qx.end(), B.qx.begin(), B.qx.end());
+        g_pts.insert(g_pts.end(), B.pts.begin(), B.pts.end());
+        g_cams.insert(g_cams.end(), B.cams.begin(), B.cams.end());
+        g_pair.insert(g_pair.end(), B.pair.begin(), B.pair.end());
       }
-      close_group();
     }
   }
   const uint32_t n_groups = (uint32_t)g_pt_start.size() - 1;
@@ -2457,7 +2478,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
               if (r <= opose[b] && (pt_free[j] || a == b)) emit(opose[b], a, b);
           }
-        }, hpp, &gext))) return rc;
+        }, hpp, T, &gext))) return rc;
     for (uint32_t& e : gext.ext_row)
       if (e != kNoChunk) e += (uint32_t)hpp.chunk_lo.size();   // rows of the partial-sum buffer: after the flat chunks
     tick("pose-pose products");
@@ -2468,7 +2489,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
               if (pt_free[j] || sl == oslot[a]) emit(np + slot_intr[sl], a, sl);
           }
-        }, hpi))) return rc;
+        }, hpi, T))) return rc;
     for (size_t b = 0; b < hpi.block_row.size(); ++b) {   // the (pose, intrinsic) pair whose Fc^T Fi belongs to the block
       const uint32_t i = hpi.block_row[b], k = hpi.block_col[b] - d.n_poses;
       for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
@@ -2482,7 +2503,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
               if (k <= slot_intr[sb] && (pt_free[j] || sa == sb)) emit(np + slot_intr[sb], sa, sb);
           }
-        }, hii))) return rc;
+        }, hii, T))) return rc;
   }
   for (const TripHost* h : {&hpp, &hpi, &hii})
     for (size_t b = 0; b < h->block_row.size(); ++b) c->h_blocks.emplace_back(h->block_row[b], h->block_col[b]);

@@ -259,7 +259,9 @@ def test_bundle_then_reject_loop_equals_the_reference_pipeline():
         return sc
 
     def ref_adjust(sc):
-        rc, st, poses, intr, pts = _oracle.ref_ba_adjust(sc)
+        # one thread: with OpenMP threads the reference's own sums depend on the schedule, and on this outlier scene its loop then
+        # ends with 6469 or 6473 observations from run to run (256-thread host, round-2 call 5) - the device result is 6469
+        rc, st, poses, intr, pts = _oracle.ref_ba_adjust(sc, num_threads=1)
         assert rc == 0
         out = dict(sc); out["poses"] = poses; out["intrinsics"] = intr; out["points"] = pts
         return out
