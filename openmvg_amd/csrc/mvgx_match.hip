@@ -465,7 +465,9 @@ __global__ __launch_bounds__(256, 2) void l2_top2_ratio_kernel(MatchParams p) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-template <int kMode>
+// kDbg != 0: timing experiments only (results are wrong): bit 0 drops the epilogue, bit 1 the per-tile LDS fragment loads,
+// bit 2 the per-window wait + barrier + staging - what each costs is the difference to kDbg = 0 (tools/filter_breakdown.py).
+template <int kMode, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x kStageBytes
 
@@ -519,11 +521,12 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(b[n][s]));
 
   for (int win = 0; win < nwin; ++win) {
-    if constexpr (kMode == kStageGldsAsm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (!(kDbg & 4) && kMode == kStageGldsAsm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!(kDbg & 4)) __syncthreads();
     char* buf = smem + (win & 1) * kStageBytes;
     char* nbuf = smem + ((win + 1) & 1) * kStageBytes;
-    if constexpr (kMode == kStageRegs) {
+    if constexpr (kDbg & 4) {
+    } else if constexpr (kMode == kStageRegs) {
       const int wn = (win + 1 < nwin) ? win + 1 : win;
       stage_issue(sr, gI + (size_t)wn * kWinTiles * kTileBytes, gC + wn * kWinRows, wave, lane);
     } else if (win + 1 < nwin) {
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
     for (int r = 0; r < 16; ++r) accB[r] = kNegInit;
 
 #define MVGX_EPILOGUE(ACC, N)                                          \
+  if constexpr (kDbg & 1) { asm volatile("" : "+v"(ACC)); TQ[N] = max(TQ[N], ACC[0]); } else \
   {                                                                    \
     int tq = TQ[N];                                                    \
     _Pragma("unroll") for (int s = 0; s < 8; ++s) {                    \
@@ -580,14 +584,18 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
   {                                                                                                \
     const int tn_ = (TN);                                                                          \
     MVGX_CHAIN(accA, 0, A, CV)                                                                     \
+    if constexpr (kDbg & 2) { _Pragma("unroll") for (int s = 0; s < 4; ++s) AN[s] = A[s]; CN = CV; } else { \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                  \
         AN[s] = *reinterpret_cast<const v4i*>(wb + tn_ * kTileBytes + s * 1024);                   \
+    }                                                                                              \
     MVGX_EPILOGUE(accB, 3)                                                                         \
     MVGX_INTERLEAVE()                                                                              \
     MVGX_CHAIN(accB, 1, A, CV)                                                                     \
+    if constexpr (!(kDbg & 2)) {                                                                   \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
       const int4 c4 = *reinterpret_cast<const int4*>(wc + tn_ * (kTileRows * 4) + g * 32);        \
       CN[g * 4 + 0] = c4.x; CN[g * 4 + 1] = c4.y; CN[g * 4 + 2] = c4.z; CN[g * 4 + 3] = c4.w;     \
+    }                                                                                              \
     }                                                                                              \
     MVGX_EPILOGUE(accA, 0)                                                                         \
     MVGX_INTERLEAVE()                                                                              \
@@ -950,6 +958,7 @@ struct mvgx_match_ctx {
   int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
   int keep_host_results = 1;
   int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
+  int debug_filter = 0;     // 1..7: timing experiments of l2_filter_kernel (see its kDbg), results invalid
   int stream_hold = 0;      // mvgx_match_run_stream: 1 = a batch's buffers survive two further sink calls (see Slot)
   int pinned_stream = 1;    // host buffers of the stream mode: pinned (contexts that are run repeatedly) or plain memory (one-shot)
   // regions
@@ -1159,6 +1168,9 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+#define MVGX_DBG_ATTR(D) MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  MVGX_DBG_ATTR(1) MVGX_DBG_ATTR(2) MVGX_DBG_ATTR(3) MVGX_DBG_ATTR(4) MVGX_DBG_ATTR(5) MVGX_DBG_ATTR(6) MVGX_DBG_ATTR(7)
+#undef MVGX_DBG_ATTR
   guard.c = nullptr;
   *out = c;
   return MVGX_OK;
@@ -1218,6 +1230,9 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->keep_host_results = value != 0;
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
+  } else if (!strcmp(key, "debug_filter")) {
+    MVGX_REQUIRE(value >= 0 && value <= 7, MVGX_ERR_ARG, "debug_filter must be 0..7");
+    c->debug_filter = (int)value;
   } else if (!strcmp(key, "stream_hold")) {
     c->stream_hold = value != 0;
   } else if (!strcmp(key, "pinned_stream")) {
@@ -1395,6 +1410,10 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 2) {
         hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
+      } else if (c->debug_filter) {   // timing experiments (wrong results; verify is skipped below)
+#define MVGX_DBG_CASE(D) case D: hipLaunchKernelGGL((l2_filter_kernel<kStageGldsAsm, D>), dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp); break;
+        switch (c->debug_filter) { MVGX_DBG_CASE(1) MVGX_DBG_CASE(2) MVGX_DBG_CASE(3) MVGX_DBG_CASE(4) MVGX_DBG_CASE(5) MVGX_DBG_CASE(6) MVGX_DBG_CASE(7) default: break; }
+#undef MVGX_DBG_CASE
       } else {
         hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       }
@@ -1402,7 +1421,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       if (c->profile) MVGX_HIP(hipEventRecord(e1, stream));
       MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
       st.n_kernel_launches += 1;
-      if (c->variant == 4) {
+      if (c->variant == 4 && !c->debug_filter) {
         if (c->profile) {
           const size_t nslots = (size_t)nb * c->qstride;
           hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, stream,
@@ -1499,7 +1518,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
   float ms = 0.f;
   MVGX_HIP(hipEventElapsedTime(&ms, c->ev_total0, c->ev_total1));
   st.total_ms = ms;
-  if (c->variant == 4) {   // the verify kernel cross-checks the filter's d0 against its own exact recomputation
+  if (c->variant == 4 && !c->debug_filter) {   // the verify kernel cross-checks the filter's d0 against its own exact recomputation
     uint32_t flags[2] = {0, 0};
     MVGX_HIP(hipMemcpy(flags, c->d_err.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     (void)hipMemset(c->d_err.p, 0, 2 * sizeof(uint32_t));
