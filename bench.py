@@ -245,6 +245,8 @@ def main():
             from bench_hamming import hamming_bench_record, l2f_bench_record
             out["hamming"] = hamming_bench_record(local_rank, cpu=not args.no_cpu_baseline)
             out["l2_float"] = l2f_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+            from bench_hamming import l2u8_bench_record
+            out["l2_uint8_144"] = l2u8_bench_record(local_rank)
         except Exception as e:  # side record only
             out["hamming"] = {"status": f"failed: {e!r}"}
     if rank == 0:

@@ -115,7 +115,43 @@ def l2f_bench_record(device=0, n_images=200, n_desc=2000, steps=3, cpu_seconds=8
     return rec
 
 
+VALU_I32_OPS_PEAK = 256 * 4 * 16 * 2.4e9           # one integer lane-op per lane and cycle (v_dot4_u32_u8 counts as one)
+L2U8_OPS_PER_DESC_PAIR_144 = 36 + 9               # 36 dot products + 9 other VALU per descriptor pair at 144 bytes
+
+
+def l2u8_bench_record(device=0, n_images=200, n_desc=2000, steps=3, dim=144):
+    """BRUTE_FORCE_L2 on AKAZE_Liop_Regions-like 144-byte uint8 descriptors (the third mvgx_bruteforce kernel): 200 images x 2000,
+    exhaustive pairs. No CPU baseline leg (the matching family's baselines are the SIFT / Hamming / float records)."""
+    from openmvg_amd import matching
+    rng = np.random.default_rng(0x110B)
+    imgs = [rng.integers(0, 256, size=(n_desc, dim), dtype=np.uint8) for _ in range(n_images)]
+    pairs = matching.exhaustive_pairs_array(n_images)
+    rsq = np.float32(0.8) * np.float32(0.8)
+    ctx = matching.L2u8Context(device)
+    ctx.set_regions(imgs, dim)
+    ctx.run(pairs[:1000], rsq)
+    kernel_ms = 0.0; launches = 0; desc_pairs = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st, off, _ = ctx.run(pairs, rsq)
+        kernel_ms += st.kernel_ms; launches += int(st.n_kernel_launches); desc_pairs += int(st.n_desc_pairs)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    ach = desc_pairs * L2U8_OPS_PER_DESC_PAIR_144 / max(kernel_ms * 1e-3, 1e-12)
+    return {"metric": "descriptor pairs/s (brute-force L2<uint8> 2-NN + ratio matching, 144-byte descriptors)",
+            "value": desc_pairs / dt, "unit": "descriptor pairs/s", "dtype": "u8 (v_dot4_u32_u8, exact int32)",
+            "config": {"workload": f"{n_images} images x {n_desc} {dim}-byte descriptors, exhaustive pairs ({len(pairs)} image pairs), ratio 0.8",
+                       "matches": int(off[-1])},
+            "ms_per_step": dt / steps * 1e3,
+            "roofline": {"bound": "valu", "achieved": ach / 1e12, "peak": VALU_I32_OPS_PEAK / 1e12, "unit": "T lane-ops/s",
+                         "frac": ach / VALU_I32_OPS_PEAK, "traffic": None, "kernel": "l2u8_top2_ratio_kernel<36>", "launches": launches,
+                         "mean_launch_ms": kernel_ms / max(launches, 1)}}
+
+
 if __name__ == "__main__":
+    if "l2u8" in sys.argv:
+        print(json.dumps(l2u8_bench_record()))
+        sys.exit(0)
     if "l2f" in sys.argv:
         print(json.dumps(l2f_bench_record(cpu="--no-cpu" not in sys.argv)))
         sys.exit(0)

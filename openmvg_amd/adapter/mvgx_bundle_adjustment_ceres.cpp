@@ -5,9 +5,8 @@
 // constructor, ceres_options() and Adjust() (sfm_data_BA_ceres.hpp:31-69) — so sequential_SfM.cpp:1190-1215 and the
 // other call sites that construct Bundle_Adjustment_Ceres by name run the MI355X solver unchanged. Only Ceres'
 // enum header is needed (ceres/types.h); no Ceres object code is linked by this file. IntrinsicsToCostFunction
-// (sfm_data_BA_ceres.hpp:24-29) builds ceres::CostFunction objects and is therefore NOT provided here: the two
-// reference files that call it outside Adjust (sfm_data_BA_ceres.cpp itself and SfM_Localizer.cpp:349) keep using
-// Ceres when they are part of the link.
+// (sfm_data_BA_ceres.hpp:24-29) builds ceres::CostFunction objects and is therefore NOT provided here: in the reference tree
+// it is called only inside sfm_data_BA_ceres.cpp itself (:367, :415), i.e. from the Adjust() this file replaces.
 #include <utility>
 
 #include "ceres/types.h"

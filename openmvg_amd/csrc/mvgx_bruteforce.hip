@@ -424,7 +424,11 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
   int rc;
   float kernel_ms = 0.f;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
-  const uint64_t B = (uint64_t)c->batch_pairs;
+  // pairs per batch: the option, capped so that the scratch (4 B per pair and query slot) stays near 2 GB when the images carry
+  // tens of thousands of descriptors (the same rule as mvgx_match_run); match totals of a batch are 32-bit on the device
+  const uint64_t B = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->batch_pairs, std::max<uint64_t>(16, (1ull << 29) / std::max<uint32_t>(c->qstride, 1))));
+  MVGX_REQUIRE(B * std::max<uint32_t>(c->qstride, 1) < (1ull << 32), MVGX_ERR_UNSUPPORTED,
+               "images of %u descriptor slots: a 16-pair batch overflows the 32-bit match offsets of the device path", c->qstride);
   for (uint64_t p0 = 0; p0 < n_pairs; p0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, n_pairs - p0);
     const uint32_t blocks_per_pair = std::max<uint32_t>(1, c->qstride / kQBlock);
