@@ -185,6 +185,31 @@ int mvgx_l2u8_run(mvgx_l2u8_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs
 int mvgx_l2u8_results(mvgx_l2u8_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
 
 /* ------------------------------------------------------------------------------------------------
+ * CASCADE HASHING (CASCADE_HASHING_L2, the default nearest-neighbour method of main_ComputeMatches for scalar regions)
+ * replaces the MATCHING stage of matching_image_collection/Cascade_Hashing_Matcher_Regions.cpp:134-215:
+ *   matching/cascade_hasher.hpp:241-367 CascadeHasher::Match_HashedDescriptions (candidates from the query's bucket in every
+ *   bucket group, de-duplicated in order of appearance, the ten nearest in Hamming distance of the hash codes, exact
+ *   L2<uint8> on those, the two smallest (distance, id) pairs) and the NNdistanceRatio test with Square(dist_ratio).
+ * The HASHING stage (cascade_hasher.hpp:154-239: zero-mean descriptor, primary / secondary random projections - single-
+ * precision Eigen products) stays host code of the caller; its per-descriptor outputs are inputs here, so the device part
+ * is integer work and the lists are bit-identical for any ratio. The openMVG adapter runs the reference's own
+ * CascadeHasher for the hashing stage and applies the reference's two de-duplication steps (:218-226) to the lists.
+ *   desc_rows[k]  n_desc[k] x 128 uint8      hash_codes[k]  n_desc[k] x 16 bytes (stl::dynamic_bitset blocks)
+ *   bucket_ids[k] n_desc[k] x n_groups uint16 (HashedDescription::bucket_ids), values < 2^bits_per_bucket
+ * Results: per pair the list BEFORE de-duplication, (descriptor of I, descriptor of J) in ascending J.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mvgx_cascade_ctx mvgx_cascade_ctx;
+int mvgx_cascade_create(int device, mvgx_cascade_ctx** out);
+int mvgx_cascade_destroy(mvgx_cascade_ctx* ctx);
+int mvgx_cascade_set_option(mvgx_cascade_ctx* ctx, const char* key /* "batch_pairs" */, int64_t value);
+int mvgx_cascade_set_regions(mvgx_cascade_ctx* ctx, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
+                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket);
+int mvgx_cascade_run(mvgx_cascade_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
+                     mvgx_match_stats* stats /* may be NULL */);
+int mvgx_cascade_results(mvgx_cascade_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);
+
+/* ------------------------------------------------------------------------------------------------
  * BUNDLE ADJUSTMENT
  * replaces: sfm/sfm_data_BA_ceres.cpp:165-608 (Bundle_Adjustment_Ceres::Adjust) and, underneath it,
  *           vendored Ceres 1.13: program_evaluator.h:138-285, residual_block.cc:68-196, corrector.cc:41-155,

@@ -1,0 +1,243 @@
+// mvgx_cascade_hashing_matcher_regions.cpp — link-time replacement for openMVG's
+//   src/openMVG/matching_image_collection/Cascade_Hashing_Matcher_Regions.cpp
+// (CASCADE_HASHING_L2: the default nearest-neighbour method of main_ComputeMatches for scalar regions,
+//  main_ComputeMatches.cpp:254-258). Same header, same mangled symbols; link libmvgx_hip.so.
+//
+// Split of the work (reference lines are Cascade_Hashing_Matcher_Regions.cpp):
+//   host, with the reference's own library code (so the values are the reference's bit for bit):
+//     * hashing stage :66-131 - CascadeHasher::Init, the zero-mean descriptor (mean over the images of the per-image mean),
+//       CreateHashedDescriptions per image (single-precision Eigen products) - here on all host threads instead of inside
+//       one `omp critical`;
+//     * the two de-duplication steps :218-226 - IndMatch::getDeduplicated and IndMatchDecorator<float>::getDeduplicated
+//       (whose std::set ordering is the library's) - on helper threads, the container is filled from the calling thread;
+//   MI355X (mvgx_cascade_*): the matching stage :166-215 - bucket candidates, Hamming ranking of the hash codes, exact L2 on
+//     the ten best, the two nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
+// 128-byte uint8 regions (SIFT) take that route. Other scalar regions (float descriptors, other lengths) keep working through
+// the reference's own CascadeHasher::Match_HashedDescriptions on the host: that code is not part of the accelerated path.
+// A device failure throws (no silent fallback for the accelerated type).
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <typeinfo>
+#include <unordered_map>
+#include <vector>
+
+#include "openMVG/features/feature.hpp"
+#include "openMVG/features/regions.hpp"
+#include "openMVG/matching/cascade_hasher.hpp"
+#include "openMVG/matching/indMatch.hpp"
+#include "openMVG/matching/indMatchDecoratorXY.hpp"
+#include "openMVG/matching/matching_filters.hpp"
+#include "openMVG/matching_image_collection/Cascade_Hashing_Matcher_Regions.hpp"
+#include "openMVG/numeric/numeric.h"
+#include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
+#include "openMVG/system/logger.hpp"
+#include "openMVG/system/progressinterface.hpp"
+#include "openMVG/types.hpp"
+
+#include "mvgx.h"
+
+namespace openMVG {
+namespace matching_image_collection {
+
+namespace {
+
+constexpr uint64_t kPairsPerCall = 1u << 16;   // cancellation / progress granularity of the device route
+
+template <class F>
+void on_host_threads(size_t n, F f) {   // f(index) for every index, indices handed out dynamically
+  const unsigned threads = (unsigned)std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+  if (threads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::atomic<size_t> next{0};
+  auto body = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body);
+  body();
+  for (auto& t : pool) t.join();
+}
+
+// everything the matching stage needs to know about one view
+template <typename ScalarT>
+struct View {
+  std::shared_ptr<features::Regions> regions;
+  matching::HashedDescriptions hashed;
+  std::vector<features::PointFeature> positions;
+  size_t count() const { return regions ? regions->RegionCount() : 0; }
+  const ScalarT* rows() const { return reinterpret_cast<const ScalarT*>(regions->DescriptorRawData()); }
+};
+
+// the reference's last two steps on one pair's putative list (entries (index in I, index in J))
+void deduplicate(matching::IndMatches& v, const std::vector<features::PointFeature>& posI, const std::vector<features::PointFeature>& posJ) {
+  matching::IndMatch::getDeduplicated(v);
+  matching::IndMatchDecorator<float> by_position(v, posI, posJ);
+  by_position.getDeduplicated(v);
+}
+
+template <typename ScalarT>
+void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pairs, float dist_ratio,
+                      matching::PairWiseMatchesContainer& out, system::ProgressInterface* progress) {
+  using RowMajor = Eigen::Matrix<ScalarT, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+  progress->Restart(pairs.size(), "- Matching -");
+  // views in ascending id = the row order of the zero-mean matrix (:88-108)
+  std::map<IndexT, View<ScalarT>> views;
+  for (const Pair& p : pairs) { views[p.first]; views[p.second]; }
+  if (views.empty()) return;
+  for (auto& kv : views) kv.second.regions = provider.get(kv.first);
+  const size_t dimension = views.begin()->second.regions->DescriptorLength();
+  matching::CascadeHasher hasher;
+  hasher.Init(dimension);
+  Eigen::VectorXf zero_mean;
+  {
+    Eigen::MatrixXf per_view(views.size(), dimension);
+    per_view.fill(0.0f);
+    size_t row = 0;
+    for (auto& kv : views) {
+      View<ScalarT>& v = kv.second;
+      if (v.count() > 0) {
+        Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
+        per_view.row(row) = matching::CascadeHasher::GetZeroMeanDescriptor(m);
+      }
+      ++row;
+    }
+    zero_mean = matching::CascadeHasher::GetZeroMeanDescriptor(per_view);
+  }
+  std::vector<View<ScalarT>*> order;
+  for (auto& kv : views) order.push_back(&kv.second);
+  on_host_threads(order.size(), [&](size_t k) {
+    View<ScalarT>& v = *order[k];
+    Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
+    v.hashed = hasher.CreateHashedDescriptions(m, zero_mean);   // const member, per-view outputs: thread safe
+    v.positions = v.regions->GetRegionsPositions();
+  });
+
+  // pairs in the reference's visiting order (grouped by I, ascending), minus the ones it skips (:151-176)
+  std::vector<Pair> todo;
+  uint32_t skipped = 0;
+  for (const Pair& p : pairs) {
+    const View<ScalarT>& vi = views.at(p.first);
+    const View<ScalarT>& vj = views.at(p.second);
+    if (vi.count() == 0 || vi.regions->Type_id() != vj.regions->Type_id()) { ++skipped; continue; }
+    todo.push_back(p);
+  }
+  if (skipped) (*progress) += skipped;
+
+  const bool on_device = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
+  if (!on_device) {
+    // the reference's own matching stage, pair by pair on the host threads; the container is filled by this thread
+    std::vector<matching::IndMatches> lists(todo.size());
+    on_host_threads(todo.size(), [&](size_t k) {
+      if (progress->hasBeenCanceled()) return;
+      const View<ScalarT>& vi = views.at(todo[k].first);
+      const View<ScalarT>& vj = views.at(todo[k].second);
+      using DistanceT = typename Accumulator<ScalarT>::Type;
+      Eigen::Map<RowMajor> mI(const_cast<ScalarT*>(vi.rows()), vi.count(), dimension), mJ(const_cast<ScalarT*>(vj.rows()), vj.count(), dimension);
+      matching::IndMatches nn;
+      std::vector<DistanceT> dist;
+      hasher.template Match_HashedDescriptions<RowMajor, DistanceT>(vj.hashed, mJ, vi.hashed, mI, &nn, &dist);
+      std::vector<int> kept;
+      matching::NNdistanceRatio(dist.begin(), dist.end(), 2, kept, Square(dist_ratio));
+      matching::IndMatches& v = lists[k];
+      for (int q : kept) v.emplace_back(nn[q * 2].j_, nn[q * 2].i_);
+      deduplicate(v, vi.positions, vj.positions);
+    });
+    for (size_t k = 0; k < todo.size(); ++k) {
+      if (!lists[k].empty()) out.insert({todo[k], std::move(lists[k])});
+      ++(*progress);
+    }
+    return;
+  }
+
+  // ---- device route: dense view numbering, hash outputs flattened ----
+  std::unordered_map<IndexT, uint32_t> dense;
+  std::vector<const uint8_t*> rows;
+  std::vector<std::vector<uint8_t>> codes;
+  std::vector<std::vector<uint16_t>> buckets;
+  std::vector<const uint8_t*> code_ptr;
+  std::vector<const uint16_t*> bucket_ptr;
+  std::vector<uint32_t> n_desc;
+  std::vector<const View<ScalarT>*> view_of;
+  for (auto& kv : views) {
+    const View<ScalarT>& v = kv.second;
+    dense[kv.first] = (uint32_t)rows.size();
+    view_of.push_back(&v);
+    const size_t n = v.count();
+    n_desc.push_back((uint32_t)n);
+    rows.push_back(n ? reinterpret_cast<const uint8_t*>(v.regions->DescriptorRawData()) : nullptr);
+    codes.emplace_back(n * 16);
+    buckets.emplace_back(n * 6);
+    for (size_t r = 0; r < n; ++r) {
+      const matching::HashedDescription& h = v.hashed.hashed_desc[r];
+      if (h.hash_code.num_blocks() != 16 || h.bucket_ids.size() != 6) throw std::runtime_error("mvgx cascade hashing: unexpected hash layout");
+      std::memcpy(&codes.back()[r * 16], h.hash_code.data(), 16);
+      for (int g = 0; g < 6; ++g) buckets.back()[r * 6 + g] = h.bucket_ids[g];
+    }
+  }
+  for (size_t k = 0; k < rows.size(); ++k) { code_ptr.push_back(codes[k].data()); bucket_ptr.push_back(buckets[k].data()); }
+  std::vector<uint32_t> dev_pairs;
+  for (const Pair& p : todo) { dev_pairs.push_back(dense[p.first]); dev_pairs.push_back(dense[p.second]); }
+
+  struct Ctx { mvgx_cascade_ctx* c = nullptr; ~Ctx() { if (c) mvgx_cascade_destroy(c); } } ctx;
+  auto fail = [&](const char* what, int rc) {
+    const std::string msg = std::string("mvgx (MI355X cascade hashing): ") + what + " failed with status " + std::to_string(rc) + ": " + mvgx_last_error();
+    OPENMVG_LOG_ERROR << msg;
+    throw std::runtime_error(msg);
+  };
+  int rc = mvgx_cascade_create(-1, &ctx.c);
+  if (rc != MVGX_OK) fail("create", rc);
+  rc = mvgx_cascade_set_regions(ctx.c, rows.data(), code_ptr.data(), bucket_ptr.data(), n_desc.data(), (uint32_t)rows.size(), 128, 16, 6, 10);
+  if (rc != MVGX_OK) fail("set_regions", rc);
+  const float ratio_sq = Square(dist_ratio);
+  const uint64_t n_pairs = todo.size();
+  for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
+    if (progress->hasBeenCanceled()) break;
+    const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
+    rc = mvgx_cascade_run(ctx.c, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+    if (rc != MVGX_OK) fail("run", rc);
+    const uint64_t* offsets = nullptr;
+    const uint32_t* ij = nullptr;
+    mvgx_cascade_results(ctx.c, &offsets, &ij);
+    std::vector<matching::IndMatches> lists(nb);
+    on_host_threads((size_t)((nb + 255) / 256), [&](size_t chunk) {
+      for (uint64_t k = chunk * 256, hi = std::min<uint64_t>(nb, k + 256); k < hi; ++k) {
+        const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
+        if (!n) continue;
+        matching::IndMatches& v = lists[k];
+        v.reserve(n);
+        for (uint64_t m = 0; m < n; ++m) v.emplace_back(ij[2 * (lo + m)], ij[2 * (lo + m) + 1]);
+        deduplicate(v, view_of[dev_pairs[2 * (p0 + k)]]->positions, view_of[dev_pairs[2 * (p0 + k) + 1]]->positions);
+      }
+    });
+    for (uint64_t k = 0; k < nb; ++k)
+      if (!lists[k].empty()) out.insert({todo[p0 + k], std::move(lists[k])});
+    (*progress) += (uint32_t)nb;
+  }
+}
+
+}  // namespace
+
+Cascade_Hashing_Matcher_Regions::Cascade_Hashing_Matcher_Regions(float dist_ratio) : Matcher(), f_dist_ratio_(dist_ratio) {}
+
+void Cascade_Hashing_Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& regions_provider, const Pair_Set& pairs,
+                                            matching::PairWiseMatchesContainer& map_PutativeMatches,
+                                            system::ProgressInterface* progress) const {
+  if (!regions_provider || regions_provider->IsBinary()) return;
+  if (!progress) progress = &system::ProgressInterface::dummy();
+  const std::string type = regions_provider->Type_id();
+  if (type == typeid(unsigned char).name())
+    match_collection<unsigned char>(*regions_provider, pairs, f_dist_ratio_, map_PutativeMatches, progress);
+  else if (type == typeid(float).name())
+    match_collection<float>(*regions_provider, pairs, f_dist_ratio_, map_PutativeMatches, progress);
+  else
+    OPENMVG_LOG_ERROR << "Matcher not implemented for this region type: " << type;
+}
+
+}  // namespace matching_image_collection
+}  // namespace openMVG

@@ -228,6 +228,144 @@ __global__ __launch_bounds__(kQBlock) void l2u8_top2_ratio_kernel(L2uParams p) {
   if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// CASCADE_HASHING_L2 (the default -n of main_ComputeMatches for scalar regions), matching stage on the device.
+// Replaces matching/cascade_hasher.hpp:241-367 (CascadeHasher::Match_HashedDescriptions, NN = 2, kNumTopCandidates = 10) +
+// matching_image_collection/Cascade_Hashing_Matcher_Regions.cpp:196-215 (NNdistanceRatio with Square(ratio)). The HASHING
+// stage (hash code and bucket ids of every descriptor: single-precision Eigen products, cascade_hasher.hpp:176-220) stays
+// host code of the caller - the openMVG adapter runs the reference's own CascadeHasher for it - so everything here is
+// integer work on given codes and the lists are bit-identical:
+//   one lane = one query descriptor of J. Candidates = the database descriptors of I in the query's bucket of each group
+//   (CSR per image, ascending ids inside a bucket), in group order; a candidate met again in a later group is skipped
+//   (its first appearance counts: it is a repeat iff it shares the query's bucket in an earlier group); queries with at most
+//   two raw candidates are dropped. The ten candidates of smallest Hamming distance between the 128-bit codes, ties in
+//   order of appearance = the ten smallest keys (distance << 24 | appearance index), kept in a register insertion network.
+//   Their exact L2<uint8> distances (v_dot4_u32_u8), the two smallest (distance, id) pairs in lexicographic order - a total
+//   order, unlike the brute-force path no tie can be ambiguous - and the fp32 ratio test of the reference.
+// Latency / L2-traffic bound gather work (~12 candidates per query at 2 000 descriptors and 1 024 buckets per group).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kCasGroupsMax = 8;
+constexpr int kCasTop = 10;
+struct CasParams {
+  const uint32_t* words;        // descriptors, 32 dwords (128 bytes) per row
+  const uint4* hash;            // 128-bit hash code per row
+  const uint4* bids;            // bucket ids per row: 8 x uint16 (groups beyond n_groups unused)
+  const uint32_t* bstart;       // per image: n_groups * n_buckets + 1 offsets into its items
+  const uint32_t* items;        // per image: n_groups lists of its rows, grouped by bucket (ascending row inside a bucket)
+  const uint64_t* img_row_off;
+  const uint32_t* img_n;
+  const uint2* pairs;
+  const uint2* work;
+  uint32_t* best;
+  uint32_t* count;
+  uint32_t qstride, n_groups, n_buckets;
+  float ratio_sq;
+};
+__device__ __forceinline__ uint32_t cas_bid(const uint4& b, int g) {
+  const uint32_t w = g < 2 ? b.x : g < 4 ? b.y : g < 6 ? b.z : b.w;
+  return (g & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+__global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
+  __shared__ uint32_t sh_count;
+  const uint2 w = p.work[blockIdx.x];
+  const uint2 ij = p.pairs[w.x];
+  const uint32_t nJ = p.img_n[ij.y];
+  const uint32_t q = w.y + threadIdx.x;
+  const bool active = q < nJ;
+  if (threadIdx.x == 0) sh_count = 0;
+  __syncthreads();
+  uint32_t out = kInvalid;
+  if (active) {
+    const uint64_t offI = p.img_row_off[ij.x], rowJ = p.img_row_off[ij.y] + q;
+    const uint4 hq = p.hash[rowJ], bq = p.bids[rowJ];
+    const int G = (int)p.n_groups;
+    const uint32_t* __restrict__ bs = p.bstart + (size_t)ij.x * ((size_t)G * p.n_buckets + 1);
+    const uint32_t* __restrict__ it = p.items + offI * (uint64_t)G;
+    uint32_t s[kCasGroupsMax], len[kCasGroupsMax], raw = 0;
+#pragma unroll
+    for (int g = 0; g < kCasGroupsMax; ++g) {
+      s[g] = 0; len[g] = 0;
+      if (g < G) {
+        const uint32_t b = (uint32_t)g * p.n_buckets + cas_bid(bq, g);
+        s[g] = bs[b];
+        len[g] = bs[b + 1] - s[g];
+        raw += len[g];
+      }
+    }
+    if (raw > 2) {
+      uint32_t top[kCasTop];
+#pragma unroll
+      for (int k = 0; k < kCasTop; ++k) top[k] = 0xFFFFFFFFu;
+      uint32_t t = 0;
+#pragma unroll
+      for (int g = 0; g < kCasGroupsMax; ++g) {
+        for (uint32_t e = 0; e < len[g]; ++e, ++t) {
+          const uint32_t id = it[s[g] + e];
+          const uint4 bi = p.bids[offI + id];
+          bool repeat = false;
+#pragma unroll
+          for (int g2 = 0; g2 < kCasGroupsMax; ++g2)
+            if (g2 < g) repeat = repeat || cas_bid(bi, g2) == cas_bid(bq, g2);
+          if (repeat) continue;
+          const uint4 hi = p.hash[offI + id];
+          const uint32_t ham = __popc(hi.x ^ hq.x) + __popc(hi.y ^ hq.y) + __popc(hi.z ^ hq.z) + __popc(hi.w ^ hq.w);
+          uint32_t key = (ham << 24) | t;
+#pragma unroll
+          for (int k = 0; k < kCasTop; ++k) {   // sorted insertion: the list keeps the ten smallest keys
+            const uint32_t lo = umin32(key, top[k]), hi2 = umax32(key, top[k]);
+            top[k] = lo; key = hi2;
+          }
+        }
+      }
+      // exact distances of the (up to) ten selected candidates; the two smallest (distance, id) pairs
+      uint32_t qv[32];
+      {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.words + rowJ * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const uint4 v = src[k]; qv[4 * k] = v.x; qv[4 * k + 1] = v.y; qv[4 * k + 2] = v.z; qv[4 * k + 3] = v.w; }
+      }
+      uint32_t qn = 0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) qn = __builtin_amdgcn_udot4(qv[k], qv[k], qn, false);
+      uint64_t b0 = ~0ull, b1 = ~0ull;   // (distance << 32 | id): lexicographic (distance, id)
+      int n_top = 0;
+#pragma unroll
+      for (int k = 0; k < kCasTop; ++k) {
+        if (top[k] == 0xFFFFFFFFu) continue;
+        ++n_top;
+        const uint32_t tt = top[k] & 0xFFFFFFu;
+        uint32_t cum = 0, idx = 0;
+#pragma unroll
+        for (int g = 0; g < kCasGroupsMax; ++g) {
+          if (tt >= cum && tt < cum + len[g]) idx = s[g] + (tt - cum);
+          cum += len[g];
+        }
+        const uint32_t id = it[idx];
+        const uint4* __restrict__ row = reinterpret_cast<const uint4*>(p.words + (offI + id) * 32);
+        uint32_t dot = 0, rn = 0;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+          const uint4 v = row[c4];
+          dot = __builtin_amdgcn_udot4(v.x, qv[4 * c4], dot, false); rn = __builtin_amdgcn_udot4(v.x, v.x, rn, false);
+          dot = __builtin_amdgcn_udot4(v.y, qv[4 * c4 + 1], dot, false); rn = __builtin_amdgcn_udot4(v.y, v.y, rn, false);
+          dot = __builtin_amdgcn_udot4(v.z, qv[4 * c4 + 2], dot, false); rn = __builtin_amdgcn_udot4(v.z, v.z, rn, false);
+          dot = __builtin_amdgcn_udot4(v.w, qv[4 * c4 + 3], dot, false); rn = __builtin_amdgcn_udot4(v.w, v.w, rn, false);
+        }
+        const uint32_t dist = rn + qn - 2u * dot;   // exact (< 2^24)
+        top2_u64(((uint64_t)dist << 32) | id, b0, b1);
+      }
+      if (n_top >= 2) {
+        const float d0 = (float)(uint32_t)(b0 >> 32), d1 = (float)(uint32_t)(b1 >> 32);
+        if (d0 < __fmul_rn(p.ratio_sq, d1)) out = (uint32_t)b0;
+      }
+    }
+    p.best[(size_t)w.x * p.qstride + q] = out;
+  }
+  if (out != kInvalid) atomicAdd(&sh_count, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_count) atomicAdd(&p.count[w.x], sh_count);
+}
+
 // exclusive scan of the per-pair counts (one workgroup)
 __global__ __launch_bounds__(1024) void hamming_scan_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ offsets) {
   __shared__ uint32_t part[1024];
@@ -306,6 +444,10 @@ struct BfCtx {
   uint32_t n_images = 0, nw = 0, desc_bytes = 0, max_n = 0, qstride = 0;
   std::vector<uint32_t> h_n;
   Buf<uint32_t> d_words, d_n, d_best, d_count, d_offsets, d_norms;
+  // kind 3 (cascade hashing): hash codes, bucket ids, per-image bucket lists
+  Buf<uint4> d_hash, d_bids;
+  Buf<uint32_t> d_bstart, d_items;
+  uint32_t cas_groups = 0, cas_buckets = 0;
   Buf<uint64_t> d_row_off;
   Buf<uint2> d_pairs, d_work, d_ij;
   Buf<uint2> hp_pairs, hp_work;
@@ -317,6 +459,7 @@ struct BfCtx {
 struct mvgx_hamming_ctx : BfCtx {};
 struct mvgx_l2f_ctx : BfCtx {};
 struct mvgx_l2u8_ctx : BfCtx {};
+struct mvgx_cascade_ctx : BfCtx {};
 
 namespace {
 
@@ -334,6 +477,7 @@ int bf_create(int kind, int device, BfCtx* c) {
 void bf_release(BfCtx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_hash.release(); c->d_bids.release(); c->d_bstart.release(); c->d_items.release();
   c->d_words.release(); c->d_norms.release(); c->d_n.release(); c->d_best.release(); c->d_count.release(); c->d_offsets.release();
   c->d_row_off.release(); c->d_pairs.release(); c->d_work.release(); c->d_ij.release();
   c->hp_pairs.release(); c->hp_work.release(); c->hp_offsets.release();
@@ -409,7 +553,8 @@ int bf_set_regions(BfCtx* c, const uint8_t* const* desc_rows, const uint32_t* n_
 int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mvgx_match_stats* stats) {
   MVGX_REQUIRE(c && (pairs_IJ || n_pairs == 0), MVGX_ERR_ARG, "run: NULL argument");
   MVGX_REQUIRE(c->nw != 0 || c->n_images == 0, MVGX_ERR_STATE, "run before set_regions");
-  MVGX_REQUIRE(ratio <= 1.0f && ratio >= 0.0f, MVGX_ERR_UNSUPPORTED,
+  // (cascade hashing orders its ten candidates by (distance, id): no ambiguous tie, any ratio is reproduced)
+  MVGX_REQUIRE(c->kind == 3 || (ratio <= 1.0f && ratio >= 0.0f), MVGX_ERR_UNSUPPORTED,
                "ratio = %g: the device path reproduces the reference only for 0 <= ratio <= 1 "
                "(ties are libstdc++ partial_sort order beyond that)", (double)ratio);
   MVGX_HIP(hipSetDevice(c->device));
@@ -420,7 +565,7 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
   c->res_ij.clear();
   mvgx_match_stats st;
   memset(&st, 0, sizeof(st));
-  st.variant = (c->kind == 0 ? 100 : c->kind == 1 ? 200 : 300) + c->nw;
+  st.variant = (c->kind == 0 ? 100 : c->kind == 1 ? 200 : c->kind == 2 ? 300 : 400) + c->nw;
   int rc;
   float kernel_ms = 0.f;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -438,7 +583,8 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
       const uint32_t I = pairs_IJ[2 * (p0 + k)], J = pairs_IJ[2 * (p0 + k) + 1];
       c->hp_pairs.p[k] = make_uint2(I, J);
       const uint32_t nI = c->h_n[I], nJ = c->h_n[J];
-      if (nI < 2 || nJ == 0) continue;   // matcher_brute_force.hpp:108-113, Matcher_Regions.cpp:65-69,85-90
+      // matcher_brute_force.hpp:108-113, Matcher_Regions.cpp:65-69,85-90; cascade: an empty I is skipped (Cascade_Hashing_Matcher_Regions.cpp:153-157)
+      if (c->kind == 3 ? (nI == 0 || nJ == 0) : (nI < 2 || nJ == 0)) continue;
       for (uint32_t q0 = 0; q0 < nJ; q0 += kQBlock) c->hp_work.p[n_work++] = make_uint2(k, q0);
       st.n_pairs += 1;
       st.n_desc_pairs += (uint64_t)nI * nJ;
@@ -452,7 +598,13 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
     MVGX_HIP(hipMemsetAsync(c->d_count.p, 0, nb * sizeof(uint32_t), c->stream));
     if (n_work) {
       MVGX_HIP(hipEventRecord(c->evk0, c->stream));
-      if (c->kind == 0) {
+      if (c->kind == 3) {
+        CasParams cp;
+        cp.words = c->d_words.p; cp.hash = c->d_hash.p; cp.bids = c->d_bids.p; cp.bstart = c->d_bstart.p; cp.items = c->d_items.p;
+        cp.img_row_off = c->d_row_off.p; cp.img_n = c->d_n.p; cp.pairs = c->d_pairs.p; cp.work = c->d_work.p; cp.best = c->d_best.p;
+        cp.count = c->d_count.p; cp.qstride = c->qstride; cp.n_groups = c->cas_groups; cp.n_buckets = c->cas_buckets; cp.ratio_sq = ratio;
+        hipLaunchKernelGGL(cascade_match_kernel, dim3(n_work), dim3(kQBlock), 0, c->stream, cp);
+      } else if (c->kind == 0) {
         HamParams hp;
         hp.words = c->d_words.p; hp.img_row_off = c->d_row_off.p; hp.img_n = c->d_n.p; hp.pairs = c->d_pairs.p; hp.work = c->d_work.p;
         hp.best = c->d_best.p; hp.count = c->d_count.p; hp.qstride = c->qstride; hp.ratio = ratio;
@@ -588,6 +740,73 @@ int mvgx_l2u8_run(mvgx_l2u8_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, 
 
 int mvgx_l2u8_results(mvgx_l2u8_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
   MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_l2u8_results: NULL argument");
+  *offsets = c->res_offsets.data();
+  *ij = c->res_ij.data();
+  return MVGX_OK;
+}
+
+int mvgx_cascade_create(int device, mvgx_cascade_ctx** out) { return bf_create_as(3, device, out); }
+int mvgx_cascade_destroy(mvgx_cascade_ctx* c) { if (c) { bf_release(c); delete c; } return MVGX_OK; }
+int mvgx_cascade_set_option(mvgx_cascade_ctx* c, const char* key, int64_t value) { return bf_set_option(c, key, value); }
+
+int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
+                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && hash_codes && bucket_ids && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_set_regions: NULL argument");
+  MVGX_REQUIRE(dim == 128 && hash_bytes == 16, MVGX_ERR_UNSUPPORTED,
+               "cascade hashing on the device: 128-byte uint8 descriptors with 128-bit codes (SIFT_Regions; CascadeHasher::Init(128)); "
+               "got length %u, %u code bytes", dim, hash_bytes);
+  MVGX_REQUIRE(n_groups >= 1 && n_groups <= (uint32_t)kCasGroupsMax && bits_per_bucket >= 1 && bits_per_bucket <= 16, MVGX_ERR_UNSUPPORTED,
+               "cascade hashing on the device: 1..8 bucket groups of 2^1..2^16 buckets (got %u groups, %u bits)", n_groups, bits_per_bucket);
+  int rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4);
+  if (rc) return rc;
+  const uint32_t NB = 1u << bits_per_bucket, G = n_groups;
+  c->cas_groups = G; c->cas_buckets = NB;
+  std::vector<uint64_t> off(n_images + 1, 0);
+  for (uint32_t k = 0; k < n_images; ++k) {
+    MVGX_REQUIRE(n_desc[k] == 0 || (hash_codes[k] && bucket_ids[k]), MVGX_ERR_ARG, "image %u: NULL hash / bucket array", k);
+    MVGX_REQUIRE(n_desc[k] < (1u << 24) / G, MVGX_ERR_UNSUPPORTED, "image %u: %u descriptors (limit 2^24 / groups: the appearance index has 24 bits)", k, n_desc[k]);
+    off[k + 1] = off[k] + n_desc[k];
+  }
+  const uint64_t rows = off[n_images];
+  std::vector<uint4> hash((size_t)std::max<uint64_t>(rows, 1)), bids((size_t)std::max<uint64_t>(rows, 1));
+  std::vector<uint32_t> bstart((size_t)std::max<uint32_t>(n_images, 1) * ((size_t)G * NB + 1), 0u), items((size_t)std::max<uint64_t>(rows * G, 1), 0u);
+  for (uint32_t k = 0; k < n_images; ++k) {
+    const uint32_t n = n_desc[k];
+    uint32_t* bs = bstart.data() + (size_t)k * ((size_t)G * NB + 1);
+    for (uint32_t r = 0; r < n; ++r) {
+      memcpy(&hash[off[k] + r], hash_codes[k] + (size_t)r * 16, 16);
+      uint16_t b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t g = 0; g < G; ++g) {
+        b8[g] = bucket_ids[k][(size_t)r * G + g];
+        MVGX_REQUIRE(b8[g] < NB, MVGX_ERR_ARG, "image %u, descriptor %u: bucket id %u out of range", k, r, (unsigned)b8[g]);
+        bs[(size_t)g * NB + b8[g] + 1]++;
+      }
+      memcpy(&bids[off[k] + r], b8, 16);
+    }
+    for (size_t b = 0; b < (size_t)G * NB; ++b) bs[b + 1] += bs[b];
+    std::vector<uint32_t> fill(bs, bs + (size_t)G * NB);
+    uint32_t* it = items.data() + off[k] * G;
+    for (uint32_t g = 0; g < G; ++g)
+      for (uint32_t r = 0; r < n; ++r) it[fill[(size_t)g * NB + bucket_ids[k][(size_t)r * G + g]]++] = r;   // ascending r inside a bucket (cascade_hasher.hpp:229-234)
+  }
+  if ((rc = c->d_hash.ensure(hash.size())) || (rc = c->d_bids.ensure(bids.size())) || (rc = c->d_bstart.ensure(bstart.size())) ||
+      (rc = c->d_items.ensure(items.size())))
+    return rc;
+  MVGX_HIP(hipMemcpyAsync(c->d_hash.p, hash.data(), hash.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_bids.p, bids.data(), bids.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_bstart.p, bstart.data(), bstart.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  return MVGX_OK;
+}
+
+int mvgx_cascade_run(mvgx_cascade_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, mvgx_match_stats* stats) {
+  return bf_run(c, pairs_IJ, n_pairs, ratio_sq, stats);
+}
+
+int mvgx_cascade_results(mvgx_cascade_ctx* c, const uint64_t** offsets, const uint32_t** ij) {
+  MVGX_REQUIRE(c && offsets && ij, MVGX_ERR_ARG, "mvgx_cascade_results: NULL argument");
   *offsets = c->res_offsets.data();
   *ij = c->res_ij.data();
   return MVGX_OK;

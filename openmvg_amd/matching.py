@@ -304,6 +304,30 @@ class L2u8Context(HammingContext):
     _dtype = np.uint8
 
 
+class CascadeContext(HammingContext):
+    """CASCADE_HASHING_L2, matching stage (thin wrapper over mvgx_cascade_*): 128-byte uint8 descriptors with the hash codes and
+    bucket ids the caller's hashing stage produced (the openMVG adapter runs the reference's CascadeHasher for that); run() takes
+    the squared ratio and returns the lists before the reference's de-duplication steps."""
+    _prefix = "mvgx_cascade"
+    _dtype = np.uint8
+
+    def set_regions(self, desc_list, hash_list, bucket_list, n_groups=6, bits_per_bucket=10):
+        d = [np.ascontiguousarray(x, np.uint8).reshape(-1, 128) for x in desc_list]
+        h = [np.ascontiguousarray(x, np.uint8).reshape(-1, 16) for x in hash_list]
+        b = [np.ascontiguousarray(x, np.uint16).reshape(-1, n_groups) for x in bucket_list]
+        n = len(d)
+        dp = (C.c_void_p * max(n, 1))(); hp = (C.c_void_p * max(n, 1))(); bp = (C.c_void_p * max(n, 1))()
+        cnt = (C.c_uint32 * max(n, 1))()
+        for k in range(n):
+            assert len(h[k]) == len(d[k]) == len(b[k])
+            dp[k] = d[k].ctypes.data if len(d[k]) else None
+            hp[k] = h[k].ctypes.data if len(d[k]) else None
+            bp[k] = b[k].ctypes.data if len(d[k]) else None
+            cnt[k] = len(d[k])
+        self._keep = (d, h, b)
+        _capi.check(self._fn("set_regions")(self._h, dp, hp, bp, cnt, n, 128, 16, n_groups, bits_per_bucket))
+
+
 class Float_Regions(Regions):
     """Scalar_Regions<SIOPointFeature, float, L> stand-in (AKAZE_Float_Regions: L = 64): an (n, L) float32 array."""
 

@@ -285,6 +285,86 @@ uint64_t oracle_matcher_regions_match_f32(const float* const* desc_rows, const u
   return overflow ? (uint64_t)-1 : total;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * CASCADE_HASHING_L2, the matching stage (the hashing stage - single-precision Eigen products - stays the reference's own
+ * code: its outputs, the per-descriptor hash code and bucket ids, are inputs here).
+ * Restates  matching/cascade_hasher.hpp:241-367  CascadeHasher::Match_HashedDescriptions (queries = descriptors of J,
+ * database = descriptors of I, NN = 2, kNumTopCandidates = 10) followed by  matching_image_collection/
+ * Cascade_Hashing_Matcher_Regions.cpp:196-215  (NNdistanceRatio with Square(ratio), IndMatch(database id, query id)).
+ * The two de-duplication steps that follow in the reference (:218-226) work on feature coordinates and are host code
+ * of the caller; this function returns the list BEFORE them, in ascending query order.
+ *   hash: n x hash_bytes (stl::dynamic_bitset blocks, unsigned char);  bids: n x n_groups uint16 bucket ids
+ * ------------------------------------------------------------------------------------------------------------------ */
+static unsigned popcount8(unsigned v) { unsigned c = 0; while (v) { c += v & 1u; v >>= 1; } return c; }
+
+uint32_t oracle_cascade_match_pair_u8(const uint8_t* descI, const uint8_t* hashI, const uint16_t* bidsI, uint32_t nI,
+                                      const uint8_t* descJ, const uint8_t* hashJ, const uint16_t* bidsJ, uint32_t nJ,
+                                      uint32_t dim, uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket,
+                                      float ratio_sq, uint32_t* out_ij /* capacity 2 * nJ */) {
+  const uint32_t n_buckets = 1u << bits_per_bucket, n_hash_bits = hash_bytes * 8;
+  /* buckets of the database image: group -> bucket -> ascending descriptor ids (cascade_hasher.hpp:222-236) */
+  uint32_t* start = (uint32_t*)calloc((size_t)n_groups * n_buckets + 1, sizeof(uint32_t));
+  uint32_t* items = (uint32_t*)malloc(((size_t)n_groups * nI + 1) * sizeof(uint32_t));
+  for (uint32_t g = 0; g < n_groups; ++g)
+    for (uint32_t k = 0; k < nI; ++k) start[(size_t)g * n_buckets + bidsI[(size_t)k * n_groups + g] + 1]++;
+  for (size_t b = 0; b < (size_t)n_groups * n_buckets; ++b) start[b + 1] += start[b];
+  {
+    uint32_t* fill = (uint32_t*)malloc((size_t)n_groups * n_buckets * sizeof(uint32_t));
+    memcpy(fill, start, (size_t)n_groups * n_buckets * sizeof(uint32_t));
+    for (uint32_t g = 0; g < n_groups; ++g)
+      for (uint32_t k = 0; k < nI; ++k) items[fill[(size_t)g * n_buckets + bidsI[(size_t)k * n_groups + g]]++] = k;
+    free(fill);
+  }
+  uint32_t* cand = (uint32_t*)malloc(((size_t)n_groups * nI + 1) * sizeof(uint32_t));
+  uint8_t* used = (uint8_t*)malloc(nI + 1);
+  uint32_t* by_ham = (uint32_t*)malloc(((size_t)(n_hash_bits + 1) * nI + 1) * sizeof(uint32_t));   /* column h: ids at distance h */
+  uint32_t* n_ham = (uint32_t*)malloc((n_hash_bits + 1) * sizeof(uint32_t));
+  uint32_t n_out = 0;
+  for (uint32_t q = 0; q < nJ; ++q) {
+    size_t nc = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+      const size_t b = (size_t)g * n_buckets + bidsJ[(size_t)q * n_groups + g];
+      for (uint32_t e = start[b]; e < start[b + 1]; ++e) { cand[nc++] = items[e]; used[items[e]] = 0; }
+    }
+    if (nc <= 2) continue;   /* "not at least NN candidates": the raw count, duplicates included (:283) */
+    memset(n_ham, 0, (n_hash_bits + 1) * sizeof(uint32_t));
+    for (size_t c = 0; c < nc; ++c) {
+      const uint32_t id = cand[c];
+      if (used[id]) continue;
+      used[id] = 1;
+      unsigned h = 0;
+      for (uint32_t w = 0; w < hash_bytes; ++w) h += popcount8((unsigned)(hashJ[(size_t)q * hash_bytes + w] ^ hashI[(size_t)id * hash_bytes + w]));
+      by_ham[(size_t)h * nI + n_ham[h]++] = id;
+    }
+    /* the (up to) ten candidates of smallest Hamming distance, ties in order of first appearance (:338-352) */
+    float dist[10];
+    uint32_t ids[10];
+    int nt = 0;
+    for (uint32_t h = 0; h <= n_hash_bits && nt < 10; ++h)
+      for (uint32_t k = 0; k < n_ham[h] && nt < 10; ++k) {
+        const uint32_t id = by_ham[(size_t)h * nI + k];
+        dist[nt] = (float)oracle_l2_u8(descI + (size_t)id * dim, descJ + (size_t)q * dim, dim);   /* DistanceType = float (:185-188) */
+        ids[nt++] = id;
+      }
+    if (nt < 2) continue;
+    /* std::partial_sort of (distance, id) pairs, first two: a total order, so "the two smallest pairs" (:356-365) */
+    int i0 = 0, i1 = -1;
+    for (int k = 1; k < nt; ++k)
+      if (dist[k] < dist[i0] || (dist[k] == dist[i0] && ids[k] < ids[i0])) i0 = k;
+    for (int k = 0; k < nt; ++k) {
+      if (k == i0) continue;
+      if (i1 < 0 || dist[k] < dist[i1] || (dist[k] == dist[i1] && ids[k] < ids[i1])) i1 = k;
+    }
+    if (dist[i0] < ratio_sq * dist[i1]) {   /* NNdistanceRatio, matching_filters.hpp:39-60 */
+      out_ij[2 * n_out] = ids[i0];
+      out_ij[2 * n_out + 1] = q;
+      ++n_out;
+    }
+  }
+  free(start); free(items); free(cand); free(used); free(by_ham); free(n_ham);
+  return n_out;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -6,6 +6,8 @@
 //   openMVG::matching::L2<uint8_t>                                   matching/metric.hpp:55-93 (+ metric_simd.hpp AVX2)
 //   openMVG::matching::ArrayMatcherBruteForce<uint8_t, L2<uint8_t>>  matching/matcher_brute_force.hpp:27-201
 //   openMVG::matching_image_collection::Matcher_Regions              matching_image_collection/Matcher_Regions.cpp:22-107
+//   openMVG::matching_image_collection::Cascade_Hashing_Matcher_Regions, openMVG::matching::CascadeHasher
+//                                                                    Cascade_Hashing_Matcher_Regions.cpp:28-272, cascade_hasher.hpp
 // fed through an in-memory sfm::Regions_Provider (sfm/pipelines/sfm_regions_provider.hpp:30-144, cache_ is protected).
 // Used to (a) validate oracle/match_oracle.c, (b) serve as the "reference" CPU baseline in bench.py.
 #include <chrono>
@@ -19,6 +21,8 @@
 #include "openMVG/matching/matcher_brute_force.hpp"
 #include "openMVG/matching/metric.hpp"
 #include "openMVG/matching/metric_hamming.hpp"
+#include "openMVG/matching/cascade_hasher.hpp"
+#include "openMVG/matching_image_collection/Cascade_Hashing_Matcher_Regions.hpp"
 #include "openMVG/matching_image_collection/Matcher_Regions.hpp"
 #include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
 
@@ -240,6 +244,68 @@ uint64_t ref_matcher_regions_match_liop144(const uint8_t* const* desc_rows, cons
   for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
   matching::PairWiseMatches out;
   matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) {
+      flat[2 * m] = kv.second[m].i_;
+      flat[2 * m + 1] = kv.second[m].j_;
+    }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
+}
+
+// ---- CASCADE_HASHING_L2 ------------------------------------------------------------------------------------------------
+// The hashing stage exactly as Cascade_Hashing_Matcher_Regions.cpp:66-131 runs it (CascadeHasher::Init(dimension), the zero-mean
+// descriptor = mean over the images of the per-image mean, CreateHashedDescriptions per image), with the per-descriptor outputs
+// copied out: hash_out[k] n x 16 bytes (dynamic_bitset blocks), bids_out[k] n x 6 uint16. Used by the tests as the input of the
+// device / restatement matching stage.
+int ref_cascade_hash_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint8_t* const* hash_out,
+                        uint16_t* const* bids_out) {
+  using BaseMat = Eigen::Matrix<unsigned char, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+  matching::CascadeHasher hasher;
+  hasher.Init(128);
+  Eigen::MatrixXf per_image(n_images, 128);
+  per_image.fill(0.0f);
+  for (uint32_t k = 0; k < n_images; ++k)
+    if (n_desc[k] > 0) {
+      Eigen::Map<BaseMat> m(const_cast<unsigned char*>(desc_rows[k]), n_desc[k], 128);
+      per_image.row(k) = matching::CascadeHasher::GetZeroMeanDescriptor(m);
+    }
+  const Eigen::VectorXf zero_mean = matching::CascadeHasher::GetZeroMeanDescriptor(per_image);
+  for (uint32_t k = 0; k < n_images; ++k) {
+    Eigen::Map<BaseMat> m(const_cast<unsigned char*>(desc_rows[k]), n_desc[k], 128);
+    const matching::HashedDescriptions h = hasher.CreateHashedDescriptions(m, zero_mean);
+    for (size_t r = 0; r < h.hashed_desc.size(); ++r) {
+      if (h.hashed_desc[r].hash_code.num_blocks() != 16 || h.hashed_desc[r].bucket_ids.size() != 6) return 0;
+      std::memcpy(hash_out[k] + r * 16, h.hashed_desc[r].hash_code.data(), 16);
+      for (int g = 0; g < 6; ++g) bids_out[k][r * 6 + g] = h.hashed_desc[r].bucket_ids[g];
+    }
+  }
+  return 1;
+}
+
+// Cascade_Hashing_Matcher_Regions(dist_ratio).Match on in-memory SIFT_Regions whose features sit at feat_xy[k] (n x 2 floats:
+// the reference removes matches that repeat the same coordinates, Cascade_Hashing_Matcher_Regions.cpp:221-226). Same output
+// convention as ref_matcher_regions_match_u8.
+uint64_t ref_cascade_matcher_regions_match_u8(const uint8_t* const* desc_rows, const float* const* feat_xy, const uint32_t* n_desc,
+                                              uint32_t n_images, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                              ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::SIFT_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) {
+    std::shared_ptr<features::Regions> r = make_sift_regions(desc_rows[k], n_desc[k]);
+    auto* sr = static_cast<features::SIFT_Regions*>(r.get());
+    for (uint32_t q = 0; q < n_desc[k]; ++q) sr->Features()[q] = features::SIOPointFeature(feat_xy[k][2 * q], feat_xy[k][2 * q + 1], 1.f, 0.f);
+    provider->set(k, r);
+  }
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Cascade_Hashing_Matcher_Regions matcher(dist_ratio);
   std::shared_ptr<sfm::Regions_Provider> base = provider;
   matcher.Match(base, pairs, out, nullptr);
   std::vector<uint32_t> flat;

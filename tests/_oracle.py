@@ -115,6 +115,62 @@ def ref_matcher_regions_match(descs, pairs, dist_ratio, lib=None):
     return out
 
 
+# ---- cascade hashing ------------------------------------------------------------------------------------------------
+def ref_cascade_hash(descs, lib=None):
+    """The reference's hashing stage (CascadeHasher::Init(128), zero-mean descriptor over the images, CreateHashedDescriptions):
+    per image (hash codes (n, 16) uint8, bucket ids (n, 6) uint16). oracle/_ref only."""
+    arrs, ptrs, cnt = _desc_tables(descs)
+    n = len(arrs)
+    hashes = [np.zeros((len(a), 16), np.uint8) for a in arrs]
+    bids = [np.zeros((len(a), 6), np.uint16) for a in arrs]
+    hp = (C.c_void_p * max(n, 1))(); bp = (C.c_void_p * max(n, 1))()
+    for k in range(n):
+        hp[k] = hashes[k].ctypes.data if len(arrs[k]) else None
+        bp[k] = bids[k].ctypes.data if len(arrs[k]) else None
+    L = lib or ref_match()
+    L.ref_cascade_hash_u8.restype = C.c_int
+    assert L.ref_cascade_hash_u8(ptrs, cnt, n, hp, bp) == 1
+    return hashes, bids
+
+
+def ref_cascade_matcher_regions_match(descs, feats_xy, pairs, dist_ratio, lib=None):
+    """The reference's Cascade_Hashing_Matcher_Regions(dist_ratio).Match on in-memory SIFT_Regions with the given feature
+    positions. Returns {(I, J): (n, 2) uint32}. lib: the adapter build exporting the same shim."""
+    arrs, ptrs, cnt = _desc_tables(descs)
+    n = len(arrs)
+    xy = [np.ascontiguousarray(f, np.float32).reshape(-1, 2) for f in feats_xy]
+    xp = (C.c_void_p * max(n, 1))()
+    for k in range(n):
+        xp[k] = xy[k].ctypes.data if len(xy[k]) else None
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = {}
+
+    def sink(_user, I, J, pij, m):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(m), 2)).copy()
+
+    cb = SINK(sink)
+    L = lib or ref_match()
+    L.ref_cascade_matcher_regions_match_u8.restype = C.c_uint64
+    L.ref_cascade_matcher_regions_match_u8(ptrs, xp, cnt, n, C.c_void_p(pairs.ctypes.data), C.c_uint64(len(pairs)), C.c_float(dist_ratio), cb, None)
+    return out
+
+
+def port_cascade_match_pair(descI, hashI, bidsI, descJ, hashJ, bidsJ, dist_ratio):
+    """C restatement of the cascade MATCHING stage for one pair (queries = J, database = I), list before the reference's
+    de-duplication steps: (n, 2) uint32 (descriptor of I, descriptor of J) in ascending J."""
+    descI = np.ascontiguousarray(descI, np.uint8).reshape(-1, 128); descJ = np.ascontiguousarray(descJ, np.uint8).reshape(-1, 128)
+    hashI = np.ascontiguousarray(hashI, np.uint8).reshape(-1, 16); hashJ = np.ascontiguousarray(hashJ, np.uint8).reshape(-1, 16)
+    bidsI = np.ascontiguousarray(bidsI, np.uint16).reshape(-1, 6); bidsJ = np.ascontiguousarray(bidsJ, np.uint16).reshape(-1, 6)
+    out = np.zeros((max(len(descJ), 1), 2), np.uint32)
+    L = port()
+    L.oracle_cascade_match_pair_u8.restype = C.c_uint32
+    r = np.float32(dist_ratio)
+    n = L.oracle_cascade_match_pair_u8(C.c_void_p(descI.ctypes.data), C.c_void_p(hashI.ctypes.data), C.c_void_p(bidsI.ctypes.data), C.c_uint32(len(descI)),
+                                       C.c_void_p(descJ.ctypes.data), C.c_void_p(hashJ.ctypes.data), C.c_void_p(bidsJ.ctypes.data), C.c_uint32(len(descJ)),
+                                       C.c_uint32(128), C.c_uint32(16), C.c_uint32(6), C.c_uint32(10), C.c_float(r * r), C.c_void_p(out.ctypes.data))
+    return out[: int(n)].copy()
+
+
 def _bin_tables(descs, L):
     arrs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, L) for d in descs]
     n = len(arrs)
@@ -585,7 +641,7 @@ def adapter():
         m = _bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64",
-                     "ref_matcher_regions_match_liop144"):
+                     "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_hash_u8"):
             setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare"):
             setattr(both, name, getattr(b, name))

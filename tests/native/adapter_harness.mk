@@ -41,8 +41,8 @@ $(OUT)/ref_shim_ba.o: $(ROOT)/oracle/ref_shim_ba.cpp
 	@mkdir -p $(OUT)
 	$(CXX) $(BASEFLAGS) -c $< -o $@
 
-$(OUT)/libmvgx_openmvg_adapter.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
-	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
+$(OUT)/libmvgx_openmvg_adapter.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
 
 $(OUT)/libmvgx_openmvg_adapter_ba.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
 	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
@@ -50,8 +50,8 @@ $(OUT)/libmvgx_openmvg_adapter_ba.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_a
 # The matcher half once more, linked against the two emulation libraries instead of libmvgx_hip.so: the C++ routing code of the
 # adapter (region-type dispatch, batching, delivery threads) runs on the CPU test box (tests/test_adapter_emu_cpu.py).
 emu: $(OUT)/libmvgx_openmvg_adapter_emu.so
-$(OUT)/libmvgx_openmvg_adapter_emu.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) $(OUT)/libmvgx_ba_emu.so $(OUT)/libmvgx_match_emu.so $(lastword $(MAKEFILE_LIST))
-	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(REF_MATCH_OBJS) -L$(OUT) -lmvgx_match_emu -lmvgx_ba_emu -lpthread
+$(OUT)/libmvgx_openmvg_adapter_emu.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) $(OUT)/libmvgx_ba_emu.so $(OUT)/libmvgx_match_emu.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) -L$(OUT) -lmvgx_match_emu -lmvgx_ba_emu -lpthread
 
 $(OUT)/libmvgx_openmvg_adapter_ba_emu.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(OUT)/libmvgx_ba_emu.so $(lastword $(MAKEFILE_LIST))
 	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(OUT) -lmvgx_ba_emu -lpthread

@@ -76,3 +76,15 @@ def test_ratio_above_one_uses_the_reference_route():
     got = _oracle.ref_matcher_regions_match(descs, pairs, 1.05, lib=_oracle.adapter_emu())
     if _oracle.have_ref_match():
         _same(got, _oracle.ref_matcher_regions_match(descs, pairs, 1.05))
+
+
+@pytest.mark.parametrize("tag", ["synthetic", "synthetic_grid", "sceaux"])
+def test_cascade_hashing_replacement_equals_the_reference_lists(tag):
+    """Cascade_Hashing_Matcher_Regions::Match of the replacement TU (hashing stage = the reference's CascadeHasher on the host,
+    matching stage = emulated device code, de-duplication = the reference's classes) against the reference's stored containers:
+    same pairs, same lists in the same order - including the cases where the coordinate de-duplication removes matches"""
+    from tests.test_cascade import load
+    descs, xy, hs, bs, pairs, ref = load(tag)
+    for ratio in (0.8, 0.6):
+        got = _oracle.ref_cascade_matcher_regions_match(descs, xy, pairs, ratio, lib=_oracle.adapter_emu())
+        _same(got, ref[int(ratio * 100)])

@@ -165,3 +165,18 @@ def test_bundle_adjustment_ceres_replacement_on_the_devices_of_the_environment(n
     assert rc == 0 and stats[3] == ref_stats[3] == 1.0
     assert abs(stats[1] - ref_stats[1]) < 1e-6, (stats[1], ref_stats[1])
     assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["synthetic", "synthetic_grid", "sceaux"])
+def test_cascade_hashing_replacement_equals_the_reference_lists(tag):
+    """-n CASCADEHASHINGL2 (main_ComputeMatches' default) through the replacement TU: hashing by the reference's CascadeHasher on
+    the host, matching stage on the MI355X, the reference's de-duplication classes - containers equal the reference's stored ones
+    (synthetic set with an empty image, a grid of repeated feature positions, the real SceauxCastle regions), order included"""
+    from tests.test_cascade import load
+    descs, xy, hs, bs, pairs, ref = load(tag)
+    for ratio in (0.8, 0.6):
+        got = _oracle.ref_cascade_matcher_regions_match(descs, xy, pairs, ratio, lib=_oracle.adapter())
+        _same(got, ref[int(ratio * 100)])
+    if _oracle.have_ref_match():    # and live against the reference TU at another ratio
+        _same(_oracle.ref_cascade_matcher_regions_match(descs, xy, pairs, 0.9, lib=_oracle.adapter()),
+              _oracle.ref_cascade_matcher_regions_match(descs, xy, pairs, 0.9))
