@@ -19,6 +19,8 @@
 #include "openMVG/features/regions_factory.hpp"
 #include "openMVG/matching/indMatch.hpp"
 #include "openMVG/matching/matcher_brute_force.hpp"
+#include "openMVG/matching/matching_filters.hpp"
+#include "openMVG/numeric/numeric.h"
 #include "openMVG/matching/metric.hpp"
 #include "openMVG/matching/metric_hamming.hpp"
 #include "openMVG/matching/cascade_hasher.hpp"
@@ -318,6 +320,45 @@ uint64_t ref_cascade_matcher_regions_match_u8(const uint8_t* const* desc_rows, c
     if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
   }
   return out.size();
+}
+
+// CascadeHasher with a chosen bucket layout on ONE pair (queries = J, database = I): Init(128, n_groups, bits_per_bucket), the
+// zero-mean descriptor over the two images, CreateHashedDescriptions, Match_HashedDescriptions (NN = 2) and NNdistanceRatio -
+// the list before the de-duplication steps, as (index in I, index in J). The hash outputs are copied out as well (16 bytes and
+// n_groups uint16 per descriptor), so that the restatement / the device stage can be run on exactly these inputs. Few bits per
+// bucket put hundreds of candidates in a bucket: the regime where the top-ten selection and the repeat test do real work.
+// Returns the number of matches.
+uint32_t ref_cascade_match_pair_u8(const uint8_t* descI, uint32_t nI, const uint8_t* descJ, uint32_t nJ, uint32_t n_groups,
+                                   uint32_t bits_per_bucket, float dist_ratio, uint8_t* hashI, uint16_t* bidsI, uint8_t* hashJ,
+                                   uint16_t* bidsJ, uint32_t* out_ij /* capacity 2 * nJ */) {
+  using BaseMat = Eigen::Matrix<unsigned char, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+  matching::CascadeHasher hasher;
+  hasher.Init(128, uint8_t(n_groups), uint8_t(bits_per_bucket));
+  Eigen::Map<BaseMat> mI(const_cast<unsigned char*>(descI), nI, 128), mJ(const_cast<unsigned char*>(descJ), nJ, 128);
+  Eigen::MatrixXf per_image(2, 128);
+  per_image.fill(0.0f);
+  if (nI) per_image.row(0) = matching::CascadeHasher::GetZeroMeanDescriptor(mI);
+  if (nJ) per_image.row(1) = matching::CascadeHasher::GetZeroMeanDescriptor(mJ);
+  const Eigen::VectorXf zero_mean = matching::CascadeHasher::GetZeroMeanDescriptor(per_image);
+  const matching::HashedDescriptions hI = hasher.CreateHashedDescriptions(mI, zero_mean), hJ = hasher.CreateHashedDescriptions(mJ, zero_mean);
+  auto copy_out = [&](const matching::HashedDescriptions& h, uint8_t* hash, uint16_t* bids) {
+    for (size_t r = 0; r < h.hashed_desc.size(); ++r) {
+      std::memcpy(hash + r * 16, h.hashed_desc[r].hash_code.data(), 16);
+      for (uint32_t g = 0; g < n_groups; ++g) bids[r * n_groups + g] = h.hashed_desc[r].bucket_ids[g];
+    }
+  };
+  copy_out(hI, hashI, bidsI);
+  copy_out(hJ, hashJ, bidsJ);
+  matching::IndMatches nn;
+  std::vector<float> dist;
+  hasher.Match_HashedDescriptions<BaseMat, float>(hJ, mJ, hI, mI, &nn, &dist);
+  std::vector<int> kept;
+  matching::NNdistanceRatio(dist.begin(), dist.end(), 2, kept, Square(dist_ratio));
+  for (size_t k = 0; k < kept.size(); ++k) {
+    out_ij[2 * k] = nn[kept[k] * 2].j_;
+    out_ij[2 * k + 1] = nn[kept[k] * 2].i_;
+  }
+  return uint32_t(kept.size());
 }
 
 }  // extern "C"

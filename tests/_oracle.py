@@ -155,19 +155,34 @@ def ref_cascade_matcher_regions_match(descs, feats_xy, pairs, dist_ratio, lib=No
     return out
 
 
-def port_cascade_match_pair(descI, hashI, bidsI, descJ, hashJ, bidsJ, dist_ratio):
+def ref_cascade_match_pair(descI, descJ, dist_ratio, n_groups=6, bits_per_bucket=10):
+    """The reference's CascadeHasher with a chosen bucket layout on one pair (oracle/_ref): returns (matches (n, 2) before the
+    de-duplication steps, hashI, bidsI, hashJ, bidsJ)."""
+    descI = np.ascontiguousarray(descI, np.uint8).reshape(-1, 128); descJ = np.ascontiguousarray(descJ, np.uint8).reshape(-1, 128)
+    hI = np.zeros((len(descI), 16), np.uint8); hJ = np.zeros((len(descJ), 16), np.uint8)
+    bI = np.zeros((len(descI), n_groups), np.uint16); bJ = np.zeros((len(descJ), n_groups), np.uint16)
+    out = np.zeros((max(len(descJ), 1), 2), np.uint32)
+    L = ref_match()
+    L.ref_cascade_match_pair_u8.restype = C.c_uint32
+    n = L.ref_cascade_match_pair_u8(C.c_void_p(descI.ctypes.data), C.c_uint32(len(descI)), C.c_void_p(descJ.ctypes.data), C.c_uint32(len(descJ)),
+                                    C.c_uint32(n_groups), C.c_uint32(bits_per_bucket), C.c_float(dist_ratio), C.c_void_p(hI.ctypes.data),
+                                    C.c_void_p(bI.ctypes.data), C.c_void_p(hJ.ctypes.data), C.c_void_p(bJ.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out[: int(n)].copy(), hI, bI, hJ, bJ
+
+
+def port_cascade_match_pair(descI, hashI, bidsI, descJ, hashJ, bidsJ, dist_ratio, n_groups=6, bits_per_bucket=10):
     """C restatement of the cascade MATCHING stage for one pair (queries = J, database = I), list before the reference's
     de-duplication steps: (n, 2) uint32 (descriptor of I, descriptor of J) in ascending J."""
     descI = np.ascontiguousarray(descI, np.uint8).reshape(-1, 128); descJ = np.ascontiguousarray(descJ, np.uint8).reshape(-1, 128)
     hashI = np.ascontiguousarray(hashI, np.uint8).reshape(-1, 16); hashJ = np.ascontiguousarray(hashJ, np.uint8).reshape(-1, 16)
-    bidsI = np.ascontiguousarray(bidsI, np.uint16).reshape(-1, 6); bidsJ = np.ascontiguousarray(bidsJ, np.uint16).reshape(-1, 6)
+    bidsI = np.ascontiguousarray(bidsI, np.uint16).reshape(-1, n_groups); bidsJ = np.ascontiguousarray(bidsJ, np.uint16).reshape(-1, n_groups)
     out = np.zeros((max(len(descJ), 1), 2), np.uint32)
     L = port()
     L.oracle_cascade_match_pair_u8.restype = C.c_uint32
     r = np.float32(dist_ratio)
     n = L.oracle_cascade_match_pair_u8(C.c_void_p(descI.ctypes.data), C.c_void_p(hashI.ctypes.data), C.c_void_p(bidsI.ctypes.data), C.c_uint32(len(descI)),
                                        C.c_void_p(descJ.ctypes.data), C.c_void_p(hashJ.ctypes.data), C.c_void_p(bidsJ.ctypes.data), C.c_uint32(len(descJ)),
-                                       C.c_uint32(128), C.c_uint32(16), C.c_uint32(6), C.c_uint32(10), C.c_float(r * r), C.c_void_p(out.ctypes.data))
+                                       C.c_uint32(128), C.c_uint32(16), C.c_uint32(n_groups), C.c_uint32(bits_per_bucket), C.c_float(r * r), C.c_void_p(out.ctypes.data))
     return out[: int(n)].copy()
 
 

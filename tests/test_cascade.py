@@ -126,3 +126,54 @@ def test_any_ratio_is_reproduced():
     for I, J in pairs[:3]:
         m = _oracle.port_cascade_match_pair(descs[I], hs[I], bs[I], descs[J], hs[J], bs[J], 1.2)
         assert np.array_equal(got.get((int(I), int(J)), np.zeros((0, 2), np.uint32)), m)
+
+
+# ---- bucket layouts that load the selection logic (tests/golden/cascade_layouts.npz, make_cascade_layouts_golden.py) -------------
+LAYOUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cascade_layouts.npz")
+
+
+def _layout_cases():
+    z = np.load(LAYOUTS)
+    return [tuple(int(v) for v in row) for row in z["layouts"]]
+
+
+def _layout(g, b):
+    z = np.load(LAYOUTS)
+    t = f"g{g}b{b}"
+    return z["descI"], z["descJ"], z[f"{t}/hashI"], z[f"{t}/bidsI"], z[f"{t}/hashJ"], z[f"{t}/bidsJ"], {0.8: z[f"{t}/r8"], 1.3: z[f"{t}/r13"]}
+
+
+@pytest.mark.parametrize("g,b", _layout_cases())
+def test_restatement_on_crowded_buckets(g, b):
+    dI, dJ, hI, bI, hJ, bJ, want = _layout(g, b)
+    for ratio, w in want.items():
+        assert np.array_equal(_oracle.port_cascade_match_pair(dI, hI, bI, dJ, hJ, bJ, ratio, g, b), w), (g, b, ratio)
+    assert len(want[1.3]) >= len(want[0.8]) > (50 if b <= 10 else 0)     # 2^16 buckets: almost every bucket is empty
+
+
+def _device_pair(dI, dJ, hI, bI, hJ, bJ, ratio, g, b):
+    ctx = matching.CascadeContext(0)
+    try:
+        ctx.set_regions([dI, dJ], [hI, hJ], [bI, bJ], n_groups=g, bits_per_bucket=b)
+        r = np.float32(ratio)
+        _, off, ij = ctx.run(np.array([[0, 1]], np.uint32), r * r)
+    finally:
+        ctx.close()
+    return ij
+
+
+@pytest.mark.parametrize("g,b", [(6, 2), (3, 1), (8, 4), (8, 16)])
+def test_emulated_device_code_on_crowded_buckets(g, b):
+    from tests import _emu
+    dI, dJ, hI, bI, hJ, bJ, want = _layout(g, b)
+    with _emu.emulated():
+        for ratio, w in want.items():
+            assert np.array_equal(_device_pair(dI, dJ, hI, bI, hJ, bJ, ratio, g, b), w), (g, b, ratio)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g,b", _layout_cases())
+def test_device_code_on_crowded_buckets(g, b):
+    dI, dJ, hI, bI, hJ, bJ, want = _layout(g, b)
+    for ratio, w in want.items():
+        assert np.array_equal(_device_pair(dI, dJ, hI, bI, hJ, bJ, ratio, g, b), w), (g, b, ratio)
