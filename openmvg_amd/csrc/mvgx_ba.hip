@@ -729,18 +729,36 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(GroupList G, const 
   const uint32_t p0 = G.pt_start[g], np = G.pt_start[g + 1] - p0;
   double hv = 0.0;
   if ((uint32_t)tid < np * 3) hv = hp[(size_t)G.pts[p0 + tid / 3] * 3 + tid % 3];
-  for (uint32_t e = tid; e < ne; e += 256) {
-    const uint32_t qx = G.obs_qx[e0 + e], q = qx >> 8, x = qx & 255u;
-    const double2* __restrict__ zr = reinterpret_cast<const double2*>(Z + (size_t)G.obs[e0 + e] * 18);
-    double2 v[9];
+  static_assert(kGroupPts * kGroupCams <= 512, "two observations per thread cover a group");
+  {
+    // both observations of a thread: first their indices, then all 18 record loads, then the LDS stores - two memory round
+    // trips per workgroup instead of four
+    const uint32_t ea = tid, eb = tid + 256;
+    const bool has_a = ea < ne, has_b = eb < ne;
+    const uint32_t qxa = has_a ? G.obs_qx[e0 + ea] : 0u, qxb = has_b ? G.obs_qx[e0 + eb] : 0u;
+    const uint32_t oa = has_a ? G.obs[e0 + ea] : 0u, ob = has_b ? G.obs[e0 + eb] : 0u;
+    const double2* __restrict__ za = reinterpret_cast<const double2*>(Z + (size_t)oa * 18);
+    const double2* __restrict__ zb = reinterpret_cast<const double2*>(Z + (size_t)ob * 18);
+    double2 va[9], vb[9];
 #pragma unroll
-    for (int w = 0; w < 9; ++w) v[w] = zr[w];
-    double* __restrict__ dst = lds + (6 * x) * kGroupRS + 3 * q;
+    for (int w = 0; w < 9; ++w) { va[w] = has_a ? za[w] : make_double2(0.0, 0.0); vb[w] = has_b ? zb[w] : make_double2(0.0, 0.0); }
+    if (has_a) {
+      double* __restrict__ dst = lds + (6 * (qxa & 255u)) * kGroupRS + 3 * (qxa >> 8);
 #pragma unroll
-    for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
-      const int k = (2 * w) / 6, cc = (2 * w) % 6;
-      dst[cc * kGroupRS + k] = v[w].x;
-      dst[(cc + 1) * kGroupRS + k] = v[w].y;
+      for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
+        const int k = (2 * w) / 6, cc = (2 * w) % 6;
+        dst[cc * kGroupRS + k] = va[w].x;
+        dst[(cc + 1) * kGroupRS + k] = va[w].y;
+      }
+    }
+    if (has_b) {
+      double* __restrict__ dst = lds + (6 * (qxb & 255u)) * kGroupRS + 3 * (qxb >> 8);
+#pragma unroll
+      for (int w = 0; w < 9; ++w) {
+        const int k = (2 * w) / 6, cc = (2 * w) % 6;
+        dst[cc * kGroupRS + k] = vb[w].x;
+        dst[(cc + 1) * kGroupRS + k] = vb[w].y;
+      }
     }
   }
   if ((uint32_t)tid < np * 3) lds[(6 * kGroupCams) * kGroupRS + tid] = hv;
@@ -919,12 +937,23 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
   double (*col)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 2 * 64 * kLS);   // aliases Tmp: 16 pivot columns of the panel
   double* rd = lds + 2 * 64 * kLS + 64 * 17;                                      // 1 / L[r][r]
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  for (int q = tid; q < 4096; q += 256) {
-    const int c = q >> 6, r = q & 63;
-    double v = (r == c) ? 1.0 : 0.0;   // identity padding of a partial last block
-    if (r < kb && c < kb) v = (r >= c) ? A[(size_t)(k0 + c) * ld + (k0 + r)] : 0.0;
-    L[r][c] = v;
-    Li[r][c] = 0.0;
+  {
+    // all 16 loads of a thread are issued before the first LDS store: as a rolled loop every element paid a full memory
+    // round trip (the compiler keeps load -> wait -> store per iteration), ~11 of the kernel's 25 microseconds
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = tid + 256 * i, c = q >> 6, r = q & 63;
+      const bool inside = r < kb && c < kb;
+      v[i] = (r == c && !inside) ? 1.0 : 0.0;   // identity padding of a partial last block
+      if (inside && r >= c) v[i] = A[(size_t)(k0 + c) * ld + (k0 + r)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = tid + 256 * i, c = q >> 6, r = q & 63;
+      L[r][c] = v[i];
+      Li[r][c] = 0.0;
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
@@ -1042,7 +1071,14 @@ __global__ __launch_bounds__(256) void sp_factor_kernel(SpSys s, int f0, int* fa
 }
 
 // kUpdate false: T, dst(L) = X(A) Linv_k^T (only the q <= column part of the triangular inverse is walked);
-// kUpdate true:  U, dst(A) -= sum over contributors X(L) Y(L)^T.
+// kUpdate true:  U, dst(A) -= sum over contributors X(L) Y(L)^T. The contributor list of a task is fetched 64 entries at a
+// time (one per lane, handed out by v_readlane) and the 32 operand loads of contributor c + 1 are in flight while the 16
+// MFMAs of contributor c run: as a plain loop every contributor cost two dependent memory round trips (index, then operands),
+// which was the whole 23 microseconds of this kernel.
+__device__ __forceinline__ void sp_load_operands(const double* __restrict__ X, const double* __restrict__ Y, double (&xv)[16], double (&yv)[16]) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) { xv[ks] = X[ks * 256]; yv[ks] = Y[ks * 256]; }
+}
 template <bool kUpdate>
 __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tasks) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -1051,12 +1087,19 @@ __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tas
   const mvgx_sparse::GemmTask g = (kUpdate ? s.u_tasks : s.t_tasks)[t0 + t];
   const mvgx_sparse::SlotPair* __restrict__ pairs = kUpdate ? s.u_pairs : s.t_pairs;
   d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
-  const int ksteps = kUpdate ? 16 : 4 * (g.bj + 1);
-  for (int c = g.c0; c < g.c1; ++c) {
-    const mvgx_sparse::SlotPair p = pairs[c];
-    // lane (li, lk) feeds X[16 bi + li][4 ks + lk] and Y[16 bj + li][4 ks + lk]; element (r, q) of a tile sits at q * 64 + r
-    const double* __restrict__ X = (kUpdate ? s.L : s.A) + (size_t)p.a * 4096 + 16 * g.bi + li + lk * 64;
-    const double* __restrict__ Y = (kUpdate ? s.L : s.Linv) + (size_t)p.b * 4096 + 16 * g.bj + li + lk * 64;
+  // lane (li, lk) feeds X[16 bi + li][4 ks + lk] and Y[16 bj + li][4 ks + lk]; element (r, q) of a tile sits at q * 64 + r
+  const size_t xoff = 16 * g.bi + li + lk * 64, yoff = 16 * g.bj + li + lk * 64;
+  double* __restrict__ dst = (kUpdate ? s.A : s.L) + (size_t)g.dst * 4096 + (size_t)(16 * g.bj + lk) * 64 + 16 * g.bi + li;
+  double old[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (kUpdate) {   // the destination is read up front, not after the last MFMA
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) old[reg] = dst[reg * 256];
+  }
+  if constexpr (!kUpdate) {
+    const int ksteps = 4 * (g.bj + 1);
+    const mvgx_sparse::SlotPair p = pairs[g.c0];
+    const double* __restrict__ X = s.A + (size_t)p.a * 4096 + xoff;
+    const double* __restrict__ Y = s.Linv + (size_t)p.b * 4096 + yoff;
     double xv[16], yv[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -1066,12 +1109,34 @@ __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tas
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
       if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[ks], xv[ks], acc, 0, 0, 0);   // D[c][r]: stores coalesce along r
-  }
-  double* __restrict__ dst = (kUpdate ? s.A : s.L) + (size_t)g.dst * 4096 + (size_t)(16 * g.bj + lk) * 64 + 16 * g.bi + li;
+  } else {
+    for (int cbase = g.c0; cbase < g.c1; cbase += 64) {
+      const int n = min(64, g.c1 - cbase);
+      const mvgx_sparse::SlotPair mine = lane < n ? pairs[cbase + lane] : mvgx_sparse::SlotPair{0, 0};
+      double xa[16], ya[16], xb[16], yb[16];
+      {
+        const int pa = __builtin_amdgcn_readlane(mine.a, 0), pb = __builtin_amdgcn_readlane(mine.b, 0);
+        sp_load_operands(s.L + (size_t)pa * 4096 + xoff, s.L + (size_t)pb * 4096 + yoff, xa, ya);
+      }
+      for (int i = 0; i < n; i += 2) {
+        if (i + 1 < n) {
+          const int pa = __builtin_amdgcn_readlane(mine.a, i + 1), pb = __builtin_amdgcn_readlane(mine.b, i + 1);
+          sp_load_operands(s.L + (size_t)pa * 4096 + xoff, s.L + (size_t)pb * 4096 + yoff, xb, yb);
+        }
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    if (kUpdate) dst[reg * 256] -= acc[reg]; else dst[reg * 256] = acc[reg];
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ks], xa[ks], acc, 0, 0, 0);
+        if (i + 1 >= n) break;
+        if (i + 2 < n) {
+          const int pa = __builtin_amdgcn_readlane(mine.a, i + 2), pb = __builtin_amdgcn_readlane(mine.b, i + 2);
+          sp_load_operands(s.L + (size_t)pa * 4096 + xoff, s.L + (size_t)pb * 4096 + yoff, xa, ya);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb[ks], xb[ks], acc, 0, 0, 0);
+      }
+    }
   }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = kUpdate ? old[reg] - acc[reg] : acc[reg];
 }
 
 // Reverse sweep, one workgroup per tile column of the level: z_k = Linv_k^T (y_k - sum over the tiles below L_ik^T z_i).
@@ -1080,11 +1145,22 @@ __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
   const int k = s.f_cols[f0 + blockIdx.x];
   const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
   double v = 0;
-  for (int e = s.bs_start[k]; e < s.bs_start[k + 1]; ++e) {
-    const double* __restrict__ tile = s.L + (size_t)s.bs_slot[e] * 4096 + c * 64 + part * 16;
-    const double* __restrict__ zi = s.z + (size_t)s.bs_row[e] * 64 + part * 16;
+  // the (slot, row) indices of the tiles below are fetched 64 at a time (one per lane, v_readlane hands them out): the loads of
+  // a tile no longer wait for an index load of their own
+  const int lane = tid & 63;
+  for (int ebase = s.bs_start[k]; ebase < s.bs_start[k + 1]; ebase += 64) {
+    const int n = min(64, s.bs_start[k + 1] - ebase);
+    const int my_slot = lane < n ? s.bs_slot[ebase + lane] : 0, my_row = lane < n ? s.bs_row[ebase + lane] : 0;
+    for (int i = 0; i < n; ++i) {
+      const int slot = __builtin_amdgcn_readlane(my_slot, i), row = __builtin_amdgcn_readlane(my_row, i);
+      const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
+      const double* __restrict__ zi = s.z + (size_t)row * 64 + part * 16;
+      double tv[16], zv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v += tile[q] * zi[q];
+      for (int q = 0; q < 16; ++q) { tv[q] = tile[q]; zv[q] = zi[q]; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += tv[q] * zv[q];
+    }
   }
   v += __shfl_xor(v, 1);
   v += __shfl_xor(v, 2);
@@ -1135,10 +1211,20 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(double* __restrict
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (int q = tid; q < 64 * 64; q += 256) {
-    const int k = q >> 6, r = q & 63;
-    P[k][r] = (k < kb && row0 + r <= n) ? A[(size_t)(k0 + k) * ld + (row0 + r)] : 0.0;
-    Q[k][r] = linvT[k * 64 + r];   // zero beyond the factor's triangle, identity padding beyond kb
+  {
+    double pv[16], qv[16];   // all 32 loads of a thread in flight before the first LDS store (one memory round trip, not sixteen)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = tid + 256 * i, k = q >> 6, r = q & 63;
+      pv[i] = (k < kb && row0 + r <= n) ? A[(size_t)(k0 + k) * ld + (row0 + r)] : 0.0;
+      qv[i] = linvT[k * 64 + r];   // zero beyond the factor's triangle, identity padding beyond kb
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = tid + 256 * i, k = q >> 6, r = q & 63;
+      P[k][r] = pv[i];
+      Q[k][r] = qv[i];
+    }
   }
   __syncthreads();
   mfma_tile_32x32(P, Q, 64, rbase, cbase, acc);
