@@ -110,6 +110,10 @@ struct GroupList {
   uint32_t* obs_start = nullptr;   // n_groups + 1 -> entries
   uint32_t* obs = nullptr;         // entry: observation index
   uint16_t* obs_qx = nullptr;      // entry: (local point << 8) | local camera
+  uint32_t* obs_pt = nullptr;      // entry: point of the observation
+  uint32_t* obs_pose = nullptr;    // entry: pose of the observation
+  uint32_t* ungrouped = nullptr;   // observations of the points outside every group (their Z comes from ba_obs_z_kernel)
+  uint32_t n_ungrouped = 0;
   uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
   uint32_t* pts = nullptr;         // local point -> point
   uint32_t* chunk = nullptr;       // n_groups x kGroupPairs: row of tpp.part for local cameras (x <= y), kNoChunk: no common point
@@ -585,31 +589,36 @@ __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_r
   d.hp[(size_t)p * 3 + 2] = li[3] * g[0] + li[4] * g[1] + li[5] * g[2];
 }
 
-// per observation: Z = L_p^-1 Es^T Fc_s (3 x 6)
-__global__ __launch_bounds__(256) void ba_obs_z_kernel(Dev d) {
-  const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= d.n_obs) return;
-  const uint32_t p = d.opt[o], ip = d.opose[o];
-  double a[8], b[16], e0[3], e1[3], li[6];
-  load_rec<8>(d.JA + (size_t)o * kJA, a);
-  load_rec<16>(d.JB + (size_t)o * kJB, b);
+// per observation: Z = L_p^-1 Es^T Fc_s (3 x 6); a = {r, E} record, b = {r, Fc} record, sp / sc = point / pose column scales
+__device__ __forceinline__ void obs_z_math(const double (&a)[8], const double (&b)[16], const double (&sp)[3], const double (&li)[6],
+                                           const double (&sc)[6], double (&Z)[18]) {
+  double e0[3], e1[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const double s = d.scale_pt[(size_t)p * 3 + c];
-    e0[c] = a[2 + c] * s; e1[c] = a[5 + c] * s;
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) li[c] = d.Linv3[(size_t)p * 6 + c];
-  double Z[18];
+  for (int c = 0; c < 3; ++c) { e0[c] = a[2 + c] * sp[c]; e1[c] = a[5 + c] * sp[c]; }
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    const double sc = d.scale_cam[6 * ip + c];
-    const double f0 = b[2 + c] * sc, f1 = b[8 + c] * sc;
+    const double f0 = b[2 + c] * sc[c], f1 = b[8 + c] * sc[c];
     const double y0 = e0[0] * f0 + e1[0] * f1, y1 = e0[1] * f0 + e1[1] * f1, y2 = e0[2] * f0 + e1[2] * f1;
     Z[c] = li[0] * y0;
     Z[6 + c] = li[1] * y0 + li[2] * y1;
     Z[12 + c] = li[3] * y0 + li[4] * y1 + li[5] * y2;
   }
+}
+// list == nullptr: every observation; else the n listed ones (observations of points outside the point groups: the groups'
+// own observations get their Z from ba_schur_group_kernel while it stages them)
+__global__ __launch_bounds__(256) void ba_obs_z_kernel(Dev d, const uint32_t* __restrict__ list, uint64_t n) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t o = list ? list[idx] : idx;
+  const uint32_t p = d.opt[o], ip = d.opose[o];
+  double a[8], b[16], sp[3], li[6], sc[6], Z[18];
+  load_rec<8>(d.JA + (size_t)o * kJA, a);
+  load_rec<16>(d.JB + (size_t)o * kJB, b);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) sp[c] = d.scale_pt[(size_t)p * 3 + c];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { li[c] = d.Linv3[(size_t)p * 6 + c]; sc[c] = d.scale_cam[6 * ip + c]; }
+  obs_z_math(a, b, sp, li, sc, Z);
   double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)o * 18);
 #pragma unroll
   for (int k = 0; k < 9; ++k) zo[k] = make_double2(Z[2 * k], Z[2 * k + 1]);
@@ -717,8 +726,7 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
     }
   }
 }
-__global__ __launch_bounds__(256) void ba_schur_group_kernel(GroupList G, const double* __restrict__ Z, const double* __restrict__ hp,
-                                                             double* __restrict__ part) {
+__global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G, const double* __restrict__ hp, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [64 columns][kGroupRS]
   const int g = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
@@ -731,33 +739,47 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(GroupList G, const 
   if ((uint32_t)tid < np * 3) hv = hp[(size_t)G.pts[p0 + tid / 3] * 3 + tid % 3];
   static_assert(kGroupPts * kGroupCams <= 512, "two observations per thread cover a group");
   {
-    // both observations of a thread: first their indices, then all 18 record loads, then the LDS stores - two memory round
-    // trips per workgroup instead of four
+    // Both observations of a thread: first their indices, then every Jacobian / scale / factor load of both, then the Z blocks
+    // are formed (the arithmetic of ba_obs_z_kernel), written to the Z array the back-substitution reads and staged in LDS - the
+    // separate pass over the observations that only produced Z is gone for grouped points.
     const uint32_t ea = tid, eb = tid + 256;
     const bool has_a = ea < ne, has_b = eb < ne;
-    const uint32_t qxa = has_a ? G.obs_qx[e0 + ea] : 0u, qxb = has_b ? G.obs_qx[e0 + eb] : 0u;
-    const uint32_t oa = has_a ? G.obs[e0 + ea] : 0u, ob = has_b ? G.obs[e0 + eb] : 0u;
-    const double2* __restrict__ za = reinterpret_cast<const double2*>(Z + (size_t)oa * 18);
-    const double2* __restrict__ zb = reinterpret_cast<const double2*>(Z + (size_t)ob * 18);
-    double2 va[9], vb[9];
+    const uint32_t ia = has_a ? e0 + ea : e0, ib = has_b ? e0 + eb : e0;
+    const uint32_t qxa = G.obs_qx[ia], qxb = G.obs_qx[ib];
+    const uint32_t oa = G.obs[ia], ob = G.obs[ib], pa = G.obs_pt[ia], pb = G.obs_pt[ib], ca = G.obs_pose[ia], cb = G.obs_pose[ib];
+    double aa[8], ab[8], ba_[16], bb[16], spa[3], spb[3], lia[6], lib[6], sca[6], scb[6];
+    load_rec<8>(d.JA + (size_t)oa * kJA, aa); load_rec<8>(d.JA + (size_t)ob * kJA, ab);
+    load_rec<16>(d.JB + (size_t)oa * kJB, ba_); load_rec<16>(d.JB + (size_t)ob * kJB, bb);
 #pragma unroll
-    for (int w = 0; w < 9; ++w) { va[w] = has_a ? za[w] : make_double2(0.0, 0.0); vb[w] = has_b ? zb[w] : make_double2(0.0, 0.0); }
+    for (int c = 0; c < 3; ++c) { spa[c] = d.scale_pt[(size_t)pa * 3 + c]; spb[c] = d.scale_pt[(size_t)pb * 3 + c]; }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      lia[c] = d.Linv3[(size_t)pa * 6 + c]; lib[c] = d.Linv3[(size_t)pb * 6 + c];
+      sca[c] = d.scale_cam[6 * ca + c]; scb[c] = d.scale_cam[6 * cb + c];
+    }
+    double Za[18], Zb[18];
+    obs_z_math(aa, ba_, spa, lia, sca, Za);
+    obs_z_math(ab, bb, spb, lib, scb, Zb);
     if (has_a) {
+      double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)oa * 18);
       double* __restrict__ dst = lds + (6 * (qxa & 255u)) * kGroupRS + 3 * (qxa >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
         const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        dst[cc * kGroupRS + k] = va[w].x;
-        dst[(cc + 1) * kGroupRS + k] = va[w].y;
+        zo[w] = make_double2(Za[2 * w], Za[2 * w + 1]);
+        dst[cc * kGroupRS + k] = Za[2 * w];
+        dst[(cc + 1) * kGroupRS + k] = Za[2 * w + 1];
       }
     }
     if (has_b) {
+      double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)ob * 18);
       double* __restrict__ dst = lds + (6 * (qxb & 255u)) * kGroupRS + 3 * (qxb >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {
         const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        dst[cc * kGroupRS + k] = vb[w].x;
-        dst[(cc + 1) * kGroupRS + k] = vb[w].y;
+        zo[w] = make_double2(Zb[2 * w], Zb[2 * w + 1]);
+        dst[cc * kGroupRS + k] = Zb[2 * w];
+        dst[(cc + 1) * kGroupRS + k] = Zb[2 * w + 1];
       }
     }
   }
@@ -1822,7 +1844,12 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   Dev& d = c->d;
   MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
   if (d.n_pts) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
-  if (d.n_obs) hipLaunchKernelGGL(ba_obs_z_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d);
+  if (d.grp.n_groups) {   // grouped observations get their Z inside ba_schur_group_kernel
+    if (d.grp.n_ungrouped)
+      hipLaunchKernelGGL(ba_obs_z_kernel, dim3((d.grp.n_ungrouped + 255) / 256), dim3(256), 0, c->stream, d, d.grp.ungrouped, (uint64_t)d.grp.n_ungrouped);
+  } else if (d.n_obs) {
+    hipLaunchKernelGGL(ba_obs_z_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, (const uint32_t*)nullptr, (uint64_t)d.n_obs);
+  }
   if (d.n_islots) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if (d.sp.enabled) MVGX_HIP(hipMemsetAsync(d.sp.A, 0, (size_t)d.sp.n_slots * 4096 * sizeof(double), c->stream));
@@ -1830,7 +1857,7 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   if (d.tpp.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
   if (d.grp.n_groups)
-    hipLaunchKernelGGL(ba_schur_group_kernel, dim3(d.grp.n_groups), dim3(256), kGroupLds, c->stream, d.grp, d.Zpose, d.hp, d.tpp.part);
+    hipLaunchKernelGGL(ba_schur_group_kernel, dim3(d.grp.n_groups), dim3(256), kGroupLds, c->stream, d, d.grp, d.hp, d.tpp.part);
   if (d.tpi.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(8 * ((d.tpi.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
   if (d.tii.n_chunks)
@@ -2667,6 +2694,15 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs, g_obs, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_qx, g_obs_qx, c->stream))) return rc;
+      {
+        std::vector<uint32_t> g_obs_pt(g_obs.size()), g_obs_pose(g_obs.size()), ungrouped;
+        for (size_t e = 0; e < g_obs.size(); ++e) { g_obs_pt[e] = opt_[g_obs[e]]; g_obs_pose[e] = opose[g_obs[e]]; }
+        for (uint64_t o = 0; o < no; ++o) if (!in_group[opt_[o]]) ungrouped.push_back((uint32_t)o);
+        d.grp.n_ungrouped = (uint32_t)ungrouped.size();
+        if ((rc = dev_upload(c->pool, &d.grp.obs_pt, g_obs_pt, c->stream))) return rc;
+        if ((rc = dev_upload(c->pool, &d.grp.obs_pose, g_obs_pose, c->stream))) return rc;
+        if ((rc = dev_upload(c->pool, &d.grp.ungrouped, ungrouped, c->stream))) return rc;
+      }
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.chunk, gext.ext_row, c->stream))) return rc;
