@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvgx_hip.so")
+LIB_PATH = os.environ.get("MVGX_LIB_PATH") or os.path.join(_HERE, "lib", "libmvgx_hip.so")   # (override: kernel-variant experiments)
 
 MVGX_OK = 0
 MVGX_ERR_ARG, MVGX_ERR_HIP, MVGX_ERR_NODEV, MVGX_ERR_STATE, MVGX_ERR_UNSUPPORTED, MVGX_ERR_NUMERIC = 1, 2, 3, 4, 5, 6

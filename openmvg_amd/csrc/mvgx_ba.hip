@@ -99,9 +99,14 @@ struct TripList {
 // instead of once per partner) - the list stays for the points that fit no group (long tracks, constant points).
 constexpr int kGroupCams = 10;                                    // local cameras per group: 60 pose columns + h
 constexpr int kGroupPairs = kGroupCams * (kGroupCams + 1) / 2;    // destination blocks of a group
-constexpr int kGroupPts = 42;                                     // 126 rows of K
-constexpr int kGroupRS = 130;                                     // doubles between columns in LDS: = 2 mod 32 -> an MFMA operand read
-                                                                  // (16 columns x 2 rows per half wave) touches every bank pair once
+#ifndef MVGX_GROUP_PTS
+#define MVGX_GROUP_PTS 42
+#define MVGX_GROUP_RS 130
+#endif
+constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points rows of K
+constexpr int kGroupRS = MVGX_GROUP_RS;                           // doubles between columns in LDS, >= 3 kGroupPts and = 2 x odd (mod 32): the 16
+                                                                  // columns x 2 rows a half wave reads as an MFMA operand then fall on distinct banks
+static_assert(kGroupRS >= 3 * kGroupPts + 2 && (kGroupRS % 4) == 2, "group tile layout");
 constexpr int kGroupLds = 64 * kGroupRS * (int)sizeof(double);
 constexpr int kGroupMinPts = 8;                                   // smaller groups go to the flat list
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
