@@ -2762,7 +2762,10 @@ int mvgx_ba_comm_init(mvgx_ba_ctx* c, int world, int rank, const void* unique_id
   MVGX_HIP(hipSetDevice(c->device));
   mvgx::rccl_destroy(c->rccl);
   c->rccl = nullptr;
-  return mvgx::rccl_init(&c->rccl, world, rank, unique_id128);
+  int rc = mvgx::rccl_init(&c->rccl, world, rank, unique_id128);
+  if (rc) return rc;
+  if ((rc = mvgx::rccl_self_check(c->rccl, c->stream))) { mvgx::rccl_destroy(c->rccl); c->rccl = nullptr; }
+  return rc;
 }
 
 int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {

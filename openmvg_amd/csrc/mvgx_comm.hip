@@ -108,6 +108,29 @@ int rccl_allreduce_f64(RcclComm* c, double* device_buffer, uint64_t count, int o
   return MVGX_OK;
 }
 
+// The data-type / operator codes above are restated from rccl.h (the library is bound by dlopen, its header is not
+// included): one tiny all-reduce of known values per operator right after the communicator exists turns a mismatch with
+// the installed librccl into an error instead of silently wrong sums.
+int rccl_self_check(RcclComm* c, hipStream_t stream) {
+  double* d = nullptr;
+  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&d), 4 * sizeof(double)));
+  const double r1 = (double)(c->rank + 1);
+  const double h[4] = {1.0, r1, r1, -r1};
+  double got[4] = {0, 0, 0, 0};
+  int rc = MVGX_OK;
+  if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, stream) != hipSuccess) rc = MVGX_ERR_HIP;
+  if (!rc) rc = rccl_allreduce_f64(c, d, 2, MVGX_REDUCE_SUM, stream);
+  if (!rc) rc = rccl_allreduce_f64(c, d + 2, 2, MVGX_REDUCE_MAX, stream);
+  if (!rc && (hipMemcpyAsync(got, d, sizeof(got), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) rc = MVGX_ERR_HIP;
+  (void)hipFree(d);
+  if (rc) return rc;
+  const double w = (double)c->world;
+  MVGX_REQUIRE(got[0] == w && got[1] == w * (w + 1) / 2 && got[2] == w && got[3] == -1.0, MVGX_ERR_HIP,
+               "RCCL self-check failed (sum: %g %g, max: %g %g for world %d): data-type / operator codes of this librccl differ from "
+               "the ones mvgx_comm.hip assumes (rccl.h ncclFloat64 = 8, ncclSum = 0, ncclMax = 2)", got[0], got[1], got[2], got[3], c->world);
+  return MVGX_OK;
+}
+
 }  // namespace mvgx
 
 extern "C" int mvgx_comm_unique_id(void* out128) {

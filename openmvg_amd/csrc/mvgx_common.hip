@@ -148,7 +148,12 @@ void Arena::release() {
       else drop.push_back(s);
     }
   }
-  for (const Slab& s : drop) { (void)hipSetDevice(s.device); (void)hipFree(s.p); }
+  if (!drop.empty()) {   // the caller's current device is left as it was
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (const Slab& s : drop) { (void)hipSetDevice(s.device); (void)hipFree(s.p); }
+    if (have) (void)hipSetDevice(cur);
+  }
   slabs_.clear();
   bump_ = -1; off_ = 0; next_ = 0;
 }

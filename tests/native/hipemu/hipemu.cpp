@@ -265,6 +265,7 @@ int rccl_unique_id(void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPP
 int rccl_init(RcclComm**, int, int, const void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPPORTED; }
 void rccl_destroy(RcclComm*) {}
 int rccl_allreduce_f64(RcclComm*, double*, uint64_t, int, hipStream_t) { return MVGX_ERR_UNSUPPORTED; }
+int rccl_self_check(RcclComm*, hipStream_t) { return MVGX_ERR_UNSUPPORTED; }
 }  // namespace mvgx
 extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out); }
 #include "mvgx_ba.hip"
