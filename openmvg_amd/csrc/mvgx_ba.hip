@@ -170,6 +170,11 @@ struct Dev {
   // (pose, intrinsic) pairs and intrinsics: observation lists for the Gram kernels
   uint32_t *pi_obs = nullptr, *pichunk_lo = nullptr, *pichunk_hi = nullptr, *pi_chunk0 = nullptr, *pose_pi_start = nullptr;
   uint32_t *iobs = nullptr, *igchunk_lo = nullptr, *igchunk_hi = nullptr, *igchunk_start = nullptr;
+  // matrix-core Gram path: the intrinsic blocks come out of the same pass as the (pose, intrinsic) blocks; per intrinsic the
+  // list of the (pose, intrinsic) chunks that belong to it
+  int gram_mfma = 0;
+  uint32_t *intr_pichunk_start = nullptr, *intr_pichunk = nullptr;
+  double* pichunk_ipart = nullptr;   // n_pichunks x kIntrGram
   // pose-centre priors
   uint32_t *prior_pose = nullptr, *pose_prior_start = nullptr, *pose_prior_idx = nullptr;
   double *prior_center = nullptr, *prior_weight = nullptr, *Jprior = nullptr;
@@ -446,6 +451,54 @@ __global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
   if (threadIdx.x < kPiGram)
     d.pichunk_part[(size_t)ch * kPiGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
+// The same blocks on the f64 matrix cores, and the intrinsic's own blocks with them: the two rows of an observation's camera
+// Jacobian are two rows of F = [Fc (6) | Fi (8) | r | 0], and F^T F of a chunk holds Fc^T Fc, Fc^T Fi, Fi^T Fi, Fc^T r and Fi^T r.
+// One wave per chunk; lane (li, lk) feeds element li of row k0 + lk straight from the Jacobian records as BOTH operands of
+// v_mfma_f64_16x16x4_f64 (16 lanes read 14 consecutive doubles of a record), 64 observations of loads in flight per block.
+// The separate pass over the observations of every intrinsic (ba_intr_gram_kernel) is not needed on this path.
+__global__ __launch_bounds__(256) void ba_pi_gram_mfma_kernel(Dev d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const uint32_t ch = blockIdx.x * 4 + wave;
+  if (ch >= (uint32_t)d.n_pichunks) return;   // wave-uniform
+  const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
+  // where element li of Jacobian row `parity` lives: JB = {r(2), Fc row 0 (6), Fc row 1 (6), pad}, JC = {Fi row 0 (8), Fi row 1 (8)}
+  const int parity = lk & 1;
+  const bool from_c = li >= 6 && li < 14;
+  const int off = li < 6 ? 2 + 6 * parity + li : from_c ? 8 * parity + (li - 6) : parity;   // li == 14: r; li == 15: unused
+  const double* __restrict__ base = from_c ? d.JC : d.JB;
+  d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+  for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
+    const uint32_t nblk = min(64u, hi - e0);
+    const uint32_t mine = lane < nblk ? d.pi_obs[e0 + lane] : 0u;
+    double v[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {   // k-step ks covers observations 2 ks (rows lk = 0, 1) and 2 ks + 1 (lk = 2, 3)
+      const uint32_t oa = __builtin_amdgcn_readlane(mine, 2 * ks), ob = __builtin_amdgcn_readlane(mine, 2 * ks + 1);
+      const uint32_t o = (lk >> 1) ? ob : oa;
+      const bool live = (uint32_t)(2 * ks + (lk >> 1)) < nblk && li < 15;
+      v[ks] = live ? base[(size_t)o * 16 + off] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+      if ((uint32_t)(2 * ks) < nblk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ks], v[ks], acc, 0, 0, 0);
+  }
+  // D[i = lk + 4 reg][j = li]
+  double* __restrict__ pp = d.pichunk_part + (size_t)ch * kPiGram;
+  double* __restrict__ ip = d.pichunk_ipart + (size_t)ch * kIntrGram;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = lk + 4 * reg, j = li;
+    const double val = acc[reg];
+    if (i < 6) {
+      if (j < 6) { if (i <= j) pp[tri6(i, j)] = val; }
+      else if (j < 14) pp[kPoseGram + i * 8 + (j - 6)] = val;
+      else if (j == 14) pp[21 + i] = val;
+    } else if (i < 14) {
+      if (j >= 6 && j < 14) { if (i <= j) ip[tri8(i - 6, j - 6)] = val; }
+      else if (j == 14) ip[36 + (i - 6)] = val;
+    }
+  }
+}
 // per (pose, intrinsic) pair: sum of its chunks
 __global__ __launch_bounds__(128) void ba_pi_finish_kernel(Dev d) {
   const uint32_t q = blockIdx.x;
@@ -516,7 +569,11 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   const int g = threadIdx.x >> 6, t = threadIdx.x & 63;
   if (t < kIntrGram) {
     double v = 0;
-    for (uint32_t ch = d.igchunk_start[k] + g; ch < d.igchunk_start[k + 1]; ch += 16) v += d.igram_part[(size_t)ch * kIntrGram + t];
+    if (d.gram_mfma) {
+      for (uint32_t q = d.intr_pichunk_start[k] + g; q < d.intr_pichunk_start[k + 1]; q += 16) v += d.pichunk_ipart[(size_t)d.intr_pichunk[q] * kIntrGram + t];
+    } else {
+      for (uint32_t ch = d.igchunk_start[k] + g; ch < d.igchunk_start[k + 1]; ch += 16) v += d.igram_part[(size_t)ch * kIntrGram + t];
+    }
     sh[g][t] = v;
   }
   __syncthreads();
@@ -1820,10 +1877,13 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   int rc = eval<true>(c, d.poses, d.intr, d.pts);
   if (rc) return rc;
   if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
-  if (d.n_pichunks) hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  if (d.n_pichunks) {
+    if (d.gram_mfma) hipLaunchKernelGGL(ba_pi_gram_mfma_kernel, dim3((d.n_pichunks + 3) / 4), dim3(256), 0, c->stream, d);
+    else hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  }
   if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
   if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
-  if (d.n_igchunks) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
+  if (d.n_igchunks && !d.gram_mfma) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
   if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(1024), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
@@ -2447,6 +2507,17 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   }
   pi_chunk0.push_back((uint32_t)pichunk_lo.size());
   d.n_pichunks = (int)pichunk_lo.size();
+  // the chunks of every intrinsic (ascending chunk id): its own Gram blocks are summed from them on the matrix-core path
+  std::vector<uint32_t> intr_pichunk_start(d.n_intr + 1, 0), intr_pichunk(pichunk_lo.size());
+  {
+    std::vector<uint32_t> chunk_intr(pichunk_lo.size());
+    for (int q = 0; q < d.n_pi; ++q)
+      for (uint32_t ch = pi_chunk0[q]; ch < pi_chunk0[q + 1]; ++ch) { chunk_intr[ch] = pi_intr[q]; intr_pichunk_start[pi_intr[q] + 1]++; }
+    for (uint32_t k = 0; k < d.n_intr; ++k) intr_pichunk_start[k + 1] += intr_pichunk_start[k];
+    std::vector<uint32_t> fill(intr_pichunk_start.begin(), intr_pichunk_start.end() - 1);
+    for (uint32_t ch = 0; ch < (uint32_t)chunk_intr.size(); ++ch) intr_pichunk[fill[chunk_intr[ch]]++] = ch;
+  }
+  { const char* env = getenv("MVGX_BA_GRAM"); d.gram_mfma = !(env && !strcmp(env, "valu")); }
   // observations by intrinsic, cut into chunks
   std::vector<uint32_t> iobs_start, iobs, igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
   counting_sort_indices(no, d.n_intr, T, [&](uint64_t k) { return ointr[k]; }, iobs_start, iobs);
@@ -2664,6 +2735,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   UP(cam_active, cam_active); UP(cam_counts, cam_counts); UP(pt_free, pt_free);
   UP(pi_obs, pi_obs); UP(pichunk_lo, pichunk_lo); UP(pichunk_hi, pichunk_hi); UP(pi_chunk0, pi_chunk0); UP(pose_pi_start, pose_pi_start);
   UP(iobs, iobs); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
+  UP(intr_pichunk_start, intr_pichunk_start); UP(intr_pichunk, intr_pichunk);
   UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
   UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
   tick("small allocations + uploads");
@@ -2672,6 +2744,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(cn_pt, (size_t)d.n_pts * 3); AL(g_pt, (size_t)d.n_pts * 3); AL(scale_pt, (size_t)d.n_pts * 3); AL(diag_pt, (size_t)d.n_pts * 3);
   AL(pichunk_part, (size_t)d.n_pichunks * kPiGram); AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
   AL(igram_part, (size_t)d.n_igchunks * kIntrGram); AL(igram, (size_t)d.n_intr * kIntrGram);
+  AL(pichunk_ipart, (size_t)d.n_pichunks * kIntrGram);
   AL(Linv3, (size_t)d.n_pts * 6); AL(hp, (size_t)d.n_pts * 3);
   AL(Zpose, (size_t)no * 18); AL(Zint, (size_t)d.n_islots * 24);
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);

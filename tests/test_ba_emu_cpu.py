@@ -576,3 +576,24 @@ def test_model_cost_from_the_normal_equations_equals_the_jacobian_form(devices, 
     assert abs(a.final_cost - b.final_cost) <= 1e-11 * b.final_cost
     for x, y in zip(out["normal"][1], out["jacobian"][1]):
         assert np.allclose(x, y, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_cams=9, n_points=150, track_len=5, model=3, n_intr_groups=3, seed=141),
+    dict(n_cams=6, n_points=700, track_len=6, model=4, n_intr_groups=1, seed=142),     # 4 200 observations of one intrinsic: several chunks, odd tails
+])
+def test_gram_blocks_on_the_matrix_cores_equal_the_valu_form(kw, monkeypatch):
+    """Fc^T Fc, Fc^T Fi, Fi^T Fi and the gradients of a (pose, intrinsic) chunk as one F^T F on the f64 matrix cores
+    (ba_pi_gram_mfma_kernel, the intrinsic's blocks from the same pass) against the per-thread accumulation + separate intrinsic
+    pass (MVGX_BA_GRAM=valu): same LM trajectory, parameters equal to rounding"""
+    sc = synth.ba_scene(**kw)
+    sc = synth.add_pose_priors(sc, sigma=0.005, huber_a=2e-4)
+    opt = ba.default_options(max_num_iterations=4)
+    with _emu.emulated():
+        c = ba.BaContext(sc); s1 = c.solve(opt); p1 = c.read_params(); c.close()
+        monkeypatch.setenv("MVGX_BA_GRAM", "valu")
+        c = ba.BaContext(sc); s2 = c.solve(opt); p2 = c.read_params(); c.close()
+    assert s1.num_iterations == s2.num_iterations and abs(s1.final_cost - s2.final_cost) <= 1e-10 * s2.final_cost
+    assert abs(s1.initial_cost - s2.initial_cost) <= 1e-14 * s2.initial_cost
+    for x, y in zip(p1, p2):
+        assert np.allclose(x, y, rtol=1e-8, atol=1e-9)
