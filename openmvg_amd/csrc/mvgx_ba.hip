@@ -279,13 +279,35 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __r
 // ------------------------------------------------------------------------------------------------------
 // linearize: residual (+ Jacobian) per observation, weight, Huber loss correction, cost partial sums
 // ------------------------------------------------------------------------------------------------------
+// A wave's 64 records of SLOTS 16-byte slots each leave through LDS: every lane drops its record (padded stride: no bank
+// conflicts), then lane l stores slots l, l + 64, ... of the wave's contiguous block - 1 KiB per store instruction instead of
+// 64 partial lines (thread-per-record stores at a 64 / 128-byte stride cost four times their bytes in L2 write requests).
+template <int SLOTS>
+__device__ __forceinline__ void store_records_coalesced(double2* lds_wave /* 64 x (SLOTS + 1) */, const double2 (&v)[SLOTS], bool active,
+                                                        double2* __restrict__ wave_base, int n_valid) {
+  const int lane = threadIdx.x & 63;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) lds_wave[lane * (SLOTS + 1) + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = t * 64 + lane, rec = i / SLOTS, slot = i - rec * SLOTS;
+    if (rec < n_valid) wave_base[i] = lds_wave[rec * (SLOTS + 1) + slot];
+  }
+  __syncthreads();
+}
+
 template <bool kJac>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* __restrict__ poses,
                                                            const double* __restrict__ intr, const double* __restrict__ pts,
                                                            double* __restrict__ part /* gridDim x 2 */) {
   __shared__ double sh[4];
+  __shared__ double2 rec_lds[kJac ? 4 * 64 * 9 : 1];   // 36 KiB: the records of the four waves, one array at a time
   const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0, sq = 0;
+  double2 va[4], vb[8], vc[8];
   if (o < d.n_obs) {
     const uint32_t ip = d.opose[o], ii = d.ointr[o], ix = d.opt[o];
     double pin[8], pp[6], px[3], obs[2], r[2], Ji[16], Jc[12], Jp[6];
@@ -311,19 +333,26 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
       const double sr = corrector_scale(rho);
       const double sc = sr * w;
       const double r0 = r[0] * sr, r1 = r[1] * sr;
-      double2* __restrict__ a = reinterpret_cast<double2*>(d.JA + (size_t)o * kJA);
-      a[0] = make_double2(r0, r1);
+      va[0] = make_double2(r0, r1);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) a[1 + k] = make_double2(Jp[2 * k] * sc, Jp[2 * k + 1] * sc);
-      double2* __restrict__ b = reinterpret_cast<double2*>(d.JB + (size_t)o * kJB);
-      b[0] = make_double2(r0, r1);
+      for (int k = 0; k < 3; ++k) va[1 + k] = make_double2(Jp[2 * k] * sc, Jp[2 * k + 1] * sc);
+      vb[0] = make_double2(r0, r1);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) b[1 + k] = make_double2(Jc[2 * k] * sc, Jc[2 * k + 1] * sc);
-      b[7] = make_double2(0.0, 0.0);
-      double2* __restrict__ cc = reinterpret_cast<double2*>(d.JC + (size_t)o * kJC);
+      for (int k = 0; k < 6; ++k) vb[1 + k] = make_double2(Jc[2 * k] * sc, Jc[2 * k + 1] * sc);
+      vb[7] = make_double2(0.0, 0.0);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) cc[k] = make_double2(Ji[2 * k] * sc, Ji[2 * k + 1] * sc);
+      for (int k = 0; k < 8; ++k) vc[k] = make_double2(Ji[2 * k] * sc, Ji[2 * k + 1] * sc);
     }
+  }
+  if (kJac) {   // uniform: the three record arrays leave coalesced (see store_records_coalesced)
+    const int wave = threadIdx.x >> 6;
+    const uint64_t o0 = (uint64_t)blockIdx.x * blockDim.x + (uint64_t)wave * 64;   // first observation of the wave
+    const int n_valid = o0 >= d.n_obs ? 0 : (int)min<uint64_t>(64, d.n_obs - o0);
+    const bool active = o < d.n_obs;
+    double2* lw = rec_lds + wave * 64 * 9;
+    store_records_coalesced<4>(lw, va, active, reinterpret_cast<double2*>(d.JA + (size_t)o0 * kJA), n_valid);
+    store_records_coalesced<8>(lw, vb, active, reinterpret_cast<double2*>(d.JB + (size_t)o0 * kJB), n_valid);
+    store_records_coalesced<8>(lw, vc, active, reinterpret_cast<double2*>(d.JC + (size_t)o0 * kJC), n_valid);
   }
   const double c = block_sum(cost, sh);
   const double q = block_sum(sq, sh);
