@@ -107,7 +107,8 @@ constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points 
 constexpr int kGroupRS = MVGX_GROUP_RS;                           // doubles between columns in LDS, >= 3 kGroupPts and = 2 x odd (mod 32): the 16
                                                                   // columns x 2 rows a half wave reads as an MFMA operand then fall on distinct banks
 static_assert(kGroupRS >= 3 * kGroupPts + 2 && (kGroupRS % 4) == 2, "group tile layout");
-constexpr int kGroupLds = 64 * kGroupRS * (int)sizeof(double);
+constexpr int kGroupStageLds = kGroupPts * kGroupCams * 10 * 16;   // the group's Z records (9 slots + observation id) on their way to HBM
+constexpr int kGroupLds = 64 * kGroupRS * (int)sizeof(double) > kGroupStageLds ? 64 * kGroupRS * (int)sizeof(double) : kGroupStageLds;
 constexpr int kGroupMinPts = 8;                                   // smaller groups go to the flat list
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 struct GroupList {
@@ -829,10 +830,8 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
   }
 }
 __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G, const double* __restrict__ hp, double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [64 columns][kGroupRS]
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [64 columns][kGroupRS]; before that: the Z records in transit
   const int g = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
-  __syncthreads();
   // one observation per thread and turn: its 144-byte Z record arrives as nine independent 16-byte loads (neighbouring
   // lanes read neighbouring records: the observations of a point are contiguous), then 18 LDS stores
   const uint32_t e0 = G.obs_start[g], ne = G.obs_start[g + 1] - e0;
@@ -862,24 +861,43 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
     double Za[18], Zb[18];
     obs_z_math(aa, ba_, spa, lia, sca, Za);
     obs_z_math(ab, bb, spb, lib, scb, Zb);
+    // The Z records go to HBM through LDS: record e occupies ten 16-byte slots (nine of data, the observation id in the tenth),
+    // then consecutive threads store consecutive slots - the records of a point are contiguous in Z, so the stores are whole
+    // lines instead of 16 bytes at a 144-byte stride.
+    double2* st = reinterpret_cast<double2*>(lds);
     if (has_a) {
-      double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)oa * 18);
+#pragma unroll
+      for (int w = 0; w < 9; ++w) st[ea * 10 + w] = make_double2(Za[2 * w], Za[2 * w + 1]);
+      st[ea * 10 + 9] = make_double2(__hiloint2double(0, (int)oa), 0.0);
+    }
+    if (has_b) {
+#pragma unroll
+      for (int w = 0; w < 9; ++w) st[eb * 10 + w] = make_double2(Zb[2 * w], Zb[2 * w + 1]);
+      st[eb * 10 + 9] = make_double2(__hiloint2double(0, (int)ob), 0.0);
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < ne * 9; idx += 256) {
+      const uint32_t rec = idx / 9, slot = idx - rec * 9;
+      const uint32_t o = (uint32_t)__double2loint(st[rec * 10 + 9].x);
+      reinterpret_cast<double2*>(d.Zpose + (size_t)o * 18)[slot] = st[rec * 10 + slot];
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    if (has_a) {
       double* __restrict__ dst = lds + (6 * (qxa & 255u)) * kGroupRS + 3 * (qxa >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
         const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        zo[w] = make_double2(Za[2 * w], Za[2 * w + 1]);
         dst[cc * kGroupRS + k] = Za[2 * w];
         dst[(cc + 1) * kGroupRS + k] = Za[2 * w + 1];
       }
     }
     if (has_b) {
-      double2* __restrict__ zo = reinterpret_cast<double2*>(d.Zpose + (size_t)ob * 18);
       double* __restrict__ dst = lds + (6 * (qxb & 255u)) * kGroupRS + 3 * (qxb >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {
         const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        zo[w] = make_double2(Zb[2 * w], Zb[2 * w + 1]);
         dst[cc * kGroupRS + k] = Zb[2 * w];
         dst[(cc + 1) * kGroupRS + k] = Zb[2 * w + 1];
       }
