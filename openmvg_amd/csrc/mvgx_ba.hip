@@ -120,6 +120,7 @@ struct GroupList {
   uint32_t* obs_pose = nullptr;    // entry: pose of the observation
   uint32_t* ungrouped = nullptr;   // observations of the points outside every group (their Z comes from ba_obs_z_kernel)
   uint32_t n_ungrouped = 0;
+  int dbg = 0;   // MVGX_BA_GROUP_DEBUG (timing experiments, wrong results): 1 no Z stores, 2 no MFMA loop, 4 no partial-block stores, 8 no LDS scatter
   uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
   uint32_t* pts = nullptr;         // local point -> point
   uint32_t* chunk = nullptr;       // n_groups x kGroupPairs: row of tpp.part for local cameras (x <= y), kNoChunk: no common point
@@ -811,8 +812,9 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
 // tiles shared out over the four waves; every (local camera x, local camera y >= x) block and the rhs column are written
 // as one partial block of the pose x pose list (fixed slot, no atomics), summed per destination by ba_schur_assemble.
 __device__ __forceinline__ int group_pair_index(int x, int y) { return x * kGroupCams - x * (x - 1) / 2 + (y - x); }
-__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, const uint32_t* __restrict__ chunk, double* __restrict__ part,
-                                                 int li, int lk) {
+// A finished 16 x 16 tile of the group's Z^T Z goes to LDS as partial blocks: out[pair (x <= y)][42] = 6 x 6 block (+ the rhs
+// for x == y from the h column); the blocks then leave as contiguous 336-byte runs (ba_schur_group_kernel's last loop).
+__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk) {
   const int J = 16 * tj + li;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
@@ -820,12 +822,10 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
     if (I >= 6 * kGroupCams || J > 6 * kGroupCams || I > J) continue;
     const int x = I / 6, r = I - 6 * x;
     if (J == 6 * kGroupCams) {   // column of h_p: the rhs of camera x
-      const uint32_t ch = chunk[group_pair_index(x, x)];
-      if (ch != kNoChunk) part[(size_t)ch * 42 + 36 + r] = acc[reg];
+      out[group_pair_index(x, x) * 42 + 36 + r] = acc[reg];
     } else {
       const int y = J / 6, c = J - 6 * y;
-      const uint32_t ch = chunk[group_pair_index(x, y)];
-      if (ch != kNoChunk) part[(size_t)ch * 42 + r * 6 + c] = acc[reg];
+      out[group_pair_index(x, y) * 42 + r * 6 + c] = acc[reg];
     }
   }
 }
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
       st[eb * 10 + 9] = make_double2(__hiloint2double(0, (int)ob), 0.0);
     }
     __syncthreads();
-    for (uint32_t idx = tid; idx < ne * 9; idx += 256) {
+    for (uint32_t idx = tid; idx < ne * 9 && !(G.dbg & 1); idx += 256) {
       const uint32_t rec = idx / 9, slot = idx - rec * 9;
       const uint32_t o = (uint32_t)__double2loint(st[rec * 10 + 9].x);
       reinterpret_cast<double2*>(d.Zpose + (size_t)o * 18)[slot] = st[rec * 10 + slot];
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
     __syncthreads();
     for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
     __syncthreads();
-    if (has_a) {
+    if (has_a && !(G.dbg & 8)) {
       double* __restrict__ dst = lds + (6 * (qxa & 255u)) * kGroupRS + 3 * (qxa >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
         dst[(cc + 1) * kGroupRS + k] = Za[2 * w + 1];
       }
     }
-    if (has_b) {
+    if (has_b && !(G.dbg & 8)) {
       double* __restrict__ dst = lds + (6 * (qxb & 255u)) * kGroupRS + 3 * (qxb >> 8);
 #pragma unroll
       for (int w = 0; w < 9; ++w) {
@@ -906,13 +906,14 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
   if ((uint32_t)tid < np * 3) lds[(6 * kGroupCams) * kGroupRS + tid] = hv;
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int rows = (int)(3 * np + 3) & ~3;
+  const int rows = (G.dbg & 2) ? 0 : ((int)(3 * np + 3) & ~3);
   const double* __restrict__ col0 = lds + (0 * 16 + li) * kGroupRS + lk;
   const double* __restrict__ col1 = lds + (1 * 16 + li) * kGroupRS + lk;
   const double* __restrict__ col2 = lds + (2 * 16 + li) * kGroupRS + lk;
   const double* __restrict__ col3 = lds + (3 * 16 + li) * kGroupRS + lk;
   d4_t a0 = d4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
   const uint32_t* __restrict__ chunk = G.chunk + (size_t)g * kGroupPairs;
+  double* out = lds;   // kGroupPairs x 42 doubles: the operand matrix is overwritten once every wave is through its MFMA loop
   // tiles (ti, tj), ti <= tj: wave 0: (0,0) (0,1) (0,2); wave 1: (0,3) (1,1) (1,2); wave 2: (1,3) (2,2); wave 3: (2,3) (3,3)
   if (wave == 0) {
     for (int k0 = 0; k0 < rows; k0 += 4) {
@@ -921,7 +922,6 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
       a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, a1, 0, 0, 0);
       a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f2, a2, 0, 0, 0);
     }
-    group_store_tile(a0, 0, 0, chunk, part, li, lk); group_store_tile(a1, 0, 1, chunk, part, li, lk); group_store_tile(a2, 0, 2, chunk, part, li, lk);
   } else if (wave == 1) {
     for (int k0 = 0; k0 < rows; k0 += 4) {
       const double f0 = col0[k0], f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
@@ -929,21 +929,31 @@ __global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G,
       a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, a1, 0, 0, 0);
       a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f2, a2, 0, 0, 0);
     }
-    group_store_tile(a0, 0, 3, chunk, part, li, lk); group_store_tile(a1, 1, 1, chunk, part, li, lk); group_store_tile(a2, 1, 2, chunk, part, li, lk);
   } else if (wave == 2) {
     for (int k0 = 0; k0 < rows; k0 += 4) {
       const double f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
       a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f3, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, a1, 0, 0, 0);
     }
-    group_store_tile(a0, 1, 3, chunk, part, li, lk); group_store_tile(a1, 2, 2, chunk, part, li, lk);
   } else {
     for (int k0 = 0; k0 < rows; k0 += 4) {
       const double f2 = col2[k0], f3 = col3[k0];
       a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f3, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f3, f3, a1, 0, 0, 0);
     }
-    group_store_tile(a0, 2, 3, chunk, part, li, lk); group_store_tile(a1, 3, 3, chunk, part, li, lk);
+  }
+  __syncthreads();   // all operand reads are done: the region now takes the partial blocks
+  if (wave == 0) { group_store_tile(a0, 0, 0, out, li, lk); group_store_tile(a1, 0, 1, out, li, lk); group_store_tile(a2, 0, 2, out, li, lk); }
+  else if (wave == 1) { group_store_tile(a0, 0, 3, out, li, lk); group_store_tile(a1, 1, 1, out, li, lk); group_store_tile(a2, 1, 2, out, li, lk); }
+  else if (wave == 2) { group_store_tile(a0, 1, 3, out, li, lk); group_store_tile(a1, 2, 2, out, li, lk); }
+  else { group_store_tile(a0, 2, 3, out, li, lk); group_store_tile(a1, 3, 3, out, li, lk); }
+  __syncthreads();
+  // the blocks leave as contiguous runs of 42 doubles (elements a block does not define - the rhs of an off-diagonal block, the
+  // lower triangle of a diagonal one - carry whatever the region held: ba_schur_assemble never uses them)
+  for (int idx = tid; idx < kGroupPairs * 42 && !(G.dbg & 4); idx += 256) {
+    const int pair = idx / 42;
+    const uint32_t ch = chunk[pair];
+    if (ch != kNoChunk) part[(size_t)ch * 42 + (idx - pair * 42)] = out[idx];
   }
 }
 
@@ -2825,6 +2835,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if ((rc = dev_alloc(c->pool, &l.part, ((size_t)l.n_chunks + l.n_ext) * e.nv))) return rc;
     }
     d.grp.n_groups = n_groups;
+    if (const char* env = getenv("MVGX_BA_GROUP_DEBUG")) d.grp.dbg = atoi(env);
     c->n_grouped_points = (uint32_t)g_pts.size();
     if (n_groups) {
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
