@@ -1058,7 +1058,7 @@ __global__ void ba_pack_fail_kernel(Dev d) { d.scalars[kSFail] = (double)*d.fail
 // ------------------------------------------------------------------------------------------------------
 constexpr int kLS = 65;    // LDS row stride of the 64 x 64 factor / inverse
 constexpr int kTS = 80;    // LDS row stride of a k-major 64-wide MFMA operand tile (rows k, k+1 land 32 banks apart)
-constexpr int kDiagLds = (2 * 64 * kLS + 64 * 17 + 64) * (int)sizeof(double);
+constexpr int kDiagLds = (2 * 64 * kLS + 128 * 17 + 64 + 8) * (int)sizeof(double);
 
 __device__ __forceinline__ double fast_rcp(double x) {   // v_rcp_f64 + two Newton steps (full precision for finite x > 0)
   double r = __builtin_amdgcn_rcp(x);
@@ -1074,21 +1074,118 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {   // sr
   return __hiloint2double(hi, lo);
 }
 
+// Pieces of the in-LDS inverse of a 64 x 64 Cholesky factor (chol_diag_inv_body). All are executed by ONE wave.
+// LDS writes of a wave followed by reads of other lanes of the SAME wave: no s_barrier needed (a wave's LDS operations
+// complete in order), only the compiler has to keep the order.
+__device__ __forceinline__ void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// acc + X Y for 16 x 16 blocks in LDS arrays of row stride kLS: X[i][k] = Xp[i * kLS + k], Y[k][j] = Yp[k * kLS + j];
+// the result element (lk + 4 reg, li) is in acc[reg] of lane (li, lk)
+__device__ __forceinline__ d4_t block_mma(const double* Xp, const double* Yp, d4_t acc, int li, int lk) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xp[li * kLS + 4 * ks + lk], Yp[(4 * ks + lk) * kLS + li], acc, 0, 0, 0);
+  return acc;
+}
+// the same with Y in a wave-private scratch block of row stride 17
+__device__ __forceinline__ d4_t block_mma_t(const double* Xp, const double (*Y)[17], d4_t acc, int li, int lk) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xp[li * kLS + 4 * ks + lk], Y[4 * ks + lk][li], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void block_store(double* d, int stride, d4_t v, double scale, int li, int lk) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) d[(lk + 4 * reg) * stride + li] = scale * v[reg];
+}
+// inverse of the lower-triangular 16 x 16 diagonal block at b0 by forward substitution, one column per lane (16 lanes);
+// rd[r] = 1 / L[r][r]
+__device__ __forceinline__ void diag_block_inverse(const double (*L)[kLS], double (*Li)[kLS], const double* rd, int b0, int lane) {
+  if (lane < 16) {
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) v -= L[b0 + r][b0 + q] * x[q];
+      x[r] = v * rd[b0 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Li[b0 + r][b0 + lane] = x[r];
+  }
+}
+
+// One step of the blocked inverse, executed by a whole wave with wave-uniform parameters (scalar control flow only):
+//   acc = [nothing | the wave's scratch block S0 | scratch block 1 of wave `from`] + sum_{p < np} L[I][K0 + p] Linv[K0 + p][J]
+//   out 0 / 1: acc is left in the wave's scratch block S0 / S1;   out 2: Linv[I][J] = -Linv[I][I] acc
+struct InvTask { int I, J, K0, np, init /* 0 zero, 1 own S0, 2 S1 of wave 2 */, out; };
+// [slot: panel 2, panel 3, after the loop round A, round B][wave][step]; I < 0: idle
+__device__ const InvTask kInvSchedule[4][4][2] = {
+  // while panel 2 is factored (final: L columns 0..31, Linv00 from the slot before)
+  {{{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}}, {{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}},
+   {{1, 0, 0, 1, 0, 0}, {-1, 0, 0, 0, 0, 0}},                                  // wave 2: S0 = L10 Linv00
+   {{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}}},
+  // while panel 3 is factored (final: L columns 0..47, Linv11)
+  {{{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}}, {{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}},
+   {{1, 0, 0, 0, 1, 2}, {-1, 0, 0, 0, 0, 0}},                                  // wave 2: Linv10 = -Linv11 S0
+   {{2, 1, 1, 1, 0, 0}, {-1, 0, 0, 0, 0, 0}}},                                 // wave 3: S0 = L21 Linv11
+  // round A (final: L, all diagonal blocks of Linv, Linv10)
+  {{{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}},
+   {{2, 0, 0, 2, 0, 2}, {-1, 0, 0, 0, 0, 0}},                                  // wave 1: Linv20 = -Linv22 (L20 Linv00 + L21 Linv10)
+   {{3, 0, 0, 2, 0, 1}, {3, 1, 1, 1, 0, 0}},                                   // wave 2: S1 = L30 Linv00 + L31 Linv10, S0 = L31 Linv11
+   {{2, 1, 0, 0, 1, 2}, {3, 2, 2, 1, 0, 0}}},                                  // wave 3: Linv21 = -Linv22 S0, then S0 = L32 Linv22
+  // round B: block row 3
+  {{{-1, 0, 0, 0, 0, 0}, {-1, 0, 0, 0, 0, 0}},
+   {{3, 0, 2, 1, 2, 2}, {-1, 0, 0, 0, 0, 0}},                                  // wave 1: Linv30 = -Linv33 (S1 of wave 2 + L32 Linv20)
+   {{3, 1, 2, 1, 1, 2}, {-1, 0, 0, 0, 0, 0}},                                  // wave 2: Linv31 = -Linv33 (S0 + L32 Linv21)
+   {{3, 2, 0, 0, 1, 2}, {-1, 0, 0, 0, 0, 0}}},                                 // wave 3: Linv32 = -Linv33 S0
+};
+__device__ __forceinline__ void inverse_task(const double (*L)[kLS], double (*Li)[kLS], double (*Tmp)[17], double (*S0)[17],
+                                             const InvTask t, int li, int lk) {
+  if (t.I < 0) return;
+  d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+  if (t.init) {
+    const double (*src)[17] = t.init == 1 ? S0 : Tmp + 32 * 2 + 16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[reg] = src[lk + 4 * reg][li];
+  }
+  for (int p = 0; p < t.np; ++p) acc = block_mma(&L[16 * t.I][16 * (t.K0 + p)], &Li[16 * (t.K0 + p)][16 * t.J], acc, li, lk);
+  if (t.out < 2) {
+    block_store(&S0[16 * t.out][0], 17, acc, 1.0, li, lk);
+    return;
+  }
+  if (t.np > 0 || t.init != 1) {   // otherwise S0 already holds acc
+    lds_wave_sync();               // all lanes have read S0 before it is overwritten
+    block_store(&S0[0][0], 17, acc, 1.0, li, lk);
+  }
+  lds_wave_sync();
+  block_store(&Li[16 * t.I][16 * t.J], kLS, block_mma_t(&Li[16 * t.I][16 * t.I], S0, d4_t{0.0, 0.0, 0.0, 0.0}, li, lk), -1.0, li, lk);
+}
+
 // Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
 // processed as four 64 x 16 column panels: a register-resident panel factorisation by one wave, then a rank-16 update
-// of the remaining columns by all four. The inverse is built from the 16 x 16 diagonal blocks outwards.
+// of the remaining columns by all four. The inverse is built block by block (16 x 16) by the three waves the panel
+// factorisation leaves idle.
 // kDense: the factor goes back into A and the inverse is stored twice (k-major for the panel GEMM, row-major for the
 // back substitution); otherwise (block-sparse solver) only the k-major inverse is kept.
+// MVGX_BA_FACTOR_DEBUG=1: shader-clock stamps of the phases of the factor-and-invert kernel (workgroup 0), printed at destroy
+__device__ long long g_factor_stamps[12];
+__device__ int g_factor_debug;
+#define MVGX_STAMP(i) do { if (stamping) g_factor_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 template <bool kDense>
 __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int ld, int k0, int kb,
                                                    double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail,
                                                    double* lds) {
   double (*L)[kLS] = reinterpret_cast<double (*)[kLS]>(lds);
   double (*Li)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 64 * kLS);
-  double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);
-  double (*col)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 2 * 64 * kLS);   // aliases Tmp: 16 pivot columns of the panel
-  double* rd = lds + 2 * 64 * kLS + 64 * 17;                                      // 1 / L[r][r]
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);     // two 16 x 16 scratch blocks per wave
+  double* rd = lds + 2 * 64 * kLS + 128 * 17;                                     // 1 / L[r][r]
+  double* flag = rd + 64;
+  const int tid = threadIdx.x;
+  const bool stamping = g_factor_debug && blockIdx.x == 0 && tid == 0;   // read once: one global load, not one per stamp
+  MVGX_STAMP(0);
   {
     // all 16 loads of a thread are issued before the first LDS store: as a rolled loop every element paid a full memory
     // round trip (the compiler keeps load -> wait -> store per iteration), ~11 of the kernel's 25 microseconds
@@ -1108,9 +1205,18 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
     }
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
+  MVGX_STAMP(1);
+  // the wave index as a scalar: everything wave-dependent below is a scalar branch or a table lookup, no exec-masked regions
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  // The inverse of the factor, Linv[I][J] = -Linv[I][I] sum_{K=J}^{I-1} L[I][K] Linv[K][J] over 16 x 16 blocks, is built by waves
+  // 1..3 WHILE wave 0 factors the next panel (the panel chain is serial and one wave wide): a piece is scheduled into the first
+  // panel slot in which its inputs are final (kInvSchedule), so that only the last block row is left for after the loop.
+  // Products run on the f64 matrix core with operands read from LDS; a wave keeps partial sums in two private 16 x 16 blocks.
+  double (*T0)[17] = Tmp + 32 * wave;
+#pragma unroll
   for (int jb = 0; jb < 4; ++jb) {
     const int j0 = jb * 16;
+    MVGX_STAMP(2 + jb);
     // Panel of 16 columns, factored by wave 0 alone with lane = row and the row's 16 panel entries in registers: the pivot
     // column reaches the other lanes through v_readlane (scalar operands), so the 16 pivots cost neither LDS traffic nor
     // barriers. Right-looking on UNscaled columns: a_rt -= (a_rj / d_j) a_pt for t > j, p = j0 + j; the 1 / sqrt(d)
@@ -1124,27 +1230,44 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double dj = readlane_f64(a[j], j0 + j);
+        // the column entries a(j0 + t, j) are all fetched (into scalar registers) BEFORE the multiplier is known: fetched one
+        // at a time in front of their FMA, each step paid the VALU -> SGPR -> VALU round trip of the single resident wave
+        double cj[16];
+#pragma unroll
+        for (int t = j + 1; t < 16; ++t) cj[t] = readlane_f64(a[j], j0 + t);   // lower triangle
         ok = ok && (dj > 0.0) && isfinite(dj);
         const double dsafe = ok ? dj : 1.0;
         if (lane == j) dmine = dsafe;
         const double lj = a[j] * fast_rcp(dsafe);
 #pragma unroll
-        for (int t = j + 1; t < 16; ++t) a[t] -= lj * readlane_f64(a[j], j0 + t);   // a(j0 + t, j): lower triangle
+        for (int t = j + 1; t < 16; ++t) a[t] -= lj * cj[t];
       }
       const double rsm = 1.0 / sqrt(dmine);
-      if (lane == 0) col[0][0] = ok ? 1.0 : -1.0;   // flag for the uniform exit below
+      if (lane == 0) flag[0] = ok ? 1.0 : -1.0;   // for the uniform exit below
+      if (lane < 16) rd[j0 + lane] = rsm;          // 1 / L[r][r]
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const double rst = readlane_f64(rsm, t);   // wave collective: outside the lane-dependent select
         L[lane][j0 + t] = (lane >= j0 + t) ? a[t] * rst : 0.0;
       }
+      if (jb == 3) {   // the last diagonal block is inverted by the wave that produced it
+        lds_wave_sync();
+        diag_block_inverse(L, Li, rd, 48, lane);
+      }
+    } else if (jb >= 1) {
+      if (wave == 1) diag_block_inverse(L, Li, rd, 16 * (jb - 1), lane);
+      if (jb >= 2) {
+        inverse_task(L, Li, Tmp, T0, kInvSchedule[jb - 2][wave][0], li, lk);
+        inverse_task(L, Li, Tmp, T0, kInvSchedule[jb - 2][wave][1], li, lk);
+      }
     }
     __syncthreads();
-    if (!(col[0][0] > 0.0)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform: not positive definite
+    if (!(flag[0] > 0.0)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform: not positive definite
+    if (jb == 3) break;
     // rank-16 update of the columns right of the panel, one 16 x 16 block (I, J), I >= J > jb, per wave and turn:
     // D = P_I P_J^T with P_X = L[16 X .. 16 X + 15][j0 .. j0 + 15] on the f64 matrix core (4 k-steps of 4)
     {
-      const int li = lane & 15, lk = lane >> 4, nbk = 3 - jb, ntile = nbk * (nbk + 1) / 2;
+      const int nbk = 3 - jb, ntile = nbk * (nbk + 1) / 2;
       for (int tile = wave; tile < ntile; tile += 4) {
         int bi = 0, bj = tile;
         while (bj > bi) { bj -= bi + 1; ++bi; }
@@ -1159,49 +1282,22 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
     }
     __syncthreads();
   }
-  // inverse of the factor: 16 x 16 diagonal blocks by forward substitution (one column per thread) ...
-  if (tid < 64) rd[tid] = 1.0 / L[tid][tid];
+  MVGX_STAMP(6);
+  // what is left: block rows 2 (columns 0, 1) and 3, in two rounds
+  inverse_task(L, Li, Tmp, T0, kInvSchedule[2][wave][0], li, lk);
+  inverse_task(L, Li, Tmp, T0, kInvSchedule[2][wave][1], li, lk);
   __syncthreads();
-  if (tid < 64) {
-    const int b0 = (tid >> 4) * 16, c = tid & 15;
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int q = 0; q < r; ++q) v -= L[b0 + r][b0 + q] * x[q];
-      x[r] = v * rd[b0 + r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Li[b0 + r][b0 + c] = x[r];
-  }
+  MVGX_STAMP(7);
+  inverse_task(L, Li, Tmp, T0, kInvSchedule[3][wave][0], li, lk);
   __syncthreads();
-  // ... then the blocks below the diagonal, by block distance: Linv[I][J] = -Linv[I][I] sum_{K=J}^{I-1} L[I][K] Linv[K][J]
-  for (int dist = 1; dist < 4; ++dist) {
-    for (int I = dist; I < 4; ++I) {
-      const int Jb = I - dist;
-      double v = 0;
-      for (int K = Jb; K < I; ++K)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v += L[16 * I + ty][16 * K + q] * Li[16 * K + q][16 * Jb + tx];
-      Tmp[16 * I + ty][tx] = v;
-    }
-    __syncthreads();
-    for (int I = dist; I < 4; ++I) {
-      const int Jb = I - dist;
-      double v = 0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += Li[16 * I + ty][16 * I + q] * Tmp[16 * I + q][tx];
-      Li[16 * I + ty][16 * Jb + tx] = -v;
-    }
-    __syncthreads();
-  }
+  MVGX_STAMP(8);
   for (int q = tid; q < 4096; q += 256) {
     const int c = q >> 6, r = q & 63;
     if (kDense && r < kb && c < kb && r >= c) A[(size_t)(k0 + c) * ld + (k0 + r)] = L[r][c];
     linv[q] = Li[r][c];                  // k-major: linv[k = c][col = r] = Linv[r][c]
     if (kDense) linv[4096 + q] = Li[q >> 6][q & 63]; // row-major
   }
+  MVGX_STAMP(9);
 }
 __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__ A, int ld, int k0, int kb, double* __restrict__ linv, int* fail) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2460,6 +2556,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.huber_a = p->huber_a;
   d.prior_huber_a = p->prior_huber_a;
   c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
+  if (getenv("MVGX_BA_FACTOR_DEBUG")) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_factor_debug), &one, sizeof(one)); }
   if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
   if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
@@ -2885,6 +2982,12 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (getenv("MVGX_BA_FACTOR_DEBUG")) {
+    long long st[12];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_factor_stamps), sizeof(st)) == hipSuccess)
+      fprintf(stderr, "[mvgx factor kernel, shader clocks] load %lld | panels (+ overlapped inverse) %lld %lld %lld %lld | inverse tail A %lld | tail B %lld | store %lld | total %lld\n",
+              st[1] - st[0], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[9] - st[0]);
+  }
   c->pool.release();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
@@ -2894,6 +2997,28 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   mvgx::rccl_destroy(c->rccl);
   delete c;
+  return MVGX_OK;
+}
+
+// Test hook (not declared in include/mvgx.h): factor-and-invert one kb x kb block (kb <= 64) with the kernel of the dense
+// solver. a: column-major 64 x 64, lower triangle read; l_out: 64 x 64 column-major factor; linv_out: 2 x 4096 doubles as the
+// kernel stores them ([k][c] = Linv[c][k], then row-major).
+int mvgx_debug_factor64(const double* a, int kb, double* l_out, double* linv_out) {
+  MVGX_REQUIRE(a && l_out && linv_out && kb > 0 && kb <= 64, MVGX_ERR_ARG, "mvgx_debug_factor64: bad argument");
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
+  double *dA = nullptr, *dLi = nullptr; int* dfail = nullptr; int fail = 0;
+  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&dA), 4096 * sizeof(double)));
+  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&dLi), 8192 * sizeof(double)));
+  MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&dfail), sizeof(int)));
+  MVGX_HIP(hipMemcpy(dA, a, 4096 * sizeof(double), hipMemcpyHostToDevice));
+  MVGX_HIP(hipMemset(dfail, 0, sizeof(int)));
+  hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(256), kDiagLds, 0, dA, 64, 0, kb, dLi, dfail);
+  MVGX_HIP(hipStreamSynchronize(0));
+  MVGX_HIP(hipMemcpy(l_out, dA, 4096 * sizeof(double), hipMemcpyDeviceToHost));
+  MVGX_HIP(hipMemcpy(linv_out, dLi, 8192 * sizeof(double), hipMemcpyDeviceToHost));
+  MVGX_HIP(hipMemcpy(&fail, dfail, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dLi); (void)hipFree(dfail);
+  MVGX_REQUIRE(fail == 0, MVGX_ERR_NUMERIC, "mvgx_debug_factor64: not positive definite");
   return MVGX_OK;
 }
 

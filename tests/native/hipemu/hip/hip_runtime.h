@@ -118,6 +118,13 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+#define HIP_SYMBOL(x) (x)
+template <class T> static inline hipError_t hipMemcpyFromSymbol(void* dst, const T& sym, size_t n) { memcpy(dst, &sym, n); return hipSuccess; }
+template <class T> static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy(&sym, src, n); return hipSuccess; }
+static inline long long __builtin_amdgcn_s_memtime() { return 0; }
+// a wave's lanes are separate fibers here: the compiler-only wave barrier of the hardware must really wait for all lanes
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::readlane_i32(0, 0))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 // failure injection for the error paths: HIPEMU_FAIL_MALLOC_AFTER=n makes the (n+1)-th and later device allocations fail

@@ -597,3 +597,9 @@ def test_gram_blocks_on_the_matrix_cores_equal_the_valu_form(kw, monkeypatch):
     assert abs(s1.initial_cost - s2.initial_cost) <= 1e-14 * s2.initial_cost
     for x, y in zip(p1, p2):
         assert np.allclose(x, y, rtol=1e-8, atol=1e-9)
+
+
+def test_factor_and_invert_kernel_against_numpy():
+    """the 64 x 64 Cholesky + inverse workgroup kernel under the emulation: full, partial (identity-padded) and tiny blocks"""
+    from tests import _factor64
+    _factor64.check_factor64(_emu.handle())

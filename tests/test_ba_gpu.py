@@ -378,3 +378,10 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert np.allclose(pg, pf, atol=1e-8) and np.allclose(ig, if_, rtol=1e-8, atol=1e-8) and np.allclose(xg, xf, atol=1e-7)
     rc, osum, *_ = _oracle.port_ba_solve(sc)
     assert s_g.num_iterations == osum.num_iterations and abs(s_g.final_rmse - osum.final_rmse) < RMSE_TOL
+
+
+def test_factor_and_invert_kernel_against_numpy():
+    """the 64 x 64 Cholesky + inverse workgroup kernel (panel chain on one wave, blocked inverse on the other three) on its own:
+    full, partial (identity-padded) and tiny blocks"""
+    from tests import _factor64
+    _factor64.check_factor64(_capi.lib())
