@@ -260,18 +260,19 @@ __device__ __forceinline__ double* sys_elem(const Dev& d, int row, int col) {
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ part, int n, int stride, int nk,
                                                                double* __restrict__ out, int out_off, int is_max) {
   __shared__ double sh[16];
-  const int per = (n + 1023) / 1024, lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+  // thread t takes rows t, t + 1024, ...: neighbouring lanes read neighbouring rows (a run of consecutive rows per thread made
+  // every load a separate line; 25 microseconds for the 20 000 partials of C5), eight loads in flight
   for (int k = 0; k < nk; ++k) {
     double v = 0;
-    int i = lo;
-    for (; i + 8 <= hi; i += 8) {
+    int i = (int)threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
       double t[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t[q] = part[(size_t)(i + q) * stride + k];
+      for (int q = 0; q < 8; ++q) t[q] = part[(size_t)(i + q * 1024) * stride + k];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v = is_max ? fmax(v, t[q]) : v + t[q];
     }
-    for (; i < hi; ++i) { const double t = part[(size_t)i * stride + k]; v = is_max ? fmax(v, t) : v + t; }
+    for (; i < n; i += 1024) { const double t = part[(size_t)i * stride + k]; v = is_max ? fmax(v, t) : v + t; }
     const double t = is_max ? block_max(v, sh) : block_sum(v, sh);
     if (threadIdx.x == 0) out[out_off + k] = t;
     __syncthreads();
@@ -612,7 +613,19 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   if (t < kIntrGram) {
     double v = 0;
     if (d.gram_mfma) {
-      for (uint32_t q = d.intr_pichunk_start[k] + g; q < d.intr_pichunk_start[k + 1]; q += 16) v += d.pichunk_ipart[(size_t)d.intr_pichunk[q] * kIntrGram + t];
+      // eight (index, value) loads in flight, added in list order: one at a time this was a chain of dependent round trips
+      // (73 microseconds for the 4 000 chunks of one intrinsic group)
+      const uint32_t q1 = d.intr_pichunk_start[k + 1];
+      for (uint32_t q = d.intr_pichunk_start[k] + g; q < q1; q += 128) {
+        uint32_t id[8];
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) id[j] = d.intr_pichunk[min(q + 16 * j, q1 - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = d.pichunk_ipart[(size_t)id[j] * kIntrGram + t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += (q + 16 * j < q1) ? x[j] : 0.0;
+      }
     } else {
       for (uint32_t ch = d.igchunk_start[k] + g; ch < d.igchunk_start[k + 1]; ch += 16) v += d.igram_part[(size_t)ch * kIntrGram + t];
     }
@@ -969,7 +982,19 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
   const bool diag = rcb == ccb;
   if (e >= WA * WB && !diag) return;
   double sum = 0;
-  for (uint32_t ch = L.block_chunk0[b]; ch < L.block_chunk0[b + 1]; ++ch) sum += L.part[(size_t)ch * NV + e];
+  {   // eight loads in flight, added in list order
+    const uint32_t c1 = L.block_chunk0[b + 1];
+    uint32_t ch = L.block_chunk0[b];
+    const double* __restrict__ q = L.part + e;
+    for (; ch + 8 <= c1; ch += 8) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = q[(size_t)(ch + j) * NV];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; ch < c1; ++ch) sum += q[(size_t)ch * NV];
+  }
   if (KIND == 0 && L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
     const uint32_t x1 = L.block_ext0[b + 1];
     uint32_t x = L.block_ext0[b];
@@ -1939,7 +1964,7 @@ struct mvgx_ba_ctx {
   Dev d;
   mvgx::Arena pool;                    // every device allocation (slabs go back to the process-wide cache in destroy)
   double* h_scalars = nullptr;         // pinned
-  int* h_fail = nullptr;               // pinned
+  int* h_fail = nullptr;               // the slot after h_scalars
   mvgx_allreduce_f64 allreduce = nullptr;
   void* allreduce_user = nullptr;
   mvgx::RcclComm* rccl = nullptr;
@@ -1977,8 +2002,7 @@ namespace {
 #define BA_LAUNCH_CHECK() MVGX_HIP(hipGetLastError())
 
 int read_scalars(mvgx_ba_ctx* c) {
-  MVGX_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, kSCount * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  MVGX_HIP(hipMemcpyAsync(c->h_fail, c->d.fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, (kSCount + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   return MVGX_OK;
 }
@@ -2308,6 +2332,23 @@ int exchange_system(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
+// x + delta and its cost, enqueued behind the step that produced delta WITHOUT waiting for the step's verdict: an invalid step
+// (failed factorisation, non-positive model cost change) is rare and only wastes these launches - the candidate arrays and
+// scalars they write are not read in that case - while every valid step saves one host round trip per iteration.
+int enqueue_candidate_and_cost(mvgx_ba_ctx* c) {
+  Dev& d = c->d;
+  phase_begin(c);
+  // the kernel writes EVERY entry of the three candidate arrays (x + 0 for constant parameters): no copy of x beforehand
+  hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 4, 4, d.scalars, kSCamStepSq, 0);
+  BA_LAUNCH_CHECK();
+  int rc = all_reduce(c, d.scalars + kSStepSq, 2);   // point parts
+  if (rc) return rc;
+  if ((rc = eval<false>(c, d.cposes, d.cintr, d.cpts))) return rc;
+  phase_end(c, kPhCost);
+  return MVGX_OK;
+}
+
 // LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver::SolveImpl. ok=false <=> LINEAR_SOLVER_FAILURE.
 int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   Dev& d = c->d;
@@ -2343,6 +2384,7 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     if ((rc = all_reduce(c, d.scalars + kSFail, 1, MVGX_REDUCE_MAX))) return rc;
   }
   phase_end(c, kPhBacksub);
+  if ((rc = enqueue_candidate_and_cost(c))) return rc;
   if ((rc = read_scalars(c))) return rc;
   *model_cost_change = c->model_cost_from_jacobian ? c->h_scalars[kSModel] : c->h_scalars[kSModelPt] + c->h_scalars[kSModelCam];
   const bool failed = multi_rank(c) ? (c->h_scalars[kSFail] != 0.0) : (*c->h_fail != 0);
@@ -2350,30 +2392,18 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   return MVGX_OK;
 }
 
-int make_candidate_and_cost(mvgx_ba_ctx* c, double* step_norm, double* x_norm, double* cand_cost) {
-  Dev& d = c->d;
-  phase_begin(c);
-  MVGX_HIP(hipMemcpyAsync(d.cposes, d.poses, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  MVGX_HIP(hipMemcpyAsync(d.cintr, d.intr, (size_t)d.n_intr * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 4, 4, d.scalars, kSCamStepSq, 0);
-  BA_LAUNCH_CHECK();
-  int rc = all_reduce(c, d.scalars + kSStepSq, 2);   // point parts
-  if (rc) return rc;
-  if ((rc = eval<false>(c, d.cposes, d.cintr, d.cpts))) return rc;
-  phase_end(c, kPhCost);
-  if ((rc = read_scalars(c))) return rc;
+// step and parameter norms and the candidate's cost, from the scalars compute_step fetched
+void candidate_results(const mvgx_ba_ctx* c, double* step_norm, double* x_norm, double* cand_cost) {
   *step_norm = std::sqrt(c->h_scalars[kSCamStepSq] + c->h_scalars[kSStepSq]);
   *x_norm = std::sqrt(c->h_scalars[kSCamXSq] + c->h_scalars[kSXSq]);
   *cand_cost = c->h_scalars[kSCost];
-  return MVGX_OK;
 }
 
 int accept_candidate(mvgx_ba_ctx* c) {
-  Dev& d = c->d;
-  MVGX_HIP(hipMemcpyAsync(d.poses, d.cposes, (size_t)d.n_poses * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  MVGX_HIP(hipMemcpyAsync(d.intr, d.cintr, (size_t)d.n_intr * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  MVGX_HIP(hipMemcpyAsync(d.pts, d.cpts, (size_t)d.n_pts * 3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  Dev& d = c->d;   // passed by value to every launch: exchanging the pointers here is the whole acceptance, nothing is copied
+  std::swap(d.poses, d.cposes);
+  std::swap(d.intr, d.cintr);
+  std::swap(d.pts, d.cpts);
   return MVGX_OK;
 }
 
@@ -2434,7 +2464,7 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   }
   c->invalid = 0;
   double step_norm, x_norm, cand;
-  if ((rc = make_candidate_and_cost(c, &step_norm, &x_norm, &cand))) return rc;
+  candidate_results(c, &step_norm, &x_norm, &cand);
   if (!c->x_norm_valid) x_norm = -1.0;  // Init() leaves x_norm_ = -1 until the first accepted step
   if (opt->verbose)
     fprintf(stderr, "[mvgx ba] it %d cost %.9e cand %.9e model %.6e radius %.3e |step| %.3e\n", c->iteration, c->x_cost, cand,
@@ -2548,8 +2578,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
-  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), kSCount * sizeof(double), hipHostMallocDefault));
-  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_fail), sizeof(int), hipHostMallocDefault));
+  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 1) * sizeof(double), hipHostMallocDefault));
+  c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
   d.n_poses = p->n_poses; d.n_intr = p->n_intrinsics; d.n_pts = p->n_points; d.n_obs = p->n_obs; d.n_priors = p->n_pose_priors;
   d.N = 6 * (int)d.n_poses + 8 * (int)d.n_intr; d.LD = d.N + 1;
@@ -2955,7 +2985,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
   AL(part, (size_t)4 * std::max(c->grid_obs, c->grid_vec) + 16);
-  AL(scalars, kSCount); AL(fail, 1);
+  AL(scalars, kSCount + 1);   // the fail word lives in the slot after the scalars: one D2H copy fetches both
+  d.fail = reinterpret_cast<int*>(d.scalars + kSCount);
 #undef UP
 #undef AL
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
@@ -2990,7 +3021,6 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   }
   c->pool.release();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
-  if (c->h_fail) (void)hipHostFree(c->h_fail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Timeline of ONE LM iteration from a rocprofv3 --kernel-trace CSV (<prefix>_kernel_trace.csv): every launch between two
+consecutive Jacobian evaluations (ba_linearize_kernel<true>), with its start offset, duration and the idle gap before it.
+Usage: ba_timeline.py <kernel_trace.csv> [which-iteration (default: the last complete one)]"""
+import csv, sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda t: t[0])
+marks = [i for i, k in enumerate(ks) if "ba_linearize_kernel<true>" in k[2]]
+if len(marks) < 2:
+    sys.exit("fewer than two Jacobian evaluations in the trace")
+which = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 2
+a, b = marks[which], marks[which + 1]
+t0 = ks[a][0]
+prev_end = t0
+busy = 0
+gaps = []
+print(f"iteration {which}: {b - a} launches, {(ks[b][0] - t0) / 1e3:.1f} us from Jacobian evaluation to Jacobian evaluation")
+for s, e, name in ks[a:b]:
+    short = name.replace("(anonymous namespace)::", "").split("(")[0][:48]
+    gap = (s - prev_end) / 1e3
+    print(f"  +{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:8.1f} us  gap {gap:7.1f}  {short}")
+    busy += e - s
+    if gap > 8.0: gaps.append((gap, short))
+    prev_end = max(prev_end, e)
+tail = (ks[b][0] - prev_end) / 1e3
+print(f"  gap before the next Jacobian evaluation {tail:.1f} us")
+print(f"busy {busy / 1e3:.1f} us, idle {((ks[b][0] - t0) - busy) / 1e3:.1f} us; gaps > 8 us: " + ", ".join(f"{g:.0f} us before {n}" for g, n in gaps) + (f", {tail:.0f} us at the end" if tail > 8 else ""))
