@@ -465,8 +465,9 @@ __global__ __launch_bounds__(256, 2) void l2_top2_ratio_kernel(MatchParams p) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-// kDbg != 0: timing experiments only (results are wrong): bit 0 drops the epilogue, bit 1 the per-tile LDS fragment loads,
+// kDbg bits 0..2: timing experiments only (results are wrong): bit 0 drops the epilogue, bit 1 the per-tile LDS fragment loads,
 // bit 2 the per-window wait + barrier + staging - what each costs is the difference to kDbg = 0 (tools/filter_breakdown.py).
+// kDbg = 8 / 16: earlier forms of the epilogue with valid results (see kFold below).
 template <int kMode, int kDbg = 0>
 __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x kStageBytes
@@ -497,12 +498,21 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
   const int8_t* gI = p.tiles + (size_t)tileI0 * kTileBytes;
   const int* gC = p.cinit + (size_t)tileI0 * kTileRows;
 
+  // The P-class maxima are kept per window (TW) and folded into the run-long maxima TP and into the window maximum once per
+  // window: 8 v_max3 per chain instead of 16, +20 VALU per query tile and window (13.08 -> 12.77 ms per launch in one run,
+  // profiles/round2_filter_epilogue_forms_call28.json). TW takes 32 registers (248 of 256 in use).
+  // kDbg bit 3 (results VALID) selects the earlier epilogue (both partitions updated per chain); bit 4 single-buffers the
+  // accumulator initialiser under the new one (re-fetched behind its last use in a tile: 235 registers, 12.85 ms). Both are
+  // kept for comparison and as cross-checks of each other in the tests.
+  constexpr bool kFold = (kDbg & 8) == 0;
+  constexpr bool kOneCv = kFold && (kDbg & 16) != 0;
   int TP[kNQ][8];                      // P-class maxima
+  int TW[kNQ][8];                      // kFold: P-class maxima of the current window
   int Q1[kNQ], Q2[kNQ], Qg[kNQ];       // best / second-best window maximum, best window
 #pragma unroll
   for (int n = 0; n < kNQ; ++n) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) TP[n][s] = kNegInit;
+    for (int s = 0; s < 8; ++s) { TP[n][s] = kNegInit; TW[n][s] = kNegInit; }
     Q1[n] = kNegInit; Q2[n] = kNegInit; Qg[n] = 0;
   }
 
@@ -561,6 +571,10 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
 
 #define MVGX_EPILOGUE(ACC, N)                                          \
   if constexpr (kDbg & 1) { asm volatile("" : "+v"(ACC)); TQ[N] = max(TQ[N], ACC[0]); } else \
+  if constexpr (kFold) {                                               \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s)                      \
+      TW[N][s] = max(max(TW[N][s], ACC[2 * s]), ACC[2 * s + 1]);       \
+  } else                                                               \
   {                                                                    \
     int tq = TQ[N];                                                    \
     _Pragma("unroll") for (int s = 0; s < 8; ++s) {                    \
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
 #define MVGX_INTERLEAVE()                                                                    \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                         \
-    __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x2, kFold ? 2 : 4, 0);                             \
   }
 
 #define MVGX_TILE(A, CV, AN, CN, TN)                                                              \
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
     MVGX_EPILOGUE(accB, 3)                                                                         \
     MVGX_INTERLEAVE()                                                                              \
     MVGX_CHAIN(accB, 1, A, CV)                                                                     \
-    if constexpr (!(kDbg & 2)) {                                                                   \
+    if constexpr (!(kDbg & 2) && !kOneCv) {                                                        \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
       const int4 c4 = *reinterpret_cast<const int4*>(wc + tn_ * (kTileRows * 4) + g * 32);        \
       CN[g * 4 + 0] = c4.x; CN[g * 4 + 1] = c4.y; CN[g * 4 + 2] = c4.z; CN[g * 4 + 3] = c4.w;     \
@@ -602,7 +616,19 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
     MVGX_CHAIN(accA, 2, A, CV)                                                                     \
     MVGX_EPILOGUE(accB, 1)                                                                         \
     MVGX_INTERLEAVE()                                                                              \
-    MVGX_CHAIN(accB, 3, A, CV)                                                                     \
+    if constexpr (kOneCv) {  /* CV is dead after the first MFMA of the tile's last chain: fetch the next tile's */ \
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], b[3][0], CV, 0, 0, 0);                   \
+      if constexpr (!(kDbg & 2))                                                                   \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
+        const int4 c4 = *reinterpret_cast<const int4*>(wc + tn_ * (kTileRows * 4) + g * 32);      \
+        CV[g * 4 + 0] = c4.x; CV[g * 4 + 1] = c4.y; CV[g * 4 + 2] = c4.z; CV[g * 4 + 3] = c4.w;   \
+      }                                                                                            \
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1], b[3][1], accB, 0, 0, 0);                 \
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2], b[3][2], accB, 0, 0, 0);                 \
+      accB = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[3], b[3][3], accB, 0, 0, 0);                 \
+    } else {                                                                                       \
+      MVGX_CHAIN(accB, 3, A, CV)                                                                   \
+    }                                                                                              \
     MVGX_EPILOGUE(accA, 2)                                                                         \
     MVGX_INTERLEAVE()                                                                              \
   }
@@ -611,17 +637,36 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
     v4i an[4];
     v16i cn;
     int t = 0;
-    for (; t + 1 < nt; t += 2) {
-      MVGX_TILE(a, cv, an, cn, t + 1)
-      MVGX_TILE(an, cn, a, cv, min(t + 2, nt - 1))
+    if constexpr (kOneCv) {
+      for (; t + 1 < nt; t += 2) {
+        MVGX_TILE(a, cv, an, cv, t + 1)
+        MVGX_TILE(an, cv, a, cv, min(t + 2, nt - 1))
+      }
+      if (t < nt) MVGX_TILE(a, cv, an, cv, t)
+    } else {
+      for (; t + 1 < nt; t += 2) {
+        MVGX_TILE(a, cv, an, cn, t + 1)
+        MVGX_TILE(an, cn, a, cv, min(t + 2, nt - 1))
+      }
+      if (t < nt) MVGX_TILE(a, cv, an, cn, t)
     }
-    if (t < nt) MVGX_TILE(a, cv, an, cn, t)
     MVGX_EPILOGUE(accB, 3)   // drain
 #undef MVGX_EPILOGUE
 #undef MVGX_CHAIN
 #undef MVGX_TILE
 #undef MVGX_INTERLEAVE
     if constexpr (kMode == kStageRegs) stage_commit(nbuf, sr, wave, lane);
+    if constexpr (kFold) {   // the window's class maxima: their maximum is the window maximum, then they join the run-long maxima
+#pragma unroll
+      for (int n = 0; n < kNQ; ++n) {
+        int tq = max(max(TW[n][0], TW[n][1]), TW[n][2]);
+        tq = max(max(tq, TW[n][3]), TW[n][4]);
+        tq = max(max(tq, TW[n][5]), TW[n][6]);
+        TQ[n] = max(tq, TW[n][7]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { TP[n][s] = max(TP[n][s], TW[n][s]); TW[n][s] = kNegInit; }
+      }
+    }
     // fold the window maximum into the running (best, best window, second best) over windows
 #pragma unroll
     for (int n = 0; n < kNQ; ++n) {
@@ -958,7 +1003,7 @@ struct mvgx_match_ctx {
   int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
   int keep_host_results = 1;
   int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
-  int debug_filter = 0;     // 1..7: timing experiments of l2_filter_kernel (see its kDbg), results invalid
+  int debug_filter = 0;     // 1..7: timing experiments of l2_filter_kernel (see its kDbg), results invalid; 8, 16: earlier forms (valid)
   int stream_hold = 0;      // mvgx_match_run_stream: 1 = a batch's buffers survive two further sink calls (see Slot)
   int pinned_stream = 1;    // host buffers of the stream mode: pinned (contexts that are run repeatedly) or plain memory (one-shot)
   // regions
@@ -1169,8 +1214,9 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
 #define MVGX_DBG_ATTR(D) MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
-  MVGX_DBG_ATTR(1) MVGX_DBG_ATTR(2) MVGX_DBG_ATTR(3) MVGX_DBG_ATTR(4) MVGX_DBG_ATTR(5) MVGX_DBG_ATTR(6) MVGX_DBG_ATTR(7)
+  MVGX_DBG_ATTR(1) MVGX_DBG_ATTR(2) MVGX_DBG_ATTR(3) MVGX_DBG_ATTR(4) MVGX_DBG_ATTR(5) MVGX_DBG_ATTR(6) MVGX_DBG_ATTR(7) MVGX_DBG_ATTR(8) MVGX_DBG_ATTR(16)
 #undef MVGX_DBG_ATTR
+  if (const char* e = getenv("MVGX_MATCH_FILTER")) c->debug_filter = atoi(e) & 31;   // experiments: see l2_filter_kernel's kDbg
   guard.c = nullptr;
   *out = c;
   return MVGX_OK;
@@ -1231,7 +1277,7 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
   } else if (!strcmp(key, "debug_filter")) {
-    MVGX_REQUIRE(value >= 0 && value <= 7, MVGX_ERR_ARG, "debug_filter must be 0..7");
+    MVGX_REQUIRE((value >= 0 && value <= 8) || value == 16, MVGX_ERR_ARG, "debug_filter must be 0..8 or 16");
     c->debug_filter = (int)value;
   } else if (!strcmp(key, "stream_hold")) {
     c->stream_hold = value != 0;
@@ -1412,7 +1458,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->debug_filter) {   // timing experiments (wrong results; verify is skipped below)
 #define MVGX_DBG_CASE(D) case D: hipLaunchKernelGGL((l2_filter_kernel<kStageGldsAsm, D>), dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp); break;
-        switch (c->debug_filter) { MVGX_DBG_CASE(1) MVGX_DBG_CASE(2) MVGX_DBG_CASE(3) MVGX_DBG_CASE(4) MVGX_DBG_CASE(5) MVGX_DBG_CASE(6) MVGX_DBG_CASE(7) default: break; }
+        switch (c->debug_filter) { MVGX_DBG_CASE(1) MVGX_DBG_CASE(2) MVGX_DBG_CASE(3) MVGX_DBG_CASE(4) MVGX_DBG_CASE(5) MVGX_DBG_CASE(6) MVGX_DBG_CASE(7) MVGX_DBG_CASE(8) MVGX_DBG_CASE(16) default: break; }
 #undef MVGX_DBG_CASE
       } else {
         hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
@@ -1421,7 +1467,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       if (c->profile) MVGX_HIP(hipEventRecord(e1, stream));
       MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
       st.n_kernel_launches += 1;
-      if (c->variant == 4 && !c->debug_filter) {
+      if (c->variant == 4 && !(c->debug_filter & 7)) {
         if (c->profile) {
           const size_t nslots = (size_t)nb * c->qstride;
           hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, stream,
@@ -1518,7 +1564,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
   float ms = 0.f;
   MVGX_HIP(hipEventElapsedTime(&ms, c->ev_total0, c->ev_total1));
   st.total_ms = ms;
-  if (c->variant == 4 && !c->debug_filter) {   // the verify kernel cross-checks the filter's d0 against its own exact recomputation
+  if (c->variant == 4 && !(c->debug_filter & 7)) {   // the verify kernel cross-checks the filter's d0 against its own exact recomputation
     uint32_t flags[2] = {0, 0};
     MVGX_HIP(hipMemcpy(flags, c->d_err.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     (void)hipMemset(c->d_err.p, 0, 2 * sizeof(uint32_t));

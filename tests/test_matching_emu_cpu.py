@@ -53,7 +53,7 @@ def test_adversarial_set(ratio):
     pairs = _both_directions(len(imgs))
     o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
     with _emu.emulated():
-        for variant in (43, 1):
+        for variant in (43, 48, 1):
             _, off, ij = run_hip(imgs, pairs, ratio, variant)
             assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), variant
 
@@ -78,8 +78,9 @@ def test_extreme_values_and_parity_skew():
     with _emu.emulated():
         for ratio in (1.0, 0.8):
             o_off, o_ij = _oracle.port_matcher_regions_match(imgs, pairs, ratio)
-            _, off, ij = run_hip(imgs, pairs, ratio, 41)
-            assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), ratio
+            for variant in (41, 48):
+                _, off, ij = run_hip(imgs, pairs, ratio, variant)
+                assert np.array_equal(off, o_off) and np.array_equal(ij, o_ij), (ratio, variant)
 
 
 def test_batch_pipeline_options_and_result_buffers():
