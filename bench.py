@@ -29,12 +29,12 @@ if ROOT not in sys.path:
 
 I8_MFMA_DENSE_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: i8 MFMA = 2x the 2.5 PF bf16 dense peak (2xK); ubench 4404 TOPS
 FLOP_PER_DESC_PAIR = 256.0          # 128 MAC
-# HBM bytes of the filter kernel per image pair (2000 x 2000 descriptors), from the PMC pass committed as
-# profiles/round1_match_v2_traffic_pmc_call17.json and, with the final batch pipeline, profiles/round1_match_traffic_pmc_call42.json
-# (same figures): (TCC_EA0_RDREQ x 64 B x 2 [gfx950 correction for 16 B/lane streams,
-# MI355X_MICROARCH.md] + TCC_EA0_WRREQ x 64 B) / 79 800 pairs. Counters cannot be read inside this process; the figure is
-# scaled to this run's pairs per launch. Algorithmic minimum (every image read once) is ~0.1 GB per launch.
-HBM_BYTES_PER_IMAGE_PAIR_MEASURED = (2.3186e10 + 1.8911e9) / 79800.0
+# HBM bytes of the filter kernel per image pair (2000 x 2000 descriptors), from the PMC pass of one pass over THIS workload
+# committed as profiles/round2_match_traffic_pmc_call26.json (tools/pmc_traffic_summary.py; round 1: ...traffic_pmc_call42.json,
+# 314 KB): (TCC_EA0_RDREQ x 64 B x 2 [gfx950 correction for 16 B/lane streams, MI355X_MICROARCH.md] + TCC_EA0_WRREQ x 64 B)
+# / 499 500 pairs. Counters cannot be read inside this process; the figure is scaled to this run's pairs per launch.
+# Algorithmic minimum (every image read once) is ~0.1 GB per launch.
+HBM_BYTES_PER_IMAGE_PAIR_MEASURED = (1.44266810624e11 + 8.111838464e9) / 499500.0
 
 
 def parse():
@@ -204,7 +204,7 @@ def main():
                          "traffic": (HBM_BYTES_PER_IMAGE_PAIR_MEASURED * (args.desc / 2000.0) * len(pairs) * args.steps / max(launches, 1)
                                      if variant == 4 else None),
                          "traffic_measured_in_run": False,
-                         "traffic_note": "HBM bytes per launch, PMC pass profiles/round1_match_traffic_pmc_call42.json scaled by pairs per launch "
+                         "traffic_note": "HBM bytes per launch, PMC pass profiles/round2_match_traffic_pmc_call26.json scaled by pairs per launch "
                                          "(counters cannot be read inside this process)",
                          "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},
