@@ -72,7 +72,8 @@ int mvgx_match_create(int device, mvgx_match_ctx** out);
 int mvgx_match_create_multi(const int* devices, int n_devices, mvgx_match_ctx** out);
 int mvgx_match_destroy(mvgx_match_ctx* ctx);
 
-/* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch),
+/* knobs: "variant" (kernel variant id), "profile" (1: HIP events around every match-kernel launch; 2: also a statistics
+ * pass that counts the candidates the filter hands to the verify stage, reported in kernel_vgprs),
  * "batch_pairs" (pairs per device batch), "keep_host_results" (0: skip D2H of the match lists),
  * "overlap" (default 1: two batch slots, batch b filters while batch b-1 is verified/compacted/copied; 0: one at a time),
  * "double_buffer_results" (default 0, see mvgx_match_run),

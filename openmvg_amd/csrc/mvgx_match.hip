@@ -1268,7 +1268,7 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     MVGX_REQUIRE(value >= 1 && value <= 3, MVGX_ERR_ARG, "stage must be 1..3");
     c->stage = (int)value;
   } else if (!strcmp(key, "profile")) {
-    c->profile = value != 0;
+    c->profile = value < 0 ? 0 : (int)std::min<int64_t>(value, 2);   // 1: kernel timing events; 2: also count the filter's candidates
   } else if (!strcmp(key, "batch_pairs")) {
     MVGX_REQUIRE(value >= 1 && value <= (1 << 20), MVGX_ERR_ARG, "batch_pairs must be in [1, 2^20]");
     c->batch_pairs = value;
@@ -1468,7 +1468,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
       st.n_kernel_launches += 1;
       if (c->variant == 4 && !(c->debug_filter & 7)) {
-        if (c->profile) {
+        if (c->profile >= 2) {   // statistics pass (0.13 ms per batch): only on request, not in the timed runs of bench.py ("profile" 1)
           const size_t nslots = (size_t)nb * c->qstride;
           hipLaunchKernelGGL(count_candidates_kernel, dim3((unsigned)((nslots + 16383) / 16384)), dim3(256), 0, stream,
                              sl.d_best.p, nslots, c->d_err.p + 1);

@@ -29,7 +29,7 @@ def main():
             c.set_option("stage", v - 40)
         else:
             c.set_option("variant", v)
-        c.set_option("profile", 1)
+        c.set_option("profile", 2)   # 2: also count the filter's candidates
         c.set_regions(descs)
         c.run(pairs[:1000], 0.64, fetch=False)
         ctxs[v] = c
