@@ -32,3 +32,19 @@ def check_factor64(handle):
     for seed, kb in enumerate((64, 64, 64, 63, 49, 48, 37, 33, 32, 17, 16, 5, 1)):
         errs = factor64_errors(handle, kb, 100 + seed)
         assert max(errs) < 1e-12, (kb, errs)
+
+
+def check_factor64_rejects_indefinite(handle):
+    """a block that is not positive definite must be reported (fail flag -> MVGX_ERR_NUMERIC), whichever panel meets the bad pivot"""
+    f = handle.mvgx_debug_factor64
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    for bad in (0, 17, 40, 63):
+        m = rng.standard_normal((64, 128))
+        a = m @ m.T + 64 * np.eye(64)
+        a[bad, bad] = -1.0
+        full = np.asfortranarray(a)
+        l_out = np.zeros((64, 64), order="F")
+        linv = np.zeros(8192)
+        assert f(full.ctypes.data, 64, l_out.ctypes.data, linv.ctypes.data) == 6, bad   # MVGX_ERR_NUMERIC

@@ -603,3 +603,4 @@ def test_factor_and_invert_kernel_against_numpy():
     """the 64 x 64 Cholesky + inverse workgroup kernel under the emulation: full, partial (identity-padded) and tiny blocks"""
     from tests import _factor64
     _factor64.check_factor64(_emu.handle())
+    _factor64.check_factor64_rejects_indefinite(_emu.handle())

@@ -385,3 +385,4 @@ def test_factor_and_invert_kernel_against_numpy():
     full, partial (identity-padded) and tiny blocks"""
     from tests import _factor64
     _factor64.check_factor64(_capi.lib())
+    _factor64.check_factor64_rejects_indefinite(_capi.lib())

@@ -237,3 +237,4 @@ def test_stream_hold_keeps_a_batch_valid_for_two_further_sink_calls(devices):
     assert checked[0] >= 2 * (len(held) - 2)
     got = np.concatenate([c[2][1] for c in sorted(held, key=lambda h: h[0])])
     assert np.array_equal(got, o_ij)
+

@@ -366,3 +366,23 @@ def test_streaming_keeps_host_memory_flat():
         assert 8 * tot[0] > 20 * (rss1 - rss0)    # the whole run's lists are >20x what the process grew by
     finally:
         ctx.close()
+
+
+def test_profile_level_2_counts_the_filter_candidates():
+    """ "profile" 2 adds the statistics pass: candidates handed to the verify stage (reported in kernel_vgprs) are at least the
+    accepted matches and at most the queries; level 1 (what bench.py times) does not run it"""
+    imgs = synth.image_descriptors(3, n_desc=200, seed=4)
+    p = matching.exhaustive_pairs_array(3)
+    pairs = np.concatenate([p, p[:, ::-1]])
+    for level, counted in ((1, False), (2, True)):
+        ctx = matching.MatchContext(0)
+        try:
+            ctx.set_option("profile", level)
+            ctx.set_regions(imgs)
+            st, off, ij = ctx.run(pairs, np.float32(0.8) * np.float32(0.8))
+        finally:
+            ctx.close()
+        if counted:
+            assert int(st.n_matches) <= int(st.kernel_vgprs) <= 200 * len(pairs)
+        else:
+            assert int(st.kernel_vgprs) == 0
