@@ -52,6 +52,7 @@ def parse():
                                                            "instead of streaming them (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parity-seconds", type=float, default=2.0, help="N > 1: seconds of CPU matching per rank for the sampled parity check")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--side-deadline", type=float, default=900.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
@@ -217,6 +218,26 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
+    if world > 1 and not args.no_cpu_baseline:
+        # N > 1: no CPU throughput figure (rank 0 at N = 1 only), but correctness evidence for EVERY rank's shard: each rank in
+        # turn (the host cores are shared) matches a small random sample of ITS pairs on the CPU and compares its device lists
+        # entry by entry; the verdicts are combined over the ranks.
+        par = None
+        for turn in range(world):
+            if turn == rank:
+                try:
+                    _, sample, cpu_lists = cpu_baseline(descs, pairs, args.ratio, args.parity_seconds)
+                    par = parity_on_sample(ctx, ratio_sq, sample, cpu_lists)
+                except Exception as e:
+                    par = {"pairs_checked": 0, "non_empty_pairs": 0, "matches_checked": 0, "identical": False, "error": repr(e)}
+            dist.barrier()
+        t = torch.tensor([float(par["pairs_checked"]), float(par["non_empty_pairs"]), float(par["matches_checked"]),
+                          0.0 if par["identical"] else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            out["parity"] = {"pairs_checked": int(t[0]), "non_empty_pairs": int(t[1]), "matches_checked": int(t[2]),
+                             "identical": bool(t[3] == 0.0), "ranks_checked": world, "ranks_differing": int(t[3]),
+                             "against": "the reference's CPU path on a random sample of every rank's own pair shard (same run)"}
     ctx.close()
     ba_rec = ba_c5 = None
     # The side records below must never cost the headline line: if one of them stalls (the BA leg has collectives; a rank
@@ -246,7 +267,7 @@ def main():
             out["hamming"] = hamming_bench_record(local_rank, cpu=not args.no_cpu_baseline)
             out["l2_float"] = l2f_bench_record(local_rank, cpu=not args.no_cpu_baseline)
             from bench_hamming import l2u8_bench_record
-            out["l2_uint8_144"] = l2u8_bench_record(local_rank)
+            out["l2_uint8_144"] = l2u8_bench_record(local_rank, cpu=not args.no_cpu_baseline)
         except Exception as e:  # side record only
             out["hamming"] = {"status": f"failed: {e!r}"}
     if rank == 0:

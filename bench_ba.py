@@ -157,9 +157,9 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None):
                      "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_iteration": bytes_it},
     }
-    if cpu and world == 1:
+    if cpu and rank == 0:   # every --gpus N: the reference on the FULL scene beside the sharded solve (rmse_diff_vs_reference)
         try:
-            rec["cpu_baseline"] = cpu_reference(scene, s, cpu_budget_s)
+            rec["cpu_baseline"] = cpu_reference(scene, s, cpu_budget_s if world == 1 else 0.0)
         except Exception as e:  # side figure only
             rec["cpu_baseline"] = {"kind": "reference", "error": repr(e)}
     return rec
