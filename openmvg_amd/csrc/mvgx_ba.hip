@@ -60,7 +60,6 @@ using mvgx::set_error;
 using namespace mvgx_ba;
 
 constexpr int kJA = 8, kJB = 16, kJC = 16;   // doubles per observation record: {r, E} | {r, Fc, pad} | {Fi}
-constexpr int kIntrChunk = 2048;   // observations per workgroup of the intrinsic Gram kernel
 constexpr int kPiChunk = 512;      // observations per workgroup of the (pose, intrinsic) Gram kernel
 using d4_t = __attribute__((ext_vector_type(4))) double;   // accumulator of v_mfma_f64_16x16x4_f64
 constexpr int kTripChunk = 1024;   // (entity a, entity b) products per wave of the Schur-product kernel
@@ -71,7 +70,7 @@ constexpr int kPriorJ = 21;        // per pose-centre prior: corrected r (3) | c
 
 // kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
 // point parts are rank-local and summed across ranks.
-enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSModelPt, kSModelCam, kSCount = 12 };
+enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSModelPt, kSModelCam, kSGmaxGrp, kSCount = 14 };
 
 // One list of Schur products -Z_a^T Z_b, sorted by the (row block, column block) of S they add into. Entities are
 // observations (pose blocks, width 6) or (point, intrinsic) slots (intrinsic blocks, width 8).
@@ -86,44 +85,68 @@ struct TripList {
   uint32_t* block_chunk0 = nullptr;   // n_blocks + 1
   int32_t* block_own = nullptr;       // pose x intrinsic lists: the (pose, intrinsic) pair whose Fc^T Fi adds in, or -1
   double* part = nullptr;             // (n_chunks + n_ext) x (WA * WB + WA)
-  // pose x pose list only: partial blocks written by the point-group kernel (GroupList), numbered in block order after
-  // the n_chunks chunks of the flat list
+  // partial blocks written by the point-group kernel (GroupList), numbered in block order after the n_chunks chunks of the flat list
   uint32_t n_ext = 0;
   uint32_t* block_ext0 = nullptr;     // n_blocks + 1 (null: none)
 };
 
-// Points whose observations fall on at most kGroupCams poses are processed in groups that share such a camera set: the
-// group's Z blocks are staged once into LDS as a dense (3 n_points) x 64 matrix (6 columns per local camera, column 60 =
-// h_p, zero where a point does not see a camera) and Z^T Z - all Schur products of the group, all destination blocks at
-// once - runs on the f64 matrix cores. Per product this reads 1/11 of what the flat product list reads (each Z block once
-// instead of once per partner) - the list stays for the points that fit no group (long tracks, constant points).
-constexpr int kGroupCams = 10;                                    // local cameras per group: 60 pose columns + h
-constexpr int kGroupPairs = kGroupCams * (kGroupCams + 1) / 2;    // destination blocks of a group
+// Point groups - the fused path. Free points whose observations fall on at most kGroupCams distinct poses and kGroupIntr distinct
+// intrinsics are processed in groups of up to kGroupPts points that share such a camera set; consecutive groups with the SAME
+// camera set form a supergroup = one workgroup. Nothing of the Jacobian is stored for these points: the workgroup evaluates the
+// residuals and closed-form Jacobians of the group's observations from (observation, parameters) in registers (one observation
+// per thread), reduces V_p / gradient / column norms per point in LDS, factors V_p, forms the Z blocks, stages them as a dense
+// (3 n_points) x 80 matrix (6 columns per local pose, 8 per local intrinsic, column kGroupHCol = h_p, zero where a point does not
+// see a camera) and computes Z^T Z - all Schur products of the group: pose x pose, pose x intrinsic, intrinsic x intrinsic and the
+// rhs - on the f64 matrix cores, accumulating over the groups of the supergroup. The back-substitution runs the same code up to the
+// Z blocks again (mode kGroupBacksub) instead of reading stored Z blocks: per LM iteration the points' observations are read twice
+// (24 bytes each), no per-observation record is written. Long tracks, constant points, poses seen twice by a point and points
+// with more intrinsics than kGroupIntr stay on the record-based path below (JA / JB / JC records, flat product lists).
+constexpr int kGroupCams = 10;                                    // local poses per group: 60 pose columns
+constexpr int kGroupIntr = 2;                                     // local intrinsics per group: 16 intrinsic columns
+constexpr int kGroupHCol = 6 * kGroupCams + 8 * kGroupIntr;       // the column of h_p (76)
+constexpr int kGroupCols = 80;                                    // 5 x 16: the columns 77..79 are padding (zero)
+constexpr int kGroupColTiles = kGroupCols / 16;
+constexpr int kGroupTiles = kGroupColTiles * (kGroupColTiles + 1) / 2;   // upper 16 x 16 tiles of Z^T Z (15)
+constexpr int kGroupPairsPP = kGroupCams * (kGroupCams + 1) / 2;  // destination blocks of a group: pose x pose (55)
+constexpr int kGroupPairsPI = kGroupCams * kGroupIntr;            // pose x intrinsic (20)
+constexpr int kGroupPairsII = kGroupIntr * (kGroupIntr + 1) / 2;  // intrinsic x intrinsic (3)
+constexpr int kNVpp = 6 * 6 + 6, kNVpi = 6 * 8 + 6, kNVii = 8 * 8 + 8;   // doubles per partial block (block | rhs) of the three product families
 #ifndef MVGX_GROUP_PTS
-#define MVGX_GROUP_PTS 42
-#define MVGX_GROUP_RS 130
+#define MVGX_GROUP_PTS 32
 #endif
-constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points rows of K
-constexpr int kGroupRS = MVGX_GROUP_RS;                           // doubles between columns in LDS, >= 3 kGroupPts and = 2 x odd (mod 32): the 16
-                                                                  // columns x 2 rows a half wave reads as an MFMA operand then fall on distinct banks
-static_assert(kGroupRS >= 3 * kGroupPts + 2 && (kGroupRS % 4) == 2, "group tile layout");
-constexpr int kGroupStageLds = kGroupPts * kGroupCams * 10 * 16;   // the group's Z records (9 slots + observation id) on their way to HBM
-constexpr int kGroupLds = 64 * kGroupRS * (int)sizeof(double) > kGroupStageLds ? 64 * kGroupRS * (int)sizeof(double) : kGroupStageLds;
-constexpr int kGroupMinPts = 8;                                   // smaller groups go to the flat list
+constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points rows of the staged matrix
+constexpr int kGroupThreads = 256;                                // one observation per thread: a group holds at most this many observations
+constexpr int kGroupWaves = kGroupThreads / 64;
+constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves;
+constexpr int kGroupRS = 3 * kGroupPts + 2;                       // doubles between columns in LDS, = 2 x odd (mod 32): the 16 columns x 2 rows a
+                                                                  // half wave reads as an MFMA operand then fall on distinct banks
+static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255, "group tile layout");
+constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
+constexpr int kGroupM = kGroupCols * kGroupRS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
+static_assert(kGroupM >= 24 * kGroupThreads && kGroupM >= kGroupOut && kGroupM >= 3 * kGroupThreads + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
+constexpr int kGroupSums = kGroupPts * 16, kGroupPtab = kGroupPts * 12;
+constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab) * (int)sizeof(double) + (kGroupThreads + kGroupPts + 1) * (int)sizeof(uint32_t);
+constexpr int kGroupMinPts = 8;                                   // smaller groups go to the record-based path
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+enum GroupMode { kGroupNorms = 0, kGroupForward = 1, kGroupBacksub = 2 };
 struct GroupList {
-  uint32_t n_groups = 0;
-  uint32_t* obs_start = nullptr;   // n_groups + 1 -> entries
-  uint32_t* obs = nullptr;         // entry: observation index
-  uint16_t* obs_qx = nullptr;      // entry: (local point << 8) | local camera
-  uint32_t* obs_pt = nullptr;      // entry: point of the observation
-  uint32_t* obs_pose = nullptr;    // entry: pose of the observation
-  uint32_t* ungrouped = nullptr;   // observations of the points outside every group (their Z comes from ba_obs_z_kernel)
-  uint32_t n_ungrouped = 0;
-  int dbg = 0;   // MVGX_BA_GROUP_DEBUG (timing experiments, wrong results): 1 no Z stores, 2 no MFMA loop, 4 no partial-block stores, 8 no LDS scatter
+  uint32_t n_sg = 0, n_groups = 0;
+  uint32_t* sg_start = nullptr;    // n_sg + 1 -> groups
+  uint32_t* obs_start = nullptr;   // n_groups + 1 -> entries (one per observation, point by point)
   uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
-  uint32_t* pts = nullptr;         // local point -> point
-  uint32_t* chunk = nullptr;       // n_groups x kGroupPairs: row of tpp.part for local cameras (x <= y), kNoChunk: no common point
+  uint32_t* pts = nullptr;         // grouped point -> point
+  uint32_t* pt_estart = nullptr;   // grouped point (+ 1) -> its first entry
+  uint32_t* eq = nullptr;          // entry: local point | local pose << 8 | local intrinsic << 12
+  uint32_t* eobs = nullptr;        // entry: observation index (weights / control flags)
+  double2* exy = nullptr;          // entry: the observation
+  uint32_t* cams = nullptr;        // n_sg x kGroupCams: pose of a local pose (unused: 0)
+  uint32_t* intrs = nullptr;       // n_sg x kGroupIntr
+  uint32_t* chunk_pp = nullptr;    // n_sg x kGroupPairsPP: row of tpp.part for local poses (x <= y), kNoChunk: no common point
+  uint32_t* chunk_pi = nullptr;    // n_sg x kGroupPairsPI: row of tpi.part for (local pose x, local intrinsic k)
+  uint32_t* chunk_ii = nullptr;    // n_sg x kGroupPairsII: row of tii.part for local intrinsics (k <= k')
+  double* gmax_part = nullptr;     // n_sg: max |gradient| over the supergroup's points (forward pass)
+  uint32_t* ungrouped = nullptr;   // observations of the points outside every group (record-based path)
+  uint32_t n_ungrouped = 0;
 };
 
 // Block-sparse storage of the reduced camera system (ba_sparse_plan.h): 64 x 64 tiles of the permuted, padded matrix,
@@ -150,7 +173,7 @@ struct Dev {
   uint64_t n_obs = 0;
   int N = 0, LD = 0;             // camera system size and leading dimension
   int n_islots = 0;              // (point, intrinsic) slots
-  int n_pi = 0, n_pichunks = 0, n_igchunks = 0;
+  int n_pi = 0, n_pichunks = 0;
   double huber_a = 0, prior_huber_a = 0;
   // parameters
   double *poses = nullptr, *intr = nullptr, *pts = nullptr;      // x_
@@ -169,12 +192,14 @@ struct Dev {
   uint8_t* cam_active = nullptr;      // N: free component of a block that has residuals
   uint8_t* cam_counts = nullptr;      // N: component belongs to a block that is in the reduced program (x-norm)
   uint8_t* pt_free = nullptr;         // n_pts: point is a free parameter block with residuals
+  uint8_t* pt_grouped = nullptr;      // n_pts: point belongs to a point group (fused path: no records, no stored Z); null: no groups
   // (pose, intrinsic) pairs and intrinsics: observation lists for the Gram kernels
   uint32_t *pi_obs = nullptr, *pichunk_lo = nullptr, *pichunk_hi = nullptr, *pi_chunk0 = nullptr, *pose_pi_start = nullptr;
-  uint32_t *iobs = nullptr, *igchunk_lo = nullptr, *igchunk_hi = nullptr, *igchunk_start = nullptr;
-  // matrix-core Gram path: the intrinsic blocks come out of the same pass as the (pose, intrinsic) blocks; per intrinsic the
-  // list of the (pose, intrinsic) chunks that belong to it
-  int gram_mfma = 0;
+  uint32_t *pichunk_pose = nullptr, *pichunk_intr = nullptr;   // n_pichunks: the pair of the chunk
+  uint32_t* pi_pt = nullptr;          // n_obs, (pose, intrinsic) order: point of the observation
+  double2* pi_xy = nullptr;           // n_obs, (pose, intrinsic) order: the observation
+  // the intrinsic's own Gram blocks come out of the same pass as the (pose, intrinsic) blocks; per intrinsic the list of the
+  // (pose, intrinsic) chunks that belong to it
   uint32_t *intr_pichunk_start = nullptr, *intr_pichunk = nullptr;
   double* pichunk_ipart = nullptr;   // n_pichunks x kIntrGram
   // pose-centre priors
@@ -184,7 +209,7 @@ struct Dev {
   double *JA = nullptr, *JB = nullptr, *JC = nullptr;   // n_obs records each
   double *cn_cam = nullptr, *g_cam = nullptr, *scale_cam = nullptr, *diag_cam = nullptr;   // N
   double *cn_pt = nullptr, *g_pt = nullptr, *scale_pt = nullptr, *diag_pt = nullptr;       // 3 n_pts
-  double *pichunk_part = nullptr, *pi_gram = nullptr, *pose_gram = nullptr, *igram_part = nullptr, *igram = nullptr;
+  double *pichunk_part = nullptr, *pi_gram = nullptr, *pose_gram = nullptr, *igram = nullptr;
   double *Linv3 = nullptr, *hp = nullptr;   // per point: L_p^-1 (6, lower) and h_p = L_p^-1 Es^T r (3)
   double *Zpose = nullptr, *Zint = nullptr; // n_obs x 18, n_islots x 24
   TripList tpp, tpi, tii;
@@ -302,6 +327,52 @@ __device__ __forceinline__ void store_records_coalesced(double2* lds_wave /* 64 
   __syncthreads();
 }
 
+// Loss-corrected residual and Jacobian of one observation at the current parameters, as ba_linearize_kernel forms them:
+// WeightedCostFunction (camera_functor.hpp:35-90; weight 0 selects the unweighted functor), control points without loss
+// function, Huber corrector (corrector.cc:81-85,126-129: residual and Jacobian scale by sqrt(rho')). o: the observation's index
+// in the point-sorted arrays (weights / control flags). Returns r (corrected) and the factor sc of the Jacobian entries.
+__device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2]) {
+  double w = 1.0;
+  if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
+  const bool ctrl = d.octrl && d.octrl[o];
+  r[0] *= w; r[1] *= w;
+  const double s = r[0] * r[0] + r[1] * r[1];
+  double rho[3];
+  huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s, rho);
+  const double sr = corrector_scale(rho);
+  r[0] *= sr; r[1] *= sr;
+  return sr * w;
+}
+
+// The records of the listed observations only (the points outside the point groups), one thread each, plain stores: the slow path.
+__global__ __launch_bounds__(256) void ba_linearize_list_kernel(Dev d, const uint32_t* __restrict__ list, uint32_t n) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t o = list[idx];
+  const uint32_t ip = d.opose[o], ii = d.ointr[o], ix = d.opt[o];
+  double pin[8], pp[6], px[3], obs[2], r[2], Ji[16], Jc[12], Jp[6];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)ii * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+  obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
+  eval_observation<true>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp);
+  const double sc = correct_observation(d, o, r);
+  double* __restrict__ ja = d.JA + (size_t)o * kJA;
+  double* __restrict__ jb = d.JB + (size_t)o * kJB;
+  double* __restrict__ jc = d.JC + (size_t)o * kJC;
+  ja[0] = r[0]; ja[1] = r[1]; jb[0] = r[0]; jb[1] = r[1];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ja[2 + k] = Jp[k] * sc;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) jb[2 + k] = Jc[k] * sc;
+  jb[14] = 0.0; jb[15] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) jc[k] = Ji[k] * sc;
+}
+
 template <bool kJac>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* __restrict__ poses,
                                                            const double* __restrict__ intr, const double* __restrict__ pts,
@@ -416,7 +487,7 @@ __global__ __launch_bounds__(256) void ba_track_angle_kernel(Dev d, const double
 // pose-centre priors (one workgroup): cost added onto scalars[kSCost]; with kJac the loss-corrected residual and
 // Jacobian rows are kept for the Gram / gradient / model-cost kernels
 template <bool kJac>
-__global__ __launch_bounds__(256) void ba_prior_kernel(Dev d, const double* __restrict__ poses) {
+__global__ __launch_bounds__(256) void ba_prior_kernel(Dev d, const double* __restrict__ poses, int add_cost) {
   __shared__ double sh[4];
   double cost = 0;
   for (uint32_t q = threadIdx.x; q < d.n_priors; q += blockDim.x) {
@@ -434,134 +505,108 @@ __global__ __launch_bounds__(256) void ba_prior_kernel(Dev d, const double* __re
     }
   }
   const double c = block_sum(cost, sh);
-  if (threadIdx.x == 0) d.scalars[kSCost] += c;
+  if (threadIdx.x == 0 && add_cost) d.scalars[kSCost] += c;
 }
 
 // ------------------------------------------------------------------------------------------------------
 // column norms (unscaled) and gradient J^T r
 // ------------------------------------------------------------------------------------------------------
-// Column norms and gradient of the point blocks: cn_p = sum_o diag(E_o^T E_o), g_p = sum_o E_o^T r_o over the point's
-// observations. A workgroup takes kNormPts consecutive points; their observations are one contiguous range (observations are
-// sorted by point), read one 64-byte record per lane - neighbouring lanes, neighbouring records - and turned into the six
-// per-observation terms in LDS; then one thread per point adds its terms in observation order (the order a thread walking its
-// own records used: same sums, but that walk read 16 bytes per lane and request at a 640-byte stride, 121 microseconds at C5).
-constexpr int kNormPts = 64;
-constexpr int kNormObs = 1024;   // observations staged at a time (48 KiB)
+// Column norms and gradient of the point blocks on the record-based path: cn_p = sum_o diag(E_o^T E_o), g_p = sum_o E_o^T r_o over
+// the point's observations, one thread per point (grouped points get theirs from ba_point_group_kernel).
 __global__ __launch_bounds__(256) void ba_point_norms_kernel(Dev d) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // 6 doubles per staged observation
-  const uint32_t p0 = blockIdx.x * kNormPts, p1 = min(p0 + (uint32_t)kNormPts, d.n_pts);
-  const uint32_t o0 = d.pt_start[p0], o1 = d.pt_start[p1];
-  const uint32_t p = p0 + threadIdx.x;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.n_pts || (d.pt_grouped && d.pt_grouped[p])) return;
   double cn[3] = {0, 0, 0}, g[3] = {0, 0, 0};
-  for (uint32_t base = o0; base < o1; base += kNormObs) {   // (a chunk at a time: tracks can be long)
-    const uint32_t n = min((uint32_t)kNormObs, o1 - base);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-      double a[8];
-      load_rec<8>(d.JA + (size_t)(base + i) * kJA, a);
+  for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+    double a[8];
+    load_rec<8>(d.JA + (size_t)o * kJA, a);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        lds[i * 6 + c] = a[2 + c] * a[2 + c] + a[5 + c] * a[5 + c];
-        lds[i * 6 + 3 + c] = a[2 + c] * a[0] + a[5 + c] * a[1];
-      }
+    for (int c = 0; c < 3; ++c) {
+      cn[c] += a[2 + c] * a[2 + c] + a[5 + c] * a[5 + c];
+      g[c] += a[2 + c] * a[0] + a[5 + c] * a[1];
     }
-    __syncthreads();
-    if (threadIdx.x < kNormPts && p < p1) {
-      const uint32_t lo = max(d.pt_start[p], base), hi = min(d.pt_start[p + 1], base + n);
-      for (uint32_t o = lo; o < hi; ++o) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { cn[c] += lds[(o - base) * 6 + c]; g[c] += lds[(o - base) * 6 + 3 + c]; }
-      }
-    }
-    __syncthreads();
   }
-  if (threadIdx.x < kNormPts && p < p1) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = cn[c]; d.g_pt[(size_t)p * 3 + c] = g[c]; }
-  }
+  for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = cn[c]; d.g_pt[(size_t)p * 3 + c] = g[c]; }
 }
 
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
 __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r * (r - 1)) / 2 + (c - r); }
 
-// one workgroup per chunk of the observations of a (pose, intrinsic) pair: Fc^T Fc (upper, 21), Fc^T r (6),
-// Fc^T Fi (6 x 8), all UNscaled
-__global__ __launch_bounds__(256) void ba_pi_gram_kernel(Dev d) {
-  __shared__ double sh[4][kPiGram];
+// Gram blocks of the camera columns, by (pose, intrinsic) pair: the two rows of an observation's camera Jacobian are two rows of
+// F = [Fc (6) | Fi (8) | r | 0], and F^T F of a chunk holds Fc^T Fc, Fc^T Fi, Fi^T Fi, Fc^T r and Fi^T r - UNscaled. One workgroup
+// per chunk of the pair's observations (camera order: pi_xy / pi_pt are copies of the observations in that order, 20 contiguous
+// bytes each; the points are gathered). Nothing is read back from a stored Jacobian: every thread evaluates its observation,
+// drops the two rows into LDS, and each wave runs v_mfma_f64_16x16x4_f64 over its own 64 observations with lane (li, lk) feeding
+// element li of row k0 + lk as BOTH operands; the four accumulators are summed in wave order.
+constexpr int kGramRow = 34;   // doubles per staged observation (2 x 16 + pad: 16-byte aligned, conflict-free 16-byte stores)
+__global__ __launch_bounds__(256) void ba_cam_gram_kernel(Dev d) {
+  __shared__ __attribute__((aligned(16))) double F[256 * kGramRow];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t ch = blockIdx.x;
-  double acc[kPiGram];
-#pragma unroll
-  for (int k = 0; k < kPiGram; ++k) acc[k] = 0.0;
-  for (uint32_t e = d.pichunk_lo[ch] + threadIdx.x; e < d.pichunk_hi[ch]; e += 256) {
-    const uint32_t o = d.pi_obs[e];
-    double b[16], h[16];
-    load_rec<16>(d.JB + (size_t)o * kJB, b);
-    load_rec<16>(d.JC + (size_t)o * kJC, h);
-    const double r0 = b[0], r1 = b[1];
-    const double* f0 = b + 2; const double* f1 = b + 8; const double* h0 = h; const double* h1 = h + 8;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-      for (int c = r; c < 6; ++c) acc[tri6(r, c)] += f0[r] * f0[c] + f1[r] * f1[c];
-      acc[21 + r] += f0[r] * r0 + f1[r] * r1;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[kPoseGram + r * 8 + c] += f0[r] * h0[c] + f1[r] * h1[c];
-    }
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kPiGram; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) sh[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kPiGram)
-    d.pichunk_part[(size_t)ch * kPiGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
-// The same blocks on the f64 matrix cores, and the intrinsic's own blocks with them: the two rows of an observation's camera
-// Jacobian are two rows of F = [Fc (6) | Fi (8) | r | 0], and F^T F of a chunk holds Fc^T Fc, Fc^T Fi, Fi^T Fi, Fc^T r and Fi^T r.
-// One wave per chunk; lane (li, lk) feeds element li of row k0 + lk straight from the Jacobian records as BOTH operands of
-// v_mfma_f64_16x16x4_f64 (16 lanes read 14 consecutive doubles of a record), 64 observations of loads in flight per block.
-// The separate pass over the observations of every intrinsic (ba_intr_gram_kernel) is not needed on this path.
-__global__ __launch_bounds__(256) void ba_pi_gram_mfma_kernel(Dev d) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const uint32_t ch = blockIdx.x * 4 + wave;
-  if (ch >= (uint32_t)d.n_pichunks) return;   // wave-uniform
   const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
-  // where element li of Jacobian row `parity` lives: JB = {r(2), Fc row 0 (6), Fc row 1 (6), pad}, JC = {Fi row 0 (8), Fi row 1 (8)}
-  const int parity = lk & 1;
-  const bool from_c = li >= 6 && li < 14;
-  const int off = li < 6 ? 2 + 6 * parity + li : from_c ? 8 * parity + (li - 6) : parity;   // li == 14: r; li == 15: unused
-  const double* __restrict__ base = from_c ? d.JC : d.JB;
+  const uint32_t ip = d.pichunk_pose[ch], ii = d.pichunk_intr[ch];
+  double pin[8], pp[6];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)ii * 8 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
+  const int model = d.model[ii];
   d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
-  for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
-    const uint32_t nblk = min(64u, hi - e0);
-    const uint32_t mine = lane < nblk ? d.pi_obs[e0 + lane] : 0u;
-    double v[32];
+  for (uint32_t base = lo; base < hi; base += 256) {
+    const uint32_t e = base + tid;
+    double2* __restrict__ row = reinterpret_cast<double2*>(F + tid * kGramRow);
+    if (e < hi) {
+      const uint32_t ix = d.pi_pt[e];
+      const double2 xy = d.pi_xy[e];
+      double px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {   // k-step ks covers observations 2 ks (rows lk = 0, 1) and 2 ks + 1 (lk = 2, 3)
-      const uint32_t oa = __builtin_amdgcn_readlane(mine, 2 * ks), ob = __builtin_amdgcn_readlane(mine, 2 * ks + 1);
-      const uint32_t o = (lk >> 1) ? ob : oa;
-      const bool live = (uint32_t)(2 * ks + (lk >> 1)) < nblk && li < 15;
-      v[ks] = live ? base[(size_t)o * 16 + off] : 0.0;
+      for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+      eval_observation<true>(model, pin, pp, px, obs, r, Ji, Jc, Jp);
+      const double sc = correct_observation(d, (d.oweight || d.octrl) ? d.pi_obs[e] : 0, r);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // row h: Fc (6) | Fi (8) | r | 0
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] = Jc[6 * h + c] * sc;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[6 + c] = Ji[8 * h + c] * sc;
+        v[14] = r[h]; v[15] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[8 * h + c] = make_double2(v[2 * c], v[2 * c + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = make_double2(0.0, 0.0);
     }
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks)
-      if ((uint32_t)(2 * ks) < nblk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ks], v[ks], acc, 0, 0, 0);
+    __syncthreads();
+    const uint32_t w0 = base + 64u * wave;
+    const int nw = w0 >= hi ? 0 : (int)min(64u, hi - w0);   // observations of this wave in this round
+    const double* __restrict__ src = F + (size_t)(64 * wave + (lk >> 1)) * kGramRow + 16 * (lk & 1) + li;
+    for (int ks = 0; 2 * ks < nw; ++ks) {   // k-step ks: rows of observations 2 ks (lk = 0, 1) and 2 ks + 1 (lk = 2, 3)
+      const double v = src[(size_t)(2 * ks) * kGramRow];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+    __syncthreads();
   }
-  // D[i = lk + 4 reg][j = li]
-  double* __restrict__ pp = d.pichunk_part + (size_t)ch * kPiGram;
-  double* __restrict__ ip = d.pichunk_ipart + (size_t)ch * kIntrGram;
+  // D[i = lk + 4 reg][j = li] of the four waves, summed in wave order
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) F[(wave * 4 + reg) * 64 + lane] = acc[reg];
+  __syncthreads();
+  if (wave != 0) return;
+  double* __restrict__ outp = d.pichunk_part + (size_t)ch * kPiGram;
+  double* __restrict__ outi = d.pichunk_ipart + (size_t)ch * kIntrGram;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int i = lk + 4 * reg, j = li;
-    const double val = acc[reg];
+    const double val = ((F[(0 * 4 + reg) * 64 + lane] + F[(1 * 4 + reg) * 64 + lane]) + F[(2 * 4 + reg) * 64 + lane]) + F[(3 * 4 + reg) * 64 + lane];
     if (i < 6) {
-      if (j < 6) { if (i <= j) pp[tri6(i, j)] = val; }
-      else if (j < 14) pp[kPoseGram + i * 8 + (j - 6)] = val;
-      else if (j == 14) pp[21 + i] = val;
+      if (j < 6) { if (i <= j) outp[tri6(i, j)] = val; }
+      else if (j < 14) outp[kPoseGram + i * 8 + (j - 6)] = val;
+      else if (j == 14) outp[21 + i] = val;
     } else if (i < 14) {
-      if (j >= 6 && j < 14) { if (i <= j) ip[tri8(i - 6, j - 6)] = val; }
-      else if (j == 14) ip[36 + (i - 6)] = val;
+      if (j >= 6 && j < 14) { if (i <= j) outi[tri8(i - 6, j - 6)] = val; }
+      else if (j == 14) outi[36 + (i - 6)] = val;
     }
   }
 }
@@ -597,37 +642,6 @@ __global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
     if (t == tri6(c, c)) d.cn_cam[6 * i + c] = v;
 }
 
-// chunk of the observations of one intrinsic: Fi^T Fi (upper, 36), Fi^T r (8), UNscaled
-__global__ __launch_bounds__(256) void ba_intr_gram_kernel(Dev d) {
-  __shared__ double sh[4][kIntrGram];
-  const uint32_t ch = blockIdx.x;
-  double acc[kIntrGram];
-#pragma unroll
-  for (int k = 0; k < kIntrGram; ++k) acc[k] = 0.0;
-  for (uint32_t e = d.igchunk_lo[ch] + threadIdx.x; e < d.igchunk_hi[ch]; e += 256) {
-    const uint32_t o = d.iobs[e];
-    double h[16];
-    load_rec<16>(d.JC + (size_t)o * kJC, h);
-    const double2 rr = *reinterpret_cast<const double2*>(d.JA + (size_t)o * kJA);
-    const double r0 = rr.x, r1 = rr.y;
-    const double* h0 = h; const double* h1 = h + 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-#pragma unroll
-      for (int c = r; c < 8; ++c) acc[tri8(r, c)] += h0[r] * h0[c] + h1[r] * h1[c];
-      acc[36 + r] += h0[r] * r0 + h1[r] * r1;
-    }
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kIntrGram; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) sh[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kIntrGram)
-    d.igram_part[(size_t)ch * kIntrGram + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
 // per intrinsic: 16 groups of threads stride its chunks, fixed-order combine
 __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   __shared__ double sh[16][kIntrGram];
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   const int g = threadIdx.x >> 6, t = threadIdx.x & 63;
   if (t < kIntrGram) {
     double v = 0;
-    if (d.gram_mfma) {
+    {
       // eight (index, value) loads in flight, added in list order: one at a time this was a chain of dependent round trips
       // (73 microseconds for the 4 000 chunks of one intrinsic group)
       const uint32_t q1 = d.intr_pichunk_start[k + 1];
@@ -649,8 +663,6 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += (q + 16 * j < q1) ? x[j] : 0.0;
       }
-    } else {
-      for (uint32_t ch = d.igchunk_start[k] + g; ch < d.igchunk_start[k + 1]; ch += 16) v += d.igram_part[(size_t)ch * kIntrGram + t];
     }
     sh[g][t] = v;
   }
@@ -675,7 +687,8 @@ __global__ void ba_make_scaling_kernel(Dev d, int jacobi) {
 }
 
 // LM diagonal = clamp(diag(Js^T Js), min, max) (levenberg_marquardt_strategy.cc:75-87) + max |gradient| partials
-__global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, double dmax, double* __restrict__ part) {
+// skip_grouped: the points of the point groups get their diagonal (and their share of max |gradient|) inside ba_point_group_kernel
+__global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, double dmax, double* __restrict__ part, int skip_grouped) {
   __shared__ double sh[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   double gm = 0;
@@ -684,7 +697,7 @@ __global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, dou
     d.diag_cam[i] = fmin(fmax(d.cn_cam[i] * s * s, dmin), dmax);
     if (d.cam_active[i]) gm = fabs(d.g_cam[i]);
   }
-  if (i < (size_t)d.n_pts * 3) {
+  if (i < (size_t)d.n_pts * 3 && !(skip_grouped && d.pt_grouped && d.pt_grouped[i / 3])) {
     const double s = d.scale_pt[i];
     d.diag_pt[i] = fmin(fmax(d.cn_pt[i] * s * s, dmin), dmax);
     if (s != 0.0) gm = fmax(gm, fabs(d.g_pt[i]));
@@ -699,7 +712,7 @@ __global__ __launch_bounds__(256) void ba_lm_diag_kernel(Dev d, double dmin, dou
 // per point: V = Es^T Es + D^2 = L L^T, L^-1, h = L^-1 Es^T r
 __global__ __launch_bounds__(256) void ba_point_solve_kernel(Dev d, double inv_radius) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.n_pts) return;
+  if (p >= d.n_pts || (d.pt_grouped && d.pt_grouped[p])) return;
   const uint32_t o0 = d.pt_start[p], o1 = d.pt_start[p + 1];
   const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
   double V[6] = {d.diag_pt[(size_t)p * 3] * inv_radius, 0, 0, d.diag_pt[(size_t)p * 3 + 1] * inv_radius, 0,
@@ -771,6 +784,7 @@ __global__ __launch_bounds__(256) void ba_slot_z_kernel(Dev d) {
   const int c = idx & 7;
   if (s >= (uint32_t)d.n_islots) return;
   const uint32_t p = d.slot_point[s], ik = d.slot_intr[s];
+  if (d.pt_grouped && d.pt_grouped[p]) return;
   const double sp[3] = {d.scale_pt[(size_t)p * 3], d.scale_pt[(size_t)p * 3 + 1], d.scale_pt[(size_t)p * 3 + 2]};
   const double sc = d.scale_cam[6 * d.n_poses + 8 * ik + c];
   double y0 = 0, y1 = 0, y2 = 0;
@@ -844,152 +858,325 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
   }
 }
 
-// One workgroup per point group: Z^T Z of the group's dense (rows x 64) matrix on the f64 matrix cores, upper 16 x 16
-// tiles shared out over the four waves; every (local camera x, local camera y >= x) block and the rhs column are written
-// as one partial block of the pose x pose list (fixed slot, no atomics), summed per destination by ba_schur_assemble.
-__device__ __forceinline__ int group_pair_index(int x, int y) { return x * kGroupCams - x * (x - 1) / 2 + (y - x); }
-// A finished 16 x 16 tile of the group's Z^T Z goes to LDS as partial blocks: out[pair (x <= y)][42] = 6 x 6 block (+ the rhs
-// for x == y from the h column); the blocks then leave as contiguous 336-byte runs (ba_schur_group_kernel's last loop).
+// ------------------------------------------------------------------------------------------------------
+// the fused point-group pass (see GroupList)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int group_pair_pp(int x, int y) { return x * kGroupCams - x * (x - 1) / 2 + (y - x); }   // x <= y
+__device__ __forceinline__ int group_pair_ii(int k, int l) { return k * kGroupIntr - k * (k - 1) / 2 + (l - k); }   // k <= l
+// upper tile t of the kGroupColTiles x kGroupColTiles tile grid, row by row: (0,0) (0,1) .. (0,4) (1,1) ..
+__device__ __forceinline__ void group_tile(int t, int& ti, int& tj) {
+  ti = 0;
+  int n = kGroupColTiles;
+  while (t >= n) { t -= n; --n; ++ti; }
+  tj = ti + t;
+}
+// A finished 16 x 16 tile of the supergroup's Z^T Z goes to LDS as partial blocks of the three product families:
+//   out + 0                      [pair (x <= y)][42]  6 x 6 block (+ the rhs of pose x for x == y, from the h column)
+//   out + 55 * 42                [x * kGroupIntr + k][54]  6 x 8 block
+//   out + 55 * 42 + 20 * 54      [pair (k <= l)][72]  8 x 8 block (+ the rhs of intrinsic k for k == l)
+// Only elements with global column I <= J are defined (the upper triangle of a diagonal block is the whole block).
 __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk) {
+  double* __restrict__ out_pi = out + kGroupPairsPP * kNVpp;
+  double* __restrict__ out_ii = out_pi + kGroupPairsPI * kNVpi;
   const int J = 16 * tj + li;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int I = 16 * ti + lk + 4 * reg;
-    if (I >= 6 * kGroupCams || J > 6 * kGroupCams || I > J) continue;
-    const int x = I / 6, r = I - 6 * x;
-    if (J == 6 * kGroupCams) {   // column of h_p: the rhs of camera x
-      out[group_pair_index(x, x) * 42 + 36 + r] = acc[reg];
-    } else {
+    if (I >= kGroupHCol || J > kGroupHCol || I > J) continue;
+    const bool i_pose = I < 6 * kGroupCams;
+    const int x = i_pose ? I / 6 : (I - 6 * kGroupCams) / 8;
+    const int r = i_pose ? I - 6 * x : (I - 6 * kGroupCams) - 8 * x;
+    if (J == kGroupHCol) {   // column of h_p: the rhs
+      if (i_pose) out[group_pair_pp(x, x) * kNVpp + 36 + r] = acc[reg];
+      else out_ii[group_pair_ii(x, x) * kNVii + 64 + r] = acc[reg];
+    } else if (J < 6 * kGroupCams) {   // I <= J: I is a pose column too
       const int y = J / 6, c = J - 6 * y;
-      out[group_pair_index(x, y) * 42 + r * 6 + c] = acc[reg];
+      out[group_pair_pp(x, y) * kNVpp + r * 6 + c] = acc[reg];
+    } else {
+      const int l = (J - 6 * kGroupCams) / 8, c = (J - 6 * kGroupCams) - 8 * l;
+      if (i_pose) out_pi[(x * kGroupIntr + l) * kNVpi + r * 8 + c] = acc[reg];
+      else out_ii[group_pair_ii(x, l) * kNVii + r * 8 + c] = acc[reg];
     }
   }
 }
-__global__ __launch_bounds__(256) void ba_schur_group_kernel(Dev d, GroupList G, const double* __restrict__ hp, double* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [64 columns][kGroupRS]; before that: the Z records in transit
-  const int g = blockIdx.x, tid = threadIdx.x;
-  // one observation per thread and turn: its 144-byte Z record arrives as nine independent 16-byte loads (neighbouring
-  // lanes read neighbouring records: the observations of a point are contiguous), then 18 LDS stores
-  const uint32_t e0 = G.obs_start[g], ne = G.obs_start[g + 1] - e0;
-  const uint32_t p0 = G.pt_start[g], np = G.pt_start[g + 1] - p0;
-  double hv = 0.0;
-  if ((uint32_t)tid < np * 3) hv = hp[(size_t)G.pts[p0 + tid / 3] * 3 + tid % 3];
-  static_assert(kGroupPts * kGroupCams <= 512, "two observations per thread cover a group");
+
+// One workgroup per supergroup, one thread per observation of the current group. MODE:
+//   kGroupNorms    column norms and gradient of the points (iteration zero: the Jacobi scaling needs the norms first)
+//   kGroupForward  per point V = Es^T Es + D^2 = L L^T, h = L^-1 Es^T r, Z = L^-1 Es^T Fs; S -= Z^T Z, rhs -= Z^T h as
+//                  partial blocks of the three product lists; g_pt, diag_pt and max |g_pt| on the way
+//   kGroupBacksub  the same up to Z, then step_pt = -L^-T (h - sum Z z)
+template <int MODE>
+__global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
+                                                                       double* __restrict__ part_pp, double* __restrict__ part_pi,
+                                                                       double* __restrict__ part_ii) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [column][kGroupRS] -> partial blocks
+  double* const sums = lds + kGroupM;             // [point][16]
+  double* const ptab = sums + kGroupSums;         // [point][12]: L^-1 (6) | h (3)
+  uint32_t* const ek = reinterpret_cast<uint32_t*>(ptab + kGroupPtab);   // [thread]: entry word of the observation
+  uint32_t* const pe = ek + kGroupThreads;        // [point + 1]: first entry (group-relative)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const uint32_t sg = blockIdx.x;
+  const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
+  const uint32_t* __restrict__ cams = G.cams + (size_t)sg * kGroupCams;
+  const uint32_t* __restrict__ intrs = G.intrs + (size_t)sg * kGroupIntr;
+  constexpr int NT = kGroupThreads;
+  d4_t acc[kGroupTilesPerWave];
+  int tti[kGroupTilesPerWave], ttj[kGroupTilesPerWave];
+#pragma unroll
+  for (int j = 0; j < kGroupTilesPerWave; ++j) {
+    acc[j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    group_tile(min(wave + j * kGroupWaves, kGroupTiles - 1), tti[j], ttj[j]);
+  }
+  double gmax = 0.0;
+  for (uint32_t g = g0; g < g1; ++g) {
+    const uint32_t e0 = G.obs_start[g], ne = G.obs_start[g + 1] - e0;
+    const uint32_t p0 = G.pt_start[g], np = G.pt_start[g + 1] - p0;
+    __syncthreads();   // the previous group's readers of M / sums / ptab / ek / pe are done
+    // ---- 1. the observation of this thread: residual, closed-form Jacobian, loss correction, column scales. What stays in
+    // registers until the point factors exist: the scaled rows Es (2 x 3), Fc_s (2 x 6), Fi_s (2 x 8); the per-observation terms
+    // of the point sums go straight to LDS ----
+    const bool has = (uint32_t)tid < ne;
+    int q = 0, x = 0;
+    uint32_t pose_id = 0;
+    double es0[3], es1[3], fc0[6], fc1[6], fi0[8], fi1[8];
+    if (has) {
+      const uint32_t qxk = G.eq[e0 + tid];
+      ek[tid] = qxk;
+      q = (int)(qxk & 255u); x = (int)((qxk >> 8) & 15u);
+      const int kk = (int)((qxk >> 12) & 15u);
+      const double2 xy = G.exy[e0 + tid];
+      pose_id = cams[x];
+      const uint32_t intr_id = intrs[kk];
+      const uint32_t ix = G.pts[p0 + q];
+      double pin[8], pp[6], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)intr_id * 8 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)pose_id * 6 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+      eval_observation<true>(d.model[intr_id], pin, pp, px, obs, r, Ji, Jc, Jp);
+      const double sc = correct_observation(d, (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0, r);
+      // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double e0u = Jp[c] * sc, e1u = Jp[3 + c] * sc;
+        M[(9 + c) * NT + tid] = e0u * e0u + e1u * e1u;
+        M[(12 + c) * NT + tid] = e0u * r[0] + e1u * r[1];
+        if (MODE != kGroupNorms) { const double sp = d.scale_pt[(size_t)ix * 3 + c]; es0[c] = e0u * sp; es1[c] = e1u * sp; }
+      }
+      if (MODE != kGroupNorms) {
+        M[0 * NT + tid] = es0[0] * es0[0] + es1[0] * es1[0]; M[1 * NT + tid] = es0[0] * es0[1] + es1[0] * es1[1];
+        M[2 * NT + tid] = es0[0] * es0[2] + es1[0] * es1[2]; M[3 * NT + tid] = es0[1] * es0[1] + es1[1] * es1[1];
+        M[4 * NT + tid] = es0[1] * es0[2] + es1[1] * es1[2]; M[5 * NT + tid] = es0[2] * es0[2] + es1[2] * es1[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M[(6 + c) * NT + tid] = es0[c] * r[0] + es1[c] * r[1];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double s_ = d.scale_cam[6 * (size_t)pose_id + c] * sc;
+          fc0[c] = Jc[c] * s_; fc1[c] = Jc[6 + c] * s_;
+        }
+        const size_t icol = 6 * (size_t)d.n_poses + 8 * (size_t)intr_id;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const double s_ = d.scale_cam[icol + c] * sc;
+          fi0[c] = Ji[c] * s_; fi1[c] = Ji[8 + c] * s_;
+        }
+      }
+    }
+    if ((uint32_t)tid <= np) pe[tid] = G.pt_estart[p0 + tid] - e0;
+    __syncthreads();
+    // ---- 2. per point: the 15 sums over its observations, in observation order ----
+    for (int it = tid; it < (int)np * 15; it += NT) {
+      const int pq = it / 15, v = it - pq * 15;
+      if (MODE == kGroupNorms && v < 9) continue;
+      double sum = 0.0;
+      for (uint32_t e = pe[pq]; e < pe[pq + 1]; ++e) sum += M[v * NT + e];
+      sums[pq * 16 + v] = sum;
+    }
+    __syncthreads();
+    // ---- 3. per point: norms / gradient out; LM diagonal, V = L L^T, L^-1, h ----
+    if ((uint32_t)tid < np) {
+      const uint32_t p = G.pts[p0 + tid];
+      const double* __restrict__ sm = sums + tid * 16;
+      if (MODE == kGroupNorms) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = sm[9 + c]; d.g_pt[(size_t)p * 3 + c] = sm[12 + c]; }
+      } else {
+        double V[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]}, li6[6];
+        double dg[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double sp = d.scale_pt[(size_t)p * 3 + c];
+          dg[c] = fmin(fmax(sm[9 + c] * sp * sp, dmin), dmax);
+        }
+        V[0] += dg[0] * inv_radius; V[3] += dg[1] * inv_radius; V[5] += dg[2] * inv_radius;
+        if (!chol_inv3(V, li6)) { atomicExch(d.fail, 1); for (int c = 0; c < 6; ++c) li6[c] = 0.0; }
+        double* __restrict__ pt = ptab + tid * 12;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pt[c] = li6[c];
+        pt[6] = li6[0] * sm[6];
+        pt[7] = li6[1] * sm[6] + li6[2] * sm[7];
+        pt[8] = li6[3] * sm[6] + li6[4] * sm[7] + li6[5] * sm[8];
+        if (MODE == kGroupForward) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            d.g_pt[(size_t)p * 3 + c] = sm[12 + c]; d.diag_pt[(size_t)p * 3 + c] = dg[c];
+            gmax = fmax(gmax, fabs(sm[12 + c]));
+          }
+        }
+      }
+    }
+    if (MODE == kGroupNorms) continue;
+    // ---- 4. intrinsic slots: Zint[q][k][:, c] = L_q^-1 sum over the point's observations with local intrinsic k of Es^T Fi_s[:, c] ----
+    // (the sums of step 2 have been read: the terms of this step may replace them)
+    if (has) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NT + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
+      }
+    }
+    __syncthreads();
+    constexpr int kSlotItems = kGroupPts * kGroupIntr * 8;
+    constexpr int kSlotRounds = (kSlotItems + NT - 1) / NT;
+    double zs[kSlotRounds][3];
+#pragma unroll
+    for (int rd = 0; rd < kSlotRounds; ++rd) {
+      const int it = tid + rd * NT;
+      zs[rd][0] = zs[rd][1] = zs[rd][2] = 0.0;
+      if (it < (int)np * kGroupIntr * 8) {
+        const int pq = it / (kGroupIntr * 8), rem = it - pq * (kGroupIntr * 8), k = rem >> 3, c = rem & 7;
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        for (uint32_t e = pe[pq]; e < pe[pq + 1]; ++e) {
+          if ((int)((ek[e] >> 12) & 15u) != k) continue;
+          y0 += M[c * NT + e]; y1 += M[(8 + c) * NT + e]; y2 += M[(16 + c) * NT + e];
+        }
+        const double* __restrict__ pt = ptab + pq * 12;
+        zs[rd][0] = pt[0] * y0;
+        zs[rd][1] = pt[1] * y0 + pt[2] * y1;
+        zs[rd][2] = pt[3] * y0 + pt[4] * y1 + pt[5] * y2;
+      }
+    }
+    const double* __restrict__ ptq = ptab + q * 12;   // L_q^-1 of this thread's point
+    __syncthreads();   // the per-observation terms in M have been read
+    if (MODE == kGroupBacksub) {
+      // ---- 5b. t = h - sum Z z, step = -L^-T t ----
+      if (has) {
+        double u[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {   // Z[:, c] = L_q^-1 Es^T Fc_s[:, c]
+          const double y0 = es0[0] * fc0[c] + es1[0] * fc1[c], y1 = es0[1] * fc0[c] + es1[1] * fc1[c], y2 = es0[2] * fc0[c] + es1[2] * fc1[c];
+          const double z = d.zsol[6 * (size_t)pose_id + c];
+          u[0] += (ptq[0] * y0) * z;
+          u[1] += (ptq[1] * y0 + ptq[2] * y1) * z;
+          u[2] += (ptq[3] * y0 + ptq[4] * y1 + ptq[5] * y2) * z;
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) M[e * NT + tid] = u[e];
+      }
+      double* __restrict__ W = M + 3 * NT;   // [row][point][kGroupIntr * 8]
+#pragma unroll
+      for (int rd = 0; rd < kSlotRounds; ++rd) {
+        const int it = tid + rd * NT;
+        if (it < (int)np * kGroupIntr * 8) {
+          const int rem = it % (kGroupIntr * 8), k = rem >> 3, c = rem & 7;
+          const double z = d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[k] + c];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) W[e * kSlotItems + it] = zs[rd][e] * z;
+        }
+      }
+      __syncthreads();
+      if ((uint32_t)tid < np) {
+        const double* __restrict__ pt = ptab + tid * 12;
+        double t[3] = {pt[6], pt[7], pt[8]};
+        for (uint32_t e = pe[tid]; e < pe[tid + 1]; ++e) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) t[r] -= M[r * NT + e];
+        }
+        for (int j = 0; j < kGroupIntr * 8; ++j) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) t[r] -= W[r * kSlotItems + tid * (kGroupIntr * 8) + j];
+        }
+        const uint32_t p = G.pts[p0 + tid];
+        d.step_pt[(size_t)p * 3 + 0] = -(pt[0] * t[0] + pt[1] * t[1] + pt[3] * t[2]);
+        d.step_pt[(size_t)p * 3 + 1] = -(pt[2] * t[1] + pt[4] * t[2]);
+        d.step_pt[(size_t)p * 3 + 2] = -(pt[5] * t[2]);
+      }
+      continue;
+    }
+    // ---- 5. the staged matrix: rows 3 q .. 3 q + 2, columns 6 x .. (poses), 60 + 8 k .. (intrinsics), kGroupHCol (h) ----
+    for (int i = tid; i < kGroupM / 2; i += NT) reinterpret_cast<double2*>(M)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    if (has) {
+      double* __restrict__ dst = M + (6 * x) * kGroupRS + 3 * q;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double y0 = es0[0] * fc0[c] + es1[0] * fc1[c], y1 = es0[1] * fc0[c] + es1[1] * fc1[c], y2 = es0[2] * fc0[c] + es1[2] * fc1[c];
+        dst[c * kGroupRS + 0] = ptq[0] * y0;
+        dst[c * kGroupRS + 1] = ptq[1] * y0 + ptq[2] * y1;
+        dst[c * kGroupRS + 2] = ptq[3] * y0 + ptq[4] * y1 + ptq[5] * y2;
+      }
+    }
+#pragma unroll
+    for (int rd = 0; rd < kSlotRounds; ++rd) {
+      const int it = tid + rd * NT;
+      if (it < (int)np * kGroupIntr * 8) {
+        const int pq = it / (kGroupIntr * 8), rem = it - pq * (kGroupIntr * 8);   // rem = 8 k + c: the column behind the pose columns
+        double* __restrict__ dst = M + (6 * kGroupCams + rem) * kGroupRS + 3 * pq;
+        dst[0] = zs[rd][0]; dst[1] = zs[rd][1]; dst[2] = zs[rd][2];
+      }
+    }
+    if ((uint32_t)tid < np) {
+      double* __restrict__ dst = M + kGroupHCol * kGroupRS + 3 * tid;
+      dst[0] = ptab[tid * 12 + 6]; dst[1] = ptab[tid * 12 + 7]; dst[2] = ptab[tid * 12 + 8];
+    }
+    __syncthreads();
+    // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
+    const int rows = ((int)(3 * np + 3)) & ~3;
+#pragma unroll
+    for (int j = 0; j < kGroupTilesPerWave; ++j) {
+      if (wave + j * kGroupWaves < kGroupTiles) {   // wave-uniform
+        const double* __restrict__ ca = M + (16 * tti[j] + li) * kGroupRS + lk;
+        const double* __restrict__ cb = M + (16 * ttj[j] + li) * kGroupRS + lk;
+        d4_t a = acc[j];
+        for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0], cb[k0], a, 0, 0, 0);
+        acc[j] = a;
+      }
+    }
+  }
+  if (MODE != kGroupForward) return;
+  // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
+  __syncthreads();
+  double* const out = M;
+#pragma unroll
+  for (int j = 0; j < kGroupTilesPerWave; ++j)
+    if (wave + j * kGroupWaves < kGroupTiles) group_store_tile(acc[j], tti[j], ttj[j], out, li, lk);
   {
-    // Both observations of a thread: first their indices, then every Jacobian / scale / factor load of both, then the Z blocks
-    // are formed (the arithmetic of ba_obs_z_kernel), written to the Z array the back-substitution reads and staged in LDS - the
-    // separate pass over the observations that only produced Z is gone for grouped points.
-    const uint32_t ea = tid, eb = tid + 256;
-    const bool has_a = ea < ne, has_b = eb < ne;
-    const uint32_t ia = has_a ? e0 + ea : e0, ib = has_b ? e0 + eb : e0;
-    const uint32_t qxa = G.obs_qx[ia], qxb = G.obs_qx[ib];
-    const uint32_t oa = G.obs[ia], ob = G.obs[ib], pa = G.obs_pt[ia], pb = G.obs_pt[ib], ca = G.obs_pose[ia], cb = G.obs_pose[ib];
-    double aa[8], ab[8], ba_[16], bb[16], spa[3], spb[3], lia[6], lib[6], sca[6], scb[6];
-    load_rec<8>(d.JA + (size_t)oa * kJA, aa); load_rec<8>(d.JA + (size_t)ob * kJA, ab);
-    load_rec<16>(d.JB + (size_t)oa * kJB, ba_); load_rec<16>(d.JB + (size_t)ob * kJB, bb);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { spa[c] = d.scale_pt[(size_t)pa * 3 + c]; spb[c] = d.scale_pt[(size_t)pb * 3 + c]; }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      lia[c] = d.Linv3[(size_t)pa * 6 + c]; lib[c] = d.Linv3[(size_t)pb * 6 + c];
-      sca[c] = d.scale_cam[6 * ca + c]; scb[c] = d.scale_cam[6 * cb + c];
-    }
-    double Za[18], Zb[18];
-    obs_z_math(aa, ba_, spa, lia, sca, Za);
-    obs_z_math(ab, bb, spb, lib, scb, Zb);
-    // The Z records go to HBM through LDS: record e occupies ten 16-byte slots (nine of data, the observation id in the tenth),
-    // then consecutive threads store consecutive slots - the records of a point are contiguous in Z, so the stores are whole
-    // lines instead of 16 bytes at a 144-byte stride.
-    double2* st = reinterpret_cast<double2*>(lds);
-    if (has_a) {
-#pragma unroll
-      for (int w = 0; w < 9; ++w) st[ea * 10 + w] = make_double2(Za[2 * w], Za[2 * w + 1]);
-      st[ea * 10 + 9] = make_double2(__hiloint2double(0, (int)oa), 0.0);
-    }
-    if (has_b) {
-#pragma unroll
-      for (int w = 0; w < 9; ++w) st[eb * 10 + w] = make_double2(Zb[2 * w], Zb[2 * w + 1]);
-      st[eb * 10 + 9] = make_double2(__hiloint2double(0, (int)ob), 0.0);
-    }
-    __syncthreads();
-    for (uint32_t idx = tid; idx < ne * 9 && !(G.dbg & 1); idx += 256) {
-      const uint32_t rec = idx / 9, slot = idx - rec * 9;
-      const uint32_t o = (uint32_t)__double2loint(st[rec * 10 + 9].x);
-      reinterpret_cast<double2*>(d.Zpose + (size_t)o * 18)[slot] = st[rec * 10 + slot];
-    }
-    __syncthreads();
-    for (int i = tid; i < 64 * kGroupRS / 2; i += 256) reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
-    __syncthreads();
-    if (has_a && !(G.dbg & 8)) {
-      double* __restrict__ dst = lds + (6 * (qxa & 255u)) * kGroupRS + 3 * (qxa >> 8);
-#pragma unroll
-      for (int w = 0; w < 9; ++w) {   // element 2 w = (k, c) with k = (2 w) / 6, c = (2 w) % 6; the next one is (k, c + 1)
-        const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        dst[cc * kGroupRS + k] = Za[2 * w];
-        dst[(cc + 1) * kGroupRS + k] = Za[2 * w + 1];
-      }
-    }
-    if (has_b && !(G.dbg & 8)) {
-      double* __restrict__ dst = lds + (6 * (qxb & 255u)) * kGroupRS + 3 * (qxb >> 8);
-#pragma unroll
-      for (int w = 0; w < 9; ++w) {
-        const int k = (2 * w) / 6, cc = (2 * w) % 6;
-        dst[cc * kGroupRS + k] = Zb[2 * w];
-        dst[(cc + 1) * kGroupRS + k] = Zb[2 * w + 1];
-      }
-    }
+    const double gm = block_max(gmax, sums);   // (block_max synchronises: the tiles above are in LDS afterwards)
+    if (tid == 0) G.gmax_part[sg] = gm;
   }
-  if ((uint32_t)tid < np * 3) lds[(6 * kGroupCams) * kGroupRS + tid] = hv;
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int rows = (G.dbg & 2) ? 0 : ((int)(3 * np + 3) & ~3);
-  const double* __restrict__ col0 = lds + (0 * 16 + li) * kGroupRS + lk;
-  const double* __restrict__ col1 = lds + (1 * 16 + li) * kGroupRS + lk;
-  const double* __restrict__ col2 = lds + (2 * 16 + li) * kGroupRS + lk;
-  const double* __restrict__ col3 = lds + (3 * 16 + li) * kGroupRS + lk;
-  d4_t a0 = d4_t{0.0, 0.0, 0.0, 0.0}, a1 = a0, a2 = a0;
-  const uint32_t* __restrict__ chunk = G.chunk + (size_t)g * kGroupPairs;
-  double* out = lds;   // kGroupPairs x 42 doubles: the operand matrix is overwritten once every wave is through its MFMA loop
-  // tiles (ti, tj), ti <= tj: wave 0: (0,0) (0,1) (0,2); wave 1: (0,3) (1,1) (1,2); wave 2: (1,3) (2,2); wave 3: (2,3) (3,3)
-  if (wave == 0) {
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-      const double f0 = col0[k0], f1 = col1[k0], f2 = col2[k0];
-      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f2, a2, 0, 0, 0);
-    }
-  } else if (wave == 1) {
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-      const double f0 = col0[k0], f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
-      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f3, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, a1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f2, a2, 0, 0, 0);
-    }
-  } else if (wave == 2) {
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-      const double f1 = col1[k0], f2 = col2[k0], f3 = col3[k0];
-      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f3, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, a1, 0, 0, 0);
-    }
-  } else {
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-      const double f2 = col2[k0], f3 = col3[k0];
-      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f3, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f3, f3, a1, 0, 0, 0);
-    }
+  const uint32_t* __restrict__ cpp = G.chunk_pp + (size_t)sg * kGroupPairsPP;
+  const uint32_t* __restrict__ cpi = G.chunk_pi + (size_t)sg * kGroupPairsPI;
+  const uint32_t* __restrict__ cii = G.chunk_ii + (size_t)sg * kGroupPairsII;
+  // (elements a block does not define - the rhs of an off-diagonal block, the lower triangle of a diagonal one - carry whatever
+  // the region held: ba_schur_assemble never uses them)
+  for (int idx = tid; idx < kGroupPairsPP * kNVpp; idx += NT) {
+    const int pair = idx / kNVpp;
+    const uint32_t ch = cpp[pair];
+    if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + (idx - pair * kNVpp)] = out[idx];
   }
-  __syncthreads();   // all operand reads are done: the region now takes the partial blocks
-  if (wave == 0) { group_store_tile(a0, 0, 0, out, li, lk); group_store_tile(a1, 0, 1, out, li, lk); group_store_tile(a2, 0, 2, out, li, lk); }
-  else if (wave == 1) { group_store_tile(a0, 0, 3, out, li, lk); group_store_tile(a1, 1, 1, out, li, lk); group_store_tile(a2, 1, 2, out, li, lk); }
-  else if (wave == 2) { group_store_tile(a0, 1, 3, out, li, lk); group_store_tile(a1, 2, 2, out, li, lk); }
-  else { group_store_tile(a0, 2, 3, out, li, lk); group_store_tile(a1, 3, 3, out, li, lk); }
-  __syncthreads();
-  // the blocks leave as contiguous runs of 42 doubles (elements a block does not define - the rhs of an off-diagonal block, the
-  // lower triangle of a diagonal one - carry whatever the region held: ba_schur_assemble never uses them)
-  for (int idx = tid; idx < kGroupPairs * 42 && !(G.dbg & 4); idx += 256) {
-    const int pair = idx / 42;
-    const uint32_t ch = chunk[pair];
-    if (ch != kNoChunk) part[(size_t)ch * 42 + (idx - pair * 42)] = out[idx];
+  for (int idx = tid; idx < kGroupPairsPI * kNVpi; idx += NT) {
+    const int pair = idx / kNVpi;
+    const uint32_t ch = cpi[pair];
+    if (ch != kNoChunk) part_pi[(size_t)ch * kNVpi + (idx - pair * kNVpi)] = out[kGroupPairsPP * kNVpp + idx];
+  }
+  for (int idx = tid; idx < kGroupPairsII * kNVii; idx += NT) {
+    const int pair = idx / kNVii;
+    const uint32_t ch = cii[pair];
+    if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + (idx - pair * kNVii)] = out[kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + idx];
   }
 }
 
@@ -1018,7 +1205,7 @@ __global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList 
     }
     for (; ch < c1; ++ch) sum += q[(size_t)ch * NV];
   }
-  if (KIND == 0 && L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
+  if (L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
     const uint32_t x1 = L.block_ext0[b + 1];
     uint32_t x = L.block_ext0[b];
     const double* __restrict__ q = L.part + (size_t)L.n_chunks * NV + e;
@@ -1700,7 +1887,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(Dev d) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)d.N) d.step_cam[i] = d.cam_active[i] ? -d.zsol[i] : 0.0;   // step = -solution
-  if (p >= d.n_pts) return;
+  if (p >= d.n_pts || (d.pt_grouped && d.pt_grouped[p])) return;
   double t[3] = {d.hp[(size_t)p * 3], d.hp[(size_t)p * 3 + 1], d.hp[(size_t)p * 3 + 2]};
   for (uint32_t o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
     const uint32_t ip = d.opose[o];
@@ -1996,6 +2183,9 @@ struct mvgx_ba_ctx {
   // LM state (persists across mvgx_ba_lm_iteration calls)
   bool started = false;
   double x_cost = 0, radius = 0, decrease_factor = 2.0, gradient_max_norm = 0;
+  double dmin = 1e-6, dmax = 1e32;     // LM diagonal clamp of the options the current Jacobian evaluation ran with
+  bool gmax_pending = false;           // max |gradient| of the last Jacobian evaluation is still on the device
+  bool gmax_resolved = false;          // ... and arrived with this iteration's step
   bool reuse_diagonal = false, x_norm_valid = false, last_successful = true;
   int iteration = 0, invalid = 0, successful = 0, termination = 1;
   bool finished = false;
@@ -2076,42 +2266,66 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
   BA_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 2, 2, d.scalars,
                      kSCost, 0);
-  if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<kJac>, dim3(1), dim3(256), 0, c->stream, d, poses);
+  if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<kJac>, dim3(1), dim3(256), 0, c->stream, d, poses, 1);
   BA_LAUNCH_CHECK();
   return all_reduce(c, d.scalars + kSCost, 2);
 }
 
-// TrustRegionMinimizer::EvaluateGradientAndJacobian: J, cost, Gram blocks / column norms, gradient (+ scaling at iteration 0)
+// launch of the fused point-group pass in one of its three modes
+template <int MODE>
+void launch_point_groups(mvgx_ba_ctx* c, double inv_radius, double dmin, double dmax) {
+  Dev& d = c->d;
+  hipLaunchKernelGGL(ba_point_group_kernel<MODE>, dim3(d.grp.n_sg), dim3(kGroupThreads), kGroupLds, c->stream, d, d.grp, inv_radius, dmin, dmax,
+                     d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
+                     d.tii.part + (size_t)d.tii.n_chunks * kNVii);
+}
+
+// TrustRegionMinimizer::EvaluateGradientAndJacobian at the current x (its cost is known: c->x_cost - the cost pass of the
+// candidate that became x, or of the start). What depends on the Jacobian alone is formed here: the Gram blocks of the camera
+// columns with their column norms and gradient (ba_cam_gram_kernel evaluates the observations itself), the Jacobian records,
+// column norms and gradients of the points OUTSIDE the point groups, the Jacobi scaling at iteration 0, the LM diagonal. The
+// points of the groups have no stored Jacobian: their norms come from the kGroupNorms pass at iteration 0 (the scaling needs
+// them first) and from the forward pass of the next compute_step afterwards, which also reports their max |gradient|
+// (scalars[kSGmaxGrp]): c->gmax_pending tells lm_iteration to complete gradient_max_norm with it.
 int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, bool iteration_zero) {
   Dev& d = c->d;
   phase_begin(c);
-  int rc = eval<true>(c, d.poses, d.intr, d.pts);
-  if (rc) return rc;
-  if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + kNormPts - 1) / kNormPts), dim3(256), kNormObs * 6 * sizeof(double), c->stream, d);
-  if (d.n_pichunks) {
-    if (d.gram_mfma) hipLaunchKernelGGL(ba_pi_gram_mfma_kernel, dim3((d.n_pichunks + 3) / 4), dim3(256), 0, c->stream, d);
-    else hipLaunchKernelGGL(ba_pi_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  int rc;
+  if (d.n_obs) {
+    if (!d.grp.n_sg) {
+      hipLaunchKernelGGL(ba_linearize_kernel<true>, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.poses, d.intr, d.pts, d.part);
+    } else if (d.grp.n_ungrouped) {
+      hipLaunchKernelGGL(ba_linearize_list_kernel, dim3((d.grp.n_ungrouped + 255) / 256), dim3(256), 0, c->stream, d, d.grp.ungrouped, d.grp.n_ungrouped);
+    }
   }
+  if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<true>, dim3(1), dim3(256), 0, c->stream, d, d.poses, 0);
+  BA_LAUNCH_CHECK();
+  // (always: a point without observations is on neither path's lists, and its norms / factor / step must still be defined)
+  if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
+  if (d.n_pichunks) hipLaunchKernelGGL(ba_cam_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
   if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
   if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
-  if (d.n_igchunks && !d.gram_mfma) hipLaunchKernelGGL(ba_intr_gram_kernel, dim3(d.n_igchunks), dim3(256), 0, c->stream, d);
   if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(1024), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
   if ((rc = all_reduce(c, d.g_cam, d.N))) return rc;
   if (iteration_zero) {
+    if (d.grp.n_sg) launch_point_groups<kGroupNorms>(c, 0.0, 0.0, 0.0);
     hipLaunchKernelGGL(ba_make_scaling_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, opt->jacobi_scaling);
     BA_LAUNCH_CHECK();
   }
+  c->dmin = opt->min_lm_diagonal; c->dmax = opt->max_lm_diagonal;
   hipLaunchKernelGGL(ba_lm_diag_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, opt->min_lm_diagonal,
-                     opt->max_lm_diagonal, d.part);
+                     opt->max_lm_diagonal, d.part, iteration_zero ? 0 : 1);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 1, 1, d.scalars, kSGmax, 1);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.scalars + kSGmax, 1, MVGX_REDUCE_MAX))) return rc;   // point gradients are rank-local
   phase_end(c, kPhJacobian);
-  if ((rc = read_scalars(c))) return rc;
-  c->x_cost = c->h_scalars[kSCost];
-  c->gradient_max_norm = c->h_scalars[kSGmax];
+  c->gmax_pending = !iteration_zero;
+  if (iteration_zero) {   // the first gradient_max_norm is tested before any step is computed
+    if ((rc = read_scalars(c))) return rc;
+    c->gradient_max_norm = c->h_scalars[kSGmax];
+  }
   return MVGX_OK;
 }
 
@@ -2119,21 +2333,24 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
 int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   Dev& d = c->d;
   MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
+  const bool flat = !d.grp.n_sg || d.grp.n_ungrouped;   // some points are on the record-based path
   if (d.n_pts) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
-  if (d.grp.n_groups) {   // grouped observations get their Z inside ba_schur_group_kernel
+  if (d.grp.n_sg) {
     if (d.grp.n_ungrouped)
       hipLaunchKernelGGL(ba_obs_z_kernel, dim3((d.grp.n_ungrouped + 255) / 256), dim3(256), 0, c->stream, d, d.grp.ungrouped, (uint64_t)d.grp.n_ungrouped);
   } else if (d.n_obs) {
     hipLaunchKernelGGL(ba_obs_z_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, (const uint32_t*)nullptr, (uint64_t)d.n_obs);
   }
-  if (d.n_islots) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
+  if (d.n_islots && flat) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if (d.sp.enabled) MVGX_HIP(hipMemsetAsync(d.sp.A, 0, (size_t)d.sp.n_slots * 4096 * sizeof(double), c->stream));
   else MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
+  if (d.grp.n_sg) {
+    launch_point_groups<kGroupForward>(c, inv_radius, c->dmin, c->dmax);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.grp.gmax_part, (int)d.grp.n_sg, 1, 1, d.scalars, kSGmaxGrp, 1);
+  }
   if (d.tpp.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
-  if (d.grp.n_groups)
-    hipLaunchKernelGGL(ba_schur_group_kernel, dim3(d.grp.n_groups), dim3(256), kGroupLds, c->stream, d, d.grp, d.hp, d.tpp.part);
   if (d.tpi.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 8>), dim3(8 * ((d.tpi.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpi, d.Zpose, d.Zint, d.hp, d.opt);
   if (d.tii.n_chunks)
@@ -2387,7 +2604,8 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   if ((rc = factor_and_solve(c))) return rc;
   phase_end(c, kPhSolve);
   phase_begin(c);
-  hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);
+  hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);   // camera steps; points of the record-based path
+  if (d.grp.n_sg) launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax);
   if (c->model_cost_from_jacobian) {   // Ceres' own form (trust_region_minimizer.cc:402-405): one more pass over the Jacobian records
     if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
@@ -2406,9 +2624,17 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     BA_LAUNCH_CHECK();
     if ((rc = all_reduce(c, d.scalars + kSFail, 1, MVGX_REDUCE_MAX))) return rc;
   }
+  if (c->gmax_pending && multi_rank(c)) {   // max |gradient| of the grouped points (rank-local), from this step's forward pass
+    if ((rc = all_reduce(c, d.scalars + kSGmaxGrp, 1, MVGX_REDUCE_MAX))) return rc;
+  }
   phase_end(c, kPhBacksub);
   if ((rc = enqueue_candidate_and_cost(c))) return rc;
   if ((rc = read_scalars(c))) return rc;
+  if (c->gmax_pending) {   // the Jacobian evaluation before this step left its max |gradient| on the device (see there)
+    c->gradient_max_norm = std::max(c->h_scalars[kSGmax], c->h_scalars[kSGmaxGrp]);
+    c->gmax_pending = false;
+    c->gmax_resolved = true;
+  }
   *model_cost_change = c->model_cost_from_jacobian ? c->h_scalars[kSModel] : c->h_scalars[kSModelPt] + c->h_scalars[kSModelCam];
   const bool failed = multi_rank(c) ? (c->h_scalars[kSFail] != 0.0) : (*c->h_fail != 0);
   *ok = !failed && std::isfinite(*model_cost_change);
@@ -2455,6 +2681,7 @@ int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   }
   if ((rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts))) return rc;
   if ((rc = read_scalars(c))) return rc;
+  c->x_cost = c->h_scalars[kSCost];
   c->initial_rmse = rmse_from(c);
   c->radius = opt->initial_radius;
   c->decrease_factor = 2.0;
@@ -2471,13 +2698,20 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   // FinalizeIterationAndCheckIfMinimizerCanContinue
   if (c->last_successful) ++c->successful;
   if (c->iteration >= opt->max_num_iterations) { c->termination = 1; c->finished = true; return MVGX_OK; }
-  if (c->last_successful && c->gradient_max_norm <= opt->gradient_tolerance) { c->termination = 0; c->finished = true; return MVGX_OK; }
+  if (c->last_successful && !c->gmax_pending && c->gradient_max_norm <= opt->gradient_tolerance) { c->termination = 0; c->finished = true; return MVGX_OK; }
   if (c->radius <= opt->min_radius) { c->termination = 0; c->finished = true; return MVGX_OK; }
   ++c->iteration;
   bool ok = false;
   double model_cost_change = 0;
+  c->gmax_resolved = false;
   int rc = compute_step(c, &ok, &model_cost_change);
   if (rc) return rc;
+  // The gradient test of this iteration's start, made now that the max |gradient| of the last Jacobian evaluation has come back
+  // with the step's scalars (one host round trip per iteration instead of two): the step just computed is dropped, as if the
+  // test had fired before it.
+  if (c->gmax_resolved && c->last_successful && c->gradient_max_norm <= opt->gradient_tolerance) {
+    --c->iteration; c->termination = 0; c->finished = true; return MVGX_OK;
+  }
   c->reuse_diagonal = true;
   if (!(ok && model_cost_change > 0.0)) {  // HandleInvalidStep + StepIsInvalid (= StepRejected(0))
     if (++c->invalid >= opt->max_consecutive_invalid_steps) { c->termination = 2; c->finished = true; return MVGX_OK; }
@@ -2497,6 +2731,7 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   const double relative_decrease = (c->x_cost - cand) / model_cost_change;
   if (relative_decrease > opt->min_relative_decrease) {
     if ((rc = accept_candidate(c))) return rc;
+    c->x_cost = cand;   // the cost pass of the candidate IS the cost at the new x
     if ((rc = evaluate_gradient_and_jacobian(c, opt, false))) return rc;
     c->radius = c->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
     c->radius = std::min(opt->max_radius, c->radius);
@@ -2735,17 +2970,19 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     std::vector<uint32_t> fill(intr_pichunk_start.begin(), intr_pichunk_start.end() - 1);
     for (uint32_t ch = 0; ch < (uint32_t)chunk_intr.size(); ++ch) intr_pichunk[fill[chunk_intr[ch]]++] = ch;
   }
-  { const char* env = getenv("MVGX_BA_GRAM"); d.gram_mfma = !(env && !strcmp(env, "valu")); }
-  // observations by intrinsic, cut into chunks
-  std::vector<uint32_t> iobs_start, iobs, igchunk_lo, igchunk_hi, igchunk_start(d.n_intr + 1, 0);
-  counting_sort_indices(no, d.n_intr, T, [&](uint64_t k) { return ointr[k]; }, iobs_start, iobs);
-  for (uint32_t k = 0; k < d.n_intr; ++k) {
-    for (uint32_t lo = iobs_start[k]; lo < iobs_start[k + 1]; lo += kIntrChunk) {
-      igchunk_lo.push_back(lo); igchunk_hi.push_back(std::min<uint32_t>(lo + kIntrChunk, iobs_start[k + 1]));
+  // the Gram kernel's inputs in (pose, intrinsic) order: the observation and its point, contiguous; the pair of every chunk
+  std::vector<uint32_t> pi_pt(no), pichunk_pose(pichunk_lo.size()), pichunk_intr(pichunk_lo.size());
+  std::vector<double2> pi_xy(no);
+  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+    for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+      const uint32_t o = pi_obs[k];
+      pi_pt[k] = opt_[o];
+      pi_xy[k] = make_double2(oxy[2 * (size_t)o], oxy[2 * (size_t)o + 1]);
     }
-    igchunk_start[k + 1] = (uint32_t)igchunk_lo.size();
-  }
-  d.n_igchunks = (int)igchunk_lo.size();
+  });
+  for (uint32_t i = 0; i < d.n_poses; ++i)
+    for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
+      for (uint32_t ch = pi_chunk0[q]; ch < pi_chunk0[q + 1]; ++ch) { pichunk_pose[ch] = i; pichunk_intr[ch] = pi_intr[q]; }
   // slots by intrinsic (ascending slot index): the rows of the intrinsic-intrinsic products
   std::vector<uint32_t> islot_start(d.n_intr + 1, 0), islot(slot_intr.size());
   for (uint32_t s_ : slot_intr) islot_start[s_ + 1]++;
@@ -2762,25 +2999,28 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // Schur products by destination block, generated row by row on host threads. Constant / unused points have Z = 0: only
   // their (a, a) products are listed, so that every diagonal block exists (it carries the Gram block and the rhs).
   TripHost hpp, hpi, hii;
-  // Point groups of the pose x pose products (GroupList): free points with at most kGroupCams distinct poses, ordered by
-  // (lowest pose, highest pose, hash of the pose set); consecutive points join a group while the union of their poses stays within kGroupCams
-  // and the group within kGroupPts points. Groups of fewer than kGroupMinPts points are dissolved (their points stay in
-  // the flat list, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups.
+  // Point groups (GroupList): free points with at most kGroupCams distinct poses and kGroupIntr distinct intrinsics, ordered by
+  // (lowest pose, highest pose, hash of the pose set); consecutive points join a group while the union of their poses stays within
+  // kGroupCams, the union of their intrinsics within kGroupIntr and the group within kGroupPts points. A group that closes because
+  // it is full hands its camera set to the next one: groups with the same set form a supergroup (one workgroup, one set of partial
+  // blocks), up to kMaxSgGroups of them. Groups of fewer than kGroupMinPts points are dissolved unless they continue a supergroup
+  // (their points stay on the record-based path, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups;
+  // so does MVGX_BA_MODEL_COST=jacobian (Ceres' form of the model cost reads the Jacobian records of every observation).
+  constexpr int kMaxSgGroups = 8;
   std::vector<uint8_t> in_group(d.n_pts, 0);
-  std::vector<uint32_t> g_obs_start{0}, g_obs, g_pt_start{0}, g_pts, g_cams;   // g_cams: kGroupCams per group, UINT32_MAX = unused
-  std::vector<uint16_t> g_obs_qx;
-  std::vector<uint8_t> g_pair;   // kGroupPairs per group: some point sees both cameras
+  std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_eobs, g_eq, g_pt_start{0}, g_pts, g_pt_estart, sg_cams, sg_intrs;
+  std::vector<uint8_t> sg_pp, sg_pi, sg_ii;   // per supergroup: which destination blocks exist
   {
     const char* env = getenv("MVGX_BA_GROUPS");
-    if (!(env && atoi(env) == 0) && d.n_poses && d.n_pts) {
+    if (!(env && atoi(env) == 0) && !c->model_cost_from_jacobian && d.n_poses && d.n_pts) {
       std::vector<uint32_t> lo_pose(d.n_pts, UINT32_MAX), hi_pose(d.n_pts, 0);
       std::vector<uint64_t> set_key(d.n_pts, 0);   // (highest pose, order-independent hash of the pose set): equal sets become neighbours
       parallel_for_dynamic(n_pgrains, 1, T, [&](size_t g, unsigned) {
         for (uint32_t j = (uint32_t)(g * 4096), e = (uint32_t)std::min<size_t>(d.n_pts, (g + 1) * 4096); j < e; ++j) {
           const uint32_t o0 = pt_start[j], o1 = pt_start[j + 1];
-          bool ok = pt_free[j] && o1 > o0 && o1 - o0 <= (uint32_t)kGroupCams;
+          bool ok = pt_free[j] && o1 > o0 && o1 - o0 <= (uint32_t)kGroupCams && ptk_start[j + 1] - ptk_start[j] <= (uint32_t)kGroupIntr;
           for (uint32_t o = o0; o < o1 && ok; ++o) {
-            for (uint32_t o2 = o0; o2 < o; ++o2) ok = ok && opose[o2] != opose[o];   // a pose seen twice (shared by two views): flat list
+            for (uint32_t o2 = o0; o2 < o; ++o2) ok = ok && opose[o2] != opose[o];   // a pose seen twice (shared by two views): record path
             lo_pose[j] = std::min(lo_pose[j], opose[o]); hi_pose[j] = std::max(hi_pose[j], opose[o]);
             uint64_t h = (uint64_t)opose[o] * 0x9E3779B97F4A7C15ull;
             h ^= h >> 29;
@@ -2797,81 +3037,132 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       });
       // groups never span two lowest-pose buckets, so the buckets are swept independently (host threads) and their groups
       // stitched in bucket order: the result does not depend on the thread count
-      struct BucketGroups { std::vector<uint32_t> obs_n, obs, pt_n, pts, cams; std::vector<uint16_t> qx; std::vector<uint8_t> pair; };
+      struct BucketGroups {
+        std::vector<uint32_t> sg_n, obs_n, eobs, eq, pt_n, pts, cams, intrs;   // sg_n: groups per supergroup
+        std::vector<uint8_t> pp, pi, ii;
+      };
       std::vector<BucketGroups> per_bucket(d.n_poses);
       parallel_for_dynamic(d.n_poses, 4, T, [&](size_t bucket, unsigned) {
         BucketGroups& B = per_bucket[bucket];
-        std::vector<uint32_t> cams, merged, cur;
-        auto close_group = [&]() {
-          if (cur.size() >= (size_t)kGroupMinPts) {
-            const size_t g = B.pt_n.size();
-            B.cams.resize((g + 1) * kGroupCams, UINT32_MAX);
-            std::copy(cams.begin(), cams.end(), B.cams.begin() + g * kGroupCams);
-            B.pair.resize((g + 1) * kGroupPairs, 0);
-            uint32_t n_obs_g = 0;
-            for (size_t q = 0; q < cur.size(); ++q) {
-              const uint32_t j = cur[q];
-              in_group[j] = 1;
-              B.pts.push_back(j);
-              uint8_t xs[kGroupCams];
-              int nx = 0;
-              for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
-                const int x = (int)(std::lower_bound(cams.begin(), cams.end(), opose[o]) - cams.begin());
-                B.obs.push_back(o);
-                B.qx.push_back((uint16_t)((q << 8) | (unsigned)x));
-                xs[nx++] = (uint8_t)x;
-                ++n_obs_g;
-              }
-              for (int a = 0; a < nx; ++a)
-                for (int b2 = 0; b2 < nx; ++b2)
-                  if (xs[a] <= xs[b2]) B.pair[g * kGroupPairs + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b2] - xs[a])] = 1;
-            }
-            B.obs_n.push_back(n_obs_g);
-            B.pt_n.push_back((uint32_t)cur.size());
+        std::vector<uint32_t> cams, intrs, mc, mi, cur;
+        std::vector<uint32_t> tail_cams, tail_intrs;   // sets of the supergroup under construction (sorted)
+        bool sg_open = false;
+        uint32_t cur_obs = 0;   // observations of `cur`
+        auto local = [](const std::vector<uint32_t>& v, uint32_t id) { return (int)(std::lower_bound(v.begin(), v.end(), id) - v.begin()); };
+        // emits `cur` as a group of the open supergroup (same camera / intrinsic sets) or as the first group of a new one
+        auto emit_group = [&](bool continues) {
+          if (!continues) {
+            B.sg_n.push_back(0);
+            const size_t sgi = B.sg_n.size() - 1;
+            B.cams.resize((sgi + 1) * kGroupCams, 0); B.intrs.resize((sgi + 1) * kGroupIntr, 0);
+            std::copy(cams.begin(), cams.end(), B.cams.begin() + sgi * kGroupCams);
+            std::copy(intrs.begin(), intrs.end(), B.intrs.begin() + sgi * kGroupIntr);
+            B.pp.resize((sgi + 1) * kGroupPairsPP, 0); B.pi.resize((sgi + 1) * kGroupPairsPI, 0); B.ii.resize((sgi + 1) * kGroupPairsII, 0);
+            tail_cams = cams; tail_intrs = intrs;
           }
-          cur.clear(); cams.clear();
+          const size_t sgi = B.sg_n.size() - 1;
+          B.sg_n[sgi]++;
+          uint32_t n_obs_g = 0;
+          for (size_t q = 0; q < cur.size(); ++q) {
+            const uint32_t j = cur[q];
+            in_group[j] = 1;
+            B.pts.push_back(j);
+            uint8_t xs[kGroupCams], ks[kGroupCams];
+            int nx = 0;
+            for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+              const int x = local(tail_cams, opose[o]), k = local(tail_intrs, ointr[o]);
+              B.eobs.push_back(o);
+              B.eq.push_back((uint32_t)q | ((uint32_t)x << 8) | ((uint32_t)k << 12));
+              xs[nx] = (uint8_t)x; ks[nx] = (uint8_t)k; ++nx;
+              ++n_obs_g;
+            }
+            for (int a = 0; a < nx; ++a)
+              for (int b2 = 0; b2 < nx; ++b2) {
+                if (xs[a] <= xs[b2]) B.pp[sgi * kGroupPairsPP + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b2] - xs[a])] = 1;
+                B.pi[sgi * kGroupPairsPI + xs[a] * kGroupIntr + ks[b2]] = 1;
+                if (ks[a] <= ks[b2]) B.ii[sgi * kGroupPairsII + ks[a] * kGroupIntr - ks[a] * (ks[a] - 1) / 2 + (ks[b2] - ks[a])] = 1;
+              }
+          }
+          B.obs_n.push_back(n_obs_g);
+          B.pt_n.push_back((uint32_t)cur.size());
+        };
+        auto close_group = [&]() {
+          const bool continues = sg_open && cams == tail_cams && intrs == tail_intrs && B.sg_n.back() < (uint32_t)kMaxSgGroups;
+          if (cur.size() >= (size_t)kGroupMinPts || (continues && !cur.empty())) { emit_group(continues); sg_open = true; }
+          else sg_open = false;
+          cur.clear(); cur_obs = 0;
         };
         for (uint32_t q = lo_start[bucket]; q < lo_start[bucket + 1]; ++q) {
           const uint32_t j = order[q];
-          uint32_t pc[kGroupCams];
-          int npc = 0;
+          uint32_t pc[kGroupCams], pk[kGroupCams];
+          int npc = 0, npk = 0;
           for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) pc[npc++] = opose[o];
-          std::sort(pc, pc + npc);
-          merged.clear();
-          std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(merged));
-          if (cur.size() == (size_t)kGroupPts || merged.size() > (size_t)kGroupCams) {
+          for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl) pk[npk++] = slot_intr[sl];
+          std::sort(pc, pc + npc); std::sort(pk, pk + npk);
+          if (cur.size() == (size_t)kGroupPts || cur_obs + (uint32_t)npc > (uint32_t)kGroupThreads) close_group();   // full: the next group starts from the same sets (and may continue the supergroup)
+          mc.clear(); mi.clear();
+          std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(mc));
+          std::set_union(intrs.begin(), intrs.end(), pk, pk + npk, std::back_inserter(mi));
+          if (mc.size() > (size_t)kGroupCams || mi.size() > (size_t)kGroupIntr) {
             close_group();
-            merged.assign(pc, pc + npc);
+            sg_open = false;
+            mc.assign(pc, pc + npc); mi.assign(pk, pk + npk);
           }
-          cams = merged;
-          cur.push_back(j);
+          cams = mc; intrs = mi;
+          cur.push_back(j); cur_obs += (uint32_t)npc;
         }
         close_group();
       });
       for (const BucketGroups& B : per_bucket) {
-        for (size_t g = 0; g < B.pt_n.size(); ++g) {
-          g_obs_start.push_back(g_obs_start.back() + B.obs_n[g]);
-          g_pt_start.push_back(g_pt_start.back() + B.pt_n[g]);
+        size_t g = 0;
+        for (size_t sgi = 0; sgi < B.sg_n.size(); ++sgi) {
+          sg_start.push_back(sg_start.back() + B.sg_n[sgi]);
+          for (uint32_t k = 0; k < B.sg_n[sgi]; ++k, ++g) {
+            g_obs_start.push_back(g_obs_start.back() + B.obs_n[g]);
+            g_pt_start.push_back(g_pt_start.back() + B.pt_n[g]);
+          }
         }
-        g_obs.insert(g_obs.end(), B.obs.begin(), B.obs.end());
-        g_obs_qx.insert(g_obs_qx.end(), B.qx.begin(), B.qx.end());
+        g_eobs.insert(g_eobs.end(), B.eobs.begin(), B.eobs.end());
+        g_eq.insert(g_eq.end(), B.eq.begin(), B.eq.end());
         g_pts.insert(g_pts.end(), B.pts.begin(), B.pts.end());
-        g_cams.insert(g_cams.end(), B.cams.begin(), B.cams.end());
-        g_pair.insert(g_pair.end(), B.pair.begin(), B.pair.end());
+        sg_cams.insert(sg_cams.end(), B.cams.begin(), B.cams.end());
+        sg_intrs.insert(sg_intrs.end(), B.intrs.begin(), B.intrs.end());
+        sg_pp.insert(sg_pp.end(), B.pp.begin(), B.pp.end());
+        sg_pi.insert(sg_pi.end(), B.pi.begin(), B.pi.end());
+        sg_ii.insert(sg_ii.end(), B.ii.begin(), B.ii.end());
       }
+      // first entry of every grouped point (its observations are consecutive entries)
+      g_pt_estart.resize(g_pts.size() + 1);
+      { uint32_t e = 0;
+        for (size_t q = 0; q < g_pts.size(); ++q) { g_pt_estart[q] = e; e += pt_start[g_pts[q] + 1] - pt_start[g_pts[q]]; }
+        g_pt_estart[g_pts.size()] = e; }
     }
   }
-  const uint32_t n_groups = (uint32_t)g_pt_start.size() - 1;
-  TripExt gext;
+  const uint32_t n_groups = (uint32_t)g_pt_start.size() - 1, n_sg = (uint32_t)sg_start.size() - 1;
+  // destination blocks of the supergroups, per product family: (row block, column block) -> partial-block id
+  TripExt gext_pp, gext_pi, gext_ii;
   {
     const size_t n_cb = (size_t)d.n_poses + d.n_intr;
-    gext.rows.resize(n_cb);
-    gext.ext_row.assign((size_t)n_groups * kGroupPairs, kNoChunk);
-    for (uint32_t g = 0; g < n_groups; ++g)
+    const uint32_t np_ = d.n_poses;
+    gext_pp.rows.resize(n_cb); gext_pi.rows.resize(n_cb); gext_ii.rows.resize(n_cb);
+    gext_pp.ext_row.assign((size_t)n_sg * kGroupPairsPP, kNoChunk);
+    gext_pi.ext_row.assign((size_t)n_sg * kGroupPairsPI, kNoChunk);
+    gext_ii.ext_row.assign((size_t)n_sg * kGroupPairsII, kNoChunk);
+    for (uint32_t sgi = 0; sgi < n_sg; ++sgi) {
+      const uint32_t* cm = sg_cams.data() + (size_t)sgi * kGroupCams;
+      const uint32_t* im = sg_intrs.data() + (size_t)sgi * kGroupIntr;
       for (int x = 0, t = 0; x < kGroupCams; ++x)
         for (int y = x; y < kGroupCams; ++y, ++t)
-          if (g_pair[(size_t)g * kGroupPairs + t]) gext.rows[g_cams[(size_t)g * kGroupCams + x]].emplace_back(g_cams[(size_t)g * kGroupCams + y], g * kGroupPairs + t);
-    parallel_for_dynamic(n_cb, 16, T, [&](size_t r, unsigned) { std::sort(gext.rows[r].begin(), gext.rows[r].end()); });
+          if (sg_pp[(size_t)sgi * kGroupPairsPP + t]) gext_pp.rows[cm[x]].emplace_back(cm[y], sgi * kGroupPairsPP + t);
+      for (int x = 0; x < kGroupCams; ++x)
+        for (int k = 0; k < kGroupIntr; ++k)
+          if (sg_pi[(size_t)sgi * kGroupPairsPI + x * kGroupIntr + k]) gext_pi.rows[cm[x]].emplace_back(np_ + im[k], sgi * kGroupPairsPI + x * kGroupIntr + k);
+      for (int k = 0, t = 0; k < kGroupIntr; ++k)
+        for (int l = k; l < kGroupIntr; ++l, ++t)
+          if (sg_ii[(size_t)sgi * kGroupPairsII + t]) gext_ii.rows[np_ + im[k]].emplace_back(np_ + im[l], sgi * kGroupPairsII + t);
+    }
+    for (TripExt* e : {&gext_pp, &gext_pi, &gext_ii})
+      parallel_for_dynamic(n_cb, 16, T, [&](size_t r, unsigned) { std::sort(e->rows[r].begin(), e->rows[r].end()); });
   }
   tick("point groups");
   {
@@ -2885,18 +3176,17 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
               if (r <= opose[b] && (pt_free[j] || a == b)) emit(opose[b], a, b);
           }
-        }, hpp, T, &gext))) return rc;
-    for (uint32_t& e : gext.ext_row)
-      if (e != kNoChunk) e += (uint32_t)hpp.chunk_lo.size();   // rows of the partial-sum buffer: after the flat chunks
+        }, hpp, T, &gext_pp))) return rc;
     tick("pose-pose products");
     if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-intrinsic: Z_a^T Zint_slot
           if (r >= np) return;
           for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
             const uint32_t a = pose_obs[q], j = opt_[a];
+            if (in_group[j]) continue;   // all products of the point are formed by its group
             for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
               if (pt_free[j] || sl == oslot[a]) emit(np + slot_intr[sl], a, sl);
           }
-        }, hpi, T))) return rc;
+        }, hpi, T, &gext_pi))) return rc;
     for (size_t b = 0; b < hpi.block_row.size(); ++b) {   // the (pose, intrinsic) pair whose Fc^T Fi belongs to the block
       const uint32_t i = hpi.block_row[b], k = hpi.block_col[b] - d.n_poses;
       for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
@@ -2907,10 +3197,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           const uint32_t k = r - np;
           for (uint32_t q = islot_start[k]; q < islot_start[k + 1]; ++q) {
             const uint32_t sa = islot[q], j = slot_point[sa];
+            if (in_group[j]) continue;
             for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
               if (k <= slot_intr[sb] && (pt_free[j] || sa == sb)) emit(np + slot_intr[sb], sa, sb);
           }
-        }, hii, T))) return rc;
+        }, hii, T, &gext_ii))) return rc;
   }
   for (const TripHost* h : {&hpp, &hpi, &hii})
     for (size_t b = 0; b < h->block_row.size(); ++b) c->h_blocks.emplace_back(h->block_row[b], h->block_col[b]);
@@ -2952,19 +3243,24 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
   UP(cam_active, cam_active); UP(cam_counts, cam_counts); UP(pt_free, pt_free);
   UP(pi_obs, pi_obs); UP(pichunk_lo, pichunk_lo); UP(pichunk_hi, pichunk_hi); UP(pi_chunk0, pi_chunk0); UP(pose_pi_start, pose_pi_start);
-  UP(iobs, iobs); UP(igchunk_lo, igchunk_lo); UP(igchunk_hi, igchunk_hi); UP(igchunk_start, igchunk_start);
+  UP(pichunk_pose, pichunk_pose); UP(pichunk_intr, pichunk_intr); UP(pi_pt, pi_pt); UP(pi_xy, pi_xy);
   UP(intr_pichunk_start, intr_pichunk_start); UP(intr_pichunk, intr_pichunk);
   UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
   UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
   tick("small allocations + uploads");
-  AL(JA, (size_t)kJA * no); AL(JB, (size_t)kJB * no); AL(JC, (size_t)kJC * no);
+  // Jacobian records and stored Z blocks: only when some point is on the record-based path (they are indexed by observation:
+  // with point groups only the entries of the other points are ever touched)
+  bool record_path = false;
+  for (uint32_t j = 0; j < d.n_pts && !record_path; ++j) record_path = !in_group[j] && pt_start[j + 1] > pt_start[j];
+  const uint64_t nrec = record_path ? no : 0;
+  AL(JA, (size_t)kJA * nrec); AL(JB, (size_t)kJB * nrec); AL(JC, (size_t)kJC * nrec);
   AL(cn_cam, d.N); AL(g_cam, d.N); AL(scale_cam, d.N); AL(diag_cam, d.N);
   AL(cn_pt, (size_t)d.n_pts * 3); AL(g_pt, (size_t)d.n_pts * 3); AL(scale_pt, (size_t)d.n_pts * 3); AL(diag_pt, (size_t)d.n_pts * 3);
   AL(pichunk_part, (size_t)d.n_pichunks * kPiGram); AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
-  AL(igram_part, (size_t)d.n_igchunks * kIntrGram); AL(igram, (size_t)d.n_intr * kIntrGram);
+  AL(igram, (size_t)d.n_intr * kIntrGram);
   AL(pichunk_ipart, (size_t)d.n_pichunks * kIntrGram);
   AL(Linv3, (size_t)d.n_pts * 6); AL(hp, (size_t)d.n_pts * 3);
-  AL(Zpose, (size_t)no * 18); AL(Zint, (size_t)d.n_islots * 24);
+  AL(Zpose, (size_t)nrec * 18); AL(Zint, (size_t)(record_path ? d.n_islots : 0) * 24);
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
   tick("large scratch allocations");
   {
@@ -2984,25 +3280,31 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if (h.n_ext && (rc = dev_upload(c->pool, &l.block_ext0, h.block_ext0, c->stream))) return rc;
       if ((rc = dev_alloc(c->pool, &l.part, ((size_t)l.n_chunks + l.n_ext) * e.nv))) return rc;
     }
-    d.grp.n_groups = n_groups;
-    if (const char* env = getenv("MVGX_BA_GROUP_DEBUG")) d.grp.dbg = atoi(env);
+    d.grp.n_groups = n_groups; d.grp.n_sg = n_sg;
     c->n_grouped_points = (uint32_t)g_pts.size();
-    if (n_groups) {
+    if (n_sg) {
+      std::vector<double2> g_exy(g_eobs.size());
+      std::vector<uint32_t> ungrouped;
+      for (size_t e = 0; e < g_eobs.size(); ++e) g_exy[e] = make_double2(oxy[2 * (size_t)g_eobs[e]], oxy[2 * (size_t)g_eobs[e] + 1]);
+      for (uint64_t o = 0; o < no; ++o) if (!in_group[opt_[o]]) ungrouped.push_back((uint32_t)o);
+      d.grp.n_ungrouped = (uint32_t)ungrouped.size();
+      if ((rc = dev_upload(c->pool, &d.grp.sg_start, sg_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.obs, g_obs, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.obs_qx, g_obs_qx, c->stream))) return rc;
-      {
-        std::vector<uint32_t> g_obs_pt(g_obs.size()), g_obs_pose(g_obs.size()), ungrouped;
-        for (size_t e = 0; e < g_obs.size(); ++e) { g_obs_pt[e] = opt_[g_obs[e]]; g_obs_pose[e] = opose[g_obs[e]]; }
-        for (uint64_t o = 0; o < no; ++o) if (!in_group[opt_[o]]) ungrouped.push_back((uint32_t)o);
-        d.grp.n_ungrouped = (uint32_t)ungrouped.size();
-        if ((rc = dev_upload(c->pool, &d.grp.obs_pt, g_obs_pt, c->stream))) return rc;
-        if ((rc = dev_upload(c->pool, &d.grp.obs_pose, g_obs_pose, c->stream))) return rc;
-        if ((rc = dev_upload(c->pool, &d.grp.ungrouped, ungrouped, c->stream))) return rc;
-      }
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.chunk, gext.ext_row, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.pt_estart, g_pt_estart, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.eq, g_eq, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.eobs, g_eobs, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.exy, g_exy, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.cams, sg_cams, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.intrs, sg_intrs, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.chunk_pp, gext_pp.ext_row, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.chunk_pi, gext_pi.ext_row, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.chunk_ii, gext_ii.ext_row, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.ungrouped, ungrouped, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.pt_grouped, in_group, c->stream))) return rc;
+      if ((rc = dev_alloc(c->pool, &d.grp.gmax_part, (size_t)n_sg))) return rc;
+      MVGX_HIP(hipStreamSynchronize(c->stream));   // g_exy / ungrouped are locals
     }
   }
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
@@ -3014,7 +3316,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 #undef AL
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_schur_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupForward>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupBacksub>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));

@@ -527,11 +527,14 @@ def test_multi_device_from_the_environment_only_for_large_problems(monkeypatch):
     dict(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=2, seed=101),
     dict(n_cams=30, n_points=700, track_len=10, model=1, n_intr_groups=1, seed=102),      # ten poses per point: full groups
     dict(n_cams=16, n_points=200, track_len=12, model=1, n_intr_groups=1, seed=103),      # tracks longer than a group: flat list only
+    dict(n_cams=10, n_points=260, track_len=10, model=3, n_intr_groups=2, seed=104),      # one camera set, two intrinsics: supergroups of several groups
+    dict(n_cams=16, n_points=400, track_len=4, model=2, n_intr_groups=8, seed=105),       # many points with more than two intrinsics: both paths mixed
 ])
 def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkeypatch):
-    """pose x pose Schur products: points that share a set of <= 10 poses are multiplied group-wise (Z^T Z of the group's dense
-    matrix, f64 MFMA, one partial block per destination); the result must equal the flat product list's (MVGX_BA_GROUPS=0)
-    and the oracle's; constant points and a pose seen twice by one point stay on the flat list"""
+    """The fused point-group pass (ba_point_group_kernel: Jacobian evaluated in registers, per-point factors in LDS, Z^T Z of the
+    group's dense matrix incl. the intrinsic columns on the f64 MFMA, partial blocks of all three product families, back-substitution
+    by recomputation) must equal the record-based path (MVGX_BA_GROUPS=0: Jacobian records, flat product lists) and the oracle;
+    constant points, a pose seen twice by one point, long tracks and points with more than two intrinsics stay on the record path"""
     sc = synth.ba_scene(**kw)
     sc = synth.add_control_points(sc, n_ctrl=4, weight=10.0)                  # constant points with observations
     sc["obs_pose"] = np.asarray(sc["obs_pose"]).copy()
@@ -544,7 +547,9 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
         monkeypatch.setenv("MVGX_BA_GROUPS", "0")
         c = ba.BaContext(sc); s_f = c.solve(opt); pf, if_, xf = c.read_params(); info_f = c.solver_info(); c.close()
     assert info_f.n_point_groups == 0
-    if kw["track_len"] <= 10:
+    if kw["n_intr_groups"] > 2:
+        assert 0 < info.n_grouped_points < 0.9 * kw["n_points"]
+    elif kw["track_len"] <= 10:
         assert info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]
     else:
         assert info.n_point_groups == 0
@@ -582,21 +587,20 @@ def test_model_cost_from_the_normal_equations_equals_the_jacobian_form(devices, 
     dict(n_cams=9, n_points=150, track_len=5, model=3, n_intr_groups=3, seed=141),
     dict(n_cams=6, n_points=700, track_len=6, model=4, n_intr_groups=1, seed=142),     # 4 200 observations of one intrinsic: several chunks, odd tails
 ])
-def test_gram_blocks_on_the_matrix_cores_equal_the_valu_form(kw, monkeypatch):
-    """Fc^T Fc, Fc^T Fi, Fi^T Fi and the gradients of a (pose, intrinsic) chunk as one F^T F on the f64 matrix cores
-    (ba_pi_gram_mfma_kernel, the intrinsic's blocks from the same pass) against the per-thread accumulation + separate intrinsic
-    pass (MVGX_BA_GRAM=valu): same LM trajectory, parameters equal to rounding"""
+def test_gram_blocks_on_the_matrix_cores_equal_the_oracle(kw):
+    """Fc^T Fc, Fc^T Fi, Fi^T Fi and the gradients of a (pose, intrinsic) chunk as one F^T F on the f64 matrix cores, the rows
+    evaluated by the kernel itself (ba_cam_gram_kernel, the intrinsic's blocks from the same pass; chunks of 512 observations with
+    partial last rounds), with pose priors adding their rows: same LM trajectory as the oracle, parameters equal to rounding"""
     sc = synth.ba_scene(**kw)
     sc = synth.add_pose_priors(sc, sigma=0.005, huber_a=2e-4)
-    opt = ba.default_options(max_num_iterations=4)
+    opt = dict(max_num_iterations=4)
     with _emu.emulated():
-        c = ba.BaContext(sc); s1 = c.solve(opt); p1 = c.read_params(); c.close()
-        monkeypatch.setenv("MVGX_BA_GRAM", "valu")
-        c = ba.BaContext(sc); s2 = c.solve(opt); p2 = c.read_params(); c.close()
-    assert s1.num_iterations == s2.num_iterations and abs(s1.final_cost - s2.final_cost) <= 1e-10 * s2.final_cost
-    assert abs(s1.initial_cost - s2.initial_cost) <= 1e-14 * s2.initial_cost
-    for x, y in zip(p1, p2):
-        assert np.allclose(x, y, rtol=1e-8, atol=1e-9)
+        c = ba.BaContext(sc); s1 = c.solve(ba.default_options(**opt)); p1 = c.read_params(); c.close()
+    rc, osum, opp, opi, opx, _ = _oracle.port_ba_solve(sc, options=_oracle.default_ba_options(**opt))
+    assert rc == 0 and s1.num_iterations == osum.num_iterations and abs(s1.final_cost - osum.final_cost) <= 1e-9 * osum.final_cost
+    assert abs(s1.initial_cost - osum.initial_cost) <= 1e-12 * osum.initial_cost
+    for x, y in zip(p1, (opp, opi, opx)):
+        assert np.allclose(x, y, rtol=1e-8, atol=1e-8)
 
 
 def test_factor_and_invert_kernel_against_numpy():

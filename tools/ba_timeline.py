@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Timeline of ONE LM iteration from a rocprofv3 --kernel-trace CSV (<prefix>_kernel_trace.csv): every launch between two
-consecutive Jacobian evaluations (ba_linearize_kernel<true>), with its start offset, duration and the idle gap before it.
+consecutive Jacobian evaluations (ba_cam_gram_kernel), with its start offset, duration and the idle gap before it.
 Usage: ba_timeline.py <kernel_trace.csv> [which-iteration (default: the last complete one)]"""
 import csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda t: t[0])
-marks = [i for i, k in enumerate(ks) if "ba_linearize_kernel<true>" in k[2]]
+marks = [i for i, k in enumerate(ks) if "ba_cam_gram_kernel" in k[2] or "ba_linearize_kernel<true>" in k[2] and False]
 if len(marks) < 2:
     sys.exit("fewer than two Jacobian evaluations in the trace")
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 2
