@@ -28,20 +28,35 @@ MVGX_HD int intr_param_count(int model) {
          model == kCamFisheye ? 7 : model == kCamSpherical ? 0 : -1;
 }
 
-// p = R(aa) X + t. When kJac: R = dp/dX (row-major 3x3) and A = dp/d(aa) (row-major 3x3).
-template <bool kJac>
-MVGX_HD void transform_point(const double* pose, const double* X, double p[3], double R[9], double A[9]) {
+// The terms of the rotation that depend on the pose alone (one sqrt, one sin, one cos, one division): a kernel that evaluates
+// many observations of one pose forms them once. trig = {cos theta, sin theta, 1 - cos theta, w0, w1, w2, 1 / theta, flag};
+// flag = 0 selects the first-order branch (theta^2 <= DBL_EPSILON, ceres/rotation.h:563-622), the other entries are unused then.
+constexpr int kPoseTrig = 8;
+MVGX_HD void pose_trig(const double* pose, double* trig) {
   const double a0 = pose[0], a1 = pose[1], a2 = pose[2];
-  const double x0 = X[0], x1 = X[1], x2 = X[2];
   const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
   if (theta2 > 2.220446049250313e-16 /* DBL_EPSILON */) {
     const double theta = sqrt(theta2);
     const double c = cos(theta), s = sin(theta);
     const double ti = 1.0 / theta;
-    const double w0 = a0 * ti, w1 = a1 * ti, w2 = a2 * ti;
+    trig[0] = c; trig[1] = s; trig[2] = 1.0 - c;
+    trig[3] = a0 * ti; trig[4] = a1 * ti; trig[5] = a2 * ti;
+    trig[6] = ti; trig[7] = 1.0;
+  } else {
+    for (int k = 0; k < 7; ++k) trig[k] = 0.0;
+    trig[7] = 0.0;
+  }
+}
+
+// p = R(aa) X + t with the pose's rotation terms given. When kJac: R = dp/dX (row-major 3x3) and A = dp/d(aa) (row-major 3x3).
+template <bool kJac>
+MVGX_HD void transform_point_t(const double* pose, const double* trig, const double* X, double p[3], double R[9], double A[9]) {
+  const double x0 = X[0], x1 = X[1], x2 = X[2];
+  if (trig[7] != 0.0) {
+    const double c = trig[0], s = trig[1], k = trig[2];
+    const double w0 = trig[3], w1 = trig[4], w2 = trig[5], ti = trig[6];
     const double wx0 = w1 * x2 - w2 * x1, wx1 = w2 * x0 - w0 * x2, wx2 = w0 * x1 - w1 * x0;
     const double wdx = w0 * x0 + w1 * x1 + w2 * x2;
-    const double k = 1.0 - c;
     const double tmp = wdx * k;
     p[0] = x0 * c + wx0 * s + w0 * tmp;
     p[1] = x1 * c + wx1 * s + w1 * tmp;
@@ -69,6 +84,7 @@ MVGX_HD void transform_point(const double* pose, const double* X, double p[3], d
     }
   } else {
     // first-order branch: p = X + aa x X
+    const double a0 = pose[0], a1 = pose[1], a2 = pose[2];
     p[0] = x0 + (a1 * x2 - a2 * x1);
     p[1] = x1 + (a2 * x0 - a0 * x2);
     p[2] = x2 + (a0 * x1 - a1 * x0);
@@ -84,15 +100,23 @@ MVGX_HD void transform_point(const double* pose, const double* X, double p[3], d
   p[0] += pose[3]; p[1] += pose[4]; p[2] += pose[5];
 }
 
+// p = R(aa) X + t. When kJac: R = dp/dX (row-major 3x3) and A = dp/d(aa) (row-major 3x3).
+template <bool kJac>
+MVGX_HD void transform_point(const double* pose, const double* X, double p[3], double R[9], double A[9]) {
+  double trig[kPoseTrig];
+  pose_trig(pose, trig);
+  transform_point_t<kJac>(pose, trig, X, p, R, A);
+}
+
 // Residual r = project(intr, pose, X) - obs and, when kJac, the row-major Jacobians
 //   Ji (2 x 8, columns beyond the model's parameter count are 0), Jc (2 x 6: angle-axis | t), Jp (2 x 3).
 // Functors of sfm_data_BA_ceres_camera_functor.hpp: pinhole :103-194, radial K1 :207-300, radial K3 :313-412,
 // Brown T2 :425-545, fisheye :548-660, spherical :662-760.
 template <bool kJac>
-MVGX_HD void eval_observation(int model, const double* intr, const double* pose, const double* X, const double* obs,
-                              double r[2], double* Ji, double* Jc, double* Jp) {
+MVGX_HD void eval_observation_t(int model, const double* intr, const double* pose, const double* trig, const double* X, const double* obs,
+                                double r[2], double* Ji, double* Jc, double* Jp) {
   double p[3], R[9], A[9];
-  transform_point<kJac>(pose, X, p, R, A);
+  transform_point_t<kJac>(pose, trig, X, p, R, A);
   double g00, g01, g02, g10, g11, g12;   // G = d r / d p (2 x 3)
   if (kJac)
     for (int c = 0; c < 16; ++c) Ji[c] = 0.0;
@@ -187,6 +211,14 @@ MVGX_HD void eval_observation(int model, const double* intr, const double* pose,
     Jc[3] = g00; Jc[4] = g01; Jc[5] = g02;
     Jc[9] = g10; Jc[10] = g11; Jc[11] = g12;
   }
+}
+
+template <bool kJac>
+MVGX_HD void eval_observation(int model, const double* intr, const double* pose, const double* X, const double* obs,
+                              double r[2], double* Ji, double* Jc, double* Jp) {
+  double trig[kPoseTrig];
+  pose_trig(pose, trig);
+  eval_observation_t<kJac>(model, intr, pose, trig, X, obs, r, Ji, Jc, Jp);
 }
 
 // PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): r = weight o (C(pose) - prior), C = -R(-aa) t.

@@ -120,12 +120,15 @@ constexpr int kGroupWaves = kGroupThreads / 64;
 constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves;
 constexpr int kGroupRS = 3 * kGroupPts + 2;                       // doubles between columns in LDS, = 2 x odd (mod 32): the 16 columns x 2 rows a
                                                                   // half wave reads as an MFMA operand then fall on distinct banks
-static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255, "group tile layout");
+static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255 && kGroupIntr == 2, "group tile layout (the slot ranges assume two local intrinsics)");
 constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
 constexpr int kGroupM = kGroupCols * kGroupRS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
-static_assert(kGroupM >= 24 * kGroupThreads && kGroupM >= kGroupOut && kGroupM >= 3 * kGroupThreads + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
-constexpr int kGroupSums = kGroupPts * 16, kGroupPtab = kGroupPts * 12;
-constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab) * (int)sizeof(double) + (kGroupThreads + kGroupPts + 1) * (int)sizeof(uint32_t);
+static_assert(kGroupM >= 24 * (kGroupThreads + 1) && kGroupM >= kGroupOut && kGroupM >= 3 * (kGroupThreads + 1) + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
+constexpr int kGroupSums = kGroupPts * 20, kGroupPtab = kGroupPts * 12;
+constexpr int kGroupCamRow = 6 + kPoseTrig + 6;                     // per local pose: parameters | rotation terms | column scales
+constexpr int kGroupIntrRow = 8 + 8;                              // per local intrinsic: parameters | column scales
+constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr;   // ... and the solution's components
+constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr) * (int)sizeof(uint32_t);
 constexpr int kGroupMinPts = 8;                                   // smaller groups go to the record-based path
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 enum GroupMode { kGroupNorms = 0, kGroupForward = 1, kGroupBacksub = 2 };
@@ -136,6 +139,7 @@ struct GroupList {
   uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
   uint32_t* pts = nullptr;         // grouped point -> point
   uint32_t* pt_estart = nullptr;   // grouped point (+ 1) -> its first entry
+  uint32_t* pt_ksplit = nullptr;   // grouped point -> the first of its entries with local intrinsic 1 (entries of a point: intrinsic 0 first)
   uint32_t* eq = nullptr;          // entry: local point | local pose << 8 | local intrinsic << 12
   uint32_t* eobs = nullptr;        // entry: observation index (weights / control flags)
   double2* exy = nullptr;          // entry: the observation
@@ -905,6 +909,11 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
 //   kGroupForward  per point V = Es^T Es + D^2 = L L^T, h = L^-1 Es^T r, Z = L^-1 Es^T Fs; S -= Z^T Z, rhs -= Z^T h as
 //                  partial blocks of the three product lists; g_pt, diag_pt and max |g_pt| on the way
 //   kGroupBacksub  the same up to Z, then step_pt = -L^-T (h - sum Z z)
+// MVGX_BA_GROUP_DEBUG=1: shader clocks of thread 0 of every workgroup between the phases of ba_point_group_kernel, summed per phase
+// (0 observation, 1 point sums, 2 point factors, 3 slots, 4 back-substitution, 5 matrix staging, 6 MFMA, 7 partial blocks out)
+__device__ unsigned long long g_group_stamps[8];
+__device__ int g_group_debug;
+#define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_group_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
 template <int MODE>
 __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
@@ -913,14 +922,21 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
   double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [column][kGroupRS] -> partial blocks
   double* const sums = lds + kGroupM;             // [point][16]
   double* const ptab = sums + kGroupSums;         // [point][12]: L^-1 (6) | h (3)
-  uint32_t* const ek = reinterpret_cast<uint32_t*>(ptab + kGroupPtab);   // [thread]: entry word of the observation
+  double* const ctab = ptab + kGroupPtab;         // [local pose][kGroupCamRow]: parameters | rotation terms | column scales
+  double* const itab = ctab + kGroupCams * kGroupCamRow;   // [local intrinsic][kGroupIntrRow]: parameters | column scales
+  double* const ztab = itab + kGroupIntr * kGroupIntrRow;  // back-substitution: the reduced solution at the group's columns (the staged matrix's column order)
+  uint32_t* const ek = reinterpret_cast<uint32_t*>(ztab + 6 * kGroupCams + 8 * kGroupIntr);   // [thread]: entry word of the observation
   uint32_t* const pe = ek + kGroupThreads;        // [point + 1]: first entry (group-relative)
+  uint32_t* const pks = pe + kGroupPts + 1;       // [point]: first entry of the point's observations with local intrinsic 1
+  int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t sg = blockIdx.x;
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
   const uint32_t* __restrict__ cams = G.cams + (size_t)sg * kGroupCams;
   const uint32_t* __restrict__ intrs = G.intrs + (size_t)sg * kGroupIntr;
   constexpr int NT = kGroupThreads;
+  constexpr int NSUM = MODE == kGroupBacksub ? 18 : 15;   // per-observation terms summed per point (back-substitution: + Es^T (Fs z))
+  constexpr int NS = kGroupThreads + 1;   // stride of the per-observation terms [value][thread]: odd, so that the readers of one observation's values hit distinct banks
   d4_t acc[kGroupTilesPerWave];
   int tti[kGroupTilesPerWave], ttj[kGroupTilesPerWave];
 #pragma unroll
@@ -928,78 +944,145 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     acc[j] = d4_t{0.0, 0.0, 0.0, 0.0};
     group_tile(min(wave + j * kGroupWaves, kGroupTiles - 1), tti[j], ttj[j]);
   }
+  // The cameras of a supergroup are the same for all of its groups: their parameters, the rotation terms that depend on the pose
+  // alone (sqrt, sin, cos, division: once per pose here instead of once per observation), the Jacobi scales of their columns and -
+  // for the back-substitution - the reduced solution at those columns go to LDS once; the observations then read LDS rows instead
+  // of gathering 30 doubles each through the vector memory path.
+  if (tid < kGroupCams) {
+    const uint32_t ip = cams[tid];
+    double pp[6], trig[kPoseTrig];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
+    pose_trig(pp, trig);
+    double* __restrict__ row = ctab + tid * kGroupCamRow;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { row[k] = pp[k]; row[6 + kPoseTrig + k] = d.scale_cam[6 * (size_t)ip + k]; }
+#pragma unroll
+    for (int k = 0; k < kPoseTrig; ++k) row[6 + k] = trig[k];
+  } else if (tid >= 64 && tid < 64 + kGroupIntr * kGroupIntrRow) {
+    const int k = (tid - 64) / kGroupIntrRow, j = (tid - 64) - k * kGroupIntrRow;
+    const uint32_t ii = intrs[k];
+    itab[k * kGroupIntrRow + j] = j < 8 ? d.intr[(size_t)ii * 8 + j] : d.scale_cam[6 * (size_t)d.n_poses + 8 * (size_t)ii + (j - 8)];
+    if (j == 0) imodel[k] = d.model[ii];
+  } else if (MODE == kGroupBacksub && tid >= 128 && tid < 128 + 6 * kGroupCams + 8 * kGroupIntr) {
+    const int j = tid - 128;
+    ztab[j] = j < 6 * kGroupCams ? d.zsol[6 * (size_t)cams[j / 6] + j % 6]
+                                 : d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[(j - 6 * kGroupCams) >> 3] + ((j - 6 * kGroupCams) & 7)];
+  }
   double gmax = 0.0;
+  const bool stamping = g_group_debug && tid == 0;
+  long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0;
+  // The first words of a group (its ranges, this thread's entry, the point of a point thread) are fetched one group ahead: they
+  // head the chains of dependent loads (entry -> ids -> parameters), which then start from registers.
+  uint32_t nx_e0 = G.obs_start[g0], nx_ne = G.obs_start[g0 + 1] - nx_e0, nx_p0 = G.pt_start[g0], nx_np = G.pt_start[g0 + 1] - nx_p0;
+  uint32_t nx_qxk = (uint32_t)tid < nx_ne ? G.eq[nx_e0 + tid] : 0u;
+  double2 nx_xy = (uint32_t)tid < nx_ne ? G.exy[nx_e0 + tid] : make_double2(0.0, 0.0);
+  uint32_t nx_pt = (uint32_t)tid < nx_np ? G.pts[nx_p0 + tid] : 0u;
+  uint32_t nx_pe = (uint32_t)tid <= nx_np ? G.pt_estart[nx_p0 + tid] - nx_e0 : 0u;
+  uint32_t nx_pk = MODE == kGroupForward && (uint32_t)tid < nx_np ? G.pt_ksplit[nx_p0 + tid] - nx_e0 : 0u;
   for (uint32_t g = g0; g < g1; ++g) {
-    const uint32_t e0 = G.obs_start[g], ne = G.obs_start[g + 1] - e0;
-    const uint32_t p0 = G.pt_start[g], np = G.pt_start[g + 1] - p0;
+    const uint32_t e0 = nx_e0, ne = nx_ne, p0 = nx_p0, np = nx_np;
+    const uint32_t qxk = nx_qxk, my_pt = nx_pt, my_pe = nx_pe, my_pk = nx_pk;
+    const double2 xy = nx_xy;
+    if (g + 1 < g1) {
+      nx_e0 = G.obs_start[g + 1]; nx_ne = G.obs_start[g + 2] - nx_e0; nx_p0 = G.pt_start[g + 1]; nx_np = G.pt_start[g + 2] - nx_p0;
+      nx_qxk = (uint32_t)tid < nx_ne ? G.eq[nx_e0 + tid] : 0u;
+      nx_xy = (uint32_t)tid < nx_ne ? G.exy[nx_e0 + tid] : make_double2(0.0, 0.0);
+      nx_pt = (uint32_t)tid < nx_np ? G.pts[nx_p0 + tid] : 0u;
+      nx_pe = (uint32_t)tid <= nx_np ? G.pt_estart[nx_p0 + tid] - nx_e0 : 0u;
+      nx_pk = MODE == kGroupForward && (uint32_t)tid < nx_np ? G.pt_ksplit[nx_p0 + tid] - nx_e0 : 0u;
+    }
+    // a point thread's scales: fetched here, used after the point sums (a dependent load there would stall the whole workgroup)
+    double my_sp[3] = {0.0, 0.0, 0.0};
+    if (MODE != kGroupNorms && (uint32_t)tid < np) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) my_sp[c] = d.scale_pt[(size_t)my_pt * 3 + c];
+    }
     __syncthreads();   // the previous group's readers of M / sums / ptab / ek / pe are done
     // ---- 1. the observation of this thread: residual, closed-form Jacobian, loss correction, column scales. What stays in
     // registers until the point factors exist: the scaled rows Es (2 x 3), Fc_s (2 x 6), Fi_s (2 x 8); the per-observation terms
     // of the point sums go straight to LDS ----
     const bool has = (uint32_t)tid < ne;
     int q = 0, x = 0;
-    uint32_t pose_id = 0;
     double es0[3], es1[3], fc0[6], fc1[6], fi0[8], fi1[8];
     if (has) {
-      const uint32_t qxk = G.eq[e0 + tid];
       ek[tid] = qxk;
       q = (int)(qxk & 255u); x = (int)((qxk >> 8) & 15u);
       const int kk = (int)((qxk >> 12) & 15u);
-      const double2 xy = G.exy[e0 + tid];
-      pose_id = cams[x];
-      const uint32_t intr_id = intrs[kk];
       const uint32_t ix = G.pts[p0 + q];
-      double pin[8], pp[6], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)intr_id * 8 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)pose_id * 6 + k];
+      double pin[8], pp[6], trig[kPoseTrig], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
-      eval_observation<true>(d.model[intr_id], pin, pp, px, obs, r, Ji, Jc, Jp);
+      const double* __restrict__ crow = ctab + x * kGroupCamRow;
+      const double* __restrict__ irow = itab + kk * kGroupIntrRow;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pp[k] = crow[k];
+#pragma unroll
+      for (int k = 0; k < kPoseTrig; ++k) trig[k] = crow[6 + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pin[k] = irow[k];
+      eval_observation_t<true>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
       const double sc = correct_observation(d, (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0, r);
       // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const double e0u = Jp[c] * sc, e1u = Jp[3 + c] * sc;
-        M[(9 + c) * NT + tid] = e0u * e0u + e1u * e1u;
-        M[(12 + c) * NT + tid] = e0u * r[0] + e1u * r[1];
+        M[(9 + c) * NS + tid] = e0u * e0u + e1u * e1u;
+        M[(12 + c) * NS + tid] = e0u * r[0] + e1u * r[1];
         if (MODE != kGroupNorms) { const double sp = d.scale_pt[(size_t)ix * 3 + c]; es0[c] = e0u * sp; es1[c] = e1u * sp; }
       }
       if (MODE != kGroupNorms) {
-        M[0 * NT + tid] = es0[0] * es0[0] + es1[0] * es1[0]; M[1 * NT + tid] = es0[0] * es0[1] + es1[0] * es1[1];
-        M[2 * NT + tid] = es0[0] * es0[2] + es1[0] * es1[2]; M[3 * NT + tid] = es0[1] * es0[1] + es1[1] * es1[1];
-        M[4 * NT + tid] = es0[1] * es0[2] + es1[1] * es1[2]; M[5 * NT + tid] = es0[2] * es0[2] + es1[2] * es1[2];
+        M[0 * NS + tid] = es0[0] * es0[0] + es1[0] * es1[0]; M[1 * NS + tid] = es0[0] * es0[1] + es1[0] * es1[1];
+        M[2 * NS + tid] = es0[0] * es0[2] + es1[0] * es1[2]; M[3 * NS + tid] = es0[1] * es0[1] + es1[1] * es1[1];
+        M[4 * NS + tid] = es0[1] * es0[2] + es1[1] * es1[2]; M[5 * NS + tid] = es0[2] * es0[2] + es1[2] * es1[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) M[(6 + c) * NT + tid] = es0[c] * r[0] + es1[c] * r[1];
+        for (int c = 0; c < 3; ++c) M[(6 + c) * NS + tid] = es0[c] * r[0] + es1[c] * r[1];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const double s_ = d.scale_cam[6 * (size_t)pose_id + c] * sc;
+          const double s_ = crow[6 + kPoseTrig + c] * sc;
           fc0[c] = Jc[c] * s_; fc1[c] = Jc[6 + c] * s_;
         }
-        const size_t icol = 6 * (size_t)d.n_poses + 8 * (size_t)intr_id;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const double s_ = d.scale_cam[icol + c] * sc;
+          const double s_ = irow[8 + c] * sc;
           fi0[c] = Ji[c] * s_; fi1[c] = Ji[8 + c] * s_;
+        }
+        if (MODE == kGroupBacksub) {
+          // sum_e Z_e z = L^-1 sum_e Es^T (Fs z): the two-vector w = Fc_s z_pose + Fi_s z_intr of this observation, then Es^T w
+          double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) { const double z = ztab[6 * x + c]; w0 += fc0[c] * z; w1 += fc1[c] * z; }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) { const double z = ztab[6 * kGroupCams + 8 * kk + c]; w0 += fi0[c] * z; w1 += fi1[c] * z; }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) M[(15 + c) * NS + tid] = es0[c] * w0 + es1[c] * w1;
         }
       }
     }
-    if ((uint32_t)tid <= np) pe[tid] = G.pt_estart[p0 + tid] - e0;
+    if ((uint32_t)tid <= np) pe[tid] = my_pe;
+    if (MODE == kGroupForward && (uint32_t)tid < np) pks[tid] = my_pk;
     __syncthreads();
+    MVGX_GSTAMP(0);
     // ---- 2. per point: the 15 sums over its observations, in observation order ----
-    for (int it = tid; it < (int)np * 15; it += NT) {
-      const int pq = it / 15, v = it - pq * 15;
+    for (int it = tid; it < (int)np * NSUM; it += NT) {
+      const int pq = it / NSUM, v = it - pq * NSUM;
       if (MODE == kGroupNorms && v < 9) continue;
+      const uint32_t elo = pe[pq], ehi = pe[pq + 1];
+      const double* __restrict__ src = M + v * NS;
+      double term[kGroupCams];
+#pragma unroll
+      for (int j = 0; j < kGroupCams; ++j) term[j] = src[min(elo + (uint32_t)j, ehi - 1)];   // independent loads, all in flight
       double sum = 0.0;
-      for (uint32_t e = pe[pq]; e < pe[pq + 1]; ++e) sum += M[v * NT + e];
-      sums[pq * 16 + v] = sum;
+#pragma unroll
+      for (int j = 0; j < kGroupCams; ++j) sum += elo + (uint32_t)j < ehi ? term[j] : 0.0;
+      sums[pq * 20 + v] = sum;
     }
     __syncthreads();
+    MVGX_GSTAMP(1);
     // ---- 3. per point: norms / gradient out; LM diagonal, V = L L^T, L^-1, h ----
     if ((uint32_t)tid < np) {
-      const uint32_t p = G.pts[p0 + tid];
-      const double* __restrict__ sm = sums + tid * 16;
+      const uint32_t p = my_pt;
+      const double* __restrict__ sm = sums + tid * 20;
       if (MODE == kGroupNorms) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = sm[9 + c]; d.g_pt[(size_t)p * 3 + c] = sm[12 + c]; }
@@ -1007,10 +1090,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
         double V[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]}, li6[6];
         double dg[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double sp = d.scale_pt[(size_t)p * 3 + c];
-          dg[c] = fmin(fmax(sm[9 + c] * sp * sp, dmin), dmax);
-        }
+        for (int c = 0; c < 3; ++c) dg[c] = fmin(fmax(sm[9 + c] * my_sp[c] * my_sp[c], dmin), dmax);
         V[0] += dg[0] * inv_radius; V[3] += dg[1] * inv_radius; V[5] += dg[2] * inv_radius;
         if (!chol_inv3(V, li6)) { atomicExch(d.fail, 1); for (int c = 0; c < 6; ++c) li6[c] = 0.0; }
         double* __restrict__ pt = ptab + tid * 12;
@@ -1019,6 +1099,14 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
         pt[6] = li6[0] * sm[6];
         pt[7] = li6[1] * sm[6] + li6[2] * sm[7];
         pt[8] = li6[3] * sm[6] + li6[4] * sm[7] + li6[5] * sm[8];
+        if (MODE == kGroupBacksub) {   // step = -L^-T (h - L^-1 sum_e Es^T (Fs z))
+          const double t0 = pt[6] - li6[0] * sm[15];
+          const double t1 = pt[7] - (li6[1] * sm[15] + li6[2] * sm[16]);
+          const double t2 = pt[8] - (li6[3] * sm[15] + li6[4] * sm[16] + li6[5] * sm[17]);
+          d.step_pt[(size_t)p * 3 + 0] = -(li6[0] * t0 + li6[1] * t1 + li6[3] * t2);
+          d.step_pt[(size_t)p * 3 + 1] = -(li6[2] * t1 + li6[4] * t2);
+          d.step_pt[(size_t)p * 3 + 2] = -(li6[5] * t2);
+        }
         if (MODE == kGroupForward) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -1028,14 +1116,15 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
         }
       }
     }
-    if (MODE == kGroupNorms) continue;
+    MVGX_GSTAMP(2);
+    if (MODE != kGroupForward) continue;
     // ---- 4. intrinsic slots: Zint[q][k][:, c] = L_q^-1 sum over the point's observations with local intrinsic k of Es^T Fi_s[:, c] ----
     // (the sums of step 2 have been read: the terms of this step may replace them)
     if (has) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NT + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
+        for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NS + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
       }
     }
     __syncthreads();
@@ -1049,10 +1138,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       if (it < (int)np * kGroupIntr * 8) {
         const int pq = it / (kGroupIntr * 8), rem = it - pq * (kGroupIntr * 8), k = rem >> 3, c = rem & 7;
         double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-        for (uint32_t e = pe[pq]; e < pe[pq + 1]; ++e) {
-          if ((int)((ek[e] >> 12) & 15u) != k) continue;
-          y0 += M[c * NT + e]; y1 += M[(8 + c) * NT + e]; y2 += M[(16 + c) * NT + e];
-        }
+        // the observations of a point are ordered by local intrinsic (host): those of intrinsic k are one contiguous range
+        const uint32_t elo = k == 0 ? pe[pq] : pks[pq], ehi = k == 0 ? pks[pq] : pe[pq + 1];
+        for (uint32_t e = elo; e < ehi; ++e) { y0 += M[c * NS + e]; y1 += M[(8 + c) * NS + e]; y2 += M[(16 + c) * NS + e]; }
         const double* __restrict__ pt = ptab + pq * 12;
         zs[rd][0] = pt[0] * y0;
         zs[rd][1] = pt[1] * y0 + pt[2] * y1;
@@ -1061,51 +1149,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     }
     const double* __restrict__ ptq = ptab + q * 12;   // L_q^-1 of this thread's point
     __syncthreads();   // the per-observation terms in M have been read
-    if (MODE == kGroupBacksub) {
-      // ---- 5b. t = h - sum Z z, step = -L^-T t ----
-      if (has) {
-        double u[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {   // Z[:, c] = L_q^-1 Es^T Fc_s[:, c]
-          const double y0 = es0[0] * fc0[c] + es1[0] * fc1[c], y1 = es0[1] * fc0[c] + es1[1] * fc1[c], y2 = es0[2] * fc0[c] + es1[2] * fc1[c];
-          const double z = d.zsol[6 * (size_t)pose_id + c];
-          u[0] += (ptq[0] * y0) * z;
-          u[1] += (ptq[1] * y0 + ptq[2] * y1) * z;
-          u[2] += (ptq[3] * y0 + ptq[4] * y1 + ptq[5] * y2) * z;
-        }
-#pragma unroll
-        for (int e = 0; e < 3; ++e) M[e * NT + tid] = u[e];
-      }
-      double* __restrict__ W = M + 3 * NT;   // [row][point][kGroupIntr * 8]
-#pragma unroll
-      for (int rd = 0; rd < kSlotRounds; ++rd) {
-        const int it = tid + rd * NT;
-        if (it < (int)np * kGroupIntr * 8) {
-          const int rem = it % (kGroupIntr * 8), k = rem >> 3, c = rem & 7;
-          const double z = d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[k] + c];
-#pragma unroll
-          for (int e = 0; e < 3; ++e) W[e * kSlotItems + it] = zs[rd][e] * z;
-        }
-      }
-      __syncthreads();
-      if ((uint32_t)tid < np) {
-        const double* __restrict__ pt = ptab + tid * 12;
-        double t[3] = {pt[6], pt[7], pt[8]};
-        for (uint32_t e = pe[tid]; e < pe[tid + 1]; ++e) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) t[r] -= M[r * NT + e];
-        }
-        for (int j = 0; j < kGroupIntr * 8; ++j) {
-#pragma unroll
-          for (int r = 0; r < 3; ++r) t[r] -= W[r * kSlotItems + tid * (kGroupIntr * 8) + j];
-        }
-        const uint32_t p = G.pts[p0 + tid];
-        d.step_pt[(size_t)p * 3 + 0] = -(pt[0] * t[0] + pt[1] * t[1] + pt[3] * t[2]);
-        d.step_pt[(size_t)p * 3 + 1] = -(pt[2] * t[1] + pt[4] * t[2]);
-        d.step_pt[(size_t)p * 3 + 2] = -(pt[5] * t[2]);
-      }
-      continue;
-    }
+    MVGX_GSTAMP(3);
     // ---- 5. the staged matrix: rows 3 q .. 3 q + 2, columns 6 x .. (poses), 60 + 8 k .. (intrinsics), kGroupHCol (h) ----
     for (int i = tid; i < kGroupM / 2; i += NT) reinterpret_cast<double2*>(M)[i] = make_double2(0.0, 0.0);
     __syncthreads();
@@ -1133,6 +1177,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       dst[0] = ptab[tid * 12 + 6]; dst[1] = ptab[tid * 12 + 7]; dst[2] = ptab[tid * 12 + 8];
     }
     __syncthreads();
+    MVGX_GSTAMP(5);
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
     const int rows = ((int)(3 * np + 3)) & ~3;
 #pragma unroll
@@ -1145,6 +1190,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
         acc[j] = a;
       }
     }
+    MVGX_GSTAMP(6);
   }
   if (MODE != kGroupForward) return;
   // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
@@ -1178,43 +1224,53 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     const uint32_t ch = cii[pair];
     if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + (idx - pair * kNVii)] = out[kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + idx];
   }
+  MVGX_GSTAMP(7);
 }
 
 // KIND 0: pose x pose, 1: pose x intrinsic, 2: intrinsic x intrinsic. Sums the chunks of one destination block, adds the
 // scaled Gram block that belongs there, writes the block (and, for diagonal blocks, the rhs entries) into S.
-template <int WA, int WB, int KIND>
-__global__ __launch_bounds__(128) void ba_schur_assemble_kernel(Dev d, TripList L) {
+template <int WA, int WB, int KIND, int SG>
+__global__ __launch_bounds__(128 * SG) void ba_schur_assemble_kernel(Dev d, TripList L) {
   constexpr int NV = WA * WB + WA;
+  __shared__ double red[SG > 1 ? SG : 1][128];
   const uint32_t b = blockIdx.x;
-  const int e = threadIdx.x;
-  if (e >= NV) return;
+  const int e = threadIdx.x & 127, sgi = threadIdx.x >> 7;   // SG groups of 128 threads stride the partial blocks of the destination
   const uint32_t rcb = L.block_row[b], ccb = L.block_col[b];
   const bool diag = rcb == ccb;
-  if (e >= WA * WB && !diag) return;
+  const bool live = e < NV && (e < WA * WB || diag);
   double sum = 0;
-  {   // eight loads in flight, added in list order
+  if (live) {   // eight loads in flight, added in list order
     const uint32_t c1 = L.block_chunk0[b + 1];
-    uint32_t ch = L.block_chunk0[b];
+    uint32_t ch = L.block_chunk0[b] + sgi;
     const double* __restrict__ q = L.part + e;
-    for (; ch + 8 <= c1; ch += 8) {
+    for (; ch + 7 * SG < c1; ch += 8 * SG) {
       double v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = q[(size_t)(ch + j) * NV];
+      for (int j = 0; j < 8; ++j) v[j] = q[(size_t)(ch + j * SG) * NV];
 #pragma unroll
       for (int j = 0; j < 8; ++j) sum += v[j];
     }
-    for (; ch < c1; ++ch) sum += q[(size_t)ch * NV];
+    for (; ch < c1; ch += SG) sum += q[(size_t)ch * NV];
   }
-  if (L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
+  if (live && L.block_ext0) {   // partial blocks of the point groups: loads four at a time, summed in list order
     const uint32_t x1 = L.block_ext0[b + 1];
-    uint32_t x = L.block_ext0[b];
+    uint32_t x = L.block_ext0[b] + sgi;
     const double* __restrict__ q = L.part + (size_t)L.n_chunks * NV + e;
-    for (; x + 4 <= x1; x += 4) {
-      const double v0 = q[(size_t)x * NV], v1 = q[(size_t)(x + 1) * NV], v2 = q[(size_t)(x + 2) * NV], v3 = q[(size_t)(x + 3) * NV];
+    for (; x + 3 * SG < x1; x += 4 * SG) {
+      const double v0 = q[(size_t)x * NV], v1 = q[(size_t)(x + SG) * NV], v2 = q[(size_t)(x + 2 * SG) * NV], v3 = q[(size_t)(x + 3 * SG) * NV];
       sum += v0; sum += v1; sum += v2; sum += v3;
     }
-    for (; x < x1; ++x) sum += q[(size_t)x * NV];
+    for (; x < x1; x += SG) sum += q[(size_t)x * NV];
   }
+  if (SG > 1) {   // (a shared intrinsic's block collects a partial block from every supergroup that sees it: thousands)
+    red[sgi][e] = sum;
+    __syncthreads();
+    if (sgi != 0) return;
+    sum = 0;
+#pragma unroll
+    for (int j = 0; j < SG; ++j) sum += red[j][e];
+  }
+  if (!live) return;
   const uint32_t np = d.n_poses;
   const int row0 = rcb < np ? 6 * (int)rcb : 6 * (int)np + 8 * (int)(rcb - np);
   const int col0 = ccb < np ? 6 * (int)ccb : 6 * (int)np + 8 * (int)(ccb - np);
@@ -2356,9 +2412,9 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   if (d.tii.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(8 * ((d.tii.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
   BA_LAUNCH_CHECK();
-  if (d.tpp.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 6, 0>), dim3(d.tpp.n_blocks), dim3(128), 0, c->stream, d, d.tpp);
-  if (d.tpi.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 8, 1>), dim3(d.tpi.n_blocks), dim3(128), 0, c->stream, d, d.tpi);
-  if (d.tii.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<8, 8, 2>), dim3(d.tii.n_blocks), dim3(128), 0, c->stream, d, d.tii);
+  if (d.tpp.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 6, 0, 1>), dim3(d.tpp.n_blocks), dim3(128), 0, c->stream, d, d.tpp);
+  if (d.tpi.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<6, 8, 1, 1>), dim3(d.tpi.n_blocks), dim3(128), 0, c->stream, d, d.tpi);
+  if (d.tii.n_blocks) hipLaunchKernelGGL((ba_schur_assemble_kernel<8, 8, 2, 8>), dim3(d.tii.n_blocks), dim3(1024), 0, c->stream, d, d.tii);
   BA_LAUNCH_CHECK();
   return MVGX_OK;
 }
@@ -2845,6 +2901,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.prior_huber_a = p->prior_huber_a;
   c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
   if (getenv("MVGX_BA_FACTOR_DEBUG")) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_factor_debug), &one, sizeof(one)); }
+  { const int on = getenv("MVGX_BA_GROUP_DEBUG") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_debug), &on, sizeof(on)); }
   if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
   if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
@@ -3008,7 +3065,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // so does MVGX_BA_MODEL_COST=jacobian (Ceres' form of the model cost reads the Jacobian records of every observation).
   constexpr int kMaxSgGroups = 8;
   std::vector<uint8_t> in_group(d.n_pts, 0);
-  std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_eobs, g_eq, g_pt_start{0}, g_pts, g_pt_estart, sg_cams, sg_intrs;
+  std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_eobs, g_eq, g_pt_start{0}, g_pts, g_nk0, g_pt_estart, g_pt_ksplit, sg_cams, sg_intrs;
   std::vector<uint8_t> sg_pp, sg_pi, sg_ii;   // per supergroup: which destination blocks exist
   {
     const char* env = getenv("MVGX_BA_GROUPS");
@@ -3038,7 +3095,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       // groups never span two lowest-pose buckets, so the buckets are swept independently (host threads) and their groups
       // stitched in bucket order: the result does not depend on the thread count
       struct BucketGroups {
-        std::vector<uint32_t> sg_n, obs_n, eobs, eq, pt_n, pts, cams, intrs;   // sg_n: groups per supergroup
+        std::vector<uint32_t> sg_n, obs_n, eobs, eq, pt_n, pts, nk0, cams, intrs;   // sg_n: groups per supergroup; nk0: per point, its observations with local intrinsic 0
         std::vector<uint8_t> pp, pi, ii;
       };
       std::vector<BucketGroups> per_bucket(d.n_poses);
@@ -3069,13 +3126,18 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             B.pts.push_back(j);
             uint8_t xs[kGroupCams], ks[kGroupCams];
             int nx = 0;
-            for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
-              const int x = local(tail_cams, opose[o]), k = local(tail_intrs, ointr[o]);
-              B.eobs.push_back(o);
-              B.eq.push_back((uint32_t)q | ((uint32_t)x << 8) | ((uint32_t)k << 12));
-              xs[nx] = (uint8_t)x; ks[nx] = (uint8_t)k; ++nx;
-              ++n_obs_g;
-            }
+            uint32_t n_k0 = 0;
+            for (int pass = 0; pass < kGroupIntr; ++pass)   // the observations with local intrinsic 0 first, then those with 1
+              for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) {
+                const int x = local(tail_cams, opose[o]), k = local(tail_intrs, ointr[o]);
+                if (k != pass) continue;
+                B.eobs.push_back(o);
+                B.eq.push_back((uint32_t)q | ((uint32_t)x << 8) | ((uint32_t)k << 12));
+                xs[nx] = (uint8_t)x; ks[nx] = (uint8_t)k; ++nx;
+                ++n_obs_g;
+                n_k0 += k == 0;
+              }
+            B.nk0.push_back(n_k0);
             for (int a = 0; a < nx; ++a)
               for (int b2 = 0; b2 < nx; ++b2) {
                 if (xs[a] <= xs[b2]) B.pp[sgi * kGroupPairsPP + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b2] - xs[a])] = 1;
@@ -3125,6 +3187,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         g_eobs.insert(g_eobs.end(), B.eobs.begin(), B.eobs.end());
         g_eq.insert(g_eq.end(), B.eq.begin(), B.eq.end());
         g_pts.insert(g_pts.end(), B.pts.begin(), B.pts.end());
+        g_nk0.insert(g_nk0.end(), B.nk0.begin(), B.nk0.end());
         sg_cams.insert(sg_cams.end(), B.cams.begin(), B.cams.end());
         sg_intrs.insert(sg_intrs.end(), B.intrs.begin(), B.intrs.end());
         sg_pp.insert(sg_pp.end(), B.pp.begin(), B.pp.end());
@@ -3134,7 +3197,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       // first entry of every grouped point (its observations are consecutive entries)
       g_pt_estart.resize(g_pts.size() + 1);
       { uint32_t e = 0;
-        for (size_t q = 0; q < g_pts.size(); ++q) { g_pt_estart[q] = e; e += pt_start[g_pts[q] + 1] - pt_start[g_pts[q]]; }
+        g_pt_ksplit.resize(g_pts.size());
+        for (size_t q = 0; q < g_pts.size(); ++q) { g_pt_estart[q] = e; g_pt_ksplit[q] = e + g_nk0[q]; e += pt_start[g_pts[q] + 1] - pt_start[g_pts[q]]; }
         g_pt_estart[g_pts.size()] = e; }
     }
   }
@@ -3293,6 +3357,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_estart, g_pt_estart, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &d.grp.pt_ksplit, g_pt_ksplit, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.eq, g_eq, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.eobs, g_eobs, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.exy, g_exy, c->stream))) return rc;
@@ -3345,6 +3410,13 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_factor_stamps), sizeof(st)) == hipSuccess)
       fprintf(stderr, "[mvgx factor kernel, shader clocks] load %lld | panels (+ overlapped inverse) %lld %lld %lld %lld | inverse tail A %lld | tail B %lld | store %lld | total %lld\n",
               st[1] - st[0], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[9] - st[0]);
+  }
+  if (getenv("MVGX_BA_GROUP_DEBUG")) {
+    unsigned long long st[8];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_group_stamps), sizeof(st)) == hipSuccess)
+      fprintf(stderr, "[mvgx point-group kernel, shader clocks summed over workgroups and launches] observation %llu | point sums %llu | point factors %llu | "
+              "slots %llu | back-substitution %llu | matrix staging %llu | mfma %llu | partial blocks out %llu\n",
+              st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
   }
   c->pool.release();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);

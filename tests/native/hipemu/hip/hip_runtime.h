@@ -99,6 +99,7 @@ static inline double __hiloint2double(int hi, int lo) { long long b = ((long lon
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
