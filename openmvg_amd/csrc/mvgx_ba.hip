@@ -1619,11 +1619,9 @@ __device__ __forceinline__ void sp_load_operands(const double* __restrict__ X, c
   for (int ks = 0; ks < 16; ++ks) { xv[ks] = X[ks * 256]; yv[ks] = Y[ks * 256]; }
 }
 template <bool kUpdate>
-__global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tasks) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const int t = (int)blockIdx.x * 4 + wave;
-  if (t >= n_tasks) return;   // wave-uniform
-  const mvgx_sparse::GemmTask g = (kUpdate ? s.u_tasks : s.t_tasks)[t0 + t];
+__device__ __forceinline__ void sp_gemm_task(const SpSys& s, int task) {   // one wave, one task (wave-uniform)
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const mvgx_sparse::GemmTask g = (kUpdate ? s.u_tasks : s.t_tasks)[task];
   const mvgx_sparse::SlotPair* __restrict__ pairs = kUpdate ? s.u_pairs : s.t_pairs;
   d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
   // lane (li, lk) feeds X[16 bi + li][4 ks + lk] and Y[16 bj + li][4 ks + lk]; element (r, q) of a tile sits at q * 64 + r
@@ -1677,11 +1675,15 @@ __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tas
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = kUpdate ? old[reg] - acc[reg] : acc[reg];
 }
+template <bool kUpdate>
+__global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tasks) {
+  const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (t >= n_tasks) return;   // wave-uniform
+  sp_gemm_task<kUpdate>(s, t0 + t);
+}
 
 // Reverse sweep, one workgroup per tile column of the level: z_k = Linv_k^T (y_k - sum over the tiles below L_ik^T z_i).
-__global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
-  __shared__ double w[64];
-  const int k = s.f_cols[f0 + blockIdx.x];
+__device__ __forceinline__ void sp_backsolve_col(const SpSys& s, int k, double* w /* 64 doubles of LDS */) {
   const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
   double v = 0;
   // the (slot, row) indices of the tiles below are fetched 64 at a time (one per lane, v_readlane hands them out): the loads of
@@ -1713,6 +1715,11 @@ __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
   u += __shfl_xor(u, 2);
   if (part == 0) s.z[(size_t)k * 64 + c] = u;
 }
+__global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
+  __shared__ double w[64];
+  sp_backsolve_col(s, s.f_cols[f0 + blockIdx.x], w);
+}
+
 __global__ void sp_gather_solution_kernel(Dev d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.N) d.zsol[i] = d.sp.z[d.sp.pcol[i]];
@@ -2426,6 +2433,11 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 // C3 and 1.5 % faster on C5 - the cross-stream dependencies cost what the overlap gains; replaying the same sequence
 // as a captured HIP graph cost 4-16 ms of instantiation per context, more than a whole small solve. An update kernel on
 // 128 x 128 tiles (64 x 64 per wave) was 2.1x slower per launch than the 64 x 64 one at C5 (profiles/round1_ba_c5_update128_call18.json).
+// Round 3, measured and not kept: the top levels of the elimination tree (one tile column each) as ONE launch - a single workgroup
+// walking factor / panel / update level by level and straight back down the reverse sweep. The factor-and-invert body needs
+// exactly four waves (its barriers count every wave of the workgroup), so the 16 sub-block tasks of a tile that the separate T / U
+// launches spread over 16 waves on other CUs ran four rounds deep, two dependent memory round trips each: 4 top levels of C3
+// took 235 us in the fused launch against ~140 us as 16 launches, 6 levels of C5 262 us against ~216 us.
 int factor_and_solve_sparse(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   const mvgx_sparse::Plan& pl = c->plan;
