@@ -358,6 +358,41 @@ typedef struct mvgx_ba_solver_info {
 } mvgx_ba_solver_info;
 int mvgx_ba_get_solver_info(mvgx_ba_ctx* ctx, mvgx_ba_solver_info* out);   /* MVGX_ERR_STATE before the first iteration */
 
+/* ---- geometric filter of putative matches: a-contrario fundamental-matrix estimation --------------------------
+ * Replaces, per image pair of a putative-match container, GeometricFilter_FMatrix_AC::Robust_estimation
+ * (matching_image_collection/F_ACRobust.hpp:65-122): ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT>
+ * (robust_estimation/robust_estimator_ACRansacKernelAdaptator.hpp:104-202) + ACRANSAC
+ * (robust_estimation/robust_estimator_ACRansac.hpp:339-489), as called for every pair by
+ * ImageCollectionGeometricFilter::Robust_model_estimation (matching_image_collection/GeometricFilter.hpp:66-131).
+ * Pair p owns the correspondences [match_start[p], match_start[p + 1]) of xI / xJ: (undistorted) pixel positions of the matched
+ * features in image I / J, what MatchesPairToMat (Geometric_Filter_utils.hpp:56-64) builds, in the order of the pair's IndMatches;
+ * image_wh[4 p ..] = {w_I, h_I, w_J, h_J} (View::ui_width / ui_height). Outputs: inlier_mask[m] = 1 for the geometric inliers of a
+ * pair whose estimation succeeded (the reference's geometric_inliers are the putative matches with mask 1, in their order),
+ * results[p]. One wave of the device runs one pair; pairs with at most 7 correspondences are rejected without estimation like the
+ * reference does. Not reproduced (MVGX_ERR_UNSUPPORTED): an unbounded precision (the exhaustive NFA form), pairs with more than
+ * 12 000 correspondences. Parity: same sample sequence, tables and NFA arithmetic; the minimal solver's null space is computed by
+ * elimination instead of Eigen's eigen-solver, so models agree to rounding, not bit for bit (parity policy). */
+typedef struct mvgx_geofilter_options {
+  double precision;          /* GeometricFilter_FMatrix_AC::m_dPrecision, pixels (main_GeometricFilter: 4.0)  */
+  uint32_t max_iterations;   /* m_stIteration (main_GeometricFilter: 2048; constructor default 1024)          */
+} mvgx_geofilter_options;
+typedef struct mvgx_geofilter_result {
+  double F[9];               /* m_F, row-major, in pixel coordinates (identity if no model was found)          */
+  double precision_robust;   /* ACRansacOut.first -> m_dPrecision_robust (pixels)                              */
+  double nfa;                /* ACRansacOut.second                                                             */
+  uint32_t n_inliers;        /* |vec_inliers|                                                                  */
+  uint32_t ok;               /* Robust_estimation's return value: n_inliers > 2.5 x 7                          */
+} mvgx_geofilter_result;
+typedef struct mvgx_geofilter_stats {
+  uint64_t n_pairs, n_pairs_estimated, n_pairs_ok, n_inliers;
+  double kernel_ms;          /* device time of the estimation kernels (HIP events)                             */
+  double host_prepare_ms;    /* normalisation + per-pair constants on host threads                             */
+  double total_ms;           /* the whole call incl. transfers                                                 */
+} mvgx_geofilter_stats;
+int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,19 @@ class BaSolverInfo(C.Structure):
     ]
 
 
+class GeofilterOptions(C.Structure):
+    _fields_ = [("precision", C.c_double), ("max_iterations", C.c_uint32)]
+
+
+class GeofilterResult(C.Structure):
+    _fields_ = [("F", C.c_double * 9), ("precision_robust", C.c_double), ("nfa", C.c_double), ("n_inliers", C.c_uint32), ("ok", C.c_uint32)]
+
+
+class GeofilterStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_pairs_estimated", C.c_uint64), ("n_pairs_ok", C.c_uint64), ("n_inliers", C.c_uint64),
+                ("kernel_ms", C.c_double), ("host_prepare_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
 MATCH_BATCH_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
@@ -168,6 +181,8 @@ PROTOTYPES = {
     "mvgx_ba_residuals": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvgx_ba_track_angles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvgx_ba_get_solver_info": (C.c_int, [C.c_void_p, C.POINTER(BaSolverInfo)]),
+    "mvgx_geofilter_f_acransac": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GeofilterOptions),
+                                            C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
 }
 
 _lib = None

@@ -1,0 +1,631 @@
+// libmvgx_hip.so - a-contrario fundamental-matrix filter of putative matches on gfx950.
+//
+// Reference path reproduced (paths under /root/reference/src/openMVG):
+//   matching_image_collection/GeometricFilter.hpp:66-131     ImageCollectionGeometricFilter::Robust_model_estimation: one robust
+//                                                             estimation per image pair of the putative-match container
+//   matching_image_collection/F_ACRobust.hpp:65-122          GeometricFilter_FMatrix_AC::Robust_estimation
+//   robust_estimation/robust_estimator_ACRansacKernelAdaptator.hpp:104-202   ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError>
+//   robust_estimation/robust_estimator_ACRansac.hpp:339-489  ACRANSAC, :196-262 the quantified NFA (20-bin histogram), :58-119 tables
+//   robust_estimation/rand_sampling.hpp:43-110               the two UniformSample forms; std::mt19937 + libstdc++ 11 uniform_int_distribution
+//   multiview/solver_fundamental_kernel.cpp:37-93,157-166    seven-point solver, EpipolarDistanceError; numeric/poly.h:32-96 the cubic
+//
+// Mapping. AC-RANSAC is a sequential program per image pair - the sample of iteration k + 1 depends on whether iteration k found a
+// better model (the sampling pool shrinks to its inliers) - and there are as many independent programs as image pairs with matches
+// (configs[1]: up to 499 500). ONE WAVE runs one pair from start to end: control flow is wave-uniform (every lane tracks the same
+// scalars), the per-correspondence work of an iteration (residuals of up to three models, histogram, inlier count, pool rebuild)
+// is spread over the 64 lanes, the 7 x 9 elimination of the minimal solver over 63 lanes (one matrix element each, pivots and
+// rows by cross-lane shuffles). The Mersenne-Twister state, the sampling pool and the pair's log-combinatorial tables live in
+// the wave's slice of LDS; the normalised correspondences (32 bytes each) stay in L2 - a pair re-reads its few KiB once per model.
+// No workgroup barrier anywhere: the four waves of a workgroup are four unrelated pairs.
+//
+// What is exact and what is not (parity policy): the sample sequence (generator, Lemire's bounded draw, both
+// samplers), the float tables, histogram bins, NFA arithmetic (no contraction) and the control flow are the reference's. The
+// null space of the 7 x 9 system comes from complete-pivoting elimination instead of Eigen's eigenvectors of A^T A: the pencil's
+// fundamental matrices agree up to scale and rounding, so residuals differ in the last bits and - when the cubic is badly
+// conditioned in one basis - occasionally by more; a pair whose decisive residual sits within that distance of a histogram edge
+// can end with another inlier set. The compiled reference has the same sensitivity to its own Eigen build.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "mvgx_common.h"
+
+namespace {
+
+using mvgx::set_error;
+
+constexpr int kBins = 20;        // robust_estimator_ACRansac.hpp:221
+constexpr int kMinSamples = 7, kMaxModels = 3;
+constexpr int kMtN = 624, kMtM = 397;
+
+struct GeoPair {   // per pair, prepared on the host (glibc's log10 / hypot / sqrt: the reference's values)
+  uint64_t start;
+  uint32_t n, pad_;
+  double max_threshold, loge0, bins_by_interval;
+  double bin_value[kBins];
+  double logalpha_bin[kBins];   // logalpha0 + multError * log10(bin_value + FLT_EPSILON)
+};
+struct GeoResult {
+  double F[9];             // best model, normalised coordinates (row-major); valid if have_model
+  double error_max, min_nfa;
+  uint32_t n_inliers, have_model;
+};
+
+// ---- arithmetic that must not be contracted into FMAs (the reference's build has none) ----
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+__device__ __forceinline__ void wave_sync() {   // LDS writes of this wave visible to its other lanes (a wave's LDS operations complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- std::mt19937: state in LDS, every lane tracks the same index ----
+__device__ __forceinline__ void mt_twist(uint32_t* mt, int lane) {
+  // mt[i] = mt[(i + 397) % 624] ^ twist(mt[i], mt[i + 1]) for i = 0 .. 623 in order; 64 consecutive i per round: mt[i + 1] is read
+  // before any lane of the round writes, mt[i - 227] (i >= 227) was written at least three rounds earlier
+  for (int base = 0; base < kMtN - 1; base += 64) {
+    const int i = base + lane;
+    uint32_t a = 0, b = 0, c = 0;
+    if (i < kMtN - 1) { a = mt[i]; b = mt[i + 1]; c = mt[i + kMtM < kMtN ? i + kMtM : i + kMtM - kMtN]; }
+    wave_sync();
+    if (i < kMtN - 1) {
+      const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      mt[i] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    wave_sync();
+  }
+  const uint32_t y = (mt[kMtN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+  const uint32_t v = mt[kMtM - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  wave_sync();
+  if (lane == 0) mt[kMtN - 1] = v;
+  wave_sync();
+}
+__device__ __forceinline__ uint32_t mt_next(uint32_t* mt, int& idx, int lane) {
+  if (idx >= kMtN) { mt_twist(mt, lane); idx = 0; }
+  uint32_t y = mt[idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+// std::uniform_int_distribution<uint32_t>(a, b) of libstdc++ 11 on a 32-bit engine (bits/uniform_int_dist.h, _S_nd)
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t* mt, int& idx, int lane, uint32_t a, uint32_t b) {
+  const uint32_t urange = b - a;
+  if (urange == 0xffffffffu) return mt_next(mt, idx, lane) + a;
+  const uint32_t range = urange + 1;
+  uint64_t product = (uint64_t)mt_next(mt, idx, lane) * range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (0u - range) % range;
+    while (low < threshold) { product = (uint64_t)mt_next(mt, idx, lane) * range; low = (uint32_t)product; }
+  }
+  return (uint32_t)(product >> 32) + a;
+}
+
+// ---- numeric/poly.h:32-75 ----
+__device__ __forceinline__ int solve_cubic(double a, double b, double c, double x[3]) {
+  const double eps = 2.220446049250313e-16;
+  a /= 3;
+  double p = (b - 3 * a * a) / 3;
+  double q = (2 * a * a * a - a * b + c) / 2;
+  double d = q * q + p * p * p;
+  const double tolq = fmax(fabs(2 * a * a * a), fmax(fabs(a * b), fabs(c)));
+  const double tolp = fmax(fabs(b), fabs(3 * a * a));
+  int n = (d > eps * fmax(p * p * tolp, fabs(q) * tolq) ? 1 : 3);
+  if (n == 1) {
+    d = pow(fabs(q) + sqrt(d), 1 / 3.0);
+    x[0] = d - p / d;
+    if (q > 0) x[0] = -x[0];
+  } else {
+    if (3 * p >= -eps * tolp) { n = 1; x[0] = 0; }
+    else {
+      p = sqrt(-p);
+      q /= p * p * p;
+      d = (q <= -1) ? 3.14159265358979323846 : (q >= 1) ? 0.0 : acos(q);
+      for (int i = 0; i < 3; ++i) x[i] = -2 * p * cos((d + 2 * 3.14159265358979323846 * i) / 3);
+    }
+  }
+  for (int i = 0; i < n; ++i) x[i] -= a;
+  return n;
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double lane_value_f64(double v, int src_lane) {   // src_lane wave-uniform: two v_readlane, no LDS crossbar
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// maximum of a 32-bit key over the wave, the same value in every lane: quad / half-row / row exchanges on the DPP path, the four
+// rows through scalar registers (a butterfly of ds_bpermute round trips cost ~2000 clocks per pivot search here)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // lane ^ 1
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // lane ^ 2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // the other quad of the half row
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // the other half of the row
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+
+// EpipolarDistanceError (solver_fundamental_kernel.cpp:157-166)
+__device__ __forceinline__ double epipolar_error(const double (&F)[9], double2 x, double2 y) {
+  const double fx0 = F[0] * x.x + F[1] * x.y + F[2], fx1 = F[3] * x.x + F[4] * x.y + F[5], fx2 = F[6] * x.x + F[7] * x.y + F[8];
+  const double dt = fx0 * y.x + fx1 * y.y + fx2;
+  return dt * dt / (fx0 * fx0 + fx1 * fx1);
+}
+
+// SevenPointSolver::Solve on the sample s[0..6] (wave-uniform): the two null vectors F1, F2 of the 7 x 9 system and the real
+// roots of det(F1 + alpha F2) = 0; model t is F1 + roots[t] F2. Every lane gets everything.
+__device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane,
+                                           double (&F1)[9], double (&F2)[9], double (&roots)[3]) {
+  // lane = 9 r + c holds A[r][c] = x2h[c / 3] * x1h[c % 3] of sample point r (EncodeEpipolarEquation, solver_fundamental_kernel.hpp:83-93)
+  const int r = lane < 63 ? lane / 9 : 6, c = lane < 63 ? lane - 9 * (lane / 9) : 8;
+  uint32_t si = s[0];
+#pragma unroll
+  for (int k = 1; k < 7; ++k) si = (r == k) ? s[k] : si;
+  const double2 p1 = x1[si], p2 = x2[si];
+  const int ci = c / 3, cj = c - 3 * ci;
+  const double h2 = ci == 0 ? p2.x : ci == 1 ? p2.y : 1.0, h1 = cj == 0 ? p1.x : cj == 1 ? p1.y : 1.0;
+  double a = h2 * h1;
+  // Gauss-Jordan elimination with complete pivoting; the two columns without a pivot span the null space. The pivot is the
+  // element of largest magnitude as a float (a choice within 2^-18 of the largest is as good a pivot), lowest lane on ties:
+  // key = float bits with the low 6 bits replaced by 63 - lane.
+  uint32_t row_used = 0, col_used = 0;
+  int prow[7], pcol[7], n_piv = 0;
+#pragma unroll
+  for (int step = 0; step < 7; ++step) {
+    const bool cand = lane < 63 && !((row_used >> r) & 1u) && !((col_used >> c) & 1u);
+    const float mag = (float)fabs(a);
+    const uint32_t key = (cand && mag > 0.f && mag == mag) ? ((__float_as_uint(mag) & ~63u) | (uint32_t)(63 - lane)) : 0u;
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) break;   // rank deficient sample (wave-uniform): fewer pivots, the first two free columns are used
+    const int who = 63 - (int)(best & 63u);
+    const int pr = who / 9, pc = who - 9 * (who / 9);
+    const double ipiv = 1.0 / lane_value_f64(a, who);
+    const double rowv = shfl_f64(a, 9 * pr + c);   // pivot row, my column
+    const double colv = shfl_f64(a, 9 * r + pc);   // my row, pivot column
+    if (r != pr) a -= (colv * ipiv) * rowv;
+    row_used |= 1u << pr; col_used |= 1u << pc;
+    prow[step] = pr; pcol[step] = pc;
+    n_piv = step + 1;
+  }
+  int f1 = 0;
+  while ((col_used >> f1) & 1u) ++f1;
+  int f2 = f1 + 1;
+  while ((col_used >> f2) & 1u) ++f2;
+  // lane u < 9 gets component u of the two null vectors: 1 at the free column, -A[prow][free] / A[prow][pcol] at a pivot column
+  double F1u = lane == f1 ? 1.0 : 0.0, F2u = lane == f2 ? 1.0 : 0.0;
+#pragma unroll
+  for (int step = 0; step < 7; ++step) {
+    if (step < n_piv) {   // wave-uniform
+      const double iden = 1.0 / lane_value_f64(a, 9 * prow[step] + pcol[step]);
+      const double n1 = lane_value_f64(a, 9 * prow[step] + f1), n2 = lane_value_f64(a, 9 * prow[step] + f2);
+      if (lane == pcol[step]) { F1u = -n1 * iden; F2u = -n2 * iden; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 9; ++u) { F1[u] = lane_value_f64(F1u, u); F2[u] = lane_value_f64(F2u, u); }
+  // det(F1 + alpha F2) = 0 (solver_fundamental_kernel.cpp:62-86), coefficients in ascending powers of alpha
+  const double a_ = F1[0], j = F2[0], b = F1[1], k = F2[1], c_ = F1[2], l = F2[2], d = F1[3], m = F2[3], e = F1[4], n = F2[4],
+               f = F1[5], o = F2[5], g = F1[6], p = F2[6], h = F1[7], q = F2[7], i = F1[8], rr = F2[8];
+  const double P[4] = {
+    a_*e*i + b*f*g + c_*d*h - a_*f*h - b*d*i - c_*e*g,
+    a_*e*rr + a_*i*n + b*f*p + b*g*o + c_*d*q + c_*h*m + d*h*l + e*i*j + f*g*k -
+    a_*f*q - a_*h*o - b*d*rr - b*i*m - c_*e*p - c_*g*n - d*i*k - e*g*l - f*h*j,
+    a_*n*rr + b*o*p + c_*m*q + d*l*q + e*j*rr + f*k*p + g*k*o + h*l*m + i*j*n -
+    a_*o*q - b*m*rr - c_*n*p - d*k*rr - e*l*p - f*j*q - g*l*n - h*j*o - i*k*m,
+    j*n*rr + k*o*p + l*m*q - j*o*q - k*m*rr - l*n*p};
+  roots[0] = roots[1] = roots[2] = 0.0;
+  if (P[0] == 0.0) return 0;   // poly.h:88-91
+  return solve_cubic(P[2] / P[3], P[1] / P[3], P[0] / P[3], roots);
+}
+
+// float logcombi(k, n) (robust_estimator_ACRansac.hpp:58-72) on the shared table of log10 values
+__device__ __forceinline__ float logcombi(uint32_t k, uint32_t n, const float* __restrict__ l10) {
+  if (k >= n) return 0.f;
+  if (n - k < k) k = n - k;
+  float r = 0.f;
+  for (uint32_t i = 1; i <= k; ++i) r += l10[n - i + 1] - l10[i];
+  return r;
+}
+
+// number of correspondences whose residual under F is at most thr (all lanes get the sum): ballots, no shuffles
+__device__ __forceinline__ uint32_t count_within(const double (&F)[9], const double2* __restrict__ x1, const double2* __restrict__ x2, uint32_t n,
+                                                 double thr, int lane) {
+  uint32_t cnt = 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t i = base + lane;
+    const bool in = i < n && epipolar_error(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= thr;
+    cnt += (uint32_t)__popcll(__ballot(in));
+  }
+  return cnt;
+}
+
+// ApplyTransformationToPoints with the preconditioner of the image size (conditioning.cpp:44-67): x' = s x + t per coordinate, one
+// product and one sum each, no contraction - the values the reference's Eigen expression produces
+__global__ __launch_bounds__(256) void geofilter_normalize_kernel(const GeoPair* __restrict__ pairs, const double* __restrict__ norm /* 6 per pair */,
+                                                                  uint32_t n_pairs, const double2* __restrict__ xI, const double2* __restrict__ xJ,
+                                                                  double2* __restrict__ x1n, double2* __restrict__ x2n) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pairs) return;
+  const uint64_t lo = pairs[p].start;
+  const uint32_t n = pairs[p].n;
+  const double* __restrict__ t = norm + 6 * (size_t)p;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double2 a = xI[lo + i], b = xJ[lo + i];
+    x1n[lo + i] = make_double2(add_rn(mul_rn(t[0], a.x), t[1]), add_rn(mul_rn(t[0], a.y), t[2]));
+    x2n[lo + i] = make_double2(add_rn(mul_rn(t[3], b.x), t[4]), add_rn(mul_rn(t[3], b.y), t[5]));
+  }
+}
+
+constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (20) | the model of the current inlier list (18 words = 9 doubles at 8-byte alignment + 2)
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
+                                                                          uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
+                                                                          const double2* __restrict__ x2n, const float* __restrict__ l10,
+                                                                          const uint32_t* __restrict__ mt_init, uint32_t max_iterations,
+                                                                          GeoResult* __restrict__ results, uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t w = blockIdx.x * WAVES + wave;
+  if (w >= n_work) return;   // wave-uniform; no workgroup barrier below
+  const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
+  const uint32_t per_wave = kMtN + 3 * cap1 + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
+  uint32_t* const mt = lds_u32 + (size_t)wave * per_wave;
+  uint32_t* const pool = mt + kMtN;
+  float* const logc_n = reinterpret_cast<float*>(pool + cap1);
+  float* const logc_k = logc_n + cap1;
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(logc_k + cap1);
+  double* const inlF_lds = reinterpret_cast<double*>(hist + 24);   // the model behind the current inlier list / pool (rarely touched: kept out of registers)
+  const uint32_t pidx = order[w];
+  const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
+  const uint32_t n = P.n;
+  const double max_threshold = P.max_threshold, bins_by_interval = P.bins_by_interval, loge0 = P.loge0;
+  const double2* __restrict__ x1 = x1n + P.start;
+  const double2* __restrict__ x2 = x2n + P.start;
+  // lane b < 20 keeps the constants of histogram bin b
+  const double my_bin_value = lane < kBins ? P.bin_value[lane] : 0.0, my_logalpha = lane < kBins ? P.logalpha_bin[lane] : 0.0;
+  // ---- set-up: generator (std::mt19937(5489) before its first twist), pool = 0..n-1, tables ----
+  for (int i = lane; i < kMtN; i += 64) mt[i] = mt_init[i];
+  for (uint32_t i = lane; i < n; i += 64) pool[i] = i;
+  for (uint32_t k = lane; k <= n; k += 64) { logc_n[k] = logcombi(k, n, l10); logc_k[k] = logcombi(kMinSamples, k, l10); }
+  if (lane < 9) inlF_lds[lane] = 0.0;
+  wave_sync();
+  int mt_idx = kMtN;
+  uint32_t pool_size = n;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  double minNFA = inf, errorMax = inf;
+  double bestFu = 0.0;   // lane u < 9: component u of the best model
+  double inl_thr = 0.0;
+  uint32_t inl_count = 0, have_model = 0;
+  int nIterReserve = (int)(max_iterations / 10);
+  unsigned nIter = max_iterations - (unsigned)nIterReserve;
+  bool ac_mode = false;
+  uint32_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (unsigned iter = 0; iter < nIter && iter < max_iterations; ++iter) {
+    // ---- sample (rand_sampling.hpp) ----
+    if (ac_mode) {
+      if (pool_size >= (uint32_t)kMinSamples) {   // else UniformSample returns false and vec_sample keeps its values
+        const uint32_t last = pool_size - 1;
+#pragma unroll
+        for (uint32_t i = 0; i < 7; ++i) {
+          const uint32_t jx = uniform_u32(mt, mt_idx, lane, i, last);
+          const uint32_t vi = pool[i], vj = pool[jx];
+          wave_sync();
+          if (lane == 0) { pool[i] = vj; pool[jx] = vi; }
+          wave_sync();
+          s[i] = vj;
+        }
+      }
+    } else {
+      int got = 0;
+      while (got < 7) {
+        const uint32_t cand = uniform_u32(mt, mt_idx, lane, 0, n - 1);
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) found = found || (k < got && s[k] == cand);
+        if (!found) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) if (k == got) s[k] = cand;
+          ++got;
+        }
+      }
+    }
+    // ---- fit, evaluate ----
+    double F1[9], F2[9], roots[3];
+    const int nm = seven_point(x1, x2, s, lane, F1, F2, roots);
+    bool better = false;
+    for (int mi = 0; mi < nm; ++mi) {
+      const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
+      double F[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) F[u] = F1[u] + root * F2[u];
+      if (lane < kBins) hist[lane] = 0;
+      wave_sync();
+      uint32_t n_le = 0;
+      for (uint32_t base = 0; base < n; base += 256) {   // four rounds of loads in flight
+        double2 a1[4], a2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t i = base + 64 * q + lane;
+          a1[q] = x1[i < n ? i : 0]; a2[q] = x2[i < n ? i : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t i = base + 64 * q + lane;
+          const double e = epipolar_error(F, a1[q], a2[q]);
+          const bool in = i < n && e <= max_threshold;
+          if (!ac_mode) n_le += (uint32_t)__popcll(__ballot(in));
+          if (i < n && !(e < 0.0)) {   // Histogram::Add (histogram.hpp:72-86); a NaN / huge value ends in no bin, like the cast to size_t on x86-64
+            const double t = mul_rn(e, bins_by_interval);
+            if (t >= 0.0 && t < (double)kBins) atomicAdd(&hist[(int)t], 1u);
+          }
+        }
+      }
+      if (!ac_mode && (double)n_le > 2.5 * kMinSamples) ac_mode = true;   // MAX-CONSENSUS warm-up (:404-414)
+      wave_sync();
+      if (ac_mode) {   // ComputeNFA_and_inliers, quantified form (:196-262): lane b evaluates bin b, the first bin of minimal NFA wins
+        uint32_t cum = 0;
+#pragma unroll
+        for (int b = 0; b < kBins; ++b) cum += (b <= lane) ? hist[b] : 0u;
+        double cur = inf;
+        if (lane < kBins && cum > (uint32_t)kMinSamples && my_bin_value > 1.1920928955078125e-07) {
+          cur = add_rn(add_rn(add_rn(loge0, mul_rn(my_logalpha, (double)(cum - kMinSamples))), (double)logc_n[cum]), (double)logc_k[cum]);
+          if (!(cur < 0)) cur = inf;
+        }
+        // minimum over the 20 lanes, lowest bin on ties (the sequential scan keeps the first strict improvement)
+        double cb_nfa = inf, cb_thr = 0.0;
+#pragma unroll
+        for (int b = 0; b < kBins; ++b) {
+          const double v = lane_value_f64(cur, b);
+          if (v < cb_nfa) { cb_nfa = v; cb_thr = lane_value_f64(my_bin_value, b); }
+        }
+        if (cb_nfa < minNFA) {   // the inlier list is rebuilt even if it then turns out too short (the reference's behaviour)
+          const uint32_t cnt = count_within(F, x1, x2, n, cb_thr, lane);
+          wave_sync();
+          if (lane < 9) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) if (lane == u) inlF_lds[u] = F[u];
+          }
+          wave_sync();
+          inl_thr = cb_thr; inl_count = cnt;
+          if (cnt > (uint32_t)kMinSamples) {
+            better = true; minNFA = cb_nfa; errorMax = cb_thr; have_model = 1;
+#pragma unroll
+            for (int u = 0; u < 9; ++u) if (lane == u) bestFu = F[u];
+          }
+        }
+      }
+    }
+    // ---- loop control (:445-474) ----
+    if (!ac_mode && iter > (unsigned)(nIterReserve * 2)) { nIter = 0; continue; }
+    if (ac_mode && ((better && minNFA < 0) || ((iter + 1) == nIter && nIterReserve > 0))) {
+      if (inl_count == 0) { ++nIter; --nIterReserve; }
+      else {
+        // vec_index = vec_inliers: the correspondences within inl_thr of the list's model, in index order
+        double F[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) F[u] = inlF_lds[u];
+        uint32_t m = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+          const uint32_t i = base + lane;
+          const bool in = i < n && epipolar_error(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= inl_thr;
+          const unsigned long long bal = __ballot(in);
+          if (in) pool[m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+          m += (uint32_t)__popcll(bal);
+        }
+        wave_sync();
+        pool_size = m;
+        if (nIterReserve) { nIter = iter + 1 + (unsigned)nIterReserve; nIterReserve = 0; }
+      }
+    }
+  }
+  if (minNFA >= 0) inl_count = 0;   // no meaningful model (:477-478)
+  const bool good = (double)inl_count > kMinSamples * 2.5;   // F_ACRobust.hpp:103
+  {
+    double F[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) F[u] = inlF_lds[u];
+    for (uint32_t i = lane; i < n; i += 64) mask[P.start + i] = (good && epipolar_error(F, x1[i], x2[i]) <= inl_thr) ? 1 : 0;
+  }
+  if (lane < 9) results[pidx].F[lane] = bestFu;
+  if (lane == 0) {
+    results[pidx].error_max = errorMax; results[pidx].min_nfa = minNFA; results[pidx].n_inliers = inl_count; results[pidx].have_model = have_model;
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { MVGX_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16))); return MVGX_OK; }
+};
+
+template <int WAVES>
+int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
+                 const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, hipStream_t stream) {
+  if (!n_work) return MVGX_OK;
+  const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + kWaveScratch) * sizeof(uint32_t);
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(geofilter_f_acransac_kernel<WAVES>, dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
+                     n_cap, x1, x2, l10, mt_init, max_it, res, mask);
+  MVGX_HIP(hipGetLastError());
+  return MVGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats) {
+  MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || (image_wh && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
+  const uint64_t n_total = match_start[n_pairs];
+  MVGX_REQUIRE(n_total == 0 || (xI && xJ && inlier_mask), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
+  MVGX_REQUIRE(std::isfinite(opt->precision) && opt->precision > 0.0, MVGX_ERR_UNSUPPORTED,
+               "mvgx_geofilter_f_acransac: precision must be a finite upper bound (the exhaustive NFA form of an unbounded precision is not "
+               "reproduced on the device; main_GeometricFilter passes 4.0)");
+  MVGX_REQUIRE(opt->max_iterations >= 1, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: max_iterations must be at least 1");
+  constexpr uint32_t kCap0 = 256, kCap1 = 1024, kCap2 = 4096, kCap3 = 12000;   // correspondences per pair: the LDS a wave needs grows with them (4 / 4 / 2 / 1 waves per workgroup)
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    MVGX_REQUIRE(match_start[p + 1] >= match_start[p], MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: match_start must be non-decreasing");
+    MVGX_REQUIRE(match_start[p + 1] - match_start[p] <= kCap3, MVGX_ERR_UNSUPPORTED,
+                 "mvgx_geofilter_f_acransac: pair %llu has %llu correspondences, more than the %u one wave's LDS holds", (unsigned long long)p,
+                 (unsigned long long)(match_start[p + 1] - match_start[p]), kCap3);
+  }
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = mvgx::select_device(device < 0 ? -1 : device);
+  if (rc) return rc;
+  // ---- host preparation (ACKernelAdaptor's constructor + NFA_Interface's constants), on host threads ----
+  std::vector<GeoPair> hp(n_pairs);
+  std::vector<double> norm(n_pairs * 6);   // {s1, tx1, ty1, s2, tx2, ty2}; the points are normalised on the device
+  uint32_t n_max = 0;
+  for (uint64_t p = 0; p < n_pairs; ++p) n_max = std::max<uint32_t>(n_max, (uint32_t)(match_start[p + 1] - match_start[p]));
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, (size_t)(n_pairs / 4096 + 1)}));
+  auto prep = [&](unsigned tix) {
+    for (uint64_t p = tix; p < n_pairs; p += T) {
+      const uint64_t lo = match_start[p];
+      const uint32_t n = (uint32_t)(match_start[p + 1] - lo);
+      GeoPair& g = hp[p];
+      g.start = lo; g.n = n; g.pad_ = 0;
+      double t[2][3];
+      for (int im = 0; im < 2; ++im) {   // conditioning.cpp:44-53
+        const int w = (int)image_wh[4 * p + 2 * im], h = (int)image_wh[4 * p + 2 * im + 1];
+        const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
+        t[im][0] = dNorm; t[im][1] = -.5f * w * dNorm; t[im][2] = -.5 * h * dNorm;
+        for (int k = 0; k < 3; ++k) norm[6 * p + 3 * im + k] = t[im][k];
+      }
+      const int w2 = (int)image_wh[4 * p + 2], h2 = (int)image_wh[4 * p + 3];
+      const double logalpha0 = std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
+      g.max_threshold = opt->precision * opt->precision * t[1][0] * t[1][0];
+      g.loge0 = n > (uint32_t)kMinSamples ? std::log10((double)kMaxModels * (n - kMinSamples)) : 0.0;
+      g.bins_by_interval = kBins / (g.max_threshold - 0.0);
+      const double val = (g.max_threshold - 0.0) / static_cast<double>(kBins - 1);
+      for (int b = 0; b < kBins; ++b) {
+        g.bin_value[b] = val * static_cast<double>(b) + 0.0;
+        g.logalpha_bin[b] = logalpha0 + 0.5 * std::log10(g.bin_value[b] + std::numeric_limits<float>::epsilon());
+      }
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(prep, t);
+    prep(0);
+    for (auto& th : pool) th.join();
+  }
+  // pairs that run the estimation (more than 7 correspondences), by size class, largest first inside a class
+  std::vector<uint32_t> order;
+  order.reserve(n_pairs);
+  for (uint64_t p = 0; p < n_pairs; ++p) if (hp[p].n > (uint32_t)kMinSamples) order.push_back((uint32_t)p);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hp[a].n > hp[b].n; });
+  uint32_t c3 = 0, c2 = 0, c1 = 0;   // [0, c3): n > kCap2; [c3, c2): n > kCap1; [c2, c1): n > kCap0; the rest <= kCap0
+  while (c3 < order.size() && hp[order[c3]].n > kCap2) ++c3;
+  c2 = c3;
+  while (c2 < order.size() && hp[order[c2]].n > kCap1) ++c2;
+  c1 = c2;
+  while (c1 < order.size() && hp[order[c1]].n > kCap0) ++c1;
+  std::vector<float> l10(n_max + 2);
+  for (uint32_t i = 0; i <= n_max + 1; ++i) l10[i] = (float)::log10((double)static_cast<float>(i));   // log10 of a float through the C function, as the reference's unqualified call resolves
+  uint32_t mt_init[kMtN];
+  mt_init[0] = 5489u;
+  for (int i = 1; i < kMtN; ++i) mt_init[i] = 1812433253u * (mt_init[i - 1] ^ (mt_init[i - 1] >> 30)) + (uint32_t)i;
+  const auto t_prep = std::chrono::steady_clock::now();
+  // ---- device ----
+  hipStream_t stream = nullptr;
+  MVGX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm;
+  if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_total * sizeof(double2))) ||
+      (rc = d_x2.alloc(n_total * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
+      (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_raw1.alloc(n_total * sizeof(double2))) ||
+      (rc = d_raw2.alloc(n_total * sizeof(double2))) || (rc = d_norm.alloc(norm.size() * sizeof(double))))
+    return rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  MVGX_HIP(hipEventCreate(&e0));
+  MVGX_HIP(hipEventCreate(&e1));
+  struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
+  if (n_pairs) MVGX_HIP(hipMemcpyAsync(d_pairs.p, hp.data(), n_pairs * sizeof(GeoPair), hipMemcpyHostToDevice, stream));
+  if (!order.empty()) MVGX_HIP(hipMemcpyAsync(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  if (n_total) {
+    MVGX_HIP(hipMemcpyAsync(d_raw1.p, xI, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemcpyAsync(d_raw2.p, xJ, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemcpyAsync(d_norm.p, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemsetAsync(d_mask.p, 0, n_total, stream));
+  }
+  MVGX_HIP(hipMemcpyAsync(d_l10.p, l10.data(), l10.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  MVGX_HIP(hipMemcpyAsync(d_mt.p, mt_init, sizeof(mt_init), hipMemcpyHostToDevice, stream));
+  if (n_pairs) MVGX_HIP(hipMemsetAsync(d_res.p, 0, n_pairs * sizeof(GeoResult), stream));
+  MVGX_HIP(hipEventRecord(e0, stream));
+  const uint32_t* ord = static_cast<const uint32_t*>(d_order.p);
+  const auto* px1 = static_cast<const double2*>(d_x1.p);
+  const auto* px2 = static_cast<const double2*>(d_x2.p);
+  if (n_total) {   // (plain pointers in the launch: the buffers own their memory and must not be captured by value)
+    const auto* pp = static_cast<const GeoPair*>(d_pairs.p);
+    const auto* pn = static_cast<const double*>(d_norm.p);
+    const auto *r1 = static_cast<const double2*>(d_raw1.p), *r2 = static_cast<const double2*>(d_raw2.p);
+    auto *o1 = static_cast<double2*>(d_x1.p), *o2 = static_cast<double2*>(d_x2.p);
+    hipLaunchKernelGGL(geofilter_normalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, r1, r2, o1, o2);
+    MVGX_HIP(hipGetLastError());
+  }
+  if ((rc = launch_class<1>(static_cast<GeoPair*>(d_pairs.p), ord, c3, kCap3, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
+                            opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
+    return rc;
+  if ((rc = launch_class<2>(static_cast<GeoPair*>(d_pairs.p), ord + c3, c2 - c3, kCap2, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
+                            opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
+    return rc;
+  if ((rc = launch_class<4>(static_cast<GeoPair*>(d_pairs.p), ord + c2, c1 - c2, kCap1, px1, px2, static_cast<float*>(d_l10.p),
+                            static_cast<uint32_t*>(d_mt.p), opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
+    return rc;
+  if ((rc = launch_class<4>(static_cast<GeoPair*>(d_pairs.p), ord + c1, (uint32_t)order.size() - c1, kCap0, px1, px2, static_cast<float*>(d_l10.p),
+                            static_cast<uint32_t*>(d_mt.p), opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
+    return rc;
+  MVGX_HIP(hipEventRecord(e1, stream));
+  std::vector<GeoResult> hr(n_pairs);
+  if (n_pairs) MVGX_HIP(hipMemcpyAsync(hr.data(), d_res.p, n_pairs * sizeof(GeoResult), hipMemcpyDeviceToHost, stream));
+  if (n_total) MVGX_HIP(hipMemcpyAsync(inlier_mask, d_mask.p, n_total, hipMemcpyDeviceToHost, stream));
+  MVGX_HIP(hipStreamSynchronize(stream));
+  float kernel_ms = 0.f;
+  (void)hipEventElapsedTime(&kernel_ms, e0, e1);
+  // ---- results in the reference's terms: Unnormalize (conditioning.cpp:87-89), unormalizeError, the 2.5 x 7 acceptance ----
+  uint64_t n_ok = 0, n_inl = 0;
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    mvgx_geofilter_result& o = results[p];
+    const GeoResult& r = hr[p];
+    const bool ran = hp[p].n > (uint32_t)kMinSamples;
+    double Fm[9];
+    for (int u = 0; u < 9; ++u) Fm[u] = (ran && r.have_model) ? r.F[u] : ((u % 4 == 0) ? 1.0 : 0.0);   // m_F starts as the identity
+    double err = ran ? r.error_max : 0.0;
+    if (ran && r.n_inliers > 0) {
+      const double* t = &norm[6 * p];
+      const double N1[9] = {t[0], 0, t[1], 0, t[0], t[2], 0, 0, 1}, N2[9] = {t[3], 0, t[4], 0, t[3], t[5], 0, 0, 1};
+      double tmp[9], res[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s_ = 0; for (int k = 0; k < 3; ++k) s_ += N2[3 * k + a] * Fm[3 * k + b]; tmp[3 * a + b] = s_; }
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s_ = 0; for (int k = 0; k < 3; ++k) s_ += tmp[3 * a + k] * N1[3 * k + b]; res[3 * a + b] = s_; }
+      std::memcpy(Fm, res, sizeof(res));
+      err = std::sqrt(err) / t[3];
+    }
+    std::memcpy(o.F, Fm, sizeof(Fm));
+    o.precision_robust = err;
+    o.nfa = ran ? r.min_nfa : 0.0;
+    o.n_inliers = ran ? r.n_inliers : 0;
+    o.ok = ran && (double)r.n_inliers > kMinSamples * 2.5;
+    n_ok += o.ok; n_inl += o.ok ? o.n_inliers : 0;
+  }
+  if (stats) {
+    stats->n_pairs = n_pairs; stats->n_pairs_estimated = order.size(); stats->n_pairs_ok = n_ok; stats->n_inliers = n_inl;
+    stats->kernel_ms = kernel_ms;
+    stats->host_prepare_ms = std::chrono::duration<double, std::milli>(t_prep - t_begin).count();
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return MVGX_OK;
+}
+
+}  // extern "C"

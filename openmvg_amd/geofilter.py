@@ -1,0 +1,73 @@
+"""Host-side mirror of openMVG's geometric filtering of putative matches on top of the mvgx C ABI.
+
+  ImageCollectionGeometricFilter::Robust_model_estimation      matching_image_collection/GeometricFilter.hpp:66-131
+  GeometricFilter_FMatrix_AC(dPrecision, iteration)             matching_image_collection/F_ACRobust.hpp:32-122
+  MatchesPairToMat                                              matching_image_collection/Geometric_Filter_utils.hpp:56-64
+
+All numerics run in libmvgx_hip.so on the GPU (one wave per image pair); there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class GeometricFilter_FMatrix_AC:
+    """Field names of the reference functor; `Robust_estimation` of one pair is `filter_pairs` on a one-pair container."""
+
+    def __init__(self, dPrecision=4.0, iteration=1024):
+        self.m_dPrecision = float(dPrecision)
+        self.m_stIteration = int(iteration)
+
+
+def filter_pairs(xI, xJ, match_start, image_wh, functor=None, device=-1):
+    """xI, xJ: (N, 2) float64 pixel positions of the putative matches of all pairs, pair p owning rows
+    [match_start[p], match_start[p + 1]); image_wh: (n_pairs, 4) uint32 {w_I, h_I, w_J, h_J}.
+    Returns (inlier_mask (N,) bool, results structured array, stats)."""
+    functor = functor or GeometricFilter_FMatrix_AC(4.0, 2048)
+    xI = np.ascontiguousarray(xI, np.float64).reshape(-1, 2)
+    xJ = np.ascontiguousarray(xJ, np.float64).reshape(-1, 2)
+    start = np.ascontiguousarray(match_start, np.uint64)
+    wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 4)
+    n_pairs = len(start) - 1
+    if len(wh) != n_pairs or int(start[-1]) != len(xI) or len(xI) != len(xJ):
+        raise ValueError("filter_pairs: inconsistent array sizes")
+    mask = np.zeros(max(len(xI), 1), np.uint8)
+    res = (_capi.GeofilterResult * max(n_pairs, 1))()
+    st = _capi.GeofilterStats()
+    opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _capi.check(_capi.lib().mvgx_geofilter_f_acransac(int(device), P(xI), P(xJ), P(start), P(wh), n_pairs, C.byref(opt), P(mask),
+                                                      C.cast(res, C.c_void_p), C.byref(st)))
+    out = np.zeros(n_pairs, dtype=[("F", np.float64, (3, 3)), ("precision_robust", np.float64), ("nfa", np.float64),
+                                   ("n_inliers", np.uint32), ("ok", bool)])
+    for p in range(n_pairs):
+        out["F"][p] = np.array(res[p].F[:]).reshape(3, 3)
+        out["precision_robust"][p] = res[p].precision_robust
+        out["nfa"][p] = res[p].nfa
+        out["n_inliers"][p] = res[p].n_inliers
+        out["ok"][p] = bool(res[p].ok)
+    return mask[:len(xI)].astype(bool), out, st
+
+
+def Robust_model_estimation(putative_matches, feats_xy, image_sizes, functor=None, device=-1):
+    """The container form: putative_matches = {(I, J): (n, 2) uint32 index pairs} (a PairWiseMatches), feats_xy[k] = (n_k, 2)
+    feature positions of image k (undistorted where the reference would undistort them), image_sizes[k] = (w, h). Returns the
+    geometric matches {(I, J): (m, 2)}: only the pairs whose estimation succeeded, like _map_GeometricMatches."""
+    keys = sorted(putative_matches)
+    xs_i, xs_j, start, wh = [], [], [0], []
+    for (i, j) in keys:
+        m = np.asarray(putative_matches[(i, j)], np.uint32).reshape(-1, 2)
+        xs_i.append(np.asarray(feats_xy[i], np.float64)[m[:, 0]])
+        xs_j.append(np.asarray(feats_xy[j], np.float64)[m[:, 1]])
+        start.append(start[-1] + len(m))
+        wh.append((*image_sizes[i], *image_sizes[j]))
+    if not keys:
+        return {}
+    mask, res, _ = filter_pairs(np.concatenate(xs_i), np.concatenate(xs_j), np.asarray(start, np.uint64), np.asarray(wh, np.uint32), functor, device)
+    out = {}
+    for k, key in enumerate(keys):
+        if res["ok"][k]:
+            out[key] = np.asarray(putative_matches[key], np.uint32).reshape(-1, 2)[mask[start[k]:start[k + 1]]]
+    return out

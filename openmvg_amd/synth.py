@@ -259,3 +259,56 @@ def float_descriptors(n_images, n_desc=300, dim=64, seed=0, noise=0.05):
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         out.append(np.ascontiguousarray(d.astype(np.float32)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Two-view correspondences for the geometric filter: per image pair two pinhole views of a random point cloud
+# (rotation about y, baseline along x), pixel noise on the second view, a share of uniformly random outliers; some pairs have
+# no geometry at all (the filter's early exit), some fewer than 8 correspondences (rejected without estimation).
+# ---------------------------------------------------------------------------------------------------------
+def two_view_matches(n_pairs, seed=0, n_min=8, n_max=400, inlier_frac=(0.3, 0.9), noise_px=0.4, no_geometry_frac=0.25, tiny_frac=0.02,
+                     sizes=((1000, 1000), (1280, 960), (1920, 1080))):
+    """Returns dict(xI, xJ: (N, 2) float64 pixels; start: (n_pairs + 1,) uint64; wh: (n_pairs, 4) uint32 {w_I, h_I, w_J, h_J};
+    is_inlier: (N,) bool ground truth)."""
+    rng = np.random.default_rng(seed)
+    xs_i, xs_j, truth, start, wh = [], [], [], [0], []
+    for _ in range(n_pairs):
+        u = rng.random()
+        n = int(rng.integers(0, 8)) if u < tiny_frac else int(rng.integers(n_min, n_max + 1))
+        (wi, hi), (wj, hj) = sizes[rng.integers(len(sizes))], sizes[rng.integers(len(sizes))]
+        f = 0.9 * max(wi, hi)
+        th = rng.uniform(0.03, 0.25) * (1 if rng.random() < 0.5 else -1)
+        base = rng.uniform(0.3, 1.0)
+        X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), 6 + rng.uniform(-1.5, 1.5, n)], 1)
+        Y = np.stack([np.cos(th) * X[:, 0] + np.sin(th) * X[:, 2] - base, X[:, 1] + 0.05, -np.sin(th) * X[:, 0] + np.cos(th) * X[:, 2]], 1)
+        a = np.stack([f * X[:, 0] / X[:, 2] + wi / 2, f * X[:, 1] / X[:, 2] + hi / 2], 1)
+        b = np.stack([f * Y[:, 0] / Y[:, 2] + wj / 2, f * Y[:, 1] / Y[:, 2] + hj / 2], 1) + rng.normal(0, noise_px, (n, 2))
+        frac = 0.0 if rng.random() < no_geometry_frac else rng.uniform(*inlier_frac)
+        inl = rng.random(n) < frac
+        b[~inl] = np.stack([rng.uniform(0, wj, (~inl).sum()), rng.uniform(0, hj, (~inl).sum())], 1)
+        xs_i.append(a); xs_j.append(b); truth.append(inl)
+        start.append(start[-1] + n)
+        wh.append((wi, hi, wj, hj))
+    cat = lambda v, w: np.ascontiguousarray(np.concatenate(v) if v else np.zeros((0, w)), dtype=np.float64)   # noqa: E731
+    return dict(xI=cat(xs_i, 2).reshape(-1, 2), xJ=cat(xs_j, 2).reshape(-1, 2), start=np.asarray(start, np.uint64),
+                wh=np.asarray(wh, np.uint32).reshape(-1, 4), is_inlier=np.concatenate(truth) if truth else np.zeros(0, bool))
+
+
+def two_view_matches_bulk(n_pairs, n=250, seed=0, inlier_frac=(0.3, 0.9), noise_px=0.4, no_geometry_frac=0.25, size=(1000, 1000)):
+    """The same kind of scene as two_view_matches with n correspondences in every pair, generated in bulk (bench workloads)."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    f = 0.9 * max(w, h)
+    th = rng.uniform(0.03, 0.25, (n_pairs, 1)) * np.where(rng.random((n_pairs, 1)) < 0.5, 1.0, -1.0)
+    base = rng.uniform(0.3, 1.0, (n_pairs, 1))
+    X0, X1, X2 = rng.uniform(-2, 2, (n_pairs, n)), rng.uniform(-1.5, 1.5, (n_pairs, n)), 6 + rng.uniform(-1.5, 1.5, (n_pairs, n))
+    Y0, Y1, Y2 = np.cos(th) * X0 + np.sin(th) * X2 - base, X1 + 0.05, -np.sin(th) * X0 + np.cos(th) * X2
+    a = np.stack([f * X0 / X2 + w / 2, f * X1 / X2 + h / 2], 2)
+    b = np.stack([f * Y0 / Y2 + w / 2, f * Y1 / Y2 + h / 2], 2) + rng.normal(0, noise_px, (n_pairs, n, 2))
+    frac = np.where(rng.random((n_pairs, 1)) < no_geometry_frac, 0.0, rng.uniform(*inlier_frac, (n_pairs, 1)))
+    inl = rng.random((n_pairs, n)) < frac
+    out = np.stack([rng.uniform(0, w, (n_pairs, n)), rng.uniform(0, h, (n_pairs, n))], 2)
+    b = np.where(inl[:, :, None], b, out)
+    return dict(xI=np.ascontiguousarray(a.reshape(-1, 2)), xJ=np.ascontiguousarray(b.reshape(-1, 2)),
+                start=(np.arange(n_pairs + 1, dtype=np.uint64) * np.uint64(n)), wh=np.tile(np.array([w, h, w, h], np.uint32), (n_pairs, 1)),
+                is_inlier=inl.reshape(-1))

@@ -662,3 +662,42 @@ def adapter():
             setattr(both, name, getattr(b, name))
         _adapter = both
     return _adapter
+
+
+# ---------------------------------------------------------------------------------------------------------
+# geometric filter checkers
+# ---------------------------------------------------------------------------------------------------------
+_refgeo = None
+
+
+def have_ref_geofilter():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+
+
+def _geofilter_call(fn, tv, precision, max_iterations, threads=None):
+    xI = np.ascontiguousarray(tv["xI"], np.float64); xJ = np.ascontiguousarray(tv["xJ"], np.float64)
+    start = np.ascontiguousarray(tv["start"], np.uint64); wh = np.ascontiguousarray(tv["wh"], np.uint32)
+    n_pairs = len(start) - 1
+    mask = np.zeros(max(int(start[-1]), 1), np.uint8); ok = np.zeros(max(n_pairs, 1), np.uint8)
+    F = np.zeros((max(n_pairs, 1), 9)); prec = np.zeros(max(n_pairs, 1)); nfa = np.zeros(max(n_pairs, 1))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    args = [P(xI), P(xJ), P(start), P(wh), C.c_uint64(n_pairs), C.c_double(precision), C.c_uint32(max_iterations)]
+    if threads is not None:
+        args.append(C.c_int(threads))
+    fn.restype = C.c_double
+    secs = fn(*args, P(mask), P(ok), P(F), P(prec), P(nfa))
+    return dict(mask=mask[:int(start[-1])].astype(bool), ok=ok[:n_pairs].astype(bool), F=F[:n_pairs].reshape(-1, 3, 3), precision=prec[:n_pairs],
+                nfa=nfa[:n_pairs], seconds=secs)
+
+
+def ref_geofilter(tv, precision=4.0, max_iterations=2048, threads=0):
+    """The reference's own ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError> + ACRANSAC per pair (oracle/_ref/libref_geofilter.so)."""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    return _geofilter_call(_refgeo.ref_geofilter_f_acransac, tv, precision, max_iterations, threads)
+
+
+def port_geofilter(tv, precision=4.0, max_iterations=2048):
+    """oracle/geofilter_oracle.cpp, the plain C++ restatement (one thread)."""
+    return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)

@@ -257,6 +257,7 @@ namespace {   // the kernels' `extern __shared__` arrays (same unnamed namespace
 thread_local __attribute__((aligned(16))) double panel[32768];
 thread_local __attribute__((aligned(16))) double zs[32768];
 thread_local __attribute__((aligned(16))) double lds[32768];
+thread_local __attribute__((aligned(16))) uint32_t lds_u32[65536];
 }  // namespace
 #include "mvgx_common.hip"
 namespace mvgx {   // no RCCL in the emulation: the callback transport of mvgx_ba_set_allreduce covers multi-rank tests
@@ -271,4 +272,5 @@ extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out)
 #include "mvgx_ba.hip"
 #include "mvgx_ba_multi.hip"
 #include "mvgx_bruteforce.hip"
+#include "mvgx_geofilter.hip"
 #endif  // HIPEMU_NO_PRODUCT

@@ -1,0 +1,73 @@
+"""Geometric filter, CPU side: the restatement against the compiled reference and its stored outputs, the
+device code under the HIP emulation against the same, the host mirror, argument handling."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openmvg_amd import _capi, geofilter, synth
+from tests import _emu, _geofilter_cases as gc, _oracle
+
+GOLD = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "geofilter.npz"))
+
+
+def _gold_tv(sel=None):
+    start = GOLD["start"].astype(np.int64)
+    pairs = range(len(start) - 1) if sel is None else sel
+    xs_i, xs_j, st, wh = [], [], [0], []
+    idx = []
+    for p in pairs:
+        xs_i.append(GOLD["xI"][start[p]:start[p + 1]]); xs_j.append(GOLD["xJ"][start[p]:start[p + 1]])
+        st.append(st[-1] + int(start[p + 1] - start[p])); wh.append(GOLD["wh"][p]); idx.append(p)
+    tv = dict(xI=np.concatenate(xs_i), xJ=np.concatenate(xs_j), start=np.asarray(st, np.uint64), wh=np.asarray(wh, np.uint32))
+    ref = dict(mask=np.concatenate([GOLD["mask"][start[p]:start[p + 1]] for p in idx]), ok=GOLD["ok"][idx], F=GOLD["F"][idx],
+               precision=GOLD["precision"][idx], nfa=GOLD["nfa"][idx])
+    return tv, ref
+
+
+def test_restatement_equals_the_stored_reference_outputs():
+    """oracle/geofilter_oracle.cpp on the golden inputs: same inlier sets as the reference (stored), NFA / precision / F per policy;
+    at most 1 % of the pairs may fall under policy (b)"""
+    tv, ref = _gold_tv()
+    got = _oracle.port_geofilter(tv, float(GOLD["precision_px"]), int(GOLD["max_iterations"]))
+    differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.01 * rep["pairs"], rep
+
+
+@pytest.mark.skipif(not _oracle.have_ref_geofilter(), reason="oracle/_ref/libref_geofilter.so not built (needs /root/reference)")
+def test_restatement_equals_the_compiled_reference_live():
+    tv = synth.two_view_matches(400, seed=77, n_max=250)
+    ref = _oracle.ref_geofilter(tv)
+    got = _oracle.port_geofilter(tv)
+    differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
+    assert len(differing) <= 0.01 * rep["pairs"], rep
+    # few iterations: the max-consensus warm-up and its early exit decide (robust_estimator_ACRansac.hpp:445-451)
+    ref2 = _oracle.ref_geofilter(tv, max_iterations=40); got2 = _oracle.port_geofilter(tv, max_iterations=40)
+    differing2, rep2 = gc.compare(tv["start"], ref2, got2["mask"], got2["ok"], got2["F"], got2["precision"], got2["nfa"])
+    assert len(differing2) <= 0.01 * rep2["pairs"], rep2
+
+
+def test_emulated_device_code_equals_the_stored_reference_outputs():
+    """the kernel of openmvg_amd/csrc/mvgx_geofilter.hip under tests/native/hipemu (one fiber per lane) on a handful of golden pairs,
+    incl. one without geometry, one below 8 correspondences"""
+    start = GOLD["start"].astype(np.int64)
+    n = np.diff(start)
+    small = [int(p) for p in np.argsort(n) if n[p] <= 90]
+    sel = small[:2] + [p for p in small if GOLD["ok"][p]][:4] + [p for p in small if not GOLD["ok"][p] and n[p] > 7][:2]
+    tv, ref = _gold_tv(sel)
+    with _emu.emulated():
+        mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(4.0, 2048))
+    differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert not differing, (rep, differing)
+    assert int(st.n_pairs_ok) == int(ref["ok"].sum())
+
+
+def test_container_mirror_and_argument_errors():
+    with _emu.emulated():
+        assert geofilter.Robust_model_estimation({}, [], []) == {}
+        xI = np.zeros((3, 2)); start = np.array([0, 3], np.uint64); wh = np.array([[100, 100, 100, 100]], np.uint32)
+        mask, res, st = geofilter.filter_pairs(xI, xI, start, wh)   # fewer than 8 correspondences: rejected without estimation
+        assert not mask.any() and not res["ok"][0] and res["n_inliers"][0] == 0 and np.array_equal(res["F"][0], np.eye(3))
+        with pytest.raises(_capi.MvgxError) as e:
+            geofilter.filter_pairs(xI, xI, start, wh, geofilter.GeometricFilter_FMatrix_AC(float("inf"), 1024))
+        assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
