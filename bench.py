@@ -270,6 +270,11 @@ def main():
             out["l2_uint8_144"] = l2u8_bench_record(local_rank, cpu=not args.no_cpu_baseline)
         except Exception as e:  # side record only
             out["hamming"] = {"status": f"failed: {e!r}"}
+        try:   # the step after putative matching
+            from bench_geofilter import geofilter_bench_record
+            out["geometric_filter"] = geofilter_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            out["geometric_filter"] = {"status": f"failed: {e!r}"}
     if rank == 0:
         if ba_rec is not None:
             out["ba"] = ba_rec

@@ -1,0 +1,29 @@
+// mvgx_geometric_filter.hpp - openMVG-side adapter of the MI355X geometric filter.
+//
+// ImageCollectionGeometricFilter::Robust_model_estimation is a member TEMPLATE defined in the reference header
+// (openMVG/matching_image_collection/GeometricFilter.hpp:66-131); its callers (software/SfM/main_GeometricFilter.cpp:303-309,
+// software/SfM/main_ComputeMatches... pipelines) instantiate it with a functor type. There is no translation unit to replace, so the
+// drop-in is an explicit specialisation for the fundamental-matrix functor: a caller that includes THIS header (one line after its
+// include of GeometricFilter.hpp, or -include on the command line) gets the declaration below, the compiler no longer instantiates
+// the primary template for GeometricFilter_FMatrix_AC, and the linker takes the definition of mvgx_geometric_filter.cpp, which
+// runs all image pairs of the container through mvgx_geofilter_f_acransac (include/mvgx.h). Same signature, same container
+// (_map_GeometricMatches), same acceptance rule; the guided-matching step, if asked for, runs the reference's own
+// Geometry_guided_matching with the estimated F. The other functors (H, E, ...) keep the reference's template.
+#ifndef MVGX_GEOMETRIC_FILTER_HPP
+#define MVGX_GEOMETRIC_FILTER_HPP
+
+#include "openMVG/matching_image_collection/F_ACRobust.hpp"
+#include "openMVG/matching_image_collection/GeometricFilter.hpp"
+
+namespace openMVG {
+namespace matching_image_collection {
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>(
+    const GeometricFilter_FMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+}  // namespace matching_image_collection
+}  // namespace openMVG
+
+#endif  // MVGX_GEOMETRIC_FILTER_HPP

@@ -62,3 +62,69 @@ double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64
 }
 
 }  // extern "C"
+
+// ---- container level: ImageCollectionGeometricFilter::Robust_model_estimation on an in-memory scene --------------------------
+// The same caller code is compiled twice: into oracle/_ref/libref_geofilter.so against the reference headers alone (the member
+// template of GeometricFilter.hpp is instantiated), and into the adapter harness with -include mvgx_geometric_filter.hpp, where
+// the explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp is linked instead (tests/native/adapter_harness.mk).
+#include "openMVG/cameras/Camera_Pinhole_Radial.hpp"
+#include "openMVG/features/regions_factory.hpp"
+#include "openMVG/matching_image_collection/F_ACRobust.hpp"
+#include "openMVG/matching_image_collection/GeometricFilter.hpp"
+#include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
+#include "openMVG/sfm/sfm_data.hpp"
+
+namespace {
+struct InMemoryRegionsProvider : public sfm::Regions_Provider {
+  void set(IndexT id, std::shared_ptr<features::Regions> r) { cache_[id] = std::move(r); }
+  void set_type(features::Regions* t) { region_type_.reset(t); }
+};
+}  // namespace
+
+extern "C" {
+typedef void (*geo_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
+
+// images: feat_xy (2 floats per feature, image k owning [feat_start[k], feat_start[k + 1])), descs (128 bytes per feature or NULL),
+// image_wh (w, h per image); k1 != 0: all views share one Pinhole_Intrinsic_Radial_K1 (the positions are then undistorted by
+// MatchesPairToMat). putative matches: pairs_IJ, match_start, matches_ij (feature indices). The geometric matches are handed to
+// `sink` in container order. Returns the number of pairs in the result.
+uint64_t ref_geofilter_container(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                 const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                 double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
+  sfm::SfM_Data scene;
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new features::SIFT_Regions());
+  for (uint32_t k = 0; k < n_images; ++k) {
+    scene.views[k] = std::make_shared<sfm::View>("", k, k1 != 0.0 ? 0 : UndefinedIndexT, UndefinedIndexT, image_wh[2 * k], image_wh[2 * k + 1]);
+    auto r = std::make_shared<features::SIFT_Regions>();
+    const uint64_t lo = feat_start[k], n = feat_start[k + 1] - lo;
+    r->Features().resize(n);
+    r->Descriptors().resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      r->Features()[i] = features::SIOPointFeature(feat_xy[2 * (lo + i)], feat_xy[2 * (lo + i) + 1], 1.f, 0.f);
+      if (descs) std::memcpy(r->Descriptors()[i].data(), descs + (lo + i) * 128, 128);
+      else std::memset(r->Descriptors()[i].data(), 0, 128);
+    }
+    provider->set(k, r);
+  }
+  if (k1 != 0.0)
+    scene.intrinsics[0] = std::make_shared<cameras::Pinhole_Intrinsic_Radial_K1>(image_wh[0], image_wh[1], 0.9 * image_wh[0], image_wh[0] / 2.0, image_wh[1] / 2.0, k1);
+  matching::PairWiseMatches putative;
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    matching::IndMatches m;
+    for (uint64_t i = match_start[p]; i < match_start[p + 1]; ++i) m.emplace_back(matches_ij[2 * i], matches_ij[2 * i + 1]);
+    putative.insert({{pairs_IJ[2 * p], pairs_IJ[2 * p + 1]}, std::move(m)});
+  }
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matching_image_collection::ImageCollectionGeometricFilter filter(&scene, base);
+  filter.Robust_model_estimation(matching_image_collection::GeometricFilter_FMatrix_AC(precision, max_iterations), putative, guided != 0, distance_ratio);
+  const matching::PairWiseMatches& out = filter.Get_geometric_matches();
+  std::vector<uint32_t> buf;
+  for (const auto& kv : out) {
+    buf.clear();
+    for (const auto& m : kv.second) { buf.push_back(m.i_); buf.push_back(m.j_); }
+    sink(user, kv.first.first, kv.first.second, buf.data(), (uint32_t)kv.second.size());
+  }
+  return out.size();
+}
+}  // extern "C"

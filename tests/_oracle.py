@@ -701,3 +701,54 @@ def ref_geofilter(tv, precision=4.0, max_iterations=2048, threads=0):
 def port_geofilter(tv, precision=4.0, max_iterations=2048):
     """oracle/geofilter_oracle.cpp, the plain C++ restatement (one thread)."""
     return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)
+
+
+# ---- the geometric filter at container level: the same caller (oracle/ref_shim_geofilter.cpp::ref_geofilter_container) in the
+# reference library and in the adapter harness (explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp) ----
+ADAPTER_GEO_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_geo.so")
+ADAPTER_GEO_EMU_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_geo_emu.so")
+GEO_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
+_geo_libs = {}
+
+
+def geofilter_container_lib(kind):
+    """kind: "reference" (oracle/_ref/libref_geofilter.so), "adapter" (GPU), "adapter_emu" (HIP emulation). None if unavailable."""
+    if kind in _geo_libs:
+        return _geo_libs[kind]
+    path = {"reference": os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"), "adapter": ADAPTER_GEO_SO, "adapter_emu": ADAPTER_GEO_EMU_SO}[kind]
+    lib = None
+    try:
+        if kind == "adapter_emu":
+            if adapter_emu() is None:   # builds the `emu` targets of the harness
+                return None
+        if os.path.exists(path):
+            lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+            lib.ref_geofilter_container.restype = C.c_uint64
+    except Exception:
+        lib = None
+    _geo_libs[kind] = lib
+    return lib
+
+
+def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None):
+    """feats_xy: list of (n_k, 2) float32 positions; image_wh: (n_images, 2); putative: {(I, J): (n, 2) uint32}. -> {(I, J): (m, 2)}"""
+    lib = geofilter_container_lib(kind)
+    fx = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float32).reshape(-1, 2) for f in feats_xy]), np.float32)
+    fstart = np.cumsum([0] + [len(f) for f in feats_xy]).astype(np.uint64)
+    wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 2)
+    keys = sorted(putative)
+    pij = np.ascontiguousarray(np.asarray(keys, np.uint32).reshape(-1, 2))
+    mstart = np.cumsum([0] + [len(putative[k]) for k in keys]).astype(np.uint64)
+    mij = np.ascontiguousarray(np.concatenate([np.asarray(putative[k], np.uint32).reshape(-1, 2) for k in keys]) if keys else np.zeros((0, 2), np.uint32))
+    dd = None if descs is None else np.ascontiguousarray(np.concatenate(descs), np.uint8)
+    out = {}
+
+    def sink(_u, I, J, p, n):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(p, shape=(int(n), 2)).copy() if n else np.zeros((0, 2), np.uint32)
+
+    cb = GEO_SINK(sink)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    lib.ref_geofilter_container(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij),
+                                C.c_uint64(len(keys)), C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if guided else 0),
+                                C.c_double(ratio), C.c_double(k1), cb, None)
+    return out

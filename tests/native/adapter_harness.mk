@@ -32,7 +32,23 @@ REF_BA_OBJS := $(REFOBJ)/ba/openMVG/numeric/numeric.o $(REFOBJ)/ba/openMVG/sfm/s
             $(REFOBJ)/third_party/stlplus3/filesystemSimplified/wildcard.o
 RPATH := -Wl,-rpath,'$$ORIGIN/../../../openmvg_amd/lib'
 
-all: $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so
+all: $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so $(OUT)/libmvgx_openmvg_adapter_geo.so
+
+# The geometric filter: the caller code of oracle/ref_shim_geofilter.cpp compiled with the adapter's header forced in first
+# (what a maintainer does with one #include in main_GeometricFilter.cpp), linked with the specialisation's object and the
+# reference sources the caller still needs (compiled here: no AVX2, like the adapter object)
+GEO_REF_SRCS := $(REF)/openMVG/multiview/solver_fundamental_kernel.cpp $(REF)/openMVG/numeric/numeric.cpp $(REF)/openMVG/multiview/conditioning.cpp \
+            $(REF)/openMVG/matching_image_collection/Geometric_Filter_utils.cpp $(REF)/openMVG/features/feature.cpp \
+            $(REF)/third_party/stlplus3/filesystemSimplified/file_system.cpp $(REF)/third_party/stlplus3/filesystemSimplified/portability_fixes.cpp \
+            $(REF)/third_party/stlplus3/filesystemSimplified/wildcard.cpp
+GEO_FLAGS := $(BASEFLAGS) -I$(ROOT)/openmvg_amd/adapter -include $(ROOT)/openmvg_amd/adapter/mvgx_geometric_filter.hpp
+$(OUT)/libmvgx_openmvg_adapter_geo.so: $(ROOT)/oracle/ref_shim_geofilter.cpp $(AOBJ)/mvgx_geometric_filter.o $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
+	@mkdir -p $(OUT)
+	$(CXX) $(GEO_FLAGS) -shared -Wl,-Bsymbolic $(RPATH) -o $@ $(ROOT)/oracle/ref_shim_geofilter.cpp $(GEO_REF_SRCS) $(AOBJ)/mvgx_geometric_filter.o -L$(LIBDIR) -lmvgx_hip -lpthread
+$(OUT)/libmvgx_openmvg_adapter_geo_emu.so: $(ROOT)/oracle/ref_shim_geofilter.cpp $(AOBJ)/mvgx_geometric_filter.o $(OUT)/libmvgx_ba_emu.so $(lastword $(MAKEFILE_LIST))
+	@mkdir -p $(OUT)
+	$(CXX) $(GEO_FLAGS) -shared -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(ROOT)/oracle/ref_shim_geofilter.cpp $(GEO_REF_SRCS) $(AOBJ)/mvgx_geometric_filter.o -L$(OUT) -lmvgx_ba_emu -lpthread
+emu: $(OUT)/libmvgx_openmvg_adapter_geo_emu.so
 
 $(OUT)/ref_shim_match.o: $(ROOT)/oracle/ref_shim_match.cpp
 	@mkdir -p $(OUT)

@@ -71,3 +71,20 @@ def test_container_mirror_and_argument_errors():
         with pytest.raises(_capi.MvgxError) as e:
             geofilter.filter_pairs(xI, xI, start, wh, geofilter.GeometricFilter_FMatrix_AC(float("inf"), 1024))
         assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
+
+
+def test_adapter_specialisation_fills_the_container_like_the_reference_template():
+    """ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>: the same caller code linked once against
+    the reference header's template and once against the explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp
+    (device code under the HIP emulation): same pairs in the container, same match lists, with and without a distorting
+    intrinsic (MatchesPairToMat undistorts the positions)"""
+    from tests import _geofilter_scene
+    ref_lib, emu_lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib("adapter_emu")
+    if ref_lib is None or emu_lib is None:
+        pytest.skip("needs /root/reference (reference library and adapter harness)")
+    feats, wh, putative = _geofilter_scene.collection(n_pairs=6, seed=9, n_min=40, n_max=70, inlier_frac=(0.6, 0.9), no_geometry_frac=0.2)
+    for k1 in (0.0, 0.02):
+        want = _oracle.geofilter_container("reference", feats, wh, putative, max_iterations=512, k1=k1)
+        got = _oracle.geofilter_container("adapter_emu", feats, wh, putative, max_iterations=512, k1=k1)
+        assert set(want) == set(got) and len(want) >= 2
+        assert all(np.array_equal(want[k], got[k]) for k in want)

@@ -71,3 +71,19 @@ def test_container_form():
     for p in range(30):
         if res["ok"][p]:
             assert len(geo[(2 * p, 2 * p + 1)]) == int(mask[start[p]:start[p + 1]].sum())
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_adapter_specialisation_against_the_reference_template(guided):
+    """the drop-in (openmvg_amd/adapter/mvgx_geometric_filter.{hpp,cpp}) on the device against the reference's member template
+    through identical caller code; guided matching runs the reference's own Geometry_guided_matching with the device's F"""
+    from tests import _geofilter_scene
+    ref_lib, dev_lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib("adapter")
+    if ref_lib is None or dev_lib is None:
+        pytest.skip("reference library / adapter harness not built")
+    feats, wh, putative = _geofilter_scene.collection(n_pairs=200, seed=21, n_max=250)
+    descs = [np.random.default_rng(7 + k).integers(0, 256, (len(f), 128), dtype=np.uint8) for k, f in enumerate(feats)] if guided else None
+    want = _oracle.geofilter_container("reference", feats, wh, putative, guided=guided, ratio=0.8, descs=descs)
+    got = _oracle.geofilter_container("adapter", feats, wh, putative, guided=guided, ratio=0.8, descs=descs)
+    differing = [k for k in set(want) | set(got) if k not in want or k not in got or not np.array_equal(want[k], got[k])]
+    assert len(want) > 100 and len(differing) <= 2, (len(want), len(got), differing[:5])
