@@ -2615,6 +2615,7 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
   } else if (d.N > 0) {
     const size_t bytes = (size_t)d.N * d.LD * sizeof(double) + (size_t)((d.N + 63) / 64) * 8192 * sizeof(double);
     size_t free_b = 0, total_b = 0;
+    mvgx::trim_device_cache();   // idle cached slabs would read as used memory
     MVGX_HIP(hipMemGetInfo(&free_b, &total_b));
     MVGX_REQUIRE(bytes < free_b, MVGX_ERR_UNSUPPORTED,
                  "reduced camera system of %d columns: its factor fills more than half of the dense triangle, and the dense "
@@ -2832,6 +2833,32 @@ int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
 
 }  // namespace
 
+namespace mvgx {
+// Argument checks of a problem description, shared by the single- and the multi-device entry points: bad input is MVGX_ERR_ARG /
+// MVGX_ERR_UNSUPPORTED here, not a fault inside a worker thread later.
+int ba_validate_problem(const mvgx_ba_problem* p) {
+  MVGX_REQUIRE((p->poses || !p->n_poses) && (p->intrinsics || !p->n_intrinsics) && (p->points || !p->n_points), MVGX_ERR_ARG,
+               "mvgx_ba_create: NULL parameter array");
+  MVGX_REQUIRE(p->intr_model || !p->n_intrinsics, MVGX_ERR_ARG, "mvgx_ba_create: NULL camera-model array");
+  MVGX_REQUIRE(!p->n_obs || (p->obs_pose && p->obs_intr && p->obs_point && p->obs_xy), MVGX_ERR_ARG,
+               "mvgx_ba_create: NULL observation array");
+  MVGX_REQUIRE(!p->n_pose_priors || (p->prior_pose && p->prior_center && p->prior_weight), MVGX_ERR_ARG,
+               "mvgx_ba_create: NULL pose-prior array");
+  for (uint32_t k = 0; k < p->n_intrinsics; ++k)
+    MVGX_REQUIRE(mvgx_ba::intr_param_count(p->intr_model[k]) >= 0, MVGX_ERR_UNSUPPORTED,
+                 "intrinsic %u: camera model %d has no cost functor (sfm_data_BA_ceres.cpp:84-108)", k, p->intr_model[k]);
+  for (uint64_t k = 0; k < p->n_obs; ++k)
+    MVGX_REQUIRE(p->obs_pose[k] < p->n_poses && p->obs_intr[k] < p->n_intrinsics && p->obs_point[k] < p->n_points, MVGX_ERR_ARG,
+                 "observation %llu references a block out of range", (unsigned long long)k);
+  for (uint32_t k = 0; k < p->n_pose_priors; ++k)
+    MVGX_REQUIRE(p->prior_pose[k] < p->n_poses, MVGX_ERR_ARG, "pose prior %u references a pose out of range", k);
+  return MVGX_OK;
+}
+void ba_ctx_comm_abort(mvgx_ba_ctx* c) {
+  if (c && c->rccl) rccl_abort(c->rccl);
+}
+}  // namespace mvgx
+
 extern "C" {
 
 void mvgx_ba_default_options(mvgx_ba_options* o) {
@@ -2853,6 +2880,7 @@ void mvgx_ba_default_options(mvgx_ba_options* o) {
 
 int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(devices && p && out && n_devices >= 1, MVGX_ERR_ARG, "mvgx_ba_create_multi: bad argument");
+  { const int vrc = mvgx::ba_validate_problem(p); if (vrc) return vrc; }
   // never more shards than points (an empty shard would only add latency)
   n_devices = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)n_devices, p->n_points));
   if (n_devices == 1) return mvgx_ba_create(devices[0] < 0 ? -2 : devices[0], p, out);
@@ -2868,6 +2896,7 @@ int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_proble
 
 int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(p && out, MVGX_ERR_ARG, "mvgx_ba_create: NULL argument");
+  { const int vrc = mvgx::ba_validate_problem(p); if (vrc) return vrc; }   // before any dispatch to the multi-device path
   if (device == -1) {   // "no preference": MVGX_DEVICES may name the device(s); small problems stay on one device
     std::vector<int> devs;
     const int rc = mvgx::devices_from_env(devs);
@@ -2878,21 +2907,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     if (!devs.empty()) device = devs[0];
   }
   if (device < 0) device = -1;
-  MVGX_REQUIRE((p->poses || !p->n_poses) && (p->intrinsics || !p->n_intrinsics) && (p->points || !p->n_points), MVGX_ERR_ARG,
-               "mvgx_ba_create: NULL parameter array");
-  MVGX_REQUIRE(!p->n_obs || (p->obs_pose && p->obs_intr && p->obs_point && p->obs_xy), MVGX_ERR_ARG,
-               "mvgx_ba_create: NULL observation array");
   MVGX_REQUIRE(p->n_obs < (1ull << 31), MVGX_ERR_ARG, "mvgx_ba_create: too many observations for one device shard");
-  MVGX_REQUIRE(!p->n_pose_priors || (p->prior_pose && p->prior_center && p->prior_weight), MVGX_ERR_ARG,
-               "mvgx_ba_create: NULL pose-prior array");
-  for (uint32_t k = 0; k < p->n_intrinsics; ++k)
-    MVGX_REQUIRE(intr_param_count(p->intr_model[k]) >= 0, MVGX_ERR_UNSUPPORTED,
-                 "intrinsic %u: camera model %d has no cost functor (sfm_data_BA_ceres.cpp:84-108)", k, p->intr_model[k]);
-  for (uint64_t k = 0; k < p->n_obs; ++k)
-    MVGX_REQUIRE(p->obs_pose[k] < p->n_poses && p->obs_intr[k] < p->n_intrinsics && p->obs_point[k] < p->n_points, MVGX_ERR_ARG,
-                 "observation %llu references a block out of range", (unsigned long long)k);
-  for (uint32_t k = 0; k < p->n_pose_priors; ++k)
-    MVGX_REQUIRE(p->prior_pose[k] < p->n_poses, MVGX_ERR_ARG, "pose prior %u references a pose out of range", k);
   int rc = mvgx::select_device(device);
   if (rc) return rc;
   auto* c = new mvgx_ba_ctx();

@@ -14,4 +14,8 @@ int ba_multi_read_params(BaMulti* m, double* poses, double* intrinsics, double* 
 int ba_multi_residuals(BaMulti* m, double* residual_norm);
 int ba_multi_track_angles(BaMulti* m, double* max_angle_deg);
 int ba_multi_solver_info(BaMulti* m, mvgx_ba_solver_info* out);
+// internal (mvgx_ba.hip): fails the RCCL collectives a context has in flight (another shard of the same process failed);
+// argument checks shared by mvgx_ba_create and mvgx_ba_create_multi
+void ba_ctx_comm_abort(mvgx_ba_ctx* c);
+int ba_validate_problem(const mvgx_ba_problem* p);
 }  // namespace mvgx

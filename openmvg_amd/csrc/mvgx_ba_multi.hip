@@ -122,7 +122,7 @@ int peer_allreduce(void* user, void* device_buffer, uint64_t count, int op, void
       if (g->tmp[r]) (void)hipFree(g->tmp[r]);
       g->tmp[r] = nullptr; g->tmp_cap[r] = 0;
       const size_t want = std::max<uint64_t>(count, 4096);
-      if ((e = hipMalloc(reinterpret_cast<void**>(&g->tmp[r]), want * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
+      if ((e = device_malloc(reinterpret_cast<void**>(&g->tmp[r]), want * sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
       g->tmp_cap[r] = want;
     }
     const unsigned grid = (unsigned)std::min<uint64_t>(1024, (count + 255) / 256);
@@ -197,6 +197,8 @@ struct BaMulti {
   uint32_t n_points = 0;
   uint64_t n_obs = 0;
   bool use_rccl = false;
+  bool comm_ready = false;   // the shards' communicators exist (RCCL transport): a failing shard aborts them
+  std::mutex abort_mu;
   PeerGroup peers;
   std::vector<PeerRank> peer_rank;
 };
@@ -204,6 +206,16 @@ struct BaMulti {
 namespace {
 
 // runs fn(rank) on one host thread per shard; the first failing status is returned with its message
+// A shard that fails must not leave the others waiting inside a collective: the peer transport's barrier is aborted; on the RCCL
+// transport every communicator is aborted (ncclCommAbort fails the all-reduces in flight), after which the multi-device context
+// can only be destroyed - its entry points report MVGX_ERR_STATE.
+void abort_collectives(BaMulti* m) {
+  m->peers.bar.abort();
+  if (m->use_rccl && m->comm_ready) {
+    std::lock_guard<std::mutex> lk(m->abort_mu);
+    for (mvgx_ba_ctx* c : m->child) ba_ctx_comm_abort(c);
+  }
+}
 template <class F>
 int on_all(BaMulti* m, F fn) {
   std::vector<int> rc(m->n, MVGX_OK);
@@ -212,10 +224,10 @@ int on_all(BaMulti* m, F fn) {
   for (int r = 1; r < m->n; ++r)
     th.emplace_back([&, r]() {
       rc[r] = fn(r);
-      if (rc[r]) { err[r] = mvgx_last_error(); m->peers.bar.abort(); }
+      if (rc[r]) { err[r] = mvgx_last_error(); abort_collectives(m); }
     });
   rc[0] = fn(0);
-  if (rc[0]) { err[0] = mvgx_last_error(); m->peers.bar.abort(); }
+  if (rc[0]) { err[0] = mvgx_last_error(); abort_collectives(m); }
   for (auto& t : th) t.join();
   {   // a failed collective leaves the barrier aborted: re-arm it for the next call
     std::lock_guard<std::mutex> lk(m->peers.bar.mu);
@@ -338,12 +350,16 @@ int ba_multi_create(const int* devices, int n_devices, const mvgx_ba_problem* p,
     if (r != 0) {   // prior residuals touch replicated blocks only: exactly one shard may hold them
       sp.n_pose_priors = 0; sp.prior_pose = nullptr; sp.prior_center = nullptr; sp.prior_weight = nullptr;
     }
-    int rc = mvgx_ba_create(m->devices[r], &sp, &m->child[r]);
-    if (rc) return rc;
+    return mvgx_ba_create(m->devices[r], &sp, &m->child[r]);
+  });
+  if (rc) return rc;   // (a shard that cannot be built - e.g. out of memory on one device - ends the call here, before any rank waits in ncclCommInitRank)
+  // ---- the transport, once every shard exists ----
+  const int rc2 = on_all(m, [&](int r) -> int {
     if (m->use_rccl) return mvgx_ba_comm_init(m->child[r], m->n, r, uid);
     return mvgx_ba_set_allreduce(m->child[r], &peer_allreduce, &m->peer_rank[r]);
   });
-  if (rc) return rc;
+  if (rc2) return rc2;
+  m->comm_ready = true;
   guard.m = nullptr;
   *out = m;
   return MVGX_OK;

@@ -423,7 +423,7 @@ struct Buf {
     release();
     const size_t want = std::max<size_t>(n + n / 4, 16);
     if (pinned) MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), 0));
-    else MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
+    else MVGX_HIP(mvgx::device_malloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
     cap = want;
     return MVGX_OK;
   }

@@ -28,6 +28,7 @@ struct Api {
   CommInitRankFn comm_init_rank = nullptr;
   AllReduceFn all_reduce = nullptr;
   CommDestroyFn comm_destroy = nullptr;
+  CommDestroyFn comm_abort = nullptr;   // ncclCommAbort(comm): same signature as ncclCommDestroy
   GetErrorStringFn error_string = nullptr;
 };
 
@@ -45,6 +46,7 @@ Api* api() {
       a.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(a.handle, "ncclCommInitRank"));
       a.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(a.handle, "ncclAllReduce"));
       a.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(a.handle, "ncclCommDestroy"));
+      a.comm_abort = reinterpret_cast<CommDestroyFn>(dlsym(a.handle, "ncclCommAbort"));
       a.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(a.handle, "ncclGetErrorString"));
     }
   }
@@ -99,9 +101,22 @@ void rccl_destroy(RcclComm* c) {
   delete c;
 }
 
+// A rank of the same process failed outside a collective: the others may be blocked inside ncclAllReduce (or in the stream
+// synchronisation behind it) waiting for a contribution that will never come. ncclCommAbort may be called from another thread
+// while the communicator is in use: it fails the operations in flight and releases the communicator; the object stays (comm =
+// null) so that later calls report an error instead of touching freed state.
+void rccl_abort(RcclComm* c) {
+  if (!c || !c->comm) return;
+  Api* a = api();
+  Comm comm = c->comm;
+  c->comm = nullptr;
+  if (a && a->comm_abort) a->comm_abort(comm);
+}
+
 int rccl_allreduce_f64(RcclComm* c, double* device_buffer, uint64_t count, int op, hipStream_t stream) {
   Api* a = api();
   if (!a) return MVGX_ERR_HIP;
+  MVGX_REQUIRE(c && c->comm, MVGX_ERR_STATE, "all-reduce on an aborted RCCL communicator (another device shard failed): destroy the context");
   const int rc = a->all_reduce(device_buffer, device_buffer, count, kNcclFloat64, op == MVGX_REDUCE_MAX ? kNcclMax : kNcclSum,
                                c->comm, stream);
   MVGX_REQUIRE(rc == 0, MVGX_ERR_HIP, "ncclAllReduce(%llu doubles): %s", (unsigned long long)count, nccl_err(a, rc));

@@ -33,6 +33,10 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 int select_device(int device);
+// frees the idle device-memory slabs the Arena cache holds for the current device (see mvgx_common.hip)
+void trim_device_cache();
+// hipMalloc that, on failure, trims the Arena cache of the current device and tries once more
+hipError_t device_malloc(void** p, size_t bytes);
 
 // MVGX_DEVICES: "all" or a comma-separated list of device ordinals (an ordinal may repeat: several contexts on one device,
 // used by the single-GPU tests of the multi-device paths). Unset / empty -> `out` stays empty (the current device).
@@ -41,7 +45,8 @@ int devices_from_env(std::vector<int>& out);
 // Device memory of one context, sub-allocated from a few large slabs that are handed back to a process-wide cache when the
 // context is destroyed: an SfM engine calls Bundle_Adjustment::Adjust hundreds of times (sequential_SfM.cpp:593-596, :1190-1215),
 // and a context makes ~80 allocations - through hipMalloc / hipFree that is several milliseconds per call, from the cache a few
-// microseconds. MVGX_DEVICE_CACHE_MB bounds what the cache keeps per device (default 4096; 0: no caching).
+// microseconds. MVGX_DEVICE_CACHE_MB bounds what the cache keeps per device (default 4096; 0: no caching); trim_device_cache()
+// returns the idle slabs of the current device to the driver.
 class Arena {
  public:
   Arena() = default;

@@ -141,10 +141,10 @@ void Arena::release() {
   std::vector<Slab> drop;
   {
     std::lock_guard<std::mutex> lk(c.mu);
-    size_t cached = 0;
-    for (const auto& e : c.free_) cached += e.size;
-    for (const Slab& s : slabs_) {
-      if (cached + s.size <= c.limit()) { c.free_.push_back(SlabCache::Entry{s.p, s.size, s.device}); cached += s.size; }
+    for (const Slab& s : slabs_) {   // MVGX_DEVICE_CACHE_MB bounds what the cache keeps PER DEVICE
+      size_t cached = 0;
+      for (const auto& e : c.free_) cached += e.device == s.device ? e.size : 0;
+      if (cached + s.size <= c.limit()) c.free_.push_back(SlabCache::Entry{s.p, s.size, s.device});
       else drop.push_back(s);
     }
   }
@@ -156,6 +156,34 @@ void Arena::release() {
   }
   slabs_.clear();
   bump_ = -1; off_ = 0; next_ = 0;
+}
+
+// Hands the idle slabs of the current device back to the driver: cached slabs are invisible to every other allocator, so a
+// hipMemGetInfo reading counts them as used and a plain hipMalloc next to the cache can fail while gigabytes sit idle. Called
+// before such a reading and after a failed hipMalloc (then the allocation is retried once).
+void trim_device_cache() {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  SlabCache& c = slab_cache();
+  std::vector<SlabCache::Entry> drop;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (size_t k = 0; k < c.free_.size();) {
+      if (c.free_[k].device == device) { drop.push_back(c.free_[k]); c.free_.erase(c.free_.begin() + k); }
+      else ++k;
+    }
+  }
+  for (auto& d : drop) (void)hipFree(d.p);
+}
+
+hipError_t device_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    trim_device_cache();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
 }
 
 size_t Arena::bytes_reserved() const {

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { MVGX_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16))); return MVGX_OK; }
+  int alloc(size_t bytes) { MVGX_HIP(mvgx::device_malloc(&p, std::max<size_t>(bytes, 16))); return MVGX_OK; }
 };
 
 template <int WAVES>

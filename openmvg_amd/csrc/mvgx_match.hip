@@ -945,7 +945,7 @@ struct DevBuf {
     if (n <= cap) return MVGX_OK;
     if (p) { MVGX_HIP(hipFree(p)); p = nullptr; cap = 0; }
     const size_t want = std::max<size_t>(n, 16);
-    MVGX_HIP(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
+    MVGX_HIP(mvgx::device_malloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
     cap = want;
     return MVGX_OK;
   }
@@ -1216,7 +1216,16 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
 #define MVGX_DBG_ATTR(D) MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGldsAsm, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_DBG_ATTR(1) MVGX_DBG_ATTR(2) MVGX_DBG_ATTR(3) MVGX_DBG_ATTR(4) MVGX_DBG_ATTR(5) MVGX_DBG_ATTR(6) MVGX_DBG_ATTR(7) MVGX_DBG_ATTR(8) MVGX_DBG_ATTR(16)
 #undef MVGX_DBG_ATTR
-  if (const char* e = getenv("MVGX_MATCH_FILTER")) c->debug_filter = atoi(e) & 31;   // experiments: see l2_filter_kernel's kDbg
+  if (const char* e = getenv("MVGX_MATCH_FILTER")) {   // experiments: see l2_filter_kernel's kDbg; the same values the option accepts
+    const int v = atoi(e);
+#ifdef MVGX_FILTER_TIMING_VARIANTS
+    const bool ok = (v >= 0 && v <= 8) || v == 16;
+#else
+    const bool ok = v == 0 || v == 8 || v == 16;
+#endif
+    if (ok) c->debug_filter = v;
+    else fprintf(stderr, "[mvgx] MVGX_MATCH_FILTER=%s ignored (not a form this build of the library has)\n", e);
+  }
   guard.c = nullptr;
   *out = c;
   return MVGX_OK;
@@ -1277,7 +1286,13 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
   } else if (!strcmp(key, "debug_filter")) {
+#ifdef MVGX_FILTER_TIMING_VARIANTS
     MVGX_REQUIRE((value >= 0 && value <= 8) || value == 16, MVGX_ERR_ARG, "debug_filter must be 0..8 or 16");
+#else
+    MVGX_REQUIRE(value == 0 || value == 8 || value == 16, MVGX_ERR_ARG,
+                 "debug_filter must be 0, 8 or 16 (the timing variants 1..7 return wrong lists and exist only in a library built with "
+                 "-DMVGX_FILTER_TIMING_VARIANTS)");
+#endif
     c->debug_filter = (int)value;
   } else if (!strcmp(key, "stream_hold")) {
     c->stream_hold = value != 0;
@@ -1458,7 +1473,11 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_filter_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->debug_filter) {   // timing experiments (wrong results; verify is skipped below)
 #define MVGX_DBG_CASE(D) case D: hipLaunchKernelGGL((l2_filter_kernel<kStageGldsAsm, D>), dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp); break;
-        switch (c->debug_filter) { MVGX_DBG_CASE(1) MVGX_DBG_CASE(2) MVGX_DBG_CASE(3) MVGX_DBG_CASE(4) MVGX_DBG_CASE(5) MVGX_DBG_CASE(6) MVGX_DBG_CASE(7) MVGX_DBG_CASE(8) MVGX_DBG_CASE(16) default: break; }
+        switch (c->debug_filter) {
+#ifdef MVGX_FILTER_TIMING_VARIANTS   // parts of the kernel compiled out (wrong results): only in a build made for tools/filter_breakdown.py
+          MVGX_DBG_CASE(1) MVGX_DBG_CASE(2) MVGX_DBG_CASE(3) MVGX_DBG_CASE(4) MVGX_DBG_CASE(5) MVGX_DBG_CASE(6) MVGX_DBG_CASE(7)
+#endif
+          MVGX_DBG_CASE(8) MVGX_DBG_CASE(16) default: break; }
 #undef MVGX_DBG_CASE
       } else {
         hipLaunchKernelGGL(l2_filter_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
@@ -1633,8 +1652,15 @@ int run_multi(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSin
       });
       if (ready == nd) break;
       Mail m = mail[ready];
+      if (feed.stop.load()) {   // a sink call already returned non-zero (or a device failed): include/mvgx.h promises the sink is not entered again
+        mail[ready].result = 1;
+        mail[ready].done = true;
+        cv_dev.notify_all();
+        continue;
+      }
       lk.unlock();
       const int r = sink(m.p0, m.nb, m.offsets, m.ij);
+      if (r != 0) feed.stop.store(1);
       lk.lock();
       mail[ready].result = r;
       mail[ready].done = true;

@@ -617,7 +617,7 @@ def adapter_emu():
             _emu.build(); _emu.build_match()
             subprocess.run(["make", "-f", os.path.join(ROOT, "tests", "native", "adapter_harness.mk"), "emu"], check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            _adapter_emu = _bind_match_shim(C.CDLL(ADAPTER_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+            _adapter_emu = _bind_match_shim(C.CDLL(ADAPTER_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW | os.RTLD_DEEPBIND))
         except Exception:
             return None
     return _adapter_emu
@@ -634,7 +634,7 @@ def adapter_ba_emu():
         if adapter_emu() is None:   # builds the `emu` targets
             return None
         try:
-            _adapter_ba_emu = _bind_ba_shim(C.CDLL(ADAPTER_BA_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
+            _adapter_ba_emu = _bind_ba_shim(C.CDLL(ADAPTER_BA_EMU_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW | os.RTLD_DEEPBIND))
         except Exception:
             return None
     return _adapter_ba_emu
@@ -722,7 +722,9 @@ def geofilter_container_lib(kind):
             if adapter_emu() is None:   # builds the `emu` targets of the harness
                 return None
         if os.path.exists(path):
-            lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+            # DEEPBIND: the library's own dependencies (the emulation library / libmvgx_hip.so it was linked with) come before a
+            # libmvgx_hip.so some other test loaded with RTLD_GLOBAL
+            lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW | os.RTLD_DEEPBIND)
             lib.ref_geofilter_container.restype = C.c_uint64
     except Exception:
         lib = None

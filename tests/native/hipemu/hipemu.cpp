@@ -265,6 +265,7 @@ struct RcclComm {};
 int rccl_unique_id(void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPPORTED; }
 int rccl_init(RcclComm**, int, int, const void*) { set_error("hipemu: no RCCL"); return MVGX_ERR_UNSUPPORTED; }
 void rccl_destroy(RcclComm*) {}
+void rccl_abort(RcclComm*) {}
 int rccl_allreduce_f64(RcclComm*, double*, uint64_t, int, hipStream_t) { return MVGX_ERR_UNSUPPORTED; }
 int rccl_self_check(RcclComm*, hipStream_t) { return MVGX_ERR_UNSUPPORTED; }
 }  // namespace mvgx

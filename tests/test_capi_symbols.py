@@ -52,4 +52,6 @@ def test_every_built_shared_library_resolves_all_its_symbols():
         glob.glob(os.path.join(root, "oracle", "_build", "*.so")) + glob.glob(os.path.join(root, "tests", "native", "_build", "libmvgx_openmvg_adapter*.so"))
     assert any(p.endswith("libmvgx_hip.so") for p in libs)
     for p in sorted(libs):
-        ctypes.CDLL(p, mode=os.RTLD_NOW)
+        # (DEEPBIND: a library's own dependencies before whatever an earlier test put into the global scope - the *_emu adapter
+        # libraries must bind to the emulation library they were linked with, not to a globally loaded libmvgx_hip.so)
+        ctypes.CDLL(p, mode=os.RTLD_NOW | os.RTLD_DEEPBIND)

@@ -1,4 +1,5 @@
-"""Where the time of l2_filter_kernel goes: the kernel re-timed with parts removed (results invalid, timing experiments only;
+"""(needs a library built with -DMVGX_FILTER_TIMING_VARIANTS: the forms 1..7 of the filter kernel with parts compiled out return wrong
+lists and are not part of the shipped library) Where the time of l2_filter_kernel goes: the kernel re-timed with parts removed (results invalid, timing experiments only;
 option "debug_filter" bit 0 = no epilogue, bit 1 = no per-tile LDS fragment loads, bit 2 = no per-window wait / barrier / staging).
 400 images x 2000 descriptors, 79 800 pairs in one batch per run, overlap off (isolated kernel time). One JSON line."""
 import json, os, sys
