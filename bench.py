@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parity-seconds", type=float, default=2.0, help="N > 1: seconds of CPU matching per rank for the sampled parity check")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip tools/scale_selfcheck.py (sharded vs one-device agreement, both BA transports)")
     ap.add_argument("--side-deadline", type=float, default=900.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
@@ -122,6 +123,19 @@ def main():
     all_pairs = matching.exhaustive_pairs_array(n_images)
     from openmvg_amd import sharding
     pairs = np.ascontiguousarray(sharding.shard_pairs(all_pairs, [len(d) for d in descs], rank, world))
+
+    selfcheck = None
+    if world > 1 and not args.no_selfcheck:
+        # multi-GPU readiness (tools/scale_selfcheck.py): rank 0 runs the in-process sharded forms of both halves over all visible
+        # devices against the one-device run before anything is timed; the other ranks wait at the barrier
+        if rank == 0:
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_selfcheck.py")], capture_output=True, text=True, timeout=600)
+                selfcheck = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"ok": False, "error": r.stderr[-400:]}
+            except Exception as e:
+                selfcheck = {"ok": False, "error": repr(e)}
+        dist.barrier()
 
     ctx = matching.MatchContext(local_rank)
     if args.variant >= 0:
@@ -210,6 +224,8 @@ def main():
                          "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},
         }
+        if selfcheck is not None:
+            out["scale_selfcheck"] = selfcheck
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], sample, cpu_lists = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)

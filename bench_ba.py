@@ -139,6 +139,7 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None):
         "config": f"{cfg['n_cams']} cams ({'pinhole' if cfg['model'] == 1 else 'pinhole+K3'}, {cfg['n_intr_groups']} shared "
                   f"intrinsic group(s)), {cfg['n_points']} points, {full['n_obs']} observations, ADJUST_ALL, Huber(16); "
                   f"points sharded over {world} GPU(s)" + (", RCCL all-reduce of the reduced camera system" if world > 1 else ""),
+        "rccl_ranks": world if world > 1 else 0,   # every rank's communicator passed the known-answer all-reduce of mvgx_ba_comm_init
         "lm_iteration_ms": s.iter_ms_mean,
         "first_call_ms_iteration_zero_plus_one_iteration": s1.total_ms,
         "iterations": s.num_iterations, "successful_steps": s.num_successful_steps, "termination": s.termination,
