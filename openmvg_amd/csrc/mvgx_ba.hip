@@ -2220,6 +2220,13 @@ int dev_alloc(mvgx::Arena& pool, T** p, size_t n) {
   return pool.alloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
 }
 template <typename T>
+int dev_upload_n(mvgx::Arena& pool, T** p, const T* v, size_t n, hipStream_t s) {
+  int rc = dev_alloc(pool, p, n);
+  if (rc) return rc;
+  if (n) MVGX_HIP(hipMemcpyAsync(*p, v, n * sizeof(T), hipMemcpyHostToDevice, s));
+  return MVGX_OK;
+}
+template <typename T>
 int dev_upload(mvgx::Arena& pool, T** p, const std::vector<T>& v, hipStream_t s) {
   int rc = dev_alloc(pool, p, v.size());
   if (rc) return rc;
@@ -2847,9 +2854,20 @@ int ba_validate_problem(const mvgx_ba_problem* p) {
   for (uint32_t k = 0; k < p->n_intrinsics; ++k)
     MVGX_REQUIRE(mvgx_ba::intr_param_count(p->intr_model[k]) >= 0, MVGX_ERR_UNSUPPORTED,
                  "intrinsic %u: camera model %d has no cost functor (sfm_data_BA_ceres.cpp:84-108)", k, p->intr_model[k]);
-  for (uint64_t k = 0; k < p->n_obs; ++k)
-    MVGX_REQUIRE(p->obs_pose[k] < p->n_poses && p->obs_intr[k] < p->n_intrinsics && p->obs_point[k] < p->n_points, MVGX_ERR_ARG,
-                 "observation %llu references a block out of range", (unsigned long long)k);
+  {
+    constexpr uint64_t kGrain = 1u << 16;
+    const uint64_t n_grains = (p->n_obs + kGrain - 1) / kGrain;
+    std::atomic<uint64_t> bad{UINT64_MAX};
+    parallel_for_dynamic((size_t)n_grains, 1, host_threads(p->n_obs), [&](size_t g, unsigned) {
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(p->n_obs, (g + 1) * kGrain); k < e; ++k)
+        if (!(p->obs_pose[k] < p->n_poses && p->obs_intr[k] < p->n_intrinsics && p->obs_point[k] < p->n_points)) {
+          uint64_t cur = bad.load();
+          while (k < cur && !bad.compare_exchange_weak(cur, k)) {}
+          return;
+        }
+    });
+    MVGX_REQUIRE(bad.load() == UINT64_MAX, MVGX_ERR_ARG, "observation %llu references a block out of range", (unsigned long long)bad.load());
+  }
   for (uint32_t k = 0; k < p->n_pose_priors; ++k)
     MVGX_REQUIRE(p->prior_pose[k] < p->n_poses, MVGX_ERR_ARG, "pose prior %u references a pose out of range", k);
   return MVGX_OK;
@@ -2948,43 +2966,73 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   const unsigned T = host_threads(no);
   // observations sorted by point (stable): identity when the caller's list already is (a landmark-by-landmark export of an
   // SfM_Data scene), else one counting sort
-  std::vector<uint64_t> perm(no);
+  // (vectors of trivially copyable elements that are written in full below: allocated without the zero fill, whose page
+  // faults on one thread were a third of this phase)
+  struct NoInit { uint32_t v; NoInit() {} };
+  static_assert(sizeof(NoInit) == sizeof(uint32_t), "layout");
+  constexpr size_t kGrain = 16384;
+  const size_t n_grains = (size_t)((no + kGrain - 1) / kGrain);
   std::vector<uint32_t> pt_start(d.n_pts + 1, 0);
-  for (uint64_t k = 0; k < no; ++k) pt_start[p->obs_point[k] + 1]++;
-  for (uint32_t j = 0; j < d.n_pts; ++j) pt_start[j + 1] += pt_start[j];
-  {
-    bool sorted = true;
-    for (uint64_t k = 1; k < no && sorted; ++k) sorted = p->obs_point[k - 1] <= p->obs_point[k];
-    if (sorted) {
-      std::iota(perm.begin(), perm.end(), 0ull);
-    } else {
-      std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
-      for (uint64_t k = 0; k < no; ++k) perm[fill[p->obs_point[k]]++] = k;
-    }
+  std::atomic<int> unsorted{0};
+  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+    bool bad = false;
+    for (uint64_t k = std::max<uint64_t>(1, g * kGrain), e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) bad = bad || p->obs_point[k - 1] > p->obs_point[k];
+    if (bad) unsorted.store(1);
+  });
+  const bool sorted = !unsorted.load();
+  std::vector<uint64_t> perm;   // only when the caller's list is not sorted by point
+  if (sorted) {
+    // CSR starts from the boundaries of the sorted list: observation k opens the points (obs_point[k - 1], obs_point[k]]
+    parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+        const uint32_t cur = p->obs_point[k], prev = k ? p->obs_point[k - 1] : UINT32_MAX;
+        if (k == 0) { for (uint32_t q = 0; q <= cur; ++q) pt_start[q] = 0; }
+        else if (cur != prev) { for (uint32_t q = prev + 1; q <= cur; ++q) pt_start[q] = (uint32_t)k; }
+      }
+    });
+    const uint32_t last = no ? p->obs_point[no - 1] : UINT32_MAX;
+    for (uint32_t q = (no ? last + 1 : 0); q <= d.n_pts; ++q) pt_start[q] = (uint32_t)no;
+  } else {
+    for (uint64_t k = 0; k < no; ++k) pt_start[p->obs_point[k] + 1]++;
+    for (uint32_t j = 0; j < d.n_pts; ++j) pt_start[j + 1] += pt_start[j];
+    perm.resize(no);
+    std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
+    for (uint64_t k = 0; k < no; ++k) perm[fill[p->obs_point[k]]++] = k;
   }
-  std::vector<uint32_t> opose(no), ointr(no), opt_(no), oslot(no);
-  std::vector<double> oxy(2 * no), oweight;
+  std::vector<NoInit> opose_s(no), ointr_s(no), opt_s(no), oslot_s(no), oorig_s(no);
+  uint32_t* const opose = &opose_s.data()->v; uint32_t* const ointr = &ointr_s.data()->v; uint32_t* const opt_ = &opt_s.data()->v;
+  uint32_t* const oslot = &oslot_s.data()->v; uint32_t* const oorig = &oorig_s.data()->v;
+  struct NoInitD { double v; NoInitD() {} };
+  std::vector<NoInitD> oxy_s(2 * no);
+  double* const oxy = &oxy_s.data()->v;
+  std::vector<double> oweight;
   std::vector<uint8_t> octrl;
   if (p->obs_weight) oweight.resize(no);
   if (p->obs_is_control) octrl.resize(no);
-  constexpr size_t kGrain = 16384;
-  const size_t n_grains = (size_t)((no + kGrain - 1) / kGrain);
+  std::vector<double> ctrl_count(n_grains, 0.0);
   parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+    double nc = 0;
     for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
-      const uint64_t s_ = perm[k];
-      opose[k] = p->obs_pose[s_]; ointr[k] = p->obs_intr[s_]; opt_[k] = p->obs_point[s_];
+      const uint64_t s_ = sorted ? k : perm[k];
+      opose[k] = p->obs_pose[s_]; ointr[k] = p->obs_intr[s_]; opt_[k] = p->obs_point[s_]; oorig[k] = (uint32_t)s_;
       oxy[2 * k] = p->obs_xy[2 * s_]; oxy[2 * k + 1] = p->obs_xy[2 * s_ + 1];
       if (p->obs_weight) oweight[k] = p->obs_weight[s_];
-      if (p->obs_is_control) octrl[k] = p->obs_is_control[s_] ? 1 : 0;
+      if (p->obs_is_control) { octrl[k] = p->obs_is_control[s_] ? 1 : 0; nc += octrl[k]; }
     }
+    ctrl_count[g] = nc;
   });
   double n_rmse = (double)no;
-  if (p->obs_is_control)
-    for (uint64_t k = 0; k < no; ++k) if (p->obs_is_control[k]) n_rmse -= 1.0;
+  for (double v : ctrl_count) n_rmse -= v;
   c->n_obs_rmse_local = n_rmse;
   tick("sort by point + gather");
   std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_free(d.n_pts, 0);
-  for (uint64_t k = 0; k < no; ++k) { pose_used[opose[k]] = 1; intr_used[ointr[k]] = 1; pt_free[opt_[k]] = 1; }
+  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {   // (concurrent stores of the same value 1)
+    for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+      if (!pose_used[opose[k]]) pose_used[opose[k]] = 1;
+      if (!intr_used[ointr[k]]) intr_used[ointr[k]] = 1;
+      if (!pt_free[opt_[k]]) pt_free[opt_[k]] = 1;
+    }
+  });
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_used[p->prior_pose[k]] = 1;
   for (uint32_t j = 0; j < d.n_pts; ++j)
     if (p->points_constant || (p->point_const_mask && p->point_const_mask[j])) pt_free[j] = 0;
@@ -3029,10 +3077,16 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     if (!one) std::stable_sort(b_, e_, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
   });
   std::vector<uint32_t> pi_start, pi_intr, pose_pi_start(d.n_poses + 1, 0), pichunk_lo, pichunk_hi, pi_chunk0;
-  for (uint32_t i = 0; i < d.n_poses; ++i) {
-    for (uint32_t q = prow_start[i]; q < prow_start[i + 1]; ++q)
-      if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) { pi_start.push_back(q); pi_intr.push_back(ointr[pi_obs[q]]); }
-    pose_pi_start[i + 1] = (uint32_t)pi_start.size();
+  {
+    std::vector<std::vector<uint32_t>> per_pose(d.n_poses);   // the first list position of every (pose, intrinsic) pair of the pose
+    parallel_for_dynamic(d.n_poses, 4, T, [&](size_t i, unsigned) {
+      for (uint32_t q = prow_start[i]; q < prow_start[i + 1]; ++q)
+        if (q == prow_start[i] || ointr[pi_obs[q]] != ointr[pi_obs[q - 1]]) per_pose[i].push_back(q);
+    });
+    for (uint32_t i = 0; i < d.n_poses; ++i) {
+      for (uint32_t q : per_pose[i]) { pi_start.push_back(q); pi_intr.push_back(ointr[pi_obs[q]]); }
+      pose_pi_start[i + 1] = (uint32_t)pi_start.size();
+    }
   }
   d.n_pi = (int)pi_start.size();
   pi_start.push_back((uint32_t)no);
@@ -3327,8 +3381,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   tick("masks, parameter copies");
   UP(poses, h_poses); UP(intr, h_intr); UP(pts, h_pts); UP(model, h_model);
   AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
-  UP(opose, opose); UP(ointr, ointr); UP(opt, opt_); UP(oxy, oxy);
-  { std::vector<uint32_t> oorig(perm.begin(), perm.end()); UP(oorig, oorig); }
+#define UPN(field, ptr, n) if ((rc = dev_upload_n(c->pool, &d.field, ptr, (size_t)(n), c->stream))) return rc
+  UPN(opose, opose, no); UPN(ointr, ointr, no); UPN(opt, opt_, no); UPN(oxy, oxy, 2 * no); UPN(oorig, oorig, no);
+#undef UPN
   if (p->obs_weight) { UP(oweight, oweight); }
   if (p->obs_is_control) { UP(octrl, octrl); }
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
@@ -3376,8 +3431,26 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     if (n_sg) {
       std::vector<double2> g_exy(g_eobs.size());
       std::vector<uint32_t> ungrouped;
-      for (size_t e = 0; e < g_eobs.size(); ++e) g_exy[e] = make_double2(oxy[2 * (size_t)g_eobs[e]], oxy[2 * (size_t)g_eobs[e] + 1]);
-      for (uint64_t o = 0; o < no; ++o) if (!in_group[opt_[o]]) ungrouped.push_back((uint32_t)o);
+      const size_t n_egrains = (g_eobs.size() + kGrain - 1) / kGrain;
+      parallel_for_dynamic(n_egrains, 1, T, [&](size_t g, unsigned) {
+        for (size_t e = g * kGrain, e1 = std::min(g_eobs.size(), (g + 1) * kGrain); e < e1; ++e)
+          g_exy[e] = make_double2(oxy[2 * (size_t)g_eobs[e]], oxy[2 * (size_t)g_eobs[e] + 1]);
+      });
+      {   // observations of the points outside every group, ascending: counted per grain, then filled
+        std::vector<uint32_t> cnt(n_grains + 1, 0);
+        parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+          uint32_t n = 0;
+          for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) n += !in_group[opt_[o]];
+          cnt[g + 1] = n;
+        });
+        for (size_t g = 0; g < n_grains; ++g) cnt[g + 1] += cnt[g];
+        ungrouped.resize(cnt[n_grains]);
+        if (!ungrouped.empty())
+          parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+            uint32_t at = cnt[g];
+            for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) if (!in_group[opt_[o]]) ungrouped[at++] = (uint32_t)o;
+          });
+      }
       d.grp.n_ungrouped = (uint32_t)ungrouped.size();
       if ((rc = dev_upload(c->pool, &d.grp.sg_start, sg_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
