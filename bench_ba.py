@@ -6,6 +6,19 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0
+# HBM bytes of one LM iteration per bench scene, from the committed rocprofv3 PMC passes of tools/ba_iterations.py on the same scenes
+# (FETCH_SIZE x 2 [gfx950 reports half the bytes of reads, MI355X_MICROARCH.md; calibrated on kernels of known byte counts] +
+# WRITE_SIZE, one window between two Jacobian evaluations; tools/pmc_kernels.py). Counters cannot be read inside this process:
+# the record carries the stored figure with traffic_measured_in_run = false and the file it came from.
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_ba_iteration_traffic.json")
+
+
+def stored_traffic(name):
+    try:
+        import json
+        return json.load(open(TRAFFIC_FILE)).get(name)
+    except Exception:
+        return None
 
 
 def algorithmic_bytes_per_iteration(n_obs, n_pts, n_cam, n_cols, s_bytes=None):
@@ -132,6 +145,7 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None):
     finally:
         os.environ.pop("MVGX_BA_PHASE_TIMING", None)
     scene = full
+    traffic = stored_traffic("c5" if (name == "c5" or world > 1) else "c3")
     n_cols = 6 * scene["n_poses"] + 8 * scene["n_intrinsics"]
     bytes_it = algorithmic_bytes_per_iteration(scene["n_obs"], scene["n_points"], scene["n_poses"], n_cols,
                                                info.n_factor_tiles * 4096 * 8 if info.sparse else None)
@@ -155,7 +169,12 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None):
                            "note": "flop = operations on the stored tiles of the factor (the sparse count when the solver is sparse)"}),
         "initial_rmse": s.initial_rmse, "final_rmse": s.final_rmse, "final_cost": s.final_cost,
         "roofline": {"bound": "hbm", "achieved": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": bytes_it / (s.iter_ms_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get("hbm_bytes_per_iteration") if world == 1 else None,
+                     "traffic_over_algorithmic": ((traffic or {}).get("hbm_bytes_per_iteration", 0) / bytes_it) if (traffic and world == 1) else None,
+                     "traffic_measured_in_run": False,
+                     "traffic_note": (f"PMC pass {os.path.relpath(TRAFFIC_FILE, os.path.dirname(os.path.abspath(__file__)))} ({(traffic or {}).get('command')}): "
+                                      "FETCH_SIZE x 2 + WRITE_SIZE of one LM iteration on this scene") if traffic else "no PMC pass stored for this scene",
                      "algorithmic_bytes_per_iteration": bytes_it},
     }
     if cpu and rank == 0:   # every --gpus N: the reference on the FULL scene beside the sharded solve (rmse_diff_vs_reference)

@@ -40,12 +40,17 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <numeric>
+#include <pthread.h>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "ba_math.h"
@@ -115,12 +120,16 @@ constexpr int kNVpp = 6 * 6 + 6, kNVpi = 6 * 8 + 6, kNVii = 8 * 8 + 8;   // doub
 #define MVGX_GROUP_PTS 32
 #endif
 constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points rows of the staged matrix
-constexpr int kGroupThreads = 256;                                // one observation per thread: a group holds at most this many observations
+#ifndef MVGX_GROUP_THREADS
+#define MVGX_GROUP_THREADS 256
+#endif
+constexpr int kGroupThreads = MVGX_GROUP_THREADS;                 // one observation per thread: a group holds at most this many observations
 constexpr int kGroupWaves = kGroupThreads / 64;
 constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves;
 constexpr int kGroupRS = 3 * kGroupPts + 2;                       // doubles between columns in LDS, = 2 x odd (mod 32): the 16 columns x 2 rows a
                                                                   // half wave reads as an MFMA operand then fall on distinct banks
 static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255 && kGroupIntr == 2, "group tile layout (the slot ranges assume two local intrinsics)");
+static_assert(kGroupThreads >= 128 + 6 * kGroupCams + 8 * kGroupIntr, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128..");
 constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
 constexpr int kGroupM = kGroupCols * kGroupRS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
 static_assert(kGroupM >= 24 * (kGroupThreads + 1) && kGroupM >= kGroupOut && kGroupM >= 3 * (kGroupThreads + 1) + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
@@ -188,7 +197,7 @@ struct Dev {
   double* oxy = nullptr;
   double* oweight = nullptr;          // n_obs or null
   uint8_t* octrl = nullptr;           // n_obs or null
-  uint32_t* oorig = nullptr;          // n_obs: index of the observation in the caller's arrays
+  uint32_t* oorig = nullptr;          // n_obs: index of the observation in the caller's arrays (null: identity)
   uint32_t* pt_start = nullptr;       // n_pts + 1
   uint32_t* ptk_start = nullptr;      // n_pts + 1 -> intrinsic slots of a point
   uint32_t* slot_intr = nullptr;      // n_islots
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(256) void ba_residual_norm_kernel(Dev d, const uint
   for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
   obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
   eval_observation<false>(d.model[ii], pin, pp, px, obs, r, nullptr, nullptr, nullptr);
-  out[orig_index[o]] = sqrt(r[0] * r[0] + r[1] * r[1]);
+  out[orig_index ? orig_index[o] : (uint32_t)o] = sqrt(r[0] * r[0] + r[1] * r[1]);
 }
 
 // world ray of every observation (3 doubles each, point-sorted order) at the current parameters
@@ -532,6 +541,17 @@ __global__ __launch_bounds__(256) void ba_point_norms_kernel(Dev d) {
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) { d.cn_pt[(size_t)p * 3 + c] = cn[c]; d.g_pt[(size_t)p * 3 + c] = g[c]; }
+}
+
+// Lists that are permutations of uploaded ones are made on the device (mvgx_ba_create): out_pt[i] = opt[idx[i]] (optional),
+// out_xy[i] = the image point of observation idx[i]
+__global__ __launch_bounds__(256) void ba_gather_lists_kernel(const uint32_t* __restrict__ idx, uint32_t n, const uint32_t* __restrict__ opt,
+                                                              const double* __restrict__ oxy, uint32_t* __restrict__ out_pt, double2* __restrict__ out_xy) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = idx[i];
+  if (out_pt) out_pt[i] = opt[o];
+  out_xy[i] = *reinterpret_cast<const double2*>(oxy + 2 * (size_t)o);
 }
 
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
@@ -2096,14 +2116,84 @@ struct TripExt {
 // in [0, n), indices handed out dynamically; results must not depend on which thread ran an index.
 inline unsigned host_threads(size_t work_items) {
   if (const char* env = getenv("MVGX_HOST_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(env)));   // as told
-  // one thread per ~16k items: starting a thread costs tens of microseconds, and the small problems an SfM engine sends most
-  // often (initial pair, local adjustments) are built faster by the calling thread alone
+  // one thread per ~16k items: waking a thread costs microseconds, and the small problems an SfM engine sends most often
+  // (initial pair, local adjustments) are built faster by the calling thread alone
+  // (32 at most: measured on the 2 x 64-core bench host, 5M observations: 16 threads 33 ms, 32 threads 21.5 ms, 64 threads 21.8 ms
+  // typical but one call in three at 45 - 70 ms)
   const unsigned want = (unsigned)std::min<size_t>(work_items / 16384, 32);
   return std::max(1u, std::min(std::thread::hardware_concurrency(), want));
 }
+
+// The workers behind parallel_for_dynamic: started once per process (a structure build runs ~30 parallel loops; starting and
+// joining 31 threads for each of them cost about a millisecond per loop), parked on a condition variable between jobs. One job
+// at a time: a caller that finds the pool busy (several contexts being created at once) runs its loop on threads of its own.
+class HostPool {
+ public:
+  static HostPool* instance() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      pthread_atfork(nullptr, nullptr, [] { g_pool_ = nullptr; });   // a forked child has no workers: it starts its own on first use
+    });
+    HostPool* p = g_pool_.load(std::memory_order_acquire);
+    if (p) return p;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    p = g_pool_.load(std::memory_order_acquire);
+    if (!p) { p = new HostPool(); g_pool_.store(p, std::memory_order_release); }   // never destroyed (workers may outlive main's statics)
+    return p;
+  }
+  // runs body(t) for t in [0, threads): t = 0 on the calling thread; false when the pool is busy (the caller then uses its own threads)
+  bool run(unsigned threads, const std::function<void(unsigned)>& body) {
+    std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+    if (!job.owns_lock()) return false;
+    const unsigned helpers = std::min<unsigned>(threads - 1, (unsigned)workers_.size());
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      body_ = &body; want_ = helpers; remaining_ = helpers; ++epoch_;
+    }
+    cv_start_.notify_all();
+    body(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return remaining_ == 0; });
+    body_ = nullptr;
+    return true;
+  }
+ private:
+  HostPool() {
+    const unsigned n = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u)) - 1;
+    for (unsigned t = 0; t < n; ++t) workers_.emplace_back([this, t] { work(t + 1); }), workers_.back().detach();
+  }
+  void work(unsigned tix) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* body = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_start_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (tix <= want_) body = body_;
+      }
+      if (!body) continue;
+      (*body)(tix);
+      bool last;
+      { std::lock_guard<std::mutex> lk(mu_); last = --remaining_ == 0; }
+      if (last) cv_done_.notify_one();
+    }
+  }
+  static std::atomic<HostPool*> g_pool_;
+  std::vector<std::thread> workers_;
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_start_, cv_done_;
+  const std::function<void(unsigned)>* body_ = nullptr;
+  unsigned want_ = 0, remaining_ = 0;
+  uint64_t epoch_ = 0;
+};
+std::atomic<HostPool*> HostPool::g_pool_{nullptr};
+
 template <class F>
 void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
   if (threads <= 1 || n <= grain) { for (size_t i = 0; i < n; ++i) f(i, 0u); return; }
+  threads = (unsigned)std::min<size_t>(threads, (n + grain - 1) / grain);
   std::atomic<size_t> next{0};
   auto body = [&](unsigned tix) {
     for (;;) {
@@ -2113,6 +2203,7 @@ void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
       for (size_t i = lo; i < hi; ++i) f(i, tix);
     }
   };
+  if (HostPool::instance()->run(threads, body)) return;
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < threads; ++t) pool.emplace_back(body, t);
   body(0);
@@ -2122,9 +2213,8 @@ void parallel_for_dynamic(size_t n, size_t grain, unsigned threads, F f) {
 // Stable counting sort of the indices 0..n-1 by key(i) in [0, n_keys): start[n_keys + 1] and order[n] (ascending index inside a
 // key), with per-thread histograms over contiguous index ranges; the result does not depend on the thread count.
 template <class Key>
-void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key key, std::vector<uint32_t>& start, std::vector<uint32_t>& order) {
+void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key key, std::vector<uint32_t>& start, uint32_t* order) {
   start.assign((size_t)n_keys + 1, 0);
-  order.resize(n);
   if (threads <= 1 || n < 4096 || (uint64_t)threads * n_keys > (1u << 24)) {
     for (uint64_t i = 0; i < n; ++i) start[key(i) + 1]++;
     for (uint32_t k = 0; k < n_keys; ++k) start[k + 1] += start[k];
@@ -2133,8 +2223,9 @@ void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key ke
     return;
   }
   const uint64_t per = (n + threads - 1) / threads;
-  std::vector<std::vector<uint32_t>> hist(threads, std::vector<uint32_t>(n_keys, 0));
+  std::vector<std::vector<uint32_t>> hist(threads);
   parallel_for_dynamic(threads, 1, threads, [&](size_t t, unsigned) {
+    hist[t].assign(n_keys, 0);
     for (uint64_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) hist[t][key(i)]++;
   });
   uint32_t run = 0;
@@ -2146,6 +2237,11 @@ void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key ke
   parallel_for_dynamic(threads, 1, threads, [&](size_t t, unsigned) {
     for (uint64_t i = t * per, e = std::min(n, (t + 1) * per); i < e; ++i) order[hist[t][key(i)]++] = (uint32_t)i;
   });
+}
+template <class Key>
+void counting_sort_indices(uint64_t n, uint32_t n_keys, unsigned threads, Key key, std::vector<uint32_t>& start, std::vector<uint32_t>& order) {
+  order.resize(n);
+  counting_sort_indices(n, n_keys, threads, key, start, order.data());
 }
 
 // Product list of one family, generated row by row (row = camera block of the first factor). gen(r, emit) must call
@@ -2914,6 +3010,7 @@ int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_proble
 
 int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(p && out, MVGX_ERR_ARG, "mvgx_ba_create: NULL argument");
+  const auto t_enter = std::chrono::steady_clock::now();
   { const int vrc = mvgx::ba_validate_problem(p); if (vrc) return vrc; }   // before any dispatch to the multi-device path
   if (device == -1) {   // "no preference": MVGX_DEVICES may name the device(s); small problems stay on one device
     std::vector<int> devs;
@@ -2928,16 +3025,31 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_REQUIRE(p->n_obs < (1ull << 31), MVGX_ERR_ARG, "mvgx_ba_create: too many observations for one device shard");
   int rc = mvgx::select_device(device);
   if (rc) return rc;
+  // MVGX_BA_CREATE_TIMING=1: phase times of this function on stderr (host structure vs allocation vs upload)
+  const bool timing = getenv("MVGX_BA_CREATE_TIMING") != nullptr;
+  auto t_prev = t_enter;
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mvgx_ba_create] %-36s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+  mvgx::HostArena ha;   // the large lists of the structure build and the sources of the uploads (declared before the guard: the
+                        // guard's destroy drains the stream before the slabs go back to the cache)
   auto* c = new mvgx_ba_ctx();
   struct Guard {   // every early return below (allocation failure, bad product list) releases what was built so far
     mvgx_ba_ctx* c;
     ~Guard() { if (c) mvgx_ba_destroy(c); }
   } guard{c};
+  tick("validation");
   MVGX_HIP(hipGetDevice(&c->device));
-  MVGX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if ((rc = mvgx::acquire_stream(&c->stream))) return rc;
+  tick("stream");
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
+  tick("events");
   MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 1) * sizeof(double), hipHostMallocDefault));
+  tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
   d.n_poses = p->n_poses; d.n_intr = p->n_intrinsics; d.n_pts = p->n_points; d.n_obs = p->n_obs; d.n_priors = p->n_pose_priors;
@@ -2946,32 +3058,27 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   d.prior_huber_a = p->prior_huber_a;
   c->phase_timing = getenv("MVGX_BA_PHASE_TIMING") != nullptr;
   if (getenv("MVGX_BA_FACTOR_DEBUG")) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_factor_debug), &one, sizeof(one)); }
-  { const int on = getenv("MVGX_BA_GROUP_DEBUG") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_debug), &on, sizeof(on)); }
+  {   // (a synchronous copy: only when the setting changes)
+    static std::atomic<int> last_on{0};
+    const int on = getenv("MVGX_BA_GROUP_DEBUG") ? 1 : 0;
+    if (last_on.exchange(on) != on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_debug), &on, sizeof(on));
+  }
   if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
   if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
-  // MVGX_BA_CREATE_TIMING=1: phase times of this function on stderr (host structure vs allocation vs upload)
-  const bool timing = getenv("MVGX_BA_CREATE_TIMING") != nullptr;
-  auto t_prev = std::chrono::steady_clock::now();
-  auto tick = [&](const char* what) {
-    if (!timing) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[mvgx_ba_create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-    t_prev = now;
-  };
-
+  tick("settings");
   // ---- host-side structure (the analogue of Ceres' preprocessor: ordering, chunks, block structure) ----
   const unsigned T = host_threads(no);
   // observations sorted by point (stable): identity when the caller's list already is (a landmark-by-landmark export of an
   // SfM_Data scene), else one counting sort
-  // (vectors of trivially copyable elements that are written in full below: allocated without the zero fill, whose page
-  // faults on one thread were a third of this phase)
-  struct NoInit { uint32_t v; NoInit() {} };
-  static_assert(sizeof(NoInit) == sizeof(uint32_t), "layout");
   constexpr size_t kGrain = 16384;
   const size_t n_grains = (size_t)((no + kGrain - 1) / kGrain);
+#define HA(type, name, n) type* name = nullptr; if ((rc = ha.array(&name, std::max<size_t>((size_t)(n), 1)))) return rc
+#define UP(field, vec) if ((rc = dev_upload(c->pool, &d.field, vec, c->stream))) return rc
+#define UPN(field, ptr, n) if ((rc = dev_upload_n(c->pool, &d.field, ptr, (size_t)(n), c->stream))) return rc
+#define AL(field, n) if ((rc = dev_alloc(c->pool, &d.field, (size_t)(n)))) return rc
   std::vector<uint32_t> pt_start(d.n_pts + 1, 0);
   std::atomic<int> unsorted{0};
   parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
@@ -2999,28 +3106,61 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
     for (uint64_t k = 0; k < no; ++k) perm[fill[p->obs_point[k]]++] = k;
   }
-  std::vector<NoInit> opose_s(no), ointr_s(no), opt_s(no), oslot_s(no), oorig_s(no);
-  uint32_t* const opose = &opose_s.data()->v; uint32_t* const ointr = &ointr_s.data()->v; uint32_t* const opt_ = &opt_s.data()->v;
-  uint32_t* const oslot = &oslot_s.data()->v; uint32_t* const oorig = &oorig_s.data()->v;
-  struct NoInitD { double v; NoInitD() {} };
-  std::vector<NoInitD> oxy_s(2 * no);
-  double* const oxy = &oxy_s.data()->v;
-  std::vector<double> oweight;
-  std::vector<uint8_t> octrl;
-  if (p->obs_weight) oweight.resize(no);
-  if (p->obs_is_control) octrl.resize(no);
+  // Uploads of the caller's arrays go through page-locked scratch (mvgx::HostArena), copied there by the host threads: from
+  // pageable memory hipMemcpyAsync blocks the caller and moved 8 GB/s here (18 ms for the observation list of the 5M-observation
+  // scene); from page-locked memory it is an asynchronous DMA at 50 GB/s that overlaps the rest of this function.
+  auto staged_upload = [&](auto** dev, const auto* src, size_t n) -> int {
+    using E = std::remove_cv_t<std::remove_reference_t<decltype(*src)>>;
+    int rc_ = dev_alloc(c->pool, dev, n);
+    if (rc_ || !n) return rc_;
+    if (n * sizeof(E) < (1u << 20)) { MVGX_HIP(hipMemcpyAsync(*dev, src, n * sizeof(E), hipMemcpyHostToDevice, c->stream)); return MVGX_OK; }
+    E* st = nullptr;
+    if ((rc_ = ha.array(&st, n))) return rc_;
+    const size_t per = (1u << 20) / sizeof(E), n_chunks = (n + per - 1) / per;
+    parallel_for_dynamic(n_chunks, 1, T, [&](size_t ch, unsigned) { memcpy(st + ch * per, src + ch * per, std::min(per, n - ch * per) * sizeof(E)); });
+    MVGX_HIP(hipMemcpyAsync(*dev, st, n * sizeof(E), hipMemcpyHostToDevice, c->stream));
+    return MVGX_OK;
+  };
+#define UPS(field, ptr, n) if ((rc = staged_upload(&d.field, ptr, (size_t)(n)))) return rc
+  UPS(poses, p->poses, (size_t)d.n_poses * 6); UPS(intr, p->intrinsics, (size_t)d.n_intr * 8); UPS(pts, p->points, (size_t)d.n_pts * 3);
+  UPS(model, p->intr_model, d.n_intr);
+  AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
+  // The observation list in point order. A list that arrives sorted is read where it lies (oorig stays null: identity); else it
+  // is gathered into the page-locked scratch.
+  const uint32_t* opose = p->obs_pose; const uint32_t* ointr = p->obs_intr; const uint32_t* opt_ = p->obs_point;
+  const double* oxy = p->obs_xy;
+  HA(uint32_t, oslot, no);
+  HA(double, oweight, p->obs_weight ? no : 0);
+  HA(uint8_t, octrl, p->obs_is_control ? no : 0);
+  if (!sorted) {
+    HA(uint32_t, g_pose, no); HA(uint32_t, g_intr, no); HA(uint32_t, g_pt, no); HA(uint32_t, g_orig, no); HA(double, g_xy, 2 * no);
+    parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+        const uint64_t s_ = perm[k];
+        g_pose[k] = p->obs_pose[s_]; g_intr[k] = p->obs_intr[s_]; g_pt[k] = p->obs_point[s_]; g_orig[k] = (uint32_t)s_;
+        g_xy[2 * k] = p->obs_xy[2 * s_]; g_xy[2 * k + 1] = p->obs_xy[2 * s_ + 1];
+      }
+    });
+    opose = g_pose; ointr = g_intr; opt_ = g_pt; oxy = g_xy;
+    UPN(oorig, g_orig, no);
+    UPN(opose, opose, no); UPN(ointr, ointr, no); UPN(opt, opt_, no); UPN(oxy, oxy, 2 * no);
+  } else {
+    UPS(opose, opose, no); UPS(ointr, ointr, no); UPS(opt, opt_, no); UPS(oxy, oxy, 2 * no);
+  }
   std::vector<double> ctrl_count(n_grains, 0.0);
-  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
-    double nc = 0;
-    for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
-      const uint64_t s_ = sorted ? k : perm[k];
-      opose[k] = p->obs_pose[s_]; ointr[k] = p->obs_intr[s_]; opt_[k] = p->obs_point[s_]; oorig[k] = (uint32_t)s_;
-      oxy[2 * k] = p->obs_xy[2 * s_]; oxy[2 * k + 1] = p->obs_xy[2 * s_ + 1];
-      if (p->obs_weight) oweight[k] = p->obs_weight[s_];
-      if (p->obs_is_control) { octrl[k] = p->obs_is_control[s_] ? 1 : 0; nc += octrl[k]; }
-    }
-    ctrl_count[g] = nc;
-  });
+  if (p->obs_weight || p->obs_is_control) {
+    parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+      double nc = 0;
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+        const uint64_t s_ = sorted ? k : perm[k];
+        if (p->obs_weight) oweight[k] = p->obs_weight[s_];
+        if (p->obs_is_control) { octrl[k] = p->obs_is_control[s_] ? 1 : 0; nc += octrl[k]; }
+      }
+      ctrl_count[g] = nc;
+    });
+    if (p->obs_weight) { UPN(oweight, oweight, no); }
+    if (p->obs_is_control) { UPN(octrl, octrl, no); }
+  }
   double n_rmse = (double)no;
   for (double v : ctrl_count) n_rmse -= v;
   c->n_obs_rmse_local = n_rmse;
@@ -3036,6 +3176,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_used[p->prior_pose[k]] = 1;
   for (uint32_t j = 0; j < d.n_pts; ++j)
     if (p->points_constant || (p->point_const_mask && p->point_const_mask[j])) pt_free[j] = 0;
+  tick("  used flags");
   // (point, intrinsic) slots: the distinct intrinsics of a point in order of first appearance; counted, then filled
   std::vector<uint32_t> ptk_start(d.n_pts + 1, 0);
   const size_t n_pgrains = ((size_t)d.n_pts + 4095) / 4096;
@@ -3065,17 +3206,33 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     }
   });
   d.n_islots = (int)slot_intr.size();
+  tick("  point-intrinsic slots");
   // observations by pose (ascending observation index inside a pose): the rows of the product lists; then, inside a pose,
   // stably by intrinsic: the (pose, intrinsic) pairs of the Gram kernels, cut into chunks of kPiChunk observations
-  std::vector<uint32_t> prow_start, pose_obs;
+  std::vector<uint32_t> prow_start;
+  HA(uint32_t, pose_obs, no);
   counting_sort_indices(no, d.n_poses, T, [&](uint64_t k) { return opose[k]; }, prow_start, pose_obs);
-  std::vector<uint32_t> pi_obs(pose_obs);
+  tick("  counting sort by pose");
+  // (the usual case - every view has one intrinsic - needs no second list)
+  std::vector<uint8_t> pose_mixed(d.n_poses, 0);
+  std::atomic<int> any_mixed{0};
   parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
-    auto b_ = pi_obs.begin() + prow_start[i], e_ = pi_obs.begin() + prow_start[i + 1];
-    bool one = true;   // the usual case: a view has one intrinsic
-    for (auto it = b_; it != e_ && one; ++it) one = ointr[*it] == ointr[*b_];
-    if (!one) std::stable_sort(b_, e_, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
+    bool one = true;
+    for (uint32_t q = prow_start[i]; q < prow_start[i + 1] && one; ++q) one = ointr[pose_obs[q]] == ointr[pose_obs[prow_start[i]]];
+    if (!one) { pose_mixed[i] = 1; any_mixed.store(1); }
   });
+  uint32_t* pi_obs = pose_obs;
+  if (any_mixed.load()) {
+    HA(uint32_t, pi_sorted, no);
+    pi_obs = pi_sorted;
+    parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
+      uint32_t* b_ = pi_obs + prow_start[i]; uint32_t* e_ = pi_obs + prow_start[i + 1];
+      std::copy(pose_obs + prow_start[i], pose_obs + prow_start[i + 1], b_);
+      if (pose_mixed[i]) std::stable_sort(b_, e_, [&](uint32_t x, uint32_t y) { return ointr[x] < ointr[y]; });
+    });
+  }
+  UPN(pi_obs, pi_obs, no);
+  tick("  pi_obs");
   std::vector<uint32_t> pi_start, pi_intr, pose_pi_start(d.n_poses + 1, 0), pichunk_lo, pichunk_hi, pi_chunk0;
   {
     std::vector<std::vector<uint32_t>> per_pose(d.n_poses);   // the first list position of every (pose, intrinsic) pair of the pose
@@ -3108,25 +3265,16 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     std::vector<uint32_t> fill(intr_pichunk_start.begin(), intr_pichunk_start.end() - 1);
     for (uint32_t ch = 0; ch < (uint32_t)chunk_intr.size(); ++ch) intr_pichunk[fill[chunk_intr[ch]]++] = ch;
   }
-  // the Gram kernel's inputs in (pose, intrinsic) order: the observation and its point, contiguous; the pair of every chunk
-  std::vector<uint32_t> pi_pt(no), pichunk_pose(pichunk_lo.size()), pichunk_intr(pichunk_lo.size());
-  std::vector<double2> pi_xy(no);
-  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
-    for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
-      const uint32_t o = pi_obs[k];
-      pi_pt[k] = opt_[o];
-      pi_xy[k] = make_double2(oxy[2 * (size_t)o], oxy[2 * (size_t)o + 1]);
-    }
-  });
+  tick("  pairs and chunks");
+  // the Gram kernel's inputs in (pose, intrinsic) order - the point and the image point of every observation, contiguous - are
+  // gathered on the device from the lists uploaded above; the pair of every chunk
+  AL(pi_pt, no); AL(pi_xy, no);
+  if (no) hipLaunchKernelGGL(ba_gather_lists_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, c->stream, d.pi_obs, (uint32_t)no, d.opt, d.oxy, d.pi_pt, d.pi_xy);
+  std::vector<uint32_t> pichunk_pose(pichunk_lo.size()), pichunk_intr(pichunk_lo.size());
   for (uint32_t i = 0; i < d.n_poses; ++i)
     for (uint32_t q = pose_pi_start[i]; q < pose_pi_start[i + 1]; ++q)
       for (uint32_t ch = pi_chunk0[q]; ch < pi_chunk0[q + 1]; ++ch) { pichunk_pose[ch] = i; pichunk_intr[ch] = pi_intr[q]; }
-  // slots by intrinsic (ascending slot index): the rows of the intrinsic-intrinsic products
-  std::vector<uint32_t> islot_start(d.n_intr + 1, 0), islot(slot_intr.size());
-  for (uint32_t s_ : slot_intr) islot_start[s_ + 1]++;
-  for (uint32_t i = 0; i < d.n_intr; ++i) islot_start[i + 1] += islot_start[i];
-  { std::vector<uint32_t> fill(islot_start.begin(), islot_start.end() - 1);
-    for (uint32_t q = 0; q < (uint32_t)slot_intr.size(); ++q) islot[fill[slot_intr[q]]++] = q; }
+  tick("  chunk pairs");
   // pose-centre priors by pose
   std::vector<uint32_t> prior_pose(p->prior_pose, p->prior_pose + d.n_priors), pose_prior_start(d.n_poses + 1, 0), pose_prior_idx(d.n_priors);
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_prior_start[prior_pose[k] + 1]++;
@@ -3144,9 +3292,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // blocks), up to kMaxSgGroups of them. Groups of fewer than kGroupMinPts points are dissolved unless they continue a supergroup
   // (their points stay on the record-based path, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups;
   // so does MVGX_BA_MODEL_COST=jacobian (Ceres' form of the model cost reads the Jacobian records of every observation).
-  constexpr int kMaxSgGroups = 8;
+  constexpr int kMaxSgGroups = 2048 / kGroupThreads;   // a supergroup covers up to 2048 observations
   std::vector<uint8_t> in_group(d.n_pts, 0);
-  std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_eobs, g_eq, g_pt_start{0}, g_pts, g_nk0, g_pt_estart, g_pt_ksplit, sg_cams, sg_intrs;
+  std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_pt_start{0}, g_pts, g_pt_estart, g_pt_ksplit, sg_cams, sg_intrs;
+  uint32_t* g_eobs = nullptr; uint32_t* g_eq = nullptr;   // [entry]: observation, entry word (HostArena)
+  size_t n_gentries = 0;
   std::vector<uint8_t> sg_pp, sg_pi, sg_ii;   // per supergroup: which destination blocks exist
   {
     const char* env = getenv("MVGX_BA_GROUPS");
@@ -3168,11 +3318,13 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           if (!ok) lo_pose[j] = UINT32_MAX;
         }
       });
+      tick("  point keys");
       std::vector<uint32_t> lo_start, order;   // eligible points by lowest pose (bucket n_poses: not eligible)
       counting_sort_indices(d.n_pts, d.n_poses + 1, T, [&](uint64_t j) { return lo_pose[j] == UINT32_MAX ? d.n_poses : lo_pose[j]; }, lo_start, order);
       parallel_for_dynamic(d.n_poses, 1, T, [&](size_t i, unsigned) {
         std::stable_sort(order.begin() + lo_start[i], order.begin() + lo_start[i + 1], [&](uint32_t x, uint32_t y) { return set_key[x] < set_key[y]; });
       });
+      tick("  points by lowest pose, set key");
       // groups never span two lowest-pose buckets, so the buckets are swept independently (host threads) and their groups
       // stitched in bucket order: the result does not depend on the thread count
       struct BucketGroups {
@@ -3180,8 +3332,14 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         std::vector<uint8_t> pp, pi, ii;
       };
       std::vector<BucketGroups> per_bucket(d.n_poses);
-      parallel_for_dynamic(d.n_poses, 4, T, [&](size_t bucket, unsigned) {
+      parallel_for_dynamic(d.n_poses, 1, T, [&](size_t bucket, unsigned) {
         BucketGroups& B = per_bucket[bucket];
+        {   // (one allocation per list instead of a doubling series)
+          size_t n_e = 0;
+          const size_t n_p = lo_start[bucket + 1] - lo_start[bucket];
+          for (uint32_t q = lo_start[bucket]; q < lo_start[bucket + 1]; ++q) n_e += pt_start[order[q] + 1] - pt_start[order[q]];
+          B.eobs.reserve(n_e); B.eq.reserve(n_e); B.pts.reserve(n_p); B.nk0.reserve(n_p);
+        }
         std::vector<uint32_t> cams, intrs, mc, mi, cur;
         std::vector<uint32_t> tail_cams, tail_intrs;   // sets of the supergroup under construction (sorted)
         bool sg_open = false;
@@ -3256,34 +3414,52 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         }
         close_group();
       });
-      for (const BucketGroups& B : per_bucket) {
-        size_t g = 0;
-        for (size_t sgi = 0; sgi < B.sg_n.size(); ++sgi) {
-          sg_start.push_back(sg_start.back() + B.sg_n[sgi]);
-          for (uint32_t k = 0; k < B.sg_n[sgi]; ++k, ++g) {
-            g_obs_start.push_back(g_obs_start.back() + B.obs_n[g]);
-            g_pt_start.push_back(g_pt_start.back() + B.pt_n[g]);
-          }
-        }
-        g_eobs.insert(g_eobs.end(), B.eobs.begin(), B.eobs.end());
-        g_eq.insert(g_eq.end(), B.eq.begin(), B.eq.end());
-        g_pts.insert(g_pts.end(), B.pts.begin(), B.pts.end());
-        g_nk0.insert(g_nk0.end(), B.nk0.begin(), B.nk0.end());
-        sg_cams.insert(sg_cams.end(), B.cams.begin(), B.cams.end());
-        sg_intrs.insert(sg_intrs.end(), B.intrs.begin(), B.intrs.end());
-        sg_pp.insert(sg_pp.end(), B.pp.begin(), B.pp.end());
-        sg_pi.insert(sg_pi.end(), B.pi.begin(), B.pi.end());
-        sg_ii.insert(sg_ii.end(), B.ii.begin(), B.ii.end());
+      tick("  greedy groups per bucket");
+      // the buckets' groups stitched in bucket order: offsets from a serial prefix over the buckets, copies on host threads
+      const size_t nb = per_bucket.size();
+      std::vector<uint32_t> off_sg(nb + 1, 0), off_g(nb + 1, 0), off_e(nb + 1, 0), off_p(nb + 1, 0);
+      for (size_t b = 0; b < nb; ++b) {
+        const BucketGroups& B = per_bucket[b];
+        off_sg[b + 1] = off_sg[b] + (uint32_t)B.sg_n.size(); off_g[b + 1] = off_g[b] + (uint32_t)B.obs_n.size();
+        off_e[b + 1] = off_e[b] + (uint32_t)B.eobs.size(); off_p[b + 1] = off_p[b] + (uint32_t)B.pts.size();
       }
-      // first entry of every grouped point (its observations are consecutive entries)
-      g_pt_estart.resize(g_pts.size() + 1);
-      { uint32_t e = 0;
-        g_pt_ksplit.resize(g_pts.size());
-        for (size_t q = 0; q < g_pts.size(); ++q) { g_pt_estart[q] = e; g_pt_ksplit[q] = e + g_nk0[q]; e += pt_start[g_pts[q] + 1] - pt_start[g_pts[q]]; }
-        g_pt_estart[g_pts.size()] = e; }
+      const size_t tsg = off_sg[nb], tg = off_g[nb], te = off_e[nb], tp = off_p[nb];
+      n_gentries = te;
+      sg_start.resize(tsg + 1); g_obs_start.resize(tg + 1); g_pt_start.resize(tg + 1);
+      g_pts.resize(tp); g_pt_estart.resize(tp + 1); g_pt_ksplit.resize(tp);
+      sg_cams.resize(tsg * kGroupCams); sg_intrs.resize(tsg * kGroupIntr);
+      sg_pp.resize(tsg * kGroupPairsPP); sg_pi.resize(tsg * kGroupPairsPI); sg_ii.resize(tsg * kGroupPairsII);
+      if ((rc = ha.array(&g_eobs, std::max<size_t>(te, 1))) || (rc = ha.array(&g_eq, std::max<size_t>(te, 1)))) return rc;
+      parallel_for_dynamic(nb, 1, T, [&](size_t b, unsigned) {
+        const BucketGroups& B = per_bucket[b];
+        uint32_t g = off_g[b];
+        for (size_t sgi = 0; sgi < B.sg_n.size(); ++sgi) { g += B.sg_n[sgi]; sg_start[off_sg[b] + sgi + 1] = g; }
+        uint32_t e = off_e[b], q = off_p[b];
+        for (size_t k = 0; k < B.obs_n.size(); ++k) {
+          e += B.obs_n[k]; q += B.pt_n[k];
+          g_obs_start[off_g[b] + k + 1] = e; g_pt_start[off_g[b] + k + 1] = q;
+        }
+        std::copy(B.eobs.begin(), B.eobs.end(), g_eobs + off_e[b]);
+        std::copy(B.eq.begin(), B.eq.end(), g_eq + off_e[b]);
+        std::copy(B.pts.begin(), B.pts.end(), g_pts.begin() + off_p[b]);
+        std::copy(B.cams.begin(), B.cams.end(), sg_cams.begin() + (size_t)off_sg[b] * kGroupCams);
+        std::copy(B.intrs.begin(), B.intrs.end(), sg_intrs.begin() + (size_t)off_sg[b] * kGroupIntr);
+        std::copy(B.pp.begin(), B.pp.end(), sg_pp.begin() + (size_t)off_sg[b] * kGroupPairsPP);
+        std::copy(B.pi.begin(), B.pi.end(), sg_pi.begin() + (size_t)off_sg[b] * kGroupPairsPI);
+        std::copy(B.ii.begin(), B.ii.end(), sg_ii.begin() + (size_t)off_sg[b] * kGroupPairsII);
+        // first entry of every grouped point (its observations are consecutive entries), and where its local intrinsic 1 starts
+        uint32_t ee = off_e[b];
+        for (size_t k = 0; k < B.pts.size(); ++k) {
+          g_pt_estart[off_p[b] + k] = ee; g_pt_ksplit[off_p[b] + k] = ee + B.nk0[k];
+          ee += pt_start[B.pts[k] + 1] - pt_start[B.pts[k]];
+        }
+      });
+      g_pt_estart[tp] = (uint32_t)te;
+      tick("  stitch");
     }
   }
   const uint32_t n_groups = (uint32_t)g_pt_start.size() - 1, n_sg = (uint32_t)sg_start.size() - 1;
+  tick("  entry starts");
   // destination blocks of the supergroups, per product family: (row block, column block) -> partial-block id
   TripExt gext_pp, gext_pi, gext_ii;
   {
@@ -3306,18 +3482,46 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         for (int l = k; l < kGroupIntr; ++l, ++t)
           if (sg_ii[(size_t)sgi * kGroupPairsII + t]) gext_ii.rows[np_ + im[k]].emplace_back(np_ + im[l], sgi * kGroupPairsII + t);
     }
+    tick("  destination rows");
     for (TripExt* e : {&gext_pp, &gext_pi, &gext_ii})
       parallel_for_dynamic(n_cb, 16, T, [&](size_t r, unsigned) { std::sort(e->rows[r].begin(), e->rows[r].end()); });
   }
   tick("point groups");
+  // The observations of the points outside every group, ascending (counted per grain, then filled): the record-based path works
+  // on these alone. By pose (ascending observation inside a pose) they are the rows of the product lists; their (point, intrinsic)
+  // slots by intrinsic the rows of the intrinsic-intrinsic products.
+  uint32_t* ungrouped = nullptr;
+  size_t n_ungrouped = 0;
+  {
+    std::vector<uint32_t> cnt(n_grains + 1, 0);
+    parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+      uint32_t n = 0;
+      for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) n += !in_group[opt_[o]];
+      cnt[g + 1] = n;
+    });
+    for (size_t g = 0; g < n_grains; ++g) cnt[g + 1] += cnt[g];
+    n_ungrouped = cnt[n_grains];
+    if ((rc = ha.array(&ungrouped, std::max<size_t>(n_ungrouped, 1)))) return rc;
+    if (n_ungrouped)
+      parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+        uint32_t at = cnt[g];
+        if (at == cnt[g + 1]) return;
+        for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) if (!in_group[opt_[o]]) ungrouped[at++] = (uint32_t)o;
+      });
+  }
+  std::vector<uint32_t> urow_start, urow;   // [pose] -> positions in `ungrouped`
+  counting_sort_indices(n_ungrouped, d.n_poses, T, [&](uint64_t i) { return opose[ungrouped[i]]; }, urow_start, urow);
+  std::vector<uint32_t> uslots, islot_start, islot;   // slots of the points outside every group, by intrinsic (ascending slot)
+  for (uint32_t q = 0; q < (uint32_t)slot_intr.size(); ++q) if (!in_group[slot_point[q]]) uslots.push_back(q);
+  counting_sort_indices(uslots.size(), d.n_intr, T, [&](uint64_t i) { return slot_intr[uslots[i]]; }, islot_start, islot);
+  tick("lists of the ungrouped points");
   {
     const size_t n_cb = (size_t)d.n_poses + d.n_intr;
     const uint32_t np = d.n_poses;
     if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-pose: Z_a^T Z_b, pose(a) <= pose(b), same point
           if (r >= np) return;
-          for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
-            const uint32_t a = pose_obs[q], j = opt_[a];
-            if (in_group[j]) continue;   // all products of the point are formed by its group
+          for (uint32_t q = urow_start[r]; q < urow_start[r + 1]; ++q) {   // (all products of a grouped point are formed by its group)
+            const uint32_t a = ungrouped[urow[q]], j = opt_[a];
             for (uint32_t b = pt_start[j]; b < pt_start[j + 1]; ++b)
               if (r <= opose[b] && (pt_free[j] || a == b)) emit(opose[b], a, b);
           }
@@ -3325,9 +3529,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     tick("pose-pose products");
     if ((rc = build_trip_list(n_cb, [&](uint32_t r, auto emit) {   // pose-intrinsic: Z_a^T Zint_slot
           if (r >= np) return;
-          for (uint32_t q = prow_start[r]; q < prow_start[r + 1]; ++q) {
-            const uint32_t a = pose_obs[q], j = opt_[a];
-            if (in_group[j]) continue;   // all products of the point are formed by its group
+          for (uint32_t q = urow_start[r]; q < urow_start[r + 1]; ++q) {
+            const uint32_t a = ungrouped[urow[q]], j = opt_[a];
             for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl)
               if (pt_free[j] || sl == oslot[a]) emit(np + slot_intr[sl], a, sl);
           }
@@ -3341,8 +3544,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           if (r < np) return;
           const uint32_t k = r - np;
           for (uint32_t q = islot_start[k]; q < islot_start[k + 1]; ++q) {
-            const uint32_t sa = islot[q], j = slot_point[sa];
-            if (in_group[j]) continue;
+            const uint32_t sa = uslots[islot[q]], j = slot_point[sa];
             for (uint32_t sb = ptk_start[j]; sb < ptk_start[j + 1]; ++sb)
               if (k <= slot_intr[sb] && (pt_free[j] || sa == sb)) emit(np + slot_intr[sb], sa, sb);
           }
@@ -3371,33 +3573,19 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       cam_counts[6 * d.n_poses + 8 * k + cpt] = in_program && cpt < K;
     }
   }
-  std::vector<double> h_poses(p->poses, p->poses + (size_t)d.n_poses * 6), h_intr(p->intrinsics, p->intrinsics + (size_t)d.n_intr * 8),
-      h_pts(p->points, p->points + (size_t)d.n_pts * 3);
-  std::vector<int> h_model(p->intr_model, p->intr_model + d.n_intr);
   std::vector<double> h_pc(p->prior_center, p->prior_center + (size_t)d.n_priors * 3), h_pw(p->prior_weight, p->prior_weight + (size_t)d.n_priors * 3);
-
-#define UP(field, vec) if ((rc = dev_upload(c->pool, &d.field, vec, c->stream))) return rc
-#define AL(field, n) if ((rc = dev_alloc(c->pool, &d.field, (size_t)(n)))) return rc
   tick("masks, parameter copies");
-  UP(poses, h_poses); UP(intr, h_intr); UP(pts, h_pts); UP(model, h_model);
-  AL(cposes, d.n_poses * 6); AL(cintr, d.n_intr * 8); AL(cpts, (size_t)d.n_pts * 3);
-#define UPN(field, ptr, n) if ((rc = dev_upload_n(c->pool, &d.field, ptr, (size_t)(n), c->stream))) return rc
-  UPN(opose, opose, no); UPN(ointr, ointr, no); UPN(opt, opt_, no); UPN(oxy, oxy, 2 * no); UPN(oorig, oorig, no);
-#undef UPN
-  if (p->obs_weight) { UP(oweight, oweight); }
-  if (p->obs_is_control) { UP(octrl, octrl); }
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
   UP(cam_active, cam_active); UP(cam_counts, cam_counts); UP(pt_free, pt_free);
-  UP(pi_obs, pi_obs); UP(pichunk_lo, pichunk_lo); UP(pichunk_hi, pichunk_hi); UP(pi_chunk0, pi_chunk0); UP(pose_pi_start, pose_pi_start);
-  UP(pichunk_pose, pichunk_pose); UP(pichunk_intr, pichunk_intr); UP(pi_pt, pi_pt); UP(pi_xy, pi_xy);
+  UP(pichunk_lo, pichunk_lo); UP(pichunk_hi, pichunk_hi); UP(pi_chunk0, pi_chunk0); UP(pose_pi_start, pose_pi_start);
+  UP(pichunk_pose, pichunk_pose); UP(pichunk_intr, pichunk_intr);
   UP(intr_pichunk_start, intr_pichunk_start); UP(intr_pichunk, intr_pichunk);
   UP(prior_pose, prior_pose); UP(pose_prior_start, pose_prior_start); UP(pose_prior_idx, pose_prior_idx);
   UP(prior_center, h_pc); UP(prior_weight, h_pw); AL(Jprior, (size_t)d.n_priors * kPriorJ);
   tick("small allocations + uploads");
   // Jacobian records and stored Z blocks: only when some point is on the record-based path (they are indexed by observation:
   // with point groups only the entries of the other points are ever touched)
-  bool record_path = false;
-  for (uint32_t j = 0; j < d.n_pts && !record_path; ++j) record_path = !in_group[j] && pt_start[j + 1] > pt_start[j];
+  const bool record_path = n_ungrouped != 0;
   const uint64_t nrec = record_path ? no : 0;
   AL(JA, (size_t)kJA * nrec); AL(JB, (size_t)kJB * nrec); AL(JC, (size_t)kJC * nrec);
   AL(cn_cam, d.N); AL(g_cam, d.N); AL(scale_cam, d.N); AL(diag_cam, d.N);
@@ -3426,50 +3614,33 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if (h.n_ext && (rc = dev_upload(c->pool, &l.block_ext0, h.block_ext0, c->stream))) return rc;
       if ((rc = dev_alloc(c->pool, &l.part, ((size_t)l.n_chunks + l.n_ext) * e.nv))) return rc;
     }
+    tick("  trip lists");
     d.grp.n_groups = n_groups; d.grp.n_sg = n_sg;
     c->n_grouped_points = (uint32_t)g_pts.size();
     if (n_sg) {
-      std::vector<double2> g_exy(g_eobs.size());
-      std::vector<uint32_t> ungrouped;
-      const size_t n_egrains = (g_eobs.size() + kGrain - 1) / kGrain;
-      parallel_for_dynamic(n_egrains, 1, T, [&](size_t g, unsigned) {
-        for (size_t e = g * kGrain, e1 = std::min(g_eobs.size(), (g + 1) * kGrain); e < e1; ++e)
-          g_exy[e] = make_double2(oxy[2 * (size_t)g_eobs[e]], oxy[2 * (size_t)g_eobs[e] + 1]);
-      });
-      {   // observations of the points outside every group, ascending: counted per grain, then filled
-        std::vector<uint32_t> cnt(n_grains + 1, 0);
-        parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
-          uint32_t n = 0;
-          for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) n += !in_group[opt_[o]];
-          cnt[g + 1] = n;
-        });
-        for (size_t g = 0; g < n_grains; ++g) cnt[g + 1] += cnt[g];
-        ungrouped.resize(cnt[n_grains]);
-        if (!ungrouped.empty())
-          parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
-            uint32_t at = cnt[g];
-            for (uint64_t o = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); o < e; ++o) if (!in_group[opt_[o]]) ungrouped[at++] = (uint32_t)o;
-          });
-      }
-      d.grp.n_ungrouped = (uint32_t)ungrouped.size();
+      d.grp.n_ungrouped = (uint32_t)n_ungrouped;
       if ((rc = dev_upload(c->pool, &d.grp.sg_start, sg_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_estart, g_pt_estart, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_ksplit, g_pt_ksplit, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.eq, g_eq, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.eobs, g_eobs, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.exy, g_exy, c->stream))) return rc;
+      if ((rc = dev_upload_n(c->pool, &d.grp.eq, g_eq, n_gentries, c->stream))) return rc;
+      if ((rc = dev_upload_n(c->pool, &d.grp.eobs, g_eobs, n_gentries, c->stream))) return rc;
+      // the image points of the entries: gathered on the device
+      if ((rc = dev_alloc(c->pool, &d.grp.exy, n_gentries))) return rc;
+      if (n_gentries)
+        hipLaunchKernelGGL(ba_gather_lists_kernel, dim3((unsigned)((n_gentries + 255) / 256)), dim3(256), 0, c->stream, d.grp.eobs, (uint32_t)n_gentries,
+                           d.opt, d.oxy, static_cast<uint32_t*>(nullptr), d.grp.exy);
       if ((rc = dev_upload(c->pool, &d.grp.cams, sg_cams, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.intrs, sg_intrs, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.chunk_pp, gext_pp.ext_row, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.chunk_pi, gext_pi.ext_row, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.chunk_ii, gext_ii.ext_row, c->stream))) return rc;
-      if ((rc = dev_upload(c->pool, &d.grp.ungrouped, ungrouped, c->stream))) return rc;
+      if ((rc = dev_upload_n(c->pool, &d.grp.ungrouped, ungrouped, n_ungrouped, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.pt_grouped, in_group, c->stream))) return rc;
       if ((rc = dev_alloc(c->pool, &d.grp.gmax_part, (size_t)n_sg))) return rc;
-      MVGX_HIP(hipStreamSynchronize(c->stream));   // g_exy / ungrouped are locals
+      tick("  group uploads");
     }
   }
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
@@ -3478,7 +3649,10 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(scalars, kSCount + 1);   // the fail word lives in the slot after the scalars: one D2H copy fetches both
   d.fail = reinterpret_cast<int*>(d.scalars + kSCount);
 #undef UP
+#undef UPN
+#undef UPS
 #undef AL
+#undef HA
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
@@ -3491,6 +3665,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   tick("product lists upload (enqueue)");
   MVGX_HIP(hipStreamSynchronize(c->stream));
   tick("stream drain");
+  if (timing) fprintf(stderr, "[mvgx_ba_create] %-36s %8.2f ms\n", "total (before the locals are released)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
   guard.c = nullptr;
   *out = c;
   return MVGX_OK;
@@ -3523,8 +3698,8 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
   mvgx::rccl_destroy(c->rccl);
+  mvgx::release_stream(c->device, c->stream);   // (synchronised above)
   delete c;
   return MVGX_OK;
 }

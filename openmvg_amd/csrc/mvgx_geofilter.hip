@@ -540,8 +540,10 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
   const auto t_prep = std::chrono::steady_clock::now();
   // ---- device ----
   hipStream_t stream = nullptr;
-  MVGX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  if ((rc = mvgx::acquire_stream(&stream))) return rc;
+  int stream_device = 0;
+  MVGX_HIP(hipGetDevice(&stream_device));
+  struct StreamGuard { int dev; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(dev, s); } } sg{stream_device, stream};
   DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm;
   if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_total * sizeof(double2))) ||
       (rc = d_x2.alloc(n_total * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
