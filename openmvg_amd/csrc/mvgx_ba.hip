@@ -2362,6 +2362,8 @@ struct mvgx_ba_ctx {
   uint32_t n_grouped_points = 0;
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
+  bool plan_ready = false, plan_sparse = false;   // symbolic phase of the reduced solve done (mvgx_ba_create; again at the first iteration when a communicator was attached since)
+  double x_sqerr = 0;   // sum of squared residuals at x (the RMSE's numerator), kept with x_cost
   int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
   mvgx_sparse::Plan plan;          // host copy of the schedule (launch geometry per level)
   int update128_min_tiles = 128;   // tuning (MVGX_BA_UPDATE128_MIN_TILES): deferred updates with at least this many 128 x 128 tiles use them
@@ -2670,10 +2672,12 @@ int setup_block_exchange(mvgx_ba_ctx* c, std::vector<std::pair<uint32_t, uint32_
 // dissection order when it needs fewer rounds of dependent launches than the dense sweep has block steps and no more tiles
 // than the dense triangle, the dense blocked Cholesky otherwise.
 // MVGX_BA_SOLVER=dense|sparse forces either; MVGX_BA_ND_LEAF_COLS tunes the dissection depth.
-int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& blocks) {
+// Symbolic phase of the reduced solve (host only): nested-dissection ordering, tile structure of the factor, task lists. Depends on
+// the block structure alone, so mvgx_ba_create runs it for the context's own blocks; a context that is bound to a communicator
+// afterwards plans again at its first iteration, on the union of the ranks' blocks.
+int plan_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& blocks) {
   Dev& d = c->d;
-  if (c->solver_ready) return MVGX_OK;
-  int rc;
+  if (c->plan_ready) return MVGX_OK;
   bool sparse = false;
   const uint32_t np = d.n_poses;
   if (d.N > 0 && c->solver_mode != 1) {
@@ -2686,6 +2690,17 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
     sparse = ok && (c->solver_mode == 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
     MVGX_REQUIRE(ok || c->solver_mode != 2, MVGX_ERR_UNSUPPORTED, "MVGX_BA_SOLVER=sparse: the reduced system fills too much for the task lists");
   }
+  c->plan_sparse = sparse;
+  c->plan_ready = true;
+  return MVGX_OK;
+}
+
+int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>& blocks) {
+  Dev& d = c->d;
+  if (c->solver_ready) return MVGX_OK;
+  int rc = plan_solver(c, blocks);
+  if (rc) return rc;
+  const bool sparse = c->plan_sparse;
   if (sparse) {
     const mvgx_sparse::Plan& pl = c->plan;
     SpSys& s = d.sp;
@@ -2713,8 +2728,7 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
     // rows 1..63 of the rhs tiles and the padding are never written: zero once
     MVGX_HIP(hipMemsetAsync(s.L, 0, (size_t)pl.n_slots * 4096 * sizeof(double), c->stream));
     MVGX_HIP(hipMemsetAsync(s.z, 0, (size_t)pl.nT * 64 * sizeof(double), c->stream));
-    MVGX_HIP(hipStreamSynchronize(c->stream));   // the host vectors behind the uploads are the plan's: keep until here anyway
-    s.enabled = 1;
+    s.enabled = 1;   // (the host vectors behind the uploads are the plan's: they live as long as the context)
   } else if (d.N > 0) {
     const size_t bytes = (size_t)d.N * d.LD * sizeof(double) + (size_t)((d.N + 63) / 64) * 8192 * sizeof(double);
     size_t free_b = 0, total_b = 0;
@@ -2839,8 +2853,8 @@ int global_obs_count(mvgx_ba_ctx* c) {
   return MVGX_OK;
 }
 
-double rmse_from(const mvgx_ba_ctx* c) {
-  return c->n_obs_global > 0 ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * c->n_obs_global)) : 0.0;
+double rmse_from(const mvgx_ba_ctx* c) {   // of the current x
+  return c->n_obs_global > 0 ? std::sqrt(c->x_sqerr / (2.0 * c->n_obs_global)) : 0.0;
 }
 
 int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
@@ -2854,6 +2868,7 @@ int start(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   if ((rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts))) return rc;
   if ((rc = read_scalars(c))) return rc;
   c->x_cost = c->h_scalars[kSCost];
+  c->x_sqerr = c->h_scalars[kSSqErr];
   c->initial_rmse = rmse_from(c);
   c->radius = opt->initial_radius;
   c->decrease_factor = 2.0;
@@ -2904,6 +2919,7 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   if (relative_decrease > opt->min_relative_decrease) {
     if ((rc = accept_candidate(c))) return rc;
     c->x_cost = cand;   // the cost pass of the candidate IS the cost at the new x
+    c->x_sqerr = c->h_scalars[kSSqErr];
     if ((rc = evaluate_gradient_and_jacobian(c, opt, false))) return rc;
     c->radius = c->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
     c->radius = std::min(opt->max_radius, c->radius);
@@ -2918,9 +2934,8 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
 
 int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
   if (!s) return MVGX_OK;
-  int rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts);
-  if (rc) return rc;
-  if ((rc = read_scalars(c))) return rc;
+  // (cost and squared error at the final x were computed when that x was evaluated as a candidate: no pass of their own)
+  MVGX_HIP(hipStreamSynchronize(c->stream));
   s->num_iterations = c->iteration;
   s->num_successful_steps = c->successful;
   s->termination = c->termination;
@@ -2928,7 +2943,7 @@ int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
   s->final_cost = c->x_cost;
   s->initial_rmse = c->initial_rmse;
   s->final_rmse = rmse_from(c);
-  phase_collect(c);   // read_scalars above synchronised the stream
+  phase_collect(c);   // (the stream is idle)
   s->jacobian_ms = c->phase_ms[kPhJacobian]; s->schur_ms = c->phase_ms[kPhSchur]; s->solve_ms = c->phase_ms[kPhSolve];
   s->backsub_ms = c->phase_ms[kPhBacksub]; s->cost_ms = c->phase_ms[kPhCost];
   return MVGX_OK;
@@ -2968,10 +2983,15 @@ int ba_validate_problem(const mvgx_ba_problem* p) {
     MVGX_REQUIRE(p->prior_pose[k] < p->n_poses, MVGX_ERR_ARG, "pose prior %u references a pose out of range", k);
   return MVGX_OK;
 }
+static thread_local bool g_defer_plan = false;
+void ba_create_defer_plan(bool on) { g_defer_plan = on; }
+bool ba_create_plan_deferred() { return g_defer_plan; }
 void ba_ctx_comm_abort(mvgx_ba_ctx* c) {
   if (c && c->rccl) rccl_abort(c->rccl);
 }
 }  // namespace mvgx
+
+namespace mvgx { bool ba_create_plan_deferred(); }
 
 extern "C" {
 
@@ -3665,6 +3685,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   tick("product lists upload (enqueue)");
   MVGX_HIP(hipStreamSynchronize(c->stream));
   tick("stream drain");
+  if (!mvgx::ba_create_plan_deferred() && (rc = plan_solver(c, c->h_blocks))) return rc;
+  tick("reduced solve: symbolic phase");
   if (timing) fprintf(stderr, "[mvgx_ba_create] %-36s %8.2f ms\n", "total (before the locals are released)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
   guard.c = nullptr;
   *out = c;
@@ -3733,6 +3755,7 @@ int mvgx_ba_comm_init(mvgx_ba_ctx* c, int world, int rank, const void* unique_id
   MVGX_HIP(hipSetDevice(c->device));
   mvgx::rccl_destroy(c->rccl);
   c->rccl = nullptr;
+  c->plan_ready = false;   // the plan is made on the union of the ranks' blocks
   int rc = mvgx::rccl_init(&c->rccl, world, rank, unique_id128);
   if (rc) return rc;
   if ((rc = mvgx::rccl_self_check(c->rccl, c->stream))) { mvgx::rccl_destroy(c->rccl); c->rccl = nullptr; }
@@ -3744,6 +3767,7 @@ int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {
   MVGX_REQUIRE(!c->multi, MVGX_ERR_STATE, "mvgx_ba_set_allreduce: a multi-device context has its own exchange");
   c->allreduce = fn;
   c->allreduce_user = user;
+  c->plan_ready = false;   // the plan is made on the union of the ranks' blocks
   return MVGX_OK;
 }
 
@@ -3863,7 +3887,7 @@ int mvgx_ba_evaluate(mvgx_ba_ctx* c, double* cost, double* rmse) {
   if ((rc = read_scalars(c))) return rc;
   if (cost) *cost = c->h_scalars[kSCost];
   if (c->n_obs_global == 0 && (rc = global_obs_count(c))) return rc;
-  if (rmse) *rmse = rmse_from(c);
+  if (rmse) *rmse = c->n_obs_global > 0 ? std::sqrt(c->h_scalars[kSSqErr] / (2.0 * c->n_obs_global)) : 0.0;
   return MVGX_OK;
 }
 

@@ -17,5 +17,8 @@ int ba_multi_solver_info(BaMulti* m, mvgx_ba_solver_info* out);
 // internal (mvgx_ba.hip): fails the RCCL collectives a context has in flight (another shard of the same process failed);
 // argument checks shared by mvgx_ba_create and mvgx_ba_create_multi
 void ba_ctx_comm_abort(mvgx_ba_ctx* c);
+// while set on the calling thread, mvgx_ba_create leaves the symbolic phase of the reduced solve to the first iteration (the shards
+// of a multi-device context are bound to a transport right after, and plan on the union of their blocks)
+void ba_create_defer_plan(bool on);
 int ba_validate_problem(const mvgx_ba_problem* p);
 }  // namespace mvgx

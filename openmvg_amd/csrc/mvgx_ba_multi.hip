@@ -350,7 +350,10 @@ int ba_multi_create(const int* devices, int n_devices, const mvgx_ba_problem* p,
     if (r != 0) {   // prior residuals touch replicated blocks only: exactly one shard may hold them
       sp.n_pose_priors = 0; sp.prior_pose = nullptr; sp.prior_center = nullptr; sp.prior_weight = nullptr;
     }
-    return mvgx_ba_create(m->devices[r], &sp, &m->child[r]);
+    ba_create_defer_plan(true);
+    const int rc_ = mvgx_ba_create(m->devices[r], &sp, &m->child[r]);
+    ba_create_defer_plan(false);
+    return rc_;
   });
   if (rc) return rc;   // (a shard that cannot be built - e.g. out of memory on one device - ends the call here, before any rank waits in ncclCommInitRank)
   // ---- the transport, once every shard exists ----

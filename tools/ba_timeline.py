@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Timeline of ONE LM iteration from a rocprofv3 --kernel-trace CSV (<prefix>_kernel_trace.csv): every launch between two
 consecutive Jacobian evaluations (ba_cam_gram_kernel), with its start offset, duration and the idle gap before it.
-Usage: ba_timeline.py <kernel_trace.csv> [which-iteration (default: the last complete one)]"""
+Usage: ba_timeline.py <kernel_trace.csv> [which-iteration (default: the last complete one) | head | tail]
+head: everything up to the second Jacobian evaluation (iteration zero and the first iteration); tail: from the last one on."""
 import csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -9,8 +10,14 @@ ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 marks = [i for i, k in enumerate(ks) if "ba_cam_gram_kernel" in k[2] or "ba_linearize_kernel<true>" in k[2] and False]
 if len(marks) < 2:
     sys.exit("fewer than two Jacobian evaluations in the trace")
-which = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 2
-a, b = marks[which], marks[which + 1]
+arg = sys.argv[2] if len(sys.argv) > 2 else str(len(marks) - 2)
+if arg == "head":
+    which, a, b = "head", 0, marks[1]
+elif arg == "tail":
+    which, a, b = "tail", marks[-1], len(ks) - 1
+else:
+    which = int(arg)
+    a, b = marks[which], marks[which + 1]
 t0 = ks[a][0]
 prev_end = t0
 busy = 0
