@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--ratio", type=float, default=0.8)
     ap.add_argument("--batch-pairs", type=int, default=0, help="image pairs per device batch (default: library default)")
     ap.add_argument("--overlap", type=int, default=-1, help="0: one batch at a time (isolated kernel timings); default: library default (1)")
+    ap.add_argument("--verify-alone", type=int, default=-1, help="1: a filter kernel never shares the device with the previous batch's verify kernel; default: library default")
     ap.add_argument("--collect", action="store_true", help="keep the run's match lists in one pinned host buffer (mvgx_match_run) "
                                                            "instead of streaming them (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +143,8 @@ def main():
         ctx.set_option("variant", args.variant)
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
+    if args.verify_alone >= 0:
+        ctx.set_option("verify_alone", args.verify_alone)
     if args.batch_pairs > 0:
         ctx.set_option("batch_pairs", args.batch_pairs)
     elif len(pairs) < 16 * 32768:   # a shard of the 1k-image set: keep >= 16 batches in the two-slot pipeline (fill / drain)

@@ -2148,36 +2148,55 @@ class HostPool {
     if (!job.owns_lock()) return false;
     const unsigned helpers = std::min<unsigned>(threads - 1, (unsigned)workers_.size());
     {
-      std::lock_guard<std::mutex> lk(mu_);
-      body_ = &body; want_ = helpers; remaining_ = helpers; ++epoch_;
+      std::lock_guard<std::mutex> lk(mu_);   // the job and its epoch change together (workers read them under the lock); a worker about to sleep cannot miss it
+      body_ = &body; want_ = helpers;
+      remaining_.store(helpers, std::memory_order_relaxed);
+      epoch_.fetch_add(1, std::memory_order_release);
     }
-    cv_start_.notify_all();
+    if (sleepers_.load(std::memory_order_acquire)) cv_start_.notify_all();
     body(0);
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [&] { return remaining_ == 0; });
-    body_ = nullptr;
+    for (int i = 0; i < kSpin && remaining_.load(std::memory_order_acquire); ++i) cpu_relax();
+    if (remaining_.load(std::memory_order_acquire)) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [&] { return remaining_.load(std::memory_order_acquire) == 0; });
+    }
     return true;
   }
  private:
+  // A structure build is ~30 loops a few hundred microseconds apart: a worker that went to sleep on the condition variable
+  // between two of them cost 50 - 100 us to wake (x 30 loops: half of a 100k-observation build), so workers poll the epoch for
+  // about that long before they sleep.
+  static constexpr int kSpin = 1 << 15;
+  static void cpu_relax() { __builtin_ia32_pause(); }
   HostPool() {
-    const unsigned n = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u)) - 1;
+    const unsigned n = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)) - 1;   // (host_threads() asks for at most 32, MVGX_HOST_THREADS for at most 64: beyond the pool the caller's own threads)
     for (unsigned t = 0; t < n; ++t) workers_.emplace_back([this, t] { work(t + 1); }), workers_.back().detach();
   }
   void work(unsigned tix) {
     uint64_t seen = 0;
+    bool active = false;   // took part in the last job: only those poll (a build that uses 6 threads must not keep 31 polling)
     for (;;) {
-      const std::function<void(unsigned)>* body = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_start_.wait(lk, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (tix <= want_) body = body_;
+      bool got = false;
+      for (int i = 0; active && i < kSpin; ++i) {
+        if (epoch_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        cpu_relax();
       }
-      if (!body) continue;
+      if (!got) {
+        std::unique_lock<std::mutex> lk(mu_);
+        sleepers_.fetch_add(1, std::memory_order_acq_rel);
+        cv_start_.wait(lk, [&] { return epoch_.load(std::memory_order_acquire) != seen; });
+        sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+      }
+      const std::function<void(unsigned)>* body;
+      unsigned want;
+      { std::lock_guard<std::mutex> lk(mu_); seen = epoch_.load(std::memory_order_relaxed); body = body_; want = want_; }
+      active = tix <= want;
+      if (!active) continue;   // (a job cannot end - and the next one begin - before every worker it counts on has run it)
       (*body)(tix);
-      bool last;
-      { std::lock_guard<std::mutex> lk(mu_); last = --remaining_ == 0; }
-      if (last) cv_done_.notify_one();
+      if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        std::lock_guard<std::mutex> lk(mu_);
+        cv_done_.notify_one();
+      }
     }
   }
   static std::atomic<HostPool*> g_pool_;
@@ -2185,8 +2204,9 @@ class HostPool {
   std::mutex job_mu_, mu_;
   std::condition_variable cv_start_, cv_done_;
   const std::function<void(unsigned)>* body_ = nullptr;
-  unsigned want_ = 0, remaining_ = 0;
-  uint64_t epoch_ = 0;
+  unsigned want_ = 0;
+  std::atomic<unsigned> remaining_{0}, sleepers_{0};
+  std::atomic<uint64_t> epoch_{0};
 };
 std::atomic<HostPool*> HostPool::g_pool_{nullptr};
 

@@ -1003,6 +1003,7 @@ struct mvgx_match_ctx {
   int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
   int keep_host_results = 1;
   int overlap = 1;   // 1: batch b's filter runs beside batch b-1's verify/scan/compaction/copies (two slots)
+  int verify_alone = 0;   // 1: the next filter kernel also waits for this batch's verify kernel (the two never share the device)
   int debug_filter = 0;     // 1..7: timing experiments of l2_filter_kernel (see its kDbg), results invalid; 8, 16: earlier forms (valid)
   int stream_hold = 0;      // mvgx_match_run_stream: 1 = a batch's buffers survive two further sink calls (see Slot)
   int pinned_stream = 1;    // host buffers of the stream mode: pinned (contexts that are run repeatedly) or plain memory (one-shot)
@@ -1285,6 +1286,8 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->keep_host_results = value != 0;
   } else if (!strcmp(key, "overlap")) {
     c->overlap = value != 0;
+  } else if (!strcmp(key, "verify_alone")) {
+    c->verify_alone = value != 0;
   } else if (!strcmp(key, "debug_filter")) {
 #ifdef MVGX_FILTER_TIMING_VARIANTS
     MVGX_REQUIRE((value >= 0 && value <= 8) || value == 16, MVGX_ERR_ARG, "debug_filter must be 0..8 or 16");
@@ -1484,7 +1487,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       }
       MVGX_HIP(hipGetLastError());
       if (c->profile) MVGX_HIP(hipEventRecord(e1, stream));
-      MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
+      if (!c->verify_alone) MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
       st.n_kernel_launches += 1;
       if (c->variant == 4 && !(c->debug_filter & 7)) {
         if (c->profile >= 2) {   // statistics pass (0.13 ms per batch): only on request, not in the timed runs of bench.py ("profile" 1)
@@ -1495,6 +1498,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_verify_kernel, dim3(n_work), dim3(256), 0, stream, mp);
         MVGX_HIP(hipGetLastError());
       }
+      if (c->verify_alone) MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
     }
     if (!n_work) MVGX_HIP(hipEventRecord(sl.ev_filter, stream));
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sl.d_count.p, nb, sl.d_offsets.p);

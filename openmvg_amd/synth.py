@@ -312,3 +312,38 @@ def two_view_matches_bulk(n_pairs, n=250, seed=0, inlier_frac=(0.3, 0.9), noise_
     return dict(xI=np.ascontiguousarray(a.reshape(-1, 2)), xJ=np.ascontiguousarray(b.reshape(-1, 2)),
                 start=(np.arange(n_pairs + 1, dtype=np.uint64) * np.uint64(n)), wh=np.tile(np.array([w, h, w, h], np.uint32), (n_pairs, 1)),
                 is_inlier=inl.reshape(-1))
+
+
+def sfm_image_set(n_images, n_desc=2000, visible=1200, stride=120, seed=0x5F3D5E7, size=(2000, 1500), noise_px=0.5, desc_noise=3):
+    """A consistent image collection for the matching -> geometric-filter pipeline: cameras on an arc looking at a cloud of
+    landmarks; image k sees the landmarks [k * stride, k * stride + visible) (neighbours share most of them, images more than
+    visible / stride apart share none) plus n_desc - visible clutter features. A landmark's descriptor is its world descriptor
+    + integer noise, its position the pinhole projection + Gaussian noise; clutter has random descriptors and positions.
+    Returns dict(desc=[(n_desc, 128) u8], xy=[(n_desc, 2) f64], landmark=[(n_desc,) int64, -1 for clutter], size=(w, h))."""
+    rng = np.random.default_rng(seed)
+    w, h = size
+    f = 0.9 * max(w, h)
+    n_land = (n_images - 1) * stride + visible
+    world = world_descriptors(n_land, seed=seed ^ 0x1111)
+    ang = rng.uniform(0, 2 * np.pi, n_land)   # landmarks in a ball of radius 1.5 around the origin
+    X = np.stack([rng.uniform(-1.5, 1.5, n_land), rng.uniform(-1.0, 1.0, n_land), rng.uniform(-1.5, 1.5, n_land)], 1)
+    del ang
+    desc, xy, land = [], [], []
+    for k in range(n_images):
+        r = np.random.default_rng(seed + 1 + k)
+        th = 0.004 * k   # the cameras move along an arc of radius 8, looking at the origin
+        c = np.array([8.0 * np.sin(th), 0.3 * np.sin(0.05 * k), -8.0 * np.cos(th)])
+        zc = -c / np.linalg.norm(c); xc = np.cross([0.0, 1.0, 0.0], zc); xc /= np.linalg.norm(xc); yc = np.cross(zc, xc)
+        R = np.stack([xc, yc, zc])
+        ids = np.arange(k * stride, k * stride + visible)
+        P = (X[ids] - c) @ R.T
+        uv = np.stack([f * P[:, 0] / P[:, 2] + w / 2, f * P[:, 1] / P[:, 2] + h / 2], 1) + r.normal(0, noise_px, (visible, 2))
+        d = np.clip(world[ids].astype(np.int16) + r.integers(-desc_noise, desc_noise + 1, (visible, 128), dtype=np.int16), 0, 255).astype(np.uint8)
+        n_cl = n_desc - visible
+        dc = world_descriptors(n_cl, seed=(seed ^ 0x2222) + k)
+        uvc = np.stack([r.uniform(0, w, n_cl), r.uniform(0, h, n_cl)], 1)
+        perm = r.permutation(n_desc)
+        desc.append(np.ascontiguousarray(np.concatenate([d, dc])[perm]))
+        xy.append(np.ascontiguousarray(np.concatenate([uv, uvc])[perm]))
+        land.append(np.concatenate([ids, -np.ones(n_cl, np.int64)])[perm])
+    return dict(desc=desc, xy=xy, landmark=land, size=(w, h))
