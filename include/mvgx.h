@@ -392,6 +392,16 @@ typedef struct mvgx_geofilter_stats {
 int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
                               uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                               mvgx_geofilter_stats* stats /* may be NULL */);
+/* The same estimation on a PairWiseMatches-shaped input: instead of gathered coordinates (MatchesPairToMat,
+ * Geometric_Filter_utils.hpp:56-64, per pair) the caller hands over the feature positions of every image once - feat_xy, image k
+ * owning rows [feat_start[k], feat_start[k + 1]) - and per pair its two images (pairs[2 p], pairs[2 p + 1]) and the index pairs
+ * (i, j) of its putative matches (ij rows [match_start[p], match_start[p + 1])): exactly what Matcher_Regions::Match produces.
+ * image_wh is per IMAGE here: {w, h}. The gather runs on the device; results, mask and statistics as above. Image or feature
+ * indices out of range -> MVGX_ERR_ARG. */
+int mvgx_geofilter_f_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                      const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
+                                      const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,8 @@ PROTOTYPES = {
     "mvgx_ba_get_solver_info": (C.c_int, [C.c_void_p, C.POINTER(BaSolverInfo)]),
     "mvgx_geofilter_f_acransac": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GeofilterOptions),
                                             C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
+    "mvgx_geofilter_f_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_uint64, C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
 }
 
 _lib = None

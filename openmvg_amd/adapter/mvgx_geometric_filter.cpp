@@ -8,19 +8,24 @@
 //     from the point of cancellation (checked before the device call and between its result batches);
 //   * with b_guided_matching the reference's own Geometry_guided_matching runs on the host with the estimated F and precision and
 //     its result replaces the inlier list.
-// Inputs of the device call: MatchesPairToMat (Geometric_Filter_utils.cpp:52-89, the reference's own function: undistorted pixel
-// positions of the matched features) for every pair, gathered on OpenMP threads, and the image sizes of the two views.
+// Inputs of the device call (mvgx_geofilter_f_acransac_indexed): the undistorted pixel positions of the features of every view that
+// occurs (the expressions of MatchesPointsToMat, Geometric_Filter_utils.cpp:33-49, once per feature on OpenMP threads), the index
+// pairs of the putative matches as the container holds them, and the image sizes of the views.
 // What the device does not reproduce is routed to the reference's own code: an unbounded precision (m_dPrecision = infinity) and
 // pairs with more than 12 000 putative matches run functor.Robust_estimation on the host, pair by pair.
 #include "mvgx_geometric_filter.hpp"
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "mvgx.h"
+#include "openMVG/cameras/Camera_Intrinsics.hpp"
+#include "openMVG/features/feature.hpp"
 #include "openMVG/matching_image_collection/Geometric_Filter_utils.hpp"
 #include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
 #include "openMVG/sfm/sfm_data.hpp"
@@ -71,23 +76,51 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
       start.push_back(start.back() + its[p]->second.size());
     }
   }
-  std::vector<double> xI(2 * start.back()), xJ(2 * start.back());
-  std::vector<uint32_t> wh(4 * dev_pairs.size());
+  // The device call takes the container as it is: the (undistorted) positions of every feature of the views that occur - computed
+  // once per view, with the expressions of MatchesPointsToMat (Geometric_Filter_utils.cpp:33-49), where the reference recomputes
+  // them for every match of every pair - and the index pairs of the matches; the gather runs on the device.
+  static_assert(sizeof(matching::IndMatch) == 2 * sizeof(uint32_t), "IndMatch is two 32-bit indices");
+  std::map<IndexT, uint32_t> view_slot;
+  for (size_t k : dev_pairs) { view_slot.emplace(its[k]->first.first, 0u); view_slot.emplace(its[k]->first.second, 0u); }
+  std::vector<IndexT> slot_view;
+  for (auto& kv : view_slot) { kv.second = (uint32_t)slot_view.size(); slot_view.push_back(kv.first); }
+  const size_t n_views = slot_view.size();
+  std::vector<features::PointFeatures> positions(n_views);
+  std::vector<uint64_t> feat_start(n_views + 1, 0);
+  std::vector<uint32_t> wh(2 * std::max<size_t>(n_views, 1));
+#ifdef OPENMVG_USE_OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+  for (int64_t v = 0; v < (int64_t)n_views; ++v) {
+    positions[v] = regions_provider_->get(slot_view[v])->GetRegionsPositions();
+    feat_start[v + 1] = positions[v].size();
+    const sfm::View* view = sfm_data_->GetViews().at(slot_view[v]).get();
+    wh[2 * v] = view->ui_width; wh[2 * v + 1] = view->ui_height;
+  }
+  for (size_t v = 0; v < n_views; ++v) feat_start[v + 1] += feat_start[v];
+  std::vector<double> feat_xy(2 * std::max<uint64_t>(feat_start[n_views], 1));
+#ifdef OPENMVG_USE_OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+  for (int64_t v = 0; v < (int64_t)n_views; ++v) {
+    const sfm::View* view = sfm_data_->GetViews().at(slot_view[v]).get();
+    const cameras::IntrinsicBase* cam =
+        sfm_data_->GetIntrinsics().count(view->id_intrinsic) ? sfm_data_->GetIntrinsics().at(view->id_intrinsic).get() : nullptr;
+    double* dst = feat_xy.data() + 2 * feat_start[v];
+    for (size_t i = 0; i < positions[v].size(); ++i) {
+      const Vec2 x = cam ? Vec2(cam->get_ud_pixel(positions[v][i].coords().cast<double>())) : Vec2(positions[v][i].coords().cast<double>());
+      dst[2 * i] = x(0); dst[2 * i + 1] = x(1);
+    }
+    features::PointFeatures().swap(positions[v]);
+  }
+  std::vector<uint32_t> pair_views(2 * std::max<size_t>(dev_pairs.size(), 1)), ij(2 * std::max<uint64_t>(start.back(), 1));
 #ifdef OPENMVG_USE_OPENMP
 #pragma omp parallel for schedule(dynamic, 64)
 #endif
   for (int64_t k = 0; k < (int64_t)dev_pairs.size(); ++k) {
     const auto& kv = *its[dev_pairs[k]];
-    Mat2X a, b;
-    MatchesPairToMat(kv.first, kv.second, sfm_data_, regions_provider_, a, b);
-    const uint64_t lo = start[k];
-    for (size_t i = 0; i < kv.second.size(); ++i) {
-      xI[2 * (lo + i)] = a(0, i); xI[2 * (lo + i) + 1] = a(1, i);
-      xJ[2 * (lo + i)] = b(0, i); xJ[2 * (lo + i) + 1] = b(1, i);
-    }
-    const sfm::View* vi = sfm_data_->GetViews().at(kv.first.first).get();
-    const sfm::View* vj = sfm_data_->GetViews().at(kv.first.second).get();
-    wh[4 * k] = vi->ui_width; wh[4 * k + 1] = vi->ui_height; wh[4 * k + 2] = vj->ui_width; wh[4 * k + 3] = vj->ui_height;
+    pair_views[2 * k] = view_slot.at(kv.first.first); pair_views[2 * k + 1] = view_slot.at(kv.first.second);
+    if (!kv.second.empty()) std::memcpy(ij.data() + 2 * start[k], kv.second.data(), kv.second.size() * sizeof(matching::IndMatch));
   }
   std::vector<uint8_t> mask(start.back() ? start.back() : 1);
   std::vector<mvgx_geofilter_result> res(dev_pairs.size() ? dev_pairs.size() : 1);
@@ -95,10 +128,11 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
     mvgx_geofilter_options opt;
     opt.precision = functor.m_dPrecision;
     opt.max_iterations = functor.m_stIteration;
-    const int rc = mvgx_geofilter_f_acransac(-1, xI.data(), xJ.data(), start.data(), wh.data(), dev_pairs.size(), &opt, mask.data(), res.data(), nullptr);
+    const int rc = mvgx_geofilter_f_acransac_indexed(-1, feat_xy.data(), feat_start.data(), wh.data(), (uint32_t)n_views, pair_views.data(), start.data(),
+                                                     ij.data(), dev_pairs.size(), &opt, mask.data(), res.data(), nullptr);
     if (rc != MVGX_OK) {   // no CPU substitute for a failing device: report like the matcher adapter does
       OPENMVG_LOG_ERROR << "mvgx geometric filter: " << mvgx_last_error();
-      throw std::runtime_error(std::string("mvgx_geofilter_f_acransac failed: ") + mvgx_last_error());
+      throw std::runtime_error(std::string("mvgx_geofilter_f_acransac_indexed failed: ") + mvgx_last_error());
     }
   }
   // results in container order; guided matching (host, the reference's code) on OpenMP threads like the reference's loop

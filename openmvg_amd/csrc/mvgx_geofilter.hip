@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -265,6 +266,28 @@ __global__ __launch_bounds__(256) void geofilter_normalize_kernel(const GeoPair*
   }
 }
 
+// The same with MatchesPairToMat (Geometric_Filter_utils.hpp:56-64) in front: the correspondences of pair (I, J) are index pairs
+// (i, j) into the feature positions of the two images
+__global__ __launch_bounds__(256) void geofilter_normalize_indexed_kernel(const GeoPair* __restrict__ pairs, const double* __restrict__ norm, uint32_t n_pairs,
+                                                                          const double2* __restrict__ feat_xy, const uint64_t* __restrict__ feat_start,
+                                                                          const uint2* __restrict__ pair_images, const uint2* __restrict__ ij,
+                                                                          double2* __restrict__ x1n, double2* __restrict__ x2n) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pairs) return;
+  const uint64_t lo = pairs[p].start;
+  const uint32_t n = pairs[p].n;
+  const double* __restrict__ t = norm + 6 * (size_t)p;
+  const uint2 im = pair_images[p];
+  const double2* __restrict__ fI = feat_xy + feat_start[im.x];
+  const double2* __restrict__ fJ = feat_xy + feat_start[im.y];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint2 m = ij[lo + i];
+    const double2 a = fI[m.x], b = fJ[m.y];
+    x1n[lo + i] = make_double2(add_rn(mul_rn(t[0], a.x), t[1]), add_rn(mul_rn(t[0], a.y), t[2]));
+    x2n[lo + i] = make_double2(add_rn(mul_rn(t[3], b.x), t[4]), add_rn(mul_rn(t[3], b.y), t[5]));
+  }
+}
+
 constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (20) | the model of the current inlier list (18 words = 9 doubles at 8-byte alignment + 2)
 
 template <int WAVES>
@@ -462,14 +485,32 @@ int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_wor
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
-                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
-                              mvgx_geofilter_stats* stats) {
+// Where the correspondences come from: gathered coordinates (xI / xJ, image_wh per pair) or, `indexed`, the feature positions of
+// every image plus index pairs (image_wh per image)
+struct GeoSource {
+  bool indexed = false;
+  const double* xI = nullptr; const double* xJ = nullptr;
+  const double* feat_xy = nullptr; const uint64_t* feat_start = nullptr; uint32_t n_images = 0;
+  const uint32_t* pair_images = nullptr; const uint32_t* ij = nullptr;
+};
+
+int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
+                  uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                  mvgx_geofilter_stats* stats) {
   MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || (image_wh && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
   const uint64_t n_total = match_start[n_pairs];
-  MVGX_REQUIRE(n_total == 0 || (xI && xJ && inlier_mask), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
+  MVGX_REQUIRE(n_total == 0 || inlier_mask, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL inlier mask");
+  if (src.indexed) {
+    MVGX_REQUIRE(n_pairs == 0 || (src.pair_images && src.feat_start), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: NULL pair / feature-start array");
+    MVGX_REQUIRE(n_total == 0 || (src.feat_xy && src.ij), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: NULL position / index array");
+    for (uint64_t p = 0; p < n_pairs; ++p)
+      MVGX_REQUIRE(src.pair_images[2 * p] < src.n_images && src.pair_images[2 * p + 1] < src.n_images, MVGX_ERR_ARG,
+                   "mvgx_geofilter_f_acransac_indexed: pair %llu names an image out of range", (unsigned long long)p);
+  } else {
+    MVGX_REQUIRE(n_total == 0 || (src.xI && src.xJ), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
+  }
   MVGX_REQUIRE(std::isfinite(opt->precision) && opt->precision > 0.0, MVGX_ERR_UNSUPPORTED,
                "mvgx_geofilter_f_acransac: precision must be a finite upper bound (the exhaustive NFA form of an unbounded precision is not "
                "reproduced on the device; main_GeometricFilter passes 4.0)");
@@ -490,20 +531,30 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
   uint32_t n_max = 0;
   for (uint64_t p = 0; p < n_pairs; ++p) n_max = std::max<uint32_t>(n_max, (uint32_t)(match_start[p + 1] - match_start[p]));
   const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, (size_t)(n_pairs / 4096 + 1)}));
+  std::atomic<int64_t> bad_pair{-1};
   auto prep = [&](unsigned tix) {
     for (uint64_t p = tix; p < n_pairs; p += T) {
       const uint64_t lo = match_start[p];
       const uint32_t n = (uint32_t)(match_start[p + 1] - lo);
       GeoPair& g = hp[p];
       g.start = lo; g.n = n; g.pad_ = 0;
+      if (src.indexed) {
+        const uint32_t I = src.pair_images[2 * p], J = src.pair_images[2 * p + 1];
+        const uint64_t nI = src.feat_start[I + 1] - src.feat_start[I], nJ = src.feat_start[J + 1] - src.feat_start[J];
+        bool bad = false;
+        for (uint32_t m = 0; m < n; ++m) bad = bad || src.ij[2 * (lo + m)] >= nI || src.ij[2 * (lo + m) + 1] >= nJ;
+        if (bad) bad_pair.store((int64_t)p);
+      }
       double t[2][3];
       for (int im = 0; im < 2; ++im) {   // conditioning.cpp:44-53
-        const int w = (int)image_wh[4 * p + 2 * im], h = (int)image_wh[4 * p + 2 * im + 1];
+        const uint32_t* whp = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + im] : image_wh + 4 * p + 2 * im;
+        const int w = (int)whp[0], h = (int)whp[1];
         const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
         t[im][0] = dNorm; t[im][1] = -.5f * w * dNorm; t[im][2] = -.5 * h * dNorm;
         for (int k = 0; k < 3; ++k) norm[6 * p + 3 * im + k] = t[im][k];
       }
-      const int w2 = (int)image_wh[4 * p + 2], h2 = (int)image_wh[4 * p + 3];
+      const uint32_t* wh2 = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + 1] : image_wh + 4 * p + 2;
+      const int w2 = (int)wh2[0], h2 = (int)wh2[1];
       const double logalpha0 = std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
       g.max_threshold = opt->precision * opt->precision * t[1][0] * t[1][0];
       g.loge0 = n > (uint32_t)kMinSamples ? std::log10((double)kMaxModels * (n - kMinSamples)) : 0.0;
@@ -521,6 +572,7 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
     prep(0);
     for (auto& th : pool) th.join();
   }
+  MVGX_REQUIRE(bad_pair.load() < 0, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: pair %lld has a feature index out of range", (long long)bad_pair.load());
   // pairs that run the estimation (more than 7 correspondences), by size class, largest first inside a class
   std::vector<uint32_t> order;
   order.reserve(n_pairs);
@@ -544,12 +596,19 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
   int stream_device = 0;
   MVGX_HIP(hipGetDevice(&stream_device));
   struct StreamGuard { int dev; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(dev, s); } } sg{stream_device, stream};
-  DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm;
+  DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm, d_feat, d_fstart, d_pimg;
+  const uint64_t n_feat = src.indexed && src.n_images ? src.feat_start[src.n_images] : 0;
   if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_total * sizeof(double2))) ||
       (rc = d_x2.alloc(n_total * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
-      (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_raw1.alloc(n_total * sizeof(double2))) ||
-      (rc = d_raw2.alloc(n_total * sizeof(double2))) || (rc = d_norm.alloc(norm.size() * sizeof(double))))
+      (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_norm.alloc(norm.size() * sizeof(double))))
     return rc;
+  if (src.indexed) {   // d_raw1: the index pairs
+    if ((rc = d_raw1.alloc(n_total * sizeof(uint2))) || (rc = d_feat.alloc(n_feat * sizeof(double2))) ||
+        (rc = d_fstart.alloc(((size_t)src.n_images + 1) * sizeof(uint64_t))) || (rc = d_pimg.alloc(n_pairs * sizeof(uint2))))
+      return rc;
+  } else if ((rc = d_raw1.alloc(n_total * sizeof(double2))) || (rc = d_raw2.alloc(n_total * sizeof(double2)))) {
+    return rc;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   MVGX_HIP(hipEventCreate(&e0));
   MVGX_HIP(hipEventCreate(&e1));
@@ -557,8 +616,15 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
   if (n_pairs) MVGX_HIP(hipMemcpyAsync(d_pairs.p, hp.data(), n_pairs * sizeof(GeoPair), hipMemcpyHostToDevice, stream));
   if (!order.empty()) MVGX_HIP(hipMemcpyAsync(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   if (n_total) {
-    MVGX_HIP(hipMemcpyAsync(d_raw1.p, xI, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
-    MVGX_HIP(hipMemcpyAsync(d_raw2.p, xJ, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
+    if (src.indexed) {
+      MVGX_HIP(hipMemcpyAsync(d_raw1.p, src.ij, n_total * sizeof(uint2), hipMemcpyHostToDevice, stream));
+      MVGX_HIP(hipMemcpyAsync(d_feat.p, src.feat_xy, n_feat * sizeof(double2), hipMemcpyHostToDevice, stream));
+      MVGX_HIP(hipMemcpyAsync(d_fstart.p, src.feat_start, ((size_t)src.n_images + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+      MVGX_HIP(hipMemcpyAsync(d_pimg.p, src.pair_images, n_pairs * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    } else {
+      MVGX_HIP(hipMemcpyAsync(d_raw1.p, src.xI, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
+      MVGX_HIP(hipMemcpyAsync(d_raw2.p, src.xJ, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
+    }
     MVGX_HIP(hipMemcpyAsync(d_norm.p, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(d_mask.p, 0, n_total, stream));
   }
@@ -574,7 +640,14 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
     const auto* pn = static_cast<const double*>(d_norm.p);
     const auto *r1 = static_cast<const double2*>(d_raw1.p), *r2 = static_cast<const double2*>(d_raw2.p);
     auto *o1 = static_cast<double2*>(d_x1.p), *o2 = static_cast<double2*>(d_x2.p);
-    hipLaunchKernelGGL(geofilter_normalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, r1, r2, o1, o2);
+    if (src.indexed) {
+      const auto* ft = static_cast<const double2*>(d_feat.p);
+      const auto* fs = static_cast<const uint64_t*>(d_fstart.p);
+      const auto *pim = static_cast<const uint2*>(d_pimg.p), *mij = static_cast<const uint2*>(d_raw1.p);
+      hipLaunchKernelGGL(geofilter_normalize_indexed_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, ft, fs, pim, mij, o1, o2);
+    } else {
+      hipLaunchKernelGGL(geofilter_normalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, r1, r2, o1, o2);
+    }
     MVGX_HIP(hipGetLastError());
   }
   if ((rc = launch_class<1>(static_cast<GeoPair*>(d_pairs.p), ord, c3, kCap3, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
@@ -628,6 +701,28 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
   return MVGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.xI = xI; src.xJ = xJ;
+  return geofilter_run(device, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_f_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                      const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
+                                      const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.indexed = true;
+  src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
+  return geofilter_run(device, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
 }
 
 }  // extern "C"

@@ -40,15 +40,50 @@ def filter_pairs(xI, xJ, match_start, image_wh, functor=None, device=-1):
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
     _capi.check(_capi.lib().mvgx_geofilter_f_acransac(int(device), P(xI), P(xJ), P(start), P(wh), n_pairs, C.byref(opt), P(mask),
                                                       C.cast(res, C.c_void_p), C.byref(st)))
+    out = _results_array(res, n_pairs)
+    return mask[:len(xI)].astype(bool), out, st
+
+
+def _results_array(res, n_pairs):
     out = np.zeros(n_pairs, dtype=[("F", np.float64, (3, 3)), ("precision_robust", np.float64), ("nfa", np.float64),
                                    ("n_inliers", np.uint32), ("ok", bool)])
-    for p in range(n_pairs):
-        out["F"][p] = np.array(res[p].F[:]).reshape(3, 3)
-        out["precision_robust"][p] = res[p].precision_robust
-        out["nfa"][p] = res[p].nfa
-        out["n_inliers"][p] = res[p].n_inliers
-        out["ok"][p] = bool(res[p].ok)
-    return mask[:len(xI)].astype(bool), out, st
+    if n_pairs:
+        raw = np.frombuffer(res, dtype=np.dtype([("F", np.float64, (9,)), ("precision_robust", np.float64), ("nfa", np.float64),
+                                                 ("n_inliers", np.uint32), ("ok", np.int32)], align=True), count=n_pairs)
+        out["F"] = raw["F"].reshape(-1, 3, 3); out["precision_robust"] = raw["precision_robust"]; out["nfa"] = raw["nfa"]
+        out["n_inliers"] = raw["n_inliers"]; out["ok"] = raw["ok"] != 0
+    return out
+
+
+def filter_pairs_indexed(feats_xy, image_sizes, pairs, match_start, ij, functor=None, device=-1):
+    """The PairWiseMatches-shaped form (mvgx_geofilter_f_acransac_indexed): feats_xy = list of (n_k, 2) feature positions per image
+    (or one (N, 2) array with feat_start), image_sizes (n_images, 2) {w, h}, pairs (n_pairs, 2) image ids, ij (n_matches, 2) index
+    pairs with pair p owning rows [match_start[p], match_start[p + 1]). The positions are gathered on the device.
+    Returns (inlier_mask (n_matches,) bool, results structured array, stats)."""
+    functor = functor or GeometricFilter_FMatrix_AC(4.0, 2048)
+    if isinstance(feats_xy, tuple):
+        feat, fstart = feats_xy
+        feat = np.ascontiguousarray(feat, np.float64).reshape(-1, 2); fstart = np.ascontiguousarray(fstart, np.uint64)
+    else:
+        counts = [len(f) for f in feats_xy]
+        fstart = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        feat = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float64).reshape(-1, 2) for f in feats_xy]) if counts else np.zeros((0, 2)))
+    n_images = len(fstart) - 1
+    wh = np.ascontiguousarray(image_sizes, np.uint32).reshape(-1, 2)
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    start = np.ascontiguousarray(match_start, np.uint64)
+    ij = np.ascontiguousarray(ij, np.uint32).reshape(-1, 2)
+    n_pairs = len(pairs)
+    if len(wh) != n_images or len(start) != n_pairs + 1 or int(start[-1]) != len(ij):
+        raise ValueError("filter_pairs_indexed: inconsistent array sizes")
+    mask = np.zeros(max(len(ij), 1), np.uint8)
+    res = (_capi.GeofilterResult * max(n_pairs, 1))()
+    st = _capi.GeofilterStats()
+    opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _capi.check(_capi.lib().mvgx_geofilter_f_acransac_indexed(int(device), P(feat), P(fstart), P(wh), n_images, P(pairs), P(start), P(ij), n_pairs,
+                                                              C.byref(opt), P(mask), C.cast(res, C.c_void_p), C.byref(st)))
+    return mask[:len(ij)].astype(bool), _results_array(res, n_pairs), st
 
 
 def Robust_model_estimation(putative_matches, feats_xy, image_sizes, functor=None, device=-1):
@@ -56,16 +91,14 @@ def Robust_model_estimation(putative_matches, feats_xy, image_sizes, functor=Non
     feature positions of image k (undistorted where the reference would undistort them), image_sizes[k] = (w, h). Returns the
     geometric matches {(I, J): (m, 2)}: only the pairs whose estimation succeeded, like _map_GeometricMatches."""
     keys = sorted(putative_matches)
-    xs_i, xs_j, start, wh = [], [], [0], []
-    for (i, j) in keys:
-        m = np.asarray(putative_matches[(i, j)], np.uint32).reshape(-1, 2)
-        xs_i.append(np.asarray(feats_xy[i], np.float64)[m[:, 0]])
-        xs_j.append(np.asarray(feats_xy[j], np.float64)[m[:, 1]])
-        start.append(start[-1] + len(m))
-        wh.append((*image_sizes[i], *image_sizes[j]))
     if not keys:
         return {}
-    mask, res, _ = filter_pairs(np.concatenate(xs_i), np.concatenate(xs_j), np.asarray(start, np.uint64), np.asarray(wh, np.uint32), functor, device)
+    n_images = len(feats_xy)
+    lists = [np.asarray(putative_matches[k], np.uint32).reshape(-1, 2) for k in keys]
+    start = np.concatenate([[0], np.cumsum([len(m) for m in lists])]).astype(np.uint64)
+    sizes = np.array([image_sizes[k] for k in range(n_images)], np.uint32).reshape(-1, 2)
+    mask, res, _ = filter_pairs_indexed([feats_xy[k] for k in range(n_images)], sizes, np.array(keys, np.uint32),
+                                        start, np.concatenate(lists) if len(lists) else np.zeros((0, 2), np.uint32), functor, device)
     out = {}
     for k, key in enumerate(keys):
         if res["ok"][k]:

@@ -73,6 +73,40 @@ def test_container_mirror_and_argument_errors():
         assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
 
 
+def test_indexed_form_equals_the_gathered_form_under_emulation():
+    """mvgx_geofilter_f_acransac_indexed (feature positions per image + index pairs, gathered on the device) returns what the
+    gathered form returns on the same correspondences; indices out of range are argument errors"""
+    start = GOLD["start"].astype(np.int64)
+    n = np.diff(start)
+    small = [int(p) for p in np.argsort(n) if 7 < n[p] <= 80]
+    sel = small[:1] + [p for p in small if GOLD["ok"][p]][:3]
+    tv, ref = _gold_tv(sel)
+    st0 = tv["start"].astype(np.int64)
+    feats, sizes, pairs, ij = [], [], [], []
+    for p in range(len(sel)):   # images 2 p, 2 p + 1 hold the pair's features in shuffled order, plus three unused features each
+        m = int(st0[p + 1] - st0[p])
+        pi, pj = np.random.default_rng(p).permutation(m + 3)[:m], np.random.default_rng(50 + p).permutation(m + 3)[:m]
+        fi = np.full((m + 3, 2), 7.0); fj = np.full((m + 3, 2), 9.0)
+        fi[pi] = tv["xI"][st0[p]:st0[p + 1]]; fj[pj] = tv["xJ"][st0[p]:st0[p + 1]]
+        feats += [fi, fj]; sizes += [tv["wh"][p][:2], tv["wh"][p][2:]]
+        pairs.append((2 * p, 2 * p + 1)); ij.append(np.stack([pi, pj], 1))
+    ij = np.concatenate(ij).astype(np.uint32)
+    f = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
+    with _emu.emulated():
+        mask_g, res_g, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], f)
+        mask_i, res_i, st = geofilter.filter_pairs_indexed(feats, np.array(sizes), np.array(pairs), tv["start"], ij, f)
+        assert np.array_equal(mask_g, mask_i) and np.array_equal(res_g["ok"], res_i["ok"]) and np.array_equal(res_g["F"], res_i["F"])
+        assert np.array_equal(res_g["nfa"], res_i["nfa"]) and int(st.n_pairs_ok) == int(res_g["ok"].sum())
+        bad = ij.copy(); bad[0, 0] = len(feats[0])
+        with pytest.raises(_capi.MvgxError) as e:
+            geofilter.filter_pairs_indexed(feats, np.array(sizes), np.array(pairs), tv["start"], bad, f)
+        assert e.value.code == _capi.MVGX_ERR_ARG
+        badp = np.array(pairs); badp[1, 1] = len(feats)
+        with pytest.raises(_capi.MvgxError) as e:
+            geofilter.filter_pairs_indexed(feats, np.array(sizes), badp, tv["start"], ij, f)
+        assert e.value.code == _capi.MVGX_ERR_ARG
+
+
 def test_adapter_specialisation_fills_the_container_like_the_reference_template():
     """ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>: the same caller code linked once against
     the reference header's template and once against the explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp
