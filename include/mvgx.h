@@ -206,6 +206,17 @@ int mvgx_cascade_set_option(mvgx_cascade_ctx* ctx, const char* key /* "batch_pai
 int mvgx_cascade_set_regions(mvgx_cascade_ctx* ctx, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
                              const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
                              uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket);
+/* The HASHING stage on the device (cascade_hasher.hpp:120-163 Init, :179-239 CreateHashedDescriptions) in place of
+ * mvgx_cascade_set_regions: the projections are generated like CascadeHasher::Init(dim, n_groups, bits_per_bucket, random_seed)
+ * (std::mt19937 + std::normal_distribution<>, the reference's default seed is 5489), every descriptor is centred on zero_mean
+ * (dim floats: the caller's CascadeHasher::GetZeroMeanDescriptor result) and projected with the operation order of Eigen 3.4's
+ * single-precision column-major matrix x vector kernel (column blocks of 16, products and sums rounded separately - no FMA, as
+ * in a reference build without -mfma), so codes and bucket ids equal the reference's bit for bit (tests/test_cascade.py against
+ * the compiled reference). hash_codes_out[k] (n_desc[k] x 16 bytes) / bucket_ids_out[k] (n_desc[k] x n_groups uint16) receive
+ * the per-descriptor outputs when non-NULL. */
+int mvgx_cascade_hash_regions(mvgx_cascade_ctx* ctx, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                              const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
+                              uint8_t* const* hash_codes_out /* may be NULL */, uint16_t* const* bucket_ids_out /* may be NULL */);
 int mvgx_cascade_run(mvgx_cascade_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
                      mvgx_match_stats* stats /* may be NULL */);
 int mvgx_cascade_results(mvgx_cascade_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);

@@ -5,13 +5,16 @@
 //
 // Split of the work (reference lines are Cascade_Hashing_Matcher_Regions.cpp):
 //   host, with the reference's own library code (so the values are the reference's bit for bit):
-//     * hashing stage :66-131 - CascadeHasher::Init, the zero-mean descriptor (mean over the images of the per-image mean),
-//       CreateHashedDescriptions per image (single-precision Eigen products) - here on all host threads instead of inside
-//       one `omp critical`;
+//     * the zero-mean descriptor :78-104 (mean over the images of the per-image mean, CascadeHasher::GetZeroMeanDescriptor), the
+//       per-image means on all host threads;
 //     * the two de-duplication steps :218-226 - IndMatch::getDeduplicated and IndMatchDecorator<float>::getDeduplicated
 //       (whose std::set ordering is the library's) - on helper threads, the container is filled from the calling thread;
-//   MI355X (mvgx_cascade_*): the matching stage :166-215 - bucket candidates, Hamming ranking of the hash codes, exact L2 on
-//     the ten best, the two nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
+//   MI355X (mvgx_cascade_*):
+//     * the rest of the hashing stage :66-76, :107-131 - the random projections of CascadeHasher::Init and CreateHashedDescriptions
+//       per descriptor (mvgx_cascade_hash_regions: Eigen's single-precision product order reproduced, codes and bucket ids
+//       bit-identical - tests/test_cascade.py, tests/test_adapter_*.py);
+//     * the matching stage :166-215 - bucket candidates, Hamming ranking of the hash codes, exact L2 on the ten best, the two
+//       nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
 // 128-byte uint8 regions (SIFT) take that route. Other scalar regions (float descriptors, other lengths) keep working through
 // the reference's own CascadeHasher::Match_HashedDescriptions on the host: that code is not part of the accelerated path.
 // A device failure throws (no silent fallback for the accelerated type).
@@ -21,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <random>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -94,27 +98,31 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   const size_t dimension = views.begin()->second.regions->DescriptorLength();
   matching::CascadeHasher hasher;
   hasher.Init(dimension);
+  const bool on_device = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
+  std::vector<View<ScalarT>*> order;
+  for (auto& kv : views) order.push_back(&kv.second);
+  // the zero-mean descriptor (:78-104): the reference's own GetZeroMeanDescriptor, per view on the host threads, then over the views
   Eigen::VectorXf zero_mean;
   {
     Eigen::MatrixXf per_view(views.size(), dimension);
     per_view.fill(0.0f);
-    size_t row = 0;
-    for (auto& kv : views) {
-      View<ScalarT>& v = kv.second;
+    on_host_threads(order.size(), [&](size_t k) {
+      View<ScalarT>& v = *order[k];
       if (v.count() > 0) {
         Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
-        per_view.row(row) = matching::CascadeHasher::GetZeroMeanDescriptor(m);
+        per_view.row(k) = matching::CascadeHasher::GetZeroMeanDescriptor(m);   // (rows of a column-major matrix: disjoint elements)
       }
-      ++row;
-    }
+    });
     zero_mean = matching::CascadeHasher::GetZeroMeanDescriptor(per_view);
   }
-  std::vector<View<ScalarT>*> order;
-  for (auto& kv : views) order.push_back(&kv.second);
+  // hash codes and bucket ids: on the device for 128-byte uint8 regions (mvgx_cascade_hash_regions below, bit-identical to
+  // CreateHashedDescriptions), else the reference's CreateHashedDescriptions on the host threads
   on_host_threads(order.size(), [&](size_t k) {
     View<ScalarT>& v = *order[k];
-    Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
-    v.hashed = hasher.CreateHashedDescriptions(m, zero_mean);   // const member, per-view outputs: thread safe
+    if (!on_device) {
+      Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
+      v.hashed = hasher.CreateHashedDescriptions(m, zero_mean);   // const member, per-view outputs: thread safe
+    }
     v.positions = v.regions->GetRegionsPositions();
   });
 
@@ -129,7 +137,6 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   }
   if (skipped) (*progress) += skipped;
 
-  const bool on_device = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
   if (!on_device) {
     // the reference's own matching stage, pair by pair on the host threads; the container is filled by this thread
     std::vector<matching::IndMatches> lists(todo.size());
@@ -155,13 +162,9 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     return;
   }
 
-  // ---- device route: dense view numbering, hash outputs flattened ----
+  // ---- device route: dense view numbering; hashing and matching stages both on the device ----
   std::unordered_map<IndexT, uint32_t> dense;
   std::vector<const uint8_t*> rows;
-  std::vector<std::vector<uint8_t>> codes;
-  std::vector<std::vector<uint16_t>> buckets;
-  std::vector<const uint8_t*> code_ptr;
-  std::vector<const uint16_t*> bucket_ptr;
   std::vector<uint32_t> n_desc;
   std::vector<const View<ScalarT>*> view_of;
   for (auto& kv : views) {
@@ -171,16 +174,7 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     const size_t n = v.count();
     n_desc.push_back((uint32_t)n);
     rows.push_back(n ? reinterpret_cast<const uint8_t*>(v.regions->DescriptorRawData()) : nullptr);
-    codes.emplace_back(n * 16);
-    buckets.emplace_back(n * 6);
-    for (size_t r = 0; r < n; ++r) {
-      const matching::HashedDescription& h = v.hashed.hashed_desc[r];
-      if (h.hash_code.num_blocks() != 16 || h.bucket_ids.size() != 6) throw std::runtime_error("mvgx cascade hashing: unexpected hash layout");
-      std::memcpy(&codes.back()[r * 16], h.hash_code.data(), 16);
-      for (int g = 0; g < 6; ++g) buckets.back()[r * 6 + g] = h.bucket_ids[g];
-    }
   }
-  for (size_t k = 0; k < rows.size(); ++k) { code_ptr.push_back(codes[k].data()); bucket_ptr.push_back(buckets[k].data()); }
   std::vector<uint32_t> dev_pairs;
   for (const Pair& p : todo) { dev_pairs.push_back(dense[p.first]); dev_pairs.push_back(dense[p.second]); }
 
@@ -192,8 +186,9 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   };
   int rc = mvgx_cascade_create(-1, &ctx.c);
   if (rc != MVGX_OK) fail("create", rc);
-  rc = mvgx_cascade_set_regions(ctx.c, rows.data(), code_ptr.data(), bucket_ptr.data(), n_desc.data(), (uint32_t)rows.size(), 128, 16, 6, 10);
-  if (rc != MVGX_OK) fail("set_regions", rc);
+  // CascadeHasher::Init(dimension) defaults: 6 bucket groups, 10 bits per bucket, std::mt19937::default_seed
+  rc = mvgx_cascade_hash_regions(ctx.c, rows.data(), n_desc.data(), (uint32_t)rows.size(), 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, nullptr, nullptr);
+  if (rc != MVGX_OK) fail("hash_regions", rc);
   const float ratio_sq = Square(dist_ratio);
   const uint64_t n_pairs = todo.size();
   for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {

@@ -20,7 +20,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <mutex>
+#include <random>
+#include <thread>
 #include <vector>
 
 #include "mvgx_common.h"
@@ -435,6 +439,69 @@ struct Buf {
 
 }  // namespace
 
+namespace {
+// HASHING stage of CASCADE_HASHING_L2 (matching/cascade_hasher.hpp:179-223, CreateHashedDescriptions): per descriptor
+//   descriptor = row.cast<float>() - zero_mean;  primary_projection = P1 * descriptor  (128 x 128);  hash bit j = primary_projection(j) > 0
+//   per bucket group g: secondary_projection = P2[g] * descriptor (bits x 128); bucket id = the bits (projection > 0), first row most significant
+// The products are Eigen 3.4 column-major matrix x vector products in single precision (GeneralMatrixVector.h,
+// general_matrix_vector_product<..., ColMajor, ...>::run): for 128 columns the kernel walks the columns in blocks of 16
+// (block_cols = cols < 128 ? cols : (stride * 4 < 32000 ? 16 : 4)); inside a block every output row accumulates
+// c = a(i, j) * x(j) + c from c = 0 in ascending j - a rounded product and a rounded sum, the reference objects are built without
+// FMA - and the block's c is then added to the row's result (res = c * 1 + res). One lane per descriptor reproduces exactly that
+// order with __fmul_rn / __fadd_rn (no contraction); the projection rows are wave-uniform and come through the scalar cache.
+// P: [128 + groups * bits][128] floats, row q = row q of the primary projection, then the rows of the secondary projections.
+constexpr int kCasDim = 128, kCasBlockCols = 16;
+__global__ __launch_bounds__(256) void cascade_hash_kernel(const uint32_t* __restrict__ words, uint64_t n_rows, const float* __restrict__ zero_mean,
+                                                           const float* __restrict__ P, int n_groups, int bits, uint4* __restrict__ hash,
+                                                           uint4* __restrict__ bids) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < n_rows;
+  float d[kCasDim];
+  {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(words + (live ? r : 0) * (kCasDim / 4));
+#pragma unroll
+    for (int q = 0; q < kCasDim / 16; ++q) {
+      const uint4 w = src[q];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[16 * q + e] = __fsub_rn((float)((ww[e >> 2] >> (8 * (e & 3))) & 255u), zero_mean[16 * q + e]);
+    }
+  }
+  auto project = [&](const float* __restrict__ row) -> float {   // one output row: eight column blocks of sixteen
+    float res = 0.0f;
+#pragma unroll
+    for (int b = 0; b < kCasDim / kCasBlockCols; ++b) {
+      float c = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kCasBlockCols; ++j) c = __fadd_rn(__fmul_rn(row[kCasBlockCols * b + j], d[kCasBlockCols * b + j]), c);
+      res = __fadd_rn(c, res);
+    }
+    return res;
+  };
+  uint32_t code[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    for (int b = 0; b < 32; ++b) {
+      const float v = project(P + (size_t)(32 * w + b) * kCasDim);
+      if (v > 0.0f) code[w] |= 1u << b;   // dynamic_bitset: bit q of the code = bit (q % 8) of byte q / 8
+    }
+  uint32_t ids[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g >= n_groups) break;   // uniform
+    uint32_t id = 0;
+    for (int k = 0; k < bits; ++k) {
+      const float v = project(P + (size_t)(kCasDim + g * bits + k) * kCasDim);
+      id = (id << 1) + (v > 0.0f ? 1u : 0u);
+    }
+    ids[g] = id & 0xFFFFu;   // uint16_t bucket_id
+  }
+  if (!live) return;
+  hash[r] = make_uint4(code[0], code[1], code[2], code[3]);
+  bids[r] = make_uint4(ids[0] | (ids[1] << 16), ids[2] | (ids[3] << 16), ids[4] | (ids[5] << 16), ids[6] | (ids[7] << 16));
+}
+}  // namespace
+
 struct BfCtx {
   int kind = 0;   // 0: Hamming on packed bits (nw dwords per row), 1: L2<float> (nw floats per row), 2: L2<uint8> (nw dwords per row)
   int device = 0;
@@ -749,56 +816,151 @@ int mvgx_cascade_create(int device, mvgx_cascade_ctx** out) { return bf_create_a
 int mvgx_cascade_destroy(mvgx_cascade_ctx* c) { if (c) { bf_release(c); delete c; } return MVGX_OK; }
 int mvgx_cascade_set_option(mvgx_cascade_ctx* c, const char* key, int64_t value) { return bf_set_option(c, key, value); }
 
-int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
-                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
-                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
-  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && hash_codes && bucket_ids && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_set_regions: NULL argument");
+}  // extern "C"
+
+namespace {
+int cas_check_shape(uint32_t dim, uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
   MVGX_REQUIRE(dim == 128 && hash_bytes == 16, MVGX_ERR_UNSUPPORTED,
                "cascade hashing on the device: 128-byte uint8 descriptors with 128-bit codes (SIFT_Regions; CascadeHasher::Init(128)); "
                "got length %u, %u code bytes", dim, hash_bytes);
   MVGX_REQUIRE(n_groups >= 1 && n_groups <= (uint32_t)kCasGroupsMax && bits_per_bucket >= 1 && bits_per_bucket <= 16, MVGX_ERR_UNSUPPORTED,
                "cascade hashing on the device: 1..8 bucket groups of 2^1..2^16 buckets (got %u groups, %u bits)", n_groups, bits_per_bucket);
-  int rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4);
-  if (rc) return rc;
-  const uint32_t NB = 1u << bits_per_bucket, G = n_groups;
+  return MVGX_OK;
+}
+
+// per image and bucket group the lists of its descriptors by bucket, ascending descriptor inside a bucket (cascade_hasher.hpp:
+// 225-237), from the bucket ids (8 x uint16 per descriptor); images are independent: host threads
+int cas_build_buckets(BfCtx* c, const uint4* bids, const uint32_t* n_desc, uint32_t n_images, uint32_t G, uint32_t bits_per_bucket) {
+  const uint32_t NB = 1u << bits_per_bucket;
   c->cas_groups = G; c->cas_buckets = NB;
   std::vector<uint64_t> off(n_images + 1, 0);
   for (uint32_t k = 0; k < n_images; ++k) {
-    MVGX_REQUIRE(n_desc[k] == 0 || (hash_codes[k] && bucket_ids[k]), MVGX_ERR_ARG, "image %u: NULL hash / bucket array", k);
     MVGX_REQUIRE(n_desc[k] < (1u << 24) / G, MVGX_ERR_UNSUPPORTED, "image %u: %u descriptors (limit 2^24 / groups: the appearance index has 24 bits)", k, n_desc[k]);
     off[k + 1] = off[k] + n_desc[k];
   }
   const uint64_t rows = off[n_images];
-  std::vector<uint4> hash((size_t)std::max<uint64_t>(rows, 1)), bids((size_t)std::max<uint64_t>(rows, 1));
   std::vector<uint32_t> bstart((size_t)std::max<uint32_t>(n_images, 1) * ((size_t)G * NB + 1), 0u), items((size_t)std::max<uint64_t>(rows * G, 1), 0u);
-  for (uint32_t k = 0; k < n_images; ++k) {
+  std::vector<int> bad(n_images, -1);
+  auto image = [&](uint32_t k) {
     const uint32_t n = n_desc[k];
     uint32_t* bs = bstart.data() + (size_t)k * ((size_t)G * NB + 1);
-    for (uint32_t r = 0; r < n; ++r) {
-      memcpy(&hash[off[k] + r], hash_codes[k] + (size_t)r * 16, 16);
-      uint16_t b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t* b16 = reinterpret_cast<const uint16_t*>(bids + off[k]);
+    for (uint32_t r = 0; r < n; ++r)
       for (uint32_t g = 0; g < G; ++g) {
-        b8[g] = bucket_ids[k][(size_t)r * G + g];
-        MVGX_REQUIRE(b8[g] < NB, MVGX_ERR_ARG, "image %u, descriptor %u: bucket id %u out of range", k, r, (unsigned)b8[g]);
-        bs[(size_t)g * NB + b8[g] + 1]++;
+        const uint32_t b = b16[(size_t)r * 8 + g];
+        if (b >= NB) { bad[k] = (int)r; return; }
+        bs[(size_t)g * NB + b + 1]++;
       }
-      memcpy(&bids[off[k] + r], b8, 16);
-    }
     for (size_t b = 0; b < (size_t)G * NB; ++b) bs[b + 1] += bs[b];
     std::vector<uint32_t> fill(bs, bs + (size_t)G * NB);
     uint32_t* it = items.data() + off[k] * G;
     for (uint32_t g = 0; g < G; ++g)
-      for (uint32_t r = 0; r < n; ++r) it[fill[(size_t)g * NB + bucket_ids[k][(size_t)r * G + g]]++] = r;   // ascending r inside a bucket (cascade_hasher.hpp:229-234)
+      for (uint32_t r = 0; r < n; ++r) it[fill[(size_t)g * NB + b16[(size_t)r * 8 + g]]++] = r;   // ascending r inside a bucket
+  };
+  {
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::thread::hardware_concurrency(), (uint64_t)32, rows / 8192 + 1, (uint64_t)std::max(n_images, 1u)}));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { for (uint32_t k = t; k < n_images; k += T) image(k); });
+    for (uint32_t k = 0; k < n_images; k += T) image(k);
+    for (auto& x : th) x.join();
   }
-  if ((rc = c->d_hash.ensure(hash.size())) || (rc = c->d_bids.ensure(bids.size())) || (rc = c->d_bstart.ensure(bstart.size())) ||
-      (rc = c->d_items.ensure(items.size())))
-    return rc;
-  MVGX_HIP(hipMemcpyAsync(c->d_hash.p, hash.data(), hash.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
-  MVGX_HIP(hipMemcpyAsync(c->d_bids.p, bids.data(), bids.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  for (uint32_t k = 0; k < n_images; ++k)
+    MVGX_REQUIRE(bad[k] < 0, MVGX_ERR_ARG, "image %u, descriptor %d: bucket id out of range", k, bad[k]);
+  int rc;
+  if ((rc = c->d_bstart.ensure(bstart.size())) || (rc = c->d_items.ensure(items.size()))) return rc;
   MVGX_HIP(hipMemcpyAsync(c->d_bstart.p, bstart.data(), bstart.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(c->d_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   return MVGX_OK;
+}
+
+// CascadeHasher::Init(dim, groups, bits, seed) (cascade_hasher.hpp:120-163): the projections are std::normal_distribution<>(0, 1)
+// draws of a std::mt19937, converted to float, row by row - the primary projection first, then the secondary ones. The same
+// standard-library facilities give the same values as the reference's own Init (libstdc++ on both sides of the boundary here).
+const std::vector<float>& cas_projections(uint32_t dim, uint32_t groups, uint32_t bits, uint32_t seed) {
+  struct Entry { uint32_t dim, groups, bits, seed; std::vector<float> P; };
+  static std::mutex mu;
+  static std::vector<Entry*> cache;   // never freed: a handful of parameter sets per process
+  std::lock_guard<std::mutex> lk(mu);
+  for (Entry* e : cache) if (e->dim == dim && e->groups == groups && e->bits == bits && e->seed == seed) return e->P;
+  Entry* e = new Entry{dim, groups, bits, seed, {}};
+  e->P.resize(((size_t)dim + (size_t)groups * bits) * dim);
+  std::mt19937 gen(seed);
+  std::normal_distribution<> nd(0, 1);
+  for (float& v : e->P) v = (float)nd(gen);
+  cache.push_back(e);
+  return e->P;
+}
+}  // namespace
+
+extern "C" {
+
+int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
+                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
+  MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && hash_codes && bucket_ids && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_set_regions: NULL argument");
+  int rc = cas_check_shape(dim, hash_bytes, n_groups, bits_per_bucket);
+  if (rc) return rc;
+  if ((rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4))) return rc;
+  const uint32_t G = n_groups;
+  std::vector<uint64_t> off(n_images + 1, 0);
+  for (uint32_t k = 0; k < n_images; ++k) {
+    MVGX_REQUIRE(n_desc[k] == 0 || (hash_codes[k] && bucket_ids[k]), MVGX_ERR_ARG, "image %u: NULL hash / bucket array", k);
+    off[k + 1] = off[k] + n_desc[k];
+  }
+  const uint64_t rows = off[n_images];
+  std::vector<uint4> hash((size_t)std::max<uint64_t>(rows, 1)), bids((size_t)std::max<uint64_t>(rows, 1));
+  for (uint32_t k = 0; k < n_images; ++k)
+    for (uint32_t r = 0; r < n_desc[k]; ++r) {
+      memcpy(&hash[off[k] + r], hash_codes[k] + (size_t)r * 16, 16);
+      uint16_t b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t g = 0; g < G; ++g) b8[g] = bucket_ids[k][(size_t)r * G + g];
+      memcpy(&bids[off[k] + r], b8, 16);
+    }
+  if ((rc = c->d_hash.ensure(hash.size())) || (rc = c->d_bids.ensure(bids.size()))) return rc;
+  MVGX_HIP(hipMemcpyAsync(c->d_hash.p, hash.data(), hash.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(c->d_bids.p, bids.data(), bids.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  return cas_build_buckets(c, bids.data(), n_desc, n_images, G, bits_per_bucket);
+}
+
+int mvgx_cascade_hash_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                              const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
+                              uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {
+  MVGX_REQUIRE(c && zero_mean && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_hash_regions: NULL argument");
+  int rc = cas_check_shape(dim, 16, n_groups, bits_per_bucket);
+  if (rc) return rc;
+  if ((rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4))) return rc;   // the descriptors, row after row, on the device
+  uint64_t rows = 0;
+  for (uint32_t k = 0; k < n_images; ++k) rows += n_desc[k];
+  const std::vector<float>& P = cas_projections(dim, n_groups, bits_per_bucket, random_seed);
+  Buf<float> d_P, d_zm;
+  if ((rc = d_P.ensure(P.size())) || (rc = d_zm.ensure(dim)) || (rc = c->d_hash.ensure((size_t)std::max<uint64_t>(rows, 1))) ||
+      (rc = c->d_bids.ensure((size_t)std::max<uint64_t>(rows, 1))))
+    return rc;
+  struct Release { Buf<float>&a, &b; ~Release() { a.release(); b.release(); } } release{d_P, d_zm};
+  MVGX_HIP(hipMemcpyAsync(d_P.p, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  MVGX_HIP(hipMemcpyAsync(d_zm.p, zero_mean, dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  std::vector<uint4> bids((size_t)std::max<uint64_t>(rows, 1)), hash;
+  if (rows) {
+    hipLaunchKernelGGL(cascade_hash_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, c->d_words.p, rows, d_zm.p, d_P.p, (int)n_groups,
+                       (int)bits_per_bucket, c->d_hash.p, c->d_bids.p);
+    MVGX_HIP(hipGetLastError());
+    MVGX_HIP(hipMemcpyAsync(bids.data(), c->d_bids.p, rows * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+    if (hash_codes_out) {
+      hash.resize(rows);
+      MVGX_HIP(hipMemcpyAsync(hash.data(), c->d_hash.p, rows * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  uint64_t at = 0;
+  for (uint32_t k = 0; k < n_images; ++k) {   // the per-descriptor outputs in the reference's shapes, on request
+    for (uint32_t r = 0; r < n_desc[k]; ++r) {
+      if (hash_codes_out && hash_codes_out[k]) memcpy(hash_codes_out[k] + (size_t)r * 16, &hash[at + r], 16);
+      if (bucket_ids_out && bucket_ids_out[k]) memcpy(bucket_ids_out[k] + (size_t)r * n_groups, &bids[at + r], n_groups * sizeof(uint16_t));
+    }
+    at += n_desc[k];
+  }
+  return cas_build_buckets(c, bids.data(), n_desc, n_images, n_groups, bits_per_bucket);
 }
 
 int mvgx_cascade_run(mvgx_cascade_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, mvgx_match_stats* stats) {

@@ -328,6 +328,83 @@ class CascadeContext(HammingContext):
         _capi.check(self._fn("set_regions")(self._h, dp, hp, bp, cnt, n, 128, 16, n_groups, bits_per_bucket))
 
 
+    def hash_regions(self, desc_list, zero_mean=None, n_groups=6, bits_per_bucket=10, random_seed=5489, fetch=False):
+        """The hashing stage on the device (mvgx_cascade_hash_regions) in place of set_regions: descriptors only; zero_mean
+        defaults to cascade_zero_mean(desc_list). fetch=True also returns (hash codes [(n, 16) uint8], bucket ids [(n, groups)
+        uint16]) per image, the shapes of the reference's HashedDescription."""
+        d = [np.ascontiguousarray(x, np.uint8).reshape(-1, 128) for x in desc_list]
+        zm = np.ascontiguousarray(cascade_zero_mean(d) if zero_mean is None else zero_mean, np.float32).reshape(128)
+        n = len(d)
+        dp = (C.c_void_p * max(n, 1))(); hp = (C.c_void_p * max(n, 1))(); bp = (C.c_void_p * max(n, 1))()
+        cnt = (C.c_uint32 * max(n, 1))()
+        h = [np.zeros((len(x), 16), np.uint8) for x in d] if fetch else None
+        b = [np.zeros((len(x), n_groups), np.uint16) for x in d] if fetch else None
+        for k in range(n):
+            dp[k] = d[k].ctypes.data if len(d[k]) else None
+            cnt[k] = len(d[k])
+            if fetch:
+                hp[k] = h[k].ctypes.data if len(d[k]) else None
+                bp[k] = b[k].ctypes.data if len(d[k]) else None
+        self._keep = (d, zm)
+        _capi.check(self._fn("hash_regions")(self._h, dp, cnt, n, 128, zm.ctypes.data, n_groups, bits_per_bucket, random_seed,
+                                             hp if fetch else None, bp if fetch else None))
+        return (h, b) if fetch else None
+
+
+def cascade_zero_mean(desc_list):
+    """The zero-mean descriptor of the reference's hashing stage (Cascade_Hashing_Matcher_Regions.cpp:78-104: the mean over the images
+    of the per-image mean, both CascadeHasher::GetZeroMeanDescriptor = cast<float>().colwise().mean()) with Eigen 3.4's operation
+    order in single precision, as an AVX build evaluates it (tests/test_cascade.py pins it against the compiled reference):
+      * per image (row-major uint8 map, cast to float: no packet access): each column is summed row after row, then divided by n;
+      * over the images (column-major MatrixXf, 32-byte aligned): each column is a contiguous run reduced by Eigen's linear vectorised
+        redux - two 8-float accumulators over the aligned part, a third packet if one is left, the horizontal sum
+        ((a0+a4)+(a2+a6))+((a1+a5)+(a3+a7)), then the leading and trailing scalars - and divided by the number of images."""
+    f32 = np.float32
+    n_img = len(desc_list)
+    per = np.zeros((n_img, 128), f32)
+    for k, d in enumerate(desc_list):
+        d = np.asarray(d, np.uint8).reshape(-1, 128)
+        if len(d) == 0:
+            continue
+        acc = d[0].astype(f32)
+        for r in range(1, len(d)):
+            acc = acc + d[r].astype(f32)   # float32 + float32: one rounding per step, per column
+        per[k] = acc / f32(len(d))
+    if n_img == 0:
+        return np.zeros(128, f32)
+    out = np.zeros(128, f32)
+    ps = 8
+    for c in range(128):
+        col = per[:, c]
+        size = n_img
+        start = min((-(c * n_img)) % ps, size)   # floats up to the next 32-byte boundary of the column-major storage
+        aligned_size2 = ((size - start) // (2 * ps)) * (2 * ps)
+        aligned_size = ((size - start) // ps) * ps
+        end2, end = start + aligned_size2, start + aligned_size
+        if aligned_size:
+            p0 = col[start:start + ps].copy()
+            if aligned_size > ps:
+                p1 = col[start + ps:start + 2 * ps].copy()
+                for i in range(start + 2 * ps, end2, 2 * ps):
+                    p0 = p0 + col[i:i + ps]
+                    p1 = p1 + col[i + ps:i + 2 * ps]
+                p0 = p0 + p1
+                if end > end2:
+                    p0 = p0 + col[end2:end2 + ps]
+            b = p0[:4] + p0[4:]
+            res = f32(f32(b[0] + b[2]) + f32(b[1] + b[3]))
+            for i in range(0, start):
+                res = f32(res + col[i])
+            for i in range(end, size):
+                res = f32(res + col[i])
+        else:
+            res = col[0]
+            for i in range(1, size):
+                res = f32(res + col[i])
+        out[c] = f32(res) / f32(n_img)
+    return out
+
+
 class Float_Regions(Regions):
     """Scalar_Regions<SIOPointFeature, float, L> stand-in (AKAZE_Float_Regions: L = 64): an (n, L) float32 array."""
 

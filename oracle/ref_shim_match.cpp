@@ -290,6 +290,23 @@ int ref_cascade_hash_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc,
   return 1;
 }
 
+// The zero-mean descriptor of the hashing stage alone (Cascade_Hashing_Matcher_Regions.cpp:78-104: the mean over the images of the
+// per-image mean, both CascadeHasher::GetZeroMeanDescriptor): 128 floats. The device hashing stage takes it as an input.
+int ref_cascade_zero_mean_u8(const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, float* out128) {
+  using BaseMat = Eigen::Matrix<unsigned char, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+  Eigen::MatrixXf per_image(n_images, 128);
+  per_image.fill(0.0f);
+  for (uint32_t k = 0; k < n_images; ++k)
+    if (n_desc[k] > 0) {
+      Eigen::Map<BaseMat> m(const_cast<unsigned char*>(desc_rows[k]), n_desc[k], 128);
+      per_image.row(k) = matching::CascadeHasher::GetZeroMeanDescriptor(m);
+    }
+  const Eigen::VectorXf zero_mean = matching::CascadeHasher::GetZeroMeanDescriptor(per_image);
+  if (zero_mean.size() != 128) return 0;
+  for (int j = 0; j < 128; ++j) out128[j] = zero_mean(j);
+  return 1;
+}
+
 // Cascade_Hashing_Matcher_Regions(dist_ratio).Match on in-memory SIFT_Regions whose features sit at feat_xy[k] (n x 2 floats:
 // the reference removes matches that repeat the same coordinates, Cascade_Hashing_Matcher_Regions.cpp:221-226). Same output
 // convention as ref_matcher_regions_match_u8.

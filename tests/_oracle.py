@@ -133,6 +133,16 @@ def ref_cascade_hash(descs, lib=None):
     return hashes, bids
 
 
+def ref_cascade_zero_mean(descs, lib=None):
+    """The reference's zero-mean descriptor of the hashing stage (128 float32). oracle/_ref only."""
+    arrs, ptrs, cnt = _desc_tables(descs)
+    out = np.zeros(128, np.float32)
+    L = lib or ref_match()
+    L.ref_cascade_zero_mean_u8.restype = C.c_int
+    assert L.ref_cascade_zero_mean_u8(ptrs, cnt, len(arrs), out.ctypes.data_as(C.c_void_p)) == 1
+    return out
+
+
 def ref_cascade_matcher_regions_match(descs, feats_xy, pairs, dist_ratio, lib=None):
     """The reference's Cascade_Hashing_Matcher_Regions(dist_ratio).Match on in-memory SIFT_Regions with the given feature
     positions. Returns {(I, J): (n, 2) uint32}. lib: the adapter build exporting the same shim."""

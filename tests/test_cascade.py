@@ -100,6 +100,71 @@ def test_emulated_device_code_equals_the_restatement():
         assert np.array_equal(finish_distinct(got[k], xy[k[0]]), v), k
 
 
+def hashed_on_device(descs, fetch=True):
+    ctx = matching.CascadeContext(0)
+    try:
+        return ctx.hash_regions(descs, fetch=fetch)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.skipif(not _oracle.have_ref_match(), reason="oracle/_ref not built")
+def test_zero_mean_restatement_equals_the_compiled_reference():
+    """matching.cascade_zero_mean (Eigen 3.4's reduction order restated in numpy float32) against the reference's
+    GetZeroMeanDescriptor chain, bit for bit, over image counts that move the 32-byte alignment of the per-image matrix' columns"""
+    from openmvg_amd import synth
+    for n_img, n_desc in [(1, 50), (2, 40), (3, 33), (7, 10), (8, 9), (9, 60), (16, 20), (17, 20), (25, 7), (33, 3), (41, 12)]:
+        descs = synth.random_descriptors(n_img, [n_desc + (k % 3) for k in range(n_img)], seed=n_img)
+        if n_img > 2:
+            descs[1] = np.zeros((0, 128), np.uint8)
+        zr = _oracle.ref_cascade_zero_mean(descs)
+        zm = matching.cascade_zero_mean(descs)
+        assert np.array_equal(zr.view(np.uint32), zm.view(np.uint32)), (n_img, n_desc)
+    descs, xy, hs, bs, pairs, ref = load("sceaux")
+    assert np.array_equal(_oracle.ref_cascade_zero_mean(descs).view(np.uint32), matching.cascade_zero_mean(descs).view(np.uint32))
+
+
+def test_emulated_hashing_stage_equals_the_stored_reference_codes():
+    """mvgx_cascade_hash_regions (projections generated like CascadeHasher::Init, Eigen's product order per descriptor) under the
+    HIP emulation: hash codes and bucket ids equal the ones the reference's CreateHashedDescriptions produced for the fixture, and
+    the lists that follow equal the ones obtained from the reference's codes"""
+    from tests import _emu
+    descs, xy, hs, bs, pairs, ref = load("synthetic")
+    with _emu.emulated():
+        h, b = hashed_on_device(descs)
+        ctx = matching.CascadeContext(0)
+        try:
+            ctx.hash_regions(descs)
+            st, off, ij = ctx.run(pairs, np.float32(0.8) * np.float32(0.8))
+        finally:
+            ctx.close()
+        st2, want = device_lists(descs, hs, bs, pairs, 0.8)
+    for k in range(len(descs)):
+        assert np.array_equal(h[k], hs[k]), k
+        assert np.array_equal(b[k], bs[k]), k
+    got = _oracle.offsets_to_dict(pairs, off, ij)
+    assert got.keys() == want.keys() and all(np.array_equal(got[k], want[k]) for k in want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["synthetic", "synthetic_grid", "sceaux"])
+def test_hashing_stage_on_the_device_equals_the_stored_reference_codes(tag):
+    descs, xy, hs, bs, pairs, ref = load(tag)
+    h, b = hashed_on_device(descs)
+    for k in range(len(descs)):
+        assert np.array_equal(h[k], hs[k]), (tag, k)
+        assert np.array_equal(b[k], bs[k]), (tag, k)
+    ctx = matching.CascadeContext(0)
+    try:
+        ctx.hash_regions(descs)
+        st, off, ij = ctx.run(pairs, np.float32(0.8) * np.float32(0.8))
+    finally:
+        ctx.close()
+    st2, want = device_lists(descs, hs, bs, pairs, 0.8)
+    got = _oracle.offsets_to_dict(pairs, off, ij)
+    assert got.keys() == want.keys() and all(np.array_equal(got[k], want[k]) for k in want)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,ratio", [("synthetic", 0.8), ("synthetic", 0.6), ("synthetic_grid", 0.8), ("sceaux", 0.8), ("sceaux", 0.6)])
 def test_device_code_equals_the_restatement_and_the_reference(tag, ratio):
