@@ -178,6 +178,7 @@ struct SpSys {
   const mvgx_sparse::GemmTask *t_tasks = nullptr, *u_tasks = nullptr;
   const mvgx_sparse::SlotPair *t_pairs = nullptr, *u_pairs = nullptr;
   const int32_t *f_cols = nullptr, *bs_start = nullptr, *bs_slot = nullptr, *bs_row = nullptr;
+  const int32_t* level_of = nullptr;  // nT: level of a tile column in the elimination tree
 };
 
 struct Dev {
@@ -1740,6 +1741,72 @@ __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
   sp_backsolve_col(s, s.f_cols[f0 + blockIdx.x], w);
 }
 
+// The top of the elimination tree is a chain - one tile column per level, each depending on all the ones above it - and its part
+// of the reverse sweep ran as one launch per column, each a series of dependent trips to L2 (column id, list bounds, (slot, row)
+// lists, tiles + z, store): ~10 us per level, 12 levels at C5. Here ONE workgroup walks the chain from the root down: the column
+// ids, list bounds, lists and rhs slots of the whole chain are fetched into LDS up front, the chain's part of the solution stays
+// in LDS, so a step is one trip to L2 for the tiles (independent of z) plus LDS work. Same arithmetic, same order as
+// sp_backsolve_col. Columns f_cols[f_lo .. f_lo + n_chain) are the columns of levels level0 .. level0 + n_chain - 1; every tile
+// below a chain column lies in a row of the chain (an ancestor).
+constexpr int kChainMax = 32, kChainEntriesMax = 1024;
+__global__ __launch_bounds__(256) void sp_backsolve_chain_kernel(SpSys s, int f_lo, int n_chain, int level0) {
+  __shared__ double zc[kChainMax][64];
+  __shared__ double w[64];
+  __shared__ int col_k[kChainMax], col_e0[kChainMax + 1], col_y[kChainMax];
+  __shared__ int e_slot[kChainEntriesMax], e_pos[kChainEntriesMax];
+  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
+  if (tid < n_chain) {
+    const int k = s.f_cols[f_lo + tid];
+    col_k[tid] = k;
+    col_y[tid] = s.tmap[(size_t)s.nT * s.nT + k];
+  }
+  __syncthreads();
+  if (tid == 0) {   // list offsets of the chain's columns inside e_slot / e_pos
+    int at = 0;
+    for (int q = 0; q < n_chain; ++q) { col_e0[q] = at; at += s.bs_start[col_k[q] + 1] - s.bs_start[col_k[q]]; }
+    col_e0[n_chain] = at;
+  }
+  __syncthreads();
+  for (int q = 0; q < n_chain; ++q) {
+    const int b0 = s.bs_start[col_k[q]], n = col_e0[q + 1] - col_e0[q];
+    for (int i = tid; i < n; i += 256) {
+      e_slot[col_e0[q] + i] = s.bs_slot[b0 + i];
+      e_pos[col_e0[q] + i] = s.level_of[s.bs_row[b0 + i]] - level0;
+    }
+  }
+  __syncthreads();
+  for (int q = n_chain - 1; q >= 0; --q) {
+    const int k = col_k[q];
+    // (issued first: neither depends on the solution of the columns above)
+    const double* __restrict__ li = s.Linv + (size_t)k * 4096 + c * 64 + part * 16;
+    double lv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) lv[j] = li[j];
+    const double yk = part == 0 ? s.L[(size_t)col_y[q] * 4096 + c * 64] : 0.0;
+    double v = 0;
+    for (int e = col_e0[q]; e < col_e0[q + 1]; ++e) {
+      const double* __restrict__ tile = s.L + (size_t)e_slot[e] * 4096 + c * 64 + part * 16;
+      const double* __restrict__ zi = &zc[e_pos[e]][part * 16];
+      double tv[16], zv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { tv[j] = tile[j]; zv[j] = zi[j]; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += tv[j] * zv[j];
+    }
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    if (part == 0) w[c] = yk - v;
+    __syncthreads();
+    double u = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u += lv[j] * w[part * 16 + j];
+    u += __shfl_xor(u, 1);
+    u += __shfl_xor(u, 2);
+    if (part == 0) { zc[q][c] = u; s.z[(size_t)k * 64 + c] = u; }
+    __syncthreads();
+  }
+}
+
 __global__ void sp_gather_solution_kernel(Dev d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.N) d.zsol[i] = d.sp.z[d.sp.pcol[i]];
@@ -2382,6 +2449,7 @@ struct mvgx_ba_ctx {
   uint32_t n_grouped_points = 0;
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
+  int bs_chain_levels = 0;   // the top levels of the elimination tree with one tile column each (sp_backsolve_chain_kernel), 0: none
   bool plan_ready = false, plan_sparse = false;   // symbolic phase of the reduced solve done (mvgx_ba_create; again at the first iteration when a communicator was attached since)
   double x_sqerr = 0;   // sum of squared residuals at x (the RMSE's numerator), kept with x_cost
   int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
@@ -2573,7 +2641,13 @@ int factor_and_solve_sparse(mvgx_ba_ctx* c) {
     if (nu) hipLaunchKernelGGL(sp_gemm_kernel<true>, dim3((nu + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.u_start[l], nu);
   }
   BA_LAUNCH_CHECK();
-  for (int l = pl.n_levels - 1; l >= 0; --l)
+  int l_top = pl.n_levels - 1;
+  if (c->bs_chain_levels >= 2) {   // the chain at the top of the tree: one workgroup, one launch
+    const int l0 = pl.n_levels - c->bs_chain_levels;
+    hipLaunchKernelGGL(sp_backsolve_chain_kernel, dim3(1), dim3(256), 0, c->stream, d.sp, pl.f_start[l0], c->bs_chain_levels, l0);
+    l_top = l0 - 1;
+  }
+  for (int l = l_top; l >= 0; --l)
     hipLaunchKernelGGL(sp_backsolve_kernel, dim3(pl.f_start[l + 1] - pl.f_start[l]), dim3(256), 0, c->stream, d.sp, pl.f_start[l]);
   hipLaunchKernelGGL(sp_gather_solution_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
@@ -2735,6 +2809,22 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
     if ((rc = dev_upload(c->pool, &bs_start, pl.bs_start, c->stream))) return rc;
     if ((rc = dev_upload(c->pool, &bs_slot, pl.bs_slot, c->stream))) return rc;
     if ((rc = dev_upload(c->pool, &bs_row, pl.bs_row, c->stream))) return rc;
+    int32_t* level_of = nullptr;
+    if ((rc = dev_upload(c->pool, &level_of, pl.level_of, c->stream))) return rc;
+    s.level_of = level_of;
+    {   // the chain at the top: as many single-column levels as the kernel's LDS tables hold (MVGX_BA_BACKSOLVE_CHAIN=0: none)
+      const char* env = getenv("MVGX_BA_BACKSOLVE_CHAIN");
+      int n = 0; size_t entries = 0;
+      if (!(env && atoi(env) == 0))
+        for (int l = pl.n_levels - 1; l >= 0 && pl.f_start[l + 1] - pl.f_start[l] == 1 && n < kChainMax; --l) {
+          const int k = pl.f_cols[pl.f_start[l]];
+          const size_t e = (size_t)(pl.bs_start[k + 1] - pl.bs_start[k]);
+          if (entries + e > (size_t)kChainEntriesMax) break;
+          entries += e; ++n;
+        }
+      c->bs_chain_levels = n;
+      if (getenv("MVGX_BA_PLAN_DEBUG")) fprintf(stderr, "[mvgx ba plan] tile columns %d, levels %d, chain at the top %d levels (%zu tiles below its columns)\n", pl.nT, pl.n_levels, n, entries);
+    }
     if ((rc = dev_upload(c->pool, &tt, pl.t_tasks, c->stream))) return rc;
     if ((rc = dev_upload(c->pool, &ut, pl.u_tasks, c->stream))) return rc;
     if ((rc = dev_upload(c->pool, &tp, pl.t_pairs, c->stream))) return rc;
