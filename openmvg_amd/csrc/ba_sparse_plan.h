@@ -35,7 +35,13 @@ struct GemmTask {   // one 16 x 16 sub-block of a tile: dst(bi, bj) (-)= sum ove
   int32_t dst;      // slot of the destination tile
   int16_t bi, bj;   // sub-block row / column (0..3)
   int32_t c0, c1;   // contributor range in the pair list
+  // A long contributor list (a border tile collects one contribution from EVERY column of a level) is cut into n_chunks tasks of
+  // at most kSplitChunk contributors; chunk tasks leave their partial sums in scratch block `scratch + chunk`, and the one that
+  // arrives last (counter `group`) adds them up in chunk order and applies them to the destination. n_chunks <= 1: an ordinary task.
+  int16_t chunk = 0, n_chunks = 0;
+  int32_t group = 0, scratch = 0;
 };
+constexpr int kSplitMin = 7, kSplitChunk = 4;   // lists of kSplitMin or more contributors are cut into chunks of kSplitChunk
 struct SlotPair { int32_t a, b; };   // T: (slot of A_ik, tile column k -> Linv_k); U: (slot of L_ik, slot of L_jk)
 
 struct PlanParams {
@@ -57,6 +63,7 @@ struct Plan {
   std::vector<int32_t> t_start, u_start;                 // [n_levels + 1]
   std::vector<SlotPair> t_pairs, u_pairs;
   std::vector<int32_t> bs_start, bs_slot, bs_row;        // per tile column: the factor tiles below it (slot, tile row)
+  int n_split_groups = 0, n_scratch_blocks = 0;          // of the U tasks with split contributor lists (GemmTask)
   uint64_t n_fill_tiles = 0;       // tiles of the factor (lower triangle incl. diagonal, without the rhs row)
   double flops = 0;                // multiply-adds x 2 of the numeric phase on the non-zero tiles
 };
@@ -368,10 +375,22 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
       const int c0 = (int)out.u_pairs.size();
       for (size_t q = a; q < b; ++q) out.u_pairs.push_back(SlotPair{contribs[q].a, contribs[q].b});
       const int c1 = (int)out.u_pairs.size();
+      const int n_c = c1 - c0;
+      const int chunks = n_c >= kSplitMin ? (n_c + kSplitChunk - 1) / kSplitChunk : 1;
       for (int bi = 0; bi < (contribs[a].rhs ? 1 : 4); ++bi)
         for (int bj = 0; bj < 4; ++bj) {
           if (contribs[a].diag && bj > bi) continue;   // lower triangle of a diagonal tile
-          out.u_tasks.push_back(GemmTask{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0, c1});
+          if (chunks == 1) {
+            out.u_tasks.push_back(GemmTask{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0, c1});
+            continue;
+          }
+          for (int ch = 0; ch < chunks; ++ch) {
+            GemmTask g{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0 + ch * kSplitChunk, std::min(c1, c0 + (ch + 1) * kSplitChunk)};
+            g.chunk = (int16_t)ch; g.n_chunks = (int16_t)chunks; g.group = out.n_split_groups; g.scratch = out.n_scratch_blocks;
+            out.u_tasks.push_back(g);
+          }
+          out.n_split_groups += 1;
+          out.n_scratch_blocks += chunks;
         }
       a = b;
     }

@@ -179,6 +179,8 @@ struct SpSys {
   const mvgx_sparse::SlotPair *t_pairs = nullptr, *u_pairs = nullptr;
   const int32_t *f_cols = nullptr, *bs_start = nullptr, *bs_slot = nullptr, *bs_row = nullptr;
   const int32_t* level_of = nullptr;  // nT: level of a tile column in the elimination tree
+  double* u_scratch = nullptr;        // partial sums of the U tasks with split contributor lists: 256 doubles per chunk
+  unsigned* u_counter = nullptr;      // arrivals per split group (left at zero by the last arrival)
 };
 
 struct Dev {
@@ -1693,6 +1695,29 @@ __device__ __forceinline__ void sp_gemm_task(const SpSys& s, int task) {   // on
       }
     }
   }
+  if constexpr (kUpdate) {
+    if (g.n_chunks > 1) {   // wave-uniform: a chunk of a long contributor list
+      double* __restrict__ part = s.u_scratch + (size_t)(g.scratch + g.chunk) * 256 + lane;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) part[reg * 64] = acc[reg];
+      __threadfence();   // the partial sums are visible device-wide before this chunk counts as arrived
+      unsigned arrived = 0;
+      if (lane == 0) arrived = atomicAdd(s.u_counter + g.group, 1u);
+      arrived = __builtin_amdgcn_readfirstlane(arrived);
+      if (arrived + 1 != (unsigned)g.n_chunks) return;
+      __threadfence();   // last arrival: the other chunks' partial sums are read from memory, in chunk order
+      double tot[4] = {0.0, 0.0, 0.0, 0.0};
+      const double* __restrict__ all = s.u_scratch + (size_t)g.scratch * 256 + lane;
+      for (int ch = 0; ch < g.n_chunks; ++ch) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) tot[reg] += __builtin_nontemporal_load(all + (size_t)ch * 256 + reg * 64);
+      }
+      if (lane == 0) s.u_counter[g.group] = 0;   // ready for the next factorisation
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = old[reg] - tot[reg];
+      return;
+    }
+  }
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = kUpdate ? old[reg] - acc[reg] : acc[reg];
 }
@@ -2784,6 +2809,16 @@ int plan_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>
     sparse = ok && (c->solver_mode == 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
     MVGX_REQUIRE(ok || c->solver_mode != 2, MVGX_ERR_UNSUPPORTED, "MVGX_BA_SOLVER=sparse: the reduced system fills too much for the task lists");
   }
+  if (sparse && getenv("MVGX_BA_PLAN_DEBUG")) {
+    const mvgx_sparse::Plan& pl = c->plan;
+    for (int l = 0; l < pl.n_levels; ++l) {
+      int longest = 0; long total = 0;
+      for (int t = pl.u_start[l]; t < pl.u_start[l + 1]; ++t) { const int n = pl.u_tasks[t].c1 - pl.u_tasks[t].c0; longest = std::max(longest, n); total += n; }
+      if (l == 0) fprintf(stderr, "[mvgx ba plan] %d U task groups with split contributor lists (%d chunks)\n", pl.n_split_groups, pl.n_scratch_blocks);
+      fprintf(stderr, "[mvgx ba plan] level %2d: %3d columns, %5d T tasks, %6d U tasks, %7ld contributions, longest list %d\n", l,
+              pl.f_start[l + 1] - pl.f_start[l], pl.t_start[l + 1] - pl.t_start[l], pl.u_start[l + 1] - pl.u_start[l], total, longest);
+    }
+  }
   c->plan_sparse = sparse;
   c->plan_ready = true;
   return MVGX_OK;
@@ -2835,6 +2870,9 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
     if ((rc = dev_alloc(c->pool, &s.L, (size_t)pl.n_slots * 4096))) return rc;
     if ((rc = dev_alloc(c->pool, &s.Linv, (size_t)pl.nT * 4096))) return rc;
     if ((rc = dev_alloc(c->pool, &s.z, (size_t)pl.nT * 64))) return rc;
+    if ((rc = dev_alloc(c->pool, &s.u_scratch, (size_t)std::max(pl.n_scratch_blocks, 1) * 256))) return rc;
+    if ((rc = dev_alloc(c->pool, &s.u_counter, (size_t)std::max(pl.n_split_groups, 1)))) return rc;
+    MVGX_HIP(hipMemsetAsync(s.u_counter, 0, (size_t)std::max(pl.n_split_groups, 1) * sizeof(unsigned), c->stream));
     // rows 1..63 of the rhs tiles and the padding are never written: zero once
     MVGX_HIP(hipMemsetAsync(s.L, 0, (size_t)pl.n_slots * 4096 * sizeof(double), c->stream));
     MVGX_HIP(hipMemsetAsync(s.z, 0, (size_t)pl.nT * 64 * sizeof(double), c->stream));

@@ -97,6 +97,7 @@ static inline double __hiloint2double(int hi, int lo) { long long b = ((long lon
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
 
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
+static inline void __threadfence() {}   // (one host thread runs the lanes: program order is memory order)
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
