@@ -6,7 +6,7 @@ from tests.test_matching_gpu import run_hip
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t0=time.time(); n_cases=0; bad=0
 pools = [list(range(0,40)), list(range(250,264)), list(range(505,522)), [767,768,769,1023,1024,1025]]
-while time.time()-t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 240:
+while time.time()-t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 240):
     k = int(rng.integers(2,5))
     sizes = [int(rng.choice(pools[int(rng.integers(0,len(pools)))])) for _ in range(k)]
     mode = int(rng.integers(0,3))
