@@ -218,6 +218,8 @@ struct Dev {
   // (pose, intrinsic) chunks that belong to it
   uint32_t *intr_pichunk_start = nullptr, *intr_pichunk = nullptr;
   double* pichunk_ipart = nullptr;   // n_pichunks x kIntrGram
+  double* intr_slice_part = nullptr; // n_intr x kIntrSlices x kIntrGram: slice sums of ba_intr_finish_kernel
+  unsigned* intr_arrivals = nullptr; // n_intr: workgroups of ba_intr_finish_kernel that have delivered their slice (left at zero)
   // pose-centre priors
   uint32_t *prior_pose = nullptr, *pose_prior_start = nullptr, *pose_prior_idx = nullptr;
   double *prior_center = nullptr, *prior_weight = nullptr, *Jprior = nullptr;
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(256) void ba_cam_gram_kernel(Dev d) {
   __shared__ __attribute__((aligned(16))) double F[256 * kGramRow];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t ch = blockIdx.x;
+  if (ch == 0 && tid == 0) *d.fail = 0;   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration)
   const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
   const uint32_t ip = d.pichunk_pose[ch], ii = d.pichunk_intr[ch];
   double pin[8], pp[6];
@@ -669,18 +672,22 @@ __global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
     if (t == tri6(c, c)) d.cn_cam[6 * i + c] = v;
 }
 
-// per intrinsic: 16 groups of threads stride its chunks, fixed-order combine
+// per intrinsic: kIntrSlices workgroups, each summing a contiguous slice of the intrinsic's chunk list (16 groups of threads stride
+// it, eight loads in flight, fixed-order combine); the workgroup that arrives last adds the slices in slice order and writes the
+// block. (One workgroup per intrinsic walked ~4 000 chunks of a shared intrinsic in 30 dependent rounds: 22 us at C3.)
+constexpr int kIntrSlices = 8;
 __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   __shared__ double sh[16][kIntrGram];
-  const uint32_t k = blockIdx.x;
+  __shared__ unsigned s_last;
+  const uint32_t k = blockIdx.x / kIntrSlices, slice = blockIdx.x % kIntrSlices;
   const int g = threadIdx.x >> 6, t = threadIdx.x & 63;
   if (t < kIntrGram) {
     double v = 0;
     {
-      // eight (index, value) loads in flight, added in list order: one at a time this was a chain of dependent round trips
-      // (73 microseconds for the 4 000 chunks of one intrinsic group)
-      const uint32_t q1 = d.intr_pichunk_start[k + 1];
-      for (uint32_t q = d.intr_pichunk_start[k] + g; q < q1; q += 128) {
+      const uint32_t q00 = d.intr_pichunk_start[k], n_all = d.intr_pichunk_start[k + 1] - q00;
+      const uint32_t per = (n_all + kIntrSlices - 1) / kIntrSlices;
+      const uint32_t q0 = q00 + min(n_all, slice * per), q1 = q00 + min(n_all, (slice + 1) * per);
+      for (uint32_t q = q0 + g; q < q1; q += 128) {
         uint32_t id[8];
         double x[8];
 #pragma unroll
@@ -694,10 +701,25 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
     sh[g][t] = v;
   }
   __syncthreads();
-  if (g != 0 || t >= kIntrGram) return;
+  if (g == 0 && t < kIntrGram) {
+    double v = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += sh[q][t];
+    d.intr_slice_part[((size_t)k * kIntrSlices + slice) * kIntrGram + t] = v;
+    __threadfence();   // the slice's sums are visible device-wide before the workgroup counts as arrived
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(d.intr_arrivals + k, 1u);
+    s_last = prev + 1 == (unsigned)kIntrSlices;
+    if (s_last) d.intr_arrivals[k] = 0;   // ready for the next evaluation
+  }
+  __syncthreads();
+  if (!s_last || g != 0 || t >= kIntrGram) return;
+  __threadfence();
   double v = 0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) v += sh[q][t];
+  for (int q = 0; q < kIntrSlices; ++q) v += __builtin_nontemporal_load(d.intr_slice_part + ((size_t)k * kIntrSlices + q) * kIntrGram + t);
   d.igram[(size_t)k * kIntrGram + t] = v;
   const int col0 = 6 * (int)d.n_poses + 8 * (int)k;
   if (t >= 36) d.g_cam[col0 + (t - 36)] = v;
@@ -2474,6 +2496,8 @@ struct mvgx_ba_ctx {
   uint32_t n_grouped_points = 0;
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
+  bool all_points_grouped = false;   // every point is in a group: the per-point kernels of the record path have nothing to do
+  bool fail_clear = false;           // the device's fail word was cleared by the last Jacobian evaluation and nothing has run since that can set it
   int bs_chain_levels = 0;   // the top levels of the elimination tree with one tile column each (sp_backsolve_chain_kernel), 0: none
   bool plan_ready = false, plan_sparse = false;   // symbolic phase of the reduced solve done (mvgx_ba_create; again at the first iteration when a communicator was attached since)
   double x_sqerr = 0;   // sum of squared residuals at x (the RMSE's numerator), kept with x_cost
@@ -2582,11 +2606,12 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<true>, dim3(1), dim3(256), 0, c->stream, d, d.poses, 0);
   BA_LAUNCH_CHECK();
   // (always: a point without observations is on neither path's lists, and its norms / factor / step must still be defined)
-  if (d.n_pts) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
-  if (d.n_pichunks) hipLaunchKernelGGL(ba_cam_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  if (d.n_pts && !c->all_points_grouped) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
+  if (d.n_pichunks) hipLaunchKernelGGL(ba_cam_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);   // (also clears the fail word)
+  c->fail_clear = d.n_pichunks != 0;
   if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
   if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
-  if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr), dim3(1024), 0, c->stream, d);
+  if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr * kIntrSlices), dim3(1024), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
   if ((rc = all_reduce(c, d.g_cam, d.N))) return rc;
@@ -2613,9 +2638,10 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
 // Partial reduced camera system of this rank at the current radius (raw sums: LM diagonal not yet added)
 int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   Dev& d = c->d;
-  MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));
+  if (!c->fail_clear) MVGX_HIP(hipMemsetAsync(d.fail, 0, sizeof(int), c->stream));   // (a step that follows a rejected one: no Jacobian evaluation in between)
+  c->fail_clear = false;
   const bool flat = !d.grp.n_sg || d.grp.n_ungrouped;   // some points are on the record-based path
-  if (d.n_pts) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
+  if (d.n_pts && !c->all_points_grouped) hipLaunchKernelGGL(ba_point_solve_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
   if (d.grp.n_sg) {
     if (d.grp.n_ungrouped)
       hipLaunchKernelGGL(ba_obs_z_kernel, dim3((d.grp.n_ungrouped + 255) / 256), dim3(256), 0, c->stream, d, d.grp.ungrouped, (uint64_t)d.grp.n_ungrouped);
@@ -3761,6 +3787,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(pichunk_part, (size_t)d.n_pichunks * kPiGram); AL(pi_gram, (size_t)d.n_pi * kPiGram); AL(pose_gram, (size_t)d.n_poses * kPoseGram);
   AL(igram, (size_t)d.n_intr * kIntrGram);
   AL(pichunk_ipart, (size_t)d.n_pichunks * kIntrGram);
+  AL(intr_slice_part, (size_t)d.n_intr * kIntrSlices * kIntrGram); AL(intr_arrivals, d.n_intr);
+  MVGX_HIP(hipMemsetAsync(d.intr_arrivals, 0, (size_t)std::max<uint32_t>(d.n_intr, 1) * sizeof(unsigned), c->stream));
   AL(Linv3, (size_t)d.n_pts * 6); AL(hp, (size_t)d.n_pts * 3);
   AL(Zpose, (size_t)nrec * 18); AL(Zint, (size_t)(record_path ? d.n_islots : 0) * 24);
   AL(zsol, d.N); AL(step_cam, d.N); AL(step_pt, (size_t)d.n_pts * 3);
@@ -3785,6 +3813,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     tick("  trip lists");
     d.grp.n_groups = n_groups; d.grp.n_sg = n_sg;
     c->n_grouped_points = (uint32_t)g_pts.size();
+    c->all_points_grouped = d.n_pts != 0 && g_pts.size() == (size_t)d.n_pts;
     if (n_sg) {
       d.grp.n_ungrouped = (uint32_t)n_ungrouped;
       if ((rc = dev_upload(c->pool, &d.grp.sg_start, sg_start, c->stream))) return rc;
