@@ -338,6 +338,7 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
   std::vector<Contrib> contribs;
   for (int l = 0; l < out.n_levels; ++l) {
     contribs.clear();
+    int level_scratch = 0;
     for (int q = out.f_start[l]; q < out.f_start[l + 1]; ++q) {
       const int k = out.f_cols[q];
       const auto& s = below[k];
@@ -377,6 +378,7 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
       const int c1 = (int)out.u_pairs.size();
       const int n_c = c1 - c0;
       const int chunks = n_c >= kSplitMin ? (n_c + kSplitChunk - 1) / kSplitChunk : 1;
+      if (chunks > 32767) return false;   // (GemmTask::n_chunks is 16 bits: a level of more than 131 000 columns - dense path)
       for (int bi = 0; bi < (contribs[a].rhs ? 1 : 4); ++bi)
         for (int bj = 0; bj < 4; ++bj) {
           if (contribs[a].diag && bj > bi) continue;   // lower triangle of a diagonal tile
@@ -386,11 +388,12 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
           }
           for (int ch = 0; ch < chunks; ++ch) {
             GemmTask g{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0 + ch * kSplitChunk, std::min(c1, c0 + (ch + 1) * kSplitChunk)};
-            g.chunk = (int16_t)ch; g.n_chunks = (int16_t)chunks; g.group = out.n_split_groups; g.scratch = out.n_scratch_blocks;
+            g.chunk = (int16_t)ch; g.n_chunks = (int16_t)chunks; g.group = out.n_split_groups; g.scratch = level_scratch;
             out.u_tasks.push_back(g);
           }
           out.n_split_groups += 1;
-          out.n_scratch_blocks += chunks;
+          level_scratch += chunks;   // (the scratch blocks of a level are free again when its update kernel has ended: levels share them)
+          out.n_scratch_blocks = std::max(out.n_scratch_blocks, level_scratch);
         }
       a = b;
     }
