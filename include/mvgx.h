@@ -381,7 +381,7 @@ int mvgx_ba_get_solver_info(mvgx_ba_ctx* ctx, mvgx_ba_solver_info* out);   /* MV
  * pair whose estimation succeeded (the reference's geometric_inliers are the putative matches with mask 1, in their order),
  * results[p]. One wave of the device runs one pair; pairs with at most 7 correspondences are rejected without estimation like the
  * reference does. Not reproduced (MVGX_ERR_UNSUPPORTED): an unbounded precision (the exhaustive NFA form), pairs with more than
- * 12 000 correspondences. Parity: same sample sequence, tables and NFA arithmetic; the minimal solver's null space is computed by
+ * 2^20 correspondences (up to 12 000 a wave's tables are in LDS, above that in global scratch). Parity: same sample sequence, tables and NFA arithmetic; the minimal solver's null space is computed by
  * elimination instead of Eigen's eigen-solver, so models agree to rounding, not bit for bit (parity policy). */
 typedef struct mvgx_geofilter_options {
   double precision;          /* GeometricFilter_FMatrix_AC::m_dPrecision, pixels (main_GeometricFilter: 4.0)  */

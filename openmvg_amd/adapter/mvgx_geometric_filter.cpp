@@ -12,7 +12,7 @@
 // occurs (the expressions of MatchesPointsToMat, Geometric_Filter_utils.cpp:33-49, once per feature on OpenMP threads), the index
 // pairs of the putative matches as the container holds them, and the image sizes of the views.
 // What the device does not reproduce is routed to the reference's own code: an unbounded precision (m_dPrecision = infinity) and
-// pairs with more than 12 000 putative matches run functor.Robust_estimation on the host, pair by pair.
+// pairs with more than 2^20 putative matches run functor.Robust_estimation on the host, pair by pair.
 #include "mvgx_geometric_filter.hpp"
 
 #include <cmath>
@@ -35,7 +35,7 @@ namespace openMVG {
 namespace matching_image_collection {
 
 namespace {
-constexpr size_t kDeviceMaxMatches = 12000;   // mvgx_geofilter_f_acransac's bound per pair
+constexpr size_t kDeviceMaxMatches = size_t(1) << 20;   // mvgx_geofilter_f_acransac's bound per pair
 
 // the reference's loop body for one pair (GeometricFilter.hpp:93-128) with the reference's own functor: the route for what the
 // device call does not cover

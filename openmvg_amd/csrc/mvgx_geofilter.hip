@@ -290,23 +290,27 @@ __global__ __launch_bounds__(256) void geofilter_normalize_indexed_kernel(const 
 
 constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (20) | the model of the current inlier list (18 words = 9 doubles at 8-byte alignment + 2)
 
-template <int WAVES>
+// kGlobalTables: the sampling pool and the two log-combinatorial tables of a wave (3 x n words) live in a global scratch block
+// instead of LDS - the class of pairs with more correspondences than a workgroup's LDS holds (one wave per workgroup; the generator,
+// the histogram and the model stay in LDS)
+template <int WAVES, bool kGlobalTables = false>
 __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
                                                                           const uint32_t* __restrict__ mt_init, uint32_t max_iterations,
-                                                                          GeoResult* __restrict__ results, uint8_t* __restrict__ mask) {
+                                                                          GeoResult* __restrict__ results, uint8_t* __restrict__ mask,
+                                                                          uint32_t* __restrict__ table_scratch = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * WAVES + wave;
   if (w >= n_work) return;   // wave-uniform; no workgroup barrier below
   const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
-  const uint32_t per_wave = kMtN + 3 * cap1 + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
+  const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
   uint32_t* const mt = lds_u32 + (size_t)wave * per_wave;
-  uint32_t* const pool = mt + kMtN;
+  uint32_t* const pool = kGlobalTables ? table_scratch + (size_t)w * 3 * cap1 : mt + kMtN;
   float* const logc_n = reinterpret_cast<float*>(pool + cap1);
   float* const logc_k = logc_n + cap1;
-  uint32_t* const hist = reinterpret_cast<uint32_t*>(logc_k + cap1);
+  uint32_t* const hist = kGlobalTables ? mt + kMtN : reinterpret_cast<uint32_t*>(logc_k + cap1);
   double* const inlF_lds = reinterpret_cast<double*>(hist + 24);   // the model behind the current inlier list / pool (rarely touched: kept out of registers)
   const uint32_t pidx = order[w];
   const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
@@ -482,6 +486,16 @@ int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_wor
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
+// the class above the LDS classes: tables in `scratch` (n_work x 3 x ((n_cap + 2) & ~1) words)
+int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
+                        const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream) {
+  if (!n_work) return MVGX_OK;
+  const size_t lds = (size_t)(kMtN + kWaveScratch) * sizeof(uint32_t);
+  hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
+                     max_it, res, mask, scratch);
+  MVGX_HIP(hipGetLastError());
+  return MVGX_OK;
+}
 
 }  // namespace
 
@@ -516,11 +530,12 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
                "reproduced on the device; main_GeometricFilter passes 4.0)");
   MVGX_REQUIRE(opt->max_iterations >= 1, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: max_iterations must be at least 1");
   constexpr uint32_t kCap0 = 256, kCap1 = 1024, kCap2 = 4096, kCap3 = 12000;   // correspondences per pair: the LDS a wave needs grows with them (4 / 4 / 2 / 1 waves per workgroup)
+  constexpr uint32_t kCapGlobal = 1u << 20;   // above kCap3 the wave's tables live in global scratch (geofilter_f_acransac_kernel<1, true>)
   for (uint64_t p = 0; p < n_pairs; ++p) {
     MVGX_REQUIRE(match_start[p + 1] >= match_start[p], MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: match_start must be non-decreasing");
-    MVGX_REQUIRE(match_start[p + 1] - match_start[p] <= kCap3, MVGX_ERR_UNSUPPORTED,
-                 "mvgx_geofilter_f_acransac: pair %llu has %llu correspondences, more than the %u one wave's LDS holds", (unsigned long long)p,
-                 (unsigned long long)(match_start[p + 1] - match_start[p]), kCap3);
+    MVGX_REQUIRE(match_start[p + 1] - match_start[p] <= kCapGlobal, MVGX_ERR_UNSUPPORTED,
+                 "mvgx_geofilter_f_acransac: pair %llu has %llu correspondences (limit %u)", (unsigned long long)p,
+                 (unsigned long long)(match_start[p + 1] - match_start[p]), kCapGlobal);
   }
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = mvgx::select_device(device < 0 ? -1 : device);
@@ -578,7 +593,9 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
   order.reserve(n_pairs);
   for (uint64_t p = 0; p < n_pairs; ++p) if (hp[p].n > (uint32_t)kMinSamples) order.push_back((uint32_t)p);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hp[a].n > hp[b].n; });
-  uint32_t c3 = 0, c2 = 0, c1 = 0;   // [0, c3): n > kCap2; [c3, c2): n > kCap1; [c2, c1): n > kCap0; the rest <= kCap0
+  uint32_t c4 = 0, c3 = 0, c2 = 0, c1 = 0;   // [0, c4): n > kCap3 (global tables); [c4, c3): n > kCap2; [c3, c2): n > kCap1; [c2, c1): n > kCap0; the rest <= kCap0
+  while (c4 < order.size() && hp[order[c4]].n > kCap3) ++c4;
+  c3 = c4;
   while (c3 < order.size() && hp[order[c3]].n > kCap2) ++c3;
   c2 = c3;
   while (c2 < order.size() && hp[order[c2]].n > kCap1) ++c2;
@@ -650,7 +667,15 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
     }
     MVGX_HIP(hipGetLastError());
   }
-  if ((rc = launch_class<1>(static_cast<GeoPair*>(d_pairs.p), ord, c3, kCap3, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
+  DevBuf d_tables;
+  if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
+    const uint32_t cap_g = hp[order[0]].n;
+    if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
+    if ((rc = launch_class_global(static_cast<GeoPair*>(d_pairs.p), ord, c4, cap_g, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
+                                  opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), static_cast<uint32_t*>(d_tables.p), stream)))
+      return rc;
+  }
+  if ((rc = launch_class<1>(static_cast<GeoPair*>(d_pairs.p), ord + c4, c3 - c4, kCap3, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
                             opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
     return rc;
   if ((rc = launch_class<2>(static_cast<GeoPair*>(d_pairs.p), ord + c3, c2 - c3, kCap2, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),

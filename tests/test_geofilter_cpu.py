@@ -107,6 +107,19 @@ def test_indexed_form_equals_the_gathered_form_under_emulation():
         assert e.value.code == _capi.MVGX_ERR_ARG
 
 
+def test_emulated_global_table_class_follows_the_restatement():
+    """a pair with more than 12 000 correspondences runs with the wave's pool and log tables in global scratch
+    (geofilter_f_acransac_kernel<1, true>); few iterations: the emulation walks 12 001 residuals per model"""
+    from openmvg_amd import synth
+    tv = synth.two_view_matches_bulk(1, n=12001, seed=77, inlier_frac=(0.5, 0.7), no_geometry_frac=0.0)
+    want = _oracle.port_geofilter(tv, max_iterations=12)
+    with _emu.emulated():
+        mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(4.0, 12))
+    ref = dict(mask=want["mask"], ok=want["ok"], F=want["F"], precision=want["precision"], nfa=want["nfa"])
+    differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert bool(res["ok"][0]) == bool(want["ok"][0]) and not differing, (rep, differing)
+
+
 def test_adapter_specialisation_fills_the_container_like_the_reference_template():
     """ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>: the same caller code linked once against
     the reference header's template and once against the explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp

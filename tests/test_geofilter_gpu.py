@@ -49,9 +49,27 @@ def test_edge_cases_and_errors():
     with pytest.raises(_capi.MvgxError) as e:
         geofilter.filter_pairs(xI, xJ, start, wh, geofilter.GeometricFilter_FMatrix_AC(float("inf"), 64))
     assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
-    big = np.zeros((12001, 2))
+    big = np.zeros(((1 << 20) + 1, 2))
     with pytest.raises(_capi.MvgxError):
-        geofilter.filter_pairs(big, big, np.array([0, 12001], np.uint64), wh[:1])
+        geofilter.filter_pairs(big, big, np.array([0, (1 << 20) + 1], np.uint64), wh[:1])
+
+
+def test_pairs_beyond_the_lds_classes_against_the_compiled_reference():
+    """more than 12 000 correspondences in a pair: the wave's sampling pool and log tables live in global scratch
+    (geofilter_f_acransac_kernel<1, true>), mixed with pairs of the LDS classes in one call"""
+    if not _oracle.have_ref_geofilter():
+        pytest.skip("oracle/_ref/libref_geofilter.so not built")
+    tvs = [synth.two_view_matches_bulk(3, n=12001, seed=41, no_geometry_frac=0.0), synth.two_view_matches_bulk(2, n=20000, seed=42, inlier_frac=(0.4, 0.6), no_geometry_frac=0.0),
+           synth.two_view_matches_bulk(4, n=300, seed=43)]
+    xI = np.concatenate([t["xI"] for t in tvs]); xJ = np.concatenate([t["xJ"] for t in tvs])
+    counts = np.concatenate([np.diff(t["start"].astype(np.int64)) for t in tvs])
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    wh = np.concatenate([t["wh"] for t in tvs])
+    tv = dict(xI=xI, xJ=xJ, start=start, wh=wh)
+    ref = _oracle.ref_geofilter(tv, 4.0, 256)
+    mask, res, st = geofilter.filter_pairs(xI, xJ, start, wh, geofilter.GeometricFilter_FMatrix_AC(4.0, 256))
+    differing, rep = gc.compare(start, ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert res["ok"][:5].all() and not differing, (rep, differing)
 
 
 def test_container_form():
