@@ -73,9 +73,10 @@ constexpr int kPiGram = 75;        // per (pose, intrinsic) pair: the 27 above |
 constexpr int kIntrGram = 44;      // per intrinsic: Fi^T Fi upper triangle (36) | Fi^T r (8)
 constexpr int kPriorJ = 21;        // per pose-centre prior: corrected r (3) | corrected d r / d pose (3 x 6)
 
-// kSCamStepSq..kSXSq are contiguous (one reduction writes all four); the camera parts are replicated on every rank, the
+// kSCamStepSq..kSModelCam are contiguous (one reduction writes all six: ba_step_scalars_kernel; kSStepSq..kSModelPt are the rank-local
+// point parts, summed over the ranks in one all-reduce); the camera parts are replicated on every rank, the
 // point parts are rank-local and summed across ranks.
-enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSGmax, kSFail, kSNobs, kSModelPt, kSModelCam, kSGmaxGrp, kSCount = 14 };
+enum Scalar { kSCost = 0, kSSqErr, kSModel, kSCamStepSq, kSCamXSq, kSStepSq, kSXSq, kSModelPt, kSModelCam, kSGmax, kSFail, kSNobs, kSGmaxGrp, kSCount = 14 };
 
 // One list of Schur products -Z_a^T Z_b, sorted by the (row block, column block) of S they add into. Entities are
 // observations (pose blocks, width 6) or (point, intrinsic) slots (intrinsic blocks, width 8).
@@ -1873,9 +1874,12 @@ __global__ __launch_bounds__(256) void sp_backsolve_chain_kernel(SpSys s, int f_
   }
 }
 
-__global__ void sp_gather_solution_kernel(Dev d) {
+__global__ void sp_gather_solution_kernel(Dev d) {   // also the camera part of the step (ba_backsub_kernel's first line: step = -solution)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < d.N) d.zsol[i] = d.sp.z[d.sp.pcol[i]];
+  if (i >= d.N) return;
+  const double z = d.sp.z[d.sp.pcol[i]];
+  d.zsol[i] = z;
+  d.step_cam[i] = d.cam_active[i] ? -z : 0.0;
 }
 
 // 32 x 32 sub-tile of D[c][r] = sum_k Q[k][c] P[k][r] on one wave: 2 x 2 MFMA blocks, MFMA row index = c, column = r.
@@ -2162,26 +2166,10 @@ __global__ __launch_bounds__(256) void ba_model_cost_kernel(Dev d, double* __res
   const double t = block_sum(v, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-// The same quantity from the normal equations, without a pass over the observations: the step solves
+// The same quantity from the normal equations, without a pass over the observations (ba_step_scalars_kernel below): the step solves
 // (Js^T Js + D^2) s = -gs exactly (direct solver), hence -(Js s)^T (r + Js s / 2) = -s^T gs - s^T Js^T Js s / 2 = (s^T D^2 s - s^T gs) / 2,
-// with gs = scale o g the gradient and D^2 = LM diagonal / radius of the scaled problem. part[2 b] = the workgroup's point
-// components (rank-local in a multi-rank run), part[2 b + 1] = its camera components (replicated).
-__global__ __launch_bounds__(256) void ba_model_cost_vec_kernel(Dev d, double inv_radius, double* __restrict__ part) {
-  __shared__ double sh[4];
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double vc = 0, vp = 0;
-  if (i < (size_t)d.N) {
-    const double s = d.step_cam[i];
-    vc = 0.5 * s * (s * d.diag_cam[i] * inv_radius - d.g_cam[i] * d.scale_cam[i]);
-  }
-  if (i < (size_t)d.n_pts * 3) {
-    const double s = d.step_pt[i];
-    vp = 0.5 * s * (s * d.diag_pt[i] * inv_radius - d.g_pt[i] * d.scale_pt[i]);
-  }
-  const double tp = block_sum(vp, sh);
-  const double tc = block_sum(vc, sh);
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = tp; part[2 * blockIdx.x + 1] = tc; }
-}
+// with gs = scale o g the gradient and D^2 = LM diagonal / radius of the scaled problem; the point components are rank-local in a
+// multi-rank run, the camera components replicated.
 // the prior rows' share of the model cost change, added onto scalars[kSModel] (one workgroup)
 __global__ __launch_bounds__(256) void ba_prior_model_kernel(Dev d) {
   __shared__ double sh[4];
@@ -2225,6 +2213,43 @@ __global__ __launch_bounds__(256) void ba_candidate_kernel(Dev d, double* __rest
   const double b = block_sum(xsq, sh);
   if (threadIdx.x == 0) {
     part[4 * blockIdx.x] = ca; part[4 * blockIdx.x + 1] = cb; part[4 * blockIdx.x + 2] = a; part[4 * blockIdx.x + 3] = b;
+  }
+}
+
+// ba_model_cost_vec_kernel and ba_candidate_kernel in one pass over the step (both read it once; as two launches with a reduction each
+// they were four launches): part[6 b + 0..3] = the candidate's sums, [4] / [5] = the point / camera parts of the model cost change
+__global__ __launch_bounds__(256) void ba_step_scalars_kernel(Dev d, double inv_radius, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double dsq = 0, xsq = 0, cdsq = 0, cxsq = 0, vc = 0, vp = 0;
+  if (i < (size_t)d.N) {
+    const int np6 = 6 * (int)d.n_poses;
+    double* x; double* cx; size_t idx;
+    if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
+    const double s = d.step_cam[i];
+    const double delta = s * d.scale_cam[i];
+    cx[idx] = x[idx] + delta;
+    cdsq = delta * delta;
+    if (d.cam_counts[i]) cxsq = x[idx] * x[idx];
+    vc = 0.5 * s * (s * d.diag_cam[i] * inv_radius - d.g_cam[i] * d.scale_cam[i]);
+  }
+  if (i < (size_t)d.n_pts * 3) {
+    const double s = d.step_pt[i];
+    const double delta = s * d.scale_pt[i];
+    d.cpts[i] = d.pts[i] + delta;
+    dsq += delta * delta;
+    if (d.scale_pt[i] != 0.0) xsq += d.pts[i] * d.pts[i];
+    vp = 0.5 * s * (s * d.diag_pt[i] * inv_radius - d.g_pt[i] * d.scale_pt[i]);
+  }
+  const double ca = block_sum(cdsq, sh);
+  const double cb = block_sum(cxsq, sh);
+  const double a = block_sum(dsq, sh);
+  const double b = block_sum(xsq, sh);
+  const double tp = block_sum(vp, sh);
+  const double tc = block_sum(vc, sh);
+  if (threadIdx.x == 0) {
+    double* o = part + 6 * (size_t)blockIdx.x;
+    o[0] = ca; o[1] = cb; o[2] = a; o[3] = b; o[4] = tp; o[5] = tc;
   }
 }
 
@@ -2955,15 +2980,17 @@ int exchange_system(mvgx_ba_ctx* c) {
 // x + delta and its cost, enqueued behind the step that produced delta WITHOUT waiting for the step's verdict: an invalid step
 // (failed factorisation, non-positive model cost change) is rare and only wastes these launches - the candidate arrays and
 // scalars they write are not read in that case - while every valid step saves one host round trip per iteration.
-int enqueue_candidate_and_cost(mvgx_ba_ctx* c) {
+int enqueue_candidate_and_cost(mvgx_ba_ctx* c, bool candidate_done) {
   Dev& d = c->d;
   phase_begin(c);
-  // the kernel writes EVERY entry of the three candidate arrays (x + 0 for constant parameters): no copy of x beforehand
-  hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 4, 4, d.scalars, kSCamStepSq, 0);
-  BA_LAUNCH_CHECK();
-  int rc = all_reduce(c, d.scalars + kSStepSq, 2);   // point parts
-  if (rc) return rc;
+  int rc;
+  if (!candidate_done) {   // (else ba_step_scalars_kernel has formed the candidate with the model cost)
+    // the kernel writes EVERY entry of the three candidate arrays (x + 0 for constant parameters): no copy of x beforehand
+    hipLaunchKernelGGL(ba_candidate_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, d.part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 4, 4, d.scalars, kSCamStepSq, 0);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, d.scalars + kSStepSq, 2))) return rc;   // point parts
+  }
   if ((rc = eval<false>(c, d.cposes, d.cintr, d.cpts))) return rc;
   phase_end(c, kPhCost);
   return MVGX_OK;
@@ -2984,7 +3011,8 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   if ((rc = factor_and_solve(c))) return rc;
   phase_end(c, kPhSolve);
   phase_begin(c);
-  hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);   // camera steps; points of the record-based path
+  if (!(d.sp.enabled && c->all_points_grouped))   // (sparse solve + every point grouped: the gather kernel has written the camera steps, no point is left for this kernel)
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);   // camera steps; points of the record-based path
   if (d.grp.n_sg) launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax);
   if (c->model_cost_from_jacobian) {   // Ceres' own form (trust_region_minimizer.cc:402-405): one more pass over the Jacobian records
     if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
@@ -2994,10 +3022,10 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     BA_LAUNCH_CHECK();
     if ((rc = all_reduce(c, d.scalars + kSModel, 1))) return rc;
   } else {
-    hipLaunchKernelGGL(ba_model_cost_vec_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, inv_radius, d.part);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 2, 2, d.scalars, kSModelPt, 0);
+    hipLaunchKernelGGL(ba_step_scalars_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, inv_radius, d.part);   // model cost + candidate
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 6, 6, d.scalars, kSCamStepSq, 0);
     BA_LAUNCH_CHECK();
-    if ((rc = all_reduce(c, d.scalars + kSModelPt, 1))) return rc;   // point parts; the camera part is the same on every rank
+    if ((rc = all_reduce(c, d.scalars + kSStepSq, 3))) return rc;   // the rank-local point parts; the camera parts are the same on every rank
   }
   if (multi_rank(c)) {   // a point block that failed to invert on one rank fails the step everywhere
     hipLaunchKernelGGL(ba_pack_fail_kernel, dim3(1), dim3(1), 0, c->stream, d);
@@ -3008,7 +3036,7 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
     if ((rc = all_reduce(c, d.scalars + kSGmaxGrp, 1, MVGX_REDUCE_MAX))) return rc;
   }
   phase_end(c, kPhBacksub);
-  if ((rc = enqueue_candidate_and_cost(c))) return rc;
+  if ((rc = enqueue_candidate_and_cost(c, !c->model_cost_from_jacobian))) return rc;
   if ((rc = read_scalars(c))) return rc;
   if (c->gmax_pending) {   // the Jacobian evaluation before this step left its max |gradient| on the device (see there)
     c->gradient_max_norm = std::max(c->h_scalars[kSGmax], c->h_scalars[kSGmaxGrp]);
@@ -3862,7 +3890,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   }
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
-  AL(part, (size_t)4 * std::max(c->grid_obs, c->grid_vec) + 16);
+  AL(part, (size_t)6 * std::max(c->grid_obs, c->grid_vec) + 16);   // up to six partial sums per workgroup (ba_step_scalars_kernel)
   AL(scalars, kSCount + 1);   // the fail word lives in the slot after the scalars: one D2H copy fetches both
   d.fail = reinterpret_cast<int*>(d.scalars + kSCount);
 #undef UP
