@@ -1015,6 +1015,14 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     ztab[j] = j < 6 * kGroupCams ? d.zsol[6 * (size_t)cams[j / 6] + j % 6]
                                  : d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[(j - 6 * kGroupCams) >> 3] + ((j - 6 * kGroupCams) & 7)];
   }
+  if (MODE == kGroupForward) {
+    // The reduced system is zeroed here, a slice per workgroup - the assemble pass that follows this kernel writes only the blocks
+    // that exist, the tiles of the fill must start at zero - instead of by a memset launch in front of this kernel.
+    double2* const z2 = reinterpret_cast<double2*>(d.sp.enabled ? d.sp.A : d.S);
+    const size_t n2 = (d.sp.enabled ? (size_t)d.sp.n_slots * 4096 : (size_t)d.N * d.LD) / 2;   // (N (N + 1) is even)
+    const size_t per = (n2 + gridDim.x - 1) / gridDim.x, lo = (size_t)sg * per, hi = lo + per < n2 ? lo + per : n2;
+    for (size_t i = lo + tid; i < hi; i += kGroupThreads) z2[i] = make_double2(0.0, 0.0);
+  }
   double gmax = 0.0;
   const bool stamping = g_group_debug && tid == 0;
   long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0;
@@ -1345,10 +1353,17 @@ __device__ __forceinline__ void schur_assemble_block(const Dev& d, const TripLis
 // pose or pose x intrinsic destinations per workgroup (one per group of 128 threads), one intrinsic x intrinsic destination per
 // workgroup (eight groups stride its thousands of partial blocks). As three launches the families ran one after the other
 // (C5 17.8 + 7.2 + 9.4 us, C3 6.3 + 5.9 + 11.5 us).
-__global__ __launch_bounds__(1024) void ba_schur_assemble_all_kernel(Dev d, uint32_t wg_pp, uint32_t wg_pi) {
+__global__ __launch_bounds__(1024) void ba_schur_assemble_all_kernel(Dev d, uint32_t wg_pp, uint32_t wg_pi, uint32_t wg_ii) {
   __shared__ double red[8][128];
   const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const uint32_t wg = blockIdx.x;
+  if (wg == wg_pp + wg_pi + wg_ii) {   // one more workgroup: max |gradient| over the supergroups of the forward pass (was a launch of its own)
+    double v = 0;
+    for (uint32_t i = threadIdx.x; i < d.grp.n_sg; i += 1024) v = fmax(v, d.grp.gmax_part[i]);
+    const double t = block_max(v, &red[0][0]);
+    if (threadIdx.x == 0) d.scalars[kSGmaxGrp] = t;
+    return;
+  }
   if (wg < wg_pp) {
     const uint32_t b = wg * 8 + grp;
     if (b < d.tpp.n_blocks) schur_assemble_block<6, 6, 0, 1>(d, d.tpp, b, e, 0, red);
@@ -2694,11 +2709,12 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
   }
   if (d.n_islots && flat) hipLaunchKernelGGL(ba_slot_z_kernel, dim3((8 * d.n_islots + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
-  if (d.sp.enabled) MVGX_HIP(hipMemsetAsync(d.sp.A, 0, (size_t)d.sp.n_slots * 4096 * sizeof(double), c->stream));
-  else MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
+  if (!d.grp.n_sg) {   // (with point groups their forward pass zeroes the system, a slice per workgroup)
+    if (d.sp.enabled) MVGX_HIP(hipMemsetAsync(d.sp.A, 0, (size_t)d.sp.n_slots * 4096 * sizeof(double), c->stream));
+    else MVGX_HIP(hipMemsetAsync(d.S, 0, (size_t)d.N * d.LD * sizeof(double), c->stream));
+  }
   if (d.grp.n_sg) {
-    launch_point_groups<kGroupForward>(c, inv_radius, c->dmin, c->dmax);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.grp.gmax_part, (int)d.grp.n_sg, 1, 1, d.scalars, kSGmaxGrp, 1);
+    launch_point_groups<kGroupForward>(c, inv_radius, c->dmin, c->dmax);   // (max |gradient| of its supergroups: reduced by the assemble launch below)
   }
   if (d.tpp.n_chunks)
     hipLaunchKernelGGL((ba_schur_products_kernel<6, 6>), dim3(8 * ((d.tpp.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tpp, d.Zpose, d.Zpose, d.hp, d.opt);
@@ -2708,8 +2724,9 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
     hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(8 * ((d.tii.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
   BA_LAUNCH_CHECK();
   {
-    const uint32_t wg_pp = (d.tpp.n_blocks + 7) / 8, wg_pi = (d.tpi.n_blocks + 7) / 8, wg_all = wg_pp + wg_pi + d.tii.n_blocks;
-    if (wg_all) hipLaunchKernelGGL(ba_schur_assemble_all_kernel, dim3(wg_all), dim3(1024), 0, c->stream, d, wg_pp, wg_pi);
+    const uint32_t wg_pp = (d.tpp.n_blocks + 7) / 8, wg_pi = (d.tpi.n_blocks + 7) / 8, wg_ii = d.tii.n_blocks;
+    const uint32_t wg_all = wg_pp + wg_pi + wg_ii + (d.grp.n_sg ? 1u : 0u);
+    if (wg_all) hipLaunchKernelGGL(ba_schur_assemble_all_kernel, dim3(wg_all), dim3(1024), 0, c->stream, d, wg_pp, wg_pi, wg_ii);
   }
   BA_LAUNCH_CHECK();
   return MVGX_OK;
