@@ -112,7 +112,10 @@ MVGX_HD void transform_point(const double* pose, const double* X, double p[3], d
 //   Ji (2 x 8, columns beyond the model's parameter count are 0), Jc (2 x 6: angle-axis | t), Jp (2 x 3).
 // Functors of sfm_data_BA_ceres_camera_functor.hpp: pinhole :103-194, radial K1 :207-300, radial K3 :313-412,
 // Brown T2 :425-545, fisheye :548-660, spherical :662-760.
-template <bool kJac>
+// kPinholeFamily: the caller guarantees model is one of pinhole / radial K1 / radial K3 / Brown T2 (the polynomial models): the
+// branches of the spherical and fisheye functors (atan2, atan, sqrt, divisions) are compiled out - in the fused point-group kernels
+// they cost registers on every problem although almost no scene uses them.
+template <bool kJac, bool kPinholeFamily = false>
 MVGX_HD void eval_observation_t(int model, const double* intr, const double* pose, const double* trig, const double* X, const double* obs,
                                 double r[2], double* Ji, double* Jc, double* Jp) {
   double p[3], R[9], A[9];
@@ -120,7 +123,7 @@ MVGX_HD void eval_observation_t(int model, const double* intr, const double* pos
   double g00, g01, g02, g10, g11, g12;   // G = d r / d p (2 x 3)
   if (kJac)
     for (int c = 0; c < 16; ++c) Ji[c] = 0.0;
-  if (model == kCamSpherical) {
+  if (!kPinholeFamily && model == kCamSpherical) {
     // lon = atan2(x, z), lat = atan2(-y, |(x, z)|); r = (lon, -lat) size / 2pi + (w, h) / 2 - obs, size = max(w, h)
     const double w = intr[0], h = intr[1];
     const double size = w > h ? w : h;
@@ -169,7 +172,7 @@ MVGX_HD void eval_observation_t(int model, const double* intr, const double* pos
           Ji[7] = f * (r2 + 2.0 * u * u);     Ji[8 + 7] = f * 2.0 * u * v;
         }
       }
-    } else if (model == kCamFisheye) {
+    } else if (!kPinholeFamily && model == kCamFisheye) {
       const double rr = sqrt(r2);
       if (rr > 1e-8) {   // else cdist = 1 (a constant in the reference's functor: zero derivative)
         const double th = atan(rr);

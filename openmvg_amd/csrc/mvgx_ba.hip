@@ -139,6 +139,12 @@ constexpr int kGroupCamRow = 6 + kPoseTrig + 6;                     // per local
 constexpr int kGroupIntrRow = 8 + 8;                              // per local intrinsic: parameters | column scales
 constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr;   // ... and the solution's components
 constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr) * (int)sizeof(uint32_t);
+// The norms and back-substitution modes never stage the matrix: their region M holds only the per-observation terms of the point
+// sums (18 x (threads + 1) doubles), which lets a third workgroup onto the CU (49 KB instead of 74 KB each).
+constexpr int kGroupMSmall = (18 * (kGroupThreads + 1) + 1) & ~1;
+constexpr int kGroupLdsSmall = kGroupLds - (kGroupM - kGroupMSmall) * (int)sizeof(double);
+template <int MODE> constexpr int group_m_doubles() { return MODE == 1 /* kGroupForward */ ? kGroupM : kGroupMSmall; }
+template <int MODE> constexpr int group_lds_bytes() { return MODE == 1 ? kGroupLds : kGroupLdsSmall; }
 constexpr int kGroupMinPts = 8;                                   // smaller groups go to the record-based path
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 enum GroupMode { kGroupNorms = 0, kGroupForward = 1, kGroupBacksub = 2 };
@@ -960,13 +966,13 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
 __device__ unsigned long long g_group_stamps[8];
 __device__ int g_group_debug;
 #define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_group_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
-template <int MODE>
+template <int MODE, bool kPinholeFamily = false>
 __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
                                                                        double* __restrict__ part_ii) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [column][kGroupRS] -> partial blocks
-  double* const sums = lds + kGroupM;             // [point][16]
+  double* const sums = lds + group_m_doubles<MODE>();   // [point][20]
   double* const ptab = sums + kGroupSums;         // [point][12]: L^-1 (6) | h (3)
   double* const ctab = ptab + kGroupPtab;         // [local pose][kGroupCamRow]: parameters | rotation terms | column scales
   double* const itab = ctab + kGroupCams * kGroupCamRow;   // [local intrinsic][kGroupIntrRow]: parameters | column scales
@@ -1075,7 +1081,7 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       for (int k = 0; k < kPoseTrig; ++k) trig[k] = crow[6 + k];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pin[k] = irow[k];
-      eval_observation_t<true>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
+      eval_observation_t<true, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
       const double sc = correct_observation(d, (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0, r);
       // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
 #pragma unroll
@@ -2555,6 +2561,7 @@ struct mvgx_ba_ctx {
   uint32_t n_grouped_points = 0;
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
+  bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
   bool all_points_grouped = false;   // every point is in a group: the per-point kernels of the record path have nothing to do
   bool fail_clear = false;           // the device's fail word was cleared by the last Jacobian evaluation and nothing has run since that can set it
   int bs_chain_levels = 0;   // the top levels of the elimination tree with one tile column each (sp_backsolve_chain_kernel), 0: none
@@ -2639,9 +2646,14 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
 template <int MODE>
 void launch_point_groups(mvgx_ba_ctx* c, double inv_radius, double dmin, double dmax) {
   Dev& d = c->d;
-  hipLaunchKernelGGL(ba_point_group_kernel<MODE>, dim3(d.grp.n_sg), dim3(kGroupThreads), kGroupLds, c->stream, d, d.grp, inv_radius, dmin, dmax,
-                     d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
-                     d.tii.part + (size_t)d.tii.n_chunks * kNVii);
+  if (c->pinhole_family)   // every intrinsic is a polynomial model: the variant without the spherical / fisheye branches
+    hipLaunchKernelGGL((ba_point_group_kernel<MODE, true>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
+                       d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
+                       d.tii.part + (size_t)d.tii.n_chunks * kNVii);
+  else
+    hipLaunchKernelGGL((ba_point_group_kernel<MODE, false>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
+                       d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
+                       d.tii.part + (size_t)d.tii.n_chunks * kNVii);
 }
 
 // TrustRegionMinimizer::EvaluateGradientAndJacobian at the current x (its cost is known: c->x_cost - the cost pass of the
@@ -3920,6 +3932,15 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupForward>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupBacksub>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupForward, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupBacksub, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+  c->pinhole_family = true;
+  for (uint32_t k = 0; k < d.n_intr; ++k) {
+    const int m = p->intr_model[k];
+    c->pinhole_family = c->pinhole_family && (m == mvgx_ba::kCamPinhole || m == mvgx_ba::kCamRadial1 || m == mvgx_ba::kCamRadial3 || m == mvgx_ba::kCamBrown);
+  }
+  if (const char* env = getenv("MVGX_BA_GENERIC_MODELS")) c->pinhole_family = c->pinhole_family && atoi(env) == 0;
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
