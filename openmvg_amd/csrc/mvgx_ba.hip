@@ -576,8 +576,11 @@ __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r 
 // drops the two rows into LDS, and each wave runs v_mfma_f64_16x16x4_f64 over its own 64 observations with lane (li, lk) feeding
 // element li of row k0 + lk as BOTH operands; the four accumulators are summed in wave order.
 constexpr int kGramRow = 34;   // doubles per staged observation (2 x 16 + pad: 16-byte aligned, conflict-free 16-byte stores)
-__global__ __launch_bounds__(256) void ba_cam_gram_kernel(Dev d) {
-  __shared__ __attribute__((aligned(16))) double F[256 * kGramRow];
+template <bool kPinholeFamily>
+__global__ __launch_bounds__(256, kPinholeFamily ? 3 : 2) void ba_cam_gram_kernel(Dev d) {
+  // a wave stages HALF of its 64 observations at a time (lanes 0..31, then 32..63): 8.7 KB of LDS per wave instead of 17.4 KB lets
+  // three workgroups share a CU (the polynomial-model variant needs 124 registers; with whole waves staged, LDS held it at two)
+  __shared__ __attribute__((aligned(16))) double F[128 * kGramRow];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t ch = blockIdx.x;
   if (ch == 0 && tid == 0) *d.fail = 0;   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration)
@@ -589,20 +592,22 @@ __global__ __launch_bounds__(256) void ba_cam_gram_kernel(Dev d) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
   const int model = d.model[ii];
+  double trig[kPoseTrig];
+  pose_trig(pp, trig);   // (the pose is the chunk's: once per thread)
   d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
   for (uint32_t base = lo; base < hi; base += 256) {
     const uint32_t e = base + tid;
-    double2* __restrict__ row = reinterpret_cast<double2*>(F + tid * kGramRow);
+    double2 rows[16];   // row 0: Fc (6) | Fi (8) | r | 0, then row 1
     if (e < hi) {
       const uint32_t ix = d.pi_pt[e];
       const double2 xy = d.pi_xy[e];
       double px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
-      eval_observation<true>(model, pin, pp, px, obs, r, Ji, Jc, Jp);
+      eval_observation_t<true, kPinholeFamily>(model, pin, pp, trig, px, obs, r, Ji, Jc, Jp);
       const double sc = correct_observation(d, (d.oweight || d.octrl) ? d.pi_obs[e] : 0, r);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {   // row h: Fc (6) | Fi (8) | r | 0
+      for (int h = 0; h < 2; ++h) {
         double v[16];
 #pragma unroll
         for (int c = 0; c < 6; ++c) v[c] = Jc[6 * h + c] * sc;
@@ -610,21 +615,30 @@ __global__ __launch_bounds__(256) void ba_cam_gram_kernel(Dev d) {
         for (int c = 0; c < 8; ++c) v[6 + c] = Ji[8 * h + c] * sc;
         v[14] = r[h]; v[15] = 0.0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) row[8 * h + c] = make_double2(v[2 * c], v[2 * c + 1]);
+        for (int c = 0; c < 8; ++c) rows[8 * h + c] = make_double2(v[2 * c], v[2 * c + 1]);
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = make_double2(0.0, 0.0);
+      for (int c = 0; c < 16; ++c) rows[c] = make_double2(0.0, 0.0);
     }
-    __syncthreads();
     const uint32_t w0 = base + 64u * wave;
     const int nw = w0 >= hi ? 0 : (int)min(64u, hi - w0);   // observations of this wave in this round
-    const double* __restrict__ src = F + (size_t)(64 * wave + (lk >> 1)) * kGramRow + 16 * (lk & 1) + li;
-    for (int ks = 0; 2 * ks < nw; ++ks) {   // k-step ks: rows of observations 2 ks (lk = 0, 1) and 2 ks + 1 (lk = 2, 3)
-      const double v = src[(size_t)(2 * ks) * kGramRow];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half) {
+        double2* __restrict__ row = reinterpret_cast<double2*>(F + (32 * wave + (lane & 31)) * kGramRow);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[c] = rows[c];
+      }
+      __syncthreads();
+      const int nh = min(32, max(0, nw - 32 * half));   // observations of this half
+      const double* __restrict__ src = F + (size_t)(32 * wave + (lk >> 1)) * kGramRow + 16 * (lk & 1) + li;
+      for (int ks = 0; 2 * ks < nh; ++ks) {   // k-step ks: rows of observations 2 ks (lk = 0, 1) and 2 ks + 1 (lk = 2, 3)
+        const double v = src[(size_t)(2 * ks) * kGramRow];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   // D[i = lk + 4 reg][j = li] of the four waves, summed in wave order
 #pragma unroll
@@ -2678,7 +2692,10 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
   BA_LAUNCH_CHECK();
   // (always: a point without observations is on neither path's lists, and its norms / factor / step must still be defined)
   if (d.n_pts && !c->all_points_grouped) hipLaunchKernelGGL(ba_point_norms_kernel, dim3((d.n_pts + 255) / 256), dim3(256), 0, c->stream, d);
-  if (d.n_pichunks) hipLaunchKernelGGL(ba_cam_gram_kernel, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);   // (also clears the fail word)
+  if (d.n_pichunks) {   // (also clears the fail word)
+    if (c->pinhole_family) hipLaunchKernelGGL(ba_cam_gram_kernel<true>, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+    else hipLaunchKernelGGL(ba_cam_gram_kernel<false>, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
+  }
   c->fail_clear = d.n_pichunks != 0;
   if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
   if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
