@@ -577,7 +577,7 @@ __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r 
 // element li of row k0 + lk as BOTH operands; the four accumulators are summed in wave order.
 constexpr int kGramRow = 34;   // doubles per staged observation (2 x 16 + pad: 16-byte aligned, conflict-free 16-byte stores)
 template <bool kPinholeFamily>
-__global__ __launch_bounds__(256, kPinholeFamily ? 3 : 2) void ba_cam_gram_kernel(Dev d) {
+__global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kernel(Dev d) {
   // a wave stages HALF of its 64 observations at a time (lanes 0..31, then 32..63): 8.7 KB of LDS per wave instead of 17.4 KB lets
   // three workgroups share a CU (the polynomial-model variant needs 124 registers; with whole waves staged, LDS held it at two)
   __shared__ __attribute__((aligned(16))) double F[128 * kGramRow];
