@@ -1,16 +1,16 @@
 #!/bin/bash
 # round 3, call 30: state-of-the-tree verification - the full GPU suite, smoke(), the driver's bench command, and the bench's main
 # pass under rocprofv3 --kernel-trace --stats (side records off) for the per-kernel summary
-mkdir -p gpurun_out/r3_30
+mkdir -p gpurun_out/${CALL_DIR:-r3_30}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=$GRAFT_REPO_ROOT/gpurun_out/r3_30
+O=$GRAFT_REPO_ROOT/gpurun_out/${CALL_DIR:-r3_30}
 R=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu_all.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest_gpu_all.log | tail -2
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 (time timeout 1500 python bench.py) > $O/bench.json 2> $O/bench.err
 python - <<'PY'
 import json, os
-O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r3_30/"
+O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/"+os.environ.get("CALL_DIR","r3_30")+"/"
 r=json.loads(open(O+"bench.json").read().strip().splitlines()[-1])
 print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['mean_launch_ms'], r['parity']['identical'])
 for k in ('ba','ba_c5_single_gpu'):
