@@ -136,7 +136,13 @@ def main():
                 selfcheck = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"ok": False, "error": r.stderr[-400:]}
             except Exception as e:
                 selfcheck = {"ok": False, "error": repr(e)}
-        dist.barrier()
+        # (the other ranks wait on the host: a barrier of the RCCL group would park a spinning kernel on every other GPU while the
+        # self-check - its own process - uses those GPUs, and would run into the group's collective timeout if the check is slow)
+        try:
+            wait_group = dist.new_group(backend="gloo")
+            dist.barrier(group=wait_group)
+        except Exception:
+            dist.barrier()
 
     ctx = matching.MatchContext(local_rank)
     if args.variant >= 0:
