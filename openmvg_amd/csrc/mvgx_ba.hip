@@ -2552,7 +2552,10 @@ struct mvgx_ba_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Dev d;
   mvgx::Arena pool;                    // every device allocation (slabs go back to the process-wide cache in destroy)
-  double* h_scalars = nullptr;         // pinned
+  double* h_scalars = nullptr;         // pinned: kSCount scalars | fail word | sequence number of the last publication
+  double* h_scalars_dev = nullptr;     // the same block as the device addresses it
+  unsigned long long publish_seq = 0;
+  bool poll_scalars = true;
   int* h_fail = nullptr;               // the slot after h_scalars
   mvgx_allreduce_f64 allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -2599,9 +2602,36 @@ namespace {
 
 #define BA_LAUNCH_CHECK() MVGX_HIP(hipGetLastError())
 
+// The scalars of a step reach the host through its page-locked, device-visible block: a one-wave kernel copies them there and then
+// raises a sequence number the host polls - the copy engine + hipStreamSynchronize pair it replaces woke the host 10 - 15 us after
+// the stream had drained (an LM iteration waits for exactly one such hand-over). MVGX_BA_POLL_SCALARS=0: the copy + synchronise form.
+__global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double* __restrict__ scalars, double* __restrict__ host, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t <= kSCount) host[t] = scalars[t];   // (the fail word rides in slot kSCount)
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) *reinterpret_cast<volatile unsigned long long*>(host + kSCount + 1) = seq;
+}
 int read_scalars(mvgx_ba_ctx* c) {
-  MVGX_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, (kSCount + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  MVGX_HIP(hipStreamSynchronize(c->stream));
+  if (!c->poll_scalars) {
+    MVGX_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, (kSCount + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MVGX_HIP(hipStreamSynchronize(c->stream));
+    return MVGX_OK;
+  }
+  const unsigned long long seq = ++c->publish_seq;
+  hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(64), 0, c->stream, c->d.scalars, c->h_scalars_dev, seq);
+  BA_LAUNCH_CHECK();
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_scalars + kSCount + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0; *flag != seq; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0xFFFFF) == 0xFFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // a failed launch / device fault: ask the runtime
+      MVGX_HIP(hipStreamSynchronize(c->stream));
+      MVGX_REQUIRE(*flag == seq, MVGX_ERR_HIP, "the scalars of the step did not reach the host");
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return MVGX_OK;
 }
 
@@ -3336,7 +3366,10 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
   tick("events");
-  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 1) * sizeof(double), hipHostMallocDefault));
+  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 2) * sizeof(double), hipHostMallocDefault));
+  memset(c->h_scalars, 0, (kSCount + 2) * sizeof(double));
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) { (void)hipGetLastError(); c->poll_scalars = false; }
+  if (const char* env = getenv("MVGX_BA_POLL_SCALARS")) c->poll_scalars = c->poll_scalars && atoi(env) != 0;
   tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;

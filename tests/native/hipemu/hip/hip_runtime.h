@@ -97,6 +97,7 @@ static inline double __hiloint2double(int hi, int lo) { long long b = ((long lon
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
 
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
+static inline void __threadfence_system() {}
 static inline void __threadfence() {}   // (one host thread runs the lanes: program order is memory order)
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p += v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p += v; return o; }
@@ -146,6 +147,7 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)64 << 30; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
