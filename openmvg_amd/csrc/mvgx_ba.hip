@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
   __shared__ __attribute__((aligned(16))) double F[128 * kGramRow];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t ch = blockIdx.x;
-  if (ch == 0 && tid == 0) *d.fail = 0;   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration)
+  if (ch == 0 && tid == 0) { *d.fail = 0; d.scalars[kSGmax] = 0.0; }   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration) and the gradient maximum ready for ba_gram_finish_kernel's atomic max
   const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
   const uint32_t ip = d.pichunk_pose[ch], ii = d.pichunk_intr[ch];
   double pin[8], pp[6];
@@ -661,46 +661,69 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
     }
   }
 }
-// per (pose, intrinsic) pair: sum of its chunks
-__global__ __launch_bounds__(128) void ba_pi_finish_kernel(Dev d) {
-  const uint32_t q = blockIdx.x;
-  const int t = threadIdx.x;
-  if (t >= kPiGram) return;
-  double v = 0;
-  for (uint32_t ch = d.pi_chunk0[q]; ch < d.pi_chunk0[q + 1]; ++ch) v += d.pichunk_part[(size_t)ch * kPiGram + t];
-  d.pi_gram[(size_t)q * kPiGram + t] = v;
+// The three finish steps of the Gram blocks in one launch (they were three, the pose step waiting for the pair step): workgroups of
+// 1 024 threads - eight (pose, intrinsic) pairs per workgroup, then 32 poses per workgroup (a pose sums its pairs' chunk partials
+// itself, pair by pair: the same sums in the same order as via pi_gram), then the slices of the intrinsics. fold_diag (one rank, not
+// iteration zero, every point grouped): the camera part of ba_lm_diag_kernel is done here as well - LM diagonal from the column
+// norms, max |gradient| into scalars[kSGmax] (cleared by the Gram kernel; one atomic max per workgroup on the bits of a non-negative
+// double: order-independent) - and that kernel and its reduction are not launched.
+constexpr int kIntrSlices = 8;   // workgroups per intrinsic in ba_gram_finish_kernel: each sums a contiguous slice of the intrinsic's chunk list
+__device__ __forceinline__ void finish_column(const Dev& d, int col, double cn, double dmin, double dmax) {
+  const double s = d.scale_cam[col];
+  d.diag_cam[col] = fmin(fmax(cn * s * s, dmin), dmax);
 }
-// per pose: sum of its (pose, intrinsic) pairs and of its pose-centre priors -> pose_gram (27), column norms, gradient
-__global__ __launch_bounds__(32) void ba_pose_finish_kernel(Dev d) {
-  const uint32_t i = blockIdx.x;
-  const int t = threadIdx.x;
-  if (t >= kPoseGram) return;
-  double v = 0;
-  for (uint32_t q = d.pose_pi_start[i]; q < d.pose_pi_start[i + 1]; ++q) v += d.pi_gram[(size_t)q * kPiGram + t];
-  if (d.n_priors) {
-    int r = 0, c = 0;   // (r, c) of upper-triangle index t < 21
-    if (t < 21) { int k = t; while (k >= 6 - r) { k -= 6 - r; ++r; } c = r + k; }
-    for (uint32_t e = d.pose_prior_start[i]; e < d.pose_prior_start[i + 1]; ++e) {
-      const double* jp = d.Jprior + (size_t)d.pose_prior_idx[e] * kPriorJ;
-      if (t < 21) { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + r] * jp[3 + k * 6 + c]; }
-      else { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + (t - 21)] * jp[k]; }
-    }
-  }
-  d.pose_gram[(size_t)i * kPoseGram + t] = v;
-  if (t >= 21) d.g_cam[6 * i + (t - 21)] = v;
-#pragma unroll
-  for (int c = 0; c < 6; ++c)
-    if (t == tri6(c, c)) d.cn_cam[6 * i + c] = v;
-}
-
-// per intrinsic: kIntrSlices workgroups, each summing a contiguous slice of the intrinsic's chunk list (16 groups of threads stride
-// it, eight loads in flight, fixed-order combine); the workgroup that arrives last adds the slices in slice order and writes the
-// block. (One workgroup per intrinsic walked ~4 000 chunks of a shared intrinsic in 30 dependent rounds: 22 us at C3.)
-constexpr int kIntrSlices = 8;
-__global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
+__global__ __launch_bounds__(1024) void ba_gram_finish_kernel(Dev d, uint32_t wg_pi, uint32_t wg_pose, int fold_diag, double dmin, double dmax) {
   __shared__ double sh[16][kIntrGram];
   __shared__ unsigned s_last;
-  const uint32_t k = blockIdx.x / kIntrSlices, slice = blockIdx.x % kIntrSlices;
+  const uint32_t wg = blockIdx.x;
+  double gm = 0.0;   // fold_diag: max |gradient| over the active camera columns this thread finishes
+  if (wg < wg_pi) {   // ---- (pose, intrinsic) pairs ----
+    const uint32_t q = wg * 8 + (threadIdx.x >> 7);
+    const int t = threadIdx.x & 127;
+    if (q < (uint32_t)d.n_pi && t < kPiGram) {
+      double v = 0;
+      for (uint32_t ch = d.pi_chunk0[q]; ch < d.pi_chunk0[q + 1]; ++ch) v += d.pichunk_part[(size_t)ch * kPiGram + t];
+      d.pi_gram[(size_t)q * kPiGram + t] = v;
+    }
+    return;
+  }
+  if (wg < wg_pi + wg_pose) {   // ---- poses ----
+    const uint32_t i = (wg - wg_pi) * 32 + (threadIdx.x >> 5);
+    const int t = threadIdx.x & 31;
+    if (i < d.n_poses && t < kPoseGram) {
+      double v = 0;
+      for (uint32_t q = d.pose_pi_start[i]; q < d.pose_pi_start[i + 1]; ++q) {
+        double w = 0;
+        for (uint32_t ch = d.pi_chunk0[q]; ch < d.pi_chunk0[q + 1]; ++ch) w += d.pichunk_part[(size_t)ch * kPiGram + t];
+        v += w;
+      }
+      if (d.n_priors) {
+        int r = 0, c = 0;   // (r, c) of upper-triangle index t < 21
+        if (t < 21) { int k = t; while (k >= 6 - r) { k -= 6 - r; ++r; } c = r + k; }
+        for (uint32_t e = d.pose_prior_start[i]; e < d.pose_prior_start[i + 1]; ++e) {
+          const double* jp = d.Jprior + (size_t)d.pose_prior_idx[e] * kPriorJ;
+          if (t < 21) { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + r] * jp[3 + k * 6 + c]; }
+          else { for (int k = 0; k < 3; ++k) v += jp[3 + k * 6 + (t - 21)] * jp[k]; }
+        }
+      }
+      d.pose_gram[(size_t)i * kPoseGram + t] = v;
+      if (t >= 21) {
+        d.g_cam[6 * i + (t - 21)] = v;
+        if (fold_diag && d.cam_active[6 * i + (t - 21)]) gm = fabs(v);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        if (t == tri6(c, c)) { d.cn_cam[6 * i + c] = v; if (fold_diag) finish_column(d, 6 * (int)i + c, v, dmin, dmax); }
+    }
+    if (fold_diag) {
+      const double m = block_max(gm, &sh[0][0]);
+      if (threadIdx.x == 0 && m > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(d.scalars + kSGmax), (unsigned long long)__double_as_longlong(m));
+    }
+    return;
+  }
+  // ---- intrinsics: kIntrSlices workgroups each, the last arrival combines the slices ----
+  const uint32_t wi = wg - wg_pi - wg_pose;
+  const uint32_t k = wi / kIntrSlices, slice = wi % kIntrSlices;
   const int g = threadIdx.x >> 6, t = threadIdx.x & 63;
   if (t < kIntrGram) {
     double v = 0;
@@ -743,10 +766,15 @@ __global__ __launch_bounds__(1024) void ba_intr_finish_kernel(Dev d) {
   for (int q = 0; q < kIntrSlices; ++q) v += __builtin_nontemporal_load(d.intr_slice_part + ((size_t)k * kIntrSlices + q) * kIntrGram + t);
   d.igram[(size_t)k * kIntrGram + t] = v;
   const int col0 = 6 * (int)d.n_poses + 8 * (int)k;
-  if (t >= 36) d.g_cam[col0 + (t - 36)] = v;
+  if (t >= 36) {
+    d.g_cam[col0 + (t - 36)] = v;
+    // (one wave finishes an intrinsic: its eight gradient entries go to the maximum one by one)
+    if (fold_diag && d.cam_active[col0 + (t - 36)] && v != 0.0)
+      atomicMax(reinterpret_cast<unsigned long long*>(d.scalars + kSGmax), (unsigned long long)__double_as_longlong(fabs(v)));
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c)
-    if (t == tri8(c, c)) d.cn_cam[col0 + c] = v;
+    if (t == tri8(c, c)) { d.cn_cam[col0 + c] = v; if (fold_diag) finish_column(d, col0 + c, v, dmin, dmax); }
 }
 
 // jacobian_scaling_ = 1 / (1 + sqrt(|col|^2)) at iteration 0 (trust_region_minimizer.cc:239-254); 0 for inactive columns
@@ -2727,9 +2755,14 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
     else hipLaunchKernelGGL(ba_cam_gram_kernel<false>, dim3(d.n_pichunks), dim3(256), 0, c->stream, d);
   }
   c->fail_clear = d.n_pichunks != 0;
-  if (d.n_pi) hipLaunchKernelGGL(ba_pi_finish_kernel, dim3(d.n_pi), dim3(128), 0, c->stream, d);
-  if (d.n_poses) hipLaunchKernelGGL(ba_pose_finish_kernel, dim3(d.n_poses), dim3(32), 0, c->stream, d);
-  if (d.n_intr) hipLaunchKernelGGL(ba_intr_finish_kernel, dim3(d.n_intr * kIntrSlices), dim3(1024), 0, c->stream, d);
+  c->dmin = opt->min_lm_diagonal; c->dmax = opt->max_lm_diagonal;
+  // (one rank, not iteration zero, every point grouped: the finish launch also forms the LM diagonal and the gradient maximum of
+  // the camera columns - there is nothing else for ba_lm_diag_kernel to do)
+  const bool fold_diag = !iteration_zero && !multi_rank(c) && c->all_points_grouped && d.n_pichunks != 0;
+  {
+    const uint32_t wg_pi = ((uint32_t)d.n_pi + 7) / 8, wg_pose = (d.n_poses + 31) / 32, wg_all = wg_pi + wg_pose + d.n_intr * kIntrSlices;
+    if (wg_all) hipLaunchKernelGGL(ba_gram_finish_kernel, dim3(wg_all), dim3(1024), 0, c->stream, d, wg_pi, wg_pose, fold_diag ? 1 : 0, c->dmin, c->dmax);
+  }
   BA_LAUNCH_CHECK();
   if ((rc = all_reduce(c, d.cn_cam, d.N))) return rc;
   if ((rc = all_reduce(c, d.g_cam, d.N))) return rc;
@@ -2738,11 +2771,12 @@ int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, b
     hipLaunchKernelGGL(ba_make_scaling_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, opt->jacobi_scaling);
     BA_LAUNCH_CHECK();
   }
-  c->dmin = opt->min_lm_diagonal; c->dmax = opt->max_lm_diagonal;
-  hipLaunchKernelGGL(ba_lm_diag_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, opt->min_lm_diagonal,
-                     opt->max_lm_diagonal, d.part, iteration_zero ? 0 : 1);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 1, 1, d.scalars, kSGmax, 1);
-  BA_LAUNCH_CHECK();
+  if (!fold_diag) {
+    hipLaunchKernelGGL(ba_lm_diag_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d, opt->min_lm_diagonal,
+                       opt->max_lm_diagonal, d.part, iteration_zero ? 0 : 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, c->grid_vec, 1, 1, d.scalars, kSGmax, 1);
+    BA_LAUNCH_CHECK();
+  }
   if ((rc = all_reduce(c, d.scalars + kSGmax, 1, MVGX_REDUCE_MAX))) return rc;   // point gradients are rank-local
   phase_end(c, kPhJacobian);
   c->gmax_pending = !iteration_zero;
