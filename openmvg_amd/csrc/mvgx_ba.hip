@@ -130,14 +130,16 @@ constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves
 constexpr int kGroupRS = 3 * kGroupPts + 2;                       // doubles between columns in LDS, = 2 x odd (mod 32): the 16 columns x 2 rows a
                                                                   // half wave reads as an MFMA operand then fall on distinct banks
 static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255 && kGroupIntr == 2, "group tile layout (the slot ranges assume two local intrinsics)");
-static_assert(kGroupThreads >= 128 + 6 * kGroupCams + 8 * kGroupIntr, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128..");
+static_assert(224 >= 128 + 6 * kGroupCams + 8 * kGroupIntr && kGroupThreads >= 224 + 8 * kGroupIntr, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128.., 224..");
 constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
 constexpr int kGroupM = kGroupCols * kGroupRS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
 static_assert(kGroupM >= 24 * (kGroupThreads + 1) && kGroupM >= kGroupOut && kGroupM >= 3 * (kGroupThreads + 1) + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
 constexpr int kGroupSums = kGroupPts * 20, kGroupPtab = kGroupPts * 12;
 constexpr int kGroupCamRow = 6 + kPoseTrig + 6;                     // per local pose: parameters | rotation terms | column scales
 constexpr int kGroupIntrRow = 8 + 8;                              // per local intrinsic: parameters | column scales
-constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr;   // ... and the solution's components
+constexpr int kGroupCandRow = 6 + kPoseTrig;                       // per local pose of the candidate x + delta: parameters | rotation terms
+constexpr int kGroupCand = kGroupCams * kGroupCandRow + kGroupIntr * 8 + 3 * kGroupPts;   // back-substitution with the candidate's cost: the candidate's cameras, the point threads' running sums
+constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr + kGroupCand;   // ... the solution's components, the candidate
 constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr) * (int)sizeof(uint32_t);
 // The norms and back-substitution modes never stage the matrix: their region M holds only the per-observation terms of the point
 // sums (18 x (threads + 1) doubles), which lets a third workgroup onto the CU (49 KB instead of 74 KB each).
@@ -251,6 +253,7 @@ struct Dev {
   double* linv = nullptr;             // per Cholesky block step: L11^-1 k-major (64 x 64), then row-major (64 x 64)
   double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
   double* part = nullptr;             // partial sums (reductions)
+  double* grp_part = nullptr;         // n_sg x 5: the supergroups' sums of the back-substitution pass with the candidate (ba_step_reduce_kernel)
   double* scalars = nullptr;          // kSCount
   int* fail = nullptr;
 };
@@ -1009,9 +1012,9 @@ __device__ unsigned long long g_group_stamps[8];
 __device__ int g_group_debug;
 #define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_group_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
 template <int MODE, bool kPinholeFamily = false>
-__global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
+__global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (MODE == 2 && !kPinholeFamily)) ? 2 : 3) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
-                                                                       double* __restrict__ part_ii) {
+                                                                       double* __restrict__ part_ii, double* __restrict__ cand_part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [column][kGroupRS] -> partial blocks
   double* const sums = lds + group_m_doubles<MODE>();   // [point][20]
@@ -1019,7 +1022,15 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
   double* const ctab = ptab + kGroupPtab;         // [local pose][kGroupCamRow]: parameters | rotation terms | column scales
   double* const itab = ctab + kGroupCams * kGroupCamRow;   // [local intrinsic][kGroupIntrRow]: parameters | column scales
   double* const ztab = itab + kGroupIntr * kGroupIntrRow;  // back-substitution: the reduced solution at the group's columns (the staged matrix's column order)
-  uint32_t* const ek = reinterpret_cast<uint32_t*>(ztab + 6 * kGroupCams + 8 * kGroupIntr);   // [thread]: entry word of the observation
+  double* const ccand = ztab + 6 * kGroupCams + 8 * kGroupIntr;   // back-substitution + candidate: [local pose][kGroupCandRow] | [local intrinsic][8] of x + delta
+  uint32_t* const ek = reinterpret_cast<uint32_t*>(ccand + kGroupCand);   // [thread]: entry word of the observation
+  // kGroupBacksub with cand_part: the pass also forms the candidate x + delta of its points and the candidate's cost over its
+  // observations (the cameras of x + delta are in d.cposes / d.cintr already), and what ba_step_scalars_kernel sums over the points -
+  // five partial sums per supergroup; the observations are then not visited a fourth time in the iteration (ba_linearize_kernel<false>).
+  const bool with_cand = MODE == kGroupBacksub && cand_part != nullptr;
+  double c_cost = 0.0, c_sq = 0.0;
+  double* const pacc = ccand + kGroupCams * kGroupCandRow + kGroupIntr * 8;   // [3][point thread]: |delta|^2, |x|^2, model cost terms (in LDS: registers are what this mode is short of)
+  if (with_cand && threadIdx.x < 3 * kGroupPts) pacc[threadIdx.x] = 0.0;
   uint32_t* const pe = ek + kGroupThreads;        // [point + 1]: first entry (group-relative)
   uint32_t* const pks = pe + kGroupPts + 1;       // [point]: first entry of the point's observations with local intrinsic 1
   int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
@@ -1053,6 +1064,16 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     for (int k = 0; k < 6; ++k) { row[k] = pp[k]; row[6 + kPoseTrig + k] = d.scale_cam[6 * (size_t)ip + k]; }
 #pragma unroll
     for (int k = 0; k < kPoseTrig; ++k) row[6 + k] = trig[k];
+    if (with_cand) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pp[k] = d.cposes[(size_t)ip * 6 + k];
+      pose_trig(pp, trig);
+      double* __restrict__ crow2 = ccand + tid * kGroupCandRow;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) crow2[k] = pp[k];
+#pragma unroll
+      for (int k = 0; k < kPoseTrig; ++k) crow2[6 + k] = trig[k];
+    }
   } else if (tid >= 64 && tid < 64 + kGroupIntr * kGroupIntrRow) {
     const int k = (tid - 64) / kGroupIntrRow, j = (tid - 64) - k * kGroupIntrRow;
     const uint32_t ii = intrs[k];
@@ -1062,6 +1083,9 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
     const int j = tid - 128;
     ztab[j] = j < 6 * kGroupCams ? d.zsol[6 * (size_t)cams[j / 6] + j % 6]
                                  : d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[(j - 6 * kGroupCams) >> 3] + ((j - 6 * kGroupCams) & 7)];
+  } else if (with_cand && tid >= 224 && tid < 224 + 8 * kGroupIntr) {
+    const int j = tid - 224;
+    ccand[kGroupCams * kGroupCandRow + j] = d.cintr[(size_t)intrs[j >> 3] * 8 + (j & 7)];
   }
   if (MODE == kGroupForward) {
     // The reduced system is zeroed here, a slice per workgroup - the assemble pass that follows this kernel writes only the blocks
@@ -1115,6 +1139,10 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       double pin[8], pp[6], trig[kPoseTrig], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+      if (with_cand) {   // the point thread takes x from here (every observation of the point writes the same three values)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ptab[q * 12 + 9 + k] = px[k];
+      }
       const double* __restrict__ crow = ctab + x * kGroupCamRow;
       const double* __restrict__ irow = itab + kk * kGroupIntrRow;
 #pragma unroll
@@ -1205,9 +1233,24 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
           const double t0 = pt[6] - li6[0] * sm[15];
           const double t1 = pt[7] - (li6[1] * sm[15] + li6[2] * sm[16]);
           const double t2 = pt[8] - (li6[3] * sm[15] + li6[4] * sm[16] + li6[5] * sm[17]);
-          d.step_pt[(size_t)p * 3 + 0] = -(li6[0] * t0 + li6[1] * t1 + li6[3] * t2);
-          d.step_pt[(size_t)p * 3 + 1] = -(li6[2] * t1 + li6[4] * t2);
-          d.step_pt[(size_t)p * 3 + 2] = -(li6[5] * t2);
+          const double st[3] = {-(li6[0] * t0 + li6[1] * t1 + li6[3] * t2), -(li6[2] * t1 + li6[4] * t2), -(li6[5] * t2)};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) d.step_pt[(size_t)p * 3 + c] = st[c];
+          if (with_cand) {   // the point of x + delta; its terms of |delta|^2, |x|^2 and of the model cost change (as ba_step_scalars_kernel forms them)
+            double c_dsq = pacc[tid], c_xsq = pacc[kGroupPts + tid], c_vp = pacc[2 * kGroupPts + tid];
+            const double my_px[3] = {pt[9], pt[10], pt[11]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const double delta = st[c] * my_sp[c];
+              const double cp = my_px[c] + delta;
+              d.cpts[(size_t)p * 3 + c] = cp;
+              pt[9 + c] = cp;
+              c_dsq += delta * delta;
+              if (my_sp[c] != 0.0) c_xsq += my_px[c] * my_px[c];
+              c_vp += 0.5 * st[c] * (st[c] * dg[c] * inv_radius - sm[12 + c] * my_sp[c]);
+            }
+            pacc[tid] = c_dsq; pacc[kGroupPts + tid] = c_xsq; pacc[2 * kGroupPts + tid] = c_vp;
+          }
         }
         if (MODE == kGroupForward) {
 #pragma unroll
@@ -1219,6 +1262,34 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       }
     }
     MVGX_GSTAMP(2);
+    if (with_cand) {   // (uniform) the observation of this thread at x + delta: cost terms only
+      __syncthreads();
+      if (has) {
+        const int kk = (int)((qxk >> 12) & 15u);
+        double pin[8], pp[6], trig[kPoseTrig], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
+        const double* __restrict__ crow2 = ccand + x * kGroupCandRow;
+        const double* __restrict__ irow2 = ccand + kGroupCams * kGroupCandRow + kk * 8;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) px[k] = ptab[q * 12 + 9 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pp[k] = crow2[k];
+#pragma unroll
+        for (int k = 0; k < kPoseTrig; ++k) trig[k] = crow2[6 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pin[k] = irow2[k];
+        eval_observation_t<false, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
+        const uint64_t o = (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0;
+        double w = 1.0;
+        if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
+        const bool ctrl = d.octrl && d.octrl[o];
+        r[0] *= w; r[1] *= w;
+        const double s2 = r[0] * r[0] + r[1] * r[1];
+        double rho[3];
+        huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s2, rho);
+        c_cost += 0.5 * rho[0];
+        c_sq += ctrl ? 0.0 : s2;
+      }
+    }
     if (MODE != kGroupForward) continue;
     // ---- 4. intrinsic slots: Zint[q][k][:, c] = L_q^-1 sum over the point's observations with local intrinsic k of Es^T Fi_s[:, c] ----
     // (the sums of step 2 have been read: the terms of this step may replace them)
@@ -1293,6 +1364,13 @@ __global__ __launch_bounds__(kGroupThreads, 2) void ba_point_group_kernel(Dev d,
       }
     }
     MVGX_GSTAMP(6);
+  }
+  if (with_cand) {   // (uniform) the supergroup's five sums, in wave order
+    __syncthreads();
+    const bool ptt = tid < kGroupPts;
+    const double v0 = block_sum(c_cost, sums), v1 = block_sum(c_sq, sums), v2 = block_sum(ptt ? pacc[tid] : 0.0, sums),
+                 v3 = block_sum(ptt ? pacc[kGroupPts + tid] : 0.0, sums), v4 = block_sum(ptt ? pacc[2 * kGroupPts + tid] : 0.0, sums);
+    if (tid == 0) { double* o = cand_part + 5 * (size_t)sg; o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; }
   }
   if (MODE != kGroupForward) return;
   // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
@@ -2316,6 +2394,56 @@ __global__ __launch_bounds__(256) void ba_step_scalars_kernel(Dev d, double inv_
   }
 }
 
+// The camera half of ba_step_scalars_kernel alone (the candidate's poses and intrinsics, |delta|^2, |x|^2 and the model cost change of
+// the camera columns: part[3 b + 0..2]) - run BEFORE the back-substitution of the point groups when that pass forms the points'
+// half and the candidate's cost itself (it reads the candidate's cameras).
+__global__ __launch_bounds__(256) void ba_step_scalars_cam_kernel(Dev d, double inv_radius, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double cdsq = 0, cxsq = 0, vc = 0;
+  if (i < (size_t)d.N) {
+    const int np6 = 6 * (int)d.n_poses;
+    double* x; double* cx; size_t idx;
+    if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
+    const double s = d.step_cam[i];
+    const double delta = s * d.scale_cam[i];
+    cx[idx] = x[idx] + delta;
+    cdsq = delta * delta;
+    if (d.cam_counts[i]) cxsq = x[idx] * x[idx];
+    vc = 0.5 * s * (s * d.diag_cam[i] * inv_radius - d.g_cam[i] * d.scale_cam[i]);
+  }
+  const double ca = block_sum(cdsq, sh);
+  const double cb = block_sum(cxsq, sh);
+  const double tc = block_sum(vc, sh);
+  if (threadIdx.x == 0) { double* o = part + 3 * (size_t)blockIdx.x; o[0] = ca; o[1] = cb; o[2] = tc; }
+}
+// The eight sums of a step whose back-substitution formed the candidate: one workgroup per sum (all at once instead of one after the
+// other), rows in index order as reduce_partials_kernel takes them. cam_part: n_cam x 3 (ba_step_scalars_cam_kernel), grp_part: n_sg x 5.
+__global__ __launch_bounds__(1024) void ba_step_reduce_kernel(const double* __restrict__ cam_part, int n_cam, const double* __restrict__ grp_part, int n_sg,
+                                                              double* __restrict__ scalars) {
+  __shared__ double sh[16];
+  // sum -> (source, column, scalar)
+  const int k = blockIdx.x;
+  const bool cam = k >= 5;
+  const int col = cam ? k - 5 : k;
+  const int dst = cam ? (col == 0 ? kSCamStepSq : col == 1 ? kSCamXSq : kSModelCam)
+                      : (col == 0 ? kSCost : col == 1 ? kSSqErr : col == 2 ? kSStepSq : col == 3 ? kSXSq : kSModelPt);
+  const double* __restrict__ part = cam ? cam_part : grp_part;
+  const int n = cam ? n_cam : n_sg, stride = cam ? 3 : 5;
+  double v = 0;
+  int i = (int)threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    double t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = part[(size_t)(i + q * 1024) * stride + col];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += t[q];
+  }
+  for (; i < n; i += 1024) v += part[(size_t)i * stride + col];
+  const double t = block_sum(v, sh);
+  if (threadIdx.x == 0) scalars[dst] = t;
+}
+
 // ---- host side of the assembly: product lists sorted by destination block ----
 struct TripHost {
   std::vector<uint2> trips;
@@ -2607,6 +2735,7 @@ struct mvgx_ba_ctx {
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
+  bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
   bool all_points_grouped = false;   // every point is in a group: the per-point kernels of the record path have nothing to do
   bool fail_clear = false;           // the device's fail word was cleared by the last Jacobian evaluation and nothing has run since that can set it
   int bs_chain_levels = 0;   // the top levels of the elimination tree with one tile column each (sp_backsolve_chain_kernel), 0: none
@@ -2716,16 +2845,16 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
 
 // launch of the fused point-group pass in one of its three modes
 template <int MODE>
-void launch_point_groups(mvgx_ba_ctx* c, double inv_radius, double dmin, double dmax) {
+void launch_point_groups(mvgx_ba_ctx* c, double inv_radius, double dmin, double dmax, double* cand_part = nullptr) {
   Dev& d = c->d;
   if (c->pinhole_family)   // every intrinsic is a polynomial model: the variant without the spherical / fisheye branches
     hipLaunchKernelGGL((ba_point_group_kernel<MODE, true>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
                        d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
-                       d.tii.part + (size_t)d.tii.n_chunks * kNVii);
+                       d.tii.part + (size_t)d.tii.n_chunks * kNVii, cand_part);
   else
     hipLaunchKernelGGL((ba_point_group_kernel<MODE, false>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
                        d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
-                       d.tii.part + (size_t)d.tii.n_chunks * kNVii);
+                       d.tii.part + (size_t)d.tii.n_chunks * kNVii, cand_part);
 }
 
 // TrustRegionMinimizer::EvaluateGradientAndJacobian at the current x (its cost is known: c->x_cost - the cost pass of the
@@ -3092,6 +3221,7 @@ int exchange_system(mvgx_ba_ctx* c) {
 // scalars they write are not read in that case - while every valid step saves one host round trip per iteration.
 int enqueue_candidate_and_cost(mvgx_ba_ctx* c, bool candidate_done) {
   Dev& d = c->d;
+  if (c->candidate_cost_done) return all_reduce(c, d.scalars + kSCost, 2);   // (the back-substitution pass has formed both)
   phase_begin(c);
   int rc;
   if (!candidate_done) {   // (else ba_step_scalars_kernel has formed the candidate with the model cost)
@@ -3123,8 +3253,21 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   phase_begin(c);
   if (!(d.sp.enabled && c->all_points_grouped))   // (sparse solve + every point grouped: the gather kernel has written the camera steps, no point is left for this kernel)
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);   // camera steps; points of the record-based path
-  if (d.grp.n_sg) launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax);
-  if (c->model_cost_from_jacobian) {   // Ceres' own form (trust_region_minimizer.cc:402-405): one more pass over the Jacobian records
+  // every point grouped: the back-substitution pass forms the candidate x + delta and its cost on the way (one pass over the
+  // observations less per iteration); the camera half of the step's sums runs in front of it (MVGX_BA_SEPARATE_COST=1: the passes of old)
+  const bool fold_cand = c->fold_candidate && c->all_points_grouped && d.grp.n_sg && !c->model_cost_from_jacobian;
+  c->candidate_cost_done = fold_cand;
+  if (fold_cand) {
+    const int n_cam_wg = (d.N + 255) / 256;
+    hipLaunchKernelGGL(ba_step_scalars_cam_kernel, dim3(n_cam_wg), dim3(256), 0, c->stream, d, inv_radius, d.part);
+    launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax, d.grp_part);
+    hipLaunchKernelGGL(ba_step_reduce_kernel, dim3(8), dim3(1024), 0, c->stream, d.part, n_cam_wg, d.grp_part, (int)d.grp.n_sg, d.scalars);
+    if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<false>, dim3(1), dim3(256), 0, c->stream, d, d.cposes, 1);
+    BA_LAUNCH_CHECK();
+    if ((rc = all_reduce(c, d.scalars + kSStepSq, 3))) return rc;   // (the cost's all-reduce: where the separate cost pass has it - ranks may differ in fold_cand)
+  } else if (d.grp.n_sg) launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax);
+  if (fold_cand) {
+  } else if (c->model_cost_from_jacobian) {   // Ceres' own form (trust_region_minimizer.cc:402-405): one more pass over the Jacobian records
     if (d.n_obs) hipLaunchKernelGGL(ba_model_cost_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.part);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, c->stream, d.part, d.n_obs ? c->grid_obs : 0, 1, 1, d.scalars,
                        kSModel, 0);
@@ -3404,6 +3547,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   memset(c->h_scalars, 0, (kSCount + 2) * sizeof(double));
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) { (void)hipGetLastError(); c->poll_scalars = false; }
   if (const char* env = getenv("MVGX_BA_POLL_SCALARS")) c->poll_scalars = c->poll_scalars && atoi(env) != 0;
+  if (const char* env = getenv("MVGX_BA_SEPARATE_COST")) c->fold_candidate = atoi(env) == 0;
   tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
@@ -4004,6 +4148,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   c->grid_obs = (int)std::max<uint64_t>(1, (no + 255) / 256);
   c->grid_vec = (int)std::max<size_t>(1, (std::max<size_t>((size_t)d.N, (size_t)d.n_pts * 3) + 255) / 256);
   AL(part, (size_t)6 * std::max(c->grid_obs, c->grid_vec) + 16);   // up to six partial sums per workgroup (ba_step_scalars_kernel)
+  AL(grp_part, (size_t)5 * d.grp.n_sg + 8);
   AL(scalars, kSCount + 1);   // the fail word lives in the slot after the scalars: one D2H copy fetches both
   d.fail = reinterpret_cast<int*>(d.scalars + kSCount);
 #undef UP
