@@ -252,6 +252,7 @@ struct Dev {
   double* packed = nullptr;
   double* linv = nullptr;             // per Cholesky block step: L11^-1 k-major (64 x 64), then row-major (64 x 64)
   double *zsol = nullptr, *step_cam = nullptr, *step_pt = nullptr;
+  double asm_inv_radius = 0.0;        // != 0: the assemble launch also applies the LM diagonal (ba_finish_system_kernel's work), with this 1 / radius
   double* part = nullptr;             // partial sums (reductions)
   double* grp_part = nullptr;         // n_sg x 5: the supergroups' sums of the back-substitution pass with the candidate (ba_step_reduce_kernel)
   double* scalars = nullptr;          // kSCount
@@ -1467,11 +1468,17 @@ __device__ __forceinline__ void schur_assemble_block(const Dev& d, const TripLis
       if (diag) own = d.igram[(size_t)(rcb - np) * kIntrGram + tri8(lo, hi)];
     }
     if (diag && r > c) return;   // the upper triangle of a diagonal block is the whole block (sparse mode: one home per element)
-    *sys_elem(d, row0 + r, col0 + c) = own * d.scale_cam[row0 + r] * d.scale_cam[col0 + c] - sum;
+    double val = own * d.scale_cam[row0 + r] * d.scale_cam[col0 + c] - sum;
+    // asm_inv_radius != 0: ba_finish_system_kernel's work here (one rank, every camera block has its diagonal destination) -
+    // S_jj += diag_j / radius for free components, a unit diagonal for constant / unused ones
+    if (d.asm_inv_radius != 0.0 && diag && r == c) val = d.cam_active[row0 + r] ? val + d.diag_cam[row0 + r] * d.asm_inv_radius : 1.0;
+    *sys_elem(d, row0 + r, col0 + c) = val;
   } else {
     const int r = e - WA * WB;
     const double g = KIND == 0 ? d.pose_gram[(size_t)rcb * kPoseGram + 21 + r] : d.igram[(size_t)(rcb - np) * kIntrGram + 36 + r];
-    *sys_elem(d, row0 + r, d.N) = g * d.scale_cam[row0 + r] - sum;
+    double val = g * d.scale_cam[row0 + r] - sum;
+    if (d.asm_inv_radius != 0.0 && !d.cam_active[row0 + r]) val = 0.0;   // (... and a zero right-hand side)
+    *sys_elem(d, row0 + r, d.N) = val;
   }
 }
 
@@ -2397,7 +2404,8 @@ __global__ __launch_bounds__(256) void ba_step_scalars_kernel(Dev d, double inv_
 // The camera half of ba_step_scalars_kernel alone (the candidate's poses and intrinsics, |delta|^2, |x|^2 and the model cost change of
 // the camera columns: part[3 b + 0..2]) - run BEFORE the back-substitution of the point groups when that pass forms the points'
 // half and the candidate's cost itself (it reads the candidate's cameras).
-__global__ __launch_bounds__(256) void ba_step_scalars_cam_kernel(Dev d, double inv_radius, double* __restrict__ part) {
+// gather: sp_gather_solution_kernel's work first (the solution of the block-sparse solve at its column -> zsol, step_cam), same thread.
+__global__ __launch_bounds__(256) void ba_step_scalars_cam_kernel(Dev d, double inv_radius, double* __restrict__ part, int gather) {
   __shared__ double sh[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   double cdsq = 0, cxsq = 0, vc = 0;
@@ -2405,7 +2413,13 @@ __global__ __launch_bounds__(256) void ba_step_scalars_cam_kernel(Dev d, double 
     const int np6 = 6 * (int)d.n_poses;
     double* x; double* cx; size_t idx;
     if ((int)i < np6) { x = d.poses; cx = d.cposes; idx = i; } else { x = d.intr; cx = d.cintr; idx = i - np6; }
-    const double s = d.step_cam[i];
+    double s;
+    if (gather) {
+      const double z = d.sp.z[d.sp.pcol[i]];
+      d.zsol[i] = z;
+      s = d.cam_active[i] ? -z : 0.0;
+      d.step_cam[i] = s;
+    } else s = d.step_cam[i];
     const double delta = s * d.scale_cam[i];
     cx[idx] = x[idx] + delta;
     cdsq = delta * delta;
@@ -2419,6 +2433,8 @@ __global__ __launch_bounds__(256) void ba_step_scalars_cam_kernel(Dev d, double 
 }
 // The eight sums of a step whose back-substitution formed the candidate: one workgroup per sum (all at once instead of one after the
 // other), rows in index order as reduce_partials_kernel takes them. cam_part: n_cam x 3 (ba_step_scalars_cam_kernel), grp_part: n_sg x 5.
+// (Publishing the scalars to the host from the workgroup that finishes last - arrival counter, fences, the stores to host memory -
+// was measured: this kernel 4.7 -> 11.9 us against the 3.9 us of ba_publish_scalars_kernel's own launch. Not kept.)
 __global__ __launch_bounds__(1024) void ba_step_reduce_kernel(const double* __restrict__ cam_part, int n_cam, const double* __restrict__ grp_part, int n_sg,
                                                               double* __restrict__ scalars) {
   __shared__ double sh[16];
@@ -2735,6 +2751,8 @@ struct mvgx_ba_ctx {
   bool model_cost_from_jacobian = false;   // MVGX_BA_MODEL_COST=jacobian: ba_model_cost_kernel instead of the normal-equation form
   bool solver_ready = false;
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
+  bool diag_blocks_complete = false;   // every pose / intrinsic block has a diagonal destination block in the assemble lists
+  bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
   bool all_points_grouped = false;   // every point is in a group: the per-point kernels of the record path have nothing to do
   bool fail_clear = false;           // the device's fail word was cleared by the last Jacobian evaluation and nothing has run since that can set it
@@ -2946,6 +2964,7 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
     hipLaunchKernelGGL((ba_schur_products_kernel<8, 8>), dim3(8 * ((d.tii.n_chunks + 7) / 8)), dim3(64), 0, c->stream, d.tii, d.Zint, d.Zint, d.hp, d.slot_point);
   BA_LAUNCH_CHECK();
   {
+    d.asm_inv_radius = c->diag_blocks_complete && !multi_rank(c) ? inv_radius : 0.0;
     const uint32_t wg_pp = (d.tpp.n_blocks + 7) / 8, wg_pi = (d.tpi.n_blocks + 7) / 8, wg_ii = d.tii.n_blocks;
     const uint32_t wg_all = wg_pp + wg_pi + wg_ii + (d.grp.n_sg ? 1u : 0u);
     if (wg_all) hipLaunchKernelGGL(ba_schur_assemble_all_kernel, dim3(wg_all), dim3(1024), 0, c->stream, d, wg_pp, wg_pi, wg_ii);
@@ -2984,7 +3003,10 @@ int factor_and_solve_sparse(mvgx_ba_ctx* c) {
   }
   for (int l = l_top; l >= 0; --l)
     hipLaunchKernelGGL(sp_backsolve_kernel, dim3(pl.f_start[l + 1] - pl.f_start[l]), dim3(256), 0, c->stream, d.sp, pl.f_start[l]);
-  hipLaunchKernelGGL(sp_gather_solution_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d);
+  if (c->fold_cand_now)   // (compute_step: this step's back-substitution forms the candidate - the gather and the camera half of the step's sums are one launch)
+    hipLaunchKernelGGL(ba_step_scalars_cam_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, 1.0 / c->radius, d.part, 1);
+  else
+    hipLaunchKernelGGL(sp_gather_solution_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d);
   BA_LAUNCH_CHECK();
   return MVGX_OK;
 }
@@ -3244,22 +3266,23 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   int rc = assemble_system(c, inv_radius);
   if (rc) return rc;
   if ((rc = exchange_system(c))) return rc;
-  if (d.N) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);
+  if (d.N && d.asm_inv_radius == 0.0) hipLaunchKernelGGL(ba_finish_system_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, inv_radius);   // (else: done by the assemble launch)
   BA_LAUNCH_CHECK();
   phase_end(c, kPhSchur);
   phase_begin(c);
+  // every point grouped: the back-substitution pass forms the candidate x + delta and its cost on the way (one pass over the
+  // observations less per iteration); the camera half of the step's sums runs in front of it (MVGX_BA_SEPARATE_COST=1: the passes of old)
+  const bool fold_cand = c->fold_candidate && c->all_points_grouped && d.grp.n_sg && !c->model_cost_from_jacobian;
+  c->fold_cand_now = fold_cand;
   if ((rc = factor_and_solve(c))) return rc;
   phase_end(c, kPhSolve);
   phase_begin(c);
   if (!(d.sp.enabled && c->all_points_grouped))   // (sparse solve + every point grouped: the gather kernel has written the camera steps, no point is left for this kernel)
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(c->grid_vec), dim3(256), 0, c->stream, d);   // camera steps; points of the record-based path
-  // every point grouped: the back-substitution pass forms the candidate x + delta and its cost on the way (one pass over the
-  // observations less per iteration); the camera half of the step's sums runs in front of it (MVGX_BA_SEPARATE_COST=1: the passes of old)
-  const bool fold_cand = c->fold_candidate && c->all_points_grouped && d.grp.n_sg && !c->model_cost_from_jacobian;
   c->candidate_cost_done = fold_cand;
   if (fold_cand) {
     const int n_cam_wg = (d.N + 255) / 256;
-    hipLaunchKernelGGL(ba_step_scalars_cam_kernel, dim3(n_cam_wg), dim3(256), 0, c->stream, d, inv_radius, d.part);
+    if (!d.sp.enabled) hipLaunchKernelGGL(ba_step_scalars_cam_kernel, dim3(n_cam_wg), dim3(256), 0, c->stream, d, inv_radius, d.part, 0);   // (else: with the gather)
     launch_point_groups<kGroupBacksub>(c, inv_radius, c->dmin, c->dmax, d.grp_part);
     hipLaunchKernelGGL(ba_step_reduce_kernel, dim3(8), dim3(1024), 0, c->stream, d.part, n_cam_wg, d.grp_part, (int)d.grp.n_sg, d.scalars);
     if (d.n_priors) hipLaunchKernelGGL(ba_prior_kernel<false>, dim3(1), dim3(256), 0, c->stream, d, d.cposes, 1);
@@ -4051,6 +4074,12 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   }
   for (const TripHost* h : {&hpp, &hpi, &hii})
     for (size_t b = 0; b < h->block_row.size(); ++b) c->h_blocks.emplace_back(h->block_row[b], h->block_col[b]);
+  {   // does every camera block have a diagonal destination in the assemble lists? (then the LM diagonal can be applied there)
+    size_t n_diag = 0;
+    for (const TripHost* h : {&hpp, &hii})
+      for (size_t b = 0; b < h->block_row.size(); ++b) n_diag += h->block_row[b] == h->block_col[b];
+    c->diag_blocks_complete = n_diag == (size_t)d.n_poses + d.n_intr;
+  }
   tick("pose-intr / intr-intr products");
   // active / counted camera components
   std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
