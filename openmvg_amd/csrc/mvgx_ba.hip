@@ -579,6 +579,11 @@ __device__ __forceinline__ constexpr int tri8(int r, int c) { return r * 8 - (r 
 // bytes each; the points are gathered). Nothing is read back from a stored Jacobian: every thread evaluates its observation,
 // drops the two rows into LDS, and each wave runs v_mfma_f64_16x16x4_f64 over its own 64 observations with lane (li, lk) feeding
 // element li of row k0 + lk as BOTH operands; the four accumulators are summed in wave order.
+// a value that is the same in every lane, moved to scalar registers (the compiler cannot prove the uniformity of a gathered load)
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 constexpr int kGramRow = 34;   // doubles per staged observation (2 x 16 + pad: 16-byte aligned, conflict-free 16-byte stores)
 template <bool kPinholeFamily>
 __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kernel(Dev d) {
@@ -590,14 +595,19 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
   if (ch == 0 && tid == 0) { *d.fail = 0; d.scalars[kSGmax] = 0.0; }   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration) and the gradient maximum ready for ba_gram_finish_kernel's atomic max
   const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
   const uint32_t ip = d.pichunk_pose[ch], ii = d.pichunk_intr[ch];
+  // the chunk's camera is the same for every thread: its 14 parameters live in scalar registers (28 vector registers less - with
+  // them in vector registers the polynomial-model variant spilled 4 - 14 registers at its 128-register budget: 20 - 60 bytes of
+  // scratch traffic per observation)
   double pin[8], pp[6];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pin[k] = d.intr[(size_t)ii * 8 + k];
+  for (int k = 0; k < 8; ++k) pin[k] = uniform_f64(d.intr[(size_t)ii * 8 + k]);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) pp[k] = d.poses[(size_t)ip * 6 + k];
-  const int model = d.model[ii];
+  for (int k = 0; k < 6; ++k) pp[k] = uniform_f64(d.poses[(size_t)ip * 6 + k]);
+  const int model = __builtin_amdgcn_readfirstlane(d.model[ii]);
   double trig[kPoseTrig];
   pose_trig(pp, trig);   // (the pose is the chunk's: once per thread)
+#pragma unroll
+  for (int k = 0; k < kPoseTrig; ++k) trig[k] = uniform_f64(trig[k]);
   d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
   for (uint32_t base = lo; base < hi; base += 256) {
     const uint32_t e = base + tid;
