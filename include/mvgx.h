@@ -32,7 +32,8 @@ extern "C" {
 const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
 /* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors;
- * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream) */
+ * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream; 5: geometric filter; 6: indexed filter entry,
+ * cascade hashing on the device; 7: homography model of the geometric filter) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -410,6 +411,21 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
  * image_wh is per IMAGE here: {w, h}. The gather runs on the device; results, mask and statistics as above. Image or feature
  * indices out of range -> MVGX_ERR_ARG. */
 int mvgx_geofilter_f_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                      const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
+                                      const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats /* may be NULL */);
+
+/* The homography model of the same filter: GeometricFilter_HMatrix_AC::Robust_estimation (matching_image_collection/H_ACRobust.hpp:49-113) -
+ * ACKernelAdaptor<homography::kernel::FourPointSolver, AsymmetricError, UnnormalizerI> with the point-to-point error model
+ * (multiview/solver_homography_kernel.cpp:37-93, solver_homography_kernel.hpp:60-64) + the same ACRANSAC. Same arguments, result
+ * layout and limits as the two entries above; result.F holds m_H (x_J ~ H x_I, pixels), ok is n_inliers > 2.5 x 4, pairs with at most
+ * 4 correspondences are rejected without estimation. Parity: as for F - the null vector of the 8 x 9 DLT system comes from
+ * complete-pivoting elimination instead of Eigen's JacobiSVD (the same line to rounding; a rank-deficient sample has a family of
+ * null vectors and the two methods pick different members). */
+int mvgx_geofilter_h_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats /* may be NULL */);
+int mvgx_geofilter_h_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
                                       const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
                                       const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                                       mvgx_geofilter_stats* stats /* may be NULL */);

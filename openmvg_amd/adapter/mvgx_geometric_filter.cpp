@@ -1,9 +1,10 @@
-// mvgx_geometric_filter.cpp - definition of the explicit specialisation declared in mvgx_geometric_filter.hpp: the geometric filter
-// of a putative-match container with GeometricFilter_FMatrix_AC on the MI355X.
+// mvgx_geometric_filter.cpp - definitions of the explicit specialisations declared in mvgx_geometric_filter.hpp: the geometric filter
+// of a putative-match container with GeometricFilter_FMatrix_AC or GeometricFilter_HMatrix_AC on the MI355X.
 //
-// Reference behaviour reproduced (openMVG/matching_image_collection/GeometricFilter.hpp:66-131, F_ACRobust.hpp:65-122):
+// Reference behaviour reproduced (openMVG/matching_image_collection/GeometricFilter.hpp:66-131, F_ACRobust.hpp:65-122,
+// H_ACRobust.hpp:49-113):
 //   * every pair of the container is estimated independently; a pair enters _map_GeometricMatches only if Robust_estimation
-//     returned true (more than 2.5 x 7 inliers), with the putative matches of the inliers in their original order;
+//     returned true (more than 2.5 x 7 inliers for F, 2.5 x 4 for H), with the putative matches of the inliers in their original order;
 //   * the progress bar is restarted with the number of pairs and advanced once per pair; a cancelled run leaves the container empty
 //     from the point of cancellation (checked before the device call and between its result batches);
 //   * with b_guided_matching the reference's own Geometry_guided_matching runs on the host with the estimated F and precision and
@@ -14,6 +15,7 @@
 // What the device does not reproduce is routed to the reference's own code: an unbounded precision (m_dPrecision = infinity) and
 // pairs with more than 2^20 putative matches run functor.Robust_estimation on the host, pair by pair.
 #include "mvgx_geometric_filter.hpp"
+#include "openMVG/matching_image_collection/H_ACRobust.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -39,10 +41,11 @@ constexpr size_t kDeviceMaxMatches = size_t(1) << 20;   // mvgx_geofilter_f_acra
 
 // the reference's loop body for one pair (GeometricFilter.hpp:93-128) with the reference's own functor: the route for what the
 // device call does not cover
-bool reference_pair(const GeometricFilter_FMatrix_AC& functor, const sfm::SfM_Data* sfm_data,
+template <class Functor>
+bool reference_pair(const Functor& functor, const sfm::SfM_Data* sfm_data,
                     const std::shared_ptr<sfm::Regions_Provider>& regions_provider, const Pair& pair, const IndMatches& putative,
                     bool guided, double ratio, IndMatches& out) {
-  GeometricFilter_FMatrix_AC f = functor;
+  Functor f = functor;
   if (!f.Robust_estimation(sfm_data, regions_provider, pair, putative, out)) return false;
   if (guided) {
     IndMatches g;
@@ -51,12 +54,25 @@ bool reference_pair(const GeometricFilter_FMatrix_AC& functor, const sfm::SfM_Da
   }
   return true;
 }
-}  // namespace
 
-template <>
-void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>(
-    const GeometricFilter_FMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
-    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+// what differs between the two functors: the member that holds the model and the C entry point
+template <class Functor> struct ModelOf;
+template <> struct ModelOf<GeometricFilter_FMatrix_AC> {
+  static Mat3& model(GeometricFilter_FMatrix_AC& f) { return f.m_F; }
+  static constexpr const char* entry_name = "mvgx_geofilter_f_acransac_indexed";
+  template <class... A> static int run(A... a) { return mvgx_geofilter_f_acransac_indexed(a...); }
+};
+template <> struct ModelOf<GeometricFilter_HMatrix_AC> {
+  static Mat3& model(GeometricFilter_HMatrix_AC& f) { return f.m_H; }
+  static constexpr const char* entry_name = "mvgx_geofilter_h_acransac_indexed";
+  template <class... A> static int run(A... a) { return mvgx_geofilter_h_acransac_indexed(a...); }
+};
+
+// the body of both specialisations; the members of ImageCollectionGeometricFilter it works on are passed in under their names
+template <class Functor>
+void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm::Regions_Provider>& regions_provider_,
+                      PairWiseMatches& _map_GeometricMatches, const Functor& functor, const PairWiseMatches& putative_matches,
+                      const bool b_guided_matching, const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
   if (!my_progress_bar) my_progress_bar = &system::ProgressInterface::dummy();
   my_progress_bar->Restart(putative_matches.size(), "- Geometric filtering -");
   const size_t n_pairs = putative_matches.size();
@@ -128,11 +144,12 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
     mvgx_geofilter_options opt;
     opt.precision = functor.m_dPrecision;
     opt.max_iterations = functor.m_stIteration;
-    const int rc = mvgx_geofilter_f_acransac_indexed(-1, feat_xy.data(), feat_start.data(), wh.data(), (uint32_t)n_views, pair_views.data(), start.data(),
-                                                     ij.data(), dev_pairs.size(), &opt, mask.data(), res.data(), nullptr);
+    const int rc = ModelOf<Functor>::run(-1, (const double*)feat_xy.data(), (const uint64_t*)feat_start.data(), (const uint32_t*)wh.data(), (uint32_t)n_views,
+                                         (const uint32_t*)pair_views.data(), (const uint64_t*)start.data(), (const uint32_t*)ij.data(), (uint64_t)dev_pairs.size(),
+                                         (const mvgx_geofilter_options*)&opt, mask.data(), res.data(), (mvgx_geofilter_stats*)nullptr);
     if (rc != MVGX_OK) {   // no CPU substitute for a failing device: report like the matcher adapter does
       OPENMVG_LOG_ERROR << "mvgx geometric filter: " << mvgx_last_error();
-      throw std::runtime_error(std::string("mvgx_geofilter_f_acransac_indexed failed: ") + mvgx_last_error());
+      throw std::runtime_error(std::string(ModelOf<Functor>::entry_name) + " failed: " + mvgx_last_error());
     }
   }
   // results in container order; guided matching (host, the reference's code) on OpenMP threads like the reference's loop
@@ -157,9 +174,9 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
         for (size_t i = 0; i < kv.second.size(); ++i)
           if (mask[lo + i]) inliers.push_back(kv.second[i]);
         if (b_guided_matching) {
-          GeometricFilter_FMatrix_AC f = functor;
+          Functor f = functor;
           for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) f.m_F(r, c) = res[k].F[3 * r + c];
+            for (int c = 0; c < 3; ++c) ModelOf<Functor>::model(f)(r, c) = res[k].F[3 * r + c];
           f.m_dPrecision_robust = res[k].precision_robust;
           IndMatches g;
           f.Geometry_guided_matching(sfm_data_, regions_provider_, kv.first, d_distance_ratio, g);
@@ -175,6 +192,21 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
     }
     ++(*my_progress_bar);
   }
+}
+}  // namespace
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>(
+    const GeometricFilter_FMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
+}
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMatrix_AC>(
+    const GeometricFilter_HMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
 }
 
 }  // namespace matching_image_collection

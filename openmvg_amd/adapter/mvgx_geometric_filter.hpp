@@ -8,12 +8,14 @@
 // the primary template for GeometricFilter_FMatrix_AC, and the linker takes the definition of mvgx_geometric_filter.cpp, which
 // runs all image pairs of the container through mvgx_geofilter_f_acransac (include/mvgx.h). Same signature, same container
 // (_map_GeometricMatches), same acceptance rule; the guided-matching step, if asked for, runs the reference's own
-// Geometry_guided_matching with the estimated F. The other functors (H, E, ...) keep the reference's template.
+// Geometry_guided_matching with the estimated model. The homography functor (GeometricFilter_HMatrix_AC, H_ACRobust.hpp) has the same
+// kind of specialisation over mvgx_geofilter_h_acransac_indexed; the other functors (E, ...) keep the reference's template.
 #ifndef MVGX_GEOMETRIC_FILTER_HPP
 #define MVGX_GEOMETRIC_FILTER_HPP
 
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
+#include "openMVG/matching_image_collection/H_ACRobust.hpp"
 
 namespace openMVG {
 namespace matching_image_collection {
@@ -21,6 +23,11 @@ namespace matching_image_collection {
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMatrix_AC>(
     const GeometricFilter_FMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMatrix_AC>(
+    const GeometricFilter_HMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* progress_bar);
 
 }  // namespace matching_image_collection

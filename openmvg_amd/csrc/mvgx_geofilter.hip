@@ -44,7 +44,11 @@ namespace {
 using mvgx::set_error;
 
 constexpr int kBins = 20;        // robust_estimator_ACRansac.hpp:221
-constexpr int kMinSamples = 7, kMaxModels = 3;
+constexpr int kMinSamples = 7, kMaxModels = 3;   // the fundamental-matrix model (SevenPointSolver)
+// The estimated model: the a-contrario loop is the same program for both, what differs is the minimal solver, the residual, the
+// sample size and - on the host - logalpha0 / multError of the NFA (point-to-line for F, point-to-point for H).
+enum GeoModel { kModelF = 0, kModelH = 1 };
+template <int MODEL> constexpr int model_min_samples() { return MODEL == kModelH ? 4 : kMinSamples; }   // Solver::MINIMUM_SAMPLES
 constexpr int kMtN = 624, kMtM = 397;
 
 struct GeoPair {   // per pair, prepared on the host (glibc's log10 / hypot / sqrt: the reference's values)
@@ -162,6 +166,89 @@ __device__ __forceinline__ double epipolar_error(const double (&F)[9], double2 x
   return dt * dt / (fx0 * fx0 + fx1 * fx1);
 }
 
+// AsymmetricError (multiview/solver_homography_kernel.hpp:60-64): |y - hnormalized(H [x; 1])|^2, products and sums rounded one by one
+// (the reference's build has no fused multiply-add)
+__device__ __forceinline__ double homography_error(const double (&H)[9], double2 x, double2 y) {
+  const double v0 = add_rn(add_rn(mul_rn(H[0], x.x), mul_rn(H[1], x.y)), H[2]);
+  const double v1 = add_rn(add_rn(mul_rn(H[3], x.x), mul_rn(H[4], x.y)), H[5]);
+  const double v2 = add_rn(add_rn(mul_rn(H[6], x.x), mul_rn(H[7], x.y)), H[8]);
+  const double dx = y.x - v0 / v2, dy = y.y - v1 / v2;
+  return add_rn(mul_rn(dx, dx), mul_rn(dy, dy));
+}
+template <int MODEL>
+__device__ __forceinline__ double model_error(const double (&M)[9], double2 x, double2 y) {
+  return MODEL == kModelH ? homography_error(M, x, y) : epipolar_error(M, x, y);
+}
+
+// FourPointSolver::Solve on the sample s[0..3] (wave-uniform; multiview/solver_homography_kernel.cpp:37-93): the null vector of the
+// 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3. Lane r
+// (mod 8) keeps row r in registers; Gauss-Jordan elimination with complete pivoting, the pivot row broadcast through v_readlane;
+// the column left without a pivot carries the null space (the reference takes the last right singular vector of the same matrix:
+// the same line up to rounding and scale; a rank-deficient sample gives SOME null vector in both, not the same one).
+__device__ __forceinline__ void four_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane, double (&H)[9]) {
+  const int r = lane & 7, pt = r >> 1;
+  const uint32_t si = pt == 0 ? s[0] : pt == 1 ? s[1] : pt == 2 ? s[2] : s[3];
+  const double2 p1 = x1[si], p2 = x2[si];
+  const bool second = r & 1;
+  const double t = second ? p2.y : p2.x;
+  double a[9];
+  a[0] = second ? 0.0 : p1.x; a[1] = second ? 0.0 : p1.y; a[2] = second ? 0.0 : 1.0;
+  a[3] = second ? p1.x : 0.0; a[4] = second ? p1.y : 0.0; a[5] = second ? 1.0 : 0.0;
+  a[6] = -t * p1.x; a[7] = -t * p1.y; a[8] = -t;
+  uint32_t row_used = 0, col_used = 0;
+  int prow[8], pcol[8], n_piv = 0;
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    // this lane's best candidate: largest magnitude (as a float: a choice within 2^-17 of the largest is as good a pivot) over the
+    // columns without a pivot, lowest (row, column) on ties - key = float bits with the low 7 bits replaced by 127 - (9 r + c)
+    uint32_t key = 0u;
+    if (!((row_used >> r) & 1u)) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float mag = (float)fabs(a[c]);
+        const uint32_t k = (!((col_used >> c) & 1u) && mag > 0.f && mag == mag) ? ((__float_as_uint(mag) & ~127u) | (uint32_t)(127 - (9 * r + c))) : 0u;
+        key = k > key ? k : key;
+      }
+    }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) break;   // rank deficient sample (wave-uniform)
+    const int who = 127 - (int)(best & 127u);
+    const int pr = who / 9, pc = who - 9 * pr;
+    double rowv[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) rowv[c] = lane_value_f64(a[c], pr);
+    double piv = rowv[0], colv = a[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) { piv = (c == pc) ? rowv[c] : piv; colv = (c == pc) ? a[c] : colv; }
+    const double f = colv * (1.0 / piv);
+    if (r != pr) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) a[c] -= f * rowv[c];
+    }
+    row_used |= 1u << pr; col_used |= 1u << pc;
+    prow[step] = pr; pcol[step] = pc;
+    n_piv = step + 1;
+  }
+  int fc = 0;
+  while ((col_used >> fc) & 1u) ++fc;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) H[u] = (u == fc) ? 1.0 : 0.0;
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    if (step < n_piv) {   // wave-uniform
+      double num = 0.0, den = 1.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const double v = lane_value_f64(a[c], prow[step]);
+        num = (c == fc) ? v : num; den = (c == pcol[step]) ? v : den;
+      }
+      const double h = -num / den;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) H[u] = (u == pcol[step]) ? h : H[u];
+    }
+  }
+}
+
 // SevenPointSolver::Solve on the sample s[0..6] (wave-uniform): the two null vectors F1, F2 of the 7 x 9 system and the real
 // roots of det(F1 + alpha F2) = 0; model t is F1 + roots[t] F2. Every lane gets everything.
 __device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane,
@@ -238,12 +325,13 @@ __device__ __forceinline__ float logcombi(uint32_t k, uint32_t n, const float* _
 }
 
 // number of correspondences whose residual under F is at most thr (all lanes get the sum): ballots, no shuffles
+template <int MODEL>
 __device__ __forceinline__ uint32_t count_within(const double (&F)[9], const double2* __restrict__ x1, const double2* __restrict__ x2, uint32_t n,
                                                  double thr, int lane) {
   uint32_t cnt = 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t i = base + lane;
-    const bool in = i < n && epipolar_error(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= thr;
+    const bool in = i < n && model_error<MODEL>(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= thr;
     cnt += (uint32_t)__popcll(__ballot(in));
   }
   return cnt;
@@ -293,7 +381,7 @@ constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (2
 // kGlobalTables: the sampling pool and the two log-combinatorial tables of a wave (3 x n words) live in a global scratch block
 // instead of LDS - the class of pairs with more correspondences than a workgroup's LDS holds (one wave per workgroup; the generator,
 // the histogram and the model stay in LDS)
-template <int WAVES, bool kGlobalTables = false>
+template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF>
 __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
@@ -304,6 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * WAVES + wave;
   if (w >= n_work) return;   // wave-uniform; no workgroup barrier below
+  constexpr int kMin = model_min_samples<MODEL>();
   const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
   const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
   uint32_t* const mt = lds_u32 + (size_t)wave * per_wave;
@@ -323,7 +412,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   // ---- set-up: generator (std::mt19937(5489) before its first twist), pool = 0..n-1, tables ----
   for (int i = lane; i < kMtN; i += 64) mt[i] = mt_init[i];
   for (uint32_t i = lane; i < n; i += 64) pool[i] = i;
-  for (uint32_t k = lane; k <= n; k += 64) { logc_n[k] = logcombi(k, n, l10); logc_k[k] = logcombi(kMinSamples, k, l10); }
+  for (uint32_t k = lane; k <= n; k += 64) { logc_n[k] = logcombi(k, n, l10); logc_k[k] = logcombi(kMin, k, l10); }
   if (lane < 9) inlF_lds[lane] = 0.0;
   wave_sync();
   int mt_idx = kMtN;
@@ -340,10 +429,10 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   for (unsigned iter = 0; iter < nIter && iter < max_iterations; ++iter) {
     // ---- sample (rand_sampling.hpp) ----
     if (ac_mode) {
-      if (pool_size >= (uint32_t)kMinSamples) {   // else UniformSample returns false and vec_sample keeps its values
+      if (pool_size >= (uint32_t)kMin) {   // else UniformSample returns false and vec_sample keeps its values
         const uint32_t last = pool_size - 1;
 #pragma unroll
-        for (uint32_t i = 0; i < 7; ++i) {
+        for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
           const uint32_t jx = uniform_u32(mt, mt_idx, lane, i, last);
           const uint32_t vi = pool[i], vj = pool[jx];
           wave_sync();
@@ -354,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
       }
     } else {
       int got = 0;
-      while (got < 7) {
+      while (got < kMin) {
         const uint32_t cand = uniform_u32(mt, mt_idx, lane, 0, n - 1);
         bool found = false;
 #pragma unroll
@@ -367,14 +456,21 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
       }
     }
     // ---- fit, evaluate ----
-    double F1[9], F2[9], roots[3];
-    const int nm = seven_point(x1, x2, s, lane, F1, F2, roots);
+    double F1[9], F2[9], roots[3] = {0.0, 0.0, 0.0};
+    int nm = 1;
+    if (MODEL == kModelH) {
+      four_point(x1, x2, s, lane, F1);   // (one model per sample: MAX_MODELS = 1)
+#pragma unroll
+      for (int u = 0; u < 9; ++u) F2[u] = 0.0;
+    } else {
+      nm = seven_point(x1, x2, s, lane, F1, F2, roots);
+    }
     bool better = false;
     for (int mi = 0; mi < nm; ++mi) {
       const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
       double F[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) F[u] = F1[u] + root * F2[u];
+      for (int u = 0; u < 9; ++u) F[u] = MODEL == kModelH ? F1[u] : F1[u] + root * F2[u];
       if (lane < kBins) hist[lane] = 0;
       wave_sync();
       uint32_t n_le = 0;
@@ -388,7 +484,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t i = base + 64 * q + lane;
-          const double e = epipolar_error(F, a1[q], a2[q]);
+          const double e = model_error<MODEL>(F, a1[q], a2[q]);
           const bool in = i < n && e <= max_threshold;
           if (!ac_mode) n_le += (uint32_t)__popcll(__ballot(in));
           if (i < n && !(e < 0.0)) {   // Histogram::Add (histogram.hpp:72-86); a NaN / huge value ends in no bin, like the cast to size_t on x86-64
@@ -397,15 +493,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
           }
         }
       }
-      if (!ac_mode && (double)n_le > 2.5 * kMinSamples) ac_mode = true;   // MAX-CONSENSUS warm-up (:404-414)
+      if (!ac_mode && (double)n_le > 2.5 * kMin) ac_mode = true;   // MAX-CONSENSUS warm-up (:404-414)
       wave_sync();
       if (ac_mode) {   // ComputeNFA_and_inliers, quantified form (:196-262): lane b evaluates bin b, the first bin of minimal NFA wins
         uint32_t cum = 0;
 #pragma unroll
         for (int b = 0; b < kBins; ++b) cum += (b <= lane) ? hist[b] : 0u;
         double cur = inf;
-        if (lane < kBins && cum > (uint32_t)kMinSamples && my_bin_value > 1.1920928955078125e-07) {
-          cur = add_rn(add_rn(add_rn(loge0, mul_rn(my_logalpha, (double)(cum - kMinSamples))), (double)logc_n[cum]), (double)logc_k[cum]);
+        if (lane < kBins && cum > (uint32_t)kMin && my_bin_value > 1.1920928955078125e-07) {
+          cur = add_rn(add_rn(add_rn(loge0, mul_rn(my_logalpha, (double)(cum - kMin))), (double)logc_n[cum]), (double)logc_k[cum]);
           if (!(cur < 0)) cur = inf;
         }
         // minimum over the 20 lanes, lowest bin on ties (the sequential scan keeps the first strict improvement)
@@ -416,7 +512,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
           if (v < cb_nfa) { cb_nfa = v; cb_thr = lane_value_f64(my_bin_value, b); }
         }
         if (cb_nfa < minNFA) {   // the inlier list is rebuilt even if it then turns out too short (the reference's behaviour)
-          const uint32_t cnt = count_within(F, x1, x2, n, cb_thr, lane);
+          const uint32_t cnt = count_within<MODEL>(F, x1, x2, n, cb_thr, lane);
           wave_sync();
           if (lane < 9) {
 #pragma unroll
@@ -424,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
           }
           wave_sync();
           inl_thr = cb_thr; inl_count = cnt;
-          if (cnt > (uint32_t)kMinSamples) {
+          if (cnt > (uint32_t)kMin) {
             better = true; minNFA = cb_nfa; errorMax = cb_thr; have_model = 1;
 #pragma unroll
             for (int u = 0; u < 9; ++u) if (lane == u) bestFu = F[u];
@@ -444,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
         uint32_t m = 0;
         for (uint32_t base = 0; base < n; base += 64) {
           const uint32_t i = base + lane;
-          const bool in = i < n && epipolar_error(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= inl_thr;
+          const bool in = i < n && model_error<MODEL>(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= inl_thr;
           const unsigned long long bal = __ballot(in);
           if (in) pool[m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
           m += (uint32_t)__popcll(bal);
@@ -456,12 +552,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
     }
   }
   if (minNFA >= 0) inl_count = 0;   // no meaningful model (:477-478)
-  const bool good = (double)inl_count > kMinSamples * 2.5;   // F_ACRobust.hpp:103
+  const bool good = (double)inl_count > kMin * 2.5;   // F_ACRobust.hpp:103, H_ACRobust.hpp:98
   {
     double F[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) F[u] = inlF_lds[u];
-    for (uint32_t i = lane; i < n; i += 64) mask[P.start + i] = (good && epipolar_error(F, x1[i], x2[i]) <= inl_thr) ? 1 : 0;
+    for (uint32_t i = lane; i < n; i += 64) mask[P.start + i] = (good && model_error<MODEL>(F, x1[i], x2[i]) <= inl_thr) ? 1 : 0;
   }
   if (lane < 9) results[pidx].F[lane] = bestFu;
   if (lane == 0) {
@@ -475,23 +571,24 @@ struct DevBuf {
   int alloc(size_t bytes) { MVGX_HIP(mvgx::device_malloc(&p, std::max<size_t>(bytes, 16))); return MVGX_OK; }
 };
 
-template <int WAVES>
+template <int WAVES, int MODEL>
 int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
                  const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, hipStream_t stream) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + kWaveScratch) * sizeof(uint32_t);
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(geofilter_f_acransac_kernel<WAVES>, dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
                      n_cap, x1, x2, l10, mt_init, max_it, res, mask);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
 // the class above the LDS classes: tables in `scratch` (n_work x 3 x ((n_cap + 2) & ~1) words)
+template <int MODEL>
 int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
                         const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)(kMtN + kWaveScratch) * sizeof(uint32_t);
-  hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
+  hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
                      max_it, res, mask, scratch);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
@@ -510,9 +607,27 @@ struct GeoSource {
   const uint32_t* pair_images = nullptr; const uint32_t* ij = nullptr;
 };
 
-int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
+// the launches of the five size classes (largest pairs first) for one model
+template <int MODEL>
+int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const std::vector<GeoPair>& hp, uint32_t c4, uint32_t c3,
+                   uint32_t c2, uint32_t c1, const uint32_t (&caps)[4], const double2* px1, const double2* px2, const float* l10, const uint32_t* mt,
+                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream) {
+  int rc;
+  if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
+    const uint32_t cap_g = hp[order[0]].n;
+    if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
+    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream))) return rc;
+  }
+  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
+  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
+  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
+  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream);
+}
+
+int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
                   uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                   mvgx_geofilter_stats* stats) {
+  const int min_samples = model == kModelH ? 4 : kMinSamples, max_models = model == kModelH ? 1 : kMaxModels;
   MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || (image_wh && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
   const uint64_t n_total = match_start[n_pairs];
   MVGX_REQUIRE(n_total == 0 || inlier_mask, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL inlier mask");
@@ -570,14 +685,17 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
       }
       const uint32_t* wh2 = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + 1] : image_wh + 4 * p + 2;
       const int w2 = (int)wh2[0], h2 = (int)wh2[1];
-      const double logalpha0 = std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
+      // ACParametrizationHelper (robust_estimator_ACRansacKernelAdaptator.hpp:38-81): point-to-line for F, point-to-point for H
+      const double logalpha0 = model == kModelH ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (t[1][0] * t[1][0]))
+                                                : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
+      const double mult_error = model == kModelH ? 1.0 : 0.5;
       g.max_threshold = opt->precision * opt->precision * t[1][0] * t[1][0];
-      g.loge0 = n > (uint32_t)kMinSamples ? std::log10((double)kMaxModels * (n - kMinSamples)) : 0.0;
+      g.loge0 = n > (uint32_t)min_samples ? std::log10((double)max_models * (n - min_samples)) : 0.0;
       g.bins_by_interval = kBins / (g.max_threshold - 0.0);
       const double val = (g.max_threshold - 0.0) / static_cast<double>(kBins - 1);
       for (int b = 0; b < kBins; ++b) {
         g.bin_value[b] = val * static_cast<double>(b) + 0.0;
-        g.logalpha_bin[b] = logalpha0 + 0.5 * std::log10(g.bin_value[b] + std::numeric_limits<float>::epsilon());
+        g.logalpha_bin[b] = logalpha0 + mult_error * std::log10(g.bin_value[b] + std::numeric_limits<float>::epsilon());
       }
     }
   };
@@ -588,10 +706,10 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
     for (auto& th : pool) th.join();
   }
   MVGX_REQUIRE(bad_pair.load() < 0, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: pair %lld has a feature index out of range", (long long)bad_pair.load());
-  // pairs that run the estimation (more than 7 correspondences), by size class, largest first inside a class
+  // pairs that run the estimation (more correspondences than a minimal sample), by size class, largest first inside a class
   std::vector<uint32_t> order;
   order.reserve(n_pairs);
-  for (uint64_t p = 0; p < n_pairs; ++p) if (hp[p].n > (uint32_t)kMinSamples) order.push_back((uint32_t)p);
+  for (uint64_t p = 0; p < n_pairs; ++p) if (hp[p].n > (uint32_t)min_samples) order.push_back((uint32_t)p);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hp[a].n > hp[b].n; });
   uint32_t c4 = 0, c3 = 0, c2 = 0, c1 = 0;   // [0, c4): n > kCap3 (global tables); [c4, c3): n > kCap2; [c3, c2): n > kCap1; [c2, c1): n > kCap0; the rest <= kCap0
   while (c4 < order.size() && hp[order[c4]].n > kCap3) ++c4;
@@ -668,25 +786,17 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
     MVGX_HIP(hipGetLastError());
   }
   DevBuf d_tables;
-  if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
-    const uint32_t cap_g = hp[order[0]].n;
-    if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
-    if ((rc = launch_class_global(static_cast<GeoPair*>(d_pairs.p), ord, c4, cap_g, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
-                                  opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), static_cast<uint32_t*>(d_tables.p), stream)))
-      return rc;
+  {
+    const uint32_t caps[4] = {kCap0, kCap1, kCap2, kCap3};
+    auto* dp = static_cast<const GeoPair*>(d_pairs.p);
+    auto* dl = static_cast<const float*>(d_l10.p);
+    auto* dm = static_cast<const uint32_t*>(d_mt.p);
+    auto* dr = static_cast<GeoResult*>(d_res.p);
+    auto* dk = static_cast<uint8_t*>(d_mask.p);
+    rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
+                          : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
+    if (rc) return rc;
   }
-  if ((rc = launch_class<1>(static_cast<GeoPair*>(d_pairs.p), ord + c4, c3 - c4, kCap3, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
-                            opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
-    return rc;
-  if ((rc = launch_class<2>(static_cast<GeoPair*>(d_pairs.p), ord + c3, c2 - c3, kCap2, px1, px2, static_cast<float*>(d_l10.p), static_cast<uint32_t*>(d_mt.p),
-                            opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
-    return rc;
-  if ((rc = launch_class<4>(static_cast<GeoPair*>(d_pairs.p), ord + c2, c1 - c2, kCap1, px1, px2, static_cast<float*>(d_l10.p),
-                            static_cast<uint32_t*>(d_mt.p), opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
-    return rc;
-  if ((rc = launch_class<4>(static_cast<GeoPair*>(d_pairs.p), ord + c1, (uint32_t)order.size() - c1, kCap0, px1, px2, static_cast<float*>(d_l10.p),
-                            static_cast<uint32_t*>(d_mt.p), opt->max_iterations, static_cast<GeoResult*>(d_res.p), static_cast<uint8_t*>(d_mask.p), stream)))
-    return rc;
   MVGX_HIP(hipEventRecord(e1, stream));
   std::vector<GeoResult> hr(n_pairs);
   if (n_pairs) MVGX_HIP(hipMemcpyAsync(hr.data(), d_res.p, n_pairs * sizeof(GeoResult), hipMemcpyDeviceToHost, stream));
@@ -699,7 +809,7 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
   for (uint64_t p = 0; p < n_pairs; ++p) {
     mvgx_geofilter_result& o = results[p];
     const GeoResult& r = hr[p];
-    const bool ran = hp[p].n > (uint32_t)kMinSamples;
+    const bool ran = hp[p].n > (uint32_t)min_samples;
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = (ran && r.have_model) ? r.F[u] : ((u % 4 == 0) ? 1.0 : 0.0);   // m_F starts as the identity
     double err = ran ? r.error_max : 0.0;
@@ -707,6 +817,11 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
       const double* t = &norm[6 * p];
       const double N1[9] = {t[0], 0, t[1], 0, t[0], t[2], 0, 0, 1}, N2[9] = {t[3], 0, t[4], 0, t[3], t[5], 0, 0, 1};
       double tmp[9], res[9];
+      if (model == kModelH) {   // UnnormalizerI (conditioning.cpp:80-82): H = N2^-1 H N1; N2 = [s 0 tx; 0 s ty; 0 0 1]
+        const double is = 1.0 / t[3];
+        const double N2i[9] = {is, 0, -t[4] * is, 0, is, -t[5] * is, 0, 0, 1};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s_ = 0; for (int k = 0; k < 3; ++k) s_ += N2i[3 * a + k] * Fm[3 * k + b]; tmp[3 * a + b] = s_; }
+      } else   // UnnormalizerT: F = N2^T F N1
       for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s_ = 0; for (int k = 0; k < 3; ++k) s_ += N2[3 * k + a] * Fm[3 * k + b]; tmp[3 * a + b] = s_; }
       for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s_ = 0; for (int k = 0; k < 3; ++k) s_ += tmp[3 * a + k] * N1[3 * k + b]; res[3 * a + b] = s_; }
       std::memcpy(Fm, res, sizeof(res));
@@ -716,7 +831,7 @@ int geofilter_run(int device, const GeoSource& src, const uint64_t* match_start,
     o.precision_robust = err;
     o.nfa = ran ? r.min_nfa : 0.0;
     o.n_inliers = ran ? r.n_inliers : 0;
-    o.ok = ran && (double)r.n_inliers > kMinSamples * 2.5;
+    o.ok = ran && (double)r.n_inliers > min_samples * 2.5;
     n_ok += o.ok; n_inl += o.ok ? o.n_inliers : 0;
   }
   if (stats) {
@@ -737,7 +852,15 @@ int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, co
                               mvgx_geofilter_stats* stats) {
   GeoSource src;
   src.xI = xI; src.xJ = xJ;
-  return geofilter_run(device, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+  return geofilter_run(device, kModelF, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_h_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                              uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.xI = xI; src.xJ = xJ;
+  return geofilter_run(device, kModelH, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
 }
 
 int mvgx_geofilter_f_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
@@ -747,7 +870,17 @@ int mvgx_geofilter_f_acransac_indexed(int device, const double* feat_xy, const u
   GeoSource src;
   src.indexed = true;
   src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
-  return geofilter_run(device, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+  return geofilter_run(device, kModelF, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_h_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                      const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
+                                      const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.indexed = true;
+  src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
+  return geofilter_run(device, kModelH, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
 }
 
 }  // extern "C"

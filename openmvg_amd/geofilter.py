@@ -2,6 +2,7 @@
 
   ImageCollectionGeometricFilter::Robust_model_estimation      matching_image_collection/GeometricFilter.hpp:66-131
   GeometricFilter_FMatrix_AC(dPrecision, iteration)             matching_image_collection/F_ACRobust.hpp:32-122
+  GeometricFilter_HMatrix_AC(dPrecision, iteration)             matching_image_collection/H_ACRobust.hpp:32-113
   MatchesPairToMat                                              matching_image_collection/Geometric_Filter_utils.hpp:56-64
 
 All numerics run in libmvgx_hip.so on the GPU (one wave per image pair); there is no CPU fallback.
@@ -16,9 +17,16 @@ from . import _capi
 class GeometricFilter_FMatrix_AC:
     """Field names of the reference functor; `Robust_estimation` of one pair is `filter_pairs` on a one-pair container."""
 
+    _entry, _entry_indexed = "mvgx_geofilter_f_acransac", "mvgx_geofilter_f_acransac_indexed"
+
     def __init__(self, dPrecision=4.0, iteration=1024):
         self.m_dPrecision = float(dPrecision)
         self.m_stIteration = int(iteration)
+
+
+class GeometricFilter_HMatrix_AC(GeometricFilter_FMatrix_AC):
+    """The homography functor (H_ACRobust.hpp:32-113): same fields; the result's "F" field then holds m_H (x_J ~ H x_I)."""
+    _entry, _entry_indexed = "mvgx_geofilter_h_acransac", "mvgx_geofilter_h_acransac_indexed"
 
 
 def filter_pairs(xI, xJ, match_start, image_wh, functor=None, device=-1):
@@ -38,7 +46,7 @@ def filter_pairs(xI, xJ, match_start, image_wh, functor=None, device=-1):
     st = _capi.GeofilterStats()
     opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-    _capi.check(_capi.lib().mvgx_geofilter_f_acransac(int(device), P(xI), P(xJ), P(start), P(wh), n_pairs, C.byref(opt), P(mask),
+    _capi.check(getattr(_capi.lib(), functor._entry)(int(device), P(xI), P(xJ), P(start), P(wh), n_pairs, C.byref(opt), P(mask),
                                                       C.cast(res, C.c_void_p), C.byref(st)))
     out = _results_array(res, n_pairs)
     return mask[:len(xI)].astype(bool), out, st
@@ -81,7 +89,7 @@ def filter_pairs_indexed(feats_xy, image_sizes, pairs, match_start, ij, functor=
     st = _capi.GeofilterStats()
     opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-    _capi.check(_capi.lib().mvgx_geofilter_f_acransac_indexed(int(device), P(feat), P(fstart), P(wh), n_images, P(pairs), P(start), P(ij), n_pairs,
+    _capi.check(getattr(_capi.lib(), functor._entry_indexed)(int(device), P(feat), P(fstart), P(wh), n_images, P(pairs), P(start), P(ij), n_pairs,
                                                               C.byref(opt), P(mask), C.cast(res, C.c_void_p), C.byref(st)))
     return mask[:len(ij)].astype(bool), _results_array(res, n_pairs), st
 

@@ -294,6 +294,34 @@ def two_view_matches(n_pairs, seed=0, n_min=8, n_max=400, inlier_frac=(0.3, 0.9)
                 wh=np.asarray(wh, np.uint32).reshape(-1, 4), is_inlier=np.concatenate(truth) if truth else np.zeros(0, bool))
 
 
+def two_view_homography_matches(n_pairs, seed=0, n_min=5, n_max=400, inlier_frac=(0.3, 0.9), noise_px=0.4, no_geometry_frac=0.25, tiny_frac=0.03,
+                                sizes=((1000, 1000), (1280, 960), (1920, 1080))):
+    """Putative matches of image pairs related by a homography (a plane seen from two views / a rotating camera): x_J ~ H x_I + noise
+    for the inliers, uniform positions for the rest. Same dict as two_view_matches."""
+    rng = np.random.default_rng(seed)
+    xs_i, xs_j, truth, start, wh = [], [], [], [0], []
+    for _ in range(n_pairs):
+        u = rng.random()
+        n = int(rng.integers(0, 5)) if u < tiny_frac else int(rng.integers(n_min, n_max + 1))
+        (wi, hi), (wj, hj) = sizes[rng.integers(len(sizes))], sizes[rng.integers(len(sizes))]
+        th = rng.uniform(-0.3, 0.3); sc = rng.uniform(0.8, 1.25)
+        H = np.array([[sc * np.cos(th), -sc * np.sin(th), rng.uniform(-0.1, 0.1) * wj],
+                      [sc * np.sin(th), sc * np.cos(th), rng.uniform(-0.1, 0.1) * hj],
+                      [rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-4, 1e-4), 1.0]])
+        a = np.stack([rng.uniform(0, wi, n), rng.uniform(0, hi, n)], 1)
+        ah = np.concatenate([a, np.ones((n, 1))], 1) @ H.T
+        b = ah[:, :2] / ah[:, 2:3] + rng.normal(0, noise_px, (n, 2))
+        frac = 0.0 if rng.random() < no_geometry_frac else rng.uniform(*inlier_frac)
+        inl = rng.random(n) < frac
+        b[~inl] = np.stack([rng.uniform(0, wj, (~inl).sum()), rng.uniform(0, hj, (~inl).sum())], 1)
+        xs_i.append(a); xs_j.append(b); truth.append(inl)
+        start.append(start[-1] + n)
+        wh.append((wi, hi, wj, hj))
+    cat = lambda v, w: np.ascontiguousarray(np.concatenate(v) if v else np.zeros((0, w)), dtype=np.float64)   # noqa: E731
+    return dict(xI=cat(xs_i, 2).reshape(-1, 2), xJ=cat(xs_j, 2).reshape(-1, 2), start=np.asarray(start, np.uint64),
+                wh=np.asarray(wh, np.uint32).reshape(-1, 4), is_inlier=np.concatenate(truth) if truth else np.zeros(0, bool))
+
+
 def two_view_matches_bulk(n_pairs, n=250, seed=0, inlier_frac=(0.3, 0.9), noise_px=0.4, no_geometry_frac=0.25, size=(1000, 1000)):
     """The same kind of scene as two_view_matches with n correspondences in every pair, generated in bulk (bench workloads)."""
     rng = np.random.default_rng(seed)

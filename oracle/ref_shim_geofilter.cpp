@@ -19,22 +19,19 @@
 #include <omp.h>
 
 #include "openMVG/multiview/solver_fundamental_kernel.hpp"
+#include "openMVG/multiview/solver_homography_kernel.hpp"
 #include "openMVG/numeric/numeric.h"
 #include "openMVG/robust_estimation/robust_estimator_ACRansac.hpp"
 #include "openMVG/robust_estimation/robust_estimator_ACRansacKernelAdaptator.hpp"
 
 using namespace openMVG;
 
-extern "C" {
-
-// pairs: for pair p the correspondences [start[p], start[p + 1]) of xI / xJ (2 doubles each, pixels), image sizes wh[4 p ..] =
-// {w_I, h_I, w_J, h_J}. Outputs: inlier_mask per correspondence (1: geometric inlier of a pair whose estimation succeeded),
-// ok[p] (Robust_estimation returned true), F[9 p ..] row-major (m_F), prec[p] (m_dPrecision_robust = ACRansacOut.first),
-// nfa[p] (ACRansacOut.second). Returns the seconds spent.
-double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
-                                double precision, uint32_t max_iterations, int num_threads, uint8_t* inlier_mask, uint8_t* ok, double* F,
-                                double* prec, double* nfa) {
-  using KernelType = robust::ACKernelAdaptor<fundamental::kernel::SevenPointSolver, fundamental::kernel::EpipolarDistanceError, UnnormalizerT, Mat3>;
+// One robust estimation per pair with the given kernel adaptor (F: point-to-line, H: point-to-point), as the functors'
+// Robust_estimation members run it.
+template <typename KernelType>
+static double run_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs, double precision,
+                           uint32_t max_iterations, int num_threads, bool point_to_line, uint8_t* inlier_mask, uint8_t* ok, double* F, double* prec,
+                           double* nfa) {
   const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(dynamic) num_threads(num_threads > 0 ? num_threads : omp_get_max_threads())
   for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
@@ -46,11 +43,11 @@ double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64
     }
     std::memset(inlier_mask + lo, 0, n);
     Mat3 model = Mat3::Identity();
-    const KernelType kernel(x1, wh[4 * p], wh[4 * p + 1], x2, wh[4 * p + 2], wh[4 * p + 3], true);
-    const double upper_bound_precision = Square(precision);   // F_ACRobust.hpp:98
+    const KernelType kernel(x1, wh[4 * p], wh[4 * p + 1], x2, wh[4 * p + 2], wh[4 * p + 3], point_to_line);
+    const double upper_bound_precision = Square(precision);   // F_ACRobust.hpp:98, H_ACRobust.hpp:92
     std::vector<uint32_t> vec_inliers;
     const std::pair<double, double> out = robust::ACRANSAC(kernel, vec_inliers, max_iterations, &model, upper_bound_precision);
-    const bool good = vec_inliers.size() > KernelType::MINIMUM_SAMPLES * 2.5;   // F_ACRobust.hpp:103
+    const bool good = vec_inliers.size() > KernelType::MINIMUM_SAMPLES * 2.5;   // F_ACRobust.hpp:103, H_ACRobust.hpp:98
     ok[p] = good ? 1 : 0;
     prec[p] = out.first; nfa[p] = out.second;
     for (int r = 0; r < 3; ++r)
@@ -59,6 +56,28 @@ double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64
       for (const uint32_t idx : vec_inliers) inlier_mask[lo + idx] = 1;
   }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+extern "C" {
+
+// pairs: for pair p the correspondences [start[p], start[p + 1]) of xI / xJ (2 doubles each, pixels), image sizes wh[4 p ..] =
+// {w_I, h_I, w_J, h_J}. Outputs: inlier_mask per correspondence (1: geometric inlier of a pair whose estimation succeeded),
+// ok[p] (Robust_estimation returned true), F[9 p ..] row-major (m_F), prec[p] (m_dPrecision_robust = ACRansacOut.first),
+// nfa[p] (ACRansacOut.second). Returns the seconds spent.
+double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
+                                double precision, uint32_t max_iterations, int num_threads, uint8_t* inlier_mask, uint8_t* ok, double* F,
+                                double* prec, double* nfa) {
+  using KernelType = robust::ACKernelAdaptor<fundamental::kernel::SevenPointSolver, fundamental::kernel::EpipolarDistanceError, UnnormalizerT, Mat3>;
+  return run_acransac<KernelType>(xI, xJ, start, wh, n_pairs, precision, max_iterations, num_threads, true, inlier_mask, ok, F, prec, nfa);
+}
+
+// the same for GeometricFilter_HMatrix_AC::Robust_estimation (matching_image_collection/H_ACRobust.hpp:49-113): the homography
+// kernel, "configure as point to point error model"; F receives m_H
+double ref_geofilter_h_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
+                                double precision, uint32_t max_iterations, int num_threads, uint8_t* inlier_mask, uint8_t* ok, double* F,
+                                double* prec, double* nfa) {
+  using KernelType = robust::ACKernelAdaptor<homography::kernel::FourPointSolver, homography::kernel::AsymmetricError, UnnormalizerI, Mat3>;
+  return run_acransac<KernelType>(xI, xJ, start, wh, n_pairs, precision, max_iterations, num_threads, false, inlier_mask, ok, F, prec, nfa);
 }
 
 }  // extern "C"
@@ -70,6 +89,7 @@ double ref_geofilter_f_acransac(const double* xI, const double* xJ, const uint64
 #include "openMVG/cameras/Camera_Pinhole_Radial.hpp"
 #include "openMVG/features/regions_factory.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
+#include "openMVG/matching_image_collection/H_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
 #include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
 #include "openMVG/sfm/sfm_data.hpp"
@@ -81,16 +101,16 @@ struct InMemoryRegionsProvider : public sfm::Regions_Provider {
 };
 }  // namespace
 
-extern "C" {
-typedef void (*geo_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
+extern "C" typedef void (*geo_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
 
 // images: feat_xy (2 floats per feature, image k owning [feat_start[k], feat_start[k + 1])), descs (128 bytes per feature or NULL),
 // image_wh (w, h per image); k1 != 0: all views share one Pinhole_Intrinsic_Radial_K1 (the positions are then undistorted by
 // MatchesPairToMat). putative matches: pairs_IJ, match_start, matches_ij (feature indices). The geometric matches are handed to
 // `sink` in container order. Returns the number of pairs in the result.
-uint64_t ref_geofilter_container(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
-                                 const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
-                                 double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
+template <class Functor>
+static uint64_t container_impl(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                               const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                               double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
   sfm::SfM_Data scene;
   auto provider = std::make_shared<InMemoryRegionsProvider>();
   provider->set_type(new features::SIFT_Regions());
@@ -117,7 +137,7 @@ uint64_t ref_geofilter_container(const float* feat_xy, const uint8_t* descs, con
   }
   std::shared_ptr<sfm::Regions_Provider> base = provider;
   matching_image_collection::ImageCollectionGeometricFilter filter(&scene, base);
-  filter.Robust_model_estimation(matching_image_collection::GeometricFilter_FMatrix_AC(precision, max_iterations), putative, guided != 0, distance_ratio);
+  filter.Robust_model_estimation(Functor(precision, max_iterations), putative, guided != 0, distance_ratio);
   const matching::PairWiseMatches& out = filter.Get_geometric_matches();
   std::vector<uint32_t> buf;
   for (const auto& kv : out) {
@@ -126,5 +146,20 @@ uint64_t ref_geofilter_container(const float* feat_xy, const uint8_t* descs, con
     sink(user, kv.first.first, kv.first.second, buf.data(), (uint32_t)kv.second.size());
   }
   return out.size();
+}
+
+extern "C" {
+uint64_t ref_geofilter_container(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                 const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                 double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
+  return container_impl<matching_image_collection::GeometricFilter_FMatrix_AC>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
+                                                                               n_pairs, precision, max_iterations, guided, distance_ratio, k1, sink, user);
+}
+// the same caller with the homography functor (H_ACRobust.hpp)
+uint64_t ref_geofilter_container_h(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                   const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                   double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
+  return container_impl<matching_image_collection::GeometricFilter_HMatrix_AC>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
+                                                                               n_pairs, precision, max_iterations, guided, distance_ratio, k1, sink, user);
 }
 }  // extern "C"

@@ -5,8 +5,9 @@ import numpy as np
 from openmvg_amd import synth
 
 
-def collection(n_pairs=12, seed=5, n_max=120, size=(1000, 1000), **kw):
-    tv = synth.two_view_matches(n_pairs, seed=seed, n_max=n_max, tiny_frac=0.1, sizes=(size,), **kw)
+def collection(n_pairs=12, seed=5, n_max=120, size=(1000, 1000), homography=False, **kw):
+    gen = synth.two_view_homography_matches if homography else synth.two_view_matches
+    tv = gen(n_pairs, seed=seed, n_max=n_max, tiny_frac=0.1, sizes=(size,), **kw)
     start = tv["start"].astype(np.int64)
     feats, putative = [], {}
     for p in range(n_pairs):   # images 2 p and 2 p + 1

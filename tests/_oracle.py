@@ -708,6 +708,14 @@ def ref_geofilter(tv, precision=4.0, max_iterations=2048, threads=0):
     return _geofilter_call(_refgeo.ref_geofilter_f_acransac, tv, precision, max_iterations, threads)
 
 
+def ref_geofilter_h(tv, precision=4.0, max_iterations=2048, threads=0):
+    """The reference's ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI> (point-to-point) + ACRANSAC per pair; "F" = m_H."""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    return _geofilter_call(_refgeo.ref_geofilter_h_acransac, tv, precision, max_iterations, threads)
+
+
 def port_geofilter(tv, precision=4.0, max_iterations=2048):
     """oracle/geofilter_oracle.cpp, the plain C++ restatement (one thread)."""
     return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)
@@ -742,7 +750,7 @@ def geofilter_container_lib(kind):
     return lib
 
 
-def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None):
+def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None, model="f"):
     """feats_xy: list of (n_k, 2) float32 positions; image_wh: (n_images, 2); putative: {(I, J): (n, 2) uint32}. -> {(I, J): (m, 2)}"""
     lib = geofilter_container_lib(kind)
     fx = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float32).reshape(-1, 2) for f in feats_xy]), np.float32)
@@ -760,7 +768,9 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
 
     cb = GEO_SINK(sink)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-    lib.ref_geofilter_container(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij),
+    fn = lib.ref_geofilter_container if model == "f" else lib.ref_geofilter_container_h
+    fn.restype = C.c_uint64
+    fn(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij),
                                 C.c_uint64(len(keys)), C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if guided else 0),
                                 C.c_double(ratio), C.c_double(k1), cb, None)
     return out

@@ -1,0 +1,136 @@
+"""Geometric filter, homography model (GeometricFilter_HMatrix_AC): the device path of mvgx_geofilter_h_acransac
+against the compiled reference's own kernel adaptor + ACRANSAC (oracle/_ref/libref_geofilter.so::ref_geofilter_h_acransac) and
+against its stored outputs (tests/golden/geofilter_h.npz, tests/golden/make_geofilter_h_golden.py). Parity policy of
+tests/_geofilter_cases.py: identical inlier sets, then NFA equal to 1e-9, precision equal, H equal to 1e-6 after normalisation; the
+share of pairs that differ is counted and bounded. There is no separate C restatement of this model: the checker is the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from openmvg_amd import geofilter, synth
+from tests import _emu, _geofilter_cases as gc, _oracle
+
+GOLD_H = np.load(os.path.join(os.path.dirname(__file__), "golden", "geofilter_h.npz"))
+FUNCTOR = geofilter.GeometricFilter_HMatrix_AC
+
+
+def _gold_tv(sel=None):
+    start = GOLD_H["start"].astype(np.int64)
+    idx = list(range(len(start) - 1)) if sel is None else list(sel)
+    st = np.cumsum([0] + [int(start[p + 1] - start[p]) for p in idx]).astype(np.uint64)
+    cat = lambda key: np.concatenate([GOLD_H[key][start[p]:start[p + 1]] for p in idx])   # noqa: E731
+    tv = dict(xI=cat("xI"), xJ=cat("xJ"), start=st, wh=GOLD_H["wh"][idx].astype(np.uint32))
+    ref = dict(mask=cat("mask"), ok=GOLD_H["ok"][idx], F=GOLD_H["F"][idx], precision=GOLD_H["precision"][idx], nfa=GOLD_H["nfa"][idx])
+    return tv, ref
+
+
+def test_emulated_device_code_equals_the_stored_reference_outputs():
+    """the kernel under tests/native/hipemu on a handful of golden pairs: empty pairs, successful ones, pairs without a homography,
+    one with five correspondences (just above the minimal sample)"""
+    start = GOLD_H["start"].astype(np.int64)
+    n = np.diff(start)
+    small = [int(p) for p in np.argsort(n) if n[p] <= 70]
+    sel = small[:2] + [p for p in small if GOLD_H["ok"][p]][:4] + [p for p in small if not GOLD_H["ok"][p] and n[p] > 4][:2]
+    tv, ref = _gold_tv(sel)
+    with _emu.emulated():
+        mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, 2048))
+    differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert not differing and rep["pairs_ok_reference"] >= 3, (rep, differing)
+    assert int(st.n_pairs_estimated) == int((n[sel] > 4).sum())
+
+
+def test_emulated_indexed_form_equals_the_gathered_form():
+    rng = np.random.default_rng(12)
+    tv = synth.two_view_homography_matches(3, seed=31, n_min=20, n_max=40, tiny_frac=0.0, no_geometry_frac=0.0)
+    # three images per pair would be the general case; here pair p joins images 2 p and 2 p + 1 and lists its matches in shuffled order
+    feats, ij, sizes, pairs = [], [], [], []
+    st = tv["start"].astype(np.int64)
+    for p in range(3):
+        a, b = tv["xI"][st[p]:st[p + 1]], tv["xJ"][st[p]:st[p + 1]]
+        pa, pb = rng.permutation(len(a)), rng.permutation(len(b))
+        fa = np.zeros_like(a); fa[pa] = a
+        fb = np.zeros_like(b); fb[pb] = b
+        feats += [fa, fb]; ij.append(np.stack([pa, pb], 1)); sizes += [tv["wh"][p][:2], tv["wh"][p][2:]]; pairs.append((2 * p, 2 * p + 1))
+    with _emu.emulated():
+        m1, r1, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, 256))
+        m2, r2, _ = geofilter.filter_pairs_indexed(feats, np.array(sizes), np.array(pairs), tv["start"], np.concatenate(ij), FUNCTOR(4.0, 256))
+    assert np.array_equal(m1, m2) and np.array_equal(r1["F"], r2["F"]) and np.array_equal(r1["nfa"], r2["nfa"]) and r1["ok"].all()
+
+
+@pytest.mark.gpu
+def test_golden_fixture_inlier_sets_on_the_device():
+    tv, ref = _gold_tv()
+    mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(float(GOLD_H["precision_px"]), int(GOLD_H["max_iterations"])))
+    differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.02 * rep["pairs"], (rep, differing)
+    assert int(st.n_pairs) == rep["pairs"] and st.kernel_ms > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,iters", [(dict(seed=5, n_max=400), 2048), (dict(seed=6, n_max=120, inlier_frac=(0.15, 0.5)), 1024),
+                                      (dict(seed=7, n_max=200), 37), (dict(seed=8, n_min=1100, n_max=1300, tiny_frac=0.0), 2048)])
+def test_against_the_compiled_reference(kw, iters):
+    """mixed sizes (three LDS classes), low inlier ratios, an iteration budget that ends inside the warm-up"""
+    if not _oracle.have_ref_geofilter():
+        pytest.skip("oracle/_ref/libref_geofilter.so not built")
+    n_pairs = 60 if kw.get("n_min", 0) > 1000 else 1200
+    tv = synth.two_view_homography_matches(n_pairs, **kw)
+    ref = _oracle.ref_geofilter_h(tv, 4.0, iters)
+    mask, res, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, iters))
+    differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert len(differing) <= max(1, 0.02 * rep["pairs"]), (rep, differing[:10])
+    truth_kept = (mask & tv["is_inlier"]).sum() / max(1, (tv["is_inlier"] & np.repeat(ref["ok"], np.diff(tv["start"].astype(np.int64)))).sum())
+    assert truth_kept > 0.7 or iters < 100   # (the a-contrario precision is tighter than the 4 px bound: part of the noisy true matches fall outside it)
+
+
+@pytest.mark.gpu
+def test_pairs_beyond_the_lds_classes_and_degenerate_inputs():
+    """a pair with more than 12 000 correspondences (tables in global scratch) beside small ones; pairs of 4 and 5 correspondences;
+    identical points; all points on one line (rank-deficient DLT systems: any null vector is a model, none may crash or be accepted
+    where the reference rejects)"""
+    rng = np.random.default_rng(3)
+    big = synth.two_view_homography_matches(1, seed=99, n_min=12500, n_max=12500, tiny_frac=0.0, no_geometry_frac=0.0, sizes=((4000, 3000),))
+    blocks_i = [big["xI"], rng.uniform(0, 900, (4, 2)), rng.uniform(0, 900, (5, 2)), np.tile([[100.0, 200.0]], (30, 1)),
+                np.stack([np.linspace(0, 900, 40), np.linspace(0, 900, 40)], 1)]
+    blocks_j = [big["xJ"]] + [b + rng.normal(0, 0.3, b.shape) for b in blocks_i[1:]]
+    xI, xJ = np.concatenate(blocks_i), np.concatenate(blocks_j)
+    start = np.cumsum([0] + [len(b) for b in blocks_i]).astype(np.uint64)
+    wh = np.array([[4000, 3000, 4000, 3000]] + [[1000, 1000, 1000, 1000]] * 4, np.uint32)
+    mask, res, st = geofilter.filter_pairs(xI, xJ, start, wh, FUNCTOR(4.0, 1024))
+    assert res["ok"][0] and not res["ok"][1] and np.array_equal(res["F"][1], np.eye(3)) and not mask[start[1]:start[2]].any()
+    if _oracle.have_ref_geofilter():
+        ref = _oracle.ref_geofilter_h(dict(xI=xI, xJ=xJ, start=start, wh=wh), 4.0, 1024)
+        assert np.array_equal(ref["ok"][:3], res["ok"][:3])
+        lo, hi = int(start[0]), int(start[1])
+        assert np.array_equal(ref["mask"][lo:hi], mask[lo:hi]) or (ref["mask"][lo:hi] != mask[lo:hi]).mean() < 1e-3
+
+
+def _container_case(kind, guided=False):
+    from tests import _geofilter_scene
+    ref_lib, lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib(kind)
+    if ref_lib is None or lib is None or not hasattr(ref_lib, "ref_geofilter_container_h"):
+        pytest.skip("needs the reference library and the adapter harness (tools/prep_gpu.sh)")
+    big = kind == "adapter"
+    feats, wh, putative = _geofilter_scene.collection(n_pairs=40 if big else 5, seed=9, n_min=40, n_max=200 if big else 60, inlier_frac=(0.6, 0.9),
+                                                      no_geometry_frac=0.2, homography=True)
+    for k1 in (0.0, 0.02):
+        want = _oracle.geofilter_container("reference", feats, wh, putative, max_iterations=512, k1=k1, model="h", guided=guided)
+        got = _oracle.geofilter_container(kind, feats, wh, putative, max_iterations=512, k1=k1, model="h", guided=guided)
+        assert set(want) == set(got) and len(want) >= 2
+        n_same = sum(np.array_equal(want[k], got[k]) for k in want)
+        assert n_same >= len(want) - (1 if big else 0), (n_same, len(want))
+
+
+def test_adapter_specialisation_fills_the_container_like_the_reference_template():
+    """ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMatrix_AC>: the same caller code
+    (oracle/ref_shim_geofilter.cpp::ref_geofilter_container_h) linked against the reference header's template and against the explicit
+    specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp (device code under the HIP emulation): same pairs in the container,
+    same match lists, with and without a distorting intrinsic"""
+    _container_case("adapter_emu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("guided", [False, True])
+def test_adapter_specialisation_on_the_device(guided):
+    _container_case("adapter", guided)
