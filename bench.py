@@ -298,6 +298,7 @@ def main():
         try:   # the step after putative matching
             from bench_geofilter import geofilter_bench_record
             out["geometric_filter"] = geofilter_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+            out["geometric_filter_homography"] = geofilter_bench_record(local_rank, n_pairs=20000, cpu=not args.no_cpu_baseline, cpu_pairs=3000, model="h")
         except Exception as e:
             out["geometric_filter"] = {"status": f"failed: {e!r}"}
     if rank == 0:

@@ -15,10 +15,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, cpu_pairs=6000):
+def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, cpu_pairs=6000, model="f"):
+    """model "f": GeometricFilter_FMatrix_AC; "h": GeometricFilter_HMatrix_AC (H_ACRobust.hpp) on pairs related by homographies"""
     from openmvg_amd import geofilter, synth
-    tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
-    fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
+    if model == "h":
+        tv = synth.two_view_homography_matches(n_pairs, seed=0x6E0F, n_min=n, n_max=n, tiny_frac=0.0)
+        fun = geofilter.GeometricFilter_HMatrix_AC(4.0, 2048)
+    else:
+        tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
+        fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
     geofilter.filter_pairs(tv["xI"][:n * 512], tv["xJ"][:n * 512], tv["start"][:513], tv["wh"][:512], fun, device)   # warm-up
     kernel_ms = total_ms = 0.0
     t0 = time.perf_counter()
@@ -26,7 +31,7 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
         mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun, device)
         kernel_ms += st.kernel_ms; total_ms += st.total_ms
     dt = time.perf_counter() - t0
-    rec = {"metric": "image pairs/s (a-contrario fundamental-matrix filter of putative matches)", "value": n_pairs * steps / (kernel_ms * 1e-3),
+    rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (kernel_ms * 1e-3),
            "unit": "image pairs/s (device kernel time)", "dtype": "f64",
            "config": {"workload": f"{n_pairs} image pairs x {n} putative matches (25 % of the pairs without geometry, the others 30-90 % inliers, "
                                   f"0.4 px noise), precision 4 px, 2048 iterations", "pairs_accepted": int(st.n_pairs_ok), "inliers": int(st.n_inliers)},
@@ -39,11 +44,12 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
             if _oracle.have_ref_geofilter():
                 m = min(cpu_pairs, n_pairs)
                 sub = dict(xI=tv["xI"][:n * m], xJ=tv["xJ"][:n * m], start=tv["start"][:m + 1], wh=tv["wh"][:m])
-                _oracle.ref_geofilter(dict(xI=sub["xI"][:n * 64], xJ=sub["xJ"][:n * 64], start=sub["start"][:65], wh=sub["wh"][:64]))
-                ref = _oracle.ref_geofilter(sub)
+                ref_fn = _oracle.ref_geofilter_h if model == "h" else _oracle.ref_geofilter
+                ref_fn(dict(xI=sub["xI"][:n * 64], xJ=sub["xJ"][:n * 64], start=sub["start"][:65], wh=sub["wh"][:64]))
+                ref = ref_fn(sub)
                 rec["cpu_baseline"] = {"value": m / ref["seconds"], "unit": "image pairs/s", "cores": os.cpu_count(), "kind": "reference",
-                                       "sample": f"the first {m} pairs of the same set in {ref['seconds']:.1f} s (ACKernelAdaptor<SevenPointSolver, "
-                                                 f"EpipolarDistanceError> + ACRANSAC, OpenMP over the pairs)"}
+                                       "sample": f"the first {m} pairs of the same set in {ref['seconds']:.1f} s (ACKernelAdaptor<"
+                                                 f"{'FourPointSolver, AsymmetricError' if model == 'h' else 'SevenPointSolver, EpipolarDistanceError'}> + ACRANSAC, OpenMP over the pairs)"}
                 rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
                 differing, rep = gc.compare(sub["start"], ref, mask[:n * m], res["ok"][:m], res["F"][:m], res["precision_robust"][:m], res["nfa"][:m])
                 rec["parity"] = dict(rep, policy="identical inlier sets (then NFA, precision equal and F equal to 1e-6 - asserted); pairs_differing = "
