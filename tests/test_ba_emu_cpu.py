@@ -559,6 +559,22 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert abs(s_g.final_rmse - osum.final_rmse) < 1e-9
 
 
+def test_candidate_cost_from_the_back_substitution_pass_equals_the_separate_passes(monkeypatch):
+    """every point grouped: x + delta and its cost come from the back-substitution pass of the point groups (weights, a Huber-active
+    outlier share, two intrinsics); MVGX_BA_SEPARATE_COST=1 keeps ba_step_scalars_kernel + ba_linearize_kernel<false> - same trajectory"""
+    sc = synth.ba_scene(n_cams=8, n_points=120, track_len=5, model=3, n_intr_groups=2, seed=131, outlier_frac=0.05)
+    opt = ba.default_options(max_num_iterations=4)
+    with _emu.emulated():
+        c = ba.BaContext(sc); s_a = c.solve(opt); pa, ia, xa = c.read_params(); info = c.solver_info(); c.close()
+        monkeypatch.setenv("MVGX_BA_SEPARATE_COST", "1")
+        c = ba.BaContext(sc); s_b = c.solve(opt); pb, ib, xb = c.read_params(); c.close()
+    assert info.n_grouped_points == 120
+    assert s_a.num_iterations == s_b.num_iterations and abs(s_a.final_cost - s_b.final_cost) <= 1e-12 * s_b.final_cost
+    assert np.allclose(pa, pb, atol=1e-10) and np.allclose(ia, ib, rtol=1e-10, atol=1e-10) and np.allclose(xa, xb, atol=1e-9)
+    rc, osum, *_ = _oracle.port_ba_solve(sc, opt)
+    assert abs(s_a.final_rmse - osum.final_rmse) < 1e-9
+
+
 @pytest.mark.parametrize("devices", [None, [0, 0]])
 def test_model_cost_from_the_normal_equations_equals_the_jacobian_form(devices, monkeypatch):
     """model_cost_change of trust_region_minimizer.cc:402-405, -(J s)^T (r + J s / 2), is evaluated as (s^T D^2 s - s^T g) / 2 from the

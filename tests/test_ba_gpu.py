@@ -380,6 +380,26 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert s_g.num_iterations == osum.num_iterations and abs(s_g.final_rmse - osum.final_rmse) < RMSE_TOL
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_cams=60, n_points=6000, track_len=10, model=3, n_intr_groups=2, seed=121, outlier_frac=0.02),
+    dict(n_cams=30, n_points=2500, track_len=6, model=7, n_intr_groups=1, seed=122),      # spherical: the generic kernel variants
+    dict(n_cams=40, n_points=3000, track_len=8, model=1, n_intr_groups=1, seed=123),
+])
+def test_candidate_cost_from_the_back_substitution_pass_equals_the_separate_passes(kw, monkeypatch):
+    """every point grouped: the back-substitution pass forms x + delta and its cost itself (ba_point_group_kernel<kGroupBacksub> with
+    cand_part, ba_step_scalars_cam_kernel, ba_step_reduce_kernel; the Gram finish launch forms the cameras' LM diagonal). The
+    passes of old (MVGX_BA_SEPARATE_COST=1: ba_step_scalars_kernel + ba_linearize_kernel<false>) must give the same trajectory."""
+    sc = synth.ba_scene(**kw)
+    c = ba.BaContext(sc); s_a = c.solve(); pa, ia, xa = c.read_params(); info = c.solver_info(); c.close()
+    assert info.n_grouped_points == kw["n_points"]
+    monkeypatch.setenv("MVGX_BA_SEPARATE_COST", "1")
+    c = ba.BaContext(sc); s_b = c.solve(); pb, ib, xb = c.read_params(); c.close()
+    assert s_a.num_iterations == s_b.num_iterations and abs(s_a.final_cost - s_b.final_cost) <= 1e-11 * s_b.final_cost
+    assert np.allclose(pa, pb, atol=1e-9) and np.allclose(ia, ib, rtol=1e-9, atol=1e-9) and np.allclose(xa, xb, atol=1e-8)
+    rc, osum, *_ = _oracle.port_ba_solve(sc)
+    assert s_a.num_iterations == osum.num_iterations and abs(s_a.final_rmse - osum.final_rmse) < RMSE_TOL
+
+
 def test_factor_and_invert_kernel_against_numpy():
     """the 64 x 64 Cholesky + inverse workgroup kernel (panel chain on one wave, blocked inverse on the other three) on its own:
     full, partial (identity-padded) and tiny blocks"""
