@@ -1012,6 +1012,35 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
   }
 }
 
+// 1 / sqrt(x): v_rsq_f64 + two Newton steps (full precision for finite x > 0)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  r = fma(fma(-hx * r, r, 0.5), r, r);
+  r = fma(fma(-hx * r, r, 0.5), r, r);
+  return r;
+}
+// chol_inv3 (ba_math.h) for the point threads of ba_point_group_kernel: the three pivots through 1 / sqrt - no square root, no
+// division (their IEEE sequences are ~20 dependent instructions each, and the phase runs on one lane in eight while the rest of the
+// workgroup waits at the barrier). Same quantities to rounding.
+__device__ __forceinline__ bool chol_inv3_fast(const double v[6], double li[6]) {
+  if (!(v[0] > 0.0)) return false;
+  const double i00 = fast_rsqrt(v[0]);
+  const double l10 = v[1] * i00, l20 = v[2] * i00;
+  const double d1 = v[3] - l10 * l10;
+  if (!(d1 > 0.0)) return false;
+  const double i11 = fast_rsqrt(d1);
+  const double l21 = (v[4] - l20 * l10) * i11;
+  const double d2 = v[5] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0.0)) return false;
+  const double i22 = fast_rsqrt(d2);
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  li[0] = i00; li[1] = i10; li[2] = i11; li[3] = i20; li[4] = i21; li[5] = i22;
+  return true;
+}
+
 // One workgroup per supergroup, one thread per observation of the current group. MODE:
 //   kGroupNorms    column norms and gradient of the points (iteration zero: the Jacobi scaling needs the norms first)
 //   kGroupForward  per point V = Es^T Es + D^2 = L L^T, h = L^-1 Es^T r, Z = L^-1 Es^T Fs; S -= Z^T Z, rhs -= Z^T h as
@@ -1233,7 +1262,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
         for (int c = 0; c < 3; ++c) dg[c] = fmin(fmax(sm[9 + c] * my_sp[c] * my_sp[c], dmin), dmax);
         V[0] += dg[0] * inv_radius; V[3] += dg[1] * inv_radius; V[5] += dg[2] * inv_radius;
-        if (!chol_inv3(V, li6)) { atomicExch(d.fail, 1); for (int c = 0; c < 6; ++c) li6[c] = 0.0; }
+        if (!chol_inv3_fast(V, li6)) { atomicExch(d.fail, 1); for (int c = 0; c < 6; ++c) li6[c] = 0.0; }
         double* __restrict__ pt = ptab + tid * 12;
 #pragma unroll
         for (int c = 0; c < 6; ++c) pt[c] = li6[c];

@@ -95,6 +95,7 @@ static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); ret
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
 static inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &b, 8); return d; }
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
+#define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))   /* v_rsq_f64: refined on the device likewise */
 
 static inline int atomicExch(int* p, int v) { const int o = *p; *p = v; return o; }
 static inline void __threadfence_system() {}
