@@ -1950,6 +1950,52 @@ __device__ __forceinline__ void sp_gemm_task(const SpSys& s, int task) {   // on
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = kUpdate ? old[reg] - acc[reg] : acc[reg];
 }
+// A level with ONE tile column k (the chain at the top of the elimination tree): its update tasks need nothing but the tiles A_ik,
+// A_jk below the diagonal and Linv_k - the two 16-row strips of L they multiply are rebuilt in registers exactly as the T task
+// forms them (same MFMA order, so the same bits): lane (li, lk) of the T product D[c][r] ends up holding L(16 b + li, 16 cb + lk +
+// 4 reg), which IS the operand element of k-step 4 cb + reg of the update product - no exchange between lanes. The T tasks (the
+// stored L tiles are still needed by the reverse sweep) then run beside the update tasks in one launch instead of in front of them:
+// one launch boundary less per chain level.
+__device__ __forceinline__ void sp_strip_from_a(const double* __restrict__ X, const double* __restrict__ Linv, int li, int lk, double (&strip)[16]) {
+  double xv[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) xv[ks] = X[ks * 256];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const double* __restrict__ Y = Linv + 16 * cb + li + lk * 64;
+    double yv[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) yv[ks] = ks < 4 * (cb + 1) ? Y[ks * 256] : 0.0;
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < 4 * (cb + 1)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[ks], xv[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) strip[4 * cb + reg] = acc[reg];
+  }
+}
+__global__ __launch_bounds__(256) void sp_chain_level_kernel(SpSys s, int t0, int n_t, int u0, int n_u, int k) {
+  const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (t >= n_t + n_u) return;   // wave-uniform
+  if (t >= n_u) { sp_gemm_task<false>(s, t0 + (t - n_u)); return; }   // (the update tasks first: they are what the next level waits for)
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const mvgx_sparse::GemmTask g = s.u_tasks[u0 + t];
+  const mvgx_sparse::SlotPair p = s.u_pairs[g.c0];   // one contributor: the level's column
+  double* __restrict__ dst = s.A + (size_t)g.dst * 4096 + (size_t)(16 * g.bj + lk) * 64 + 16 * g.bi + li;
+  double old[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) old[reg] = dst[reg * 256];
+  const double* __restrict__ Linv = s.Linv + (size_t)k * 4096;
+  double la[16], lb[16];
+  sp_strip_from_a(s.A + (size_t)p.a * 4096 + 16 * g.bi + li + lk * 64, Linv, li, lk, la);
+  sp_strip_from_a(s.A + (size_t)p.b * 4096 + 16 * g.bj + li + lk * 64, Linv, li, lk, lb);
+  d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[ks], la[ks], acc, 0, 0, 0);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = old[reg] - acc[reg];
+}
+
 template <bool kUpdate>
 __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tasks) {
   const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -2791,6 +2837,7 @@ struct mvgx_ba_ctx {
   bool solver_ready = false;
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
   bool diag_blocks_complete = false;   // every pose / intrinsic block has a diagonal destination block in the assemble lists
+  int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
   bool all_points_grouped = false;   // every point is in a group: the per-point kernels of the record path have nothing to do
@@ -3030,6 +3077,11 @@ int factor_and_solve_sparse(mvgx_ba_ctx* c) {
   for (int l = 0; l < pl.n_levels; ++l) {
     const int nf = pl.f_start[l + 1] - pl.f_start[l], nt = pl.t_start[l + 1] - pl.t_start[l], nu = pl.u_start[l + 1] - pl.u_start[l];
     hipLaunchKernelGGL(sp_factor_kernel, dim3(nf), dim3(256), kDiagLds, c->stream, d.sp, pl.f_start[l], d.fail);
+    if (nf == 1 && nu && nu <= c->chain_fuse_max_tasks) {   // a chain level: panel and update tasks in one launch (sp_chain_level_kernel)
+      hipLaunchKernelGGL(sp_chain_level_kernel, dim3((nt + nu + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.t_start[l], nt, pl.u_start[l], nu,
+                         pl.f_cols[pl.f_start[l]]);
+      continue;
+    }
     if (nt) hipLaunchKernelGGL(sp_gemm_kernel<false>, dim3((nt + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.t_start[l], nt);
     if (nu) hipLaunchKernelGGL(sp_gemm_kernel<true>, dim3((nu + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.u_start[l], nu);
   }
@@ -3610,6 +3662,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) { (void)hipGetLastError(); c->poll_scalars = false; }
   if (const char* env = getenv("MVGX_BA_POLL_SCALARS")) c->poll_scalars = c->poll_scalars && atoi(env) != 0;
   if (const char* env = getenv("MVGX_BA_SEPARATE_COST")) c->fold_candidate = atoi(env) == 0;
+  if (const char* env = getenv("MVGX_BA_CHAIN_FUSE")) c->chain_fuse_max_tasks = atoi(env);
   tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
