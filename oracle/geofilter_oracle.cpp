@@ -19,6 +19,14 @@
 //   std::mt19937 (default seed 5489) and libstdc++ 11's std::uniform_int_distribution<uint32_t> on a 32-bit engine
 //   (bits/uniform_int_dist.h: Lemire's multiply-shift with rejection) - the sample sequence is part of the result.
 //
+// The homography model (port_geofilter_h_acransac) shares everything above but the kernel adaptor:
+//   matching_image_collection/H_ACRobust.hpp:49-113             GeometricFilter_HMatrix_AC::Robust_estimation (point-to-point, 2.5 x 4)
+//   multiview/solver_homography_kernel.cpp:37-93, .hpp:60-64     FourPointSolver (null vector of the 8 x 9 DLT system; the reference: last
+//                                                               right singular vector, numeric/nullspace.cpp:14-32), AsymmetricError
+//   robust_estimator_ACRansacKernelAdaptator.hpp:38-81          logalpha0 / multError of the point-to-point parametrisation
+//   multiview/conditioning.cpp:80-82                            UnnormalizerI
+// Pinned to the compiled reference and its stored outputs by tests/test_geofilter_h.py.
+//
 // One deliberate difference: the reference takes the two-dimensional null space of the 7 x 9 system from
 // Eigen::SelfAdjointEigenSolver on A^T A (its two smallest eigenvectors); here it comes from Householder reflections of A^T (the
 // last two columns of Q), the device code uses complete-pivoting elimination. The three bases span the same plane for a sample in
@@ -79,12 +87,14 @@ float logcombi(uint32_t k, uint32_t n, const std::vector<float>& l10) {
 
 struct Model { double f[9]; };   // row-major 3 x 3
 
-// null space of the 7 x 9 system: A^T = Q R by Householder reflections, the last two columns of Q
-void nullspace7(const double A[7][9], double f1[9], double f2[9]) {
-  double M[9][7];   // A^T
-  for (int r = 0; r < 7; ++r) for (int c = 0; c < 9; ++c) M[c][r] = A[r][c];
-  double V[7][9];   // Householder vectors
-  for (int k = 0; k < 7; ++k) {
+// null space of an R x 9 system (R = 7: seven-point, two vectors; R = 8: four-point DLT, one vector): A^T = Q R by Householder
+// reflections, the last 9 - R columns of Q
+template <int R>
+void nullspace_rows(const double A[R][9], double (*out)[9]) {
+  double M[9][R];   // A^T
+  for (int r = 0; r < R; ++r) for (int c = 0; c < 9; ++c) M[c][r] = A[r][c];
+  double V[R][9];   // Householder vectors
+  for (int k = 0; k < R; ++k) {
     double norm = 0;
     for (int i = k; i < 9; ++i) norm += M[i][k] * M[i][k];
     norm = std::sqrt(norm);
@@ -95,25 +105,30 @@ void nullspace7(const double A[7][9], double f1[9], double f2[9]) {
     for (int i = k; i < 9; ++i) vv += v[i] * v[i];
     for (int i = 0; i < 9; ++i) V[k][i] = v[i];
     if (vv == 0) continue;
-    for (int j = k; j < 7; ++j) {
+    for (int j = k; j < R; ++j) {
       double dot = 0;
       for (int i = k; i < 9; ++i) dot += v[i] * M[i][j];
       const double s = 2 * dot / vv;
       for (int i = k; i < 9; ++i) M[i][j] -= s * v[i];
     }
   }
-  for (int which = 0; which < 2; ++which) {   // Q e_7, Q e_8 with Q = H_0 H_1 ... H_6
+  for (int which = 0; which < 9 - R; ++which) {   // Q e_R .. Q e_8 with Q = H_0 H_1 ... H_(R-1)
     double q[9] = {0};
-    q[7 + which] = 1;
-    for (int k = 6; k >= 0; --k) {
+    q[R + which] = 1;
+    for (int k = R - 1; k >= 0; --k) {
       double vv = 0, dot = 0;
       for (int i = 0; i < 9; ++i) { vv += V[k][i] * V[k][i]; dot += V[k][i] * q[i]; }
       if (vv == 0) continue;
       const double s = 2 * dot / vv;
       for (int i = 0; i < 9; ++i) q[i] -= s * V[k][i];
     }
-    std::memcpy(which ? f2 : f1, q, sizeof(q));
+    std::memcpy(out[which], q, sizeof(q));
   }
+}
+void nullspace7(const double A[7][9], double f1[9], double f2[9]) {
+  double out[2][9];
+  nullspace_rows<7>(A, out);
+  std::memcpy(f1, out[0], sizeof(out[0])); std::memcpy(f2, out[1], sizeof(out[1]));
 }
 
 int solve_cubic(double a, double b, double c, double x[3]) {   // numeric/poly.h:32-75
@@ -174,6 +189,25 @@ inline double epipolar_error(const Model& F, const double* x, const double* y) {
   return dt * dt / (fx0 * fx0 + fx1 * fx1);
 }
 
+// FourPointSolver::Solve (multiview/solver_homography_kernel.cpp:37-93): the null vector of the 8 x 9 DLT system, row-major H
+int four_point(const double* x1, const double* x2, const uint32_t s[4], Model out[1]) {
+  double A[8][9];
+  for (int i = 0; i < 4; ++i) {
+    const double x = x1[2 * s[i]], y = x1[2 * s[i] + 1], u = x2[2 * s[i]], v = x2[2 * s[i] + 1];
+    const double r0[9] = {x, y, 1.0, 0.0, 0.0, 0.0, -u * x, -u * y, -u}, r1[9] = {0.0, 0.0, 0.0, x, y, 1.0, -v * x, -v * y, -v};
+    std::memcpy(A[2 * i], r0, sizeof(r0)); std::memcpy(A[2 * i + 1], r1, sizeof(r1));
+  }
+  double h[1][9];
+  nullspace_rows<8>(A, h);
+  std::memcpy(out[0].f, h[0], sizeof(h[0]));
+  return 1;
+}
+inline double homography_error(const Model& H, const double* x, const double* y) {   // AsymmetricError, solver_homography_kernel.hpp:60-64
+  const double v0 = (H.f[0] * x[0] + H.f[1] * x[1]) + H.f[2], v1 = (H.f[3] * x[0] + H.f[4] * x[1]) + H.f[5], v2 = (H.f[6] * x[0] + H.f[7] * x[1]) + H.f[8];
+  const double dx = y[0] - v0 / v2, dy = y[1] - v1 / v2;
+  return dx * dx + dy * dy;
+}
+
 struct Pair {
   uint32_t n;
   std::vector<double> x1, x2;   // normalised
@@ -186,10 +220,17 @@ struct Pair {
 
 extern "C" {
 
-// same interface as ref_geofilter_f_acransac (oracle/ref_shim_geofilter.cpp), one thread
-double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
-                                 double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
-                                 double* prec, double* nfa_out) {
+}  // extern "C"
+
+namespace {
+// homography = false: ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT> (point to line);
+// homography = true: ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI> configured point to point (H_ACRobust.hpp:77-87)
+double port_acransac(bool homography, const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
+                     double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
+                     double* prec, double* nfa_out) {
+  const uint32_t kMin = homography ? 4 : 7;                 // Solver::MINIMUM_SAMPLES
+  const double max_models = homography ? 1.0 : 3.0;         // Solver::MAX_MODELS
+  const double mult_error = homography ? 1.0 : 0.5;         // ACParametrizationHelper::MultError
   const double inf = std::numeric_limits<double>::infinity();
   for (uint64_t pp = 0; pp < n_pairs; ++pp) {
     const uint64_t lo = start[pp];
@@ -197,7 +238,7 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
     std::memset(inlier_mask + lo, 0, n);
     ok[pp] = 0; prec[pp] = 0.0; nfa_out[pp] = 0.0;   // nData <= sizeSample: {0, 0} (ACRansac.hpp:354-355)
     for (int u = 0; u < 9; ++u) Fout[9 * pp + u] = (u % 4 == 0) ? 1.0 : 0.0;   // m_F = Identity
-    if (n <= 7) continue;
+    if (n <= kMin) continue;
     // ---- ACKernelAdaptor: normalisation by the image sizes (conditioning.cpp:44-53) ----
     double T[2][3];   // {s, tx, ty} of image I / J
     for (int im = 0; im < 2; ++im) {
@@ -211,24 +252,25 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
       x2[2 * i] = T[1][0] * xJ[2 * (lo + i)] + T[1][1]; x2[2 * i + 1] = T[1][0] * xJ[2 * (lo + i) + 1] + T[1][2];
     }
     const int w2 = (int)wh[4 * pp + 2], h2 = (int)wh[4 * pp + 3];
-    const double logalpha0 = std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / T[1][0]);   // point to line
+    const double logalpha0 = homography ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (T[1][0] * T[1][0]))   // point to point
+                                        : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / T[1][0]);   // point to line
     const double upper = precision * precision;
     const bool quantified = upper != inf;
     if (!quantified) continue;   // the exhaustive NFA form (no precision bound) is not restated: main_GeometricFilter always passes one
     const double max_threshold = upper * T[1][0] * T[1][0];
     // ---- NFA_Interface: tables ----
-    const double loge0 = std::log10(3.0 * (n - 7));
+    const double loge0 = std::log10(max_models * (n - kMin));
     std::vector<float> l10(n + 1), logc_n(n + 1), logc_k(n + 1);
     // (the reference calls the unqualified log10 on a float: with <cmath> of libstdc++ that is the C function on a double, rounded to float)
     for (uint32_t i = 0; i <= n; ++i) l10[i] = (float)::log10((double)static_cast<float>(i));
-    for (uint32_t k = 0; k <= n; ++k) { logc_n[k] = logcombi(k, n, l10); logc_k[k] = logcombi(7, k, l10); }
+    for (uint32_t k = 0; k <= n; ++k) { logc_n[k] = logcombi(k, n, l10); logc_k[k] = logcombi(kMin, k, l10); }
     const int nBins = 20;
     const double bins_by_interval = nBins / (max_threshold - 0.0);
     double bin_value[20];
     { const double val = (max_threshold - 0.0) / static_cast<double>(nBins - 1);
       for (int i = 0; i < nBins; ++i) bin_value[i] = val * static_cast<double>(i) + 0.0; }
     // ---- ACRANSAC ----
-    std::vector<uint32_t> vec_index(n), vec_sample(7), vec_inliers;
+    std::vector<uint32_t> vec_index(n), vec_sample(kMin), vec_inliers;
     for (uint32_t i = 0; i < n; ++i) vec_index[i] = i;
     std::vector<double> residuals(n);
     double minNFA = inf, errorMax = inf;
@@ -240,27 +282,27 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
     Mt19937 rng;
     for (unsigned iter = 0; iter < nIter && iter < max_iterations; ++iter) {
       if (ac_mode) {   // rand_sampling.hpp:84-110
-        if (7 <= vec_index.size()) {
+        if (kMin <= vec_index.size()) {
           const uint32_t last = (uint32_t)vec_index.size() - 1;
-          for (uint32_t i = 0; i < 7; ++i) std::swap(vec_index[i], vec_index[uniform_u32(rng, i, last)]);
-          for (int i = 0; i < 7; ++i) vec_sample[i] = vec_index[i];
+          for (uint32_t i = 0; i < kMin; ++i) std::swap(vec_index[i], vec_index[uniform_u32(rng, i, last)]);
+          for (uint32_t i = 0; i < kMin; ++i) vec_sample[i] = vec_index[i];
         }
       } else {   // :43-66
         vec_sample.clear();
-        while (vec_sample.size() < 7) {
+        while (vec_sample.size() < kMin) {
           const uint32_t s = uniform_u32(rng, 0, n - 1);
           if (std::find(vec_sample.begin(), vec_sample.end(), s) == vec_sample.end()) vec_sample.push_back(s);
         }
       }
       Model models[3];
-      const int nm = seven_point(x1.data(), x2.data(), vec_sample.data(), models);
+      const int nm = homography ? four_point(x1.data(), x2.data(), vec_sample.data(), models) : seven_point(x1.data(), x2.data(), vec_sample.data(), models);
       bool better = false;
       for (int mi = 0; mi < nm; ++mi) {
-        for (uint32_t i = 0; i < n; ++i) residuals[i] = epipolar_error(models[mi], &x1[2 * i], &x2[2 * i]);
+        for (uint32_t i = 0; i < n; ++i) residuals[i] = homography ? homography_error(models[mi], &x1[2 * i], &x2[2 * i]) : epipolar_error(models[mi], &x1[2 * i], &x2[2 * i]);
         if (!ac_mode) {
           unsigned nInlier = 0;
           for (uint32_t i = 0; i < n; ++i) nInlier += residuals[i] <= max_threshold;
-          if (nInlier > 2.5 * 7) ac_mode = true;
+          if (nInlier > 2.5 * kMin) ac_mode = true;
         }
         if (ac_mode) {   // ComputeNFA_and_inliers, quantified form (:196-262)
           size_t freq[20] = {0};
@@ -277,16 +319,16 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
           unsigned cum = 0;
           for (int bin = 0; bin < nBins; ++bin) {
             cum += (unsigned)freq[bin];
-            if (cum > 7 && bin_value[bin] > std::numeric_limits<float>::epsilon()) {
-              const double logalpha = logalpha0 + 0.5 * std::log10(bin_value[bin] + std::numeric_limits<float>::epsilon());
-              const double cur = loge0 + logalpha * (double)(cum - 7) + logc_n[cum] + logc_k[cum];
+            if (cum > kMin && bin_value[bin] > std::numeric_limits<float>::epsilon()) {
+              const double logalpha = logalpha0 + mult_error * std::log10(bin_value[bin] + std::numeric_limits<float>::epsilon());
+              const double cur = loge0 + logalpha * (double)(cum - kMin) + logc_n[cum] + logc_k[cum];
               if (cur < cb_nfa && cur < 0) { cb_nfa = cur; cb_thr = bin_value[bin]; }
             }
           }
           if (cb_nfa < minNFA) {
-            vec_inliers.clear();   // (updated even when the function then reports "not better": size <= 7)
+            vec_inliers.clear();   // (updated even when the function then reports "not better": size <= MINIMUM_SAMPLES)
             for (uint32_t i = 0; i < n; ++i) if (residuals[i] <= cb_thr) vec_inliers.push_back(i);
-            if (vec_inliers.size() > 7) {
+            if (vec_inliers.size() > kMin) {
               better = true; minNFA = cb_nfa; errorMax = cb_thr; best = models[mi]; have_model = true;
             }
           }
@@ -308,12 +350,17 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
       // Unnormalize: F = N2^T F N1 (conditioning.cpp:87-89), errorMax -> sqrt(errorMax) / N2(0,0)
       const double N1[9] = {T[0][0], 0, T[0][1], 0, T[0][0], T[0][2], 0, 0, 1}, N2[9] = {T[1][0], 0, T[1][1], 0, T[1][0], T[1][2], 0, 0, 1};
       double tmp[9], res[9];
+      if (homography) {   // UnnormalizerI (conditioning.cpp:80-82): H = N2^-1 H N1
+        const double is = 1.0 / T[1][0];
+        const double N2i[9] = {is, 0, -T[1][1] * is, 0, is, -T[1][2] * is, 0, 0, 1};
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += N2i[3 * r + k] * Fm[3 * k + c]; tmp[3 * r + c] = s; }
+      } else
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += N2[3 * k + r] * Fm[3 * k + c]; tmp[3 * r + c] = s; }
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += tmp[3 * r + k] * N1[3 * k + c]; res[3 * r + c] = s; }
       std::memcpy(Fm, res, sizeof(res));
       errorMax = std::sqrt(errorMax) / T[1][0];
     }
-    const bool good = vec_inliers.size() > 7 * 2.5;
+    const bool good = vec_inliers.size() > kMin * 2.5;
     ok[pp] = good;
     prec[pp] = errorMax; nfa_out[pp] = minNFA;
     std::memcpy(Fout + 9 * pp, Fm, sizeof(Fm));
@@ -321,5 +368,18 @@ double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint6
   }
   return 0.0;
 }
+}  // namespace
 
+extern "C" {
+// same interface as ref_geofilter_f_acransac / ref_geofilter_h_acransac (oracle/ref_shim_geofilter.cpp), one thread
+double port_geofilter_f_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
+                                 double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
+                                 double* prec, double* nfa_out) {
+  return port_acransac(false, xI, xJ, start, wh, n_pairs, precision, max_iterations, inlier_mask, ok, Fout, prec, nfa_out);
+}
+double port_geofilter_h_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
+                                 double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
+                                 double* prec, double* nfa_out) {
+  return port_acransac(true, xI, xJ, start, wh, n_pairs, precision, max_iterations, inlier_mask, ok, Fout, prec, nfa_out);
+}
 }  // extern "C"

@@ -721,6 +721,11 @@ def port_geofilter(tv, precision=4.0, max_iterations=2048):
     return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)
 
 
+def port_geofilter_h(tv, precision=4.0, max_iterations=2048):
+    """oracle/geofilter_oracle.cpp, the homography model of the restatement (Householder null vector of the 8 x 9 DLT system)."""
+    return _geofilter_call(port().port_geofilter_h_acransac, tv, precision, max_iterations)
+
+
 # ---- the geometric filter at container level: the same caller (oracle/ref_shim_geofilter.cpp::ref_geofilter_container) in the
 # reference library and in the adapter harness (explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp) ----
 ADAPTER_GEO_SO = os.path.join(ROOT, "tests", "native", "_build", "libmvgx_openmvg_adapter_geo.so")

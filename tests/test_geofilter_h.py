@@ -25,6 +25,24 @@ def _gold_tv(sel=None):
     return tv, ref
 
 
+def test_restatement_equals_the_stored_reference_outputs():
+    """oracle/geofilter_oracle.cpp (homography model) on the golden inputs: same inlier sets as the reference (stored), NFA / precision / H
+    per policy; at most 1 % of the pairs may fall under policy (b)"""
+    tv, ref = _gold_tv()
+    got = _oracle.port_geofilter_h(tv, float(GOLD_H["precision_px"]), int(GOLD_H["max_iterations"]))
+    differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.01 * rep["pairs"], (rep, differing)
+
+
+@pytest.mark.skipif(not _oracle.have_ref_geofilter(), reason="oracle/_ref/libref_geofilter.so not built (needs /root/reference)")
+def test_restatement_equals_the_compiled_reference_live():
+    tv = synth.two_view_homography_matches(300, seed=78, n_max=200)
+    for iters in (2048, 40):   # 40: the max-consensus warm-up and its early exit decide
+        ref = _oracle.ref_geofilter_h(tv, 4.0, iters); got = _oracle.port_geofilter_h(tv, 4.0, iters)
+        differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
+        assert len(differing) <= 0.01 * rep["pairs"], (iters, rep, differing)
+
+
 def test_emulated_device_code_equals_the_stored_reference_outputs():
     """the kernel under tests/native/hipemu on a handful of golden pairs: empty pairs, successful ones, pairs without a homography,
     one with five correspondences (just above the minimal sample)"""
