@@ -153,6 +153,8 @@ enum GroupMode { kGroupNorms = 0, kGroupForward = 1, kGroupBacksub = 2 };
 struct GroupList {
   uint32_t n_sg = 0, n_groups = 0;
   uint32_t* sg_start = nullptr;    // n_sg + 1 -> groups
+  uint32_t* sg_order = nullptr;    // n_sg: workgroup -> supergroup, largest first (the dispatcher hands workgroups out in index order: the
+                                   // short ones then fill the tail of the launch instead of a long one starting last)
   uint32_t* obs_start = nullptr;   // n_groups + 1 -> entries (one per observation, point by point)
   uint32_t* pt_start = nullptr;    // n_groups + 1 -> pts
   uint32_t* pts = nullptr;         // grouped point -> point
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   uint32_t* const pks = pe + kGroupPts + 1;       // [point]: first entry of the point's observations with local intrinsic 1
   int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const uint32_t sg = blockIdx.x;
+  const uint32_t sg = G.sg_order[blockIdx.x];
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
   const uint32_t* __restrict__ cams = G.cams + (size_t)sg * kGroupCams;
   const uint32_t* __restrict__ intrs = G.intrs + (size_t)sg * kGroupIntr;
@@ -2837,6 +2839,7 @@ struct mvgx_ba_ctx {
   bool solver_ready = false;
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
   bool diag_blocks_complete = false;   // every pose / intrinsic block has a diagonal destination block in the assemble lists
+  std::vector<uint32_t> h_sg_order;   // (a member: the asynchronous upload may read it after mvgx_ba_create's locals are gone)
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
@@ -3906,7 +3909,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // blocks), up to kMaxSgGroups of them. Groups of fewer than kGroupMinPts points are dissolved unless they continue a supergroup
   // (their points stay on the record-based path, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups;
   // so does MVGX_BA_MODEL_COST=jacobian (Ceres' form of the model cost reads the Jacobian records of every observation).
-  constexpr int kMaxSgGroups = 2048 / kGroupThreads;   // a supergroup covers up to 2048 observations
+  // A supergroup covers up to 2048 observations (8 groups). MVGX_BA_SG_GROUPS=n sets another limit (sweep of call 83 / 84: 2 - 6 groups
+  // are 10 - 15 % slower - the per-supergroup prologue, MFMA flush and partial blocks; 10 - 20 worse as well; 24 - 32, one supergroup per
+  // camera set of the bench scenes, -2.5 % at C5 but +20 % at C3, whose 200 sets do not fill the device).
+  int kMaxSgGroups = 2048 / kGroupThreads;
+  if (const char* env = getenv("MVGX_BA_SG_GROUPS")) kMaxSgGroups = std::max(1, std::min(64, atoi(env)));
   std::vector<uint8_t> in_group(d.n_pts, 0);
   std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_pt_start{0}, g_pts, g_pt_estart, g_pt_ksplit, sg_cams, sg_intrs;
   uint32_t* g_eobs = nullptr; uint32_t* g_eq = nullptr;   // [entry]: observation, entry word (HostArena)
@@ -4243,6 +4250,13 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     if (n_sg) {
       d.grp.n_ungrouped = (uint32_t)n_ungrouped;
       if ((rc = dev_upload(c->pool, &d.grp.sg_start, sg_start, c->stream))) return rc;
+      c->h_sg_order.resize(n_sg);
+      for (uint32_t q = 0; q < (uint32_t)n_sg; ++q) c->h_sg_order[q] = q;
+      if (!getenv("MVGX_BA_SG_INDEX_ORDER"))   // (index order: the order of construction, for A/B runs)
+        std::stable_sort(c->h_sg_order.begin(), c->h_sg_order.end(), [&](uint32_t a, uint32_t b) {
+          return g_obs_start[sg_start[a + 1]] - g_obs_start[sg_start[a]] > g_obs_start[sg_start[b + 1]] - g_obs_start[sg_start[b]];
+        });
+      if ((rc = dev_upload(c->pool, &d.grp.sg_order, c->h_sg_order, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pts, g_pts, c->stream))) return rc;
