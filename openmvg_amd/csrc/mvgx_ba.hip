@@ -1538,14 +1538,16 @@ __global__ __launch_bounds__(1024) void ba_schur_assemble_all_kernel(Dev d, uint
     if (threadIdx.x == 0) d.scalars[kSGmaxGrp] = t;
     return;
   }
-  if (wg < wg_pp) {
-    const uint32_t b = wg * 8 + grp;
-    if (b < d.tpp.n_blocks) schur_assemble_block<6, 6, 0, 1>(d, d.tpp, b, e, 0, red);
-  } else if (wg < wg_pp + wg_pi) {
-    const uint32_t b = (wg - wg_pp) * 8 + grp;
+  // (the intrinsic x intrinsic destinations first: their workgroups walk thousands of partial blocks each and should not be the ones
+  // the dispatcher starts last)
+  if (wg < wg_ii) {
+    schur_assemble_block<8, 8, 2, 8>(d, d.tii, wg, e, grp, red);
+  } else if (wg < wg_ii + wg_pi) {
+    const uint32_t b = (wg - wg_ii) * 8 + grp;
     if (b < d.tpi.n_blocks) schur_assemble_block<6, 8, 1, 1>(d, d.tpi, b, e, 0, red);
   } else {
-    schur_assemble_block<8, 8, 2, 8>(d, d.tii, wg - wg_pp - wg_pi, e, grp, red);
+    const uint32_t b = (wg - wg_ii - wg_pi) * 8 + grp;
+    if (b < d.tpp.n_blocks) schur_assemble_block<6, 6, 0, 1>(d, d.tpp, b, e, 0, red);
   }
 }
 
@@ -3909,10 +3911,11 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   // blocks), up to kMaxSgGroups of them. Groups of fewer than kGroupMinPts points are dissolved unless they continue a supergroup
   // (their points stay on the record-based path, as do long tracks and constant points). MVGX_BA_GROUPS=0 disables the groups;
   // so does MVGX_BA_MODEL_COST=jacobian (Ceres' form of the model cost reads the Jacobian records of every observation).
-  // A supergroup covers up to 2048 observations (8 groups). MVGX_BA_SG_GROUPS=n sets another limit (sweep of call 83 / 84: 2 - 6 groups
-  // are 10 - 15 % slower - the per-supergroup prologue, MFMA flush and partial blocks; 10 - 20 worse as well; 24 - 32, one supergroup per
-  // camera set of the bench scenes, -2.5 % at C5 but +20 % at C3, whose 200 sets do not fill the device).
-  int kMaxSgGroups = 2048 / kGroupThreads;
+  // A supergroup covers up to 2048 observations (8 groups); problems of 4 M observations and more - enough supergroups to fill the device
+  // several times either way - up to 4096 (16 groups): fewer prologues, MFMA flushes and partial blocks. MVGX_BA_SG_GROUPS=n sets the
+  // limit (sweeps of calls 83 / 84 / 86 with the largest-first launch order: C3 0.625 ms at 8, 0.654 at 12, 0.715 at 16, 0.726 at 6;
+  // C5 1.747 ms at 8, 1.729 at 12, 1.714 at 16, 1.754 at 24, 1.914 at 6).
+  int kMaxSgGroups = no >= 4000000ull ? 4096 / kGroupThreads : 2048 / kGroupThreads;
   if (const char* env = getenv("MVGX_BA_SG_GROUPS")) kMaxSgGroups = std::max(1, std::min(64, atoi(env)));
   std::vector<uint8_t> in_group(d.n_pts, 0);
   std::vector<uint32_t> sg_start{0}, g_obs_start{0}, g_pt_start{0}, g_pts, g_pt_estart, g_pt_ksplit, sg_cams, sg_intrs;
