@@ -27,14 +27,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-I8_MFMA_DENSE_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: i8 MFMA = 2x the 2.5 PF bf16 dense peak (2xK); ubench 4404 TOPS
+# ONE peak constant for the i8 matrix pipe (DESIGN.md section 6 cites the same): 1 024 SIMDs x 1 024 MAC/clk x 2 x 2.4 GHz = 5.03 POPS,
+# i.e. 2x the 2.5 PF bf16 dense figure of MI355X_MICROARCH.md (its own i8 microbenchmark floor is ">= 3 944 TOPS"). Measured here on
+# zero operands, profiles/round1_ubench_valu_mfma_call3.log: 4 759 TOPS with v_mfma_i32_32x32x32_i8, 4 986 with 16x16x64.
+I8_MFMA_DENSE_PEAK_TFLOPS = 5000.0
+I8_PEAK_NOTE = ("nominal: 1024 SIMDs x 1024 MAC/clk x 2 x 2.4 GHz = 2x the 2.5 PF bf16 dense figure (MI355X_MICROARCH.md; its i8 microbenchmark floor: "
+                ">= 3944 TOPS); tools/ubench.hip on zero operands: 4759 TOPS (32x32x32), 4986 (16x16x64), profiles/round1_ubench_valu_mfma_call3.log")
 FLOP_PER_DESC_PAIR = 256.0          # 128 MAC
-# HBM bytes of the filter kernel per image pair (2000 x 2000 descriptors), from the PMC pass of one pass over THIS workload
-# committed as profiles/round2_match_traffic_pmc_call26.json (tools/pmc_traffic_summary.py; round 1: ...traffic_pmc_call42.json,
-# 314 KB): (TCC_EA0_RDREQ x 64 B x 2 [gfx950 correction for 16 B/lane streams, MI355X_MICROARCH.md] + TCC_EA0_WRREQ x 64 B)
-# / 499 500 pairs. Counters cannot be read inside this process; the figure is scaled to this run's pairs per launch.
-# Algorithmic minimum (every image read once) is ~0.1 GB per launch.
-HBM_BYTES_PER_IMAGE_PAIR_MEASURED = (1.44266810624e11 + 8.111838464e9) / 499500.0
+# HBM bytes of the filter kernel per image pair (2000 x 2000 descriptors): the PMC pass of one pass over THIS workload on this
+# round's tree, committed under profiles/ (tools/pmc_traffic_summary.py: (TCC_EA0_RDREQ x 64 B x 2 [gfx950 correction for 16 B/lane
+# streams, MI355X_MICROARCH.md] + TCC_EA0_WRREQ x 64 B) / 499 500 pairs). Counters cannot be read inside this process; the
+# figure is scaled to this run's pairs per launch and the record names the file it came from. Algorithmic minimum (every image
+# read once) is ~0.1 GB per launch.
+MATCH_TRAFFIC_PROFILES = ("profiles/round4_match_traffic_pmc.json", "profiles/round2_match_traffic_pmc_call26.json")
+
+
+def match_traffic_profile():
+    for rel in MATCH_TRAFFIC_PROFILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return float(json.load(f)["filter_kernel"]["bytes_per_image_pair"]), rel
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def parse():
@@ -205,6 +220,7 @@ def main():
         flop_per_launch = (desc_pairs / max(launches, 1)) * FLOP_PER_DESC_PAIR
         mean_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
         achieved = flop_per_launch / mean_launch_s / 1e12 if mean_launch_s > 0 else 0.0
+        bytes_per_pair, traffic_file = match_traffic_profile()
         out = {
             "metric": "descriptor pairs/s (brute-force L2 2-NN + ratio matching)",
             "value": value,
@@ -224,11 +240,11 @@ def main():
                        "results": "collected (one pinned host buffer)" if args.collect else "streamed (two pinned batch buffers)",
                        "parallelism": f"pair-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS,
-                         "traffic": (HBM_BYTES_PER_IMAGE_PAIR_MEASURED * (args.desc / 2000.0) * len(pairs) * args.steps / max(launches, 1)
-                                     if variant == 4 else None),
+                         "frac": achieved / I8_MFMA_DENSE_PEAK_TFLOPS, "peak_note": I8_PEAK_NOTE,
+                         "traffic": (bytes_per_pair * (args.desc / 2000.0) * len(pairs) * args.steps / max(launches, 1)
+                                     if variant == 4 and bytes_per_pair else None),
                          "traffic_measured_in_run": False,
-                         "traffic_note": "HBM bytes per launch, PMC pass profiles/round2_match_traffic_pmc_call26.json scaled by pairs per launch "
+                         "traffic_note": f"HBM bytes per launch, PMC pass {traffic_file} scaled by pairs per launch "
                                          "(counters cannot be read inside this process)",
                          "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},

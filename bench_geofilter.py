@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+RESIDENT_WAVES = 256 * 4 * 3      # 256 CUs x 4 SIMDs x 3 waves (the kernel's 168 VGPRs; LDS would allow 6)
+SHADER_CLOCK_HZ = 2.4e9           # nominal (MI355X_MICROARCH.md)
+
 
 def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, cpu_pairs=6000, model="f"):
     """model "f": GeometricFilter_FMatrix_AC; "h": GeometricFilter_HMatrix_AC (H_ACRobust.hpp) on pairs related by homographies"""
@@ -25,19 +28,35 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
         tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
         fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
     geofilter.filter_pairs(tv["xI"][:n * 512], tv["xJ"][:n * 512], tv["start"][:513], tv["wh"][:512], fun, device)   # warm-up
+    # the dependent chain of one iteration without contention: 256 pairs = 64 workgroups of four waves, one wave per SIMD on 64 CUs
+    _, _, st1 = geofilter.filter_pairs(tv["xI"][:n * 256], tv["xJ"][:n * 256], tv["start"][:257], tv["wh"][:256], fun, device)
+    chain_clocks = st1.wave_clocks / max(int(st1.n_iterations), 1)
     kernel_ms = total_ms = 0.0
+    iters = models = clocks = 0
     t0 = time.perf_counter()
     for _ in range(steps):
         mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun, device)
         kernel_ms += st.kernel_ms; total_ms += st.total_ms
+        iters += int(st.n_iterations); models += int(st.n_models); clocks += int(st.wave_clocks)
     dt = time.perf_counter() - t0
-    rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (kernel_ms * 1e-3),
-           "unit": "image pairs/s (device kernel time)", "dtype": "f64",
+    ach = iters / (kernel_ms * 1e-3)
+    peak = RESIDENT_WAVES * SHADER_CLOCK_HZ / chain_clocks
+    rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (total_ms * 1e-3),
+           "unit": "image pairs/s (whole call: host preparation, transfers, kernels)", "dtype": "f64",
+           "image_pairs_per_s_kernel_time": n_pairs * steps / (kernel_ms * 1e-3),
+           "roofline": {"bound": "latency", "achieved": ach, "peak": peak, "unit": "a-contrario iterations/s", "frac": ach / peak, "traffic": None,
+                        "kernel": f"geofilter_f_acransac_kernel<4, false, {'kModelH' if model == 'h' else 'kModelF'}>",
+                        "iterations_per_pass": iters / steps, "models_per_iteration": models / max(iters, 1),
+                        "clocks_per_iteration_and_wave": clocks / max(iters, 1), "clocks_per_iteration_one_wave_per_simd": chain_clocks,
+                        "resident_waves": RESIDENT_WAVES, "clock_hz_nominal": SHADER_CLOCK_HZ,
+                        "note": "one wave runs one pair's sequential program: the floor of an iteration is its dependent chain (sample -> minimal solver -> "
+                                "residuals / histogram -> NFA), measured in this run with one wave per SIMD (s_memtime, first to last instruction of every "
+                                "wave / iterations); peak = resident waves (3 per SIMD: 168 VGPRs) x clock / that chain. The SQ counter pass of the same "
+                                "workload is profiles/round4_geofilter_pmc_*.json"},
            "config": {"workload": f"{n_pairs} image pairs x {n} putative matches (25 % of the pairs without geometry, the others 30-90 % inliers, "
                                   f"0.4 px noise), precision 4 px, 2048 iterations", "pairs_accepted": int(st.n_pairs_ok), "inliers": int(st.n_inliers)},
            "kernel_ms_per_pass": kernel_ms / steps, "call_ms_per_pass_incl_host_prepare_and_transfers": total_ms / steps,
-           "wall_ms_per_pass_python": dt / steps * 1e3, "host_prepare_ms": st.host_prepare_ms,
-           "image_pairs_per_s_whole_call": n_pairs * steps / (total_ms * 1e-3)}
+           "wall_ms_per_pass_python": dt / steps * 1e3, "host_prepare_ms": st.host_prepare_ms}
     if cpu:
         try:
             from tests import _geofilter_cases as gc, _oracle
@@ -50,7 +69,7 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
                 rec["cpu_baseline"] = {"value": m / ref["seconds"], "unit": "image pairs/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"the first {m} pairs of the same set in {ref['seconds']:.1f} s (ACKernelAdaptor<"
                                                  f"{'FourPointSolver, AsymmetricError' if model == 'h' else 'SevenPointSolver, EpipolarDistanceError'}> + ACRANSAC, OpenMP over the pairs)"}
-                rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+                rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]   # whole call against whole call
                 differing, rep = gc.compare(sub["start"], ref, mask[:n * m], res["ok"][:m], res["F"][:m], res["precision_robust"][:m], res["nfa"][:m])
                 rec["parity"] = dict(rep, policy="identical inlier sets (then NFA, precision equal and F equal to 1e-6 - asserted); pairs_differing = "
                                                  "pairs whose decisive residual is within rounding of a histogram edge (DESIGN.md)")

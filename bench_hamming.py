@@ -19,6 +19,33 @@ VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 LANE_OPS_PER_DESC_PAIR = 35.0
 
 
+def _cpu_leg(rec, ctx, imgs, pairs, n_desc, run_ratio, cpu_seconds, ref_fn, port_fn, label):
+    """The reference's Matcher_Regions on a bounded random sample of the same pair list (cpu_baseline), and the device lists of
+    those very pairs - same context, same resident descriptors as the timed region - compared entry by entry (parity)."""
+    try:
+        from tests import _oracle
+        kind = "reference" if _oracle.have_ref_match() else "port"
+        fn = ref_fn(_oracle) if kind == "reference" else (lambda d, p, r: _oracle.offsets_to_dict(p, *port_fn(_oracle)(d, p, r)))
+        order = np.random.default_rng(1).permutation(len(pairs))
+        fn(imgs, pairs[order[:8]], 0.8)
+        t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
+        per = max((time.perf_counter() - t0) / 32.0, 1e-5)
+        n = int(max(32, min(len(pairs), cpu_seconds / per)))
+        sample = np.ascontiguousarray(pairs[order[:n]])
+        t0 = time.perf_counter(); cpu_lists = fn(imgs, sample, 0.8); cdt = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
+                               "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, {label})"}
+        rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        _, soff, sij = ctx.run(sample, run_ratio)
+        gpu = _oracle.offsets_to_dict(sample, soff, sij)
+        same = set(gpu) == set(cpu_lists) and all(np.array_equal(gpu[k], cpu_lists[k]) for k in gpu)
+        rec["parity"] = {"pairs_checked": int(n), "non_empty_pairs": int(len(cpu_lists)),
+                         "matches_checked": int(sum(len(v) for v in cpu_lists.values())), "identical": bool(same),
+                         "against": "cpu_baseline lists (same run, same pairs)"}
+    except Exception as e:
+        rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+
+
 def hamming_bench_record(device=0, n_images=300, n_desc=2000, steps=3, cpu_seconds=8.0, cpu=True):
     from openmvg_amd import matching, synth
     imgs = synth.binary_descriptors(n_images, n_desc, seed=0xA4A2E)
@@ -32,7 +59,6 @@ def hamming_bench_record(device=0, n_images=300, n_desc=2000, steps=3, cpu_secon
         st, off, _ = ctx.run(pairs, 0.8)
         kernel_ms += st.kernel_ms; launches += int(st.n_kernel_launches); desc_pairs += int(st.n_desc_pairs)
     dt = time.perf_counter() - t0
-    ctx.close()
     ach = desc_pairs * LANE_OPS_PER_DESC_PAIR / max(kernel_ms * 1e-3, 1e-12)
     rec = {
         "metric": "descriptor pairs/s (brute-force Hamming 2-NN + ratio matching)", "value": desc_pairs / dt,
@@ -45,22 +71,9 @@ def hamming_bench_record(device=0, n_images=300, n_desc=2000, steps=3, cpu_secon
                      "launches": launches, "mean_launch_ms": kernel_ms / max(launches, 1)},
     }
     if cpu:
-        try:
-            from tests import _oracle
-            kind = "reference" if _oracle.have_ref_match() else "port"
-            fn = (_oracle.ref_matcher_regions_match_binary64 if kind == "reference"
-                  else lambda d, p, r: _oracle.port_matcher_regions_match_hamming(d, p, r))
-            order = np.random.default_rng(1).permutation(len(pairs))
-            fn(imgs, pairs[order[:8]], 0.8)
-            t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
-            per = max((time.perf_counter() - t0) / 32.0, 1e-5)
-            n = int(max(32, min(len(pairs), cpu_seconds / per)))
-            t0 = time.perf_counter(); fn(imgs, pairs[order[:n]], 0.8); cdt = time.perf_counter() - t0
-            rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
-                                   "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, BRUTE_FORCE_HAMMING)"}
-            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
-        except Exception as e:
-            rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+        _cpu_leg(rec, ctx, imgs, pairs, n_desc, 0.8, cpu_seconds, lambda o: o.ref_matcher_regions_match_binary64,
+                 lambda o: o.port_matcher_regions_match_hamming, "BRUTE_FORCE_HAMMING")
+    ctx.close()
     return rec
 
 
@@ -83,7 +96,6 @@ def l2f_bench_record(device=0, n_images=200, n_desc=2000, steps=3, cpu_seconds=8
         st, off, _ = ctx.run(pairs, rsq)
         kernel_ms += st.kernel_ms; launches += int(st.n_kernel_launches); desc_pairs += int(st.n_desc_pairs)
     dt = time.perf_counter() - t0
-    ctx.close()
     ach = desc_pairs * F32_OPS_PER_DESC_PAIR / max(kernel_ms * 1e-3, 1e-12)
     rec = {
         "metric": "descriptor pairs/s (brute-force L2<float> 2-NN + ratio matching, reference summation order)",
@@ -96,22 +108,9 @@ def l2f_bench_record(device=0, n_images=200, n_desc=2000, steps=3, cpu_seconds=8
                      "launches": launches, "mean_launch_ms": kernel_ms / max(launches, 1)},
     }
     if cpu:
-        try:
-            from tests import _oracle
-            kind = "reference" if _oracle.have_ref_match() else "port"
-            fn = (_oracle.ref_matcher_regions_match_float64 if kind == "reference"
-                  else lambda d, p, r: _oracle.port_matcher_regions_match_f32(d, p, r))
-            order = np.random.default_rng(1).permutation(len(pairs))
-            fn(imgs, pairs[order[:8]], 0.8)
-            t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
-            per = max((time.perf_counter() - t0) / 32.0, 1e-5)
-            n = int(max(32, min(len(pairs), cpu_seconds / per)))
-            t0 = time.perf_counter(); fn(imgs, pairs[order[:n]], 0.8); cdt = time.perf_counter() - t0
-            rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
-                                   "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, BRUTE_FORCE_L2, float)"}
-            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
-        except Exception as e:
-            rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+        _cpu_leg(rec, ctx, imgs, pairs, n_desc, rsq, cpu_seconds, lambda o: o.ref_matcher_regions_match_float64,
+                 lambda o: o.port_matcher_regions_match_f32, "BRUTE_FORCE_L2, float")
+    ctx.close()
     return rec
 
 
@@ -165,29 +164,8 @@ def l2u8_bench_record(device=0, n_images=200, n_desc=2000, steps=3, dim=144, cpu
                         "frac": ach / VALU_I32_OPS_PEAK, "traffic": None, "kernel": "l2u8_top2_ratio_kernel<36>", "launches": launches,
                         "mean_launch_ms": kernel_ms / max(launches, 1)}}
     if cpu:
-        try:
-            from tests import _oracle
-            kind = "reference" if _oracle.have_ref_match() else "port"
-            fn = (_oracle.ref_matcher_regions_match_liop144 if kind == "reference"
-                  else lambda d, p, r: _oracle.offsets_to_dict(p, *_oracle.port_matcher_regions_match(d, p, r, dim=dim)))
-            order = np.random.default_rng(1).permutation(len(pairs))
-            fn(imgs, pairs[order[:8]], 0.8)
-            t0 = time.perf_counter(); fn(imgs, pairs[order[8:40]], 0.8)
-            per = max((time.perf_counter() - t0) / 32.0, 1e-5)
-            n = int(max(32, min(len(pairs), cpu_seconds / per)))
-            sample = np.ascontiguousarray(pairs[order[:n]])
-            t0 = time.perf_counter(); cpu_lists = fn(imgs, sample, 0.8); cdt = time.perf_counter() - t0
-            rec["cpu_baseline"] = {"value": n * n_desc * n_desc / cdt, "unit": "descriptor pairs/s", "cores": os.cpu_count(), "kind": kind,
-                                   "sample": f"{n} random image pairs of the same set in {cdt:.1f} s (Matcher_Regions, BRUTE_FORCE_L2, AKAZE_Liop_Regions)"}
-            rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
-            _, soff, sij = ctx.run(sample, rsq)
-            gpu = _oracle.offsets_to_dict(sample, soff, sij)
-            same = set(gpu) == set(cpu_lists) and all(np.array_equal(gpu[k], cpu_lists[k]) for k in gpu)
-            rec["parity"] = {"pairs_checked": int(n), "non_empty_pairs": int(len(cpu_lists)),
-                             "matches_checked": int(sum(len(v) for v in cpu_lists.values())), "identical": bool(same),
-                             "against": "cpu_baseline lists (same run, same pairs)"}
-        except Exception as e:
-            rec["cpu_baseline"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
+        _cpu_leg(rec, ctx, imgs, pairs, n_desc, rsq, cpu_seconds, lambda o: o.ref_matcher_regions_match_liop144,
+                 lambda o: (lambda d, p, r: o.port_matcher_regions_match(d, p, r, dim=dim)), "BRUTE_FORCE_L2, AKAZE_Liop_Regions")
     ctx.close()
     return rec
 

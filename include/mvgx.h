@@ -33,7 +33,8 @@ const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
 /* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors;
  * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream; 5: geometric filter; 6: indexed filter entry,
- * cascade hashing on the device; 7: homography model of the geometric filter) */
+ * cascade hashing on the device; 7: homography model of the geometric filter; 8: iteration / clock counters in
+ * mvgx_geofilter_stats, essential-matrix model of the geometric filter) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -400,6 +401,10 @@ typedef struct mvgx_geofilter_stats {
   double kernel_ms;          /* device time of the estimation kernels (HIP events)                             */
   double host_prepare_ms;    /* normalisation + per-pair constants on host threads                             */
   double total_ms;           /* the whole call incl. transfers                                                 */
+  /* measurement (ABI version 8): what the estimation waves did, summed over the estimated pairs                  */
+  uint64_t n_iterations;     /* a-contrario iterations run (sample + fit + evaluation of its models)           */
+  uint64_t n_models;         /* models evaluated (F: 1 - 3 per iteration, H: 1)                                */
+  uint64_t wave_clocks;      /* shader clocks (s_memtime) from the first to the last instruction of every wave */
 } mvgx_geofilter_stats;
 int mvgx_geofilter_f_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
                               uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,

@@ -117,7 +117,8 @@ class GeofilterResult(C.Structure):
 
 class GeofilterStats(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("n_pairs_estimated", C.c_uint64), ("n_pairs_ok", C.c_uint64), ("n_inliers", C.c_uint64),
-                ("kernel_ms", C.c_double), ("host_prepare_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("host_prepare_ms", C.c_double), ("total_ms", C.c_double),
+                ("n_iterations", C.c_uint64), ("n_models", C.c_uint64), ("wave_clocks", C.c_uint64)]
 
 
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)

@@ -62,6 +62,8 @@ struct GeoResult {
   double F[9];             // best model, normalised coordinates (row-major); valid if have_model
   double error_max, min_nfa;
   uint32_t n_inliers, have_model;
+  uint32_t n_iterations, n_models;   // measurement: a-contrario iterations run / models evaluated by this pair's wave
+  uint64_t clocks;                   // measurement: shader clocks (s_memtime) between the wave's first and last instruction
 };
 
 // ---- arithmetic that must not be contracted into FMAs (the reference's build has none) ----
@@ -392,6 +394,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * WAVES + wave;
   if (w >= n_work) return;   // wave-uniform; no workgroup barrier below
+  const long long t_start = __builtin_amdgcn_s_memtime();
+  uint32_t n_iter_run = 0, n_models_run = 0;
   constexpr int kMin = model_min_samples<MODEL>();
   const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
   const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
       nm = seven_point(x1, x2, s, lane, F1, F2, roots);
     }
     bool better = false;
+    ++n_iter_run; n_models_run += (uint32_t)nm;
     for (int mi = 0; mi < nm; ++mi) {
       const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
       double F[9];
@@ -562,6 +567,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   if (lane < 9) results[pidx].F[lane] = bestFu;
   if (lane == 0) {
     results[pidx].error_max = errorMax; results[pidx].min_nfa = minNFA; results[pidx].n_inliers = inl_count; results[pidx].have_model = have_model;
+    results[pidx].n_iterations = n_iter_run; results[pidx].n_models = n_models_run;
+    results[pidx].clocks = (uint64_t)(__builtin_amdgcn_s_memtime() - t_start);
   }
 }
 
@@ -805,11 +812,12 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   float kernel_ms = 0.f;
   (void)hipEventElapsedTime(&kernel_ms, e0, e1);
   // ---- results in the reference's terms: Unnormalize (conditioning.cpp:87-89), unormalizeError, the 2.5 x 7 acceptance ----
-  uint64_t n_ok = 0, n_inl = 0;
+  uint64_t n_ok = 0, n_inl = 0, n_iter = 0, n_mod = 0, clocks = 0;
   for (uint64_t p = 0; p < n_pairs; ++p) {
     mvgx_geofilter_result& o = results[p];
     const GeoResult& r = hr[p];
     const bool ran = hp[p].n > (uint32_t)min_samples;
+    if (ran) { n_iter += r.n_iterations; n_mod += r.n_models; clocks += r.clocks; }
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = (ran && r.have_model) ? r.F[u] : ((u % 4 == 0) ? 1.0 : 0.0);   // m_F starts as the identity
     double err = ran ? r.error_max : 0.0;
@@ -839,6 +847,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     stats->kernel_ms = kernel_ms;
     stats->host_prepare_ms = std::chrono::duration<double, std::milli>(t_prep - t_begin).count();
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    stats->n_iterations = n_iter; stats->n_models = n_mod; stats->wave_clocks = clocks;
   }
   return MVGX_OK;
 }

@@ -5,8 +5,29 @@ control flow exactly, but take the null space of the seven-point system from ano
 fundamental matrix agrees with the reference's to rounding only. A pair therefore either (a) ends with the SAME inlier set - then
 its NFA must be equal to 1e-9 relative, its precision equal and its F equal to 1e-6 after normalisation - or (b) belongs to the small
 share whose decisive residual lies within rounding of a histogram edge / whose cubic is badly conditioned in one basis; that
-share is counted and bounded (the compiled reference shows the same sensitivity to its own Eigen build)."""
+share is counted and bounded BY THE REFERENCE'S OWN BUILD-TO-BUILD SPREAD: profiles/round4_geofilter_reference_vs_reference.json
+(tools/geofilter_ref_vs_ref.py) runs the same openMVG sources compiled -O3 and -O3 -mavx2 -mfma on the bench sets - the two builds
+end with different inlier sets on 50 of 100 000 pairs for the fundamental matrix (5.0e-4) and on 0 of 20 000 for the homography
+(taken as < 3 of 20 000, the 95 % upper bound of a count of zero); on pairs with identical inlier sets their models still differ by
+up to 1.3e-5. `allowed_differing` is the 99 % Poisson quantile of that share at a test's sample size: 0 up to 20 pairs (the real-image pairs; smoke asks for 0 of its 24), 1 at 240, 3 at 1 000,
+8 at 6 000 - instead of the flat 1 - 2 % of round 3."""
+import math
+
 import numpy as np
+
+REFERENCE_BUILD_SPREAD = {"f": 50 / 100000.0, "h": 3 / 20000.0}
+
+
+def allowed_differing(n_pairs, model="f", quantile=0.99):
+    """largest count of differing pairs consistent (at `quantile`) with the reference's own build-to-build spread"""
+    lam = REFERENCE_BUILD_SPREAD[model] * n_pairs
+    k, term = 0, math.exp(-lam)
+    cdf = term
+    while cdf < quantile:
+        k += 1
+        term *= lam / k
+        cdf += term
+    return k
 
 
 def normalised(F):

@@ -15,7 +15,7 @@ def test_golden_fixture_inlier_sets():
     tv, ref = _gold_tv()
     mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(float(GOLD["precision_px"]), int(GOLD["max_iterations"])))
     differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
-    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.01 * rep["pairs"], (rep, differing)
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= gc.allowed_differing(rep["pairs"]), (rep, differing)
     assert int(st.n_pairs) == rep["pairs"] and st.kernel_ms > 0
 
 
@@ -30,7 +30,7 @@ def test_against_the_compiled_reference(kw, iters):
     ref = _oracle.ref_geofilter(tv, 4.0, iters)
     mask, res, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(4.0, iters))
     differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
-    assert len(differing) <= max(1, 0.01 * rep["pairs"]), (rep, differing[:10])
+    assert len(differing) <= gc.allowed_differing(rep["pairs"]), (rep, differing[:10])
 
 
 def test_edge_cases_and_errors():

@@ -31,7 +31,7 @@ def test_restatement_equals_the_stored_reference_outputs():
     tv, ref = _gold_tv()
     got = _oracle.port_geofilter_h(tv, float(GOLD_H["precision_px"]), int(GOLD_H["max_iterations"]))
     differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
-    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.01 * rep["pairs"], (rep, differing)
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= gc.allowed_differing(rep["pairs"], "h"), (rep, differing)
 
 
 @pytest.mark.skipif(not _oracle.have_ref_geofilter(), reason="oracle/_ref/libref_geofilter.so not built (needs /root/reference)")
@@ -40,7 +40,7 @@ def test_restatement_equals_the_compiled_reference_live():
     for iters in (2048, 40):   # 40: the max-consensus warm-up and its early exit decide
         ref = _oracle.ref_geofilter_h(tv, 4.0, iters); got = _oracle.port_geofilter_h(tv, 4.0, iters)
         differing, rep = gc.compare(tv["start"], ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
-        assert len(differing) <= 0.01 * rep["pairs"], (iters, rep, differing)
+        assert len(differing) <= gc.allowed_differing(rep["pairs"], "h"), (iters, rep, differing)
 
 
 def test_emulated_device_code_equals_the_stored_reference_outputs():
@@ -81,7 +81,7 @@ def test_golden_fixture_inlier_sets_on_the_device():
     tv, ref = _gold_tv()
     mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(float(GOLD_H["precision_px"]), int(GOLD_H["max_iterations"])))
     differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
-    assert rep["pairs_ok_reference"] > 100 and len(differing) <= 0.02 * rep["pairs"], (rep, differing)
+    assert rep["pairs_ok_reference"] > 100 and len(differing) <= gc.allowed_differing(rep["pairs"], "h"), (rep, differing)
     assert int(st.n_pairs) == rep["pairs"] and st.kernel_ms > 0
 
 
@@ -97,7 +97,7 @@ def test_against_the_compiled_reference(kw, iters):
     ref = _oracle.ref_geofilter_h(tv, 4.0, iters)
     mask, res, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, iters))
     differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
-    assert len(differing) <= max(1, 0.02 * rep["pairs"]), (rep, differing[:10])
+    assert len(differing) <= gc.allowed_differing(rep["pairs"], "h"), (rep, differing[:10])
     truth_kept = (mask & tv["is_inlier"]).sum() / max(1, (tv["is_inlier"] & np.repeat(ref["ok"], np.diff(tv["start"].astype(np.int64)))).sum())
     assert truth_kept > 0.7 or iters < 100   # (the a-contrario precision is tighter than the 4 px bound: part of the noisy true matches fall outside it)
 

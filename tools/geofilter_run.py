@@ -1,10 +1,17 @@
 """One pass of the geometric filter over a synthetic workload (the command profiled by the rocprofv3 passes of the kernel).
-Usage: geofilter_run.py [n_pairs] [n_matches]"""
+Usage: geofilter_run.py [n_pairs] [n_matches] [f|h]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openmvg_amd import geofilter, synth
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 250
-tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
-mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(4.0, 2048))
-print("pairs", n_pairs, "kernel_ms", st.kernel_ms, "ok", int(st.n_pairs_ok))
+model = sys.argv[3] if len(sys.argv) > 3 else "f"
+if model == "h":
+    tv = synth.two_view_homography_matches(n_pairs, seed=0x6E0F, n_min=n, n_max=n, tiny_frac=0.0)
+    fun = geofilter.GeometricFilter_HMatrix_AC(4.0, 2048)
+else:
+    tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
+    fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
+mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
+print("model", model, "pairs", n_pairs, "kernel_ms", st.kernel_ms, "ok", int(st.n_pairs_ok), "iterations", int(st.n_iterations), "models", int(st.n_models),
+      "wave_clocks", int(st.wave_clocks))
