@@ -16,6 +16,17 @@ if ROOT not in sys.path:
 
 RESIDENT_WAVES = 256 * 4 * 3      # 256 CUs x 4 SIMDs x 3 waves (the kernel's 168 VGPRs; LDS would allow 6)
 SHADER_CLOCK_HZ = 2.4e9           # nominal (MI355X_MICROARCH.md)
+PMC_PROFILE = "profiles/round4_geofilter_pmc_call228.json"   # SQ counter passes of tools/geofilter_run.py (tools/gpu.sh geopmc)
+
+
+def valu_cycles_per_iteration(model):
+    """SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / iterations of the committed counter pass: the kernel's own VALU issue time per iteration"""
+    try:
+        with open(os.path.join(ROOT, PMC_PROFILE)) as f:
+            r = json.load(f)[model]
+        return r["raw"]["b"]["SQ_ACTIVE_INST_VALU"] * 4.0 / r["iterations"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, cpu_pairs=6000, model="f"):
@@ -41,6 +52,7 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
     dt = time.perf_counter() - t0
     ach = iters / (kernel_ms * 1e-3)
     peak = RESIDENT_WAVES * SHADER_CLOCK_HZ / chain_clocks
+    vci = valu_cycles_per_iteration(model)
     rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (total_ms * 1e-3),
            "unit": "image pairs/s (whole call: host preparation, transfers, kernels)", "dtype": "f64",
            "image_pairs_per_s_kernel_time": n_pairs * steps / (kernel_ms * 1e-3),
@@ -49,10 +61,12 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
                         "iterations_per_pass": iters / steps, "models_per_iteration": models / max(iters, 1),
                         "clocks_per_iteration_and_wave": clocks / max(iters, 1), "clocks_per_iteration_one_wave_per_simd": chain_clocks,
                         "resident_waves": RESIDENT_WAVES, "clock_hz_nominal": SHADER_CLOCK_HZ,
+                        "valu_cycles_per_iteration_pmc": vci,
+                        "frac_of_valu_issue_floor": (ach * vci / (1024 * SHADER_CLOCK_HZ)) if vci else None,
                         "note": "one wave runs one pair's sequential program: the floor of an iteration is its dependent chain (sample -> minimal solver -> "
                                 "residuals / histogram -> NFA), measured in this run with one wave per SIMD (s_memtime, first to last instruction of every "
-                                "wave / iterations); peak = resident waves (3 per SIMD: 168 VGPRs) x clock / that chain. The SQ counter pass of the same "
-                                "workload is profiles/round4_geofilter_pmc_*.json"},
+                                "wave / iterations); peak = resident waves (3 per SIMD: 168 VGPRs) x clock / that chain. frac_of_valu_issue_floor = the same "
+                                f"rate against 1024 SIMDs x clock / the VALU issue cycles of an iteration, from the SQ counter pass {PMC_PROFILE}"},
            "config": {"workload": f"{n_pairs} image pairs x {n} putative matches (25 % of the pairs without geometry, the others 30-90 % inliers, "
                                   f"0.4 px noise), precision 4 px, 2048 iterations", "pairs_accepted": int(st.n_pairs_ok), "inliers": int(st.n_inliers)},
            "kernel_ms_per_pass": kernel_ms / steps, "call_ms_per_pass_incl_host_prepare_and_transfers": total_ms / steps,

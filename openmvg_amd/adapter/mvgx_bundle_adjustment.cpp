@@ -40,6 +40,7 @@
 #include "openMVG/types.hpp"
 
 #include "mvgx.h"
+#include "mvgx_adapter_policy.hpp"
 #include "mvgx_bundle_adjustment.hpp"
 
 namespace openMVG {
@@ -316,14 +317,15 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 
   tick("scene -> arrays");
   mvgx_ba_ctx* ctx = nullptr;
-  int rc = mvgx_ba_create(options_.device_, &prob, &ctx);
+  const bool inj_create = mvgx_adapter::injected("ba", "create");
+  int rc = inj_create ? MVGX_ERR_NODEV : mvgx_ba_create(options_.device_, &prob, &ctx);
   tick("mvgx_ba_create");
   if (rc == MVGX_ERR_UNSUPPORTED) {
     OPENMVG_LOG_ERROR << "Cannot create a CostFunction for this camera model. (" << mvgx_last_error() << ")";
     return false;
   }
-  if (rc != MVGX_OK) {
-    OPENMVG_LOG_ERROR << "mvgx BA: " << mvgx_last_error();
+  if (rc != MVGX_OK) {   // the reference's convention: log, return false (mvgx_adapter_policy.hpp; MVGX_ON_DEVICE_ERROR=throw throws)
+    mvgx_adapter::device_failure(mvgx_adapter::kBundle, "bundle adjustment", "mvgx_ba_create", rc, inj_create);
     return false;
   }
   mvgx_ba_options opt;

@@ -17,7 +17,7 @@
 //       nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
 // 128-byte uint8 regions (SIFT) take that route. Other scalar regions (float descriptors, other lengths) keep working through
 // the reference's own CascadeHasher::Match_HashedDescriptions on the host: that code is not part of the accelerated path.
-// A device failure throws (no silent fallback for the accelerated type).
+// A failing device call is logged once and the remaining pairs run through the reference's own classes (mvgx_adapter_policy.hpp).
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -48,6 +48,7 @@
 #include "openMVG/types.hpp"
 
 #include "mvgx.h"
+#include "mvgx_adapter_policy.hpp"
 
 namespace openMVG {
 namespace matching_image_collection {
@@ -125,6 +126,13 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     }
     v.positions = v.regions->GetRegionsPositions();
   });
+  // MVGX_CASCADE_HASH=host: the hashing stage stays with the reference's CascadeHasher on the host threads and only the matching stage
+  // runs on the device (mvgx_cascade_set_regions) - for openMVG builds whose Eigen kernels are compiled with FMA (-march=native): the
+  // device hashing reproduces the non-FMA operation order (mvgx.h), such a build's own CascadeHasher rounds differently near zero.
+  // Default "device"; "check" hashes the first view both ways once and switches to "host" with a warning on a mismatch.
+  const char* hash_env = std::getenv("MVGX_CASCADE_HASH");
+  bool hash_host = hash_env && !std::strcmp(hash_env, "host");
+  const bool hash_check = hash_env && !std::strcmp(hash_env, "check");
 
   // pairs in the reference's visiting order (grouped by I, ascending), minus the ones it skips (:151-176)
   std::vector<Pair> todo;
@@ -137,10 +145,12 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   }
   if (skipped) (*progress) += skipped;
 
-  if (!on_device) {
-    // the reference's own matching stage, pair by pair on the host threads; the container is filled by this thread
-    std::vector<matching::IndMatches> lists(todo.size());
-    on_host_threads(todo.size(), [&](size_t k) {
+  // the reference's own matching stage for the pairs todo[first ..), pair by pair on the host threads; the container is filled by this
+  // thread. Route of the region types the device does not cover, and - after a device failure - of the pairs it did not deliver.
+  auto host_route = [&](size_t first) {
+    std::vector<matching::IndMatches> lists(todo.size() - first);
+    on_host_threads(todo.size() - first, [&](size_t kk) {
+      const size_t k = first + kk;
       if (progress->hasBeenCanceled()) return;
       const View<ScalarT>& vi = views.at(todo[k].first);
       const View<ScalarT>& vj = views.at(todo[k].second);
@@ -151,14 +161,25 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
       hasher.template Match_HashedDescriptions<RowMajor, DistanceT>(vj.hashed, mJ, vi.hashed, mI, &nn, &dist);
       std::vector<int> kept;
       matching::NNdistanceRatio(dist.begin(), dist.end(), 2, kept, Square(dist_ratio));
-      matching::IndMatches& v = lists[k];
+      matching::IndMatches& v = lists[kk];
       for (int q : kept) v.emplace_back(nn[q * 2].j_, nn[q * 2].i_);
       deduplicate(v, vi.positions, vj.positions);
     });
-    for (size_t k = 0; k < todo.size(); ++k) {
-      if (!lists[k].empty()) out.insert({todo[k], std::move(lists[k])});
+    for (size_t k = first; k < todo.size(); ++k) {
+      if (!lists[k - first].empty()) out.insert({todo[k], std::move(lists[k - first])});
       ++(*progress);
     }
+  };
+  // hash codes and bucket ids of every view by the reference's own class (the non-device types; MVGX_CASCADE_HASH=host; fallback)
+  auto hash_on_host = [&]() {
+    on_host_threads(order.size(), [&](size_t k) {
+      View<ScalarT>& v = *order[k];
+      Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
+      v.hashed = hasher.CreateHashedDescriptions(m, zero_mean);   // const member, per-view outputs: thread safe
+    });
+  };
+  if (!on_device) {
+    host_route(0);
     return;
   }
 
@@ -179,23 +200,85 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   for (const Pair& p : todo) { dev_pairs.push_back(dense[p.first]); dev_pairs.push_back(dense[p.second]); }
 
   struct Ctx { mvgx_cascade_ctx* c = nullptr; ~Ctx() { if (c) mvgx_cascade_destroy(c); } } ctx;
-  auto fail = [&](const char* what, int rc) {
-    const std::string msg = std::string("mvgx (MI355X cascade hashing): ") + what + " failed with status " + std::to_string(rc) + ": " + mvgx_last_error();
-    OPENMVG_LOG_ERROR << msg;
-    throw std::runtime_error(msg);
+  // Error convention (mvgx_adapter_policy.hpp): a failing device call is logged once and the pairs not yet delivered run through the
+  // reference's own hashing + matching classes above (or the failure is thrown, MVGX_ON_DEVICE_ERROR=throw).
+  using mvgx_adapter::injected;
+  bool failed = false;
+  uint64_t delivered = 0;
+  auto step = [&](const char* stage, int rc_call, bool inj) {
+    if (!inj && rc_call == MVGX_OK) return true;
+    mvgx_adapter::device_failure(mvgx_adapter::kCascade, "cascade hashing", stage, inj ? MVGX_ERR_NODEV : rc_call, inj);
+    failed = true;
+    return false;
   };
-  int rc = mvgx_cascade_create(-1, &ctx.c);
-  if (rc != MVGX_OK) fail("create", rc);
-  // CascadeHasher::Init(dimension) defaults: 6 bucket groups, 10 bits per bucket, std::mt19937::default_seed
-  rc = mvgx_cascade_hash_regions(ctx.c, rows.data(), n_desc.data(), (uint32_t)rows.size(), 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, nullptr, nullptr);
-  if (rc != MVGX_OK) fail("hash_regions", rc);
+  // host-side hash outputs in the layout of mvgx_cascade_set_regions (codes: 16 bytes, bucket ids: 6 x uint16 per descriptor)
+  std::vector<std::vector<uint8_t>> codes;
+  std::vector<std::vector<uint16_t>> buckets;
+  std::vector<const uint8_t*> code_ptr;
+  std::vector<const uint16_t*> bucket_ptr;
+  auto pack_host_hashes = [&]() {
+    codes.clear(); buckets.clear(); code_ptr.clear(); bucket_ptr.clear();
+    for (const View<ScalarT>* v : view_of) {
+      const size_t n = v->count();
+      codes.emplace_back(n * 16);
+      buckets.emplace_back(n * 6);
+      for (size_t r = 0; r < n; ++r) {
+        const matching::HashedDescription& h = v->hashed.hashed_desc[r];
+        std::memcpy(&codes.back()[r * 16], h.hash_code.data(), 16);
+        for (int g = 0; g < 6; ++g) buckets.back()[r * 6 + g] = h.bucket_ids[g];
+      }
+    }
+    for (size_t k = 0; k < codes.size(); ++k) { code_ptr.push_back(codes[k].data()); bucket_ptr.push_back(buckets[k].data()); }
+  };
+  bool inj = injected("cascade", "create");
+  int rc = inj ? MVGX_OK : mvgx_cascade_create(-1, &ctx.c);
+  if (step("create", rc, inj)) {
+    if (hash_check && !rows.empty()) {
+      // one view hashed both ways: the device's codes against this build's own CascadeHasher
+      size_t probe = 0;
+      while (probe + 1 < rows.size() && n_desc[probe] == 0) ++probe;
+      const uint32_t n = n_desc[probe];
+      std::vector<uint8_t> dev_codes((size_t)n * 16);
+      std::vector<uint16_t> dev_buckets((size_t)n * 6);
+      uint8_t* cp = dev_codes.data(); uint16_t* bp = dev_buckets.data();
+      rc = mvgx_cascade_hash_regions(ctx.c, rows.data() + probe, n_desc.data() + probe, 1, 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, &cp, &bp);
+      if (rc == MVGX_OK && n) {
+        View<ScalarT>& v = *order[probe];
+        Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
+        const matching::HashedDescriptions href = hasher.CreateHashedDescriptions(m, zero_mean);
+        bool same = true;
+        for (uint32_t r = 0; r < n && same; ++r) {
+          same = !std::memcmp(&dev_codes[(size_t)r * 16], href.hashed_desc[r].hash_code.data(), 16);
+          for (int g = 0; g < 6 && same; ++g) same = dev_buckets[(size_t)r * 6 + g] == href.hashed_desc[r].bucket_ids[g];
+        }
+        if (!same) {
+          OPENMVG_LOG_WARNING << "mvgx cascade hashing: this build's CascadeHasher rounds differently from the device hashing stage "
+                                 "(Eigen compiled with FMA?) - hashing on the host (MVGX_CASCADE_HASH=host)";
+          hash_host = true;
+        }
+      }
+    }
+    if (hash_host) {
+      hash_on_host();
+      pack_host_hashes();
+      inj = injected("cascade", "hash");
+      if (!inj) rc = mvgx_cascade_set_regions(ctx.c, rows.data(), code_ptr.data(), bucket_ptr.data(), n_desc.data(), (uint32_t)rows.size(), 128, 16, 6, 10);
+      step("set_regions", rc, inj);
+    } else {
+      // CascadeHasher::Init(dimension) defaults: 6 bucket groups, 10 bits per bucket, std::mt19937::default_seed
+      inj = injected("cascade", "hash");
+      if (!inj) rc = mvgx_cascade_hash_regions(ctx.c, rows.data(), n_desc.data(), (uint32_t)rows.size(), 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, nullptr, nullptr);
+      step("hash_regions", rc, inj);
+    }
+  }
   const float ratio_sq = Square(dist_ratio);
   const uint64_t n_pairs = todo.size();
-  for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
+  for (uint64_t p0 = 0; !failed && p0 < n_pairs; p0 += kPairsPerCall) {
     if (progress->hasBeenCanceled()) break;
     const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
-    rc = mvgx_cascade_run(ctx.c, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
-    if (rc != MVGX_OK) fail("run", rc);
+    inj = injected("cascade", "run");
+    if (!inj) rc = mvgx_cascade_run(ctx.c, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+    if (!step("run", rc, inj)) break;
     const uint64_t* offsets = nullptr;
     const uint32_t* ij = nullptr;
     mvgx_cascade_results(ctx.c, &offsets, &ij);
@@ -213,6 +296,13 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     for (uint64_t k = 0; k < nb; ++k)
       if (!lists[k].empty()) out.insert({todo[p0 + k], std::move(lists[k])});
     (*progress) += (uint32_t)nb;
+    delivered = p0 + nb;
+  }
+  mvgx_adapter::counters().device_pairs.fetch_add(delivered);
+  if (failed && !progress->hasBeenCanceled()) {
+    if (!hash_host) hash_on_host();
+    mvgx_adapter::counters().fallback_pairs.fetch_add(n_pairs - delivered);
+    host_route((size_t)delivered);
   }
 }
 

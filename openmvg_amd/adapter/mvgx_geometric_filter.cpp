@@ -5,15 +5,16 @@
 // H_ACRobust.hpp:49-113):
 //   * every pair of the container is estimated independently; a pair enters _map_GeometricMatches only if Robust_estimation
 //     returned true (more than 2.5 x 7 inliers for F, 2.5 x 4 for H), with the putative matches of the inliers in their original order;
-//   * the progress bar is restarted with the number of pairs and advanced once per pair; a cancelled run leaves the container empty
-//     from the point of cancellation (checked before the device call and between its result batches);
+//   * the progress bar is restarted with the number of pairs and advanced once per pair; the device is called in batches of
+//     kPairsPerCall pairs and cancellation is checked between them: a cancelled run leaves the container empty from that point;
 //   * with b_guided_matching the reference's own Geometry_guided_matching runs on the host with the estimated F and precision and
 //     its result replaces the inlier list.
 // Inputs of the device call (mvgx_geofilter_f_acransac_indexed): the undistorted pixel positions of the features of every view that
 // occurs (the expressions of MatchesPointsToMat, Geometric_Filter_utils.cpp:33-49, once per feature on OpenMP threads), the index
 // pairs of the putative matches as the container holds them, and the image sizes of the views.
 // What the device does not reproduce is routed to the reference's own code: an unbounded precision (m_dPrecision = infinity) and
-// pairs with more than 2^20 putative matches run functor.Robust_estimation on the host, pair by pair.
+// pairs with more than 2^20 putative matches run functor.Robust_estimation on the host, pair by pair - and so do the pairs of a
+// batch whose device call failed (logged once; mvgx_adapter_policy.hpp; MVGX_ON_DEVICE_ERROR=throw stops instead).
 #include "mvgx_geometric_filter.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
 
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "mvgx.h"
+#include "mvgx_adapter_policy.hpp"
 #include "openMVG/cameras/Camera_Intrinsics.hpp"
 #include "openMVG/features/feature.hpp"
 #include "openMVG/matching_image_collection/Geometric_Filter_utils.hpp"
@@ -38,6 +40,7 @@ namespace matching_image_collection {
 
 namespace {
 constexpr size_t kDeviceMaxMatches = size_t(1) << 20;   // mvgx_geofilter_f_acransac's bound per pair
+constexpr size_t kPairsPerCall = 65536;                 // pairs per device call: progress / cancellation granularity, bounded staging memory
 
 // the reference's loop body for one pair (GeometricFilter.hpp:93-128) with the reference's own functor: the route for what the
 // device call does not cover
@@ -140,17 +143,33 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   }
   std::vector<uint8_t> mask(start.back() ? start.back() : 1);
   std::vector<mvgx_geofilter_result> res(dev_pairs.size() ? dev_pairs.size() : 1);
-  if (!dev_pairs.empty() && !my_progress_bar->hasBeenCanceled()) {
+  size_t n_dev_done = 0;   // dev_pairs[0, n_dev_done): results valid
+  if (!dev_pairs.empty()) {
     mvgx_geofilter_options opt;
     opt.precision = functor.m_dPrecision;
     opt.max_iterations = functor.m_stIteration;
-    const int rc = ModelOf<Functor>::run(-1, (const double*)feat_xy.data(), (const uint64_t*)feat_start.data(), (const uint32_t*)wh.data(), (uint32_t)n_views,
-                                         (const uint32_t*)pair_views.data(), (const uint64_t*)start.data(), (const uint32_t*)ij.data(), (uint64_t)dev_pairs.size(),
-                                         (const mvgx_geofilter_options*)&opt, mask.data(), res.data(), (mvgx_geofilter_stats*)nullptr);
-    if (rc != MVGX_OK) {   // no CPU substitute for a failing device: report like the matcher adapter does
-      OPENMVG_LOG_ERROR << "mvgx geometric filter: " << mvgx_last_error();
-      throw std::runtime_error(std::string(ModelOf<Functor>::entry_name) + " failed: " + mvgx_last_error());
+    std::vector<uint64_t> start_b;
+    for (size_t b0 = 0; b0 < dev_pairs.size() && !my_progress_bar->hasBeenCanceled(); b0 += kPairsPerCall) {
+      const size_t nb = std::min(kPairsPerCall, dev_pairs.size() - b0);
+      start_b.assign(nb + 1, 0);
+      for (size_t k = 0; k <= nb; ++k) start_b[k] = start[b0 + k] - start[b0];   // a call's match_start begins at zero
+      const bool inj = mvgx_adapter::injected("geofilter", "run");
+      const int rc = inj ? MVGX_ERR_NODEV
+                         : ModelOf<Functor>::run(-1, (const double*)feat_xy.data(), (const uint64_t*)feat_start.data(), (const uint32_t*)wh.data(), (uint32_t)n_views,
+                                                 (const uint32_t*)pair_views.data() + 2 * b0, (const uint64_t*)start_b.data(), (const uint32_t*)ij.data() + 2 * start[b0],
+                                                 (uint64_t)nb, (const mvgx_geofilter_options*)&opt, mask.data() + start[b0], res.data() + b0, (mvgx_geofilter_stats*)nullptr);
+      if (rc != MVGX_OK) {
+        // logged once; the pairs from here on take the reference's own functor below (or the failure is thrown)
+        mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", ModelOf<Functor>::entry_name, rc, inj);
+        break;
+      }
+      n_dev_done = b0 + nb;
     }
+    if (!my_progress_bar->hasBeenCanceled()) {
+      for (size_t k = n_dev_done; k < dev_pairs.size(); ++k) on_device[dev_pairs[k]] = 0;
+      mvgx_adapter::counters().fallback_pairs.fetch_add(dev_pairs.size() - n_dev_done);
+    }
+    mvgx_adapter::counters().device_pairs.fetch_add(n_dev_done);
   }
   // results in container order; guided matching (host, the reference's code) on OpenMP threads like the reference's loop
   std::vector<int64_t> dev_index(n_pairs, -1);
@@ -167,6 +186,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       ok = reference_pair(functor, sfm_data_, regions_provider_, kv.first, kv.second, b_guided_matching, d_distance_ratio, inliers);
     } else {
       const int64_t k = dev_index[p];
+      if ((size_t)k >= n_dev_done) continue;   // (cancelled between two device calls)
       ok = res[k].ok != 0;
       if (ok) {
         inliers.reserve(res[k].n_inliers);

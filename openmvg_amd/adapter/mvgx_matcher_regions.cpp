@@ -9,7 +9,8 @@
 //        -> the MI355X path: every (I, J) of the Pair_Set goes to the C ABI in batches, match lists come back
 //           bit-identical to RegionsMatcherT<ArrayMatcherBruteForce<uchar, L2<uchar>>>::MatchDistanceRatio
 //           (regions_matcher.hpp:162-207) and are inserted in the container in ascending (I, J) order.
-//           A HIP failure on this path throws (no silent CPU fallback).
+//           A failing device call is logged once and the remaining pairs run through the reference's own route
+//           (mvgx_adapter_policy.hpp; MVGX_ON_DEVICE_ERROR=throw restores the exception).
 //   -n BRUTEFORCEHAMMING on binary uint8 regions of <= 64 bytes (AKAZE_Binary_Regions) with dist_ratio <= 1
 //        -> the MI355X popcount path (mvgx_hamming_*), bit-identical to
 //           RegionsMatcherT<ArrayMatcherBruteForce<uchar, Hamming<uchar>>>::MatchDistanceRatio (regions_matcher.cpp:184-191)
@@ -52,6 +53,7 @@
 #include "openMVG/system/progressinterface.hpp"
 
 #include "mvgx.h"
+#include "mvgx_adapter_policy.hpp"
 
 namespace openMVG {
 namespace matching_image_collection {
@@ -184,13 +186,6 @@ class ListBuilder {
 
 unsigned builder_helpers() { return std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u); }
 
-[[noreturn]] void device_failure(const char* what, int rc) {
-  const std::string msg = std::string("mvgx (MI355X matching): ") + what + " failed with status " + std::to_string(rc) +
-                          ": " + mvgx_last_error();
-  OPENMVG_LOG_ERROR << msg;
-  throw std::runtime_error(msg);
-}
-
 // The reference's generic per-pair route for matcher types the device path does not cover.
 void match_generic(matching::EMatcherType type, float ratio, const std::shared_ptr<sfm::Regions_Provider>& provider,
                    const std::vector<Pair>& pairs, matching::PairWiseMatchesContainer& out,
@@ -319,17 +314,33 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       ~Contexts() { release(); }
     } ctx;
     // device -1 = "no preference": MVGX_DEVICES (e.g. "all") makes the SIFT path one context over several GPUs of the node
-    int rc = hamming ? mvgx_hamming_create(-1, &ctx.hm) : f32 ? mvgx_l2f_create(-1, &ctx.lf) : u8o ? mvgx_l2u8_create(-1, &ctx.lu)
-                                                                                                  : mvgx_match_create(-1, &ctx.l2);
-    if (rc != MVGX_OK) device_failure("create", rc);
+    // Error convention (mvgx_adapter_policy.hpp): a failing device call is logged once; the pairs whose lists have not reached the
+    // container go through the reference's own RegionMatcherFactory route below (or the failure is thrown, MVGX_ON_DEVICE_ERROR=throw).
+    using mvgx_adapter::injected;
+    bool failed = false;
+    uint64_t delivered = 0;   // device pairs [0, delivered): lists in the container (or known to be empty), progress advanced
+    auto step = [&](const char* stage, int rc_call, bool inj) {   // true = go on with the device
+      if (!inj && rc_call == MVGX_OK) return true;
+      mvgx_adapter::device_failure(mvgx_adapter::kMatch, "matching", stage, inj ? MVGX_ERR_NODEV : rc_call, inj);
+      failed = true;
+      return false;
+    };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());
-    rc = hamming ? mvgx_hamming_set_regions(ctx.hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
-         : f32   ? mvgx_l2f_set_regions(ctx.lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
-         : u8o   ? mvgx_l2u8_set_regions(ctx.lu, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len))
-                 : mvgx_match_set_regions(ctx.l2, rows.data(), n_desc.data(), n_img, 128);
-    if (rc != MVGX_OK) device_failure("set_regions", rc);
+    int rc = MVGX_OK;
+    bool inj = injected("match", "create");
+    if (!inj) rc = hamming ? mvgx_hamming_create(-1, &ctx.hm) : f32 ? mvgx_l2f_create(-1, &ctx.lf) : u8o ? mvgx_l2u8_create(-1, &ctx.lu)
+                                                                                                        : mvgx_match_create(-1, &ctx.l2);
+    if (step("create", rc, inj)) {
+      inj = injected("match", "set_regions");
+      if (!inj)
+        rc = hamming ? mvgx_hamming_set_regions(ctx.hm, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len ? binary_len : 64))
+             : f32   ? mvgx_l2f_set_regions(ctx.lf, reinterpret_cast<const float* const*>(rows.data()), n_desc.data(), n_img, 64)
+             : u8o   ? mvgx_l2u8_set_regions(ctx.lu, rows.data(), n_desc.data(), n_img, static_cast<uint32_t>(binary_len))
+                     : mvgx_match_set_regions(ctx.l2, rows.data(), n_desc.data(), n_img, 128);
+      step("set_regions", rc, inj);
+    }
     tick("context + upload + tile build");
-    if (ctx.l2) {
+    if (!failed && ctx.l2) {
       // SIFT path: the lists arrive batch by batch on THIS thread (mvgx_match_run_stream) while the device(s) work on the
       // next batches; host memory beside the container itself is two batches per device. Cancellation is polled per batch.
       // "stream_hold": a batch's buffers outlive two further sink calls, so batch k is converted by the helper threads while
@@ -340,6 +351,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       ListBuilder list_builder(builder_helpers());
       struct Stream {
         ListBuilder& builder; const Sink* sink; const uint32_t* pairs; system::ProgressInterface* progress; std::exception_ptr error;
+        uint64_t* delivered;
         static int on_batch(void* user, uint64_t first_pair, uint32_t nb, const uint32_t* offsets, const uint32_t* ij) {
           Stream& s = *static_cast<Stream*>(user);
           static const int debug_skip = std::getenv("MVGX_ADAPTER_DEBUG_SKIP") ? std::atoi(std::getenv("MVGX_ADAPTER_DEBUG_SKIP")) : 0;
@@ -348,30 +360,34 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
             s.builder.submit(s.pairs + 2 * first_pair, nb, offsets, nullptr, ij);
             while (s.builder.pending() > 2) s.builder.take_oldest(*s.sink);
             (*s.progress) += nb;
+            *s.delivered = first_pair + nb;   // (batches arrive in order; what is still pending in the builder is flushed after the run)
           } catch (...) {   // never unwind through the C frames: stop the run, rethrow after it has returned
             s.error = std::current_exception();
             return 1;
           }
           return s.progress->hasBeenCanceled() ? 1 : 0;
         }
-      } stream{list_builder, &sink, dev_pairs.data(), progress, nullptr};
+      } stream{list_builder, &sink, dev_pairs.data(), progress, nullptr, &delivered};
       if (!progress->hasBeenCanceled()) {
-        rc = mvgx_match_run_stream(ctx.l2, dev_pairs.data(), n_pairs, ratio_sq, &Stream::on_batch, &stream, nullptr);
+        inj = injected("match", "run");
+        rc = inj ? MVGX_OK : mvgx_match_run_stream(ctx.l2, dev_pairs.data(), n_pairs, ratio_sq, &Stream::on_batch, &stream, nullptr);
         if (stream.error) std::rethrow_exception(stream.error);
-        if (rc != MVGX_OK) device_failure("run", rc);
         while (stream.builder.pending()) stream.builder.take_oldest(sink);   // the last batches: their buffers live until the next call on the context
+        step("run", rc, inj);
       }
       tick("device runs + container fill");
-    } else {
+    } else if (!failed) {
       ListBuilder builder(builder_helpers());
       for (uint64_t p0 = 0; p0 < n_pairs; p0 += kPairsPerCall) {
         const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
         if (progress->hasBeenCanceled()) break;
-        rc = hamming ? mvgx_hamming_run(ctx.hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
-             : f32   ? mvgx_l2f_run(ctx.lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
-                     : mvgx_l2u8_run(ctx.lu, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+        inj = injected("match", "run");
+        if (!inj)
+          rc = hamming ? mvgx_hamming_run(ctx.hm, dev_pairs.data() + 2 * p0, nb, f_dist_ratio_, nullptr)
+               : f32   ? mvgx_l2f_run(ctx.lf, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr)
+                       : mvgx_l2u8_run(ctx.lu, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
         tick("device run");
-        if (rc != MVGX_OK) device_failure("run", rc);
+        if (!step("run", rc, inj)) break;
         const uint64_t* offsets = nullptr;
         const uint32_t* ij = nullptr;
         if (hamming) mvgx_hamming_results(ctx.hm, &offsets, &ij);
@@ -381,7 +397,18 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
         builder.take_oldest(sink);
         tick("container fill");
         (*progress) += static_cast<uint32_t>(nb);
+        delivered = p0 + nb;
       }
+    }
+    mvgx_adapter::counters().device_pairs.fetch_add(delivered);
+    if (failed && !progress->hasBeenCanceled()) {
+      // the host application's own reference route for what the device did not deliver (Pair_Set order is kept: dev_pairs is in it)
+      std::vector<Pair> rest;
+      rest.reserve(n_pairs - delivered);
+      for (uint64_t k = delivered; k < n_pairs; ++k) rest.emplace_back(ids[dev_pairs[2 * k]], ids[dev_pairs[2 * k + 1]]);
+      mvgx_adapter::counters().fallback_pairs.fetch_add(rest.size());
+      match_generic(eMatcherType_, f_dist_ratio_, regions_provider, rest, map_PutativeMatches, progress);
+      tick("reference route after a device failure");
     }
     ctx.release();
     tick("context destroy");

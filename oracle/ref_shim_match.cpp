@@ -12,6 +12,7 @@
 // Used to (a) validate oracle/match_oracle.c, (b) serve as the "reference" CPU baseline in bench.py.
 #include <chrono>
 #include <cstdint>
+#include <exception>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -133,7 +134,11 @@ uint64_t ref_matcher_regions_match_u8(const uint8_t* const* desc_rows, const uin
   matching::PairWiseMatches out;
   matching_image_collection::Matcher_Regions matcher(dist_ratio, matching::BRUTE_FORCE_L2);
   std::shared_ptr<sfm::Regions_Provider> base = provider;
-  matcher.Match(base, pairs, out, nullptr);
+  try {   // (the reference's Match never throws; a replacement TU asked to - MVGX_ON_DEVICE_ERROR=throw - must not unwind into ctypes)
+    matcher.Match(base, pairs, out, nullptr);
+  } catch (const std::exception&) {
+    return UINT64_MAX;
+  }
   std::vector<uint32_t> flat;
   for (const auto& kv : out) {
     flat.resize(kv.second.size() * 2);

@@ -111,7 +111,9 @@ def ref_matcher_regions_match(descs, pairs, dist_ratio, lib=None):
         out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(n), 2)).copy()
 
     cb = SINK(sink)
-    (lib or ref_match()).ref_matcher_regions_match_u8(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    n = (lib or ref_match()).ref_matcher_regions_match_u8(ptrs, cnt, len(arrs), pairs.ctypes.data, len(pairs), np.float32(dist_ratio), cb, None)
+    if n == 2 ** 64 - 1:
+        raise RuntimeError("Matcher_Regions::Match threw")
     return out
 
 

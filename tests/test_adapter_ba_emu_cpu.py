@@ -47,3 +47,21 @@ def test_functors_control_points_priors(name):
     assert abs(stats[1] - ref_stats[1]) < 1e-6, (stats[1], ref_stats[1])
     assert np.allclose(pts, z[f"{tag}/ref_points"], atol=1e-5)
     assert np.allclose(poses[:, 3:], z[f"{tag}/ref_poses"][:, 3:], atol=1e-5)
+
+
+def test_injected_device_failure_makes_adjust_return_false(monkeypatch, capfd):
+    """error convention of the boundary: Adjust() reports a failing device through its return value, like the reference
+    reports an unusable solution (sfm_data_BA_ceres.cpp:503-507) - no exception, poses / intrinsics untouched"""
+    z = _golden()
+    tag = "tiny_pinhole|14|6|1"
+    keys = ("poses", "intrinsics", "intr_model", "points", "obs_pose", "obs_intr", "obs_point", "obs_xy")
+    sc = {k: z[f"{tag}/{k}"].copy() for k in keys}
+    sc["n_poses"] = len(sc["poses"]); sc["n_intrinsics"] = len(sc["intrinsics"]); sc["n_points"] = len(sc["points"]); sc["n_obs"] = len(sc["obs_pose"])
+    monkeypatch.setenv("MVGX_ADAPTER_INJECT_FAILURE", "ba:create")
+    rc, stats, poses, intr, pts = _oracle.ref_ba_adjust(sc, 14, 6, 1, lib=_oracle.adapter_ba_emu())
+    monkeypatch.delenv("MVGX_ADAPTER_INJECT_FAILURE")
+    assert stats[3] == 0.0   # Adjust returned false
+    assert np.array_equal(intr, sc["intrinsics"])
+    assert "Adjust() returns false" in capfd.readouterr().err
+    rc, stats, *_ = _oracle.ref_ba_adjust(sc, 14, 6, 1, lib=_oracle.adapter_ba_emu())   # and the next call works
+    assert stats[3] == 1.0

@@ -20,12 +20,22 @@ def _same(a, b):
         assert np.array_equal(a[k], b[k]), k
 
 
+def _adapter_counters(lib, reset=False):
+    import ctypes as C
+    out = (C.c_uint64 * 3)()
+    lib.mvgx_adapter_counters(out, 1 if reset else 0)
+    return int(out[0]), int(out[1]), int(out[2])   # device pairs, fallback pairs, device failures
+
+
 def test_matcher_regions_replacement_equals_reference():
     descs = synth.image_descriptors(7, n_desc=450, seed=11)
     descs[3] = descs[3][:0]          # an image without regions (Matcher_Regions.cpp:65-69,85-90)
     descs[5] = descs[5][:1]          # a database of one descriptor: NN=2 > rows (matcher_brute_force.hpp:108-113)
     pairs = matching.exhaustive_pairs_array(7)
+    _adapter_counters(_oracle.adapter(), reset=True)
     got = _oracle.ref_matcher_regions_match(descs, pairs, 0.8, lib=_oracle.adapter())
+    # the container came from the device: every pair counted there, the reference route behind the error policy never entered
+    assert _adapter_counters(_oracle.adapter(), reset=True) == (len(pairs), 0, 0)
     off, ij = _oracle.port_matcher_regions_match(descs, pairs, 0.8)
     _same(got, _oracle.offsets_to_dict(pairs, off, ij))
     if _oracle.have_ref_match():

@@ -135,3 +135,24 @@ def test_adapter_specialisation_fills_the_container_like_the_reference_template(
         got = _oracle.geofilter_container("adapter_emu", feats, wh, putative, max_iterations=512, k1=k1)
         assert set(want) == set(got) and len(want) >= 2
         assert all(np.array_equal(want[k], got[k]) for k in want)
+
+
+def test_adapter_specialisation_injected_device_failure_uses_the_reference_functor(monkeypatch, capfd):
+    """error convention (openmvg_amd/adapter/mvgx_adapter_policy.hpp): a failing device call is logged once and the pairs run through
+    the reference's own functor.Robust_estimation inside the replacement - same container as the reference template, no exception"""
+    import ctypes as C
+    if _oracle.geofilter_container_lib("adapter_emu") is None or _oracle.geofilter_container_lib("reference") is None:
+        pytest.skip("adapter harness / reference library not present")
+    from tests._geofilter_scene import collection
+    feats, wh, putative = collection(n_pairs=8, seed=5, n_max=120)
+    want = _oracle.geofilter_container("reference", feats, wh, putative)
+    lib = _oracle.geofilter_container_lib("adapter_emu")
+    out = (C.c_uint64 * 3)()
+    lib.mvgx_adapter_counters(out, 1)
+    monkeypatch.setenv("MVGX_ADAPTER_INJECT_FAILURE", "geofilter:run")
+    got = _oracle.geofilter_container("adapter_emu", feats, wh, putative)
+    monkeypatch.delenv("MVGX_ADAPTER_INJECT_FAILURE")
+    lib.mvgx_adapter_counters(out, 1)
+    assert (int(out[0]), int(out[1]), int(out[2])) == (0, len(putative), 1)
+    assert got.keys() == want.keys() and all(np.array_equal(got[k], want[k]) for k in want)
+    assert "continuing with the reference's own CPU code" in capfd.readouterr().err
