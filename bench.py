@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--side-deadline", type=float, default=900.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="TEST HOOK (tests/test_bench_rehearsal_cpu.py), never a measurement: the N > 1 control flow of this file on a box "
+                         "without GPUs - gloo process group, the HIP emulation libraries of tests/native (the same device source compiled "
+                         "for the host) in place of libmvgx_hip.so, the BA exchange through the callback transport over gloo, a tiny image "
+                         "set and BA scene. The printed line carries \"rehearsal\": true.")
     return ap.parse_args()
 
 
@@ -126,15 +131,28 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rehearsal = args.rehearsal
+    if rehearsal:
+        # the emulation libraries are test infrastructure (tests/_emu.py): only this flag routes the C ABI to them
+        from tests import _emu
+        globals()['_emulation'] = _emu.emulated()   # (kept alive: the context manager restores the real library when collected)
+        globals()['_emulation'].__enter__()
+        local_rank = 0
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    tdev = "cpu" if rehearsal else "cuda"
 
     from openmvg_amd import matching, synth
 
-    n_images = args.images if args.images > 0 else (10000 if world >= 8 else 1000)
+    n_images = args.images if args.images > 0 else (10 if rehearsal else 10000 if world >= 8 else 1000)
+    if rehearsal:
+        args.desc = min(args.desc, 96)
     descs = synth.image_descriptors(n_images, n_desc=args.desc, seed=0xC0FFEE00)
     all_pairs = matching.exhaustive_pairs_array(n_images)
     from openmvg_amd import sharding
@@ -147,7 +165,8 @@ def main():
         if rank == 0:
             import subprocess
             try:
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_selfcheck.py")], capture_output=True, text=True, timeout=600)
+                env = dict(os.environ, MVGX_SELFCHECK_REHEARSAL="1") if rehearsal else None
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_selfcheck.py")], capture_output=True, text=True, timeout=600, env=env)
                 selfcheck = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"ok": False, "error": r.stderr[-400:]}
             except Exception as e:
                 selfcheck = {"ok": False, "error": repr(e)}
@@ -168,6 +187,8 @@ def main():
         ctx.set_option("verify_alone", args.verify_alone)
     if args.batch_pairs > 0:
         ctx.set_option("batch_pairs", args.batch_pairs)
+    elif rehearsal:
+        ctx.set_option("batch_pairs", 8)   # several batches through the two-slot pipeline
     elif len(pairs) < 16 * 32768:   # a shard of the 1k-image set: keep >= 16 batches in the two-slot pipeline (fill / drain)
         ctx.set_option("batch_pairs", max(4096, len(pairs) // 16))
     ctx.set_option("profile", 1)
@@ -177,7 +198,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     def one_pass():
         if args.collect:
@@ -204,7 +226,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([dt, float(desc_pairs), kernel_ms, float(launches)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(desc_pairs), kernel_ms, float(launches)], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -234,6 +256,7 @@ def main():
             "vs_baseline": None,
             "dtype": "i8 (int32 accumulate)",
             "data": "synthetic",
+            **({"rehearsal": True} if rehearsal else {}),
             "config": {"workload": f"{n_images} images x {args.desc} SIFT-like uint8x128 descriptors, exhaustive pairs "
                                    f"({len(all_pairs)} image pairs, {len(pairs)} on rank 0), ratio {args.ratio}",
                        "kernel_variant": variant, "matches_rank0": matches,
@@ -273,7 +296,7 @@ def main():
                     par = {"pairs_checked": 0, "non_empty_pairs": 0, "matches_checked": 0, "identical": False, "error": repr(e)}
             dist.barrier()
         t = torch.tensor([float(par["pairs_checked"]), float(par["non_empty_pairs"]), float(par["matches_checked"]),
-                          0.0 if par["identical"] else 1.0], dtype=torch.float64, device="cuda")
+                          0.0 if par["identical"] else 1.0], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         if rank == 0:
             out["parity"] = {"pairs_checked": int(t[0]), "non_empty_pairs": int(t[1]), "matches_checked": int(t[2]),
@@ -297,12 +320,12 @@ def main():
     if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
         try:
             from bench_ba import ba_bench_record
-            ba_rec = ba_bench_record(local_rank, world, cpu=not args.no_cpu_baseline)
-            if world == 1 and not args.no_ba_c5:   # configs[4] fits one GPU: reported beside its sharded runs at N > 1
+            ba_rec = ba_bench_record(local_rank, world, cpu=not args.no_cpu_baseline, rehearsal=rehearsal)
+            if world == 1 and not args.no_ba_c5 and not rehearsal:   # configs[4] fits one GPU: reported beside its sharded runs at N > 1
                 ba_c5 = ba_bench_record(local_rank, 1, cpu=not args.no_cpu_baseline, name="c5")
         except Exception as e:  # the BA leg is a side record: never lose the matching line
             ba_rec = ba_rec or {"status": f"failed: {e!r}"}
-    if rank == 0 and world == 1 and not args.no_hamming:
+    if rank == 0 and world == 1 and not args.no_hamming and not rehearsal:
         try:
             from bench_hamming import hamming_bench_record, l2f_bench_record
             out["hamming"] = hamming_bench_record(local_rank, cpu=not args.no_cpu_baseline)

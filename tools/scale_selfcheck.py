@@ -22,6 +22,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     from openmvg_amd import _capi, ba, matching, synth
+    rehearsal = os.environ.get("MVGX_SELFCHECK_REHEARSAL") == "1"   # bench.py --rehearsal: emulated devices, tiny sizes, ordinals "0,0"
+    if rehearsal:
+        from tests import _emu
+        globals()['_emulation'] = _emu.emulated()   # (kept alive: the context manager restores the real library when collected)
+        globals()['_emulation'].__enter__()
+        os.environ.setdefault("MVGX_SELFCHECK_DEVICES", "0,0")
     n_dev = _capi.device_count()
     out = {"devices": int(n_dev)}
     env = os.environ.get("MVGX_SELFCHECK_DEVICES")   # e.g. "0,0": the sharded forms with a repeated ordinal on a one-GPU box (peer transport only)
@@ -33,20 +39,23 @@ def main():
     out["ordinals"] = devs
     ok = True
     # ---- matching ----
-    descs = synth.image_descriptors(64, n_desc=2000, seed=0xC0FFEE00)
-    pairs = matching.exhaustive_pairs_array(64)
+    n_img, n_desc = (6, 80) if rehearsal else (64, 2000)
+    descs = synth.image_descriptors(n_img, n_desc=n_desc, seed=0xC0FFEE00)
+    pairs = matching.exhaustive_pairs_array(n_img)
     rsq = np.float32(0.8) * np.float32(0.8)
     c1 = matching.MatchContext(0); c1.set_regions(descs)
     _, off1, ij1 = c1.run(pairs, rsq); c1.close()
     t0 = time.perf_counter()
-    cm = matching.MatchContext(devices=devs); cm.set_option("batch_pairs", 64); cm.set_regions(descs)
+    cm = matching.MatchContext(devices=devs); cm.set_option("batch_pairs", 4 if rehearsal else 64); cm.set_regions(descs)
     _, offm, ijm = cm.run(pairs, rsq); cm.close()
     same = bool(np.array_equal(off1, offm) and np.array_equal(ij1, ijm))
     out["matching"] = {"image_pairs": int(len(pairs)), "matches": int(off1[-1]), "identical_to_one_device": same, "seconds": time.perf_counter() - t0}
     ok &= same
     # ---- BA, both transports ----
     import bench_ba
-    scene = synth.ba_scene(**bench_ba.ba_config(1))
+    scene = synth.ba_scene(**bench_ba.ba_config(1, rehearsal=rehearsal))
+    if rehearsal:
+        os.environ["MVGX_BA_MULTI_MIN_OBS"] = "1"
     c = ba.BaContext(scene, device=0); s1 = c.solve(); c.close()
     out["ba"] = {"one_device": {"iterations": int(s1.num_iterations), "final_rmse": float(s1.final_rmse)}}
     for transport in (("rccl", "peer") if len(set(devs)) == len(devs) else ("peer",)):   # RCCL needs distinct devices
