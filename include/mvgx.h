@@ -434,6 +434,25 @@ int mvgx_geofilter_h_acransac_indexed(int device, const double* feat_xy, const u
                                       const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs,
                                       const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                                       mvgx_geofilter_stats* stats /* may be NULL */);
+/* The essential-matrix model, GeometricFilter_EMatrix_AC (matching_image_collection/E_ACRobust.hpp:39-150; main_GeometricFilter -g e,
+ * the model of the calibrated pipelines): ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError> + ACRANSAC with samples of
+ * five, up to ten models per sample (multiview/solver_essential_five_point.cpp:170-230 on the device: null space, constraint expansion,
+ * Gauss-Jordan elimination, Hessenberg + shifted QR iteration of the 10 x 10 action matrix, one wave per image pair), residuals =
+ * EpipolarDistanceError of F = K_J^-T E K_I^-1 on the PIXEL positions, precision in pixels (no normalisation), acceptance above
+ * 2.5 x 5 inliers. Additional inputs: the cameras' bearing vectors of the positions (what Pinhole_Intrinsic::operator()(x) returns,
+ * Camera_Pinhole.hpp:136-139: normalised Kinv (x, y, 1); 3 doubles per match, or per feature in the indexed form - computed by the
+ * caller with the camera's own code) and the calibration matrices (row-major 3 x 3: 18 doubles per pair {K_I, K_J}, or 9 per image).
+ * results[p].F receives m_E, results[p].precision_robust = ACRansacOut.first as the reference stores it (for this adaptor the SQUARED
+ * pixel distance: ACKernelAdaptorEssential::unormalizeError returns its argument). Same parity policy as the F / H models. */
+int mvgx_geofilter_e_acransac(int device, const double* xI, const double* xJ, const double* bearingI, const double* bearingJ,
+                              const uint64_t* match_start, const uint32_t* image_wh, const double* K, uint64_t n_pairs,
+                              const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                              mvgx_geofilter_stats* stats /* may be NULL */);
+int mvgx_geofilter_e_acransac_indexed(int device, const double* feat_xy, const double* feat_bearing, const uint64_t* feat_start,
+                                      const uint32_t* image_wh, const double* image_K, uint32_t n_images, const uint32_t* pairs,
+                                      const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs, const mvgx_geofilter_options* opt,
+                                      uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats /* may be NULL */);
+
 
 #ifdef __cplusplus
 }

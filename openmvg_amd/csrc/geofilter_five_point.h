@@ -1,0 +1,503 @@
+// geofilter_five_point.h - the five-point relative-pose solver of the essential-matrix model, one wave per sample (included by
+// mvgx_geofilter.hip after its helpers: wave_sync, lane_value_f64, shfl_f64, wave_max_u32).
+//
+// Reference (paths under /root/reference/src/openMVG): multiview/solver_essential_five_point.cpp:170-230 FivePointsRelativePose =
+//   1. FivePointsNullspaceBasis :35-42      four-dimensional null space of the 5 x 9 epipolar system (there: the eigenvectors of A^T A)
+//   2. FivePointsPolynomialConstraints :115-168   det(E) = 0 and 2 E E^T E - trace(E E^T) E = 0 on E = x E1 + y E2 + z E3 + E4: ten cubic
+//                                            polynomials, monomial order [xxx xxy xyy yyy xxz xyz yyz xzz yzz zzz | xx xy yy xz yz zz x y z 1]
+//   3. Gauss-Jordan elimination of the 10 x 20 system on its cubic columns (there: FullPivLU of the left block, solve) :180-182
+//   4. action matrix of the multiplication by x on [xx xy yy xz yz zz x y z 1] :187-193
+//   5. real eigenvalues / eigenvectors of the 10 x 10 action matrix (there: Eigen::EigenSolver = Householder Hessenberg + Francis
+//      double-shift QR), E = E_basis (x, y, z, 1) from the last four eigenvector components :195-212
+// What runs where: 1 - elimination with complete pivoting over 45 lanes, then a Gram-Schmidt pass (the reference's basis is
+// orthonormal: the conditioning of 2 - 5 depends on it); 2 - lane r builds row r of the constraint matrix; 3 - lane r owns row r,
+// pivot rows travel through v_readlane; 5 - Householder Hessenberg reduction and the EISPACK hqr iteration on the wave's 10 x 10 matrix
+// in LDS: the shift logic is wave-uniform scalar code, the row / column updates of every reflector are spread over the lanes; the ten
+// candidate eigenvectors are then solved for at once, lane s taking eigenvalue s (the action matrix's rows 6 - 9 give four components in
+// closed form, the other five are the least-squares solution of a 6 x 5 system by Householder QR - no lane crossing).
+// Not bit-exact with Eigen (another null-space basis, another elimination order, no Schur vectors): an essential matrix agrees with
+// the reference's to rounding; the parity policy of the F and H models applies (tests/_geofilter_cases.py).
+#pragma once
+
+namespace five_point {
+
+constexpr int kN = 10;          // order of the action matrix
+constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */;   // doubles of wave-private LDS
+
+// ---- polynomials in (x, y, z): degree 1 as {x, y, z, 1}, degree 2 as {xx, xy, yy, xz, yz, zz, x, y, z, 1} (the reference's columns
+// 10..19), degree 3 in the reference's full order (solver_essential_five_point.hpp:103-125) ----
+__device__ __forceinline__ void o1(const double (&a)[4], const double (&b)[4], double (&r)[10]) {   // :44-66
+  r[0] = a[0] * b[0];
+  r[1] = a[0] * b[1] + a[1] * b[0];
+  r[2] = a[1] * b[1];
+  r[3] = a[0] * b[2] + a[2] * b[0];
+  r[4] = a[1] * b[2] + a[2] * b[1];
+  r[5] = a[2] * b[2];
+  r[6] = a[0] * b[3] + a[3] * b[0];
+  r[7] = a[1] * b[3] + a[3] * b[1];
+  r[8] = a[2] * b[3] + a[3] * b[2];
+  r[9] = a[3] * b[3];
+}
+// r += a (degree 2) x b (degree 1)   (:68-113)
+__device__ __forceinline__ void o2_add(const double (&a)[10], const double (&b)[4], double (&r)[20]) {
+  const double axx = a[0], axy = a[1], ayy = a[2], axz = a[3], ayz = a[4], azz = a[5], ax = a[6], ay = a[7], az = a[8], a1 = a[9];
+  const double bx = b[0], by = b[1], bz = b[2], b1 = b[3];
+  r[0] += axx * bx;
+  r[1] += axx * by + axy * bx;
+  r[2] += axy * by + ayy * bx;
+  r[3] += ayy * by;
+  r[4] += axx * bz + axz * bx;
+  r[5] += axy * bz + ayz * bx + axz * by;
+  r[6] += ayy * bz + ayz * by;
+  r[7] += axz * bz + azz * bx;
+  r[8] += ayz * bz + azz * by;
+  r[9] += azz * bz;
+  r[10] += axx * b1 + ax * bx;
+  r[11] += axy * b1 + ax * by + ay * bx;
+  r[12] += ayy * b1 + ay * by;
+  r[13] += axz * b1 + ax * bz + az * bx;
+  r[14] += ayz * b1 + ay * bz + az * by;
+  r[15] += azz * b1 + az * bz;
+  r[16] += ax * b1 + a1 * bx;
+  r[17] += ay * b1 + a1 * by;
+  r[18] += az * b1 + a1 * bz;
+  r[19] += a1 * b1;
+}
+
+// ---- 1. null space: basis[u][k] = component u (row-major 3 x 3 index) of basis vector k, the same in every lane ----
+__device__ __forceinline__ void nullspace(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[7], int lane, double (&basis)[9][4]) {
+  // lane 9 r + c holds A[r][c] = x2[c / 3] x1[c % 3] of sample point r < 5 (EncodeEpipolarEquation, solver_fundamental_kernel.hpp:83-93)
+  const int r = lane < 45 ? lane / 9 : 4, c = lane < 45 ? lane - 9 * (lane / 9) : 8;
+  uint32_t si = s[0];
+#pragma unroll
+  for (int k = 1; k < 5; ++k) si = (r == k) ? s[k] : si;
+  const int ci = c / 3, cj = c - 3 * ci;
+  double a = b2[3 * (size_t)si + ci] * b1[3 * (size_t)si + cj];
+  uint32_t row_used = 0, col_used = 0;
+  int prow[5], pcol[5], n_piv = 0;
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    const bool cand = lane < 45 && !((row_used >> r) & 1u) && !((col_used >> c) & 1u);
+    const float mag = (float)fabs(a);
+    const uint32_t key = (cand && mag > 0.f && mag == mag) ? ((__float_as_uint(mag) & ~63u) | (uint32_t)(63 - lane)) : 0u;
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) break;   // rank deficient sample (wave-uniform)
+    const int who = 63 - (int)(best & 63u);
+    const int pr = who / 9, pc = who - 9 * (who / 9);
+    const double ipiv = 1.0 / lane_value_f64(a, who);
+    const double rowv = shfl_f64(a, 9 * pr + c);   // pivot row, my column
+    const double colv = shfl_f64(a, 9 * r + pc);   // my row, pivot column
+    if (r != pr) a -= (colv * ipiv) * rowv;
+    row_used |= 1u << pr; col_used |= 1u << pc;
+    prow[step] = pr; pcol[step] = pc;
+    n_piv = step + 1;
+  }
+  int fcol[4] = {8, 8, 8, 8}, nf = 0;
+#pragma unroll
+  for (int u = 0; u < 9; ++u)
+    if (!((col_used >> u) & 1u) && nf < 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k == nf) fcol[k] = u;
+      ++nf;
+    }
+  // lane u < 9: component u of the four vectors - 1 at the vector's free column, -A[prow][free] / A[prow][pcol] at a pivot column
+  double bu[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bu[k] = lane == fcol[k] ? 1.0 : 0.0;
+#pragma unroll
+  for (int step = 0; step < 5; ++step) {
+    if (step < n_piv) {   // wave-uniform
+      const double iden = 1.0 / lane_value_f64(a, 9 * prow[step] + pcol[step]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double nk = lane_value_f64(a, 9 * prow[step] + fcol[k]);
+        if (lane == pcol[step]) bu[k] = -nk * iden;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 9; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) basis[u][k] = lane_value_f64(bu[k], u);
+  // modified Gram-Schmidt (every lane the same arithmetic)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      double d = 0.0;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) d += basis[u][j] * basis[u][k];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) basis[u][k] -= d * basis[u][j];
+    }
+    double n2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) n2 += basis[u][k] * basis[u][k];
+    const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) basis[u][k] *= inv;
+  }
+}
+
+// ---- 2. row `row` (< 10, this lane's) of the constraint matrix: 0 = det(E), 1 + 3 i + j = (2 E E^T E - trace(E E^T) E)(i, j) / 2 ----
+__device__ __forceinline__ void constraint_row(const double (&basis)[9][4], int row, double (&m)[20]) {
+#pragma unroll
+  for (int t = 0; t < 20; ++t) m[t] = 0.0;
+  // E[i][j] as a degree-1 polynomial: coefficients basis[3 i + j][0..3]
+  if (row == 0) {   // (:127-129)
+    double p[10], q[10], d[10];
+    o1(basis[1], basis[5], p); o1(basis[2], basis[4], q);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
+    o2_add(d, basis[6], m);
+    o1(basis[2], basis[3], p); o1(basis[0], basis[5], q);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
+    o2_add(d, basis[7], m);
+    o1(basis[0], basis[4], p); o1(basis[1], basis[3], q);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
+    o2_add(d, basis[8], m);
+    return;
+  }
+  const int i = (row - 1) / 3, j = (row - 1) - 3 * i;
+  // half the trace of E E^T (:147)
+  double tr[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) tr[t] = 0.0;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    double p[10];
+    o1(basis[u], basis[u], p);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) tr[t] += p[t];
+  }
+  // row i of E (this lane's i) and column j of E
+  double ei[3][4], ej[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ei[k][t] = i == 0 ? basis[k][t] : i == 1 ? basis[3 + k][t] : basis[6 + k][t];
+      ej[k][t] = j == 0 ? basis[3 * k][t] : j == 1 ? basis[3 * k + 1][t] : basis[3 * k + 2][t];
+    }
+  // L[i][k] = (E E^T)(i, k) - (i == k) trace / 2, then sum_k L[i][k] E[k][j]   (:136-160)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double l[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) l[t] = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < 3; ++mm) {
+      double p[10];
+      o1(ei[mm], basis[3 * k + mm], p);
+#pragma unroll
+      for (int t = 0; t < 10; ++t) l[t] += p[t];
+    }
+    if (i == k) {
+#pragma unroll
+      for (int t = 0; t < 10; ++t) l[t] -= 0.5 * tr[t];
+    }
+    o2_add(l, ej[k], m);
+  }
+}
+
+// ---- 3 + 4. lane r < 10 owns row r of [left | right]; Gauss-Jordan with complete pivoting on the left block; the action matrix goes to
+// H (LDS, row-major 10 x 10). Returns false (wave-uniform) if the left block is singular to working precision. ----
+__device__ __forceinline__ bool action_matrix(double (&m)[20], int lane, double* __restrict__ H) {
+  uint32_t row_used = 0, col_used = 0;
+  int my_pcol = -1;   // the pivot column of this lane's row
+  const int r = lane < kN ? lane : kN - 1;
+#pragma unroll 1
+  for (int step = 0; step < kN; ++step) {
+    uint32_t key = 0u;
+    if (lane < kN && !((row_used >> r) & 1u)) {
+#pragma unroll
+      for (int c = 0; c < kN; ++c) {
+        const float mag = (float)fabs(m[c]);
+        const uint32_t k = (!((col_used >> c) & 1u) && mag > 0.f && mag == mag) ? ((__float_as_uint(mag) & ~127u) | (uint32_t)(127 - (kN * r + c))) : 0u;
+        key = k > key ? k : key;
+      }
+    }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) return false;   // (wave-uniform)
+    const int who = 127 - (int)(best & 127u);
+    const int pr = who / kN, pc = who - kN * pr;
+    double rowv[20];
+#pragma unroll
+    for (int c = 0; c < 20; ++c) rowv[c] = lane_value_f64(m[c], pr);
+    double piv = rowv[0], colv = m[0];
+#pragma unroll
+    for (int c = 1; c < kN; ++c) { piv = (c == pc) ? rowv[c] : piv; colv = (c == pc) ? m[c] : colv; }
+    const double f = colv * (1.0 / piv);
+    if (lane < kN && r != pr) {
+#pragma unroll
+      for (int c = 0; c < 20; ++c) m[c] -= f * rowv[c];
+    }
+    if (lane == pr) my_pcol = pc;
+    row_used |= 1u << pr; col_used |= 1u << pc;
+  }
+  // B[pcol] = right part of the row / its pivot; rows 0 1 2 4 5 7 of B are the rows 0..5 of the action matrix (:187-192)
+  if (lane < kN) {
+    double piv = m[0];
+#pragma unroll
+    for (int c = 1; c < kN; ++c) piv = (c == my_pcol) ? m[c] : piv;
+    const double ip = 1.0 / piv;
+    const int dst = my_pcol == 0 ? 0 : my_pcol == 1 ? 1 : my_pcol == 2 ? 2 : my_pcol == 4 ? 3 : my_pcol == 5 ? 4 : my_pcol == 7 ? 5 : -1;
+    if (dst >= 0) {
+#pragma unroll
+      for (int c = 0; c < kN; ++c) H[dst * kN + c] = m[kN + c] * ip;
+    }
+  } else if (lane >= 16 && lane < 16 + 4 * kN) {   // rows 6..9: -1 at (6,0) (7,1) (8,3) (9,6)
+    const int e = lane - 16, rr = 6 + e / kN, cc = e - kN * (e / kN);
+    const int one = rr == 6 ? 0 : rr == 7 ? 1 : rr == 8 ? 3 : 6;
+    H[rr * kN + cc] = cc == one ? -1.0 : 0.0;
+  }
+  wave_sync();
+  return true;
+}
+
+// ---- 5a. Householder reduction of H (LDS) to upper Hessenberg form; v = 10 doubles of LDS ----
+__device__ __forceinline__ void hessenberg(double* __restrict__ H, double* __restrict__ v, int lane) {
+#pragma unroll 1
+  for (int k = 0; k < kN - 2; ++k) {
+    double s = 0.0;
+    for (int i = k + 2; i < kN; ++i) { const double t = H[i * kN + k]; s += t * t; }   // (wave-uniform reads)
+    if (s == 0.0) continue;
+    const double x0 = H[(k + 1) * kN + k];
+    const double norm = sqrt(x0 * x0 + s);
+    const double v0 = x0 + (x0 >= 0.0 ? norm : -norm);
+    const double tau = 1.0 / (norm * fabs(v0));   // 2 / (v^T v)
+    wave_sync();
+    if (lane > k && lane < kN) v[lane] = lane == k + 1 ? v0 : H[lane * kN + k];
+    wave_sync();
+    if (lane >= k && lane < kN) {   // (I - tau v v^T) H: column `lane`
+      double d = 0.0;
+      for (int i = k + 1; i < kN; ++i) d += v[i] * H[i * kN + lane];
+      d *= tau;
+      for (int i = k + 1; i < kN; ++i) H[i * kN + lane] -= d * v[i];
+    }
+    wave_sync();
+    if (lane < kN) {   // H (I - tau v v^T): row `lane`
+      double d = 0.0;
+      for (int j = k + 1; j < kN; ++j) d += H[lane * kN + j] * v[j];
+      d *= tau;
+      for (int j = k + 1; j < kN; ++j) H[lane * kN + j] -= d * v[j];
+    }
+    wave_sync();
+    if (lane > k + 1 && lane < kN) H[lane * kN + k] = 0.0;
+    wave_sync();
+  }
+}
+
+// ---- 5b. eigenvalues of the upper Hessenberg H (destroyed): the EISPACK hqr iteration (Francis double shift, the exceptional shifts at
+// iterations 10 and 20, 30 iterations per eigenvalue at most). The shift logic is the same scalar code in every lane (reads of LDS at
+// wave-uniform addresses); a reflector's row update runs on lanes k..nn (one column each), its column update on lanes l..min(nn, k + 3).
+// Returns false if an eigenvalue did not converge. ----
+__device__ __forceinline__ bool hqr(double* __restrict__ a, double* __restrict__ wr, double* __restrict__ wi, int lane) {
+  auto A = [&](int i, int j) -> double& { return a[i * kN + j]; };
+  double anorm = 0.0;
+  for (int i = 0; i < kN; ++i)
+    for (int j = (i > 0 ? i - 1 : 0); j < kN; ++j) anorm += fabs(A(i, j));
+  int nn = kN - 1;
+  double t = 0.0;
+  while (nn >= 0) {
+    int its = 0, l;
+    do {
+      for (l = nn; l >= 1; --l) {
+        double s = fabs(A(l - 1, l - 1)) + fabs(A(l, l));
+        if (s == 0.0) s = anorm;
+        if (fabs(A(l, l - 1)) + s == s) {
+          wave_sync();
+          if (lane == 0) A(l, l - 1) = 0.0;
+          wave_sync();
+          break;
+        }
+      }
+      double x = A(nn, nn);
+      if (l == nn) {   // one root
+        wave_sync();
+        if (lane == 0) { wr[nn] = x + t; wi[nn] = 0.0; }
+        --nn;
+      } else {
+        double y = A(nn - 1, nn - 1), w = A(nn, nn - 1) * A(nn - 1, nn);
+        if (l == nn - 1) {   // two roots
+          const double p = 0.5 * (y - x), q = p * p + w;
+          double z = sqrt(fabs(q));
+          x += t;
+          wave_sync();
+          if (q >= 0.0) {
+            z = p + (p >= 0.0 ? fabs(z) : -fabs(z));
+            if (lane == 0) { wr[nn - 1] = wr[nn] = x + z; if (z != 0.0) wr[nn] = x - w / z; wi[nn - 1] = wi[nn] = 0.0; }
+          } else if (lane == 0) {
+            wr[nn - 1] = wr[nn] = x + p; wi[nn - 1] = z; wi[nn] = -z;
+          }
+          nn -= 2;
+        } else {
+          if (its == 30) return false;
+          if (its == 10 || its == 20) {   // exceptional shift
+            t += x;
+            wave_sync();
+            if (lane <= nn) A(lane, lane) -= x;
+            wave_sync();
+            const double s = fabs(A(nn, nn - 1)) + fabs(A(nn - 1, nn - 2));
+            y = x = 0.75 * s;
+            w = -0.4375 * s * s;
+          }
+          ++its;
+          int m;
+          double p = 0.0, q = 0.0, r = 0.0, z;
+          for (m = nn - 2; m >= l; --m) {
+            z = A(m, m);
+            r = x - z;
+            double s = y - z;
+            p = (r * s - w) / A(m + 1, m) + A(m, m + 1);
+            q = A(m + 1, m + 1) - z - r - s;
+            r = A(m + 2, m + 1);
+            s = fabs(p) + fabs(q) + fabs(r);
+            p /= s; q /= s; r /= s;
+            if (m == l) break;
+            const double u = fabs(A(m, m - 1)) * (fabs(q) + fabs(r));
+            const double vv = fabs(p) * (fabs(A(m - 1, m - 1)) + fabs(z) + fabs(A(m + 1, m + 1)));
+            if (u + vv == vv) break;
+          }
+          wave_sync();
+          if (lane >= m + 2 && lane <= nn) {
+            A(lane, lane - 2) = 0.0;
+            if (lane != m + 2) A(lane, lane - 3) = 0.0;
+          }
+          wave_sync();
+          for (int k = m; k <= nn - 1; ++k) {
+            if (k != m) {
+              p = A(k, k - 1); q = A(k + 1, k - 1); r = 0.0;
+              if (k != nn - 1) r = A(k + 2, k - 1);
+              if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+            }
+            const double sq = sqrt(p * p + q * q + r * r);
+            const double s = p >= 0.0 ? sq : -sq;
+            if (s != 0.0) {
+              wave_sync();
+              if (lane == 0) {
+                if (k == m) { if (l != m) A(k, k - 1) = -A(k, k - 1); }
+                else A(k, k - 1) = -s * x;
+              }
+              p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+              wave_sync();
+              if (lane >= k && lane <= nn) {   // row modification, column `lane`
+                double pp = A(k, lane) + q * A(k + 1, lane);
+                if (k != nn - 1) { pp += r * A(k + 2, lane); A(k + 2, lane) -= pp * z; }
+                A(k + 1, lane) -= pp * y;
+                A(k, lane) -= pp * x;
+              }
+              wave_sync();
+              const int mmin = nn < k + 3 ? nn : k + 3;
+              if (lane >= l && lane <= mmin) {   // column modification, row `lane`
+                double pp = x * A(lane, k) + y * A(lane, k + 1);
+                if (k != nn - 1) { pp += z * A(lane, k + 2); A(lane, k + 2) -= pp * r; }
+                A(lane, k + 1) -= pp * q;
+                A(lane, k) -= pp;
+              }
+              wave_sync();
+            }
+          }
+        }
+      }
+    } while (l < nn - 1);
+  }
+  wave_sync();
+  return true;
+}
+
+// ---- 5c. the eigenvector of the action matrix `At` (LDS, the matrix before the reduction) for the real eigenvalue lam, per lane: rows 6..9
+// give v0 = lam^2 v9, v1 = -lam v7, v3 = -lam v8, v6 = -lam v9; with v9 = 1 the unknowns (v2, v4, v5, v7, v8) solve the 6 x 5 system of
+// rows 0..5 in the least-squares sense (Householder QR). tail = (v6, v7, v8, v9) = (x, y, z, 1) of the solution. ----
+__device__ __forceinline__ void eigenvector_tail(const double* __restrict__ At, double lam, double (&tail)[4]) {
+  double C[6][6];   // columns 0..4: unknowns v2 v4 v5 v7 v8; column 5: the right-hand side
+  const double l2 = lam * lam;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double* __restrict__ a = At + r * kN;
+    C[r][0] = a[2] - (r == 2 ? lam : 0.0);
+    C[r][1] = a[4] - (r == 4 ? lam : 0.0);
+    C[r][2] = a[5] - (r == 5 ? lam : 0.0);
+    C[r][3] = a[7] - lam * a[1] + (r == 1 ? l2 : 0.0);
+    C[r][4] = a[8] - lam * a[3] + (r == 3 ? l2 : 0.0);
+    C[r][5] = -(a[0] * l2 - a[6] * lam + a[9]) + (r == 0 ? l2 * lam : 0.0);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {   // Householder reflection of column k, applied to the columns behind it and to the right-hand side
+    double s = 0.0;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) s += C[i][k] * C[i][k];
+    const double x0 = C[k][k];
+    const double norm = sqrt(x0 * x0 + s);
+    if (norm > 0.0) {
+      const double v0 = x0 + (x0 >= 0.0 ? norm : -norm);
+      const double tau = 1.0 / (norm * fabs(v0));
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) {
+        double d = v0 * C[k][j];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) d += C[i][k] * C[i][j];
+        d *= tau;
+        C[k][j] -= d * v0;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) C[i][j] -= d * C[i][k];
+      }
+      C[k][k] = x0 >= 0.0 ? -norm : norm;
+    }
+  }
+  double u[5];
+#pragma unroll
+  for (int k = 4; k >= 0; --k) {   // back-substitution R u = Q^T d
+    double t = C[k][5];
+#pragma unroll
+    for (int j = k + 1; j < 5; ++j) t -= C[k][j] * u[j];
+    u[k] = t / C[k][k];
+  }
+  tail[0] = -lam; tail[1] = u[3]; tail[2] = u[4]; tail[3] = 1.0;
+}
+
+// FivePointSolver::Solve on the sample s[0..4] (wave-uniform). scr: kScratch doubles of wave-private LDS. The essential matrices of
+// the real solutions (row-major 3 x 3) go to Es[model][9] (LDS, 10 x 9 doubles); returns their number (wave-uniform).
+__device__ __forceinline__ int solve(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[7], int lane,
+                                     double* __restrict__ scr, double* __restrict__ Es) {
+  double* const H = scr;
+  double* const v = scr + 100;
+  double* const wr = v + 10;
+  double* const wi = wr + 10;
+  double basis[9][4];
+  nullspace(b1, b2, s, lane, basis);
+  double At_row[kN];   // this lane's row of the action matrix (lanes < 10): kept for the eigenvectors, H is destroyed by the iteration
+  {
+    double m[20];
+    constraint_row(basis, lane < kN ? lane : kN - 1, m);
+    wave_sync();
+    if (!action_matrix(m, lane, H)) return 0;
+  }
+#pragma unroll
+  for (int c = 0; c < kN; ++c) At_row[c] = H[(lane < kN ? lane : 0) * kN + c];
+  hessenberg(H, v, lane);
+  if (!hqr(H, wr, wi, lane)) return 0;
+  // the action matrix again (the iteration worked in place), then one eigenvector per lane
+#pragma unroll
+  for (int c = 0; c < kN; ++c)
+    if (lane < kN) H[lane * kN + c] = At_row[c];
+  wave_sync();
+  const double lam = wr[lane < kN ? lane : 0];
+  const bool real = lane < kN && wi[lane < kN ? lane : 0] == 0.0 && lam == lam && fabs(lam) < 1.0e150;
+  double tail[4] = {0.0, 0.0, 0.0, 0.0};
+  if (real) eigenvector_tail(H, lam, tail);
+  const unsigned long long real_mask = __ballot(real);
+  const int n = (int)__popcll(real_mask);
+  const int slot = (int)__popcll(real_mask & ((1ull << lane) - 1ull));
+  if (real) {
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+      Es[slot * 9 + u] = basis[u][0] * tail[0] + basis[u][1] * tail[1] + basis[u][2] * tail[2] + basis[u][3] * tail[3];
+  }
+  wave_sync();
+  return n;
+}
+
+}  // namespace five_point

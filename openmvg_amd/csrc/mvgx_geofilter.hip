@@ -47,8 +47,8 @@ constexpr int kBins = 20;        // robust_estimator_ACRansac.hpp:221
 constexpr int kMinSamples = 7, kMaxModels = 3;   // the fundamental-matrix model (SevenPointSolver)
 // The estimated model: the a-contrario loop is the same program for both, what differs is the minimal solver, the residual, the
 // sample size and - on the host - logalpha0 / multError of the NFA (point-to-line for F, point-to-point for H).
-enum GeoModel { kModelF = 0, kModelH = 1 };
-template <int MODEL> constexpr int model_min_samples() { return MODEL == kModelH ? 4 : kMinSamples; }   // Solver::MINIMUM_SAMPLES
+enum GeoModel { kModelF = 0, kModelH = 1, kModelE = 2 };
+template <int MODEL> constexpr int model_min_samples() { return MODEL == kModelH ? 4 : MODEL == kModelE ? 5 : kMinSamples; }   // Solver::MINIMUM_SAMPLES
 constexpr int kMtN = 624, kMtM = 397;
 
 struct GeoPair {   // per pair, prepared on the host (glibc's log10 / hypot / sqrt: the reference's values)
@@ -57,6 +57,7 @@ struct GeoPair {   // per pair, prepared on the host (glibc's log10 / hypot / sq
   double max_threshold, loge0, bins_by_interval;
   double bin_value[kBins];
   double logalpha_bin[kBins];   // logalpha0 + multError * log10(bin_value + FLT_EPSILON)
+  double k2it[9], k1i[9];       // essential model only: K2^-T and K1^-1 (row-major), F = K2^-T E K1^-1 (multiview/essential.cpp:48-53)
 };
 struct GeoResult {
   double F[9];             // best model, normalised coordinates (row-major); valid if have_model
@@ -179,8 +180,10 @@ __device__ __forceinline__ double homography_error(const double (&H)[9], double2
 }
 template <int MODEL>
 __device__ __forceinline__ double model_error(const double (&M)[9], double2 x, double2 y) {
-  return MODEL == kModelH ? homography_error(M, x, y) : epipolar_error(M, x, y);
+  return MODEL == kModelH ? homography_error(M, x, y) : epipolar_error(M, x, y);   // (the essential model evaluates its F = K2^-T E K1^-1)
 }
+
+#include "geofilter_five_point.h"
 
 // FourPointSolver::Solve on the sample s[0..3] (wave-uniform; multiview/solver_homography_kernel.cpp:37-93): the null vector of the
 // 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3. Lane r
@@ -378,18 +381,40 @@ __global__ __launch_bounds__(256) void geofilter_normalize_indexed_kernel(const 
   }
 }
 
+// essential model, indexed form: the bearing vectors of the matches gathered from the per-feature table
+__global__ __launch_bounds__(256) void geofilter_gather_bearings_kernel(const GeoPair* __restrict__ pairs, uint32_t n_pairs, const double* __restrict__ feat_bearing,
+                                                                        const uint64_t* __restrict__ feat_start, const uint2* __restrict__ pair_images,
+                                                                        const uint2* __restrict__ ij, double* __restrict__ b1, double* __restrict__ b2) {
+  const uint32_t p = blockIdx.x;
+  if (p >= n_pairs) return;
+  const uint64_t lo = pairs[p].start;
+  const uint32_t n = pairs[p].n;
+  const uint2 im = pair_images[p];
+  const double* __restrict__ fI = feat_bearing + 3 * feat_start[im.x];
+  const double* __restrict__ fJ = feat_bearing + 3 * feat_start[im.y];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint2 m = ij[lo + i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b1[3 * (lo + i) + k] = fI[3 * (size_t)m.x + k]; b2[3 * (lo + i) + k] = fJ[3 * (size_t)m.y + k]; }
+  }
+}
+
 constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (20) | the model of the current inlier list (18 words = 9 doubles at 8-byte alignment + 2)
+// the essential model adds the five-point solver's workspace, its up to ten essential matrices and their fundamental matrices
+constexpr int kEssentialScratch = 2 * (five_point::kScratch + 90 + 90);
+template <int MODEL> constexpr int wave_scratch_words() { return kWaveScratch + (MODEL == kModelE ? kEssentialScratch : 0); }
 
 // kGlobalTables: the sampling pool and the two log-combinatorial tables of a wave (3 x n words) live in a global scratch block
 // instead of LDS - the class of pairs with more correspondences than a workgroup's LDS holds (one wave per workgroup; the generator,
 // the histogram and the model stay in LDS)
 template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF>
-__global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
                                                                           const uint32_t* __restrict__ mt_init, uint32_t max_iterations,
                                                                           GeoResult* __restrict__ results, uint8_t* __restrict__ mask,
-                                                                          uint32_t* __restrict__ table_scratch = nullptr) {
+                                                                          uint32_t* __restrict__ table_scratch = nullptr,
+                                                                          const double* __restrict__ bear1 = nullptr, const double* __restrict__ bear2 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * WAVES + wave;
@@ -398,19 +423,24 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
   uint32_t n_iter_run = 0, n_models_run = 0;
   constexpr int kMin = model_min_samples<MODEL>();
   const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
-  const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + kWaveScratch;   // words: generator | pool | logc_n | logc_k | scratch
+  const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + wave_scratch_words<MODEL>();   // words: generator | pool | logc_n | logc_k | scratch
   uint32_t* const mt = lds_u32 + (size_t)wave * per_wave;
   uint32_t* const pool = kGlobalTables ? table_scratch + (size_t)w * 3 * cap1 : mt + kMtN;
   float* const logc_n = reinterpret_cast<float*>(pool + cap1);
   float* const logc_k = logc_n + cap1;
   uint32_t* const hist = kGlobalTables ? mt + kMtN : reinterpret_cast<uint32_t*>(logc_k + cap1);
   double* const inlF_lds = reinterpret_cast<double*>(hist + 24);   // the model behind the current inlier list / pool (rarely touched: kept out of registers)
+  double* const e_scr = reinterpret_cast<double*>(hist + kWaveScratch);   // essential model: solver workspace | Es[10][9] | Fs[10][9]
+  double* const e_Es = e_scr + five_point::kScratch;
+  double* const e_Fs = e_Es + 90;
   const uint32_t pidx = order[w];
   const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
   const uint32_t n = P.n;
   const double max_threshold = P.max_threshold, bins_by_interval = P.bins_by_interval, loge0 = P.loge0;
   const double2* __restrict__ x1 = x1n + P.start;
   const double2* __restrict__ x2 = x2n + P.start;
+  const double* __restrict__ bv1 = MODEL == kModelE ? bear1 + 3 * P.start : nullptr;
+  const double* __restrict__ bv2 = MODEL == kModelE ? bear2 + 3 * P.start : nullptr;
   // lane b < 20 keeps the constants of histogram bin b
   const double my_bin_value = lane < kBins ? P.bin_value[lane] : 0.0, my_logalpha = lane < kBins ? P.logalpha_bin[lane] : 0.0;
   // ---- set-up: generator (std::mt19937(5489) before its first twist), pool = 0..n-1, tables ----
@@ -466,6 +496,21 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
       four_point(x1, x2, s, lane, F1);   // (one model per sample: MAX_MODELS = 1)
 #pragma unroll
       for (int u = 0; u < 9; ++u) F2[u] = 0.0;
+    } else if (MODEL == kModelE) {
+      // FivePointSolver on the sample's bearing vectors (up to ten essential matrices, LDS), then F = K2^-T E K1^-1 per model for
+      // the pixel residuals (ACKernelAdaptorEssential::Errors; products and sums rounded one by one like the reference's 3 x 3 products)
+      nm = five_point::solve(bv1, bv2, s, lane, e_scr, e_Es);
+      for (int e = lane; e < 9 * nm; e += 64) {
+        const int mi = e / 9, u = e - 9 * mi, i = u / 3, j = u - 3 * i;
+        const double* __restrict__ E = e_Es + 9 * mi;
+        double t3[3];   // row i of K2^-T E
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t3[c] = add_rn(add_rn(mul_rn(P.k2it[3 * i], E[c]), mul_rn(P.k2it[3 * i + 1], E[3 + c])), mul_rn(P.k2it[3 * i + 2], E[6 + c]));
+        e_Fs[9 * mi + u] = add_rn(add_rn(mul_rn(t3[0], P.k1i[j]), mul_rn(t3[1], P.k1i[3 + j])), mul_rn(t3[2], P.k1i[6 + j]));
+      }
+      wave_sync();
+#pragma unroll
+      for (int u = 0; u < 9; ++u) { F1[u] = 0.0; F2[u] = 0.0; }
     } else {
       nm = seven_point(x1, x2, s, lane, F1, F2, roots);
     }
@@ -475,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
       const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
       double F[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) F[u] = MODEL == kModelH ? F1[u] : F1[u] + root * F2[u];
+      for (int u = 0; u < 9; ++u) F[u] = MODEL == kModelH ? F1[u] : MODEL == kModelE ? e_Fs[9 * mi + u] : F1[u] + root * F2[u];
       if (lane < kBins) hist[lane] = 0;
       wave_sync();
       uint32_t n_le = 0;
@@ -528,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void geofilter_f_acransac_kernel(con
           if (cnt > (uint32_t)kMin) {
             better = true; minNFA = cb_nfa; errorMax = cb_thr; have_model = 1;
 #pragma unroll
-            for (int u = 0; u < 9; ++u) if (lane == u) bestFu = F[u];
+            for (int u = 0; u < 9; ++u) if (lane == u) bestFu = MODEL == kModelE ? e_Es[9 * mi + u] : F[u];
           }
         }
       }
@@ -580,23 +625,25 @@ struct DevBuf {
 
 template <int WAVES, int MODEL>
 int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
-                 const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, hipStream_t stream) {
+                 const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, hipStream_t stream,
+                 const double* b1 = nullptr, const double* b2 = nullptr) {
   if (!n_work) return MVGX_OK;
-  const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + kWaveScratch) * sizeof(uint32_t);
+  const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
-                     n_cap, x1, x2, l10, mt_init, max_it, res, mask);
+                     n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
 // the class above the LDS classes: tables in `scratch` (n_work x 3 x ((n_cap + 2) & ~1) words)
 template <int MODEL>
 int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
-                        const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream) {
+                        const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream,
+                        const double* b1 = nullptr, const double* b2 = nullptr) {
   if (!n_work) return MVGX_OK;
-  const size_t lds = (size_t)(kMtN + kWaveScratch) * sizeof(uint32_t);
+  const size_t lds = (size_t)(kMtN + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
   hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
-                     max_it, res, mask, scratch);
+                     max_it, res, mask, scratch, b1, b2);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
@@ -612,29 +659,47 @@ struct GeoSource {
   const double* xI = nullptr; const double* xJ = nullptr;
   const double* feat_xy = nullptr; const uint64_t* feat_start = nullptr; uint32_t n_images = 0;
   const uint32_t* pair_images = nullptr; const uint32_t* ij = nullptr;
+  // essential model: bearing vectors (3 per match, or 3 per feature when indexed) and the calibration matrices (row-major 3 x 3:
+  // 18 doubles per pair {K_I, K_J}, or 9 per image when indexed)
+  const double* bI = nullptr; const double* bJ = nullptr; const double* feat_bearing = nullptr; const double* K = nullptr;
 };
+
+// inverse of a 3 x 3 matrix by cofactors (what Eigen's Matrix3d::inverse() evaluates: cofactors x 1 / det)
+inline void inverse3(const double* m, double* inv) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+  const double det = c00 * m[0] + c10 * m[1] + c20 * m[2];
+  const double id = 1.0 / det;
+  inv[0] = c00 * id; inv[3] = c10 * id; inv[6] = c20 * id;
+  inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  inv[2] = (m[1] * m[5] - m[2] * m[4]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
 
 // the launches of the five size classes (largest pairs first) for one model
 template <int MODEL>
 int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const std::vector<GeoPair>& hp, uint32_t c4, uint32_t c3,
                    uint32_t c2, uint32_t c1, const uint32_t (&caps)[4], const double2* px1, const double2* px2, const float* l10, const uint32_t* mt,
-                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream) {
+                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr) {
   int rc;
   if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
     const uint32_t cap_g = hp[order[0]].n;
     if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
-    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream))) return rc;
+    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream, b1, b2))) return rc;
   }
-  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
-  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
-  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream))) return rc;
-  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream);
+  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
+  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
+  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
+  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2);
 }
 
 int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
                   uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                   mvgx_geofilter_stats* stats) {
-  const int min_samples = model == kModelH ? 4 : kMinSamples, max_models = model == kModelH ? 1 : kMaxModels;
+  const int min_samples = model == kModelH ? 4 : model == kModelE ? 5 : kMinSamples, max_models = model == kModelH ? 1 : model == kModelE ? 10 : kMaxModels;
+  if (model == kModelE) {
+    MVGX_REQUIRE(n_pairs == 0 || src.K, MVGX_ERR_ARG, "mvgx_geofilter_e_acransac: NULL calibration matrices");
+    MVGX_REQUIRE(!match_start || match_start[n_pairs] == 0 || (src.indexed ? src.feat_bearing != nullptr : (src.bI && src.bJ)), MVGX_ERR_ARG,
+                 "mvgx_geofilter_e_acransac: NULL bearing vectors");
+  }
   MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || (image_wh && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
   const uint64_t n_total = match_start[n_pairs];
   MVGX_REQUIRE(n_total == 0 || inlier_mask, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL inlier mask");
@@ -688,13 +753,25 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
         const int w = (int)whp[0], h = (int)whp[1];
         const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
         t[im][0] = dNorm; t[im][1] = -.5f * w * dNorm; t[im][2] = -.5 * h * dNorm;
+        if (model == kModelE) { t[im][0] = 1.0; t[im][1] = 0.0; t[im][2] = 0.0; }   // ACKernelAdaptorEssential works on the pixels (N1 = N2 = I)
         for (int k = 0; k < 3; ++k) norm[6 * p + 3 * im + k] = t[im][k];
+      }
+      if (model == kModelE) {
+        const double* K1 = src.indexed ? src.K + 9 * (size_t)src.pair_images[2 * p] : src.K + 18 * p;
+        const double* K2 = src.indexed ? src.K + 9 * (size_t)src.pair_images[2 * p + 1] : src.K + 18 * p + 9;
+        double k2i[9];
+        inverse3(K1, g.k1i);
+        inverse3(K2, k2i);
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) g.k2it[3 * a + b] = k2i[3 * b + a];
+      } else {
+        for (int u = 0; u < 9; ++u) { g.k1i[u] = 0.0; g.k2it[u] = 0.0; }
       }
       const uint32_t* wh2 = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + 1] : image_wh + 4 * p + 2;
       const int w2 = (int)wh2[0], h2 = (int)wh2[1];
       // ACParametrizationHelper (robust_estimator_ACRansacKernelAdaptator.hpp:38-81): point-to-line for F, point-to-point for H
       const double logalpha0 = model == kModelH ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (t[1][0] * t[1][0]))
-                                                : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
+                               : model == kModelE ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
+                                                  : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
       const double mult_error = model == kModelH ? 1.0 : 0.5;
       g.max_threshold = opt->precision * opt->precision * t[1][0] * t[1][0];
       g.loge0 = n > (uint32_t)min_samples ? std::log10((double)max_models * (n - min_samples)) : 0.0;
@@ -738,7 +815,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   int stream_device = 0;
   MVGX_HIP(hipGetDevice(&stream_device));
   struct StreamGuard { int dev; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(dev, s); } } sg{stream_device, stream};
-  DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm, d_feat, d_fstart, d_pimg;
+  DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm, d_feat, d_fstart, d_pimg, d_b1, d_b2, d_fbear;
   const uint64_t n_feat = src.indexed && src.n_images ? src.feat_start[src.n_images] : 0;
   if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_total * sizeof(double2))) ||
       (rc = d_x2.alloc(n_total * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
@@ -750,6 +827,10 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       return rc;
   } else if ((rc = d_raw1.alloc(n_total * sizeof(double2))) || (rc = d_raw2.alloc(n_total * sizeof(double2)))) {
     return rc;
+  }
+  if (model == kModelE) {
+    if ((rc = d_b1.alloc(n_total * 3 * sizeof(double))) || (rc = d_b2.alloc(n_total * 3 * sizeof(double)))) return rc;
+    if (src.indexed && (rc = d_fbear.alloc(n_feat * 3 * sizeof(double)))) return rc;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   MVGX_HIP(hipEventCreate(&e0));
@@ -769,6 +850,14 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     }
     MVGX_HIP(hipMemcpyAsync(d_norm.p, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(d_mask.p, 0, n_total, stream));
+    if (model == kModelE) {
+      if (src.indexed) {
+        MVGX_HIP(hipMemcpyAsync(d_fbear.p, src.feat_bearing, n_feat * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+      } else {
+        MVGX_HIP(hipMemcpyAsync(d_b1.p, src.bI, n_total * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+        MVGX_HIP(hipMemcpyAsync(d_b2.p, src.bJ, n_total * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+      }
+    }
   }
   MVGX_HIP(hipMemcpyAsync(d_l10.p, l10.data(), l10.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   MVGX_HIP(hipMemcpyAsync(d_mt.p, mt_init, sizeof(mt_init), hipMemcpyHostToDevice, stream));
@@ -787,6 +876,11 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       const auto* fs = static_cast<const uint64_t*>(d_fstart.p);
       const auto *pim = static_cast<const uint2*>(d_pimg.p), *mij = static_cast<const uint2*>(d_raw1.p);
       hipLaunchKernelGGL(geofilter_normalize_indexed_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, ft, fs, pim, mij, o1, o2);
+      if (model == kModelE) {
+        const double* fb = static_cast<const double*>(d_fbear.p);
+        double *ob1 = static_cast<double*>(d_b1.p), *ob2 = static_cast<double*>(d_b2.p);
+        hipLaunchKernelGGL(geofilter_gather_bearings_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, (uint32_t)n_pairs, fb, fs, pim, mij, ob1, ob2);
+      }
     } else {
       hipLaunchKernelGGL(geofilter_normalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, r1, r2, o1, o2);
     }
@@ -801,7 +895,9 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     auto* dr = static_cast<GeoResult*>(d_res.p);
     auto* dk = static_cast<uint8_t*>(d_mask.p);
     rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
-                          : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
+         : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
+                                                      static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p))
+                            : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
     if (rc) return rc;
   }
   MVGX_HIP(hipEventRecord(e1, stream));
@@ -821,7 +917,9 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = (ran && r.have_model) ? r.F[u] : ((u % 4 == 0) ? 1.0 : 0.0);   // m_F starts as the identity
     double err = ran ? r.error_max : 0.0;
-    if (ran && r.n_inliers > 0) {
+    if (ran && r.n_inliers > 0 && model == kModelE) {
+      // ACKernelAdaptorEssential: Unnormalize does nothing, unormalizeError(val) = val (the squared pixel distance as it is)
+    } else if (ran && r.n_inliers > 0) {
       const double* t = &norm[6 * p];
       const double N1[9] = {t[0], 0, t[1], 0, t[0], t[2], 0, 0, 1}, N2[9] = {t[3], 0, t[4], 0, t[3], t[5], 0, 0, 1};
       double tmp[9], res[9];
@@ -890,6 +988,58 @@ int mvgx_geofilter_h_acransac_indexed(int device, const double* feat_xy, const u
   src.indexed = true;
   src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
   return geofilter_run(device, kModelH, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+// The essential-matrix model (E_ACRobust.hpp:39-150): ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError> + ACRANSAC.
+int mvgx_geofilter_e_acransac(int device, const double* xI, const double* xJ, const double* bearingI, const double* bearingJ, const uint64_t* match_start,
+                              const uint32_t* image_wh, const double* K, uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask,
+                              mvgx_geofilter_result* results, mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.xI = xI; src.xJ = xJ; src.bI = bearingI; src.bJ = bearingJ; src.K = K;
+  return geofilter_run(device, kModelE, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_e_acransac_indexed(int device, const double* feat_xy, const double* feat_bearing, const uint64_t* feat_start, const uint32_t* image_wh,
+                                      const double* image_K, uint32_t n_images, const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij,
+                                      uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.indexed = true;
+  src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
+  src.feat_bearing = feat_bearing; src.K = image_K;
+  return geofilter_run(device, kModelE, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+// Test hook (not declared in include/mvgx.h): the five-point solver alone on one sample of five bearing pairs (b1, b2: 5 x 3 doubles);
+// Es_out receives up to ten essential matrices (row-major), *n_out their number.
+__global__ void five_point_debug_kernel(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  __shared__ double scr[five_point::kScratch + 90];
+  const int lane = threadIdx.x & 63;
+  const uint32_t s[7] = {0, 1, 2, 3, 4, 0, 0};
+  const int n = five_point::solve(b1, b2, s, lane, scr, scr + five_point::kScratch);
+  for (int e = lane; e < 9 * n; e += 64) Es_out[e] = scr[five_point::kScratch + e];
+  if (lane == 0) *n_out = n;
+}
+int mvgx_debug_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  MVGX_REQUIRE(b1 && b2 && Es_out && n_out, MVGX_ERR_ARG, "mvgx_debug_five_point: NULL argument");
+  int rc = mvgx::select_device(-1);
+  if (rc) return rc;
+  DevBuf d1, d2, dE, dn;
+  if ((rc = d1.alloc(15 * sizeof(double))) || (rc = d2.alloc(15 * sizeof(double))) || (rc = dE.alloc(90 * sizeof(double))) || (rc = dn.alloc(sizeof(int)))) return rc;
+  MVGX_HIP(hipMemcpy(d1.p, b1, 15 * sizeof(double), hipMemcpyHostToDevice));
+  MVGX_HIP(hipMemcpy(d2.p, b2, 15 * sizeof(double), hipMemcpyHostToDevice));
+  MVGX_HIP(hipMemset(dE.p, 0, 90 * sizeof(double)));
+  {   // (plain pointers in the launch: the buffers own their memory and must not be captured by value)
+    const double *p1 = static_cast<const double*>(d1.p), *p2 = static_cast<const double*>(d2.p);
+    double* pE = static_cast<double*>(dE.p);
+    int* pn = static_cast<int*>(dn.p);
+    hipLaunchKernelGGL(five_point_debug_kernel, dim3(1), dim3(64), 0, nullptr, p1, p2, pE, pn);
+  }
+  MVGX_HIP(hipGetLastError());
+  MVGX_HIP(hipStreamSynchronize(nullptr));
+  MVGX_HIP(hipMemcpy(Es_out, dE.p, 90 * sizeof(double), hipMemcpyDeviceToHost));
+  MVGX_HIP(hipMemcpy(n_out, dn.p, sizeof(int), hipMemcpyDeviceToHost));
+  return MVGX_OK;
 }
 
 }  // extern "C"

@@ -29,6 +29,51 @@ class GeometricFilter_HMatrix_AC(GeometricFilter_FMatrix_AC):
     _entry, _entry_indexed = "mvgx_geofilter_h_acransac", "mvgx_geofilter_h_acransac_indexed"
 
 
+class GeometricFilter_EMatrix_AC(GeometricFilter_FMatrix_AC):
+    """The essential-matrix functor (E_ACRobust.hpp:39-150): same fields; the result's "F" field holds m_E, "precision_robust" the
+    squared pixel bound the reference stores. Needs the calibration matrices (filter_pairs_e)."""
+    _entry, _entry_indexed = "mvgx_geofilter_e_acransac", "mvgx_geofilter_e_acransac_indexed"
+
+
+def pinhole_bearings(K, x):
+    """Pinhole_Intrinsic::operator()(x) (Camera_Pinhole.hpp:136-139): normalised Kinv (x, y, 1) per point; K (3, 3), x (n, 2) -> (n, 3).
+    (Host mirror for callers without the camera class at hand; the openMVG adapter calls the camera's own operator.)"""
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    x = np.asarray(x, np.float64).reshape(-1, 2)
+    v = np.concatenate([x, np.ones((len(x), 1))], 1) @ np.linalg.inv(K).T
+    return np.ascontiguousarray(v / np.linalg.norm(v, axis=1, keepdims=True))
+
+
+def filter_pairs_e(xI, xJ, match_start, image_wh, K, functor=None, device=-1, bearings=None):
+    """The essential model on gathered correspondences: K (n_pairs, 2, 3, 3) = {K_I, K_J} per pair; bearings = (bI, bJ), (N, 3) each -
+    what the cameras' operator() returns for xI / xJ - or None: pinhole_bearings. Returns (inlier_mask, results, stats) like filter_pairs."""
+    functor = functor or GeometricFilter_EMatrix_AC(4.0, 2048)
+    xI = np.ascontiguousarray(xI, np.float64).reshape(-1, 2)
+    xJ = np.ascontiguousarray(xJ, np.float64).reshape(-1, 2)
+    start = np.ascontiguousarray(match_start, np.uint64)
+    wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 4)
+    n_pairs = len(start) - 1
+    K = np.ascontiguousarray(K, np.float64).reshape(-1, 18)
+    if len(wh) != n_pairs or len(K) != n_pairs or int(start[-1]) != len(xI) or len(xI) != len(xJ):
+        raise ValueError("filter_pairs_e: inconsistent array sizes")
+    if bearings is None:
+        bI = np.zeros((len(xI), 3)); bJ = np.zeros((len(xJ), 3))
+        for p in range(n_pairs):
+            lo, hi = int(start[p]), int(start[p + 1])
+            bI[lo:hi] = pinhole_bearings(K[p, :9], xI[lo:hi]); bJ[lo:hi] = pinhole_bearings(K[p, 9:], xJ[lo:hi])
+    else:
+        bI, bJ = (np.ascontiguousarray(b, np.float64).reshape(-1, 3) for b in bearings)
+    bI = np.ascontiguousarray(bI); bJ = np.ascontiguousarray(bJ)
+    mask = np.zeros(max(len(xI), 1), np.uint8)
+    res = (_capi.GeofilterResult * max(n_pairs, 1))()
+    st = _capi.GeofilterStats()
+    opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _capi.check(_capi.lib().mvgx_geofilter_e_acransac(int(device), P(xI), P(xJ), P(bI), P(bJ), P(start), P(wh), P(K), n_pairs, C.byref(opt), P(mask),
+                                                      C.cast(res, C.c_void_p), C.byref(st)))
+    return mask[:len(xI)].astype(bool), _results_array(res, n_pairs), st
+
+
 def filter_pairs(xI, xJ, match_start, image_wh, functor=None, device=-1):
     """xI, xJ: (N, 2) float64 pixel positions of the putative matches of all pairs, pair p owning rows
     [match_start[p], match_start[p + 1]); image_wh: (n_pairs, 4) uint32 {w_I, h_I, w_J, h_J}.

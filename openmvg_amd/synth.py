@@ -294,6 +294,17 @@ def two_view_matches(n_pairs, seed=0, n_min=8, n_max=400, inlier_frac=(0.3, 0.9)
                 wh=np.asarray(wh, np.uint32).reshape(-1, 4), is_inlier=np.concatenate(truth) if truth else np.zeros(0, bool))
 
 
+def two_view_calibration(tv):
+    """The calibration matrices of the cameras two_view_matches / two_view_matches_bulk projected with: f = 0.9 max(w_I, h_I) for both
+    images of a pair, principal point at the image centre. Returns (n_pairs, 2, 3, 3) float64 {K_I, K_J}."""
+    wh = np.asarray(tv["wh"], np.float64).reshape(-1, 4)
+    f = 0.9 * np.maximum(wh[:, 0], wh[:, 1])
+    K = np.zeros((len(wh), 2, 3, 3))
+    K[:, :, 0, 0] = f[:, None]; K[:, :, 1, 1] = f[:, None]; K[:, :, 2, 2] = 1.0
+    K[:, 0, 0, 2] = wh[:, 0] / 2; K[:, 0, 1, 2] = wh[:, 1] / 2; K[:, 1, 0, 2] = wh[:, 2] / 2; K[:, 1, 1, 2] = wh[:, 3] / 2
+    return K
+
+
 def two_view_homography_matches(n_pairs, seed=0, n_min=5, n_max=400, inlier_frac=(0.3, 0.9), noise_px=0.4, no_geometry_frac=0.25, tiny_frac=0.03,
                                 sizes=((1000, 1000), (1280, 960), (1920, 1080))):
     """Putative matches of image pairs related by a homography (a plane seen from two views / a rotating camera): x_J ~ H x_I + noise

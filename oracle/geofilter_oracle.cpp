@@ -208,6 +208,149 @@ inline double homography_error(const Model& H, const double* x, const double* y)
   return dx * dx + dy * dy;
 }
 
+
+// ---- FivePointSolver (multiview/solver_essential_five_point.cpp:35-230), restated with other linear algebra than both the reference
+// (Eigen: SelfAdjointEigenSolver null space, FullPivLU, EigenSolver) and the device kernel (complete-pivoting elimination + Gram-Schmidt,
+// lane-parallel QR iteration, closed-form eigenvector rows): Householder null space, Gauss-Jordan with partial pivoting, scalar
+// Hessenberg reduction by stabilised elimination + the hqr iteration, eigenvectors by elimination of (A - lambda I). ----
+namespace fivept {
+typedef double P1[4];    // {x, y, z, 1}
+typedef double P2[10];   // {xx, xy, yy, xz, yz, zz, x, y, z, 1}
+void o1(const double* a, const double* b, double* r) {
+  r[0] = a[0] * b[0]; r[1] = a[0] * b[1] + a[1] * b[0]; r[2] = a[1] * b[1]; r[3] = a[0] * b[2] + a[2] * b[0]; r[4] = a[1] * b[2] + a[2] * b[1];
+  r[5] = a[2] * b[2]; r[6] = a[0] * b[3] + a[3] * b[0]; r[7] = a[1] * b[3] + a[3] * b[1]; r[8] = a[2] * b[3] + a[3] * b[2]; r[9] = a[3] * b[3];
+}
+void o2_add(const double* a, const double* b, double* r) {   // degree 2 x degree 1, reference column order
+  const double axx = a[0], axy = a[1], ayy = a[2], axz = a[3], ayz = a[4], azz = a[5], ax = a[6], ay = a[7], az = a[8], a1 = a[9];
+  const double bx = b[0], by = b[1], bz = b[2], b1 = b[3];
+  r[0] += axx * bx; r[1] += axx * by + axy * bx; r[2] += axy * by + ayy * bx; r[3] += ayy * by; r[4] += axx * bz + axz * bx;
+  r[5] += axy * bz + ayz * bx + axz * by; r[6] += ayy * bz + ayz * by; r[7] += axz * bz + azz * bx; r[8] += ayz * bz + azz * by; r[9] += azz * bz;
+  r[10] += axx * b1 + ax * bx; r[11] += axy * b1 + ax * by + ay * bx; r[12] += ayy * b1 + ay * by; r[13] += axz * b1 + ax * bz + az * bx;
+  r[14] += ayz * b1 + ay * bz + az * by; r[15] += azz * b1 + az * bz; r[16] += ax * b1 + a1 * bx; r[17] += ay * b1 + a1 * by; r[18] += az * b1 + a1 * bz;
+  r[19] += a1 * b1;
+}
+// eigenvalues of a general real n x n matrix (n = 10): elimination to Hessenberg form (elmhes) + hqr (EISPACK / Numerical Recipes)
+bool eigenvalues(double a[10][10], double wr[10], double wi[10]) {
+  const int n = 10;
+  for (int m = 1; m < n - 1; ++m) {
+    double x = 0.0; int i = m;
+    for (int j = m; j < n; ++j) if (std::fabs(a[j][m - 1]) > std::fabs(x)) { x = a[j][m - 1]; i = j; }
+    if (i != m) { for (int j = m - 1; j < n; ++j) std::swap(a[i][j], a[m][j]); for (int j = 0; j < n; ++j) std::swap(a[j][i], a[j][m]); }
+    if (x != 0.0)
+      for (i = m + 1; i < n; ++i) {
+        double y = a[i][m - 1];
+        if (y != 0.0) { y /= x; a[i][m - 1] = y; for (int j = m; j < n; ++j) a[i][j] -= y * a[m][j]; for (int j = 0; j < n; ++j) a[j][m] += y * a[j][i]; }
+      }
+  }
+  for (int i = 2; i < n; ++i) for (int j = 0; j < i - 1; ++j) a[i][j] = 0.0;
+  double anorm = 0.0;
+  for (int i = 0; i < n; ++i) for (int j = std::max(i - 1, 0); j < n; ++j) anorm += std::fabs(a[i][j]);
+  int nn = n - 1; double t = 0.0, p = 0, q = 0, r = 0, z = 0, w, x, y, s;
+  while (nn >= 0) {
+    int its = 0, l;
+    do {
+      for (l = nn; l >= 1; --l) { s = std::fabs(a[l - 1][l - 1]) + std::fabs(a[l][l]); if (s == 0.0) s = anorm; if (std::fabs(a[l][l - 1]) + s == s) { a[l][l - 1] = 0.0; break; } }
+      x = a[nn][nn];
+      if (l == nn) { wr[nn] = x + t; wi[nn--] = 0.0; }
+      else {
+        y = a[nn - 1][nn - 1]; w = a[nn][nn - 1] * a[nn - 1][nn];
+        if (l == nn - 1) {
+          p = 0.5 * (y - x); q = p * p + w; z = std::sqrt(std::fabs(q)); x += t;
+          if (q >= 0.0) { z = p + (p >= 0.0 ? std::fabs(z) : -std::fabs(z)); wr[nn - 1] = wr[nn] = x + z; if (z != 0.0) wr[nn] = x - w / z; wi[nn - 1] = wi[nn] = 0.0; }
+          else { wr[nn - 1] = wr[nn] = x + p; wi[nn - 1] = z; wi[nn] = -z; }
+          nn -= 2;
+        } else {
+          if (its == 30) return false;
+          if (its == 10 || its == 20) { t += x; for (int i = 0; i <= nn; ++i) a[i][i] -= x; s = std::fabs(a[nn][nn - 1]) + std::fabs(a[nn - 1][nn - 2]); y = x = 0.75 * s; w = -0.4375 * s * s; }
+          ++its;
+          int m;
+          for (m = nn - 2; m >= l; --m) {
+            z = a[m][m]; r = x - z; s = y - z;
+            p = (r * s - w) / a[m + 1][m] + a[m][m + 1]; q = a[m + 1][m + 1] - z - r - s; r = a[m + 2][m + 1];
+            s = std::fabs(p) + std::fabs(q) + std::fabs(r); p /= s; q /= s; r /= s;
+            if (m == l) break;
+            const double u = std::fabs(a[m][m - 1]) * (std::fabs(q) + std::fabs(r)), v = std::fabs(p) * (std::fabs(a[m - 1][m - 1]) + std::fabs(z) + std::fabs(a[m + 1][m + 1]));
+            if (u + v == v) break;
+          }
+          for (int i = m + 2; i <= nn; ++i) { a[i][i - 2] = 0.0; if (i != m + 2) a[i][i - 3] = 0.0; }
+          for (int k = m; k <= nn - 1; ++k) {
+            if (k != m) { p = a[k][k - 1]; q = a[k + 1][k - 1]; r = 0.0; if (k != nn - 1) r = a[k + 2][k - 1]; if ((x = std::fabs(p) + std::fabs(q) + std::fabs(r)) != 0.0) { p /= x; q /= x; r /= x; } }
+            const double sq = std::sqrt(p * p + q * q + r * r);
+            if ((s = p >= 0.0 ? sq : -sq) != 0.0) {
+              if (k == m) { if (l != m) a[k][k - 1] = -a[k][k - 1]; } else a[k][k - 1] = -s * x;
+              p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+              for (int j = k; j <= nn; ++j) { p = a[k][j] + q * a[k + 1][j]; if (k != nn - 1) { p += r * a[k + 2][j]; a[k + 2][j] -= p * z; } a[k + 1][j] -= p * y; a[k][j] -= p * x; }
+              const int mmin = nn < k + 3 ? nn : k + 3;
+              for (int i = l; i <= mmin; ++i) { p = x * a[i][k] + y * a[i][k + 1]; if (k != nn - 1) { p += z * a[i][k + 2]; a[i][k + 2] -= p * r; } a[i][k + 1] -= p * q; a[i][k] -= p; }
+            }
+          }
+        }
+      }
+    } while (l < nn - 1);
+  }
+  return true;
+}
+// b1, b2: bearing vectors (3 doubles per correspondence), s: five sample indices. Essential matrices (row-major) to out; returns their number.
+int five_point(const double* b1, const double* b2, const uint32_t* s, Model* out) {
+  double A[5][9];
+  for (int r = 0; r < 5; ++r) for (int c = 0; c < 9; ++c) A[r][c] = b2[3 * (size_t)s[r] + c / 3] * b1[3 * (size_t)s[r] + c % 3];
+  double nb[4][9];
+  nullspace_rows<5>(A, nb);   // orthonormal
+  double E[9][4];             // E[3 i + j] = polynomial of entry (i, j)
+  for (int u = 0; u < 9; ++u) for (int k = 0; k < 4; ++k) E[u][k] = nb[k][u];
+  double M[10][20] = {{0}};
+  { double p[10], q[10], d[10];
+    const int t3[3][5] = {{1, 5, 2, 4, 6}, {2, 3, 0, 5, 7}, {0, 4, 1, 3, 8}};
+    for (auto& t : t3) { o1(E[t[0]], E[t[1]], p); o1(E[t[2]], E[t[3]], q); for (int k = 0; k < 10; ++k) d[k] = p[k] - q[k]; o2_add(d, E[t[4]], M[0]); } }
+  double EET[3][3][10], tr[10];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    for (int k = 0; k < 10; ++k) EET[i][j][k] = 0.0;
+    for (int m = 0; m < 3; ++m) { double p[10]; o1(E[3 * i + m], E[3 * j + m], p); for (int k = 0; k < 10; ++k) EET[i][j][k] += p[k]; }
+  }
+  for (int k = 0; k < 10; ++k) tr[k] = 0.5 * (EET[0][0][k] + EET[1][1][k] + EET[2][2][k]);
+  for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) EET[i][i][k] -= tr[k];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int m = 0; m < 3; ++m) o2_add(EET[i][m], E[3 * m + j], M[1 + 3 * i + j]);
+  // Gauss-Jordan with partial pivoting on the cubic columns: M -> [I | B]
+  for (int c = 0; c < 10; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 10; ++r) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0.0) return 0;
+    if (piv != c) for (int k = 0; k < 20; ++k) std::swap(M[piv][k], M[c][k]);
+    const double ip = 1.0 / M[c][c];
+    for (int k = 0; k < 20; ++k) M[c][k] *= ip;
+    for (int r = 0; r < 10; ++r) if (r != c) { const double f = M[r][c]; if (f != 0.0) for (int k = 0; k < 20; ++k) M[r][k] -= f * M[c][k]; }
+  }
+  double At[10][10] = {{0}}, H[10][10];
+  const int rows[6] = {0, 1, 2, 4, 5, 7};
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 10; ++c) At[r][c] = M[rows[r]][10 + c];
+  At[6][0] = At[7][1] = At[8][3] = At[9][6] = -1.0;
+  std::memcpy(H, At, sizeof(H));
+  double wr[10], wi[10];
+  if (!eigenvalues(H, wr, wi)) return 0;
+  int n = 0;
+  for (int e = 0; e < 10; ++e) {
+    if (wi[e] != 0.0 || !(std::fabs(wr[e]) < 1e150)) continue;
+    // null vector of (At - lambda I): elimination with complete pivoting, the column left without a pivot is free
+    double G[10][10];
+    for (int r = 0; r < 10; ++r) for (int c = 0; c < 10; ++c) G[r][c] = At[r][c] - (r == c ? wr[e] : 0.0);
+    int prow[10], pcol[10]; bool ru[10] = {false}, cu[10] = {false};
+    for (int st = 0; st < 9; ++st) {
+      double best = 0.0; int br = -1, bc = -1;
+      for (int r = 0; r < 10; ++r) if (!ru[r]) for (int c = 0; c < 10; ++c) if (!cu[c] && std::fabs(G[r][c]) > best) { best = std::fabs(G[r][c]); br = r; bc = c; }
+      if (br < 0) { prow[st] = -1; continue; }
+      ru[br] = cu[bc] = true; prow[st] = br; pcol[st] = bc;
+      for (int r = 0; r < 10; ++r) if (r != br) { const double f = G[r][bc] / G[br][bc]; if (f != 0.0) for (int c = 0; c < 10; ++c) G[r][c] -= f * G[br][c]; }
+    }
+    int fc = 0; while (fc < 10 && cu[fc]) ++fc;
+    double v[10] = {0}; v[fc] = 1.0;
+    for (int st = 0; st < 9; ++st) if (prow[st] >= 0) v[pcol[st]] = -G[prow[st]][fc] / G[prow[st]][pcol[st]];
+    for (int u = 0; u < 9; ++u) out[n].f[u] = E[u][0] * v[6] + E[u][1] * v[7] + E[u][2] * v[8] + E[u][3] * v[9];
+    ++n;
+  }
+  return n;
+}
+}  // namespace fivept
+
 struct Pair {
   uint32_t n;
   std::vector<double> x1, x2;   // normalised
@@ -225,11 +368,13 @@ extern "C" {
 namespace {
 // homography = false: ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT> (point to line);
 // homography = true: ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI> configured point to point (H_ACRobust.hpp:77-87)
+// essential (K != NULL): ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError> on the pixels, bearings = normalised Kinv (x, y, 1)
 double port_acransac(bool homography, const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
                      double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
-                     double* prec, double* nfa_out) {
-  const uint32_t kMin = homography ? 4 : 7;                 // Solver::MINIMUM_SAMPLES
-  const double max_models = homography ? 1.0 : 3.0;         // Solver::MAX_MODELS
+                     double* prec, double* nfa_out, const double* K = nullptr, const double* bI = nullptr, const double* bJ = nullptr) {
+  const bool essential = K != nullptr;
+  const uint32_t kMin = homography ? 4 : essential ? 5 : 7;                 // Solver::MINIMUM_SAMPLES
+  const double max_models = homography ? 1.0 : essential ? 10.0 : 3.0;      // Solver::MAX_MODELS
   const double mult_error = homography ? 1.0 : 0.5;         // ACParametrizationHelper::MultError
   const double inf = std::numeric_limits<double>::infinity();
   for (uint64_t pp = 0; pp < n_pairs; ++pp) {
@@ -245,6 +390,19 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
       const int w = (int)wh[4 * pp + 2 * im], h = (int)wh[4 * pp + 2 * im + 1];
       const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
       T[im][0] = dNorm; T[im][1] = -.5f * w * dNorm; T[im][2] = -.5 * h * dNorm;
+      if (essential) { T[im][0] = 1.0; T[im][1] = 0.0; T[im][2] = 0.0; }   // N1 = N2 = I
+    }
+    // essential: F = K2^-T E K1^-1 (multiview/essential.cpp:48-53), the inverses by cofactors
+    double k1i[9], k2i[9];
+    if (essential) {
+      for (int im = 0; im < 2; ++im) {
+        const double* m = K + 18 * pp + 9 * im; double* inv = im ? k2i : k1i;
+        const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+        const double id = 1.0 / (c00 * m[0] + c10 * m[1] + c20 * m[2]);
+        inv[0] = c00 * id; inv[3] = c10 * id; inv[6] = c20 * id;
+        inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+        inv[2] = (m[1] * m[5] - m[2] * m[4]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+      }
     }
     std::vector<double> x1(2 * n), x2(2 * n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -253,6 +411,7 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
     }
     const int w2 = (int)wh[4 * pp + 2], h2 = (int)wh[4 * pp + 3];
     const double logalpha0 = homography ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (T[1][0] * T[1][0]))   // point to point
+                             : essential ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
                                         : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / T[1][0]);   // point to line
     const double upper = precision * precision;
     const bool quantified = upper != inf;
@@ -294,8 +453,18 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
           if (std::find(vec_sample.begin(), vec_sample.end(), s) == vec_sample.end()) vec_sample.push_back(s);
         }
       }
-      Model models[3];
-      const int nm = homography ? four_point(x1.data(), x2.data(), vec_sample.data(), models) : seven_point(x1.data(), x2.data(), vec_sample.data(), models);
+      Model models[10], emodels[10];
+      int nm;
+      if (essential) {
+        nm = fivept::five_point(bI + 3 * lo, bJ + 3 * lo, vec_sample.data(), emodels);
+        for (int mi = 0; mi < nm; ++mi) {   // the model evaluated on the pixels: F = K2^-T E K1^-1
+          double tmp[9];
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tmp[3 * r + c] = (k2i[r] * emodels[mi].f[c] + k2i[3 + r] * emodels[mi].f[3 + c]) + k2i[6 + r] * emodels[mi].f[6 + c];
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) models[mi].f[3 * r + c] = (tmp[3 * r] * k1i[c] + tmp[3 * r + 1] * k1i[3 + c]) + tmp[3 * r + 2] * k1i[6 + c];
+        }
+      } else {
+        nm = homography ? four_point(x1.data(), x2.data(), vec_sample.data(), models) : seven_point(x1.data(), x2.data(), vec_sample.data(), models);
+      }
       bool better = false;
       for (int mi = 0; mi < nm; ++mi) {
         for (uint32_t i = 0; i < n; ++i) residuals[i] = homography ? homography_error(models[mi], &x1[2 * i], &x2[2 * i]) : epipolar_error(models[mi], &x1[2 * i], &x2[2 * i]);
@@ -329,7 +498,7 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
             vec_inliers.clear();   // (updated even when the function then reports "not better": size <= MINIMUM_SAMPLES)
             for (uint32_t i = 0; i < n; ++i) if (residuals[i] <= cb_thr) vec_inliers.push_back(i);
             if (vec_inliers.size() > kMin) {
-              better = true; minNFA = cb_nfa; errorMax = cb_thr; best = models[mi]; have_model = true;
+              better = true; minNFA = cb_nfa; errorMax = cb_thr; best = essential ? emodels[mi] : models[mi]; have_model = true;
             }
           }
         }
@@ -346,7 +515,7 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
     if (minNFA >= 0) vec_inliers.clear();
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = have_model ? best.f[u] : ((u % 4 == 0) ? 1.0 : 0.0);
-    if (!vec_inliers.empty()) {
+    if (!vec_inliers.empty() && !essential) {   // (ACKernelAdaptorEssential: Unnormalize does nothing, unormalizeError(val) = val)
       // Unnormalize: F = N2^T F N1 (conditioning.cpp:87-89), errorMax -> sqrt(errorMax) / N2(0,0)
       const double N1[9] = {T[0][0], 0, T[0][1], 0, T[0][0], T[0][2], 0, 0, 1}, N2[9] = {T[1][0], 0, T[1][1], 0, T[1][0], T[1][2], 0, 0, 1};
       double tmp[9], res[9];
@@ -381,5 +550,39 @@ double port_geofilter_h_acransac(const double* xI, const double* xJ, const uint6
                                  double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
                                  double* prec, double* nfa_out) {
   return port_acransac(true, xI, xJ, start, wh, n_pairs, precision, max_iterations, inlier_mask, ok, Fout, prec, nfa_out);
+}
+// the essential model: K = 18 doubles per pair {K_I, K_J} row-major; bI / bJ = the cameras' bearing vectors of the correspondences (3 doubles
+// each, as Pinhole_Intrinsic::operator() returns them) or NULL: then normalised Kinv (x, y, 1) is formed here
+double port_geofilter_e_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, const double* K, const double* bI,
+                                 const double* bJ, uint64_t n_pairs, double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok,
+                                 double* Fout, double* prec, double* nfa_out) {
+  std::vector<double> b1, b2;
+  if (!bI || !bJ) {
+    const uint64_t N = start[n_pairs];
+    b1.resize(3 * N + 3); b2.resize(3 * N + 3);
+    for (uint64_t p = 0; p < n_pairs; ++p)
+      for (int im = 0; im < 2; ++im) {
+        const double* m = K + 18 * p + 9 * im;
+        const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+        const double id = 1.0 / (c00 * m[0] + c10 * m[1] + c20 * m[2]);
+        const double inv[9] = {c00 * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id, c10 * id, (m[0] * m[8] - m[2] * m[6]) * id,
+                               (m[2] * m[3] - m[0] * m[5]) * id, c20 * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
+        const double* x = im ? xJ : xI; double* b = im ? b2.data() : b1.data();
+        for (uint64_t i = start[p]; i < start[p + 1]; ++i) {
+          const double v0 = inv[0] * x[2 * i] + inv[1] * x[2 * i + 1] + inv[2], v1 = inv[3] * x[2 * i] + inv[4] * x[2 * i + 1] + inv[5], v2 = inv[6] * x[2 * i] + inv[7] * x[2 * i + 1] + inv[8];
+          const double nn = std::sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+          b[3 * i] = v0 / nn; b[3 * i + 1] = v1 / nn; b[3 * i + 2] = v2 / nn;
+        }
+      }
+    bI = b1.data(); bJ = b2.data();
+  }
+  return port_acransac(false, xI, xJ, start, wh, n_pairs, precision, max_iterations, inlier_mask, ok, Fout, prec, nfa_out, K, bI, bJ);
+}
+// the five-point restatement alone (tests: against ref_five_point and the device's mvgx_debug_five_point)
+void port_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  const uint32_t s[5] = {0, 1, 2, 3, 4};
+  Model out[10];
+  *n_out = fivept::five_point(b1, b2, s, out);
+  for (int m = 0; m < *n_out; ++m) std::memcpy(Es_out + 9 * m, out[m].f, sizeof(out[m].f));
 }
 }  // extern "C"

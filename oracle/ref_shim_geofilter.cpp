@@ -18,6 +18,9 @@
 
 #include <omp.h>
 
+#include "openMVG/cameras/Camera_Pinhole.hpp"
+#include "openMVG/multiview/solver_essential_five_point.hpp"
+#include "openMVG/multiview/solver_essential_kernel.hpp"
 #include "openMVG/multiview/solver_fundamental_kernel.hpp"
 #include "openMVG/multiview/solver_homography_kernel.hpp"
 #include "openMVG/numeric/numeric.h"
@@ -78,6 +81,64 @@ double ref_geofilter_h_acransac(const double* xI, const double* xJ, const uint64
                                 double* prec, double* nfa) {
   using KernelType = robust::ACKernelAdaptor<homography::kernel::FourPointSolver, homography::kernel::AsymmetricError, UnnormalizerI, Mat3>;
   return run_acransac<KernelType>(xI, xJ, start, wh, n_pairs, precision, max_iterations, num_threads, false, inlier_mask, ok, F, prec, nfa);
+}
+
+// GeometricFilter_EMatrix_AC::Robust_estimation (matching_image_collection/E_ACRobust.hpp:57-150) per pair:
+// ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError, Mat3> on the pixels + the cameras' bearing vectors, ACRANSAC, more than
+// 2.5 x 5 inliers. K: 18 doubles per pair {K_I, K_J} row-major (the cameras are Pinhole_Intrinsic(w, h, K)); F receives m_E.
+double ref_geofilter_e_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, const double* K, uint64_t n_pairs,
+                                double precision, uint32_t max_iterations, int num_threads, uint8_t* inlier_mask, uint8_t* ok, double* F,
+                                double* prec, double* nfa) {
+  using KernelType = robust::ACKernelAdaptorEssential<essential::kernel::FivePointSolver, fundamental::kernel::EpipolarDistanceError, Mat3>;
+  const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic) num_threads(num_threads > 0 ? num_threads : omp_get_max_threads())
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint64_t lo = start[p], n = start[p + 1] - lo;
+    Mat2X x1(2, n), x2(2, n);
+    for (uint64_t i = 0; i < n; ++i) {
+      x1.col(i) << xI[2 * (lo + i)], xI[2 * (lo + i) + 1];
+      x2.col(i) << xJ[2 * (lo + i)], xJ[2 * (lo + i) + 1];
+    }
+    std::memset(inlier_mask + lo, 0, n);
+    Mat3 K1, K2;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { K1(r, c) = K[18 * p + 3 * r + c]; K2(r, c) = K[18 * p + 9 + 3 * r + c]; }
+    const cameras::Pinhole_Intrinsic camI(wh[4 * p], wh[4 * p + 1], K1), camJ(wh[4 * p + 2], wh[4 * p + 3], K2);
+    Mat3 model = Mat3::Identity();
+    const KernelType kernel(x1, camI(x1), wh[4 * p], wh[4 * p + 1], x2, camJ(x2), wh[4 * p + 2], wh[4 * p + 3], camI.K(), camJ.K());
+    const double upper_bound_precision = Square(precision);   // E_ACRobust.hpp:127
+    std::vector<uint32_t> vec_inliers;
+    const std::pair<double, double> out = robust::ACRANSAC(kernel, vec_inliers, max_iterations, &model, upper_bound_precision);
+    const bool good = vec_inliers.size() > KernelType::MINIMUM_SAMPLES * 2.5;   // E_ACRobust.hpp:132
+    ok[p] = good ? 1 : 0;
+    prec[p] = out.first; nfa[p] = out.second;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) F[9 * p + 3 * r + c] = model(r, c);
+    if (good)
+      for (const uint32_t idx : vec_inliers) inlier_mask[lo + idx] = 1;
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the bearing vectors Pinhole_Intrinsic(w, h, K)(x) the essential kernel receives (Camera_Pinhole.hpp:136-139): n points, 3 doubles each
+void ref_pinhole_bearings(const double* K, const double* x, uint64_t n, double* out) {
+  Mat3 Km;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Km(r, c) = K[3 * r + c];
+  const cameras::Pinhole_Intrinsic cam(1, 1, Km);
+  Mat2X pts(2, n);
+  for (uint64_t i = 0; i < n; ++i) pts.col(i) << x[2 * i], x[2 * i + 1];
+  const Mat3X b = cam(pts);
+  for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = b(k, i);
+}
+
+// FivePointsRelativePose (multiview/solver_essential_five_point.cpp:170-230) on five bearing pairs (5 x 3 doubles each): up to ten
+// essential matrices, row-major
+void ref_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  Mat3X x1(3, 5), x2(3, 5);
+  for (int i = 0; i < 5; ++i) for (int k = 0; k < 3; ++k) { x1(k, i) = b1[3 * i + k]; x2(k, i) = b2[3 * i + k]; }
+  std::vector<Mat3> Es;
+  FivePointsRelativePose(x1, x2, &Es);
+  *n_out = (int)Es.size();
+  for (size_t m = 0; m < Es.size(); ++m) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Es_out[9 * m + 3 * r + c] = Es[m](r, c);
 }
 
 }  // extern "C"

@@ -718,6 +718,64 @@ def ref_geofilter_h(tv, precision=4.0, max_iterations=2048, threads=0):
     return _geofilter_call(_refgeo.ref_geofilter_h_acransac, tv, precision, max_iterations, threads)
 
 
+def _geofilter_call_e(fn, tv, K, bearings, precision, max_iterations, threads=None):
+    """the essential model: fn(xI, xJ, start, wh, K, [bI, bJ,] n_pairs, precision, max_iterations, [threads,] mask, ok, E, precision, nfa)"""
+    xI = np.ascontiguousarray(tv["xI"], np.float64); xJ = np.ascontiguousarray(tv["xJ"], np.float64)
+    start = np.ascontiguousarray(tv["start"], np.uint64); wh = np.ascontiguousarray(tv["wh"], np.uint32)
+    K = np.ascontiguousarray(K, np.float64).reshape(-1, 18)
+    n_pairs = len(start) - 1
+    mask = np.zeros(max(int(start[-1]), 1), np.uint8); ok = np.zeros(max(n_pairs, 1), np.uint8)
+    F = np.zeros((max(n_pairs, 1), 9)); prec = np.zeros(max(n_pairs, 1)); nfa = np.zeros(max(n_pairs, 1))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    args = [P(xI), P(xJ), P(start), P(wh), P(K)]
+    keep = []
+    if bearings is not False:   # the restatement's signature carries the bearing arrays (NULL: formed there)
+        if bearings is None:
+            args += [None, None]
+        else:
+            keep = [np.ascontiguousarray(b, np.float64) for b in bearings]
+            args += [P(keep[0]), P(keep[1])]
+    args += [C.c_uint64(n_pairs), C.c_double(precision), C.c_uint32(max_iterations)]
+    if threads is not None:
+        args.append(C.c_int(threads))
+    fn.restype = C.c_double
+    secs = fn(*args, P(mask), P(ok), P(F), P(prec), P(nfa))
+    return dict(mask=mask[:int(start[-1])].astype(bool), ok=ok[:n_pairs].astype(bool), F=F[:n_pairs].reshape(-1, 3, 3), precision=prec[:n_pairs],
+                nfa=nfa[:n_pairs], seconds=secs)
+
+
+def ref_geofilter_e(tv, K, precision=4.0, max_iterations=2048, threads=0):
+    """The reference's ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError> + ACRANSAC per pair (E_ACRobust.hpp); "F" = m_E."""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    return _geofilter_call_e(_refgeo.ref_geofilter_e_acransac, tv, K, False, precision, max_iterations, threads)
+
+
+def ref_pinhole_bearings(tv, K):
+    """(bI, bJ): Pinhole_Intrinsic(w, h, K)(x) of the reference for every correspondence of tv (what the essential kernel receives)"""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    xI = np.ascontiguousarray(tv["xI"], np.float64); xJ = np.ascontiguousarray(tv["xJ"], np.float64)
+    start = np.asarray(tv["start"], np.int64); K = np.ascontiguousarray(K, np.float64).reshape(-1, 18)
+    bI = np.zeros((len(xI), 3)); bJ = np.zeros((len(xJ), 3))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    for p in range(len(start) - 1):
+        lo, hi = int(start[p]), int(start[p + 1])
+        if hi > lo:
+            for x, b, k in ((xI, bI, K[p, :9]), (xJ, bJ, K[p, 9:])):
+                out = np.zeros((hi - lo, 3)); xs = np.ascontiguousarray(x[lo:hi]); kk = np.ascontiguousarray(k)
+                _refgeo.ref_pinhole_bearings(P(kk), P(xs), C.c_uint64(hi - lo), P(out))
+                b[lo:hi] = out
+    return bI, bJ
+
+
+def port_geofilter_e(tv, K, precision=4.0, max_iterations=2048, bearings=None):
+    """oracle/geofilter_oracle.cpp, the essential model of the restatement (its own five-point solver)."""
+    return _geofilter_call_e(port().port_geofilter_e_acransac, tv, K, bearings, precision, max_iterations)
+
+
 def port_geofilter(tv, precision=4.0, max_iterations=2048):
     """oracle/geofilter_oracle.cpp, the plain C++ restatement (one thread)."""
     return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)

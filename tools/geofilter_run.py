@@ -1,5 +1,5 @@
 """One pass of the geometric filter over a synthetic workload (the command profiled by the rocprofv3 passes of the kernel).
-Usage: geofilter_run.py [n_pairs] [n_matches] [f|h]"""
+Usage: geofilter_run.py [n_pairs] [n_matches] [f|h|e]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openmvg_amd import geofilter, synth
@@ -12,6 +12,9 @@ if model == "h":
 else:
     tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
     fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
-mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
+if model == "e":
+    mask, res, st = geofilter.filter_pairs_e(tv["xI"], tv["xJ"], tv["start"], tv["wh"], synth.two_view_calibration(tv), geofilter.GeometricFilter_EMatrix_AC(4.0, 2048))
+else:
+    mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
 print("model", model, "pairs", n_pairs, "kernel_ms", st.kernel_ms, "ok", int(st.n_pairs_ok), "iterations", int(st.n_iterations), "models", int(st.n_models),
       "wave_clocks", int(st.wave_clocks))
