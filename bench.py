@@ -338,6 +338,7 @@ def main():
             from bench_geofilter import geofilter_bench_record
             out["geometric_filter"] = geofilter_bench_record(local_rank, cpu=not args.no_cpu_baseline)
             out["geometric_filter_homography"] = geofilter_bench_record(local_rank, n_pairs=20000, cpu=not args.no_cpu_baseline, cpu_pairs=3000, model="h")
+            out["geometric_filter_essential"] = geofilter_bench_record(local_rank, n_pairs=20000, steps=1, cpu=not args.no_cpu_baseline, cpu_pairs=3000, model="e")
         except Exception as e:
             out["geometric_filter"] = {"status": f"failed: {e!r}"}
     if rank == 0:

@@ -16,6 +16,20 @@ if ROOT not in sys.path:
 
 RESIDENT_WAVES = 256 * 4 * 3      # 256 CUs x 4 SIMDs x 3 waves (the kernel's 168 VGPRs; LDS would allow 6)
 SHADER_CLOCK_HZ = 2.4e9           # nominal (MI355X_MICROARCH.md)
+# pairs on which two builds of the reference (-O3 and -O3 -mavx2 -mfma) end with different inlier sets, bench sets (tools/geofilter_ref_vs_ref.py)
+REF_VS_REF_FILE = "profiles/round4_geofilter_reference_vs_reference.json"
+
+
+def _ref_vs_ref():
+    try:
+        with open(os.path.join(ROOT, REF_VS_REF_FILE)) as f:
+            r = json.load(f)
+        return {m: f"{r[m]['pairs_differing']} of {r[m]['pairs']} ({REF_VS_REF_FILE})" for m in ("f", "h", "e") if m in r}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+REF_VS_REF = _ref_vs_ref()
 PMC_PROFILE = "profiles/round4_geofilter_pmc_call228.json"   # SQ counter passes of tools/geofilter_run.py (tools/gpu.sh geopmc)
 
 
@@ -30,37 +44,52 @@ def valu_cycles_per_iteration(model):
 
 
 def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, cpu_pairs=6000, model="f"):
-    """model "f": GeometricFilter_FMatrix_AC; "h": GeometricFilter_HMatrix_AC (H_ACRobust.hpp) on pairs related by homographies"""
+    """model "f": GeometricFilter_FMatrix_AC; "h": GeometricFilter_HMatrix_AC (H_ACRobust.hpp) on pairs related by homographies;
+    "e": GeometricFilter_EMatrix_AC (E_ACRobust.hpp) on the calibrated version of the "f" set"""
     from openmvg_amd import geofilter, synth
-    if model == "h":
+    K = bear = None
+    if model == "e":
+        tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
+        K = synth.two_view_calibration(tv)
+        fun = geofilter.GeometricFilter_EMatrix_AC(4.0, 2048)
+        # one calibration for the whole set: the bearing vectors of all correspondences at once (what the cameras' operator() returns)
+        bear = (geofilter.pinhole_bearings(K[0, 0], tv["xI"]), geofilter.pinhole_bearings(K[0, 1], tv["xJ"]))
+    elif model == "h":
         tv = synth.two_view_homography_matches(n_pairs, seed=0x6E0F, n_min=n, n_max=n, tiny_frac=0.0)
         fun = geofilter.GeometricFilter_HMatrix_AC(4.0, 2048)
     else:
         tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
         fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
-    geofilter.filter_pairs(tv["xI"][:n * 512], tv["xJ"][:n * 512], tv["start"][:513], tv["wh"][:512], fun, device)   # warm-up
+    def run(m):   # the first m pairs of the set
+        if model == "e":
+            return geofilter.filter_pairs_e(tv["xI"][:n * m], tv["xJ"][:n * m], tv["start"][:m + 1], tv["wh"][:m], K[:m], fun, device,
+                                            bearings=(bear[0][:n * m], bear[1][:n * m]))
+        return geofilter.filter_pairs(tv["xI"][:n * m], tv["xJ"][:n * m], tv["start"][:m + 1], tv["wh"][:m], fun, device)
+
+    run(min(512, n_pairs))   # warm-up
     # the dependent chain of one iteration without contention: 256 pairs = 64 workgroups of four waves, one wave per SIMD on 64 CUs
-    _, _, st1 = geofilter.filter_pairs(tv["xI"][:n * 256], tv["xJ"][:n * 256], tv["start"][:257], tv["wh"][:256], fun, device)
+    _, _, st1 = run(min(256, n_pairs))
     chain_clocks = st1.wave_clocks / max(int(st1.n_iterations), 1)
     kernel_ms = total_ms = 0.0
     iters = models = clocks = 0
     t0 = time.perf_counter()
     for _ in range(steps):
-        mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun, device)
+        mask, res, st = run(n_pairs)
         kernel_ms += st.kernel_ms; total_ms += st.total_ms
         iters += int(st.n_iterations); models += int(st.n_models); clocks += int(st.wave_clocks)
     dt = time.perf_counter() - t0
     ach = iters / (kernel_ms * 1e-3)
-    peak = RESIDENT_WAVES * SHADER_CLOCK_HZ / chain_clocks
+    resident = RESIDENT_WAVES * 2 // 3 if model == "e" else RESIDENT_WAVES   # the essential instantiation holds two waves per SIMD (256 VGPRs)
+    peak = resident * SHADER_CLOCK_HZ / chain_clocks
     vci = valu_cycles_per_iteration(model)
-    rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (total_ms * 1e-3),
+    rec = {"metric": f"image pairs/s (a-contrario {'homography' if model == 'h' else 'essential-matrix' if model == 'e' else 'fundamental-matrix'} filter of putative matches)", "value": n_pairs * steps / (total_ms * 1e-3),
            "unit": "image pairs/s (whole call: host preparation, transfers, kernels)", "dtype": "f64",
            "image_pairs_per_s_kernel_time": n_pairs * steps / (kernel_ms * 1e-3),
            "roofline": {"bound": "latency", "achieved": ach, "peak": peak, "unit": "a-contrario iterations/s", "frac": ach / peak, "traffic": None,
-                        "kernel": f"geofilter_f_acransac_kernel<4, false, {'kModelH' if model == 'h' else 'kModelF'}>",
+                        "kernel": f"geofilter_f_acransac_kernel<4, false, {'kModelH' if model == 'h' else 'kModelE' if model == 'e' else 'kModelF'}>",
                         "iterations_per_pass": iters / steps, "models_per_iteration": models / max(iters, 1),
                         "clocks_per_iteration_and_wave": clocks / max(iters, 1), "clocks_per_iteration_one_wave_per_simd": chain_clocks,
-                        "resident_waves": RESIDENT_WAVES, "clock_hz_nominal": SHADER_CLOCK_HZ,
+                        "resident_waves": resident, "clock_hz_nominal": SHADER_CLOCK_HZ,
                         "valu_cycles_per_iteration_pmc": vci,
                         "frac_of_valu_issue_floor": (ach * vci / (1024 * SHADER_CLOCK_HZ)) if vci else None,
                         "note": "one wave runs one pair's sequential program: the floor of an iteration is its dependent chain (sample -> minimal solver -> "
@@ -77,15 +106,19 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
             if _oracle.have_ref_geofilter():
                 m = min(cpu_pairs, n_pairs)
                 sub = dict(xI=tv["xI"][:n * m], xJ=tv["xJ"][:n * m], start=tv["start"][:m + 1], wh=tv["wh"][:m])
-                ref_fn = _oracle.ref_geofilter_h if model == "h" else _oracle.ref_geofilter
+                if model == "e":
+                    ref_fn = lambda d: _oracle.ref_geofilter_e(d, K[:len(d["wh"])])   # noqa: E731
+                else:
+                    ref_fn = _oracle.ref_geofilter_h if model == "h" else _oracle.ref_geofilter
                 ref_fn(dict(xI=sub["xI"][:n * 64], xJ=sub["xJ"][:n * 64], start=sub["start"][:65], wh=sub["wh"][:64]))
                 ref = ref_fn(sub)
                 rec["cpu_baseline"] = {"value": m / ref["seconds"], "unit": "image pairs/s", "cores": os.cpu_count(), "kind": "reference",
                                        "sample": f"the first {m} pairs of the same set in {ref['seconds']:.1f} s (ACKernelAdaptor<"
-                                                 f"{'FourPointSolver, AsymmetricError' if model == 'h' else 'SevenPointSolver, EpipolarDistanceError'}> + ACRANSAC, OpenMP over the pairs)"}
+                                                 f"{'FourPointSolver, AsymmetricError' if model == 'h' else 'FivePointSolver, EpipolarDistanceError (ACKernelAdaptorEssential)' if model == 'e' else 'SevenPointSolver, EpipolarDistanceError'}> + ACRANSAC, OpenMP over the pairs)"}
                 rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]   # whole call against whole call
                 differing, rep = gc.compare(sub["start"], ref, mask[:n * m], res["ok"][:m], res["F"][:m], res["precision_robust"][:m], res["nfa"][:m])
-                rec["parity"] = dict(rep, policy="identical inlier sets (then NFA, precision equal and F equal to 1e-6 - asserted); pairs_differing = "
+                rec["parity"] = dict(rep, pairs_differing_between_two_builds_of_the_reference=REF_VS_REF.get(model),
+                                     policy="identical inlier sets (then NFA, precision equal and F equal to 1e-6 - asserted); pairs_differing = "
                                                  "pairs whose decisive residual is within rounding of a histogram edge (DESIGN.md)")
         except Exception as e:
             rec["cpu_baseline"] = {"value": None, "kind": "reference", "sample": f"failed: {e!r}"}

@@ -1,5 +1,5 @@
 // mvgx_geometric_filter.cpp - definitions of the explicit specialisations declared in mvgx_geometric_filter.hpp: the geometric filter
-// of a putative-match container with GeometricFilter_FMatrix_AC or GeometricFilter_HMatrix_AC on the MI355X.
+// of a putative-match container with GeometricFilter_FMatrix_AC, GeometricFilter_HMatrix_AC or GeometricFilter_EMatrix_AC on the MI355X.
 //
 // Reference behaviour reproduced (openMVG/matching_image_collection/GeometricFilter.hpp:66-131, F_ACRobust.hpp:65-122,
 // H_ACRobust.hpp:49-113):
@@ -17,6 +17,8 @@
 // batch whose device call failed (logged once; mvgx_adapter_policy.hpp; MVGX_ON_DEVICE_ERROR=throw stops instead).
 #include "mvgx_geometric_filter.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
+#include "openMVG/matching_image_collection/E_ACRobust.hpp"
+#include "openMVG/cameras/Camera_Pinhole.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -60,15 +62,34 @@ bool reference_pair(const Functor& functor, const sfm::SfM_Data* sfm_data,
 
 // what differs between the two functors: the member that holds the model and the C entry point
 template <class Functor> struct ModelOf;
+// (run: the indexed C entry with one argument list for the three models - the bearing vectors and calibration matrices only reach the
+// essential entry)
 template <> struct ModelOf<GeometricFilter_FMatrix_AC> {
   static Mat3& model(GeometricFilter_FMatrix_AC& f) { return f.m_F; }
   static constexpr const char* entry_name = "mvgx_geofilter_f_acransac_indexed";
-  template <class... A> static int run(A... a) { return mvgx_geofilter_f_acransac_indexed(a...); }
+  static constexpr bool essential = false;
+  static int run(const double* xy, const double*, const uint64_t* fs, const uint32_t* wh, const double*, uint32_t nv, const uint32_t* pv, const uint64_t* st,
+                 const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
+    return mvgx_geofilter_f_acransac_indexed(-1, xy, fs, wh, nv, pv, st, ij, nb, o, m, r, nullptr);
+  }
 };
 template <> struct ModelOf<GeometricFilter_HMatrix_AC> {
   static Mat3& model(GeometricFilter_HMatrix_AC& f) { return f.m_H; }
   static constexpr const char* entry_name = "mvgx_geofilter_h_acransac_indexed";
-  template <class... A> static int run(A... a) { return mvgx_geofilter_h_acransac_indexed(a...); }
+  static constexpr bool essential = false;
+  static int run(const double* xy, const double*, const uint64_t* fs, const uint32_t* wh, const double*, uint32_t nv, const uint32_t* pv, const uint64_t* st,
+                 const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
+    return mvgx_geofilter_h_acransac_indexed(-1, xy, fs, wh, nv, pv, st, ij, nb, o, m, r, nullptr);
+  }
+};
+template <> struct ModelOf<GeometricFilter_EMatrix_AC> {
+  static Mat3& model(GeometricFilter_EMatrix_AC& f) { return f.m_E; }
+  static constexpr const char* entry_name = "mvgx_geofilter_e_acransac_indexed";
+  static constexpr bool essential = true;
+  static int run(const double* xy, const double* bearing, const uint64_t* fs, const uint32_t* wh, const double* K, uint32_t nv, const uint32_t* pv,
+                 const uint64_t* st, const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
+    return mvgx_geofilter_e_acransac_indexed(-1, xy, bearing, fs, wh, K, nv, pv, st, ij, nb, o, m, r, nullptr);
+  }
 };
 
 // the body of both specialisations; the members of ImageCollectionGeometricFilter it works on are passed in under their names
@@ -88,8 +109,17 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   std::vector<uint8_t> on_device(n_pairs, 0);
   std::vector<uint64_t> start(1, 0);
   std::vector<size_t> dev_pairs;
+  // the essential model needs a pinhole intrinsic on both views (E_ACRobust.hpp:76-100): the other pairs take the reference's functor,
+  // which warns and rejects them
+  auto pinhole_view = [&](IndexT id) {
+    const auto vit = sfm_data_->GetViews().find(id);
+    if (vit == sfm_data_->GetViews().end()) return false;
+    const auto iit = sfm_data_->GetIntrinsics().find(vit->second->id_intrinsic);
+    return iit != sfm_data_->GetIntrinsics().end() && iit->second && cameras::isPinhole(iit->second->getType());
+  };
   for (size_t p = 0; p < n_pairs; ++p) {
-    if (device_ok && its[p]->second.size() <= kDeviceMaxMatches) {
+    if (device_ok && its[p]->second.size() <= kDeviceMaxMatches &&
+        (!ModelOf<Functor>::essential || (pinhole_view(its[p]->first.first) && pinhole_view(its[p]->first.second)))) {
       on_device[p] = 1;
       dev_pairs.push_back(p);
       start.push_back(start.back() + its[p]->second.size());
@@ -118,6 +148,10 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   }
   for (size_t v = 0; v < n_views; ++v) feat_start[v + 1] += feat_start[v];
   std::vector<double> feat_xy(2 * std::max<uint64_t>(feat_start[n_views], 1));
+  // essential model: the bearing vector of every feature by the camera's own operator() on the undistorted position (what
+  // Robust_estimation passes as (*cam_I)(xI), E_ACRobust.hpp:118-123) and the calibration matrix of every view
+  std::vector<double> feat_bearing(ModelOf<Functor>::essential ? 3 * std::max<uint64_t>(feat_start[n_views], 1) : 0);
+  std::vector<double> view_K(ModelOf<Functor>::essential ? 9 * std::max<size_t>(n_views, 1) : 0);
 #ifdef OPENMVG_USE_OPENMP
 #pragma omp parallel for schedule(dynamic)
 #endif
@@ -129,6 +163,19 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
     for (size_t i = 0; i < positions[v].size(); ++i) {
       const Vec2 x = cam ? Vec2(cam->get_ud_pixel(positions[v][i].coords().cast<double>())) : Vec2(positions[v][i].coords().cast<double>());
       dst[2 * i] = x(0); dst[2 * i + 1] = x(1);
+    }
+    if (ModelOf<Functor>::essential) {
+      const cameras::Pinhole_Intrinsic* pin = dynamic_cast<const cameras::Pinhole_Intrinsic*>(cam);
+      if (pin) {   // (views without a pinhole camera only occur in pairs that are not on the device)
+        const size_t n = positions[v].size();
+        Mat2X pts(2, n);
+        for (size_t i = 0; i < n; ++i) pts.col(i) << dst[2 * i], dst[2 * i + 1];
+        const Mat3X b = (*cam)(pts);
+        double* bd = feat_bearing.data() + 3 * feat_start[v];
+        for (size_t i = 0; i < n; ++i) { bd[3 * i] = b(0, i); bd[3 * i + 1] = b(1, i); bd[3 * i + 2] = b(2, i); }
+        const Mat3& Km = pin->K();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) view_K[9 * v + 3 * r + c] = Km(r, c);
+      }
     }
     features::PointFeatures().swap(positions[v]);
   }
@@ -155,9 +202,9 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       for (size_t k = 0; k <= nb; ++k) start_b[k] = start[b0 + k] - start[b0];   // a call's match_start begins at zero
       const bool inj = mvgx_adapter::injected("geofilter", "run");
       const int rc = inj ? MVGX_ERR_NODEV
-                         : ModelOf<Functor>::run(-1, (const double*)feat_xy.data(), (const uint64_t*)feat_start.data(), (const uint32_t*)wh.data(), (uint32_t)n_views,
-                                                 (const uint32_t*)pair_views.data() + 2 * b0, (const uint64_t*)start_b.data(), (const uint32_t*)ij.data() + 2 * start[b0],
-                                                 (uint64_t)nb, (const mvgx_geofilter_options*)&opt, mask.data() + start[b0], res.data() + b0, (mvgx_geofilter_stats*)nullptr);
+                         : ModelOf<Functor>::run(feat_xy.data(), feat_bearing.data(), feat_start.data(), wh.data(), view_K.data(), (uint32_t)n_views,
+                                                 pair_views.data() + 2 * b0, start_b.data(), ij.data() + 2 * start[b0], (uint64_t)nb, &opt,
+                                                 mask.data() + start[b0], res.data() + b0);
       if (rc != MVGX_OK) {
         // logged once; the pairs from here on take the reference's own functor below (or the failure is thrown)
         mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", ModelOf<Functor>::entry_name, rc, inj);
@@ -225,6 +272,13 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMatrix_AC>(
     const GeometricFilter_HMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
+}
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EMatrix_AC>(
+    const GeometricFilter_EMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
   filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
 }

@@ -9,10 +9,14 @@
 // runs all image pairs of the container through mvgx_geofilter_f_acransac (include/mvgx.h). Same signature, same container
 // (_map_GeometricMatches), same acceptance rule; the guided-matching step, if asked for, runs the reference's own
 // Geometry_guided_matching with the estimated model. The homography functor (GeometricFilter_HMatrix_AC, H_ACRobust.hpp) has the same
-// kind of specialisation over mvgx_geofilter_h_acransac_indexed; the other functors (E, ...) keep the reference's template.
+// kind of specialisation over mvgx_geofilter_h_acransac_indexed, and the essential-matrix functor (GeometricFilter_EMatrix_AC, E_ACRobust.hpp:
+// main_GeometricFilter -g e) over mvgx_geofilter_e_acransac_indexed - the bearing vectors of the features come from the cameras' own
+// operator(), pairs without two pinhole cameras take the reference's functor (which warns and rejects them). The other functors
+// (angular, orthographic, upright essential) keep the reference's template.
 #ifndef MVGX_GEOMETRIC_FILTER_HPP
 #define MVGX_GEOMETRIC_FILTER_HPP
 
+#include "openMVG/matching_image_collection/E_ACRobust.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
@@ -28,6 +32,11 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_FMa
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMatrix_AC>(
     const GeometricFilter_HMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EMatrix_AC>(
+    const GeometricFilter_EMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* progress_bar);
 
 }  // namespace matching_image_collection

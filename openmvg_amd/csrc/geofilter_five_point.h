@@ -24,6 +24,22 @@ namespace five_point {
 constexpr int kN = 10;          // order of the action matrix
 constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */;   // doubles of wave-private LDS
 
+// 1 / x and 1 / sqrt(x) from v_rcp_f64 / v_rsq_f64 + two Newton steps (full precision for finite normal arguments): the iteration below
+// spent 70 % of its clocks in IEEE division and square-root sequences (~150 clocks each, all on the critical path of a single wave)
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double frsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  r = fma(fma(-hx * r, r, 0.5), r, r);
+  r = fma(fma(-hx * r, r, 0.5), r, r);
+  return r;
+}
+
 // ---- polynomials in (x, y, z): degree 1 as {x, y, z, 1}, degree 2 as {xx, xy, yy, xz, yz, zz, x, y, z, 1} (the reference's columns
 // 10..19), degree 3 in the reference's full order (solver_essential_five_point.hpp:103-125) ----
 __device__ __forceinline__ void o1(const double (&a)[4], const double (&b)[4], double (&r)[10]) {   // :44-66
@@ -351,11 +367,11 @@ __device__ __forceinline__ bool hqr(double* __restrict__ a, double* __restrict__
             z = A(m, m);
             r = x - z;
             double s = y - z;
-            p = (r * s - w) / A(m + 1, m) + A(m, m + 1);
+            p = (r * s - w) * frcp(A(m + 1, m)) + A(m, m + 1);
             q = A(m + 1, m + 1) - z - r - s;
             r = A(m + 2, m + 1);
             s = fabs(p) + fabs(q) + fabs(r);
-            p /= s; q /= s; r /= s;
+            { const double is = s != 0.0 ? frcp(s) : 0.0; p *= is; q *= is; r *= is; }
             if (m == l) break;
             const double u = fabs(A(m, m - 1)) * (fabs(q) + fabs(r));
             const double vv = fabs(p) * (fabs(A(m - 1, m - 1)) + fabs(z) + fabs(A(m + 1, m + 1)));
@@ -371,9 +387,11 @@ __device__ __forceinline__ bool hqr(double* __restrict__ a, double* __restrict__
             if (k != m) {
               p = A(k, k - 1); q = A(k + 1, k - 1); r = 0.0;
               if (k != nn - 1) r = A(k + 2, k - 1);
-              if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+              if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { const double ix = frcp(x); p *= ix; q *= ix; r *= ix; }
             }
-            const double sq = sqrt(p * p + q * q + r * r);
+            const double n2 = p * p + q * q + r * r;
+            const double irs = n2 > 0.0 ? frsqrt(n2) : 0.0;   // 1 / |s|
+            const double sq = n2 * irs;
             const double s = p >= 0.0 ? sq : -sq;
             if (s != 0.0) {
               wave_sync();
@@ -381,7 +399,9 @@ __device__ __forceinline__ bool hqr(double* __restrict__ a, double* __restrict__
                 if (k == m) { if (l != m) A(k, k - 1) = -A(k, k - 1); }
                 else A(k, k - 1) = -s * x;
               }
-              p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+              { const double is = p >= 0.0 ? irs : -irs;   // 1 / s
+                p += s; x = p * is; y = q * is; z = r * is;
+                const double ip = frcp(p); q *= ip; r *= ip; }
               wave_sync();
               if (lane >= k && lane <= nn) {   // row modification, column `lane`
                 double pp = A(k, lane) + q * A(k + 1, lane);

@@ -149,6 +149,7 @@ void ref_five_point(const double* b1, const double* b2, double* Es_out, int* n_o
 // the explicit specialisation of openmvg_amd/adapter/mvgx_geometric_filter.cpp is linked instead (tests/native/adapter_harness.mk).
 #include "openMVG/cameras/Camera_Pinhole_Radial.hpp"
 #include "openMVG/features/regions_factory.hpp"
+#include "openMVG/matching_image_collection/E_ACRobust.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
@@ -171,12 +172,18 @@ extern "C" typedef void (*geo_sink)(void* user, uint32_t I, uint32_t J, const ui
 template <class Functor>
 static uint64_t container_impl(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
                                const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
-                               double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
+                               double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user,
+                               double pinhole_focal = 0.0) {
   sfm::SfM_Data scene;
   auto provider = std::make_shared<InMemoryRegionsProvider>();
   provider->set_type(new features::SIFT_Regions());
   for (uint32_t k = 0; k < n_images; ++k) {
-    scene.views[k] = std::make_shared<sfm::View>("", k, k1 != 0.0 ? 0 : UndefinedIndexT, UndefinedIndexT, image_wh[2 * k], image_wh[2 * k + 1]);
+    // pinhole_focal > 0: every view has its own Pinhole_Intrinsic (focal given, principal point at the centre) - except the LAST view, which
+    // keeps no intrinsic, so that the essential functor's "no intrinsic information" branch is exercised by its pairs
+    const bool own_pinhole = pinhole_focal > 0.0 && (k + 1 < n_images || n_images < 3);
+    scene.views[k] = std::make_shared<sfm::View>("", k, k1 != 0.0 ? 0 : own_pinhole ? k : UndefinedIndexT, UndefinedIndexT, image_wh[2 * k], image_wh[2 * k + 1]);
+    if (own_pinhole)
+      scene.intrinsics[k] = std::make_shared<cameras::Pinhole_Intrinsic>(image_wh[2 * k], image_wh[2 * k + 1], pinhole_focal, image_wh[2 * k] / 2.0, image_wh[2 * k + 1] / 2.0);
     auto r = std::make_shared<features::SIFT_Regions>();
     const uint64_t lo = feat_start[k], n = feat_start[k + 1] - lo;
     r->Features().resize(n);
@@ -222,5 +229,12 @@ uint64_t ref_geofilter_container_h(const float* feat_xy, const uint8_t* descs, c
                                    double precision, uint32_t max_iterations, int guided, double distance_ratio, double k1, geo_sink sink, void* user) {
   return container_impl<matching_image_collection::GeometricFilter_HMatrix_AC>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
                                                                                n_pairs, precision, max_iterations, guided, distance_ratio, k1, sink, user);
+}
+// the essential functor (E_ACRobust.hpp): every view but the last carries a Pinhole_Intrinsic of the given focal
+uint64_t ref_geofilter_container_e(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                   const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                   double precision, uint32_t max_iterations, int guided, double distance_ratio, double focal, geo_sink sink, void* user) {
+  return container_impl<matching_image_collection::GeometricFilter_EMatrix_AC>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
+                                                                               n_pairs, precision, max_iterations, guided, distance_ratio, 0.0, sink, user, focal);
 }
 }  // extern "C"

@@ -7,7 +7,8 @@ its NFA must be equal to 1e-9 relative, its precision equal and its F equal to 1
 share whose decisive residual lies within rounding of a histogram edge / whose cubic is badly conditioned in one basis; that
 share is counted and bounded BY THE REFERENCE'S OWN BUILD-TO-BUILD SPREAD: profiles/round4_geofilter_reference_vs_reference.json
 (tools/geofilter_ref_vs_ref.py) runs the same openMVG sources compiled -O3 and -O3 -mavx2 -mfma on the bench sets - the two builds
-end with different inlier sets on 50 of 100 000 pairs for the fundamental matrix (5.0e-4) and on 0 of 20 000 for the homography
+end with different inlier sets on 50 of 100 000 pairs for the fundamental matrix (5.0e-4), on 14 of 20 000 for the essential matrix
+(7.0e-4) and on 0 of 20 000 for the homography
 (taken as < 3 of 20 000, the 95 % upper bound of a count of zero); on pairs with identical inlier sets their models still differ by
 up to 1.3e-5. `allowed_differing` is the 99 % Poisson quantile of that share at a test's sample size: 0 up to 20 pairs (the real-image pairs; smoke asks for 0 of its 24), 1 at 240, 3 at 1 000,
 8 at 6 000 - instead of the flat 1 - 2 % of round 3."""
@@ -15,7 +16,7 @@ import math
 
 import numpy as np
 
-REFERENCE_BUILD_SPREAD = {"f": 50 / 100000.0, "h": 3 / 20000.0, "e": 50 / 100000.0}   # ("e": filled from the record below once measured)
+REFERENCE_BUILD_SPREAD = {"f": 50 / 100000.0, "h": 3 / 20000.0, "e": 14 / 20000.0}
 
 
 def allowed_differing(n_pairs, model="f", quantile=0.99):

@@ -815,7 +815,7 @@ def geofilter_container_lib(kind):
     return lib
 
 
-def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None, model="f"):
+def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None, model="f", focal=0.0):
     """feats_xy: list of (n_k, 2) float32 positions; image_wh: (n_images, 2); putative: {(I, J): (n, 2) uint32}. -> {(I, J): (m, 2)}"""
     lib = geofilter_container_lib(kind)
     fx = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float32).reshape(-1, 2) for f in feats_xy]), np.float32)
@@ -833,7 +833,9 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
 
     cb = GEO_SINK(sink)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-    fn = lib.ref_geofilter_container if model == "f" else lib.ref_geofilter_container_h
+    fn = lib.ref_geofilter_container if model == "f" else lib.ref_geofilter_container_h if model == "h" else lib.ref_geofilter_container_e
+    if model == "e":   # (the k1 slot of the shim carries the focal length of the views' pinhole cameras)
+        k1 = focal
     fn.restype = C.c_uint64
     fn(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij),
                                 C.c_uint64(len(keys)), C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if guided else 0),

@@ -160,3 +160,30 @@ def test_host_bearings_give_the_same_inlier_sets_as_the_reference_cameras():
     st = tv["start"].astype(np.int64)
     diff = sum(1 for p in range(120) if not np.array_equal(m1[st[p]:st[p + 1]], m2[st[p]:st[p + 1]]))
     assert diff <= gc.allowed_differing(120, "e")
+
+
+# ---- the drop-in: ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EMatrix_AC> ----
+def _container_case(kind, guided=False):
+    """a collection of calibrated pairs (every view but the last has a Pinhole_Intrinsic: the pairs of the last view take the functor's
+    "no intrinsic information" branch) through the same caller, linked against the reference template or the adapter's specialisation"""
+    from tests import _geofilter_scene
+    feats, wh, putative = _geofilter_scene.collection(n_pairs=5, seed=12, n_min=40, n_max=70, inlier_frac=(0.6, 0.9), no_geometry_frac=0.2, size=(1000, 1000))
+    return _oracle.geofilter_container(kind, feats, wh, putative, max_iterations=512, guided=guided, model="e", focal=900.0)
+
+
+def test_adapter_specialisation_fills_the_container_like_the_reference_template():
+    if _oracle.geofilter_container_lib("reference") is None or _oracle.geofilter_container_lib("adapter_emu") is None:
+        pytest.skip("needs /root/reference (reference library and adapter harness)")
+    want, got = _container_case("reference"), _container_case("adapter_emu")
+    assert set(want) == set(got) and len(want) >= 2 and (8, 9) not in want   # (the pair of the view without intrinsics is rejected by both)
+    assert all(np.array_equal(want[k], got[k]) for k in want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("guided", [False, True])
+def test_adapter_specialisation_on_the_device(guided):
+    if _oracle.geofilter_container_lib("reference") is None or _oracle.geofilter_container_lib("adapter") is None:
+        pytest.skip("adapter harness / reference library not present")
+    want, got = _container_case("reference", guided), _container_case("adapter", guided)
+    assert set(want) == set(got) and len(want) >= 2
+    assert all(np.array_equal(want[k], got[k]) for k in want)

@@ -39,10 +39,16 @@ def run(model, n_pairs, n):
     fma = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter_fma.so"))
     if model == "h":
         tv = synth.two_view_homography_matches(max(n_pairs, 20000), seed=0x6E0F, n_min=n, n_max=n, tiny_frac=0.0)
+    elif model == "e":
+        tv = synth.two_view_matches_bulk(max(n_pairs, 20000), n=n, seed=0x6E0F)
     else:
         tv = synth.two_view_matches_bulk(max(n_pairs, 100000), n=n, seed=0x6E0F)
     tv = dict(xI=tv["xI"][:n * n_pairs], xJ=tv["xJ"][:n * n_pairs], start=tv["start"][:n_pairs + 1], wh=tv["wh"][:n_pairs])
-    if model == "h":
+    if model == "e":
+        K = synth.two_view_calibration(tv)
+        a = _oracle.ref_geofilter_e(tv, K)
+        b = _oracle._geofilter_call_e(fma.ref_geofilter_e_acransac, tv, K, False, 4.0, 2048, 0)
+    elif model == "h":
         a = _oracle.ref_geofilter_h(tv)
         b = _oracle._geofilter_call(fma.ref_geofilter_h_acransac, tv, 4.0, 2048, 0)
     else:
@@ -68,5 +74,5 @@ if __name__ == "__main__":
     rec = {"what": "compiled reference (-O3) vs compiled reference (-O3 -mavx2 -mfma) on the bench samples of bench_geofilter.py",
            "sources": "openMVG/robust_estimation/robust_estimator_ACRansac.hpp, multiview/solver_fundamental_kernel.cpp, "
                       "multiview/solver_homography_kernel.cpp through oracle/ref_shim_geofilter.cpp (both builds)",
-           "f": run("f", n_pairs, 250), "h": run("h", n_h, 250)}
+           "f": run("f", n_pairs, 250), "h": run("h", n_h, 250), "e": run("e", n_h, 250)}
     print(json.dumps(rec, indent=1))
