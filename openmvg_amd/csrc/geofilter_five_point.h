@@ -21,8 +21,15 @@
 
 namespace five_point {
 
+#ifdef MVGX_FIVE_POINT_STAMPS   // measurement build: shader clocks of lane 0 per stage of solve(), summed over all calls
+__device__ unsigned long long g_stamps[8];
+#define FP_STAMP(i) do { const long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } while (0)
+#else
+#define FP_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kN = 10;          // order of the action matrix
-constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */;   // doubles of wave-private LDS
+constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */ + 36 /* null-space basis */;   // doubles of wave-private LDS
 
 // 1 / x and 1 / sqrt(x) from v_rcp_f64 / v_rsq_f64 + two Newton steps (full precision for finite normal arguments): the iteration below
 // spent 70 % of its clocks in IEEE division and square-root sequences (~150 clocks each, all on the critical path of a single wave)
@@ -155,27 +162,36 @@ __device__ __forceinline__ void nullspace(const double* __restrict__ b1, const d
   }
 }
 
-// ---- 2. row `row` (< 10, this lane's) of the constraint matrix: 0 = det(E), 1 + 3 i + j = (2 E E^T E - trace(E E^T) E)(i, j) / 2 ----
-__device__ __forceinline__ void constraint_row(const double (&basis)[9][4], int row, double (&m)[20]) {
+// ---- 2. row `row` (< 10, this lane's) of the constraint matrix: 0 = det(E), 1 + 3 i + j = (2 E E^T E - trace(E E^T) E)(i, j) / 2.
+// B = the null-space basis in LDS, B[4 u + k] = coefficient k of entry u of E (every polynomial is fetched where it is used: held in
+// registers next to this function's intermediate polynomials, the basis pushed the kernel into scratch memory) ----
+__device__ __forceinline__ void ld4(const double* __restrict__ B, int u, double (&e)[4]) {
 #pragma unroll
-  for (int t = 0; t < 20; ++t) m[t] = 0.0;
-  // E[i][j] as a degree-1 polynomial: coefficients basis[3 i + j][0..3]
-  if (row == 0) {   // (:127-129)
-    double p[10], q[10], d[10];
-    o1(basis[1], basis[5], p); o1(basis[2], basis[4], q);
+  for (int t = 0; t < 4; ++t) e[t] = B[4 * u + t];
+}
+__device__ __forceinline__ void constraint_row(const double* __restrict__ B, int row, double (&m)[20]) {
+  const bool row0 = row == 0;
+  // Both forms are evaluated by every lane and selected per element (a divergent branch around the determinant row kept the row in
+  // scratch memory).
+  double m0[20];   // the determinant row (:127-129)
 #pragma unroll
-    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
-    o2_add(d, basis[6], m);
-    o1(basis[2], basis[3], p); o1(basis[0], basis[5], q);
+  for (int t = 0; t < 20; ++t) { m[t] = 0.0; m0[t] = 0.0; }
+  {
+    const int trip[3][5] = {{1, 5, 2, 4, 6}, {2, 3, 0, 5, 7}, {0, 4, 1, 3, 8}};   // (E[a] E[b] - E[c] E[d]) E[e]
 #pragma unroll
-    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
-    o2_add(d, basis[7], m);
-    o1(basis[0], basis[4], p); o1(basis[1], basis[3], q);
+    for (int w = 0; w < 3; ++w) {
+      double ea[4], eb[4], p[10], q[10];
+      ld4(B, trip[w][0], ea); ld4(B, trip[w][1], eb);
+      o1(ea, eb, p);
+      ld4(B, trip[w][2], ea); ld4(B, trip[w][3], eb);
+      o1(ea, eb, q);
 #pragma unroll
-    for (int t = 0; t < 10; ++t) d[t] = p[t] - q[t];
-    o2_add(d, basis[8], m);
-    return;
+      for (int t = 0; t < 10; ++t) p[t] -= q[t];
+      ld4(B, trip[w][4], ea);
+      o2_add(p, ea, m0);
+    }
   }
+  if (row < 1) row = 1;   // (row 0 takes m0 below; its lane evaluates the (0, 0) form like lane 1)
   const int i = (row - 1) / 3, j = (row - 1) - 3 * i;
   // half the trace of E E^T (:147)
   double tr[10];
@@ -183,20 +199,16 @@ __device__ __forceinline__ void constraint_row(const double (&basis)[9][4], int 
   for (int t = 0; t < 10; ++t) tr[t] = 0.0;
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
-    double p[10];
-    o1(basis[u], basis[u], p);
+    double e[4], p[10];
+    ld4(B, u, e);
+    o1(e, e, p);
 #pragma unroll
     for (int t = 0; t < 10; ++t) tr[t] += p[t];
   }
-  // row i of E (this lane's i) and column j of E
-  double ei[3][4], ej[3][4];
+  // row i of E (this lane's i: a per-lane address)
+  double ei[3][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ei[k][t] = i == 0 ? basis[k][t] : i == 1 ? basis[3 + k][t] : basis[6 + k][t];
-      ej[k][t] = j == 0 ? basis[3 * k][t] : j == 1 ? basis[3 * k + 1][t] : basis[3 * k + 2][t];
-    }
+  for (int k = 0; k < 3; ++k) ld4(B, 3 * i + k, ei[k]);
   // L[i][k] = (E E^T)(i, k) - (i == k) trace / 2, then sum_k L[i][k] E[k][j]   (:136-160)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -205,8 +217,9 @@ __device__ __forceinline__ void constraint_row(const double (&basis)[9][4], int 
     for (int t = 0; t < 10; ++t) l[t] = 0.0;
 #pragma unroll
     for (int mm = 0; mm < 3; ++mm) {
-      double p[10];
-      o1(ei[mm], basis[3 * k + mm], p);
+      double e[4], p[10];
+      ld4(B, 3 * k + mm, e);
+      o1(ei[mm], e, p);
 #pragma unroll
       for (int t = 0; t < 10; ++t) l[t] += p[t];
     }
@@ -214,18 +227,27 @@ __device__ __forceinline__ void constraint_row(const double (&basis)[9][4], int 
 #pragma unroll
       for (int t = 0; t < 10; ++t) l[t] -= 0.5 * tr[t];
     }
-    o2_add(l, ej[k], m);
+    double ej[4];
+    ld4(B, 3 * k + j, ej);
+    o2_add(l, ej, m);
+  }
+  if (row0) {
+#pragma unroll
+    for (int t = 0; t < 20; ++t) m[t] = m0[t];
   }
 }
 
 // ---- 3 + 4. lane r < 10 owns row r of [left | right]; Gauss-Jordan with complete pivoting on the left block; the action matrix goes to
 // H (LDS, row-major 10 x 10). Returns false (wave-uniform) if the left block is singular to working precision. ----
-__device__ __forceinline__ bool action_matrix(double (&m)[20], int lane, double* __restrict__ H) {
+__device__ __forceinline__ bool action_matrix(const double (&m_in)[20], int lane, double* __restrict__ H) {
+  double m[20];   // (a private copy: worked on through the caller's array, the row stayed in scratch memory - hipcc, ROCm 7.2)
+#pragma unroll
+  for (int c = 0; c < 20; ++c) m[c] = m_in[c];
   uint32_t row_used = 0, col_used = 0;
   int my_pcol = -1;   // the pivot column of this lane's row
   const int r = lane < kN ? lane : kN - 1;
-#pragma unroll 1
-  for (int step = 0; step < kN; ++step) {
+#pragma unroll
+  for (int step = 0; step < kN; ++step) {   // (unrolled: rolled, the compiler kept the row in scratch memory - 5 000 clocks per step)
     uint32_t key = 0u;
     if (lane < kN && !((row_used >> r) & 1u)) {
 #pragma unroll
@@ -486,19 +508,39 @@ __device__ __forceinline__ int solve(const double* __restrict__ b1, const double
   double* const v = scr + 100;
   double* const wr = v + 10;
   double* const wi = wr + 10;
+  double* const basis_lds = wi + 10;
   double basis[9][4];
+#ifdef MVGX_FIVE_POINT_STAMPS
+  long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   nullspace(b1, b2, s, lane, basis);
+  FP_STAMP(0);
   double At_row[kN];   // this lane's row of the action matrix (lanes < 10): kept for the eigenvectors, H is destroyed by the iteration
   {
-    double m[20];
-    constraint_row(basis, lane < kN ? lane : kN - 1, m);
+    // the basis lives in LDS from here on (it is wave-uniform): its 72 registers are what the expansion, the elimination and the
+    // iteration were spilling
+    if (lane < 36) {
+      double mine = 0.0;
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine = lane == 4 * u + k ? basis[u][k] : mine;
+      basis_lds[lane] = mine;
+    }
     wave_sync();
+    double m[20];
+    constraint_row(basis_lds, lane < kN ? lane : kN - 1, m);
+    wave_sync();
+    FP_STAMP(1);
     if (!action_matrix(m, lane, H)) return 0;
+    FP_STAMP(2);
   }
 #pragma unroll
   for (int c = 0; c < kN; ++c) At_row[c] = H[(lane < kN ? lane : 0) * kN + c];
   hessenberg(H, v, lane);
+  FP_STAMP(3);
   if (!hqr(H, wr, wi, lane)) return 0;
+  FP_STAMP(4);
   // the action matrix again (the iteration worked in place), then one eigenvector per lane
 #pragma unroll
   for (int c = 0; c < kN; ++c)
@@ -514,9 +556,10 @@ __device__ __forceinline__ int solve(const double* __restrict__ b1, const double
   if (real) {
 #pragma unroll
     for (int u = 0; u < 9; ++u)
-      Es[slot * 9 + u] = basis[u][0] * tail[0] + basis[u][1] * tail[1] + basis[u][2] * tail[2] + basis[u][3] * tail[3];
+      Es[slot * 9 + u] = basis_lds[4 * u] * tail[0] + basis_lds[4 * u + 1] * tail[1] + basis_lds[4 * u + 2] * tail[2] + basis_lds[4 * u + 3] * tail[3];
   }
   wave_sync();
+  FP_STAMP(5);
   return n;
 }
 

@@ -140,7 +140,7 @@ constexpr int kGroupIntrRow = 8 + 8;                              // per local i
 constexpr int kGroupCandRow = 6 + kPoseTrig;                       // per local pose of the candidate x + delta: parameters | rotation terms
 constexpr int kGroupCand = kGroupCams * kGroupCandRow + kGroupIntr * 8 + 3 * kGroupPts;   // back-substitution with the candidate's cost: the candidate's cameras, the point threads' running sums
 constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr + kGroupCand;   // ... the solution's components, the candidate
-constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr) * (int)sizeof(uint32_t);
+constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr + 2) * (int)sizeof(uint32_t);
 // The norms and back-substitution modes never stage the matrix: their region M holds only the per-observation terms of the point
 // sums (18 x (threads + 1) doubles), which lets a third workgroup onto the CU (49 KB instead of 74 KB each).
 constexpr int kGroupMSmall = (18 * (kGroupThreads + 1) + 1) & ~1;
@@ -1076,6 +1076,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   uint32_t* const pe = ek + kGroupThreads;        // [point + 1]: first entry (group-relative)
   uint32_t* const pks = pe + kGroupPts + 1;       // [point]: first entry of the point's observations with local intrinsic 1
   int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
+  int* const ncam_used = imodel + kGroupIntr;                         // forward: local poses of the supergroup that carry observations
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t sg = G.sg_order[blockIdx.x];
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
@@ -1129,6 +1130,12 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     const int j = tid - 224;
     ccand[kGroupCams * kGroupCandRow + j] = d.cintr[(size_t)intrs[j >> 3] * 8 + (j & 7)];
   }
+  if (MODE == kGroupForward && tid >= 192) {   // (wave 3: the waves 0..2 stage the tables above)
+    const int x = tid - 192;
+    const bool used = x < kGroupCams && G.chunk_pp[(size_t)sg * kGroupPairsPP + group_pair_pp(x, x)] != kNoChunk;
+    const int n_used = (int)__popcll(__ballot(used));
+    if (x == 0) *ncam_used = n_used;
+  }
   if (MODE == kGroupForward) {
     // The reduced system is zeroed here, a slice per workgroup - the assemble pass that follows this kernel writes only the blocks
     // that exist, the tiles of the fill must start at zero - instead of by a memset launch in front of this kernel.
@@ -1148,10 +1155,21 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   uint32_t nx_pt = (uint32_t)tid < nx_np ? G.pts[nx_p0 + tid] : 0u;
   uint32_t nx_pe = (uint32_t)tid <= nx_np ? G.pt_estart[nx_p0 + tid] - nx_e0 : 0u;
   uint32_t nx_pk = MODE == kGroupForward && (uint32_t)tid < nx_np ? G.pt_ksplit[nx_p0 + tid] - nx_e0 : 0u;
+  // ... and so is the point of this thread's observation, in two steps that each start a phase after the load they depend on has
+  // landed (entry word -> point id -> coordinates and scales): an observation thread used to open every group with those two
+  // dependent trips to memory while the rest of its wave waited
+  uint32_t nx_ix = (uint32_t)tid < nx_ne ? G.pts[nx_p0 + (nx_qxk & 255u)] : 0u;
+  double nx_px[3] = {0.0, 0.0, 0.0}, nx_spo[3] = {0.0, 0.0, 0.0};
+  if ((uint32_t)tid < nx_ne) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nx_px[k] = d.pts[(size_t)nx_ix * 3 + k]; if (MODE == kGroupForward) nx_spo[k] = d.scale_pt[(size_t)nx_ix * 3 + k]; }
+  }
   for (uint32_t g = g0; g < g1; ++g) {
     const uint32_t e0 = nx_e0, ne = nx_ne, p0 = nx_p0, np = nx_np;
     const uint32_t qxk = nx_qxk, my_pt = nx_pt, my_pe = nx_pe, my_pk = nx_pk;
     const double2 xy = nx_xy;
+    const double cur_px[3] = {nx_px[0], nx_px[1], nx_px[2]}, cur_spo[3] = {nx_spo[0], nx_spo[1], nx_spo[2]};
+    const uint32_t cur_ix = nx_ix;   // (the scales are fetched ahead in the forward mode only: the back-substitution sits at its register budget of three waves per SIMD)
     if (g + 1 < g1) {
       nx_e0 = G.obs_start[g + 1]; nx_ne = G.obs_start[g + 2] - nx_e0; nx_p0 = G.pt_start[g + 1]; nx_np = G.pt_start[g + 2] - nx_p0;
       nx_qxk = (uint32_t)tid < nx_ne ? G.eq[nx_e0 + tid] : 0u;
@@ -1177,10 +1195,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       ek[tid] = qxk;
       q = (int)(qxk & 255u); x = (int)((qxk >> 8) & 15u);
       const int kk = (int)((qxk >> 12) & 15u);
-      const uint32_t ix = G.pts[p0 + q];
-      double pin[8], pp[6], trig[kPoseTrig], px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
+      double pin[8], pp[6], trig[kPoseTrig], px[3] = {cur_px[0], cur_px[1], cur_px[2]}, obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
       if (with_cand) {   // the point thread takes x from here (every observation of the point writes the same three values)
 #pragma unroll
         for (int k = 0; k < 3; ++k) ptab[q * 12 + 9 + k] = px[k];
@@ -1201,7 +1216,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         const double e0u = Jp[c] * sc, e1u = Jp[3 + c] * sc;
         M[(9 + c) * NS + tid] = e0u * e0u + e1u * e1u;
         M[(12 + c) * NS + tid] = e0u * r[0] + e1u * r[1];
-        if (MODE != kGroupNorms) { const double sp = d.scale_pt[(size_t)ix * 3 + c]; es0[c] = e0u * sp; es1[c] = e1u * sp; }
+        if (MODE != kGroupNorms) { const double sp = MODE == kGroupForward ? cur_spo[c] : d.scale_pt[(size_t)cur_ix * 3 + c]; es0[c] = e0u * sp; es1[c] = e1u * sp; }
       }
       if (MODE != kGroupNorms) {
         M[0 * NS + tid] = es0[0] * es0[0] + es1[0] * es1[0]; M[1 * NS + tid] = es0[0] * es0[1] + es1[0] * es1[1];
@@ -1233,6 +1248,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     }
     if ((uint32_t)tid <= np) pe[tid] = my_pe;
     if (MODE == kGroupForward && (uint32_t)tid < np) pks[tid] = my_pk;
+    if (g + 1 < g1) nx_ix = (uint32_t)tid < nx_ne ? G.pts[nx_p0 + (nx_qxk & 255u)] : 0u;
     __syncthreads();
     MVGX_GSTAMP(0);
     // ---- 2. per point: the 15 sums over its observations, in observation order ----
@@ -1251,6 +1267,10 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     }
     __syncthreads();
     MVGX_GSTAMP(1);
+    if (g + 1 < g1 && (uint32_t)tid < nx_ne) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { nx_px[k] = d.pts[(size_t)nx_ix * 3 + k]; if (MODE == kGroupForward) nx_spo[k] = d.scale_pt[(size_t)nx_ix * 3 + k]; }
+    }
     // ---- 3. per point: norms / gradient out; LM diagonal, V = L L^T, L^-1, h ----
     if ((uint32_t)tid < np) {
       const uint32_t p = my_pt;
@@ -1343,31 +1363,61 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       }
     }
     __syncthreads();
-    constexpr int kSlotItems = kGroupPts * kGroupIntr * 8;
-    constexpr int kSlotRounds = (kSlotItems + NT - 1) / NT;
-    double zs[kSlotRounds][3];
+    // one item per (point, column): the entries of the point are at most kGroupCams, ordered by local intrinsic (host) - the first
+    // pks - pe of them belong to intrinsic 0; all 3 x kGroupCams terms are fetched before the first sum (the two ranges used to be two
+    // rounds of a loop with one dependent trip to LDS per entry), each range summed in entry order as before
+    static_assert(kGroupPts * 8 <= kGroupThreads, "one slot item per thread");
+    double zs[kGroupIntr][3];
 #pragma unroll
-    for (int rd = 0; rd < kSlotRounds; ++rd) {
-      const int it = tid + rd * NT;
-      zs[rd][0] = zs[rd][1] = zs[rd][2] = 0.0;
-      if (it < (int)np * kGroupIntr * 8) {
-        const int pq = it / (kGroupIntr * 8), rem = it - pq * (kGroupIntr * 8), k = rem >> 3, c = rem & 7;
-        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-        // the observations of a point are ordered by local intrinsic (host): those of intrinsic k are one contiguous range
-        const uint32_t elo = k == 0 ? pe[pq] : pks[pq], ehi = k == 0 ? pks[pq] : pe[pq + 1];
-        for (uint32_t e = elo; e < ehi; ++e) { y0 += M[c * NS + e]; y1 += M[(8 + c) * NS + e]; y2 += M[(16 + c) * NS + e]; }
+    for (int k = 0; k < kGroupIntr; ++k) zs[k][0] = zs[k][1] = zs[k][2] = 0.0;
+    {
+      const int pq = tid >> 3, c = tid & 7;
+      if (pq < (int)np) {
+        const uint32_t elo = pe[pq], ehi = pe[pq + 1], esp = pks[pq];
+        double y[kGroupIntr][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          double t0[kGroupCams / 2], t1[kGroupCams / 2], t2[kGroupCams / 2];
+#pragma unroll
+          for (int j = 0; j < kGroupCams / 2; ++j) {
+            const uint32_t e = min(elo + (uint32_t)(half * (kGroupCams / 2) + j), ehi - 1);
+            t0[j] = M[c * NS + e]; t1[j] = M[(8 + c) * NS + e]; t2[j] = M[(16 + c) * NS + e];
+          }
+#pragma unroll
+          for (int j = 0; j < kGroupCams / 2; ++j) {
+            const uint32_t e = elo + (uint32_t)(half * (kGroupCams / 2) + j);
+            const bool in0 = e < esp, in1 = e >= esp && e < ehi;
+            y[0][0] += in0 ? t0[j] : 0.0; y[0][1] += in0 ? t1[j] : 0.0; y[0][2] += in0 ? t2[j] : 0.0;
+            y[1][0] += in1 ? t0[j] : 0.0; y[1][1] += in1 ? t1[j] : 0.0; y[1][2] += in1 ? t2[j] : 0.0;
+          }
+        }
         const double* __restrict__ pt = ptab + pq * 12;
-        zs[rd][0] = pt[0] * y0;
-        zs[rd][1] = pt[1] * y0 + pt[2] * y1;
-        zs[rd][2] = pt[3] * y0 + pt[4] * y1 + pt[5] * y2;
+#pragma unroll
+        for (int k = 0; k < kGroupIntr; ++k) {
+          zs[k][0] = pt[0] * y[k][0];
+          zs[k][1] = pt[1] * y[k][0] + pt[2] * y[k][1];
+          zs[k][2] = pt[3] * y[k][0] + pt[4] * y[k][1] + pt[5] * y[k][2];
+        }
       }
     }
     const double* __restrict__ ptq = ptab + q * 12;   // L_q^-1 of this thread's point
     __syncthreads();   // the per-observation terms in M have been read
     MVGX_GSTAMP(3);
     // ---- 5. the staged matrix: rows 3 q .. 3 q + 2, columns 6 x .. (poses), 60 + 8 k .. (intrinsics), kGroupHCol (h) ----
-    for (int i = tid; i < kGroupM / 2; i += NT) reinterpret_cast<double2*>(M)[i] = make_double2(0.0, 0.0);
-    __syncthreads();
+    // A group whose every point is observed by every local pose of the supergroup in use (points grouped by identical pose sets: the
+    // common case) writes every cell of the columns that count - pose columns by the observation threads, intrinsic columns and h by
+    // the point items - so only the padding rows behind the last point need zeros; the columns of local poses without observations
+    // keep whatever the region held: an element of Z^T Z depends on its own two columns only, and the blocks of those poses have
+    // no destination (kNoChunk). Any other group clears the region first.
+    const int rows = ((int)(3 * np + 3)) & ~3;
+    const bool dense = ne == np * (uint32_t)*ncam_used;   // (a point sees a pose at most once: groups hold no repeated pose)
+    if (!dense) {
+      for (int i = tid; i < kGroupM / 2; i += NT) reinterpret_cast<double2*>(M)[i] = make_double2(0.0, 0.0);
+      __syncthreads();
+    } else {
+      const int npad = rows - 3 * (int)np;   // 0..3 rows
+      for (int i = tid; i < kGroupCols * npad; i += NT) M[(i / npad) * kGroupRS + 3 * (int)np + (i - (i / npad) * npad)] = 0.0;
+    }
     if (has) {
       double* __restrict__ dst = M + (6 * x) * kGroupRS + 3 * q;
 #pragma unroll
@@ -1378,13 +1428,12 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         dst[c * kGroupRS + 2] = ptq[3] * y0 + ptq[4] * y1 + ptq[5] * y2;
       }
     }
+    if ((tid >> 3) < (int)np) {
+      const int pq = tid >> 3, c = tid & 7;
 #pragma unroll
-    for (int rd = 0; rd < kSlotRounds; ++rd) {
-      const int it = tid + rd * NT;
-      if (it < (int)np * kGroupIntr * 8) {
-        const int pq = it / (kGroupIntr * 8), rem = it - pq * (kGroupIntr * 8);   // rem = 8 k + c: the column behind the pose columns
-        double* __restrict__ dst = M + (6 * kGroupCams + rem) * kGroupRS + 3 * pq;
-        dst[0] = zs[rd][0]; dst[1] = zs[rd][1]; dst[2] = zs[rd][2];
+      for (int k = 0; k < kGroupIntr; ++k) {   // column 8 k + c behind the pose columns
+        double* __restrict__ dst = M + (6 * kGroupCams + 8 * k + c) * kGroupRS + 3 * pq;
+        dst[0] = zs[k][0]; dst[1] = zs[k][1]; dst[2] = zs[k][2];
       }
     }
     if ((uint32_t)tid < np) {
@@ -1394,7 +1443,6 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     __syncthreads();
     MVGX_GSTAMP(5);
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
-    const int rows = ((int)(3 * np + 3)) & ~3;
 #pragma unroll
     for (int j = 0; j < kGroupTilesPerWave; ++j) {
       if (wave + j * kGroupWaves < kGroupTiles) {   // wave-uniform
