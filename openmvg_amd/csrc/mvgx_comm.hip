@@ -4,6 +4,8 @@
 // RCCL is bound at run time (dlopen) so that single-GPU users need no librccl.
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include <cstring>
 
 #include "mvgx_comm.h"
@@ -62,7 +64,8 @@ const char* nccl_err(Api* a, int rc) { return a->error_string ? a->error_string(
 }  // namespace
 
 struct RcclComm {
-  Comm comm = nullptr;
+  Comm comm = nullptr;               // set once by rccl_init, released by rccl_destroy only (after the shard threads have joined)
+  std::atomic<bool> aborted{false};  // rccl_abort ran: all-reduce refuses; the communicator object itself stays until destroy
   int world = 1, rank = 0;
 };
 
@@ -97,26 +100,28 @@ int rccl_init(RcclComm** out, int world, int rank, const void* unique_id) {
 void rccl_destroy(RcclComm* c) {
   if (!c) return;
   Api* a = api();
-  if (a && c->comm) a->comm_destroy(c->comm);
+  // (an aborted communicator was released by ncclCommAbort: ncclCommDestroy on it would be a second release)
+  if (a && c->comm && !c->aborted.load()) a->comm_destroy(c->comm);
   delete c;
 }
 
 // A rank of the same process failed outside a collective: the others may be blocked inside ncclAllReduce (or in the stream
 // synchronisation behind it) waiting for a contribution that will never come. ncclCommAbort may be called from another thread
-// while the communicator is in use: it fails the operations in flight and releases the communicator; the object stays (comm =
-// null) so that later calls report an error instead of touching freed state.
+// while the communicator is in use: it fails the operations in flight. The handle is NOT cleared here (a shard thread
+// could load it just before the abort and call ncclAllReduce on freed state, and the plain pointer was a data race): `aborted` is
+// an atomic flag, set first and exactly once; all-reduce checks it before every call, and the RcclComm object lives until
+// rccl_destroy, which the owner calls after the shard threads have joined.
 void rccl_abort(RcclComm* c) {
   if (!c || !c->comm) return;
+  if (c->aborted.exchange(true)) return;
   Api* a = api();
-  Comm comm = c->comm;
-  c->comm = nullptr;
-  if (a && a->comm_abort) a->comm_abort(comm);
+  if (a && a->comm_abort) a->comm_abort(c->comm);
 }
 
 int rccl_allreduce_f64(RcclComm* c, double* device_buffer, uint64_t count, int op, hipStream_t stream) {
   Api* a = api();
   if (!a) return MVGX_ERR_HIP;
-  MVGX_REQUIRE(c && c->comm, MVGX_ERR_STATE, "all-reduce on an aborted RCCL communicator (another device shard failed): destroy the context");
+  MVGX_REQUIRE(c && c->comm && !c->aborted.load(), MVGX_ERR_STATE, "all-reduce on an aborted RCCL communicator (another device shard failed): destroy the context");
   const int rc = a->all_reduce(device_buffer, device_buffer, count, kNcclFloat64, op == MVGX_REDUCE_MAX ? kNcclMax : kNcclSum,
                                c->comm, stream);
   MVGX_REQUIRE(rc == 0, MVGX_ERR_HIP, "ncclAllReduce(%llu doubles): %s", (unsigned long long)count, nccl_err(a, rc));

@@ -75,6 +75,14 @@ for mode in "$@"; do
       echo "tree $s $(python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
       echo "prev $s $(MVGX_LIB_PATH=$R/tools/_build/libmvgx_prev.so python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
     done; done ;;
+  descsweep)  # the filter kernel's fraction of the i8 peak by descriptors per image (the per-workgroup start and the per-image finish amortise)
+    for dsc in 1000 2000 4000 8000; do
+      n=$((2000000 / dsc)); [ $n -gt 1000 ] && n=1000
+      python bench.py --images $n --desc $dsc --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print(json.dumps({'images': $n, 'descriptors_per_image': $dsc, 'value': r['value'], 'frac': r['roofline']['frac'], 'mean_launch_ms': r['roofline']['mean_launch_ms'], 'ms_per_step': r['ms_per_step']}))" | tee -a "$O/match_frac_by_descriptors.jsonl"
+    done ;;
   env:*)      # env:NAME=VALUE applies to the modes that follow
     export "${mode#env:}" ;;
   run:*)      # run:<script under tools/ or repo-relative python file with args, '+' for spaces>
