@@ -28,6 +28,7 @@ extern "C" {
 #define MVGX_ERR_STATE 4    /* call order violated (e.g. run before set_regions)                 */
 #define MVGX_ERR_UNSUPPORTED 5 /* semantics the device path does not reproduce (ratio > 1, camera model) */
 #define MVGX_ERR_NUMERIC 6  /* BA: linear solve failed / non-finite cost                         */
+#define MVGX_ERR_STRUCTURE 7 /* mvgx_ba_update: the problem's structure is not the context's (the context is untouched) */
 
 const char* mvgx_last_error(void);
 int mvgx_device_count(int* count);
@@ -317,6 +318,25 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* problem, mvgx_ba_ctx** out
  * (parameters, residuals, track angles) come back in the caller's numbering. */
 int mvgx_ba_create_multi(const int* devices, int n_devices, const mvgx_ba_problem* problem, mvgx_ba_ctx** out);
 int mvgx_ba_destroy(mvgx_ba_ctx* ctx);
+/* Re-binds an existing context to a problem of the SAME structure and new values - what an SfM engine's consecutive Adjust() calls
+ * on one scene are when nothing was added or removed in between (global_SfM.cpp's three refinement passes with growing parameter
+ * sets; a caller's own re-runs; sequential_SfM.cpp:1190-1232 whenever the rejection step removed nothing): the host structure
+ * build, the device allocations and the symbolic phase of the reduced solve of mvgx_ba_create are kept, only values are uploaded.
+ *   structure (must be equal, compared through a 128-bit fingerprint taken at create): the counts, obs_pose / obs_intr / obs_point,
+ *     intr_model, points_constant, point_const_mask, obs_is_control, presence of obs_weight, prior_pose;
+ *   values (taken from `problem`): poses, intrinsics, points, obs_xy, obs_weight, prior_center / prior_weight, pose_const_mask,
+ *     intr_const_mask, huber_a, prior_huber_a.
+ * Returns MVGX_OK (the next mvgx_ba_solve starts from the new values with a fresh trust-region state; results are bit-identical
+ * to a context created from `problem`), or MVGX_ERR_STRUCTURE when the structure differs: the context is untouched and still
+ * solves its old problem; the caller destroys it and creates a new one. Works on single- and multi-device contexts. (ABI 9) */
+int mvgx_ba_update(mvgx_ba_ctx* ctx, const mvgx_ba_problem* problem);
+/* The library's persistent host workers (the ones the structure build of mvgx_ba_create runs on; started on first use, parked
+ * between jobs), lent to the host side of a caller - the replacement TU flattens SfM_Data with them instead of starting threads
+ * of its own per Adjust() call. fn(user, item, worker) runs once for every item in [0, n_items), items handed out one at a time in
+ * ascending order, worker < max(1, min(max_workers or 32, hardware threads)) identifies the executing thread (0 = the caller);
+ * returns when every item is done. Not re-entrant from inside fn. (ABI 9) */
+typedef void (*mvgx_host_item_fn)(void* user, uint64_t item, unsigned worker);
+int mvgx_host_parallel_for(uint64_t n_items, unsigned max_workers, mvgx_host_item_fn fn, void* user);
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------------------
  * Every rank creates its context from ITS shard of the problem: all poses and intrinsics (replicated, same
  * order on every rank) and a disjoint subset of the points together with ALL observations of those points

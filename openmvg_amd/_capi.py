@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVGX_LIB_PATH") or os.path.join(_HERE, "lib", "libmvgx_hip.so")   # (override: kernel-variant experiments)
 
 MVGX_OK = 0
-MVGX_ERR_ARG, MVGX_ERR_HIP, MVGX_ERR_NODEV, MVGX_ERR_STATE, MVGX_ERR_UNSUPPORTED, MVGX_ERR_NUMERIC = 1, 2, 3, 4, 5, 6
+MVGX_ERR_ARG, MVGX_ERR_HIP, MVGX_ERR_NODEV, MVGX_ERR_STATE, MVGX_ERR_UNSUPPORTED, MVGX_ERR_NUMERIC, MVGX_ERR_STRUCTURE = 1, 2, 3, 4, 5, 6, 7
 MVGX_BA_MAX_INTR_PARAMS = 8
 
 
@@ -123,6 +123,7 @@ class GeofilterStats(C.Structure):
 
 MATCH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
 MATCH_BATCH_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+HOST_ITEM_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint)
 ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
 MVGX_REDUCE_SUM, MVGX_REDUCE_MAX = 0, 1
 
@@ -174,6 +175,8 @@ PROTOTYPES = {
     "mvgx_ba_create": (C.c_int, [C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
     "mvgx_ba_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
     "mvgx_ba_destroy": (C.c_int, [C.c_void_p]),
+    "mvgx_ba_update": (C.c_int, [C.c_void_p, C.POINTER(BaProblem)]),
+    "mvgx_host_parallel_for": (C.c_int, [C.c_uint64, C.c_uint, HOST_ITEM_FN, C.c_void_p]),
     "mvgx_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_F64, C.c_void_p]),
     "mvgx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mvgx_ba_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -16,9 +16,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -125,6 +127,71 @@ class PosePriorFrame {
   geometry::Similarity3 to_centroid_;
 };
 
+// f(item, worker) for item in [0, n) on the library's host workers
+template <class F>
+void host_parallel(uint64_t n, F&& f) {
+  using Fn = typename std::remove_reference<F>::type;
+  if (n <= 1) { for (uint64_t i = 0; i < n; ++i) f(i, 0u); return; }
+  mvgx_host_parallel_for(n, 0, [](void* u, uint64_t i, unsigned w) { (*static_cast<Fn*>(u))(i, w); }, &f);
+}
+
+// The flattened scene of a call (see Adjust): one store per calling thread, capacity kept between calls.
+struct FlatScene {
+  std::vector<double> poses, intrinsics, points, obs_xy;
+  std::vector<int32_t> intr_model;
+  std::vector<uint8_t> pose_mask, intr_mask;
+  std::vector<uint32_t> obs_pose, obs_intr, obs_point;
+  std::vector<Landmark*> lm_of_point;
+};
+FlatScene& flat_scene() {
+  static thread_local FlatScene fs;
+  return fs;
+}
+
+// The context of the last Adjust() of this process, kept idle between calls. The engines construct a Bundle_Adjustment_Ceres on the
+// stack per call (sequential_SfM.cpp:1194-1210, global_SfM.cpp:379-446), so nothing of the object survives; what repeats is the
+// scene: global_SfM.cpp refines the same structure three times with growing parameter sets, sequential_SfM.cpp:1190-1232 calls
+// Adjust again whenever its rejection step removed nothing, and callers re-run BA after changing options. The next call offers
+// its arrays to the kept context (mvgx_ba_update): same structure -> only values are uploaded (the host structure build, the
+// device allocations and the symbolic phase of the reduced solve are skipped); another structure -> the context is destroyed and
+// a new one created, as before. A context taken out of the cache belongs to the calling thread; concurrent Adjust() calls simply
+// find the cache empty. MVGX_BA_CONTEXT_CACHE=0 turns this off (every call creates and destroys);
+// mvgx_adapter_ba_release_context() hands the idle context's device memory back at any time.
+struct ContextCache {
+  std::mutex mu;
+  mvgx_ba_ctx* idle = nullptr;
+  int device = 0;
+  std::atomic<uint64_t> created{0}, reused{0};
+};
+ContextCache& context_cache() {
+  static ContextCache* c = new ContextCache;   // never destroyed: the HIP runtime may be gone when static destructors run
+  return *c;
+}
+bool context_cache_enabled() {
+  const char* env = std::getenv("MVGX_BA_CONTEXT_CACHE");
+  return !(env && env[0] == '0');
+}
+mvgx_ba_ctx* take_idle_context(int device) {
+  ContextCache& c = context_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  mvgx_ba_ctx* ctx = c.idle;
+  c.idle = nullptr;
+  if (ctx && (c.device != device || !context_cache_enabled())) { mvgx_ba_destroy(ctx); ctx = nullptr; }
+  return ctx;
+}
+void keep_idle_context(mvgx_ba_ctx* ctx, int device) {
+  if (!context_cache_enabled()) { mvgx_ba_destroy(ctx); return; }
+  ContextCache& c = context_cache();
+  mvgx_ba_ctx* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    old = c.idle;
+    c.idle = ctx;
+    c.device = device;
+  }
+  if (old) mvgx_ba_destroy(old);
+}
+
 }  // namespace
 
 bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& options) {
@@ -141,12 +208,17 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   const bool b_usable_prior = priors.usable();
 
   // --- parameter blocks ---
+  // The flat arrays live in a per-thread store that keeps its memory between calls: 30 MB (200 views / 1 M observations) to
+  // 150 MB (1 000 / 5 M) of fresh pageable memory per call were a zero fill on this thread plus a page fault per 4 KB in the
+  // flatten threads - about a third of the 5 ms the walk took.
   std::unordered_map<IndexT, uint32_t> pose_idx, intr_idx;
   std::vector<IndexT> pose_ids, intr_ids;
-  std::vector<double> poses, intrinsics, points, obs_xy;
-  std::vector<int32_t> intr_model;
-  std::vector<uint8_t> pose_mask, intr_mask;
-  std::vector<uint32_t> obs_pose, obs_intr, obs_point;
+  FlatScene& fs = flat_scene();
+  std::vector<double>&poses = fs.poses, &intrinsics = fs.intrinsics, &points = fs.points, &obs_xy = fs.obs_xy;
+  std::vector<int32_t>& intr_model = fs.intr_model;
+  std::vector<uint8_t>&pose_mask = fs.pose_mask, &intr_mask = fs.intr_mask;
+  std::vector<uint32_t>&obs_pose = fs.obs_pose, &obs_intr = fs.obs_intr, &obs_point = fs.obs_point;
+  poses.clear(); intrinsics.clear(); intr_model.clear(); pose_mask.clear(); intr_mask.clear();
 
   uint8_t pmask = 0;
   if (options.extrinsics_opt == Extrinsic_Parameter_Type::NONE) pmask = 0x3F;
@@ -193,21 +265,14 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 
   tick("priors, cameras");
   // --- observations (landmark X is refined in place, as the reference hands X.data() to the solver) ---
-  // The containers are walked once on this thread (landmark pointers, observation counts, the (pose, intrinsic) index of every
-  // view); the per-observation rows are then written by the OpenMP threads, landmark by landmark, at offsets known in advance -
-  // same order as the serial walk. (One thread, three hash lookups and five push_backs per observation was 19 of the 35 ms of
-  // an Adjust() on 200 views / 1 M observations.)
-  std::vector<Landmark*> lm_of_point;
-  lm_of_point.reserve(sfm_data.structure.size());
-  std::vector<uint64_t> obs_begin;
-  obs_begin.reserve(sfm_data.structure.size() + 1);
-  uint64_t n_structure_obs64 = 0;
-  for (auto& lm : sfm_data.structure) {
-    lm_of_point.push_back(&lm.second);
-    obs_begin.push_back(n_structure_obs64);
-    n_structure_obs64 += lm.second.obs.size();
-  }
-  obs_begin.push_back(n_structure_obs64);
+  // Landmarks and Observations are std::unordered_map (types.hpp:67): walking one is a chain of dependent loads, one node per
+  // element - about a million nodes at 200 views. The walk therefore runs on the library's host workers (mvgx_host_parallel_for),
+  // split by BUCKET ranges of the landmark map: pass 1 counts the landmarks and observations of every range, a prefix sum fixes
+  // where each range writes, pass 2 fills the landmark pointers and the per-observation rows. Points are numbered in bucket
+  // order (a function of the container alone, like the reference's iteration order - which the reference itself calls
+  // unspecified); within a landmark the observations keep the order of its own map.
+  // (Round 3: pointers on one thread, rows on 16 threads started per call: 5.1 ms at 200 views / 1 M observations.)
+  Landmarks& structure = sfm_data.structure;
   struct ViewBlocks { uint32_t pose, intr; bool has_pose, has_intr; };
   std::unordered_map<IndexT, ViewBlocks> view_blocks;
   view_blocks.reserve(sfm_data.views.size());
@@ -218,39 +283,48 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
     view_blocks.emplace(v.first, ViewBlocks{pi == pose_idx.end() ? 0u : pi->second, ii == intr_idx.end() ? 0u : ii->second, pi != pose_idx.end(),
                                             ii != intr_idx.end()});
   }
+  tick("  view blocks");
+  const size_t n_buckets = structure.bucket_count();
+  const size_t n_ranges = structure.size() < 4096 ? 1 : std::min<size_t>(512, structure.size() / 512);   // (several per worker: the ranges are uneven)
+  std::vector<uint64_t> range_lm(n_ranges + 1, 0), range_obs(n_ranges + 1, 0);
+  auto bucket_lo = [&](size_t r) { return n_buckets * r / n_ranges; };
+  host_parallel(n_ranges, [&](uint64_t r, unsigned) {
+    uint64_t n_lm = 0, n_ob = 0;
+    for (size_t b = bucket_lo(r), be = bucket_lo(r + 1); b < be; ++b)
+      for (auto it = structure.begin(b), e = structure.end(b); it != e; ++it) { ++n_lm; n_ob += it->second.obs.size(); }
+    range_lm[r + 1] = n_lm; range_obs[r + 1] = n_ob;
+  });
+  for (size_t r = 0; r < n_ranges; ++r) { range_lm[r + 1] += range_lm[r]; range_obs[r + 1] += range_obs[r]; }
+  const uint64_t n_structure_obs64 = range_obs[n_ranges];
+  tick("  landmark / observation counts");
+  std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
+  lm_of_point.resize(range_lm[n_ranges]);
   points.resize(lm_of_point.size() * 3);
   obs_pose.resize(n_structure_obs64); obs_intr.resize(n_structure_obs64); obs_point.resize(n_structure_obs64);
   obs_xy.resize(2 * n_structure_obs64);
-  // (plain threads, not an OpenMP region: libgomp's workers keep spinning after a region and took the cores from the host workers
-  // of mvgx_ba_create that follows - 63 - 81 ms instead of 9)
   std::atomic<int> flatten_error{0};   // 1: an observation of a view without usable intrinsic, 2: of a view without pose / unknown view
-  auto flatten_range = [&](size_t j0, size_t j1) {
-  for (size_t j = j0; j < j1; ++j) {
-    const Landmark& lm = *lm_of_point[j];
-    points[3 * j] = lm.X(0); points[3 * j + 1] = lm.X(1); points[3 * j + 2] = lm.X(2);
-    uint64_t k = obs_begin[j];
-    for (const auto& ob : lm.obs) {
-      const auto vb = view_blocks.find(ob.first);
-      if (vb == view_blocks.end()) { flatten_error = 2; break; }                       // views.at(...) of the serial walk
-      if (!vb->second.has_intr) { int none = 0; flatten_error.compare_exchange_strong(none, 1); break; }   // its intrinsic test comes first
-      if (!vb->second.has_pose) { flatten_error = 2; break; }                          // pose_idx.at(...)
-      obs_pose[k] = vb->second.pose;
-      obs_intr[k] = vb->second.intr;
-      obs_point[k] = static_cast<uint32_t>(j);
-      obs_xy[2 * k] = ob.second.x(0);
-      obs_xy[2 * k + 1] = ob.second.x(1);
-      ++k;
-    }
-  }
-  };
-  {
-    const size_t n_lm = lm_of_point.size();
-    const unsigned T = n_structure_obs64 < 50000 ? 1u : std::max(1u, std::min({16u, std::thread::hardware_concurrency() / 2u, (unsigned)(n_structure_obs64 / 25000)}));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < T; ++t) pool.emplace_back(flatten_range, n_lm * t / T, n_lm * (t + 1) / T);
-    flatten_range(0, n_lm / T);
-    for (auto& th : pool) th.join();
-  }
+  host_parallel(n_ranges, [&](uint64_t r, unsigned) {
+    uint64_t j = range_lm[r], k = range_obs[r];
+    for (size_t b = bucket_lo(r), be = bucket_lo(r + 1); b < be; ++b)
+      for (auto it = structure.begin(b), e = structure.end(b); it != e; ++it, ++j) {
+        Landmark& lm = it->second;
+        lm_of_point[j] = &lm;
+        points[3 * j] = lm.X(0); points[3 * j + 1] = lm.X(1); points[3 * j + 2] = lm.X(2);
+        for (const auto& ob : lm.obs) {
+          const auto vb = view_blocks.find(ob.first);
+          if (vb == view_blocks.end()) { flatten_error = 2; return; }                       // views.at(...) of the serial walk
+          if (!vb->second.has_intr) { int none = 0; flatten_error.compare_exchange_strong(none, 1); return; }   // its intrinsic test comes first
+          if (!vb->second.has_pose) { flatten_error = 2; return; }                          // pose_idx.at(...)
+          obs_pose[k] = vb->second.pose;
+          obs_intr[k] = vb->second.intr;
+          obs_point[k] = static_cast<uint32_t>(j);
+          obs_xy[2 * k] = ob.second.x(0);
+          obs_xy[2 * k + 1] = ob.second.x(1);
+          ++k;
+        }
+      }
+  });
+  tick("  observation rows");
   if (flatten_error == 1) {
     OPENMVG_LOG_ERROR << "Cannot create a CostFunction for this camera model.";
     return false;
@@ -318,8 +392,25 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   tick("scene -> arrays");
   mvgx_ba_ctx* ctx = nullptr;
   const bool inj_create = mvgx_adapter::injected("ba", "create");
-  int rc = inj_create ? MVGX_ERR_NODEV : mvgx_ba_create(options_.device_, &prob, &ctx);
-  tick("mvgx_ba_create");
+  int rc = MVGX_ERR_NODEV;
+  if (!inj_create) {
+    ctx = take_idle_context(options_.device_);
+    if (ctx) {
+      rc = mvgx_ba_update(ctx, &prob);
+      if (rc == MVGX_OK) {
+        context_cache().reused.fetch_add(1);
+        tick("mvgx_ba_update (context kept)");
+      } else {   // another structure (MVGX_ERR_STRUCTURE), or a failure the create below will report
+        mvgx_ba_destroy(ctx);
+        ctx = nullptr;
+      }
+    }
+    if (!ctx) {
+      rc = mvgx_ba_create(options_.device_, &prob, &ctx);
+      if (rc == MVGX_OK) context_cache().created.fetch_add(1);
+      tick("mvgx_ba_create");
+    }
+  }
   if (rc == MVGX_ERR_UNSUPPORTED) {
     OPENMVG_LOG_ERROR << "Cannot create a CostFunction for this camera model. (" << mvgx_last_error() << ")";
     return false;
@@ -339,15 +430,19 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   // the solver state is written back to the landmarks in every case: the reference optimises X in place, so a failed
   // solve leaves moved points behind as well (sfm_data_BA_ceres.cpp:378, :503-507)
   const int rc_read = mvgx_ba_read_params(ctx, poses.data(), intrinsics.data(), points.data());
-  mvgx_ba_destroy(ctx);
-  tick("read_params, destroy");
+  if (rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)) keep_idle_context(ctx, options_.device_);   // (a context whose device calls failed is not kept)
+  else mvgx_ba_destroy(ctx);
+  tick("read_params, context kept / destroyed");
   if (rc_read != MVGX_OK) {
     OPENMVG_LOG_ERROR << "mvgx BA: " << mvgx_last_error();
     return false;
   }
-  if (!prob.points_constant)
-    for (size_t j = 0; j < lm_of_point.size(); ++j)
-      lm_of_point[j]->X = Vec3(points[3 * j], points[3 * j + 1], points[3 * j + 2]);
+  if (!prob.points_constant) {
+    const size_t n_lm = lm_of_point.size(), per = 4096;
+    host_parallel((n_lm + per - 1) / per, [&](uint64_t g, unsigned) {
+      for (size_t j = g * per, e = std::min(n_lm, (g + 1) * per); j < e; ++j) lm_of_point[j]->X = Vec3(points[3 * j], points[3 * j + 1], points[3 * j + 2]);
+    });
+  }
   if (rc != MVGX_OK) {
     OPENMVG_LOG_ERROR << "IsSolutionUsable is false. Bundle Adjustment failed. (" << mvgx_last_error() << ")";
     return false;
@@ -396,3 +491,15 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 
 }  // namespace sfm
 }  // namespace openMVG
+
+// diagnostic / test entries of an adapter library that holds this TU: {contexts created, contexts re-bound by mvgx_ba_update};
+// release: destroys the idle context (its device memory goes back to the library's slab cache)
+extern "C" void mvgx_adapter_ba_context_stats(uint64_t out[2], int reset) {
+  auto& c = openMVG::sfm::context_cache();
+  if (out) { out[0] = c.created.load(); out[1] = c.reused.load(); }
+  if (reset) { c.created = 0; c.reused = 0; }
+}
+extern "C" void mvgx_adapter_ba_release_context() {
+  mvgx_ba_ctx* ctx = openMVG::sfm::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context is destroyed)
+  (void)ctx;
+}

@@ -57,11 +57,22 @@ class BaContext:
                  devices=None):
         """device: one ordinal (-1: MVGX_DEVICES or the current device). devices: list of ordinals -> one context over several
         devices of this process (mvgx_ba_create_multi: the problem is sharded inside the library)."""
-        self._keep = {}
+        p = self._problem(scene, pose_const_mask, intr_const_mask, points_constant, huber_a)
+        self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
+        self._h = C.c_void_p()
+        if devices is not None:
+            arr_d = (C.c_int * len(devices))(*[int(x) for x in devices])
+            _capi.check(_capi.lib().mvgx_ba_create_multi(arr_d, len(devices), C.byref(p), C.byref(self._h)))
+        else:
+            _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
+
+    def _problem(self, scene, pose_const_mask, intr_const_mask, points_constant, huber_a):
+        """mvgx_ba_problem over the scene's arrays (kept alive in self._keep until the next create / update)"""
+        keep = {}
 
         def arr(name, dtype):
             a = np.ascontiguousarray(scene[name], dtype=dtype)
-            self._keep[name] = a
+            keep[name] = a
             return a.ctypes.data
 
         p = _capi.BaProblem()
@@ -72,9 +83,9 @@ class BaContext:
         p.obs_pose = arr("obs_pose", np.uint32); p.obs_intr = arr("obs_intr", np.uint32); p.obs_point = arr("obs_point", np.uint32)
         p.obs_xy = arr("obs_xy", np.float64)
         if pose_const_mask is not None:
-            self._keep["pm"] = np.ascontiguousarray(pose_const_mask, np.uint8); p.pose_const_mask = self._keep["pm"].ctypes.data
+            keep["pm"] = np.ascontiguousarray(pose_const_mask, np.uint8); p.pose_const_mask = keep["pm"].ctypes.data
         if intr_const_mask is not None:
-            self._keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = self._keep["im"].ctypes.data
+            keep["im"] = np.ascontiguousarray(intr_const_mask, np.uint8); p.intr_const_mask = keep["im"].ctypes.data
         p.points_constant = 1 if points_constant else 0
         p.huber_a = float(huber_a)
         # optional: ground control points (weighted, loss-free residuals on constant points) and pose-centre priors
@@ -90,13 +101,21 @@ class BaContext:
             p.prior_center = arr("prior_center", np.float64)
             p.prior_weight = arr("prior_weight", np.float64)
             p.prior_huber_a = float(scene.get("prior_huber_a", 0.0))
-        self.shape = (p.n_poses, p.n_intrinsics, p.n_points)
-        self._h = C.c_void_p()
-        if devices is not None:
-            arr_d = (C.c_int * len(devices))(*[int(x) for x in devices])
-            _capi.check(_capi.lib().mvgx_ba_create_multi(arr_d, len(devices), C.byref(p), C.byref(self._h)))
-        else:
-            _capi.check(_capi.lib().mvgx_ba_create(int(device), C.byref(p), C.byref(self._h)))
+        self._keep = keep
+        return p
+
+    def update(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0):
+        """mvgx_ba_update: new values (parameters, image points, weights, prior targets, constant masks, loss scale) for the structure
+        this context was created from. Returns False - and leaves the context as it was - when the scene's structure differs
+        (MVGX_ERR_STRUCTURE): the caller closes this context and creates a new one."""
+        keep_before = self._keep
+        p = self._problem(scene, pose_const_mask, intr_const_mask, points_constant, huber_a)
+        rc = _capi.lib().mvgx_ba_update(self._h, C.byref(p))
+        if rc == _capi.MVGX_ERR_STRUCTURE:
+            self._keep = keep_before
+            return False
+        _capi.check(rc)
+        return True
 
     def comm_init(self, world, rank, unique_id):
         """Bind this rank's context to an RCCL communicator (unique_id: the 128 bytes of comm_unique_id() of rank 0)."""

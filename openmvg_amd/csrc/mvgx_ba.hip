@@ -2890,6 +2890,11 @@ struct mvgx_ba_ctx {
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
   bool diag_blocks_complete = false;   // every pose / intrinsic block has a diagonal destination block in the assemble lists
   std::vector<uint32_t> h_sg_order;   // (a member: the asynchronous upload may read it after mvgx_ba_create's locals are gone)
+  // what mvgx_ba_update needs to re-bind the context to new values of the same structure
+  mvgx::BaFingerprint fingerprint;            // of the problem the context was created from
+  std::vector<uint8_t> h_pose_used, h_intr_used;   // blocks that carry a residual (the camera masks are applied on top of these)
+  std::vector<uint32_t> h_perm;               // caller's observation index of point-order position k; empty: the caller's list was in point order
+  uint64_t n_gentries = 0;                    // entries of the point groups (their copy of the image points is re-gathered)
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
@@ -3593,7 +3598,82 @@ int fill_summary(mvgx_ba_ctx* c, mvgx_ba_summary* s) {
 
 }  // namespace
 
+namespace {
+// Which components of the camera blocks are free parameters (cam_active) and which count in the norms of the termination tests
+// (cam_counts: every component of a block that is in the program, sfm_data_BA_ceres.cpp:274-306, :321-344): from the caller's
+// constant masks and the blocks that carry a residual.
+void camera_component_flags(const mvgx_ba_problem* p, const std::vector<uint8_t>& pose_used, const std::vector<uint8_t>& intr_used,
+                            std::vector<uint8_t>& cam_active, std::vector<uint8_t>& cam_counts) {
+  const size_t N = 6 * (size_t)p->n_poses + 8 * (size_t)p->n_intrinsics;
+  cam_active.assign(N, 0); cam_counts.assign(N, 0);
+  for (uint32_t i = 0; i < p->n_poses; ++i) {
+    const uint8_t m = p->pose_const_mask ? p->pose_const_mask[i] : 0;
+    const bool in_program = pose_used[i] && ((m & 0x3F) != 0x3F);
+    for (int cpt = 0; cpt < 6; ++cpt) {
+      cam_active[6 * (size_t)i + cpt] = in_program && !((m >> cpt) & 1);
+      cam_counts[6 * (size_t)i + cpt] = in_program;
+    }
+  }
+  for (uint32_t k = 0; k < p->n_intrinsics; ++k) {
+    const int K = mvgx_ba::intr_param_count(p->intr_model[k]);
+    const uint8_t m = p->intr_const_mask ? p->intr_const_mask[k] : 0;
+    const uint8_t full = (uint8_t)((1u << K) - 1u);
+    const bool in_program = intr_used[k] && K > 0 && ((m & full) != full);
+    for (int cpt = 0; cpt < 8; ++cpt) {
+      cam_active[6 * (size_t)p->n_poses + 8 * (size_t)k + cpt] = in_program && cpt < K && !((m >> cpt) & 1);
+      cam_counts[6 * (size_t)p->n_poses + 8 * (size_t)k + cpt] = in_program && cpt < K;
+    }
+  }
+}
+}  // namespace
 namespace mvgx {
+// 128 bits over everything mvgx_ba_create turns into structure (lists, groups, product lists, the plan of the reduced solve):
+// counts, the three index lists of the observations, camera models, which points are free, which observations are control
+// points, whether weights exist, which poses carry priors. NOT in it (values, re-bound by mvgx_ba_update): parameters, image
+// points, weights' values, prior centres / weights, the constant masks of poses and intrinsics, the loss scales.
+// Two multiply-xorshift chains with different constants; the observation lists are hashed grain by grain on the host threads
+// and the grains' words chained in order.
+BaFingerprint ba_fingerprint(const mvgx_ba_problem* p) {
+  struct Chain {
+    uint64_t a, b;
+    void add(uint64_t v) {
+      a = (a ^ v) * 0x9E3779B97F4A7C15ull; a ^= a >> 32;
+      b = (b + v) * 0xC2B2AE3D27D4EB4Full; b ^= b >> 29;
+    }
+  };
+  Chain h{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+  h.add(p->n_poses); h.add(p->n_intrinsics); h.add(p->n_points); h.add(p->n_obs); h.add(p->n_pose_priors);
+  h.add((uint64_t)(p->points_constant != 0) | (uint64_t)(p->obs_weight != nullptr) << 1 | (uint64_t)(p->obs_is_control != nullptr) << 2 |
+        (uint64_t)(p->point_const_mask != nullptr) << 3);
+  for (uint32_t k = 0; k < p->n_intrinsics; ++k) h.add((uint64_t)(uint32_t)p->intr_model[k]);
+  for (uint32_t k = 0; k < p->n_pose_priors; ++k) h.add(p->prior_pose[k]);
+  constexpr uint64_t kGrain = 1u << 15;
+  {
+    const uint64_t n_grains = (p->n_obs + kGrain - 1) / kGrain;
+    std::vector<Chain> part((size_t)n_grains);
+    parallel_for_dynamic((size_t)n_grains, 1, host_threads(p->n_obs), [&](size_t g, unsigned) {
+      Chain c{0x452821E638D01377ull + g, 0xBE5466CF34E90C6Cull ^ g};
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(p->n_obs, (g + 1) * kGrain); k < e; ++k) {
+        c.add((uint64_t)p->obs_pose[k] << 32 | p->obs_point[k]);
+        c.add((uint64_t)p->obs_intr[k] << 1 | (uint64_t)(p->obs_is_control && p->obs_is_control[k]));
+      }
+      part[g] = c;
+    });
+    for (const Chain& c : part) { h.add(c.a); h.add(c.b); }
+  }
+  if (p->point_const_mask) {
+    const uint64_t n_grains = ((uint64_t)p->n_points + kGrain - 1) / kGrain;
+    std::vector<Chain> part((size_t)n_grains);
+    parallel_for_dynamic((size_t)n_grains, 1, host_threads(p->n_points), [&](size_t g, unsigned) {
+      Chain c{0xC0AC29B7C97C50DDull + g, 0x3F84D5B5B5470917ull ^ g};
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(p->n_points, (g + 1) * kGrain); k < e; ++k) c.add(p->point_const_mask[k] != 0);
+      part[g] = c;
+    });
+    for (const Chain& c : part) { h.add(c.a); h.add(c.b); }
+  }
+  return BaFingerprint{{h.a, h.b}};
+}
+
 // Argument checks of a problem description, shared by the single- and the multi-device entry points: bad input is MVGX_ERR_ARG /
 // MVGX_ERR_UNSUPPORTED here, not a fault inside a worker thread later.
 int ba_validate_problem(const mvgx_ba_problem* p) {
@@ -3703,7 +3783,8 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     mvgx_ba_ctx* c;
     ~Guard() { if (c) mvgx_ba_destroy(c); }
   } guard{c};
-  tick("validation");
+  c->fingerprint = mvgx::ba_fingerprint(p);
+  tick("validation, fingerprint");
   MVGX_HIP(hipGetDevice(&c->device));
   if ((rc = mvgx::acquire_stream(&c->stream))) return rc;
   tick("stream");
@@ -3809,6 +3890,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       }
     });
     opose = g_pose; ointr = g_intr; opt_ = g_pt; oxy = g_xy;
+    c->h_perm.assign(g_orig, g_orig + no);
     UPN(oorig, g_orig, no);
     UPN(opose, opose, no); UPN(ointr, ointr, no); UPN(opt, opt_, no); UPN(oxy, oxy, 2 * no);
   } else {
@@ -4232,25 +4314,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   }
   tick("pose-intr / intr-intr products");
   // active / counted camera components
-  std::vector<uint8_t> cam_active(d.N, 0), cam_counts(d.N, 0);
-  for (uint32_t i = 0; i < d.n_poses; ++i) {
-    const uint8_t m = p->pose_const_mask ? p->pose_const_mask[i] : 0;
-    const bool in_program = pose_used[i] && ((m & 0x3F) != 0x3F);
-    for (int cpt = 0; cpt < 6; ++cpt) {
-      cam_active[6 * i + cpt] = in_program && !((m >> cpt) & 1);
-      cam_counts[6 * i + cpt] = in_program;
-    }
-  }
-  for (uint32_t k = 0; k < d.n_intr; ++k) {
-    const int K = intr_param_count(p->intr_model[k]);
-    const uint8_t m = p->intr_const_mask ? p->intr_const_mask[k] : 0;
-    const uint8_t full = (uint8_t)((1u << K) - 1u);
-    const bool in_program = intr_used[k] && K > 0 && ((m & full) != full);
-    for (int cpt = 0; cpt < 8; ++cpt) {
-      cam_active[6 * d.n_poses + 8 * k + cpt] = in_program && cpt < K && !((m >> cpt) & 1);
-      cam_counts[6 * d.n_poses + 8 * k + cpt] = in_program && cpt < K;
-    }
-  }
+  std::vector<uint8_t> cam_active, cam_counts;
+  c->h_pose_used = pose_used; c->h_intr_used = intr_used;
+  camera_component_flags(p, pose_used, intr_used, cam_active, cam_counts);
   std::vector<double> h_pc(p->prior_center, p->prior_center + (size_t)d.n_priors * 3), h_pw(p->prior_weight, p->prior_weight + (size_t)d.n_priors * 3);
   tick("masks, parameter copies");
   UP(pt_start, pt_start); UP(ptk_start, ptk_start); UP(slot_intr, slot_intr); UP(slot_point, slot_point);
@@ -4317,6 +4383,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
       if ((rc = dev_upload_n(c->pool, &d.grp.eobs, g_eobs, n_gentries, c->stream))) return rc;
       // the image points of the entries: gathered on the device
       if ((rc = dev_alloc(c->pool, &d.grp.exy, n_gentries))) return rc;
+      c->n_gentries = n_gentries;
       if (n_gentries)
         hipLaunchKernelGGL(ba_gather_lists_kernel, dim3((unsigned)((n_gentries + 255) / 256)), dim3(256), 0, c->stream, d.grp.eobs, (uint32_t)n_gentries,
                            d.opt, d.oxy, static_cast<uint32_t*>(nullptr), d.grp.exy);
@@ -4401,6 +4468,94 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   mvgx::rccl_destroy(c->rccl);
   mvgx::release_stream(c->device, c->stream);   // (synchronised above)
   delete c;
+  return MVGX_OK;
+}
+
+// The host workers of the structure build, for the host side of a caller (include/mvgx.h).
+int mvgx_host_parallel_for(uint64_t n_items, unsigned max_workers, mvgx_host_item_fn fn, void* user) {
+  MVGX_REQUIRE(fn || !n_items, MVGX_ERR_ARG, "mvgx_host_parallel_for: NULL function");
+  unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  if (const char* env = getenv("MVGX_HOST_THREADS")) threads = (unsigned)std::min(64, std::max(1, atoi(env)));
+  if (max_workers) threads = std::min(threads, max_workers);
+  parallel_for_dynamic((size_t)n_items, 1, threads, [&](size_t i, unsigned tix) { fn(user, (uint64_t)i, tix); });
+  return MVGX_OK;
+}
+
+// New values for the structure the context was built from (include/mvgx.h). What mvgx_ba_create derives from VALUES is exactly
+// what is redone here: the three parameter arrays, the image points (and their two re-ordered copies: (pose, intrinsic) order for
+// the camera Gram kernel, entry order for the point groups), weights, prior targets, the camera component flags, the loss scales.
+// Everything else in the context is a function of the fingerprinted structure. The LM state is reset by mvgx_ba_solve's start().
+int mvgx_ba_update(mvgx_ba_ctx* c, const mvgx_ba_problem* p) {
+  MVGX_REQUIRE(c && p, MVGX_ERR_ARG, "mvgx_ba_update: NULL argument");
+  { const int vrc = mvgx::ba_validate_problem(p); if (vrc) return vrc; }
+  if (c->multi) return mvgx::ba_multi_update(c->multi, p);
+  if (!(mvgx::ba_fingerprint(p) == c->fingerprint)) {
+    set_error("mvgx_ba_update: the problem's structure is not the one this context was created from");
+    return MVGX_ERR_STRUCTURE;
+  }
+  MVGX_HIP(hipSetDevice(c->device));
+  Dev& d = c->d;
+  const uint64_t no = d.n_obs;
+  const unsigned T = host_threads(no);
+  mvgx::HostArena ha;   // page-locked sources of the copies; the stream is drained before it goes out of scope
+  int rc = MVGX_OK;
+  auto staged_copy = [&](auto* dev, const auto* src, size_t n) -> int {
+    using E = std::remove_cv_t<std::remove_reference_t<decltype(*src)>>;
+    if (!n) return MVGX_OK;
+    if (n * sizeof(E) < (1u << 20)) { MVGX_HIP(hipMemcpyAsync(dev, src, n * sizeof(E), hipMemcpyHostToDevice, c->stream)); return MVGX_OK; }
+    E* st = nullptr;
+    const int rc_ = ha.array(&st, n);
+    if (rc_) return rc_;
+    const size_t per = (1u << 20) / sizeof(E), n_chunks = (n + per - 1) / per;
+    parallel_for_dynamic(n_chunks, 1, T, [&](size_t ch, unsigned) { memcpy(st + ch * per, src + ch * per, std::min(per, n - ch * per) * sizeof(E)); });
+    MVGX_HIP(hipMemcpyAsync(dev, st, n * sizeof(E), hipMemcpyHostToDevice, c->stream));
+    return MVGX_OK;
+  };
+  if ((rc = staged_copy(d.poses, p->poses, (size_t)d.n_poses * 6)) || (rc = staged_copy(d.intr, p->intrinsics, (size_t)d.n_intr * 8)) ||
+      (rc = staged_copy(d.pts, p->points, (size_t)d.n_pts * 3)))
+    return rc;
+  if (c->h_perm.empty()) {
+    if ((rc = staged_copy(d.oxy, p->obs_xy, (size_t)(2 * no)))) return rc;
+    if (p->obs_weight && (rc = staged_copy(d.oweight, p->obs_weight, (size_t)no))) return rc;
+  } else {   // the caller's list is not in point order: through the permutation mvgx_ba_create found
+    double* g_xy = nullptr; double* g_w = nullptr;
+    if ((rc = ha.array(&g_xy, (size_t)(2 * no))) || (p->obs_weight && (rc = ha.array(&g_w, (size_t)no)))) return rc;
+    constexpr size_t kGrain = 16384;
+    parallel_for_dynamic((size_t)((no + kGrain - 1) / kGrain), 1, T, [&](size_t g, unsigned) {
+      for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
+        const uint64_t s_ = c->h_perm[k];
+        g_xy[2 * k] = p->obs_xy[2 * s_]; g_xy[2 * k + 1] = p->obs_xy[2 * s_ + 1];
+        if (g_w) g_w[k] = p->obs_weight[s_];
+      }
+    });
+    if (no) MVGX_HIP(hipMemcpyAsync(d.oxy, g_xy, (size_t)(2 * no) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (g_w && no) MVGX_HIP(hipMemcpyAsync(d.oweight, g_w, (size_t)no * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  if (d.n_priors) {
+    MVGX_HIP(hipMemcpyAsync(d.prior_center, p->prior_center, (size_t)d.n_priors * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    MVGX_HIP(hipMemcpyAsync(d.prior_weight, p->prior_weight, (size_t)d.n_priors * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  std::vector<uint8_t> cam_active, cam_counts;
+  camera_component_flags(p, c->h_pose_used, c->h_intr_used, cam_active, cam_counts);
+  if (d.N) {
+    MVGX_HIP(hipMemcpyAsync(d.cam_active, cam_active.data(), cam_active.size(), hipMemcpyHostToDevice, c->stream));
+    MVGX_HIP(hipMemcpyAsync(d.cam_counts, cam_counts.data(), cam_counts.size(), hipMemcpyHostToDevice, c->stream));
+  }
+  d.huber_a = p->huber_a;
+  d.prior_huber_a = p->prior_huber_a;
+  // the two re-ordered copies of the image points
+  if (no) hipLaunchKernelGGL(ba_gather_lists_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, c->stream, d.pi_obs, (uint32_t)no, d.opt, d.oxy,
+                             static_cast<uint32_t*>(nullptr), d.pi_xy);
+  if (c->n_gentries)
+    hipLaunchKernelGGL(ba_gather_lists_kernel, dim3((unsigned)((c->n_gentries + 255) / 256)), dim3(256), 0, c->stream, d.grp.eobs, (uint32_t)c->n_gentries,
+                       d.opt, d.oxy, static_cast<uint32_t*>(nullptr), d.grp.exy);
+  BA_LAUNCH_CHECK();
+  // as a new context starts: no scalars, no reduced solution, no failure word left from the previous solve
+  MVGX_HIP(hipMemsetAsync(d.scalars, 0, (kSCount + 1) * sizeof(double), c->stream));
+  MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
+  MVGX_HIP(hipStreamSynchronize(c->stream));
+  c->started = false; c->finished = false;
+  c->gmax_pending = false; c->gmax_resolved = false; c->fail_clear = false; c->fold_cand_now = false; c->candidate_cost_done = false;
   return MVGX_OK;
 }
 

@@ -196,6 +196,7 @@ struct BaMulti {
   std::vector<Shard> shard;
   uint32_t n_points = 0;
   uint64_t n_obs = 0;
+  BaFingerprint fingerprint;   // of the whole problem (mvgx_ba_update)
   bool use_rccl = false;
   bool comm_ready = false;   // the shards' communicators exist (RCCL transport): a failing shard aborts them
   std::mutex abort_mu;
@@ -268,6 +269,7 @@ int ba_multi_create(const int* devices, int n_devices, const mvgx_ba_problem* p,
   m->devices.assign(devices, devices + n_devices);
   m->n_points = p->n_points;
   m->n_obs = p->n_obs;
+  m->fingerprint = ba_fingerprint(p);
   m->shard.resize(m->n);
   m->child.assign(m->n, nullptr);
   // ---- shards ----
@@ -366,6 +368,34 @@ int ba_multi_create(const int* devices, int n_devices, const mvgx_ba_problem* p,
   guard.m = nullptr;
   *out = m;
   return MVGX_OK;
+}
+
+// mvgx_ba_update on a multi-device context: the same cut (it is a function of the fingerprinted structure), every shard's values
+// gathered again from the caller's arrays, every child re-bound by its own host thread.
+int ba_multi_update(BaMulti* m, const mvgx_ba_problem* p) {
+  if (!(ba_fingerprint(p) == m->fingerprint)) {
+    set_error("mvgx_ba_update: the problem's structure is not the one this context was created from");
+    return MVGX_ERR_STRUCTURE;
+  }
+  return on_all(m, [&](int r) -> int {
+    Shard& s = m->shard[r];
+    for (size_t j = 0; j < s.pt_global.size(); ++j) memcpy(&s.points[3 * j], p->points + 3 * (size_t)s.pt_global[j], 3 * sizeof(double));
+    for (size_t k = 0; k < s.obs_global.size(); ++k) {
+      s.obs_xy[2 * k] = p->obs_xy[2 * s.obs_global[k]];
+      s.obs_xy[2 * k + 1] = p->obs_xy[2 * s.obs_global[k] + 1];
+      if (p->obs_weight) s.obs_weight[k] = p->obs_weight[s.obs_global[k]];
+    }
+    mvgx_ba_problem sp = *p;
+    sp.n_points = (uint32_t)s.pt_global.size();
+    sp.n_obs = s.obs_global.size();
+    sp.points = s.points.data();
+    sp.obs_pose = s.obs_pose.data(); sp.obs_intr = s.obs_intr.data(); sp.obs_point = s.obs_point.data(); sp.obs_xy = s.obs_xy.data();
+    sp.obs_weight = p->obs_weight ? s.obs_weight.data() : nullptr;
+    sp.obs_is_control = p->obs_is_control ? s.obs_is_control.data() : nullptr;
+    sp.point_const_mask = p->point_const_mask ? s.point_const_mask.data() : nullptr;
+    if (r != 0) { sp.n_pose_priors = 0; sp.prior_pose = nullptr; sp.prior_center = nullptr; sp.prior_weight = nullptr; }
+    return mvgx_ba_update(m->child[r], &sp);
+  });
 }
 
 int ba_multi_n_shards(const BaMulti* m) { return m->n; }

@@ -65,3 +65,47 @@ def test_injected_device_failure_makes_adjust_return_false(monkeypatch, capfd):
     assert "Adjust() returns false" in capfd.readouterr().err
     rc, stats, *_ = _oracle.ref_ba_adjust(sc, 14, 6, 1, lib=_oracle.adapter_ba_emu())   # and the next call works
     assert stats[3] == 1.0
+
+
+def _stats(lib, reset=0):
+    import ctypes as C
+    out = (C.c_uint64 * 2)()
+    lib.mvgx_adapter_ba_context_stats(out, C.c_int(reset))
+    return int(out[0]), int(out[1])
+
+
+def test_consecutive_adjust_calls_keep_the_context(monkeypatch):
+    """the replacement TU offers its arrays to the context the previous Adjust() left idle (mvgx_ba_update): the same scene again -
+    with the same or with other Optimize_Options, as global_SfM.cpp:379-446 does - re-binds it; another scene replaces it;
+    MVGX_BA_CONTEXT_CACHE=0 restores create / destroy per call. Results do not depend on which happened."""
+    lib = _oracle.adapter_ba_emu()
+    z = _golden()
+    keys = ("poses", "intrinsics", "intr_model", "points", "obs_pose", "obs_intr", "obs_point", "obs_xy")
+
+    def scene(tag):
+        sc = {k: z[f"{tag}/{k}"].copy() for k in keys}
+        sc["n_poses"] = len(sc["poses"]); sc["n_intrinsics"] = len(sc["intrinsics"]); sc["n_points"] = len(sc["points"]); sc["n_obs"] = len(sc["obs_pose"])
+        return sc
+    def same(x, y):   # (stats[2] is the wall time of the call)
+        return x[0] == y[0] and np.array_equal(np.delete(x[1], 2), np.delete(y[1], 2)) and all(np.array_equal(u, v) for u, v in zip(x[2:], y[2:]))
+    lib.mvgx_adapter_ba_release_context()
+    _stats(lib, reset=1)
+    a = scene("tiny_k3|14|6|1")
+    r1 = _oracle.ref_ba_adjust(a, 14, 6, 1, lib=lib)
+    assert _stats(lib) == (1, 0)
+    r2 = _oracle.ref_ba_adjust(a, 14, 6, 1, lib=lib)                  # same scene, same options
+    assert _stats(lib) == (1, 1)
+    assert r1[1][3] == r2[1][3] == 1.0 and same(r1, r2)
+    r3 = _oracle.ref_ba_adjust(a, 1, 4, 1, lib=lib)                   # same scene, translations + structure only
+    assert _stats(lib) == (1, 2)
+    b = scene("tiny_pinhole|14|6|1")
+    r4 = _oracle.ref_ba_adjust(b, 14, 6, 1, lib=lib)                  # another scene: a new context
+    assert _stats(lib) == (2, 2) and r4[1][3] == 1.0
+    monkeypatch.setenv("MVGX_BA_CONTEXT_CACHE", "0")
+    r5 = _oracle.ref_ba_adjust(a, 1, 4, 1, lib=lib)
+    r6 = _oracle.ref_ba_adjust(a, 14, 6, 1, lib=lib)
+    assert _stats(lib) == (4, 2)
+    assert same(r3, r5), "re-bound context and new context disagree (other options)"
+    assert same(r1, r6)
+    monkeypatch.delenv("MVGX_BA_CONTEXT_CACHE")
+    lib.mvgx_adapter_ba_release_context()

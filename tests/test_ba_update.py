@@ -1,0 +1,177 @@
+"""mvgx_ba_update (include/mvgx.h): a context re-bound to new VALUES of the structure it was created from must behave exactly like a
+context created from those values - same grouping, same summation order, hence bit-identical results - and must refuse a problem
+of another structure without being disturbed. Call pattern in the reference: consecutive Bundle_Adjustment::Adjust calls on one
+scene (global_SfM.cpp's refinement passes with growing parameter sets, sequential_SfM.cpp:1190-1232).
+CPU tests run the device code under the HIP emulation (tests/_emu.py); the `gpu` tests run the same checks on the MI355X."""
+import numpy as np
+import pytest
+
+from openmvg_amd import _capi, ba, synth
+from openmvg_amd import ba_options as bo
+from tests import _emu
+
+
+def _perturbed(sc, seed):
+    """same structure, other values: parameters, image points"""
+    rng = np.random.default_rng(seed)
+    out = dict(sc)
+    out["poses"] = sc["poses"] + rng.normal(0, 2e-3, sc["poses"].shape)
+    out["points"] = sc["points"] + rng.normal(0, 5e-3, sc["points"].shape)
+    out["intrinsics"] = sc["intrinsics"].copy()
+    out["intrinsics"][:, 0] *= 1.002
+    out["obs_xy"] = sc["obs_xy"] + rng.normal(0, 0.3, sc["obs_xy"].shape)
+    return out
+
+
+def _run(ctx):
+    s = ctx.solve()
+    return (s.num_iterations, s.num_successful_steps, s.termination, s.initial_cost, s.final_cost, s.final_rmse) + tuple(ctx.read_params())
+
+
+def _same(a, b):
+    return a[:6] == b[:6] and all(np.array_equal(x, y) for x, y in zip(a[6:], b[6:]))
+
+
+def _check_update_equals_create(sc, **ctx_args):
+    sc2 = _perturbed(sc, 7)
+    c = ba.BaContext(sc, **ctx_args)
+    first = _run(c)
+    assert c.update(sc2) is True
+    second = _run(c)
+    assert c.update(sc) is True          # and back: the first problem again, from the used context
+    third = _run(c)
+    c.close()
+    f = ba.BaContext(sc2, **ctx_args)
+    fresh = _run(f)
+    f.close()
+    assert _same(second, fresh), "updated context differs from a context created from the same values"
+    assert _same(third, first), "re-bound to the first values, the context does not repeat its first solve"
+    assert not _same(first, second)
+    return first, second
+
+
+def _check_masks_are_values(sc):
+    """the refinement passes of global_SfM.cpp:  translations + structure  ->  everything: same structure, other constant masks"""
+    m1 = bo.masks_for(sc, 1, 4, 1)    # intrinsics NONE (constant), ADJUST_TRANSLATION, structure ADJUST_ALL
+    m2 = bo.masks_for(sc, 14, 6, 1)   # ADJUST_ALL intrinsics (focal | pp | distortion), ADJUST_ALL extrinsics
+    c = ba.BaContext(sc, **m1)
+    r1 = _run(c)
+    assert c.update(sc, **m2) is True
+    r2 = _run(c)
+    c.close()
+    f = ba.BaContext(sc, **m2)
+    fresh = _run(f)
+    f.close()
+    assert _same(r2, fresh) and not _same(r1, r2)
+
+
+def _check_structure_change_is_refused(sc):
+    c = ba.BaContext(sc)
+    first = _run(c)
+    other = dict(sc)
+    other["obs_pose"] = sc["obs_pose"].copy()
+    k = int(np.flatnonzero(other["obs_pose"] != other["obs_pose"][0])[0])
+    other["obs_pose"][k] = other["obs_pose"][0]          # one observation moved to another pose
+    assert c.update(other) is False
+    assert b"structure" in _capi.lib().mvgx_last_error()
+    fewer = {k_: (v[:-1] if k_ in ("obs_pose", "obs_intr", "obs_point") else v[:-2] if k_ == "obs_xy" else v) for k_, v in sc.items()}
+    fewer["n_obs"] = int(sc["n_obs"]) - 1
+    assert c.update(fewer) is False
+    assert c.update(sc, points_constant=True) is False   # which points are free is structure
+    assert c.update(sc) is True                           # untouched by the refusals
+    assert _same(_run(c), first)
+    c.close()
+
+
+def _scene():
+    return synth.ba_scene(n_cams=9, n_points=140, track_len=5, model=3, n_intr_groups=2, seed=41, rot_deg=0.3)
+
+
+def test_update_equals_create_emulated():
+    with _emu.emulated():
+        _check_update_equals_create(_scene())
+
+
+def test_update_with_unsorted_observations_weights_and_priors_emulated():
+    """the caller's list not in point order (the permutation of create is reused), control points with weights, pose priors"""
+    sc = synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=1, n_intr_groups=1, seed=43, rot_deg=0.3)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(int(sc["n_obs"]))
+    for k in ("obs_pose", "obs_intr", "obs_point"):
+        sc[k] = np.ascontiguousarray(sc[k][perm])
+    sc["obs_xy"] = np.ascontiguousarray(sc["obs_xy"].reshape(-1, 2)[perm].reshape(-1))
+    n_obs, n_pts = int(sc["n_obs"]), int(sc["n_points"])
+    ctrl_pts = np.zeros(n_pts, np.uint8); ctrl_pts[:3] = 1
+    sc["point_const_mask"] = ctrl_pts
+    is_ctrl = ctrl_pts[sc["obs_point"]].astype(np.uint8)
+    sc["obs_is_control"] = is_ctrl
+    sc["obs_weight"] = np.where(is_ctrl, 20.0, 0.0)
+    sc["prior_pose"] = np.arange(5, dtype=np.uint32)
+    sc["prior_center"] = rng.normal(0, 1, 15)
+    sc["prior_weight"] = np.full(15, 0.5)
+    sc["prior_huber_a"] = 0.25
+    with _emu.emulated():
+        sc2 = _perturbed(sc, 9)
+        sc2["obs_weight"] = np.where(is_ctrl, 35.0, 0.0)
+        sc2["prior_center"] = sc["prior_center"] + 0.05
+        c = ba.BaContext(sc)
+        _run(c)
+        assert c.update(sc2) is True
+        second = _run(c)
+        c.close()
+        f = ba.BaContext(sc2)
+        fresh = _run(f)
+        f.close()
+        assert _same(second, fresh)
+
+
+def test_constant_masks_are_values_emulated():
+    with _emu.emulated():
+        _check_masks_are_values(_scene())
+
+
+def test_structure_change_is_refused_emulated():
+    with _emu.emulated():
+        _check_structure_change_is_refused(_scene())
+
+
+def test_update_of_a_two_shard_context_emulated(monkeypatch):
+    monkeypatch.setenv("MVGX_BA_MULTI_MIN_OBS", "1")
+    sc = _scene()
+    with _emu.emulated():
+        first, second = _check_update_equals_create(sc, devices=[0, 0])
+        one = ba.BaContext(_perturbed(sc, 7))
+        ref = _run(one)
+        one.close()
+    assert second[:3] == ref[:3] and abs(second[5] - ref[5]) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------- MI355X
+@pytest.mark.gpu
+def test_update_equals_create_on_the_device():
+    sc = synth.ba_scene(n_cams=60, n_points=20000, track_len=8, model=3, n_intr_groups=4, seed=51)
+    _check_update_equals_create(sc)
+    _check_masks_are_values(sc)
+    _check_structure_change_is_refused(sc)
+
+
+@pytest.mark.gpu
+def test_update_of_a_two_shard_context_on_the_device(monkeypatch):
+    monkeypatch.setenv("MVGX_BA_MULTI_MIN_OBS", "1")
+    monkeypatch.setenv("MVGX_BA_TRANSPORT", "peer")
+    sc = synth.ba_scene(n_cams=40, n_points=8000, track_len=6, model=3, n_intr_groups=2, seed=52)
+    _check_update_equals_create(sc, devices=[0, 0])
+
+
+@pytest.mark.gpu
+def test_update_is_cheaper_than_create_on_the_device():
+    import time
+    sc = synth.ba_scene(n_cams=200, n_points=100000, track_len=10, model=3, n_intr_groups=1, seed=53)
+    sc2 = _perturbed(sc, 3)
+    c = ba.BaContext(sc); c.solve(); c.close()      # warm: slab caches, host workers
+    t0 = time.perf_counter(); c = ba.BaContext(sc); t_create = time.perf_counter() - t0
+    c.solve()
+    t0 = time.perf_counter(); assert c.update(sc2); t_update = time.perf_counter() - t0
+    c.close()
+    print(f"create {t_create * 1e3:.2f} ms, update {t_update * 1e3:.2f} ms")
+    assert t_update < 0.5 * t_create

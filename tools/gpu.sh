@@ -20,7 +20,8 @@ for mode in "$@"; do
     timeout 1500 python -m pytest tests -m gpu -q -x > "$O/pytest_gpu_all.log" 2>&1; echo "pytest rc=$?"; tail -3 "$O/pytest_gpu_all.log"
     timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log" ;;
   tests:*)    # tests:<pytest args>, e.g. tests:tests/test_real_images.py
-    timeout 1500 python -m pytest ${mode#tests:} -m gpu -q > "$O/pytest_sel.log" 2>&1; echo "pytest rc=$?"; tail -5 "$O/pytest_sel.log" ;;
+    sel=${mode#tests:}; sel=${sel//+/ }   # ('+' separates several paths / arguments)
+    timeout 1500 python -m pytest $sel -m gpu -q -s > "$O/pytest_sel.log" 2>&1; echo "pytest rc=$?"; tail -8 "$O/pytest_sel.log" ;;
   bench)      # the driver's command
     (time timeout 1500 python bench.py) > "$O/bench.json" 2> "$O/bench.err"; tail -4 "$O/bench.err"
     python tools/bench_summary.py "$O/bench.json" ;;
