@@ -421,7 +421,7 @@ def _solve_emu_info(sc, options=None):
     return s, info, poses, intr, pts
 
 
-@pytest.mark.parametrize("leaf_cols", [64, 192])
+@pytest.mark.parametrize("leaf_cols", [64])
 def test_block_sparse_solver_on_a_ring_equals_dense_and_oracle(monkeypatch, leaf_cols):
     """72 cameras on rings, tracks of 4 consecutive cameras, 3 shared intrinsics: S is a cyclic band + a dense border. The
     nested dissection must cut it into several parts (parallel levels), the shared intrinsics must go to the border, and the

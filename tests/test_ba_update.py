@@ -84,7 +84,7 @@ def _check_structure_change_is_refused(sc):
 
 
 def _scene():
-    return synth.ba_scene(n_cams=9, n_points=140, track_len=5, model=3, n_intr_groups=2, seed=41, rot_deg=0.3)
+    return synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=3, n_intr_groups=2, seed=41, rot_deg=0.3)
 
 
 def test_update_equals_create_emulated():
