@@ -54,7 +54,7 @@ inline bool injected(const char* component, const char* stage) {
   return want == env;
 }
 
-enum Component { kMatch = 0, kCascade = 1, kGeofilter = 2, kBundle = 3 };
+enum Component { kMatch = 0, kCascade = 1, kGeofilter = 2, kBundle = 3, kFilters = 4 };
 
 // Logs once per process and component; throws when the caller asked for it. Returns normally otherwise: the caller continues on
 // the reference route (or returns false).
@@ -65,7 +65,7 @@ inline void device_failure(Component comp, const char* component, const char* st
                           (was_injected ? "injected by MVGX_ADAPTER_INJECT_FAILURE" : mvgx_last_error());
   const uint64_t bit = uint64_t(1) << comp;
   if (!(c.logged.fetch_or(bit) & bit))
-    OPENMVG_LOG_ERROR << msg << (throw_on_device_error() ? "" : comp == kBundle ? " - Adjust() returns false"
+    OPENMVG_LOG_ERROR << msg << (throw_on_device_error() ? "" : comp == kBundle ? " - Adjust() returns false" : comp == kFilters ? " - continuing with the reference's own CPU code"
                                                                                  : " - continuing with the reference's own CPU code for the remaining pairs");
   if (throw_on_device_error()) throw std::runtime_error(msg);
 }

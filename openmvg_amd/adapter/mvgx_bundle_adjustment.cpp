@@ -44,6 +44,7 @@
 #include "mvgx.h"
 #include "mvgx_adapter_policy.hpp"
 #include "mvgx_bundle_adjustment.hpp"
+#include "mvgx_scene_arrays.hpp"
 
 namespace openMVG {
 namespace sfm {
@@ -127,71 +128,6 @@ class PosePriorFrame {
   geometry::Similarity3 to_centroid_;
 };
 
-// f(item, worker) for item in [0, n) on the library's host workers
-template <class F>
-void host_parallel(uint64_t n, F&& f) {
-  using Fn = typename std::remove_reference<F>::type;
-  if (n <= 1) { for (uint64_t i = 0; i < n; ++i) f(i, 0u); return; }
-  mvgx_host_parallel_for(n, 0, [](void* u, uint64_t i, unsigned w) { (*static_cast<Fn*>(u))(i, w); }, &f);
-}
-
-// The flattened scene of a call (see Adjust): one store per calling thread, capacity kept between calls.
-struct FlatScene {
-  std::vector<double> poses, intrinsics, points, obs_xy;
-  std::vector<int32_t> intr_model;
-  std::vector<uint8_t> pose_mask, intr_mask;
-  std::vector<uint32_t> obs_pose, obs_intr, obs_point;
-  std::vector<Landmark*> lm_of_point;
-};
-FlatScene& flat_scene() {
-  static thread_local FlatScene fs;
-  return fs;
-}
-
-// The context of the last Adjust() of this process, kept idle between calls. The engines construct a Bundle_Adjustment_Ceres on the
-// stack per call (sequential_SfM.cpp:1194-1210, global_SfM.cpp:379-446), so nothing of the object survives; what repeats is the
-// scene: global_SfM.cpp refines the same structure three times with growing parameter sets, sequential_SfM.cpp:1190-1232 calls
-// Adjust again whenever its rejection step removed nothing, and callers re-run BA after changing options. The next call offers
-// its arrays to the kept context (mvgx_ba_update): same structure -> only values are uploaded (the host structure build, the
-// device allocations and the symbolic phase of the reduced solve are skipped); another structure -> the context is destroyed and
-// a new one created, as before. A context taken out of the cache belongs to the calling thread; concurrent Adjust() calls simply
-// find the cache empty. MVGX_BA_CONTEXT_CACHE=0 turns this off (every call creates and destroys);
-// mvgx_adapter_ba_release_context() hands the idle context's device memory back at any time.
-struct ContextCache {
-  std::mutex mu;
-  mvgx_ba_ctx* idle = nullptr;
-  int device = 0;
-  std::atomic<uint64_t> created{0}, reused{0};
-};
-ContextCache& context_cache() {
-  static ContextCache* c = new ContextCache;   // never destroyed: the HIP runtime may be gone when static destructors run
-  return *c;
-}
-bool context_cache_enabled() {
-  const char* env = std::getenv("MVGX_BA_CONTEXT_CACHE");
-  return !(env && env[0] == '0');
-}
-mvgx_ba_ctx* take_idle_context(int device) {
-  ContextCache& c = context_cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  mvgx_ba_ctx* ctx = c.idle;
-  c.idle = nullptr;
-  if (ctx && (c.device != device || !context_cache_enabled())) { mvgx_ba_destroy(ctx); ctx = nullptr; }
-  return ctx;
-}
-void keep_idle_context(mvgx_ba_ctx* ctx, int device) {
-  if (!context_cache_enabled()) { mvgx_ba_destroy(ctx); return; }
-  ContextCache& c = context_cache();
-  mvgx_ba_ctx* old = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(c.mu);
-    old = c.idle;
-    c.idle = ctx;
-    c.device = device;
-  }
-  if (old) mvgx_ba_destroy(old);
-}
-
 }  // namespace
 
 bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& options) {
@@ -213,7 +149,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   // flatten threads - about a third of the 5 ms the walk took.
   std::unordered_map<IndexT, uint32_t> pose_idx, intr_idx;
   std::vector<IndexT> pose_ids, intr_ids;
-  FlatScene& fs = flat_scene();
+  mvgx_adapter::FlatScene& fs = mvgx_adapter::flat_scene();
   std::vector<double>&poses = fs.poses, &intrinsics = fs.intrinsics, &points = fs.points, &obs_xy = fs.obs_xy;
   std::vector<int32_t>& intr_model = fs.intr_model;
   std::vector<uint8_t>&pose_mask = fs.pose_mask, &intr_mask = fs.intr_mask;
@@ -265,65 +201,10 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 
   tick("priors, cameras");
   // --- observations (landmark X is refined in place, as the reference hands X.data() to the solver) ---
-  // Landmarks and Observations are std::unordered_map (types.hpp:67): walking one is a chain of dependent loads, one node per
-  // element - about a million nodes at 200 views. The walk therefore runs on the library's host workers (mvgx_host_parallel_for),
-  // split by BUCKET ranges of the landmark map: pass 1 counts the landmarks and observations of every range, a prefix sum fixes
-  // where each range writes, pass 2 fills the landmark pointers and the per-observation rows. Points are numbered in bucket
-  // order (a function of the container alone, like the reference's iteration order - which the reference itself calls
-  // unspecified); within a landmark the observations keep the order of its own map.
-  // (Round 3: pointers on one thread, rows on 16 threads started per call: 5.1 ms at 200 views / 1 M observations.)
-  Landmarks& structure = sfm_data.structure;
-  struct ViewBlocks { uint32_t pose, intr; bool has_pose, has_intr; };
-  std::unordered_map<IndexT, ViewBlocks> view_blocks;
-  view_blocks.reserve(sfm_data.views.size());
-  for (const auto& v : sfm_data.views) {
-    const View* view = v.second.get();
-    const auto pi = pose_idx.find(view->id_pose);
-    const auto ii = intr_idx.find(view->id_intrinsic);
-    view_blocks.emplace(v.first, ViewBlocks{pi == pose_idx.end() ? 0u : pi->second, ii == intr_idx.end() ? 0u : ii->second, pi != pose_idx.end(),
-                                            ii != intr_idx.end()});
-  }
-  tick("  view blocks");
-  const size_t n_buckets = structure.bucket_count();
-  const size_t n_ranges = structure.size() < 4096 ? 1 : std::min<size_t>(512, structure.size() / 512);   // (several per worker: the ranges are uneven)
-  std::vector<uint64_t> range_lm(n_ranges + 1, 0), range_obs(n_ranges + 1, 0);
-  auto bucket_lo = [&](size_t r) { return n_buckets * r / n_ranges; };
-  host_parallel(n_ranges, [&](uint64_t r, unsigned) {
-    uint64_t n_lm = 0, n_ob = 0;
-    for (size_t b = bucket_lo(r), be = bucket_lo(r + 1); b < be; ++b)
-      for (auto it = structure.begin(b), e = structure.end(b); it != e; ++it) { ++n_lm; n_ob += it->second.obs.size(); }
-    range_lm[r + 1] = n_lm; range_obs[r + 1] = n_ob;
-  });
-  for (size_t r = 0; r < n_ranges; ++r) { range_lm[r + 1] += range_lm[r]; range_obs[r + 1] += range_obs[r]; }
-  const uint64_t n_structure_obs64 = range_obs[n_ranges];
-  tick("  landmark / observation counts");
+  // (the walk of the two unordered_maps on the library's host workers: mvgx_scene_arrays.hpp)
+  int flatten_error = 0;   // 1: an observation of a view without usable intrinsic, 2: of a view without pose / unknown view
+  const uint64_t n_structure_obs64 = mvgx_adapter::flatten_observations(sfm_data, pose_idx, intr_idx, fs, &flatten_error, tick);
   std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
-  lm_of_point.resize(range_lm[n_ranges]);
-  points.resize(lm_of_point.size() * 3);
-  obs_pose.resize(n_structure_obs64); obs_intr.resize(n_structure_obs64); obs_point.resize(n_structure_obs64);
-  obs_xy.resize(2 * n_structure_obs64);
-  std::atomic<int> flatten_error{0};   // 1: an observation of a view without usable intrinsic, 2: of a view without pose / unknown view
-  host_parallel(n_ranges, [&](uint64_t r, unsigned) {
-    uint64_t j = range_lm[r], k = range_obs[r];
-    for (size_t b = bucket_lo(r), be = bucket_lo(r + 1); b < be; ++b)
-      for (auto it = structure.begin(b), e = structure.end(b); it != e; ++it, ++j) {
-        Landmark& lm = it->second;
-        lm_of_point[j] = &lm;
-        points[3 * j] = lm.X(0); points[3 * j + 1] = lm.X(1); points[3 * j + 2] = lm.X(2);
-        for (const auto& ob : lm.obs) {
-          const auto vb = view_blocks.find(ob.first);
-          if (vb == view_blocks.end()) { flatten_error = 2; return; }                       // views.at(...) of the serial walk
-          if (!vb->second.has_intr) { int none = 0; flatten_error.compare_exchange_strong(none, 1); return; }   // its intrinsic test comes first
-          if (!vb->second.has_pose) { flatten_error = 2; return; }                          // pose_idx.at(...)
-          obs_pose[k] = vb->second.pose;
-          obs_intr[k] = vb->second.intr;
-          obs_point[k] = static_cast<uint32_t>(j);
-          obs_xy[2 * k] = ob.second.x(0);
-          obs_xy[2 * k + 1] = ob.second.x(1);
-          ++k;
-        }
-      }
-  });
   tick("  observation rows");
   if (flatten_error == 1) {
     OPENMVG_LOG_ERROR << "Cannot create a CostFunction for this camera model.";
@@ -394,11 +275,11 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   const bool inj_create = mvgx_adapter::injected("ba", "create");
   int rc = MVGX_ERR_NODEV;
   if (!inj_create) {
-    ctx = take_idle_context(options_.device_);
+    ctx = mvgx_adapter::take_idle_context(options_.device_);
     if (ctx) {
       rc = mvgx_ba_update(ctx, &prob);
       if (rc == MVGX_OK) {
-        context_cache().reused.fetch_add(1);
+        mvgx_adapter::context_cache().reused.fetch_add(1);
         tick("mvgx_ba_update (context kept)");
       } else {   // another structure (MVGX_ERR_STRUCTURE), or a failure the create below will report
         mvgx_ba_destroy(ctx);
@@ -407,7 +288,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
     }
     if (!ctx) {
       rc = mvgx_ba_create(options_.device_, &prob, &ctx);
-      if (rc == MVGX_OK) context_cache().created.fetch_add(1);
+      if (rc == MVGX_OK) mvgx_adapter::context_cache().created.fetch_add(1);
       tick("mvgx_ba_create");
     }
   }
@@ -430,7 +311,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   // the solver state is written back to the landmarks in every case: the reference optimises X in place, so a failed
   // solve leaves moved points behind as well (sfm_data_BA_ceres.cpp:378, :503-507)
   const int rc_read = mvgx_ba_read_params(ctx, poses.data(), intrinsics.data(), points.data());
-  if (rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)) keep_idle_context(ctx, options_.device_);   // (a context whose device calls failed is not kept)
+  if (rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)) mvgx_adapter::keep_idle_context(ctx, options_.device_);   // (a context whose device calls failed is not kept)
   else mvgx_ba_destroy(ctx);
   tick("read_params, context kept / destroyed");
   if (rc_read != MVGX_OK) {
@@ -439,7 +320,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   }
   if (!prob.points_constant) {
     const size_t n_lm = lm_of_point.size(), per = 4096;
-    host_parallel((n_lm + per - 1) / per, [&](uint64_t g, unsigned) {
+    mvgx_adapter::host_parallel((n_lm + per - 1) / per, [&](uint64_t g, unsigned) {
       for (size_t j = g * per, e = std::min(n_lm, (g + 1) * per); j < e; ++j) lm_of_point[j]->X = Vec3(points[3 * j], points[3 * j + 1], points[3 * j + 2]);
     });
   }
@@ -495,11 +376,11 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 // diagnostic / test entries of an adapter library that holds this TU: {contexts created, contexts re-bound by mvgx_ba_update};
 // release: destroys the idle context (its device memory goes back to the library's slab cache)
 extern "C" void mvgx_adapter_ba_context_stats(uint64_t out[2], int reset) {
-  auto& c = openMVG::sfm::context_cache();
+  auto& c = mvgx_adapter::context_cache();
   if (out) { out[0] = c.created.load(); out[1] = c.reused.load(); }
   if (reset) { c.created = 0; c.reused = 0; }
 }
 extern "C" void mvgx_adapter_ba_release_context() {
-  mvgx_ba_ctx* ctx = openMVG::sfm::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context is destroyed)
+  mvgx_ba_ctx* ctx = mvgx_adapter::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context is destroyed)
   (void)ctx;
 }

@@ -256,10 +256,11 @@ int ref_ba_prior_prepare(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, u
 // A negative threshold skips that filter. obs_keep[n_obs] = 1 for the observations that survive; counts[0..1] = the two
 // return values. max_angle (optional, n_points): the per-track maximum of the reference's own AngleBetweenRay over
 // get_ud_pixel'd observation pairs, evaluated BEFORE any filtering (the loop of :84-110 around the library calls).
-int ref_ba_filters(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
-                   const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
-                   const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, double px_threshold,
-                   uint32_t min_track_length, double min_angle_deg, uint8_t* obs_keep, uint64_t* counts, double* max_angle) {
+static int filters_impl(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                        const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                        const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, double px_threshold,
+                        uint32_t min_track_length, double min_angle_deg, uint8_t* obs_keep, uint64_t* counts, double* max_angle,
+                        double* seconds /* optional [2]: wall time inside the two library calls */) {
   SfM_Data scene;
   const int rc0 = build_scene(scene, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
                               obs_point, obs_xy, Extras());
@@ -284,13 +285,32 @@ int ref_ba_filters(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_
       max_angle[lm.first] = best;
     }
   }
+  const auto t0 = std::chrono::steady_clock::now();
   counts[0] = px_threshold >= 0 ? RemoveOutliers_PixelResidualError(scene, px_threshold, min_track_length) : 0;
+  const auto t1 = std::chrono::steady_clock::now();
   counts[1] = min_angle_deg >= 0 ? RemoveOutliers_AngleError(scene, min_angle_deg) : 0;
+  const auto t2 = std::chrono::steady_clock::now();
+  if (seconds) { seconds[0] = std::chrono::duration<double>(t1 - t0).count(); seconds[1] = std::chrono::duration<double>(t2 - t1).count(); }
   for (uint64_t k = 0; k < n_obs; ++k) {
     const auto lm = scene.structure.find(obs_point[k]);
     obs_keep[k] = (lm != scene.structure.end() && lm->second.obs.count(obs_pose[k])) ? 1 : 0;
   }
   return 0;
+}
+int ref_ba_filters(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                   const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                   const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, double px_threshold,
+                   uint32_t min_track_length, double min_angle_deg, uint8_t* obs_keep, uint64_t* counts, double* max_angle) {
+  return filters_impl(n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr, obs_point, obs_xy, px_threshold,
+                      min_track_length, min_angle_deg, obs_keep, counts, max_angle, nullptr);
+}
+// ... the same, also reporting the wall time spent inside RemoveOutliers_PixelResidualError and RemoveOutliers_AngleError
+int ref_ba_filters_timed(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
+                         const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,
+                         const uint32_t* obs_intr, const uint32_t* obs_point, const double* obs_xy, double px_threshold,
+                         uint32_t min_track_length, double min_angle_deg, uint8_t* obs_keep, uint64_t* counts, double* seconds) {
+  return filters_impl(n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr, obs_point, obs_xy, px_threshold,
+                      min_track_length, min_angle_deg, obs_keep, counts, nullptr, seconds);
 }
 
 // The reference's BAF export (sfm/sfm_data_io_baf.hpp:38-147) of the same flat scene: pins openmvg_amd.io.save_baf.

@@ -565,10 +565,12 @@ def port_ba_track_angles(scene):
     return out
 
 
-def ref_ba_filters(scene, px_threshold=4.0, min_track_length=2, min_angle_deg=2.0, lib_path=None):
+def ref_ba_filters(scene, px_threshold=4.0, min_track_length=2, min_angle_deg=2.0, lib_path=None, lib=None):
     """The reference's RemoveOutliers_PixelResidualError + RemoveOutliers_AngleError (sfm/sfm_data_filters.cpp) on the flat
-    scene (oracle/ref_shim_ba.cpp::ref_ba_filters). -> (obs_keep bool[n_obs], (n_residual, n_angle), max_angle[n_points])"""
-    L = C.CDLL(lib_path or REF_BA_SO)
+    scene (oracle/ref_shim_ba.cpp::ref_ba_filters). -> (obs_keep bool[n_obs], (n_residual, n_angle), max_angle[n_points]).
+    lib: a loaded adapter library (adapter() / adapter_ba_emu()): the same caller code over the replacement TU
+    openmvg_amd/adapter/mvgx_outlier_filters.cpp."""
+    L = lib if lib is not None else C.CDLL(lib_path or REF_BA_SO)
     L.ref_ba_filters.restype = C.c_int
     L.ref_ba_filters.argtypes = ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 +
                                  [C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])
@@ -579,6 +581,21 @@ def ref_ba_filters(scene, px_threshold=4.0, min_track_length=2, min_angle_deg=2.
                           int(min_track_length), float(min_angle_deg), keep.ctypes.data, counts.ctypes.data, ang.ctypes.data)
     assert rc == 0, rc
     return keep.astype(bool), (int(counts[0]), int(counts[1])), ang
+
+
+def ref_ba_filters_timed(scene, px_threshold=4.0, min_track_length=2, min_angle_deg=2.0, lib=None):
+    """ref_ba_filters + the wall time inside the two filter calls -> (obs_keep, (n_residual, n_angle), (s_residual, s_angle))"""
+    L = lib if lib is not None else C.CDLL(REF_BA_SO)
+    fn = L.ref_ba_filters_timed
+    fn.restype = C.c_int
+    fn.argtypes = ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 + [C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p])
+    poses, intr, model, pts, op, oi, ox, xy = _flat(scene)
+    keep = np.zeros(len(op), np.uint8); counts = np.zeros(2, np.uint64); sec = np.zeros(2)
+    rc = fn(len(poses), len(intr), len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data,
+            oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, float(px_threshold), int(min_track_length), float(min_angle_deg), keep.ctypes.data,
+            counts.ctypes.data, sec.ctypes.data)
+    assert rc == 0, rc
+    return keep.astype(bool), (int(counts[0]), int(counts[1])), (float(sec[0]), float(sec[1]))
 
 
 def ref_save_baf(scene, path):
@@ -671,8 +688,10 @@ def adapter():
                      "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_hash_u8",
                      "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
-        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare"):
+        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "mvgx_adapter_ba_context_stats",
+                     "mvgx_adapter_ba_release_context"):
             setattr(both, name, getattr(b, name))
+        both.ba_counters = b.mvgx_adapter_counters   # (the counters of the BA half)
         _adapter = both
     return _adapter
 

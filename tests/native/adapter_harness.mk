@@ -30,6 +30,10 @@ REF_BA_OBJS := $(REFOBJ)/ba/openMVG/numeric/numeric.o $(REFOBJ)/ba/openMVG/sfm/s
             $(REFOBJ)/third_party/stlplus3/filesystemSimplified/file_system.o \
             $(REFOBJ)/third_party/stlplus3/filesystemSimplified/portability_fixes.o \
             $(REFOBJ)/third_party/stlplus3/filesystemSimplified/wildcard.o
+# the BA adapter libraries: sfm_data_filters.cpp compiled as INTEGRATION.md prescribes (its two outlier filters renamed to *_cpu: the
+# replacement TU mvgx_outlier_filters.cpp defines the original names and falls back to these)
+ADAPTER_BA_REF_OBJS := $(filter-out $(REFOBJ)/ba/openMVG/sfm/sfm_data_filters.o,$(REF_BA_OBJS)) $(OUT)/sfm_data_filters_cpu.o
+ADAPTER_BA_OBJS := $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(AOBJ)/mvgx_outlier_filters.o
 RPATH := -Wl,-rpath,'$$ORIGIN/../../../openmvg_amd/lib'
 
 all: $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so $(OUT)/libmvgx_openmvg_adapter_geo.so
@@ -60,11 +64,15 @@ $(OUT)/ref_shim_ba.o: $(ROOT)/oracle/ref_shim_ba.cpp
 	@mkdir -p $(OUT)
 	$(CXX) $(BASEFLAGS) -c $< -o $@
 
+$(OUT)/sfm_data_filters_cpu.o: $(REF)/openMVG/sfm/sfm_data_filters.cpp
+	@mkdir -p $(OUT)
+	$(CXX) $(BASEFLAGS) -DRemoveOutliers_PixelResidualError=RemoveOutliers_PixelResidualError_cpu -DRemoveOutliers_AngleError=RemoveOutliers_AngleError_cpu -c $< -o $@
+
 $(OUT)/libmvgx_openmvg_adapter.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
 	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
 
-$(OUT)/libmvgx_openmvg_adapter_ba.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
-	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
+$(OUT)/libmvgx_openmvg_adapter_ba.so: $(OUT)/ref_shim_ba.o $(ADAPTER_BA_OBJS) $(ADAPTER_BA_REF_OBJS) $(LIBDIR)/libmvgx_hip.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic $(RPATH) -o $@ $(OUT)/ref_shim_ba.o $(ADAPTER_BA_OBJS) $(ADAPTER_BA_REF_OBJS) -L$(LIBDIR) -lmvgx_hip -lpthread
 
 # The matcher half once more, linked against the two emulation libraries instead of libmvgx_hip.so: the C++ routing code of the
 # adapter (region-type dispatch, batching, delivery threads) runs on the CPU test box (tests/test_adapter_emu_cpu.py).
@@ -72,8 +80,8 @@ emu: $(OUT)/libmvgx_openmvg_adapter_emu.so
 $(OUT)/libmvgx_openmvg_adapter_emu.so: $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) $(OUT)/libmvgx_ba_emu.so $(OUT)/libmvgx_match_emu.so $(lastword $(MAKEFILE_LIST))
 	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_match.o $(AOBJ)/mvgx_matcher_regions.o $(AOBJ)/mvgx_cascade_hashing_matcher_regions.o $(REF_MATCH_OBJS) -L$(OUT) -lmvgx_match_emu -lmvgx_ba_emu -lpthread
 
-$(OUT)/libmvgx_openmvg_adapter_ba_emu.so: $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) $(OUT)/libmvgx_ba_emu.so $(lastword $(MAKEFILE_LIST))
-	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_ba.o $(AOBJ)/mvgx_bundle_adjustment.o $(AOBJ)/mvgx_bundle_adjustment_ceres.o $(REF_BA_OBJS) -L$(OUT) -lmvgx_ba_emu -lpthread
+$(OUT)/libmvgx_openmvg_adapter_ba_emu.so: $(OUT)/ref_shim_ba.o $(ADAPTER_BA_OBJS) $(ADAPTER_BA_REF_OBJS) $(OUT)/libmvgx_ba_emu.so $(lastword $(MAKEFILE_LIST))
+	$(CXX) -shared -fopenmp -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN' -o $@ $(OUT)/ref_shim_ba.o $(ADAPTER_BA_OBJS) $(ADAPTER_BA_REF_OBJS) -L$(OUT) -lmvgx_ba_emu -lpthread
 emu: $(OUT)/libmvgx_openmvg_adapter_ba_emu.so
 
 clean:

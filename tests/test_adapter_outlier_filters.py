@@ -1,0 +1,120 @@
+"""The replacement of RemoveOutliers_PixelResidualError / RemoveOutliers_AngleError (openmvg_amd/adapter/mvgx_outlier_filters.cpp:
+residual norms and track angles on the device, the reference's expressions for values at the threshold, the reference's erasure and
+return values) against the reference TU, through the same caller code (oracle/ref_shim_ba.cpp::ref_ba_filters).
+CPU: the adapter library linked against the HIP emulation; `gpu`: against libmvgx_hip.so on the MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openmvg_amd import synth
+from tests import _oracle
+
+needs_ref = pytest.mark.skipif(not _oracle.have_ref_ba(), reason="oracle/_ref/libref_ba.so not built")
+
+
+def _counters(fn):
+    out = (C.c_uint64 * 3)()
+    fn(out, C.c_int(1))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def _scene(n_cams, n_points, seed, **kw):
+    sc = synth.ba_scene(n_cams=n_cams, n_points=n_points, track_len=5, model=3, n_intr_groups=2, seed=seed, outlier_frac=0.06, n_rings=1, **kw)
+    # a few tracks with a tiny baseline: two observations from the same pose ring neighbour -> small ray angle
+    return sc
+
+
+def _check(lib, counters, sc, thresholds):
+    for px, min_len, ang in thresholds:
+        keep_r, counts_r, _ = _oracle.ref_ba_filters(sc, px, min_len, ang)
+        _counters(counters)
+        keep_o, counts_o, _ = _oracle.ref_ba_filters(sc, px, min_len, ang, lib=lib)
+        dev, fb, fail = _counters(counters)
+        assert fail == 0 and fb == 0 and dev == (px >= 0) + (ang >= 0), (dev, fb, fail)   # both filters ran on the device
+        assert counts_o == counts_r, (px, min_len, ang, counts_o, counts_r)
+        assert np.array_equal(keep_o, keep_r)
+    return counts_r
+
+
+@needs_ref
+@pytest.mark.skipif(_oracle.adapter_ba_emu() is None, reason="openMVG tree / adapter objects not present")
+def test_filters_equal_the_reference_under_emulation():
+    lib = _oracle.adapter_ba_emu()
+    sc = _scene(8, 120, 17)
+    counts = _check(lib, lib.mvgx_adapter_counters, sc, [(4.0, 2, 2.0), (1.5, 3, -1.0), (-1.0, 2, 8.0), (0.0, 2, 0.0)])
+    assert counts is not None
+
+
+@needs_ref
+@pytest.mark.skipif(_oracle.adapter_ba_emu() is None, reason="openMVG tree / adapter objects not present")
+def test_thresholds_at_a_computed_value_follow_the_reference_expression():
+    """a threshold equal to an observation's own residual norm / a track's own angle as the reference computes them: the strict
+    comparisons (> threshold, < angle) must come out as in the reference, whatever the device's last bits are"""
+    lib = _oracle.adapter_ba_emu()
+    sc = _scene(6, 60, 23)
+    _, _, ang = _oracle.ref_ba_filters(sc, -1.0, 2, -1.0)
+    from openmvg_amd import ba
+    from tests import _emu
+    with _emu.emulated():   # the device's own values: thresholds that sit exactly on what the device computes
+        c = ba.BaContext(sc); res = c.residuals(); dev_ang = c.track_angles(); c.close()
+    thresholds = [(-1.0, 2, float(np.sort(ang)[len(ang) // 2])), (-1.0, 2, float(np.sort(dev_ang)[len(dev_ang) // 3]))]
+    thresholds += [(float(v), 2, -1.0) for v in np.sort(res)[[len(res) // 4, len(res) // 2, -3]]]
+    _check(lib, lib.mvgx_adapter_counters, sc, thresholds)
+
+
+@needs_ref
+@pytest.mark.skipif(_oracle.adapter_ba_emu() is None, reason="openMVG tree / adapter objects not present")
+def test_filters_rebind_the_context_adjust_left_idle_and_fall_back_on_a_failing_device(monkeypatch, capfd):
+    lib = _oracle.adapter_ba_emu()
+    sc = _scene(7, 80, 29)
+    stats = (C.c_uint64 * 2)()
+    lib.mvgx_adapter_ba_release_context()
+    lib.mvgx_adapter_ba_context_stats(stats, C.c_int(1))
+    rc, st, poses, intr, pts = _oracle.ref_ba_adjust(sc, lib=lib)
+    assert st[3] == 1.0
+    solved = dict(sc); solved["poses"] = poses; solved["intrinsics"] = intr; solved["points"] = pts
+    keep_o, counts_o, _ = _oracle.ref_ba_filters(solved, 4.0, 2, 2.0, lib=lib)
+    lib.mvgx_adapter_ba_context_stats(stats, C.c_int(0))
+    assert (int(stats[0]), int(stats[1])) == (1, 2) or int(stats[0]) == 2   # Adjust created it; the first filter re-bound it (the second sees fewer observations when the first erased some)
+    keep_r, counts_r, _ = _oracle.ref_ba_filters(solved, 4.0, 2, 2.0)
+    assert counts_o == counts_r and np.array_equal(keep_o, keep_r)
+    # a failing device: the reference's own functions finish the call, logged once
+    monkeypatch.setenv("MVGX_ADAPTER_INJECT_FAILURE", "filters:residuals")
+    _counters(lib.mvgx_adapter_counters)
+    keep_f, counts_f, _ = _oracle.ref_ba_filters(solved, 4.0, 2, -1.0, lib=lib)
+    monkeypatch.delenv("MVGX_ADAPTER_INJECT_FAILURE")
+    dev, fb, fail = _counters(lib.mvgx_adapter_counters)
+    assert fail == 1 and dev == 0
+    keep_r2, counts_r2, _ = _oracle.ref_ba_filters(solved, 4.0, 2, -1.0)
+    assert counts_f == counts_r2 and np.array_equal(keep_f, keep_r2)
+    assert "continuing with the reference's own CPU code" in capfd.readouterr().err
+    lib.mvgx_adapter_ba_release_context()
+
+
+# ---------------------------------------------------------------------------------------------------- MI355X
+@pytest.mark.gpu
+@needs_ref
+def test_filters_equal_the_reference_on_the_device():
+    a = _oracle.adapter()
+    sc = synth.ba_scene(n_cams=60, n_points=20000, track_len=8, model=3, n_intr_groups=3, seed=61, outlier_frac=0.03)
+    _check(a, a.ba_counters, sc, [(4.0, 2, 2.0), (2.0, 3, 5.0)])
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_filter_time_after_adjust_on_the_device():
+    """what the `do { BA } while (reject)` loop pays between two Adjust() calls: the reference's two passes against the replacement's"""
+    a = _oracle.adapter()
+    sc = synth.ba_scene(n_cams=200, n_points=100000, track_len=10, model=3, n_intr_groups=1, seed=0xAD1A + 200, outlier_frac=0.01)
+    rc, st, poses, intr, pts = _oracle.ref_ba_adjust(sc, lib=a)   # the filters see a solved scene, as in the loop
+    assert st[3] == 1.0
+    sc = dict(sc); sc["poses"] = poses; sc["intrinsics"] = intr; sc["points"] = pts
+    _oracle.ref_ba_filters_timed(sc, 4.0, 2, 2.0, lib=a)   # warm
+    keep_o, counts_o, sec_o = _oracle.ref_ba_filters_timed(sc, 4.0, 2, 2.0, lib=a)
+    keep_r, counts_r, sec_r = _oracle.ref_ba_filters_timed(sc, 4.0, 2, 2.0)
+    print(f"RemoveOutliers_PixelResidualError: replacement {sec_o[0] * 1e3:.2f} ms, reference {sec_r[0] * 1e3:.2f} ms; "
+          f"RemoveOutliers_AngleError: replacement {sec_o[1] * 1e3:.2f} ms, reference {sec_r[1] * 1e3:.2f} ms "
+          f"({sc['n_obs']} observations, {sc['n_points']} tracks, removed {counts_r})")
+    assert counts_o == counts_r and np.array_equal(keep_o, keep_r)
+    assert sec_o[0] < sec_r[0] and sec_o[1] < sec_r[1]
