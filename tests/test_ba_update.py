@@ -175,3 +175,23 @@ def test_update_is_cheaper_than_create_on_the_device():
     c.close()
     print(f"create {t_create * 1e3:.2f} ms, update {t_update * 1e3:.2f} ms")
     assert t_update < 0.5 * t_create
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_update_of_degenerate_problems_emulated(case):
+    """the edge scenes of tests/test_ba_emu_cpu.py (no observations, unused blocks, everything constant ...): re-binding each to
+    itself repeats its solve; none of them is taken for another's structure"""
+    from tests.test_ba_emu_cpu import _edge_scenes
+    scenes = _edge_scenes()
+    name, sc, masks = scenes[case]
+    with _emu.emulated():
+        c = ba.BaContext(sc, **masks)
+        first = _run(c)
+        assert c.update(sc, **masks) is True, name
+        assert _same(_run(c), first), name
+        other_name, other, other_masks = scenes[(case + 1) % len(scenes)]
+        same_structure = all(np.array_equal(np.asarray(sc[k]), np.asarray(other[k])) for k in ("obs_pose", "obs_intr", "obs_point", "intr_model")) and \
+            all(int(sc[k]) == int(other[k]) for k in ("n_poses", "n_intrinsics", "n_points")) and \
+            bool(masks.get("points_constant", False)) == bool(other_masks.get("points_constant", False))
+        assert c.update(other, **other_masks) is same_structure, (name, other_name)
+        c.close()
