@@ -330,6 +330,16 @@ int mvgx_ba_destroy(mvgx_ba_ctx* ctx);
  * to a context created from `problem`), or MVGX_ERR_STRUCTURE when the structure differs: the context is untouched and still
  * solves its old problem; the caller destroys it and creates a new one. Works on single- and multi-device contexts. (ABI 9) */
 int mvgx_ba_update(mvgx_ba_ctx* ctx, const mvgx_ba_problem* problem);
+/* mvgx_ba_update with some observations switched off: `problem` still has the context's structure, obs_enabled[k] == 0 (k in the
+ * order of the problem's observation arrays) removes observation k from the program - no residual, no Jacobian rows, no cost, not
+ * in the RMSE, not in the track's angle - a point left without observations stops being a parameter (it keeps its value, takes no
+ * step, does not count in the parameter norm) and a pose / intrinsic block left without observations leaves the program, as when the
+ * reference builds its problem from a scene those observations and tracks were erased from (the rejection step of
+ * sequential_SfM.cpp:1190-1232: RemoveOutliers_* erase, then Adjust() again). Equal to a context created from the reduced scene up to
+ * the order of the sums (the point groups are the original ones): same iterations and decisions on the test scenes, final RMSE to
+ * 1e-12. mvgx_ba_residuals / mvgx_ba_track_angles keep the indexing of `problem`. obs_enabled NULL = mvgx_ba_update; a later
+ * mvgx_ba_update switches everything back on. MVGX_ERR_UNSUPPORTED on a multi-device context. (ABI 9) */
+int mvgx_ba_update_subset(mvgx_ba_ctx* ctx, const mvgx_ba_problem* problem, const uint8_t* obs_enabled);
 /* The library's persistent host workers (the ones the structure build of mvgx_ba_create runs on; started on first use, parked
  * between jobs), lent to the host side of a caller - the replacement TU flattens SfM_Data with them instead of starting threads
  * of its own per Adjust() call. fn(user, item, worker) runs once for every item in [0, n_items), items handed out one at a time in

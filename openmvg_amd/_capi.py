@@ -176,6 +176,7 @@ PROTOTYPES = {
     "mvgx_ba_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(BaProblem), C.POINTER(C.c_void_p)]),
     "mvgx_ba_destroy": (C.c_int, [C.c_void_p]),
     "mvgx_ba_update": (C.c_int, [C.c_void_p, C.POINTER(BaProblem)]),
+    "mvgx_ba_update_subset": (C.c_int, [C.c_void_p, C.POINTER(BaProblem), C.c_void_p]),
     "mvgx_host_parallel_for": (C.c_int, [C.c_uint64, C.c_uint, HOST_ITEM_FN, C.c_void_p]),
     "mvgx_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_F64, C.c_void_p]),
     "mvgx_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -104,13 +104,19 @@ class BaContext:
         self._keep = keep
         return p
 
-    def update(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0):
+    def update(self, scene, pose_const_mask=None, intr_const_mask=None, points_constant=False, huber_a=16.0, obs_enabled=None):
         """mvgx_ba_update: new values (parameters, image points, weights, prior targets, constant masks, loss scale) for the structure
         this context was created from. Returns False - and leaves the context as it was - when the scene's structure differs
         (MVGX_ERR_STRUCTURE): the caller closes this context and creates a new one."""
         keep_before = self._keep
         p = self._problem(scene, pose_const_mask, intr_const_mask, points_constant, huber_a)
-        rc = _capi.lib().mvgx_ba_update(self._h, C.byref(p))
+        if obs_enabled is not None:   # mvgx_ba_update_subset: observations switched off without changing the structure
+            en = np.ascontiguousarray(obs_enabled, np.uint8)
+            assert en.shape == (int(scene["n_obs"]),)
+            self._keep["obs_enabled"] = en
+            rc = _capi.lib().mvgx_ba_update_subset(self._h, C.byref(p), en.ctypes.data)
+        else:
+            rc = _capi.lib().mvgx_ba_update(self._h, C.byref(p))
         if rc == _capi.MVGX_ERR_STRUCTURE:
             self._keep = keep_before
             return False

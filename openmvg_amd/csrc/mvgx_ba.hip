@@ -211,6 +211,7 @@ struct Dev {
   double* oxy = nullptr;
   double* oweight = nullptr;          // n_obs or null
   uint8_t* octrl = nullptr;           // n_obs or null
+  uint8_t* odisabled = nullptr;       // n_obs or null (mvgx_ba_update_subset): the observation contributes nothing - residual, Jacobian rows, cost, ray
   uint32_t* oorig = nullptr;          // n_obs: index of the observation in the caller's arrays (null: identity)
   uint32_t* pt_start = nullptr;       // n_pts + 1
   uint32_t* ptk_start = nullptr;      // n_pts + 1 -> intrinsic slots of a point
@@ -363,6 +364,7 @@ __device__ __forceinline__ void store_records_coalesced(double2* lds_wave /* 64 
 // function, Huber corrector (corrector.cc:81-85,126-129: residual and Jacobian scale by sqrt(rho')). o: the observation's index
 // in the point-sorted arrays (weights / control flags). Returns r (corrected) and the factor sc of the Jacobian entries.
 __device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2]) {
+  if (d.odisabled && d.odisabled[o]) { r[0] = 0.0; r[1] = 0.0; return 0.0; }   // as if the observation were not in the problem
   double w = 1.0;
   if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
   const bool ctrl = d.octrl && d.octrl[o];
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
     double w = 1.0;
     if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
     const bool ctrl = d.octrl && d.octrl[o];   // control point: no loss function, not in the RMSE
+    if (d.odisabled && d.odisabled[o]) w = 0.0;   // (mvgx_ba_update_subset: zero residual, zero rows, no cost)
     r[0] *= w; r[1] *= w;
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3];
@@ -505,8 +508,10 @@ __global__ __launch_bounds__(256) void ba_track_angle_kernel(Dev d, const double
   const uint32_t lo = d.pt_start[p], hi = d.pt_start[p + 1];
   double best = 0.0;
   for (uint32_t a = lo; a < hi; ++a) {
+    if (d.odisabled && d.odisabled[a]) continue;
     const double ra[3] = {rays[3 * (size_t)a], rays[3 * (size_t)a + 1], rays[3 * (size_t)a + 2]};
     for (uint32_t b = a + 1; b < hi; ++b) {
+      if (d.odisabled && d.odisabled[b]) continue;
       const double rb[3] = {rays[3 * (size_t)b], rays[3 * (size_t)b + 1], rays[3 * (size_t)b + 2]};
       const double ang = ray_angle_deg(ra, rb);
       best = ang > best ? ang : best;   // std::max(angle, max_angle): a NaN angle never replaces the maximum
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
       eval_observation_t<true, kPinholeFamily>(model, pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl) ? d.pi_obs[e] : 0, r);
+      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? d.pi_obs[e] : 0, r);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         double v[16];
@@ -1209,7 +1214,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
       for (int k = 0; k < 8; ++k) pin[k] = irow[k];
       eval_observation_t<true, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0, r);
+      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0, r);
       // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1340,9 +1345,10 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
         for (int k = 0; k < 8; ++k) pin[k] = irow2[k];
         eval_observation_t<false, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-        const uint64_t o = (d.oweight || d.octrl) ? G.eobs[e0 + tid] : 0;
+        const uint64_t o = (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0;
         double w = 1.0;
         if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
+        if (d.odisabled && d.odisabled[o]) w = 0.0;
         const bool ctrl = d.octrl && d.octrl[o];
         r[0] *= w; r[1] *= w;
         const double s2 = r[0] * r[0] + r[1] * r[1];
@@ -2895,6 +2901,10 @@ struct mvgx_ba_ctx {
   std::vector<uint8_t> h_pose_used, h_intr_used;   // blocks that carry a residual (the camera masks are applied on top of these)
   std::vector<uint32_t> h_perm;               // caller's observation index of point-order position k; empty: the caller's list was in point order
   uint64_t n_gentries = 0;                    // entries of the point groups (their copy of the image points is re-gathered)
+  std::vector<uint8_t> h_pt_free;             // which points are free parameter blocks with residuals (structure)
+  double n_obs_rmse_all = 0;                  // n_obs_rmse_local of the whole structure (a subset counts its own)
+  uint8_t* odisabled_buf = nullptr;           // device array behind Dev::odisabled (allocated by the first mvgx_ba_update_subset)
+  double* filter_scratch = nullptr;           // 3 n_obs doubles: residual norms / observation rays (mvgx_ba_residuals, mvgx_ba_track_angles)
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
@@ -3913,6 +3923,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   double n_rmse = (double)no;
   for (double v : ctrl_count) n_rmse -= v;
   c->n_obs_rmse_local = n_rmse;
+  c->n_obs_rmse_all = n_rmse;
   tick("sort by point + gather");
   std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_free(d.n_pts, 0);
   parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {   // (concurrent stores of the same value 1)
@@ -4315,7 +4326,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   tick("pose-intr / intr-intr products");
   // active / counted camera components
   std::vector<uint8_t> cam_active, cam_counts;
-  c->h_pose_used = pose_used; c->h_intr_used = intr_used;
+  c->h_pose_used = pose_used; c->h_intr_used = intr_used; c->h_pt_free = pt_free;
   camera_component_flags(p, pose_used, intr_used, cam_active, cam_counts);
   std::vector<double> h_pc(p->prior_center, p->prior_center + (size_t)d.n_priors * 3), h_pw(p->prior_weight, p->prior_weight + (size_t)d.n_priors * 3);
   tick("masks, parameter copies");
@@ -4485,10 +4496,20 @@ int mvgx_host_parallel_for(uint64_t n_items, unsigned max_workers, mvgx_host_ite
 // what is redone here: the three parameter arrays, the image points (and their two re-ordered copies: (pose, intrinsic) order for
 // the camera Gram kernel, entry order for the point groups), weights, prior targets, the camera component flags, the loss scales.
 // Everything else in the context is a function of the fingerprinted structure. The LM state is reset by mvgx_ba_solve's start().
-int mvgx_ba_update(mvgx_ba_ctx* c, const mvgx_ba_problem* p) {
+static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_t* obs_enabled);
+int mvgx_ba_update(mvgx_ba_ctx* c, const mvgx_ba_problem* p) { return ba_update_impl(c, p, nullptr); }
+// ... and with a subset of the observations switched off (include/mvgx.h): the structure stays the context's; an observation that
+// is off contributes nothing (Dev::odisabled), a point left without observations stops being a parameter (pt_free 0: scale 0, no
+// step, not in |x|), a camera block left without observations leaves the program (camera_component_flags), the RMSE counts the
+// observations that are on.
+int mvgx_ba_update_subset(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_t* obs_enabled) { return ba_update_impl(c, p, obs_enabled); }
+static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_t* obs_enabled) {
   MVGX_REQUIRE(c && p, MVGX_ERR_ARG, "mvgx_ba_update: NULL argument");
   { const int vrc = mvgx::ba_validate_problem(p); if (vrc) return vrc; }
-  if (c->multi) return mvgx::ba_multi_update(c->multi, p);
+  if (c->multi) {
+    MVGX_REQUIRE(!obs_enabled, MVGX_ERR_UNSUPPORTED, "mvgx_ba_update_subset: not available on a multi-device context");
+    return mvgx::ba_multi_update(c->multi, p);
+  }
   if (!(mvgx::ba_fingerprint(p) == c->fingerprint)) {
     set_error("mvgx_ba_update: the problem's structure is not the one this context was created from");
     return MVGX_ERR_STRUCTURE;
@@ -4535,8 +4556,41 @@ int mvgx_ba_update(mvgx_ba_ctx* c, const mvgx_ba_problem* p) {
     MVGX_HIP(hipMemcpyAsync(d.prior_center, p->prior_center, (size_t)d.n_priors * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     MVGX_HIP(hipMemcpyAsync(d.prior_weight, p->prior_weight, (size_t)d.n_priors * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
+  // which blocks carry a residual: the structure's, or - with a subset - those of the observations that are on
+  std::vector<uint8_t> pose_used_sub, intr_used_sub, pt_free_sub, odis;
+  const std::vector<uint8_t>*pose_used = &c->h_pose_used, *intr_used = &c->h_intr_used, *pt_free = &c->h_pt_free;
+  double n_rmse = c->n_obs_rmse_all;
+  bool any_off = false;
+  if (obs_enabled) {
+    pose_used_sub.assign(d.n_poses, 0); intr_used_sub.assign(d.n_intr, 0);
+    std::vector<uint8_t> pt_seen(d.n_pts, 0);
+    odis.assign((size_t)std::max<uint64_t>(no, 1), 0);
+    n_rmse = 0;
+    for (uint64_t k = 0; k < no; ++k) {   // k: position in point order; s_: the caller's index
+      const uint64_t s_ = c->h_perm.empty() ? k : c->h_perm[k];
+      if (obs_enabled[s_]) {
+        pose_used_sub[p->obs_pose[s_]] = 1; intr_used_sub[p->obs_intr[s_]] = 1; pt_seen[p->obs_point[s_]] = 1;
+        n_rmse += (p->obs_is_control && p->obs_is_control[s_]) ? 0.0 : 1.0;
+      } else {
+        odis[k] = 1; any_off = true;
+      }
+    }
+    for (uint32_t k = 0; k < d.n_priors; ++k) pose_used_sub[p->prior_pose[k]] = 1;
+    pt_free_sub = c->h_pt_free;
+    for (uint32_t j = 0; j < d.n_pts; ++j) pt_free_sub[j] = pt_free_sub[j] && pt_seen[j];
+    pose_used = &pose_used_sub; intr_used = &intr_used_sub; pt_free = &pt_free_sub;
+  }
+  if (any_off) {
+    if (!c->odisabled_buf && (rc = dev_alloc(c->pool, &c->odisabled_buf, (size_t)no))) return rc;
+    MVGX_HIP(hipMemcpyAsync(c->odisabled_buf, odis.data(), (size_t)no, hipMemcpyHostToDevice, c->stream));
+    d.odisabled = c->odisabled_buf;
+  } else {
+    d.odisabled = nullptr;
+  }
+  c->n_obs_rmse_local = n_rmse;
+  if (d.n_pts) MVGX_HIP(hipMemcpyAsync(d.pt_free, pt_free->data(), (size_t)d.n_pts, hipMemcpyHostToDevice, c->stream));
   std::vector<uint8_t> cam_active, cam_counts;
-  camera_component_flags(p, c->h_pose_used, c->h_intr_used, cam_active, cam_counts);
+  camera_component_flags(p, *pose_used, *intr_used, cam_active, cam_counts);
   if (d.N) {
     MVGX_HIP(hipMemcpyAsync(d.cam_active, cam_active.data(), cam_active.size(), hipMemcpyHostToDevice, c->stream));
     MVGX_HIP(hipMemcpyAsync(d.cam_counts, cam_counts.data(), cam_counts.size(), hipMemcpyHostToDevice, c->stream));
@@ -4653,14 +4707,25 @@ int mvgx_ba_read_params(mvgx_ba_ctx* c, double* poses, double* intrinsics, doubl
   return MVGX_OK;
 }
 
+static int filter_scratch(mvgx_ba_ctx* c, double** out) {   // 3 n_obs doubles for mvgx_ba_residuals / mvgx_ba_track_angles, on first use
+  if (!c->filter_scratch) {
+    const int rc = dev_alloc(c->pool, &c->filter_scratch, (size_t)3 * (size_t)c->d.n_obs);
+    if (rc) return rc;
+  }
+  *out = c->filter_scratch;
+  return MVGX_OK;
+}
 int mvgx_ba_residuals(mvgx_ba_ctx* c, double* residual_norm) {
   MVGX_REQUIRE(c && residual_norm, MVGX_ERR_ARG, "mvgx_ba_residuals: NULL argument");
   if (c->multi) return mvgx::ba_multi_residuals(c->multi, residual_norm);
   MVGX_HIP(hipSetDevice(c->device));
   Dev& d = c->d;
   if (!d.n_obs) return MVGX_OK;
-  double* out = nullptr;   // the Z array is free between LM iterations: borrow its first n_obs doubles
-  out = d.Zpose;
+  // scratch of its own (3 doubles per observation, allocated at the first call): until round 4 this borrowed the Z array of the
+  // record path, which a scene whose points are all grouped allocates EMPTY - the n_obs doubles then ran over the arrays the arena
+  // placed behind it (step vectors, then the product lists), harmless only as long as the context was destroyed right after
+  double* out = nullptr;
+  { const int rc_ = filter_scratch(c, &out); if (rc_) return rc_; }
   hipLaunchKernelGGL(ba_residual_norm_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, d.oorig, out);
   BA_LAUNCH_CHECK();
   MVGX_HIP(hipMemcpyAsync(residual_norm, out, (size_t)d.n_obs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -4678,8 +4743,9 @@ int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
     for (uint32_t p = 0; p < d.n_pts; ++p) max_angle_deg[p] = 0.0;
     return MVGX_OK;
   }
-  // scratch that is free between LM iterations: rays in the Z array (18 doubles per observation), angles in h_p (3 per point)
-  double* rays = d.Zpose;
+  // rays in the context's filter scratch (3 doubles per observation), angles in h_p (3 per point: free between LM iterations)
+  double* rays = nullptr;
+  { const int rc_ = filter_scratch(c, &rays); if (rc_) return rc_; }
   double* out = d.hp;
   hipLaunchKernelGGL(ba_obs_ray_kernel, dim3(c->grid_obs), dim3(256), 0, c->stream, d, rays);
   BA_LAUNCH_CHECK();
