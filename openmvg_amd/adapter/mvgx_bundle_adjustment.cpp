@@ -148,8 +148,9 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   // 150 MB (1 000 / 5 M) of fresh pageable memory per call were a zero fill on this thread plus a page fault per 4 KB in the
   // flatten threads - about a third of the 5 ms the walk took.
   std::unordered_map<IndexT, uint32_t> pose_idx, intr_idx;
-  std::vector<IndexT> pose_ids, intr_ids;
   mvgx_adapter::FlatScene& fs = mvgx_adapter::flat_scene();
+  std::vector<IndexT>&pose_ids = fs.pose_ids, &intr_ids = fs.intr_ids;
+  pose_ids.clear(); intr_ids.clear();
   std::vector<double>&poses = fs.poses, &intrinsics = fs.intrinsics, &points = fs.points, &obs_xy = fs.obs_xy;
   std::vector<int32_t>& intr_model = fs.intr_model;
   std::vector<uint8_t>&pose_mask = fs.pose_mask, &intr_mask = fs.intr_mask;
@@ -271,27 +272,14 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   prob.huber_a = options_.bUse_loss_function_ ? Square(4.0) : 0.0;
 
   tick("scene -> arrays");
-  mvgx_ba_ctx* ctx = nullptr;
+  // the context: the kept one re-bound (same structure: values only; the same scene minus observations: those switched off), or a
+  // new one (mvgx_scene_arrays.hpp)
+  const bool plain = obs_weight.empty() && prior_pose.empty();
+  mvgx_adapter::BoundContext bound;
   const bool inj_create = mvgx_adapter::injected("ba", "create");
-  int rc = MVGX_ERR_NODEV;
-  if (!inj_create) {
-    ctx = mvgx_adapter::take_idle_context(options_.device_);
-    if (ctx) {
-      rc = mvgx_ba_update(ctx, &prob);
-      if (rc == MVGX_OK) {
-        mvgx_adapter::context_cache().reused.fetch_add(1);
-        tick("mvgx_ba_update (context kept)");
-      } else {   // another structure (MVGX_ERR_STRUCTURE), or a failure the create below will report
-        mvgx_ba_destroy(ctx);
-        ctx = nullptr;
-      }
-    }
-    if (!ctx) {
-      rc = mvgx_ba_create(options_.device_, &prob, &ctx);
-      if (rc == MVGX_OK) mvgx_adapter::context_cache().created.fetch_add(1);
-      tick("mvgx_ba_create");
-    }
-  }
+  int rc = inj_create ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(options_.device_, prob, fs, plain, bound);
+  mvgx_ba_ctx* ctx = bound.ctx;
+  tick(bound.route);
   if (rc == MVGX_ERR_UNSUPPORTED) {
     OPENMVG_LOG_ERROR << "Cannot create a CostFunction for this camera model. (" << mvgx_last_error() << ")";
     return false;
@@ -310,10 +298,16 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   tick("mvgx_ba_solve");
   // the solver state is written back to the landmarks in every case: the reference optimises X in place, so a failed
   // solve leaves moved points behind as well (sfm_data_BA_ceres.cpp:378, :503-507)
-  const int rc_read = mvgx_ba_read_params(ctx, poses.data(), intrinsics.data(), points.data());
-  if (rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)) mvgx_adapter::keep_idle_context(ctx, options_.device_);   // (a context whose device calls failed is not kept)
-  else mvgx_ba_destroy(ctx);
-  tick("read_params, context kept / destroyed");
+  const int rc_read = mvgx_ba_read_params(ctx, poses.data(), intrinsics.data(), bound.subset ? bound.points_old.data() : points.data());
+  if (rc_read == MVGX_OK && bound.subset)   // the context holds the kept structure: this scene's points are a selection of its points
+    for (size_t j = 0; j < bound.point_old.size(); ++j)
+      for (int a = 0; a < 3; ++a) points[3 * j + a] = bound.points_old[3 * static_cast<size_t>(bound.point_old[j]) + a];
+  // (the context goes back into the slot after the write-back: that hands the flat arrays over with it)
+  struct Release {
+    mvgx_adapter::BoundContext& b; mvgx_adapter::FlatScene& fs; int device; bool plain, healthy;
+    ~Release() { mvgx_adapter::release_bound_context(b, device, fs, plain, healthy); }
+  } release{bound, fs, options_.device_, plain, rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)};   // (a context whose device calls failed is not kept)
+  tick("read_params");
   if (rc_read != MVGX_OK) {
     OPENMVG_LOG_ERROR << "mvgx BA: " << mvgx_last_error();
     return false;
@@ -377,8 +371,14 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
 // release: destroys the idle context (its device memory goes back to the library's slab cache)
 extern "C" void mvgx_adapter_ba_context_stats(uint64_t out[2], int reset) {
   auto& c = mvgx_adapter::context_cache();
-  if (out) { out[0] = c.created.load(); out[1] = c.reused.load(); }
-  if (reset) { c.created = 0; c.reused = 0; }
+  if (out) { out[0] = c.created.load(); out[1] = c.reused.load() + c.subset.load(); }
+  if (reset) { c.created = 0; c.reused = 0; c.subset = 0; }
+}
+// ... {created, re-bound with the same structure, re-bound with observations switched off}
+extern "C" void mvgx_adapter_ba_context_stats3(uint64_t out[3], int reset) {
+  auto& c = mvgx_adapter::context_cache();
+  if (out) { out[0] = c.created.load(); out[1] = c.reused.load(); out[2] = c.subset.load(); }
+  if (reset) { c.created = 0; c.reused = 0; c.subset = 0; }
 }
 extern "C" void mvgx_adapter_ba_release_context() {
   mvgx_ba_ctx* ctx = mvgx_adapter::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context is destroyed)

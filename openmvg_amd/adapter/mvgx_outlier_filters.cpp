@@ -55,15 +55,17 @@ using mvgx_adapter::FlatScene;
 // false: the scene is not one the device path takes (a camera model without functor, a landmark observing a view without pose or
 // intrinsic - the reference's .at() / GetPoseOrDie would throw or abort there, and does when the caller falls back to it) or a
 // device call failed (logged by the policy).
-bool bind_scene(SfM_Data& sfm_data, FlatScene& fs, mvgx_ba_ctx** out_ctx, const char* stage) {
+bool bind_scene(SfM_Data& sfm_data, FlatScene& fs, mvgx_adapter::BoundContext& bound, const char* stage) {
   std::unordered_map<IndexT, uint32_t> pose_idx, intr_idx;
   fs.poses.clear(); fs.intrinsics.clear(); fs.intr_model.clear(); fs.pose_mask.clear(); fs.intr_mask.clear();
+  fs.pose_ids.clear(); fs.intr_ids.clear();
   for (const auto& it : sfm_data.poses) {
     const Mat3 R = it.second.rotation();
     const Vec3 t = it.second.translation();
     double aa[3];
     ceres::RotationMatrixToAngleAxis(static_cast<const double*>(R.data()), aa);
-    pose_idx.emplace(it.first, static_cast<uint32_t>(pose_idx.size()));
+    pose_idx.emplace(it.first, static_cast<uint32_t>(fs.pose_ids.size()));
+    fs.pose_ids.push_back(it.first);
     fs.poses.insert(fs.poses.end(), {aa[0], aa[1], aa[2], t(0), t(1), t(2)});
   }
   for (const auto& it : sfm_data.intrinsics) {
@@ -71,7 +73,8 @@ bool bind_scene(SfM_Data& sfm_data, FlatScene& fs, mvgx_ba_ctx** out_ctx, const 
     std::vector<double> prm = it.second->getParams();
     if (prm.size() > MVGX_BA_MAX_INTR_PARAMS) return false;
     if (prm.empty()) prm = {static_cast<double>(it.second->w()), static_cast<double>(it.second->h())};   // CAMERA_SPHERICAL: data of the functor
-    intr_idx.emplace(it.first, static_cast<uint32_t>(intr_idx.size()));
+    intr_idx.emplace(it.first, static_cast<uint32_t>(fs.intr_ids.size()));
+    fs.intr_ids.push_back(it.first);
     fs.intr_model.push_back(static_cast<int32_t>(it.second->getType()));
     for (size_t k = 0; k < MVGX_BA_MAX_INTR_PARAMS; ++k) fs.intrinsics.push_back(k < prm.size() ? prm[k] : 0.0);
   }
@@ -89,25 +92,11 @@ bool bind_scene(SfM_Data& sfm_data, FlatScene& fs, mvgx_ba_ctx** out_ctx, const 
   prob.obs_xy = fs.obs_xy.data();
   prob.huber_a = Square(4.0);   // (as Adjust() with its default loss: the kept context's structure does not depend on it)
   const bool inj = mvgx_adapter::injected("filters", stage);
-  int rc = MVGX_ERR_NODEV;
-  mvgx_ba_ctx* ctx = nullptr;
-  if (!inj) {
-    ctx = mvgx_adapter::take_idle_context(-1);
-    if (ctx) {
-      rc = mvgx_ba_update(ctx, &prob);
-      if (rc == MVGX_OK) mvgx_adapter::context_cache().reused.fetch_add(1);
-      else { mvgx_ba_destroy(ctx); ctx = nullptr; }
-    }
-    if (!ctx) {
-      rc = mvgx_ba_create(-1, &prob, &ctx);
-      if (rc == MVGX_OK) mvgx_adapter::context_cache().created.fetch_add(1);
-    }
-  }
+  const int rc = inj ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(-1, prob, fs, /* plain */ true, bound);
   if (rc != MVGX_OK) {
     if (rc != MVGX_ERR_UNSUPPORTED) mvgx_adapter::device_failure(mvgx_adapter::kFilters, "outlier filters", "mvgx_ba_create", rc, inj);
     return false;
   }
-  *out_ctx = ctx;
   return true;
 }
 
@@ -117,32 +106,39 @@ bool near_threshold(double v, double thr) { return std::fabs(v - thr) <= 1e-9 * 
 
 IndexT RemoveOutliers_PixelResidualError(SfM_Data& sfm_data, const double dThresholdPixel, const unsigned int minTrackLength) {
   FlatScene& fs = mvgx_adapter::flat_scene();
-  mvgx_ba_ctx* ctx = nullptr;
-  if (!bind_scene(sfm_data, fs, &ctx, "residuals")) return RemoveOutliers_PixelResidualError_cpu(sfm_data, dThresholdPixel, minTrackLength);
-  std::vector<double>& norm = fs.scratch;
-  norm.resize(std::max<size_t>(fs.obs_pose.size(), 1));
-  const int rc = mvgx_ba_residuals(ctx, norm.data());
+  mvgx_adapter::BoundContext bound;
+  if (!bind_scene(sfm_data, fs, bound, "residuals")) return RemoveOutliers_PixelResidualError_cpu(sfm_data, dThresholdPixel, minTrackLength);
+  std::vector<double>& norm = fs.scratch;   // in the indexing of the context's structure (the kept one on the subset route)
+  norm.resize(std::max<size_t>(bound.subset ? bound.kept->obs_pose.size() : fs.obs_pose.size(), 1));
+  const int rc = mvgx_ba_residuals(bound.ctx, norm.data());
+  // (the context goes back into the slot when this function is done with the flat arrays: the hand-over takes them along)
+  struct Release {
+    mvgx_adapter::BoundContext& b; FlatScene& fs; bool healthy;
+    ~Release() { mvgx_adapter::release_bound_context(b, -1, fs, true, healthy); }
+  } release{bound, fs, rc == MVGX_OK};
+  const std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
+  const std::vector<IndexT>& lm_key = fs.lm_key;
+  const std::vector<uint64_t>&obs_first = fs.obs_first, &obs_old = bound.obs_old;
+  const bool subset = bound.subset;
   if (rc != MVGX_OK) {
-    mvgx_ba_destroy(ctx);
     mvgx_adapter::device_failure(mvgx_adapter::kFilters, "outlier filters", "mvgx_ba_residuals", rc, false);
     return RemoveOutliers_PixelResidualError_cpu(sfm_data, dThresholdPixel, minTrackLength);
   }
-  mvgx_adapter::keep_idle_context(ctx, -1);
   mvgx_adapter::counters().device_pairs.fetch_add(1);
   // erasure: the observations of a landmark are visited in the order of the walk that numbered them (an unordered_map keeps the
   // order of the elements it keeps); landmarks are independent, so the host workers take ranges of them; the landmarks themselves
   // leave the (shared) structure map afterwards on this thread
-  const size_t n_lm = fs.lm_of_point.size(), per = 2048, n_ranges = (n_lm + per - 1) / per;
+  const size_t n_lm = lm_of_point.size(), per = 2048, n_ranges = (n_lm + per - 1) / per;
   std::vector<IndexT> removed(std::max<size_t>(n_ranges, 1), 0);
   std::vector<uint8_t> drop(std::max<size_t>(n_lm, 1), 0);
   mvgx_adapter::host_parallel(n_ranges, [&](uint64_t r, unsigned) {
     IndexT count = 0;
     for (size_t j = r * per, e = std::min(n_lm, (r + 1) * per); j < e; ++j) {
-      Landmark& lm = *fs.lm_of_point[j];
+      Landmark& lm = *lm_of_point[j];
       Observations& obs = lm.obs;
-      uint64_t k = fs.obs_first[j];
+      uint64_t k = obs_first[j];
       for (Observations::iterator it = obs.begin(); it != obs.end(); ++k) {
-        double v = norm[k];
+        double v = norm[subset ? obs_old[k] : k];
         if (near_threshold(v, dThresholdPixel)) {   // the reference's own expression decides a borderline observation
           const View* view = sfm_data.views.at(it->first).get();
           const geometry::Pose3 pose = sfm_data.GetPoseOrDie(view);
@@ -159,29 +155,35 @@ IndexT RemoveOutliers_PixelResidualError(SfM_Data& sfm_data, const double dThres
   IndexT outlier_count = 0;
   for (size_t r = 0; r < n_ranges; ++r) outlier_count += removed[r];
   for (size_t j = 0; j < n_lm; ++j)
-    if (drop[j]) sfm_data.structure.erase(fs.lm_key[j]);
+    if (drop[j]) sfm_data.structure.erase(lm_key[j]);
   return outlier_count;
 }
 
 IndexT RemoveOutliers_AngleError(SfM_Data& sfm_data, const double dMinAcceptedAngle) {
   FlatScene& fs = mvgx_adapter::flat_scene();
-  mvgx_ba_ctx* ctx = nullptr;
-  if (!bind_scene(sfm_data, fs, &ctx, "angles")) return RemoveOutliers_AngleError_cpu(sfm_data, dMinAcceptedAngle);
-  std::vector<double>& angle = fs.scratch;
-  angle.resize(std::max<size_t>(fs.lm_of_point.size(), 1));
-  const int rc = mvgx_ba_track_angles(ctx, angle.data());
+  mvgx_adapter::BoundContext bound;
+  if (!bind_scene(sfm_data, fs, bound, "angles")) return RemoveOutliers_AngleError_cpu(sfm_data, dMinAcceptedAngle);
+  std::vector<double>& angle = fs.scratch;   // per point of the context's structure (the kept one on the subset route)
+  angle.resize(std::max<size_t>(bound.subset ? bound.kept->lm_key.size() : fs.lm_of_point.size(), 1));
+  const int rc = mvgx_ba_track_angles(bound.ctx, angle.data());
+  struct Release {
+    mvgx_adapter::BoundContext& b; FlatScene& fs; bool healthy;
+    ~Release() { mvgx_adapter::release_bound_context(b, -1, fs, true, healthy); }
+  } release{bound, fs, rc == MVGX_OK};
+  const std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
+  const std::vector<IndexT>& lm_key = fs.lm_key;
+  const std::vector<uint32_t>& point_old = bound.point_old;
+  const bool subset = bound.subset;
   if (rc != MVGX_OK) {
-    mvgx_ba_destroy(ctx);
     mvgx_adapter::device_failure(mvgx_adapter::kFilters, "outlier filters", "mvgx_ba_track_angles", rc, false);
     return RemoveOutliers_AngleError_cpu(sfm_data, dMinAcceptedAngle);
   }
-  mvgx_adapter::keep_idle_context(ctx, -1);
   mvgx_adapter::counters().device_pairs.fetch_add(1);
   IndexT removedTrack_count = 0;
-  for (size_t j = 0; j < fs.lm_of_point.size(); ++j) {
-    double max_angle = angle[j];
+  for (size_t j = 0; j < lm_of_point.size(); ++j) {
+    double max_angle = angle[subset ? point_old[j] : j];
     if (near_threshold(max_angle, dMinAcceptedAngle)) {   // the reference's loop for a borderline track (:84-110)
-      const Observations& obs = fs.lm_of_point[j]->obs;
+      const Observations& obs = lm_of_point[j]->obs;
       max_angle = 0.0;
       for (Observations::const_iterator it1 = obs.begin(); it1 != obs.end(); ++it1) {
         const View* view1 = sfm_data.views.at(it1->first).get();
@@ -198,7 +200,7 @@ IndexT RemoveOutliers_AngleError(SfM_Data& sfm_data, const double dMinAcceptedAn
       }
     }
     if (max_angle < dMinAcceptedAngle) {
-      sfm_data.structure.erase(fs.lm_key[j]);
+      sfm_data.structure.erase(lm_key[j]);
       ++removedTrack_count;
     }
   }

@@ -41,6 +41,7 @@ struct FlatScene {
   std::vector<int32_t> intr_model;
   std::vector<uint8_t> pose_mask, intr_mask;
   std::vector<uint32_t> obs_pose, obs_intr, obs_point;
+  std::vector<IndexT> pose_ids, intr_ids;   // dense index -> key in SfM_Data::poses / ::intrinsics
   std::vector<Landmark*> lm_of_point;
   std::vector<IndexT> lm_key;   // the landmark's key in SfM_Data::structure
   std::vector<uint64_t> obs_first;   // [point]: index of its first observation row
@@ -53,18 +54,37 @@ inline FlatScene& flat_scene() {
 
 // The context of the last Adjust() of this process, kept idle between calls. The engines construct a Bundle_Adjustment_Ceres on the
 // stack per call (sequential_SfM.cpp:1194-1210, global_SfM.cpp:379-446), so nothing of the object survives; what repeats is the
-// scene: global_SfM.cpp refines the same structure three times with growing parameter sets, sequential_SfM.cpp:1190-1232 calls
-// Adjust again whenever its rejection step removed nothing, and callers re-run BA after changing options. The next call offers
-// its arrays to the kept context (mvgx_ba_update): same structure -> only values are uploaded (the host structure build, the
-// device allocations and the symbolic phase of the reduced solve are skipped); another structure -> the context is destroyed and
-// a new one created, as before. A context taken out of the cache belongs to the calling thread; concurrent Adjust() calls simply
-// find the cache empty. MVGX_BA_CONTEXT_CACHE=0 turns this off (every call creates and destroys);
-// mvgx_adapter_ba_release_context() hands the idle context's device memory back at any time.
+// scene. The next call (Adjust(), or one of the two outlier filters) offers its arrays to the kept context:
+//   same structure (global_SfM.cpp's refinement passes with growing parameter sets; a rejection round that removed nothing; the
+//     filters right after Adjust())                                     -> mvgx_ba_update: values only;
+//   the same scene MINUS observations / tracks (what RemoveOutliers_* leave behind: the `do { BA } while (reject)` loop of
+//     sequential_SfM.cpp:1190-1232)                                     -> mvgx_ba_update_subset: the kept structure with those
+//     observations switched off - found by walking the kept arrays and the new ones side by side (erasing from an unordered_map
+//     keeps the order of what stays);
+//   anything else (views or tracks added: a resection)                  -> the context is destroyed and a new one created.
+// A context taken out of the slot belongs to the calling thread; concurrent calls find the slot empty and create their own.
+// MVGX_BA_CONTEXT_CACHE=0 turns this off (every call creates and destroys); mvgx_adapter_ba_release_context() frees the idle
+// context at any time.
+struct KeptStructure {   // the arrays the kept context was created from
+  std::vector<IndexT> pose_ids, intr_ids, lm_key;
+  std::vector<int32_t> intr_model;
+  std::vector<uint32_t> obs_pose, obs_intr, obs_point;
+  std::vector<uint64_t> obs_first;    // [point]: its first observation
+  std::vector<double> points, obs_xy; // values of that call (what a switched-off observation / an absent point keeps)
+  bool plain = false;                 // neither control points nor pose priors: the only kind the subset route takes
+  void take_from(FlatScene& fs, bool is_plain) {   // (swaps: both sides keep their capacity)
+    pose_ids.swap(fs.pose_ids); intr_ids.swap(fs.intr_ids); lm_key.swap(fs.lm_key); intr_model.swap(fs.intr_model);
+    obs_pose.swap(fs.obs_pose); obs_intr.swap(fs.obs_intr); obs_point.swap(fs.obs_point); obs_first.swap(fs.obs_first);
+    points.swap(fs.points); obs_xy.swap(fs.obs_xy);
+    plain = is_plain;
+  }
+};
 struct ContextCache {
   std::mutex mu;
   mvgx_ba_ctx* idle = nullptr;
+  KeptStructure* kept = nullptr;
   int device = 0;
-  std::atomic<uint64_t> created{0}, reused{0};
+  std::atomic<uint64_t> created{0}, reused{0}, subset{0};
 };
 inline ContextCache& context_cache() {
   static ContextCache* c = new ContextCache;   // never destroyed: the HIP runtime may be gone when static destructors run
@@ -74,27 +94,147 @@ inline bool context_cache_enabled() {
   const char* env = std::getenv("MVGX_BA_CONTEXT_CACHE");
   return !(env && env[0] == '0');
 }
-inline mvgx_ba_ctx* take_idle_context(int device) {
+// the idle context and its structure arrays leave the slot together (nullptr: nothing usable is kept)
+inline mvgx_ba_ctx* take_idle_context(int device, KeptStructure** kept = nullptr) {
   ContextCache& c = context_cache();
   std::lock_guard<std::mutex> lock(c.mu);
   mvgx_ba_ctx* ctx = c.idle;
-  c.idle = nullptr;
+  KeptStructure* ks = c.kept;
+  c.idle = nullptr; c.kept = nullptr;
   if (ctx && (c.device != device || !context_cache_enabled())) { mvgx_ba_destroy(ctx); ctx = nullptr; }
+  if (!ctx || !kept) { delete ks; ks = nullptr; }
+  if (kept) *kept = ks;
   return ctx;
 }
-inline void keep_idle_context(mvgx_ba_ctx* ctx, int device) {
-  if (!context_cache_enabled()) { mvgx_ba_destroy(ctx); return; }
+inline void keep_idle_context(mvgx_ba_ctx* ctx, int device, KeptStructure* kept = nullptr) {
+  if (!context_cache_enabled()) { mvgx_ba_destroy(ctx); delete kept; return; }
   ContextCache& c = context_cache();
   mvgx_ba_ctx* old = nullptr;
+  KeptStructure* old_kept = nullptr;
   {
     std::lock_guard<std::mutex> lock(c.mu);
-    old = c.idle;
-    c.idle = ctx;
+    old = c.idle; old_kept = c.kept;
+    c.idle = ctx; c.kept = kept;
     c.device = device;
   }
   if (old) mvgx_ba_destroy(old);
+  delete old_kept;
 }
 
+// Is the scene in `fs` the scene of `ks` minus observations / whole tracks? Both lists are in the walk's order (bucket order of
+// the landmark map, each landmark's own observation order): erasing elements of an unordered_map does not move the ones that
+// stay, so the new lists are subsequences of the kept ones exactly when only erasures happened. On success: enabled[k_old] = 1
+// for the kept observations that are still there, point_old[j_new] / obs_old[k_new] = their indices in the kept arrays.
+inline bool express_in_kept_structure(const KeptStructure& ks, const FlatScene& fs, std::vector<uint8_t>& enabled,
+                                      std::vector<uint32_t>& point_old, std::vector<uint64_t>& obs_old) {
+  if (ks.pose_ids != fs.pose_ids || ks.intr_ids != fs.intr_ids || ks.intr_model != fs.intr_model) return false;
+  const size_t n_old = ks.lm_key.size(), n_new = fs.lm_key.size();
+  const uint64_t no_old = ks.obs_pose.size(), no_new = fs.obs_pose.size();
+  if (n_new > n_old || no_new > no_old) return false;
+  enabled.assign(std::max<size_t>(no_old, 1), 0);
+  point_old.resize(n_new);
+  obs_old.resize(no_new);
+  // the points on this thread (one pass over the two key lists), the observations of the matched points on the host workers
+  size_t jo = 0;
+  for (size_t jn = 0; jn < n_new; ++jn, ++jo) {
+    while (jo < n_old && ks.lm_key[jo] != fs.lm_key[jn]) ++jo;
+    if (jo == n_old) return false;
+    point_old[jn] = static_cast<uint32_t>(jo);
+  }
+  std::atomic<int> failed{0};
+  const size_t per = 4096;
+  host_parallel((n_new + per - 1) / per, [&](uint64_t g, unsigned) {
+    for (size_t jn = g * per, e = std::min(n_new, (g + 1) * per); jn < e; ++jn) {
+      const size_t jp = point_old[jn];
+      uint64_t ko = ks.obs_first[jp];
+      const uint64_t ko_end = jp + 1 < n_old ? ks.obs_first[jp + 1] : no_old;
+      const uint64_t kn_end = jn + 1 < n_new ? fs.obs_first[jn + 1] : no_new;
+      for (uint64_t kn = fs.obs_first[jn]; kn < kn_end; ++kn, ++ko) {
+        while (ko < ko_end && !(ks.obs_pose[ko] == fs.obs_pose[kn] && ks.obs_intr[ko] == fs.obs_intr[kn])) ++ko;
+        if (ko == ko_end) { failed.store(1); return; }
+        enabled[ko] = 1;
+        obs_old[kn] = ko;
+      }
+    }
+  });
+  return failed.load() == 0;
+}
+
+// A device context bound to the scene in `fs` / `prob` by the cheapest of the three routes above.
+struct BoundContext {
+  mvgx_ba_ctx* ctx = nullptr;
+  KeptStructure* kept = nullptr;     // the structure arrays that go back into the slot with the context (subset route: the old ones)
+  bool subset = false;               // the context holds the KEPT structure: parameters / residuals / angles come back in its indexing
+  std::vector<uint32_t> point_old;   // subset: [new point] -> kept point
+  std::vector<uint64_t> obs_old;     // subset: [new observation] -> kept observation
+  std::vector<double> points_old;    // subset: the kept-indexed point array handed to the library (read_params target)
+  const char* route = "";
+};
+// rc of the library call that decided (MVGX_OK: bc.ctx is ready). `plain`: prob has neither control points nor priors.
+inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, bool plain, BoundContext& bc) {
+  KeptStructure* ks = nullptr;
+  mvgx_ba_ctx* ctx = take_idle_context(device, &ks);
+  int rc = MVGX_ERR_STRUCTURE;
+  if (ctx) {
+    rc = mvgx_ba_update(ctx, &prob);
+    if (rc == MVGX_OK) {
+      context_cache().reused.fetch_add(1);
+      bc.route = "mvgx_ba_update (context kept)";
+    } else if (rc == MVGX_ERR_STRUCTURE && plain && ks && ks->plain) {
+      std::vector<uint8_t> enabled;
+      if (express_in_kept_structure(*ks, fs, enabled, bc.point_old, bc.obs_old)) {
+        // the kept structure with this call's values: cameras and masks as given, points / image points where they still exist
+        bc.points_old = ks->points;
+        {
+          const size_t n_new = bc.point_old.size(), no_new = bc.obs_old.size(), per = 16384;
+          host_parallel((n_new + per - 1) / per, [&](uint64_t g, unsigned) {
+            for (size_t jn = g * per, e = std::min(n_new, (g + 1) * per); jn < e; ++jn)
+              for (int a = 0; a < 3; ++a) bc.points_old[3 * static_cast<size_t>(bc.point_old[jn]) + a] = fs.points[3 * jn + a];
+          });
+          host_parallel((no_new + per - 1) / per, [&](uint64_t g, unsigned) {
+            for (size_t kn = g * per, e = std::min(no_new, (g + 1) * per); kn < e; ++kn) {
+              ks->obs_xy[2 * bc.obs_old[kn]] = fs.obs_xy[2 * kn];
+              ks->obs_xy[2 * bc.obs_old[kn] + 1] = fs.obs_xy[2 * kn + 1];
+            }
+          });
+        }
+        mvgx_ba_problem old = prob;
+        old.n_points = static_cast<uint32_t>(ks->lm_key.size());
+        old.n_obs = ks->obs_pose.size();
+        old.points = bc.points_old.data();
+        old.obs_pose = ks->obs_pose.data(); old.obs_intr = ks->obs_intr.data(); old.obs_point = ks->obs_point.data();
+        old.obs_xy = ks->obs_xy.data();
+        rc = mvgx_ba_update_subset(ctx, &old, enabled.data());
+        if (rc == MVGX_OK) {
+          context_cache().subset.fetch_add(1);
+          bc.subset = true;
+          bc.route = "mvgx_ba_update_subset (context kept, observations off)";
+        }
+      }
+    }
+    if (rc != MVGX_OK) { mvgx_ba_destroy(ctx); ctx = nullptr; }
+  }
+  if (!ctx) {
+    delete ks; ks = nullptr;
+    rc = mvgx_ba_create(device, &prob, &ctx);
+    if (rc == MVGX_OK) { context_cache().created.fetch_add(1); bc.route = "mvgx_ba_create"; }
+    else ctx = nullptr;
+  }
+  bc.ctx = ctx;
+  bc.kept = ks;
+  return rc;
+}
+// after the caller's last use of the context: back into the slot with the structure arrays it was built from
+inline void release_bound_context(BoundContext& bc, int device, FlatScene& fs, bool plain, bool healthy) {
+  if (!bc.ctx) return;
+  if (!healthy) { mvgx_ba_destroy(bc.ctx); delete bc.kept; bc.ctx = nullptr; bc.kept = nullptr; return; }
+  if (!bc.subset) {   // created from / re-bound to the arrays in fs: they become the kept ones
+    if (!bc.kept) bc.kept = new KeptStructure;
+    bc.kept->take_from(fs, plain);
+  }
+  keep_idle_context(bc.ctx, device, bc.kept);
+  bc.ctx = nullptr; bc.kept = nullptr;
+}
 
 // Landmarks and Observations are std::unordered_map (types.hpp:67): walking one is a chain of dependent loads, one node per
 // element - about a million nodes at 200 views. The walk therefore runs on the library's host workers (mvgx_host_parallel_for),

@@ -4566,14 +4566,28 @@ static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_
     std::vector<uint8_t> pt_seen(d.n_pts, 0);
     odis.assign((size_t)std::max<uint64_t>(no, 1), 0);
     n_rmse = 0;
-    for (uint64_t k = 0; k < no; ++k) {   // k: position in point order; s_: the caller's index
-      const uint64_t s_ = c->h_perm.empty() ? k : c->h_perm[k];
-      if (obs_enabled[s_]) {
-        pose_used_sub[p->obs_pose[s_]] = 1; intr_used_sub[p->obs_intr[s_]] = 1; pt_seen[p->obs_point[s_]] = 1;
-        n_rmse += (p->obs_is_control && p->obs_is_control[s_]) ? 0.0 : 1.0;
-      } else {
-        odis[k] = 1; any_off = true;
-      }
+    {   // (host threads: the flags are bytes that only ever receive 1, the counts are summed per grain)
+      constexpr uint64_t kGrain = 1u << 15;
+      const size_t n_grains = (size_t)((no + kGrain - 1) / kGrain);
+      std::vector<double> cnt(n_grains, 0.0);
+      std::vector<uint8_t> off(n_grains, 0);
+      parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {
+        double n = 0; bool any = false;
+        for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {   // k: position in point order; s_: the caller's index
+          const uint64_t s_ = c->h_perm.empty() ? k : c->h_perm[k];
+          if (obs_enabled[s_]) {
+            // (read before write: a few hundred flag bytes stored to by every thread for every observation bounce between the cores)
+            if (!pose_used_sub[p->obs_pose[s_]]) pose_used_sub[p->obs_pose[s_]] = 1;
+            if (!intr_used_sub[p->obs_intr[s_]]) intr_used_sub[p->obs_intr[s_]] = 1;
+            if (!pt_seen[p->obs_point[s_]]) pt_seen[p->obs_point[s_]] = 1;
+            n += (p->obs_is_control && p->obs_is_control[s_]) ? 0.0 : 1.0;
+          } else {
+            odis[k] = 1; any = true;
+          }
+        }
+        cnt[g] = n; off[g] = any;
+      });
+      for (size_t g = 0; g < n_grains; ++g) { n_rmse += cnt[g]; any_off = any_off || off[g]; }
     }
     for (uint32_t k = 0; k < d.n_priors; ++k) pose_used_sub[p->prior_pose[k]] = 1;
     pt_free_sub = c->h_pt_free;

@@ -313,6 +313,60 @@ int ref_ba_filters_timed(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, u
                       min_track_length, min_angle_deg, obs_keep, counts, nullptr, seconds);
 }
 
+// The loop of SequentialSfMReconstructionEngine::BundleAdjustment (sequential_SfM.cpp:1190-1232) on ONE SfM_Data:
+//   do { Bundle_Adjustment_Ceres(options).Adjust(scene, ADJUST_ALL) } while (badTrackRejector(px_threshold, 0));
+// with badTrackRejector = RemoveOutliers_PixelResidualError(px_threshold, 2) + RemoveOutliers_AngleError(2.0) > count (:1226-1232),
+// at most max_rounds rounds. Outputs: obs_keep[n_obs] (observations still in the scene), the parameter arrays, rounds[0] = number
+// of Adjust() calls, seconds[3 r .. 3 r + 2] = wall time of round r's Adjust / residual filter / angle filter, removed[2 r .. ] = what
+// the two filters of round r removed. The scene lives through all rounds: what a replacement TU keeps between calls is exercised.
+int ref_ba_reject_loop(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, double* poses, double* intrinsics,
+                       const int32_t* intr_model, double* points, const uint32_t* obs_pose, const uint32_t* obs_intr,
+                       const uint32_t* obs_point, const double* obs_xy, double px_threshold, uint32_t count, int max_rounds,
+                       int num_threads, uint8_t* obs_keep, int32_t* rounds, double* seconds, uint64_t* removed, double* rmse) {
+  SfM_Data scene;
+  const int rc0 = build_scene(scene, n_poses, n_intr, n_points, n_obs, poses, intrinsics, intr_model, points, obs_pose, obs_intr,
+                              obs_point, obs_xy, Extras());
+  if (rc0) return rc0;
+  Bundle_Adjustment_Ceres::BA_Ceres_options opt(false, num_threads != 1);
+  if (num_threads > 0) opt.nb_threads_ = unsigned(num_threads);
+  const Optimize_Options oo(Intrinsic_Parameter_Type::ADJUST_ALL, Extrinsic_Parameter_Type::ADJUST_ALL, Structure_Parameter_Type::ADJUST_ALL);
+  int r = 0;
+  bool again = true;
+  using clk = std::chrono::steady_clock;
+  while (again && r < max_rounds) {
+    Bundle_Adjustment_Ceres ba(opt);   // (constructed per call, as the engine does)
+    const auto t0 = clk::now();
+    const bool ok = ba.Adjust(scene, oo);
+    const auto t1 = clk::now();
+    if (!ok) return 1;
+    const IndexT n_res = RemoveOutliers_PixelResidualError(scene, px_threshold, 2);
+    const auto t2 = clk::now();
+    const IndexT n_ang = RemoveOutliers_AngleError(scene, 2.0);
+    const auto t3 = clk::now();
+    seconds[3 * r] = std::chrono::duration<double>(t1 - t0).count();
+    seconds[3 * r + 1] = std::chrono::duration<double>(t2 - t1).count();
+    seconds[3 * r + 2] = std::chrono::duration<double>(t3 - t2).count();
+    removed[2 * r] = n_res; removed[2 * r + 1] = n_ang;
+    again = (n_res + n_ang) > count;
+    ++r;
+  }
+  rounds[0] = r;
+  rmse[0] = rmse_of(scene);
+  for (uint64_t k = 0; k < n_obs; ++k) {
+    const auto lm = scene.structure.find(obs_point[k]);
+    obs_keep[k] = (lm != scene.structure.end() && lm->second.obs.count(obs_pose[k])) ? 1 : 0;
+  }
+  {   // (flatten_scene expects every landmark to exist: here tracks were erased - their points keep the input values)
+    std::vector<double> all(points, points + 3 * size_t(n_points));
+    SfM_Data cameras_only;
+    cameras_only.poses = scene.poses; cameras_only.intrinsics = scene.intrinsics;
+    flatten_scene(cameras_only, n_poses, n_intr, 0, poses, intrinsics, points);
+    for (const auto& lm : scene.structure)
+      for (int a = 0; a < 3; ++a) points[3 * size_t(lm.first) + a] = lm.second.X(a);
+  }
+  return 0;
+}
+
 // The reference's BAF export (sfm/sfm_data_io_baf.hpp:38-147) of the same flat scene: pins openmvg_amd.io.save_baf.
 int ref_save_baf(uint32_t n_poses, uint32_t n_intr, uint32_t n_points, uint64_t n_obs, const double* poses,
                  const double* intrinsics, const int32_t* intr_model, const double* points, const uint32_t* obs_pose,

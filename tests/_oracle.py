@@ -598,6 +598,26 @@ def ref_ba_filters_timed(scene, px_threshold=4.0, min_track_length=2, min_angle_
     return keep.astype(bool), (int(counts[0]), int(counts[1])), (float(sec[0]), float(sec[1]))
 
 
+def ref_ba_reject_loop(scene, px_threshold=4.0, count=0, max_rounds=8, num_threads=0, lib=None):
+    """oracle/ref_shim_ba.cpp::ref_ba_reject_loop: `do { Adjust } while (badTrackRejector)` on one SfM_Data.
+    -> dict(keep, poses, intrinsics, points, rounds, seconds[rounds][3], removed[rounds][2], rmse)"""
+    L = lib if lib is not None else C.CDLL(REF_BA_SO)
+    fn = L.ref_ba_reject_loop
+    fn.restype = C.c_int
+    fn.argtypes = ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 + [C.c_double, C.c_uint32, C.c_int, C.c_int] + [C.c_void_p] * 5)
+    poses, intr, model, pts, op, oi, ox, xy = _flat(scene)
+    poses = poses.copy(); intr = intr.copy(); pts = pts.copy()
+    keep = np.zeros(len(op), np.uint8); rounds = np.zeros(1, np.int32); sec = np.zeros(3 * max_rounds); rem = np.zeros(2 * max_rounds, np.uint64)
+    rmse = np.zeros(1)
+    rc = fn(len(poses), len(intr), len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data,
+            oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, float(px_threshold), int(count), int(max_rounds), int(num_threads), keep.ctypes.data,
+            rounds.ctypes.data, sec.ctypes.data, rem.ctypes.data, rmse.ctypes.data)
+    assert rc == 0, rc
+    r = int(rounds[0])
+    return dict(keep=keep.astype(bool), poses=poses, intrinsics=intr, points=pts, rounds=r, seconds=sec[:3 * r].reshape(r, 3),
+                removed=rem[:2 * r].reshape(r, 2).astype(np.int64), rmse=float(rmse[0]))
+
+
 def ref_save_baf(scene, path):
     """The reference's Save_BAF (sfm/sfm_data_io_baf.hpp) on the flat scene (oracle/ref_shim_ba.cpp::ref_save_baf)."""
     L = C.CDLL(REF_BA_SO)
@@ -688,7 +708,7 @@ def adapter():
                      "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_hash_u8",
                      "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
-        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "mvgx_adapter_ba_context_stats",
+        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
                      "mvgx_adapter_ba_release_context"):
             setattr(both, name, getattr(b, name))
         both.ba_counters = b.mvgx_adapter_counters   # (the counters of the BA half)

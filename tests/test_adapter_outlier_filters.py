@@ -118,3 +118,47 @@ def test_filter_time_after_adjust_on_the_device():
           f"({sc['n_obs']} observations, {sc['n_points']} tracks, removed {counts_r})")
     assert counts_o == counts_r and np.array_equal(keep_o, keep_r)
     assert sec_o[0] < sec_r[0] and sec_o[1] < sec_r[1]
+
+
+def _stats3(lib, reset=0):
+    out = (C.c_uint64 * 3)()
+    lib.mvgx_adapter_ba_context_stats3(out, C.c_int(reset))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def _check_reject_loop(lib, sc, monkeypatch):
+    """the whole `do { BA } while (reject)` loop on one SfM_Data: the replacement TUs (kept context: re-bound for the filters, re-bound
+    with observations switched off for the next Adjust) against the reference TUs, and against themselves with the context slot off"""
+    ref = _oracle.ref_ba_reject_loop(sc)
+    lib.mvgx_adapter_ba_release_context()
+    _stats3(lib, reset=1)
+    ours = _oracle.ref_ba_reject_loop(sc, lib=lib)
+    created, rebound, subset = _stats3(lib)
+    assert ours["rounds"] == ref["rounds"] >= 2, (ours["rounds"], ref["rounds"])
+    assert np.array_equal(ours["removed"], ref["removed"]) and np.array_equal(ours["keep"], ref["keep"])
+    assert abs(ours["rmse"] - ref["rmse"]) < 1e-6
+    # one context for the whole loop: created by the first Adjust; the residual filter re-binds it, the angle filter and every later
+    # call find the scene reduced and switch observations off
+    assert created == 1 and rebound >= 1 and subset >= ours["rounds"], (created, rebound, subset)
+    monkeypatch.setenv("MVGX_BA_CONTEXT_CACHE", "0")
+    plain = _oracle.ref_ba_reject_loop(sc, lib=lib)
+    monkeypatch.delenv("MVGX_BA_CONTEXT_CACHE")
+    assert plain["rounds"] == ours["rounds"] and np.array_equal(plain["keep"], ours["keep"])
+    assert abs(plain["rmse"] - ours["rmse"]) < 1e-9 and np.allclose(plain["points"], ours["points"], rtol=1e-7, atol=1e-8)
+    lib.mvgx_adapter_ba_release_context()
+    return ours, ref
+
+
+@needs_ref
+@pytest.mark.skipif(_oracle.adapter_ba_emu() is None, reason="openMVG tree / adapter objects not present")
+def test_reject_loop_on_one_scene_under_emulation(monkeypatch):
+    _check_reject_loop(_oracle.adapter_ba_emu(), synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=3, n_intr_groups=2, seed=91, outlier_frac=0.05, n_rings=1), monkeypatch)
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_reject_loop_on_one_scene_on_the_device(monkeypatch):
+    sc = synth.ba_scene(n_cams=60, n_points=20000, track_len=8, model=3, n_intr_groups=3, seed=63, outlier_frac=0.02)
+    ours, ref = _check_reject_loop(_oracle.adapter(), sc, monkeypatch)
+    print("rounds", ours["rounds"], "seconds per round (Adjust, residual filter, angle filter): replacement", np.round(ours["seconds"] * 1e3, 2).tolist(),
+          "ms; reference", np.round(ref["seconds"] * 1e3, 1).tolist(), "ms")
