@@ -304,9 +304,9 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
       for (int a = 0; a < 3; ++a) points[3 * j + a] = bound.points_old[3 * static_cast<size_t>(bound.point_old[j]) + a];
   // (the context goes back into the slot after the write-back: that hands the flat arrays over with it)
   struct Release {
-    mvgx_adapter::BoundContext& b; mvgx_adapter::FlatScene& fs; int device; bool plain, healthy;
-    ~Release() { mvgx_adapter::release_bound_context(b, device, fs, plain, healthy); }
-  } release{bound, fs, options_.device_, plain, rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)};   // (a context whose device calls failed is not kept)
+    mvgx_adapter::BoundContext& b; mvgx_adapter::FlatScene& fs; bool plain, healthy;
+    ~Release() { mvgx_adapter::release_bound_context(b, fs, plain, healthy); }
+  } release{bound, fs, plain, rc_read == MVGX_OK && (rc == MVGX_OK || rc == MVGX_ERR_NUMERIC)};   // (a context whose device calls failed is not kept)
   tick("read_params");
   if (rc_read != MVGX_OK) {
     OPENMVG_LOG_ERROR << "mvgx BA: " << mvgx_last_error();
@@ -381,6 +381,6 @@ extern "C" void mvgx_adapter_ba_context_stats3(uint64_t out[3], int reset) {
   if (reset) { c.created = 0; c.reused = 0; c.subset = 0; }
 }
 extern "C" void mvgx_adapter_ba_release_context() {
-  mvgx_ba_ctx* ctx = mvgx_adapter::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context is destroyed)
+  mvgx_ba_ctx* ctx = mvgx_adapter::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context and its kept arrays are destroyed)
   (void)ctx;
 }

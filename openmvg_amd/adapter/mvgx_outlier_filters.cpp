@@ -92,7 +92,7 @@ bool bind_scene(SfM_Data& sfm_data, FlatScene& fs, mvgx_adapter::BoundContext& b
   prob.obs_xy = fs.obs_xy.data();
   prob.huber_a = Square(4.0);   // (as Adjust() with its default loss: the kept context's structure does not depend on it)
   const bool inj = mvgx_adapter::injected("filters", stage);
-  const int rc = inj ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(-1, prob, fs, /* plain */ true, bound);
+  const int rc = inj ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(mvgx_adapter::kAnyDevice, prob, fs, /* plain */ true, bound);
   if (rc != MVGX_OK) {
     if (rc != MVGX_ERR_UNSUPPORTED) mvgx_adapter::device_failure(mvgx_adapter::kFilters, "outlier filters", "mvgx_ba_create", rc, inj);
     return false;
@@ -114,7 +114,7 @@ IndexT RemoveOutliers_PixelResidualError(SfM_Data& sfm_data, const double dThres
   // (the context goes back into the slot when this function is done with the flat arrays: the hand-over takes them along)
   struct Release {
     mvgx_adapter::BoundContext& b; FlatScene& fs; bool healthy;
-    ~Release() { mvgx_adapter::release_bound_context(b, -1, fs, true, healthy); }
+    ~Release() { mvgx_adapter::release_bound_context(b, fs, true, healthy); }
   } release{bound, fs, rc == MVGX_OK};
   const std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
   const std::vector<IndexT>& lm_key = fs.lm_key;
@@ -168,7 +168,7 @@ IndexT RemoveOutliers_AngleError(SfM_Data& sfm_data, const double dMinAcceptedAn
   const int rc = mvgx_ba_track_angles(bound.ctx, angle.data());
   struct Release {
     mvgx_adapter::BoundContext& b; FlatScene& fs; bool healthy;
-    ~Release() { mvgx_adapter::release_bound_context(b, -1, fs, true, healthy); }
+    ~Release() { mvgx_adapter::release_bound_context(b, fs, true, healthy); }
   } release{bound, fs, rc == MVGX_OK};
   const std::vector<Landmark*>& lm_of_point = fs.lm_of_point;
   const std::vector<IndexT>& lm_key = fs.lm_key;

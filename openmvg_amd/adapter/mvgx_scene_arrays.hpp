@@ -94,13 +94,17 @@ inline bool context_cache_enabled() {
   const char* env = std::getenv("MVGX_BA_CONTEXT_CACHE");
   return !(env && env[0] == '0');
 }
-// the idle context and its structure arrays leave the slot together (nullptr: nothing usable is kept)
-inline mvgx_ba_ctx* take_idle_context(int device, KeptStructure** kept = nullptr) {
+// the idle context and its structure arrays leave the slot together (nullptr: nothing usable is kept). kAnyDevice (the outlier
+// filters, which have no device option of their own): whatever device the kept context lives on - *device receives it.
+constexpr int kAnyDevice = -1000000;
+inline mvgx_ba_ctx* take_idle_context(int device, KeptStructure** kept = nullptr, int* device_of_context = nullptr) {
   ContextCache& c = context_cache();
   std::lock_guard<std::mutex> lock(c.mu);
   mvgx_ba_ctx* ctx = c.idle;
   KeptStructure* ks = c.kept;
   c.idle = nullptr; c.kept = nullptr;
+  if (ctx && device == kAnyDevice) device = c.device;
+  if (device_of_context) *device_of_context = device == kAnyDevice ? -1 : device;
   if (ctx && (c.device != device || !context_cache_enabled())) { mvgx_ba_destroy(ctx); ctx = nullptr; }
   if (!ctx || !kept) { delete ks; ks = nullptr; }
   if (kept) *kept = ks;
@@ -164,6 +168,7 @@ inline bool express_in_kept_structure(const KeptStructure& ks, const FlatScene& 
 struct BoundContext {
   mvgx_ba_ctx* ctx = nullptr;
   KeptStructure* kept = nullptr;     // the structure arrays that go back into the slot with the context (subset route: the old ones)
+  int device = -1;                   // where the context lives (what it goes back into the slot with)
   bool subset = false;               // the context holds the KEPT structure: parameters / residuals / angles come back in its indexing
   std::vector<uint32_t> point_old;   // subset: [new point] -> kept point
   std::vector<uint64_t> obs_old;     // subset: [new observation] -> kept observation
@@ -173,7 +178,8 @@ struct BoundContext {
 // rc of the library call that decided (MVGX_OK: bc.ctx is ready). `plain`: prob has neither control points nor priors.
 inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, bool plain, BoundContext& bc) {
   KeptStructure* ks = nullptr;
-  mvgx_ba_ctx* ctx = take_idle_context(device, &ks);
+  mvgx_ba_ctx* ctx = take_idle_context(device, &ks, &device);   // (kAnyDevice becomes the kept context's device, or -1)
+  bc.device = device;
   int rc = MVGX_ERR_STRUCTURE;
   if (ctx) {
     rc = mvgx_ba_update(ctx, &prob);
@@ -225,8 +231,9 @@ inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, 
   return rc;
 }
 // after the caller's last use of the context: back into the slot with the structure arrays it was built from
-inline void release_bound_context(BoundContext& bc, int device, FlatScene& fs, bool plain, bool healthy) {
+inline void release_bound_context(BoundContext& bc, FlatScene& fs, bool plain, bool healthy) {
   if (!bc.ctx) return;
+  const int device = bc.device;
   if (!healthy) { mvgx_ba_destroy(bc.ctx); delete bc.kept; bc.ctx = nullptr; bc.kept = nullptr; return; }
   if (!bc.subset) {   // created from / re-bound to the arrays in fs: they become the kept ones
     if (!bc.kept) bc.kept = new KeptStructure;

@@ -29,7 +29,11 @@ __device__ unsigned long long g_stamps[8];
 #endif
 
 constexpr int kN = 10;          // order of the action matrix
-constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */ + 36 /* null-space basis */;   // doubles of wave-private LDS
+constexpr int kPolyScratch = 10 * 11 /* the Hyman polynomials x_i */ + 12 /* monic coefficients */ + 20 /* roots (re | im) */ + 10 /* start radii */;
+constexpr int kScratch = 100 /* H */ + 10 /* v */ + 10 /* wr */ + 10 /* wi */ + 36 /* null-space basis */ + kPolyScratch;   // doubles of wave-private LDS
+#ifndef MVGX_FIVE_POINT_ABERTH
+#define MVGX_FIVE_POINT_ABERTH 1   // eigenvalues of the action matrix: characteristic polynomial + Ehrlich-Aberth (hqr stays as the fallback and, with 0, as the only route)
+#endif
 
 // 1 / x and 1 / sqrt(x) from v_rcp_f64 / v_rsq_f64 + two Newton steps (full precision for finite normal arguments): the iteration below
 // spent 70 % of its clocks in IEEE division and square-root sequences (~150 clocks each, all on the critical path of a single wave)
@@ -513,6 +517,197 @@ __device__ __forceinline__ void eigenvector_tail(const double* __restrict__ At, 
   tail[0] = -be; tail[1] = u[3]; tail[2] = u[4]; tail[3] = al;
 }
 
+// ---- 5e. the eigenvalues without a QR iteration (round 4) ----
+// hqr on ONE 10 x 10 matrix keeps a wave busy for ~209 k clocks of mostly scalar, dependent work (70 % of a five-point solve).
+// Here instead, from the Hessenberg form H (same eigenvalues as the action matrix):
+//   1. the characteristic polynomial by Hyman's recurrence in polynomial arithmetic: x_9 = 1,
+//      x_{i-1}(z) = ((z - h_ii) x_i(z) - sum_{j > i} h_ij x_j(z)) / h_{i,i-1},  p(z) ~ (z - h_00) x_0(z) - sum_{j >= 1} h_0j x_j(z);
+//      lane k carries coefficient k, ten steps of at most ten multiply-adds;
+//   2. all ten roots at once by the Ehrlich-Aberth iteration on the monic coefficients (lane i = root i, complex arithmetic, start
+//      radii from the Newton polygon of the coefficient moduli as in Bini's algorithm): cubic convergence, ~10 rounds of ~250
+//      instructions;
+//   3. the roots with a negligible imaginary part are polished ON THE MATRIX - Newton steps with p and p' from Hyman's recurrence
+//      evaluated on H itself (backward stable), so what the coefficients lost does not reach the eigenvalue - and must converge as
+//      real roots to count as real (Eigen's criterion is imag() == 0 of a RealSchur form: a 2 x 2 block with non-negative
+//      discriminant; the two agree unless the discriminant is within rounding of zero).
+// Anything unusual - a vanishing subdiagonal, a non-finite value, no convergence in kAberthIter rounds, two polished roots that
+// coincide - returns false and the caller runs hqr on the same H.
+constexpr int kAberthIter = 48;
+__device__ unsigned long long g_hqr_fallbacks;   // solves whose eigenvalues came from hqr after all (diagnostic: mvgx_debug_five_point_fallbacks)
+__device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.0e300; }   // (false for NaN as well)
+
+// p(x) and p'(x) up to the same constant factor, from the Hessenberg matrix in LDS (all lanes may pass different x)
+__device__ __forceinline__ void hyman(const double* __restrict__ H, const double* __restrict__ rsub /* 1 / h_{i,i-1}, i = 1..9 */, double x,
+                                      double& q, double& dq) {
+  double y[kN], dy[kN];
+  y[kN - 1] = 1.0; dy[kN - 1] = 0.0;
+#pragma unroll
+  for (int i = kN - 1; i >= 1; --i) {
+    double t = (x - H[i * kN + i]) * y[i], dt = y[i] + (x - H[i * kN + i]) * dy[i];
+#pragma unroll
+    for (int j = i + 1; j < kN; ++j) { t -= H[i * kN + j] * y[j]; dt -= H[i * kN + j] * dy[j]; }
+    y[i - 1] = t * rsub[i]; dy[i - 1] = dt * rsub[i];
+  }
+  double t = (x - H[0]) * y[0], dt = y[0] + (x - H[0]) * dy[0];
+#pragma unroll
+  for (int j = 1; j < kN; ++j) { t -= H[j] * y[j]; dt -= H[j] * dy[j]; }
+  q = t; dq = dt;
+}
+
+__device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H, double* __restrict__ wr, double* __restrict__ wi,
+                                                   double* __restrict__ ps /* kPolyScratch */, double* __restrict__ rsub /* 10: v */, int lane) {
+  double* const X = ps;              // [i][k]: coefficient k of x_i
+  double* const coef = ps + 110;     // monic: coef[k], k = 0..10
+  double* const zre = coef + 12;
+  double* const zim = zre + 10;
+  double* const rad = zim + 10;
+  // ---- 1. characteristic polynomial ----
+  bool ok = true;
+  if (lane >= 1 && lane < kN) {
+    const double h = H[lane * kN + lane - 1];
+    ok = h != 0.0 && finite_d(h);
+    rsub[lane] = ok ? 1.0 / h : 0.0;
+  }
+  if (__ballot(!ok)) return false;
+  if (lane <= kN) X[(kN - 1) * 11 + lane] = lane == 0 ? 1.0 : 0.0;
+  wave_sync();
+  for (int i = kN - 1; i >= 1; --i) {   // (uniform)
+    if (lane <= kN) {
+      double t = (lane > 0 ? X[i * 11 + lane - 1] : 0.0) - H[i * kN + i] * X[i * 11 + lane];
+      for (int j = i + 1; j < kN; ++j) t -= H[i * kN + j] * X[j * 11 + lane];
+      X[(i - 1) * 11 + lane] = t * rsub[i];
+    }
+    wave_sync();
+  }
+  double mine = 0.0;
+  if (lane <= kN) {
+    double t = (lane > 0 ? X[lane - 1] : 0.0) - H[0] * X[lane];
+#pragma unroll
+    for (int j = 1; j < kN; ++j) t -= H[j] * X[j * 11 + lane];
+    mine = t;
+  }
+  const double lead = __shfl(mine, kN);
+  if (!(lead != 0.0) || !finite_d(lead)) return false;
+  mine = mine / lead;
+  if (__ballot(lane <= kN && !finite_d(mine))) return false;
+  if (lane <= kN) coef[lane] = mine;
+  wave_sync();
+  // ---- 2a. start radii: Newton polygon of (k, log |a_k|) - its upper hull; an edge from k1 to k2 carries k2 - k1 roots of modulus
+  // (|a_k1| / |a_k2|)^(1 / (k2 - k1)). One lane walks the eleven points (gift wrapping from k = 0). ----
+  if (lane == 0) {
+    double la[kN + 1];
+#pragma unroll
+    for (int k = 0; k <= kN; ++k) { const double a = fabs(coef[k]); la[k] = a > 0.0 ? log(a) : -1.0e300; }
+    int k1 = 0;
+    while (k1 < kN) {
+      int best = k1 + 1;
+      double slope = -1.0e308;
+#pragma unroll
+      for (int k2 = 1; k2 <= kN; ++k2) {
+        if (k2 <= k1) continue;
+        double lk1 = 0.0;
+#pragma unroll
+        for (int q = 0; q <= kN; ++q) lk1 = q == k1 ? la[q] : lk1;
+        const double sl = (la[k2] - lk1) / (double)(k2 - k1);
+        if (sl >= slope) { slope = sl; best = k2; }   // (the farthest point of the steepest slope: a hull edge)
+      }
+      const double r = exp(-slope);   // (|a_k1| / |a_best|)^(1 / (best - k1))
+      for (int q = k1; q < best; ++q) rad[q] = r;
+      k1 = best;
+    }
+  }
+  wave_sync();
+  // ---- 2b. Ehrlich-Aberth ----
+  double zr = 0.0, zi = 0.0;
+  if (lane < kN) {
+    double r = rad[lane];
+    if (!(r > 1.0e-150)) r = 1.0e-150;
+    if (!(r < 1.0e150)) r = 1.0e150;
+    const double ang = 0.62831853071795865 * (double)lane + 0.7;   // 2 pi / 10 apart, off the axes
+    zr = r * cos(ang); zi = r * sin(ang);
+    zre[lane] = zr; zim[lane] = zi;
+  }
+  wave_sync();
+  bool done = lane >= kN;
+  int it = 0;
+  for (; it < kAberthIter; ++it) {   // (uniform)
+    double wr_ = 0.0, wi_ = 0.0;
+    if (lane < kN && !done) {
+      // p and p' by Horner on the monic coefficients (real) at the complex point
+      double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+      for (int k = kN - 1; k >= 0; --k) {
+        const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
+        const double npr = pr * zr - pi * zi + coef[k], npi = pr * zi + pi * zr;
+        dr = ndr; di = ndi; pr = npr; pi = npi;
+      }
+      // Newton correction N = p / p'
+      const double dn = dr * dr + di * di;
+      double nr = 0.0, ni = 0.0;
+      if (dn > 0.0 && finite_d(dn)) { const double idn = 1.0 / dn; nr = (pr * dr + pi * di) * idn; ni = (pi * dr - pr * di) * idn; }
+      // S = sum_{j != i} 1 / (z_i - z_j)
+      double sr = 0.0, si = 0.0;
+#pragma unroll
+      for (int j = 0; j < kN; ++j) {
+        const double ar = zr - zre[j], ai = zi - zim[j];
+        const double an = ar * ar + ai * ai;
+        if (j != lane && an > 0.0) { const double ia = 1.0 / an; sr += ar * ia; si -= ai * ia; }
+      }
+      // w = N / (1 - N S)
+      const double er = 1.0 - (nr * sr - ni * si), ei = -(nr * si + ni * sr);
+      const double en = er * er + ei * ei;
+      if (en > 0.0 && finite_d(en)) { const double ie = 1.0 / en; wr_ = (nr * er + ni * ei) * ie; wi_ = (ni * er - nr * ei) * ie; }
+      else { wr_ = nr; wi_ = ni; }
+    }
+    wave_sync();   // every lane has read the roots of this round
+    if (lane < kN && !done) {
+      zr -= wr_; zi -= wi_;
+      zre[lane] = zr; zim[lane] = zi;
+      const double zz = zr * zr + zi * zi, ww = wr_ * wr_ + wi_ * wi_;
+      done = ww <= 1.0e-24 * zz || (zz == 0.0 && ww == 0.0);   // |w| <= 1e-12 |z|: the real ones are polished on the matrix below
+      if (!finite_d(zz)) done = false;
+    }
+    wave_sync();
+    if (!__ballot(!done)) break;
+  }
+  if (__ballot(!done)) return false;   // no convergence (or a non-finite iterate): hqr decides
+  // ---- 3. real roots: polished on the matrix ----
+  bool real = false;
+  double x = zr;
+  if (lane < kN) {
+    const double az = sqrt(zr * zr + zi * zi);
+    real = fabs(zi) <= 1.0e-6 * az || az == 0.0;
+  }
+  bool bad = false;
+  if (real) {
+    double step = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      double q, dq;
+      hyman(H, rsub, x, q, dq);
+      step = dq != 0.0 ? q / dq : 0.0;
+      x -= step;
+    }
+    // a root that is real converges quadratically from here; one that is not (a conjugate pair close to the axis) does not
+    const bool converged = fabs(step) <= 1.0e-9 * fabs(x) + 1.0e-300 && finite_d(x);
+    if (!converged) { if (fabs(zi) <= 1.0e-12 * fabs(zr)) bad = true; real = false; }   // (an essentially real root that does not polish: let hqr decide)
+  }
+  if (__ballot(bad)) return false;
+  // two polished roots on the same value: a double root or a pair drawn together - hqr decides
+  if (lane < kN) { zre[lane] = real ? x : 0.0; zim[lane] = real ? 0.0 : 1.0; }
+  wave_sync();
+  bool dup = false;
+  if (real) {
+#pragma unroll
+    for (int j = 0; j < kN; ++j)
+      if (j != lane && zim[j] == 0.0 && fabs(zre[j] - x) <= 1.0e-10 * fabs(x)) dup = true;
+  }
+  if (__ballot(dup)) return false;
+  if (lane < kN) { wr[lane] = real ? x : zr; wi[lane] = real ? 0.0 : (zi != 0.0 ? zi : 1.0); }
+  wave_sync();
+  return true;
+}
+
 // FivePointSolver::Solve on the sample s[0..4] (wave-uniform). scr: kScratch doubles of wave-private LDS. The essential matrices of
 // the real solutions (row-major 3 x 3) go to Es[model][9] (LDS, 10 x 9 doubles); returns their number (wave-uniform).
 __device__ __forceinline__ int solve(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[7], int lane,
@@ -552,7 +747,14 @@ __device__ __forceinline__ int solve(const double* __restrict__ b1, const double
   for (int c = 0; c < kN; ++c) At_row[c] = H[(lane < kN ? lane : 0) * kN + c];
   hessenberg(H, v, lane);
   FP_STAMP(3);
+#if MVGX_FIVE_POINT_ABERTH
+  if (!eigenvalues_aberth(H, wr, wi, basis_lds + 36, v, lane)) {   // (reads H only: the fallback starts from the same matrix)
+    if (lane == 0) atomicAdd(&g_hqr_fallbacks, 1ull);
+    if (!hqr(H, wr, wi, lane)) return 0;
+  }
+#else
   if (!hqr(H, wr, wi, lane)) return 0;
+#endif
   FP_STAMP(4);
   // the action matrix again (the iteration worked in place), then one eigenvector per lane
 #pragma unroll

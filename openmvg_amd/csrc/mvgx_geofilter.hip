@@ -1020,6 +1020,14 @@ __global__ void five_point_debug_kernel(const double* b1, const double* b2, doub
   for (int e = lane; e < 9 * n; e += 64) Es_out[e] = scr[five_point::kScratch + e];
   if (lane == 0) *n_out = n;
 }
+// diagnostic (not declared in include/mvgx.h): five-point solves of this process whose eigenvalues fell back to hqr; reset != 0 clears
+int mvgx_debug_five_point_fallbacks(unsigned long long* out, int reset) {
+  unsigned long long v = 0;
+  MVGX_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(five_point::g_hqr_fallbacks), sizeof(v)));
+  if (out) *out = v;
+  if (reset) { v = 0; MVGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(five_point::g_hqr_fallbacks), &v, sizeof(v))); }
+  return MVGX_OK;
+}
 int mvgx_debug_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
   MVGX_REQUIRE(b1 && b2 && Es_out && n_out, MVGX_ERR_ARG, "mvgx_debug_five_point: NULL argument");
   int rc = mvgx::select_device(-1);

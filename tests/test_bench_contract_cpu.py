@@ -11,7 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _latest():
     files = glob.glob(os.path.join(ROOT, "profiles", "round*_bench_call*.json"))
     assert files
-    return max(files, key=lambda p: int(re.search(r"call(\d+)", p).group(1)))
+    def key(p):   # round, then the call numbering (round 4 restarted it: ..._call_r4_NN follows ..._callNNN)
+        m = re.search(r"round(\d+)_bench_call(_r\d+_)?(\d+)", os.path.basename(p))
+        return (int(m.group(1)), 1 if m.group(2) else 0, int(m.group(3)))
+    return max(files, key=key)
 
 
 def test_recorded_bench_line_has_the_contract_fields():
