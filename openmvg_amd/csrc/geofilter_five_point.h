@@ -536,7 +536,8 @@ constexpr int kAberthIter = 48;
 __device__ unsigned long long g_hqr_fallbacks;   // solves whose eigenvalues came from hqr after all (diagnostic: mvgx_debug_five_point_fallbacks)
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.0e300; }   // (false for NaN as well)
 
-// p(x) and p'(x) up to the same constant factor, from the Hessenberg matrix in LDS (all lanes may pass different x)
+// p(x) and p'(x) up to the same constant factor, from the Hessenberg matrix in LDS (every lane may pass its own x): Hyman's
+// recurrence and its derivative, backward stable (a difference quotient of p instead of p' lost one sample in 20 000 to cancellation)
 __device__ __forceinline__ void hyman(const double* __restrict__ H, const double* __restrict__ rsub /* 1 / h_{i,i-1}, i = 1..9 */, double x,
                                       double& q, double& dq) {
   double y[kN], dy[kN];
@@ -594,21 +595,16 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
   wave_sync();
   // ---- 2a. start radii: Newton polygon of (k, log |a_k|) - its upper hull; an edge from k1 to k2 carries k2 - k1 roots of modulus
   // (|a_k1| / |a_k2|)^(1 / (k2 - k1)). One lane walks the eleven points (gift wrapping from k = 0). ----
+  if (lane <= kN) { const double a = fabs(coef[lane]); X[lane] = a > 0.0 ? log(a) : -1.0e300; }   // (region X is free: log |a_k|)
+  wave_sync();
   if (lane == 0) {
-    double la[kN + 1];
-#pragma unroll
-    for (int k = 0; k <= kN; ++k) { const double a = fabs(coef[k]); la[k] = a > 0.0 ? log(a) : -1.0e300; }
     int k1 = 0;
     while (k1 < kN) {
       int best = k1 + 1;
       double slope = -1.0e308;
-#pragma unroll
-      for (int k2 = 1; k2 <= kN; ++k2) {
-        if (k2 <= k1) continue;
-        double lk1 = 0.0;
-#pragma unroll
-        for (int q = 0; q <= kN; ++q) lk1 = q == k1 ? la[q] : lk1;
-        const double sl = (la[k2] - lk1) / (double)(k2 - k1);
+      const double lk1 = X[k1];
+      for (int k2 = k1 + 1; k2 <= kN; ++k2) {
+        const double sl = (X[k2] - lk1) / (double)(k2 - k1);
         if (sl >= slope) { slope = sl; best = k2; }   // (the farthest point of the steepest slope: a hull edge)
       }
       const double r = exp(-slope);   // (|a_k1| / |a_best|)^(1 / (best - k1))
@@ -635,7 +631,7 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
     if (lane < kN && !done) {
       // p and p' by Horner on the monic coefficients (real) at the complex point
       double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll
+#pragma unroll 1
       for (int k = kN - 1; k >= 0; --k) {
         const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
         const double npr = pr * zr - pi * zi + coef[k], npi = pr * zi + pi * zr;
@@ -644,19 +640,19 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
       // Newton correction N = p / p'
       const double dn = dr * dr + di * di;
       double nr = 0.0, ni = 0.0;
-      if (dn > 0.0 && finite_d(dn)) { const double idn = 1.0 / dn; nr = (pr * dr + pi * di) * idn; ni = (pi * dr - pr * di) * idn; }
+      if (dn > 0.0 && finite_d(dn)) { const double idn = frcp(dn); nr = (pr * dr + pi * di) * idn; ni = (pi * dr - pr * di) * idn; }
       // S = sum_{j != i} 1 / (z_i - z_j)
       double sr = 0.0, si = 0.0;
-#pragma unroll
+#pragma unroll 1
       for (int j = 0; j < kN; ++j) {
         const double ar = zr - zre[j], ai = zi - zim[j];
         const double an = ar * ar + ai * ai;
-        if (j != lane && an > 0.0) { const double ia = 1.0 / an; sr += ar * ia; si -= ai * ia; }
+        if (j != lane && an > 0.0) { const double ia = frcp(an); sr += ar * ia; si -= ai * ia; }
       }
       // w = N / (1 - N S)
       const double er = 1.0 - (nr * sr - ni * si), ei = -(nr * si + ni * sr);
       const double en = er * er + ei * ei;
-      if (en > 0.0 && finite_d(en)) { const double ie = 1.0 / en; wr_ = (nr * er + ni * ei) * ie; wi_ = (ni * er - nr * ei) * ie; }
+      if (en > 0.0 && finite_d(en)) { const double ie = frcp(en); wr_ = (nr * er + ni * ei) * ie; wi_ = (ni * er - nr * ei) * ie; }
       else { wr_ = nr; wi_ = ni; }
     }
     wave_sync();   // every lane has read the roots of this round
@@ -682,10 +678,10 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
   if (real) {
     double step = 0.0;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 3; ++k) {   // (from the 1e-12 the iteration above stops at - or whatever the coefficients cost - to rounding)
       double q, dq;
       hyman(H, rsub, x, q, dq);
-      step = dq != 0.0 ? q / dq : 0.0;
+      step = dq != 0.0 ? q * frcp(dq) : 0.0;
       x -= step;
     }
     // a root that is real converges quadratically from here; one that is not (a conjugate pair close to the axis) does not
