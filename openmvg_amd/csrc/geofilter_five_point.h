@@ -631,10 +631,13 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
     if (lane < kN && !done) {
       // p and p' by Horner on the monic coefficients (real) at the complex point
       double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll 1
+      double a[kN];   // (the coefficients first: a load per step in front of its multiply-adds was a chain of LDS latencies)
+#pragma unroll
+      for (int k = 0; k < kN; ++k) a[k] = coef[k];
+#pragma unroll
       for (int k = kN - 1; k >= 0; --k) {
         const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
-        const double npr = pr * zr - pi * zi + coef[k], npi = pr * zi + pi * zr;
+        const double npr = pr * zr - pi * zi + a[k], npi = pr * zi + pi * zr;
         dr = ndr; di = ndi; pr = npr; pi = npi;
       }
       // Newton correction N = p / p'
@@ -643,11 +646,14 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
       if (dn > 0.0 && finite_d(dn)) { const double idn = frcp(dn); nr = (pr * dr + pi * di) * idn; ni = (pi * dr - pr * di) * idn; }
       // S = sum_{j != i} 1 / (z_i - z_j)
       double sr = 0.0, si = 0.0;
-#pragma unroll 1
-      for (int j = 0; j < kN; ++j) {
-        const double ar = zr - zre[j], ai = zi - zim[j];
-        const double an = ar * ar + ai * ai;
-        if (j != lane && an > 0.0) { const double ia = frcp(an); sr += ar * ia; si -= ai * ia; }
+      {
+        double ar[kN], ai[kN], ia[kN];   // (all ten reciprocals in flight: one at a time the loop was a chain of LDS and v_rcp latencies)
+#pragma unroll
+        for (int j = 0; j < kN; ++j) { ar[j] = zr - zre[j]; ai[j] = zi - zim[j]; }
+#pragma unroll
+        for (int j = 0; j < kN; ++j) { const double an = ar[j] * ar[j] + ai[j] * ai[j]; ia[j] = (j != lane && an > 0.0) ? frcp(an) : 0.0; }
+#pragma unroll
+        for (int j = 0; j < kN; ++j) { sr += ar[j] * ia[j]; si -= ai[j] * ia[j]; }
       }
       // w = N / (1 - N S)
       const double er = 1.0 - (nr * sr - ni * si), ei = -(nr * si + ni * sr);
