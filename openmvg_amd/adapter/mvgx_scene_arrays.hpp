@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -27,12 +28,26 @@ using openMVG::sfm::Landmarks;
 using openMVG::sfm::SfM_Data;
 using openMVG::sfm::View;
 
-// f(item, worker) for item in [0, n) on the library's host workers
+// f(item, worker) for item in [0, n) on the library's host workers. An exception out of f (the reference's own .at() in a
+// borderline re-evaluation, a bad_alloc) must not unwind through the C frames of the library or end a worker thread: the first one
+// is carried back and rethrown on the calling thread, the remaining items are skipped.
 template <class F>
 void host_parallel(uint64_t n, F&& f) {
   using Fn = typename std::remove_reference<F>::type;
   if (n <= 1) { for (uint64_t i = 0; i < n; ++i) f(i, 0u); return; }
-  mvgx_host_parallel_for(n, 0, [](void* u, uint64_t i, unsigned w) { (*static_cast<Fn*>(u))(i, w); }, &f);
+  struct Job { Fn* f; std::atomic<bool> failed{false}; std::mutex mu; std::exception_ptr error; } job;
+  job.f = &f;
+  mvgx_host_parallel_for(n, 0, [](void* u, uint64_t i, unsigned w) {
+    Job& j = *static_cast<Job*>(u);
+    if (j.failed.load(std::memory_order_relaxed)) return;
+    try { (*j.f)(i, w); }
+    catch (...) {
+      std::lock_guard<std::mutex> lock(j.mu);
+      if (!j.error) j.error = std::current_exception();
+      j.failed.store(true);
+    }
+  }, &job);
+  if (job.error) std::rethrow_exception(job.error);
 }
 
 // The flattened scene of a call (see Adjust): one store per calling thread, capacity kept between calls.
