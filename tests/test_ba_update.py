@@ -11,6 +11,9 @@ from openmvg_amd import ba_options as bo
 from tests import _emu
 
 
+_MAX_ITERATIONS = 4   # (the emulation runs an LM iteration in about a second: equality of the two sides does not need a converged solve)
+
+
 def _perturbed(sc, seed):
     """same structure, other values: parameters, image points"""
     rng = np.random.default_rng(seed)
@@ -24,7 +27,7 @@ def _perturbed(sc, seed):
 
 
 def _run(ctx):
-    s = ctx.solve()
+    s = ctx.solve(ba.default_options(max_num_iterations=_MAX_ITERATIONS))
     return (s.num_iterations, s.num_successful_steps, s.termination, s.initial_cost, s.final_cost, s.final_rmse) + tuple(ctx.read_params())
 
 
@@ -84,7 +87,7 @@ def _check_structure_change_is_refused(sc):
 
 
 def _scene():
-    return synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=3, n_intr_groups=2, seed=41, rot_deg=0.3)
+    return synth.ba_scene(n_cams=6, n_points=48, track_len=4, model=3, n_intr_groups=2, seed=41, rot_deg=0.3)
 
 
 def test_update_equals_create_emulated():
@@ -94,7 +97,7 @@ def test_update_equals_create_emulated():
 
 def test_update_with_unsorted_observations_weights_and_priors_emulated():
     """the caller's list not in point order (the permutation of create is reused), control points with weights, pose priors"""
-    sc = synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=1, n_intr_groups=1, seed=43, rot_deg=0.3)
+    sc = synth.ba_scene(n_cams=6, n_points=40, track_len=4, model=1, n_intr_groups=1, seed=43, rot_deg=0.3)
     rng = np.random.default_rng(5)
     perm = rng.permutation(int(sc["n_obs"]))
     for k in ("obs_pose", "obs_intr", "obs_point"):
@@ -106,9 +109,9 @@ def test_update_with_unsorted_observations_weights_and_priors_emulated():
     is_ctrl = ctrl_pts[sc["obs_point"]].astype(np.uint8)
     sc["obs_is_control"] = is_ctrl
     sc["obs_weight"] = np.where(is_ctrl, 20.0, 0.0)
-    sc["prior_pose"] = np.arange(5, dtype=np.uint32)
-    sc["prior_center"] = rng.normal(0, 1, 15)
-    sc["prior_weight"] = np.full(15, 0.5)
+    sc["prior_pose"] = np.arange(4, dtype=np.uint32)
+    sc["prior_center"] = rng.normal(0, 1, 12)
+    sc["prior_weight"] = np.full(12, 0.5)
     sc["prior_huber_a"] = 0.25
     with _emu.emulated():
         sc2 = _perturbed(sc, 9)
@@ -177,7 +180,7 @@ def test_update_is_cheaper_than_create_on_the_device():
     assert t_update < 0.5 * t_create
 
 
-@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("case", range(4))
 def test_update_of_degenerate_problems_emulated(case):
     """the edge scenes of tests/test_ba_emu_cpu.py (no observations, unused blocks, everything constant ...): re-binding each to
     itself repeats its solve; none of them is taken for another's structure"""
@@ -189,7 +192,7 @@ def test_update_of_degenerate_problems_emulated(case):
         first = _run(c)
         assert c.update(sc, **masks) is True, name
         assert _same(_run(c), first), name
-        other_name, other, other_masks = scenes[(case + 1) % len(scenes)]
+        other_name, other, other_masks = scenes[(case + 1) % 4]
         same_structure = all(np.array_equal(np.asarray(sc[k]), np.asarray(other[k])) for k in ("obs_pose", "obs_intr", "obs_point", "intr_model")) and \
             all(int(sc[k]) == int(other[k]) for k in ("n_poses", "n_intrinsics", "n_points")) and \
             bool(masks.get("points_constant", False)) == bool(other_masks.get("points_constant", False))
@@ -253,7 +256,7 @@ def test_subset_equals_the_reduced_scene_emulated():
 
 
 def test_subset_with_unsorted_observations_and_constant_intrinsics_emulated():
-    sc = synth.ba_scene(n_cams=8, n_points=90, track_len=4, model=1, n_intr_groups=2, seed=47, rot_deg=0.3)
+    sc = synth.ba_scene(n_cams=6, n_points=48, track_len=4, model=1, n_intr_groups=2, seed=47, rot_deg=0.3)
     perm = np.random.default_rng(2).permutation(int(sc["n_obs"]))
     for k in ("obs_pose", "obs_intr", "obs_point"):
         sc[k] = np.ascontiguousarray(sc[k][perm])
