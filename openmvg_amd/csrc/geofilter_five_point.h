@@ -301,7 +301,7 @@ __device__ __forceinline__ bool action_matrix(const double (&m_in)[20], int lane
 
 // ---- 5a. Householder reduction of H (LDS) to upper Hessenberg form; v = 10 doubles of LDS ----
 __device__ __forceinline__ void hessenberg(double* __restrict__ H, double* __restrict__ v, int lane) {
-#pragma unroll 1
+#pragma unroll
   for (int k = 0; k < kN - 2; ++k) {
     double s = 0.0;
     for (int i = k + 2; i < kN; ++i) { const double t = H[i * kN + k]; s += t * t; }   // (wave-uniform reads)
@@ -534,6 +534,9 @@ __device__ __forceinline__ void eigenvector_tail(const double* __restrict__ At, 
 // coincide - returns false and the caller runs hqr on the same H.
 constexpr int kAberthIter = 48;
 __device__ unsigned long long g_hqr_fallbacks;   // solves whose eigenvalues came from hqr after all (diagnostic: mvgx_debug_five_point_fallbacks)
+#ifdef MVGX_FIVE_POINT_COUNT_ROUNDS
+__device__ unsigned long long g_aberth_rounds, g_aberth_solves;
+#endif
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.0e300; }   // (false for NaN as well)
 
 // p(x) and p'(x) up to the same constant factor, from the Hessenberg matrix in LDS (every lane may pass its own x): Hyman's
@@ -572,9 +575,11 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
   if (__ballot(!ok)) return false;
   if (lane <= kN) X[(kN - 1) * 11 + lane] = lane == 0 ? 1.0 : 0.0;
   wave_sync();
-  for (int i = kN - 1; i >= 1; --i) {   // (uniform)
+#pragma unroll
+  for (int i = kN - 1; i >= 1; --i) {   // (uniform; unrolled: the reads of a step are then in flight together)
     if (lane <= kN) {
       double t = (lane > 0 ? X[i * 11 + lane - 1] : 0.0) - H[i * kN + i] * X[i * 11 + lane];
+#pragma unroll
       for (int j = i + 1; j < kN; ++j) t -= H[i * kN + j] * X[j * 11 + lane];
       X[(i - 1) * 11 + lane] = t * rsub[i];
     }
@@ -595,20 +600,28 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
   wave_sync();
   // ---- 2a. start radii: Newton polygon of (k, log |a_k|) - its upper hull; an edge from k1 to k2 carries k2 - k1 roots of modulus
   // (|a_k1| / |a_k2|)^(1 / (k2 - k1)). One lane walks the eleven points (gift wrapping from k = 0). ----
-  if (lane <= kN) { const double a = fabs(coef[lane]); X[lane] = a > 0.0 ? log(a) : -1.0e300; }   // (region X is free: log |a_k|)
-  wave_sync();
-  if (lane == 0) {
+  {
+    // lane k2 holds log |a_k2| and computes its slope from the current hull vertex k1; the steepest slope, farthest point on ties,
+    // is the next vertex (wave maximum of a key), its k2 - k1 roots get the modulus exp(-slope): one step per hull edge
+    const double la = (lane <= kN && fabs(mine) > 0.0) ? log(fabs(mine)) : -1.0e300;
     int k1 = 0;
-    while (k1 < kN) {
-      int best = k1 + 1;
-      double slope = -1.0e308;
-      const double lk1 = X[k1];
-      for (int k2 = k1 + 1; k2 <= kN; ++k2) {
-        const double sl = (X[k2] - lk1) / (double)(k2 - k1);
-        if (sl >= slope) { slope = sl; best = k2; }   // (the farthest point of the steepest slope: a hull edge)
-      }
-      const double r = exp(-slope);   // (|a_k1| / |a_best|)^(1 / (best - k1))
-      for (int q = k1; q < best; ++q) rad[q] = r;
+#pragma unroll 1
+    while (k1 < kN) {   // (uniform)
+      const double lk1 = shfl_f64(la, k1);
+      const bool cand = lane > k1 && lane <= kN;
+      const double sl = cand ? (la - lk1) * frcp((double)(lane - k1)) : -1.0e308;
+      // order-preserving key of the slope (doubles of one sign compare like their bit patterns; negative ones reversed), low 4 bits: k2
+      unsigned long long bits = (unsigned long long)__double_as_longlong(sl);
+      bits = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+      const uint32_t hi = (uint32_t)(bits >> 32);
+      const uint32_t best_hi = wave_max_u32(cand ? hi : 0u);
+      const uint32_t lo = (cand && hi == best_hi) ? (((uint32_t)bits & ~15u) | (uint32_t)lane) : 0u;
+      const uint32_t best_lo = wave_max_u32(lo);
+      const int best = (int)(best_lo & 15u);
+      if (best <= k1) break;   // (cannot happen: lane kN is always a candidate)
+      const double slope = shfl_f64(sl, best);
+      const double r = exp(-slope);
+      if (lane >= k1 && lane < best) rad[lane] = r;
       k1 = best;
     }
   }
@@ -672,6 +685,9 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
     wave_sync();
     if (!__ballot(!done)) break;
   }
+#ifdef MVGX_FIVE_POINT_COUNT_ROUNDS
+  if (lane == 0) { atomicAdd(&g_aberth_rounds, (unsigned long long)(it + 1)); atomicAdd(&g_aberth_solves, 1ull); }
+#endif
   if (__ballot(!done)) return false;   // no convergence (or a non-finite iterate): hqr decides
   // ---- 3. real roots: polished on the matrix ----
   bool real = false;
@@ -684,7 +700,7 @@ __device__ __forceinline__ bool eigenvalues_aberth(const double* __restrict__ H,
   if (real) {
     double step = 0.0;
 #pragma unroll 1
-    for (int k = 0; k < 3; ++k) {   // (from the 1e-12 the iteration above stops at - or whatever the coefficients cost - to rounding)
+    for (int k = 0; k < 2; ++k) {   // (from the 1e-12 the iteration above stops at - or whatever the coefficients cost - to rounding)
       double q, dq;
       hyman(H, rsub, x, q, dq);
       step = dq != 0.0 ? q * frcp(dq) : 0.0;

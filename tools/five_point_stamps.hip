@@ -60,6 +60,11 @@ int main() {
     unsigned long long st[8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(five_point::g_stamps), sizeof(st));
     std::vector<int> n(N); hipMemcpy(n.data(), dn, N * 4, hipMemcpyDeviceToHost);
     double mean = 0; for (int v : n) mean += v;
+#ifdef MVGX_FIVE_POINT_COUNT_ROUNDS
+    { unsigned long long r = 0, sv = 0;
+      hipMemcpyFromSymbol(&r, HIP_SYMBOL(five_point::g_aberth_rounds), sizeof(r)); hipMemcpyFromSymbol(&sv, HIP_SYMBOL(five_point::g_aberth_solves), sizeof(sv));
+      printf("Aberth rounds per solve (cumulative over the launches): %.2f\n", sv ? (double)r / (double)sv : 0.0); }
+#endif
     printf("%d solves in %.2f ms = %.0f ns per solve per device; mean models %.2f; clocks per solve: nullspace %llu | constraints %llu | gauss-jordan %llu | hessenberg %llu | hqr %llu | eigenvectors %llu\n",
            N, ms, ms * 1e6 / N, mean / N, st[0] / N, st[1] / N, st[2] / N, st[3] / N, st[4] / N, st[5] / N);
   }
