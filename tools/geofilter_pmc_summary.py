@@ -5,7 +5,7 @@ instruction mix per a-contrario iteration.  geofilter_pmc_summary.py <dir> > (pr
 import json, os, re, sys
 d = sys.argv[1]
 out = {}
-for m in "fh":
+for m in "fhe":
     try:
         a = json.load(open(os.path.join(d, f"geofilter_{m}_pmc_a.json"))); b = json.load(open(os.path.join(d, f"geofilter_{m}_pmc_b.json")))
     except OSError as e:

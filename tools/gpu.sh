@@ -38,8 +38,8 @@ for mode in "$@"; do
     python tools/pmc_kernels.py "$O/pmc_busy" --note "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 0 (headline leg)" > "$O/match_filter_busy_pmc.json" 2> "$O/matchbusy.err"
     python tools/filter_busy_summary.py "$O/match_filter_busy_pmc.json" $(find "$O/pmc_busy" -name "*kernel_trace.csv" | head -1) > "$O/match_filter_mfma_busy.json" 2>> "$O/matchbusy.err"
     grep -E "busy_frac|clock_ghz|valu_per_mfma|busy_x_clock" "$O/match_filter_mfma_busy.json"; rm -rf "$O/pmc_busy" ;;
-  geopmc)     # SQ counters of the geometric-filter kernel (F and H), two passes each
-    for m in f h; do
+  geopmc)     # SQ counters of the geometric-filter kernel (F, H and E), two passes each
+    for m in f h e; do
       pmc geo_a_$m "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" python "$R/tools/geofilter_run.py" 20000 250 $m
       pmc geo_b_$m "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" python "$R/tools/geofilter_run.py" 20000 250 $m
       python tools/pmc_kernels.py "$O/pmc_geo_a_$m" --note "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -- python tools/geofilter_run.py 20000 250 $m" > "$O/geofilter_${m}_pmc_a.json" 2> "$O/geo_a_$m.err"
