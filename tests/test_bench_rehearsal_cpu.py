@@ -57,11 +57,3 @@ def test_bench_two_ranks_rehearsal_prints_one_well_formed_line():
     if _oracle.have_ref_ba():
         cb = ba["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["rmse_diff_vs_reference"] < 1e-6, cb
-
-
-@pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, "tests", "native", "hipemu")), reason="HIP emulation sources absent")
-def test_bench_one_rank_rehearsal_line():
-    d = _run_bench(1, ("--no-ba-c5",))
-    assert d["rehearsal"] is True and d["n_gpus"] == 1 and d["scaling"] == "weak"
-    assert d["parity"]["identical"] is True and d["cpu_baseline"]["kind"] in ("reference", "port")
-    assert d["ba"]["exchange"]["ranks"] == 1 and d["ba"]["rccl_ranks"] == 0
