@@ -320,6 +320,14 @@ __device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const
   return solve_cubic(P[2] / P[3], P[1] / P[3], P[0] / P[3], roots);
 }
 
+// MVGX_GEO_STAMPS (measurement build): shader clocks of lane 0 between the stages of an a-contrario iteration, summed over all waves:
+// 0 sampling | 1 minimal solver | 2 residuals + histogram | 3 NFA over the bins | 4 inlier count of a better model | 5 loop control, pool
+#ifdef MVGX_GEO_STAMPS
+__device__ unsigned long long g_geo_stamps[8];
+#define GEO_STAMP(i) do { const long long t_now_ = __builtin_amdgcn_s_memtime(); geo_acc_[i] += (unsigned long long)(t_now_ - t_geo_); t_geo_ = t_now_; } while (0)   // (per wave, in registers: one atomic per stage and wave at the end)
+#else
+#define GEO_STAMP(i) do { } while (0)
+#endif
 // float logcombi(k, n) (robust_estimator_ACRansac.hpp:58-72) on the shared table of log10 values
 __device__ __forceinline__ float logcombi(uint32_t k, uint32_t n, const float* __restrict__ l10) {
   if (k >= n) return 0.f;
@@ -460,6 +468,10 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
   unsigned nIter = max_iterations - (unsigned)nIterReserve;
   bool ac_mode = false;
   uint32_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+#ifdef MVGX_GEO_STAMPS
+  unsigned long long geo_acc_[6] = {0, 0, 0, 0, 0, 0};
+  long long t_geo_ = __builtin_amdgcn_s_memtime();
+#endif
   for (unsigned iter = 0; iter < nIter && iter < max_iterations; ++iter) {
     // ---- sample (rand_sampling.hpp) ----
     if (ac_mode) {
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         }
       }
     }
+    GEO_STAMP(0);
     // ---- fit, evaluate ----
     double F1[9], F2[9], roots[3] = {0.0, 0.0, 0.0};
     int nm = 1;
@@ -514,6 +527,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
     } else {
       nm = seven_point(x1, x2, s, lane, F1, F2, roots);
     }
+    GEO_STAMP(1);
     bool better = false;
     ++n_iter_run; n_models_run += (uint32_t)nm;
     for (int mi = 0; mi < nm; ++mi) {
@@ -545,6 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       }
       if (!ac_mode && (double)n_le > 2.5 * kMin) ac_mode = true;   // MAX-CONSENSUS warm-up (:404-414)
       wave_sync();
+      GEO_STAMP(2);
       if (ac_mode) {   // ComputeNFA_and_inliers, quantified form (:196-262): lane b evaluates bin b, the first bin of minimal NFA wins
         uint32_t cum = 0;
 #pragma unroll
@@ -561,6 +576,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
           const double v = lane_value_f64(cur, b);
           if (v < cb_nfa) { cb_nfa = v; cb_thr = lane_value_f64(my_bin_value, b); }
         }
+        GEO_STAMP(3);
         if (cb_nfa < minNFA) {   // the inlier list is rebuilt even if it then turns out too short (the reference's behaviour)
           const uint32_t cnt = count_within<MODEL>(F, x1, x2, n, cb_thr, lane);
           wave_sync();
@@ -578,6 +594,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         }
       }
     }
+    GEO_STAMP(4);
     // ---- loop control (:445-474) ----
     if (!ac_mode && iter > (unsigned)(nIterReserve * 2)) { nIter = 0; continue; }
     if (ac_mode && ((better && minNFA < 0) || ((iter + 1) == nIter && nIterReserve > 0))) {
@@ -600,7 +617,11 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         if (nIterReserve) { nIter = iter + 1 + (unsigned)nIterReserve; nIterReserve = 0; }
       }
     }
+    GEO_STAMP(5);
   }
+#ifdef MVGX_GEO_STAMPS
+  if (lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_geo_stamps[k], geo_acc_[k]); }
+#endif
   if (minNFA >= 0) inl_count = 0;   // no meaningful model (:477-478)
   const bool good = (double)inl_count > kMin * 2.5;   // F_ACRobust.hpp:103, H_ACRobust.hpp:98
   {
@@ -1028,6 +1049,15 @@ int mvgx_debug_five_point_fallbacks(unsigned long long* out, int reset) {
   if (reset) { v = 0; MVGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(five_point::g_hqr_fallbacks), &v, sizeof(v))); }
   return MVGX_OK;
 }
+#ifdef MVGX_GEO_STAMPS
+int mvgx_debug_geo_stamps(unsigned long long* out8, int reset) {
+  unsigned long long v[8];
+  MVGX_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_geo_stamps), sizeof(v)));
+  for (int k = 0; k < 8; ++k) out8[k] = v[k];
+  if (reset) { for (auto& x : v) x = 0; MVGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_geo_stamps), v, sizeof(v))); }
+  return MVGX_OK;
+}
+#endif
 int mvgx_debug_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
   MVGX_REQUIRE(b1 && b2 && Es_out && n_out, MVGX_ERR_ARG, "mvgx_debug_five_point: NULL argument");
   int rc = mvgx::select_device(-1);

@@ -18,3 +18,13 @@ else:
     mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
 print("model", model, "pairs", n_pairs, "kernel_ms", st.kernel_ms, "ok", int(st.n_pairs_ok), "iterations", int(st.n_iterations), "models", int(st.n_models),
       "wave_clocks", int(st.wave_clocks))
+# a measurement build of the library (-DMVGX_GEO_STAMPS, MVGX_LIB_PATH): shader clocks per stage of an a-contrario iteration
+from openmvg_amd import _capi
+if hasattr(_capi.lib(), "mvgx_debug_geo_stamps"):
+    import ctypes as C
+    out = (C.c_ulonglong * 8)()
+    _capi.lib().mvgx_debug_geo_stamps(out, 1)
+    names = ["sampling", "minimal solver", "residuals + histogram", "NFA over the bins", "inliers of a better model", "loop control, pool"]
+    tot = float(sum(out[:6])) or 1.0
+    print("stage clocks per iteration:", {nm: round(out[k] / max(int(st.n_iterations), 1)) for k, nm in enumerate(names)},
+          "shares:", {nm: round(out[k] / tot, 3) for k, nm in enumerate(names)})
