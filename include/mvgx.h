@@ -209,6 +209,13 @@ int mvgx_cascade_set_option(mvgx_cascade_ctx* ctx, const char* key /* "batch_pai
 int mvgx_cascade_set_regions(mvgx_cascade_ctx* ctx, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
                              const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
                              uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket);
+/* ... for the other scalar region types Cascade_Hashing_Matcher_Regions.cpp:233-262 accepts (ABI 9): scalar_type 0 = uint8 rows of
+ * 128 (SIFT_Regions) or 144 bytes (AKAZE_Liop_Regions), 1 = float rows of length 64 (AKAZE_Float_Regions: the ten candidates are
+ * ranked by L2<float> in the reference's summation order, the ratio test runs on the float distances). hash_bytes = (dim + 7) / 8:
+ * CascadeHasher::Init(dimension) makes one code bit per dimension. The hashing stage of these types stays with the caller. */
+int mvgx_cascade_set_regions_typed(mvgx_cascade_ctx* ctx, int scalar_type, const void* const* desc_rows, const uint8_t* const* hash_codes,
+                                   const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                                   uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket);
 /* The HASHING stage on the device (cascade_hasher.hpp:120-163 Init, :179-239 CreateHashedDescriptions) in place of
  * mvgx_cascade_set_regions: the projections are generated like CascadeHasher::Init(dim, n_groups, bits_per_bucket, random_seed)
  * (std::mt19937 + std::normal_distribution<>, the reference's default seed is 5489), every descriptor is centred on zero_mean

@@ -167,6 +167,8 @@ PROTOTYPES = {
     "mvgx_cascade_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mvgx_cascade_set_regions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "mvgx_cascade_set_regions_typed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mvgx_cascade_hash_regions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mvgx_cascade_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.POINTER(MatchStats)]),

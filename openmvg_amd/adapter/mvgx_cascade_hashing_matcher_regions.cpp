@@ -15,8 +15,10 @@
 //       bit-identical - tests/test_cascade.py, tests/test_adapter_*.py);
 //     * the matching stage :166-215 - bucket candidates, Hamming ranking of the hash codes, exact L2 on the ten best, the two
 //       nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
-// 128-byte uint8 regions (SIFT) take that route. Other scalar regions (float descriptors, other lengths) keep working through
-// the reference's own CascadeHasher::Match_HashedDescriptions on the host: that code is not part of the accelerated path.
+// 128-byte uint8 regions (SIFT) take that route. 144-byte uint8 (AKAZE_Liop_Regions) and 64-float regions (AKAZE_Float_Regions) keep
+// the hashing stage on the host (CreateHashedDescriptions, once per image) and run the matching stage (per pair) on the device:
+// mvgx_cascade_set_regions_typed, float distances in L2<float>'s summation order. Other lengths keep working through the reference's
+// own CascadeHasher::Match_HashedDescriptions on the host.
 // A failing device call is logged once and the remaining pairs run through the reference's own classes (mvgx_adapter_policy.hpp).
 #include <algorithm>
 #include <atomic>
@@ -99,7 +101,12 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   const size_t dimension = views.begin()->second.regions->DescriptorLength();
   matching::CascadeHasher hasher;
   hasher.Init(dimension);
-  const bool on_device = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
+  // the device covers both stages for 128-byte uint8 regions (SIFT_Regions) and the matching stage - the part that grows with the pair
+  // count - for the other shapes openMVG's scalar describers produce: 144-byte uint8 (AKAZE_Liop_Regions) and 64-float rows
+  // (AKAZE_Float_Regions); their hashing stage is the reference's CreateHashedDescriptions on the host threads
+  constexpr bool is_float = std::is_same<ScalarT, float>::value;
+  const bool device_hashing = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
+  const bool on_device = device_hashing || (std::is_same<ScalarT, unsigned char>::value && dimension == 144) || (is_float && dimension == 64);
   std::vector<View<ScalarT>*> order;
   for (auto& kv : views) order.push_back(&kv.second);
   // the zero-mean descriptor (:78-104): the reference's own GetZeroMeanDescriptor, per view on the host threads, then over the views
@@ -120,7 +127,7 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   // CreateHashedDescriptions), else the reference's CreateHashedDescriptions on the host threads
   on_host_threads(order.size(), [&](size_t k) {
     View<ScalarT>& v = *order[k];
-    if (!on_device) {
+    if (!device_hashing) {
       Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
       v.hashed = hasher.CreateHashedDescriptions(m, zero_mean);   // const member, per-view outputs: thread safe
     }
@@ -131,8 +138,9 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   // device hashing reproduces the non-FMA operation order (mvgx.h), such a build's own CascadeHasher rounds differently near zero.
   // Default "device"; "check" hashes the first view both ways once and switches to "host" with a warning on a mismatch.
   const char* hash_env = std::getenv("MVGX_CASCADE_HASH");
-  bool hash_host = hash_env && !std::strcmp(hash_env, "host");
-  const bool hash_check = hash_env && !std::strcmp(hash_env, "check");
+  bool hash_host = !device_hashing || (hash_env && !std::strcmp(hash_env, "host"));
+  const bool hash_check = device_hashing && hash_env && !std::strcmp(hash_env, "check");
+  bool hashed_on_host = !device_hashing;   // v.hashed filled (above)
 
   // pairs in the reference's visiting order (grouped by I, ascending), minus the ones it skips (:151-176)
   std::vector<Pair> todo;
@@ -211,7 +219,8 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     failed = true;
     return false;
   };
-  // host-side hash outputs in the layout of mvgx_cascade_set_regions (codes: 16 bytes, bucket ids: 6 x uint16 per descriptor)
+  // host-side hash outputs in the layout of mvgx_cascade_set_regions_typed (codes: one bit per dimension, bucket ids: 6 x uint16 per descriptor)
+  const size_t code_bytes = (dimension + 7) / 8;
   std::vector<std::vector<uint8_t>> codes;
   std::vector<std::vector<uint16_t>> buckets;
   std::vector<const uint8_t*> code_ptr;
@@ -220,11 +229,11 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     codes.clear(); buckets.clear(); code_ptr.clear(); bucket_ptr.clear();
     for (const View<ScalarT>* v : view_of) {
       const size_t n = v->count();
-      codes.emplace_back(n * 16);
+      codes.emplace_back(n * code_bytes);
       buckets.emplace_back(n * 6);
       for (size_t r = 0; r < n; ++r) {
         const matching::HashedDescription& h = v->hashed.hashed_desc[r];
-        std::memcpy(&codes.back()[r * 16], h.hash_code.data(), 16);
+        std::memcpy(&codes.back()[r * code_bytes], h.hash_code.data(), code_bytes);
         for (int g = 0; g < 6; ++g) buckets.back()[r * 6 + g] = h.bucket_ids[g];
       }
     }
@@ -259,10 +268,12 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
       }
     }
     if (hash_host) {
-      hash_on_host();
+      if (!hashed_on_host) { hash_on_host(); hashed_on_host = true; }
       pack_host_hashes();
       inj = injected("cascade", "hash");
-      if (!inj) rc = mvgx_cascade_set_regions(ctx.c, rows.data(), code_ptr.data(), bucket_ptr.data(), n_desc.data(), (uint32_t)rows.size(), 128, 16, 6, 10);
+      if (!inj)
+        rc = mvgx_cascade_set_regions_typed(ctx.c, is_float ? 1 : 0, reinterpret_cast<const void* const*>(rows.data()), code_ptr.data(), bucket_ptr.data(),
+                                            n_desc.data(), (uint32_t)rows.size(), (uint32_t)dimension, (uint32_t)code_bytes, 6, 10);
       step("set_regions", rc, inj);
     } else {
       // CascadeHasher::Init(dimension) defaults: 6 bucket groups, 10 bits per bucket, std::mt19937::default_seed
@@ -300,7 +311,7 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   }
   mvgx_adapter::counters().device_pairs.fetch_add(delivered);
   if (failed && !progress->hasBeenCanceled()) {
-    if (!hash_host) hash_on_host();
+    if (!hashed_on_host) hash_on_host();
     mvgx_adapter::counters().fallback_pairs.fetch_add(n_pairs - delivered);
     host_route((size_t)delivered);
   }

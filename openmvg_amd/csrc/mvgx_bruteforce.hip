@@ -251,8 +251,8 @@ __global__ __launch_bounds__(kQBlock) void l2u8_top2_ratio_kernel(L2uParams p) {
 constexpr int kCasGroupsMax = 8;
 constexpr int kCasTop = 10;
 struct CasParams {
-  const uint32_t* words;        // descriptors, 32 dwords (128 bytes) per row
-  const uint4* hash;            // 128-bit hash code per row
+  const uint32_t* words;        // descriptors, DW dwords per row (uint8: length / 4 bytes packed; float: one element per dword)
+  const uint32_t* hash;         // hash code per row: HW dwords in a slot of 2, 4 or 8 (zero padded)
   const uint4* bids;            // bucket ids per row: 8 x uint16 (groups beyond n_groups unused)
   const uint32_t* bstart;       // per image: n_groups * n_buckets + 1 offsets into its items
   const uint32_t* items;        // per image: n_groups lists of its rows, grouped by bucket (ascending row inside a bucket)
@@ -269,7 +269,13 @@ __device__ __forceinline__ uint32_t cas_bid(const uint4& b, int g) {
   const uint32_t w = g < 2 ? b.x : g < 4 ? b.y : g < 6 ? b.z : b.w;
   return (g & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
+// DW: dwords per descriptor row, HW: dwords of the hash code (= descriptor length / 32, rounded up), kFloat: L2<float> on the ten
+// candidates in the reference's summation order (metric.hpp: groups of four, separate multiplies and adds) instead of L2<uint8_t>.
+// Instantiations: <32, 4, false> SIFT_Regions, <36, 5, false> AKAZE_Liop_Regions (144 bytes), <64, 2, true> AKAZE_Float_Regions.
+template <int DW, int HW, bool kFloat>
 __global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
+#pragma clang fp contract(off)
+  constexpr int HS = HW <= 2 ? 2 : HW <= 4 ? 4 : 8;   // dwords between the codes of two rows
   __shared__ uint32_t sh_count;
   const uint2 w = p.work[blockIdx.x];
   const uint2 ij = p.pairs[w.x];
@@ -281,7 +287,10 @@ __global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
   uint32_t out = kInvalid;
   if (active) {
     const uint64_t offI = p.img_row_off[ij.x], rowJ = p.img_row_off[ij.y] + q;
-    const uint4 hq = p.hash[rowJ], bq = p.bids[rowJ];
+    const uint4 bq = p.bids[rowJ];
+    uint32_t hq[HW];
+#pragma unroll
+    for (int k = 0; k < HW; ++k) hq[k] = p.hash[rowJ * HS + k];
     const int G = (int)p.n_groups;
     const uint32_t* __restrict__ bs = p.bstart + (size_t)ij.x * ((size_t)G * p.n_buckets + 1);
     const uint32_t* __restrict__ it = p.items + offI * (uint64_t)G;
@@ -311,8 +320,9 @@ __global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
           for (int g2 = 0; g2 < kCasGroupsMax; ++g2)
             if (g2 < g) repeat = repeat || cas_bid(bi, g2) == cas_bid(bq, g2);
           if (repeat) continue;
-          const uint4 hi = p.hash[offI + id];
-          const uint32_t ham = __popc(hi.x ^ hq.x) + __popc(hi.y ^ hq.y) + __popc(hi.z ^ hq.z) + __popc(hi.w ^ hq.w);
+          uint32_t ham = 0;
+#pragma unroll
+          for (int k = 0; k < HW; ++k) ham += __popc(p.hash[(offI + id) * HS + k] ^ hq[k]);
           uint32_t key = (ham << 24) | t;
 #pragma unroll
           for (int k = 0; k < kCasTop; ++k) {   // sorted insertion: the list keeps the ten smallest keys
@@ -322,16 +332,18 @@ __global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
         }
       }
       // exact distances of the (up to) ten selected candidates; the two smallest (distance, id) pairs
-      uint32_t qv[32];
+      uint32_t qv[DW];
       {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.words + rowJ * 32);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.words + rowJ * DW);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const uint4 v = src[k]; qv[4 * k] = v.x; qv[4 * k + 1] = v.y; qv[4 * k + 2] = v.z; qv[4 * k + 3] = v.w; }
+        for (int k = 0; k < DW / 4; ++k) { const uint4 v = src[k]; qv[4 * k] = v.x; qv[4 * k + 1] = v.y; qv[4 * k + 2] = v.z; qv[4 * k + 3] = v.w; }
       }
       uint32_t qn = 0;
+      if (!kFloat) {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) qn = __builtin_amdgcn_udot4(qv[k], qv[k], qn, false);
-      uint64_t b0 = ~0ull, b1 = ~0ull;   // (distance << 32 | id): lexicographic (distance, id)
+        for (int k = 0; k < DW; ++k) qn = __builtin_amdgcn_udot4(qv[k], qv[k], qn, false);
+      }
+      uint64_t b0 = ~0ull, b1 = ~0ull;   // (distance << 32 | id): lexicographic (distance, id); non-negative floats order like their bits
       int n_top = 0;
 #pragma unroll
       for (int k = 0; k < kCasTop; ++k) {
@@ -345,21 +357,37 @@ __global__ __launch_bounds__(kQBlock) void cascade_match_kernel(CasParams p) {
           cum += len[g];
         }
         const uint32_t id = it[idx];
-        const uint4* __restrict__ row = reinterpret_cast<const uint4*>(p.words + (offI + id) * 32);
-        uint32_t dot = 0, rn = 0;
+        const uint4* __restrict__ row = reinterpret_cast<const uint4*>(p.words + (offI + id) * DW);
+        uint32_t dbits;
+        if (kFloat) {
+          // L2<float>::operator()(candidate, query, size) (metric.hpp:98-135): result += ((d0 d0 + d1 d1) + d2 d2) + d3 d3 per four elements
+          float result = 0.f;
 #pragma unroll
-        for (int c4 = 0; c4 < 8; ++c4) {
-          const uint4 v = row[c4];
-          dot = __builtin_amdgcn_udot4(v.x, qv[4 * c4], dot, false); rn = __builtin_amdgcn_udot4(v.x, v.x, rn, false);
-          dot = __builtin_amdgcn_udot4(v.y, qv[4 * c4 + 1], dot, false); rn = __builtin_amdgcn_udot4(v.y, v.y, rn, false);
-          dot = __builtin_amdgcn_udot4(v.z, qv[4 * c4 + 2], dot, false); rn = __builtin_amdgcn_udot4(v.z, v.z, rn, false);
-          dot = __builtin_amdgcn_udot4(v.w, qv[4 * c4 + 3], dot, false); rn = __builtin_amdgcn_udot4(v.w, v.w, rn, false);
+          for (int c4 = 0; c4 < DW / 4; ++c4) {
+            const uint4 v = row[c4];
+            const float d0 = __uint_as_float(v.x) - __uint_as_float(qv[4 * c4]), d1 = __uint_as_float(v.y) - __uint_as_float(qv[4 * c4 + 1]);
+            const float d2 = __uint_as_float(v.z) - __uint_as_float(qv[4 * c4 + 2]), d3 = __uint_as_float(v.w) - __uint_as_float(qv[4 * c4 + 3]);
+            const float g = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+            result = result + g;
+          }
+          dbits = __float_as_uint(result);
+        } else {
+          uint32_t dot = 0, rn = 0;
+#pragma unroll
+          for (int c4 = 0; c4 < DW / 4; ++c4) {
+            const uint4 v = row[c4];
+            dot = __builtin_amdgcn_udot4(v.x, qv[4 * c4], dot, false); rn = __builtin_amdgcn_udot4(v.x, v.x, rn, false);
+            dot = __builtin_amdgcn_udot4(v.y, qv[4 * c4 + 1], dot, false); rn = __builtin_amdgcn_udot4(v.y, v.y, rn, false);
+            dot = __builtin_amdgcn_udot4(v.z, qv[4 * c4 + 2], dot, false); rn = __builtin_amdgcn_udot4(v.z, v.z, rn, false);
+            dot = __builtin_amdgcn_udot4(v.w, qv[4 * c4 + 3], dot, false); rn = __builtin_amdgcn_udot4(v.w, v.w, rn, false);
+          }
+          dbits = rn + qn - 2u * dot;   // exact (< 2^24)
         }
-        const uint32_t dist = rn + qn - 2u * dot;   // exact (< 2^24)
-        top2_u64(((uint64_t)dist << 32) | id, b0, b1);
+        top2_u64(((uint64_t)dbits << 32) | id, b0, b1);
       }
       if (n_top >= 2) {
-        const float d0 = (float)(uint32_t)(b0 >> 32), d1 = (float)(uint32_t)(b1 >> 32);
+        const float d0 = kFloat ? __uint_as_float((uint32_t)(b0 >> 32)) : (float)(uint32_t)(b0 >> 32);
+        const float d1 = kFloat ? __uint_as_float((uint32_t)(b1 >> 32)) : (float)(uint32_t)(b1 >> 32);
         if (d0 < __fmul_rn(p.ratio_sq, d1)) out = (uint32_t)b0;
       }
     }
@@ -515,6 +543,7 @@ struct BfCtx {
   Buf<uint4> d_hash, d_bids;
   Buf<uint32_t> d_bstart, d_items;
   uint32_t cas_groups = 0, cas_buckets = 0;
+  bool cas_float = false;             // cascade hashing on float rows (AKAZE_Float_Regions): L2<float> on the candidates
   Buf<uint64_t> d_row_off;
   Buf<uint2> d_pairs, d_work, d_ij;
   Buf<uint2> hp_pairs, hp_work;
@@ -667,10 +696,12 @@ int bf_run(BfCtx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio, mv
       MVGX_HIP(hipEventRecord(c->evk0, c->stream));
       if (c->kind == 3) {
         CasParams cp;
-        cp.words = c->d_words.p; cp.hash = c->d_hash.p; cp.bids = c->d_bids.p; cp.bstart = c->d_bstart.p; cp.items = c->d_items.p;
+        cp.words = c->d_words.p; cp.hash = reinterpret_cast<const uint32_t*>(c->d_hash.p); cp.bids = c->d_bids.p; cp.bstart = c->d_bstart.p; cp.items = c->d_items.p;
         cp.img_row_off = c->d_row_off.p; cp.img_n = c->d_n.p; cp.pairs = c->d_pairs.p; cp.work = c->d_work.p; cp.best = c->d_best.p;
         cp.count = c->d_count.p; cp.qstride = c->qstride; cp.n_groups = c->cas_groups; cp.n_buckets = c->cas_buckets; cp.ratio_sq = ratio;
-        hipLaunchKernelGGL(cascade_match_kernel, dim3(n_work), dim3(kQBlock), 0, c->stream, cp);
+        if (c->cas_float) hipLaunchKernelGGL((cascade_match_kernel<64, 2, true>), dim3(n_work), dim3(kQBlock), 0, c->stream, cp);
+        else if (c->nw == 36) hipLaunchKernelGGL((cascade_match_kernel<36, 5, false>), dim3(n_work), dim3(kQBlock), 0, c->stream, cp);
+        else hipLaunchKernelGGL((cascade_match_kernel<32, 4, false>), dim3(n_work), dim3(kQBlock), 0, c->stream, cp);
       } else if (c->kind == 0) {
         HamParams hp;
         hp.words = c->d_words.p; hp.img_row_off = c->d_row_off.p; hp.img_n = c->d_n.p; hp.pairs = c->d_pairs.p; hp.work = c->d_work.p;
@@ -819,10 +850,13 @@ int mvgx_cascade_set_option(mvgx_cascade_ctx* c, const char* key, int64_t value)
 }  // extern "C"
 
 namespace {
-int cas_check_shape(uint32_t dim, uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
-  MVGX_REQUIRE(dim == 128 && hash_bytes == 16, MVGX_ERR_UNSUPPORTED,
-               "cascade hashing on the device: 128-byte uint8 descriptors with 128-bit codes (SIFT_Regions; CascadeHasher::Init(128)); "
-               "got length %u, %u code bytes", dim, hash_bytes);
+// the region types of the matching stage: scalar_type 0 = uint8 (128 = SIFT_Regions, 144 = AKAZE_Liop_Regions), 1 = float (64 =
+// AKAZE_Float_Regions); the code has one bit per dimension (CascadeHasher::Init(dimension), stl::dynamic_bitset bytes)
+int cas_check_shape(int scalar_type, uint32_t dim, uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
+  const bool known = (scalar_type == 0 && (dim == 128 || dim == 144)) || (scalar_type == 1 && dim == 64);
+  MVGX_REQUIRE(known && hash_bytes == (dim + 7) / 8, MVGX_ERR_UNSUPPORTED,
+               "cascade hashing on the device: uint8 descriptors of 128 or 144 bytes or float descriptors of length 64, with one code bit "
+               "per dimension (CascadeHasher::Init(dimension)); got scalar type %d, length %u, %u code bytes", scalar_type, dim, hash_bytes);
   MVGX_REQUIRE(n_groups >= 1 && n_groups <= (uint32_t)kCasGroupsMax && bits_per_bucket >= 1 && bits_per_bucket <= 16, MVGX_ERR_UNSUPPORTED,
                "cascade hashing on the device: 1..8 bucket groups of 2^1..2^16 buckets (got %u groups, %u bits)", n_groups, bits_per_bucket);
   return MVGX_OK;
@@ -895,41 +929,54 @@ const std::vector<float>& cas_projections(uint32_t dim, uint32_t groups, uint32_
 
 extern "C" {
 
-int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
-                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
-                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
+int mvgx_cascade_set_regions_typed(mvgx_cascade_ctx* c, int scalar_type, const void* const* desc_rows, const uint8_t* const* hash_codes,
+                                   const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                                   uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
   MVGX_REQUIRE(c && (n_images == 0 || (desc_rows && hash_codes && bucket_ids && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_set_regions: NULL argument");
-  int rc = cas_check_shape(dim, hash_bytes, n_groups, bits_per_bucket);
+  int rc = cas_check_shape(scalar_type, dim, hash_bytes, n_groups, bits_per_bucket);
   if (rc) return rc;
-  if ((rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4))) return rc;
+  const bool is_float = scalar_type == 1;
+  if ((rc = bf_set_regions(c, reinterpret_cast<const uint8_t* const*>(desc_rows), n_desc, n_images, is_float ? dim * 4 : dim, is_float ? dim : dim / 4))) return rc;
+  c->cas_float = is_float;
   const uint32_t G = n_groups;
+  const uint32_t HW = (dim + 31) / 32, HS = HW <= 2 ? 2 : HW <= 4 ? 4 : 8;   // code dwords, slot dwords (cascade_match_kernel)
   std::vector<uint64_t> off(n_images + 1, 0);
   for (uint32_t k = 0; k < n_images; ++k) {
     MVGX_REQUIRE(n_desc[k] == 0 || (hash_codes[k] && bucket_ids[k]), MVGX_ERR_ARG, "image %u: NULL hash / bucket array", k);
     off[k + 1] = off[k] + n_desc[k];
   }
   const uint64_t rows = off[n_images];
-  std::vector<uint4> hash((size_t)std::max<uint64_t>(rows, 1)), bids((size_t)std::max<uint64_t>(rows, 1));
+  std::vector<uint32_t> hash((size_t)std::max<uint64_t>(rows, 1) * HS + 4, 0u);
+  std::vector<uint4> bids((size_t)std::max<uint64_t>(rows, 1));
   for (uint32_t k = 0; k < n_images; ++k)
     for (uint32_t r = 0; r < n_desc[k]; ++r) {
-      memcpy(&hash[off[k] + r], hash_codes[k] + (size_t)r * 16, 16);
+      memcpy(&hash[(off[k] + r) * HS], hash_codes[k] + (size_t)r * hash_bytes, hash_bytes);   // (the slot's tail stays zero)
       uint16_t b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (uint32_t g = 0; g < G; ++g) b8[g] = bucket_ids[k][(size_t)r * G + g];
       memcpy(&bids[off[k] + r], b8, 16);
     }
-  if ((rc = c->d_hash.ensure(hash.size())) || (rc = c->d_bids.ensure(bids.size()))) return rc;
-  MVGX_HIP(hipMemcpyAsync(c->d_hash.p, hash.data(), hash.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+  if ((rc = c->d_hash.ensure(hash.size() / 4)) || (rc = c->d_bids.ensure(bids.size()))) return rc;
+  MVGX_HIP(hipMemcpyAsync(c->d_hash.p, hash.data(), hash.size() / 4 * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(c->d_bids.p, bids.data(), bids.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
   return cas_build_buckets(c, bids.data(), n_desc, n_images, G, bits_per_bucket);
+}
+int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint8_t* const* hash_codes,
+                             const uint16_t* const* bucket_ids, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                             uint32_t hash_bytes, uint32_t n_groups, uint32_t bits_per_bucket) {
+  return mvgx_cascade_set_regions_typed(c, 0, reinterpret_cast<const void* const*>(desc_rows), hash_codes, bucket_ids, n_desc, n_images, dim, hash_bytes,
+                                        n_groups, bits_per_bucket);
 }
 
 int mvgx_cascade_hash_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
                               const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
                               uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {
   MVGX_REQUIRE(c && zero_mean && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_hash_regions: NULL argument");
-  int rc = cas_check_shape(dim, 16, n_groups, bits_per_bucket);
+  MVGX_REQUIRE(dim == 128, MVGX_ERR_UNSUPPORTED, "mvgx_cascade_hash_regions: the hashing stage on the device covers 128-byte uint8 descriptors (got length %u); "
+               "hash on the host and hand the codes to mvgx_cascade_set_regions_typed", dim);
+  int rc = cas_check_shape(0, dim, 16, n_groups, bits_per_bucket);
   if (rc) return rc;
   if ((rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4))) return rc;   // the descriptors, row after row, on the device
+  c->cas_float = false;
   uint64_t rows = 0;
   for (uint32_t k = 0; k < n_images; ++k) rows += n_desc[k];
   const std::vector<float>& P = cas_projections(dim, n_groups, bits_per_bucket, random_seed);

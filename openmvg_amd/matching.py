@@ -305,15 +305,19 @@ class L2u8Context(HammingContext):
 
 
 class CascadeContext(HammingContext):
-    """CASCADE_HASHING_L2, matching stage (thin wrapper over mvgx_cascade_*): 128-byte uint8 descriptors with the hash codes and
-    bucket ids the caller's hashing stage produced (the openMVG adapter runs the reference's CascadeHasher for that); run() takes
+    """CASCADE_HASHING_L2, matching stage (thin wrapper over mvgx_cascade_*): uint8 descriptors of 128 / 144 bytes or float ones of
+    length 64 with the hash codes and bucket ids the caller's hashing stage produced (the openMVG adapter runs the reference's CascadeHasher for that); run() takes
     the squared ratio and returns the lists before the reference's de-duplication steps."""
     _prefix = "mvgx_cascade"
     _dtype = np.uint8
 
-    def set_regions(self, desc_list, hash_list, bucket_list, n_groups=6, bits_per_bucket=10):
-        d = [np.ascontiguousarray(x, np.uint8).reshape(-1, 128) for x in desc_list]
-        h = [np.ascontiguousarray(x, np.uint8).reshape(-1, 16) for x in hash_list]
+    def set_regions(self, desc_list, hash_list, bucket_list, n_groups=6, bits_per_bucket=10, dtype=np.uint8, dim=128):
+        """dtype / dim: np.uint8 with 128 (SIFT_Regions) or 144 (AKAZE_Liop_Regions), np.float32 with 64 (AKAZE_Float_Regions) -
+        mvgx_cascade_set_regions_typed; the hash codes have one bit per dimension ((dim + 7) // 8 bytes per descriptor)."""
+        is_float = np.dtype(dtype) == np.float32
+        hb = (dim + 7) // 8
+        d = [np.ascontiguousarray(x, np.float32 if is_float else np.uint8).reshape(-1, dim) for x in desc_list]
+        h = [np.ascontiguousarray(x, np.uint8).reshape(-1, hb) for x in hash_list]
         b = [np.ascontiguousarray(x, np.uint16).reshape(-1, n_groups) for x in bucket_list]
         n = len(d)
         dp = (C.c_void_p * max(n, 1))(); hp = (C.c_void_p * max(n, 1))(); bp = (C.c_void_p * max(n, 1))()
@@ -325,8 +329,7 @@ class CascadeContext(HammingContext):
             bp[k] = b[k].ctypes.data if len(d[k]) else None
             cnt[k] = len(d[k])
         self._keep = (d, h, b)
-        _capi.check(self._fn("set_regions")(self._h, dp, hp, bp, cnt, n, 128, 16, n_groups, bits_per_bucket))
-
+        _capi.check(self._fn("set_regions_typed")(self._h, 1 if is_float else 0, dp, hp, bp, cnt, n, dim, hb, n_groups, bits_per_bucket))
 
     def hash_regions(self, desc_list, zero_mean=None, n_groups=6, bits_per_bucket=10, random_seed=5489, fetch=False):
         """The hashing stage on the device (mvgx_cascade_hash_regions) in place of set_regions: descriptors only; zero_mean

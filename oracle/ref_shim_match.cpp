@@ -344,6 +344,49 @@ uint64_t ref_cascade_matcher_regions_match_u8(const uint8_t* const* desc_rows, c
   return out.size();
 }
 
+// ... the same on in-memory AKAZE_Float_Regions (64 x float) and AKAZE_Liop_Regions (144 x uint8): the other scalar region types
+// Cascade_Hashing_Matcher_Regions::Match dispatches on (Cascade_Hashing_Matcher_Regions.cpp:233-262)
+extern "C++" {
+template <class RegionsT, class Row>
+static uint64_t cascade_match_typed(std::shared_ptr<features::Regions> (*make)(const Row*, uint32_t), const Row* const* desc_rows,
+                                    const float* const* feat_xy, const uint32_t* n_desc, uint32_t n_images, const uint32_t* pairs_IJ,
+                                    uint64_t n_pairs, float dist_ratio, ref_match_sink sink, void* user) {
+  auto provider = std::make_shared<InMemoryRegionsProvider>();
+  provider->set_type(new RegionsT());
+  for (uint32_t k = 0; k < n_images; ++k) {
+    std::shared_ptr<features::Regions> r = make(desc_rows[k], n_desc[k]);
+    auto* sr = static_cast<RegionsT*>(r.get());
+    for (uint32_t q = 0; q < n_desc[k]; ++q) sr->Features()[q] = features::SIOPointFeature(feat_xy[k][2 * q], feat_xy[k][2 * q + 1], 1.f, 0.f);
+    provider->set(k, r);
+  }
+  Pair_Set pairs;
+  for (uint64_t p = 0; p < n_pairs; ++p) pairs.insert({pairs_IJ[2 * p], pairs_IJ[2 * p + 1]});
+  matching::PairWiseMatches out;
+  matching_image_collection::Cascade_Hashing_Matcher_Regions matcher(dist_ratio);
+  std::shared_ptr<sfm::Regions_Provider> base = provider;
+  matcher.Match(base, pairs, out, nullptr);
+  std::vector<uint32_t> flat;
+  for (const auto& kv : out) {
+    flat.resize(kv.second.size() * 2);
+    for (size_t m = 0; m < kv.second.size(); ++m) { flat[2 * m] = kv.second[m].i_; flat[2 * m + 1] = kv.second[m].j_; }
+    if (sink) sink(user, kv.first.first, kv.first.second, flat.data(), uint32_t(kv.second.size()));
+  }
+  return out.size();
+}
+}  // extern "C++"
+uint64_t ref_cascade_matcher_regions_match_float64(const float* const* desc_rows, const float* const* feat_xy, const uint32_t* n_desc,
+                                                   uint32_t n_images, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                                   ref_match_sink sink, void* user) {
+  return cascade_match_typed<features::AKAZE_Float_Regions, float>(&make_float64_regions, desc_rows, feat_xy, n_desc, n_images, pairs_IJ, n_pairs,
+                                                                    dist_ratio, sink, user);
+}
+uint64_t ref_cascade_matcher_regions_match_liop144(const uint8_t* const* desc_rows, const float* const* feat_xy, const uint32_t* n_desc,
+                                                   uint32_t n_images, const uint32_t* pairs_IJ, uint64_t n_pairs, float dist_ratio,
+                                                   ref_match_sink sink, void* user) {
+  return cascade_match_typed<features::AKAZE_Liop_Regions, uint8_t>(&make_liop144_regions, desc_rows, feat_xy, n_desc, n_images, pairs_IJ, n_pairs,
+                                                                     dist_ratio, sink, user);
+}
+
 // CascadeHasher with a chosen bucket layout on ONE pair (queries = J, database = I): Init(128, n_groups, bits_per_bucket), the
 // zero-mean descriptor over the two images, CreateHashedDescriptions, Match_HashedDescriptions (NN = 2) and NNdistanceRatio -
 // the list before the de-duplication steps, as (index in I, index in J). The hash outputs are copied out as well (16 bytes and

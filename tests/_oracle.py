@@ -167,6 +167,34 @@ def ref_cascade_matcher_regions_match(descs, feats_xy, pairs, dist_ratio, lib=No
     return out
 
 
+def ref_cascade_matcher_regions_match_typed(kind, descs, feats_xy, pairs, dist_ratio, lib=None):
+    """... the same on in-memory AKAZE_Float_Regions (kind "float64": (n, 64) float32 rows) or AKAZE_Liop_Regions (kind
+    "liop144": (n, 144) uint8 rows): the other scalar region types Cascade_Hashing_Matcher_Regions::Match dispatches on."""
+    dt, dim = {"float64": (np.float32, 64), "liop144": (np.uint8, 144)}[kind]
+    arrs = [np.ascontiguousarray(d, dtype=dt).reshape(-1, dim) for d in descs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = (C.c_uint32 * max(n, 1))()
+    xy = [np.ascontiguousarray(f, np.float32).reshape(-1, 2) for f in feats_xy]
+    xp = (C.c_void_p * max(n, 1))()
+    for k in range(n):
+        ptrs[k] = arrs[k].ctypes.data if len(arrs[k]) else None
+        cnt[k] = len(arrs[k])
+        xp[k] = xy[k].ctypes.data if len(xy[k]) else None
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = {}
+
+    def sink(_user, I, J, pij, m):
+        out[(int(I), int(J))] = np.ctypeslib.as_array(pij, shape=(int(m), 2)).copy() if m else np.zeros((0, 2), np.uint32)
+
+    cb = SINK(sink)
+    L = lib or ref_match()
+    f = getattr(L, "ref_cascade_matcher_regions_match_" + kind)
+    f.restype = C.c_uint64
+    f(ptrs, xp, cnt, n, C.c_void_p(pairs.ctypes.data), C.c_uint64(len(pairs)), C.c_float(dist_ratio), cb, None)
+    return out
+
+
 def ref_cascade_match_pair(descI, descJ, dist_ratio, n_groups=6, bits_per_bucket=10):
     """The reference's CascadeHasher with a chosen bucket layout on one pair (oracle/_ref): returns (matches (n, 2) before the
     de-duplication steps, hashI, bidsI, hashJ, bidsJ)."""
@@ -705,8 +733,8 @@ def adapter():
         m = _bind_match_shim(C.CDLL(ADAPTER_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64",
-                     "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_hash_u8",
-                     "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
+                     "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_matcher_regions_match_float64",
+                     "ref_cascade_matcher_regions_match_liop144", "ref_cascade_hash_u8", "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
                      "mvgx_adapter_ba_release_context"):
