@@ -407,6 +407,16 @@ typedef struct mvgx_ba_solver_info {
   int32_t n_grouped_points;
 } mvgx_ba_solver_info;
 int mvgx_ba_get_solver_info(mvgx_ba_ctx* ctx, mvgx_ba_solver_info* out);   /* MVGX_ERR_STATE before the first iteration */
+/* The caller's choice of linear solver (ABI 9) - Bundle_Adjustment_Ceres::BA_Ceres_options::linear_solver_type_
+ * (sfm/sfm_data_BA_ceres.cpp:132-146 default, :483 handed to ceres; sequential_SfM.cpp:1193-1205 and the other engines pick
+ * DENSE_SCHUR or SPARSE_SCHUR by the pose count): both are direct solves of the Schur complement, what differs is the storage and
+ * factorisation of the reduced camera system. AUTO is the library's rule above; DENSE the dense blocked Cholesky; SPARSE the block-
+ * sparse tile Cholesky (MVGX_ERR_UNSUPPORTED when its task lists cannot be built); SPARSE_PREFERRED falls back to DENSE in that case
+ * (what the replacement TU passes for SPARSE_SCHUR). Before the first iteration the symbolic phase is simply run again; afterwards
+ * MVGX_OK when the solver in place is the one asked for, else MVGX_ERR_STATE. The environment's MVGX_BA_SOLVER (dense | sparse |
+ * auto) outranks this call. ceres' iterative types (ITERATIVE_SCHUR, CGNR) have no counterpart: see INTEGRATION.md. */
+enum { MVGX_BA_LINEAR_SOLVER_AUTO = 0, MVGX_BA_LINEAR_SOLVER_DENSE = 1, MVGX_BA_LINEAR_SOLVER_SPARSE = 2, MVGX_BA_LINEAR_SOLVER_SPARSE_PREFERRED = 3 };
+int mvgx_ba_set_linear_solver(mvgx_ba_ctx* ctx, int kind);
 
 /* ---- geometric filter of putative matches: a-contrario fundamental-matrix estimation --------------------------
  * Replaces, per image pair of a putative-match container, GeometricFilter_FMatrix_AC::Robust_estimation

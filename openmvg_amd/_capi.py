@@ -190,6 +190,7 @@ PROTOTYPES = {
     "mvgx_ba_residuals": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvgx_ba_track_angles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvgx_ba_get_solver_info": (C.c_int, [C.c_void_p, C.POINTER(BaSolverInfo)]),
+    "mvgx_ba_set_linear_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "mvgx_geofilter_f_acransac": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GeofilterOptions),
                                             C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_geofilter_f_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,

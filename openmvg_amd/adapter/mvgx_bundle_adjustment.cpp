@@ -277,7 +277,7 @@ bool Bundle_Adjustment_HIP::Adjust(SfM_Data& sfm_data, const Optimize_Options& o
   const bool plain = obs_weight.empty() && prior_pose.empty();
   mvgx_adapter::BoundContext bound;
   const bool inj_create = mvgx_adapter::injected("ba", "create");
-  int rc = inj_create ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(options_.device_, prob, fs, plain, bound);
+  int rc = inj_create ? MVGX_ERR_NODEV : mvgx_adapter::bind_context(options_.device_, prob, fs, plain, bound, options_.linear_solver_);
   mvgx_ba_ctx* ctx = bound.ctx;
   tick(bound.route);
   if (rc == MVGX_ERR_UNSUPPORTED) {
@@ -379,6 +379,12 @@ extern "C" void mvgx_adapter_ba_context_stats3(uint64_t out[3], int reset) {
   auto& c = mvgx_adapter::context_cache();
   if (out) { out[0] = c.created.load(); out[1] = c.reused.load(); out[2] = c.subset.load(); }
   if (reset) { c.created = 0; c.reused = 0; c.subset = 0; }
+}
+// how the kept context solves its reduced camera system (mvgx_ba_get_solver_info; MVGX_ERR_STATE: no context is kept)
+extern "C" int mvgx_adapter_ba_kept_solver_info(mvgx_ba_solver_info* out) {
+  auto& c = mvgx_adapter::context_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  return c.idle ? mvgx_ba_get_solver_info(c.idle, out) : MVGX_ERR_STATE;
 }
 extern "C" void mvgx_adapter_ba_release_context() {
   mvgx_ba_ctx* ctx = mvgx_adapter::take_idle_context(std::numeric_limits<int>::min());   // (no device matches: the idle context and its kept arrays are destroyed)

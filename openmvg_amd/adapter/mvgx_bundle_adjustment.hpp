@@ -23,9 +23,12 @@ class Bundle_Adjustment_HIP : public Bundle_Adjustment {
     bool bUse_loss_function_;
     int max_num_iterations_;
     int device_;  // HIP device ordinal, -1 = current
+    // reduced camera system: MVGX_BA_LINEAR_SOLVER_AUTO (the library's rule), _DENSE, _SPARSE, _SPARSE_PREFERRED (mvgx.h). The
+    // Bundle_Adjustment_Ceres replacement maps BA_Ceres_options::linear_solver_type_ onto it (mvgx_bundle_adjustment_ceres.cpp).
+    int linear_solver_;
     Options()
         : bVerbose_(true), parameter_tolerance_(1e-8), gradient_tolerance_(1e-10), bUse_loss_function_(true),
-          max_num_iterations_(50), device_(-1) {}
+          max_num_iterations_(50), device_(-1), linear_solver_(0) {}
   };
 
   Bundle_Adjustment_HIP() {}

@@ -7,11 +7,15 @@
 // enum header is needed (ceres/types.h); no Ceres object code is linked by this file. IntrinsicsToCostFunction
 // (sfm_data_BA_ceres.hpp:24-29) builds ceres::CostFunction objects and is therefore NOT provided here: in the reference tree
 // it is called only inside sfm_data_BA_ceres.cpp itself (:367, :415), i.e. from the Adjust() this file replaces.
+#include <atomic>
 #include <utility>
 
 #include "ceres/types.h"
 
 #include "openMVG/sfm/sfm_data_BA_ceres.hpp"
+#include "openMVG/system/logger.hpp"
+
+#include "mvgx.h"
 
 #include "mvgx_bundle_adjustment.hpp"
 
@@ -28,8 +32,9 @@ Bundle_Adjustment_Ceres::BA_Ceres_options::BA_Ceres_options(const bool bVerbose,
       max_linear_solver_iterations_(500) {
   (void)bmultithreaded;
   bCeres_summary_ = false;
-  // The reduced camera system is always eliminated with the Schur complement and factored densely on the GPU.
-  linear_solver_type_ = ceres::DENSE_SCHUR;
+  // The reference's default is SPARSE_SCHUR whenever ceres has a sparse library (sfm_data_BA_ceres.cpp:132-146); the device library
+  // always has its block-sparse factorisation and uses it where its plan pays (Adjust below).
+  linear_solver_type_ = ceres::SPARSE_SCHUR;
   preconditioner_type_ = ceres::JACOBI;
   sparse_linear_algebra_library_type_ = ceres::NO_SPARSE;
 }
@@ -46,6 +51,23 @@ bool Bundle_Adjustment_Ceres::Adjust(SfM_Data& sfm_data, const Optimize_Options&
   o.gradient_tolerance_ = ceres_options_.gradient_tolerance_;
   o.bUse_loss_function_ = ceres_options_.bUse_loss_function_;
   o.max_num_iterations_ = ceres_options_.max_num_iterations_;
+  // linear_solver_type_ (:483): the callers choose between the two direct Schur solvers by the pose count (sequential_SfM.cpp:1193-1205,
+  // sequential_SfM2.cpp:517-521, sfm_stellar_engine.cpp:742-756) - DENSE_SCHUR -> the dense blocked Cholesky of the reduced camera
+  // system, SPARSE_SCHUR -> sparsity is exploited: the block-sparse tile Cholesky wherever its plan needs fewer dependent launches and
+  // no more tiles than the dense sweep (the library's rule, mvgx_ba_get_solver_info), the dense one otherwise. Every other ceres type
+  // (DENSE_QR, DENSE_NORMAL_CHOLESKY, SPARSE_NORMAL_CHOLESKY, CGNR, ITERATIVE_SCHUR) solves the same normal equations; the device
+  // library has no un-eliminated or iterative solver, so those run with its own choice (one notice). MVGX_BA_SOLVER outranks all.
+  switch (ceres_options_.linear_solver_type_) {
+    case ceres::DENSE_SCHUR: o.linear_solver_ = MVGX_BA_LINEAR_SOLVER_DENSE; break;
+    case ceres::SPARSE_SCHUR: o.linear_solver_ = MVGX_BA_LINEAR_SOLVER_AUTO; break;
+    default: {
+      static std::atomic<bool> said{false};
+      if (!said.exchange(true))
+        OPENMVG_LOG_INFO << "mvgx bundle adjustment: linear_solver_type_ " << ceres_options_.linear_solver_type_
+                         << " has no device counterpart - the Schur-complement solver of the library's own choice is used";
+      o.linear_solver_ = MVGX_BA_LINEAR_SOLVER_AUTO;
+    }
+  }
   Bundle_Adjustment_HIP engine(o);
   return engine.Adjust(sfm_data, options);
 }

@@ -191,11 +191,17 @@ struct BoundContext {
   const char* route = "";
 };
 // rc of the library call that decided (MVGX_OK: bc.ctx is ready). `plain`: prob has neither control points nor priors.
-inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, bool plain, BoundContext& bc) {
+// linear_solver: MVGX_BA_LINEAR_SOLVER_* of the caller's options, or kAnySolver (the outlier filters never solve). A kept context
+// whose reduced solver is set up as the other kind is not re-used.
+constexpr int kAnySolver = -1;
+inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, bool plain, BoundContext& bc, int linear_solver = kAnySolver) {
   KeptStructure* ks = nullptr;
   mvgx_ba_ctx* ctx = take_idle_context(device, &ks, &device);   // (kAnyDevice becomes the kept context's device, or -1)
   bc.device = device;
   int rc = MVGX_ERR_STRUCTURE;
+  if (ctx && linear_solver != kAnySolver && mvgx_ba_set_linear_solver(ctx, linear_solver) != MVGX_OK) {
+    mvgx_ba_destroy(ctx); ctx = nullptr;
+  }
   if (ctx) {
     rc = mvgx_ba_update(ctx, &prob);
     if (rc == MVGX_OK) {
@@ -238,6 +244,7 @@ inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, 
   if (!ctx) {
     delete ks; ks = nullptr;
     rc = mvgx_ba_create(device, &prob, &ctx);
+    if (rc == MVGX_OK && linear_solver != kAnySolver && (rc = mvgx_ba_set_linear_solver(ctx, linear_solver)) != MVGX_OK) mvgx_ba_destroy(ctx);
     if (rc == MVGX_OK) { context_cache().created.fetch_add(1); bc.route = "mvgx_ba_create"; }
     else ctx = nullptr;
   }

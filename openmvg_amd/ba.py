@@ -171,6 +171,13 @@ class BaContext:
         _capi.check(_capi.lib().mvgx_ba_track_angles(self._h, out.ctypes.data))
         return out
 
+    LINEAR_SOLVERS = {"auto": 0, "dense": 1, "sparse": 2, "sparse_preferred": 3}
+
+    def set_linear_solver(self, kind):
+        """the caller's linear_solver_type_ (sfm_data_BA_ceres.cpp:132-146,483): "auto", "dense" (DENSE_SCHUR), "sparse" /
+        "sparse_preferred" (SPARSE_SCHUR) - mvgx_ba_set_linear_solver; before the first iteration, or naming the solver in place"""
+        _capi.check(_capi.lib().mvgx_ba_set_linear_solver(self._h, self.LINEAR_SOLVERS.get(kind, kind)))
+
     def solver_info(self):
         """how the reduced camera system is solved (mvgx_ba_get_solver_info; valid after the first iteration)"""
         info = _capi.BaSolverInfo()

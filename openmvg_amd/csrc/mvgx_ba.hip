@@ -2913,7 +2913,9 @@ struct mvgx_ba_ctx {
   int bs_chain_levels = 0;   // the top levels of the elimination tree with one tile column each (sp_backsolve_chain_kernel), 0: none
   bool plan_ready = false, plan_sparse = false;   // symbolic phase of the reduced solve done (mvgx_ba_create; again at the first iteration when a communicator was attached since)
   double x_sqerr = 0;   // sum of squared residuals at x (the RMSE's numerator), kept with x_cost
-  int solver_mode = 0;             // MVGX_BA_SOLVER: 0 auto, 1 dense, 2 sparse
+  int solver_mode = 0;             // MVGX_BA_SOLVER / mvgx_ba_set_linear_solver: 0 auto, 1 dense, 2 sparse, 3 sparse when its plan exists
+  bool solver_from_env = false;    // MVGX_BA_SOLVER names the solver: mvgx_ba_set_linear_solver leaves it alone
+  bool plan_tried = false, plan_ok = false;   // the last plan_solver attempted the sparse plan / it exists
   mvgx_sparse::Plan plan;          // host copy of the schedule (launch geometry per level)
   int update128_min_tiles = 128;   // tuning (MVGX_BA_UPDATE128_MIN_TILES): deferred updates with at least this many 128 x 128 tiles use them
   int two_level_min_n = 2048;   // tuning (MVGX_BA_TWO_LEVEL_MIN_N): reduced systems at least this wide factor with 256-column outer panels
@@ -3297,7 +3299,8 @@ int plan_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>
         (int)(np + d.n_intr), d.N, blocks, [&](int cb) { return cb < (int)np ? 6 : 8; },
         [&](int cb) { return cb < (int)np ? 6 * cb : 6 * (int)np + 8 * (cb - (int)np); }, prm, (uint64_t)1 << 25, c->plan);
     const uint64_t nd = (uint64_t)((d.N + 63) / 64);
-    sparse = ok && (c->solver_mode == 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
+    c->plan_tried = true; c->plan_ok = ok;
+    sparse = ok && (c->solver_mode >= 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
     MVGX_REQUIRE(ok || c->solver_mode != 2, MVGX_ERR_UNSUPPORTED, "MVGX_BA_SOLVER=sparse: the reduced system fills too much for the task lists");
   }
   if (sparse && getenv("MVGX_BA_PLAN_DEBUG")) {
@@ -3822,7 +3825,10 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     if (last_on.exchange(on) != on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_debug), &on, sizeof(on));
   }
   if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
-  if (const char* env = getenv("MVGX_BA_SOLVER")) c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
+  if (const char* env = getenv("MVGX_BA_SOLVER")) {
+    c->solver_mode = !strcmp(env, "dense") ? 1 : !strcmp(env, "sparse") ? 2 : 0;
+    c->solver_from_env = true;   // ("auto" included: the library's rule, whatever the caller's options say)
+  }
   if (const char* env = getenv("MVGX_BA_TWO_LEVEL_MIN_N")) c->two_level_min_n = std::max(1, atoi(env));
   if (const char* env = getenv("MVGX_BA_UPDATE128_MIN_TILES")) c->update128_min_tiles = std::max(1, atoi(env));
   const uint64_t no = d.n_obs;
@@ -4768,6 +4774,30 @@ int mvgx_ba_track_angles(mvgx_ba_ctx* c, double* max_angle_deg) {
   MVGX_HIP(hipMemcpyAsync(max_angle_deg, out, (size_t)d.n_pts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVGX_HIP(hipStreamSynchronize(c->stream));
   return MVGX_OK;
+}
+
+// Options::linear_solver_type of the caller (sfm_data_BA_ceres.cpp:132-146 default, :483 hand-over; sequential_SfM.cpp:1193-1205 picks
+// DENSE_SCHUR / SPARSE_SCHUR by the pose count): both are direct Schur-complement solves, here the storage + factorisation of the
+// reduced camera system. Before the first iteration the plan is simply made again; afterwards the call succeeds when the solver in
+// place already is what `kind` asks for, else MVGX_ERR_STATE (the device arrays of the other solver were never allocated).
+int mvgx_ba_set_linear_solver(mvgx_ba_ctx* c, int kind) {
+  MVGX_REQUIRE(c, MVGX_ERR_ARG, "mvgx_ba_set_linear_solver: NULL context");
+  MVGX_REQUIRE(kind >= MVGX_BA_LINEAR_SOLVER_AUTO && kind <= MVGX_BA_LINEAR_SOLVER_SPARSE_PREFERRED, MVGX_ERR_ARG, "mvgx_ba_set_linear_solver: kind %d", kind);
+  if (c->multi) return mvgx::ba_multi_set_linear_solver(c->multi, kind);
+  if (c->solver_from_env || kind == c->solver_mode) return MVGX_OK;
+  if (c->solver_ready) {
+    const bool sparse_now = c->d.sp.enabled != 0;
+    const bool same = (kind == MVGX_BA_LINEAR_SOLVER_DENSE && !sparse_now) || (kind >= MVGX_BA_LINEAR_SOLVER_SPARSE && sparse_now) ||
+                      (kind == MVGX_BA_LINEAR_SOLVER_SPARSE_PREFERRED && !sparse_now && c->plan_tried && !c->plan_ok) || c->d.N == 0;
+    MVGX_REQUIRE(same, MVGX_ERR_STATE, "mvgx_ba_set_linear_solver(%d) after the first iteration: the %s solver is set up", kind, sparse_now ? "block-sparse" : "dense");
+    c->solver_mode = kind;
+    return MVGX_OK;
+  }
+  c->solver_mode = kind;
+  c->plan_ready = false;
+  if (multi_rank(c) || mvgx::ba_create_plan_deferred()) return MVGX_OK;   // (planned at the first iteration, on the union of the ranks' blocks)
+  MVGX_HIP(hipSetDevice(c->device));
+  return plan_solver(c, c->h_blocks);
 }
 
 int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {

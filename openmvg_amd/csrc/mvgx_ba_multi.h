@@ -22,6 +22,7 @@ int ba_multi_read_params(BaMulti* m, double* poses, double* intrinsics, double* 
 int ba_multi_residuals(BaMulti* m, double* residual_norm);
 int ba_multi_track_angles(BaMulti* m, double* max_angle_deg);
 int ba_multi_solver_info(BaMulti* m, mvgx_ba_solver_info* out);
+int ba_multi_set_linear_solver(BaMulti* m, int kind);
 int ba_multi_update(BaMulti* m, const mvgx_ba_problem* p);   // MVGX_ERR_STRUCTURE: not the structure the shards were cut from
 // internal (mvgx_ba.hip): fails the RCCL collectives a context has in flight (another shard of the same process failed);
 // argument checks shared by mvgx_ba_create and mvgx_ba_create_multi

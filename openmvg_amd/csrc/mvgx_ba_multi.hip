@@ -468,5 +468,10 @@ int ba_multi_track_angles(BaMulti* m, double* max_angle_deg) {
 }
 
 int ba_multi_solver_info(BaMulti* m, mvgx_ba_solver_info* out) { return mvgx_ba_get_solver_info(m->child[0], out); }
+int ba_multi_set_linear_solver(BaMulti* m, int kind) {   // (the shards plan on the union of their blocks: the same answer on each)
+  for (int r = 0; r < m->n; ++r)
+    if (const int rc = mvgx_ba_set_linear_solver(m->child[r], kind)) return rc;
+  return MVGX_OK;
+}
 
 }  // namespace mvgx

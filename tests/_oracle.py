@@ -737,7 +737,7 @@ def adapter():
                      "ref_cascade_matcher_regions_match_liop144", "ref_cascade_hash_u8", "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
-                     "mvgx_adapter_ba_release_context"):
+                     "mvgx_adapter_ba_release_context", "mvgx_adapter_ba_kept_solver_info"):
             setattr(both, name, getattr(b, name))
         both.ba_counters = b.mvgx_adapter_counters   # (the counters of the BA half)
         _adapter = both
