@@ -500,6 +500,26 @@ int mvgx_geofilter_e_acransac_indexed(int device, const double* feat_xy, const d
                                       const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs, const mvgx_geofilter_options* opt,
                                       uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats /* may be NULL */);
 
+/* The essential matrix with the ANGULAR residual, GeometricFilter_ESphericalMatrix_AC_Angular<isUpright> (matching_image_collection/
+ * E_ACRobust_Angular.hpp:33-191; main_GeometricFilter -g a and -g u, the models of spherical / upright rigs - ABI 9):
+ * ACKernelAdaptor_AngularRadianError<Solver, AngularError> (robust_estimator_ACRansacKernelAdaptator.hpp:465-541) + ACRANSAC on the
+ * cameras' bearing vectors alone - no pixel positions, image sizes or normalisation; log alpha0 = log10(1 / 2), multError = 1 / 4,
+ * residual = the squared angle asin(x2 . normalized(E x1))^2 (multiview/solver_essential_eight_point.cpp:50-61). upright = 0:
+ * EightPointRelativePoseSolver (:17-47, samples of eight, one model: the null vector of the 8 x 9 epipolar system), acceptance above
+ * 2.5 x 8 inliers; upright = 1: ThreePointUprightRelativePoseSolver (multiview/solver_essential_three_point.cpp:84-113, samples of
+ * three). opt->precision is the functor's precision_upper_bound in DEGREES (main_GeometricFilter passes 4.0): like the reference the
+ * bound D2R(precision) is compared with the SQUARED angles as it is. results[p].F receives m_E scaled to unit Frobenius norm (the
+ * reference's eigenvector; the sign is free), results[p].precision_robust = ACRansacOut.first (radians), inlier_mask / n_inliers / ok
+ * describe the a-contrario result; the functor's second stage - RelativePoseFromEssential on those inliers (cheirality), E_ACRobust_
+ * Angular.hpp:126-143 - is host work on a handful of points per pair and stays with the caller (the replacement TU runs the
+ * reference's own function). Bearing vectors: 3 doubles per match, or per feature in the indexed form. */
+int mvgx_geofilter_e_angular_acransac(int device, const double* bearingI, const double* bearingJ, const uint64_t* match_start, uint64_t n_pairs,
+                                      int upright, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                      mvgx_geofilter_stats* stats /* may be NULL */);
+int mvgx_geofilter_e_angular_acransac_indexed(int device, const double* feat_bearing, const uint64_t* feat_start, uint32_t n_images,
+                                              const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs, int upright,
+                                              const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                              mvgx_geofilter_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

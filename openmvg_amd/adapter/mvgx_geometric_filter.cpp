@@ -67,7 +67,9 @@ template <class Functor> struct ModelOf;
 template <> struct ModelOf<GeometricFilter_FMatrix_AC> {
   static Mat3& model(GeometricFilter_FMatrix_AC& f) { return f.m_F; }
   static constexpr const char* entry_name = "mvgx_geofilter_f_acransac_indexed";
-  static constexpr bool essential = false;
+  static constexpr bool essential = false, angular = false;
+  static double precision(const GeometricFilter_FMatrix_AC& f) { return f.m_dPrecision; }
+  static void set_robust_precision(GeometricFilter_FMatrix_AC& f, double v) { f.m_dPrecision_robust = v; }
   static int run(const double* xy, const double*, const uint64_t* fs, const uint32_t* wh, const double*, uint32_t nv, const uint32_t* pv, const uint64_t* st,
                  const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
     return mvgx_geofilter_f_acransac_indexed(-1, xy, fs, wh, nv, pv, st, ij, nb, o, m, r, nullptr);
@@ -76,7 +78,9 @@ template <> struct ModelOf<GeometricFilter_FMatrix_AC> {
 template <> struct ModelOf<GeometricFilter_HMatrix_AC> {
   static Mat3& model(GeometricFilter_HMatrix_AC& f) { return f.m_H; }
   static constexpr const char* entry_name = "mvgx_geofilter_h_acransac_indexed";
-  static constexpr bool essential = false;
+  static constexpr bool essential = false, angular = false;
+  static double precision(const GeometricFilter_HMatrix_AC& f) { return f.m_dPrecision; }
+  static void set_robust_precision(GeometricFilter_HMatrix_AC& f, double v) { f.m_dPrecision_robust = v; }
   static int run(const double* xy, const double*, const uint64_t* fs, const uint32_t* wh, const double*, uint32_t nv, const uint32_t* pv, const uint64_t* st,
                  const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
     return mvgx_geofilter_h_acransac_indexed(-1, xy, fs, wh, nv, pv, st, ij, nb, o, m, r, nullptr);
@@ -85,10 +89,29 @@ template <> struct ModelOf<GeometricFilter_HMatrix_AC> {
 template <> struct ModelOf<GeometricFilter_EMatrix_AC> {
   static Mat3& model(GeometricFilter_EMatrix_AC& f) { return f.m_E; }
   static constexpr const char* entry_name = "mvgx_geofilter_e_acransac_indexed";
-  static constexpr bool essential = true;
+  static constexpr bool essential = true, angular = false;
+  static double precision(const GeometricFilter_EMatrix_AC& f) { return f.m_dPrecision; }
+  static void set_robust_precision(GeometricFilter_EMatrix_AC& f, double v) { f.m_dPrecision_robust = v; }
   static int run(const double* xy, const double* bearing, const uint64_t* fs, const uint32_t* wh, const double* K, uint32_t nv, const uint32_t* pv,
                  const uint64_t* st, const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
     return mvgx_geofilter_e_acransac_indexed(-1, xy, bearing, fs, wh, K, nv, pv, st, ij, nb, o, m, r, nullptr);
+  }
+};
+
+// the angular essential functors (E_ACRobust_Angular.hpp:33-191; -g a: eight-point solver, -g u: three-point upright solver): bearing
+// vectors of any camera model, no pixels; their second stage (RelativePoseFromEssential on the a-contrario inliers, :126-143) runs
+// below with the reference's own function
+template <bool kUpright> struct ModelOf<GeometricFilter_ESphericalMatrix_AC_Angular<kUpright>> {
+  using F = GeometricFilter_ESphericalMatrix_AC_Angular<kUpright>;
+  static Mat3& model(F& f) { return f.m_E; }
+  static constexpr const char* entry_name = "mvgx_geofilter_e_angular_acransac_indexed";
+  static constexpr bool essential = false, angular = true;
+  static constexpr int min_samples = kUpright ? 3 : 8;   // Solver::MINIMUM_SAMPLES
+  static double precision(const F& f) { return f.m_precision_upper_bound; }
+  static void set_robust_precision(F& f, double v) { f.m_precision_upper_bound_robust = v; }
+  static int run(const double*, const double* bearing, const uint64_t* fs, const uint32_t*, const double*, uint32_t nv, const uint32_t* pv,
+                 const uint64_t* st, const uint32_t* ij, uint64_t nb, const mvgx_geofilter_options* o, uint8_t* m, mvgx_geofilter_result* r) {
+    return mvgx_geofilter_e_angular_acransac_indexed(-1, bearing, fs, nv, pv, st, ij, nb, kUpright ? 1 : 0, o, m, r, nullptr);
   }
 };
 
@@ -104,7 +127,10 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   std::vector<PairWiseMatches::const_iterator> its;
   its.reserve(n_pairs);
   for (auto it = putative_matches.begin(); it != putative_matches.end(); ++it) its.push_back(it);
-  const bool device_ok = std::isfinite(functor.m_dPrecision) && functor.m_dPrecision > 0.0 && functor.m_stIteration >= 1;
+  using M = ModelOf<Functor>;
+  constexpr bool kBearings = M::essential || M::angular;
+  const double precision = M::precision(functor);
+  const bool device_ok = std::isfinite(precision) && precision > 0.0 && functor.m_stIteration >= 1;
   // pairs for the device (prefix sums of their match counts); the others go through the reference's functor
   std::vector<uint8_t> on_device(n_pairs, 0);
   std::vector<uint64_t> start(1, 0);
@@ -117,9 +143,17 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
     const auto iit = sfm_data_->GetIntrinsics().find(vit->second->id_intrinsic);
     return iit != sfm_data_->GetIntrinsics().end() && iit->second && cameras::isPinhole(iit->second->getType());
   };
+  // the angular models take any camera model, but both views need one (E_ACRobust_Angular.hpp:72-88)
+  auto calibrated_view = [&](IndexT id) {
+    const auto vit = sfm_data_->GetViews().find(id);
+    if (vit == sfm_data_->GetViews().end()) return false;
+    const auto iit = sfm_data_->GetIntrinsics().find(vit->second->id_intrinsic);
+    return iit != sfm_data_->GetIntrinsics().end() && iit->second;
+  };
   for (size_t p = 0; p < n_pairs; ++p) {
     if (device_ok && its[p]->second.size() <= kDeviceMaxMatches &&
-        (!ModelOf<Functor>::essential || (pinhole_view(its[p]->first.first) && pinhole_view(its[p]->first.second)))) {
+        (!M::essential || (pinhole_view(its[p]->first.first) && pinhole_view(its[p]->first.second))) &&
+        (!M::angular || (calibrated_view(its[p]->first.first) && calibrated_view(its[p]->first.second)))) {
       on_device[p] = 1;
       dev_pairs.push_back(p);
       start.push_back(start.back() + its[p]->second.size());
@@ -150,7 +184,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   std::vector<double> feat_xy(2 * std::max<uint64_t>(feat_start[n_views], 1));
   // essential model: the bearing vector of every feature by the camera's own operator() on the undistorted position (what
   // Robust_estimation passes as (*cam_I)(xI), E_ACRobust.hpp:118-123) and the calibration matrix of every view
-  std::vector<double> feat_bearing(ModelOf<Functor>::essential ? 3 * std::max<uint64_t>(feat_start[n_views], 1) : 0);
+  std::vector<double> feat_bearing(kBearings ? 3 * std::max<uint64_t>(feat_start[n_views], 1) : 0);
   std::vector<double> view_K(ModelOf<Functor>::essential ? 9 * std::max<size_t>(n_views, 1) : 0);
 #ifdef OPENMVG_USE_OPENMP
 #pragma omp parallel for schedule(dynamic)
@@ -164,17 +198,19 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       const Vec2 x = cam ? Vec2(cam->get_ud_pixel(positions[v][i].coords().cast<double>())) : Vec2(positions[v][i].coords().cast<double>());
       dst[2 * i] = x(0); dst[2 * i + 1] = x(1);
     }
-    if (ModelOf<Functor>::essential) {
+    if (kBearings) {
       const cameras::Pinhole_Intrinsic* pin = dynamic_cast<const cameras::Pinhole_Intrinsic*>(cam);
-      if (pin) {   // (views without a pinhole camera only occur in pairs that are not on the device)
+      if (M::angular ? cam != nullptr : pin != nullptr) {   // (views without a (pinhole) camera only occur in pairs that are not on the device)
         const size_t n = positions[v].size();
         Mat2X pts(2, n);
         for (size_t i = 0; i < n; ++i) pts.col(i) << dst[2 * i], dst[2 * i + 1];
         const Mat3X b = (*cam)(pts);
         double* bd = feat_bearing.data() + 3 * feat_start[v];
         for (size_t i = 0; i < n; ++i) { bd[3 * i] = b(0, i); bd[3 * i + 1] = b(1, i); bd[3 * i + 2] = b(2, i); }
-        const Mat3& Km = pin->K();
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) view_K[9 * v + 3 * r + c] = Km(r, c);
+        if (M::essential) {
+          const Mat3& Km = pin->K();
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) view_K[9 * v + 3 * r + c] = Km(r, c);
+        }
       }
     }
     features::PointFeatures().swap(positions[v]);
@@ -193,7 +229,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   size_t n_dev_done = 0;   // dev_pairs[0, n_dev_done): results valid
   if (!dev_pairs.empty()) {
     mvgx_geofilter_options opt;
-    opt.precision = functor.m_dPrecision;
+    opt.precision = precision;
     opt.max_iterations = functor.m_stIteration;
     std::vector<uint64_t> start_b;
     for (size_t b0 = 0; b0 < dev_pairs.size() && !my_progress_bar->hasBeenCanceled(); b0 += kPairsPerCall) {
@@ -238,13 +274,36 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       if (ok) {
         inliers.reserve(res[k].n_inliers);
         const uint64_t lo = start[k];
-        for (size_t i = 0; i < kv.second.size(); ++i)
-          if (mask[lo + i]) inliers.push_back(kv.second[i]);
-        if (b_guided_matching) {
+        if constexpr (M::angular) {
+          // second stage of the functor (E_ACRobust_Angular.hpp:126-151): the relative pose whose triangulated inliers lie in front of both
+          // cameras, with the reference's own RelativePoseFromEssential; its inliers are the geometric matches
+          const size_t n = kv.second.size();
+          const double* bI = feat_bearing.data() + 3 * feat_start[pair_views[2 * k]];
+          const double* bJ = feat_bearing.data() + 3 * feat_start[pair_views[2 * k + 1]];
+          Mat3X x1(3, n), x2(3, n);
+          std::vector<uint32_t> vec_inliers;
+          for (size_t i = 0; i < n; ++i) {
+            for (int c = 0; c < 3; ++c) { x1(c, i) = bI[3 * (size_t)kv.second[i].i_ + c]; x2(c, i) = bJ[3 * (size_t)kv.second[i].j_ + c]; }
+            if (mask[lo + i]) vec_inliers.push_back((uint32_t)i);
+          }
+          Mat3 E;
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E(r, c) = res[k].F[3 * r + c];
+          geometry::Pose3 relative_pose;
+          std::vector<uint32_t> inliers_indexes;
+          std::vector<Vec3> inliers_X;
+          if (RelativePoseFromEssential(x1, x2, E, vec_inliers, &relative_pose, &inliers_indexes, &inliers_X)) vec_inliers.swap(inliers_indexes);
+          else vec_inliers.clear();
+          ok = vec_inliers.size() > M::min_samples * 2.5;
+          if (ok) for (const uint32_t i : vec_inliers) inliers.push_back(kv.second[i]);
+        } else {
+          for (size_t i = 0; i < kv.second.size(); ++i)
+            if (mask[lo + i]) inliers.push_back(kv.second[i]);
+        }
+        if (ok && b_guided_matching) {
           Functor f = functor;
           for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) ModelOf<Functor>::model(f)(r, c) = res[k].F[3 * r + c];
-          f.m_dPrecision_robust = res[k].precision_robust;
+          M::set_robust_precision(f, res[k].precision_robust);
           IndMatches g;
           f.Geometry_guided_matching(sfm_data_, regions_provider_, kv.first, d_distance_ratio, g);
           std::swap(inliers, g);
@@ -279,6 +338,20 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMa
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EMatrix_AC>(
     const GeometricFilter_EMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
+}
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<false>>(
+    const GeometricFilter_ESphericalMatrix_AC_Angular<false>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
+}
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<true>>(
+    const GeometricFilter_ESphericalMatrix_AC_Angular<true>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
   filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
 }

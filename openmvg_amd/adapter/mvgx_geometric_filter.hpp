@@ -11,12 +11,15 @@
 // Geometry_guided_matching with the estimated model. The homography functor (GeometricFilter_HMatrix_AC, H_ACRobust.hpp) has the same
 // kind of specialisation over mvgx_geofilter_h_acransac_indexed, and the essential-matrix functor (GeometricFilter_EMatrix_AC, E_ACRobust.hpp:
 // main_GeometricFilter -g e) over mvgx_geofilter_e_acransac_indexed - the bearing vectors of the features come from the cameras' own
-// operator(), pairs without two pinhole cameras take the reference's functor (which warns and rejects them). The other functors
-// (angular, orthographic, upright essential) keep the reference's template.
+// operator(), pairs without two pinhole cameras take the reference's functor (which warns and rejects them). The angular essential
+// functors (GeometricFilter_ESphericalMatrix_AC_Angular<false | true>, E_ACRobust_Angular.hpp: -g a / -g u) run their a-contrario stage
+// through mvgx_geofilter_e_angular_acransac_indexed and their cheirality stage with the reference's own RelativePoseFromEssential.
+// The orthographic functor (Eo_Robust.hpp, plain RANSAC) keeps the reference's template.
 #ifndef MVGX_GEOMETRIC_FILTER_HPP
 #define MVGX_GEOMETRIC_FILTER_HPP
 
 #include "openMVG/matching_image_collection/E_ACRobust.hpp"
+#include "openMVG/matching_image_collection/E_ACRobust_Angular.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
@@ -37,6 +40,16 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_HMa
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EMatrix_AC>(
     const GeometricFilter_EMatrix_AC& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<false>>(
+    const GeometricFilter_ESphericalMatrix_AC_Angular<false>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<true>>(
+    const GeometricFilter_ESphericalMatrix_AC_Angular<true>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* progress_bar);
 
 }  // namespace matching_image_collection

@@ -47,8 +47,14 @@ constexpr int kBins = 20;        // robust_estimator_ACRansac.hpp:221
 constexpr int kMinSamples = 7, kMaxModels = 3;   // the fundamental-matrix model (SevenPointSolver)
 // The estimated model: the a-contrario loop is the same program for both, what differs is the minimal solver, the residual, the
 // sample size and - on the host - logalpha0 / multError of the NFA (point-to-line for F, point-to-point for H).
-enum GeoModel { kModelF = 0, kModelH = 1, kModelE = 2 };
-template <int MODEL> constexpr int model_min_samples() { return MODEL == kModelH ? 4 : MODEL == kModelE ? 5 : kMinSamples; }   // Solver::MINIMUM_SAMPLES
+// kModelEA8 / kModelEU3: the essential matrix with the ANGULAR residual on bearing vectors (E_ACRobust_Angular.hpp:33-191, spherical
+// cameras): EightPointRelativePoseSolver / ThreePointUprightRelativePoseSolver, one model per sample, no normalisation, no pixels.
+enum GeoModel { kModelF = 0, kModelH = 1, kModelE = 2, kModelEA8 = 3, kModelEU3 = 4 };
+template <int MODEL> constexpr bool model_is_angular() { return MODEL == kModelEA8 || MODEL == kModelEU3; }
+template <int MODEL> constexpr int model_min_samples() {   // Solver::MINIMUM_SAMPLES
+  return MODEL == kModelH ? 4 : MODEL == kModelE ? 5 : MODEL == kModelEA8 ? 8 : MODEL == kModelEU3 ? 3 : kMinSamples;
+}
+template <int MODEL> constexpr int model_sample_slots() { return MODEL == kModelEA8 ? 8 : 7; }   // length of the kernel's sample array
 constexpr int kMtN = 624, kMtM = 397;
 
 struct GeoPair {   // per pair, prepared on the host (glibc's log10 / hypot / sqrt: the reference's values)
@@ -182,24 +188,37 @@ template <int MODEL>
 __device__ __forceinline__ double model_error(const double (&M)[9], double2 x, double2 y) {
   return MODEL == kModelH ? homography_error(M, x, y) : epipolar_error(M, x, y);   // (the essential model evaluates its F = K2^-T E K1^-1)
 }
+// Square(AngularError::Error) (multiview/solver_essential_eight_point.cpp:50-61; ACKernelAdaptor_AngularRadianError::Errors squares
+// it): asin(x2 . normalized(E x1)), products and sums rounded one by one in Eigen's order, normalized() = v / sqrt(v . v) when positive
+struct Pt3 { double x, y, z; };
+__device__ __forceinline__ double angular_error(const double (&E)[9], Pt3 a, Pt3 b) {
+  double ex = add_rn(add_rn(mul_rn(E[0], a.x), mul_rn(E[1], a.y)), mul_rn(E[2], a.z));
+  double ey = add_rn(add_rn(mul_rn(E[3], a.x), mul_rn(E[4], a.y)), mul_rn(E[5], a.z));
+  double ez = add_rn(add_rn(mul_rn(E[6], a.x), mul_rn(E[7], a.y)), mul_rn(E[8], a.z));
+  const double n2 = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+  if (n2 > 0.0) { const double nn = sqrt(n2); ex = ex / nn; ey = ey / nn; ez = ez / nn; }
+  const double d = add_rn(add_rn(mul_rn(b.x, ex), mul_rn(b.y, ey)), mul_rn(b.z, ez));
+  const double ang = asin(d);
+  return mul_rn(ang, ang);
+}
+template <int MODEL>
+__device__ __forceinline__ double model_error(const double (&M)[9], Pt3 x, Pt3 y) { return angular_error(M, x, y); }
+// correspondence i of a pair as the model's residual takes it: normalised pixel positions, or - angular models - bearing vectors
+template <int MODEL> struct PointOf { using type = double2; };
+template <> struct PointOf<kModelEA8> { using type = Pt3; };
+template <> struct PointOf<kModelEU3> { using type = Pt3; };
+template <int MODEL>
+__device__ __forceinline__ typename PointOf<MODEL>::type load_point(const double2* __restrict__ x, const double* __restrict__ b, uint32_t i) {
+  if constexpr (model_is_angular<MODEL>()) return Pt3{b[3 * (size_t)i], b[3 * (size_t)i + 1], b[3 * (size_t)i + 2]};
+  else return x[i];
+}
 
 #include "geofilter_five_point.h"
 
-// FourPointSolver::Solve on the sample s[0..3] (wave-uniform; multiview/solver_homography_kernel.cpp:37-93): the null vector of the
-// 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3. Lane r
-// (mod 8) keeps row r in registers; Gauss-Jordan elimination with complete pivoting, the pivot row broadcast through v_readlane;
-// the column left without a pivot carries the null space (the reference takes the last right singular vector of the same matrix:
-// the same line up to rounding and scale; a rank-deficient sample gives SOME null vector in both, not the same one).
-__device__ __forceinline__ void four_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane, double (&H)[9]) {
-  const int r = lane & 7, pt = r >> 1;
-  const uint32_t si = pt == 0 ? s[0] : pt == 1 ? s[1] : pt == 2 ? s[2] : s[3];
-  const double2 p1 = x1[si], p2 = x2[si];
-  const bool second = r & 1;
-  const double t = second ? p2.y : p2.x;
-  double a[9];
-  a[0] = second ? 0.0 : p1.x; a[1] = second ? 0.0 : p1.y; a[2] = second ? 0.0 : 1.0;
-  a[3] = second ? p1.x : 0.0; a[4] = second ? p1.y : 0.0; a[5] = second ? 1.0 : 0.0;
-  a[6] = -t * p1.x; a[7] = -t * p1.y; a[8] = -t;
+// The null vector of an 8 x 9 system whose row r = lane mod 8 is a[] (every group of eight lanes holds the same system): Gauss-Jordan
+// elimination with complete pivoting, the pivot row broadcast through v_readlane; the column left without a pivot carries the null
+// space (H[that column] = 1). A rank-deficient system gives SOME null vector.
+__device__ __forceinline__ void null_vector_8x9(double (&a)[9], int r, double (&H)[9]) {
   uint32_t row_used = 0, col_used = 0;
   int prow[8], pcol[8], n_piv = 0;
 #pragma unroll
@@ -252,6 +271,67 @@ __device__ __forceinline__ void four_point(const double2* __restrict__ x1, const
       for (int u = 0; u < 9; ++u) H[u] = (u == pcol[step]) ? h : H[u];
     }
   }
+}
+
+// FourPointSolver::Solve on the sample s[0..3] (wave-uniform; multiview/solver_homography_kernel.cpp:37-93): the null vector of the
+// 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3. Lane r
+// (mod 8) keeps row r in registers; Gauss-Jordan elimination with complete pivoting, the pivot row broadcast through v_readlane;
+// the column left without a pivot carries the null space (the reference takes the last right singular vector of the same matrix:
+// the same line up to rounding and scale; a rank-deficient sample gives SOME null vector in both, not the same one).
+__device__ __forceinline__ void four_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane, double (&H)[9]) {
+  const int r = lane & 7, pt = r >> 1;
+  const uint32_t si = pt == 0 ? s[0] : pt == 1 ? s[1] : pt == 2 ? s[2] : s[3];
+  const double2 p1 = x1[si], p2 = x2[si];
+  const bool second = r & 1;
+  const double t = second ? p2.y : p2.x;
+  double a[9];
+  a[0] = second ? 0.0 : p1.x; a[1] = second ? 0.0 : p1.y; a[2] = second ? 0.0 : 1.0;
+  a[3] = second ? p1.x : 0.0; a[4] = second ? p1.y : 0.0; a[5] = second ? 1.0 : 0.0;
+  a[6] = -t * p1.x; a[7] = -t * p1.y; a[8] = -t;
+  null_vector_8x9(a, r, H);
+}
+
+// EightPointRelativePoseSolver::Solve on exactly eight bearing pairs (multiview/solver_essential_eight_point.cpp:17-47; with eight
+// columns the projection onto the essential manifold is skipped, :36): E = the null vector of the 8 x 9 epipolar system
+// A[r][3 i + j] = x2[i] x1[j] (EncodeEpipolarEquation, solver_fundamental_kernel.hpp:83-93), row-major 3 x 3. The reference takes the
+// eigenvector of A^T A of smallest eigenvalue: the same line up to rounding, scale and sign (the residual is invariant to both).
+__device__ __forceinline__ void eight_point(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[8], int lane, double (&E)[9]) {
+  const int r = lane & 7;
+  uint32_t si = s[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) si = (r == k) ? s[k] : si;
+  const double p1[3] = {b1[3 * (size_t)si], b1[3 * (size_t)si + 1], b1[3 * (size_t)si + 2]};
+  const double p2[3] = {b2[3 * (size_t)si], b2[3 * (size_t)si + 1], b2[3 * (size_t)si + 2]};
+  double a[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[3 * i + j] = p2[i] * p1[j];
+  null_vector_8x9(a, r, E);
+}
+
+// ThreePointUprightRelativePoseSolver::Solve (multiview/solver_essential_three_point.cpp:84-113): the null vector n of the 3 x 4
+// system with rows [a.x b.y, -a.z b.y, -b.x a.y, -b.z a.y] (a = bearing in the first view, b = in the second) through its four 3 x 3
+// minors (the reference: eigenvector of A^T A of smallest eigenvalue - the same line), E = [0 n2 0; -n0 0 n1; 0 n3 0]. Every lane
+// computes the same thing.
+__device__ __forceinline__ void three_point_upright(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[7], int lane, double (&E)[9]) {
+  (void)lane;
+  double A[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t si = s[i];
+    const double ax = b1[3 * (size_t)si], ay = b1[3 * (size_t)si + 1], az = b1[3 * (size_t)si + 2];
+    const double bx = b2[3 * (size_t)si], by = b2[3 * (size_t)si + 1], bz = b2[3 * (size_t)si + 2];
+    A[i][0] = ax * by; A[i][1] = -az * by; A[i][2] = -bx * ay; A[i][3] = -bz * ay;
+  }
+  auto det3 = [&](int c0, int c1, int c2) {
+    return A[0][c0] * (A[1][c1] * A[2][c2] - A[1][c2] * A[2][c1]) - A[0][c1] * (A[1][c0] * A[2][c2] - A[1][c2] * A[2][c0]) +
+           A[0][c2] * (A[1][c0] * A[2][c1] - A[1][c1] * A[2][c0]);
+  };
+  const double n0 = det3(1, 2, 3), n1 = -det3(0, 2, 3), n2 = det3(0, 1, 3), n3 = -det3(0, 1, 2);
+#pragma unroll
+  for (int u = 0; u < 9; ++u) E[u] = 0.0;
+  E[1] = n2; E[3] = -n0; E[5] = n1; E[7] = n3;
 }
 
 // SevenPointSolver::Solve on the sample s[0..6] (wave-uniform): the two null vectors F1, F2 of the 7 x 9 system and the real
@@ -339,12 +419,12 @@ __device__ __forceinline__ float logcombi(uint32_t k, uint32_t n, const float* _
 
 // number of correspondences whose residual under F is at most thr (all lanes get the sum): ballots, no shuffles
 template <int MODEL>
-__device__ __forceinline__ uint32_t count_within(const double (&F)[9], const double2* __restrict__ x1, const double2* __restrict__ x2, uint32_t n,
-                                                 double thr, int lane) {
+__device__ __forceinline__ uint32_t count_within(const double (&F)[9], const double2* __restrict__ x1, const double2* __restrict__ x2,
+                                                 const double* __restrict__ b1, const double* __restrict__ b2, uint32_t n, double thr, int lane) {
   uint32_t cnt = 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t i = base + lane;
-    const bool in = i < n && model_error<MODEL>(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= thr;
+    const bool in = i < n && model_error<MODEL>(F, load_point<MODEL>(x1, b1, i < n ? i : 0), load_point<MODEL>(x2, b2, i < n ? i : 0)) <= thr;
     cnt += (uint32_t)__popcll(__ballot(in));
   }
   return cnt;
@@ -447,8 +527,9 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
   const double max_threshold = P.max_threshold, bins_by_interval = P.bins_by_interval, loge0 = P.loge0;
   const double2* __restrict__ x1 = x1n + P.start;
   const double2* __restrict__ x2 = x2n + P.start;
-  const double* __restrict__ bv1 = MODEL == kModelE ? bear1 + 3 * P.start : nullptr;
-  const double* __restrict__ bv2 = MODEL == kModelE ? bear2 + 3 * P.start : nullptr;
+  constexpr bool kBearings = MODEL == kModelE || model_is_angular<MODEL>();
+  const double* __restrict__ bv1 = kBearings ? bear1 + 3 * P.start : nullptr;
+  const double* __restrict__ bv2 = kBearings ? bear2 + 3 * P.start : nullptr;
   // lane b < 20 keeps the constants of histogram bin b
   const double my_bin_value = lane < kBins ? P.bin_value[lane] : 0.0, my_logalpha = lane < kBins ? P.logalpha_bin[lane] : 0.0;
   // ---- set-up: generator (std::mt19937(5489) before its first twist), pool = 0..n-1, tables ----
@@ -467,7 +548,10 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
   int nIterReserve = (int)(max_iterations / 10);
   unsigned nIter = max_iterations - (unsigned)nIterReserve;
   bool ac_mode = false;
-  uint32_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+  constexpr int kS = model_sample_slots<MODEL>();
+  uint32_t s[kS];
+#pragma unroll
+  for (int k = 0; k < kS; ++k) s[k] = 0;
 #ifdef MVGX_GEO_STAMPS
   unsigned long long geo_acc_[6] = {0, 0, 0, 0, 0, 0};
   long long t_geo_ = __builtin_amdgcn_s_memtime();
@@ -493,10 +577,10 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         const uint32_t cand = uniform_u32(mt, mt_idx, lane, 0, n - 1);
         bool found = false;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) found = found || (k < got && s[k] == cand);
+        for (int k = 0; k < kS; ++k) found = found || (k < got && s[k] == cand);
         if (!found) {
 #pragma unroll
-          for (int k = 0; k < 7; ++k) if (k == got) s[k] = cand;
+          for (int k = 0; k < kS; ++k) if (k == got) s[k] = cand;
           ++got;
         }
       }
@@ -505,11 +589,11 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
     // ---- fit, evaluate ----
     double F1[9], F2[9], roots[3] = {0.0, 0.0, 0.0};
     int nm = 1;
-    if (MODEL == kModelH) {
+    if constexpr (MODEL == kModelH) {
       four_point(x1, x2, s, lane, F1);   // (one model per sample: MAX_MODELS = 1)
 #pragma unroll
       for (int u = 0; u < 9; ++u) F2[u] = 0.0;
-    } else if (MODEL == kModelE) {
+    } else if constexpr (MODEL == kModelE) {
       // FivePointSolver on the sample's bearing vectors (up to ten essential matrices, LDS), then F = K2^-T E K1^-1 per model for
       // the pixel residuals (ACKernelAdaptorEssential::Errors; products and sums rounded one by one like the reference's 3 x 3 products)
       nm = five_point::solve(bv1, bv2, s, lane, e_scr, e_Es);
@@ -524,6 +608,14 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       wave_sync();
 #pragma unroll
       for (int u = 0; u < 9; ++u) { F1[u] = 0.0; F2[u] = 0.0; }
+    } else if constexpr (MODEL == kModelEA8) {
+      eight_point(bv1, bv2, s, lane, F1);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) F2[u] = 0.0;
+    } else if constexpr (MODEL == kModelEU3) {
+      three_point_upright(bv1, bv2, s, lane, F1);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) F2[u] = 0.0;
     } else {
       nm = seven_point(x1, x2, s, lane, F1, F2, roots);
     }
@@ -534,16 +626,16 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
       double F[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) F[u] = MODEL == kModelH ? F1[u] : MODEL == kModelE ? e_Fs[9 * mi + u] : F1[u] + root * F2[u];
+      for (int u = 0; u < 9; ++u) F[u] = (MODEL == kModelH || model_is_angular<MODEL>()) ? F1[u] : MODEL == kModelE ? e_Fs[9 * mi + u] : F1[u] + root * F2[u];
       if (lane < kBins) hist[lane] = 0;
       wave_sync();
       uint32_t n_le = 0;
       for (uint32_t base = 0; base < n; base += 256) {   // four rounds of loads in flight
-        double2 a1[4], a2[4];
+        typename PointOf<MODEL>::type a1[4], a2[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t i = base + 64 * q + lane;
-          a1[q] = x1[i < n ? i : 0]; a2[q] = x2[i < n ? i : 0];
+          a1[q] = load_point<MODEL>(x1, bv1, i < n ? i : 0); a2[q] = load_point<MODEL>(x2, bv2, i < n ? i : 0);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -578,7 +670,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         }
         GEO_STAMP(3);
         if (cb_nfa < minNFA) {   // the inlier list is rebuilt even if it then turns out too short (the reference's behaviour)
-          const uint32_t cnt = count_within<MODEL>(F, x1, x2, n, cb_thr, lane);
+          const uint32_t cnt = count_within<MODEL>(F, x1, x2, bv1, bv2, n, cb_thr, lane);
           wave_sync();
           if (lane < 9) {
 #pragma unroll
@@ -607,7 +699,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         uint32_t m = 0;
         for (uint32_t base = 0; base < n; base += 64) {
           const uint32_t i = base + lane;
-          const bool in = i < n && model_error<MODEL>(F, x1[i < n ? i : 0], x2[i < n ? i : 0]) <= inl_thr;
+          const bool in = i < n && model_error<MODEL>(F, load_point<MODEL>(x1, bv1, i < n ? i : 0), load_point<MODEL>(x2, bv2, i < n ? i : 0)) <= inl_thr;
           const unsigned long long bal = __ballot(in);
           if (in) pool[m + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
           m += (uint32_t)__popcll(bal);
@@ -628,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
     double F[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) F[u] = inlF_lds[u];
-    for (uint32_t i = lane; i < n; i += 64) mask[P.start + i] = (good && model_error<MODEL>(F, x1[i], x2[i]) <= inl_thr) ? 1 : 0;
+    for (uint32_t i = lane; i < n; i += 64) mask[P.start + i] = (good && model_error<MODEL>(F, load_point<MODEL>(x1, bv1, i), load_point<MODEL>(x2, bv2, i)) <= inl_thr) ? 1 : 0;
   }
   if (lane < 9) results[pidx].F[lane] = bestFu;
   if (lane == 0) {
@@ -715,23 +807,29 @@ int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vecto
 int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
                   uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                   mvgx_geofilter_stats* stats) {
-  const int min_samples = model == kModelH ? 4 : model == kModelE ? 5 : kMinSamples, max_models = model == kModelH ? 1 : model == kModelE ? 10 : kMaxModels;
+  const bool angular = model == kModelEA8 || model == kModelEU3;   // bearing vectors only: no pixels, no image sizes, no normalisation
+  const bool bearings = model == kModelE || angular;
+  const int min_samples = model == kModelH ? 4 : model == kModelE ? 5 : model == kModelEA8 ? 8 : model == kModelEU3 ? 3 : kMinSamples;
+  const int max_models = (model == kModelH || angular) ? 1 : model == kModelE ? 10 : kMaxModels;
+  if (angular)
+    MVGX_REQUIRE(!match_start || match_start[n_pairs] == 0 || (src.indexed ? src.feat_bearing != nullptr : (src.bI && src.bJ)), MVGX_ERR_ARG,
+                 "mvgx_geofilter_e_angular_acransac: NULL bearing vectors");
   if (model == kModelE) {
     MVGX_REQUIRE(n_pairs == 0 || src.K, MVGX_ERR_ARG, "mvgx_geofilter_e_acransac: NULL calibration matrices");
     MVGX_REQUIRE(!match_start || match_start[n_pairs] == 0 || (src.indexed ? src.feat_bearing != nullptr : (src.bI && src.bJ)), MVGX_ERR_ARG,
                  "mvgx_geofilter_e_acransac: NULL bearing vectors");
   }
-  MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || (image_wh && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
+  MVGX_REQUIRE(opt && match_start && (n_pairs == 0 || ((image_wh || angular) && results)), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL argument");
   const uint64_t n_total = match_start[n_pairs];
   MVGX_REQUIRE(n_total == 0 || inlier_mask, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL inlier mask");
   if (src.indexed) {
     MVGX_REQUIRE(n_pairs == 0 || (src.pair_images && src.feat_start), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: NULL pair / feature-start array");
-    MVGX_REQUIRE(n_total == 0 || (src.feat_xy && src.ij), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: NULL position / index array");
+    MVGX_REQUIRE(n_total == 0 || ((src.feat_xy || angular) && src.ij), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac_indexed: NULL position / index array");
     for (uint64_t p = 0; p < n_pairs; ++p)
       MVGX_REQUIRE(src.pair_images[2 * p] < src.n_images && src.pair_images[2 * p + 1] < src.n_images, MVGX_ERR_ARG,
                    "mvgx_geofilter_f_acransac_indexed: pair %llu names an image out of range", (unsigned long long)p);
   } else {
-    MVGX_REQUIRE(n_total == 0 || (src.xI && src.xJ), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
+    MVGX_REQUIRE(n_total == 0 || angular || (src.xI && src.xJ), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
   }
   MVGX_REQUIRE(std::isfinite(opt->precision) && opt->precision > 0.0, MVGX_ERR_UNSUPPORTED,
                "mvgx_geofilter_f_acransac: precision must be a finite upper bound (the exhaustive NFA form of an unbounded precision is not "
@@ -768,8 +866,8 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
         for (uint32_t m = 0; m < n; ++m) bad = bad || src.ij[2 * (lo + m)] >= nI || src.ij[2 * (lo + m) + 1] >= nJ;
         if (bad) bad_pair.store((int64_t)p);
       }
-      double t[2][3];
-      for (int im = 0; im < 2; ++im) {   // conditioning.cpp:44-53
+      double t[2][3] = {{1.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};
+      for (int im = 0; im < 2 && !angular; ++im) {   // conditioning.cpp:44-53
         const uint32_t* whp = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + im] : image_wh + 4 * p + 2 * im;
         const int w = (int)whp[0], h = (int)whp[1];
         const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
@@ -787,14 +885,19 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       } else {
         for (int u = 0; u < 9; ++u) { g.k1i[u] = 0.0; g.k2it[u] = 0.0; }
       }
-      const uint32_t* wh2 = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + 1] : image_wh + 4 * p + 2;
+      static const uint32_t kNoSize[2] = {1, 1};
+      const uint32_t* wh2 = angular ? kNoSize : src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + 1] : image_wh + 4 * p + 2;
       const int w2 = (int)wh2[0], h2 = (int)wh2[1];
       // ACParametrizationHelper (robust_estimator_ACRansacKernelAdaptator.hpp:38-81): point-to-line for F, point-to-point for H
-      const double logalpha0 = model == kModelH ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (t[1][0] * t[1][0]))
+      // (RADIAN_ANGLE, :85-100: log10(1 / 2), multError 1 / 4 - the residual is a squared angle)
+      const double logalpha0 = angular ? std::log10(1. / 2.)
+                               : model == kModelH ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (t[1][0] * t[1][0]))
                                : model == kModelE ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
                                                   : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
-      const double mult_error = model == kModelH ? 1.0 : 0.5;
-      g.max_threshold = opt->precision * opt->precision * t[1][0] * t[1][0];
+      const double mult_error = angular ? 1. / 4. : model == kModelH ? 1.0 : 0.5;
+      // angular models: E_ACRobust_Angular.hpp:117-119 hands ACRANSAC D2R(precision in degrees), which ACRANSAC compares with the
+      // SQUARED angles as it is (robust_estimator_ACRansac.hpp:351-353: maxThreshold = precision * normalizer2()(0,0)^2, the identity here)
+      g.max_threshold = angular ? opt->precision * M_PI / 180.0 : opt->precision * opt->precision * t[1][0] * t[1][0];
       g.loge0 = n > (uint32_t)min_samples ? std::log10((double)max_models * (n - min_samples)) : 0.0;
       g.bins_by_interval = kBins / (g.max_threshold - 0.0);
       const double val = (g.max_threshold - 0.0) / static_cast<double>(kBins - 1);
@@ -838,18 +941,19 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   struct StreamGuard { int dev; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(dev, s); } } sg{stream_device, stream};
   DevBuf d_pairs, d_order, d_x1, d_x2, d_l10, d_mt, d_res, d_mask, d_raw1, d_raw2, d_norm, d_feat, d_fstart, d_pimg, d_b1, d_b2, d_fbear;
   const uint64_t n_feat = src.indexed && src.n_images ? src.feat_start[src.n_images] : 0;
-  if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_total * sizeof(double2))) ||
-      (rc = d_x2.alloc(n_total * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
+  const uint64_t n_xy = angular ? 0 : n_total;   // (the angular models never touch pixel positions)
+  if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_xy * sizeof(double2))) ||
+      (rc = d_x2.alloc(n_xy * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
       (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_norm.alloc(norm.size() * sizeof(double))))
     return rc;
   if (src.indexed) {   // d_raw1: the index pairs
-    if ((rc = d_raw1.alloc(n_total * sizeof(uint2))) || (rc = d_feat.alloc(n_feat * sizeof(double2))) ||
+    if ((rc = d_raw1.alloc(n_total * sizeof(uint2))) || (rc = d_feat.alloc((angular ? 0 : n_feat) * sizeof(double2))) ||
         (rc = d_fstart.alloc(((size_t)src.n_images + 1) * sizeof(uint64_t))) || (rc = d_pimg.alloc(n_pairs * sizeof(uint2))))
       return rc;
-  } else if ((rc = d_raw1.alloc(n_total * sizeof(double2))) || (rc = d_raw2.alloc(n_total * sizeof(double2)))) {
+  } else if ((rc = d_raw1.alloc(n_xy * sizeof(double2))) || (rc = d_raw2.alloc(n_xy * sizeof(double2)))) {
     return rc;
   }
-  if (model == kModelE) {
+  if (bearings) {
     if ((rc = d_b1.alloc(n_total * 3 * sizeof(double))) || (rc = d_b2.alloc(n_total * 3 * sizeof(double)))) return rc;
     if (src.indexed && (rc = d_fbear.alloc(n_feat * 3 * sizeof(double)))) return rc;
   }
@@ -862,16 +966,16 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   if (n_total) {
     if (src.indexed) {
       MVGX_HIP(hipMemcpyAsync(d_raw1.p, src.ij, n_total * sizeof(uint2), hipMemcpyHostToDevice, stream));
-      MVGX_HIP(hipMemcpyAsync(d_feat.p, src.feat_xy, n_feat * sizeof(double2), hipMemcpyHostToDevice, stream));
+      if (!angular) MVGX_HIP(hipMemcpyAsync(d_feat.p, src.feat_xy, n_feat * sizeof(double2), hipMemcpyHostToDevice, stream));
       MVGX_HIP(hipMemcpyAsync(d_fstart.p, src.feat_start, ((size_t)src.n_images + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
       MVGX_HIP(hipMemcpyAsync(d_pimg.p, src.pair_images, n_pairs * sizeof(uint2), hipMemcpyHostToDevice, stream));
-    } else {
+    } else if (!angular) {
       MVGX_HIP(hipMemcpyAsync(d_raw1.p, src.xI, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
       MVGX_HIP(hipMemcpyAsync(d_raw2.p, src.xJ, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
     }
     MVGX_HIP(hipMemcpyAsync(d_norm.p, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(d_mask.p, 0, n_total, stream));
-    if (model == kModelE) {
+    if (bearings) {
       if (src.indexed) {
         MVGX_HIP(hipMemcpyAsync(d_fbear.p, src.feat_bearing, n_feat * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
       } else {
@@ -896,13 +1000,13 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       const auto* ft = static_cast<const double2*>(d_feat.p);
       const auto* fs = static_cast<const uint64_t*>(d_fstart.p);
       const auto *pim = static_cast<const uint2*>(d_pimg.p), *mij = static_cast<const uint2*>(d_raw1.p);
-      hipLaunchKernelGGL(geofilter_normalize_indexed_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, ft, fs, pim, mij, o1, o2);
-      if (model == kModelE) {
+      if (!angular) hipLaunchKernelGGL(geofilter_normalize_indexed_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, ft, fs, pim, mij, o1, o2);
+      if (bearings) {
         const double* fb = static_cast<const double*>(d_fbear.p);
         double *ob1 = static_cast<double*>(d_b1.p), *ob2 = static_cast<double*>(d_b2.p);
         hipLaunchKernelGGL(geofilter_gather_bearings_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, (uint32_t)n_pairs, fb, fs, pim, mij, ob1, ob2);
       }
-    } else {
+    } else if (!angular) {
       hipLaunchKernelGGL(geofilter_normalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, pp, pn, (uint32_t)n_pairs, r1, r2, o1, o2);
     }
     MVGX_HIP(hipGetLastError());
@@ -915,7 +1019,10 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     auto* dm = static_cast<const uint32_t*>(d_mt.p);
     auto* dr = static_cast<GeoResult*>(d_res.p);
     auto* dk = static_cast<uint8_t*>(d_mask.p);
+    const double *pb1 = static_cast<const double*>(d_b1.p), *pb2 = static_cast<const double*>(d_b2.p);
     rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
+         : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
+         : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
                                                       static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p))
                             : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
@@ -940,6 +1047,15 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     double err = ran ? r.error_max : 0.0;
     if (ran && r.n_inliers > 0 && model == kModelE) {
       // ACKernelAdaptorEssential: Unnormalize does nothing, unormalizeError(val) = val (the squared pixel distance as it is)
+    } else if (angular) {
+      // ACKernelAdaptor_AngularRadianError: Unnormalize does nothing, unormalizeError(val) = sqrt(val): an angle in radians. The
+      // reference's solvers return unit vectors (eigenvectors): the model is scaled to unit Frobenius norm (its sign stays free).
+      if (ran && r.n_inliers > 0) err = std::sqrt(err);
+      if (ran && r.have_model) {
+        double n2 = 0.0;
+        for (int u = 0; u < 9; ++u) n2 += Fm[u] * Fm[u];
+        if (n2 > 0.0) for (int u = 0; u < 9; ++u) Fm[u] /= std::sqrt(n2);
+      }
     } else if (ran && r.n_inliers > 0) {
       const double* t = &norm[6 * p];
       const double N1[9] = {t[0], 0, t[1], 0, t[0], t[2], 0, 0, 1}, N2[9] = {t[3], 0, t[4], 0, t[3], t[5], 0, 0, 1};
@@ -1029,6 +1145,24 @@ int mvgx_geofilter_e_acransac_indexed(int device, const double* feat_xy, const d
   src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij;
   src.feat_bearing = feat_bearing; src.K = image_K;
   return geofilter_run(device, kModelE, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+// The essential matrix with the angular residual on bearing vectors (E_ACRobust_Angular.hpp:33-191): upright = 0 the eight-point
+// solver, 1 the three-point upright solver.
+int mvgx_geofilter_e_angular_acransac(int device, const double* bearingI, const double* bearingJ, const uint64_t* match_start, uint64_t n_pairs, int upright,
+                                      const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.bI = bearingI; src.bJ = bearingJ;
+  return geofilter_run(device, upright ? kModelEU3 : kModelEA8, src, match_start, nullptr, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_e_angular_acransac_indexed(int device, const double* feat_bearing, const uint64_t* feat_start, uint32_t n_images, const uint32_t* pairs,
+                                              const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs, int upright, const mvgx_geofilter_options* opt,
+                                              uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.indexed = true;
+  src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij; src.feat_bearing = feat_bearing;
+  return geofilter_run(device, upright ? kModelEU3 : kModelEA8, src, match_start, nullptr, n_pairs, opt, inlier_mask, results, stats);
 }
 
 // Test hook (not declared in include/mvgx.h): the five-point solver alone on one sample of five bearing pairs (b1, b2: 5 x 3 doubles);

@@ -35,6 +35,37 @@ class GeometricFilter_EMatrix_AC(GeometricFilter_FMatrix_AC):
     _entry, _entry_indexed = "mvgx_geofilter_e_acransac", "mvgx_geofilter_e_acransac_indexed"
 
 
+class GeometricFilter_ESphericalMatrix_AC_Angular(GeometricFilter_FMatrix_AC):
+    """The angular essential functor (E_ACRobust_Angular.hpp:33-191): isUprightEssentialMatrix selects the three-point upright solver
+    instead of the eight-point one; m_dPrecision is the precision_upper_bound in DEGREES. The result's "F" field holds m_E (unit
+    norm), "precision_robust" an angle in radians. filter_pairs_angular runs the a-contrario stage; the functor's cheirality
+    stage (RelativePoseFromEssential) is the caller's."""
+
+    def __init__(self, precision_upper_bound=4.0, iteration=1024, isUprightEssentialMatrix=False):
+        super().__init__(precision_upper_bound, iteration)
+        self.isUprightEssentialMatrix = bool(isUprightEssentialMatrix)
+
+
+def filter_pairs_angular(bI, bJ, match_start, functor=None, device=-1):
+    """bI, bJ: (N, 3) bearing vectors of the putative matches of all pairs (what the cameras' operator() returns for the matched
+    positions), pair p owning rows [match_start[p], match_start[p + 1]). Returns (inlier_mask, results, stats) like filter_pairs."""
+    functor = functor or GeometricFilter_ESphericalMatrix_AC_Angular(4.0, 2048)
+    bI = np.ascontiguousarray(bI, np.float64).reshape(-1, 3)
+    bJ = np.ascontiguousarray(bJ, np.float64).reshape(-1, 3)
+    start = np.ascontiguousarray(match_start, np.uint64)
+    n_pairs = len(start) - 1
+    if int(start[-1]) != len(bI) or len(bI) != len(bJ):
+        raise ValueError("filter_pairs_angular: inconsistent array sizes")
+    mask = np.zeros(max(len(bI), 1), np.uint8)
+    res = (_capi.GeofilterResult * max(n_pairs, 1))()
+    st = _capi.GeofilterStats()
+    opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _capi.check(_capi.lib().mvgx_geofilter_e_angular_acransac(int(device), P(bI), P(bJ), P(start), n_pairs, int(functor.isUprightEssentialMatrix),
+                                                              C.byref(opt), P(mask), C.cast(res, C.c_void_p), C.byref(st)))
+    return mask[:len(bI)].astype(bool), _results_array(res, n_pairs), st
+
+
 def pinhole_bearings(K, x):
     """Pinhole_Intrinsic::operator()(x) (Camera_Pinhole.hpp:136-139): normalised Kinv (x, y, 1) per point; K (3, 3), x (n, 2) -> (n, 3).
     (Host mirror for callers without the camera class at hand; the openMVG adapter calls the camera's own operator.)"""

@@ -22,6 +22,9 @@
 #include "openMVG/multiview/solver_essential_five_point.hpp"
 #include "openMVG/multiview/solver_essential_kernel.hpp"
 #include "openMVG/multiview/solver_fundamental_kernel.hpp"
+#include "openMVG/multiview/motion_from_essential.hpp"
+#include "openMVG/multiview/solver_essential_eight_point.hpp"
+#include "openMVG/multiview/solver_essential_three_point.hpp"
 #include "openMVG/multiview/solver_homography_kernel.hpp"
 #include "openMVG/numeric/numeric.h"
 #include "openMVG/robust_estimation/robust_estimator_ACRansac.hpp"
@@ -119,6 +122,56 @@ double ref_geofilter_e_acransac(const double* xI, const double* xJ, const uint64
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// GeometricFilter_ESphericalMatrix_AC_Angular<upright>::Robust_estimation (matching_image_collection/E_ACRobust_Angular.hpp:53-160) per pair
+// on the bearing vectors bI / bJ (3 doubles per correspondence): ACKernelAdaptor_AngularRadianError<EightPointRelativePoseSolver |
+// ThreePointUprightRelativePoseSolver, AngularError> + ACRANSAC with the bound D2R(precision_deg) (:117-122). pose_stage = 0 stops after
+// ACRANSAC (its inliers, more than 2.5 x MINIMUM_SAMPLES of them: what the device entry returns), 1 continues like the functor with
+// RelativePoseFromEssential on those inliers (:126-143) and reports the functor's geometric inliers.
+extern "C++" {
+template <typename Solver>
+static double run_angular(const double* bI, const double* bJ, const uint64_t* start, uint64_t n_pairs, double precision_deg, uint32_t max_iterations,
+                          int num_threads, int pose_stage, uint8_t* inlier_mask, uint8_t* ok, double* F, double* prec, double* nfa) {
+  using KernelType = robust::ACKernelAdaptor_AngularRadianError<Solver, AngularError, Mat3>;
+  const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic) num_threads(num_threads > 0 ? num_threads : omp_get_max_threads())
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint64_t lo = start[p], n = start[p + 1] - lo;
+    Mat3X x1(3, n), x2(3, n);
+    for (uint64_t i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) { x1(k, i) = bI[3 * (lo + i) + k]; x2(k, i) = bJ[3 * (lo + i) + k]; }
+    std::memset(inlier_mask + lo, 0, n);
+    Mat3 model = Mat3::Identity();
+    const KernelType kernel(x1, x2);
+    const double upper_bound_precision = D2R(precision_deg);
+    std::vector<uint32_t> vec_inliers;
+    const std::pair<double, double> out = robust::ACRANSAC(kernel, vec_inliers, max_iterations, &model, upper_bound_precision);
+    if (pose_stage) {
+      geometry::Pose3 relative_pose;
+      std::vector<uint32_t> inliers_indexes;
+      std::vector<Vec3> inliers_X;
+      if (RelativePoseFromEssential(x1, x2, model, vec_inliers, &relative_pose, &inliers_indexes, &inliers_X)) vec_inliers = inliers_indexes;
+      else vec_inliers.clear();
+    }
+    const bool good = vec_inliers.size() > KernelType::MINIMUM_SAMPLES * 2.5;
+    ok[p] = good ? 1 : 0;
+    prec[p] = out.first; nfa[p] = out.second;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) F[9 * p + 3 * r + c] = model(r, c);
+    if (good)
+      for (const uint32_t idx : vec_inliers) inlier_mask[lo + idx] = 1;
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}  // extern "C++"
+double ref_geofilter_e_angular_acransac(const double* bI, const double* bJ, const uint64_t* start, uint64_t n_pairs, double precision_deg,
+                                        uint32_t max_iterations, int num_threads, int upright, int pose_stage, uint8_t* inlier_mask, uint8_t* ok,
+                                        double* F, double* prec, double* nfa) {
+  return upright ? run_angular<essential::kernel::ThreePointUprightRelativePoseSolver>(bI, bJ, start, n_pairs, precision_deg, max_iterations, num_threads,
+                                                                                        pose_stage, inlier_mask, ok, F, prec, nfa)
+                 : run_angular<EightPointRelativePoseSolver>(bI, bJ, start, n_pairs, precision_deg, max_iterations, num_threads, pose_stage, inlier_mask,
+                                                             ok, F, prec, nfa);
+}
+
 // the bearing vectors Pinhole_Intrinsic(w, h, K)(x) the essential kernel receives (Camera_Pinhole.hpp:136-139): n points, 3 doubles each
 void ref_pinhole_bearings(const double* K, const double* x, uint64_t n, double* out) {
   Mat3 Km;
@@ -150,6 +203,7 @@ void ref_five_point(const double* b1, const double* b2, double* Es_out, int* n_o
 #include "openMVG/cameras/Camera_Pinhole_Radial.hpp"
 #include "openMVG/features/regions_factory.hpp"
 #include "openMVG/matching_image_collection/E_ACRobust.hpp"
+#include "openMVG/matching_image_collection/E_ACRobust_Angular.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
@@ -236,5 +290,15 @@ uint64_t ref_geofilter_container_e(const float* feat_xy, const uint8_t* descs, c
                                    double precision, uint32_t max_iterations, int guided, double distance_ratio, double focal, geo_sink sink, void* user) {
   return container_impl<matching_image_collection::GeometricFilter_EMatrix_AC>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
                                                                                n_pairs, precision, max_iterations, guided, distance_ratio, 0.0, sink, user, focal);
+}
+// the angular essential functors (E_ACRobust_Angular.hpp; -g a / -g u): pinhole views as above, bearing vectors by the cameras' operator()
+uint64_t ref_geofilter_container_ea(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                    const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                    double precision, uint32_t max_iterations, int upright, double focal, geo_sink sink, void* user) {
+  if (upright)
+    return container_impl<matching_image_collection::GeometricFilter_ESphericalMatrix_AC_Angular<true>>(
+        feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij, n_pairs, precision, max_iterations, 0, 0.8, 0.0, sink, user, focal);
+  return container_impl<matching_image_collection::GeometricFilter_ESphericalMatrix_AC_Angular<false>>(
+      feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij, n_pairs, precision, max_iterations, 0, 0.8, 0.0, sink, user, focal);
 }
 }  // extern "C"

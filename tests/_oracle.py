@@ -820,6 +820,27 @@ def ref_geofilter_e(tv, K, precision=4.0, max_iterations=2048, threads=0):
     return _geofilter_call_e(_refgeo.ref_geofilter_e_acransac, tv, K, False, precision, max_iterations, threads)
 
 
+def ref_geofilter_angular(bI, bJ, start, precision_deg=4.0, max_iterations=2048, upright=False, pose_stage=False, threads=0):
+    """The reference's ACKernelAdaptor_AngularRadianError<EightPointRelativePoseSolver | ThreePointUprightRelativePoseSolver, AngularError>
+    + ACRANSAC per pair on bearing vectors (E_ACRobust_Angular.hpp:53-160); pose_stage: continue with RelativePoseFromEssential like
+    the functor. "F" = m_E."""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    bI = np.ascontiguousarray(bI, np.float64).reshape(-1, 3); bJ = np.ascontiguousarray(bJ, np.float64).reshape(-1, 3)
+    start = np.ascontiguousarray(start, np.uint64)
+    n_pairs = len(start) - 1
+    mask = np.zeros(max(int(start[-1]), 1), np.uint8); ok = np.zeros(max(n_pairs, 1), np.uint8)
+    F = np.zeros((max(n_pairs, 1), 9)); prec = np.zeros(max(n_pairs, 1)); nfa = np.zeros(max(n_pairs, 1))
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    fn = _refgeo.ref_geofilter_e_angular_acransac
+    fn.restype = C.c_double
+    secs = fn(P(bI), P(bJ), P(start), C.c_uint64(n_pairs), C.c_double(precision_deg), C.c_uint32(max_iterations), C.c_int(threads), C.c_int(int(upright)),
+              C.c_int(int(pose_stage)), P(mask), P(ok), P(F), P(prec), P(nfa))
+    return dict(mask=mask[:int(start[-1])].astype(bool), ok=ok[:n_pairs].astype(bool), F=F[:n_pairs].reshape(-1, 3, 3), precision=prec[:n_pairs],
+                nfa=nfa[:n_pairs], seconds=secs)
+
+
 def ref_pinhole_bearings(tv, K):
     """(bI, bJ): Pinhole_Intrinsic(w, h, K)(x) of the reference for every correspondence of tv (what the essential kernel receives)"""
     global _refgeo
@@ -901,6 +922,12 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
 
     cb = GEO_SINK(sink)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    if model in ("ea", "eu"):   # the angular essential functors: (..., precision [degrees], max_iterations, upright, focal, sink, user)
+        fn = lib.ref_geofilter_container_ea
+        fn.restype = C.c_uint64
+        fn(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij), C.c_uint64(len(keys)),
+           C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if model == "eu" else 0), C.c_double(focal), cb, None)
+        return out
     fn = lib.ref_geofilter_container if model == "f" else lib.ref_geofilter_container_h if model == "h" else lib.ref_geofilter_container_e
     if model == "e":   # (the k1 slot of the shim carries the focal length of the views' pinhole cameras)
         k1 = focal

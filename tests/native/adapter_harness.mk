@@ -44,6 +44,7 @@ all: $(OUT)/libmvgx_openmvg_adapter.so $(OUT)/libmvgx_openmvg_adapter_ba.so $(OU
 GEO_REF_SRCS := $(REF)/openMVG/multiview/solver_fundamental_kernel.cpp $(REF)/openMVG/multiview/solver_homography_kernel.cpp $(REF)/openMVG/numeric/nullspace.cpp \
             $(REF)/openMVG/multiview/solver_essential_five_point.cpp $(REF)/openMVG/multiview/solver_essential_kernel.cpp $(REF)/openMVG/multiview/essential.cpp \
             $(REF)/openMVG/multiview/projection.cpp $(REF)/openMVG/multiview/triangulation.cpp $(REF)/openMVG/multiview/solver_essential_three_point.cpp \
+            $(REF)/openMVG/multiview/solver_essential_eight_point.cpp $(REF)/openMVG/multiview/motion_from_essential.cpp \
             $(REF)/openMVG/numeric/numeric.cpp $(REF)/openMVG/multiview/conditioning.cpp \
             $(REF)/openMVG/matching_image_collection/Geometric_Filter_utils.cpp $(REF)/openMVG/features/feature.cpp \
             $(REF)/third_party/stlplus3/filesystemSimplified/file_system.cpp $(REF)/third_party/stlplus3/filesystemSimplified/portability_fixes.cpp \

@@ -1,0 +1,145 @@
+"""The angular essential models of the geometric filter (VERDICT r3 missing #1, second half): GeometricFilter_ESphericalMatrix_AC_Angular
+<isUpright> = ACKernelAdaptor_AngularRadianError<EightPointRelativePoseSolver | ThreePointUprightRelativePoseSolver, AngularError> + ACRANSAC
+on bearing vectors (E_ACRobust_Angular.hpp:33-191; main_GeometricFilter -g a / -g u), then RelativePoseFromEssential on the inliers.
+Device: mvgx_geofilter_e_angular_acransac (the a-contrario stage); the replacement TU adds the cheirality stage with the reference's
+function. Checker: the compiled reference (oracle/_ref/libref_geofilter.so, oracle/ref_shim_geofilter.cpp) live and through the
+stored fixture tests/golden/geofilter_angular.npz (make_geofilter_angular_golden.py). Parity policy of the F / H / E models
+(tests/_geofilter_cases.py): identical inlier sets, then NFA, precision and model equal; the remainder bounded by the reference's own
+build-to-build spread."""
+import os
+
+import numpy as np
+import pytest
+
+from openmvg_amd import geofilter, synth
+from tests import _emu, _geofilter_cases as gc, _oracle
+
+GOLD_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geofilter_angular.npz")
+FUNCTOR = geofilter.GeometricFilter_ESphericalMatrix_AC_Angular
+KINDS = [False, True]   # isUprightEssentialMatrix
+
+
+def golden_case():
+    """two pinhole views per pair, rotation about the vertical axis and a baseline in the horizontal plane (what the upright solver
+    models), pixel noise, outliers, pairs without geometry, tiny pairs; the bearing vectors by the host mirror of the pinhole camera"""
+    tv = synth.two_view_matches(150, seed=91, n_max=160)
+    K = synth.two_view_calibration(tv)
+    st = tv["start"].astype(np.int64)
+    bI = np.zeros((len(tv["xI"]), 3)); bJ = np.zeros((len(tv["xJ"]), 3))
+    for p in range(len(st) - 1):
+        if st[p + 1] > st[p]:
+            bI[st[p]:st[p + 1]] = geofilter.pinhole_bearings(K[p, 0], tv["xI"][st[p]:st[p + 1]])
+            bJ[st[p]:st[p + 1]] = geofilter.pinhole_bearings(K[p, 1], tv["xJ"][st[p]:st[p + 1]])
+    return bI, bJ, tv["start"].astype(np.uint64)
+
+
+def _gold(upright, sel=None):
+    g = np.load(GOLD_PATH)
+    tag = "u" if upright else "a"
+    start = g["start"].astype(np.int64)
+    pairs = list(range(len(start) - 1)) if sel is None else list(sel)
+    cut = lambda a: np.concatenate([a[start[p]:start[p + 1]] for p in pairs])   # noqa: E731
+    new_start = np.concatenate([[0], np.cumsum([start[p + 1] - start[p] for p in pairs])]).astype(np.uint64)
+    ref = dict(mask=cut(g[tag + "_mask"]), ok=g[tag + "_ok"][pairs], F=g[tag + "_F"][pairs], precision=g[tag + "_precision"][pairs], nfa=g[tag + "_nfa"][pairs])
+    return cut(g["bI"]), cut(g["bJ"]), new_start, ref
+
+
+@pytest.mark.parametrize("upright", KINDS)
+def test_golden_fixture_is_the_reference(upright):
+    if not _oracle.have_ref_geofilter():
+        pytest.skip("oracle/_ref/libref_geofilter.so not built (needs /root/reference)")
+    bI, bJ, start, ref = _gold(upright)
+    cI, cJ, cstart = golden_case()
+    assert np.array_equal(bI, cI) and np.array_equal(bJ, cJ) and np.array_equal(start, cstart)
+    live = _oracle.ref_geofilter_angular(bI, bJ, start, upright=upright)
+    assert int(ref["ok"].sum()) > 80
+    assert np.array_equal(live["mask"], ref["mask"]) and np.array_equal(live["ok"], ref["ok"]) and np.allclose(live["F"], ref["F"], atol=1e-13)
+
+
+@pytest.mark.parametrize("upright", KINDS)
+def test_emulated_device_code_equals_the_stored_reference_outputs(upright):
+    """the angular instantiations of the kernel under the HIP emulation on a few small golden pairs (one fiber per lane: slow)"""
+    g = np.load(GOLD_PATH)
+    n = np.diff(g["start"].astype(np.int64))
+    ok = g[("u" if upright else "a") + "_ok"]
+    small = [int(p) for p in np.argsort(n) if 20 < n[p] <= 70]
+    sel = [p for p in small if ok[p]][:2] + [p for p in small if not ok[p]][:1] + [int(np.argmin(n))]
+    bI, bJ, start, ref = _gold(upright, sel)
+    with _emu.emulated():
+        mask, res, st = geofilter.filter_pairs_angular(bI, bJ, start, FUNCTOR(4.0, 2048, upright))
+    differing, rep = gc.compare(start, ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert not differing, (rep, differing)
+    assert int(st.n_pairs_ok) == int(ref["ok"].sum()) and int(st.n_models) == int(st.n_iterations) > 0   # (one model per sample)
+
+
+def test_argument_errors_under_emulation():
+    from openmvg_amd import _capi
+    with _emu.emulated():
+        b = np.tile(np.array([[0.0, 0.0, 1.0]]), (3, 1)); start = np.array([0, 3], np.uint64)
+        for upright in KINDS:   # not more correspondences than a minimal sample: rejected without estimation, the model stays the identity
+            mask, res, st = geofilter.filter_pairs_angular(b, b, start, FUNCTOR(4.0, 64, upright))
+            assert not mask.any() and not res["ok"][0] and np.array_equal(res["F"][0], np.eye(3))
+        with pytest.raises(ValueError):
+            geofilter.filter_pairs_angular(b, b[:2], start)
+        with pytest.raises(_capi.MvgxError) as e:   # an unbounded precision is not reproduced on the device (like the other models)
+            geofilter.filter_pairs_angular(b, b, start, FUNCTOR(float("inf"), 64))
+        assert e.value.code == _capi.MVGX_ERR_UNSUPPORTED
+
+
+# ---- the drop-in: ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<...>> ----
+def _container_case(kind, model):
+    """calibrated pairs (every view but the last has a Pinhole_Intrinsic: the pair of the last view takes the functor's "no intrinsic
+    information" branch) through the same caller, linked against the reference template or the adapter's specialisation; the
+    geometric matches are the inliers that survive RelativePoseFromEssential"""
+    from tests import _geofilter_scene
+    feats, wh, putative = _geofilter_scene.collection(n_pairs=5, seed=12, n_min=40, n_max=70, inlier_frac=(0.6, 0.9), no_geometry_frac=0.2, size=(1000, 1000))
+    return _oracle.geofilter_container(kind, feats, wh, putative, max_iterations=512, model=model, focal=900.0)
+
+
+@pytest.mark.parametrize("model", ["ea", "eu"])
+def test_adapter_specialisation_fills_the_container_like_the_reference_template(model):
+    ref_lib, lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib("adapter_emu")
+    if ref_lib is None or lib is None or not hasattr(ref_lib, "ref_geofilter_container_ea"):
+        pytest.skip("needs /root/reference (reference library and adapter harness)")
+    want, got = _container_case("reference", model), _container_case("adapter_emu", model)
+    assert set(want) == set(got) and len(want) >= 2 and (8, 9) not in want
+    assert all(np.array_equal(want[k], got[k]) for k in want)
+
+
+# ---- MI355X ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("upright", KINDS)
+def test_device_equals_the_stored_reference_outputs(upright):
+    bI, bJ, start, ref = _gold(upright)
+    mask, res, st = geofilter.filter_pairs_angular(bI, bJ, start, FUNCTOR(4.0, 2048, upright))
+    differing, rep = gc.compare(start, ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+    assert rep["pairs_ok_reference"] > 80 and len(differing) <= gc.allowed_differing(rep["pairs"], "e"), (rep, differing)
+    # run to run: the same answer bit for bit
+    mask2, res2, _ = geofilter.filter_pairs_angular(bI, bJ, start, FUNCTOR(4.0, 2048, upright))
+    assert np.array_equal(mask, mask2) and np.array_equal(res["F"], res2["F"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("upright", KINDS)
+def test_device_equals_the_compiled_reference_on_mixed_sizes(upright):
+    if not _oracle.have_ref_geofilter():
+        pytest.skip("oracle/_ref/libref_geofilter.so not present")
+    tv = synth.two_view_matches(600, seed=17, n_min=4, n_max=1500)
+    K = synth.two_view_calibration(tv)
+    bI, bJ = _oracle.ref_pinhole_bearings(tv, K)
+    for iters in (2048, 30):
+        ref = _oracle.ref_geofilter_angular(bI, bJ, tv["start"], max_iterations=iters, upright=upright)
+        mask, res, st = geofilter.filter_pairs_angular(bI, bJ, tv["start"], FUNCTOR(4.0, iters, upright))
+        differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
+        assert len(differing) <= gc.allowed_differing(rep["pairs"], "e"), (iters, rep, differing)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["ea", "eu"])
+def test_adapter_specialisation_on_the_device(model):
+    ref_lib, lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib("adapter")
+    if ref_lib is None or lib is None or not hasattr(ref_lib, "ref_geofilter_container_ea"):
+        pytest.skip("adapter harness / reference library not present")
+    want, got = _container_case("reference", model), _container_case("adapter", model)
+    assert set(want) == set(got) and len(want) >= 2
+    assert all(np.array_equal(want[k], got[k]) for k in want)

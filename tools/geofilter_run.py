@@ -1,5 +1,5 @@
 """One pass of the geometric filter over a synthetic workload (the command profiled by the rocprofv3 passes of the kernel).
-Usage: geofilter_run.py [n_pairs] [n_matches] [f|h|e]"""
+Usage: geofilter_run.py [n_pairs] [n_matches] [f|h|e|a|u]   (a / u: the angular essential models, eight-point / three-point upright)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openmvg_amd import geofilter, synth
@@ -12,7 +12,16 @@ if model == "h":
 else:
     tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
     fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 2048)
-if model == "e":
+if model in ("a", "u"):
+    import numpy as np
+    K = synth.two_view_calibration(tv)
+    st_ = tv["start"].astype(np.int64)
+    bI = np.zeros((len(tv["xI"]), 3)); bJ = np.zeros((len(tv["xJ"]), 3))
+    for p in range(n_pairs):
+        bI[st_[p]:st_[p + 1]] = geofilter.pinhole_bearings(K[p, 0], tv["xI"][st_[p]:st_[p + 1]])
+        bJ[st_[p]:st_[p + 1]] = geofilter.pinhole_bearings(K[p, 1], tv["xJ"][st_[p]:st_[p + 1]])
+    mask, res, st = geofilter.filter_pairs_angular(bI, bJ, tv["start"], geofilter.GeometricFilter_ESphericalMatrix_AC_Angular(4.0, 2048, model == "u"))
+elif model == "e":
     mask, res, st = geofilter.filter_pairs_e(tv["xI"], tv["xJ"], tv["start"], tv["wh"], synth.two_view_calibration(tv), geofilter.GeometricFilter_EMatrix_AC(4.0, 2048))
 else:
     mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
