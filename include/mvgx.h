@@ -520,6 +520,23 @@ int mvgx_geofilter_e_angular_acransac_indexed(int device, const double* feat_bea
                                               const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, uint64_t n_pairs, int upright,
                                               const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                                               mvgx_geofilter_stats* stats /* may be NULL */);
+/* The ORTHOGRAPHIC essential matrix, GeometricFilter_EOMatrix_RA (matching_image_collection/Eo_Robust.hpp:35-165; main_GeometricFilter
+ * -g o - ABI 9): ACKernelAdaptorEssentialOrtho<ThreePointKernel, OrthographicSymmetricEpipolarDistanceError>
+ * (robust_estimator_ACRansacKernelAdaptator.hpp:384-456) + ACRANSAC with samples of three and the two closed-form models of
+ * ThreePointsRelativePose per sample (multiview/solver_essential_three_point.cpp:31-79: + - x / sqrt only, evaluated in the
+ * reference's order without contraction - the models are the reference's bit for bit), residual |E22 + x0 E02 + x1 E12 + y0 E20 +
+ * y1 E21| (multiview/solver_essential_kernel.hpp:69-78), log alpha0 of the second image's size (point to line, scale 0.5), acceptance
+ * above 2.5 x 3 inliers. xI / xJ (feat_xy in the indexed form) are the HNORMALIZED bearing vectors (b.x / b.z, b.y / b.z of what the
+ * pinhole camera's operator() returns). pair_precision[p] = the bound the functor hands to ACRANSAC for pair p (Eo_Robust.hpp:96-100: the
+ * mean of the two cameras' imagePlane_toCameraPlaneError(precision^2)); NULL: opt->precision for every pair. results[p].F = m_E,
+ * precision_robust = ACRansacOut.first. */
+int mvgx_geofilter_eo_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh,
+                               const double* pair_precision, uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask,
+                               mvgx_geofilter_result* results, mvgx_geofilter_stats* stats /* may be NULL */);
+int mvgx_geofilter_eo_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                       const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, const double* pair_precision,
+                                       uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
+                                       mvgx_geofilter_stats* stats /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,10 @@ PROTOTYPES = {
                                             C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_geofilter_e_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_uint64, C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
+    "mvgx_geofilter_eo_acransac": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(GeofilterOptions),
+                                             C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
+    "mvgx_geofilter_eo_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_uint64, C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_geofilter_e_angular_acransac": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(GeofilterOptions),
                                                     C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_geofilter_e_angular_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,

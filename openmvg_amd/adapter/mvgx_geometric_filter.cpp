@@ -115,6 +115,20 @@ template <bool kUpright> struct ModelOf<GeometricFilter_ESphericalMatrix_AC_Angu
   }
 };
 
+// the orthographic essential functor (Eo_Robust.hpp:35-165; -g o): pinhole cameras only (the functor rejects the others, :85-88); the
+// device takes the hnormalized bearing vector of every feature in place of its pixel position and the bound of every pair (the mean
+// of the two cameras' imagePlane_toCameraPlaneError(precision^2), :96-100)
+template <> struct ModelOf<GeometricFilter_EOMatrix_RA> {
+  using F = GeometricFilter_EOMatrix_RA;
+  static Mat3& model(F& f) { return f.m_E; }
+  static constexpr const char* entry_name = "mvgx_geofilter_eo_acransac_indexed";
+  static constexpr bool essential = false, angular = false;
+  static double precision(const F& f) { return f.m_dPrecision; }
+  static void set_robust_precision(F&, double) {}
+};
+template <class Functor> struct IsOrtho { static constexpr bool value = false; };
+template <> struct IsOrtho<GeometricFilter_EOMatrix_RA> { static constexpr bool value = true; };
+
 // the body of both specialisations; the members of ImageCollectionGeometricFilter it works on are passed in under their names
 template <class Functor>
 void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm::Regions_Provider>& regions_provider_,
@@ -129,6 +143,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   for (auto it = putative_matches.begin(); it != putative_matches.end(); ++it) its.push_back(it);
   using M = ModelOf<Functor>;
   constexpr bool kBearings = M::essential || M::angular;
+  constexpr bool kOrtho = IsOrtho<Functor>::value;
   const double precision = M::precision(functor);
   const bool device_ok = std::isfinite(precision) && precision > 0.0 && functor.m_stIteration >= 1;
   // pairs for the device (prefix sums of their match counts); the others go through the reference's functor
@@ -152,7 +167,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   };
   for (size_t p = 0; p < n_pairs; ++p) {
     if (device_ok && its[p]->second.size() <= kDeviceMaxMatches &&
-        (!M::essential || (pinhole_view(its[p]->first.first) && pinhole_view(its[p]->first.second))) &&
+        (!(M::essential || kOrtho) || (pinhole_view(its[p]->first.first) && pinhole_view(its[p]->first.second))) &&
         (!M::angular || (calibrated_view(its[p]->first.first) && calibrated_view(its[p]->first.second)))) {
       on_device[p] = 1;
       dev_pairs.push_back(p);
@@ -198,6 +213,13 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       const Vec2 x = cam ? Vec2(cam->get_ud_pixel(positions[v][i].coords().cast<double>())) : Vec2(positions[v][i].coords().cast<double>());
       dst[2 * i] = x(0); dst[2 * i + 1] = x(1);
     }
+    if (kOrtho && cam && cameras::isPinhole(cam->getType())) {   // (*cam)(x).colwise().hnormalized() in place of the position
+      const size_t n = positions[v].size();
+      Mat2X pts(2, n);
+      for (size_t i = 0; i < n; ++i) pts.col(i) << dst[2 * i], dst[2 * i + 1];
+      const Mat2X h = (*cam)(pts).colwise().hnormalized();
+      for (size_t i = 0; i < n; ++i) { dst[2 * i] = h(0, i); dst[2 * i + 1] = h(1, i); }
+    }
     if (kBearings) {
       const cameras::Pinhole_Intrinsic* pin = dynamic_cast<const cameras::Pinhole_Intrinsic*>(cam);
       if (M::angular ? cam != nullptr : pin != nullptr) {   // (views without a (pinhole) camera only occur in pairs that are not on the device)
@@ -224,6 +246,14 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
     pair_views[2 * k] = view_slot.at(kv.first.first); pair_views[2 * k + 1] = view_slot.at(kv.first.second);
     if (!kv.second.empty()) std::memcpy(ij.data() + 2 * start[k], kv.second.data(), kv.second.size() * sizeof(matching::IndMatch));
   }
+  std::vector<double> pair_precision(kOrtho ? std::max<size_t>(dev_pairs.size(), 1) : 0);
+  if (kOrtho)
+    for (size_t k = 0; k < dev_pairs.size(); ++k) {
+      const auto& kv = *its[dev_pairs[k]];
+      const cameras::IntrinsicBase* cI = sfm_data_->GetIntrinsics().at(sfm_data_->GetViews().at(kv.first.first)->id_intrinsic).get();
+      const cameras::IntrinsicBase* cJ = sfm_data_->GetIntrinsics().at(sfm_data_->GetViews().at(kv.first.second)->id_intrinsic).get();
+      pair_precision[k] = (cI->imagePlane_toCameraPlaneError(Square(precision)) + cJ->imagePlane_toCameraPlaneError(Square(precision))) / 2.;
+    }
   std::vector<uint8_t> mask(start.back() ? start.back() : 1);
   std::vector<mvgx_geofilter_result> res(dev_pairs.size() ? dev_pairs.size() : 1);
   size_t n_dev_done = 0;   // dev_pairs[0, n_dev_done): results valid
@@ -237,10 +267,17 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
       start_b.assign(nb + 1, 0);
       for (size_t k = 0; k <= nb; ++k) start_b[k] = start[b0 + k] - start[b0];   // a call's match_start begins at zero
       const bool inj = mvgx_adapter::injected("geofilter", "run");
-      const int rc = inj ? MVGX_ERR_NODEV
-                         : ModelOf<Functor>::run(feat_xy.data(), feat_bearing.data(), feat_start.data(), wh.data(), view_K.data(), (uint32_t)n_views,
-                                                 pair_views.data() + 2 * b0, start_b.data(), ij.data() + 2 * start[b0], (uint64_t)nb, &opt,
-                                                 mask.data() + start[b0], res.data() + b0);
+      int rc = MVGX_ERR_NODEV;
+      if constexpr (kOrtho) {
+        if (!inj)
+          rc = mvgx_geofilter_eo_acransac_indexed(-1, feat_xy.data(), feat_start.data(), wh.data(), (uint32_t)n_views, pair_views.data() + 2 * b0, start_b.data(),
+                                                  ij.data() + 2 * start[b0], pair_precision.data() + b0, (uint64_t)nb, &opt, mask.data() + start[b0], res.data() + b0,
+                                                  nullptr);
+      } else if (!inj) {
+        rc = ModelOf<Functor>::run(feat_xy.data(), feat_bearing.data(), feat_start.data(), wh.data(), view_K.data(), (uint32_t)n_views,
+                                   pair_views.data() + 2 * b0, start_b.data(), ij.data() + 2 * start[b0], (uint64_t)nb, &opt, mask.data() + start[b0],
+                                   res.data() + b0);
+      }
       if (rc != MVGX_OK) {
         // logged once; the pairs from here on take the reference's own functor below (or the failure is thrown)
         mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", ModelOf<Functor>::entry_name, rc, inj);
@@ -352,6 +389,13 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESp
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<true>>(
     const GeometricFilter_ESphericalMatrix_AC_Angular<true>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
+  filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
+}
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EOMatrix_RA>(
+    const GeometricFilter_EOMatrix_RA& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* my_progress_bar) {
   filter_container(sfm_data_, regions_provider_, _map_GeometricMatches, functor, putative_matches, b_guided_matching, d_distance_ratio, my_progress_bar);
 }

@@ -14,12 +14,14 @@
 // operator(), pairs without two pinhole cameras take the reference's functor (which warns and rejects them). The angular essential
 // functors (GeometricFilter_ESphericalMatrix_AC_Angular<false | true>, E_ACRobust_Angular.hpp: -g a / -g u) run their a-contrario stage
 // through mvgx_geofilter_e_angular_acransac_indexed and their cheirality stage with the reference's own RelativePoseFromEssential.
-// The orthographic functor (Eo_Robust.hpp, plain RANSAC) keeps the reference's template.
+// The orthographic functor (GeometricFilter_EOMatrix_RA, Eo_Robust.hpp: -g o) goes through mvgx_geofilter_eo_acransac_indexed with the
+// hnormalized bearing vectors of pinhole cameras and the functor's camera-plane bound per pair.
 #ifndef MVGX_GEOMETRIC_FILTER_HPP
 #define MVGX_GEOMETRIC_FILTER_HPP
 
 #include "openMVG/matching_image_collection/E_ACRobust.hpp"
 #include "openMVG/matching_image_collection/E_ACRobust_Angular.hpp"
+#include "openMVG/matching_image_collection/Eo_Robust.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
@@ -50,6 +52,11 @@ void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESp
 template <>
 void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_ESphericalMatrix_AC_Angular<true>>(
     const GeometricFilter_ESphericalMatrix_AC_Angular<true>& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
+    const double d_distance_ratio, system::ProgressInterface* progress_bar);
+
+template <>
+void ImageCollectionGeometricFilter::Robust_model_estimation<GeometricFilter_EOMatrix_RA>(
+    const GeometricFilter_EOMatrix_RA& functor, const PairWiseMatches& putative_matches, const bool b_guided_matching,
     const double d_distance_ratio, system::ProgressInterface* progress_bar);
 
 }  // namespace matching_image_collection

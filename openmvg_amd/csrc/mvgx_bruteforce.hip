@@ -476,8 +476,17 @@ namespace {
 // (block_cols = cols < 128 ? cols : (stride * 4 < 32000 ? 16 : 4)); inside a block every output row accumulates
 // c = a(i, j) * x(j) + c from c = 0 in ascending j - a rounded product and a rounded sum, the reference objects are built without
 // FMA - and the block's c is then added to the row's result (res = c * 1 + res). One lane per descriptor reproduces exactly that
-// order with __fmul_rn / __fadd_rn (no contraction); the projection rows are wave-uniform and come through the scalar cache.
+// order with a rounded product and a rounded sum (cas_mul_rn / cas_add_rn below: no contraction); the projection rows are wave-uniform and come through the scalar cache.
 // P: [128 + groups * bits][128] floats, row q = row q of the primary projection, then the rows of the secondary projections.
+// (OCML's rounded operations: the toolchain's __fmul_rn / __fadd_rn are plain x * y / x + y unless OCML_BASIC_ROUNDED_OPERATIONS is defined on the
+// command line, and hipcc's default contraction turned this loop into v_pk_fma_f32 - found in round 4, mvgx_geofilter.hip has the story.)
+#ifdef __HIPCC__
+__device__ __forceinline__ float cas_mul_rn(float a, float b) { return __ocml_mul_rte_f32(a, b); }
+__device__ __forceinline__ float cas_add_rn(float a, float b) { return __ocml_add_rte_f32(a, b); }
+#else   // the HIP emulation of the test-suite
+__device__ __forceinline__ float cas_mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float cas_add_rn(float a, float b) { return __fadd_rn(a, b); }
+#endif
 constexpr int kCasDim = 128, kCasBlockCols = 16;
 __global__ __launch_bounds__(256) void cascade_hash_kernel(const uint32_t* __restrict__ words, uint64_t n_rows, const float* __restrict__ zero_mean,
                                                            const float* __restrict__ P, int n_groups, int bits, uint4* __restrict__ hash,
@@ -501,8 +510,8 @@ __global__ __launch_bounds__(256) void cascade_hash_kernel(const uint32_t* __res
     for (int b = 0; b < kCasDim / kCasBlockCols; ++b) {
       float c = 0.0f;
 #pragma unroll
-      for (int j = 0; j < kCasBlockCols; ++j) c = __fadd_rn(__fmul_rn(row[kCasBlockCols * b + j], d[kCasBlockCols * b + j]), c);
-      res = __fadd_rn(c, res);
+      for (int j = 0; j < kCasBlockCols; ++j) c = cas_add_rn(cas_mul_rn(row[kCasBlockCols * b + j], d[kCasBlockCols * b + j]), c);
+      res = cas_add_rn(c, res);
     }
     return res;
   };

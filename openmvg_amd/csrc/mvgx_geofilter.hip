@@ -49,10 +49,12 @@ constexpr int kMinSamples = 7, kMaxModels = 3;   // the fundamental-matrix model
 // sample size and - on the host - logalpha0 / multError of the NFA (point-to-line for F, point-to-point for H).
 // kModelEA8 / kModelEU3: the essential matrix with the ANGULAR residual on bearing vectors (E_ACRobust_Angular.hpp:33-191, spherical
 // cameras): EightPointRelativePoseSolver / ThreePointUprightRelativePoseSolver, one model per sample, no normalisation, no pixels.
-enum GeoModel { kModelF = 0, kModelH = 1, kModelE = 2, kModelEA8 = 3, kModelEU3 = 4 };
+// kModelEO: the orthographic essential matrix (Eo_Robust.hpp:35-165): ThreePointSolver (two models per sample) and
+// OrthographicSymmetricEpipolarDistanceError on the hnormalized bearing vectors, which travel in the pixel arrays (no normalisation).
+enum GeoModel { kModelF = 0, kModelH = 1, kModelE = 2, kModelEA8 = 3, kModelEU3 = 4, kModelEO = 5 };
 template <int MODEL> constexpr bool model_is_angular() { return MODEL == kModelEA8 || MODEL == kModelEU3; }
 template <int MODEL> constexpr int model_min_samples() {   // Solver::MINIMUM_SAMPLES
-  return MODEL == kModelH ? 4 : MODEL == kModelE ? 5 : MODEL == kModelEA8 ? 8 : MODEL == kModelEU3 ? 3 : kMinSamples;
+  return MODEL == kModelH ? 4 : MODEL == kModelE ? 5 : MODEL == kModelEA8 ? 8 : (MODEL == kModelEU3 || MODEL == kModelEO) ? 3 : kMinSamples;
 }
 template <int MODEL> constexpr int model_sample_slots() { return MODEL == kModelEA8 ? 8 : 7; }   // length of the kernel's sample array
 constexpr int kMtN = 624, kMtM = 397;
@@ -74,8 +76,16 @@ struct GeoResult {
 };
 
 // ---- arithmetic that must not be contracted into FMAs (the reference's build has none) ----
+// (The toolchain's __dmul_rn / __dadd_rn are plain x * y / x + y unless OCML_BASIC_ROUNDED_OPERATIONS is defined on the command line, and
+// hipcc's default -ffp-contract=fast-honor-pragmas fuses those into v_fma_f64 - measured in round 4: the orthographic solver differed
+// from the reference by 1e-9 until this was found. OCML's rounded operations are opaque to the contraction pass.)
+#ifdef __HIPCC__
+__device__ __forceinline__ double mul_rn(double a, double b) { return __ocml_mul_rte_f64(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __ocml_add_rte_f64(a, b); }
+#else   // the HIP emulation of the test-suite (host compiler; its header keeps the two operations apart)
 __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
 __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+#endif
 
 __device__ __forceinline__ void wave_sync() {   // LDS writes of this wave visible to its other lanes (a wave's LDS operations complete in order)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -184,9 +194,15 @@ __device__ __forceinline__ double homography_error(const double (&H)[9], double2
   const double dx = y.x - v0 / v2, dy = y.y - v1 / v2;
   return add_rn(mul_rn(dx, dx), mul_rn(dy, dy));
 }
+// OrthographicSymmetricEpipolarDistanceError (multiview/solver_essential_kernel.hpp:69-78): |E22 + x0 E02 + x1 E12 + y0 E20 + y1 E21|,
+// summed left to right, no contraction
+__device__ __forceinline__ double ortho_error(const double (&E)[9], double2 x, double2 y) {
+  return fabs(add_rn(add_rn(add_rn(add_rn(E[8], mul_rn(x.x, E[2])), mul_rn(x.y, E[5])), mul_rn(y.x, E[6])), mul_rn(y.y, E[7])));
+}
 template <int MODEL>
 __device__ __forceinline__ double model_error(const double (&M)[9], double2 x, double2 y) {
-  return MODEL == kModelH ? homography_error(M, x, y) : epipolar_error(M, x, y);   // (the essential model evaluates its F = K2^-T E K1^-1)
+  return MODEL == kModelH ? homography_error(M, x, y) : MODEL == kModelEO ? ortho_error(M, x, y)
+                                                                          : epipolar_error(M, x, y);   // (the essential model evaluates its F = K2^-T E K1^-1)
 }
 // Square(AngularError::Error) (multiview/solver_essential_eight_point.cpp:50-61; ACKernelAdaptor_AngularRadianError::Errors squares
 // it): asin(x2 . normalized(E x1)), products and sums rounded one by one in Eigen's order, normalized() = v / sqrt(v . v) when positive
@@ -308,6 +324,42 @@ __device__ __forceinline__ void eight_point(const double* __restrict__ b1, const
 #pragma unroll
     for (int j = 0; j < 3; ++j) a[3 * i + j] = p2[i] * p1[j];
   null_vector_8x9(a, r, E);
+}
+
+// ThreePointsRelativePose (multiview/solver_essential_three_point.cpp:31-79; ThreePointSolver::Solve, solver_essential_kernel.cpp:49-56): the two
+// orthographic essential matrices [0 0 a; 0 0 b; c d e] of three correspondences in closed form. Only + - x / sqrt in the reference's
+// evaluation order, every operation rounded on its own: the models are the reference's bit for bit (a negative radicand gives NaN
+// models in both, which no residual accepts). Every lane computes the same thing.
+__device__ __forceinline__ void three_point_ortho(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], double (&E1)[9],
+                                                  double (&E2)[9]) {
+  const double2 p0 = x1[s[0]], p1 = x1[s[1]], p2 = x1[s[2]], q0 = x2[s[0]], q1 = x2[s[1]], q2 = x2[s[2]];
+  const double xd1x = add_rn(p1.x, -p0.x), xd1y = add_rn(p1.y, -p0.y), yd1x = add_rn(p2.x, -p0.x), yd1y = add_rn(p2.y, -p0.y);
+  const double xd2x = add_rn(q1.x, -q0.x), xd2y = add_rn(q1.y, -q0.y), yd2x = add_rn(q2.x, -q0.x), yd2y = add_rn(q2.y, -q0.y);
+  const double denom = add_rn(mul_rn(xd1x, yd1y), -mul_rn(xd1y, yd1x));
+  const double aac = add_rn(mul_rn(xd1y, yd2x), -mul_rn(xd2x, yd1y)) / denom;
+  const double aad = add_rn(mul_rn(xd1y, yd2y), -mul_rn(xd2y, yd1y)) / denom;
+  const double bbc = add_rn(mul_rn(xd2x, yd1x), -mul_rn(xd1x, yd2x)) / denom;
+  const double bbd = add_rn(mul_rn(xd2y, yd1x), -mul_rn(xd1x, yd2y)) / denom;
+  const double aac_sq = mul_rn(aac, aac), bbc_sq = mul_rn(bbc, bbc);
+  const double dd_2 = add_rn(add_rn(add_rn(-aac_sq, mul_rn(aad, aad)), -bbc_sq), mul_rn(bbd, bbd));
+  const double dd_1c = add_rn(mul_rn(mul_rn(2.0, aac), aad), mul_rn(mul_rn(2.0, bbc), bbd));
+  const double dd_0 = add_rn(add_rn(aac_sq, bbc_sq), -1.0);
+  const double d4_4 = add_rn(mul_rn(dd_1c, dd_1c), mul_rn(dd_2, dd_2));
+  const double d4_2 = add_rn(mul_rn(-dd_1c, dd_1c), mul_rn(mul_rn(2.0, dd_0), dd_2));
+  const double d4_0 = mul_rn(dd_0, dd_0);
+  const double tmp = sqrt(add_rn(mul_rn(d4_2, d4_2), -mul_rn(mul_rn(4.0, d4_4), d4_0)));
+  auto essential = [&](double root, double (&E)[9]) {
+    const double dsol = sqrt(mul_rn(-root / d4_4, 0.5));   // (/ 2.0 is exact; sqrt and / round to nearest on the device: tools/ortho_probe.hip)
+    const double num = add_rn(add_rn(add_rn(mul_rn(mul_rn(dd_2, dsol), dsol), aac_sq), bbc_sq), -1.0);   // (tmp_csol is dd_2's expression)
+    const double den = add_rn(mul_rn(mul_rn(mul_rn(2.0, aac), aad), dsol), mul_rn(mul_rn(mul_rn(2.0, bbc), bbd), dsol));
+    const double csol = -num / den;
+    const double asol = add_rn(mul_rn(aac, csol), mul_rn(aad, dsol));
+    const double bsol = add_rn(mul_rn(bbc, csol), mul_rn(bbd, dsol));
+    const double esol = add_rn(add_rn(add_rn(mul_rn(-asol, p0.x), -mul_rn(bsol, p0.y)), -mul_rn(csol, q0.x)), -mul_rn(dsol, q0.y));
+    E[0] = 0.0; E[1] = 0.0; E[2] = asol; E[3] = 0.0; E[4] = 0.0; E[5] = bsol; E[6] = csol; E[7] = dsol; E[8] = esol;
+  };
+  essential(add_rn(d4_2, tmp), E1);
+  essential(add_rn(d4_2, -tmp), E2);
 }
 
 // ThreePointUprightRelativePoseSolver::Solve (multiview/solver_essential_three_point.cpp:84-113): the null vector n of the 3 x 4
@@ -616,6 +668,9 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       three_point_upright(bv1, bv2, s, lane, F1);
 #pragma unroll
       for (int u = 0; u < 9; ++u) F2[u] = 0.0;
+    } else if constexpr (MODEL == kModelEO) {
+      three_point_ortho(x1, x2, s, F1, F2);   // (MAX_MODELS = 2: model 0 = F1, model 1 = F2)
+      nm = 2;
     } else {
       nm = seven_point(x1, x2, s, lane, F1, F2, roots);
     }
@@ -626,7 +681,9 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       const double root = mi == 0 ? roots[0] : mi == 1 ? roots[1] : roots[2];
       double F[9];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) F[u] = (MODEL == kModelH || model_is_angular<MODEL>()) ? F1[u] : MODEL == kModelE ? e_Fs[9 * mi + u] : F1[u] + root * F2[u];
+      for (int u = 0; u < 9; ++u)
+        F[u] = (MODEL == kModelH || model_is_angular<MODEL>()) ? F1[u] : MODEL == kModelEO ? (mi == 0 ? F1[u] : F2[u]) : MODEL == kModelE ? e_Fs[9 * mi + u]
+                                                                                                                                                  : F1[u] + root * F2[u];
       if (lane < kBins) hist[lane] = 0;
       wave_sync();
       uint32_t n_le = 0;
@@ -775,6 +832,7 @@ struct GeoSource {
   // essential model: bearing vectors (3 per match, or 3 per feature when indexed) and the calibration matrices (row-major 3 x 3:
   // 18 doubles per pair {K_I, K_J}, or 9 per image when indexed)
   const double* bI = nullptr; const double* bJ = nullptr; const double* feat_bearing = nullptr; const double* K = nullptr;
+  const double* pair_precision = nullptr;   // orthographic model: the bound of every pair (NULL: opt->precision for all)
 };
 
 // inverse of a 3 x 3 matrix by cofactors (what Eigen's Matrix3d::inverse() evaluates: cofactors x 1 / det)
@@ -809,8 +867,8 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
                   mvgx_geofilter_stats* stats) {
   const bool angular = model == kModelEA8 || model == kModelEU3;   // bearing vectors only: no pixels, no image sizes, no normalisation
   const bool bearings = model == kModelE || angular;
-  const int min_samples = model == kModelH ? 4 : model == kModelE ? 5 : model == kModelEA8 ? 8 : model == kModelEU3 ? 3 : kMinSamples;
-  const int max_models = (model == kModelH || angular) ? 1 : model == kModelE ? 10 : kMaxModels;
+  const int min_samples = model == kModelH ? 4 : model == kModelE ? 5 : model == kModelEA8 ? 8 : (model == kModelEU3 || model == kModelEO) ? 3 : kMinSamples;
+  const int max_models = (model == kModelH || angular) ? 1 : model == kModelE ? 10 : model == kModelEO ? 2 : kMaxModels;
   if (angular)
     MVGX_REQUIRE(!match_start || match_start[n_pairs] == 0 || (src.indexed ? src.feat_bearing != nullptr : (src.bI && src.bJ)), MVGX_ERR_ARG,
                  "mvgx_geofilter_e_angular_acransac: NULL bearing vectors");
@@ -831,7 +889,10 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   } else {
     MVGX_REQUIRE(n_total == 0 || angular || (src.xI && src.xJ), MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: NULL correspondence array");
   }
-  MVGX_REQUIRE(std::isfinite(opt->precision) && opt->precision > 0.0, MVGX_ERR_UNSUPPORTED,
+  for (uint64_t p = 0; src.pair_precision && p < n_pairs; ++p)
+    MVGX_REQUIRE(std::isfinite(src.pair_precision[p]) && src.pair_precision[p] > 0.0, MVGX_ERR_UNSUPPORTED,
+                 "mvgx_geofilter_eo_acransac: pair %llu: precision must be a finite upper bound", (unsigned long long)p);
+  MVGX_REQUIRE(src.pair_precision || (std::isfinite(opt->precision) && opt->precision > 0.0), MVGX_ERR_UNSUPPORTED,
                "mvgx_geofilter_f_acransac: precision must be a finite upper bound (the exhaustive NFA form of an unbounded precision is not "
                "reproduced on the device; main_GeometricFilter passes 4.0)");
   MVGX_REQUIRE(opt->max_iterations >= 1, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: max_iterations must be at least 1");
@@ -872,7 +933,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
         const int w = (int)whp[0], h = (int)whp[1];
         const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
         t[im][0] = dNorm; t[im][1] = -.5f * w * dNorm; t[im][2] = -.5 * h * dNorm;
-        if (model == kModelE) { t[im][0] = 1.0; t[im][1] = 0.0; t[im][2] = 0.0; }   // ACKernelAdaptorEssential works on the pixels (N1 = N2 = I)
+        if (model == kModelE || model == kModelEO) { t[im][0] = 1.0; t[im][1] = 0.0; t[im][2] = 0.0; }   // ACKernelAdaptorEssential{,Ortho}: N1 = N2 = I
         for (int k = 0; k < 3; ++k) norm[6 * p + 3 * im + k] = t[im][k];
       }
       if (model == kModelE) {
@@ -892,12 +953,15 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       // (RADIAN_ANGLE, :85-100: log10(1 / 2), multError 1 / 4 - the residual is a squared angle)
       const double logalpha0 = angular ? std::log10(1. / 2.)
                                : model == kModelH ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (t[1][0] * t[1][0]))
-                               : model == kModelE ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
+                               : (model == kModelE || model == kModelEO) ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
                                                   : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / t[1][0]);
       const double mult_error = angular ? 1. / 4. : model == kModelH ? 1.0 : 0.5;
       // angular models: E_ACRobust_Angular.hpp:117-119 hands ACRANSAC D2R(precision in degrees), which ACRANSAC compares with the
       // SQUARED angles as it is (robust_estimator_ACRansac.hpp:351-353: maxThreshold = precision * normalizer2()(0,0)^2, the identity here)
-      g.max_threshold = angular ? opt->precision * M_PI / 180.0 : opt->precision * opt->precision * t[1][0] * t[1][0];
+      // orthographic model: the value the functor hands to ACRANSAC (Eo_Robust.hpp:96-100: the mean of the two cameras'
+      // imagePlane_toCameraPlaneError(precision^2)), per pair or one for all
+      g.max_threshold = model == kModelEO ? (src.pair_precision ? src.pair_precision[p] : opt->precision)
+                        : angular ? opt->precision * M_PI / 180.0 : opt->precision * opt->precision * t[1][0] * t[1][0];
       g.loge0 = n > (uint32_t)min_samples ? std::log10((double)max_models * (n - min_samples)) : 0.0;
       g.bins_by_interval = kBins / (g.max_threshold - 0.0);
       const double val = (g.max_threshold - 0.0) / static_cast<double>(kBins - 1);
@@ -1021,6 +1085,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     auto* dk = static_cast<uint8_t*>(d_mask.p);
     const double *pb1 = static_cast<const double*>(d_b1.p), *pb2 = static_cast<const double*>(d_b2.p);
     rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
+         : model == kModelEO ? launch_classes<kModelEO>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
          : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
@@ -1045,8 +1110,8 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = (ran && r.have_model) ? r.F[u] : ((u % 4 == 0) ? 1.0 : 0.0);   // m_F starts as the identity
     double err = ran ? r.error_max : 0.0;
-    if (ran && r.n_inliers > 0 && model == kModelE) {
-      // ACKernelAdaptorEssential: Unnormalize does nothing, unormalizeError(val) = val (the squared pixel distance as it is)
+    if (ran && r.n_inliers > 0 && (model == kModelE || model == kModelEO)) {
+      // ACKernelAdaptorEssential{,Ortho}: Unnormalize does nothing, unormalizeError(val) = val (the residual as it is)
     } else if (angular) {
       // ACKernelAdaptor_AngularRadianError: Unnormalize does nothing, unormalizeError(val) = sqrt(val): an angle in radians. The
       // reference's solvers return unit vectors (eigenvectors): the model is scaled to unit Frobenius norm (its sign stays free).
@@ -1163,6 +1228,23 @@ int mvgx_geofilter_e_angular_acransac_indexed(int device, const double* feat_bea
   src.indexed = true;
   src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij; src.feat_bearing = feat_bearing;
   return geofilter_run(device, upright ? kModelEU3 : kModelEA8, src, match_start, nullptr, n_pairs, opt, inlier_mask, results, stats);
+}
+
+// The orthographic essential matrix (Eo_Robust.hpp:35-165): xI / xJ (feat_xy) carry the hnormalized bearing vectors.
+int mvgx_geofilter_eo_acransac(int device, const double* xI, const double* xJ, const uint64_t* match_start, const uint32_t* image_wh, const double* pair_precision,
+                               uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.xI = xI; src.xJ = xJ; src.pair_precision = pair_precision;
+  return geofilter_run(device, kModelEO, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
+}
+
+int mvgx_geofilter_eo_acransac_indexed(int device, const double* feat_xy, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                       const uint32_t* pairs, const uint64_t* match_start, const uint32_t* ij, const double* pair_precision, uint64_t n_pairs,
+                                       const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results, mvgx_geofilter_stats* stats) {
+  GeoSource src;
+  src.indexed = true;
+  src.feat_xy = feat_xy; src.feat_start = feat_start; src.n_images = n_images; src.pair_images = pairs; src.ij = ij; src.pair_precision = pair_precision;
+  return geofilter_run(device, kModelEO, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
 }
 
 // Test hook (not declared in include/mvgx.h): the five-point solver alone on one sample of five bearing pairs (b1, b2: 5 x 3 doubles);

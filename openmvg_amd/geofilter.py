@@ -66,6 +66,50 @@ def filter_pairs_angular(bI, bJ, match_start, functor=None, device=-1):
     return mask[:len(bI)].astype(bool), _results_array(res, n_pairs), st
 
 
+class GeometricFilter_EOMatrix_RA(GeometricFilter_FMatrix_AC):
+    """The orthographic essential functor (Eo_Robust.hpp:35-165): same fields; m_dPrecision in pixels - filter_pairs_ortho turns it
+    into the camera-plane bound of every pair like the functor (mean of precision^2 / focal of the two cameras)."""
+
+
+def filter_pairs_ortho(xI, xJ, match_start, image_wh, K, functor=None, device=-1):
+    """The orthographic essential model on gathered correspondences (pixels xI / xJ of pinhole cameras K (n_pairs, 2, 3, 3)): the
+    hnormalized bearing vectors and the per-pair bound are formed here the way Eo_Robust.hpp:90-121 forms them.
+    Returns (inlier_mask, results, stats) like filter_pairs."""
+    functor = functor or GeometricFilter_EOMatrix_RA(2.0, 1024)
+    xI = np.ascontiguousarray(xI, np.float64).reshape(-1, 2)
+    xJ = np.ascontiguousarray(xJ, np.float64).reshape(-1, 2)
+    start = np.ascontiguousarray(match_start, np.uint64)
+    wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 4)
+    n_pairs = len(start) - 1
+    K = np.ascontiguousarray(K, np.float64).reshape(-1, 2, 3, 3)
+    if len(wh) != n_pairs or len(K) != n_pairs or int(start[-1]) != len(xI) or len(xI) != len(xJ):
+        raise ValueError("filter_pairs_ortho: inconsistent array sizes")
+    hI, hJ, prec = ortho_inputs(xI, xJ, start, K, functor.m_dPrecision)
+    mask = np.zeros(max(len(xI), 1), np.uint8)
+    res = (_capi.GeofilterResult * max(n_pairs, 1))()
+    st = _capi.GeofilterStats()
+    opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _capi.check(_capi.lib().mvgx_geofilter_eo_acransac(int(device), P(hI), P(hJ), P(start), P(wh), P(prec), n_pairs, C.byref(opt), P(mask),
+                                                       C.cast(res, C.c_void_p), C.byref(st)))
+    return mask[:len(xI)].astype(bool), _results_array(res, n_pairs), st
+
+
+def ortho_inputs(xI, xJ, start, K, precision):
+    """(hI, hJ, pair_precision): hnormalized pinhole bearings of the correspondences and (precision^2 / f_I + precision^2 / f_J) / 2 per pair
+    (Pinhole_Intrinsic::imagePlane_toCameraPlaneError, Camera_Pinhole.hpp:195-198)"""
+    st = np.asarray(start, np.int64)
+    hI = np.zeros((len(xI), 2)); hJ = np.zeros((len(xJ), 2)); prec = np.zeros(max(len(st) - 1, 1))
+    for p in range(len(st) - 1):
+        lo, hi = int(st[p]), int(st[p + 1])
+        for x, h, k in ((xI, hI, K[p, 0]), (xJ, hJ, K[p, 1])):
+            if hi > lo:
+                b = pinhole_bearings(k, x[lo:hi])
+                h[lo:hi] = b[:, :2] / b[:, 2:3]
+        prec[p] = (precision * precision / K[p, 0, 0, 0] + precision * precision / K[p, 1, 0, 0]) / 2.0
+    return np.ascontiguousarray(hI), np.ascontiguousarray(hJ), np.ascontiguousarray(prec)
+
+
 def pinhole_bearings(K, x):
     """Pinhole_Intrinsic::operator()(x) (Camera_Pinhole.hpp:136-139): normalised Kinv (x, y, 1) per point; K (3, 3), x (n, 2) -> (n, 3).
     (Host mirror for callers without the camera class at hand; the openMVG adapter calls the camera's own operator.)"""

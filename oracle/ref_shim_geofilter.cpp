@@ -172,6 +172,44 @@ double ref_geofilter_e_angular_acransac(const double* bI, const double* bJ, cons
                                                              ok, F, prec, nfa);
 }
 
+// GeometricFilter_EOMatrix_RA::Robust_estimation (matching_image_collection/Eo_Robust.hpp:50-144) per pair: the cameras are
+// Pinhole_Intrinsic(w, h, K) (K: 18 doubles per pair), the bound becomes the mean of imagePlane_toCameraPlaneError(precision^2) (:96-100),
+// ACKernelAdaptorEssentialOrtho<ThreePointKernel, OrthographicSymmetricEpipolarDistanceError> on the cameras' bearing vectors, ACRANSAC,
+// more than 2.5 x 3 inliers. F receives m_E.
+double ref_geofilter_eo_acransac(const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, const double* K, uint64_t n_pairs,
+                                 double precision, uint32_t max_iterations, int num_threads, uint8_t* inlier_mask, uint8_t* ok, double* F,
+                                 double* prec, double* nfa) {
+  using KernelType = robust::ACKernelAdaptorEssentialOrtho<essential::kernel::ThreePointKernel,
+                                                           essential::kernel::OrthographicSymmetricEpipolarDistanceError, Mat3>;
+  const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic) num_threads(num_threads > 0 ? num_threads : omp_get_max_threads())
+  for (int64_t p = 0; p < (int64_t)n_pairs; ++p) {
+    const uint64_t lo = start[p], n = start[p + 1] - lo;
+    Mat2X x1(2, n), x2(2, n);
+    for (uint64_t i = 0; i < n; ++i) {
+      x1.col(i) << xI[2 * (lo + i)], xI[2 * (lo + i) + 1];
+      x2.col(i) << xJ[2 * (lo + i)], xJ[2 * (lo + i) + 1];
+    }
+    std::memset(inlier_mask + lo, 0, n);
+    Mat3 K1, K2;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { K1(r, c) = K[18 * p + 3 * r + c]; K2(r, c) = K[18 * p + 9 + 3 * r + c]; }
+    const cameras::Pinhole_Intrinsic camI(wh[4 * p], wh[4 * p + 1], K1), camJ(wh[4 * p + 2], wh[4 * p + 3], K2);
+    const double bound = (camI.imagePlane_toCameraPlaneError(Square(precision)) + camJ.imagePlane_toCameraPlaneError(Square(precision))) / 2.;
+    Mat3 model = Mat3::Identity();
+    const KernelType kernel(camI(x1), wh[4 * p], wh[4 * p + 1], camJ(x2), wh[4 * p + 2], wh[4 * p + 3]);
+    std::vector<uint32_t> vec_inliers;
+    const std::pair<double, double> out = robust::ACRANSAC(kernel, vec_inliers, max_iterations, &model, bound);
+    const bool good = vec_inliers.size() > KernelType::MINIMUM_SAMPLES * 2.5;   // Eo_Robust.hpp:128
+    ok[p] = good ? 1 : 0;
+    prec[p] = out.first; nfa[p] = out.second;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) F[9 * p + 3 * r + c] = model(r, c);
+    if (good)
+      for (const uint32_t idx : vec_inliers) inlier_mask[lo + idx] = 1;
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // the bearing vectors Pinhole_Intrinsic(w, h, K)(x) the essential kernel receives (Camera_Pinhole.hpp:136-139): n points, 3 doubles each
 void ref_pinhole_bearings(const double* K, const double* x, uint64_t n, double* out) {
   Mat3 Km;
@@ -204,6 +242,7 @@ void ref_five_point(const double* b1, const double* b2, double* Es_out, int* n_o
 #include "openMVG/features/regions_factory.hpp"
 #include "openMVG/matching_image_collection/E_ACRobust.hpp"
 #include "openMVG/matching_image_collection/E_ACRobust_Angular.hpp"
+#include "openMVG/matching_image_collection/Eo_Robust.hpp"
 #include "openMVG/matching_image_collection/F_ACRobust.hpp"
 #include "openMVG/matching_image_collection/H_ACRobust.hpp"
 #include "openMVG/matching_image_collection/GeometricFilter.hpp"
@@ -300,5 +339,12 @@ uint64_t ref_geofilter_container_ea(const float* feat_xy, const uint8_t* descs, 
         feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij, n_pairs, precision, max_iterations, 0, 0.8, 0.0, sink, user, focal);
   return container_impl<matching_image_collection::GeometricFilter_ESphericalMatrix_AC_Angular<false>>(
       feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij, n_pairs, precision, max_iterations, 0, 0.8, 0.0, sink, user, focal);
+}
+// the orthographic essential functor (Eo_Robust.hpp; -g o): pinhole views as above
+uint64_t ref_geofilter_container_eo(const float* feat_xy, const uint8_t* descs, const uint64_t* feat_start, const uint32_t* image_wh, uint32_t n_images,
+                                    const uint32_t* pairs_IJ, const uint64_t* match_start, const uint32_t* matches_ij, uint64_t n_pairs,
+                                    double precision, uint32_t max_iterations, int guided, double distance_ratio, double focal, geo_sink sink, void* user) {
+  return container_impl<matching_image_collection::GeometricFilter_EOMatrix_RA>(feat_xy, descs, feat_start, image_wh, n_images, pairs_IJ, match_start, matches_ij,
+                                                                                n_pairs, precision, max_iterations, guided, distance_ratio, 0.0, sink, user, focal);
 }
 }  // extern "C"

@@ -841,6 +841,15 @@ def ref_geofilter_angular(bI, bJ, start, precision_deg=4.0, max_iterations=2048,
                 nfa=nfa[:n_pairs], seconds=secs)
 
 
+def ref_geofilter_eo(tv, K, precision=2.0, max_iterations=1024, threads=0):
+    """The reference's ACKernelAdaptorEssentialOrtho<ThreePointKernel, OrthographicSymmetricEpipolarDistanceError> + ACRANSAC per pair as
+    GeometricFilter_EOMatrix_RA::Robust_estimation runs it (Eo_Robust.hpp:50-144: pinhole cameras K, camera-plane bound); "F" = m_E."""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    return _geofilter_call_e(_refgeo.ref_geofilter_eo_acransac, tv, K, False, precision, max_iterations, threads)
+
+
 def ref_pinhole_bearings(tv, K):
     """(bI, bJ): Pinhole_Intrinsic(w, h, K)(x) of the reference for every correspondence of tv (what the essential kernel receives)"""
     global _refgeo
@@ -922,6 +931,12 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
 
     cb = GEO_SINK(sink)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    if model == "eo":   # the orthographic essential functor: the E container's signature
+        fn = lib.ref_geofilter_container_eo
+        fn.restype = C.c_uint64
+        fn(P(fx), None if dd is None else P(dd), P(fstart), P(wh), C.c_uint32(len(feats_xy)), P(pij), P(mstart), P(mij), C.c_uint64(len(keys)),
+           C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if guided else 0), C.c_double(ratio), C.c_double(focal), cb, None)
+        return out
     if model in ("ea", "eu"):   # the angular essential functors: (..., precision [degrees], max_iterations, upright, focal, sink, user)
         fn = lib.ref_geofilter_container_ea
         fn.restype = C.c_uint64
