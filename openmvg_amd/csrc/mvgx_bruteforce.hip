@@ -976,6 +976,26 @@ int mvgx_cascade_set_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_row
                                         n_groups, bits_per_bucket);
 }
 
+// Test hook (not declared in include/mvgx.h): out[0] = cas_add_rn(cas_mul_rn(a, b), c) as cascade_hash_kernel evaluates it, out[1] = fmaf(a, b, c)
+__global__ void cas_rounded_ops_debug_kernel(const float* abc, float* out) {
+  out[0] = cas_add_rn(cas_mul_rn(abc[0], abc[1]), abc[2]);
+  out[1] = fmaf(abc[0], abc[1], abc[2]);
+}
+int mvgx_debug_rounded_ops_f32(const float* abc, float* out) {
+  MVGX_REQUIRE(abc && out, MVGX_ERR_ARG, "mvgx_debug_rounded_ops_f32: NULL argument");
+  int rc = mvgx::select_device(-1);
+  if (rc) return rc;
+  Buf<float> din, dout;
+  struct Release { Buf<float>&a, &b; ~Release() { a.release(); b.release(); } } release{din, dout};
+  if ((rc = din.ensure(3)) || (rc = dout.ensure(2))) return rc;
+  MVGX_HIP(hipMemcpy(din.p, abc, 3 * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(cas_rounded_ops_debug_kernel, dim3(1), dim3(1), 0, nullptr, (const float*)din.p, dout.p);
+  MVGX_HIP(hipGetLastError());
+  MVGX_HIP(hipStreamSynchronize(nullptr));
+  MVGX_HIP(hipMemcpy(out, dout.p, 2 * sizeof(float), hipMemcpyDeviceToHost));
+  return MVGX_OK;
+}
+
 int mvgx_cascade_hash_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
                               const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
                               uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {

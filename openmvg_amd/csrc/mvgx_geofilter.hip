@@ -1247,6 +1247,30 @@ int mvgx_geofilter_eo_acransac_indexed(int device, const double* feat_xy, const 
   return geofilter_run(device, kModelEO, src, match_start, image_wh, n_pairs, opt, inlier_mask, results, stats);
 }
 
+// Test hook (not declared in include/mvgx.h): out[0] = add_rn(mul_rn(a, b), c) as the kernels of this file evaluate it, out[1] = fma(a, b, c) -
+// tests/test_rounded_ops_gpu.py feeds values on which the two differ, so that a toolchain that contracts the former is noticed
+__global__ void rounded_ops_debug_kernel(const double* abc, double* out) {
+  out[0] = add_rn(mul_rn(abc[0], abc[1]), abc[2]);
+  out[1] = fma(abc[0], abc[1], abc[2]);
+}
+int mvgx_debug_rounded_ops(const double* abc, double* out) {
+  MVGX_REQUIRE(abc && out, MVGX_ERR_ARG, "mvgx_debug_rounded_ops: NULL argument");
+  int rc = mvgx::select_device(-1);
+  if (rc) return rc;
+  DevBuf din, dout;
+  if ((rc = din.alloc(3 * sizeof(double))) || (rc = dout.alloc(2 * sizeof(double)))) return rc;
+  MVGX_HIP(hipMemcpy(din.p, abc, 3 * sizeof(double), hipMemcpyHostToDevice));
+  {
+    const double* pi = static_cast<const double*>(din.p);
+    double* po = static_cast<double*>(dout.p);
+    hipLaunchKernelGGL(rounded_ops_debug_kernel, dim3(1), dim3(1), 0, nullptr, pi, po);
+  }
+  MVGX_HIP(hipGetLastError());
+  MVGX_HIP(hipStreamSynchronize(nullptr));
+  MVGX_HIP(hipMemcpy(out, dout.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return MVGX_OK;
+}
+
 // Test hook (not declared in include/mvgx.h): the five-point solver alone on one sample of five bearing pairs (b1, b2: 5 x 3 doubles);
 // Es_out receives up to ten essential matrices (row-major), *n_out their number.
 __global__ void five_point_debug_kernel(const double* b1, const double* b2, double* Es_out, int* n_out) {
