@@ -341,6 +341,11 @@ def main():
             out["geometric_filter_essential"] = geofilter_bench_record(local_rank, n_pairs=20000, steps=1, cpu=not args.no_cpu_baseline, cpu_pairs=3000, model="e")
         except Exception as e:
             out["geometric_filter"] = {"status": f"failed: {e!r}"}
+        try:   # the other -g models of main_GeometricFilter (angular essential a / u, orthographic essential o): one pass each
+            from bench_geofilter import geofilter_other_models_record
+            out["geometric_filter_other_models"] = geofilter_other_models_record(local_rank, cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            out["geometric_filter_other_models"] = {"status": f"failed: {e!r}"}
     if rank == 0:
         if ba_rec is not None:
             out["ba"] = ba_rec

@@ -125,5 +125,54 @@ def geofilter_bench_record(device=0, n_pairs=100000, n=250, steps=2, cpu=True, c
     return rec
 
 
+def geofilter_other_models_record(device=0, n_pairs=20000, n=250, cpu=True, cpu_pairs=2000):
+    """The remaining -g models of main_GeometricFilter on the calibrated "f" set (one pass each): "a" / "u" = GeometricFilter_ESphericalMatrix_AC_
+    Angular<false | true> (a-contrario stage; E_ACRobust_Angular.hpp), "o" = GeometricFilter_EOMatrix_RA (Eo_Robust.hpp). Per model: whole-call and
+    kernel rates, the compiled reference on the first cpu_pairs pairs, parity with it (policy of the other records; "o" is closed form and
+    bit-identical on identical inputs - tests/test_geofilter_ortho.py - here the inputs are numpy's bearing vectors, equal to 1e-16)."""
+    import numpy as np
+    from openmvg_amd import geofilter, synth
+    tv = synth.two_view_matches_bulk(n_pairs, n=n, seed=0x6E0F)
+    K = synth.two_view_calibration(tv)
+    bI, bJ = geofilter.pinhole_bearings(K[0, 0], tv["xI"]), geofilter.pinhole_bearings(K[0, 1], tv["xJ"])   # (one calibration for the whole set)
+    out = {}
+    for model in ("a", "u", "o"):
+        try:
+            if model == "o":
+                fun = geofilter.GeometricFilter_EOMatrix_RA(2.0, 1024)
+                hI, hJ = np.ascontiguousarray(bI[:, :2] / bI[:, 2:3]), np.ascontiguousarray(bJ[:, :2] / bJ[:, 2:3])
+                prec = np.full(n_pairs, (4.0 / K[0, 0, 0, 0] + 4.0 / K[0, 1, 0, 0]) / 2.0)
+                run = lambda m: geofilter.filter_pairs_ortho_prepared(hI[:n * m], hJ[:n * m], tv["start"][:m + 1], tv["wh"][:m], prec[:m], fun, device)   # noqa: E731
+            else:
+                fun = geofilter.GeometricFilter_ESphericalMatrix_AC_Angular(4.0, 2048, model == "u")
+                run = lambda m: geofilter.filter_pairs_angular(bI[:n * m], bJ[:n * m], tv["start"][:m + 1], fun, device)   # noqa: E731
+            run(min(512, n_pairs))
+            mask, res, st = run(n_pairs)
+            rec = {"metric": "image pairs/s (a-contrario " + {"a": "angular essential, eight-point", "u": "angular essential, three-point upright",
+                                                               "o": "orthographic essential"}[model] + " filter of putative matches)",
+                   "value": n_pairs / (st.total_ms * 1e-3), "unit": "image pairs/s (whole call: host preparation, transfers, kernels)", "dtype": "f64",
+                   "image_pairs_per_s_kernel_time": n_pairs / (st.kernel_ms * 1e-3), "kernel_ms_per_pass": st.kernel_ms,
+                   "config": {"workload": f"{n_pairs} image pairs x {n} putative matches (the calibrated fundamental-matrix set)", "pairs_accepted": int(st.n_pairs_ok),
+                              "iterations": int(st.n_iterations)}}
+            if cpu:
+                from tests import _geofilter_cases as gc, _oracle
+                if _oracle.have_ref_geofilter():
+                    m = min(cpu_pairs, n_pairs)
+                    if model == "o":
+                        sub = dict(xI=tv["xI"][:n * m], xJ=tv["xJ"][:n * m], start=tv["start"][:m + 1], wh=tv["wh"][:m])
+                        ref = _oracle.ref_geofilter_eo(sub, K[:m], precision=2.0, max_iterations=1024)
+                    else:
+                        ref = _oracle.ref_geofilter_angular(bI[:n * m], bJ[:n * m], tv["start"][:m + 1], 4.0, 2048, upright=(model == "u"))
+                    rec["cpu_baseline"] = {"value": m / ref["seconds"], "unit": "image pairs/s", "cores": os.cpu_count(), "kind": "reference",
+                                           "sample": f"the first {m} pairs of the same set in {ref['seconds']:.2f} s (the functor's ACRANSAC stage, OpenMP over the pairs)"}
+                    rec["gpu_over_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+                    differing, rep = gc.compare(tv["start"][:m + 1], ref, mask[:n * m], res["ok"][:m], res["F"][:m], res["precision_robust"][:m], res["nfa"][:m])
+                    rec["parity"] = dict(rep, policy="identical inlier sets (then NFA, precision equal and E equal to 1e-6 - asserted)")
+            out[model] = rec
+        except Exception as e:
+            out[model] = {"status": f"failed: {e!r}"}
+    return out
+
+
 if __name__ == "__main__":
     print(json.dumps(geofilter_bench_record(cpu="--no-cpu" not in sys.argv)))

@@ -85,14 +85,26 @@ def filter_pairs_ortho(xI, xJ, match_start, image_wh, K, functor=None, device=-1
     if len(wh) != n_pairs or len(K) != n_pairs or int(start[-1]) != len(xI) or len(xI) != len(xJ):
         raise ValueError("filter_pairs_ortho: inconsistent array sizes")
     hI, hJ, prec = ortho_inputs(xI, xJ, start, K, functor.m_dPrecision)
-    mask = np.zeros(max(len(xI), 1), np.uint8)
+    return filter_pairs_ortho_prepared(hI, hJ, start, wh, prec, functor, device)
+
+
+def filter_pairs_ortho_prepared(hI, hJ, match_start, image_wh, pair_precision, functor=None, device=-1):
+    """mvgx_geofilter_eo_acransac on inputs in the entry's own terms: hnormalized bearing vectors (N, 2) and the bound of every pair"""
+    functor = functor or GeometricFilter_EOMatrix_RA(2.0, 1024)
+    hI = np.ascontiguousarray(hI, np.float64).reshape(-1, 2); hJ = np.ascontiguousarray(hJ, np.float64).reshape(-1, 2)
+    start = np.ascontiguousarray(match_start, np.uint64); wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 4)
+    prec = np.ascontiguousarray(pair_precision, np.float64)
+    n_pairs = len(start) - 1
+    if len(wh) != n_pairs or len(prec) < n_pairs or int(start[-1]) != len(hI) or len(hI) != len(hJ):
+        raise ValueError("filter_pairs_ortho_prepared: inconsistent array sizes")
+    mask = np.zeros(max(len(hI), 1), np.uint8)
     res = (_capi.GeofilterResult * max(n_pairs, 1))()
     st = _capi.GeofilterStats()
     opt = _capi.GeofilterOptions(functor.m_dPrecision, functor.m_stIteration)
     P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
     _capi.check(_capi.lib().mvgx_geofilter_eo_acransac(int(device), P(hI), P(hJ), P(start), P(wh), P(prec), n_pairs, C.byref(opt), P(mask),
                                                        C.cast(res, C.c_void_p), C.byref(st)))
-    return mask[:len(xI)].astype(bool), _results_array(res, n_pairs), st
+    return mask[:len(hI)].astype(bool), _results_array(res, n_pairs), st
 
 
 def ortho_inputs(xI, xJ, start, K, precision):

@@ -22,3 +22,9 @@ for k in ("geometric_filter", "geometric_filter_homography", "geometric_filter_e
                  f"alone {rf.get('clocks_per_iteration_one_wave_per_simd')} frac {rf.get('frac')}; parity {b.get('parity')}; cpu {b.get('cpu_baseline', {}).get('value')}")
     elif b:
         print(k, b)
+for m, b in (r.get("geometric_filter_other_models") or {}).items():
+    if isinstance(b, dict) and "value" in b:
+        print(f"geometric_filter -g {m}: {b['value']:.4g} pairs/s whole call, kernel {b.get('image_pairs_per_s_kernel_time', 0):.4g}; parity {b.get('parity')}; "
+              f"cpu {b.get('cpu_baseline', {}).get('value')}")
+    else:
+        print("geometric_filter_other_models", m, b)
