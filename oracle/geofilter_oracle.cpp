@@ -27,6 +27,18 @@
 //   multiview/conditioning.cpp:80-82                            UnnormalizerI
 // Pinned to the compiled reference and its stored outputs by tests/test_geofilter_h.py.
 //
+// The angular essential models (port_geofilter_e_angular_acransac) and the orthographic one (port_geofilter_eo_acransac), same loop:
+//   matching_image_collection/E_ACRobust_Angular.hpp:53-160     the a-contrario stage of GeometricFilter_ESphericalMatrix_AC_Angular<isUpright>
+//                                                               (bound D2R(precision), 2.5 x MINIMUM_SAMPLES); its RelativePoseFromEssential
+//                                                               stage (:126-143) is not restated: the compiled reference checks it
+//   robust_estimator_ACRansacKernelAdaptator.hpp:85-100,465-541 RADIAN_ANGLE: log alpha0 = log10(1 / 2), multError 1 / 4, no normalisation
+//   multiview/solver_essential_eight_point.cpp:17-61            EightPointRelativePoseSolver (null vector of the 8 x 9 system), AngularError
+//   multiview/solver_essential_three_point.cpp:31-113           ThreePointUprightRelativePoseSolver; ThreePointsRelativePose (closed form)
+//   matching_image_collection/Eo_Robust.hpp:50-144, robust_estimator_ACRansacKernelAdaptator.hpp:384-456, solver_essential_kernel.hpp:69-78
+//                                                               ACKernelAdaptorEssentialOrtho, OrthographicSymmetricEpipolarDistanceError
+// Pinned to the compiled reference's stored outputs by tests/test_geofilter_angular.py / test_geofilter_ortho.py (the orthographic model
+// bit for bit: closed form, this file is compiled with -ffp-contract=off).
+//
 // One deliberate difference: the reference takes the two-dimensional null space of the 7 x 9 system from
 // Eigen::SelfAdjointEigenSolver on A^T A (its two smallest eigenvectors); here it comes from Householder reflections of A^T (the
 // last two columns of Q), the device code uses complete-pivoting elimination. The three bases span the same plane for a sample in
@@ -351,6 +363,78 @@ int five_point(const double* b1, const double* b2, const uint32_t* s, Model* out
 }
 }  // namespace fivept
 
+// ---- the angular and the orthographic essential models (E_ACRobust_Angular.hpp:33-191, Eo_Robust.hpp:35-165) ----
+// EightPointRelativePoseSolver::Solve on exactly eight bearing pairs (multiview/solver_essential_eight_point.cpp:17-47): the null vector of
+// the 8 x 9 system A[r][3 i + j] = x2[i] x1[j]; with eight columns the projection onto the essential manifold is skipped (:36)
+int eight_point_bearings(const double* b1, const double* b2, const uint32_t s[8], Model out[1]) {
+  double A[8][9];
+  for (int r = 0; r < 8; ++r)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A[r][3 * i + j] = b2[3 * (size_t)s[r] + i] * b1[3 * (size_t)s[r] + j];
+  double o[1][9];
+  nullspace_rows<8>(A, o);
+  std::memcpy(out[0].f, o[0], sizeof(o[0]));
+  return 1;
+}
+// ThreePointUprightRelativePoseSolver::Solve (multiview/solver_essential_three_point.cpp:84-113): null vector n of the 3 x 4 system with rows
+// [a.x b.y, -a.z b.y, -b.x a.y, -b.z a.y] (here by its 3 x 3 minors), E = [0 n2 0; -n0 0 n1; 0 n3 0]
+int three_point_upright(const double* b1, const double* b2, const uint32_t s[3], Model out[1]) {
+  double A[3][4];
+  for (int i = 0; i < 3; ++i) {
+    const double* a = b1 + 3 * (size_t)s[i]; const double* b = b2 + 3 * (size_t)s[i];
+    A[i][0] = a[0] * b[1]; A[i][1] = -a[2] * b[1]; A[i][2] = -b[0] * a[1]; A[i][3] = -b[2] * a[1];
+  }
+  auto det3 = [&](int c0, int c1, int c2) {
+    return A[0][c0] * (A[1][c1] * A[2][c2] - A[1][c2] * A[2][c1]) - A[0][c1] * (A[1][c0] * A[2][c2] - A[1][c2] * A[2][c0]) +
+           A[0][c2] * (A[1][c0] * A[2][c1] - A[1][c1] * A[2][c0]);
+  };
+  const double n0 = det3(1, 2, 3), n1 = -det3(0, 2, 3), n2 = det3(0, 1, 3), n3 = -det3(0, 1, 2);
+  for (int u = 0; u < 9; ++u) out[0].f[u] = 0.0;
+  out[0].f[1] = n2; out[0].f[3] = -n0; out[0].f[5] = n1; out[0].f[7] = n3;
+  return 1;
+}
+// Square(AngularError::Error) (multiview/solver_essential_eight_point.cpp:50-61, ACKernelAdaptor_AngularRadianError::Errors)
+inline double angular_error_sq(const Model& E, const double* a, const double* b) {
+  double e[3];
+  for (int r = 0; r < 3; ++r) e[r] = (E.f[3 * r] * a[0] + E.f[3 * r + 1] * a[1]) + E.f[3 * r + 2] * a[2];
+  const double n2 = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+  if (n2 > 0.0) { const double nn = std::sqrt(n2); e[0] /= nn; e[1] /= nn; e[2] /= nn; }
+  const double ang = std::asin((b[0] * e[0] + b[1] * e[1]) + b[2] * e[2]);
+  return ang * ang;
+}
+// ThreePointsRelativePose (multiview/solver_essential_three_point.cpp:31-79): the two closed-form orthographic essential matrices
+int three_point_ortho(const double* x1, const double* x2, const uint32_t s[3], Model out[2]) {
+  const double *p0 = x1 + 2 * (size_t)s[0], *p1 = x1 + 2 * (size_t)s[1], *p2 = x1 + 2 * (size_t)s[2];
+  const double *q0 = x2 + 2 * (size_t)s[0], *q1 = x2 + 2 * (size_t)s[1], *q2 = x2 + 2 * (size_t)s[2];
+  const double xd1x = p1[0] - p0[0], xd1y = p1[1] - p0[1], yd1x = p2[0] - p0[0], yd1y = p2[1] - p0[1];
+  const double xd2x = q1[0] - q0[0], xd2y = q1[1] - q0[1], yd2x = q2[0] - q0[0], yd2y = q2[1] - q0[1];
+  const double denom = xd1x * yd1y - xd1y * yd1x;
+  const double aac = (xd1y * yd2x - xd2x * yd1y) / denom, aad = (xd1y * yd2y - xd2y * yd1y) / denom;
+  const double bbc = (xd2x * yd1x - xd1x * yd2x) / denom, bbd = (xd2y * yd1x - xd1x * yd2y) / denom;
+  const double aac_sq = aac * aac;
+  const double dd_2 = -aac_sq + aad * aad - bbc * bbc + bbd * bbd;
+  const double dd_1c = 2.0 * aac * aad + 2.0 * bbc * bbd;
+  const double dd_0 = aac_sq + bbc * bbc - 1.0;
+  const double d4_4 = dd_1c * dd_1c + dd_2 * dd_2;
+  const double d4_2 = -dd_1c * dd_1c + 2.0 * dd_0 * dd_2;
+  const double d4_0 = dd_0 * dd_0;
+  const double tmp = std::sqrt(d4_2 * d4_2 - 4.0 * d4_4 * d4_0);
+  for (int k = 0; k < 2; ++k) {
+    const double root = k == 0 ? d4_2 + tmp : d4_2 - tmp;
+    const double dsol = std::sqrt(-root / d4_4 / 2.0);
+    const double csol = -(dd_2 * dsol * dsol + aac_sq + bbc * bbc - 1.0) / (2.0 * aac * aad * dsol + 2.0 * bbc * bbd * dsol);
+    const double asol = aac * csol + aad * dsol, bsol = bbc * csol + bbd * dsol;
+    const double esol = -asol * p0[0] - bsol * p0[1] - csol * q0[0] - dsol * q0[1];
+    const double e[9] = {0, 0, asol, 0, 0, bsol, csol, dsol, esol};
+    std::memcpy(out[k].f, e, sizeof(e));
+  }
+  return 2;
+}
+// OrthographicSymmetricEpipolarDistanceError (multiview/solver_essential_kernel.hpp:69-78)
+inline double ortho_error(const Model& E, const double* x, const double* y) {
+  return std::abs(E.f[8] + x[0] * E.f[2] + x[1] * E.f[5] + y[0] * E.f[6] + y[1] * E.f[7]);
+}
+
 struct Pair {
   uint32_t n;
   std::vector<double> x1, x2;   // normalised
@@ -369,13 +453,19 @@ namespace {
 // homography = false: ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT> (point to line);
 // homography = true: ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI> configured point to point (H_ACRobust.hpp:77-87)
 // essential (K != NULL): ACKernelAdaptorEssential<FivePointSolver, EpipolarDistanceError> on the pixels, bearings = normalised Kinv (x, y, 1)
+// extra: kAngular8 / kUpright3 = ACKernelAdaptor_AngularRadianError<EightPointRelativePoseSolver | ThreePointUprightRelativePoseSolver, AngularError> on
+// the bearing vectors bI / bJ alone (precision in degrees, E_ACRobust_Angular.hpp:117-119); kOrtho = ACKernelAdaptorEssentialOrtho<ThreePointKernel,
+// OrthographicSymmetricEpipolarDistanceError> on hnormalized bearing vectors in xI / xJ with the bound pair_bound[p] (Eo_Robust.hpp:96-121)
+enum Extra { kNone = 0, kAngular8 = 3, kUpright3 = 4, kOrtho = 5 };
 double port_acransac(bool homography, const double* xI, const double* xJ, const uint64_t* start, const uint32_t* wh, uint64_t n_pairs,
                      double precision, uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout,
-                     double* prec, double* nfa_out, const double* K = nullptr, const double* bI = nullptr, const double* bJ = nullptr) {
+                     double* prec, double* nfa_out, const double* K = nullptr, const double* bI = nullptr, const double* bJ = nullptr,
+                     int extra = kNone, const double* pair_bound = nullptr) {
   const bool essential = K != nullptr;
-  const uint32_t kMin = homography ? 4 : essential ? 5 : 7;                 // Solver::MINIMUM_SAMPLES
-  const double max_models = homography ? 1.0 : essential ? 10.0 : 3.0;      // Solver::MAX_MODELS
-  const double mult_error = homography ? 1.0 : 0.5;         // ACParametrizationHelper::MultError
+  const bool angular = extra == kAngular8 || extra == kUpright3, ortho = extra == kOrtho;
+  const uint32_t kMin = extra == kAngular8 ? 8 : (extra == kUpright3 || ortho) ? 3 : homography ? 4 : essential ? 5 : 7;   // Solver::MINIMUM_SAMPLES
+  const double max_models = angular ? 1.0 : ortho ? 2.0 : homography ? 1.0 : essential ? 10.0 : 3.0;      // Solver::MAX_MODELS
+  const double mult_error = angular ? 0.25 : homography ? 1.0 : 0.5;         // ACParametrizationHelper::MultError
   const double inf = std::numeric_limits<double>::infinity();
   for (uint64_t pp = 0; pp < n_pairs; ++pp) {
     const uint64_t lo = start[pp];
@@ -385,12 +475,12 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
     for (int u = 0; u < 9; ++u) Fout[9 * pp + u] = (u % 4 == 0) ? 1.0 : 0.0;   // m_F = Identity
     if (n <= kMin) continue;
     // ---- ACKernelAdaptor: normalisation by the image sizes (conditioning.cpp:44-53) ----
-    double T[2][3];   // {s, tx, ty} of image I / J
-    for (int im = 0; im < 2; ++im) {
+    double T[2][3] = {{1.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};   // {s, tx, ty} of image I / J
+    for (int im = 0; im < 2 && !angular; ++im) {
       const int w = (int)wh[4 * pp + 2 * im], h = (int)wh[4 * pp + 2 * im + 1];
       const double dNorm = 1.0 / std::sqrt(static_cast<double>(w * h));
       T[im][0] = dNorm; T[im][1] = -.5f * w * dNorm; T[im][2] = -.5 * h * dNorm;
-      if (essential) { T[im][0] = 1.0; T[im][1] = 0.0; T[im][2] = 0.0; }   // N1 = N2 = I
+      if (essential || ortho) { T[im][0] = 1.0; T[im][1] = 0.0; T[im][2] = 0.0; }   // N1 = N2 = I
     }
     // essential: F = K2^-T E K1^-1 (multiview/essential.cpp:48-53), the inverses by cofactors
     double k1i[9], k2i[9];
@@ -405,15 +495,17 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
       }
     }
     std::vector<double> x1(2 * n), x2(2 * n);
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n && !angular; ++i) {
       x1[2 * i] = T[0][0] * xI[2 * (lo + i)] + T[0][1]; x1[2 * i + 1] = T[0][0] * xI[2 * (lo + i) + 1] + T[0][2];
       x2[2 * i] = T[1][0] * xJ[2 * (lo + i)] + T[1][1]; x2[2 * i + 1] = T[1][0] * xJ[2 * (lo + i) + 1] + T[1][2];
     }
-    const int w2 = (int)wh[4 * pp + 2], h2 = (int)wh[4 * pp + 3];
-    const double logalpha0 = homography ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (T[1][0] * T[1][0]))   // point to point
+    const int w2 = angular ? 1 : (int)wh[4 * pp + 2], h2 = angular ? 1 : (int)wh[4 * pp + 3];
+    const double logalpha0 = angular ? std::log10(1. / 2.)   // RADIAN_ANGLE (robust_estimator_ACRansacKernelAdaptator.hpp:85-94)
+                             : ortho ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)
+                             : homography ? std::log10(M_PI / (w2 * static_cast<double>(h2)) / (T[1][0] * T[1][0]))   // point to point
                              : essential ? std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / 0.5)   // LogAlpha0(w2, h2, 0.5)
                                         : std::log10(2. * std::hypot(w2, h2) / (w2 * static_cast<double>(h2)) / T[1][0]);   // point to line
-    const double upper = precision * precision;
+    const double upper = angular ? precision * M_PI / 180.0 : ortho ? pair_bound[pp] : precision * precision;   // (D2R(precision); the functor's bound)
     const bool quantified = upper != inf;
     if (!quantified) continue;   // the exhaustive NFA form (no precision bound) is not restated: main_GeometricFilter always passes one
     const double max_threshold = upper * T[1][0] * T[1][0];
@@ -455,7 +547,13 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
       }
       Model models[10], emodels[10];
       int nm;
-      if (essential) {
+      if (extra == kAngular8) {
+        nm = eight_point_bearings(bI + 3 * lo, bJ + 3 * lo, vec_sample.data(), models);
+      } else if (extra == kUpright3) {
+        nm = three_point_upright(bI + 3 * lo, bJ + 3 * lo, vec_sample.data(), models);
+      } else if (ortho) {
+        nm = three_point_ortho(x1.data(), x2.data(), vec_sample.data(), models);
+      } else if (essential) {
         nm = fivept::five_point(bI + 3 * lo, bJ + 3 * lo, vec_sample.data(), emodels);
         for (int mi = 0; mi < nm; ++mi) {   // the model evaluated on the pixels: F = K2^-T E K1^-1
           double tmp[9];
@@ -467,7 +565,9 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
       }
       bool better = false;
       for (int mi = 0; mi < nm; ++mi) {
-        for (uint32_t i = 0; i < n; ++i) residuals[i] = homography ? homography_error(models[mi], &x1[2 * i], &x2[2 * i]) : epipolar_error(models[mi], &x1[2 * i], &x2[2 * i]);
+        for (uint32_t i = 0; i < n; ++i)
+          residuals[i] = angular ? angular_error_sq(models[mi], bI + 3 * (lo + i), bJ + 3 * (lo + i)) : ortho ? ortho_error(models[mi], &x1[2 * i], &x2[2 * i])
+                         : homography ? homography_error(models[mi], &x1[2 * i], &x2[2 * i]) : epipolar_error(models[mi], &x1[2 * i], &x2[2 * i]);
         if (!ac_mode) {
           unsigned nInlier = 0;
           for (uint32_t i = 0; i < n; ++i) nInlier += residuals[i] <= max_threshold;
@@ -515,7 +615,9 @@ double port_acransac(bool homography, const double* xI, const double* xJ, const 
     if (minNFA >= 0) vec_inliers.clear();
     double Fm[9];
     for (int u = 0; u < 9; ++u) Fm[u] = have_model ? best.f[u] : ((u % 4 == 0) ? 1.0 : 0.0);
-    if (!vec_inliers.empty() && !essential) {   // (ACKernelAdaptorEssential: Unnormalize does nothing, unormalizeError(val) = val)
+    if (angular) {   // ACKernelAdaptor_AngularRadianError: no normalisation, unormalizeError(val) = sqrt(val)
+      if (!vec_inliers.empty()) errorMax = std::sqrt(errorMax);
+    } else if (!vec_inliers.empty() && !essential && !ortho) {   // (ACKernelAdaptorEssential{,Ortho}: Unnormalize does nothing, unormalizeError(val) = val)
       // Unnormalize: F = N2^T F N1 (conditioning.cpp:87-89), errorMax -> sqrt(errorMax) / N2(0,0)
       const double N1[9] = {T[0][0], 0, T[0][1], 0, T[0][0], T[0][2], 0, 0, 1}, N2[9] = {T[1][0], 0, T[1][1], 0, T[1][0], T[1][2], 0, 0, 1};
       double tmp[9], res[9];
@@ -579,6 +681,17 @@ double port_geofilter_e_acransac(const double* xI, const double* xJ, const uint6
   return port_acransac(false, xI, xJ, start, wh, n_pairs, precision, max_iterations, inlier_mask, ok, Fout, prec, nfa_out, K, bI, bJ);
 }
 // the five-point restatement alone (tests: against ref_five_point and the device's mvgx_debug_five_point)
+// same interface as ref_geofilter_e_angular_acransac without the pose stage (oracle/ref_shim_geofilter.cpp); F receives m_E
+double port_geofilter_e_angular_acransac(const double* bI, const double* bJ, const uint64_t* start, uint64_t n_pairs, double precision_deg, uint32_t max_iterations,
+                                         int upright, uint8_t* inlier_mask, uint8_t* ok, double* Fout, double* prec, double* nfa) {
+  return port_acransac(false, nullptr, nullptr, start, nullptr, n_pairs, precision_deg, max_iterations, inlier_mask, ok, Fout, prec, nfa, nullptr, bI, bJ,
+                       upright ? kUpright3 : kAngular8);
+}
+// the orthographic essential model on hnormalized bearing vectors hI / hJ with the functor's bound per pair (Eo_Robust.hpp:96-121)
+double port_geofilter_eo_acransac(const double* hI, const double* hJ, const uint64_t* start, const uint32_t* wh, const double* pair_bound, uint64_t n_pairs,
+                                  uint32_t max_iterations, uint8_t* inlier_mask, uint8_t* ok, double* Fout, double* prec, double* nfa) {
+  return port_acransac(false, hI, hJ, start, wh, n_pairs, 1.0, max_iterations, inlier_mask, ok, Fout, prec, nfa, nullptr, nullptr, nullptr, kOrtho, pair_bound);
+}
 void port_five_point(const double* b1, const double* b2, double* Es_out, int* n_out) {
   const uint32_t s[5] = {0, 1, 2, 3, 4};
   Model out[10];

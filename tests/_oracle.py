@@ -874,6 +874,37 @@ def port_geofilter_e(tv, K, precision=4.0, max_iterations=2048, bearings=None):
     return _geofilter_call_e(port().port_geofilter_e_acransac, tv, K, bearings, precision, max_iterations)
 
 
+def _port_outputs(n_total, n_pairs):
+    return (np.zeros(max(n_total, 1), np.uint8), np.zeros(max(n_pairs, 1), np.uint8), np.zeros((max(n_pairs, 1), 9)), np.zeros(max(n_pairs, 1)),
+            np.zeros(max(n_pairs, 1)))
+
+
+def port_geofilter_angular(bI, bJ, start, precision_deg=4.0, max_iterations=2048, upright=False):
+    """oracle/geofilter_oracle.cpp: the a-contrario stage of the angular essential functors (its own eight-point / three-point upright solvers)"""
+    bI = np.ascontiguousarray(bI, np.float64).reshape(-1, 3); bJ = np.ascontiguousarray(bJ, np.float64).reshape(-1, 3)
+    start = np.ascontiguousarray(start, np.uint64)
+    n_pairs = len(start) - 1
+    mask, ok, F, prec, nfa = _port_outputs(int(start[-1]), n_pairs)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    fn = port().port_geofilter_e_angular_acransac
+    fn.restype = C.c_double
+    fn(P(bI), P(bJ), P(start), C.c_uint64(n_pairs), C.c_double(precision_deg), C.c_uint32(max_iterations), C.c_int(int(upright)), P(mask), P(ok), P(F), P(prec), P(nfa))
+    return dict(mask=mask[:int(start[-1])].astype(bool), ok=ok[:n_pairs].astype(bool), F=F[:n_pairs].reshape(-1, 3, 3), precision=prec[:n_pairs], nfa=nfa[:n_pairs])
+
+
+def port_geofilter_ortho(hI, hJ, start, wh, pair_bound, max_iterations=1024):
+    """oracle/geofilter_oracle.cpp: the orthographic essential model on hnormalized bearing vectors with the functor's bound per pair"""
+    hI = np.ascontiguousarray(hI, np.float64).reshape(-1, 2); hJ = np.ascontiguousarray(hJ, np.float64).reshape(-1, 2)
+    start = np.ascontiguousarray(start, np.uint64); wh = np.ascontiguousarray(wh, np.uint32); pb = np.ascontiguousarray(pair_bound, np.float64)
+    n_pairs = len(start) - 1
+    mask, ok, F, prec, nfa = _port_outputs(int(start[-1]), n_pairs)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    fn = port().port_geofilter_eo_acransac
+    fn.restype = C.c_double
+    fn(P(hI), P(hJ), P(start), P(wh), P(pb), C.c_uint64(n_pairs), C.c_uint32(max_iterations), P(mask), P(ok), P(F), P(prec), P(nfa))
+    return dict(mask=mask[:int(start[-1])].astype(bool), ok=ok[:n_pairs].astype(bool), F=F[:n_pairs].reshape(-1, 3, 3), precision=prec[:n_pairs], nfa=nfa[:n_pairs])
+
+
 def port_geofilter(tv, precision=4.0, max_iterations=2048):
     """oracle/geofilter_oracle.cpp, the plain C++ restatement (one thread)."""
     return _geofilter_call(port().port_geofilter_f_acransac, tv, precision, max_iterations)

@@ -57,6 +57,15 @@ def test_golden_fixture_is_the_reference(upright):
 
 
 @pytest.mark.parametrize("upright", KINDS)
+def test_restatement_equals_the_stored_reference_outputs(upright):
+    """oracle/geofilter_oracle.cpp (its own solvers: Householder null vector / minors) against the compiled reference's stored outputs"""
+    bI, bJ, start, ref = _gold(upright)
+    got = _oracle.port_geofilter_angular(bI, bJ, start, upright=upright)
+    differing, rep = gc.compare(start, ref, got["mask"], got["ok"], got["F"], got["precision"], got["nfa"])
+    assert rep["pairs_ok_reference"] > 80 and len(differing) <= gc.allowed_differing(rep["pairs"], "e"), (rep, differing)
+
+
+@pytest.mark.parametrize("upright", KINDS)
 def test_emulated_device_code_equals_the_stored_reference_outputs(upright):
     """the angular instantiations of the kernel under the HIP emulation on a few small golden pairs (one fiber per lane: slow)"""
     g = np.load(GOLD_PATH)

@@ -73,6 +73,14 @@ def test_golden_fixture_is_the_reference():
     assert np.array_equal(live["mask"], ref["mask"]) and np.array_equal(live["ok"], ref["ok"]) and np.array_equal(live["F"], ref["F"])
 
 
+def test_restatement_is_bit_identical_to_the_stored_reference_outputs():
+    """oracle/geofilter_oracle.cpp (plain C++, -ffp-contract=off) on every stored pair: closed form, so no tolerance"""
+    hI, hJ, start, wh, prec, ref = _gold()
+    got = _oracle.port_geofilter_ortho(hI, hJ, start, wh, prec)
+    res = dict(F=got["F"], ok=got["ok"], nfa=got["nfa"], precision_robust=got["precision"])
+    assert_identical(ref, got["mask"], res)
+
+
 def test_emulated_device_code_is_bit_identical_to_the_stored_reference_outputs():
     g = np.load(GOLD_PATH)
     n = np.diff(g["start"].astype(np.int64))
