@@ -38,8 +38,9 @@ def normalised(F):
     return F * np.sign(f[np.arange(len(F)), np.abs(f).argmax(1)])[:, None, None]
 
 
-def compare(start, ref, got_mask, got_ok, got_F, got_prec, got_nfa):
-    """Returns (pairs_differing, report). Asserts policy (a) on the pairs whose inlier sets agree."""
+def compare(start, ref, got_mask, got_ok, got_F, got_prec, got_nfa, model_tol=1e-6):
+    """Returns (pairs_differing, report). Asserts policy (a) on the pairs whose inlier sets agree (model_tol: the bound on the normalised
+    models there - two builds of the reference differ by up to 1.3e-5 on such pairs; the report carries the largest difference seen)."""
     start = np.asarray(start, np.int64)
     n_pairs = len(start) - 1
     differing = []
@@ -50,9 +51,11 @@ def compare(start, ref, got_mask, got_ok, got_F, got_prec, got_nfa):
     same = np.ones(n_pairs, bool)
     same[differing] = False
     both_ok = same & np.asarray(ref["ok"], bool)
+    dF = 0.0
     if both_ok.any():
-        dF = np.abs(normalised(ref["F"][both_ok]) - normalised(np.asarray(got_F)[both_ok])).max()
-        assert dF < 1e-6, f"F differs by {dF} on pairs with identical inlier sets"
+        dF = float(np.abs(normalised(ref["F"][both_ok]) - normalised(np.asarray(got_F)[both_ok])).max())
+        assert dF < model_tol, f"F differs by {dF} on pairs with identical inlier sets"
         assert np.allclose(ref["precision"][both_ok], np.asarray(got_prec)[both_ok], rtol=1e-12, atol=0)
         assert np.allclose(ref["nfa"][both_ok], np.asarray(got_nfa)[both_ok], rtol=1e-9, atol=1e-9)
-    return differing, {"pairs": n_pairs, "pairs_ok_reference": int(np.asarray(ref["ok"]).sum()), "pairs_differing": len(differing)}
+    return differing, {"pairs": n_pairs, "pairs_ok_reference": int(np.asarray(ref["ok"]).sum()), "pairs_differing": len(differing),
+                       "largest_model_difference_on_pairs_with_equal_inlier_sets": dF}
