@@ -333,33 +333,33 @@ __device__ __forceinline__ void eight_point(const double* __restrict__ b1, const
 __device__ __forceinline__ void three_point_ortho(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], double (&E1)[9],
                                                   double (&E2)[9]) {
   const double2 p0 = x1[s[0]], p1 = x1[s[1]], p2 = x1[s[2]], q0 = x2[s[0]], q1 = x2[s[1]], q2 = x2[s[2]];
-  const double xd1x = add_rn(p1.x, -p0.x), xd1y = add_rn(p1.y, -p0.y), yd1x = add_rn(p2.x, -p0.x), yd1y = add_rn(p2.y, -p0.y);
-  const double xd2x = add_rn(q1.x, -q0.x), xd2y = add_rn(q1.y, -q0.y), yd2x = add_rn(q2.x, -q0.x), yd2y = add_rn(q2.y, -q0.y);
-  const double denom = add_rn(mul_rn(xd1x, yd1y), -mul_rn(xd1y, yd1x));
-  const double aac = add_rn(mul_rn(xd1y, yd2x), -mul_rn(xd2x, yd1y)) / denom;
-  const double aad = add_rn(mul_rn(xd1y, yd2y), -mul_rn(xd2y, yd1y)) / denom;
-  const double bbc = add_rn(mul_rn(xd2x, yd1x), -mul_rn(xd1x, yd2x)) / denom;
-  const double bbd = add_rn(mul_rn(xd2y, yd1x), -mul_rn(xd1x, yd2y)) / denom;
-  const double aac_sq = mul_rn(aac, aac), bbc_sq = mul_rn(bbc, bbc);
-  const double dd_2 = add_rn(add_rn(add_rn(-aac_sq, mul_rn(aad, aad)), -bbc_sq), mul_rn(bbd, bbd));
-  const double dd_1c = add_rn(mul_rn(mul_rn(2.0, aac), aad), mul_rn(mul_rn(2.0, bbc), bbd));
-  const double dd_0 = add_rn(add_rn(aac_sq, bbc_sq), -1.0);
-  const double d4_4 = add_rn(mul_rn(dd_1c, dd_1c), mul_rn(dd_2, dd_2));
-  const double d4_2 = add_rn(mul_rn(-dd_1c, dd_1c), mul_rn(mul_rn(2.0, dd_0), dd_2));
-  const double d4_0 = mul_rn(dd_0, dd_0);
-  const double tmp = sqrt(add_rn(mul_rn(d4_2, d4_2), -mul_rn(mul_rn(4.0, d4_4), d4_0)));
+  const double u1x = add_rn(p1.x, -p0.x), u1y = add_rn(p1.y, -p0.y), v1x = add_rn(p2.x, -p0.x), v1y = add_rn(p2.y, -p0.y);
+  const double u2x = add_rn(q1.x, -q0.x), u2y = add_rn(q1.y, -q0.y), v2x = add_rn(q2.x, -q0.x), v2y = add_rn(q2.y, -q0.y);
+  const double denom = add_rn(mul_rn(u1x, v1y), -mul_rn(u1y, v1x));
+  const double ac = add_rn(mul_rn(u1y, v2x), -mul_rn(u2x, v1y)) / denom;
+  const double ad = add_rn(mul_rn(u1y, v2y), -mul_rn(u2y, v1y)) / denom;
+  const double bc = add_rn(mul_rn(u2x, v1x), -mul_rn(u1x, v2x)) / denom;
+  const double bd = add_rn(mul_rn(u2y, v1x), -mul_rn(u1x, v2y)) / denom;
+  const double ac2 = mul_rn(ac, ac), bc2 = mul_rn(bc, bc);
+  const double g2 = add_rn(add_rn(add_rn(-ac2, mul_rn(ad, ad)), -bc2), mul_rn(bd, bd));
+  const double g1 = add_rn(mul_rn(mul_rn(2.0, ac), ad), mul_rn(mul_rn(2.0, bc), bd));
+  const double g0 = add_rn(add_rn(ac2, bc2), -1.0);
+  const double h4 = add_rn(mul_rn(g1, g1), mul_rn(g2, g2));
+  const double h2 = add_rn(mul_rn(-g1, g1), mul_rn(mul_rn(2.0, g0), g2));
+  const double h0 = mul_rn(g0, g0);
+  const double rdisc = sqrt(add_rn(mul_rn(h2, h2), -mul_rn(mul_rn(4.0, h4), h0)));
   auto essential = [&](double root, double (&E)[9]) {
-    const double dsol = sqrt(mul_rn(-root / d4_4, 0.5));   // (/ 2.0 is exact; sqrt and / round to nearest on the device: tools/ortho_probe.hip)
-    const double num = add_rn(add_rn(add_rn(mul_rn(mul_rn(dd_2, dsol), dsol), aac_sq), bbc_sq), -1.0);   // (tmp_csol is dd_2's expression)
-    const double den = add_rn(mul_rn(mul_rn(mul_rn(2.0, aac), aad), dsol), mul_rn(mul_rn(mul_rn(2.0, bbc), bbd), dsol));
-    const double csol = -num / den;
-    const double asol = add_rn(mul_rn(aac, csol), mul_rn(aad, dsol));
-    const double bsol = add_rn(mul_rn(bbc, csol), mul_rn(bbd, dsol));
-    const double esol = add_rn(add_rn(add_rn(mul_rn(-asol, p0.x), -mul_rn(bsol, p0.y)), -mul_rn(csol, q0.x)), -mul_rn(dsol, q0.y));
-    E[0] = 0.0; E[1] = 0.0; E[2] = asol; E[3] = 0.0; E[4] = 0.0; E[5] = bsol; E[6] = csol; E[7] = dsol; E[8] = esol;
+    const double sd = sqrt(mul_rn(-root / h4, 0.5));   // (/ 2.0 is exact; sqrt and / round to nearest on the device: tools/ortho_probe.hip)
+    const double num = add_rn(add_rn(add_rn(mul_rn(mul_rn(g2, sd), sd), ac2), bc2), -1.0);
+    const double den = add_rn(mul_rn(mul_rn(mul_rn(2.0, ac), ad), sd), mul_rn(mul_rn(mul_rn(2.0, bc), bd), sd));
+    const double sc = -num / den;
+    const double sa = add_rn(mul_rn(ac, sc), mul_rn(ad, sd));
+    const double sb = add_rn(mul_rn(bc, sc), mul_rn(bd, sd));
+    const double se = add_rn(add_rn(add_rn(mul_rn(-sa, p0.x), -mul_rn(sb, p0.y)), -mul_rn(sc, q0.x)), -mul_rn(sd, q0.y));
+    E[0] = 0.0; E[1] = 0.0; E[2] = sa; E[3] = 0.0; E[4] = 0.0; E[5] = sb; E[6] = sc; E[7] = sd; E[8] = se;
   };
-  essential(add_rn(d4_2, tmp), E1);
-  essential(add_rn(d4_2, -tmp), E2);
+  essential(add_rn(h2, rdisc), E1);
+  essential(add_rn(h2, -rdisc), E2);
 }
 
 // ThreePointUprightRelativePoseSolver::Solve (multiview/solver_essential_three_point.cpp:84-113): the null vector n of the 3 x 4

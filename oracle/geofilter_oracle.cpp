@@ -406,26 +406,26 @@ inline double angular_error_sq(const Model& E, const double* a, const double* b)
 int three_point_ortho(const double* x1, const double* x2, const uint32_t s[3], Model out[2]) {
   const double *p0 = x1 + 2 * (size_t)s[0], *p1 = x1 + 2 * (size_t)s[1], *p2 = x1 + 2 * (size_t)s[2];
   const double *q0 = x2 + 2 * (size_t)s[0], *q1 = x2 + 2 * (size_t)s[1], *q2 = x2 + 2 * (size_t)s[2];
-  const double xd1x = p1[0] - p0[0], xd1y = p1[1] - p0[1], yd1x = p2[0] - p0[0], yd1y = p2[1] - p0[1];
-  const double xd2x = q1[0] - q0[0], xd2y = q1[1] - q0[1], yd2x = q2[0] - q0[0], yd2y = q2[1] - q0[1];
-  const double denom = xd1x * yd1y - xd1y * yd1x;
-  const double aac = (xd1y * yd2x - xd2x * yd1y) / denom, aad = (xd1y * yd2y - xd2y * yd1y) / denom;
-  const double bbc = (xd2x * yd1x - xd1x * yd2x) / denom, bbd = (xd2y * yd1x - xd1x * yd2y) / denom;
-  const double aac_sq = aac * aac;
-  const double dd_2 = -aac_sq + aad * aad - bbc * bbc + bbd * bbd;
-  const double dd_1c = 2.0 * aac * aad + 2.0 * bbc * bbd;
-  const double dd_0 = aac_sq + bbc * bbc - 1.0;
-  const double d4_4 = dd_1c * dd_1c + dd_2 * dd_2;
-  const double d4_2 = -dd_1c * dd_1c + 2.0 * dd_0 * dd_2;
-  const double d4_0 = dd_0 * dd_0;
-  const double tmp = std::sqrt(d4_2 * d4_2 - 4.0 * d4_4 * d4_0);
+  const double u1x = p1[0] - p0[0], u1y = p1[1] - p0[1], v1x = p2[0] - p0[0], v1y = p2[1] - p0[1];
+  const double u2x = q1[0] - q0[0], u2y = q1[1] - q0[1], v2x = q2[0] - q0[0], v2y = q2[1] - q0[1];
+  const double denom = u1x * v1y - u1y * v1x;
+  const double ac = (u1y * v2x - u2x * v1y) / denom, ad = (u1y * v2y - u2y * v1y) / denom;
+  const double bc = (u2x * v1x - u1x * v2x) / denom, bd = (u2y * v1x - u1x * v2y) / denom;
+  const double ac2 = ac * ac;
+  const double g2 = -ac2 + ad * ad - bc * bc + bd * bd;
+  const double g1 = 2.0 * ac * ad + 2.0 * bc * bd;
+  const double g0 = ac2 + bc * bc - 1.0;
+  const double h4 = g1 * g1 + g2 * g2;
+  const double h2 = -g1 * g1 + 2.0 * g0 * g2;
+  const double h0 = g0 * g0;
+  const double rdisc = std::sqrt(h2 * h2 - 4.0 * h4 * h0);
   for (int k = 0; k < 2; ++k) {
-    const double root = k == 0 ? d4_2 + tmp : d4_2 - tmp;
-    const double dsol = std::sqrt(-root / d4_4 / 2.0);
-    const double csol = -(dd_2 * dsol * dsol + aac_sq + bbc * bbc - 1.0) / (2.0 * aac * aad * dsol + 2.0 * bbc * bbd * dsol);
-    const double asol = aac * csol + aad * dsol, bsol = bbc * csol + bbd * dsol;
-    const double esol = -asol * p0[0] - bsol * p0[1] - csol * q0[0] - dsol * q0[1];
-    const double e[9] = {0, 0, asol, 0, 0, bsol, csol, dsol, esol};
+    const double root = k == 0 ? h2 + rdisc : h2 - rdisc;
+    const double sd = std::sqrt(-root / h4 / 2.0);
+    const double sc = -(g2 * sd * sd + ac2 + bc * bc - 1.0) / (2.0 * ac * ad * sd + 2.0 * bc * bd * sd);
+    const double sa = ac * sc + ad * sd, sb = bc * sc + bd * sd;
+    const double se = -sa * p0[0] - sb * p0[1] - sc * q0[0] - sd * q0[1];
+    const double e[9] = {0, 0, sa, 0, 0, sb, sc, sd, se};
     std::memcpy(out[k].f, e, sizeof(e));
   }
   return 2;

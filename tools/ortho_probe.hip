@@ -9,34 +9,34 @@ __device__ double dadd(double a, double b) { return __dadd_rn(a, b); }
 __global__ void k(const double* in, double* out) {
   const double p0x = in[0], p0y = in[1], p1x = in[2], p1y = in[3], p2x = in[4], p2y = in[5], q0x = in[6], q0y = in[7], q1x = in[8], q1y = in[9], q2x = in[10], q2y = in[11];
   int o = 0;
-  const double xd1x = dadd(p1x, -p0x), xd1y = dadd(p1y, -p0y), yd1x = dadd(p2x, -p0x), yd1y = dadd(p2y, -p0y);
-  const double xd2x = dadd(q1x, -q0x), xd2y = dadd(q1y, -q0y), yd2x = dadd(q2x, -q0x), yd2y = dadd(q2y, -q0y);
-  const double denom = dadd(dmul(xd1x, yd1y), -dmul(xd1y, yd1x)); out[o++] = denom;
-  const double n_aac = dadd(dmul(xd1y, yd2x), -dmul(xd2x, yd1y)); out[o++] = n_aac;
-  const double aac = n_aac / denom; out[o++] = aac;
-  const double aad = dadd(dmul(xd1y, yd2y), -dmul(xd2y, yd1y)) / denom; out[o++] = aad;
-  const double bbc = dadd(dmul(xd2x, yd1x), -dmul(xd1x, yd2x)) / denom; out[o++] = bbc;
-  const double bbd = dadd(dmul(xd2y, yd1x), -dmul(xd1x, yd2y)) / denom; out[o++] = bbd;
-  const double aac_sq = dmul(aac, aac), bbc_sq = dmul(bbc, bbc);
-  const double dd_2 = dadd(dadd(dadd(-aac_sq, dmul(aad, aad)), -bbc_sq), dmul(bbd, bbd)); out[o++] = dd_2;
-  const double dd_1c = dadd(dmul(dmul(2.0, aac), aad), dmul(dmul(2.0, bbc), bbd)); out[o++] = dd_1c;
-  const double dd_0 = dadd(dadd(aac_sq, bbc_sq), -1.0); out[o++] = dd_0;
-  const double d4_4 = dadd(dmul(dd_1c, dd_1c), dmul(dd_2, dd_2)); out[o++] = d4_4;
-  const double d4_2 = dadd(dmul(-dd_1c, dd_1c), dmul(dmul(2.0, dd_0), dd_2)); out[o++] = d4_2;
-  const double d4_0 = dmul(dd_0, dd_0); out[o++] = d4_0;
-  const double rad = dadd(dmul(d4_2, d4_2), -dmul(dmul(4.0, d4_4), d4_0)); out[o++] = rad;
-  const double tmp = sqrt(rad); out[o++] = tmp;
-  const double root = dadd(d4_2, tmp); out[o++] = root;
-  const double t1 = -root / d4_4; out[o++] = t1;
-  const double dsol = sqrt(dmul(t1, 0.5)); out[o++] = dsol;
-  const double num = dadd(dadd(dadd(dmul(dmul(dd_2, dsol), dsol), aac_sq), bbc_sq), -1.0); out[o++] = num;
-  const double den = dadd(dmul(dmul(dmul(2.0, aac), aad), dsol), dmul(dmul(dmul(2.0, bbc), bbd), dsol)); out[o++] = den;
-  const double csol = -num / den; out[o++] = csol;
-  out[o++] = dadd(dmul(aac, csol), dmul(aad, dsol));
-  out[o++] = dadd(dmul(bbc, csol), dmul(bbd, dsol));
+  const double u1x = dadd(p1x, -p0x), u1y = dadd(p1y, -p0y), v1x = dadd(p2x, -p0x), v1y = dadd(p2y, -p0y);
+  const double u2x = dadd(q1x, -q0x), u2y = dadd(q1y, -q0y), v2x = dadd(q2x, -q0x), v2y = dadd(q2y, -q0y);
+  const double denom = dadd(dmul(u1x, v1y), -dmul(u1y, v1x)); out[o++] = denom;
+  const double n_aac = dadd(dmul(u1y, v2x), -dmul(u2x, v1y)); out[o++] = n_aac;
+  const double ac = n_aac / denom; out[o++] = ac;
+  const double ad = dadd(dmul(u1y, v2y), -dmul(u2y, v1y)) / denom; out[o++] = ad;
+  const double bc = dadd(dmul(u2x, v1x), -dmul(u1x, v2x)) / denom; out[o++] = bc;
+  const double bd = dadd(dmul(u2y, v1x), -dmul(u1x, v2y)) / denom; out[o++] = bd;
+  const double ac2 = dmul(ac, ac), bc2 = dmul(bc, bc);
+  const double g2 = dadd(dadd(dadd(-ac2, dmul(ad, ad)), -bc2), dmul(bd, bd)); out[o++] = g2;
+  const double g1 = dadd(dmul(dmul(2.0, ac), ad), dmul(dmul(2.0, bc), bd)); out[o++] = g1;
+  const double g0 = dadd(dadd(ac2, bc2), -1.0); out[o++] = g0;
+  const double h4 = dadd(dmul(g1, g1), dmul(g2, g2)); out[o++] = h4;
+  const double h2 = dadd(dmul(-g1, g1), dmul(dmul(2.0, g0), g2)); out[o++] = h2;
+  const double h0 = dmul(g0, g0); out[o++] = h0;
+  const double rad = dadd(dmul(h2, h2), -dmul(dmul(4.0, h4), h0)); out[o++] = rad;
+  const double rdisc = sqrt(rad); out[o++] = rdisc;
+  const double root = dadd(h2, rdisc); out[o++] = root;
+  const double t1 = -root / h4; out[o++] = t1;
+  const double sd = sqrt(dmul(t1, 0.5)); out[o++] = sd;
+  const double num = dadd(dadd(dadd(dmul(dmul(g2, sd), sd), ac2), bc2), -1.0); out[o++] = num;
+  const double den = dadd(dmul(dmul(dmul(2.0, ac), ad), sd), dmul(dmul(dmul(2.0, bc), bd), sd)); out[o++] = den;
+  const double sc = -num / den; out[o++] = sc;
+  out[o++] = dadd(dmul(ac, sc), dmul(ad, sd));
+  out[o++] = dadd(dmul(bc, sc), dmul(bd, sd));
 }
 int main() {
-  const char* names[] = {"denom", "n_aac", "aac", "aad", "bbc", "bbd", "dd_2", "dd_1c", "dd_0", "d4_4", "d4_2", "d4_0", "rad", "tmp", "root", "t1", "dsol", "num", "den", "csol", "asol", "bsol"};
+  const char* names[] = {"denom", "n_aac", "ac", "ad", "bc", "bd", "g2", "g1", "g0", "h4", "h2", "h0", "rad", "rdisc", "root", "t1", "sd", "num", "den", "sc", "sa", "sb"};
   std::mt19937 g(5);
   std::uniform_real_distribution<double> u(-0.5, 0.5);
   double *din, *dout;
@@ -51,30 +51,30 @@ int main() {
     hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
     volatile double p0x = in[0], p0y = in[1], p1x = in[2], p1y = in[3], p2x = in[4], p2y = in[5], q0x = in[6], q0y = in[7], q1x = in[8], q1y = in[9], q2x = in[10], q2y = in[11];
     double h[22]; int o = 0;
-    const double xd1x = p1x - p0x, xd1y = p1y - p0y, yd1x = p2x - p0x, yd1y = p2y - p0y, xd2x = q1x - q0x, xd2y = q1y - q0y, yd2x = q2x - q0x, yd2y = q2y - q0y;
-    const double denom = xd1x * yd1y - xd1y * yd1x; h[o++] = denom;
-    const double n_aac = xd1y * yd2x - xd2x * yd1y; h[o++] = n_aac;
-    const double aac = n_aac / denom; h[o++] = aac;
-    const double aad = (xd1y * yd2y - xd2y * yd1y) / denom; h[o++] = aad;
-    const double bbc = (xd2x * yd1x - xd1x * yd2x) / denom; h[o++] = bbc;
-    const double bbd = (xd2y * yd1x - xd1x * yd2y) / denom; h[o++] = bbd;
-    const double aac_sq = aac * aac;
-    const double dd_2 = -aac_sq + aad * aad - bbc * bbc + bbd * bbd; h[o++] = dd_2;
-    const double dd_1c = 2.0 * aac * aad + 2.0 * bbc * bbd; h[o++] = dd_1c;
-    const double dd_0 = aac_sq + bbc * bbc - 1.0; h[o++] = dd_0;
-    const double d4_4 = dd_1c * dd_1c + dd_2 * dd_2; h[o++] = d4_4;
-    const double d4_2 = -dd_1c * dd_1c + 2.0 * dd_0 * dd_2; h[o++] = d4_2;
-    const double d4_0 = dd_0 * dd_0; h[o++] = d4_0;
-    const double rad = d4_2 * d4_2 - 4.0 * d4_4 * d4_0; h[o++] = rad;
-    const double tmp = std::sqrt(rad); h[o++] = tmp;
-    const double root = d4_2 + tmp; h[o++] = root;
-    const double t1 = -root / d4_4; h[o++] = t1;
-    const double dsol = std::sqrt(t1 / 2.0); h[o++] = dsol;
-    const double num = dd_2 * dsol * dsol + aac_sq + bbc * bbc - 1.0; h[o++] = num;
-    const double den = 2.0 * aac * aad * dsol + 2.0 * bbc * bbd * dsol; h[o++] = den;
-    const double csol = -num / den; h[o++] = csol;
-    h[o++] = aac * csol + aad * dsol;
-    h[o++] = bbc * csol + bbd * dsol;
+    const double u1x = p1x - p0x, u1y = p1y - p0y, v1x = p2x - p0x, v1y = p2y - p0y, u2x = q1x - q0x, u2y = q1y - q0y, v2x = q2x - q0x, v2y = q2y - q0y;
+    const double denom = u1x * v1y - u1y * v1x; h[o++] = denom;
+    const double n_aac = u1y * v2x - u2x * v1y; h[o++] = n_aac;
+    const double ac = n_aac / denom; h[o++] = ac;
+    const double ad = (u1y * v2y - u2y * v1y) / denom; h[o++] = ad;
+    const double bc = (u2x * v1x - u1x * v2x) / denom; h[o++] = bc;
+    const double bd = (u2y * v1x - u1x * v2y) / denom; h[o++] = bd;
+    const double ac2 = ac * ac;
+    const double g2 = -ac2 + ad * ad - bc * bc + bd * bd; h[o++] = g2;
+    const double g1 = 2.0 * ac * ad + 2.0 * bc * bd; h[o++] = g1;
+    const double g0 = ac2 + bc * bc - 1.0; h[o++] = g0;
+    const double h4 = g1 * g1 + g2 * g2; h[o++] = h4;
+    const double h2 = -g1 * g1 + 2.0 * g0 * g2; h[o++] = h2;
+    const double h0 = g0 * g0; h[o++] = h0;
+    const double rad = h2 * h2 - 4.0 * h4 * h0; h[o++] = rad;
+    const double rdisc = std::sqrt(rad); h[o++] = rdisc;
+    const double root = h2 + rdisc; h[o++] = root;
+    const double t1 = -root / h4; h[o++] = t1;
+    const double sd = std::sqrt(t1 / 2.0); h[o++] = sd;
+    const double num = g2 * sd * sd + ac2 + bc * bc - 1.0; h[o++] = num;
+    const double den = 2.0 * ac * ad * sd + 2.0 * bc * bd * sd; h[o++] = den;
+    const double sc = -num / den; h[o++] = sc;
+    h[o++] = ac * sc + ad * sd;
+    h[o++] = bc * sc + bd * sd;
     for (int i = 0; i < 22; ++i) {
       const bool same = (out[i] == h[i]) || (out[i] != out[i] && h[i] != h[i]);
       if (!same && bad[i]++ < 2) printf("trial %d %s device %.17g host %.17g\n", t, names[i], out[i], h[i]);
