@@ -710,20 +710,39 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
       wave_sync();
       GEO_STAMP(2);
       if (ac_mode) {   // ComputeNFA_and_inliers, quantified form (:196-262): lane b evaluates bin b, the first bin of minimal NFA wins
-        uint32_t cum = 0;
-#pragma unroll
-        for (int b = 0; b < kBins; ++b) cum += (b <= lane) ? hist[b] : 0u;
+        // cumulated histogram: lane b reads its bin, an inclusive scan inside the 16-lane row (DPP row_shr), lanes 16..19 add row 0's total
+        uint32_t cum = lane < kBins ? hist[lane] : 0u;
+        cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x111, 0xF, 0xF, true);
+        cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x112, 0xF, 0xF, true);
+        cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x114, 0xF, 0xF, true);
+        cum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cum, 0x118, 0xF, 0xF, true);
+        {
+          const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)cum, 15);
+          if (lane >= 16) cum += row0;
+        }
         double cur = inf;
         if (lane < kBins && cum > (uint32_t)kMin && my_bin_value > 1.1920928955078125e-07) {
           cur = add_rn(add_rn(add_rn(loge0, mul_rn(my_logalpha, (double)(cum - kMin))), (double)logc_n[cum]), (double)logc_k[cum]);
           if (!(cur < 0)) cur = inf;
         }
-        // minimum over the 20 lanes, lowest bin on ties (the sequential scan keeps the first strict improvement)
+        // minimum over the 20 lanes, lowest bin on ties (the sequential scan keeps the first strict improvement): wave maxima of an
+        // order-reversing key of the value's bits (high word, then low word among its holders), then the first lane that holds both
         double cb_nfa = inf, cb_thr = 0.0;
-#pragma unroll
-        for (int b = 0; b < kBins; ++b) {
-          const double v = lane_value_f64(cur, b);
-          if (v < cb_nfa) { cb_nfa = v; cb_thr = lane_value_f64(my_bin_value, b); }
+        {
+          const bool cand = lane < kBins && cur < inf;   // (a candidate is a finite negative value)
+          unsigned long long bits = (unsigned long long)__double_as_longlong(cur);
+          bits = (bits >> 63) ? bits : ~(bits | 0x8000000000000000ull);   // negative doubles: larger bit pattern = smaller value; the others below all of them
+          const uint32_t hi = cand ? (uint32_t)(bits >> 32) : 0u;
+          const uint32_t best_hi = wave_max_u32(hi);
+          if (best_hi != 0u) {   // (wave-uniform; 0: no candidate)
+            const bool top = cand && hi == best_hi;
+            const uint32_t lo = top ? (uint32_t)bits : 0u;
+            const uint32_t best_lo = wave_max_u32(lo);
+            const unsigned long long holders = __ballot(top && lo == best_lo);
+            const int b = (int)__builtin_ctzll(holders);
+            cb_nfa = lane_value_f64(cur, b);
+            cb_thr = lane_value_f64(my_bin_value, b);
+          }
         }
         GEO_STAMP(3);
         if (cb_nfa < minNFA) {   // the inlier list is rebuilt even if it then turns out too short (the reference's behaviour)

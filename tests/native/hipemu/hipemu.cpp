@@ -228,9 +228,15 @@ unsigned long long ballot(bool pred) {
 
 // DPP with full row / bank masks for the controls the kernels use: quad_perm (0x00-0xFF), row_mirror (0x140),
 // row_half_mirror (0x141) - permutations inside a row of 16 lanes, so `old` / bound_ctrl never apply
-int update_dpp(int old, int src, int dpp_ctrl, int, int, bool) {
+int update_dpp(int old, int src, int dpp_ctrl, int, int, bool bound_ctrl) {
   const int lane = g_cur & 63;
   int from;
+  if (dpp_ctrl >= 0x111 && dpp_ctrl <= 0x11F) {   // row_shr:n - lane i of a 16-lane row reads lane i - n of the same row; below the row's start: 0 (bound_ctrl) or `old`
+    const int n = dpp_ctrl & 15;
+    const bool valid = (lane & 15) >= n;
+    const int v = readlane_i32(src, valid ? lane - n : lane);   // (every lane takes part in the exchange)
+    return valid ? v : (bound_ctrl ? 0 : old);
+  }
   if (dpp_ctrl >= 0 && dpp_ctrl <= 0xFF) from = (lane & ~3) + ((dpp_ctrl >> (2 * (lane & 3))) & 3);
   else if (dpp_ctrl == 0x140) from = (lane & ~15) + (15 - (lane & 15));
   else if (dpp_ctrl == 0x141) from = (lane & ~7) + (7 - (lane & 7));
