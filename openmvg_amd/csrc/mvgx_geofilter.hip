@@ -231,40 +231,35 @@ __device__ __forceinline__ typename PointOf<MODEL>::type load_point(const double
 
 #include "geofilter_five_point.h"
 
-// The null vector of an 8 x 9 system whose row r = lane mod 8 is a[] (every group of eight lanes holds the same system): Gauss-Jordan
-// elimination with complete pivoting, the pivot row broadcast through v_readlane; the column left without a pivot carries the null
-// space (H[that column] = 1). A rank-deficient system gives SOME null vector.
-__device__ __forceinline__ void null_vector_8x9(double (&a)[9], int r, double (&H)[9]) {
+// The null vector of an 8 x 9 system spread over 36 lanes: lane 9 r0 + c (r0 < 4) holds A[r0][c] in a0 and A[r0 + 4][c] in a1 (the
+// other lanes run along with copies and never win a pivot). Gauss-Jordan elimination with complete pivoting - the pivot is the element
+// of largest magnitude as a float, lowest (row, column) on ties: key = float bits with the low 7 bits replaced by 127 - (9 r + c) -, the
+// pivot row and column reach the lanes through the LDS crossbar; the column left without a pivot carries the null space (H[that
+// column] = 1). Every lane gets the vector. A rank-deficient system gives SOME null vector. (Until round 4 every lane of a group of
+// eight held a whole row and the wave did the same work eight times over: 1 600 instructions against 760 - same arithmetic per
+// element, same results.)
+__device__ __forceinline__ void null_vector_8x9(double a0, double a1, int lane, double (&H)[9]) {
+  const bool live = lane < 36;
+  const int r0 = live ? lane / 9 : 3, c = live ? lane - 9 * (lane / 9) : 8;
   uint32_t row_used = 0, col_used = 0;
   int prow[8], pcol[8], n_piv = 0;
 #pragma unroll
   for (int step = 0; step < 8; ++step) {
-    // this lane's best candidate: largest magnitude (as a float: a choice within 2^-17 of the largest is as good a pivot) over the
-    // columns without a pivot, lowest (row, column) on ties - key = float bits with the low 7 bits replaced by 127 - (9 r + c)
-    uint32_t key = 0u;
-    if (!((row_used >> r) & 1u)) {
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const float mag = (float)fabs(a[c]);
-        const uint32_t k = (!((col_used >> c) & 1u) && mag > 0.f && mag == mag) ? ((__float_as_uint(mag) & ~127u) | (uint32_t)(127 - (9 * r + c))) : 0u;
-        key = k > key ? k : key;
-      }
-    }
-    const uint32_t best = wave_max_u32(key);
+    const bool col_free = live && !((col_used >> c) & 1u);
+    const float m0 = (float)fabs(a0), m1 = (float)fabs(a1);
+    const uint32_t k0 = (col_free && !((row_used >> r0) & 1u) && m0 > 0.f && m0 == m0) ? ((__float_as_uint(m0) & ~127u) | (uint32_t)(127 - (9 * r0 + c))) : 0u;
+    const uint32_t k1 = (col_free && !((row_used >> (r0 + 4)) & 1u) && m1 > 0.f && m1 == m1) ? ((__float_as_uint(m1) & ~127u) | (uint32_t)(127 - (9 * (r0 + 4) + c))) : 0u;
+    const uint32_t best = wave_max_u32(k0 > k1 ? k0 : k1);
     if (best == 0u) break;   // rank deficient sample (wave-uniform)
     const int who = 127 - (int)(best & 127u);
     const int pr = who / 9, pc = who - 9 * pr;
-    double rowv[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) rowv[c] = lane_value_f64(a[c], pr);
-    double piv = rowv[0], colv = a[0];
-#pragma unroll
-    for (int c = 1; c < 9; ++c) { piv = (c == pc) ? rowv[c] : piv; colv = (c == pc) ? a[c] : colv; }
-    const double f = colv * (1.0 / piv);
-    if (r != pr) {
-#pragma unroll
-      for (int c = 0; c < 9; ++c) a[c] -= f * rowv[c];
-    }
+    const double of_row = (pr >> 2) ? a1 : a0;                       // (wave-uniform choice: the half the pivot row lives in)
+    const double rowv = shfl_f64(of_row, 9 * (pr & 3) + c);          // pivot row, my column
+    const double piv = lane_value_f64(of_row, 9 * (pr & 3) + pc);
+    const double colv0 = shfl_f64(a0, 9 * r0 + pc), colv1 = shfl_f64(a1, 9 * r0 + pc);   // my rows, pivot column
+    const double ip = 1.0 / piv;
+    if (r0 != pr) { const double f = colv0 * ip; a0 -= f * rowv; }
+    if (r0 + 4 != pr) { const double f = colv1 * ip; a1 -= f * rowv; }
     row_used |= 1u << pr; col_used |= 1u << pc;
     prow[step] = pr; pcol[step] = pc;
     n_piv = step + 1;
@@ -276,12 +271,9 @@ __device__ __forceinline__ void null_vector_8x9(double (&a)[9], int r, double (&
 #pragma unroll
   for (int step = 0; step < 8; ++step) {
     if (step < n_piv) {   // wave-uniform
-      double num = 0.0, den = 1.0;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const double v = lane_value_f64(a[c], prow[step]);
-        num = (c == fc) ? v : num; den = (c == pcol[step]) ? v : den;
-      }
+      const double of_row = (prow[step] >> 2) ? a1 : a0;
+      const int base = 9 * (prow[step] & 3);
+      const double num = lane_value_f64(of_row, base + fc), den = lane_value_f64(of_row, base + pcol[step]);
       const double h = -num / den;
 #pragma unroll
       for (int u = 0; u < 9; ++u) H[u] = (u == pcol[step]) ? h : H[u];
@@ -290,21 +282,23 @@ __device__ __forceinline__ void null_vector_8x9(double (&a)[9], int r, double (&
 }
 
 // FourPointSolver::Solve on the sample s[0..3] (wave-uniform; multiview/solver_homography_kernel.cpp:37-93): the null vector of the
-// 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3. Lane r
-// (mod 8) keeps row r in registers; Gauss-Jordan elimination with complete pivoting, the pivot row broadcast through v_readlane;
-// the column left without a pivot carries the null space (the reference takes the last right singular vector of the same matrix:
+// 8 x 9 DLT system (two rows per correspondence: [x^T 1 0 0 0 -x' x^T -x'] and [0 0 0 x^T 1 -y' x^T -y']), row-major 3 x 3, by
+// null_vector_8x9 above (the reference takes the last right singular vector of the same matrix:
 // the same line up to rounding and scale; a rank-deficient sample gives SOME null vector in both, not the same one).
 __device__ __forceinline__ void four_point(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[7], int lane, double (&H)[9]) {
-  const int r = lane & 7, pt = r >> 1;
-  const uint32_t si = pt == 0 ? s[0] : pt == 1 ? s[1] : pt == 2 ? s[2] : s[3];
-  const double2 p1 = x1[si], p2 = x2[si];
-  const bool second = r & 1;
-  const double t = second ? p2.y : p2.x;
-  double a[9];
-  a[0] = second ? 0.0 : p1.x; a[1] = second ? 0.0 : p1.y; a[2] = second ? 0.0 : 1.0;
-  a[3] = second ? p1.x : 0.0; a[4] = second ? p1.y : 0.0; a[5] = second ? 1.0 : 0.0;
-  a[6] = -t * p1.x; a[7] = -t * p1.y; a[8] = -t;
-  null_vector_8x9(a, r, H);
+  // lane 9 r0 + c holds the elements (r0, c) and (r0 + 4, c): rows 2 k / 2 k + 1 belong to sample point k
+  const int r0 = lane < 36 ? lane / 9 : 3, c = lane < 36 ? lane - 9 * (lane / 9) : 8;
+  const int cm = c % 3;
+  auto element = [&](int r) {
+    const int pt = r >> 1;
+    const uint32_t si = pt == 0 ? s[0] : pt == 1 ? s[1] : pt == 2 ? s[2] : s[3];
+    const double2 p1 = x1[si], p2 = x2[si];
+    const bool second = r & 1;
+    const double t = second ? p2.y : p2.x;
+    const double h = cm == 0 ? p1.x : cm == 1 ? p1.y : 1.0;
+    return c < 3 ? (second ? 0.0 : h) : c < 6 ? (second ? h : 0.0) : -t * h;
+  };
+  null_vector_8x9(element(r0), element(r0 + 4), lane, H);
 }
 
 // EightPointRelativePoseSolver::Solve on exactly eight bearing pairs (multiview/solver_essential_eight_point.cpp:17-47; with eight
@@ -312,18 +306,15 @@ __device__ __forceinline__ void four_point(const double2* __restrict__ x1, const
 // A[r][3 i + j] = x2[i] x1[j] (EncodeEpipolarEquation, solver_fundamental_kernel.hpp:83-93), row-major 3 x 3. The reference takes the
 // eigenvector of A^T A of smallest eigenvalue: the same line up to rounding, scale and sign (the residual is invariant to both).
 __device__ __forceinline__ void eight_point(const double* __restrict__ b1, const double* __restrict__ b2, const uint32_t (&s)[8], int lane, double (&E)[9]) {
-  const int r = lane & 7;
-  uint32_t si = s[0];
+  const int r0 = lane < 36 ? lane / 9 : 3, c = lane < 36 ? lane - 9 * (lane / 9) : 8;
+  const int ci = c / 3, cj = c - 3 * ci;
+  auto element = [&](int r) {
+    uint32_t si = s[0];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) si = (r == k) ? s[k] : si;
-  const double p1[3] = {b1[3 * (size_t)si], b1[3 * (size_t)si + 1], b1[3 * (size_t)si + 2]};
-  const double p2[3] = {b2[3 * (size_t)si], b2[3 * (size_t)si + 1], b2[3 * (size_t)si + 2]};
-  double a[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) a[3 * i + j] = p2[i] * p1[j];
-  null_vector_8x9(a, r, E);
+    for (int k = 1; k < 8; ++k) si = (r == k) ? s[k] : si;
+    return b2[3 * (size_t)si + ci] * b1[3 * (size_t)si + cj];
+  };
+  null_vector_8x9(element(r0), element(r0 + 4), lane, E);
 }
 
 // ThreePointsRelativePose (multiview/solver_essential_three_point.cpp:31-79; ThreePointSolver::Solve, solver_essential_kernel.cpp:49-56): the two
