@@ -395,6 +395,7 @@ __device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const
   // key = float bits with the low 6 bits replaced by 63 - lane.
   uint32_t row_used = 0, col_used = 0;
   int prow[7], pcol[7], n_piv = 0;
+  double ipivs[7];   // 1 / pivot of every step (wave-uniform): the pivot element is not touched again, the null vectors below divide by it
 #pragma unroll
   for (int step = 0; step < 7; ++step) {
     const bool cand = lane < 63 && !((row_used >> r) & 1u) && !((col_used >> c) & 1u);
@@ -409,7 +410,7 @@ __device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const
     const double colv = shfl_f64(a, 9 * r + pc);   // my row, pivot column
     if (r != pr) a -= (colv * ipiv) * rowv;
     row_used |= 1u << pr; col_used |= 1u << pc;
-    prow[step] = pr; pcol[step] = pc;
+    prow[step] = pr; pcol[step] = pc; ipivs[step] = ipiv;
     n_piv = step + 1;
   }
   int f1 = 0;
@@ -421,7 +422,7 @@ __device__ __forceinline__ int seven_point(const double2* __restrict__ x1, const
 #pragma unroll
   for (int step = 0; step < 7; ++step) {
     if (step < n_piv) {   // wave-uniform
-      const double iden = 1.0 / lane_value_f64(a, 9 * prow[step] + pcol[step]);
+      const double iden = ipivs[step];   // (= 1 / A[prow][pcol]: later steps only change the OTHER columns of a pivot row)
       const double n1 = lane_value_f64(a, 9 * prow[step] + f1), n2 = lane_value_f64(a, 9 * prow[step] + f2);
       if (lane == pcol[step]) { F1u = -n1 * iden; F2u = -n2 * iden; }
     }
