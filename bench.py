@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--side-deadline", type=float, default=900.0, help="seconds granted to the side records (BA, Hamming, float L2)")
     ap.add_argument("--no-hamming", action="store_true", help="skip the BRUTE_FORCE_HAMMING side record (N=1 only)")
     ap.add_argument("--no-ba-c5", action="store_true", help="skip the single-GPU run of BASELINE.json configs[4] (1k cams / 5M obs)")
+    ap.add_argument("--side-stdout", action="store_true", help="also print the full side records on earlier `SIDE <name> <json>` stdout lines "
+                                                               "(default: only gpurun_out/bench_side.json; the LAST stdout line is always the compact driver line)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="TEST HOOK (tests/test_bench_rehearsal_cpu.py), never a measurement: the N > 1 control flow of this file on a box "
                          "without GPUs - gloo process group, the HIP emulation libraries of tests/native (the same device source compiled "
@@ -119,6 +121,51 @@ def parity_on_sample(ctx, ratio_sq, sample, cpu_lists):
     return {"pairs_checked": int(len(sample)), "non_empty_pairs": int(len(cpu_lists)),
             "matches_checked": int(sum(len(v) for v in cpu_lists.values())), "identical": bool(same),
             "against": "cpu_baseline lists (same run, same pairs)"}
+
+
+def emit(out, args):
+    """Full record -> gpurun_out/bench_side.json (+ `SIDE` lines on request); stdout ENDS with the one compact driver line (< 4 KB,
+    bench_line.py). fd 2 is flushed first and nothing is written after the line."""
+    import bench_line
+    side_rel = os.path.join("gpurun_out", "bench_side.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, side_rel), "w") as f:
+            json.dump(out, f)
+    except OSError:
+        side_rel = None
+    if args.side_stdout:
+        for k, v in out.items():
+            if isinstance(v, dict) and k not in ("config", "roofline", "cpu_baseline", "parity"):
+                print("SIDE " + k + " " + json.dumps(v), flush=True)
+    _, line = bench_line.compact(out, side_rel)
+    sys.stderr.flush()
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+
+
+class quiet_stderr:
+    """fd 2 -> gpurun_out/bench_stderr.log while the reference's code runs (its logger writes `INFO: [Matcher_Regions.cpp:41] ...` and
+    Ceres reports to stderr; on the driver's capture that chatter followed - and displaced - the bench line of round 4). Python-level
+    tracebacks of this process still reach the real stderr: the redirection is undone on exit of the block."""
+    def __enter__(self):
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            self.log = open(os.path.join(ROOT, "gpurun_out", "bench_stderr.log"), "ab")
+            sys.stderr.flush()
+            self.saved = os.dup(2)
+            os.dup2(self.log.fileno(), 2)
+        except OSError:
+            self.saved = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            sys.stderr.flush()
+            os.dup2(self.saved, 2)
+            os.close(self.saved)
+            self.log.close()
+        return False
 
 
 def main():
@@ -276,9 +323,10 @@ def main():
             out["scale_selfcheck"] = selfcheck
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], sample, cpu_lists = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)
-                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-                out["parity"] = parity_on_sample(ctx, ratio_sq, sample, cpu_lists)
+                with quiet_stderr():
+                    out["cpu_baseline"], sample, cpu_lists = cpu_baseline(descs, all_pairs, args.ratio, args.cpu_seconds)
+                    out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                    out["parity"] = parity_on_sample(ctx, ratio_sq, sample, cpu_lists)
             except Exception as e:  # the baseline is a reported side figure; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "descriptor pairs/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
@@ -311,12 +359,14 @@ def main():
     def give_up():
         if rank == 0:
             out.setdefault("ba", {"status": f"no result within {args.side_deadline:.0f} s"})
-            print(json.dumps(out), flush=True)
+            emit(out, args)
         os._exit(0)
 
     watchdog = threading.Timer(args.side_deadline, give_up)
     watchdog.daemon = True
     watchdog.start()
+    quiet = quiet_stderr()   # the side legs run the reference beside the device: its stderr logging goes to gpurun_out/bench_stderr.log
+    quiet.__enter__()
     if not args.no_ba:   # every rank takes part (the BA leg has a real exchange step); rank 0 reports
         try:
             from bench_ba import ba_bench_record
@@ -351,8 +401,10 @@ def main():
             out["ba"] = ba_rec
         if ba_c5 is not None:
             out["ba_c5_single_gpu"] = ba_c5
-        print(json.dumps(out), flush=True)
     watchdog.cancel()
+    quiet.__exit__(None, None, None)
+    if rank == 0:
+        emit(out, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

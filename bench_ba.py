@@ -10,7 +10,11 @@ HBM_PEAK_GBS = 8000.0
 # (FETCH_SIZE x 2 [gfx950 reports half the bytes of reads, MI355X_MICROARCH.md; calibrated on kernels of known byte counts] +
 # WRITE_SIZE, one window between two Jacobian evaluations; tools/pmc_kernels.py). Counters cannot be read inside this process:
 # the record carries the stored figure with traffic_measured_in_run = false and the file it came from.
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_ba_iteration_traffic.json")
+_PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+# (the newest pass on record: a round that re-measures drops its file beside the older ones - VERDICT r4: the bench must not keep
+# pointing at a superseded pass)
+TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, f"round{r}_ba_iteration_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
+                    os.path.join(_PROFILES, "round4_ba_iteration_traffic.json"))
 
 
 def stored_traffic(name):

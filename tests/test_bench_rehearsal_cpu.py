@@ -32,6 +32,8 @@ def _run_bench(n, extra=()):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    # the driver's contract: stdout ENDS with the one line, and the line survives a bounded capture of the tail
+    assert r.stdout.rstrip("\n").splitlines()[-1] == lines[0] and len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
 
 

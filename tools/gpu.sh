@@ -24,7 +24,9 @@ for mode in "$@"; do
     timeout 1500 python -m pytest $sel -m gpu -q -s > "$O/pytest_sel.log" 2>&1; echo "pytest rc=$?"; tail -8 "$O/pytest_sel.log" ;;
   bench)      # the driver's command
     (time timeout 1500 python bench.py) > "$O/bench.json" 2> "$O/bench.err"; tail -4 "$O/bench.err"
-    python tools/bench_summary.py "$O/bench.json" ;;
+    echo "stdout lines: $(wc -l < "$O/bench.json"), last line bytes: $(tail -1 "$O/bench.json" | wc -c)"
+    cp gpurun_out/bench_side.json "$O/bench_full.json" 2>/dev/null; cp gpurun_out/bench_stderr.log "$O/bench_reference_stderr.log" 2>/dev/null
+    python tools/bench_summary.py "$O/bench_full.json" ;;
   benchprof)  # rocprofv3 --kernel-trace --stats of the headline leg (same command, side records off)
     (cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -o bench -- python "$R/bench.py" --no-cpu-baseline --no-ba --no-hamming > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err")
     find "$O/prof_bench" -name "*kernel_stats.csv" -exec cp {} "$O/bench_kernel_stats.csv" \; ; rm -rf "$O/prof_bench"
