@@ -29,16 +29,31 @@ def _stale(target, sources):
 
 
 def build_hip(force=False, verbose=False):
+    """One object per translation unit (compiled side by side, rebuilt only when the unit or a header changed), linked into ONE shared
+    library. No relocatable device code: no kernel calls a device function of another unit."""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not _stale(LIB, deps):
-        return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    extra = os.environ.get("MVGX_HIPCC_FLAGS", "").split()   # measurement builds (-DMVGX_..._STAMPS): tools/ only
+    objs = [os.path.join(objdir, os.path.basename(s_)[:-4] + ".o") for s_ in srcs]
+    todo = [(s_, o) for s_, o in zip(srcs, objs) if force or extra or _stale(o, [s_] + hdrs)]
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(so):
+            cmd = [hipcc_path()] + flags + extra + ["-c", so[0], "-o", so[1]]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
+            list(ex.map(one, todo))
+    if todo or _stale(LIB, objs):
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -1765,6 +1765,31 @@ __device__ __forceinline__ void inverse_task(const double (*L)[kLS], double (*Li
   block_store(&Li[16 * t.I][16 * t.J], kLS, block_mma_t(&Li[16 * t.I][16 * t.I], S0, d4_t{0.0, 0.0, 0.0, 0.0}, li, lk), -1.0, li, lk);
 }
 
+// Eight pivots of the panel factorisation without a single cross-lane operand: every lane holds the (partially updated) 8 x 8 diagonal
+// block dg (lower triangle, row s at s (s + 1) / 2) and its own row a[0..7] of the same eight columns. Right-looking on unscaled columns,
+// exactly the recurrence of the rows themselves: x_t -= (x_j / d_j) dg[t][j] for t > j. Out: the multipliers lj[j] = a_j / d_j of the own
+// row, the pivots (1.0 where the block is not positive definite: ok turns false, uniformly - every lane sees the same dg).
+__device__ __forceinline__ bool panel8_factor(double (&dg)[36], double* __restrict__ a, double (&lj)[8], double* __restrict__ piv, bool ok) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double dj = dg[j * (j + 1) / 2 + j];
+    ok = ok && (dj > 0.0) && isfinite(dj);
+    const double dsafe = ok ? dj : 1.0;
+    piv[j] = dsafe;
+    const double r = fast_rcp(dsafe);
+    lj[j] = a[j] * r;
+#pragma unroll
+    for (int t = j + 1; t < 8; ++t) a[t] -= lj[j] * dg[t * (t + 1) / 2 + j];
+#pragma unroll
+    for (int s_ = j + 1; s_ < 8; ++s_) {
+      const double m = dg[s_ * (s_ + 1) / 2 + j] * r;
+#pragma unroll
+      for (int t = j + 1; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] -= m * dg[t * (t + 1) / 2 + j];
+    }
+  }
+  return ok;
+}
+
 // Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
 // processed as four 64 x 16 column panels: a register-resident panel factorisation by one wave, then a rank-16 update
 // of the remaining columns by all four. The inverse is built block by block (16 x 16) by the three waves the panel
@@ -1823,26 +1848,50 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
     // barriers. Right-looking on UNscaled columns: a_rt -= (a_rj / d_j) a_pt for t > j, p = j0 + j; the 1 / sqrt(d)
     // scaling is applied when the panel is written back. Rows above the pivot compute garbage that is never stored.
     if (wave == 0) {
-      double a[16];
+      // Round 5: the 16 columns as two sub-panels of 8 whose 8 x 8 diagonal block every lane factors REDUNDANTLY in its own registers
+      // (panel8_factor): no pivot crosses a lane any more. The v_readlane-fed form (one pivot = 2 + 2 (15 - j) readlanes in front of the
+      // multiply-adds, ~380 clocks) gave way to ~36 broadcast LDS reads per sub-panel; between the two sub-panels the eight rows
+      // j0 + 8 .. j0 + 15 hand their entries to every lane through the wave's scratch block. Same operations on the same values in the
+      // same order as the one-pivot-at-a-time form (a_rt -= (a_rj / d_j) a_pt, unscaled columns, 1 / sqrt(d) at the write-back): same bits.
+      double a[16], dg[36], lj[8], piv[16];
+      double* X = &T0[0][0];   // wave 0's scratch blocks (the inverse schedule never gives wave 0 a task): 64 doubles used
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = L[lane][j0 + t];
-      bool ok = true;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+        for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = L[j0 + s_][j0 + t];   // wave-uniform addresses: broadcast reads
+      bool ok = panel8_factor(dg, a, lj, piv, true);
+      // columns 8 .. 15 of the panel: a[8 + t] -= sum_k (a_rk / d_k) U[t][k], U = the unscaled entries of rows j0 + 8 + t, k ascending
+      if ((unsigned)(lane - (j0 + 8)) < 8u) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[(lane - (j0 + 8)) * 8 + k] = a[k];
+      }
+      lds_wave_sync();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        double u[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) u[q] = X[half * 32 + q];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[8 + 4 * half + t] -= lj[k] * u[t * 8 + k];
+      }
+      lds_wave_sync();   // every lane has read U before the scratch is reused
+      if ((unsigned)(lane - (j0 + 8)) < 8u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) X[(lane - (j0 + 8)) * 8 + t] = a[8 + t];
+      }
+      lds_wave_sync();
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+        for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = X[s_ * 8 + t];
+      ok = panel8_factor(dg, a + 8, lj, piv + 8, ok);
       double dmine = 1.0;   // lane j keeps pivot j: the 16 square roots are taken once, in parallel, after the chain
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double dj = readlane_f64(a[j], j0 + j);
-        // the column entries a(j0 + t, j) are all fetched (into scalar registers) BEFORE the multiplier is known: fetched one
-        // at a time in front of their FMA, each step paid the VALU -> SGPR -> VALU round trip of the single resident wave
-        double cj[16];
-#pragma unroll
-        for (int t = j + 1; t < 16; ++t) cj[t] = readlane_f64(a[j], j0 + t);   // lower triangle
-        ok = ok && (dj > 0.0) && isfinite(dj);
-        const double dsafe = ok ? dj : 1.0;
-        if (lane == j) dmine = dsafe;
-        const double lj = a[j] * fast_rcp(dsafe);
-#pragma unroll
-        for (int t = j + 1; t < 16; ++t) a[t] -= lj * cj[t];
-      }
+      for (int j = 0; j < 16; ++j) dmine = (lane == j) ? piv[j] : dmine;
       const double rsm = 1.0 / sqrt(dmine);
       if (lane == 0) flag[0] = ok ? 1.0 : -1.0;   // for the uniform exit below
       if (lane < 16) rd[j0 + lane] = rsm;          // 1 / L[r][r]
