@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--batch-pairs", type=int, default=0, help="image pairs per device batch (default: library default)")
     ap.add_argument("--overlap", type=int, default=-1, help="0: one batch at a time (isolated kernel timings); default: library default (1)")
     ap.add_argument("--verify-alone", type=int, default=-1, help="1: a filter kernel never shares the device with the previous batch's verify kernel; default: library default")
+    ap.add_argument("--filter-shape", type=int, default=0, help="MFMA shape of the filter kernel: 16 (v_mfma_i32_16x16x64_i8, library default) or 32 (A/B runs)")
     ap.add_argument("--collect", action="store_true", help="keep the run's match lists in one pinned host buffer (mvgx_match_run) "
                                                            "instead of streaming them (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -228,6 +229,8 @@ def main():
     ctx = matching.MatchContext(local_rank)
     if args.variant >= 0:
         ctx.set_option("variant", args.variant)
+    if args.filter_shape:
+        ctx.set_option("filter_shape", args.filter_shape)
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
     if args.verify_alone >= 0:
@@ -316,7 +319,8 @@ def main():
                          "traffic_measured_in_run": False,
                          "traffic_note": f"HBM bytes per launch, PMC pass {traffic_file} scaled by pairs per launch "
                                          "(counters cannot be read inside this process)",
-                         "kernel": "l2_filter_kernel" if variant == 4 else "l2_top2_ratio_kernel", "launches": launches,
+                         "kernel": ("l2_filter_kernel" if args.filter_shape == 32 else "l2_filter16_kernel") if variant == 4 else "l2_top2_ratio_kernel",
+                         "launches": launches,
                          "mean_launch_ms": kernel_ms / max(launches, 1)},
         }
         if selfcheck is not None:

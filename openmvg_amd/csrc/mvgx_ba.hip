@@ -1797,9 +1797,11 @@ __device__ __forceinline__ bool panel8_factor(double (&dg)[36], double* __restri
 // kDense: the factor goes back into A and the inverse is stored twice (k-major for the panel GEMM, row-major for the
 // back substitution); otherwise (block-sparse solver) only the k-major inverse is kept.
 // MVGX_BA_FACTOR_DEBUG=1: shader-clock stamps of the phases of the factor-and-invert kernel (workgroup 0), printed at destroy
-__device__ long long g_factor_stamps[12];
+__device__ long long g_factor_stamps[24];
 __device__ int g_factor_debug;
 #define MVGX_STAMP(i) do { if (stamping) g_factor_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// (inside the second panel slot, wave 0: waits for the wave's outstanding LDS operations first, so that a stamp closes what precedes it)
+#define MVGX_STAMP_W(i) do { if (stamping && jb == 1) { __builtin_amdgcn_s_waitcnt(0xc07f); g_factor_stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 template <bool kDense>
 __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int ld, int k0, int kb,
                                                    double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail,
@@ -1855,13 +1857,16 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
       // same order as the one-pivot-at-a-time form (a_rt -= (a_rj / d_j) a_pt, unscaled columns, 1 / sqrt(d) at the write-back): same bits.
       double a[16], dg[36], lj[8], piv[16];
       double* X = &T0[0][0];   // wave 0's scratch blocks (the inverse schedule never gives wave 0 a task): 64 doubles used
+      MVGX_STAMP_W(10);
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = L[lane][j0 + t];
 #pragma unroll
       for (int s_ = 0; s_ < 8; ++s_)
 #pragma unroll
         for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = L[j0 + s_][j0 + t];   // wave-uniform addresses: broadcast reads
+      MVGX_STAMP_W(11);
       bool ok = panel8_factor(dg, a, lj, piv, true);
+      MVGX_STAMP_W(12);
       // columns 8 .. 15 of the panel: a[8 + t] -= sum_k (a_rk / d_k) U[t][k], U = the unscaled entries of rows j0 + 8 + t, k ascending
       if ((unsigned)(lane - (j0 + 8)) < 8u) {
 #pragma unroll
@@ -1878,6 +1883,7 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
 #pragma unroll
           for (int k = 0; k < 8; ++k) a[8 + 4 * half + t] -= lj[k] * u[t * 8 + k];
       }
+      MVGX_STAMP_W(13);
       lds_wave_sync();   // every lane has read U before the scratch is reused
       if ((unsigned)(lane - (j0 + 8)) < 8u) {
 #pragma unroll
@@ -1888,7 +1894,9 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
       for (int s_ = 0; s_ < 8; ++s_)
 #pragma unroll
         for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = X[s_ * 8 + t];
+      MVGX_STAMP_W(14);
       ok = panel8_factor(dg, a + 8, lj, piv + 8, ok);
+      MVGX_STAMP_W(15);
       double dmine = 1.0;   // lane j keeps pivot j: the 16 square roots are taken once, in parallel, after the chain
 #pragma unroll
       for (int j = 0; j < 16; ++j) dmine = (lane == j) ? piv[j] : dmine;
@@ -1900,6 +1908,7 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
         const double rst = readlane_f64(rsm, t);   // wave collective: outside the lane-dependent select
         L[lane][j0 + t] = (lane >= j0 + t) ? a[t] * rst : 0.0;
       }
+      MVGX_STAMP_W(16);
       if (jb == 3) {   // the last diagonal block is inverted by the wave that produced it
         lds_wave_sync();
         diag_block_inverse(L, Li, rd, 48, lane);
@@ -1912,6 +1921,7 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
       }
     }
     __syncthreads();
+    MVGX_STAMP_W(17);
     if (!(flag[0] > 0.0)) { if (tid == 0) atomicExch(fail, 2); return; }   // uniform: not positive definite
     if (jb == 3) break;
     // rank-16 update of the columns right of the panel, one 16 x 16 block (I, J), I >= J > jb, per wave and turn:
@@ -1931,6 +1941,7 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
       }
     }
     __syncthreads();
+    MVGX_STAMP_W(18);
   }
   MVGX_STAMP(6);
   // what is left: block rows 2 (columns 0, 1) and 3, in two rounds
@@ -4514,10 +4525,14 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (getenv("MVGX_BA_FACTOR_DEBUG")) {
-    long long st[12];
-    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_factor_stamps), sizeof(st)) == hipSuccess)
+    long long st[24];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_factor_stamps), sizeof(st)) == hipSuccess) {
       fprintf(stderr, "[mvgx factor kernel, shader clocks] load %lld | panels (+ overlapped inverse) %lld %lld %lld %lld | inverse tail A %lld | tail B %lld | store %lld | total %lld\n",
               st[1] - st[0], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[9] - st[0]);
+      fprintf(stderr, "[mvgx factor kernel, second panel slot, wave 0] row + diagonal-block loads %lld | first 8 pivots %lld | hand-over + columns 8..15 %lld | second "
+              "diagonal block %lld | second 8 pivots %lld | square roots + write-back %lld | wait for the other waves %lld | rank-16 update + barrier %lld\n",
+              st[11] - st[10], st[12] - st[11], st[13] - st[12], st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16], st[18] - st[17]);
+    }
   }
   if (getenv("MVGX_BA_GROUP_DEBUG")) {
     unsigned long long st[8];

@@ -89,6 +89,7 @@ struct MatchParams {
   const uint32_t* img_neven;       // rows of even squared norm per image (slots of a parity half are filled in rank order)
   const uint2* pairs;              // batch-local (I, J)
   const uint2* work;               // (batch-local pair index, first query tile)
+  const uint4* work8;              // the same items as 32-byte records for l2_filter16_kernel: (pair, first query tile, tileI0, tileJ0), (ntI, ntJpad, 0, 0)
   uint32_t n_work;
   uint32_t* best;                  // [batch pairs][qstride], indexed by query SLOT: original index in I or kNoMatch
   int2* cd;                        // filter -> verify: (d0, upper bound of d1) of a candidate query slot
@@ -713,6 +714,202 @@ __global__ __launch_bounds__(256, 2) void l2_filter_kernel(MatchParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// l2_filter16 (variant 4, "filter_shape" 16; round 5): the filter on v_mfma_i32_16x16x64_i8.
+//
+// Why: on REAL descriptor bytes the device's power management holds a pure stream of 32x32x32 i8 MFMAs at 0.725 of the nominal
+// 5 POPS and a stream of 16x16x64 at 0.88 (tools/mfma_i8_shapes.hip, profiles/round5_mfma_i8_shapes_call_r5_01.txt; both reach 0.99
+// on zero operands): per MAC the 16x16 shape moves a quarter of the accumulator registers through the matrix pipe's result path.
+// Same passes per distance, same VALU per distance, same LDS bytes - only the shape of one instruction changes, and with it
+//   * the operand fetch: lane l feeds row (l & 15) of a 16-row block and the 16 k-values of quarter (l >> 4) of a 64-long k-step.
+//     Those 16 bytes are chunk (2 ks + (l >> 5)) * 64 + ((l >> 4) & 1) * 32 + blk * 16 + (l & 15) of the SAME fragment-major tile the
+//     32x32x32 kernels read: no second copy of the descriptors, one ds_read_b128 per lane and k-step as before (16 lanes = 256
+//     contiguous bytes: conflict-free);
+//   * the result: lane l holds D[4 (l >> 4) + r][l & 15], r = 0..3 - rows 4 g + r of the block for lane group g = l >> 4. In-tile rows
+//     m carry norm parity (m >> 2) & 1 (slot_row), so group g sees parity g & 1 only: w = 2 v - (g & 1) is exact as before;
+//   * the partition of the rows a lane sees (64 per window instead of 128): P-class c = 2 blk + (r >> 1), 4 classes of 16 rows per
+//     window, so a (class, window, lane group) cell is 16 rows: two adjacent slots in each of the window's 8 tiles - the SAME cells
+//     as the 32x32 kernel's (s1, half) cells under s1 = 4 (c >> 1) + 2 (g >> 1) + (c & 1), half = g & 1. The code word and the verify
+//     stage are unchanged;
+//   * a lane owns one query of each of 8 blocks of 16 (not one of each of 4 tiles of 32): 8 x (4 + 4) running maxima, the same 64
+//     registers; four lane groups are merged at the end (two exchange rounds) instead of two halves.
+// Exactness argument: the one of l2_filter_kernel with "half" read as "lane group" (other groups' best rows bound d1 from their side).
+// ------------------------------------------------------------------------------------------------
+constexpr int kNB16 = 2 * kNQ;   // query blocks of 16 per wave
+__global__ __launch_bounds__(256, 2) void l2_filter16_kernel(MatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x kStageBytes
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g4 = lane >> 4, par = g4 & 1;
+
+  const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const uint4 wr0 = p.work8[2 * (size_t)w], wr1 = p.work8[2 * (size_t)w + 1];   // one 32-byte record: no dependent table walks before the first load of data
+  struct { uint32_t x, y; } wk = {wr0.x, wr0.y};
+  const uint32_t tileI0 = wr0.z, tileJ0 = wr0.w;
+  const uint32_t ntJpad = wr1.y;
+  const int ntI = (int)wr1.x;
+  const int nwin = (ntI + kWinTiles - 1) / kWinTiles;
+  const uint32_t qt0 = wk.y + (uint32_t)wave * kNQ;
+
+  // byte offset of this lane's 16-byte chunk inside a tile, block 0, k-step 0 (see above)
+  const int lane_chunk = ((lane >> 5) * 64 + ((lane >> 4) & 1) * 32 + (lane & 15)) * 16;
+  v4i b[kNB16][2];
+  {
+    const int8_t* qsrc = p.tiles + (size_t)(tileJ0 + qt0) * kTileBytes + lane_chunk;
+#pragma unroll
+    for (int n = 0; n < kNB16; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[n][ks] = *reinterpret_cast<const v4i*>(qsrc + (n >> 1) * kTileBytes + (n & 1) * 256 + ks * 2048);
+  }
+
+  const int8_t* gI = p.tiles + (size_t)tileI0 * kTileBytes;
+  const int* gC = p.cinit + (size_t)tileI0 * kTileRows;
+
+  // validity and squared norm of the lane's eight query slots: fetched now, used after the last window (they used to be loaded there,
+  // one more trip to memory at the end of every workgroup)
+  uint32_t qperm[kNB16];
+  int qn[kNB16];
+#pragma unroll
+  for (int n = 0; n < kNB16; ++n) {
+    const bool inb = lane < 16 && qt0 + (uint32_t)(n >> 1) < ntJpad;
+    const size_t qs = (size_t)tileJ0 * kTileRows + (qt0 + (uint32_t)(n >> 1)) * kTileRows + (uint32_t)(n & 1) * 16 + (uint32_t)(lane & 15);
+    qperm[n] = inb ? p.perm[qs] : kNoMatch;
+    qn[n] = inb ? p.qnorm[qs] : 0;
+  }
+
+  int TP[kNB16][4];                         // P-class maxima of the run
+  int TW[kNB16][4];                         // ... of the current window
+  int Q1[kNB16], Q2[kNB16], Qg[kNB16];      // best / second-best window maximum, best window
+#pragma unroll
+  for (int n = 0; n < kNB16; ++n) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { TP[n][c] = kNegInit; TW[n][c] = kNegInit; }
+    Q1[n] = kNegInit; Q2[n] = kNegInit; Qg[n] = 0;
+  }
+
+  stage_window_glds_asm(smem, gI, gC, wave, lane);
+#pragma unroll
+  for (int n = 0; n < kNB16; ++n) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(b[n][ks]));
+    asm volatile("" : "+v"(qperm[n]), "+v"(qn[n]));
+  }
+
+  for (int win = 0; win < nwin; ++win) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    char* buf = smem + (win & 1) * kStageBytes;
+    char* nbuf = smem + ((win + 1) & 1) * kStageBytes;
+    if (win + 1 < nwin)
+      stage_window_glds_asm(nbuf, gI + (size_t)(win + 1) * kWinTiles * kTileBytes, gC + (win + 1) * kWinRows, wave, lane);
+
+    const int nt = min(kWinTiles, ntI - win * kWinTiles);
+    const char* wb = buf + lane_chunk;
+    const char* wc = buf + kWinTiles * kTileBytes + g4 * 16;
+    // accB starts as the neutral element of max: its first epilogue is a no-op
+    v4i accA[4], accB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accB[i] = v4i{kNegInit, kNegInit, kNegInit, kNegInit};
+
+    // one 16-row block = 16 MFMAs in two groups of four query blocks; the eight v_max3 of the previous group run in the shadow of a group
+#define MVGX_GROUP16(ACC, N0, A, CV)                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+    ACC[i_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], b[(N0) + i_][0], CV, 0, 0, 0);                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+    ACC[i_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], b[(N0) + i_][1], ACC[i_], 0, 0, 0);
+#define MVGX_EPI16(ACC, N0, BLK)                                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+    TW[(N0) + i_][2 * (BLK)] = max(max(TW[(N0) + i_][2 * (BLK)], ACC[i_][0]), ACC[i_][1]);                  \
+    TW[(N0) + i_][2 * (BLK) + 1] = max(max(TW[(N0) + i_][2 * (BLK) + 1], ACC[i_][2]), ACC[i_][3]);          \
+  }
+// the schedule of half a block: eight (MFMA, v_max3) pairs with the half's LDS reads (NDS of them) right behind the first pairs - left to
+// itself the compiler sinks a fragment load to just in front of its first use and waits there
+#define MVGX_MIX16(NDS)                                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);                                                        \
+    if (i_ < (NDS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+  }
+#define MVGX_BLOCK16(A, CV, AN, CN, BLK, NEXT_OFF, NEXT_COFF)                                               \
+  {                                                                                                         \
+    MVGX_GROUP16(accA, 0, A, CV)                                                                            \
+    AN[0] = *reinterpret_cast<const v4i*>(wb + (NEXT_OFF));                                                 \
+    AN[1] = *reinterpret_cast<const v4i*>(wb + (NEXT_OFF) + 2048);                                          \
+    MVGX_EPI16(accB, 4, 1 - (BLK))                                                                          \
+    MVGX_MIX16(2)                                                                                           \
+    MVGX_GROUP16(accB, 4, A, CV)                                                                            \
+    CN = *reinterpret_cast<const v4i*>(wc + (NEXT_COFF));                                                   \
+    MVGX_EPI16(accA, 0, BLK)                                                                                \
+    MVGX_MIX16(1)                                                                                           \
+  }
+    v4i a0[2], a1[2], c0, c1;
+    a0[0] = *reinterpret_cast<const v4i*>(wb);
+    a0[1] = *reinterpret_cast<const v4i*>(wb + 2048);
+    c0 = *reinterpret_cast<const v4i*>(wc);
+    // (the first epilogue of a window folds accB = neutral into block class 1 of blocks 4..7: a no-op)
+    for (int t = 0; t < nt; ++t) {
+      const int tn = min(t + 1, nt - 1);   // the fetch past the window's last tile re-reads it (no branch around the loads)
+      MVGX_BLOCK16(a0, c0, a1, c1, 0, t * kTileBytes + 256, t * (kTileRows * 4) + 64)
+      MVGX_BLOCK16(a1, c1, a0, c0, 1, tn * kTileBytes, tn * (kTileRows * 4))
+    }
+    MVGX_EPI16(accB, 4, 1)   // drain: the second group of the window's last block
+#undef MVGX_GROUP16
+#undef MVGX_EPI16
+#undef MVGX_MIX16
+#undef MVGX_BLOCK16
+    // the window's class maxima: their maximum is the window maximum, then they join the run-long maxima
+#pragma unroll
+    for (int n = 0; n < kNB16; ++n) {
+      const int v = max(max(max(TW[n][0], TW[n][1]), TW[n][2]), TW[n][3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { TP[n][c] = max(TP[n][c], TW[n][c]); TW[n][c] = kNegInit; }
+      const bool better = v > Q1[n];
+      Q2[n] = better ? Q1[n] : max(Q2[n], v);
+      Qg[n] = better ? win : Qg[n];
+      Q1[n] = better ? v : Q1[n];
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < kNB16; ++n) {
+    // best / second-best P-class of this lane
+    int p1 = kNegInit, p2 = kNegInit, pc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int v = TP[n][c];
+      const bool better = v > p1;
+      p2 = better ? p1 : max(p2, v);
+      pc = better ? c : pc;
+      p1 = better ? v : p1;
+    }
+    // exact w = |b'|^2 - d of the lane's best row; v2: its runner-up outside the best row's (class, window) cell
+    int W1 = 2 * p1 - par, V2 = max(2 * p2 - par, 2 * Q2[n] - par);
+    int code = (4 * (pc >> 1) + 2 * (g4 >> 1) + (pc & 1)) | (par << 3) | (Qg[n] << 4);   // (s1, half, window) of the 32x32 kernel's cells
+    // merge the four lane groups that share the query column: the winner's runner-up also has to beat the other groups' best rows.
+    // (groups g and g ^ 2 have the same parity, so their best values can be equal: then V2 >= W1, d1_ub <= d0 and the query is
+    // rejected, as the reference rejects a tie for the first place)
+#pragma unroll
+    for (int x = 16; x <= 32; x <<= 1) {
+      const int o1 = __shfl_xor(W1, x), o2 = __shfl_xor(V2, x), oc = __shfl_xor(code, x);
+      const bool mine = W1 > o1;
+      V2 = mine ? max(V2, o1) : max(o2, W1);
+      code = mine ? code : oc;
+      W1 = mine ? W1 : o1;
+    }
+    const uint32_t q = (qt0 + (uint32_t)(n >> 1)) * kTileRows + (uint32_t)(n & 1) * 16 + (uint32_t)(lane & 15);   // query slot within J
+    if (lane < 16 && qt0 + (uint32_t)(n >> 1) < ntJpad) {
+      const bool valid = qperm[n] != kNoMatch;
+      const int nq = qn[n];
+      const int d0 = nq - W1, d1ub = nq - V2;
+      const bool cand = valid && (__int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1ub)));
+      const size_t o = (size_t)wk.x * p.qstride + q;
+      p.best[o] = cand ? (uint32_t)code : kNoMatch;
+      if (cand) p.cd[o] = make_int2(d0, d1ub);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // l2_verify (variant 4, stage 2): finishes the candidates of the filter. Same work items as the filter (a workgroup
 // owns 512 query slots of one pair). 16 lanes per candidate recompute the exact distances of the 16 slots of its
 // (P-class, window, half) cell with v_dot4_i32_i8 on the tile bytes, take the cell's best (must equal d0) and its
@@ -998,6 +1195,7 @@ struct mvgx_match_ctx {
   // options
   int variant = 4;          // 0 naive; exact top-2 kernel: 1 register-staged LDS, 2 LDS-DMA builtin, 3 LDS-DMA asm;
                             // 4 = filter (1 VALU / distance) + verify, LDS staging mode in `stage`
+  int filter_shape = 16;    // MFMA shape of the variant-4 filter: 16 = v_mfma_i32_16x16x64_i8 (l2_filter16_kernel, round 5), 32 = 32x32x32
   int stage = 3;            // staging mode of variant 4 (1 / 2 / 3 as above); 3 measured fastest (sweep call 5)
   int profile = 0;
   int64_t batch_pairs = 1 << 15;   // 16 batches on the 1k-image set: short pipeline fill/drain, 262k workgroups per filter launch
@@ -1028,9 +1226,11 @@ struct mvgx_match_ctx {
     hipEvent_t ev_scan = nullptr;     // offsets of the batch are on the host
     hipEvent_t ev_filter = nullptr;   // filter kernel of the batch has finished
     DevBuf<uint2> d_pairs, d_work, d_ij;
+    DevBuf<uint4> d_work8;
     DevBuf<uint32_t> d_best, d_count, d_offsets;
     DevBuf<int2> d_cd;
     PinnedBuf<uint2> hp_pairs, hp_work;
+    PinnedBuf<uint4> hp_work8;
     PinnedBuf<uint32_t> hp_offsets;
     uint64_t p0 = 0;
     uint32_t nb = 0;
@@ -1208,6 +1408,7 @@ int mvgx_match_create(int device, mvgx_match_ctx** out) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_top2_ratio_kernel<kStageGldsAsm>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageRegs>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_filter_kernel<kStageGlds>),
@@ -1248,6 +1449,7 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
   for (auto& r : c->results) r.ij.release();
   for (auto& sl : c->slot) {
+    sl.d_work8.release(); sl.hp_work8.release();
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
     sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release(); sl.hp_ij[0].release(); sl.hp_ij[1].release();
@@ -1274,6 +1476,9 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "variant")) {
     MVGX_REQUIRE(value >= 0 && value <= 4, MVGX_ERR_ARG, "variant must be 0..4");
     c->variant = (int)value;
+  } else if (!strcmp(key, "filter_shape")) {
+    MVGX_REQUIRE(value == 16 || value == 32, MVGX_ERR_ARG, "filter_shape must be 16 or 32");
+    c->filter_shape = (int)value;
   } else if (!strcmp(key, "stage")) {
     MVGX_REQUIRE(value >= 1 && value <= 3, MVGX_ERR_ARG, "stage must be 1..3");
     c->stage = (int)value;
@@ -1418,6 +1623,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     // worst-case work items: ceil(max tiles / 16) per pair
     const uint32_t max_blocks_per_pair = std::max<uint32_t>(1, (c->max_tiles_pad + kBlockQTiles - 1) / kBlockQTiles);
     if ((rc = sl.hp_work.ensure((size_t)nb * max_blocks_per_pair))) return rc;
+    const bool records = c->variant == 4 && c->filter_shape == 16 && c->stage == 3 && !c->debug_filter;
+    if (records && (rc = sl.hp_work8.ensure((size_t)nb * max_blocks_per_pair * 2))) return rc;
     uint32_t n_work = 0;
     for (uint32_t k = 0; k < nb; ++k) {
       const uint32_t I = pairs_IJ[2 * (p0 + k)], J = pairs_IJ[2 * (p0 + k) + 1];
@@ -1426,12 +1633,19 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       // matcher_brute_force.hpp:108-113: NN(=2) > rows  -> no result; Matcher_Regions.cpp:65-69,85-90: empty regions skipped
       if (nI < 2 || nJ == 0) continue;
       const uint32_t ntJ = c->h_ntiles[J];   // occupied tiles of the query image
-      for (uint32_t qt = 0; qt < ntJ; qt += kBlockQTiles) sl.hp_work.p[n_work++] = make_uint2(k, qt);
+      for (uint32_t qt = 0; qt < ntJ; qt += kBlockQTiles) {
+        if (records) {   // everything the filter's workgroup needs to start, in ONE scalar load (it used to walk work -> pairs -> three per-image tables)
+          sl.hp_work8.p[2 * n_work] = make_uint4(k, qt, c->h_tile_off[I], c->h_tile_off[J]);
+          sl.hp_work8.p[2 * n_work + 1] = make_uint4(c->h_ntiles[I], c->h_tile_off[J + 1] - c->h_tile_off[J], 0, 0);
+        }
+        sl.hp_work.p[n_work++] = make_uint2(k, qt);
+      }
       st.n_pairs += 1;
       st.n_desc_pairs += (uint64_t)nI * nJ;
     }
     if ((rc = sl.d_pairs.ensure(nb))) return rc;
     if ((rc = sl.d_work.ensure(std::max<uint32_t>(n_work, 1)))) return rc;
+    if (records && (rc = sl.d_work8.ensure((size_t)std::max<uint32_t>(n_work, 1) * 2))) return rc;
     if ((rc = sl.d_best.ensure((size_t)nb * c->qstride))) return rc;
     if (c->variant == 4) {
       if ((rc = sl.d_cd.ensure((size_t)nb * c->qstride))) return rc;
@@ -1442,6 +1656,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     MVGX_HIP(hipMemcpyAsync(sl.d_pairs.p, sl.hp_pairs.p, nb * sizeof(uint2), hipMemcpyHostToDevice, stream));
     if (n_work)
       MVGX_HIP(hipMemcpyAsync(sl.d_work.p, sl.hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    if (n_work && records)
+      MVGX_HIP(hipMemcpyAsync(sl.d_work8.p, sl.hp_work8.p, (size_t)n_work * 2 * sizeof(uint4), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(sl.d_count.p, 0, nb * sizeof(uint32_t), stream));
 
     MatchParams mp;
@@ -1450,7 +1666,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     mp.rows_u8 = c->d_rows_view; mp.img_row_off = c->d_row_off.p;
     mp.img_tile_off = c->d_tile_off.p; mp.img_n = c->d_n.p; mp.img_ntiles = c->d_ntiles.p;
     mp.cd = sl.d_cd.p; mp.img_neven = c->d_neven.p; mp.errflag = c->d_err.p;
-    mp.pairs = sl.d_pairs.p; mp.work = sl.d_work.p; mp.n_work = n_work;
+    mp.pairs = sl.d_pairs.p; mp.work = sl.d_work.p; mp.work8 = sl.d_work8.p; mp.n_work = n_work;
     mp.best = sl.d_best.p; mp.count = sl.d_count.p; mp.qstride = c->qstride; mp.ratio_sq = ratio_sq;
 
     // filter kernels run one after the other (each fills the device); everything else of batch b-1 runs beside filter b
@@ -1470,6 +1686,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGlds>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->variant == 3) {
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
+      } else if (c->filter_shape == 16 && c->stage == 3 && !c->debug_filter) {
+        hipLaunchKernelGGL(l2_filter16_kernel, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 1) {
         hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 2) {

@@ -43,6 +43,7 @@ int readlane_i32(int v, int src_lane);
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 v16i_t mfma_i32_32x32x32_i8(v4i_t a, v4i_t b, v16i_t c, int, int, int);
+v4i_t mfma_i32_16x16x64_i8(v4i_t a, v4i_t b, v4i_t c, int, int, int);
 unsigned long long ballot(bool pred);
 int update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl);
 int lane_xor(int lane, int m);
@@ -81,6 +82,7 @@ static inline float __int2float_rn(int v) { return (float)v; }
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp
 #define __builtin_amdgcn_mfma_i32_32x32x32_i8 hipemu::mfma_i32_32x32x32_i8
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8 hipemu::mfma_i32_16x16x64_i8
 static inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool) {   // v_dot4_i32_i8: signed bytes
   for (int k = 0; k < 4; ++k) c += (int)(signed char)(a >> (8 * k)) * (int)(signed char)(b >> (8 * k));
   return c;

@@ -213,6 +213,26 @@ v16i_t mfma_i32_32x32x32_i8(v4i_t a, v4i_t b, v16i_t c, int, int, int) {
   return out;
 }
 
+// v_mfma_i32_16x16x64_i8 (gfx950): lane l feeds 16 bytes of A row i = l & 15 and of B column j = l & 15, covering
+// k = 16 (l >> 4) .. + 15; it receives D[i = 4 (l >> 4) + r][j = l & 15], r = 0..3 (the 16x16 accumulator layout of 32-bit results)
+v4i_t mfma_i32_16x16x64_i8(v4i_t a, v4i_t b, v4i_t c, int, int, int) {
+  const int me = g_cur, w0 = me & ~63, lane = me & 63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  memcpy(g_a16[par][me], &a, 16);
+  memcpy(g_b16[par][me], &b, 16);
+  wave_sync();
+  v4i_t out = c;
+  const int j = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (lane >> 4) + r;
+    int s = 0;
+    for (int k = 0; k < 64; ++k)
+      s += (int)(signed char)g_a16[par][w0 + i + 16 * (k >> 4)][k & 15] * (int)(signed char)g_b16[par][w0 + j + 16 * (k >> 4)][k & 15];
+    out[r] += s;
+  }
+  return out;
+}
+
 unsigned long long ballot(bool pred) {
   const int me = g_cur, w0 = me & ~63, par = g_parity[me];
   g_parity[me] ^= 1;

@@ -78,6 +78,13 @@ for mode in "$@"; do
       echo "tree $s $(python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
       echo "prev $s $(MVGX_LIB_PATH=$R/tools/_build/libmvgx_prev.so python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
     done; done ;;
+  matchab)    # the filter kernel on the two MFMA shapes, alternating, headline leg only
+    for rep in 1 2 3; do for shape in 16 32; do
+      python bench.py --filter-shape $shape --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print(json.dumps({'filter_shape': $shape, 'value': r['value'], 'frac': r['roofline']['frac'], 'mean_launch_ms': r['roofline']['mean_launch_ms'], 'ms_per_step': r['ms_per_step'], 'kernel': r['roofline']['kernel']}))" | tee -a "$O/match_filter_shape_ab.jsonl"
+    done; done ;;
   descsweep)  # the filter kernel's fraction of the i8 peak by descriptors per image (the per-workgroup start and the per-image finish amortise)
     for dsc in 1000 2000 4000 8000; do
       n=$((2000000 / dsc)); [ $n -gt 1000 ] && n=1000
