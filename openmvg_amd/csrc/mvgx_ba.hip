@@ -363,8 +363,21 @@ __device__ __forceinline__ void store_records_coalesced(double2* lds_wave /* 64 
 // WeightedCostFunction (camera_functor.hpp:35-90; weight 0 selects the unweighted functor), control points without loss
 // function, Huber corrector (corrector.cc:81-85,126-129: residual and Jacobian scale by sqrt(rho')). o: the observation's index
 // in the point-sorted arrays (weights / control flags). Returns r (corrected) and the factor sc of the Jacobian entries.
-__device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2]) {
-  if (d.odisabled && d.odisabled[o]) { r[0] = 0.0; r[1] = 0.0; return 0.0; }   // as if the observation were not in the problem
+// An observation that mvgx_ba_update_subset switched off contributes NOTHING - and that has to be a selection, not a product with a zero
+// weight: its projection is still evaluated (the point may be stale, on the camera's principal plane or at its centre), and inf * 0 = NaN
+// would reach the summed cost and the Gram blocks. Every Jacobian array the caller goes on to scale is cleared here.
+__device__ __forceinline__ bool observation_is_off(const Dev& d, uint64_t o) { return d.odisabled && d.odisabled[o]; }
+__device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2], double (&Ji)[16], double (&Jc)[12], double (&Jp)[6]) {
+  if (observation_is_off(d, o)) {   // as if the observation were not in the problem
+    r[0] = 0.0; r[1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ji[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Jc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
+    return 0.0;
+  }
   double w = 1.0;
   if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
   const bool ctrl = d.octrl && d.octrl[o];
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) void ba_linearize_list_kernel(Dev d, const uin
   for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
   obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
   eval_observation<true>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp);
-  const double sc = correct_observation(d, o, r);
+  const double sc = correct_observation(d, o, r, Ji, Jc, Jp);
   double* __restrict__ ja = d.JA + (size_t)o * kJA;
   double* __restrict__ jb = d.JB + (size_t)o * kJB;
   double* __restrict__ jc = d.JC + (size_t)o * kJC;
@@ -430,8 +443,18 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
     double w = 1.0;
     if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
     const bool ctrl = d.octrl && d.octrl[o];   // control point: no loss function, not in the RMSE
-    if (d.odisabled && d.odisabled[o]) w = 0.0;   // (mvgx_ba_update_subset: zero residual, zero rows, no cost)
     r[0] *= w; r[1] *= w;
+    if (observation_is_off(d, o)) {   // (mvgx_ba_update_subset: zero residual, zero rows, no cost - selected, never multiplied: see correct_observation)
+      r[0] = 0.0; r[1] = 0.0;
+      if (kJac) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Ji[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Jc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
+      }
+    }
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3];
     huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s, rho);
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
       eval_observation_t<true, kPinholeFamily>(model, pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? d.pi_obs[e] : 0, r);
+      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? d.pi_obs[e] : 0, r, Ji, Jc, Jp);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         double v[16];
@@ -1214,7 +1237,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
       for (int k = 0; k < 8; ++k) pin[k] = irow[k];
       eval_observation_t<true, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0, r);
+      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0, r, Ji, Jc, Jp);
       // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1348,9 +1371,9 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         const uint64_t o = (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0;
         double w = 1.0;
         if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
-        if (d.odisabled && d.odisabled[o]) w = 0.0;
         const bool ctrl = d.octrl && d.octrl[o];
         r[0] *= w; r[1] *= w;
+        if (observation_is_off(d, o)) { r[0] = 0.0; r[1] = 0.0; }   // selected, not multiplied (see correct_observation)
         const double s2 = r[0] * r[0] + r[1] * r[1];
         double rho[3];
         huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s2, rho);
@@ -2937,6 +2960,7 @@ struct mvgx_ba_ctx {
   mvgx::RcclComm* rccl = nullptr;
   double n_obs_rmse_local = 0;         // observations of this rank that count in the RMSE (not control points)
   double n_obs_global = 0;             // ... over all ranks
+  bool update_incomplete = false;      // a mvgx_ba_update{,_subset} failed half way: no solve until one succeeds
   // LM state (persists across mvgx_ba_lm_iteration calls)
   bool started = false;
   double x_cost = 0, radius = 0, decrease_factor = 2.0, gradient_max_norm = 0;
@@ -4589,6 +4613,12 @@ static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_
   const uint64_t no = d.n_obs;
   const unsigned T = host_threads(no);
   mvgx::HostArena ha;   // page-locked sources of the copies; the stream is drained before it goes out of scope
+  // ... on EVERY way out: an early return used to free the arena under copies still in flight. A failed update also leaves the
+  // context half re-bound: it refuses to solve until an update has gone through (update_incomplete).
+  struct Drain {
+    mvgx_ba_ctx* c; bool ok = false;
+    ~Drain() { (void)hipStreamSynchronize(c->stream); c->update_incomplete = !ok; }
+  } drain{c};
   int rc = MVGX_OK;
   auto staged_copy = [&](auto* dev, const auto* src, size_t n) -> int {
     using E = std::remove_cv_t<std::remove_reference_t<decltype(*src)>>;
@@ -4672,6 +4702,7 @@ static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_
     d.odisabled = nullptr;
   }
   c->n_obs_rmse_local = n_rmse;
+  c->n_obs_global = 0;   // (counted again by the next start() / mvgx_ba_evaluate: ADVICE r4 - evaluate() after an update divided by the old count)
   if (d.n_pts) MVGX_HIP(hipMemcpyAsync(d.pt_free, pt_free->data(), (size_t)d.n_pts, hipMemcpyHostToDevice, c->stream));
   std::vector<uint8_t> cam_active, cam_counts;
   camera_component_flags(p, *pose_used, *intr_used, cam_active, cam_counts);
@@ -4694,6 +4725,7 @@ static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_
   MVGX_HIP(hipStreamSynchronize(c->stream));
   c->started = false; c->finished = false;
   c->gmax_pending = false; c->gmax_resolved = false; c->fail_clear = false; c->fold_cand_now = false; c->candidate_cost_done = false;
+  drain.ok = true;
   return MVGX_OK;
 }
 
@@ -4745,6 +4777,7 @@ int mvgx_ba_set_allreduce(mvgx_ba_ctx* c, mvgx_allreduce_f64 fn, void* user) {
 int mvgx_ba_lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_summary* summary) {
   MVGX_REQUIRE(c && opt, MVGX_ERR_ARG, "mvgx_ba_lm_iteration: NULL argument");
   if (c->multi) return mvgx::ba_multi_solve(c->multi, opt, summary, true);
+  MVGX_REQUIRE(!c->update_incomplete, MVGX_ERR_STATE, "mvgx_ba_lm_iteration: the last mvgx_ba_update of this context failed half way - update it again (or create a new one)");
   MVGX_HIP(hipSetDevice(c->device));
   int rc;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -4762,6 +4795,7 @@ int mvgx_ba_lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_sum
 int mvgx_ba_solve(mvgx_ba_ctx* c, const mvgx_ba_options* opt, mvgx_ba_summary* summary) {
   MVGX_REQUIRE(c && opt, MVGX_ERR_ARG, "mvgx_ba_solve: NULL argument");
   if (c->multi) return mvgx::ba_multi_solve(c->multi, opt, summary, false);
+  MVGX_REQUIRE(!c->update_incomplete, MVGX_ERR_STATE, "mvgx_ba_solve: the last mvgx_ba_update of this context failed half way - update it again (or create a new one)");
   MVGX_HIP(hipSetDevice(c->device));
   int rc;
   MVGX_HIP(hipEventRecord(c->ev0, c->stream));
@@ -4888,6 +4922,7 @@ int mvgx_ba_get_solver_info(mvgx_ba_ctx* c, mvgx_ba_solver_info* out) {
 int mvgx_ba_evaluate(mvgx_ba_ctx* c, double* cost, double* rmse) {
   MVGX_REQUIRE(c, MVGX_ERR_ARG, "mvgx_ba_evaluate: NULL context");
   if (c->multi) return mvgx::ba_multi_evaluate(c->multi, cost, rmse);
+  MVGX_REQUIRE(!c->update_incomplete, MVGX_ERR_STATE, "mvgx_ba_evaluate: the last mvgx_ba_update of this context failed half way");
   MVGX_HIP(hipSetDevice(c->device));
   int rc = eval<false>(c, c->d.poses, c->d.intr, c->d.pts);
   if (rc) return rc;

@@ -255,6 +255,57 @@ def test_subset_equals_the_reduced_scene_emulated():
     assert sub[3] != full[3]
 
 
+def _check_disabled_observations_with_degenerate_projections(sc):
+    """an observation that is switched off must be SELECTED out, not multiplied by a zero weight - its projection is still
+    evaluated, and a point at the camera's centre (0 / 0) or on its principal plane (x / 0) gave inf * 0 = NaN in the cost and the Gram
+    blocks of the whole problem. Two points lose all their observations and are moved to such places; the solve must equal the one of
+    the scene without those observations, and evaluate() must divide by the count of what is on."""
+    sc = dict(sc)
+    en = np.ones(int(sc["n_obs"]), bool)
+    pts = np.array(sc["points"], float).reshape(-1, 3)
+    poses = np.array(sc["poses"], float).reshape(-1, 6)
+    # exactly degenerate projections need exact arithmetic: the pose that sees both points gets a zero rotation (X_cam = X + t, no rounding)
+    cam = int(sc["obs_pose"][np.flatnonzero(sc["obs_point"] == 5)[0]])
+    poses[cam, :3] = 0.0
+    t = poses[cam, 3:]
+    for which, ix in enumerate((5, 9)):
+        en[sc["obs_point"] == ix] = False
+        pts[ix] = -t if which == 0 else np.array([-t[0] + 0.75, -t[1] - 0.25, -t[2]])   # the camera's centre (0 / 0) / its principal plane (x / 0)
+        assert (pts[ix] + t)[2] == 0.0
+    extra = np.flatnonzero((sc["obs_pose"] == cam) & en)[:1]   # ... observed by that camera: append a disabled observation of each point
+    for ix in (5, 9):
+        for k in ("obs_pose", "obs_intr", "obs_point"):
+            sc[k] = np.ascontiguousarray(np.concatenate([sc[k], [cam if k == "obs_pose" else sc[k][extra[0]] if k == "obs_intr" else ix]]).astype(sc[k].dtype))
+        sc["obs_xy"] = np.ascontiguousarray(np.concatenate([np.asarray(sc["obs_xy"], float).reshape(-1), [10.0, 20.0]]))
+        en = np.concatenate([en, [False]])
+    sc["n_obs"] = int(len(en))
+    sc["poses"] = np.ascontiguousarray(poses.reshape(-1))
+    sc["points"] = np.ascontiguousarray(pts.reshape(-1))
+    c = ba.BaContext(sc)
+    assert c.update(sc, obs_enabled=en) is True
+    cost0, rmse0 = c.evaluate()
+    sub = _run(c)
+    c.close()
+    f = ba.BaContext(_reduced(sc, en))
+    cost_f, rmse_f = f.evaluate()
+    fresh = _run(f)
+    f.close()
+    assert np.isfinite(cost0) and np.isfinite(rmse0) and all(np.isfinite(v) for v in sub[3:6]), (cost0, rmse0, sub[3:6])
+    assert abs(cost0 - cost_f) <= 1e-12 * cost_f and abs(rmse0 - rmse_f) <= 1e-12 * rmse_f, (cost0, cost_f, rmse0, rmse_f)   # (evaluate() counts what is on)
+    assert sub[:3] == fresh[:3] and abs(sub[5] - fresh[5]) < 1e-12
+    assert np.array_equal(sub[8][5], pts[5]) and np.array_equal(sub[8][9], pts[9])   # unobserved points do not move
+
+
+def test_disabled_observations_with_degenerate_projections_emulated():
+    with _emu.emulated():
+        _check_disabled_observations_with_degenerate_projections(_scene())
+
+
+@pytest.mark.gpu
+def test_disabled_observations_with_degenerate_projections_on_the_device():
+    _check_disabled_observations_with_degenerate_projections(synth.ba_scene(n_cams=40, n_points=6000, track_len=6, model=3, n_intr_groups=2, seed=58))
+
+
 def test_subset_with_unsorted_observations_and_constant_intrinsics_emulated():
     sc = synth.ba_scene(n_cams=6, n_points=48, track_len=4, model=1, n_intr_groups=2, seed=47, rot_deg=0.3)
     perm = np.random.default_rng(2).permutation(int(sc["n_obs"]))
