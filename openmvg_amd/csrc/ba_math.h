@@ -116,10 +116,16 @@ MVGX_HD void transform_point(const double* pose, const double* X, double p[3], d
 // branches of the spherical and fisheye functors (atan2, atan, sqrt, divisions) are compiled out - in the fused point-group kernels
 // they cost registers on every problem although almost no scene uses them.
 template <bool kJac, bool kPinholeFamily = false>
+// off: the observation is switched off (mvgx_ba_update_subset). Its residual and rows are multiplied by zero afterwards, so they must be
+// FINITE whatever the (possibly stale) point is: the point is evaluated as if it sat on the optical axis at unit depth - no division by a
+// vanishing depth, no overflowing distortion polynomial, (0, 0, 1) is regular for every camera model (selecting the three
+// camera-frame coordinates costs three v_cndmask, clearing the 34 Jacobian entries after the fact cost the fused kernels 100 - 160 bytes
+// of scratch and 8 - 10 % of their time, call r5_09).
 MVGX_HD void eval_observation_t(int model, const double* intr, const double* pose, const double* trig, const double* X, const double* obs,
-                                double r[2], double* Ji, double* Jc, double* Jp) {
+                                double r[2], double* Ji, double* Jc, double* Jp, bool off = false) {
   double p[3], R[9], A[9];
   transform_point_t<kJac>(pose, trig, X, p, R, A);
+  if (off) { p[0] = 0.0; p[1] = 0.0; p[2] = 1.0; }
   double g00, g01, g02, g10, g11, g12;   // G = d r / d p (2 x 3)
   if (kJac)
     for (int c = 0; c < 16; ++c) Ji[c] = 0.0;
@@ -218,10 +224,10 @@ MVGX_HD void eval_observation_t(int model, const double* intr, const double* pos
 
 template <bool kJac>
 MVGX_HD void eval_observation(int model, const double* intr, const double* pose, const double* X, const double* obs,
-                              double r[2], double* Ji, double* Jc, double* Jp) {
+                              double r[2], double* Ji, double* Jc, double* Jp, bool off = false) {
   double trig[kPoseTrig];
   pose_trig(pose, trig);
-  eval_observation_t<kJac>(model, intr, pose, trig, X, obs, r, Ji, Jc, Jp);
+  eval_observation_t<kJac>(model, intr, pose, trig, X, obs, r, Ji, Jc, Jp, off);
 }
 
 // PoseCenterConstraintCostFunction (sfm_data_BA_ceres.cpp:44-80): r = weight o (C(pose) - prior), C = -R(-aa) t.

@@ -18,7 +18,11 @@
 //     of one level are factored by one batched launch;
 //   * per level three task lists: F (diagonal tiles to factor + invert), T (tiles below them: L_ik = A_ik L_kk^-T) and
 //     U (16 x 16 sub-blocks of the target tiles A_ij -= sum_k L_ik L_jk^T, contributors in ascending k: a fixed summation
-//     order, no atomics), plus the lists of the reverse sweep (back substitution).
+//     order, no atomics), plus the lists of the reverse sweep (back substitution);
+//   * look-ahead (round 5): the contributions of the columns of level l - 1 to the DIAGONAL tile of a column of level l - the only
+//     updates the next factorisation waits for - are applied by that column's factor workgroup itself, from A_kj and Linv_j
+//     (pre_* lists); all other T / U tasks of level l - 1 then run BESIDE the factorisation of level l in the same launch (the U tasks
+//     rebuild the strips of L they multiply from A and Linv, exactly as the T tasks form them). One launch per level instead of three.
 #ifndef MVGX_BA_SPARSE_PLAN_H_
 #define MVGX_BA_SPARSE_PLAN_H_
 
@@ -42,14 +46,19 @@ struct GemmTask {   // one 16 x 16 sub-block of a tile: dst(bi, bj) (-)= sum ove
   int32_t group = 0, scratch = 0;
 };
 constexpr int kSplitMin = 7, kSplitChunk = 4;   // lists of kSplitMin or more contributors are cut into chunks of kSplitChunk
+constexpr int kBsInline = 6;
+constexpr int kMaxPre = 6;   // look-ahead: a diagonal tile takes at most this many contributions of the previous level inside its factor workgroup
+static_assert(kMaxPre < kSplitMin, "a deferred contributor list is never a split one");
 struct SlotPair { int32_t a, b; };   // T: (slot of A_ik, tile column k -> Linv_k); U: (slot of L_ik, slot of L_jk)
 
 struct PlanParams {
   int leaf_cols = 192;          // parts at most this wide are not dissected further
   double max_sep_frac = 0.34;   // a separator heavier than this share of its subgraph is refused (no dissection)
   double min_side_frac = 0.2;   // both sides of a separator must carry at least this share
+  double sep_weight_slack = 1.25;   // separators up to this factor heavier than the lightest one compete on balance
   double dense_degree_factor = 4.0;   // border: degree > max(dense_degree_min, factor x median degree)
   int dense_degree_min = 16;
+  int max_pre = kMaxPre;        // look-ahead: contributions of the level before a factor workgroup takes itself (<= kMaxPre; tests lower it)
 };
 
 struct Plan {
@@ -63,7 +72,18 @@ struct Plan {
   std::vector<int32_t> t_start, u_start;                 // [n_levels + 1]
   std::vector<SlotPair> t_pairs, u_pairs;
   std::vector<int32_t> bs_start, bs_slot, bs_row;        // per tile column: the factor tiles below it (slot, tile row)
+  // the same per position in f_cols, as ONE 64-byte record a workgroup of the reverse sweep starts from (round 5: the sweep walked
+  // f_cols -> bs_start / tmap -> the lists -> the tiles, one trip to memory each): [0] column, [1] slot of its rhs strip, [2] entries,
+  // [3] first entry in bs_slot / bs_row, [4 + 2 i], [5 + 2 i]: (slot, row) of entry i < kBsInline
+  std::vector<int32_t> bs_rec;                           // [nT][16]
   int n_split_groups = 0, n_scratch_blocks = 0;          // of the U tasks with split contributor lists (GemmTask)
+  // look-ahead: lookahead[l] != 0 - the factor workgroups of level l apply the level-(l - 1) contributions to their diagonal tiles
+  // themselves (pre_start[k] .. pre_start[k + 1]: slot of A_kj and column j, ascending j); the U tasks that would have done it are the
+  // LAST ones of level l - 1 (u_defer_start[l - 1] .. u_start[l]): the level-by-level schedule runs them, the look-ahead schedule skips them
+  std::vector<uint8_t> lookahead;                        // [n_levels]
+  std::vector<int32_t> u_defer_start;                    // [n_levels]
+  std::vector<int32_t> pre_start, pre_slot, pre_col;     // [nT + 1], entries
+  std::vector<int32_t> slot_col;                         // [n_slots]: tile column of a slot (the rhs strip of column k counts as column k)
   uint64_t n_fill_tiles = 0;       // tiles of the factor (lower triangle incl. diagonal, without the rhs row)
   double flops = 0;                // multiply-adds x 2 of the numeric phase on the non-zero tiles
 };
@@ -136,11 +156,26 @@ struct Dissector {
     if (W > prm.leaf_cols && n_lv >= 3) {
       std::vector<long> lw(n_lv, 0);
       for (int v : order) lw[level[v]] += g.w[v];
-      long before = 0, best_w = -1;
+      // Among the level sets that qualify, the lightest - and among those within `sep_weight_slack` of the lightest, the one that cuts
+      // the subgraph most evenly (round 5). Taking the FIRST lightest level, as rounds 2 - 4 did, cut a band - all of whose level sets
+      // weigh the same - 20 : 80 at every step: an elimination tree of depth log_1.25 instead of log_2 (16 levels of dependent
+      // launches for the 1 000-camera ring where 11 do).
+      long before = 0, min_w = -1;
       for (int s = 0; s < n_lv; ++s) {
         const long after = W - before - lw[s];
         if (s > 0 && s < n_lv - 1 && before >= prm.min_side_frac * W && after >= prm.min_side_frac * W &&
-            lw[s] <= prm.max_sep_frac * W && (best_w < 0 || lw[s] < best_w)) { best_w = lw[s]; sep = s; }
+            lw[s] <= prm.max_sep_frac * W && (min_w < 0 || lw[s] < min_w)) min_w = lw[s];
+        before += lw[s];
+      }
+      before = 0;
+      long best_gap = -1;
+      for (int s = 0; s < n_lv; ++s) {
+        const long after = W - before - lw[s];
+        if (min_w >= 0 && s > 0 && s < n_lv - 1 && before >= prm.min_side_frac * W && after >= prm.min_side_frac * W &&
+            lw[s] <= prm.max_sep_frac * W && lw[s] <= prm.sep_weight_slack * min_w) {
+          const long gap = before > after ? before - after : after - before;
+          if (best_gap < 0 || gap < best_gap) { best_gap = gap; sep = s; }
+        }
         before += lw[s];
       }
     }
@@ -322,6 +357,12 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
     out.n_fill_tiles += m + 1;
   }
   out.n_slots = slots;
+  out.slot_col.assign(slots, 0);
+  for (int k = 0; k < nT; ++k) {
+    out.slot_col[out.tmap[(size_t)k * nT + k]] = k;
+    for (int i : below[k]) out.slot_col[out.tmap[(size_t)i * nT + k]] = k;
+    out.slot_col[out.tmap[(size_t)nT * nT + k]] = k;
+  }
   if (n_u_targets_est * 16 > max_tasks) return false;   // too much fill for the task-list formulation: dense path
   // ---- level schedule ----
   out.f_start.assign(out.n_levels + 1, 0);
@@ -334,8 +375,11 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
   }
   out.t_start.assign(out.n_levels + 1, 0);
   out.u_start.assign(out.n_levels + 1, 0);
-  struct Contrib { int32_t dst; int32_t k; int32_t a, b; uint8_t rhs, diag; };
+  struct Contrib { int32_t dst; int32_t k; int32_t a, b; uint8_t rhs, diag; int32_t j; };
   std::vector<Contrib> contribs;
+  out.lookahead.assign(out.n_levels, 0);
+  out.u_defer_start.assign(out.n_levels, 0);
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> pre(nT);   // per tile column: (slot of A_kj, j)
   for (int l = 0; l < out.n_levels; ++l) {
     contribs.clear();
     int level_scratch = 0;
@@ -363,48 +407,76 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
           const int i = rhs ? nT : s[a];
           const int dst = out.tmap[(size_t)i * nT + j];
           if (dst < 0) return false;   // symbolic factorisation is closed under these updates: cannot happen
-          contribs.push_back(Contrib{dst, k, out.tmap[(size_t)i * nT + k], sb, (uint8_t)rhs, (uint8_t)(i == j)});
+          contribs.push_back(Contrib{dst, k, out.tmap[(size_t)i * nT + k], sb, (uint8_t)rhs, (uint8_t)(i == j), (int32_t)j});
           out.flops += 2.0 * (rhs ? 1 : 64) * 64 * 64;
         }
       }
       out.flops += 64.0 * 64 * 64 / 3 + 64.0 * 64 * 64 / 3;   // factor + inverse of the diagonal tile
     }
     std::sort(contribs.begin(), contribs.end(), [](const Contrib& x, const Contrib& y) { return x.dst != y.dst ? x.dst < y.dst : x.k < y.k; });
-    for (size_t a = 0; a < contribs.size();) {
+    // look-ahead of the next level: every diagonal tile of level l + 1 must take its level-l contributions inside its factor workgroup
+    bool la = l + 1 < out.n_levels;
+    for (size_t a = 0; a < contribs.size() && la;) {
       size_t b = a;
       while (b < contribs.size() && contribs[b].dst == contribs[a].dst) ++b;
-      const int c0 = (int)out.u_pairs.size();
-      for (size_t q = a; q < b; ++q) out.u_pairs.push_back(SlotPair{contribs[q].a, contribs[q].b});
-      const int c1 = (int)out.u_pairs.size();
-      const int n_c = c1 - c0;
-      const int chunks = n_c >= kSplitMin ? (n_c + kSplitChunk - 1) / kSplitChunk : 1;
-      if (chunks > 32767) return false;   // (GemmTask::n_chunks is 16 bits: a level of more than 131 000 columns - dense path)
-      for (int bi = 0; bi < (contribs[a].rhs ? 1 : 4); ++bi)
-        for (int bj = 0; bj < 4; ++bj) {
-          if (contribs[a].diag && bj > bi) continue;   // lower triangle of a diagonal tile
-          if (chunks == 1) {
-            out.u_tasks.push_back(GemmTask{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0, c1});
-            continue;
-          }
-          for (int ch = 0; ch < chunks; ++ch) {
-            GemmTask g{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0 + ch * kSplitChunk, std::min(c1, c0 + (ch + 1) * kSplitChunk)};
-            g.chunk = (int16_t)ch; g.n_chunks = (int16_t)chunks; g.group = out.n_split_groups; g.scratch = level_scratch;
-            out.u_tasks.push_back(g);
-          }
-          out.n_split_groups += 1;
-          level_scratch += chunks;   // (the scratch blocks of a level are free again when its update kernel has ended: levels share them)
-          out.n_scratch_blocks = std::max(out.n_scratch_blocks, level_scratch);
-        }
+      if (contribs[a].diag && out.level_of[contribs[a].j] == l + 1 && (int)(b - a) > std::min(prm.max_pre, kMaxPre)) la = false;
       a = b;
+    }
+    if (l + 1 < out.n_levels) out.lookahead[l + 1] = la;
+    for (int pass = 0; pass < 2; ++pass) {   // 0: the tasks every schedule runs; 1: the ones the look-ahead schedule leaves to the factor workgroups
+      if (pass == 1) out.u_defer_start[l] = (int32_t)out.u_tasks.size();
+      for (size_t a = 0; a < contribs.size();) {
+        size_t b = a;
+        while (b < contribs.size() && contribs[b].dst == contribs[a].dst) ++b;
+        const bool deferred = la && contribs[a].diag && out.level_of[contribs[a].j] == l + 1;
+        if (deferred != (pass == 1)) { a = b; continue; }
+        if (deferred)
+          for (size_t q = a; q < b; ++q) pre[contribs[a].j].emplace_back(contribs[q].a, contribs[q].k);
+        const int c0 = (int)out.u_pairs.size();
+        for (size_t q = a; q < b; ++q) out.u_pairs.push_back(SlotPair{contribs[q].a, contribs[q].b});
+        const int c1 = (int)out.u_pairs.size();
+        const int n_c = c1 - c0;
+        const int chunks = n_c >= kSplitMin ? (n_c + kSplitChunk - 1) / kSplitChunk : 1;
+        if (chunks > 32767) return false;   // (GemmTask::n_chunks is 16 bits: a level of more than 131 000 columns - dense path)
+        for (int bi = 0; bi < (contribs[a].rhs ? 1 : 4); ++bi)
+          for (int bj = 0; bj < 4; ++bj) {
+            if (contribs[a].diag && bj > bi) continue;   // lower triangle of a diagonal tile
+            if (chunks == 1) {
+              out.u_tasks.push_back(GemmTask{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0, c1});
+              continue;
+            }
+            for (int ch = 0; ch < chunks; ++ch) {
+              GemmTask g{contribs[a].dst, (int16_t)bi, (int16_t)bj, c0 + ch * kSplitChunk, std::min(c1, c0 + (ch + 1) * kSplitChunk)};
+              g.chunk = (int16_t)ch; g.n_chunks = (int16_t)chunks; g.group = out.n_split_groups; g.scratch = level_scratch;
+              out.u_tasks.push_back(g);
+            }
+            out.n_split_groups += 1;
+            level_scratch += chunks;   // (the scratch blocks of a level are free again when its update kernel has ended: levels share them)
+            out.n_scratch_blocks = std::max(out.n_scratch_blocks, level_scratch);
+          }
+        a = b;
+      }
     }
     out.t_start[l + 1] = (int32_t)out.t_tasks.size();
     out.u_start[l + 1] = (int32_t)out.u_tasks.size();
+  }
+  out.pre_start.assign(nT + 1, 0);
+  for (int k = 0; k < nT; ++k) {
+    for (const auto& e : pre[k]) { out.pre_slot.push_back(e.first); out.pre_col.push_back(e.second); }
+    out.pre_start[k + 1] = (int32_t)out.pre_slot.size();
   }
   // ---- reverse sweep ----
   out.bs_start.assign(nT + 1, 0);
   for (int k = 0; k < nT; ++k) {
     for (int i : below[k]) { out.bs_slot.push_back(out.tmap[(size_t)i * nT + k]); out.bs_row.push_back(i); }
     out.bs_start[k + 1] = (int32_t)out.bs_slot.size();
+  }
+  out.bs_rec.assign((size_t)nT * 16, 0);
+  for (int f = 0; f < nT; ++f) {
+    const int k = out.f_cols[f];
+    int32_t* r = &out.bs_rec[(size_t)f * 16];
+    r[0] = k; r[1] = out.tmap[(size_t)nT * nT + k]; r[2] = out.bs_start[k + 1] - out.bs_start[k]; r[3] = out.bs_start[k];
+    for (int i = 0; i < kBsInline && i < r[2]; ++i) { r[4 + 2 * i] = out.bs_slot[r[3] + i]; r[5 + 2 * i] = out.bs_row[r[3] + i]; }
   }
   return true;
 }

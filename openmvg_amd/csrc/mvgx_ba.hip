@@ -190,6 +190,9 @@ struct SpSys {
   const mvgx_sparse::SlotPair *t_pairs = nullptr, *u_pairs = nullptr;
   const int32_t *f_cols = nullptr, *bs_start = nullptr, *bs_slot = nullptr, *bs_row = nullptr;
   const int32_t* level_of = nullptr;  // nT: level of a tile column in the elimination tree
+  // look-ahead schedule (ba_sparse_plan.h): column of a slot; per tile column the level-before contributions to its diagonal tile
+  const int32_t *slot_col = nullptr, *pre_start = nullptr, *pre_slot = nullptr, *pre_col = nullptr;
+  const int32_t* bs_rec = nullptr;    // nT x 16: what a workgroup of the reverse sweep needs to start, per position in f_cols (ba_sparse_plan.h)
   double* u_scratch = nullptr;        // partial sums of the U tasks with split contributor lists: 256 doubles per chunk
   unsigned* u_counter = nullptr;      // arrivals per split group (left at zero by the last arrival)
 };
@@ -363,21 +366,12 @@ __device__ __forceinline__ void store_records_coalesced(double2* lds_wave /* 64 
 // WeightedCostFunction (camera_functor.hpp:35-90; weight 0 selects the unweighted functor), control points without loss
 // function, Huber corrector (corrector.cc:81-85,126-129: residual and Jacobian scale by sqrt(rho')). o: the observation's index
 // in the point-sorted arrays (weights / control flags). Returns r (corrected) and the factor sc of the Jacobian entries.
-// An observation that mvgx_ba_update_subset switched off contributes NOTHING - and that has to be a selection, not a product with a zero
-// weight: its projection is still evaluated (the point may be stale, on the camera's principal plane or at its centre), and inf * 0 = NaN
-// would reach the summed cost and the Gram blocks. Every Jacobian array the caller goes on to scale is cleared here.
+// An observation that mvgx_ba_update_subset switched off contributes NOTHING: zero residual, zero scale of its rows. The rows themselves
+// must be finite for that product to be zero - the callers evaluate such an observation with `off` (ba_math.h: eval_observation_t), which
+// keeps its projection regular whatever the stale point is (inf * 0 = NaN reached the cost and the Gram blocks).
 __device__ __forceinline__ bool observation_is_off(const Dev& d, uint64_t o) { return d.odisabled && d.odisabled[o]; }
-__device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2], double (&Ji)[16], double (&Jc)[12], double (&Jp)[6]) {
-  if (observation_is_off(d, o)) {   // as if the observation were not in the problem
-    r[0] = 0.0; r[1] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Ji[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Jc[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
-    return 0.0;
-  }
+__device__ __forceinline__ double correct_observation(const Dev& d, uint64_t o, double (&r)[2]) {
+  if (observation_is_off(d, o)) { r[0] = 0.0; r[1] = 0.0; return 0.0; }   // as if the observation were not in the problem
   double w = 1.0;
   if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
   const bool ctrl = d.octrl && d.octrl[o];
@@ -404,8 +398,8 @@ __global__ __launch_bounds__(256) void ba_linearize_list_kernel(Dev d, const uin
 #pragma unroll
   for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
   obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
-  eval_observation<true>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp);
-  const double sc = correct_observation(d, o, r, Ji, Jc, Jp);
+  eval_observation<true>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp, observation_is_off(d, o));
+  const double sc = correct_observation(d, o, r);
   double* __restrict__ ja = d.JA + (size_t)o * kJA;
   double* __restrict__ jb = d.JB + (size_t)o * kJB;
   double* __restrict__ jc = d.JC + (size_t)o * kJC;
@@ -438,23 +432,14 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(Dev d, const double* 
 #pragma unroll
     for (int k = 0; k < 3; ++k) px[k] = pts[(size_t)ix * 3 + k];
     obs[0] = d.oxy[2 * o]; obs[1] = d.oxy[2 * o + 1];
-    eval_observation<kJac>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp);
+    const bool off = observation_is_off(d, o);   // (mvgx_ba_update_subset: zero residual, zero rows, no cost; evaluated with a regular projection)
+    eval_observation<kJac>(d.model[ii], pin, pp, px, obs, r, Ji, Jc, Jp, off);
     // WeightedCostFunction (camera_functor.hpp:35-90): weight 0 selects the unweighted functor
     double w = 1.0;
     if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
     const bool ctrl = d.octrl && d.octrl[o];   // control point: no loss function, not in the RMSE
+    if (off) w = 0.0;
     r[0] *= w; r[1] *= w;
-    if (observation_is_off(d, o)) {   // (mvgx_ba_update_subset: zero residual, zero rows, no cost - selected, never multiplied: see correct_observation)
-      r[0] = 0.0; r[1] = 0.0;
-      if (kJac) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) Ji[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Jc[k] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Jp[k] = 0.0;
-      }
-    }
     const double s = r[0] * r[0] + r[1] * r[1];
     double rho[3];
     huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s, rho);
@@ -648,8 +633,9 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
       double px[3], obs[2] = {xy.x, xy.y}, r[2], Ji[16], Jc[12], Jp[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) px[k] = d.pts[(size_t)ix * 3 + k];
-      eval_observation_t<true, kPinholeFamily>(model, pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? d.pi_obs[e] : 0, r, Ji, Jc, Jp);
+      const uint64_t o = (d.oweight || d.octrl || d.odisabled) ? d.pi_obs[e] : 0;
+      eval_observation_t<true, kPinholeFamily>(model, pin, pp, trig, px, obs, r, Ji, Jc, Jp, observation_is_off(d, o));
+      const double sc = correct_observation(d, o, r);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         double v[16];
@@ -1236,8 +1222,9 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       for (int k = 0; k < kPoseTrig; ++k) trig[k] = crow[6 + k];
 #pragma unroll
       for (int k = 0; k < 8; ++k) pin[k] = irow[k];
-      eval_observation_t<true, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
-      const double sc = correct_observation(d, (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0, r, Ji, Jc, Jp);
+      const uint64_t o_ = (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0;
+      eval_observation_t<true, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp, observation_is_off(d, o_));
+      const double sc = correct_observation(d, o_, r);
       // unscaled point terms: column norms and gradient (what ba_point_norms_kernel sums from the records)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1367,13 +1354,14 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         for (int k = 0; k < kPoseTrig; ++k) trig[k] = crow2[6 + k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pin[k] = irow2[k];
-        eval_observation_t<false, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp);
         const uint64_t o = (d.oweight || d.octrl || d.odisabled) ? G.eobs[e0 + tid] : 0;
+        const bool off = observation_is_off(d, o);
+        eval_observation_t<false, kPinholeFamily>(imodel[kk], pin, pp, trig, px, obs, r, Ji, Jc, Jp, off);
         double w = 1.0;
         if (d.oweight) { const double ww = d.oweight[o]; if (ww != 0.0) w = ww; }
+        if (off) w = 0.0;
         const bool ctrl = d.octrl && d.octrl[o];
         r[0] *= w; r[1] *= w;
-        if (observation_is_off(d, o)) { r[0] = 0.0; r[1] = 0.0; }   // selected, not multiplied (see correct_observation)
         const double s2 = r[0] * r[0] + r[1] * r[1];
         double rho[3];
         huber_rho_on(!ctrl && d.huber_a > 0.0, d.huber_a, s2, rho);
@@ -1788,6 +1776,33 @@ __device__ __forceinline__ void inverse_task(const double (*L)[kLS], double (*Li
   block_store(&Li[16 * t.I][16 * t.J], kLS, block_mma_t(&Li[16 * t.I][16 * t.I], S0, d4_t{0.0, 0.0, 0.0, 0.0}, li, lk), -1.0, li, lk);
 }
 
+// A 16-row strip of L_ik = A_ik Linv_k^T rebuilt in registers exactly as the T task forms the tile (same MFMA order, so the same bits):
+// lane (li, lk) of the product D[c][r] ends up holding L(16 b + li, 16 cb + lk + 4 reg) in strip[4 cb + reg], which IS the operand
+// element of k-step 4 cb + reg of an update product - no exchange between lanes. Two phases, so that a caller can put other work between
+// the issue of the loads and their use.
+__device__ const int kPreBi[4][3] = {{0, 3, 3}, {1, 1, 3}, {2, 2, 2}, {3, -1, -1}}, kPreBj[4][3] = {{0, 0, 1}, {0, 1, 2}, {0, 1, 2}, {3, 0, 0}};
+struct StripOperands { double xv[16], yv[40]; };   // yv: column blocks 0..3 of Linv, 4 (cb + 1) k-steps each (the inverse is triangular)
+__device__ __forceinline__ void sp_strip_load(const double* __restrict__ X, const double* __restrict__ Linv, int li, int lk, StripOperands& o) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) o.xv[ks] = X[ks * 256];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const double* __restrict__ Y = Linv + 16 * cb + li + lk * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4 * (cb + 1); ++ks) o.yv[2 * cb * (cb + 1) + ks] = Y[ks * 256];
+  }
+}
+__device__ __forceinline__ void sp_strip_compute(const StripOperands& o, double (&strip)[16]) {
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (cb + 1); ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.yv[2 * cb * (cb + 1) + ks], o.xv[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) strip[4 * cb + reg] = acc[reg];
+  }
+}
+
 // Eight pivots of the panel factorisation without a single cross-lane operand: every lane holds the (partially updated) 8 x 8 diagonal
 // block dg (lower triangle, row s at s (s + 1) / 2) and its own row a[0..7] of the same eight columns. Right-looking on unscaled columns,
 // exactly the recurrence of the rows themselves: x_t -= (x_j / d_j) dg[t][j] for t > j. Out: the multipliers lj[j] = a_j / d_j of the own
@@ -1825,10 +1840,13 @@ __device__ int g_factor_debug;
 #define MVGX_STAMP(i) do { if (stamping) g_factor_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 // (inside the second panel slot, wave 0: waits for the wave's outstanding LDS operations first, so that a stamp closes what precedes it)
 #define MVGX_STAMP_W(i) do { if (stamping && jb == 1) { __builtin_amdgcn_s_waitcnt(0xc07f); g_factor_stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
-template <bool kDense>
+// kPre (block-sparse solver, look-ahead schedule): before the factorisation the workgroup subtracts the contributions of the columns j of
+// the level before from the tile - sum_j L_kj L_kj^T with L_kj = A_kj Linv_j^T rebuilt here, strip by strip, in the T task's arithmetic,
+// and accumulated over j in the U task's order (16 x 16 sub-blocks, contributors ascending): the bits of the level-by-level schedule.
+template <bool kDense, bool kPre = false>
 __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int ld, int k0, int kb,
                                                    double* __restrict__ linv /* [k][c] = Linv[c][k], then [r][c] */, int* fail,
-                                                   double* lds) {
+                                                   double* lds, const SpSys* sp = nullptr, int kcol = 0) {
   double (*L)[kLS] = reinterpret_cast<double (*)[kLS]>(lds);
   double (*Li)[kLS] = reinterpret_cast<double (*)[kLS]>(lds + 64 * kLS);
   double (*Tmp)[17] = reinterpret_cast<double (*)[17]>(lds + 2 * 64 * kLS);     // two 16 x 16 scratch blocks per wave
@@ -1837,6 +1855,14 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
   const int tid = threadIdx.x;
   const bool stamping = g_factor_debug && blockIdx.x == 0 && tid == 0;   // read once: one global load, not one per stamp
   MVGX_STAMP(0);
+  int pre0 = 0, pre1 = 0;
+  StripOperands so;
+  if constexpr (kPre) {
+    pre0 = sp->pre_start[kcol]; pre1 = sp->pre_start[kcol + 1];
+    if (pre0 < pre1 && tid < 256)   // the first contributor's operands travel together with the tile itself
+      sp_strip_load(sp->A + (size_t)sp->pre_slot[pre0] * 4096 + 16 * (tid >> 6) + (tid & 15) + ((tid & 63) >> 4) * 64,
+                    sp->Linv + (size_t)sp->pre_col[pre0] * 4096, tid & 15, (tid & 63) >> 4, so);
+  }
   {
     // all 16 loads of a thread are issued before the first LDS store: as a rolled loop every element paid a full memory
     // round trip (the compiler keeps load -> wait -> store per iteration), ~11 of the kernel's 25 microseconds
@@ -1856,14 +1882,56 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
     }
   }
   __syncthreads();
-  MVGX_STAMP(1);
   // the wave index as a scalar: everything wave-dependent below is a scalar branch or a table lookup, no exec-masked regions
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  if constexpr (kPre) {
+    if (pre0 < pre1) {   // (uniform)
+      // the ten 16 x 16 sub-blocks of the lower triangle over the four waves: (row block, column block) per wave and turn, -1: idle
+      const int (*sbi)[3] = kPreBi, (*sbj)[3] = kPreBj;
+      d4_t acc[3] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
+      for (int q = pre0; q < pre1; ++q) {
+        if (q > pre0) {
+          sp_strip_load(sp->A + (size_t)sp->pre_slot[q] * 4096 + 16 * wave + li + lk * 64, sp->Linv + (size_t)sp->pre_col[q] * 4096, li, lk, so);
+          __syncthreads();   // every wave has read the tile of the contributor before
+        }
+        double strip[16];
+        sp_strip_compute(so, strip);
+        // L_kj staged where the inverse will be built (Li is cleared again below): row 16 wave + li, column 16 cb + lk + 4 reg
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Li[16 * wave + li][16 * (e >> 2) + lk + 4 * (e & 3)] = strip[e];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int bi = sbi[wave][t], bj = sbj[wave][t];
+          if (bi < 0) continue;   // (wave-uniform)
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[16 * bj + li][4 * ks + lk], Li[16 * bi + li][4 * ks + lk], acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int bi = sbi[wave][t], bj = sbj[wave][t];
+        if (bi < 0) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {   // element (row 16 bi + li, column 16 bj + lk + 4 reg) of the tile: the U task's destination
+          const int r = 16 * bi + li, cc = 16 * bj + lk + 4 * reg;
+          if (r >= cc) L[r][cc] -= acc[t][reg];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int q = tid + 256 * i; Li[q & 63][q >> 6] = 0.0; }
+      __syncthreads();
+    }
+  }
+  MVGX_STAMP(1);
   // The inverse of the factor, Linv[I][J] = -Linv[I][I] sum_{K=J}^{I-1} L[I][K] Linv[K][J] over 16 x 16 blocks, is built by waves
   // 1..3 WHILE wave 0 factors the next panel (the panel chain is serial and one wave wide): a piece is scheduled into the first
   // panel slot in which its inputs are final (kInvSchedule), so that only the last block row is left for after the loop.
   // Products run on the f64 matrix core with operands read from LDS; a wave keeps partial sums in two private 16 x 16 blocks.
   double (*T0)[17] = Tmp + 32 * wave;
+  // (unrolled: as a loop - 2 000 instead of 6 600 instructions - every slot was 10 % slower, call r5_08: the kernel is not bound by instruction fetch)
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) {
     const int j0 = jb * 16;
@@ -2144,42 +2212,154 @@ __global__ __launch_bounds__(256) void sp_gemm_kernel(SpSys s, int t0, int n_tas
   sp_gemm_task<kUpdate>(s, t0 + t);
 }
 
-// Reverse sweep, one workgroup per tile column of the level: z_k = Linv_k^T (y_k - sum over the tiles below L_ik^T z_i).
-__device__ __forceinline__ void sp_backsolve_col(const SpSys& s, int k, double* w /* 64 doubles of LDS */) {
-  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
-  double v = 0;
-  // the (slot, row) indices of the tiles below are fetched 64 at a time (one per lane, v_readlane hands them out): the loads of
-  // a tile no longer wait for an index load of their own
-  const int lane = tid & 63;
-  for (int ebase = s.bs_start[k]; ebase < s.bs_start[k + 1]; ebase += 64) {
-    const int n = min(64, s.bs_start[k + 1] - ebase);
-    const int my_slot = lane < n ? s.bs_slot[ebase + lane] : 0, my_row = lane < n ? s.bs_row[ebase + lane] : 0;
-    for (int i = 0; i < n; ++i) {
-      const int slot = __builtin_amdgcn_readlane(my_slot, i), row = __builtin_amdgcn_readlane(my_row, i);
-      const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
-      const double* __restrict__ zi = s.z + (size_t)row * 64 + part * 16;
-      double tv[16], zv[16];
+// The U task of the look-ahead schedule: the tiles L_ik, L_jk it multiplies are being written by the T tasks of the SAME launch, so the two
+// 16-row strips are rebuilt from A_ik, A_jk and Linv_k (sp_strip_*: the T task's arithmetic, the same bits) - the generalisation of
+// sp_chain_level_kernel's update to any number of contributors and to split contributor lists. Same sums in the same order as
+// sp_gemm_task<true>.
+__device__ __forceinline__ void sp_update_task_rebuilding(const SpSys& s, int task) {   // one wave, one task (wave-uniform)
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const mvgx_sparse::GemmTask g = s.u_tasks[task];
+  const mvgx_sparse::SlotPair* __restrict__ pairs = s.u_pairs;
+  d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+  const size_t xoff = 16 * g.bi + li + lk * 64, yoff = 16 * g.bj + li + lk * 64;
+  double* __restrict__ dst = s.A + (size_t)g.dst * 4096 + (size_t)(16 * g.bj + lk) * 64 + 16 * g.bi + li;
+  double old[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) { tv[q] = tile[q]; zv[q] = zi[q]; }
+  for (int reg = 0; reg < 4; ++reg) old[reg] = dst[reg * 256];
+  for (int cbase = g.c0; cbase < g.c1; cbase += 64) {
+    const int n = min(64, g.c1 - cbase);
+    const mvgx_sparse::SlotPair mine = lane < n ? pairs[cbase + lane] : mvgx_sparse::SlotPair{0, 0};
+    const int mycol = s.slot_col[mine.a];
+    for (int i = 0; i < n; ++i) {
+      const int pa = __builtin_amdgcn_readlane(mine.a, i), pb = __builtin_amdgcn_readlane(mine.b, i), k = __builtin_amdgcn_readlane(mycol, i);
+      const double* __restrict__ Linv = s.Linv + (size_t)k * 4096;
+      double la[16], lb[16];
+      {
+        StripOperands o;
+        sp_strip_load(s.A + (size_t)pa * 4096 + xoff, Linv, li, lk, o);
+        sp_strip_compute(o, la);
+        if (pa == pb && g.bi == g.bj) {   // (wave-uniform) a diagonal sub-block of a diagonal tile: one strip, twice
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) lb[ks] = la[ks];
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) o.xv[ks] = s.A[(size_t)pb * 4096 + yoff + ks * 256];
+          sp_strip_compute(o, lb);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lb[ks], la[ks], acc, 0, 0, 0);
+    }
+  }
+  if (g.n_chunks > 1) {   // wave-uniform: a chunk of a long contributor list (see sp_gemm_task)
+    double* __restrict__ part = s.u_scratch + (size_t)(g.scratch + g.chunk) * 256 + lane;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[reg * 64] = acc[reg];
+    __threadfence();
+    unsigned arrived = 0;
+    if (lane == 0) arrived = atomicAdd(s.u_counter + g.group, 1u);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived + 1 != (unsigned)g.n_chunks) return;
+    __threadfence();
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ all = s.u_scratch + (size_t)g.scratch * 256 + lane;
+    for (int ch = 0; ch < g.n_chunks; ++ch) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) tot[reg] += __builtin_nontemporal_load(all + (size_t)ch * 256 + reg * 64);
+    }
+    if (lane == 0) s.u_counter[g.group] = 0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = old[reg] - tot[reg];
+    return;
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) dst[reg * 256] = old[reg] - acc[reg];
+}
+
+// One launch per level of the elimination tree (look-ahead schedule): workgroups [0, nf) factor + invert the diagonal tiles of the level
+// (their first four waves; with `pre` they first take the contributions of the level before, chol_diag_inv_body<false, true>), the others
+// run the U tasks [u0, u0 + nu) and T tasks [t0, t0 + nt) of the level BEFORE, one per wave. Nothing in a launch depends on anything else
+// in it: the factor workgroups read A_kk, A_kj, Linv_j - final since the launch before; the U tasks write tiles of later columns only,
+// never a diagonal tile of this level; the T tasks write L. 84 KB of LDS per workgroup (one per CU) is what the factor needs; with eight
+// waves a CU still holds 8 T / U tasks.
+constexpr int kLevelThreads = 512;
+__global__ __launch_bounds__(kLevelThreads) void sp_level_kernel(SpSys s, int f0, int nf, int pre, int u0, int nu, int t0, int nt, int* fail) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x < nf) {
+    if (threadIdx.x >= 256) return;   // (whole waves: the barriers of the factor count the four that stay)
+    const int k = s.f_cols[f0 + blockIdx.x];
+    double* A = s.A + (size_t)s.tmap[(size_t)k * s.nT + k] * 4096;
+    if (pre) chol_diag_inv_body<false, true>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds, &s, k);
+    else chol_diag_inv_body<false, false>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds);
+    return;
+  }
+  const int t = ((int)blockIdx.x - nf) * (kLevelThreads / 64) + (int)(threadIdx.x >> 6);
+  if (t < nu) sp_update_task_rebuilding(s, u0 + t);                  // (the update tasks first: the longer ones)
+  else if (t < nu + nt) sp_gemm_task<false>(s, t0 + (t - nu));
+}
+
+// Reverse sweep, one workgroup per tile column of the level: z_k = Linv_k^T (y_k - sum over the tiles below L_ik^T z_i).
+// Round 5: the workgroup starts from ONE 64-byte record (column, rhs slot, its first six (slot, row) entries; wave-uniform, so scalar
+// loads) and then issues the loads of data together - the tiles below with their parts of z two entries at a time, the rhs strip, the
+// inverse: two trips to memory per level where the walk f_cols -> bs_start / tmap -> lists -> tiles -> rhs -> inverse took five or six
+// (11 us per level for a few hundred multiply-adds). Same sums in the same order.
+__device__ __forceinline__ void sp_backsolve_entry_load(const SpSys& s, int slot, int row, int c, int part, double (&tv)[16], double (&zv)[16]) {
+  const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
+  const double* __restrict__ zi = s.z + (size_t)row * 64 + part * 16;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { tv[q] = tile[q]; zv[q] = zi[q]; }
+}
+__device__ __forceinline__ void sp_backsolve_col(const SpSys& s, int f, double* w /* 64 doubles of LDS */) {
+  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3;
+  const int32_t* __restrict__ rec = s.bs_rec + (size_t)f * 16;
+  const int k = rec[0], rhs_slot = rec[1], n = rec[2], e0 = rec[3];
+  const double* __restrict__ li = s.Linv + (size_t)k * 4096 + c * 64 + part * 16;   // Linv[q][c] at c * 64 + q
+  double lv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lv[q] = li[q];
+  const double yk = part == 0 ? s.L[(size_t)rhs_slot * 4096 + c * 64] : 0.0;         // y_k[c]: row 0 of the rhs tile
+  double v = 0;
+#pragma unroll
+  for (int pr = 0; pr < mvgx_sparse::kBsInline / 2; ++pr) {
+    if (2 * pr >= n) break;   // (uniform)
+    double ta[16], za[16], tb[16], zb[16];
+    sp_backsolve_entry_load(s, rec[4 + 4 * pr], rec[5 + 4 * pr], c, part, ta, za);
+    const bool two = 2 * pr + 1 < n;
+    if (two) sp_backsolve_entry_load(s, rec[6 + 4 * pr], rec[7 + 4 * pr], c, part, tb, zb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += ta[q] * za[q];
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += tb[q] * zb[q];
+    }
+  }
+  // columns with more tiles below than a record holds: the rest of the list, its indices fetched 64 at a time (one per lane, v_readlane
+  // hands them out)
+  const int lane = tid & 63;
+  for (int ebase = e0 + mvgx_sparse::kBsInline; ebase < e0 + n; ebase += 64) {
+    const int m = min(64, e0 + n - ebase);
+    const int my_slot = lane < m ? s.bs_slot[ebase + lane] : 0, my_row = lane < m ? s.bs_row[ebase + lane] : 0;
+    for (int i = 0; i < m; ++i) {
+      double tv[16], zv[16];
+      sp_backsolve_entry_load(s, __builtin_amdgcn_readlane(my_slot, i), __builtin_amdgcn_readlane(my_row, i), c, part, tv, zv);
 #pragma unroll
       for (int q = 0; q < 16; ++q) v += tv[q] * zv[q];
     }
   }
   v += __shfl_xor(v, 1);
   v += __shfl_xor(v, 2);
-  if (part == 0) w[c] = s.L[(size_t)s.tmap[(size_t)s.nT * s.nT + k] * 4096 + c * 64] - v;   // y_k[c]: row 0 of the rhs tile
+  if (part == 0) w[c] = yk - v;
   __syncthreads();
-  const double* __restrict__ li = s.Linv + (size_t)k * 4096 + c * 64 + part * 16;   // Linv[q][c] at c * 64 + q
   double u = 0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) u += li[q] * w[part * 16 + q];
+  for (int q = 0; q < 16; ++q) u += lv[q] * w[part * 16 + q];
   u += __shfl_xor(u, 1);
   u += __shfl_xor(u, 2);
   if (part == 0) s.z[(size_t)k * 64 + c] = u;
 }
 __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
   __shared__ double w[64];
-  sp_backsolve_col(s, s.f_cols[f0 + blockIdx.x], w);
+  sp_backsolve_col(s, f0 + (int)blockIdx.x, w);
 }
 
 // The top of the elimination tree is a chain - one tile column per level, each depending on all the ones above it - and its part
@@ -2989,6 +3169,11 @@ struct mvgx_ba_ctx {
   double n_obs_rmse_all = 0;                  // n_obs_rmse_local of the whole structure (a subset counts its own)
   uint8_t* odisabled_buf = nullptr;           // device array behind Dev::odisabled (allocated by the first mvgx_ba_update_subset)
   double* filter_scratch = nullptr;           // 3 n_obs doubles: residual norms / observation rays (mvgx_ba_residuals, mvgx_ba_track_angles)
+  // block-sparse solve, MVGX_BA_LOOKAHEAD=1: one launch per level, the next level's factorisation beside the tasks of this one. Built and measured
+  // in round 5 (calls r5_06 .. r5_10), bit-identical, and 7 % SLOWER than the level-by-level schedule (C5 0.445 against 0.416 ms, C3 0.266 against
+  // 0.249): taking a contribution inside the factor workgroup costs the 6 us the separate task launch did, and the U tasks that rebuild their
+  // strips of L do six times the MFMA work at a quarter of the occupancy. Off by default; kept as the cross-check of the schedule (tests).
+  bool lookahead = false;
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
@@ -3228,6 +3413,26 @@ int assemble_system(mvgx_ba_ctx* c, double inv_radius) {
 int factor_and_solve_sparse(mvgx_ba_ctx* c) {
   Dev& d = c->d;
   const mvgx_sparse::Plan& pl = c->plan;
+  if (c->lookahead) {
+    // One launch per level (sp_level_kernel): the factorisation of level l beside the T / U tasks of level l - 1. A level whose diagonal
+    // tiles collect more contributions of the level before than a factor workgroup takes (ba_sparse_plan.h: kMaxPre) waits for them:
+    // its tasks get a launch of their own in front of its factorisation.
+    auto level = [&](int f0, int nf, int pre, int u0, int nu, int t0, int nt) {
+      const int per = kLevelThreads / 64, nb = nf + (nu + nt + per - 1) / per;
+      if (nb) hipLaunchKernelGGL(sp_level_kernel, dim3(nb), dim3(kLevelThreads), nf ? kDiagLds : 0, c->stream, d.sp, f0, nf, pre, u0, nu, t0, nt, d.fail);
+    };
+    for (int l = 0; l <= pl.n_levels; ++l) {
+      const int nf = l < pl.n_levels ? pl.f_start[l + 1] - pl.f_start[l] : 0, f0 = l < pl.n_levels ? pl.f_start[l] : 0;
+      const bool pre = l > 0 && l < pl.n_levels && pl.lookahead[l];
+      int u0 = 0, nu = 0, t0 = 0, nt = 0;
+      if (l > 0) {
+        u0 = pl.u_start[l - 1]; nu = (pre ? pl.u_defer_start[l - 1] : pl.u_start[l]) - u0;
+        t0 = pl.t_start[l - 1]; nt = pl.t_start[l] - t0;
+      }
+      if (l == 0 || pre || l == pl.n_levels) level(f0, nf, pre ? 1 : 0, u0, nu, t0, nt);
+      else { level(0, 0, 0, u0, nu, t0, nt); level(f0, nf, 0, 0, 0, 0, 0); }
+    }
+  } else
   for (int l = 0; l < pl.n_levels; ++l) {
     const int nf = pl.f_start[l + 1] - pl.f_start[l], nt = pl.t_start[l + 1] - pl.t_start[l], nu = pl.u_start[l + 1] - pl.u_start[l];
     hipLaunchKernelGGL(sp_factor_kernel, dim3(nf), dim3(256), kDiagLds, c->stream, d.sp, pl.f_start[l], d.fail);
@@ -3379,6 +3584,8 @@ int plan_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>
   if (d.N > 0 && c->solver_mode != 1) {
     mvgx_sparse::PlanParams prm;
     if (const char* env = getenv("MVGX_BA_ND_LEAF_COLS")) prm.leaf_cols = std::max(64, atoi(env));
+    if (const char* env = getenv("MVGX_BA_ND_SEP_SLACK")) prm.sep_weight_slack = std::max(1.0, atof(env));   // (1: only level sets as light as the lightest compete on balance)
+    if (const char* env = getenv("MVGX_BA_LOOKAHEAD_MAX_PRE")) prm.max_pre = std::max(0, atoi(env));   // (tests: the schedule's fall-back forms)
     const bool ok = mvgx_sparse::build_plan(
         (int)(np + d.n_intr), d.N, blocks, [&](int cb) { return cb < (int)np ? 6 : 8; },
         [&](int cb) { return cb < (int)np ? 6 * cb : 6 * (int)np + 8 * (cb - (int)np); }, prm, (uint64_t)1 << 25, c->plan);
@@ -3425,6 +3632,20 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
     int32_t* level_of = nullptr;
     if ((rc = dev_upload(c->pool, &level_of, pl.level_of, c->stream))) return rc;
     s.level_of = level_of;
+    {
+      int32_t *slot_col = nullptr, *pre_start = nullptr, *pre_slot = nullptr, *pre_col = nullptr;
+      std::vector<int32_t> ps = pl.pre_slot, pc = pl.pre_col;
+      if (ps.empty()) { ps.push_back(0); pc.push_back(0); }
+      if ((rc = dev_upload(c->pool, &slot_col, pl.slot_col, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &pre_start, pl.pre_start, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &pre_slot, ps, c->stream))) return rc;
+      if ((rc = dev_upload(c->pool, &pre_col, pc, c->stream))) return rc;
+      MVGX_HIP(hipStreamSynchronize(c->stream));   // (ps / pc are locals)
+      s.slot_col = slot_col; s.pre_start = pre_start; s.pre_slot = pre_slot; s.pre_col = pre_col;
+      int32_t* bs_rec = nullptr;
+      if ((rc = dev_upload(c->pool, &bs_rec, pl.bs_rec, c->stream))) return rc;
+      s.bs_rec = bs_rec;
+    }
     {   // the chain at the top: as many single-column levels as the kernel's LDS tables hold (MVGX_BA_BACKSOLVE_CHAIN=0: none)
       const char* env = getenv("MVGX_BA_BACKSOLVE_CHAIN");
       int n = 0; size_t entries = 0;
@@ -3894,6 +4115,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   if (const char* env = getenv("MVGX_BA_POLL_SCALARS")) c->poll_scalars = c->poll_scalars && atoi(env) != 0;
   if (const char* env = getenv("MVGX_BA_SEPARATE_COST")) c->fold_candidate = atoi(env) == 0;
   if (const char* env = getenv("MVGX_BA_CHAIN_FUSE")) c->chain_fuse_max_tasks = atoi(env);
+  if (const char* env = getenv("MVGX_BA_LOOKAHEAD")) c->lookahead = atoi(env) != 0;
   tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
@@ -4526,6 +4748,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   if (const char* env = getenv("MVGX_BA_GENERIC_MODELS")) c->pinhole_family = c->pinhole_family && atoi(env) == 0;
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_diag_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
+  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiagLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLds));
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_update128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kUpd128Lds));
   tick("product lists upload (enqueue)");

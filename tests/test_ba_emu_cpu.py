@@ -444,6 +444,36 @@ def test_block_sparse_solver_on_a_ring_equals_dense_and_oracle(monkeypatch, leaf
     assert np.allclose(xs, opx, atol=1e-9) and np.allclose(ps, opp, atol=1e-9) and np.allclose(isn, opi, rtol=1e-9, atol=1e-9)
 
 
+def _lookahead_schedules_agree(monkeypatch, sc, iters, emulated):
+    """The block-sparse solve under its three schedules: level by level (rounds 2 - 4: factor, T, U launches per level), look-ahead (round 5:
+    one launch per level, the factor workgroups take the contributions of the level before themselves, the U tasks rebuild their strips
+    of L), and look-ahead with every level on its fall-back form (MVGX_BA_LOOKAHEAD_MAX_PRE=0: tasks first, then the factorisation). The
+    arithmetic and its order are the same by construction: every output must be equal bit for bit."""
+    import contextlib
+    from tests import _emu as emu
+    out = {}
+    for name, env in (("levels", {"MVGX_BA_LOOKAHEAD": "0"}), ("lookahead", {"MVGX_BA_LOOKAHEAD": "1"}),
+                      ("fallback", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "0"}), ("one", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "1"})):
+        monkeypatch.setenv("MVGX_BA_SOLVER", "sparse")
+        monkeypatch.setenv("MVGX_BA_ND_LEAF_COLS", "64")
+        for k in ("MVGX_BA_LOOKAHEAD", "MVGX_BA_LOOKAHEAD_MAX_PRE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with (emu.emulated() if emulated else contextlib.nullcontext()):
+            ctx = ba.BaContext(sc)
+            s = ctx.solve(ba.default_options(max_num_iterations=iters)); info = ctx.solver_info(); prm = ctx.read_params(); ctx.close()
+        assert info.sparse == 1 and info.n_levels >= 3
+        out[name] = (s.num_iterations, s.num_successful_steps, s.final_cost, s.final_rmse) + tuple(prm)
+    for name in ("lookahead", "fallback", "one"):
+        a, b = out["levels"], out[name]
+        assert a[:4] == b[:4] and all(np.array_equal(x, y) for x, y in zip(a[4:], b[4:])), name
+
+
+def test_lookahead_schedule_equals_the_level_by_level_schedule_emulated(monkeypatch):
+    _lookahead_schedules_agree(monkeypatch, synth.ba_scene(n_cams=72, n_points=500, track_len=4, model=3, n_intr_groups=3, seed=71), 2, True)
+
+
 def test_block_sparse_solver_is_the_default_when_the_factor_is_sparse():
     sc = synth.ba_scene(n_cams=120, n_points=700, track_len=4, model=1, n_intr_groups=1, seed=72)
     opt = dict(max_num_iterations=1)

@@ -341,6 +341,11 @@ def test_block_sparse_solver_equals_dense_and_oracle(kw, leaf, monkeypatch):
     assert np.allclose(xs, xd, atol=tol) and np.allclose(ps, pd, atol=tol) and np.allclose(isn, idn, rtol=tol, atol=tol)
 
 
+def test_lookahead_schedule_equals_the_level_by_level_schedule(monkeypatch):
+    from tests.test_ba_emu_cpu import _lookahead_schedules_agree
+    _lookahead_schedules_agree(monkeypatch, synth.ba_scene(n_cams=300, n_points=30000, track_len=8, model=3, n_intr_groups=4, seed=77), 3, False)
+
+
 def test_block_sparse_solver_is_chosen_for_a_sequential_capture_scene(monkeypatch):
     monkeypatch.delenv("MVGX_BA_SOLVER", raising=False)
     monkeypatch.delenv("MVGX_BA_ND_LEAF_COLS", raising=False)

@@ -11,5 +11,7 @@ if "--warm" in sys.argv:   # a throw-away solve first: kernels loaded, caches fi
     c = ba.BaContext(sc); c.solve(ba.default_options(max_num_iterations=its)); c.close()
 c = ba.BaContext(sc)
 s = c.solve(ba.default_options(max_num_iterations=its))
-print(name, "iterations", s.num_iterations, "iter_ms", s.iter_ms_mean, "rmse", s.final_rmse)
+print(name, "iterations", s.num_iterations, "iter_ms", s.iter_ms_mean, "rmse", repr(s.final_rmse),
+      *(("solve_ms/it", s.solve_ms / max(s.num_iterations, 1), "schur_ms/it", s.schur_ms / max(s.num_iterations, 1), "backsub_ms/it", s.backsub_ms / max(s.num_iterations, 1),
+         "jacobian_ms/eval", s.jacobian_ms / (s.num_successful_steps + 1)) if os.environ.get("MVGX_BA_PHASE_TIMING") else ()))
 c.close()
