@@ -395,6 +395,11 @@ def main():
             out["geometric_filter_essential"] = geofilter_bench_record(local_rank, n_pairs=20000, steps=1, cpu=not args.no_cpu_baseline, cpu_pairs=3000, model="e")
         except Exception as e:
             out["geometric_filter"] = {"status": f"failed: {e!r}"}
+        try:   # the geometric filters' second stage (guided matching)
+            from bench_geofilter import guided_matching_bench_record
+            out["guided_matching"] = guided_matching_bench_record(local_rank, cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            out["guided_matching"] = {"status": f"failed: {e!r}"}
         try:   # the other -g models of main_GeometricFilter (angular essential a / u, orthographic essential o): one pass each
             from bench_geofilter import geofilter_other_models_record
             out["geometric_filter_other_models"] = geofilter_other_models_record(local_rank, cpu=not args.no_cpu_baseline)

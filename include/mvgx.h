@@ -538,6 +538,35 @@ int mvgx_geofilter_eo_acransac_indexed(int device, const double* feat_xy, const 
                                        uint64_t n_pairs, const mvgx_geofilter_options* opt, uint8_t* inlier_mask, mvgx_geofilter_result* results,
                                        mvgx_geofilter_stats* stats /* may be NULL */);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Guided matching (ABI 10): the second stage of the a-contrario geometric filters - SURVEY.md 8(f) N2's files
+ *   /root/reference/src/openMVG/robust_estimation/guided_matching.hpp:178-227  GuidedMatching(model, camL, lRegions, camR, rRegions, ...)
+ *   /root/reference/src/openMVG/matching_image_collection/F_ACRobust.hpp:109-152, E_ACRobust.hpp:153-215, H_ACRobust.hpp:136-180
+ * For every pair (I, J) and every feature i of I: over the features j of J whose geometric error under the pair's model is below
+ * error_th[pair] (kind FUNDAMENTAL: EpipolarDistanceError of F - the essential functor passes F = K2^-T E K1^-1; kind HOMOGRAPHY:
+ * AsymmetricError of H), the smallest and second smallest SquaredDescriptorDistance (L2<uint8_t>, exact); (i, j_best) is a match iff a
+ * second one exists and best < dist_ratio_sq * second (double arithmetic, guided_matching.hpp:68-112). Matches of a pair in ascending
+ * i (what IndMatch::getDeduplicated leaves). feat_xy: the positions the reference would compare - camL->get_ud_pixel(position) or the
+ * position itself - as doubles, image k owning rows [feat_start[k], feat_start[k + 1]); desc: desc_bytes (64, 128 or 144) per feature,
+ * same rows. A pair whose error_th is not a positive finite number gives no match (the functors' m_dPrecision_robust != infinity
+ * test). match_start: n_pairs + 1 offsets (out); *matches_ij: 2 uint32 per match (i, j), allocated by the library - release it with
+ * mvgx_host_free. */
+#define MVGX_GUIDED_FUNDAMENTAL 0
+#define MVGX_GUIDED_HOMOGRAPHY 1
+typedef struct mvgx_guided_stats {
+  uint64_t n_pairs, n_matches;
+  uint64_t n_geometric_tests;     /* (i, j) evaluated                                                              */
+  uint64_t n_geometric_passed;    /* ... with an error below the bound: descriptor distances that counted          */
+  uint64_t n_descriptor_stages;   /* wave-iterations in which the descriptor stage ran (some lane had passed)      */
+  double kernel_ms;               /* device time of the norm + matching kernels (HIP events)                       */
+  double total_ms;                /* the whole call incl. transfers                                                 */
+} mvgx_guided_stats;
+int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc, uint32_t desc_bytes, const uint64_t* feat_start, uint32_t n_images,
+                         const uint32_t* pairs, const double* models /* 9 per pair, row-major */, const double* error_th /* per pair */,
+                         uint64_t n_pairs, int kind, double dist_ratio_sq, uint64_t* match_start, uint32_t** matches_ij,
+                         mvgx_guided_stats* stats /* may be NULL */);
+void mvgx_host_free(void* p);   /* releases an array the library allocated for the caller (mvgx_guided_match_u8) */
+
 #ifdef __cplusplus
 }
 #endif

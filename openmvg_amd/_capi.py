@@ -128,6 +128,11 @@ ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int
 MVGX_REDUCE_SUM, MVGX_REDUCE_MAX = 0, 1
 
 # name -> (restype, argtypes). tests/test_capi_symbols.py checks every one of these is exported.
+class GuidedStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_matches", C.c_uint64), ("n_geometric_tests", C.c_uint64), ("n_geometric_passed", C.c_uint64),
+                ("n_descriptor_stages", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 PROTOTYPES = {
     "mvgx_last_error": (C.c_char_p, []),
     "mvgx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -211,6 +216,9 @@ PROTOTYPES = {
                                                     C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_geofilter_e_angular_acransac_indexed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                                             C.c_int, C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
+    "mvgx_guided_match_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GuidedStats)]),
+    "mvgx_host_free": (None, [C.c_void_p]),
 }
 
 _lib = None

@@ -35,6 +35,8 @@ struct Counters {
   std::atomic<uint64_t> fallback_pairs{0};   // image pairs finished by the host application's reference code after a device failure
   std::atomic<uint64_t> device_failures{0};  // failing mvgx_* calls seen (incl. injected ones)
   std::atomic<uint64_t> logged{0};           // bit per component: the failure of that component has been logged
+  std::atomic<uint64_t> guided_device_pairs{0};   // geometric filter: pairs whose guided matching ran on the device (mvgx_guided_match_u8)
+  std::atomic<uint64_t> guided_host_pairs{0};     // ... with the reference's own Geometry_guided_matching (other descriptor types, device failure)
 };
 inline Counters& counters() {   // one instance per linked image (function-local static of an inline function)
   static Counters c;
@@ -77,4 +79,10 @@ extern "C" __attribute__((weak)) void mvgx_adapter_counters(uint64_t out[3], int
   mvgx_adapter::Counters& c = mvgx_adapter::counters();
   if (out) { out[0] = c.device_pairs.load(); out[1] = c.fallback_pairs.load(); out[2] = c.device_failures.load(); }
   if (reset) { c.device_pairs = 0; c.fallback_pairs = 0; c.device_failures = 0; c.logged = 0; }
+}
+// ... of the geometric filter's second stage: {pairs guided on the device, pairs guided by the reference's host code}
+extern "C" __attribute__((weak)) void mvgx_adapter_guided_counters(uint64_t out[2], int reset) {
+  mvgx_adapter::Counters& c = mvgx_adapter::counters();
+  if (out) { out[0] = c.guided_device_pairs.load(); out[1] = c.guided_host_pairs.load(); }
+  if (reset) { c.guided_device_pairs = 0; c.guided_host_pairs = 0; }
 }

@@ -7,8 +7,11 @@
 //     returned true (more than 2.5 x 7 inliers for F, 2.5 x 4 for H), with the putative matches of the inliers in their original order;
 //   * the progress bar is restarted with the number of pairs and advanced once per pair; the device is called in batches of
 //     kPairsPerCall pairs and cancellation is checked between them: a cancelled run leaves the container empty from that point;
-//   * with b_guided_matching the reference's own Geometry_guided_matching runs on the host with the estimated F and precision and
-//     its result replaces the inlier list.
+//   * with b_guided_matching the functor's Geometry_guided_matching (F_ACRobust.hpp:109-152, H_ACRobust.hpp:136-180, E_ACRobust.hpp:153-215 ->
+//     robust_estimation/guided_matching.hpp:178-227) replaces the inlier list. Round 5: for uint8 descriptors of 64 / 128 / 144 bytes it runs
+//     on the device as well (mvgx_guided_match_u8: the estimated model, Square(m_dPrecision_robust), Square(dDistanceRatio), the
+//     undistorted positions the estimation stage already holds and the regions' descriptor bytes); any other region type, a pair the
+//     device did not estimate or a failing call takes the reference's own member function (mvgx_adapter_guided_counters tells which ran).
 // Inputs of the device call (mvgx_geofilter_f_acransac_indexed): the undistorted pixel positions of the features of every view that
 // occurs (the expressions of MatchesPointsToMat, Geometric_Filter_utils.cpp:33-49, once per feature on OpenMP threads), the index
 // pairs of the putative matches as the container holds them, and the image sizes of the views.
@@ -33,6 +36,7 @@
 #include "openMVG/cameras/Camera_Intrinsics.hpp"
 #include "openMVG/features/feature.hpp"
 #include "openMVG/matching_image_collection/Geometric_Filter_utils.hpp"
+#include "openMVG/multiview/essential.hpp"
 #include "openMVG/sfm/pipelines/sfm_regions_provider.hpp"
 #include "openMVG/sfm/sfm_data.hpp"
 #include "openMVG/system/logger.hpp"
@@ -291,7 +295,75 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
     }
     mvgx_adapter::counters().device_pairs.fetch_add(n_dev_done);
   }
-  // results in container order; guided matching (host, the reference's code) on OpenMP threads like the reference's loop
+  // ---- second stage on the device: guided matching of the accepted pairs (the models and bounds of the first stage never leave the process) ----
+  std::vector<uint8_t> guided_done(dev_pairs.size() ? dev_pairs.size() : 1, 0);
+  std::vector<uint64_t> guided_start;
+  uint32_t* guided_ij = nullptr;
+  struct FreeGuided { uint32_t*& p; ~FreeGuided() { if (p) mvgx_host_free(p); } } free_guided{guided_ij};
+  std::vector<size_t> guided_pairs;   // positions in dev_pairs of the pairs handed to the guided call, in call order
+  if constexpr (!M::angular && !kOrtho) {
+    if (b_guided_matching && n_dev_done > 0 && !my_progress_bar->hasBeenCanceled()) {
+      // the regions' descriptors, in the feature order of feat_start: uint8 scalar regions of one length only
+      uint32_t desc_bytes = 0;
+      bool usable = true;
+      for (size_t v = 0; v < n_views && usable; ++v) {
+        const std::shared_ptr<features::Regions> r = regions_provider_->get(slot_view[v]);
+        usable = r && r->IsScalar() && r->Type_id() == typeid(unsigned char).name() && (desc_bytes == 0 || r->DescriptorLength() == desc_bytes) &&
+                 r->RegionCount() == feat_start[v + 1] - feat_start[v];
+        if (usable) desc_bytes = (uint32_t)r->DescriptorLength();
+      }
+      usable = usable && (desc_bytes == 64 || desc_bytes == 128 || desc_bytes == 144);
+      if (usable) {
+        for (size_t k = 0; k < n_dev_done; ++k)
+          if (res[k].ok) guided_pairs.push_back(k);
+        std::vector<uint8_t> desc((size_t)feat_start[n_views] * desc_bytes + 1);
+#ifdef OPENMVG_USE_OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+        for (int64_t v = 0; v < (int64_t)n_views; ++v) {
+          const std::shared_ptr<features::Regions> r = regions_provider_->get(slot_view[v]);
+          const size_t nb = (size_t)(feat_start[v + 1] - feat_start[v]) * desc_bytes;
+          if (nb) std::memcpy(desc.data() + (size_t)feat_start[v] * desc_bytes, r->DescriptorRawData(), nb);
+        }
+        const size_t ng = guided_pairs.size();
+        std::vector<uint32_t> g_views(2 * std::max<size_t>(ng, 1));
+        std::vector<double> g_model(9 * std::max<size_t>(ng, 1)), g_th(std::max<size_t>(ng, 1));
+        for (size_t q = 0; q < ng; ++q) {
+          const size_t k = guided_pairs[q];
+          g_views[2 * q] = pair_views[2 * k]; g_views[2 * q + 1] = pair_views[2 * k + 1];
+          if constexpr (M::essential) {   // E_ACRobust.hpp:196-197: the epipolar error is taken in pixels, with F = K2^-T E K1^-1
+            Mat3 E, K1, K2, F;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+              E(r, c) = res[k].F[3 * r + c]; K1(r, c) = view_K[9 * (size_t)pair_views[2 * k] + 3 * r + c]; K2(r, c) = view_K[9 * (size_t)pair_views[2 * k + 1] + 3 * r + c];
+            }
+            FundamentalFromEssential(E, K1, K2, &F);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g_model[9 * q + 3 * r + c] = F(r, c);
+          } else {
+            std::memcpy(g_model.data() + 9 * q, res[k].F, 9 * sizeof(double));
+          }
+          g_th[q] = Square(res[k].precision_robust);   // (infinity stays infinity: no guided matches, as the functors test)
+        }
+        guided_start.assign(ng + 1, 0);
+        const bool inj = mvgx_adapter::injected("geofilter", "guided");
+        const int rc = inj ? MVGX_ERR_NODEV
+                           : mvgx_guided_match_u8(-1, feat_xy.data(), desc.data(), desc_bytes, feat_start.data(), (uint32_t)n_views, g_views.data(), g_model.data(),
+                                                  g_th.data(), (uint64_t)ng, std::is_same<Functor, GeometricFilter_HMatrix_AC>::value ? MVGX_GUIDED_HOMOGRAPHY
+                                                                                                                                     : MVGX_GUIDED_FUNDAMENTAL,
+                                                  Square(d_distance_ratio), guided_start.data(), &guided_ij, nullptr);
+        if (rc == MVGX_OK) {
+          for (size_t q = 0; q < ng; ++q) guided_done[guided_pairs[q]] = 1;
+          mvgx_adapter::counters().guided_device_pairs.fetch_add(ng);
+        } else {
+          // logged once; the pairs take the reference's own Geometry_guided_matching below (or the failure is thrown)
+          mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", "mvgx_guided_match_u8", rc, inj);
+          guided_pairs.clear();
+        }
+      }
+    }
+  }
+  std::vector<int64_t> guided_index(dev_pairs.size() ? dev_pairs.size() : 1, -1);
+  for (size_t q = 0; q < guided_pairs.size(); ++q) guided_index[guided_pairs[q]] = (int64_t)q;
+  // results in container order; what is left of the guided matching (host, the reference's code) on OpenMP threads like the reference's loop
   std::vector<int64_t> dev_index(n_pairs, -1);
   for (size_t k = 0; k < dev_pairs.size(); ++k) dev_index[dev_pairs[k]] = (int64_t)k;
 #ifdef OPENMVG_USE_OPENMP
@@ -336,7 +408,14 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
           for (size_t i = 0; i < kv.second.size(); ++i)
             if (mask[lo + i]) inliers.push_back(kv.second[i]);
         }
-        if (ok && b_guided_matching) {
+        if (ok && b_guided_matching && guided_done[k]) {
+          const int64_t q = guided_index[k];
+          IndMatches g;
+          g.reserve(guided_start[q + 1] - guided_start[q]);
+          for (uint64_t e = guided_start[q]; e < guided_start[q + 1]; ++e) g.emplace_back(guided_ij[2 * e], guided_ij[2 * e + 1]);
+          std::swap(inliers, g);
+        } else if (ok && b_guided_matching) {
+          mvgx_adapter::counters().guided_host_pairs.fetch_add(1);
           Functor f = functor;
           for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) ModelOf<Functor>::model(f)(r, c) = res[k].F[3 * r + c];

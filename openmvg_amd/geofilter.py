@@ -244,3 +244,55 @@ def Robust_model_estimation(putative_matches, feats_xy, image_sizes, functor=Non
         if res["ok"][k]:
             out[key] = np.asarray(putative_matches[key], np.uint32).reshape(-1, 2)[mask[start[k]:start[k + 1]]]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Guided matching: robust_estimation/guided_matching.hpp:178-227 through {F,H,E}_ACRobust.hpp's Geometry_guided_matching
+# ---------------------------------------------------------------------------------------------------------------------------------
+GUIDED_FUNDAMENTAL, GUIDED_HOMOGRAPHY = 0, 1
+
+
+def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRatio=0.6, kind=GUIDED_FUNDAMENTAL, device=-1):
+    """The functors' second stage for a list of image pairs on the device (mvgx_guided_match_u8).
+
+    feat_xy: per image an (n, 2) array of the positions the reference compares (cam->get_ud_pixel(position), or the position itself);
+    descs: per image an (n, 64 | 128 | 144) uint8 array; pairs: (P, 2) image indices; models: (P, 3, 3) - m_F (for the essential
+    functor F = K2^-T E K1^-1) or m_H; precision_robust: (P,) m_dPrecision_robust in pixels (infinity: no guided matching for that
+    pair, as the reference). The reference passes Square(m_dPrecision_robust) and Square(dDistanceRatio): so does this function.
+    Returns ({(I, J): (m, 2) uint32 array of (i, j)} for the pairs with at least one match, stats)."""
+    n_images = len(feat_xy)
+    start = np.zeros(n_images + 1, np.uint64)
+    for k in range(n_images):
+        if len(feat_xy[k]) != len(descs[k]):
+            raise ValueError("guided_matching: positions and descriptors of an image differ in length")
+        start[k + 1] = start[k] + len(feat_xy[k])
+    xy = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float64).reshape(-1, 2) for f in feat_xy]) if n_images else np.zeros((0, 2)))
+    nb = {int(np.asarray(d).shape[1]) for d in descs if len(d)} or {128}
+    if len(nb) != 1:
+        raise ValueError("guided_matching: descriptors of different lengths")
+    desc_bytes = nb.pop()
+    dd = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, desc_bytes) for d in descs]) if n_images else np.zeros((0, desc_bytes), np.uint8))
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    models = np.ascontiguousarray(models, np.float64).reshape(-1, 9)
+    prec = np.asarray(precision_robust, np.float64).reshape(-1)
+    if not (len(pairs) == len(models) == len(prec)):
+        raise ValueError("guided_matching: one model and one precision per pair")
+    with np.errstate(over="ignore"):
+        th = np.ascontiguousarray(prec * prec)   # Square(m_dPrecision_robust)
+    ratio_sq = float(dDistanceRatio) * float(dDistanceRatio)
+    ms = np.zeros(len(pairs) + 1, np.uint64)
+    out = C.c_void_p()
+    st = _capi.GuidedStats()
+    _capi.check(_capi.lib().mvgx_guided_match_u8(device, xy.ctypes.data, dd.ctypes.data, desc_bytes, start.ctypes.data, n_images, pairs.ctypes.data,
+                                                 models.ctypes.data, th.ctypes.data, len(pairs), int(kind), ratio_sq, ms.ctypes.data, C.byref(out), C.byref(st)))
+    try:
+        total = int(ms[-1])
+        ij = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(max(total, 1) * 2,))[:2 * total].reshape(-1, 2).copy()
+    finally:
+        _capi.lib().mvgx_host_free(out)
+    res = {}
+    for p in range(len(pairs)):
+        lo, hi = int(ms[p]), int(ms[p + 1])
+        if hi > lo:
+            res[(int(pairs[p, 0]), int(pairs[p, 1]))] = ij[lo:hi]
+    return res, st

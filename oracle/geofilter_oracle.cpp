@@ -699,3 +699,44 @@ void port_five_point(const double* b1, const double* b2, double* Es_out, int* n_
   for (int m = 0; m < *n_out; ++m) std::memcpy(Es_out + 9 * m, out[m].f, sizeof(out[m].f));
 }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Guided matching (test infrastructure like the rest of this file): restatement of
+//   /root/reference/src/openMVG/robust_estimation/guided_matching.hpp:178-227 (the Regions overload the functors call) with
+//   EpipolarDistanceError (multiview/solver_fundamental_kernel.cpp:157-166, kind 0) or AsymmetricError (solver_homography_kernel.hpp:59-63,
+//   kind 1), distanceRatio<double> (:68-112) and L2<uint8_t> (matching/metric.hpp:55-93) for ONE image pair.
+// Sums as the reference's build forms them: F x~ = (F_i0 x0 + F_i1 x1) + F_i2 (Eigen's homogeneous product), the three-element dot
+// product c0 + (c1 + c2) (Eigen's unrolled reduction), no fused multiply-add (this file is compiled with -ffp-contract=off).
+// Pinned to the compiled reference through ref_guided_match (oracle/ref_shim_geofilter.cpp) in tests/test_guided_matching.py.
+// out_ij: capacity 2 nI; returns the number of matches (ascending i).
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" uint64_t port_guided_match(int kind, const double* M, const double* xyI, const uint8_t* descI, uint64_t nI, const double* xyJ,
+                                       const uint8_t* descJ, uint64_t nJ, uint32_t desc_bytes, double error_th, double dist_ratio, uint32_t* out_ij) {
+  uint64_t n_out = 0;
+  if (!(error_th < std::numeric_limits<double>::infinity())) return 0;
+  for (uint64_t i = 0; i < nI; ++i) {
+    const double x0 = xyI[2 * i], x1 = xyI[2 * i + 1];
+    const double v0 = (M[0] * x0 + M[1] * x1) + M[2], v1 = (M[3] * x0 + M[4] * x1) + M[5], v2 = (M[6] * x0 + M[7] * x1) + M[8];
+    double bd = std::numeric_limits<double>::max(), sbd = bd;
+    uint64_t idx = 0;
+    for (uint64_t j = 0; j < nJ; ++j) {
+      const double y0 = xyJ[2 * j], y1 = xyJ[2 * j + 1];
+      double err;
+      if (kind == 0) {
+        const double dt = v0 * y0 + (v1 * y1 + v2);
+        err = (dt * dt) / (v0 * v0 + v1 * v1);
+      } else {
+        const double dx = y0 - v0 / v2, dy = y1 - v1 / v2;
+        err = dx * dx + dy * dy;
+      }
+      if (!(err < error_th)) continue;
+      int d = 0;
+      for (uint32_t k = 0; k < desc_bytes; ++k) { const int t = (int)descI[i * desc_bytes + k] - (int)descJ[j * desc_bytes + k]; d += t * t; }
+      const double dist = (double)d;
+      if (dist < bd) { idx = j; sbd = bd; bd = dist; }
+      else if (dist < sbd) sbd = dist;
+    }
+    if (sbd != std::numeric_limits<double>::max() && bd < dist_ratio * sbd) { out_ij[2 * n_out] = (uint32_t)i; out_ij[2 * n_out + 1] = (uint32_t)idx; ++n_out; }
+  }
+  return n_out;
+}

@@ -348,3 +348,34 @@ uint64_t ref_geofilter_container_eo(const float* feat_xy, const uint8_t* descs, 
                                                                                 n_pairs, precision, max_iterations, guided, distance_ratio, 0.0, sink, user, focal);
 }
 }  // extern "C"
+
+// Guided matching: the reference's own template (robust_estimation/guided_matching.hpp:178-227, the Regions overload that
+// {F,H,E}_ACRobust.hpp's Geometry_guided_matching call) for ONE image pair. cam = nullptr on both sides: the positions are compared as
+// they are stored (SIOPointFeature holds floats: pass positions that are exact in float). kind 0: EpipolarDistanceError, 1: AsymmetricError.
+// out_ij: capacity 2 nI; returns the number of matches.
+#include "openMVG/robust_estimation/guided_matching.hpp"
+#include "openMVG/multiview/solver_fundamental_kernel.hpp"
+#include "openMVG/multiview/solver_homography_kernel.hpp"
+extern "C" uint64_t ref_guided_match(int kind, const double* M, const float* xyI, const uint8_t* descI, uint64_t nI, const float* xyJ, const uint8_t* descJ,
+                                     uint64_t nJ, double error_th, double dist_ratio, uint32_t* out_ij) {
+  auto make = [](const float* xy, const uint8_t* d, uint64_t n) {
+    auto r = std::make_shared<features::SIFT_Regions>();
+    r->Features().resize(n);
+    r->Descriptors().resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      r->Features()[i] = features::SIOPointFeature(xy[2 * i], xy[2 * i + 1], 1.f, 0.f);
+      std::memcpy(r->Descriptors()[i].data(), d + i * 128, 128);
+    }
+    return r;
+  };
+  const auto rI = make(xyI, descI, nI), rJ = make(xyJ, descJ, nJ);
+  Mat3 mod;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mod(r, c) = M[3 * r + c];
+  matching::IndMatches out;
+  if (kind == 0)
+    geometry_aware::GuidedMatching<Mat3, openMVG::fundamental::kernel::EpipolarDistanceError>(mod, nullptr, *rI, nullptr, *rJ, error_th, dist_ratio, out);
+  else
+    geometry_aware::GuidedMatching<Mat3, openMVG::homography::kernel::AsymmetricError>(mod, nullptr, *rI, nullptr, *rJ, error_th, dist_ratio, out);
+  for (size_t k = 0; k < out.size(); ++k) { out_ij[2 * k] = out[k].i_; out_ij[2 * k + 1] = out[k].j_; }
+  return out.size();
+}

@@ -982,3 +982,39 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
                                 C.c_uint64(len(keys)), C.c_double(precision), C.c_uint32(max_iterations), C.c_int(1 if guided else 0),
                                 C.c_double(ratio), C.c_double(k1), cb, None)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# guided matching (robust_estimation/guided_matching.hpp:178-227): the restatement and the reference's own template, one image pair
+# ---------------------------------------------------------------------------------------------------------------------------------
+def port_guided_match(kind, M, xyI, descI, xyJ, descJ, error_th, dist_ratio):
+    """oracle/geofilter_oracle.cpp::port_guided_match -> (m, 2) uint32 (i, j); error_th and dist_ratio as the functors pass them (squared)"""
+    L = port()
+    xyI = np.ascontiguousarray(xyI, np.float64).reshape(-1, 2); xyJ = np.ascontiguousarray(xyJ, np.float64).reshape(-1, 2)
+    descI = np.ascontiguousarray(descI, np.uint8); descJ = np.ascontiguousarray(descJ, np.uint8)
+    nb = descI.shape[1] if descI.ndim == 2 and len(descI) else (descJ.shape[1] if descJ.ndim == 2 and len(descJ) else 128)
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((max(len(xyI), 1), 2), np.uint32)
+    L.port_guided_match.restype = C.c_uint64
+    n = L.port_guided_match(C.c_int(kind), M.ctypes.data_as(C.c_void_p), xyI.ctypes.data_as(C.c_void_p), descI.ctypes.data_as(C.c_void_p), C.c_uint64(len(xyI)),
+                            xyJ.ctypes.data_as(C.c_void_p), descJ.ctypes.data_as(C.c_void_p), C.c_uint64(len(xyJ)), C.c_uint32(nb), C.c_double(error_th),
+                            C.c_double(dist_ratio), out.ctypes.data_as(C.c_void_p))
+    return out[:int(n)].copy()
+
+
+def ref_guided_match(kind, M, xyI, descI, xyJ, descJ, error_th, dist_ratio):
+    """the reference's GuidedMatching<Mat3, EpipolarDistanceError | AsymmetricError> on SIFT_Regions built from the arrays (128-byte
+    descriptors; positions must be exact in float: the regions store floats) -> (m, 2) uint32"""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    xI = np.ascontiguousarray(xyI, np.float32).reshape(-1, 2); xJ = np.ascontiguousarray(xyJ, np.float32).reshape(-1, 2)
+    assert np.array_equal(xI.astype(np.float64), np.asarray(xyI, np.float64).reshape(-1, 2)) and np.array_equal(xJ.astype(np.float64), np.asarray(xyJ, np.float64).reshape(-1, 2))
+    descI = np.ascontiguousarray(descI, np.uint8).reshape(-1, 128); descJ = np.ascontiguousarray(descJ, np.uint8).reshape(-1, 128)
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((max(len(xI), 1), 2), np.uint32)
+    _refgeo.ref_guided_match.restype = C.c_uint64
+    n = _refgeo.ref_guided_match(C.c_int(kind), M.ctypes.data_as(C.c_void_p), xI.ctypes.data_as(C.c_void_p), descI.ctypes.data_as(C.c_void_p), C.c_uint64(len(xI)),
+                                 xJ.ctypes.data_as(C.c_void_p), descJ.ctypes.data_as(C.c_void_p), C.c_uint64(len(xJ)), C.c_double(error_th), C.c_double(dist_ratio),
+                                 out.ctypes.data_as(C.c_void_p))
+    return out[:int(n)].copy()

@@ -300,4 +300,5 @@ extern "C" int mvgx_comm_unique_id(void* out) { return mvgx::rccl_unique_id(out)
 #include "mvgx_ba_multi.hip"
 #include "mvgx_bruteforce.hip"
 #include "mvgx_geofilter.hip"
+#include "mvgx_guided.hip"
 #endif  // HIPEMU_NO_PRODUCT
