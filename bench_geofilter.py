@@ -45,7 +45,7 @@ def valu_cycles_per_iteration(model):
 
 def _at_least_a_second(ref_fn, sub):
     """the reference on `sub`, repeated until a second of CPU time has been measured (a 0.01 s sample is noise); returns the first
-    result with "seconds" = the mean over the repetitions and "repetitions""""
+    result with its "seconds" replaced by the mean over the repetitions, plus the number of "repetitions" made"""
     ref = ref_fn(sub)
     total, reps = ref["seconds"], 1
     while total < 1.0 and reps < 2000:
