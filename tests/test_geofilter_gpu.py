@@ -104,4 +104,5 @@ def test_adapter_specialisation_against_the_reference_template(guided):
     want = _oracle.geofilter_container("reference", feats, wh, putative, guided=guided, ratio=0.8, descs=descs)
     got = _oracle.geofilter_container("adapter", feats, wh, putative, guided=guided, ratio=0.8, descs=descs)
     differing = [k for k in set(want) | set(got) if k not in want or k not in got or not np.array_equal(want[k], got[k])]
-    assert len(want) > 100 and len(differing) <= 2, (len(want), len(got), differing[:5])
+    from tests import _geofilter_cases as gc
+    assert len(want) > 100 and len(differing) <= gc.allowed_differing(len(want), "f"), (len(want), len(got), differing[:5])
