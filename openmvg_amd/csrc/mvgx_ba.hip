@@ -193,6 +193,7 @@ struct SpSys {
   // look-ahead schedule (ba_sparse_plan.h): column of a slot; per tile column the level-before contributions to its diagonal tile
   const int32_t *slot_col = nullptr, *pre_start = nullptr, *pre_slot = nullptr, *pre_col = nullptr;
   const int32_t* bs_rec = nullptr;    // nT x 16: what a workgroup of the reverse sweep needs to start, per position in f_cols (ba_sparse_plan.h)
+  unsigned* z_flag = nullptr;         // nT: the solve (epoch) whose z_k is in s.z - the one-launch reverse sweep (sp_backsolve_all_kernel)
   double* u_scratch = nullptr;        // partial sums of the U tasks with split contributor lists: 256 doubles per chunk
   unsigned* u_counter = nullptr;      // arrivals per split group (left at zero by the last arrival)
 };
@@ -2362,6 +2363,97 @@ __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
   sp_backsolve_col(s, f0 + (int)blockIdx.x, w);
 }
 
+// The WHOLE reverse sweep as one launch (round 5): workgroup b takes the column at position nT - 1 - b of f_cols - the root first - so every
+// column a workgroup waits for belongs to a workgroup with a SMALLER index: dispatched earlier, resident or finished, whatever else occupies
+// the device (no co-residency assumption, no deadlock). A workgroup fetches everything that does not depend on the solution (its record, the
+// inverse, the rhs strip, the tiles below) at once, then waits for the z of the rows it needs - a word per column holding the number of the
+// solve whose z it carries, written after the values with device-scope release, polled with device-scope acquire - and only then loads
+// those 64 doubles per entry. A level of the sweep then costs one flag hand-over and one trip to memory for z (~3.5 us) instead of a launch,
+// its drain and three trips (10 us). Same sums in the same order as sp_backsolve_col.
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned flag_load_acquire(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store_release(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+#else   // the HIP emulation runs the workgroups of a launch one after the other, in index order: a flag is always set when it is read
+__device__ __forceinline__ unsigned flag_load_acquire(const unsigned* p) { return *p; }
+__device__ __forceinline__ void flag_store_release(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ void spin_pause() {}
+#endif
+constexpr int kBsPrefetch = 4;   // entries whose tiles a workgroup holds in registers while it waits
+__global__ __launch_bounds__(256) void sp_backsolve_all_kernel(SpSys s, unsigned epoch, int* fail) {
+  __shared__ double w[64];
+  __shared__ int give_up;
+  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3, lane = tid & 63;
+  const int f = s.nT - 1 - (int)blockIdx.x;
+  const int32_t* __restrict__ rec = s.bs_rec + (size_t)f * 16;
+  const int k = rec[0], rhs_slot = rec[1], n = rec[2], e0 = rec[3];
+  const double* __restrict__ li = s.Linv + (size_t)k * 4096 + c * 64 + part * 16;
+  double lv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lv[q] = li[q];
+  const double yk = part == 0 ? s.L[(size_t)rhs_slot * 4096 + c * 64] : 0.0;
+  double tv[kBsPrefetch][16];
+#pragma unroll
+  for (int i = 0; i < kBsPrefetch; ++i)
+    if (i < n) {   // (uniform)
+      const double* __restrict__ tile = s.L + (size_t)rec[4 + 2 * i] * 4096 + c * 64 + part * 16;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tv[i][q] = tile[q];
+    }
+  // wait for the rows this column needs: thread i of the first wave polls entry i (the lists beyond the record's six inline entries
+  // come from bs_row); bounded - a flag that never comes (it cannot, by construction) ends the solve with the failure word, not a hang
+  if (tid == 0) give_up = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + tid;
+    if (tid < 64 && i < n) {
+      const int row = i < mvgx_sparse::kBsInline ? rec[5 + 2 * i] : s.bs_row[e0 + i];
+      int spins = 0;
+      while (flag_load_acquire(s.z_flag + row) != epoch) {
+        spin_pause();
+        if (++spins > (1 << 22)) { give_up = 1; break; }
+      }
+    }
+  }
+  __syncthreads();
+  if (give_up) { if (tid == 0) atomicExch(fail, 3); return; }   // (uniform)
+  __threadfence();   // acquire on behalf of every thread: the z values read below were written before the flags seen above
+  double v = 0;
+#pragma unroll
+  for (int i = 0; i < kBsPrefetch; ++i)
+    if (i < n) {
+      const double* zi = s.z + (size_t)rec[5 + 2 * i] * 64 + part * 16;
+      double zv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zv[q] = __builtin_nontemporal_load(zi + q);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += tv[i][q] * zv[q];
+    }
+  for (int i = kBsPrefetch; i < n; ++i) {   // (rare: more than four tiles below the column)
+    const int slot = i < mvgx_sparse::kBsInline ? rec[4 + 2 * i] : s.bs_slot[e0 + i], row = i < mvgx_sparse::kBsInline ? rec[5 + 2 * i] : s.bs_row[e0 + i];
+    const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
+    const double* zi = s.z + (size_t)row * 64 + part * 16;
+    double t2[16], z2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t2[q] = tile[q]; z2[q] = __builtin_nontemporal_load(zi + q); }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += t2[q] * z2[q];
+  }
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  if (part == 0) w[c] = yk - v;
+  __syncthreads();
+  double u = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) u += lv[q] * w[part * 16 + q];
+  u += __shfl_xor(u, 1);
+  u += __shfl_xor(u, 2);
+  if (part == 0) { s.z[(size_t)k * 64 + c] = u; __threadfence(); }   // the value is visible device-wide before the column counts as solved
+  __syncthreads();
+  if (tid == 0) flag_store_release(s.z_flag + k, epoch);
+  (void)lane;
+}
+
 // The top of the elimination tree is a chain - one tile column per level, each depending on all the ones above it - and its part
 // of the reverse sweep ran as one launch per column, each a series of dependent trips to L2 (column id, list bounds, (slot, row)
 // lists, tiles + z, store): ~10 us per level, 12 levels at C5. Here ONE workgroup walks the chain from the root down: the column
@@ -3174,6 +3266,11 @@ struct mvgx_ba_ctx {
   // 0.249): taking a contribution inside the factor workgroup costs the 6 us the separate task launch did, and the U tasks that rebuild their
   // strips of L do six times the MFMA work at a quarter of the occupancy. Off by default; kept as the cross-check of the schedule (tests).
   bool lookahead = false;
+  // reverse sweep of the block-sparse solve in ONE launch, columns handed over through device-scope flags (MVGX_BA_BACKSOLVE_FLAGS=1). Built and
+  // measured in round 5 (call r5_16): bit-identical, and SLOWER - C5 solve 0.474 against 0.409 ms, C3 0.246 against 0.245: a device-scope release on
+  // this eight-XCD part writes the producer's whole L2 back, a hand-over costs ~15 us where a launch boundary costs 10. Off by default.
+  bool bs_one_launch = false;
+  unsigned bs_epoch = 0;       // number of the solve whose solution the flags of that launch announce
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve
   bool fold_candidate = true, candidate_cost_done = false;   // the candidate and its cost from the back-substitution pass of the point groups (compute_step)
@@ -3445,6 +3542,11 @@ int factor_and_solve_sparse(mvgx_ba_ctx* c) {
     if (nu) hipLaunchKernelGGL(sp_gemm_kernel<true>, dim3((nu + 3) / 4), dim3(256), 0, c->stream, d.sp, pl.u_start[l], nu);
   }
   BA_LAUNCH_CHECK();
+  if (c->bs_one_launch && pl.nT > 0) {   // the whole reverse sweep as one launch, columns handed over through flags (sp_backsolve_all_kernel)
+    c->bs_epoch += 1;
+    if (c->bs_epoch == 0) c->bs_epoch = 1;   // (0 is the value the flags start from)
+    hipLaunchKernelGGL(sp_backsolve_all_kernel, dim3(pl.nT), dim3(256), 0, c->stream, d.sp, c->bs_epoch, d.fail);
+  } else {
   int l_top = pl.n_levels - 1;
   if (c->bs_chain_levels >= 2) {   // the chain at the top of the tree: one workgroup, one launch
     const int l0 = pl.n_levels - c->bs_chain_levels;
@@ -3453,6 +3555,7 @@ int factor_and_solve_sparse(mvgx_ba_ctx* c) {
   }
   for (int l = l_top; l >= 0; --l)
     hipLaunchKernelGGL(sp_backsolve_kernel, dim3(pl.f_start[l + 1] - pl.f_start[l]), dim3(256), 0, c->stream, d.sp, pl.f_start[l]);
+  }
   if (c->fold_cand_now)   // (compute_step: this step's back-substitution forms the candidate - the gather and the camera half of the step's sums are one launch)
     hipLaunchKernelGGL(ba_step_scalars_cam_kernel, dim3((d.N + 255) / 256), dim3(256), 0, c->stream, d, 1.0 / c->radius, d.part, 1);
   else
@@ -3645,6 +3748,9 @@ int setup_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>
       int32_t* bs_rec = nullptr;
       if ((rc = dev_upload(c->pool, &bs_rec, pl.bs_rec, c->stream))) return rc;
       s.bs_rec = bs_rec;
+      if ((rc = dev_alloc(c->pool, &s.z_flag, (size_t)std::max(pl.nT, 1)))) return rc;
+      MVGX_HIP(hipMemsetAsync(s.z_flag, 0, (size_t)std::max(pl.nT, 1) * sizeof(unsigned), c->stream));
+      c->bs_epoch = 0;
     }
     {   // the chain at the top: as many single-column levels as the kernel's LDS tables hold (MVGX_BA_BACKSOLVE_CHAIN=0: none)
       const char* env = getenv("MVGX_BA_BACKSOLVE_CHAIN");
@@ -4116,6 +4222,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   if (const char* env = getenv("MVGX_BA_SEPARATE_COST")) c->fold_candidate = atoi(env) == 0;
   if (const char* env = getenv("MVGX_BA_CHAIN_FUSE")) c->chain_fuse_max_tasks = atoi(env);
   if (const char* env = getenv("MVGX_BA_LOOKAHEAD")) c->lookahead = atoi(env) != 0;
+  if (const char* env = getenv("MVGX_BA_BACKSOLVE_FLAGS")) c->bs_one_launch = atoi(env) != 0;
   tick("page-locked scalars");
   c->h_fail = reinterpret_cast<int*>(c->h_scalars + kSCount);
   Dev& d = c->d;
