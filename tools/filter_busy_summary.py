@@ -6,11 +6,11 @@
 Usage: filter_busy_summary.py <pmc_kernels.json> <kernel_trace.csv>"""
 import csv, json, sys
 j = json.load(open(sys.argv[1]))
-name = [k for k in j["per_kernel"] if k.startswith("l2_filter_kernel")][0]
+name = [k for k in j["per_kernel"] if k.startswith("l2_filter")][0]   # l2_filter_kernel or l2_filter16_kernel
 c = j["per_kernel"][name]
 dur_ns = 0; n = 0
 for r in csv.DictReader(open(sys.argv[2])):
-    if "l2_filter_kernel" in r["Kernel_Name"]:
+    if "l2_filter" in r["Kernel_Name"]:
         dur_ns += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); n += 1
 cycles = c["GRBM_GUI_ACTIVE"] / 8.0
 busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0)

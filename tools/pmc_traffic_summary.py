@@ -20,7 +20,7 @@ for f in files:
         disp[name].add(r["Dispatch_Id"])
 out = {"command": command, "image_pairs": n_pairs,
        "per_kernel_sums": {k: dict(v, _dispatches=len(disp[k])) for k, v in sums.items()}}
-fk = [k for k in sums if k.startswith("l2_filter_kernel")]
+fk = [k for k in sums if k.startswith("l2_filter")]   # l2_filter_kernel (32x32x32) or l2_filter16_kernel (16x16x64, round 5)
 if fk:
     s = sums[fk[0]]
     rd, wr = s["TCC_EA0_RDREQ_sum"] * 64.0 * 2.0, s["TCC_EA0_WRREQ_sum"] * 64.0
