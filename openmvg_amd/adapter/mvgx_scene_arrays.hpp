@@ -203,7 +203,10 @@ inline int bind_context(int device, const mvgx_ba_problem& prob, FlatScene& fs, 
     mvgx_ba_destroy(ctx); ctx = nullptr;
   }
   if (ctx) {
-    rc = mvgx_ba_update(ctx, &prob);
+    // (a scene with other counts than the kept structure cannot have its structure - no need to fingerprint a million observations
+    // to learn that; in the reject loop every call after the first erasure takes this way straight to the subset route)
+    const bool counts_differ = ks && (prob.n_obs != ks->obs_pose.size() || prob.n_points != ks->lm_key.size());
+    rc = counts_differ ? MVGX_ERR_STRUCTURE : mvgx_ba_update(ctx, &prob);
     if (rc == MVGX_OK) {
       context_cache().reused.fetch_add(1);
       bc.route = "mvgx_ba_update (context kept)";
