@@ -89,6 +89,7 @@ struct MatchParams {
   const uint32_t* img_neven;       // rows of even squared norm per image (slots of a parity half are filled in rank order)
   const uint2* pairs;              // batch-local (I, J)
   const uint2* work;               // (batch-local pair index, first query tile)
+  const uint4* work8h;             // ... for l2_filter16h_kernel: one record per 8 query tiles (256 query slots)
   const uint4* work8;              // the same items as 32-byte records for l2_filter16_kernel: (pair, first query tile, tileI0, tileJ0), (ntI, ntJpad, 0, 0)
   uint32_t n_work;
   uint32_t* best;                  // [batch pairs][qstride], indexed by query SLOT: original index in I or kNoMatch
@@ -261,6 +262,20 @@ __device__ __forceinline__ void stage_window_glds_asm(char* buf, const int8_t* _
     glds16_asm(gtiles + off + lane * 16, __builtin_amdgcn_readfirstlane(lds0 + off));
   }
   glds4_asm(grconst + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds0 + kWinTiles * kTileBytes + wave * 256));
+}
+
+// A HALF window = 4 tiles (16 KiB) + their cinit (512 B) for l2_filter16h_kernel: every wave moves a quarter of each tile, waves 0 and 1 half of the
+// constants each.
+constexpr int kHalfTiles = kWinTiles / 2;
+constexpr int kHalfStageBytes = kHalfTiles * kTileBytes + kHalfTiles * kTileRows * 4;  // 16384 + 512
+__device__ __forceinline__ void stage_half_glds_asm(char* buf, const int8_t* __restrict__ gtiles, const int* __restrict__ grconst, int wave, int lane) {
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)buf;
+#pragma unroll
+  for (int i = 0; i < kHalfTiles; ++i) {
+    const int off = i * kTileBytes + wave * 1024;
+    glds16_asm(gtiles + off + lane * 16, __builtin_amdgcn_readfirstlane(lds0 + off));
+  }
+  if (wave < 2) glds4_asm(grconst + wave * 64 + lane, __builtin_amdgcn_readfirstlane(lds0 + kHalfTiles * kTileBytes + wave * 256));
 }
 
 // LDS-DMA through the builtin (the compiler tracks it, and drains it before any later ds_read it cannot
@@ -910,6 +925,178 @@ __global__ __launch_bounds__(256, 2) void l2_filter16_kernel(MatchParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// l2_filter16h (variant 4, "filter_shape" 17; round 5): l2_filter16_kernel for THREE workgroups per CU. At two workgroups per CU (236 VGPRs, 66 KiB)
+// the matrix pipe is 74.5 % busy: a workgroup lives 49 us at 2 000 descriptors of which ~12 are not MFMA stream (start: record -> query fragments +
+// first window; eight window barriers; the four-group merge), and with two waves per SIMD nothing runs beside them. Here a wave keeps TWO query
+// tiles (4 blocks of 16: 32 VGPRs of fragments, half the running maxima) and the database streams through HALF windows of 4 tiles (2 x 16.5 KiB of
+// LDS per workgroup): <= 168 VGPRs and 33 KiB, three workgroups per CU. The Q-class of the partition stays the 8-tile window (the maxima are
+// folded every second half window), so cells, code word and verify stage are those of the other filter kernels. A workgroup owns 256 query slots:
+// its work records step by 8 query tiles (work8h), the verify stage keeps its 512-slot items.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNQh = 2;                 // query tiles per wave
+constexpr int kNBh = 2 * kNQh;          // query blocks of 16 per wave
+constexpr int kBlockQTilesH = kWaves * kNQh;   // 8 tiles = 256 queries per workgroup
+__global__ __launch_bounds__(256, 3) void l2_filter16h_kernel(MatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x kHalfStageBytes
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g4 = lane >> 4, par = g4 & 1;
+
+  const uint32_t w = xcd_remap(blockIdx.x, gridDim.x);
+  const uint4 wr0 = p.work8h[2 * (size_t)w], wr1 = p.work8h[2 * (size_t)w + 1];
+  const uint32_t pair = wr0.x;
+  const uint32_t tileI0 = wr0.z, tileJ0 = wr0.w;
+  const uint32_t ntJpad = wr1.y;
+  const int ntI = (int)wr1.x;
+  const int nhalf = (ntI + kHalfTiles - 1) / kHalfTiles;
+  const uint32_t qt0 = wr0.y + (uint32_t)wave * kNQh;
+
+  const int lane_chunk = ((lane >> 5) * 64 + ((lane >> 4) & 1) * 32 + (lane & 15)) * 16;
+  v4i b[kNBh][2];
+  {
+    const int8_t* qsrc = p.tiles + (size_t)(tileJ0 + qt0) * kTileBytes + lane_chunk;
+#pragma unroll
+    for (int n = 0; n < kNBh; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b[n][ks] = *reinterpret_cast<const v4i*>(qsrc + (n >> 1) * kTileBytes + (n & 1) * 256 + ks * 2048);
+  }
+  const int8_t* gI = p.tiles + (size_t)tileI0 * kTileBytes;
+  const int* gC = p.cinit + (size_t)tileI0 * kTileRows;
+
+  uint32_t qperm[kNBh];
+  int qn[kNBh];
+#pragma unroll
+  for (int n = 0; n < kNBh; ++n) {
+    const bool inb = lane < 16 && qt0 + (uint32_t)(n >> 1) < ntJpad;
+    const size_t qs = (size_t)tileJ0 * kTileRows + (qt0 + (uint32_t)(n >> 1)) * kTileRows + (uint32_t)(n & 1) * 16 + (uint32_t)(lane & 15);
+    qperm[n] = inb ? p.perm[qs] : kNoMatch;
+    qn[n] = inb ? p.qnorm[qs] : 0;
+  }
+
+  int TP[kNBh][4], TW[kNBh][4], Q1[kNBh], Q2[kNBh], Qg[kNBh];
+#pragma unroll
+  for (int n = 0; n < kNBh; ++n) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { TP[n][c] = kNegInit; TW[n][c] = kNegInit; }
+    Q1[n] = kNegInit; Q2[n] = kNegInit; Qg[n] = 0;
+  }
+
+  stage_half_glds_asm(smem, gI, gC, wave, lane);
+#pragma unroll
+  for (int n = 0; n < kNBh; ++n) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(b[n][ks]));
+    asm volatile("" : "+v"(qperm[n]), "+v"(qn[n]));
+  }
+
+  for (int hw = 0; hw < nhalf; ++hw) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    char* buf = smem + (hw & 1) * kHalfStageBytes;
+    char* nbuf = smem + ((hw + 1) & 1) * kHalfStageBytes;
+    if (hw + 1 < nhalf)
+      stage_half_glds_asm(nbuf, gI + (size_t)(hw + 1) * kHalfTiles * kTileBytes, gC + (hw + 1) * kHalfTiles * kTileRows, wave, lane);
+
+    const int nt = min(kHalfTiles, ntI - hw * kHalfTiles);
+    const char* wb = buf + lane_chunk;
+    const char* wc = buf + kHalfTiles * kTileBytes + g4 * 16;
+    // two accumulator sets of four query blocks ping-pong over the 16-row blocks: the eight MFMAs of a block are issued, the eight v_max3 of
+    // the block before run in their shadow. accB starts as the neutral element of max: its first epilogue is a no-op
+    v4i accA[4], accB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accB[i] = v4i{kNegInit, kNegInit, kNegInit, kNegInit};
+#define MVGX_GROUPH(ACC, A, CV)                                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+    ACC[i_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], b[i_][0], CV, 0, 0, 0);                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+    ACC[i_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], b[i_][1], ACC[i_], 0, 0, 0);
+#define MVGX_EPIH(ACC, BLK)                                                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+    TW[i_][2 * (BLK)] = max(max(TW[i_][2 * (BLK)], ACC[i_][0]), ACC[i_][1]);                                \
+    TW[i_][2 * (BLK) + 1] = max(max(TW[i_][2 * (BLK) + 1], ACC[i_][2]), ACC[i_][3]);                        \
+  }
+#define MVGX_MIXH(NDS)                                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);                                                        \
+    if (i_ < (NDS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+  }
+    v4i a0[2], a1[2], c0, c1;
+    a0[0] = *reinterpret_cast<const v4i*>(wb);
+    a0[1] = *reinterpret_cast<const v4i*>(wb + 2048);
+    c0 = *reinterpret_cast<const v4i*>(wc);
+    for (int t = 0; t < nt; ++t) {
+      const int tn = min(t + 1, nt - 1);   // the fetch past the last tile re-reads it (no branch around the loads)
+      // block 0 of tile t (accA); the maxima of the block before (block 1, accB) folded beside it
+      MVGX_GROUPH(accA, a0, c0)
+      a1[0] = *reinterpret_cast<const v4i*>(wb + t * kTileBytes + 256);
+      a1[1] = *reinterpret_cast<const v4i*>(wb + t * kTileBytes + 256 + 2048);
+      c1 = *reinterpret_cast<const v4i*>(wc + t * (kTileRows * 4) + 64);
+      MVGX_EPIH(accB, 1)
+      MVGX_MIXH(3)
+      // block 1 of tile t (accB); block 0's maxima folded
+      MVGX_GROUPH(accB, a1, c1)
+      a0[0] = *reinterpret_cast<const v4i*>(wb + tn * kTileBytes);
+      a0[1] = *reinterpret_cast<const v4i*>(wb + tn * kTileBytes + 2048);
+      c0 = *reinterpret_cast<const v4i*>(wc + tn * (kTileRows * 4));
+      MVGX_EPIH(accA, 0)
+      MVGX_MIXH(3)
+    }
+    MVGX_EPIH(accB, 1)   // drain: block 1 of the half window's last tile
+#undef MVGX_GROUPH
+#undef MVGX_EPIH
+#undef MVGX_MIXH
+    if ((hw & 1) || hw + 1 == nhalf) {   // (uniform) an 8-tile window is complete: its class maxima join the run-long ones, their maximum is the window maximum
+      const int win = hw >> 1;
+#pragma unroll
+      for (int n = 0; n < kNBh; ++n) {
+        const int v = max(max(max(TW[n][0], TW[n][1]), TW[n][2]), TW[n][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { TP[n][c] = max(TP[n][c], TW[n][c]); TW[n][c] = kNegInit; }
+        const bool better = v > Q1[n];
+        Q2[n] = better ? Q1[n] : max(Q2[n], v);
+        Qg[n] = better ? win : Qg[n];
+        Q1[n] = better ? v : Q1[n];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int n = 0; n < kNBh; ++n) {
+    int p1 = kNegInit, p2 = kNegInit, pc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int v = TP[n][c];
+      const bool better = v > p1;
+      p2 = better ? p1 : max(p2, v);
+      pc = better ? c : pc;
+      p1 = better ? v : p1;
+    }
+    int W1 = 2 * p1 - par, V2 = max(2 * p2 - par, 2 * Q2[n] - par);
+    int code = (4 * (pc >> 1) + 2 * (g4 >> 1) + (pc & 1)) | (par << 3) | (Qg[n] << 4);
+#pragma unroll
+    for (int x = 16; x <= 32; x <<= 1) {
+      const int o1 = __shfl_xor(W1, x), o2 = __shfl_xor(V2, x), oc = __shfl_xor(code, x);
+      const bool mine = W1 > o1;
+      V2 = mine ? max(V2, o1) : max(o2, W1);
+      code = mine ? code : oc;
+      W1 = mine ? W1 : o1;
+    }
+    const uint32_t q = (qt0 + (uint32_t)(n >> 1)) * kTileRows + (uint32_t)(n & 1) * 16 + (uint32_t)(lane & 15);
+    if (lane < 16 && qt0 + (uint32_t)(n >> 1) < ntJpad) {
+      const bool valid = qperm[n] != kNoMatch;
+      const int nq = qn[n];
+      const int d0 = nq - W1, d1ub = nq - V2;
+      const bool cand = valid && (__int2float_rn(d0) < __fmul_rn(p.ratio_sq, __int2float_rn(d1ub)));
+      const size_t o = (size_t)pair * p.qstride + q;
+      p.best[o] = cand ? (uint32_t)code : kNoMatch;
+      if (cand) p.cd[o] = make_int2(d0, d1ub);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // l2_verify (variant 4, stage 2): finishes the candidates of the filter. Same work items as the filter (a workgroup
 // owns 512 query slots of one pair). 16 lanes per candidate recompute the exact distances of the 16 slots of its
 // (P-class, window, half) cell with v_dot4_i32_i8 on the tile bytes, take the cell's best (must equal d0) and its
@@ -1226,11 +1413,11 @@ struct mvgx_match_ctx {
     hipEvent_t ev_scan = nullptr;     // offsets of the batch are on the host
     hipEvent_t ev_filter = nullptr;   // filter kernel of the batch has finished
     DevBuf<uint2> d_pairs, d_work, d_ij;
-    DevBuf<uint4> d_work8;
+    DevBuf<uint4> d_work8, d_work8h;
     DevBuf<uint32_t> d_best, d_count, d_offsets;
     DevBuf<int2> d_cd;
     PinnedBuf<uint2> hp_pairs, hp_work;
-    PinnedBuf<uint4> hp_work8;
+    PinnedBuf<uint4> hp_work8, hp_work8h;
     PinnedBuf<uint32_t> hp_offsets;
     uint64_t p0 = 0;
     uint32_t nb = 0;
@@ -1449,7 +1636,7 @@ int mvgx_match_destroy(mvgx_match_ctx* c) {
   c->d_row_off.release(); c->d_tile_off.release(); c->d_n.release();
   for (auto& r : c->results) r.ij.release();
   for (auto& sl : c->slot) {
-    sl.d_work8.release(); sl.hp_work8.release();
+    sl.d_work8.release(); sl.hp_work8.release(); sl.d_work8h.release(); sl.hp_work8h.release();
     sl.d_pairs.release(); sl.d_work.release(); sl.d_ij.release(); sl.d_cd.release();
     sl.d_best.release(); sl.d_count.release(); sl.d_offsets.release();
     sl.hp_pairs.release(); sl.hp_work.release(); sl.hp_offsets.release(); sl.hp_ij[0].release(); sl.hp_ij[1].release();
@@ -1477,7 +1664,7 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     MVGX_REQUIRE(value >= 0 && value <= 4, MVGX_ERR_ARG, "variant must be 0..4");
     c->variant = (int)value;
   } else if (!strcmp(key, "filter_shape")) {
-    MVGX_REQUIRE(value == 16 || value == 32, MVGX_ERR_ARG, "filter_shape must be 16 or 32");
+    MVGX_REQUIRE(value == 16 || value == 17 || value == 32, MVGX_ERR_ARG, "filter_shape must be 16, 17 (16x16x64, three workgroups per CU) or 32");
     c->filter_shape = (int)value;
   } else if (!strcmp(key, "stage")) {
     MVGX_REQUIRE(value >= 1 && value <= 3, MVGX_ERR_ARG, "stage must be 1..3");
@@ -1624,7 +1811,10 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     const uint32_t max_blocks_per_pair = std::max<uint32_t>(1, (c->max_tiles_pad + kBlockQTiles - 1) / kBlockQTiles);
     if ((rc = sl.hp_work.ensure((size_t)nb * max_blocks_per_pair))) return rc;
     const bool records = c->variant == 4 && c->filter_shape == 16 && c->stage == 3 && !c->debug_filter;
+    const bool records_h = c->variant == 4 && c->filter_shape == 17 && c->stage == 3 && !c->debug_filter;
     if (records && (rc = sl.hp_work8.ensure((size_t)nb * max_blocks_per_pair * 2))) return rc;
+    if (records_h && (rc = sl.hp_work8h.ensure((size_t)nb * max_blocks_per_pair * 4))) return rc;
+    uint32_t n_work_h = 0;
     uint32_t n_work = 0;
     for (uint32_t k = 0; k < nb; ++k) {
       const uint32_t I = pairs_IJ[2 * (p0 + k)], J = pairs_IJ[2 * (p0 + k) + 1];
@@ -1638,6 +1828,12 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
           sl.hp_work8.p[2 * n_work] = make_uint4(k, qt, c->h_tile_off[I], c->h_tile_off[J]);
           sl.hp_work8.p[2 * n_work + 1] = make_uint4(c->h_ntiles[I], c->h_tile_off[J + 1] - c->h_tile_off[J], 0, 0);
         }
+        if (records_h)
+          for (uint32_t q2 = qt; q2 < std::min(ntJ, qt + (uint32_t)kBlockQTiles); q2 += kBlockQTilesH) {
+            sl.hp_work8h.p[2 * n_work_h] = make_uint4(k, q2, c->h_tile_off[I], c->h_tile_off[J]);
+            sl.hp_work8h.p[2 * n_work_h + 1] = make_uint4(c->h_ntiles[I], c->h_tile_off[J + 1] - c->h_tile_off[J], 0, 0);
+            ++n_work_h;
+          }
         sl.hp_work.p[n_work++] = make_uint2(k, qt);
       }
       st.n_pairs += 1;
@@ -1646,6 +1842,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     if ((rc = sl.d_pairs.ensure(nb))) return rc;
     if ((rc = sl.d_work.ensure(std::max<uint32_t>(n_work, 1)))) return rc;
     if (records && (rc = sl.d_work8.ensure((size_t)std::max<uint32_t>(n_work, 1) * 2))) return rc;
+    if (records_h && (rc = sl.d_work8h.ensure((size_t)std::max<uint32_t>(n_work_h, 1) * 2))) return rc;
     if ((rc = sl.d_best.ensure((size_t)nb * c->qstride))) return rc;
     if (c->variant == 4) {
       if ((rc = sl.d_cd.ensure((size_t)nb * c->qstride))) return rc;
@@ -1658,6 +1855,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
       MVGX_HIP(hipMemcpyAsync(sl.d_work.p, sl.hp_work.p, n_work * sizeof(uint2), hipMemcpyHostToDevice, stream));
     if (n_work && records)
       MVGX_HIP(hipMemcpyAsync(sl.d_work8.p, sl.hp_work8.p, (size_t)n_work * 2 * sizeof(uint4), hipMemcpyHostToDevice, stream));
+    if (n_work_h && records_h)
+      MVGX_HIP(hipMemcpyAsync(sl.d_work8h.p, sl.hp_work8h.p, (size_t)n_work_h * 2 * sizeof(uint4), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(sl.d_count.p, 0, nb * sizeof(uint32_t), stream));
 
     MatchParams mp;
@@ -1666,7 +1865,7 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
     mp.rows_u8 = c->d_rows_view; mp.img_row_off = c->d_row_off.p;
     mp.img_tile_off = c->d_tile_off.p; mp.img_n = c->d_n.p; mp.img_ntiles = c->d_ntiles.p;
     mp.cd = sl.d_cd.p; mp.img_neven = c->d_neven.p; mp.errflag = c->d_err.p;
-    mp.pairs = sl.d_pairs.p; mp.work = sl.d_work.p; mp.work8 = sl.d_work8.p; mp.n_work = n_work;
+    mp.pairs = sl.d_pairs.p; mp.work = sl.d_work.p; mp.work8 = sl.d_work8.p; mp.work8h = sl.d_work8h.p; mp.n_work = n_work;
     mp.best = sl.d_best.p; mp.count = sl.d_count.p; mp.qstride = c->qstride; mp.ratio_sq = ratio_sq;
 
     // filter kernels run one after the other (each fills the device); everything else of batch b-1 runs beside filter b
@@ -1688,6 +1887,8 @@ int run_device(mvgx_match_ctx* c, BatchFeed& feed, float ratio_sq, const BatchSi
         hipLaunchKernelGGL(l2_top2_ratio_kernel<kStageGldsAsm>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->filter_shape == 16 && c->stage == 3 && !c->debug_filter) {
         hipLaunchKernelGGL(l2_filter16_kernel, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
+      } else if (c->filter_shape == 17 && c->stage == 3 && !c->debug_filter) {
+        hipLaunchKernelGGL(l2_filter16h_kernel, dim3(n_work_h), dim3(256), 2 * kHalfStageBytes, stream, mp);
       } else if (c->stage == 1) {
         hipLaunchKernelGGL(l2_filter_kernel<kStageRegs>, dim3(n_work), dim3(256), 2 * kStageBytes, stream, mp);
       } else if (c->stage == 2) {

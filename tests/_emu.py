@@ -98,6 +98,15 @@ __device__ __forceinline__ void stage_window_glds(char* buf, const int8_t* __res
                                                   const int* __restrict__ grconst, int wave, int lane) {
   stage_window_glds_asm(buf, gtiles, grconst, wave, lane);
 }
+constexpr int kHalfTiles = kWinTiles / 2;
+constexpr int kHalfStageBytes = kHalfTiles * kTileBytes + kHalfTiles * kTileRows * 4;
+__device__ __forceinline__ void stage_half_glds_asm(char* buf, const int8_t* __restrict__ gtiles, const int* __restrict__ grconst, int wave, int lane) {
+  for (int i = 0; i < kHalfTiles; ++i) {
+    const int off = i * kTileBytes + wave * 1024;
+    memcpy(buf + off + lane * 16, gtiles + off + lane * 16, 16);
+  }
+  if (wave < 2) memcpy(buf + kHalfTiles * kTileBytes + wave * 256 + lane * 4, grconst + wave * 64 + lane, 4);
+}
 
 """
 

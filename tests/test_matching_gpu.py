@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 # 0 naive check kernel; 1..3 exact top-2 MFMA kernel with the three window-staging forms;
 # 41..43 = variant 4 (filter + verify, the default) with staging form 1..3
+# 73 = staging form 3 with the three-workgroups-per-CU 16x16x64 filter (l2_filter16h_kernel: two query tiles per wave, half windows)
 # 43 = the default since round 5: staging form 3 with the 16x16x64 filter (l2_filter16_kernel); 63 = staging form 3 with the 32x32x32 filter
-VARIANTS = [0, 1, 2, 3, 41, 42, 43, 48, 56, 63]   # 4x: variant 4 with staging form x; 48 / 56: form 3 with the earlier epilogue forms
+VARIANTS = [0, 1, 2, 3, 41, 42, 43, 48, 56, 63, 73]   # 4x: variant 4 with staging form x; 48 / 56: form 3 with the earlier epilogue forms
 
 
 def run_hip(imgs, pairs, ratio, variant, batch_pairs=None):
@@ -26,10 +27,10 @@ def run_hip(imgs, pairs, ratio, variant, batch_pairs=None):
             ctx.set_option("variant", 4)
             ctx.set_option("stage", 3)
             ctx.set_option("debug_filter", variant - 40)
-        elif variant == 63:
+        elif variant in (63, 73):
             ctx.set_option("variant", 4)
             ctx.set_option("stage", 3)
-            ctx.set_option("filter_shape", 32)
+            ctx.set_option("filter_shape", 32 if variant == 63 else 17)
         elif variant >= 40:
             ctx.set_option("variant", 4)
             ctx.set_option("stage", variant - 40)

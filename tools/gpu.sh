@@ -81,7 +81,7 @@ for mode in "$@"; do
       echo "prev $s $(MVGX_LIB_PATH=$R/tools/_build/libmvgx_prev.so python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
     done; done ;;
   matchab)    # the filter kernel on the two MFMA shapes, alternating, headline leg only
-    for rep in 1 2 3; do for shape in 16 32; do
+    for rep in 1 2 3; do for shape in ${SHAPES:-16 32}; do
       python bench.py --filter-shape $shape --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
 import json,sys
 r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
