@@ -453,10 +453,11 @@ def _lookahead_schedules_agree(monkeypatch, sc, iters, emulated):
     from tests import _emu as emu
     out = {}
     for name, env in (("levels", {"MVGX_BA_LOOKAHEAD": "0"}), ("lookahead", {"MVGX_BA_LOOKAHEAD": "1"}),
-                      ("fallback", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "0"}), ("one", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "1"})):
+                      ("fallback", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "0"}), ("one", {"MVGX_BA_LOOKAHEAD": "1", "MVGX_BA_LOOKAHEAD_MAX_PRE": "1"}),
+                      ("flags", {"MVGX_BA_BACKSOLVE_FLAGS": "1"})):   # (the reverse sweep as one launch, columns handed over through flags)
         monkeypatch.setenv("MVGX_BA_SOLVER", "sparse")
         monkeypatch.setenv("MVGX_BA_ND_LEAF_COLS", "64")
-        for k in ("MVGX_BA_LOOKAHEAD", "MVGX_BA_LOOKAHEAD_MAX_PRE"):
+        for k in ("MVGX_BA_LOOKAHEAD", "MVGX_BA_LOOKAHEAD_MAX_PRE", "MVGX_BA_BACKSOLVE_FLAGS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -465,7 +466,7 @@ def _lookahead_schedules_agree(monkeypatch, sc, iters, emulated):
             s = ctx.solve(ba.default_options(max_num_iterations=iters)); info = ctx.solver_info(); prm = ctx.read_params(); ctx.close()
         assert info.sparse == 1 and info.n_levels >= 3
         out[name] = (s.num_iterations, s.num_successful_steps, s.final_cost, s.final_rmse) + tuple(prm)
-    for name in ("lookahead", "fallback", "one"):
+    for name in ("lookahead", "fallback", "one", "flags"):
         a, b = out["levels"], out[name]
         assert a[:4] == b[:4] and all(np.array_equal(x, y) for x, y in zip(a[4:], b[4:])), name
 
