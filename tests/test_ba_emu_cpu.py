@@ -472,7 +472,7 @@ def _lookahead_schedules_agree(monkeypatch, sc, iters, emulated):
 
 
 def test_lookahead_schedule_equals_the_level_by_level_schedule_emulated(monkeypatch):
-    _lookahead_schedules_agree(monkeypatch, synth.ba_scene(n_cams=72, n_points=500, track_len=4, model=3, n_intr_groups=3, seed=71), 2, True)
+    _lookahead_schedules_agree(monkeypatch, synth.ba_scene(n_cams=72, n_points=400, track_len=4, model=3, n_intr_groups=3, seed=71), 1, True)
 
 
 def test_block_sparse_solver_is_the_default_when_the_factor_is_sparse():
