@@ -133,6 +133,40 @@ __device__ __forceinline__ uint32_t uniform_u32(uint32_t* mt, int& idx, int lane
   return (uint32_t)(product >> 32) + a;
 }
 
+// The same two for a sample drawn AHEAD of the iteration that will use it (essential model, see the kernel): such a draw must be
+// revocable, and a twist of the generator's state is not - with may_twist == false a draw that needs one fails instead (nothing changed).
+__device__ __forceinline__ bool mt_try_next(uint32_t* mt, int& idx, int lane, bool may_twist, uint32_t& y) {
+  if (idx >= kMtN) {
+    if (!may_twist) return false;
+    mt_twist(mt, lane); idx = 0;
+  }
+  y = mt[idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return true;
+}
+__device__ __forceinline__ bool uniform_try_u32(uint32_t* mt, int& idx, int lane, uint32_t a, uint32_t b, bool may_twist, uint32_t& out) {
+  const uint32_t urange = b - a;
+  uint32_t y;
+  if (urange == 0xffffffffu) {
+    if (!mt_try_next(mt, idx, lane, may_twist, y)) return false;
+    out = y + a;
+    return true;
+  }
+  const uint32_t range = urange + 1;
+  if (!mt_try_next(mt, idx, lane, may_twist, y)) return false;
+  uint64_t product = (uint64_t)y * range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (0u - range) % range;
+    while (low < threshold) {
+      if (!mt_try_next(mt, idx, lane, may_twist, y)) return false;
+      product = (uint64_t)y * range; low = (uint32_t)product;
+    }
+  }
+  out = (uint32_t)(product >> 32) + a;
+  return true;
+}
+
 // ---- numeric/poly.h:32-75 ----
 __device__ __forceinline__ int solve_cubic(double a, double b, double c, double x[3]) {
   const double eps = 2.220446049250313e-16;
@@ -230,6 +264,7 @@ __device__ __forceinline__ typename PointOf<MODEL>::type load_point(const double
 }
 
 #include "geofilter_five_point.h"
+#include "geofilter_five_point_x4.h"
 
 // The null vector of an 8 x 9 system spread over 36 lanes: lane 9 r0 + c (r0 < 4) holds A[r0][c] in a0 and A[r0 + 4][c] in a1 (the
 // other lanes run along with copies and never win a pivot). Gauss-Jordan elimination with complete pivoting - the pivot is the element
@@ -533,20 +568,26 @@ __global__ __launch_bounds__(256) void geofilter_gather_bearings_kernel(const Ge
 
 constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (20) | the model of the current inlier list (18 words = 9 doubles at 8-byte alignment + 2)
 // the essential model adds the five-point solver's workspace, its up to ten essential matrices and their fundamental matrices
-constexpr int kEssentialScratch = 2 * (five_point::kScratch + 90 + 90);
+// (round 5: four samples are solved side by side - four workspaces, four sets of essential matrices, the fundamental matrices of the one being evaluated)
+constexpr int kAhead = 4;
+constexpr int kEssentialScratch = 2 * (kAhead * five_point::kScratch + kAhead * 90 + 90);
 template <int MODEL> constexpr int wave_scratch_words() { return kWaveScratch + (MODEL == kModelE ? kEssentialScratch : 0); }
 
 // kGlobalTables: the sampling pool and the two log-combinatorial tables of a wave (3 x n words) live in a global scratch block
 // instead of LDS - the class of pairs with more correspondences than a workgroup's LDS holds (one wave per workgroup; the generator,
 // the histogram and the model stay in LDS)
+#ifndef MVGX_GEO_E_WGS
+#define MVGX_GEO_E_WGS 2   // workgroups per CU the essential instantiation is compiled for (1: twice the registers, half the waves)
+#endif
 template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF>
-__global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
                                                                           const uint32_t* __restrict__ mt_init, uint32_t max_iterations,
                                                                           GeoResult* __restrict__ results, uint8_t* __restrict__ mask,
                                                                           uint32_t* __restrict__ table_scratch = nullptr,
-                                                                          const double* __restrict__ bear1 = nullptr, const double* __restrict__ bear2 = nullptr) {
+                                                                          const double* __restrict__ bear1 = nullptr, const double* __restrict__ bear2 = nullptr,
+                                                                          uint32_t ahead = 1) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * WAVES + wave;
@@ -563,8 +604,9 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
   uint32_t* const hist = kGlobalTables ? mt + kMtN : reinterpret_cast<uint32_t*>(logc_k + cap1);
   double* const inlF_lds = reinterpret_cast<double*>(hist + 24);   // the model behind the current inlier list / pool (rarely touched: kept out of registers)
   double* const e_scr = reinterpret_cast<double*>(hist + kWaveScratch);   // essential model: solver workspace | Es[10][9] | Fs[10][9]
-  double* const e_Es = e_scr + five_point::kScratch;
-  double* const e_Fs = e_Es + 90;
+  double* const e_Es4 = e_scr + kAhead * five_point::kScratch;   // the essential matrices of the four samples solved together
+  double* const e_Fs = e_Es4 + kAhead * 90;
+  double* e_Es = e_Es4;                                           // ... of the sample under evaluation
   const uint32_t pidx = order[w];
   const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
   const uint32_t n = P.n;
@@ -600,25 +642,49 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
   unsigned long long geo_acc_[6] = {0, 0, 0, 0, 0, 0};
   long long t_geo_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (unsigned iter = 0; iter < nIter && iter < max_iterations; ++iter) {
-    // ---- sample (rand_sampling.hpp) ----
+  // One sample from the generator and the pool as they stand (rand_sampling.hpp), into s. may_twist == false - a sample drawn AHEAD of
+  // the iteration that will use it (essential model, below): a draw that would twist the generator's state is revoked - index and pool as
+  // they were, s undefined - and false comes back.
+  auto draw_sample = [&](bool may_twist) -> bool {
+    const int idx0 = mt_idx;
     if (ac_mode) {
       if (pool_size >= (uint32_t)kMin) {   // else UniformSample returns false and vec_sample keeps its values
         const uint32_t last = pool_size - 1;
+        uint32_t swapped[kMin];
+        int n_swapped = 0;
+        bool ok = true;
 #pragma unroll
         for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
-          const uint32_t jx = uniform_u32(mt, mt_idx, lane, i, last);
-          const uint32_t vi = pool[i], vj = pool[jx];
-          wave_sync();
-          if (lane == 0) { pool[i] = vj; pool[jx] = vi; }
-          wave_sync();
-          s[i] = vj;
+          uint32_t jx = 0;
+          ok = ok && uniform_try_u32(mt, mt_idx, lane, i, last, may_twist, jx);
+          if (ok) {   // (wave-uniform)
+            const uint32_t vi = pool[i], vj = pool[jx];
+            wave_sync();
+            if (lane == 0) { pool[i] = vj; pool[jx] = vi; }
+            wave_sync();
+            s[i] = vj;
+            swapped[i] = jx; n_swapped = (int)i + 1;
+          }
+        }
+        if (!ok) {   // the exchanges made so far, undone in reverse order
+#pragma unroll
+          for (int i = kMin - 1; i >= 0; --i) {
+            if (i < n_swapped) {
+              const uint32_t vi = pool[i], vj = pool[swapped[i]];
+              wave_sync();
+              if (lane == 0) { pool[i] = vj; pool[swapped[i]] = vi; }
+              wave_sync();
+            }
+          }
+          mt_idx = idx0;
+          return false;
         }
       }
     } else {
       int got = 0;
       while (got < kMin) {
-        const uint32_t cand = uniform_u32(mt, mt_idx, lane, 0, n - 1);
+        uint32_t cand = 0;
+        if (!uniform_try_u32(mt, mt_idx, lane, 0, n - 1, may_twist, cand)) { mt_idx = idx0; return false; }
         bool found = false;
 #pragma unroll
         for (int k = 0; k < kS; ++k) found = found || (k < got && s[k] == cand);
@@ -627,6 +693,59 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
           for (int k = 0; k < kS; ++k) if (k == got) s[k] = cand;
           ++got;
         }
+      }
+    }
+    return true;
+  };
+  // Essential model, SAMPLES AHEAD (round 5). The five-point solver is 85 % of an iteration and the dependent instruction stream of ten
+  // lanes. What the generator and the pool hand out does not depend on the models found - only three events re-seat the sampling: the
+  // switch from the max-consensus warm-up to the a-contrario mode, a better model (the pool becomes its inliers) and the end of the
+  // loop. So up to four samples are drawn in a row (each from the state the one before left: the reference's sequence), solved side by
+  // side - one per 16-lane row, five_point::solve4 - and evaluated in order; after an event the samples not yet used are void: the
+  // generator's index goes back to where the last used sample left it (a sample drawn ahead never twists the state, so the index is
+  // the whole state; the pool is either untouched - warm-up - or rebuilt by the event) and the next batch draws again. Results are those
+  // of one sample per iteration, bit for bit (`ahead` = 1 is that form: tests/test_geofilter_e.py compares the two).
+  const bool x4 = MODEL == kModelE && ahead > 1;
+  unsigned iter = 0;
+  while (iter < nIter && iter < max_iterations) {
+    int kb = 1;
+    [[maybe_unused]] uint32_t S[kAhead][5];
+    [[maybe_unused]] int idx_after[kAhead] = {0, 0, 0, 0};
+    [[maybe_unused]] int nm_rows = 0;
+    if constexpr (MODEL == kModelE) {
+      if (x4) {
+        const unsigned left = (nIter < max_iterations ? nIter : max_iterations) - iter;
+        const int kb_max = (int)(left < ahead ? left : ahead);
+        kb = 0;
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+          if (j < kb_max && kb == j) {   // (kb == j: no draw of this batch was revoked)
+            if (draw_sample(j == 0)) {
+#pragma unroll
+              for (int i = 0; i < 5; ++i) S[j][i] = s[i];
+              idx_after[j] = mt_idx;
+              kb = j + 1;
+            }
+          }
+        }
+        GEO_STAMP(0);
+        uint32_t mine[5];   // the sample of this lane's row (rows beyond the batch repeat its last sample; their results are not read)
+        const int row = (lane >> 4) < kb ? (lane >> 4) : kb - 1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) mine[i] = row == 0 ? S[0][i] : row == 1 ? S[1][i] : row == 2 ? S[2][i] : S[3][i];
+        nm_rows = five_point::solve4(bv1, bv2, mine, lane, e_scr, e_Es4);
+        GEO_STAMP(1);
+      }
+    }
+#pragma unroll 1
+    for (int j = 0; j < kb; ++j) {
+    const bool ac_at_start = ac_mode;
+    // ---- sample ----
+    if (!x4) (void)draw_sample(true);
+    if constexpr (MODEL == kModelE) {
+      if (x4) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) s[i] = j == 0 ? S[0][i] : j == 1 ? S[1][i] : j == 2 ? S[2][i] : S[3][i];
       }
     }
     GEO_STAMP(0);
@@ -640,7 +759,8 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
     } else if constexpr (MODEL == kModelE) {
       // FivePointSolver on the sample's bearing vectors (up to ten essential matrices, LDS), then F = K2^-T E K1^-1 per model for
       // the pixel residuals (ACKernelAdaptorEssential::Errors; products and sums rounded one by one like the reference's 3 x 3 products)
-      nm = five_point::solve(bv1, bv2, s, lane, e_scr, e_Es);
+      if (x4) { nm = __builtin_amdgcn_readlane(nm_rows, 16 * j); e_Es = e_Es4 + 90 * j; }
+      else { nm = five_point::solve(bv1, bv2, s, lane, e_scr, e_Es4); e_Es = e_Es4; }
       for (int e = lane; e < 9 * nm; e += 64) {
         const int mi = e / 9, u = e - 9 * mi, i = u / 3, j = u - 3 * i;
         const double* __restrict__ E = e_Es + 9 * mi;
@@ -756,8 +876,9 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
     }
     GEO_STAMP(4);
     // ---- loop control (:445-474) ----
-    if (!ac_mode && iter > (unsigned)(nIterReserve * 2)) { nIter = 0; continue; }
-    if (ac_mode && ((better && minNFA < 0) || ((iter + 1) == nIter && nIterReserve > 0))) {
+    bool redraw = ac_mode != ac_at_start;   // samples drawn ahead in the other mode are void
+    if (!ac_mode && iter > (unsigned)(nIterReserve * 2)) nIter = 0;
+    else if (ac_mode && ((better && minNFA < 0) || ((iter + 1) == nIter && nIterReserve > 0))) {
       if (inl_count == 0) { ++nIter; --nIterReserve; }
       else {
         // vec_index = vec_inliers: the correspondences within inl_thr of the list's model, in index order
@@ -775,9 +896,19 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? 2 : 3) void geofilte
         wave_sync();
         pool_size = m;
         if (nIterReserve) { nIter = iter + 1 + (unsigned)nIterReserve; nIterReserve = 0; }
+        redraw = true;   // ... from the old pool as well
       }
     }
     GEO_STAMP(5);
+    ++iter;
+    if (!(iter < nIter && iter < max_iterations)) break;
+    if constexpr (MODEL == kModelE) {
+      if (x4 && redraw && j + 1 < kb) {   // the generator as the last sample used left it
+        mt_idx = j == 0 ? idx_after[0] : j == 1 ? idx_after[1] : idx_after[2];
+        break;
+      }
+    }
+    }   // samples of the batch
   }
 #ifdef MVGX_GEO_STAMPS
   if (lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_geo_stamps[k], geo_acc_[k]); }
@@ -807,12 +938,12 @@ struct DevBuf {
 template <int WAVES, int MODEL>
 int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
                  const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, hipStream_t stream,
-                 const double* b1 = nullptr, const double* b2 = nullptr) {
+                 const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
   MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
-                     n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2);
+                     n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2, ahead);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
@@ -820,11 +951,11 @@ int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_wor
 template <int MODEL>
 int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
                         const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream,
-                        const double* b1 = nullptr, const double* b2 = nullptr) {
+                        const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)(kMtN + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
   hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
-                     max_it, res, mask, scratch, b1, b2);
+                     max_it, res, mask, scratch, b1, b2, ahead);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
@@ -860,17 +991,18 @@ inline void inverse3(const double* m, double* inv) {
 template <int MODEL>
 int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const std::vector<GeoPair>& hp, uint32_t c4, uint32_t c3,
                    uint32_t c2, uint32_t c1, const uint32_t (&caps)[4], const double2* px1, const double2* px2, const float* l10, const uint32_t* mt,
-                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr) {
+                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr,
+                   uint32_t ahead = 1) {
   int rc;
   if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
     const uint32_t cap_g = hp[order[0]].n;
     if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
-    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream, b1, b2))) return rc;
+    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream, b1, b2, ahead))) return rc;
   }
-  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
-  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
-  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2))) return rc;
-  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2);
+  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
+  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
+  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
+  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead);
 }
 
 int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
@@ -1089,6 +1221,9 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   DevBuf d_tables;
   {
     const uint32_t caps[4] = {kCap0, kCap1, kCap2, kCap3};
+    // essential model: samples drawn and solved ahead of their iterations (1: one five-point solve per iteration, the form of rounds 3-4; results equal)
+    uint32_t e_ahead = kAhead;
+    if (const char* env = getenv("MVGX_GEO_E_AHEAD")) e_ahead = (uint32_t)std::min(kAhead, std::max(1, atoi(env)));
     auto* dp = static_cast<const GeoPair*>(d_pairs.p);
     auto* dl = static_cast<const float*>(d_l10.p);
     auto* dm = static_cast<const uint32_t*>(d_mt.p);
@@ -1100,7 +1235,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
          : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
-                                                      static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p))
+                                                      static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p), e_ahead)
                             : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
     if (rc) return rc;
   }
@@ -1292,6 +1427,15 @@ __global__ void five_point_debug_kernel(const double* b1, const double* b2, doub
   for (int e = lane; e < 9 * n; e += 64) Es_out[e] = scr[five_point::kScratch + e];
   if (lane == 0) *n_out = n;
 }
+// The same for solve4: four samples (b1, b2: 4 x 5 x 3 doubles), one per 16-lane row; Es_out 4 x 90, n_out 4
+__global__ __launch_bounds__(64) void five_point4_debug_kernel(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  __shared__ double scr[4 * five_point::kScratch + 4 * 90];
+  const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
+  const uint32_t s[5] = {5u * g, 5u * g + 1, 5u * g + 2, 5u * g + 3, 5u * g + 4};
+  const int n = five_point::solve4(b1, b2, s, lane, scr, scr + 4 * five_point::kScratch);
+  for (int e = gl; e < 9 * n; e += 16) Es_out[90 * g + e] = scr[4 * five_point::kScratch + 90 * g + e];
+  if (gl == 0) n_out[g] = n;
+}
 // diagnostic (not declared in include/mvgx.h): five-point solves of this process whose eigenvalues fell back to hqr; reset != 0 clears
 int mvgx_debug_five_point_fallbacks(unsigned long long* out, int reset) {
   unsigned long long v = 0;
@@ -1328,6 +1472,29 @@ int mvgx_debug_five_point(const double* b1, const double* b2, double* Es_out, in
   MVGX_HIP(hipStreamSynchronize(nullptr));
   MVGX_HIP(hipMemcpy(Es_out, dE.p, 90 * sizeof(double), hipMemcpyDeviceToHost));
   MVGX_HIP(hipMemcpy(n_out, dn.p, sizeof(int), hipMemcpyDeviceToHost));
+  return MVGX_OK;
+}
+
+// Test hook (not declared in include/mvgx.h): five_point::solve4 on four samples of five bearing pairs (b1, b2: 4 x 5 x 3 doubles)
+int mvgx_debug_five_point4(const double* b1, const double* b2, double* Es_out, int* n_out) {
+  MVGX_REQUIRE(b1 && b2 && Es_out && n_out, MVGX_ERR_ARG, "mvgx_debug_five_point4: NULL argument");
+  int rc = mvgx::select_device(-1);
+  if (rc) return rc;
+  DevBuf d1, d2, dE, dn;
+  if ((rc = d1.alloc(60 * sizeof(double))) || (rc = d2.alloc(60 * sizeof(double))) || (rc = dE.alloc(360 * sizeof(double))) || (rc = dn.alloc(4 * sizeof(int)))) return rc;
+  MVGX_HIP(hipMemcpy(d1.p, b1, 60 * sizeof(double), hipMemcpyHostToDevice));
+  MVGX_HIP(hipMemcpy(d2.p, b2, 60 * sizeof(double), hipMemcpyHostToDevice));
+  MVGX_HIP(hipMemset(dE.p, 0, 360 * sizeof(double)));
+  {
+    const double *p1 = static_cast<const double*>(d1.p), *p2 = static_cast<const double*>(d2.p);
+    double* pE = static_cast<double*>(dE.p);
+    int* pn = static_cast<int*>(dn.p);
+    hipLaunchKernelGGL(five_point4_debug_kernel, dim3(1), dim3(64), 0, nullptr, p1, p2, pE, pn);
+  }
+  MVGX_HIP(hipGetLastError());
+  MVGX_HIP(hipStreamSynchronize(nullptr));
+  MVGX_HIP(hipMemcpy(Es_out, dE.p, 360 * sizeof(double), hipMemcpyDeviceToHost));
+  MVGX_HIP(hipMemcpy(n_out, dn.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
   return MVGX_OK;
 }
 

@@ -36,6 +36,7 @@ namespace hipemu {
 extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void block_barrier();
+void site(int n);
 double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);
 typedef double d4 __attribute__((ext_vector_type(4)));
 d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int);
@@ -64,6 +65,7 @@ int lane_abs(int lane, int s);
 #define __shared__ thread_local   // one workgroup at a time on one OS thread: a per-thread static is the workgroup's LDS
 
 #define __syncthreads() hipemu::block_barrier()
+#define MVGX_EMU_SITE(n) hipemu::site(n)   // source marker for the divergence check of the scheduler
 static inline double __shfl_xor(double v, int m) { return hipemu::shfl_f64(v, hipemu::lane_xor, m); }
 static inline double __shfl_down(double v, int d) { return hipemu::shfl_f64(v, hipemu::lane_down, d); }
 static inline double __shfl(double v, int s) { return hipemu::shfl_f64(v, hipemu::lane_abs, s); }

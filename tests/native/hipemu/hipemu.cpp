@@ -30,6 +30,10 @@ thread_local unsigned char g_parity[1024];
 // ballots: a lane that has already left the kernel must not vote, and a lane that runs ahead and finishes must still be
 // counted by the slower lanes of the same ballot: votes are tagged with the lane's ballot sequence number
 thread_local unsigned g_ballot_seq[1024], g_ballot_tag[2][1024];
+// wave collectives met by every lane so far: the lanes of a wave that rendezvous must have met the same number - a collective in
+// divergent code (undefined on the device, silent garbage here) is reported instead
+thread_local unsigned g_coll_n[1024];
+thread_local int g_site[1024];   // last MVGX_EMU_SITE(n) passed by the lane (optional source markers: lanes that rendezvous must agree)
 
 void trampoline() {
   (*g_body)();
@@ -59,6 +63,8 @@ void run_block(unsigned nthreads) {
     f.st = RUNNABLE;
     g_parity[i] = 0;
     g_ballot_seq[i] = 0;
+    g_coll_n[i] = 0;
+    g_site[i] = 0;
     g_ballot_tag[0][i] = g_ballot_tag[1][i] = 0;
   }
   for (;;) {
@@ -80,6 +86,24 @@ void run_block(unsigned nthreads) {
         if (g_fibers[i].st != WAIT_WAVE) ok = false;
       }
       if (any && ok) {
+        int first = -1;
+        for (int i = w0; i < std::min(g_n, w0 + 64); ++i) {
+          if (g_fibers[i].st != WAIT_WAVE) continue;
+          if (first < 0) first = i;
+          if (g_site[i] != g_site[first]) {
+            fprintf(stderr, "hipemu: lanes %d and %d of a wave rendezvous at different places (site %d / %d, collectives %u / %u)\n", first & 63, i & 63, g_site[first], g_site[i], g_coll_n[first], g_coll_n[i]);
+            abort();
+          }
+          if (g_parity[i] != g_parity[first]) {
+            fprintf(stderr, "hipemu: exchange-buffer parity of lane %d differs from lane %d's (collectives %u / %u)\n", i & 63, first & 63, g_coll_n[i], g_coll_n[first]);
+            abort();
+          }
+          if (g_coll_n[i] != g_coll_n[first]) {
+            fprintf(stderr, "hipemu: wave collective in divergent code (block %u): lane %d is at its collective number %u, lane %d at %u\n",
+                    g_blockIdx.x, first & 63, g_coll_n[first], i & 63, g_coll_n[i]);
+            abort();
+          }
+        }
         for (int i = w0; i < std::min(g_n, w0 + 64); ++i)
           if (g_fibers[i].st == WAIT_WAVE) g_fibers[i].st = RUNNABLE;
         progressed = true;
@@ -134,6 +158,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   g_body = nullptr;
 }
 
+void site(int n) { g_site[g_cur] = n; }
+
 void block_barrier() {
   const int me = g_cur;
   yield(WAIT_BLOCK);
@@ -143,6 +169,7 @@ void block_barrier() {
 
 static void wave_sync() {
   const int me = g_cur;
+  ++g_coll_n[me];
   yield(WAIT_WAVE);
   g_cur = me;
   g_threadIdx = dim3((unsigned)me, 0, 0);

@@ -58,6 +58,67 @@ def test_five_point_emulated_device_solver_reproduces_the_reference_solutions():
     _check_five_point(h.mvgx_debug_five_point, 1e-7, sel=range(24))
 
 
+def _five_point4_equals_four_solves(h, tests):
+    """mvgx_debug_five_point4 (solve4: four samples, one per 16-lane row) == mvgx_debug_five_point on each sample, bit for bit"""
+    h.mvgx_debug_five_point.restype = C.c_int
+    h.mvgx_debug_five_point4.restype = C.c_int
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    nt = len(GOLD["fp_n"])
+    total = 0
+    for t0 in range(0, tests, 4):
+        idx = [min(t0 + k, nt - 1) for k in range(4)]
+        b1 = np.ascontiguousarray(np.stack([GOLD["fp_b1"][t] for t in idx]), np.float64)
+        b2 = np.ascontiguousarray(np.stack([GOLD["fp_b2"][t] for t in idx]), np.float64)
+        E4 = np.zeros(360); n4 = (C.c_int * 4)()
+        assert h.mvgx_debug_five_point4(P(b1), P(b2), P(E4), n4) == 0
+        for k, t in enumerate(idx):
+            E1 = np.zeros(90); n1 = C.c_int(0)
+            assert h.mvgx_debug_five_point(P(np.ascontiguousarray(b1[k])), P(np.ascontiguousarray(b2[k])), P(E1), C.byref(n1)) == 0
+            assert n1.value == n4[k], (t, n1.value, n4[k])
+            assert np.array_equal(E1[:9 * n1.value], E4[90 * k:90 * k + 9 * n1.value]), (t, np.abs(E1[:9 * n1.value] - E4[90 * k:90 * k + 9 * n1.value]).max())
+            total += n1.value
+    assert total > tests   # (more than one solution per sample on average)
+
+
+def test_five_point_four_samples_per_wave_equal_the_one_sample_solver_emulated():
+    _five_point4_equals_four_solves(_emu.handle(), 24)
+
+
+def _samples_ahead_equal_one_sample_per_iteration(tv, K, b, max_iterations, aheads=("4", "3")):
+    """MVGX_GEO_E_AHEAD=1 (one five-point solve per a-contrario iteration) against samples drawn and solved ahead: every output equal"""
+    saved = os.environ.get("MVGX_GEO_E_AHEAD")
+    out = {}
+    try:
+        for ahead in ("1",) + tuple(aheads):
+            os.environ["MVGX_GEO_E_AHEAD"] = ahead
+            mask, res, st = geofilter.filter_pairs_e(tv["xI"], tv["xJ"], tv["start"], tv["wh"], K, FUNCTOR(4.0, max_iterations), bearings=b)
+            out[ahead] = (mask.copy(), res.copy(), int(st.n_iterations), int(st.n_models), int(st.n_pairs_ok))
+    finally:
+        if saved is None:
+            os.environ.pop("MVGX_GEO_E_AHEAD", None)
+        else:
+            os.environ["MVGX_GEO_E_AHEAD"] = saved
+    one = out["1"]
+    for ahead in aheads:
+        got = out[ahead]
+        assert got[2:] == one[2:], (ahead, got[2:], one[2:])
+        assert np.array_equal(got[0], one[0]) and got[1].tobytes() == one[1].tobytes(), ahead
+    return one
+
+
+def test_samples_ahead_equal_one_sample_per_iteration_emulated():
+    """a pair the filter accepts and one it rejects, 2 048 iterations: the warm-up, the change of mode, pool rebuilds, a twist of the
+    generator inside a batch of samples (revoked draw) - all on the path"""
+    start = GOLD["start"].astype(np.int64)
+    n = np.diff(start)
+    small = [int(p) for p in np.argsort(n) if 12 < n[p] <= 60]
+    sel = [p for p in small if GOLD["ok"][p]][:2] + [p for p in small if not GOLD["ok"][p]][:1]
+    tv, ref, K, b = _gold_tv(sel)
+    with _emu.emulated():
+        one = _samples_ahead_equal_one_sample_per_iteration(tv, K, b, 2048)
+    assert one[2] > 300 and one[4] == 2   # (several twists of the 624-word state: ~5 draws per iteration)
+
+
 def _gold_tv(sel=None):
     start = GOLD["start"].astype(np.int64)
     pairs = list(range(len(start) - 1)) if sel is None else list(sel)
@@ -125,6 +186,21 @@ def test_five_point_device_solver_reproduces_the_reference_solutions():
     lib.mvgx_debug_five_point.restype = C.c_int
     worst = _check_five_point(lib.mvgx_debug_five_point, 1e-7)
     assert worst < 1e-7
+
+
+@pytest.mark.gpu
+def test_five_point_four_samples_per_wave_equal_the_one_sample_solver():
+    _five_point4_equals_four_solves(_capi.lib(), len(GOLD["fp_n"]))
+
+
+@pytest.mark.gpu
+def test_samples_ahead_equal_one_sample_per_iteration_on_the_device():
+    tv, ref, K, b = _gold_tv()
+    _samples_ahead_equal_one_sample_per_iteration(tv, K, b, 2048, aheads=("4", "2"))
+    _samples_ahead_equal_one_sample_per_iteration(tv, K, b, 37, aheads=("4",))
+    big = synth.two_view_matches(120, seed=4711, n_max=14000)   # every size class, global-table class included
+    Kb = synth.two_view_calibration(big)
+    _samples_ahead_equal_one_sample_per_iteration(big, Kb, None, 1024, aheads=("4",))
 
 
 @pytest.mark.gpu
