@@ -19,10 +19,16 @@
 // the reference's to rounding; the parity policy of the F and H models applies (tests/_geofilter_cases.py).
 #pragma once
 
+// Contraction of a product and a sum into one fused operation by the SOURCE expression only (a * b + c written as one expression), not
+// wherever the optimiser finds a product next to a sum: solve() and solve4() (geofilter_five_point_x4.h) must produce the same bits, and
+// with the toolchain's default (-ffp-contract=fast) which products get fused depended on the code around them - an unrelated edit moved
+// one sample in 64 by 7e-15 (call r5_29). Restored at the end of geofilter_five_point_x4.h.
+#pragma clang fp contract(on)
+
 namespace five_point {
 
 #ifdef MVGX_FIVE_POINT_STAMPS   // measurement build: shader clocks of lane 0 per stage of solve(), summed over all calls
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[12];
 #define FP_STAMP(i) do { const long long t_now = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&g_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } while (0)
 #else
 #define FP_STAMP(i) do { } while (0)
@@ -173,7 +179,9 @@ __device__ __forceinline__ void ld4(const double* __restrict__ B, int u, double 
 #pragma unroll
   for (int t = 0; t < 4; ++t) e[t] = B[4 * u + t];
 }
-__device__ __forceinline__ void constraint_row(const double* __restrict__ B, int row, double (&m)[20]) {
+// `park` (solve4: 20 doubles of this lane's LDS, or nullptr): where the row's lane keeps the determinant row while the other form is
+// built - both forms live in registers at once were 80 of the 256 a wave of the essential kernel has
+__device__ __forceinline__ void constraint_row(const double* __restrict__ B, int row, double (&m)[20], double* __restrict__ park = nullptr) {
   const bool row0 = row == 0;
   // Both forms are evaluated by every lane and selected per element (a divergent branch around the determinant row kept the row in
   // scratch memory).
@@ -194,6 +202,10 @@ __device__ __forceinline__ void constraint_row(const double* __restrict__ B, int
       ld4(B, trip[w][4], ea);
       o2_add(p, ea, m0);
     }
+  }
+  if (park && row0) {
+#pragma unroll
+    for (int t = 0; t < 20; ++t) park[t] = m0[t];
   }
   if (row < 1) row = 1;   // (row 0 takes m0 below; its lane evaluates the (0, 0) form like lane 1)
   const int i = (row - 1) / 3, j = (row - 1) - 3 * i;
@@ -237,7 +249,7 @@ __device__ __forceinline__ void constraint_row(const double* __restrict__ B, int
   }
   if (row0) {
 #pragma unroll
-    for (int t = 0; t < 20; ++t) m[t] = m0[t];
+    for (int t = 0; t < 20; ++t) m[t] = park ? park[t] : m0[t];
   }
 }
 

@@ -234,6 +234,12 @@ __device__ __forceinline__ void hessenberg4(double* __restrict__ H, double* __re
 
 // ---- 5e. eigenvalues_aberth() on this row's matrix; `alive`: the row still carries a sample. Returns (row-uniform) whether wr / wi hold
 // the eigenvalues; false where solve() returns false: the caller runs hqr on the same H ----
+#ifdef MVGX_FIVE_POINT_COUNT_ROUNDS
+__device__ unsigned long long g_fallback_cause[8];   // why a row's eigenvalues were left to hqr (measurement build)
+#define FP_CAUSE(i, was_ok) do { if ((lane & 15) == 0 && (was_ok) && !ok) atomicAdd(&g_fallback_cause[i], 1ull); } while (0)
+#else
+#define FP_CAUSE(i, was_ok) do { } while (0)
+#endif
 __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H, double* __restrict__ wr, double* __restrict__ wi,
                                                     double* __restrict__ ps /* kPolyScratch */, double* __restrict__ rsub /* 10: v */, int lane, bool alive) {
   const int gl = lane & 15;
@@ -243,6 +249,9 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
   double* const zim = zre + 10;
   double* const rad = zim + 10;
   bool ok = alive;
+#ifdef MVGX_FIVE_POINT_STAMPS   // (slots 6, 7: parts of the eigenvalue stage - polynomial + start radii, the iteration)
+  long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   // ---- 1. characteristic polynomial ----
   {
     bool okl = true;
@@ -251,7 +260,7 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
       okl = h != 0.0 && finite_d(h);
       rsub[gl] = okl ? 1.0 / h : 0.0;
     }
-    { const uint32_t votes = row_ballot(!okl, lane); ok = ok && !votes; }
+    { const bool was_ok_ = ok; const uint32_t votes = row_ballot(!okl, lane); ok = ok && !votes; FP_CAUSE(1, was_ok_); }
   }
   if (gl <= kN) X[(kN - 1) * 11 + gl] = gl == 0 ? 1.0 : 0.0;
   wave_sync();
@@ -273,9 +282,9 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
     mine = t;
   }
   const double lead = row_value_f64(mine, kN, lane);
-  ok = ok && lead != 0.0 && finite_d(lead);
+  { const bool was_ok_ = ok; ok = ok && lead != 0.0 && finite_d(lead); FP_CAUSE(0, was_ok_); }
   mine = mine / lead;
-  { const uint32_t votes = row_ballot(gl <= kN && !finite_d(mine), lane); ok = ok && !votes; }
+  { const bool was_ok_ = ok; const uint32_t votes = row_ballot(gl <= kN && !finite_d(mine), lane); ok = ok && !votes; FP_CAUSE(2, was_ok_); }
   if (gl <= kN) coef[gl] = mine;
   wave_sync();
   // ---- 2a. start radii: Newton polygon (one step per hull edge; rows that are through - or out - wait for the others) ----
@@ -308,6 +317,7 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
     }
   }
   wave_sync();
+  FP_STAMP(6);
   // ---- 2b. Ehrlich-Aberth ----
   double zr = 0.0, zi = 0.0;
   if (gl < kN) {
@@ -367,7 +377,8 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
 #ifdef MVGX_FIVE_POINT_COUNT_ROUNDS
   if (lane == 0) { atomicAdd(&g_aberth_rounds, (unsigned long long)(it + 1)); atomicAdd(&g_aberth_solves, 1ull); }
 #endif
-  { const uint32_t votes = row_ballot(!done, lane); ok = ok && !votes; }   // no convergence (or a non-finite iterate): hqr decides
+  FP_STAMP(7);
+  { const bool was_ok_ = ok; const uint32_t votes = row_ballot(!done, lane); ok = ok && !votes; FP_CAUSE(3, was_ok_); }   // no convergence (or a non-finite iterate): hqr decides
   // ---- 3. real roots: polished on the matrix ----
   bool real = false;
   double x = zr;
@@ -388,7 +399,8 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
     const bool converged = fabs(step) <= 1.0e-9 * fabs(x) + 1.0e-300 && finite_d(x);
     if (!converged) { if (fabs(zi) <= 1.0e-12 * fabs(zr)) bad = true; real = false; }
   }
-  { const uint32_t votes = row_ballot(bad, lane); ok = ok && !votes; }
+  FP_STAMP(8);
+  { const bool was_ok_ = ok; const uint32_t votes = row_ballot(bad, lane); ok = ok && !votes; FP_CAUSE(4, was_ok_); }
   if (gl < kN) { zre[gl] = real ? x : 0.0; zim[gl] = real ? 0.0 : 1.0; }
   wave_sync();
   bool dup = false;
@@ -397,9 +409,10 @@ __device__ __forceinline__ bool eigenvalues_aberth4(const double* __restrict__ H
     for (int j = 0; j < kN; ++j)
       if (j != gl && zim[j] == 0.0 && fabs(zre[j] - x) <= 1.0e-10 * fabs(x)) dup = true;
   }
-  { const uint32_t votes = row_ballot(dup, lane); ok = ok && !votes; }
+  { const bool was_ok_ = ok; const uint32_t votes = row_ballot(dup, lane); ok = ok && !votes; FP_CAUSE(5, was_ok_); }
   if (ok && gl < kN) { wr[gl] = real ? x : zr; wi[gl] = real ? 0.0 : (zi != 0.0 ? zi : 1.0); }
   wave_sync();
+  FP_STAMP(9);
   return ok;
 }
 
@@ -416,18 +429,25 @@ __device__ __forceinline__ int solve4(const double* __restrict__ b1, const doubl
   double* const wi = wr + 10;
   double* const basis_lds = wi + 10;
   double* const Es = Es4 + 90 * g;
+#ifdef MVGX_FIVE_POINT_STAMPS
+  long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   nullspace4(b1, b2, s, lane, basis_lds);
+  FP_STAMP(0);
   bool alive;
   {
     double m[20];
-    constraint_row(basis_lds, gl < kN ? gl : kN - 1, m);
+    constraint_row(basis_lds, gl < kN ? gl : kN - 1, m, basis_lds + 36);   // (the polynomial scratch is free until the eigenvalue stage)
     wave_sync();
+    FP_STAMP(1);
     alive = action_matrix4(m, lane, H);
+    FP_STAMP(2);
   }
   double At_row[kN];   // this lane's row of the action matrix (lanes gl < 10): kept for the eigenvectors
 #pragma unroll
   for (int c = 0; c < kN; ++c) At_row[c] = H[(gl < kN ? gl : 0) * kN + c];
   hessenberg4(H, v, lane);
+  FP_STAMP(3);
 #if MVGX_FIVE_POINT_ABERTH
   const bool have = eigenvalues_aberth4(H, wr, wi, basis_lds + 36, v, lane, alive);
 #else
@@ -446,6 +466,7 @@ __device__ __forceinline__ int solve4(const double* __restrict__ b1, const doubl
       if (g == q && !okq) alive = false;
     }
   }
+  FP_STAMP(4);
   // the action matrix again (the iteration worked in place), then one eigenvector per lane
   wave_sync();
 #pragma unroll
@@ -465,7 +486,10 @@ __device__ __forceinline__ int solve4(const double* __restrict__ b1, const doubl
       Es[slot * 9 + u] = basis_lds[4 * u] * tail[0] + basis_lds[4 * u + 1] * tail[1] + basis_lds[4 * u + 2] * tail[2] + basis_lds[4 * u + 3] * tail[3];
   }
   wave_sync();
+  FP_STAMP(5);
   return n;
 }
 
 }  // namespace five_point
+
+#pragma clang fp contract(fast)   // (the toolchain's default for the rest of the unit)
