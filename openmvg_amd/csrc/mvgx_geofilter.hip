@@ -273,6 +273,7 @@ __device__ __forceinline__ typename PointOf<MODEL>::type load_point(const double
 // column] = 1). Every lane gets the vector. A rank-deficient system gives SOME null vector. (Until round 4 every lane of a group of
 // eight held a whole row and the wave did the same work eight times over: 1 600 instructions against 760 - same arithmetic per
 // element, same results.)
+#pragma clang fp contract(on)
 __device__ __forceinline__ void null_vector_8x9(double a0, double a1, int lane, double (&H)[9]) {
   const bool live = lane < 36;
   const int r0 = live ? lane / 9 : 3, c = live ? lane - 9 * (lane / 9) : 8;
@@ -335,6 +336,80 @@ __device__ __forceinline__ void four_point(const double2* __restrict__ x1, const
   };
   null_vector_8x9(element(r0), element(r0 + 4), lane, H);
 }
+
+// The same on FOUR samples, one per 16-lane row of the wave (samples ahead, see the kernel): lane gl < 9 of a row holds COLUMN gl of the
+// row's 8 x 9 system (eight registers) instead of two elements per lane of 36; same pivot choices (keys, tie-breaks), same arithmetic
+// per element, the pivot row / column travel through the LDS crossbar inside the row. Every lane of a row gets the row's vector.
+__device__ __forceinline__ void null_vector_8x9_x4(double (&a)[8], int lane, double (&H)[9]) {
+  const int gl = lane & 15;
+  const bool live = gl < 9;
+  const int c = live ? gl : 8;
+  uint32_t row_used = 0, col_used = 0;
+  int prow[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pcol[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_piv = 0;
+  bool going = true;
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    uint32_t key = 0u;
+    if (live && !((col_used >> c) & 1u)) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float m = (float)fabs(a[r]);
+        const uint32_t k = (!((row_used >> r) & 1u) && m > 0.f && m == m) ? ((__float_as_uint(m) & ~127u) | (uint32_t)(127 - (9 * r + c))) : 0u;
+        key = k > key ? k : key;
+      }
+    }
+    const uint32_t best = five_point::row_max_u32(key);
+    going = going && best != 0u;
+    const int who = going ? 127 - (int)(best & 127u) : 0;
+    const int pr = who / 9, pc = who - 9 * pr;
+    double rowv = a[0];   // pivot row, my column
+#pragma unroll
+    for (int r = 1; r < 8; ++r) rowv = (pr == r) ? a[r] : rowv;
+    const double piv = five_point::row_value_f64(rowv, pc, lane);
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const double colv = five_point::row_value_f64(a[r], pc, lane);   // row r, pivot column
+      if (going && r != pr) { const double f = colv * ip; a[r] -= f * rowv; }
+    }
+    if (going) {
+      row_used |= 1u << pr; col_used |= 1u << pc;
+      prow[step] = pr; pcol[step] = pc;
+      n_piv = step + 1;
+    }
+  }
+  int fc = 0;
+  while ((col_used >> fc) & 1u) ++fc;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) H[u] = (u == fc) ? 1.0 : 0.0;
+#pragma unroll
+  for (int step = 0; step < 8; ++step) {
+    double of_row = a[0];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) of_row = (prow[step] == r) ? a[r] : of_row;
+    const double num = five_point::row_value_f64(of_row, fc, lane), den = five_point::row_value_f64(of_row, pcol[step], lane);
+    const double h = -num / den;
+    if (step < n_piv) {
+#pragma unroll
+      for (int u = 0; u < 9; ++u) H[u] = (u == pcol[step]) ? h : H[u];
+    }
+  }
+}
+// FourPointSolver::Solve on the sample of this lane's row (s[0..3])
+__device__ __forceinline__ void four_point_x4(const double2* __restrict__ x1, const double2* __restrict__ x2, const uint32_t (&s)[4], int lane, double (&H)[9]) {
+  const int gl = lane & 15, c = gl < 9 ? gl : 8;
+  const int cm = c % 3;
+  double a[8];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    const double2 p1 = x1[s[pt]], p2 = x2[s[pt]];
+    const double h = cm == 0 ? p1.x : cm == 1 ? p1.y : 1.0;
+    a[2 * pt] = c < 3 ? h : c < 6 ? 0.0 : -p2.x * h;
+    a[2 * pt + 1] = c < 3 ? 0.0 : c < 6 ? h : -p2.y * h;
+  }
+  null_vector_8x9_x4(a, lane, H);
+}
+#pragma clang fp contract(fast)
 
 // EightPointRelativePoseSolver::Solve on exactly eight bearing pairs (multiview/solver_essential_eight_point.cpp:17-47; with eight
 // columns the projection onto the essential manifold is skipped, :36): E = the null vector of the 8 x 9 epipolar system
@@ -571,16 +646,27 @@ constexpr int kWaveScratch = 64;   // words behind a wave's tables: histogram (2
 // (round 5: four samples are solved side by side - four workspaces, four sets of essential matrices, the fundamental matrices of the one being evaluated)
 constexpr int kAhead = 4;
 constexpr int kEssentialScratch = 2 * (kAhead * five_point::kScratch + kAhead * 90 + 90);
-template <int MODEL> constexpr int wave_scratch_words() { return kWaveScratch + (MODEL == kModelE ? kEssentialScratch : 0); }
+// fundamental / homography models: the models of the four samples solved together - per row F1 | F2 | roots | their number (22 doubles)
+constexpr int kRowModel = 22;
+// (The seven-point solver of the fundamental model was built in this form too and is not kept: its elimination is 40 % of an iteration, not
+// 75 - 85 %, and what four side by side save went into the exchange of the rows' models and 60 more spilled registers: 55 ms against 48 on
+// 20 000 pairs, profiles/round5_geofilter_f_h_samples_ahead_ab_call_r5_30.txt.)
+template <int MODEL> constexpr bool model_solves_ahead() { return MODEL == kModelE || MODEL == kModelH; }
+template <int MODEL> constexpr int wave_scratch_words() {
+  return kWaveScratch + (MODEL == kModelE ? kEssentialScratch : model_solves_ahead<MODEL>() ? 2 * kAhead * kRowModel : 0);
+}
 
 // kGlobalTables: the sampling pool and the two log-combinatorial tables of a wave (3 x n words) live in a global scratch block
 // instead of LDS - the class of pairs with more correspondences than a workgroup's LDS holds (one wave per workgroup; the generator,
 // the histogram and the model stay in LDS)
+#ifndef MVGX_GEO_WGS
+#define MVGX_GEO_WGS 3     // ... the other instantiations
+#endif
 #ifndef MVGX_GEO_E_WGS
 #define MVGX_GEO_E_WGS 2   // workgroups per CU the essential instantiation is compiled for (1: twice the registers, half the waves)
 #endif
 template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF>
-__global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVGX_GEO_WGS) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
                                                                           const uint32_t* __restrict__ mt_init, uint32_t max_iterations,
@@ -705,14 +791,15 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) 
   // generator's index goes back to where the last used sample left it (a sample drawn ahead never twists the state, so the index is
   // the whole state; the pool is either untouched - warm-up - or rebuilt by the event) and the next batch draws again. Results are those
   // of one sample per iteration, bit for bit (`ahead` = 1 is that form: tests/test_geofilter_e.py compares the two).
-  const bool x4 = MODEL == kModelE && ahead > 1;
+  const bool x4 = model_solves_ahead<MODEL>() && ahead > 1;
+  double* const row_models = e_scr;   // (fundamental / homography models: the same words of the wave's scratch)
   unsigned iter = 0;
   while (iter < nIter && iter < max_iterations) {
     int kb = 1;
-    [[maybe_unused]] uint32_t S[kAhead][5];
+    [[maybe_unused]] uint32_t S[kAhead][kMin];
     [[maybe_unused]] int idx_after[kAhead] = {0, 0, 0, 0};
     [[maybe_unused]] int nm_rows = 0;
-    if constexpr (MODEL == kModelE) {
+    if constexpr (model_solves_ahead<MODEL>()) {
       if (x4) {
         const unsigned left = (nIter < max_iterations ? nIter : max_iterations) - iter;
         const int kb_max = (int)(left < ahead ? left : ahead);
@@ -722,18 +809,34 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) 
           if (j < kb_max && kb == j) {   // (kb == j: no draw of this batch was revoked)
             if (draw_sample(j == 0)) {
 #pragma unroll
-              for (int i = 0; i < 5; ++i) S[j][i] = s[i];
+              for (int i = 0; i < kMin; ++i) S[j][i] = s[i];
               idx_after[j] = mt_idx;
               kb = j + 1;
             }
           }
         }
         GEO_STAMP(0);
-        uint32_t mine[5];   // the sample of this lane's row (rows beyond the batch repeat its last sample; their results are not read)
+        uint32_t mine[kMin];   // the sample of this lane's row (rows beyond the batch repeat its last sample; their results are not read)
         const int row = (lane >> 4) < kb ? (lane >> 4) : kb - 1;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) mine[i] = row == 0 ? S[0][i] : row == 1 ? S[1][i] : row == 2 ? S[2][i] : S[3][i];
-        nm_rows = five_point::solve4(bv1, bv2, mine, lane, e_scr, e_Es4);
+        for (int i = 0; i < kMin; ++i) mine[i] = row == 0 ? S[0][i] : row == 1 ? S[1][i] : row == 2 ? S[2][i] : S[3][i];
+        if constexpr (MODEL == kModelE) nm_rows = five_point::solve4(bv1, bv2, mine, lane, e_scr, e_Es4);
+        else {
+          // the row's models go to the wave's scratch: the evaluation below wants them in every lane, sample after sample
+          double R1[9], R2[9], rr[3] = {0.0, 0.0, 0.0};
+          int rn = 1;
+          four_point_x4(x1, x2, mine, lane, R1);
+#pragma unroll
+          for (int u = 0; u < 9; ++u) R2[u] = 0.0;
+          wave_sync();   // (the models of the batch before have been read)
+          if ((lane & 15) == 0) {
+            double* const dst = row_models + kRowModel * (lane >> 4);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { dst[u] = R1[u]; dst[9 + u] = R2[u]; }
+            dst[18] = rr[0]; dst[19] = rr[1]; dst[20] = rr[2]; dst[21] = (double)rn;
+          }
+          wave_sync();
+        }
         GEO_STAMP(1);
       }
     }
@@ -742,10 +845,10 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) 
     const bool ac_at_start = ac_mode;
     // ---- sample ----
     if (!x4) (void)draw_sample(true);
-    if constexpr (MODEL == kModelE) {
+    if constexpr (model_solves_ahead<MODEL>()) {
       if (x4) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) s[i] = j == 0 ? S[0][i] : j == 1 ? S[1][i] : j == 2 ? S[2][i] : S[3][i];
+        for (int i = 0; i < kMin; ++i) s[i] = j == 0 ? S[0][i] : j == 1 ? S[1][i] : j == 2 ? S[2][i] : S[3][i];
       }
     }
     GEO_STAMP(0);
@@ -753,7 +856,10 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) 
     double F1[9], F2[9], roots[3] = {0.0, 0.0, 0.0};
     int nm = 1;
     if constexpr (MODEL == kModelH) {
-      four_point(x1, x2, s, lane, F1);   // (one model per sample: MAX_MODELS = 1)
+      if (x4) {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) F1[u] = row_models[kRowModel * j + u];
+      } else four_point(x1, x2, s, lane, F1);   // (one model per sample: MAX_MODELS = 1)
 #pragma unroll
       for (int u = 0; u < 9; ++u) F2[u] = 0.0;
     } else if constexpr (MODEL == kModelE) {
@@ -902,7 +1008,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : 3) 
     GEO_STAMP(5);
     ++iter;
     if (!(iter < nIter && iter < max_iterations)) break;
-    if constexpr (MODEL == kModelE) {
+    if constexpr (model_solves_ahead<MODEL>()) {
       if (x4 && redraw && j + 1 < kb) {   // the generator as the last sample used left it
         mt_idx = j == 0 ? idx_after[0] : j == 1 ? idx_after[1] : idx_after[2];
         break;
@@ -1221,22 +1327,24 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   DevBuf d_tables;
   {
     const uint32_t caps[4] = {kCap0, kCap1, kCap2, kCap3};
-    // essential model: samples drawn and solved ahead of their iterations (1: one five-point solve per iteration, the form of rounds 3-4; results equal)
+    // fundamental / homography / essential models: samples drawn and solved ahead of their iterations, four side by side (1: one minimal solve per
+    // iteration, the form of rounds 3-4; results equal)
     uint32_t e_ahead = kAhead;
-    if (const char* env = getenv("MVGX_GEO_E_AHEAD")) e_ahead = (uint32_t)std::min(kAhead, std::max(1, atoi(env)));
+    if (const char* env = getenv("MVGX_GEO_AHEAD")) e_ahead = (uint32_t)std::min(kAhead, std::max(1, atoi(env)));
+    else if (const char* env2 = getenv("MVGX_GEO_E_AHEAD")) e_ahead = (uint32_t)std::min(kAhead, std::max(1, atoi(env2)));
     auto* dp = static_cast<const GeoPair*>(d_pairs.p);
     auto* dl = static_cast<const float*>(d_l10.p);
     auto* dm = static_cast<const uint32_t*>(d_mt.p);
     auto* dr = static_cast<GeoResult*>(d_res.p);
     auto* dk = static_cast<uint8_t*>(d_mask.p);
     const double *pb1 = static_cast<const double*>(d_b1.p), *pb2 = static_cast<const double*>(d_b2.p);
-    rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
+    rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead)
          : model == kModelEO ? launch_classes<kModelEO>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
          : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
          : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
                                                       static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p), e_ahead)
-                            : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream);
+                            : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead);
     if (rc) return rc;
   }
   MVGX_HIP(hipEventRecord(e1, stream));

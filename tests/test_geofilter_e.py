@@ -85,19 +85,19 @@ def test_five_point_four_samples_per_wave_equal_the_one_sample_solver_emulated()
 
 
 def _samples_ahead_equal_one_sample_per_iteration(tv, K, b, max_iterations, aheads=("4", "3")):
-    """MVGX_GEO_E_AHEAD=1 (one five-point solve per a-contrario iteration) against samples drawn and solved ahead: every output equal"""
-    saved = os.environ.get("MVGX_GEO_E_AHEAD")
+    """MVGX_GEO_AHEAD=1 (one five-point solve per a-contrario iteration) against samples drawn and solved ahead: every output equal"""
+    saved = os.environ.get("MVGX_GEO_AHEAD")
     out = {}
     try:
         for ahead in ("1",) + tuple(aheads):
-            os.environ["MVGX_GEO_E_AHEAD"] = ahead
+            os.environ["MVGX_GEO_AHEAD"] = ahead
             mask, res, st = geofilter.filter_pairs_e(tv["xI"], tv["xJ"], tv["start"], tv["wh"], K, FUNCTOR(4.0, max_iterations), bearings=b)
             out[ahead] = (mask.copy(), res.copy(), int(st.n_iterations), int(st.n_models), int(st.n_pairs_ok))
     finally:
         if saved is None:
-            os.environ.pop("MVGX_GEO_E_AHEAD", None)
+            os.environ.pop("MVGX_GEO_AHEAD", None)
         else:
-            os.environ["MVGX_GEO_E_AHEAD"] = saved
+            os.environ["MVGX_GEO_AHEAD"] = saved
     one = out["1"]
     for ahead in aheads:
         got = out[ahead]

@@ -58,6 +58,36 @@ def test_emulated_device_code_equals_the_stored_reference_outputs():
     assert int(st.n_pairs_estimated) == int((n[sel] > 4).sum())
 
 
+def _samples_ahead_equal_one_sample_per_iteration(tv, max_iterations, aheads=("4", "3")):
+    """MVGX_GEO_AHEAD=1 (one four-point solve per a-contrario iteration) against samples drawn ahead and solved four side by side: every
+    output equal (the essential model's test of the same name: tests/test_geofilter_e.py)"""
+    saved = os.environ.get("MVGX_GEO_AHEAD")
+    out = {}
+    try:
+        for ahead in ("1",) + tuple(aheads):
+            os.environ["MVGX_GEO_AHEAD"] = ahead
+            mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, max_iterations))
+            out[ahead] = (mask.copy(), res.copy(), int(st.n_iterations), int(st.n_models), int(st.n_pairs_ok))
+    finally:
+        if saved is None:
+            os.environ.pop("MVGX_GEO_AHEAD", None)
+        else:
+            os.environ["MVGX_GEO_AHEAD"] = saved
+    one = out["1"]
+    for ahead in aheads:
+        got = out[ahead]
+        assert got[2:] == one[2:], (ahead, got[2:], one[2:])
+        assert np.array_equal(got[0], one[0]) and got[1].tobytes() == one[1].tobytes(), ahead
+    return one
+
+
+def test_samples_ahead_equal_one_sample_per_iteration_emulated():
+    tv = synth.two_view_homography_matches(6, seed=11, n_min=8, n_max=60, tiny_frac=0.0)
+    with _emu.emulated():
+        one = _samples_ahead_equal_one_sample_per_iteration(tv, 2048)
+    assert one[2] > 1000 and one[4] >= 2   # (the warm-up, the change of mode, pool rebuilds, twists of the generator inside a batch)
+
+
 def test_emulated_indexed_form_equals_the_gathered_form():
     rng = np.random.default_rng(12)
     tv = synth.two_view_homography_matches(3, seed=31, n_min=20, n_max=40, tiny_frac=0.0, no_geometry_frac=0.0)
@@ -74,6 +104,15 @@ def test_emulated_indexed_form_equals_the_gathered_form():
         m1, r1, _ = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], FUNCTOR(4.0, 256))
         m2, r2, _ = geofilter.filter_pairs_indexed(feats, np.array(sizes), np.array(pairs), tv["start"], np.concatenate(ij), FUNCTOR(4.0, 256))
     assert np.array_equal(m1, m2) and np.array_equal(r1["F"], r2["F"]) and np.array_equal(r1["nfa"], r2["nfa"]) and r1["ok"].all()
+
+
+@pytest.mark.gpu
+def test_samples_ahead_equal_one_sample_per_iteration_on_the_device():
+    tv, _ = _gold_tv()
+    _samples_ahead_equal_one_sample_per_iteration(tv, 2048, aheads=("4", "2"))
+    _samples_ahead_equal_one_sample_per_iteration(tv, 37, aheads=("4",))
+    big = synth.two_view_homography_matches(120, seed=4712, n_min=8, n_max=14000, tiny_frac=0.0)   # every size class, the global-table class included
+    _samples_ahead_equal_one_sample_per_iteration(big, 1024, aheads=("4",))
 
 
 @pytest.mark.gpu
