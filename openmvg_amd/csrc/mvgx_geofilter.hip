@@ -735,36 +735,29 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
     const int idx0 = mt_idx;
     if (ac_mode) {
       if (pool_size >= (uint32_t)kMin) {   // else UniformSample returns false and vec_sample keeps its values
+        // element i is exchanged with element jx_i in [i, last]: the draws do not depend on the pool, so they come first (a revoked
+        // sample has touched nothing but the index); one lane then makes the exchanges in order (its LDS operations complete in
+        // order: no rendezvous between them), and element i is final once exchange i is done (later ones touch elements >= their own i)
         const uint32_t last = pool_size - 1;
-        uint32_t swapped[kMin];
-        int n_swapped = 0;
+        uint32_t jx[kMin];
         bool ok = true;
 #pragma unroll
         for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
-          uint32_t jx = 0;
-          ok = ok && uniform_try_u32(mt, mt_idx, lane, i, last, may_twist, jx);
-          if (ok) {   // (wave-uniform)
-            const uint32_t vi = pool[i], vj = pool[jx];
-            wave_sync();
-            if (lane == 0) { pool[i] = vj; pool[jx] = vi; }
-            wave_sync();
-            s[i] = vj;
-            swapped[i] = jx; n_swapped = (int)i + 1;
-          }
+          jx[i] = 0;
+          ok = ok && uniform_try_u32(mt, mt_idx, lane, i, last, may_twist, jx[i]);
         }
-        if (!ok) {   // the exchanges made so far, undone in reverse order
+        if (!ok) { mt_idx = idx0; return false; }
+        if (lane == 0) {
 #pragma unroll
-          for (int i = kMin - 1; i >= 0; --i) {
-            if (i < n_swapped) {
-              const uint32_t vi = pool[i], vj = pool[swapped[i]];
-              wave_sync();
-              if (lane == 0) { pool[i] = vj; pool[swapped[i]] = vi; }
-              wave_sync();
-            }
+          for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
+            const uint32_t vi = pool[i], vj = pool[jx[i]];
+            pool[i] = vj; pool[jx[i]] = vi;
           }
-          mt_idx = idx0;
-          return false;
         }
+        wave_sync();
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)kMin; ++i) s[i] = pool[i];
+        wave_sync();   // (read before the next sample's exchanges)
       }
     } else {
       int got = 0;
