@@ -30,6 +30,9 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <type_traits>
 #include <typeinfo>
@@ -61,7 +64,10 @@ constexpr uint64_t kPairsPerCall = 1u << 16;   // cancellation / progress granul
 
 template <class F>
 void on_host_threads(size_t n, F f) {   // f(index) for every index, indices handed out dynamically
-  const unsigned threads = (unsigned)std::min<size_t>(n, std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+  // (MVGX_ADAPTER_THREADS sets another limit than 32: the std::set work of the de-duplication is bound by the allocator - 128 threads
+  // were measured 30 % slower than 32 on a 256-thread host, call r5_34)
+  static const unsigned limit = [] { const char* e = std::getenv("MVGX_ADAPTER_THREADS"); const int v = e ? std::atoi(e) : 32; return (unsigned)std::max(1, v); }();
+  const unsigned threads = (unsigned)std::min<size_t>(n, std::max(1u, std::min(limit, std::thread::hardware_concurrency())));
   if (threads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
   std::atomic<size_t> next{0};
   auto body = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); };
@@ -83,7 +89,11 @@ struct View {
 
 // the reference's last two steps on one pair's putative list (entries (index in I, index in J))
 void deduplicate(matching::IndMatches& v, const std::vector<features::PointFeature>& posI, const std::vector<features::PointFeature>& posJ) {
-  matching::IndMatch::getDeduplicated(v);
+  // IndMatch::getDeduplicated = the list through a std::set<IndMatch> (ordered by (i, j)) and back: the identity on a strictly
+  // increasing list - what the device delivers (one entry per query row, in row order) - so the set is only built when it is not
+  bool increasing = true;
+  for (size_t k = 1; k < v.size() && increasing; ++k) increasing = v[k - 1] < v[k];
+  if (!increasing) matching::IndMatch::getDeduplicated(v);
   matching::IndMatchDecorator<float> by_position(v, posI, posJ);
   by_position.getDeduplicated(v);
 }
@@ -284,16 +294,27 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   }
   const float ratio_sq = Square(dist_ratio);
   const uint64_t n_pairs = todo.size();
+  // MVGX_ADAPTER_TIMING=1: wall time of the three things this loop does, on stderr at the end (device stage | the reference's two
+  // de-duplication classes on the host threads | the container, filled by this thread). Measured at 1 000 images x 2 000 (call r5_33):
+  // 0.44 | 1.45 | 0.02 s. The de-duplication is the reference's own std::set work and bound by the allocator (more threads: slower);
+  // running the next batch on the device meanwhile was built and gains nothing (the device stage has host work of its own: call r5_35).
+  const bool timing = std::getenv("MVGX_ADAPTER_TIMING") != nullptr;
+  double t_dev = 0.0, t_dedup = 0.0, t_fill = 0.0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   for (uint64_t p0 = 0; !failed && p0 < n_pairs; p0 += kPairsPerCall) {
     if (progress->hasBeenCanceled()) break;
     const uint64_t nb = std::min<uint64_t>(kPairsPerCall, n_pairs - p0);
     inj = injected("cascade", "run");
+    auto t0 = now();
     if (!inj) rc = mvgx_cascade_run(ctx.c, dev_pairs.data() + 2 * p0, nb, ratio_sq, nullptr);
+    t_dev += since(t0);
     if (!step("run", rc, inj)) break;
     const uint64_t* offsets = nullptr;
     const uint32_t* ij = nullptr;
     mvgx_cascade_results(ctx.c, &offsets, &ij);
     std::vector<matching::IndMatches> lists(nb);
+    t0 = now();
     on_host_threads((size_t)((nb + 255) / 256), [&](size_t chunk) {
       for (uint64_t k = chunk * 256, hi = std::min<uint64_t>(nb, k + 256); k < hi; ++k) {
         const uint64_t lo = offsets[k], n = offsets[k + 1] - lo;
@@ -304,11 +325,17 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
         deduplicate(v, view_of[dev_pairs[2 * (p0 + k)]]->positions, view_of[dev_pairs[2 * (p0 + k) + 1]]->positions);
       }
     });
+    t_dedup += since(t0);
+    t0 = now();
     for (uint64_t k = 0; k < nb; ++k)
       if (!lists[k].empty()) out.insert({todo[p0 + k], std::move(lists[k])});
+    t_fill += since(t0);
     (*progress) += (uint32_t)nb;
     delivered = p0 + nb;
   }
+  if (timing)
+    std::fprintf(stderr, "[mvgx cascade adapter] %llu pairs: device stage %.3f s | lists + de-duplication (host threads) %.3f s | container %.3f s\n",
+                 (unsigned long long)delivered, t_dev, t_dedup, t_fill);
   mvgx_adapter::counters().device_pairs.fetch_add(delivered);
   if (failed && !progress->hasBeenCanceled()) {
     if (!hashed_on_host) hash_on_host();
