@@ -4529,9 +4529,30 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         bool sg_open = false;
         uint32_t cur_obs = 0;   // observations of `cur`
         auto local = [](const std::vector<uint32_t>& v, uint32_t id) { return (int)(std::lower_bound(v.begin(), v.end(), id) - v.begin()); };
+        // which destination blocks the supergroup under construction has: a point with local poses P and local intrinsics K marks every
+        // (x <= y) of P x P, every (x, k) of P x K, every (k <= k') of K x K. Collected as bit rows (a few ORs per point; marking the
+        // flags themselves was |P|^2 stores per point and a third of this phase) and written out when the supergroup is complete.
+        uint16_t acc_pp[kGroupCams] = {0}, acc_pi[kGroupCams] = {0}, acc_ii[kGroupIntr] = {0};
+        static_assert(kGroupCams <= 16 && kGroupIntr <= 16, "bit rows of the destination-block flags");
+        bool acc_open = false;
+        auto flush_flags = [&]() {
+          if (!acc_open) return;
+          const size_t sgi = B.sg_n.size() - 1;
+          for (int x = 0; x < kGroupCams; ++x) {
+            for (int y = x; y < kGroupCams; ++y) if ((acc_pp[x] >> y) & 1u) B.pp[sgi * kGroupPairsPP + x * kGroupCams - x * (x - 1) / 2 + (y - x)] = 1;
+            for (int k = 0; k < kGroupIntr; ++k) if ((acc_pi[x] >> k) & 1u) B.pi[sgi * kGroupPairsPI + x * kGroupIntr + k] = 1;
+            acc_pp[x] = 0; acc_pi[x] = 0;
+          }
+          for (int k = 0; k < kGroupIntr; ++k) {
+            for (int k2 = k; k2 < kGroupIntr; ++k2) if ((acc_ii[k] >> k2) & 1u) B.ii[sgi * kGroupPairsII + k * kGroupIntr - k * (k - 1) / 2 + (k2 - k)] = 1;
+            acc_ii[k] = 0;
+          }
+          acc_open = false;
+        };
         // emits `cur` as a group of the open supergroup (same camera / intrinsic sets) or as the first group of a new one
         auto emit_group = [&](bool continues) {
           if (!continues) {
+            flush_flags();   // (of the supergroup before)
             B.sg_n.push_back(0);
             const size_t sgi = B.sg_n.size() - 1;
             B.cams.resize((sgi + 1) * kGroupCams, 0); B.intrs.resize((sgi + 1) * kGroupIntr, 0);
@@ -4561,13 +4582,12 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
                 n_k0 += k == 0;
               }
             B.nk0.push_back(n_k0);
-            for (int a = 0; a < nx; ++a)
-              for (int b2 = 0; b2 < nx; ++b2) {
-                if (xs[a] <= xs[b2]) B.pp[sgi * kGroupPairsPP + xs[a] * kGroupCams - xs[a] * (xs[a] - 1) / 2 + (xs[b2] - xs[a])] = 1;
-                B.pi[sgi * kGroupPairsPI + xs[a] * kGroupIntr + ks[b2]] = 1;
-                if (ks[a] <= ks[b2]) B.ii[sgi * kGroupPairsII + ks[a] * kGroupIntr - ks[a] * (ks[a] - 1) / 2 + (ks[b2] - ks[a])] = 1;
-              }
+            uint16_t cm = 0, km = 0;
+            for (int a = 0; a < nx; ++a) { cm |= (uint16_t)(1u << xs[a]); km |= (uint16_t)(1u << ks[a]); }
+            for (int a = 0; a < nx; ++a) { acc_pp[xs[a]] |= cm; acc_pi[xs[a]] |= km; acc_ii[ks[a]] |= km; }
+            acc_open = true;
           }
+          (void)sgi;
           B.obs_n.push_back(n_obs_g);
           B.pt_n.push_back((uint32_t)cur.size());
         };
@@ -4597,6 +4617,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           cur.push_back(j); cur_obs += (uint32_t)npc;
         }
         close_group();
+        flush_flags();
       });
       tick("  greedy groups per bucket");
       // the buckets' groups stitched in bucket order: offsets from a serial prefix over the buckets, copies on host threads
