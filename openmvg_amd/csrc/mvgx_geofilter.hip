@@ -1088,7 +1088,7 @@ inline void inverse3(const double* m, double* inv) {
 
 // the launches of the five size classes (largest pairs first) for one model
 template <int MODEL>
-int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const std::vector<GeoPair>& hp, uint32_t c4, uint32_t c3,
+int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const GeoPair* hp, uint32_t c4, uint32_t c3,
                    uint32_t c2, uint32_t c1, const uint32_t (&caps)[4], const double2* px1, const double2* px2, const float* l10, const uint32_t* mt,
                    uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr,
                    uint32_t ahead = 1) {
@@ -1150,8 +1150,16 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   int rc = mvgx::select_device(device < 0 ? -1 : device);
   if (rc) return rc;
   // ---- host preparation (ACKernelAdaptor's constructor + NFA_Interface's constants), on host threads ----
-  std::vector<GeoPair> hp(n_pairs);
-  std::vector<double> norm(n_pairs * 6);   // {s1, tx1, ty1, s2, tx2, ty2}; the points are normalised on the device
+  // (page-locked memory from the library's cache, not zeroed - every field of every pair is written below: a fresh std::vector of
+  // 100 000 pairs was 50 MB of page faults per call, two thirds of this phase; the uploads from it are asynchronous DMA)
+  mvgx::HostArena host_mem;
+  GeoPair* hp = nullptr;
+  double* norm = nullptr;   // {s1, tx1, ty1, s2, tx2, ty2}; the points are normalised on the device
+  GeoResult* hr = nullptr;
+  if ((rc = host_mem.array(&hp, std::max<uint64_t>(n_pairs, 1))) || (rc = host_mem.array(&norm, std::max<uint64_t>(n_pairs, 1) * 6)) ||
+      (rc = host_mem.array(&hr, std::max<uint64_t>(n_pairs, 1))))
+    return rc;
+  const size_t norm_size = n_pairs * 6;
   uint32_t n_max = 0;
   for (uint64_t p = 0; p < n_pairs; ++p) n_max = std::max<uint32_t>(n_max, (uint32_t)(match_start[p + 1] - match_start[p]));
   const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, (size_t)(n_pairs / 4096 + 1)}));
@@ -1170,6 +1178,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
         if (bad) bad_pair.store((int64_t)p);
       }
       double t[2][3] = {{1.0, 0.0, 0.0}, {1.0, 0.0, 0.0}};
+      if (angular) for (int k = 0; k < 6; ++k) norm[6 * p + k] = 0.0;   // (uploaded, never read: no uninitialised bytes on the wire)
       for (int im = 0; im < 2 && !angular; ++im) {   // conditioning.cpp:44-53
         const uint32_t* whp = src.indexed ? image_wh + 2 * (size_t)src.pair_images[2 * p + im] : image_wh + 4 * p + 2 * im;
         const int w = (int)whp[0], h = (int)whp[1];
@@ -1239,6 +1248,11 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   mt_init[0] = 5489u;
   for (int i = 1; i < kMtN; ++i) mt_init[i] = 1812433253u * (mt_init[i - 1] ^ (mt_init[i - 1] >> 30)) + (uint32_t)i;
   const auto t_prep = std::chrono::steady_clock::now();
+  // MVGX_GEO_TIMING=1: where a call's time goes, on stderr (host preparation | device memory | uploads issued | kernels + downloads | results)
+  const bool timing = getenv("MVGX_GEO_TIMING") != nullptr;
+  auto t_mark = t_prep;
+  double t_phase[4] = {0, 0, 0, 0};
+  auto mark = [&](int k) { const auto t = std::chrono::steady_clock::now(); t_phase[k] += std::chrono::duration<double, std::milli>(t - t_mark).count(); t_mark = t; };
   // ---- device ----
   hipStream_t stream = nullptr;
   if ((rc = mvgx::acquire_stream(&stream))) return rc;
@@ -1250,7 +1264,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   const uint64_t n_xy = angular ? 0 : n_total;   // (the angular models never touch pixel positions)
   if ((rc = d_pairs.alloc(n_pairs * sizeof(GeoPair))) || (rc = d_order.alloc(order.size() * sizeof(uint32_t))) || (rc = d_x1.alloc(n_xy * sizeof(double2))) ||
       (rc = d_x2.alloc(n_xy * sizeof(double2))) || (rc = d_l10.alloc(l10.size() * sizeof(float))) || (rc = d_mt.alloc(sizeof(mt_init))) ||
-      (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_norm.alloc(norm.size() * sizeof(double))))
+      (rc = d_res.alloc(n_pairs * sizeof(GeoResult))) || (rc = d_mask.alloc(n_total)) || (rc = d_norm.alloc(norm_size * sizeof(double))))
     return rc;
   if (src.indexed) {   // d_raw1: the index pairs
     if ((rc = d_raw1.alloc(n_total * sizeof(uint2))) || (rc = d_feat.alloc((angular ? 0 : n_feat) * sizeof(double2))) ||
@@ -1263,11 +1277,12 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     if ((rc = d_b1.alloc(n_total * 3 * sizeof(double))) || (rc = d_b2.alloc(n_total * 3 * sizeof(double)))) return rc;
     if (src.indexed && (rc = d_fbear.alloc(n_feat * 3 * sizeof(double)))) return rc;
   }
+  mark(0);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   MVGX_HIP(hipEventCreate(&e0));
   MVGX_HIP(hipEventCreate(&e1));
   struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
-  if (n_pairs) MVGX_HIP(hipMemcpyAsync(d_pairs.p, hp.data(), n_pairs * sizeof(GeoPair), hipMemcpyHostToDevice, stream));
+  if (n_pairs) MVGX_HIP(hipMemcpyAsync(d_pairs.p, hp, n_pairs * sizeof(GeoPair), hipMemcpyHostToDevice, stream));
   if (!order.empty()) MVGX_HIP(hipMemcpyAsync(d_order.p, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   if (n_total) {
     if (src.indexed) {
@@ -1279,7 +1294,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
       MVGX_HIP(hipMemcpyAsync(d_raw1.p, src.xI, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
       MVGX_HIP(hipMemcpyAsync(d_raw2.p, src.xJ, n_total * sizeof(double2), hipMemcpyHostToDevice, stream));
     }
-    MVGX_HIP(hipMemcpyAsync(d_norm.p, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemcpyAsync(d_norm.p, norm, norm_size * sizeof(double), hipMemcpyHostToDevice, stream));
     MVGX_HIP(hipMemsetAsync(d_mask.p, 0, n_total, stream));
     if (bearings) {
       if (src.indexed) {
@@ -1294,6 +1309,7 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   MVGX_HIP(hipMemcpyAsync(d_mt.p, mt_init, sizeof(mt_init), hipMemcpyHostToDevice, stream));
   if (n_pairs) MVGX_HIP(hipMemsetAsync(d_res.p, 0, n_pairs * sizeof(GeoResult), stream));
   MVGX_HIP(hipEventRecord(e0, stream));
+  mark(1);
   const uint32_t* ord = static_cast<const uint32_t*>(d_order.p);
   const auto* px1 = static_cast<const double2*>(d_x1.p);
   const auto* px2 = static_cast<const double2*>(d_x2.p);
@@ -1341,10 +1357,10 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     if (rc) return rc;
   }
   MVGX_HIP(hipEventRecord(e1, stream));
-  std::vector<GeoResult> hr(n_pairs);
-  if (n_pairs) MVGX_HIP(hipMemcpyAsync(hr.data(), d_res.p, n_pairs * sizeof(GeoResult), hipMemcpyDeviceToHost, stream));
+  if (n_pairs) MVGX_HIP(hipMemcpyAsync(hr, d_res.p, n_pairs * sizeof(GeoResult), hipMemcpyDeviceToHost, stream));
   if (n_total) MVGX_HIP(hipMemcpyAsync(inlier_mask, d_mask.p, n_total, hipMemcpyDeviceToHost, stream));
   MVGX_HIP(hipStreamSynchronize(stream));
+  mark(2);
   float kernel_ms = 0.f;
   (void)hipEventElapsedTime(&kernel_ms, e0, e1);
   // ---- results in the reference's terms: Unnormalize (conditioning.cpp:87-89), unormalizeError, the 2.5 x 7 acceptance ----
@@ -1392,6 +1408,11 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   if (stats) {
     stats->n_pairs = n_pairs; stats->n_pairs_estimated = order.size(); stats->n_pairs_ok = n_ok; stats->n_inliers = n_inl;
     stats->kernel_ms = kernel_ms;
+    mark(3);
+    if (timing)
+      fprintf(stderr, "[mvgx geofilter] %llu pairs, %llu matches: host preparation %.2f ms | device memory %.2f | uploads issued %.2f | kernels + downloads %.2f (kernels %.2f) | results %.2f\n",
+              (unsigned long long)n_pairs, (unsigned long long)n_total, std::chrono::duration<double, std::milli>(t_prep - t_begin).count(), t_phase[0], t_phase[1], t_phase[2],
+              (double)kernel_ms, t_phase[3]);
     stats->host_prepare_ms = std::chrono::duration<double, std::milli>(t_prep - t_begin).count();
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     stats->n_iterations = n_iter; stats->n_models = n_mod; stats->wave_clocks = clocks;
