@@ -49,6 +49,7 @@ __device__ __forceinline__ double g_sub(double a, double b) { return __dadd_rn(a
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
+constexpr int kQueue = 16;   // right features a lane queues for the descriptor stage before the wave drains the queues (LDS: 16 KB per workgroup)
 
 struct GuidedParams {
   const double2* xy;          // undistorted positions, all images
@@ -104,12 +105,9 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
       a0 = v0 / v2; a1 = v1 / v2; a2 = 0.0;
     }
   }
-  uint32_t mine[DW];
-  {
-    const uint32_t* __restrict__ row = P.desc + (fI + (active ? i : 0)) * DW;
-#pragma unroll
-    for (int k = 0; k < DW; ++k) mine[k] = row[k];
-  }
+  // (this lane's descriptor row stays in memory: held in registers across the test loop - 32 of them - it halved the waves per SIMD, and
+  // the test loop lives on occupancy; a drain step reads both rows 16 bytes at a time while the other waves run their tests)
+  const uint4* __restrict__ lrow = reinterpret_cast<const uint4*>(P.desc + (fI + (active ? i : 0)) * DW);
   const int na = P.norm[fI + (active ? i : 0)];
   int bd = INT_MAX, sbd = INT_MAX;
   uint32_t idx = 0;
@@ -133,33 +131,58 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
       return g_add(g_mul(dx, dx), g_mul(dy, dy)) < th;
     }
   };
-  auto descriptor_stage = [&](uint32_t j, bool pass) {
-    n_stage += 1;
-    unsigned dot = 0;
-    const uint32_t* __restrict__ rj = descJ + (size_t)j * DW;
+  // The descriptor stage, dense (round 5, second form). 0.4 % of the geometric tests pass under a fundamental matrix: a wave that looked at
+  // a right feature's descriptor as soon as ANY of its lanes passed ran that stage for 1.1 useful lanes of 64, in two of three groups of
+  // four right features - the larger half of the kernel. Instead every lane queues the right features that passed ITS test (a column of
+  // kQueue words in LDS, filled in index order), and when a column is nearly full - or at the end - the wave drains the queues: step k,
+  // every lane with more than k entries takes the distance to ITS k-th candidate (its row gathered through the vector memory path, 16 bytes
+  // at a time) and updates its best / second best. A lane still walks its candidates in index order - distanceRatio's update depends on
+  // nothing else - so the lists are the same; a drain step has ~30 useful lanes instead of 1.1 and there are ~50 x fewer of them.
+  __shared__ uint32_t queue_lds[kQueue * kThreads];
+  uint32_t* const q = queue_lds + (threadIdx.x >> 6) * (kQueue * 64) + (threadIdx.x & 63);   // entry k of this lane: q[64 k]
+  uint32_t n_q = 0;
+  auto drain = [&]() {
+    uint32_t most = n_q;
 #pragma unroll
-    for (int k = 0; k < DW; ++k) dot = __builtin_amdgcn_udot4(mine[k], rj[k], dot, false);
-    const int d = na + normJ[j] - 2 * (int)dot;
-    if (pass) {
-      n_pass += 1;
-      if (d < bd) { sbd = bd; bd = d; idx = j; }
-      else if (d < sbd) sbd = d;
+    for (int off = 32; off > 0; off >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, off));
+    for (uint32_t k = 0; k < most; ++k) {   // (wave-uniform bound)
+      n_stage += 1;
+      if (k < n_q) {
+        const uint32_t j = q[64 * k];
+        const uint4* __restrict__ rj = reinterpret_cast<const uint4*>(descJ + (size_t)j * DW);
+        unsigned dot = 0;
+#pragma unroll 2
+        for (int k4 = 0; k4 < DW / 4; ++k4) {
+          const uint4 l = lrow[k4], r = rj[k4];
+          dot = __builtin_amdgcn_udot4(l.x, r.x, dot, false);
+          dot = __builtin_amdgcn_udot4(l.y, r.y, dot, false);
+          dot = __builtin_amdgcn_udot4(l.z, r.z, dot, false);
+          dot = __builtin_amdgcn_udot4(l.w, r.w, dot, false);
+        }
+        const int d = na + normJ[j] - 2 * (int)dot;
+        n_pass += 1;
+        if (d < bd) { sbd = bd; bd = d; idx = j; }
+        else if (d < sbd) sbd = d;
+      }
     }
+    n_q = 0;
   };
+  static_assert(DW % 4 == 0, "descriptor rows are read 16 bytes at a time");
   uint32_t j = 0;
   for (; j + 4 <= nJ; j += 4) {
     const double2 y0 = xyJ[j], y1 = xyJ[j + 1], y2 = xyJ[j + 2], y3 = xyJ[j + 3];   // (wave-uniform: scalar loads)
     const bool p0 = active && geometric(y0), p1 = active && geometric(y1), p2 = active && geometric(y2), p3 = active && geometric(y3);
-    if (__ballot(p0 || p1 || p2 || p3) == 0ull) continue;   // (uniform)
-    if (__ballot(p0)) descriptor_stage(j, p0);
-    if (__ballot(p1)) descriptor_stage(j + 1, p1);
-    if (__ballot(p2)) descriptor_stage(j + 2, p2);
-    if (__ballot(p3)) descriptor_stage(j + 3, p3);
+    if (p0) { q[64 * n_q] = j; ++n_q; }
+    if (p1) { q[64 * n_q] = j + 1; ++n_q; }
+    if (p2) { q[64 * n_q] = j + 2; ++n_q; }
+    if (p3) { q[64 * n_q] = j + 3; ++n_q; }
+    if (__ballot(n_q + 4 > (uint32_t)kQueue)) drain();   // (uniform) some column could not take another group
   }
   for (; j < nJ; ++j) {
-    const bool pass = active && geometric(xyJ[j]);
-    if (__ballot(pass)) descriptor_stage(j, pass);
+    if (active && geometric(xyJ[j])) { q[64 * n_q] = j; ++n_q; }
+    if (__ballot(n_q + 4 > (uint32_t)kQueue)) drain();
   }
+  drain();
   const bool valid = active && sbd != INT_MAX && (double)bd < P.ratio_sq * (double)sbd;
   if (active) P.best[P.left_start[p] + i] = valid ? idx : kNone;
   const unsigned long long m = __ballot(valid);
@@ -200,8 +223,8 @@ struct DevArray {
   DevArray() = default;
   DevArray(const DevArray&) = delete;   // (a launch must be handed the raw pointer: the test-suite's emulation captures launch arguments by value)
   DevArray& operator=(const DevArray&) = delete;
-  ~DevArray() { if (p) (void)hipFree(p); }
-  int alloc(size_t n) { MVGX_HIP(mvgx::device_malloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T))); return MVGX_OK; }
+  // (from the call's arena - slabs of the library's device cache: fourteen hipMalloc / hipFree pairs per call were up to 23 ms of it)
+  int alloc(mvgx::Arena& a, size_t n) { return a.alloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
 template <int KIND, int DW>
@@ -254,11 +277,12 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   struct StreamGuard { int d; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(d, s); } } guard{dev, stream};
 
   const int DW = (int)desc_bytes / 4;
+  mvgx::Arena arena;   // device memory of this call
   DevArray<double2> d_xy; DevArray<uint32_t> d_desc; DevArray<int> d_norm; DevArray<uint64_t> d_fs, d_ls, d_ms; DevArray<uint32_t> d_pairs, d_best, d_count, d_ij;
   DevArray<double> d_models, d_th; DevArray<uint2> d_work; DevArray<unsigned long long> d_ctr;
-  if ((rc = d_xy.alloc(n_feat)) || (rc = d_desc.alloc(n_feat * DW)) || (rc = d_norm.alloc(n_feat)) || (rc = d_fs.alloc(n_images + 1)) || (rc = d_ls.alloc(n_pairs + 1)) ||
-      (rc = d_ms.alloc(n_pairs + 1)) || (rc = d_pairs.alloc(2 * n_pairs)) || (rc = d_best.alloc(left_start[n_pairs])) || (rc = d_count.alloc(n_pairs)) ||
-      (rc = d_models.alloc(9 * n_pairs)) || (rc = d_th.alloc(n_pairs)) || (rc = d_work.alloc(work.size())) || (rc = d_ctr.alloc(2)))
+  if ((rc = d_xy.alloc(arena, n_feat)) || (rc = d_desc.alloc(arena, n_feat * DW)) || (rc = d_norm.alloc(arena, n_feat)) || (rc = d_fs.alloc(arena, n_images + 1)) || (rc = d_ls.alloc(arena, n_pairs + 1)) ||
+      (rc = d_ms.alloc(arena, n_pairs + 1)) || (rc = d_pairs.alloc(arena, 2 * n_pairs)) || (rc = d_best.alloc(arena, left_start[n_pairs])) || (rc = d_count.alloc(arena, n_pairs)) ||
+      (rc = d_models.alloc(arena, 9 * n_pairs)) || (rc = d_th.alloc(arena, n_pairs)) || (rc = d_work.alloc(arena, work.size())) || (rc = d_ctr.alloc(arena, 2)))
     return rc;
   if (n_feat) {
     MVGX_HIP(hipMemcpyAsync(d_xy.p, feat_xy, n_feat * sizeof(double2), hipMemcpyHostToDevice, stream));
@@ -305,7 +329,7 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   uint32_t* out = static_cast<uint32_t*>(malloc(std::max<uint64_t>(total, 1) * 2 * sizeof(uint32_t)));
   MVGX_REQUIRE(out, MVGX_ERR_HIP, "mvgx_guided_match_u8: out of host memory (%llu matches)", (unsigned long long)total);
   if (total) {
-    if ((rc = d_ij.alloc(2 * total))) { free(out); return rc; }
+    if ((rc = d_ij.alloc(arena, 2 * total))) { free(out); return rc; }
     hipError_t e = hipMemcpyAsync(d_ms.p, match_start, (n_pairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
       const uint32_t *const pb = d_best.p, *const pp = d_pairs.p;
@@ -314,8 +338,14 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
       hipLaunchKernelGGL(guided_compact_kernel, dim3((unsigned)n_pairs), dim3(64), 0, stream, pb, pl, pf, pp, pm, po);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_ij.p, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    // (through page-locked memory of the library's cache: a copy straight into the fresh malloc block pins its pages on the way - up to
+    // 20 ms for 16 MB, every few calls)
+    mvgx::HostArena staging;
+    uint32_t* pinned = nullptr;
+    if (e == hipSuccess && staging.array(&pinned, 2 * total) != MVGX_OK) pinned = nullptr;
+    if (e == hipSuccess) e = hipMemcpyAsync(pinned ? pinned : out, d_ij.p, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && pinned) std::memcpy(out, pinned, 2 * total * sizeof(uint32_t));
     if (e != hipSuccess) { free(out); set_error("mvgx_guided_match_u8: %s", hipGetErrorString(e)); return MVGX_ERR_HIP; }
   }
   *matches_ij = out;
