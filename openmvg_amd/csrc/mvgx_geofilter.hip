@@ -731,6 +731,25 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
   // One sample from the generator and the pool as they stand (rand_sampling.hpp), into s. may_twist == false - a sample drawn AHEAD of
   // the iteration that will use it (essential model, below): a draw that would twist the generator's state is revoked - index and pool as
   // they were, s undefined - and false comes back.
+  // The kMin draws of a sample side by side: lane i < kMin takes word idx + i of the generator's state, tempers it and scales it to its
+  // range [lo_i, hi] exactly as uniform_int_distribution does (product >> 32); out[i] = the value of lane i. Only when every draw is
+  // accepted at once - the distribution rejects a word with probability range / 2^32 - and the state holds kMin more words; else false
+  // and nothing has changed (the caller then draws one after the other: twists, rejections and all).
+  auto draw_together = [&](uint32_t lo_step, uint32_t hi, uint32_t (&out)[kMin]) -> bool {
+    if (mt_idx + kMin > kMtN) return false;
+    const uint32_t i = (uint32_t)lane < (uint32_t)kMin ? (uint32_t)lane : 0u;
+    const uint32_t lo = lo_step * i;                 // (a-contrario mode: element i is exchanged with one of [i, last]; warm-up: all from [0, n - 1])
+    uint32_t y = mt[mt_idx + (int)i];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    const uint32_t range = hi - lo + 1;              // (never 2^32 here: hi < n)
+    const uint64_t product = (uint64_t)y * range;
+    if (__ballot((uint32_t)lane < (uint32_t)kMin && (uint32_t)product < range)) return false;   // (a word the distribution might reject: the exact path decides)
+    const uint32_t v = (uint32_t)(product >> 32) + lo;
+#pragma unroll
+    for (int k = 0; k < kMin; ++k) out[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+    mt_idx += kMin;
+    return true;
+  };
   auto draw_sample = [&](bool may_twist) -> bool {
     const int idx0 = mt_idx;
     if (ac_mode) {
@@ -740,13 +759,15 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
         // order: no rendezvous between them), and element i is final once exchange i is done (later ones touch elements >= their own i)
         const uint32_t last = pool_size - 1;
         uint32_t jx[kMin];
-        bool ok = true;
+        if (!draw_together(1u, last, jx)) {
+          bool ok = true;
 #pragma unroll
-        for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
-          jx[i] = 0;
-          ok = ok && uniform_try_u32(mt, mt_idx, lane, i, last, may_twist, jx[i]);
+          for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
+            jx[i] = 0;
+            ok = ok && uniform_try_u32(mt, mt_idx, lane, i, last, may_twist, jx[i]);
+          }
+          if (!ok) { mt_idx = idx0; return false; }
         }
-        if (!ok) { mt_idx = idx0; return false; }
         if (lane == 0) {
 #pragma unroll
           for (uint32_t i = 0; i < (uint32_t)kMin; ++i) {
@@ -760,6 +781,22 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
         wave_sync();   // (read before the next sample's exchanges)
       }
     } else {
+      // warm-up: kMin distinct indices of [0, n - 1], a repeated one drawn again - side by side when the first kMin draws are distinct
+      // (which they are 9 times in 10 at 250 correspondences), one after the other otherwise
+      uint32_t c[kMin];
+      if (draw_together(0u, n - 1, c)) {
+        bool distinct = true;
+#pragma unroll
+        for (int a = 1; a < kMin; ++a)
+#pragma unroll
+          for (int b = 0; b < a; ++b) distinct = distinct && c[a] != c[b];
+        if (distinct) {
+#pragma unroll
+          for (int k = 0; k < kMin; ++k) s[k] = c[k];
+          return true;
+        }
+        mt_idx = idx0;   // (the exact path from the same words)
+      }
       int got = 0;
       while (got < kMin) {
         uint32_t cand = 0;
