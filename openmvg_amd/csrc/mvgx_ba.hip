@@ -4345,11 +4345,12 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   c->n_obs_rmse_all = n_rmse;
   tick("sort by point + gather");
   std::vector<uint8_t> pose_used(d.n_poses, 0), intr_used(d.n_intr, 0), pt_free(d.n_pts, 0);
-  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {   // (concurrent stores of the same value 1)
+  parallel_for_dynamic(n_grains, 1, T, [&](size_t g, unsigned) {   // (concurrent stores of the same value 1: relaxed atomic accesses)
+    auto set_flag = [](uint8_t& f) { if (!__atomic_load_n(&f, __ATOMIC_RELAXED)) __atomic_store_n(&f, (uint8_t)1, __ATOMIC_RELAXED); };
     for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {
-      if (!pose_used[opose[k]]) pose_used[opose[k]] = 1;
-      if (!intr_used[ointr[k]]) intr_used[ointr[k]] = 1;
-      if (!pt_free[opt_[k]]) pt_free[opt_[k]] = 1;
+      set_flag(pose_used[opose[k]]);
+      set_flag(intr_used[ointr[k]]);
+      set_flag(pt_free[opt_[k]]);
     }
   });
   for (uint32_t k = 0; k < d.n_priors; ++k) pose_used[p->prior_pose[k]] = 1;
@@ -5027,10 +5028,12 @@ static int ba_update_impl(mvgx_ba_ctx* c, const mvgx_ba_problem* p, const uint8_
         for (uint64_t k = g * kGrain, e = std::min<uint64_t>(no, (g + 1) * kGrain); k < e; ++k) {   // k: position in point order; s_: the caller's index
           const uint64_t s_ = c->h_perm.empty() ? k : c->h_perm[k];
           if (obs_enabled[s_]) {
-            // (read before write: a few hundred flag bytes stored to by every thread for every observation bounce between the cores)
-            if (!pose_used_sub[p->obs_pose[s_]]) pose_used_sub[p->obs_pose[s_]] = 1;
-            if (!intr_used_sub[p->obs_intr[s_]]) intr_used_sub[p->obs_intr[s_]] = 1;
-            if (!pt_seen[p->obs_point[s_]]) pt_seen[p->obs_point[s_]] = 1;
+            // (read before write: a few hundred flag bytes stored to by every thread for every observation bounce between the cores;
+            // relaxed atomic accesses: several host threads set the same byte - the only value it ever receives is 1)
+            auto set_flag = [](uint8_t& f) { if (!__atomic_load_n(&f, __ATOMIC_RELAXED)) __atomic_store_n(&f, (uint8_t)1, __ATOMIC_RELAXED); };
+            set_flag(pose_used_sub[p->obs_pose[s_]]);
+            set_flag(intr_used_sub[p->obs_intr[s_]]);
+            set_flag(pt_seen[p->obs_point[s_]]);
             n += (p->obs_is_control && p->obs_is_control[s_]) ? 0.0 : 1.0;
           } else {
             odis[k] = 1; any = true;
