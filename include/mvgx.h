@@ -35,7 +35,8 @@ int mvgx_device_count(int* count);
 /* abi version, bumped on any signature or struct-layout change (2: mvgx_ba_problem control points / priors;
  * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream; 5: geometric filter; 6: indexed filter entry,
  * cascade hashing on the device; 7: homography model of the geometric filter; 8: iteration / clock counters in
- * mvgx_geofilter_stats, essential-matrix model of the geometric filter) */
+ * mvgx_geofilter_stats, essential-matrix model of the geometric filter; 9: mvgx_host_parallel_for; 10: guided matching;
+ * 11: mvgx_cascade_hash_regions_typed) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -227,6 +228,13 @@ int mvgx_cascade_set_regions_typed(mvgx_cascade_ctx* ctx, int scalar_type, const
 int mvgx_cascade_hash_regions(mvgx_cascade_ctx* ctx, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
                               const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
                               uint8_t* const* hash_codes_out /* may be NULL */, uint16_t* const* bucket_ids_out /* may be NULL */);
+/* The same for every shape the device covers (ABI 11): scalar_type 0 = uint8 rows of 128 or 144 bytes, 1 = float rows of length 64 (the shapes
+ * of mvgx_cascade_set_regions_typed); dim code bits per descriptor ((dim + 7) / 8 bytes in hash_codes_out). Eigen's kernel walks 144 columns
+ * in nine blocks of 16 and 64 columns as one block (block_cols = cols below 128): the same order here, the same bits (tests/test_cascade_typed.py
+ * against the compiled reference's CascadeHasher). */
+int mvgx_cascade_hash_regions_typed(mvgx_cascade_ctx* ctx, int scalar_type, const void* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                                    const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
+                                    uint8_t* const* hash_codes_out /* may be NULL */, uint16_t* const* bucket_ids_out /* may be NULL */);
 int mvgx_cascade_run(mvgx_cascade_ctx* ctx, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq,
                      mvgx_match_stats* stats /* may be NULL */);
 int mvgx_cascade_results(mvgx_cascade_ctx* ctx, const uint64_t** offsets, const uint32_t** ij);

@@ -176,6 +176,8 @@ PROTOTYPES = {
                                                  C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mvgx_cascade_hash_regions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mvgx_cascade_hash_regions_typed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_void_p,
+                                                  C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mvgx_cascade_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.POINTER(MatchStats)]),
     "mvgx_cascade_results": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]),
     "mvgx_ba_default_options": (None, [C.POINTER(BaOptions)]),

@@ -60,6 +60,9 @@ namespace matching_image_collection {
 
 namespace {
 
+// MVGX_CASCADE_HASH=check, last call: 0 not run, 1 the device's codes equal this build's CascadeHasher's on the probed view, 2 they differ
+// (tests read it through mvgx_adapter_cascade_last_hash_check)
+std::atomic<int> g_last_hash_check{0};
 constexpr uint64_t kPairsPerCall = 1u << 16;   // cancellation / progress granularity of the device route
 
 template <class F>
@@ -111,12 +114,11 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
   const size_t dimension = views.begin()->second.regions->DescriptorLength();
   matching::CascadeHasher hasher;
   hasher.Init(dimension);
-  // the device covers both stages for 128-byte uint8 regions (SIFT_Regions) and the matching stage - the part that grows with the pair
-  // count - for the other shapes openMVG's scalar describers produce: 144-byte uint8 (AKAZE_Liop_Regions) and 64-float rows
-  // (AKAZE_Float_Regions); their hashing stage is the reference's CreateHashedDescriptions on the host threads
+  // the device covers both stages for the shapes openMVG's scalar describers produce: 128-byte uint8 (SIFT_Regions), 144-byte uint8
+  // (AKAZE_Liop_Regions) and 64-float rows (AKAZE_Float_Regions; round 5: their hashing stage too - mvgx_cascade_hash_regions_typed)
   constexpr bool is_float = std::is_same<ScalarT, float>::value;
-  const bool device_hashing = std::is_same<ScalarT, unsigned char>::value && dimension == 128;
-  const bool on_device = device_hashing || (std::is_same<ScalarT, unsigned char>::value && dimension == 144) || (is_float && dimension == 64);
+  const bool on_device = (std::is_same<ScalarT, unsigned char>::value && (dimension == 128 || dimension == 144)) || (is_float && dimension == 64);
+  const bool device_hashing = on_device;
   std::vector<View<ScalarT>*> order;
   for (auto& kv : views) order.push_back(&kv.second);
   // the zero-mean descriptor (:78-104): the reference's own GetZeroMeanDescriptor, per view on the host threads, then over the views
@@ -257,17 +259,18 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
       size_t probe = 0;
       while (probe + 1 < rows.size() && n_desc[probe] == 0) ++probe;
       const uint32_t n = n_desc[probe];
-      std::vector<uint8_t> dev_codes((size_t)n * 16);
+      std::vector<uint8_t> dev_codes((size_t)n * code_bytes);
       std::vector<uint16_t> dev_buckets((size_t)n * 6);
       uint8_t* cp = dev_codes.data(); uint16_t* bp = dev_buckets.data();
-      rc = mvgx_cascade_hash_regions(ctx.c, rows.data() + probe, n_desc.data() + probe, 1, 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, &cp, &bp);
+      rc = mvgx_cascade_hash_regions_typed(ctx.c, is_float ? 1 : 0, reinterpret_cast<const void* const*>(rows.data() + probe), n_desc.data() + probe, 1,
+                                           (uint32_t)dimension, zero_mean.data(), 6, 10, std::mt19937::default_seed, &cp, &bp);
       if (rc == MVGX_OK && n) {
         View<ScalarT>& v = *order[probe];
         Eigen::Map<RowMajor> m(const_cast<ScalarT*>(v.rows()), v.count(), dimension);
         const matching::HashedDescriptions href = hasher.CreateHashedDescriptions(m, zero_mean);
         bool same = true;
         for (uint32_t r = 0; r < n && same; ++r) {
-          same = !std::memcmp(&dev_codes[(size_t)r * 16], href.hashed_desc[r].hash_code.data(), 16);
+          same = !std::memcmp(&dev_codes[(size_t)r * code_bytes], href.hashed_desc[r].hash_code.data(), code_bytes);
           for (int g = 0; g < 6 && same; ++g) same = dev_buckets[(size_t)r * 6 + g] == href.hashed_desc[r].bucket_ids[g];
         }
         if (!same) {
@@ -275,6 +278,7 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
                                  "(Eigen compiled with FMA?) - hashing on the host (MVGX_CASCADE_HASH=host)";
           hash_host = true;
         }
+        g_last_hash_check.store(same ? 1 : 2);
       }
     }
     if (hash_host) {
@@ -288,7 +292,9 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
     } else {
       // CascadeHasher::Init(dimension) defaults: 6 bucket groups, 10 bits per bucket, std::mt19937::default_seed
       inj = injected("cascade", "hash");
-      if (!inj) rc = mvgx_cascade_hash_regions(ctx.c, rows.data(), n_desc.data(), (uint32_t)rows.size(), 128, zero_mean.data(), 6, 10, std::mt19937::default_seed, nullptr, nullptr);
+      if (!inj)
+        rc = mvgx_cascade_hash_regions_typed(ctx.c, is_float ? 1 : 0, reinterpret_cast<const void* const*>(rows.data()), n_desc.data(), (uint32_t)rows.size(),
+                                             (uint32_t)dimension, zero_mean.data(), 6, 10, std::mt19937::default_seed, nullptr, nullptr);
       step("hash_regions", rc, inj);
     }
   }
@@ -346,6 +352,8 @@ void match_collection(const sfm::Regions_Provider& provider, const Pair_Set& pai
 
 }  // namespace
 
+int g_last_hash_check_value() { return g_last_hash_check.load(); }
+
 Cascade_Hashing_Matcher_Regions::Cascade_Hashing_Matcher_Regions(float dist_ratio) : Matcher(), f_dist_ratio_(dist_ratio) {}
 
 void Cascade_Hashing_Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& regions_provider, const Pair_Set& pairs,
@@ -364,3 +372,5 @@ void Cascade_Hashing_Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_P
 
 }  // namespace matching_image_collection
 }  // namespace openMVG
+
+extern "C" int mvgx_adapter_cascade_last_hash_check(void) { return openMVG::matching_image_collection::g_last_hash_check_value(); }

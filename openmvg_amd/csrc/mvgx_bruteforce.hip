@@ -537,6 +537,73 @@ __global__ __launch_bounds__(256) void cascade_hash_kernel(const uint32_t* __res
   hash[r] = make_uint4(code[0], code[1], code[2], code[3]);
   bids[r] = make_uint4(ids[0] | (ids[1] << 16), ids[2] | (ids[3] << 16), ids[4] | (ids[5] << 16), ids[6] | (ids[7] << 16));
 }
+// The same stage for the other shapes openMVG's scalar describers produce (round 5): 144-byte uint8 rows (AKAZE_Liop_Regions: nine column
+// blocks of 16) and 64-float rows (AKAZE_Float_Regions: fewer than 128 columns are ONE block in Eigen's kernel, block_cols = cols). One code
+// bit per dimension (CascadeHasher::Init(dimension)): DIM / 32 code dwords (rounded up) in a slot of HS dwords, the slot's tail zero.
+template <int DIM, int BLOCK, bool FLOAT>
+__global__ __launch_bounds__(256) void cascade_hash_typed_kernel(const uint32_t* __restrict__ words, uint64_t n_rows, const float* __restrict__ zero_mean,
+                                                                 const float* __restrict__ P, int n_groups, int bits, uint32_t* __restrict__ hash,
+                                                                 uint4* __restrict__ bids) {
+  constexpr int HW = (DIM + 31) / 32, HS = HW <= 2 ? 2 : HW <= 4 ? 4 : 8;
+  static_assert(DIM % BLOCK == 0 && DIM % 16 == 0, "column blocks");
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < n_rows;
+  float d[DIM];
+  if constexpr (FLOAT) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(words + (live ? r : 0) * DIM);
+#pragma unroll
+    for (int q = 0; q < DIM / 4; ++q) {
+      const uint4 w = src[q];   // (four floats)
+      d[4 * q] = __fsub_rn(__uint_as_float(w.x), zero_mean[4 * q]); d[4 * q + 1] = __fsub_rn(__uint_as_float(w.y), zero_mean[4 * q + 1]);
+      d[4 * q + 2] = __fsub_rn(__uint_as_float(w.z), zero_mean[4 * q + 2]); d[4 * q + 3] = __fsub_rn(__uint_as_float(w.w), zero_mean[4 * q + 3]);
+    }
+  } else {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(words + (live ? r : 0) * (DIM / 4));
+#pragma unroll
+    for (int q = 0; q < DIM / 16; ++q) {
+      const uint4 w = src[q];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[16 * q + e] = __fsub_rn((float)((ww[e >> 2] >> (8 * (e & 3))) & 255u), zero_mean[16 * q + e]);
+    }
+  }
+  auto project = [&](const float* __restrict__ row) -> float {
+    float res = 0.0f;
+#pragma unroll
+    for (int b = 0; b < DIM / BLOCK; ++b) {
+      float c = 0.0f;
+#pragma unroll
+      for (int j = 0; j < BLOCK; ++j) c = cas_add_rn(cas_mul_rn(row[BLOCK * b + j], d[BLOCK * b + j]), c);
+      res = cas_add_rn(c, res);
+    }
+    return res;
+  };
+  uint32_t code[HS];
+#pragma unroll
+  for (int w = 0; w < HS; ++w) code[w] = 0u;
+#pragma unroll
+  for (int w = 0; w < HW; ++w)
+    for (int b = 0; b < 32; ++b) {
+      if (32 * w + b >= DIM) break;
+      const float v = project(P + (size_t)(32 * w + b) * DIM);
+      if (v > 0.0f) code[w] |= 1u << b;
+    }
+  uint32_t ids[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g >= n_groups) break;   // uniform
+    uint32_t id = 0;
+    for (int k = 0; k < bits; ++k) {
+      const float v = project(P + (size_t)(DIM + g * bits + k) * DIM);
+      id = (id << 1) + (v > 0.0f ? 1u : 0u);
+    }
+    ids[g] = id & 0xFFFFu;
+  }
+  if (!live) return;
+#pragma unroll
+  for (int w = 0; w < HS; ++w) hash[r * HS + w] = code[w];
+  bids[r] = make_uint4(ids[0] | (ids[1] << 16), ids[2] | (ids[3] << 16), ids[4] | (ids[5] << 16), ids[6] | (ids[7] << 16));
+}
 }  // namespace
 
 struct BfCtx {
@@ -996,47 +1063,64 @@ int mvgx_debug_rounded_ops_f32(const float* abc, float* out) {
   return MVGX_OK;
 }
 
-int mvgx_cascade_hash_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
-                              const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
-                              uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {
+int mvgx_cascade_hash_regions_typed(mvgx_cascade_ctx* c, int scalar_type, const void* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                                    const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
+                                    uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {
   MVGX_REQUIRE(c && zero_mean && (n_images == 0 || (desc_rows && n_desc)), MVGX_ERR_ARG, "mvgx_cascade_hash_regions: NULL argument");
-  MVGX_REQUIRE(dim == 128, MVGX_ERR_UNSUPPORTED, "mvgx_cascade_hash_regions: the hashing stage on the device covers 128-byte uint8 descriptors (got length %u); "
-               "hash on the host and hand the codes to mvgx_cascade_set_regions_typed", dim);
-  int rc = cas_check_shape(0, dim, 16, n_groups, bits_per_bucket);
+  const uint32_t hash_bytes = (dim + 7) / 8;
+  int rc = cas_check_shape(scalar_type, dim, hash_bytes, n_groups, bits_per_bucket);
   if (rc) return rc;
-  if ((rc = bf_set_regions(c, desc_rows, n_desc, n_images, dim, dim / 4))) return rc;   // the descriptors, row after row, on the device
-  c->cas_float = false;
+  const bool is_float = scalar_type == 1;
+  // the descriptors, row after row, on the device
+  if ((rc = bf_set_regions(c, reinterpret_cast<const uint8_t* const*>(desc_rows), n_desc, n_images, is_float ? dim * 4 : dim, is_float ? dim : dim / 4))) return rc;
+  c->cas_float = is_float;
   uint64_t rows = 0;
   for (uint32_t k = 0; k < n_images; ++k) rows += n_desc[k];
+  const uint32_t HW = (dim + 31) / 32, HS = HW <= 2 ? 2 : HW <= 4 ? 4 : 8;   // code dwords, slot dwords (cascade_match_kernel)
   const std::vector<float>& P = cas_projections(dim, n_groups, bits_per_bucket, random_seed);
   Buf<float> d_P, d_zm;
-  if ((rc = d_P.ensure(P.size())) || (rc = d_zm.ensure(dim)) || (rc = c->d_hash.ensure((size_t)std::max<uint64_t>(rows, 1))) ||
-      (rc = c->d_bids.ensure((size_t)std::max<uint64_t>(rows, 1))))
+  const size_t hash_u4 = ((size_t)std::max<uint64_t>(rows, 1) * HS + 4 + 3) / 4;
+  if ((rc = d_P.ensure(P.size())) || (rc = d_zm.ensure(dim)) || (rc = c->d_hash.ensure(hash_u4)) || (rc = c->d_bids.ensure((size_t)std::max<uint64_t>(rows, 1))))
     return rc;
   struct Release { Buf<float>&a, &b; ~Release() { a.release(); b.release(); } } release{d_P, d_zm};
   MVGX_HIP(hipMemcpyAsync(d_P.p, P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   MVGX_HIP(hipMemcpyAsync(d_zm.p, zero_mean, dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  std::vector<uint4> bids((size_t)std::max<uint64_t>(rows, 1)), hash;
+  std::vector<uint4> bids((size_t)std::max<uint64_t>(rows, 1));
+  std::vector<uint32_t> hash;
   if (rows) {
-    hipLaunchKernelGGL(cascade_hash_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, c->d_words.p, rows, d_zm.p, d_P.p, (int)n_groups,
-                       (int)bits_per_bucket, c->d_hash.p, c->d_bids.p);
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    uint32_t* const h32 = reinterpret_cast<uint32_t*>(c->d_hash.p);
+    if (!is_float && dim == 128)
+      hipLaunchKernelGGL(cascade_hash_kernel, grid, dim3(256), 0, c->stream, c->d_words.p, rows, d_zm.p, d_P.p, (int)n_groups, (int)bits_per_bucket, c->d_hash.p, c->d_bids.p);
+    else if (!is_float)   // 144
+      hipLaunchKernelGGL((cascade_hash_typed_kernel<144, 16, false>), grid, dim3(256), 0, c->stream, c->d_words.p, rows, d_zm.p, d_P.p, (int)n_groups,
+                         (int)bits_per_bucket, h32, c->d_bids.p);
+    else                  // 64 floats
+      hipLaunchKernelGGL((cascade_hash_typed_kernel<64, 64, true>), grid, dim3(256), 0, c->stream, c->d_words.p, rows, d_zm.p, d_P.p, (int)n_groups,
+                         (int)bits_per_bucket, h32, c->d_bids.p);
     MVGX_HIP(hipGetLastError());
     MVGX_HIP(hipMemcpyAsync(bids.data(), c->d_bids.p, rows * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
     if (hash_codes_out) {
-      hash.resize(rows);
-      MVGX_HIP(hipMemcpyAsync(hash.data(), c->d_hash.p, rows * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+      hash.resize(rows * HS);
+      MVGX_HIP(hipMemcpyAsync(hash.data(), c->d_hash.p, rows * HS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
   }
   MVGX_HIP(hipStreamSynchronize(c->stream));
   uint64_t at = 0;
   for (uint32_t k = 0; k < n_images; ++k) {   // the per-descriptor outputs in the reference's shapes, on request
     for (uint32_t r = 0; r < n_desc[k]; ++r) {
-      if (hash_codes_out && hash_codes_out[k]) memcpy(hash_codes_out[k] + (size_t)r * 16, &hash[at + r], 16);
+      if (hash_codes_out && hash_codes_out[k]) memcpy(hash_codes_out[k] + (size_t)r * hash_bytes, &hash[(at + r) * HS], hash_bytes);
       if (bucket_ids_out && bucket_ids_out[k]) memcpy(bucket_ids_out[k] + (size_t)r * n_groups, &bids[at + r], n_groups * sizeof(uint16_t));
     }
     at += n_desc[k];
   }
   return cas_build_buckets(c, bids.data(), n_desc, n_images, n_groups, bits_per_bucket);
+}
+int mvgx_cascade_hash_regions(mvgx_cascade_ctx* c, const uint8_t* const* desc_rows, const uint32_t* n_desc, uint32_t n_images, uint32_t dim,
+                              const float* zero_mean, uint32_t n_groups, uint32_t bits_per_bucket, uint32_t random_seed,
+                              uint8_t* const* hash_codes_out, uint16_t* const* bucket_ids_out) {
+  return mvgx_cascade_hash_regions_typed(c, 0, reinterpret_cast<const void* const*>(desc_rows), n_desc, n_images, dim, zero_mean, n_groups, bits_per_bucket,
+                                         random_seed, hash_codes_out, bucket_ids_out);
 }
 
 int mvgx_cascade_run(mvgx_cascade_ctx* c, const uint32_t* pairs_IJ, uint64_t n_pairs, float ratio_sq, mvgx_match_stats* stats) {

@@ -331,16 +331,23 @@ class CascadeContext(HammingContext):
         self._keep = (d, h, b)
         _capi.check(self._fn("set_regions_typed")(self._h, 1 if is_float else 0, dp, hp, bp, cnt, n, dim, hb, n_groups, bits_per_bucket))
 
-    def hash_regions(self, desc_list, zero_mean=None, n_groups=6, bits_per_bucket=10, random_seed=5489, fetch=False):
-        """The hashing stage on the device (mvgx_cascade_hash_regions) in place of set_regions: descriptors only; zero_mean
-        defaults to cascade_zero_mean(desc_list). fetch=True also returns (hash codes [(n, 16) uint8], bucket ids [(n, groups)
-        uint16]) per image, the shapes of the reference's HashedDescription."""
-        d = [np.ascontiguousarray(x, np.uint8).reshape(-1, 128) for x in desc_list]
-        zm = np.ascontiguousarray(cascade_zero_mean(d) if zero_mean is None else zero_mean, np.float32).reshape(128)
+    def hash_regions(self, desc_list, zero_mean=None, n_groups=6, bits_per_bucket=10, random_seed=5489, fetch=False, dtype=np.uint8, dim=128):
+        """The hashing stage on the device (mvgx_cascade_hash_regions_typed) in place of set_regions: descriptors only; dtype / dim as in
+        set_regions (uint8 128 / 144, float32 64). zero_mean defaults to cascade_zero_mean(desc_list) (128-byte rows; the other shapes
+        pass the caller's CascadeHasher::GetZeroMeanDescriptor result). fetch=True also returns (hash codes [(n, (dim + 7) // 8) uint8],
+        bucket ids [(n, groups) uint16]) per image, the shapes of the reference's HashedDescription."""
+        is_float = np.dtype(dtype) == np.float32
+        hb = (dim + 7) // 8
+        d = [np.ascontiguousarray(x, np.float32 if is_float else np.uint8).reshape(-1, dim) for x in desc_list]
+        if zero_mean is None:
+            if is_float or dim != 128:
+                raise ValueError("hash_regions: zero_mean is required for other shapes than 128-byte uint8 rows")
+            zero_mean = cascade_zero_mean(d)
+        zm = np.ascontiguousarray(zero_mean, np.float32).reshape(dim)
         n = len(d)
         dp = (C.c_void_p * max(n, 1))(); hp = (C.c_void_p * max(n, 1))(); bp = (C.c_void_p * max(n, 1))()
         cnt = (C.c_uint32 * max(n, 1))()
-        h = [np.zeros((len(x), 16), np.uint8) for x in d] if fetch else None
+        h = [np.zeros((len(x), hb), np.uint8) for x in d] if fetch else None
         b = [np.zeros((len(x), n_groups), np.uint16) for x in d] if fetch else None
         for k in range(n):
             dp[k] = d[k].ctypes.data if len(d[k]) else None
@@ -349,8 +356,8 @@ class CascadeContext(HammingContext):
                 hp[k] = h[k].ctypes.data if len(d[k]) else None
                 bp[k] = b[k].ctypes.data if len(d[k]) else None
         self._keep = (d, zm)
-        _capi.check(self._fn("hash_regions")(self._h, dp, cnt, n, 128, zm.ctypes.data, n_groups, bits_per_bucket, random_seed,
-                                             hp if fetch else None, bp if fetch else None))
+        _capi.check(self._fn("hash_regions_typed")(self._h, 1 if is_float else 0, dp, cnt, n, dim, zm.ctypes.data, n_groups, bits_per_bucket, random_seed,
+                                                   hp if fetch else None, bp if fetch else None))
         return (h, b) if fetch else None
 
 

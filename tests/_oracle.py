@@ -734,7 +734,8 @@ def adapter():
         b = _bind_ba_shim(C.CDLL(ADAPTER_BA_SO, mode=os.RTLD_LOCAL | os.RTLD_NOW))
         for name in ("ref_matcher_regions_match_u8", "ref_matcher_regions_match_binary64", "ref_matcher_regions_match_float64",
                      "ref_matcher_regions_match_liop144", "ref_cascade_matcher_regions_match_u8", "ref_cascade_matcher_regions_match_float64",
-                     "ref_cascade_matcher_regions_match_liop144", "ref_cascade_hash_u8", "mvgx_adapter_counters"):   # (the counters of the matcher half: which route produced a container)
+                     "ref_cascade_matcher_regions_match_liop144", "ref_cascade_hash_u8", "mvgx_adapter_counters",
+                     "mvgx_adapter_cascade_last_hash_check"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
         for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
                      "mvgx_adapter_ba_release_context", "mvgx_adapter_ba_kept_solver_info"):

@@ -67,6 +67,31 @@ def test_replacement_matching_stage_emulated(kind):
     assert c["device_pairs"] > 0 and c["fallback_pairs"] == 0 and c["device_failures"] == 0, (before, c)
 
 
+def _hash_check(lib, kind):
+    """MVGX_CASCADE_HASH=check: the replacement TU hashes one view on the device AND with this build's own CascadeHasher and compares the
+    codes and bucket ids (round 5: the hashing stage of the 144-byte and 64-float shapes runs on the device too)"""
+    import ctypes as C
+    descs, xy, pairs = typed_case(kind)
+    saved = os.environ.get("MVGX_CASCADE_HASH")
+    os.environ["MVGX_CASCADE_HASH"] = "check"
+    try:
+        got = _oracle.ref_cascade_matcher_regions_match_typed(kind, descs, xy, pairs, 0.8, lib=lib)
+    finally:
+        if saved is None:
+            os.environ.pop("MVGX_CASCADE_HASH", None)
+        else:
+            os.environ["MVGX_CASCADE_HASH"] = saved
+    fn = lib.mvgx_adapter_cascade_last_hash_check
+    fn.restype = C.c_int
+    assert fn() == 1, fn()   # 1: equal (2: differ, 0: the check did not run)
+    _same(got, golden(kind, 0.8))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_hashing_equals_the_reference_hasher_emulated(kind):
+    _hash_check(_oracle.adapter_emu(), kind)
+
+
 def test_other_lengths_stay_on_the_reference_route():
     """the C-ABI refuses shapes outside (uint8, 128 | 144) and (float, 64) with MVGX_ERR_UNSUPPORTED; nothing is left half set"""
     from openmvg_amd import _capi
@@ -87,6 +112,12 @@ def _counters(lib, reset=False):
     out = (C.c_uint64 * 3)()
     lib.mvgx_adapter_counters(out, 1 if reset else 0)
     return {"device_pairs": int(out[0]), "fallback_pairs": int(out[1]), "device_failures": int(out[2])}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_hashing_equals_the_reference_hasher_on_the_mi355x(kind):
+    _hash_check(_oracle.adapter(), kind)
 
 
 @pytest.mark.gpu
