@@ -15,10 +15,10 @@
 //       bit-identical - tests/test_cascade.py, tests/test_adapter_*.py);
 //     * the matching stage :166-215 - bucket candidates, Hamming ranking of the hash codes, exact L2 on the ten best, the two
 //       nearest, the distance-ratio test - integer work on the hash outputs, bit-identical lists.
-// 128-byte uint8 regions (SIFT) take that route. 144-byte uint8 (AKAZE_Liop_Regions) and 64-float regions (AKAZE_Float_Regions) keep
-// the hashing stage on the host (CreateHashedDescriptions, once per image) and run the matching stage (per pair) on the device:
-// mvgx_cascade_set_regions_typed, float distances in L2<float>'s summation order. Other lengths keep working through the reference's
-// own CascadeHasher::Match_HashedDescriptions on the host.
+// 128-byte uint8 regions (SIFT), 144-byte uint8 (AKAZE_Liop_Regions) and 64-float regions (AKAZE_Float_Regions) take that route (round 5:
+// the hashing stage of the last two as well - mvgx_cascade_hash_regions_typed; MVGX_CASCADE_HASH=host keeps it with CreateHashedDescriptions
+// on the host threads and hands the codes over: mvgx_cascade_set_regions_typed); float distances in L2<float>'s summation order. Other
+// lengths keep working through the reference's own CascadeHasher::Match_HashedDescriptions on the host.
 // A failing device call is logged once and the remaining pairs run through the reference's own classes (mvgx_adapter_policy.hpp).
 #include <algorithm>
 #include <atomic>
