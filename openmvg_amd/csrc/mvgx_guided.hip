@@ -172,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
   for (; j + 4 <= nJ; j += 4) {
     const double2 y0 = xyJ[j], y1 = xyJ[j + 1], y2 = xyJ[j + 2], y3 = xyJ[j + 3];   // (wave-uniform: scalar loads)
     const bool p0 = active && geometric(y0), p1 = active && geometric(y1), p2 = active && geometric(y2), p3 = active && geometric(y3);
+    if (__ballot(p0 || p1 || p2 || p3) == 0ull) continue;   // (uniform: under a homography 15 groups of 16 end here)
     if (p0) { q[64 * n_q] = j; ++n_q; }
     if (p1) { q[64 * n_q] = j + 1; ++n_q; }
     if (p2) { q[64 * n_q] = j + 2; ++n_q; }
