@@ -665,7 +665,10 @@ template <int MODEL> constexpr int wave_scratch_words() {
 #ifndef MVGX_GEO_E_WGS
 #define MVGX_GEO_E_WGS 2   // workgroups per CU the essential instantiation is compiled for (1: twice the registers, half the waves)
 #endif
-template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF>
+// kAheadForm (essential and homography models): the instantiation that draws its samples ahead and solves four side by side; the other one
+// holds the one-sample solver (`ahead` = 1: the form the equality tests compare with). Two kernels, not one with a run-time branch: with both
+// solvers in one kernel the essential instantiation spilled 246 registers instead of 164 and ran 19 % slower (call r5_57).
+template <int WAVES, bool kGlobalTables = false, int MODEL = kModelF, bool kAheadForm = false>
 __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVGX_GEO_WGS) void geofilter_f_acransac_kernel(const GeoPair* __restrict__ pairs, const uint32_t* __restrict__ order,
                                                                           uint32_t n_work, uint32_t n_cap, const double2* __restrict__ x1n,
                                                                           const double2* __restrict__ x2n, const float* __restrict__ l10,
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
   // generator's index goes back to where the last used sample left it (a sample drawn ahead never twists the state, so the index is
   // the whole state; the pool is either untouched - warm-up - or rebuilt by the event) and the next batch draws again. Results are those
   // of one sample per iteration, bit for bit (`ahead` = 1 is that form: tests/test_geofilter_e.py compares the two).
-  const bool x4 = model_solves_ahead<MODEL>() && ahead > 1;
+  constexpr bool x4 = kAheadForm && model_solves_ahead<MODEL>();
   double* const row_models = e_scr;   // (fundamental / homography models: the same words of the wave's scratch)
   unsigned iter = 0;
   while (iter < nIter && iter < max_iterations) {
@@ -1077,9 +1080,16 @@ int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_wor
                  const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)WAVES * (kMtN + 3 * (size_t)((n_cap + 2) & ~1u) + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
-                     n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2, ahead);
+  constexpr bool kHasAheadForm = model_solves_ahead<MODEL>();   // (the other models have one instantiation)
+  if (kHasAheadForm && ahead > 1) {
+    MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL, kHasAheadForm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL, kHasAheadForm>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
+                       n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2, ahead);
+  } else {
+    MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<WAVES, false, MODEL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<WAVES, false, MODEL, false>), dim3((n_work + WAVES - 1) / WAVES), dim3(64 * WAVES), lds, stream, d_pairs, d_order, n_work,
+                       n_cap, x1, x2, l10, mt_init, max_it, res, mask, (uint32_t*)nullptr, b1, b2, ahead);
+  }
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
@@ -1090,8 +1100,13 @@ int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_
                         const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   if (!n_work) return MVGX_OK;
   const size_t lds = (size_t)(kMtN + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
-  hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
-                     max_it, res, mask, scratch, b1, b2, ahead);
+  constexpr bool kHasAheadForm = model_solves_ahead<MODEL>();
+  if (kHasAheadForm && ahead > 1)
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL, kHasAheadForm>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
+                       max_it, res, mask, scratch, b1, b2, ahead);
+  else
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL, false>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
+                       max_it, res, mask, scratch, b1, b2, ahead);
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
