@@ -30,7 +30,7 @@ def _ref_vs_ref():
 
 
 REF_VS_REF = _ref_vs_ref()
-PMC_PROFILE = "profiles/round5_geofilter_pmc_call_r5_50.json"   # SQ counter passes of tools/geofilter_run.py (tools/gpu.sh geopmc) on the kernels as they are (E and H with samples ahead)
+PMC_PROFILE = "profiles/round5_geofilter_pmc_call_r5_58.json"   # SQ counter passes of tools/geofilter_run.py (tools/gpu.sh geopmc) on the kernels as they are (E and H with samples ahead)
 
 
 def valu_cycles_per_iteration(model):
