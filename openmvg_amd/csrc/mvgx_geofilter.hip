@@ -684,10 +684,15 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
   const long long t_start = __builtin_amdgcn_s_memtime();
   uint32_t n_iter_run = 0, n_models_run = 0;
   constexpr int kMin = model_min_samples<MODEL>();
-  const uint32_t cap1 = (n_cap + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
+  const uint32_t pidx = order[w];
+  const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
+  const uint32_t n = P.n;
+  // LDS form: the class's size for every pair; global form: the pair's own (its tables sit at 3 x (start + 4 x pair) words of the
+  // scratch block - start = the pair's first correspondence: no two pairs overlap, whatever their sizes)
+  const uint32_t cap1 = ((kGlobalTables ? n : n_cap) + 2) & ~1u;   // even: the doubles behind stay 8-byte aligned
   const uint32_t per_wave = kMtN + (kGlobalTables ? 0u : 3 * cap1) + wave_scratch_words<MODEL>();   // words: generator | pool | logc_n | logc_k | scratch
   uint32_t* const mt = lds_u32 + (size_t)wave * per_wave;
-  uint32_t* const pool = kGlobalTables ? table_scratch + (size_t)w * 3 * cap1 : mt + kMtN;
+  uint32_t* const pool = kGlobalTables ? table_scratch + 3 * ((size_t)P.start + 4 * (size_t)pidx) : mt + kMtN;
   float* const logc_n = reinterpret_cast<float*>(pool + cap1);
   float* const logc_k = logc_n + cap1;
   uint32_t* const hist = kGlobalTables ? mt + kMtN : reinterpret_cast<uint32_t*>(logc_k + cap1);
@@ -696,9 +701,6 @@ __global__ __launch_bounds__(64 * WAVES, MODEL == kModelE ? MVGX_GEO_E_WGS : MVG
   double* const e_Es4 = e_scr + kAhead * five_point::kScratch;   // the essential matrices of the four samples solved together
   double* const e_Fs = e_Es4 + kAhead * 90;
   double* e_Es = e_Es4;                                           // ... of the sample under evaluation
-  const uint32_t pidx = order[w];
-  const GeoPair& P = pairs[pidx];   // (read through the scalar data path: wave-uniform)
-  const uint32_t n = P.n;
   const double max_threshold = P.max_threshold, bins_by_interval = P.bins_by_interval, loge0 = P.loge0;
   const double2* __restrict__ x1 = x1n + P.start;
   const double2* __restrict__ x2 = x2n + P.start;
@@ -1093,20 +1095,25 @@ int launch_class(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_wor
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
-// the class above the LDS classes: tables in `scratch` (n_work x 3 x ((n_cap + 2) & ~1) words)
+// the class above the LDS classes: tables in `scratch` (n_work x 3 x ((n_cap + 2) & ~1) words), workgroups of four waves like the small classes
+// (the LDS a wave needs no longer grows with its pair: the occupancy of the small classes at any size)
 template <int MODEL>
 int launch_class_global(const GeoPair* d_pairs, const uint32_t* d_order, uint32_t n_work, uint32_t n_cap, const double2* x1, const double2* x2,
                         const float* l10, const uint32_t* mt_init, uint32_t max_it, GeoResult* res, uint8_t* mask, uint32_t* scratch, hipStream_t stream,
                         const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   if (!n_work) return MVGX_OK;
-  const size_t lds = (size_t)(kMtN + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
+  constexpr int W = 4;
+  const size_t lds = (size_t)W * (kMtN + wave_scratch_words<MODEL>()) * sizeof(uint32_t);
   constexpr bool kHasAheadForm = model_solves_ahead<MODEL>();
-  if (kHasAheadForm && ahead > 1)
-    hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL, kHasAheadForm>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
-                       max_it, res, mask, scratch, b1, b2, ahead);
-  else
-    hipLaunchKernelGGL((geofilter_f_acransac_kernel<1, true, MODEL, false>), dim3(n_work), dim3(64), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2, l10, mt_init,
-                       max_it, res, mask, scratch, b1, b2, ahead);
+  if (kHasAheadForm && ahead > 1) {
+    MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<W, true, MODEL, kHasAheadForm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<W, true, MODEL, kHasAheadForm>), dim3((n_work + W - 1) / W), dim3(64 * W), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2,
+                       l10, mt_init, max_it, res, mask, scratch, b1, b2, ahead);
+  } else {
+    MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&geofilter_f_acransac_kernel<W, true, MODEL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((geofilter_f_acransac_kernel<W, true, MODEL, false>), dim3((n_work + W - 1) / W), dim3(64 * W), lds, stream, d_pairs, d_order, n_work, n_cap, x1, x2,
+                       l10, mt_init, max_it, res, mask, scratch, b1, b2, ahead);
+  }
   MVGX_HIP(hipGetLastError());
   return MVGX_OK;
 }
@@ -1138,22 +1145,20 @@ inline void inverse3(const double* m, double* inv) {
   inv[2] = (m[1] * m[5] - m[2] * m[4]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-// the launches of the five size classes (largest pairs first) for one model
+// the launches of the two forms for one model: pairs of more than kCap0 correspondences (largest first) with their tables in global
+// scratch, the others with them in LDS. (Until the end of round 5 there were three more LDS classes - up to 1 024, 4 096 and 12 000
+// correspondences at 4 / 2 / 1 waves per workgroup: their LDS left one workgroup per CU, and a pair of 2 000 correspondences ran 2.5 x
+// slower per iteration than it does in the global form, call r5_61.)
 template <int MODEL>
-int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, const GeoPair* hp, uint32_t c4, uint32_t c3,
-                   uint32_t c2, uint32_t c1, const uint32_t (&caps)[4], const double2* px1, const double2* px2, const float* l10, const uint32_t* mt,
-                   uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables, hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr,
-                   uint32_t ahead = 1) {
+int launch_classes(const GeoPair* d_pairs, const uint32_t* ord, const std::vector<uint32_t>& order, uint32_t c_global, uint32_t cap0, uint64_t n_total, uint64_t n_pairs,
+                   const double2* px1, const double2* px2, const float* l10, const uint32_t* mt, uint32_t max_it, GeoResult* res, uint8_t* mask, DevBuf& d_tables,
+                   hipStream_t stream, const double* b1 = nullptr, const double* b2 = nullptr, uint32_t ahead = 1) {
   int rc;
-  if (c4) {   // (largest first: the first pair of the class sets the table size of all of them)
-    const uint32_t cap_g = hp[order[0]].n;
-    if ((rc = d_tables.alloc((size_t)c4 * 3 * ((cap_g + 2) & ~1u) * sizeof(uint32_t)))) return rc;
-    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c4, cap_g, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream, b1, b2, ahead))) return rc;
+  if (c_global) {
+    if ((rc = d_tables.alloc(3 * ((size_t)n_total + 4 * (size_t)n_pairs + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = launch_class_global<MODEL>(d_pairs, ord, c_global, 0, px1, px2, l10, mt, max_it, res, mask, static_cast<uint32_t*>(d_tables.p), stream, b1, b2, ahead))) return rc;
   }
-  if ((rc = launch_class<1, MODEL>(d_pairs, ord + c4, c3 - c4, caps[3], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
-  if ((rc = launch_class<2, MODEL>(d_pairs, ord + c3, c2 - c3, caps[2], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
-  if ((rc = launch_class<4, MODEL>(d_pairs, ord + c2, c1 - c2, caps[1], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead))) return rc;
-  return launch_class<4, MODEL>(d_pairs, ord + c1, (uint32_t)order.size() - c1, caps[0], px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead);
+  return launch_class<4, MODEL>(d_pairs, ord + c_global, (uint32_t)order.size() - c_global, cap0, px1, px2, l10, mt, max_it, res, mask, stream, b1, b2, ahead);
 }
 
 int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* match_start, const uint32_t* image_wh,
@@ -1190,8 +1195,8 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
                "mvgx_geofilter_f_acransac: precision must be a finite upper bound (the exhaustive NFA form of an unbounded precision is not "
                "reproduced on the device; main_GeometricFilter passes 4.0)");
   MVGX_REQUIRE(opt->max_iterations >= 1, MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: max_iterations must be at least 1");
-  constexpr uint32_t kCap0 = 256, kCap1 = 1024, kCap2 = 4096, kCap3 = 12000;   // correspondences per pair: the LDS a wave needs grows with them (4 / 4 / 2 / 1 waves per workgroup)
-  constexpr uint32_t kCapGlobal = 1u << 20;   // above kCap3 the wave's tables live in global scratch (geofilter_f_acransac_kernel<1, true>)
+  constexpr uint32_t kCap0 = 256;             // correspondences per pair up to which a wave's tables (3 words per correspondence) live in LDS
+  constexpr uint32_t kCapGlobal = 1u << 20;   // above kCap0 they live in global scratch (geofilter_f_acransac_kernel<4, true>)
   for (uint64_t p = 0; p < n_pairs; ++p) {
     MVGX_REQUIRE(match_start[p + 1] >= match_start[p], MVGX_ERR_ARG, "mvgx_geofilter_f_acransac: match_start must be non-decreasing");
     MVGX_REQUIRE(match_start[p + 1] - match_start[p] <= kCapGlobal, MVGX_ERR_UNSUPPORTED,
@@ -1286,14 +1291,12 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   order.reserve(n_pairs);
   for (uint64_t p = 0; p < n_pairs; ++p) if (hp[p].n > (uint32_t)min_samples) order.push_back((uint32_t)p);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hp[a].n > hp[b].n; });
-  uint32_t c4 = 0, c3 = 0, c2 = 0, c1 = 0;   // [0, c4): n > kCap3 (global tables); [c4, c3): n > kCap2; [c3, c2): n > kCap1; [c2, c1): n > kCap0; the rest <= kCap0
-  while (c4 < order.size() && hp[order[c4]].n > kCap3) ++c4;
-  c3 = c4;
-  while (c3 < order.size() && hp[order[c3]].n > kCap2) ++c3;
-  c2 = c3;
-  while (c2 < order.size() && hp[order[c2]].n > kCap1) ++c2;
-  c1 = c2;
-  while (c1 < order.size() && hp[order[c1]].n > kCap0) ++c1;
+  // [0, c_global): more than kCap0 correspondences (tables in global scratch); the rest: tables in LDS. MVGX_GEO_GLOBAL_ABOVE = a smaller
+  // bound (tests: the global form on small pairs)
+  uint32_t global_above = kCap0;
+  if (const char* e = getenv("MVGX_GEO_GLOBAL_ABOVE")) global_above = (uint32_t)std::min<int>((int)kCap0, std::max(1, atoi(e)));
+  uint32_t c_global = 0;
+  while (c_global < order.size() && hp[order[c_global]].n > global_above) ++c_global;
   std::vector<float> l10(n_max + 2);
   for (uint32_t i = 0; i <= n_max + 1; ++i) l10[i] = (float)::log10((double)static_cast<float>(i));   // log10 of a float through the C function, as the reference's unqualified call resolves
   uint32_t mt_init[kMtN];
@@ -1387,7 +1390,6 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
   }
   DevBuf d_tables;
   {
-    const uint32_t caps[4] = {kCap0, kCap1, kCap2, kCap3};
     // fundamental / homography / essential models: samples drawn and solved ahead of their iterations, four side by side (1: one minimal solve per
     // iteration, the form of rounds 3-4; results equal)
     uint32_t e_ahead = kAhead;
@@ -1399,13 +1401,13 @@ int geofilter_run(int device, int model, const GeoSource& src, const uint64_t* m
     auto* dr = static_cast<GeoResult*>(d_res.p);
     auto* dk = static_cast<uint8_t*>(d_mask.p);
     const double *pb1 = static_cast<const double*>(d_b1.p), *pb2 = static_cast<const double*>(d_b2.p);
-    rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead)
-         : model == kModelEO ? launch_classes<kModelEO>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
-         : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
-         : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
-         : model == kModelE ? launch_classes<kModelE>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
+    rc = model == kModelH ? launch_classes<kModelH>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead)
+         : model == kModelEO ? launch_classes<kModelEO>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream)
+         : model == kModelEA8 ? launch_classes<kModelEA8>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
+         : model == kModelEU3 ? launch_classes<kModelEU3>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, pb1, pb2)
+         : model == kModelE ? launch_classes<kModelE>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream,
                                                       static_cast<const double*>(d_b1.p), static_cast<const double*>(d_b2.p), e_ahead)
-                            : launch_classes<kModelF>(dp, ord, order, hp, c4, c3, c2, c1, caps, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead);
+                            : launch_classes<kModelF>(dp, ord, order, c_global, kCap0, n_total, n_pairs, px1, px2, dl, dm, opt->max_iterations, dr, dk, d_tables, stream, nullptr, nullptr, e_ahead);
     if (rc) return rc;
   }
   MVGX_HIP(hipEventRecord(e1, stream));

@@ -108,8 +108,8 @@ def test_indexed_form_equals_the_gathered_form_under_emulation():
 
 
 def test_emulated_global_table_class_follows_the_restatement():
-    """a pair with more than 12 000 correspondences runs with the wave's pool and log tables in global scratch
-    (geofilter_f_acransac_kernel<1, true>); few iterations: the emulation walks 12 001 residuals per model"""
+    """a pair with more than 12 000 correspondences (pool and log tables in global scratch like every pair above 256:
+    geofilter_f_acransac_kernel<4, true>); few iterations: the emulation walks 12 001 residuals per model"""
     from openmvg_amd import synth
     tv = synth.two_view_matches_bulk(1, n=12001, seed=77, inlier_frac=(0.5, 0.7), no_geometry_frac=0.0)
     want = _oracle.port_geofilter(tv, max_iterations=12)
@@ -118,6 +118,32 @@ def test_emulated_global_table_class_follows_the_restatement():
     ref = dict(mask=want["mask"], ok=want["ok"], F=want["F"], precision=want["precision"], nfa=want["nfa"])
     differing, rep = gc.compare(tv["start"], ref, mask, res["ok"], res["F"], res["precision_robust"], res["nfa"])
     assert bool(res["ok"][0]) == bool(want["ok"][0]) and not differing, (rep, differing)
+
+
+def test_emulated_global_table_form_equals_the_lds_form():
+    """MVGX_GEO_GLOBAL_ABOVE=8: pairs of more than eight correspondences keep their pool and log tables in global scratch (the form of every pair
+    above 256 correspondences) - every output equal to the LDS form's on the same pairs"""
+    import os
+    tv = synth.two_view_matches(8, seed=21, n_max=60)
+    fun = geofilter.GeometricFilter_FMatrix_AC(4.0, 512)
+    out = {}
+    saved = os.environ.get("MVGX_GEO_GLOBAL_ABOVE")
+    try:
+        for form in ("lds", "global"):
+            if form == "global":
+                os.environ["MVGX_GEO_GLOBAL_ABOVE"] = "8"
+            else:
+                os.environ.pop("MVGX_GEO_GLOBAL_ABOVE", None)
+            with _emu.emulated():
+                mask, res, st = geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], fun)
+            out[form] = (mask.copy(), res.copy(), int(st.n_iterations), int(st.n_models))
+    finally:
+        if saved is None:
+            os.environ.pop("MVGX_GEO_GLOBAL_ABOVE", None)
+        else:
+            os.environ["MVGX_GEO_GLOBAL_ABOVE"] = saved
+    assert out["lds"][2:] == out["global"][2:] and out["lds"][2] > 100
+    assert np.array_equal(out["lds"][0], out["global"][0]) and out["lds"][1].tobytes() == out["global"][1].tobytes()
 
 
 def test_adapter_specialisation_fills_the_container_like_the_reference_template():

@@ -72,6 +72,40 @@ def test_pairs_beyond_the_lds_classes_against_the_compiled_reference():
     assert res["ok"][:5].all() and not differing, (rep, differing)
 
 
+@pytest.mark.parametrize("model", ["f", "h", "e"])
+def test_global_table_form_equals_the_lds_form(model):
+    """MVGX_GEO_GLOBAL_ABOVE=8 puts every pair of more than eight correspondences into the global-table form (the form of every pair above
+    256): every output equal to the LDS form's, for the three models, samples ahead included"""
+    import os
+    if model == "h":
+        tv = synth.two_view_homography_matches(300, seed=31, n_min=8, n_max=250, tiny_frac=0.0)
+        run = lambda: geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_HMatrix_AC(4.0, 1024))   # noqa: E731
+    elif model == "e":
+        tv = synth.two_view_matches(300, seed=32, n_max=250)
+        K = synth.two_view_calibration(tv)
+        run = lambda: geofilter.filter_pairs_e(tv["xI"], tv["xJ"], tv["start"], tv["wh"], K, geofilter.GeometricFilter_EMatrix_AC(4.0, 1024))   # noqa: E731
+    else:
+        tv = synth.two_view_matches(300, seed=33, n_max=250)
+        run = lambda: geofilter.filter_pairs(tv["xI"], tv["xJ"], tv["start"], tv["wh"], geofilter.GeometricFilter_FMatrix_AC(4.0, 1024))   # noqa: E731
+    out = {}
+    saved = os.environ.get("MVGX_GEO_GLOBAL_ABOVE")
+    try:
+        for form in ("lds", "global"):
+            if form == "global":
+                os.environ["MVGX_GEO_GLOBAL_ABOVE"] = "8"
+            else:
+                os.environ.pop("MVGX_GEO_GLOBAL_ABOVE", None)
+            mask, res, st = run()
+            out[form] = (mask.copy(), res.copy(), int(st.n_iterations), int(st.n_models))
+    finally:
+        if saved is None:
+            os.environ.pop("MVGX_GEO_GLOBAL_ABOVE", None)
+        else:
+            os.environ["MVGX_GEO_GLOBAL_ABOVE"] = saved
+    assert out["lds"][2:] == out["global"][2:] and out["lds"][2] > 10000
+    assert np.array_equal(out["lds"][0], out["global"][0]) and out["lds"][1].tobytes() == out["global"][1].tobytes()
+
+
 def test_container_form():
     tv = synth.two_view_matches(30, seed=11, n_max=200, tiny_frac=0.0)
     start = tv["start"].astype(np.int64)
