@@ -1065,9 +1065,12 @@ __device__ __forceinline__ bool chol_inv3_fast(const double v[6], double li[6]) 
 //   kGroupBacksub  the same up to Z, then step_pt = -L^-T (h - sum Z z)
 // MVGX_BA_GROUP_DEBUG=1: shader clocks of thread 0 of every workgroup between the phases of ba_point_group_kernel, summed per phase
 // (0 observation, 1 point sums, 2 point factors, 3 slots, 4 back-substitution, 5 matrix staging, 6 MFMA, 7 partial blocks out)
-__device__ unsigned long long g_group_stamps[8];
+__device__ unsigned long long g_group_stamps[3][8];   // [mode][phase]
 __device__ int g_group_debug;
-#define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_group_stamps[i], (unsigned long long)(t_now - t_prev)); t_prev = t_now; } } while (0)
+// (summed per workgroup in LDS and added to the global counters once, at the end of the workgroup: an atomic per stamp on eight shared
+// addresses slowed the stamped kernel by 60 % - round 6 - and the wait ended up in whichever phase came next)
+#define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); s_stamps[i] += (unsigned long long)(t_now - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define MVGX_GSTAMP_FLUSH() do { if (stamping) { for (int i_ = 0; i_ < 8; ++i_) if (s_stamps[i_]) atomicAdd(&g_group_stamps[MODE][i_], s_stamps[i_]); } } while (0)
 template <int MODE, bool kPinholeFamily = false>
 __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (MODE == 2 && !kPinholeFamily)) ? 2 : 3) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
@@ -1160,7 +1163,9 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     for (size_t i = lo + tid; i < hi; i += kGroupThreads) z2[i] = make_double2(0.0, 0.0);
   }
   double gmax = 0.0;
+  __shared__ unsigned long long s_stamps[8];
   const bool stamping = g_group_debug && tid == 0;
+  if (stamping) { for (int i_ = 0; i_ < 8; ++i_) s_stamps[i_] = 0; }
   long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0;
   // The first words of a group (its ranges, this thread's entry, the point of a point thread) are fetched one group ahead: they
   // head the chains of dependent loads (entry -> ids -> parameters), which then start from registers.
@@ -1480,7 +1485,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
                  v3 = block_sum(ptt ? pacc[kGroupPts + tid] : 0.0, sums), v4 = block_sum(ptt ? pacc[2 * kGroupPts + tid] : 0.0, sums);
     if (tid == 0) { double* o = cand_part + 5 * (size_t)sg; o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; }
   }
-  if (MODE != kGroupForward) return;
+  if (MODE != kGroupForward) { MVGX_GSTAMP_FLUSH(); return; }
   // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
   __syncthreads();
   double* const out = M;
@@ -1513,6 +1518,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + (idx - pair * kNVii)] = out[kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + idx];
   }
   MVGX_GSTAMP(7);
+  MVGX_GSTAMP_FLUSH();
 }
 
 // KIND 0: pose x pose, 1: pose x intrinsic, 2: intrinsic x intrinsic. Sums the chunks of one destination block, adds the
@@ -4911,11 +4917,13 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
     }
   }
   if (getenv("MVGX_BA_GROUP_DEBUG")) {
-    unsigned long long st[8];
+    unsigned long long st[3][8];
+    static const char* const mode_name[3] = {"norms", "forward", "back-substitution"};
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_group_stamps), sizeof(st)) == hipSuccess)
-      fprintf(stderr, "[mvgx point-group kernel, shader clocks summed over workgroups and launches] observation %llu | point sums %llu | point factors %llu | "
-              "slots %llu | back-substitution %llu | matrix staging %llu | mfma %llu | partial blocks out %llu\n",
-              st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+      for (int m = 0; m < 3; ++m)
+        fprintf(stderr, "[mvgx point-group kernel, %s mode, shader clocks of thread 0 summed over workgroups and launches] observation %llu | point sums %llu | "
+                "point factors %llu | slots %llu | back-substitution %llu | matrix staging %llu | mfma %llu | partial blocks out %llu\n",
+                mode_name[m], st[m][0], st[m][1], st[m][2], st[m][3], st[m][4], st[m][5], st[m][6], st[m][7]);
   }
   c->pool.release();
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);

@@ -75,6 +75,8 @@ for mode in "$@"; do
     for rep in 1 2 3; do for s in c3 c5; do echo "$s $(python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_iterations.txt"; done; done ;;
   baphases)   # phases of an LM iteration (HIP events around them: a little slower than the plain solve), three repetitions, optional env:... in front
     for rep in 1 2 3; do for s in c3 c5; do echo "$s $(MVGX_BA_PHASE_TIMING=1 python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_phases.txt"; done; done ;;
+  bastamps)   # MVGX_BA_GROUP_DEBUG phase stamps of ba_point_group_kernel per mode (thread 0 of every workgroup, shader clocks), both scenes
+    for s in c3 c5; do echo "== $s" | tee -a "$O/ba_group_stamps.txt"; MVGX_BA_GROUP_DEBUG=1 python tools/ba_iterations.py $s 8 --warm 2>&1 | grep -E "point-group kernel|iter_ms" | tee -a "$O/ba_group_stamps.txt"; done ;;
   baab)       # same-box A/B of a BA change: tools/_build/libmvgx_prev.so (tools/build_prev_lib.sh) against the tree, alternating
     for rep in 1 2 3; do for s in c3 c5; do
       echo "tree $s $(python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
