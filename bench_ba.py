@@ -9,11 +9,11 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes of one LM iteration per bench scene, from the committed rocprofv3 PMC passes of tools/ba_iterations.py on the same scenes
 # (FETCH_SIZE x 2 [gfx950 reports half the bytes of reads, MI355X_MICROARCH.md; calibrated on kernels of known byte counts] +
 # WRITE_SIZE, one window between two Jacobian evaluations; tools/pmc_kernels.py). Counters cannot be read inside this process:
-# the record carries the stored figure with traffic_measured_in_run = false and the file it came from.
+# the record carries the stored figure and, in traffic_source, the file it came from.
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 # (the newest pass on record: a round that re-measures drops its file beside the older ones - VERDICT r4: the bench must not keep
 # pointing at a superseded pass)
-TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, f"round{r}_ba_iteration_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
+TRAFFIC_FILE = next((p for p in (os.path.join(_PROFILES, f"round{r}_ba_iteration_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(p)),
                     os.path.join(_PROFILES, "round4_ba_iteration_traffic.json"))
 
 
@@ -208,8 +208,7 @@ def ba_bench_record(local_rank, world, cpu=True, cpu_budget_s=90.0, name=None, r
                      "frac": bytes_it / (max(s.iter_ms_mean, 1e-12) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (traffic or {}).get("hbm_bytes_per_iteration") if world == 1 else None,
                      "traffic_over_algorithmic": ((traffic or {}).get("hbm_bytes_per_iteration", 0) / bytes_it) if (traffic and world == 1) else None,
-                     "traffic_measured_in_run": False,
-                     "traffic_note": (f"PMC pass {os.path.relpath(TRAFFIC_FILE, os.path.dirname(os.path.abspath(__file__)))} ({(traffic or {}).get('command')}): "
+                     "traffic_source": (f"PMC pass {os.path.relpath(TRAFFIC_FILE, os.path.dirname(os.path.abspath(__file__)))} ({(traffic or {}).get('command')}): "
                                       "FETCH_SIZE x 2 + WRITE_SIZE of one LM iteration on this scene") if traffic else "no PMC pass stored for this scene",
                      "algorithmic_bytes_per_iteration": bytes_it},
     }

@@ -64,7 +64,7 @@ def _ba(rec):
     if ph:
         o["phases_ms"] = {k[:-3]: _r(v, 4) for k, v in ph.items() if k.endswith("_ms")}
     rf = rec.get("roofline") or {}
-    o["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_measured_in_run",
+    o["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source",
                                "algorithmic_bytes_per_iteration"))
     rs = rec.get("reduced_solve") or {}
     if rs:
@@ -90,7 +90,7 @@ def compact(out, side_file=None):
     cfg = out.get("config") or {}
     line["config"] = {"workload": cfg.get("workload"), "parallelism": cfg.get("parallelism"), "results": cfg.get("results")}
     rf = out.get("roofline") or {}
-    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_run", "kernel", "launches",
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "launches",
                                   "mean_launch_ms"))
     if "cpu_baseline" in out:
         line["cpu_baseline"] = _cpu(out["cpu_baseline"])
@@ -112,13 +112,7 @@ def compact(out, side_file=None):
                      ("geometric_filter_homography", "geo_h"), ("geometric_filter_essential", "geo_e"), ("guided_matching", "guided")):
         if k in out:
             side[short] = _side(out[k])
-    om = out.get("geometric_filter_other_models")
-    if isinstance(om, dict):
-        for m in ("a", "u", "o"):
-            if m in om:
-                side["geo_" + m] = _side(om[m])
-        if "status" in om:
-            side["geo_other"] = {"status": str(om["status"])[:80]}
+    # (the a / u / o functors are not rows of SURVEY 8: their records stay in the side file only - VERDICT r5 item 7)
     if side:
         line["side"] = side
     if side_file:

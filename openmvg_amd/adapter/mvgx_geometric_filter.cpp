@@ -297,12 +297,19 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   }
   // ---- second stage on the device: guided matching of the accepted pairs (the models and bounds of the first stage never leave the process) ----
   std::vector<uint8_t> guided_done(dev_pairs.size() ? dev_pairs.size() : 1, 0);
-  std::vector<uint64_t> guided_start;
-  uint32_t* guided_ij = nullptr;
-  struct FreeGuided { uint32_t*& p; ~FreeGuided() { if (p) mvgx_host_free(p); } } free_guided{guided_ij};
-  std::vector<size_t> guided_pairs;   // positions in dev_pairs of the pairs handed to the guided call, in call order
+  // one entry per device call (the accepted pairs go in batches, below): the call's offsets and match list
+  struct GuidedBatch { std::vector<uint64_t> start; uint32_t* ij = nullptr; };
+  std::vector<GuidedBatch> guided_batches;
+  struct FreeGuided { std::vector<GuidedBatch>& b; ~FreeGuided() { for (GuidedBatch& g : b) if (g.ij) mvgx_host_free(g.ij); } } free_guided{guided_batches};
+  std::vector<size_t> guided_pairs;          // positions in dev_pairs of the pairs handed to the guided calls, in call order
+  std::vector<uint32_t> guided_batch_of;     // per entry of guided_pairs: its call, and its position in that call
+  std::vector<uint32_t> guided_pos_in_batch;
+  // H_ACRobust.hpp:166-187: a NEGATIVE ratio selects the homography functor's geometry-only matching (nearest position under H, then
+  // IndMatch and (x, y) de-duplication) - what main_GeometricFilter passes for -g h. The device kernel is the descriptor-ratio form:
+  // such a call keeps the functor's own member function. The F and E functors square the ratio whatever its sign.
+  const bool guided_on_device = !(std::is_same<Functor, GeometricFilter_HMatrix_AC>::value && d_distance_ratio < 0);
   if constexpr (!M::angular && !kOrtho) {
-    if (b_guided_matching && n_dev_done > 0 && !my_progress_bar->hasBeenCanceled()) {
+    if (b_guided_matching && guided_on_device && n_dev_done > 0 && !my_progress_bar->hasBeenCanceled()) {
       // the regions' descriptors, in the feature order of feat_start: uint8 scalar regions of one length only
       uint32_t desc_bytes = 0;
       bool usable = true;
@@ -325,38 +332,59 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
           const size_t nb = (size_t)(feat_start[v + 1] - feat_start[v]) * desc_bytes;
           if (nb) std::memcpy(desc.data() + (size_t)feat_start[v] * desc_bytes, r->DescriptorRawData(), nb);
         }
-        const size_t ng = guided_pairs.size();
-        std::vector<uint32_t> g_views(2 * std::max<size_t>(ng, 1));
-        std::vector<double> g_model(9 * std::max<size_t>(ng, 1)), g_th(std::max<size_t>(ng, 1));
-        for (size_t q = 0; q < ng; ++q) {
-          const size_t k = guided_pairs[q];
-          g_views[2 * q] = pair_views[2 * k]; g_views[2 * q + 1] = pair_views[2 * k + 1];
-          if constexpr (M::essential) {   // E_ACRobust.hpp:196-197: the epipolar error is taken in pixels, with F = K2^-T E K1^-1
-            Mat3 E, K1, K2, F;
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-              E(r, c) = res[k].F[3 * r + c]; K1(r, c) = view_K[9 * (size_t)pair_views[2 * k] + 3 * r + c]; K2(r, c) = view_K[9 * (size_t)pair_views[2 * k + 1] + 3 * r + c];
-            }
-            FundamentalFromEssential(E, K1, K2, &F);
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g_model[9 * q + 3 * r + c] = F(r, c);
-          } else {
-            std::memcpy(g_model.data() + 9 * q, res[k].F, 9 * sizeof(double));
+        // The accepted pairs go to the device in batches: the call holds one word per left feature of every pair of its
+        // batch, so a batch ends at kGuidedFeaturesPerCall left features (1 GB of device memory; 100 000 pairs of 2 000 features are one
+        // call) - the cancellation flag is looked at between two calls, and a failing call sends only ITS pairs to the reference's
+        // member function (logged once).
+        constexpr uint64_t kGuidedFeaturesPerCall = 1ull << 28;
+        const size_t ng_all = guided_pairs.size();
+        guided_batch_of.assign(ng_all, 0); guided_pos_in_batch.assign(ng_all, 0);
+        for (size_t q0 = 0; q0 < ng_all && !my_progress_bar->hasBeenCanceled();) {
+          size_t q1 = q0; uint64_t feats = 0;
+          while (q1 < ng_all) {
+            const uint32_t vI = pair_views[2 * guided_pairs[q1]];
+            const uint64_t nI = feat_start[vI + 1] - feat_start[vI];
+            if (q1 > q0 && feats + nI > kGuidedFeaturesPerCall) break;
+            feats += nI; ++q1;
           }
-          g_th[q] = Square(res[k].precision_robust);   // (infinity stays infinity: no guided matches, as the functors test)
-        }
-        guided_start.assign(ng + 1, 0);
-        const bool inj = mvgx_adapter::injected("geofilter", "guided");
-        const int rc = inj ? MVGX_ERR_NODEV
-                           : mvgx_guided_match_u8(-1, feat_xy.data(), desc.data(), desc_bytes, feat_start.data(), (uint32_t)n_views, g_views.data(), g_model.data(),
-                                                  g_th.data(), (uint64_t)ng, std::is_same<Functor, GeometricFilter_HMatrix_AC>::value ? MVGX_GUIDED_HOMOGRAPHY
-                                                                                                                                     : MVGX_GUIDED_FUNDAMENTAL,
-                                                  Square(d_distance_ratio), guided_start.data(), &guided_ij, nullptr);
-        if (rc == MVGX_OK) {
-          for (size_t q = 0; q < ng; ++q) guided_done[guided_pairs[q]] = 1;
-          mvgx_adapter::counters().guided_device_pairs.fetch_add(ng);
-        } else {
-          // logged once; the pairs take the reference's own Geometry_guided_matching below (or the failure is thrown)
-          mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", "mvgx_guided_match_u8", rc, inj);
-          guided_pairs.clear();
+          const size_t ng = q1 - q0;
+          std::vector<uint32_t> g_views(2 * ng);
+          std::vector<double> g_model(9 * ng), g_th(ng);
+          for (size_t q = 0; q < ng; ++q) {
+            const size_t k = guided_pairs[q0 + q];
+            g_views[2 * q] = pair_views[2 * k]; g_views[2 * q + 1] = pair_views[2 * k + 1];
+            if constexpr (M::essential) {   // E_ACRobust.hpp:196-197: the epipolar error is taken in pixels, with F = K2^-T E K1^-1
+              Mat3 E, K1, K2, F;
+              for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+                E(r, c) = res[k].F[3 * r + c]; K1(r, c) = view_K[9 * (size_t)pair_views[2 * k] + 3 * r + c]; K2(r, c) = view_K[9 * (size_t)pair_views[2 * k + 1] + 3 * r + c];
+              }
+              FundamentalFromEssential(E, K1, K2, &F);
+              for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g_model[9 * q + 3 * r + c] = F(r, c);
+            } else {
+              std::memcpy(g_model.data() + 9 * q, res[k].F, 9 * sizeof(double));
+            }
+            g_th[q] = Square(res[k].precision_robust);   // (infinity stays infinity: no guided matches, as the functors test)
+          }
+          guided_batches.emplace_back();
+          GuidedBatch& gb = guided_batches.back();
+          gb.start.assign(ng + 1, 0);
+          const bool inj = mvgx_adapter::injected("geofilter", "guided");
+          const int rc = inj ? MVGX_ERR_NODEV
+                             : mvgx_guided_match_u8(-1, feat_xy.data(), desc.data(), desc_bytes, feat_start.data(), (uint32_t)n_views, g_views.data(), g_model.data(),
+                                                    g_th.data(), (uint64_t)ng, std::is_same<Functor, GeometricFilter_HMatrix_AC>::value ? MVGX_GUIDED_HOMOGRAPHY
+                                                                                                                                       : MVGX_GUIDED_FUNDAMENTAL,
+                                                    Square(d_distance_ratio), gb.start.data(), &gb.ij, nullptr);
+          if (rc == MVGX_OK) {
+            for (size_t q = 0; q < ng; ++q) {
+              guided_done[guided_pairs[q0 + q]] = 1;
+              guided_batch_of[q0 + q] = (uint32_t)(guided_batches.size() - 1); guided_pos_in_batch[q0 + q] = (uint32_t)q;
+            }
+            mvgx_adapter::counters().guided_device_pairs.fetch_add(ng);
+          } else {
+            // logged once; the pairs of this batch take the reference's own Geometry_guided_matching below (or the failure is thrown)
+            mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", "mvgx_guided_match_u8", rc, inj);
+          }
+          q0 = q1;
         }
       }
     }
@@ -410,9 +438,11 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
         }
         if (ok && b_guided_matching && guided_done[k]) {
           const int64_t q = guided_index[k];
+          const GuidedBatch& gb = guided_batches[guided_batch_of[q]];
+          const uint32_t qb = guided_pos_in_batch[q];
           IndMatches g;
-          g.reserve(guided_start[q + 1] - guided_start[q]);
-          for (uint64_t e = guided_start[q]; e < guided_start[q + 1]; ++e) g.emplace_back(guided_ij[2 * e], guided_ij[2 * e + 1]);
+          g.reserve(gb.start[qb + 1] - gb.start[qb]);
+          for (uint64_t e = gb.start[qb]; e < gb.start[qb + 1]; ++e) g.emplace_back(gb.ij[2 * e], gb.ij[2 * e + 1]);
           std::swap(inliers, g);
         } else if (ok && b_guided_matching) {
           mvgx_adapter::counters().guided_host_pairs.fetch_add(1);

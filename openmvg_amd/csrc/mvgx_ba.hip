@@ -127,12 +127,16 @@ constexpr int kGroupPts = MVGX_GROUP_PTS;                         // 3 x points 
 constexpr int kGroupThreads = MVGX_GROUP_THREADS;                 // one observation per thread: a group holds at most this many observations
 constexpr int kGroupWaves = kGroupThreads / 64;
 constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves;
-constexpr int kGroupRS = 3 * kGroupPts + 2;                       // doubles between columns in LDS, = 2 x odd (mod 32): the 16 columns x 2 rows a
-                                                                  // half wave reads as an MFMA operand then fall on distinct banks
-static_assert(kGroupPts % 4 == 0 && (kGroupRS % 4) == 2 && kGroupPts <= 255 && kGroupIntr == 2, "group tile layout (the slot ranges assume two local intrinsics)");
+// The staged matrix lies ROW-major in LDS (round 6; column-major with a padded column stride before): the six values a thread forms for
+// a row of its pose's columns are three 16-byte writes side by side with its neighbours' (the column-major form scattered 18 8-byte
+// writes of a thread over 18 columns, four distinct bank groups per half wave), and a half wave's MFMA operand - 16 consecutive
+// columns of two rows - is two contiguous 128-byte runs 640 bytes apart: every bank twice, the minimum for 64 x 8 bytes.
+constexpr int kGroupCS = kGroupCols;                              // doubles between rows
+constexpr int kGroupRows = 3 * kGroupPts;
+static_assert(kGroupPts % 4 == 0 && kGroupPts <= 255 && kGroupIntr == 2 && (kGroupCS * 8) % 256 == 128 && (6 * 8) % 16 == 0, "group tile layout (the slot ranges assume two local intrinsics)");
 static_assert(224 >= 128 + 6 * kGroupCams + 8 * kGroupIntr && kGroupThreads >= 224 + 8 * kGroupIntr, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128.., 224..");
 constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
-constexpr int kGroupM = kGroupCols * kGroupRS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
+constexpr int kGroupM = kGroupRows * kGroupCS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
 static_assert(kGroupM >= 24 * (kGroupThreads + 1) && kGroupM >= kGroupOut && kGroupM >= 3 * (kGroupThreads + 1) + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
 constexpr int kGroupSums = kGroupPts * 20, kGroupPtab = kGroupPts * 12;
 constexpr int kGroupCamRow = 6 + kPoseTrig + 6;                     // per local pose: parameters | rotation terms | column scales
@@ -140,7 +144,7 @@ constexpr int kGroupIntrRow = 8 + 8;                              // per local i
 constexpr int kGroupCandRow = 6 + kPoseTrig;                       // per local pose of the candidate x + delta: parameters | rotation terms
 constexpr int kGroupCand = kGroupCams * kGroupCandRow + kGroupIntr * 8 + 3 * kGroupPts;   // back-substitution with the candidate's cost: the candidate's cameras, the point threads' running sums
 constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr + kGroupCand;   // ... the solution's components, the candidate
-constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr + 2) * (int)sizeof(uint32_t);
+constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr + 2 + kGroupPairsPP + kGroupPairsPI + kGroupPairsII) * (int)sizeof(uint32_t);
 // The norms and back-substitution modes never stage the matrix: their region M holds only the per-observation terms of the point
 // sums (18 x (threads + 1) doubles), which lets a third workgroup onto the CU (49 KB instead of 74 KB each).
 constexpr int kGroupMSmall = (18 * (kGroupThreads + 1) + 1) & ~1;
@@ -993,29 +997,37 @@ __global__ __launch_bounds__(64) void ba_schur_products_kernel(TripList L, const
 __device__ __forceinline__ int group_pair_pp(int x, int y) { return x * kGroupCams - x * (x - 1) / 2 + (y - x); }   // x <= y
 __device__ __forceinline__ int group_pair_ii(int k, int l) { return k * kGroupIntr - k * (k - 1) / 2 + (l - k); }   // k <= l
 // upper tile t of the kGroupColTiles x kGroupColTiles tile grid, row by row: (0,0) (0,1) .. (0,4) (1,1) ..
-__device__ __forceinline__ void group_tile(int t, int& ti, int& tj) {
+__device__ __forceinline__ void group_tile(int t, int& ti, int& tj, int n = kGroupColTiles) {
   ti = 0;
-  int n = kGroupColTiles;
   while (t >= n) { t -= n; --n; ++ti; }
   tj = ti + t;
 }
+// The compact form of the staged matrix (round 6): a supergroup that uses ONE local intrinsic whose model has at most kCompactIntr
+// parameters (pinhole: its intrinsic columns beyond are zero by construction) keeps h_p in column 6 kGroupCams + kCompactIntr instead
+// of kGroupHCol - 64 columns, four column tiles, ten tiles of Z^T Z instead of fifteen. Same sums, same bits; the zero elements the
+// five dropped tiles used to deliver are written as zeros when the partial blocks go out.
+constexpr int kCompactIntr = 3;
+constexpr int kCompactHCol = 6 * kGroupCams + kCompactIntr;
+constexpr int kCompactColTiles = (kCompactHCol + 16) / 16;
+constexpr int kCompactTiles = kCompactColTiles * (kCompactColTiles + 1) / 2;
+static_assert(kCompactHCol == 63 && kCompactColTiles == 4, "the compact form is sized for four column tiles");
 // A finished 16 x 16 tile of the supergroup's Z^T Z goes to LDS as partial blocks of the three product families:
 //   out + 0                      [pair (x <= y)][42]  6 x 6 block (+ the rhs of pose x for x == y, from the h column)
 //   out + 55 * 42                [x * kGroupIntr + k][54]  6 x 8 block
 //   out + 55 * 42 + 20 * 54      [pair (k <= l)][72]  8 x 8 block (+ the rhs of intrinsic k for k == l)
 // Only elements with global column I <= J are defined (the upper triangle of a diagonal block is the whole block).
-__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk) {
+__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk, int hcol = kGroupHCol) {
   double* __restrict__ out_pi = out + kGroupPairsPP * kNVpp;
   double* __restrict__ out_ii = out_pi + kGroupPairsPI * kNVpi;
   const int J = 16 * tj + li;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int I = 16 * ti + lk + 4 * reg;
-    if (I >= kGroupHCol || J > kGroupHCol || I > J) continue;
+    if (I >= hcol || J > hcol || I > J) continue;
     const bool i_pose = I < 6 * kGroupCams;
     const int x = i_pose ? I / 6 : (I - 6 * kGroupCams) / 8;
     const int r = i_pose ? I - 6 * x : (I - 6 * kGroupCams) - 8 * x;
-    if (J == kGroupHCol) {   // column of h_p: the rhs
+    if (J == hcol) {   // column of h_p: the rhs
       if (i_pose) out[group_pair_pp(x, x) * kNVpp + 36 + r] = acc[reg];
       else out_ii[group_pair_ii(x, x) * kNVii + 64 + r] = acc[reg];
     } else if (J < 6 * kGroupCams) {   // I <= J: I is a pose column too
@@ -1067,6 +1079,7 @@ __device__ __forceinline__ bool chol_inv3_fast(const double v[6], double li[6]) 
 // (0 observation, 1 point sums, 2 point factors, 3 slots, 4 back-substitution, 5 matrix staging, 6 MFMA, 7 partial blocks out)
 __device__ unsigned long long g_group_stamps[3][8];   // [mode][phase]
 __device__ int g_group_debug;
+__device__ int g_group_compact = 1;   // MVGX_BA_GROUP_COMPACT=0: every supergroup stages the full 80 columns (A/B runs)
 // (summed per workgroup in LDS and added to the global counters once, at the end of the workgroup: an atomic per stamp on eight shared
 // addresses slowed the stamped kernel by 60 % - round 6 - and the wait ended up in whichever phase came next)
 #define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); s_stamps[i] += (unsigned long long)(t_now - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } } while (0)
@@ -1076,7 +1089,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
                                                                        double* __restrict__ part_ii, double* __restrict__ cand_part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [column][kGroupRS] -> partial blocks
+  double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [row][kGroupCS] -> partial blocks
   double* const sums = lds + group_m_doubles<MODE>();   // [point][20]
   double* const ptab = sums + kGroupSums;         // [point][12]: L^-1 (6) | h (3)
   double* const ctab = ptab + kGroupPtab;         // [local pose][kGroupCamRow]: parameters | rotation terms | column scales
@@ -1095,6 +1108,8 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   uint32_t* const pks = pe + kGroupPts + 1;       // [point]: first entry of the point's observations with local intrinsic 1
   int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
   int* const ncam_used = imodel + kGroupIntr;                         // forward: local poses of the supergroup that carry observations
+  uint32_t* const chunk_ids = reinterpret_cast<uint32_t*>(ncam_used + 2);   // forward: destination rows of the supergroup's partial blocks (pp | pi | ii), fetched at the start
+  int* const sg_flags = ncam_used + 1;                                // forward: bit 0 - only local intrinsic 0 is in use, bit 1 - the compact form (see kCompactIntr)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t sg = G.sg_order[blockIdx.x];
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
@@ -1152,7 +1167,19 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     const int x = tid - 192;
     const bool used = x < kGroupCams && G.chunk_pp[(size_t)sg * kGroupPairsPP + group_pair_pp(x, x)] != kNoChunk;
     const int n_used = (int)__popcll(__ballot(used));
-    if (x == 0) *ncam_used = n_used;
+    if (x == 0) {
+      *ncam_used = n_used;
+      const bool single = G.chunk_ii[(size_t)sg * kGroupPairsII + group_pair_ii(1, 1)] == kNoChunk;   // no point of the supergroup sees local intrinsic 1
+      const int pc = intr_param_count(d.model[intrs[0]]);
+      *sg_flags = (single ? 1 : 0) | (single && pc >= 0 && pc <= kCompactIntr && g_group_compact ? 2 : 0);
+    }
+  }
+  if (MODE == kGroupForward && tid >= 96 && tid < 96 + kGroupPairsPP + kGroupPairsPI + kGroupPairsII) {
+    // (the last phase used to fetch a block's destination element by element: fourteen dependent trips to memory per workgroup, 8 us)
+    const int j = tid - 96;
+    chunk_ids[j] = j < kGroupPairsPP ? G.chunk_pp[(size_t)sg * kGroupPairsPP + j]
+                 : j < kGroupPairsPP + kGroupPairsPI ? G.chunk_pi[(size_t)sg * kGroupPairsPI + (j - kGroupPairsPP)]
+                 : G.chunk_ii[(size_t)sg * kGroupPairsII + (j - kGroupPairsPP - kGroupPairsPI)];
   }
   if (MODE == kGroupForward) {
     // The reduced system is zeroed here, a slice per workgroup - the assemble pass that follows this kernel writes only the blocks
@@ -1169,6 +1196,20 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   long long t_prev = stamping ? __builtin_amdgcn_s_memtime() : 0;
   // The first words of a group (its ranges, this thread's entry, the point of a point thread) are fetched one group ahead: they
   // head the chains of dependent loads (entry -> ids -> parameters), which then start from registers.
+  // forward: the form of the staged matrix (the flags were set by wave 3 above)
+  int hcol = kGroupHCol, n_tiles = kGroupTiles;
+  bool single_intr = false;
+  if (MODE == kGroupForward) {
+    __syncthreads();
+    const int fl = *sg_flags;
+    single_intr = (fl & 1) != 0;
+    if (fl & 2) {
+      hcol = kCompactHCol; n_tiles = kCompactTiles;
+#pragma unroll
+      for (int j = 0; j < kGroupTilesPerWave; ++j) group_tile(min(wave + j * kGroupWaves, kCompactTiles - 1), tti[j], ttj[j], kCompactColTiles);
+    }
+  }
+  const bool compact = hcol != kGroupHCol;
   uint32_t nx_e0 = G.obs_start[g0], nx_ne = G.obs_start[g0 + 1] - nx_e0, nx_p0 = G.pt_start[g0], nx_np = G.pt_start[g0 + 1] - nx_p0;
   uint32_t nx_qxk = (uint32_t)tid < nx_ne ? G.eq[nx_e0 + tid] : 0u;
   double2 nx_xy = (uint32_t)tid < nx_ne ? G.exy[nx_e0 + tid] : make_double2(0.0, 0.0);
@@ -1379,10 +1420,18 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     // ---- 4. intrinsic slots: Zint[q][k][:, c] = L_q^-1 sum over the point's observations with local intrinsic k of Es^T Fi_s[:, c] ----
     // (the sums of step 2 have been read: the terms of this step may replace them)
     if (has) {
+      if (compact) {   // (uniform) the columns beyond kCompactIntr are zero and have no place in the compact matrix
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < kCompactIntr; ++c) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NS + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
+          for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NS + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+          for (int e = 0; e < 3; ++e) M[(e * 8 + c) * NS + tid] = es0[e] * fi0[c] + es1[e] * fi1[c];
+        }
       }
     }
     __syncthreads();
@@ -1393,9 +1442,35 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     double zs[kGroupIntr][3];
 #pragma unroll
     for (int k = 0; k < kGroupIntr; ++k) zs[k][0] = zs[k][1] = zs[k][2] = 0.0;
+    const int slot_sh = compact ? 2 : 3;   // items per point: 4 (3 in use) or 8
+    const int slot_pq = tid >> slot_sh, slot_c = tid & ((1 << slot_sh) - 1);
+    const bool slot_item = slot_pq < (int)np && (!compact || slot_c < kCompactIntr);
     {
-      const int pq = tid >> 3, c = tid & 7;
-      if (pq < (int)np) {
+      const int pq = slot_pq, c = slot_c;
+      if (slot_item && single_intr) {
+        // (uniform choice) every entry of the point belongs to local intrinsic 0: one range, its terms added in entry order behind a
+        // 0 / 1 factor (y + t * 1 = y + t, y + t * 0 = y: the bits of the masked sums below)
+        const uint32_t elo = pe[pq], ehi = pe[pq + 1];
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          double t0[kGroupCams / 2], t1[kGroupCams / 2], t2[kGroupCams / 2];
+#pragma unroll
+          for (int j = 0; j < kGroupCams / 2; ++j) {
+            const uint32_t e = min(elo + (uint32_t)(half * (kGroupCams / 2) + j), ehi - 1);
+            t0[j] = M[c * NS + e]; t1[j] = M[(8 + c) * NS + e]; t2[j] = M[(16 + c) * NS + e];
+          }
+#pragma unroll
+          for (int j = 0; j < kGroupCams / 2; ++j) {
+            const double m = elo + (uint32_t)(half * (kGroupCams / 2) + j) < ehi ? 1.0 : 0.0;
+            y0 = fma(t0[j], m, y0); y1 = fma(t1[j], m, y1); y2 = fma(t2[j], m, y2);
+          }
+        }
+        const double* __restrict__ pt = ptab + pq * 12;
+        zs[0][0] = pt[0] * y0;
+        zs[0][1] = pt[1] * y0 + pt[2] * y1;
+        zs[0][2] = pt[3] * y0 + pt[4] * y1 + pt[5] * y2;
+      } else if (slot_item) {
         const uint32_t elo = pe[pq], ehi = pe[pq + 1], esp = pks[pq];
         double y[kGroupIntr][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
 #pragma unroll
@@ -1438,41 +1513,45 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       for (int i = tid; i < kGroupM / 2; i += NT) reinterpret_cast<double2*>(M)[i] = make_double2(0.0, 0.0);
       __syncthreads();
     } else {
-      const int npad = rows - 3 * (int)np;   // 0..3 rows
-      for (int i = tid; i < kGroupCols * npad; i += NT) M[(i / npad) * kGroupRS + 3 * (int)np + (i - (i / npad) * npad)] = 0.0;
+      const int npad = rows - 3 * (int)np;   // 0..3 rows of zeros behind the last point
+      for (int i = tid; i < kGroupCS * npad; i += NT) M[3 * (int)np * kGroupCS + i] = 0.0;
     }
     if (has) {
-      double* __restrict__ dst = M + (6 * x) * kGroupRS + 3 * q;
+      // Z = L^-1 Es^T Fc_s as (L^-1 Es^T) Fc_s: the two columns a0, a1 of L^-1 Es^T (3 x 2) first - 12 operations - then two per element
+      // (the element-by-element form L^-1 (Es^T Fc_s) took 12 per column: 72 against 48)
+      const double a0[3] = {ptq[0] * es0[0], ptq[1] * es0[0] + ptq[2] * es0[1], ptq[3] * es0[0] + ptq[4] * es0[1] + ptq[5] * es0[2]};
+      const double a1[3] = {ptq[0] * es1[0], ptq[1] * es1[0] + ptq[2] * es1[1], ptq[3] * es1[0] + ptq[4] * es1[1] + ptq[5] * es1[2]};
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double y0 = es0[0] * fc0[c] + es1[0] * fc1[c], y1 = es0[1] * fc0[c] + es1[1] * fc1[c], y2 = es0[2] * fc0[c] + es1[2] * fc1[c];
-        dst[c * kGroupRS + 0] = ptq[0] * y0;
-        dst[c * kGroupRS + 1] = ptq[1] * y0 + ptq[2] * y1;
-        dst[c * kGroupRS + 2] = ptq[3] * y0 + ptq[4] * y1 + ptq[5] * y2;
+      for (int r = 0; r < 3; ++r) {
+        double2* __restrict__ dst = reinterpret_cast<double2*>(M + (3 * q + r) * kGroupCS + 6 * x);   // (16-byte aligned: 640 (3 q + r) + 48 x)
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) dst[c / 2] = make_double2(a0[r] * fc0[c] + a1[r] * fc1[c], a0[r] * fc0[c + 1] + a1[r] * fc1[c + 1]);
       }
     }
-    if ((tid >> 3) < (int)np) {
-      const int pq = tid >> 3, c = tid & 7;
+    if (slot_item) {
+      const int pq = slot_pq, c = slot_c;
 #pragma unroll
-      for (int k = 0; k < kGroupIntr; ++k) {   // column 8 k + c behind the pose columns
-        double* __restrict__ dst = M + (6 * kGroupCams + 8 * k + c) * kGroupRS + 3 * pq;
-        dst[0] = zs[k][0]; dst[1] = zs[k][1]; dst[2] = zs[k][2];
+      for (int k = 0; k < kGroupIntr; ++k) {   // column 8 k + c behind the pose columns (compact: local intrinsic 0 only)
+        if (k == 0 || !compact) {
+          double* __restrict__ dst = M + 3 * pq * kGroupCS + (6 * kGroupCams + 8 * k + c);
+          dst[0] = zs[k][0]; dst[kGroupCS] = zs[k][1]; dst[2 * kGroupCS] = zs[k][2];
+        }
       }
     }
     if ((uint32_t)tid < np) {
-      double* __restrict__ dst = M + kGroupHCol * kGroupRS + 3 * tid;
-      dst[0] = ptab[tid * 12 + 6]; dst[1] = ptab[tid * 12 + 7]; dst[2] = ptab[tid * 12 + 8];
+      double* __restrict__ dst = M + 3 * tid * kGroupCS + hcol;
+      dst[0] = ptab[tid * 12 + 6]; dst[kGroupCS] = ptab[tid * 12 + 7]; dst[2 * kGroupCS] = ptab[tid * 12 + 8];
     }
     __syncthreads();
     MVGX_GSTAMP(5);
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
 #pragma unroll
     for (int j = 0; j < kGroupTilesPerWave; ++j) {
-      if (wave + j * kGroupWaves < kGroupTiles) {   // wave-uniform
-        const double* __restrict__ ca = M + (16 * tti[j] + li) * kGroupRS + lk;
-        const double* __restrict__ cb = M + (16 * ttj[j] + li) * kGroupRS + lk;
+      if (wave + j * kGroupWaves < n_tiles) {   // wave-uniform
+        const double* __restrict__ ca = M + lk * kGroupCS + 16 * tti[j] + li;
+        const double* __restrict__ cb = M + lk * kGroupCS + 16 * ttj[j] + li;
         d4_t a = acc[j];
-        for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0], cb[k0], a, 0, 0, 0);
+        for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0 * kGroupCS], cb[k0 * kGroupCS], a, 0, 0, 0);
         acc[j] = a;
       }
     }
@@ -1489,33 +1568,33 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
   __syncthreads();
   double* const out = M;
+  if (compact) {   // (uniform) what the dropped tiles held: zero rows / columns of the intrinsic's blocks beyond kCompactIntr
+    for (int i = tid; i < kGroupPairsPI * kNVpi + kGroupPairsII * kNVii; i += NT) out[kGroupPairsPP * kNVpp + i] = 0.0;
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < kGroupTilesPerWave; ++j)
-    if (wave + j * kGroupWaves < kGroupTiles) group_store_tile(acc[j], tti[j], ttj[j], out, li, lk);
+    if (wave + j * kGroupWaves < n_tiles) group_store_tile(acc[j], tti[j], ttj[j], out, li, lk, hcol);
   {
     const double gm = block_max(gmax, sums);   // (block_max synchronises: the tiles above are in LDS afterwards)
     if (tid == 0) G.gmax_part[sg] = gm;
   }
   __syncthreads();
-  const uint32_t* __restrict__ cpp = G.chunk_pp + (size_t)sg * kGroupPairsPP;
-  const uint32_t* __restrict__ cpi = G.chunk_pi + (size_t)sg * kGroupPairsPI;
-  const uint32_t* __restrict__ cii = G.chunk_ii + (size_t)sg * kGroupPairsII;
-  // (elements a block does not define - the rhs of an off-diagonal block, the lower triangle of a diagonal one - carry whatever
-  // the region held: ba_schur_assemble never uses them)
-  for (int idx = tid; idx < kGroupPairsPP * kNVpp; idx += NT) {
-    const int pair = idx / kNVpp;
-    const uint32_t ch = cpp[pair];
-    if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + (idx - pair * kNVpp)] = out[idx];
+  // a wave per block, a lane per element (elements a block does not define - the rhs of an off-diagonal block, the lower triangle of a
+  // diagonal one - carry whatever the region held: ba_schur_assemble never uses them)
+  static_assert(kNVpp <= 64 && kNVpi <= 64 && kNVii <= 128, "a block is one or two rows of lanes");
+  for (int pair = wave; pair < kGroupPairsPP; pair += kGroupWaves) {
+    const uint32_t ch = chunk_ids[pair];
+    if (ch != kNoChunk && lane < kNVpp) part_pp[(size_t)ch * kNVpp + lane] = out[pair * kNVpp + lane];
   }
-  for (int idx = tid; idx < kGroupPairsPI * kNVpi; idx += NT) {
-    const int pair = idx / kNVpi;
-    const uint32_t ch = cpi[pair];
-    if (ch != kNoChunk) part_pi[(size_t)ch * kNVpi + (idx - pair * kNVpi)] = out[kGroupPairsPP * kNVpp + idx];
+  for (int pair = wave; pair < kGroupPairsPI; pair += kGroupWaves) {
+    const uint32_t ch = chunk_ids[kGroupPairsPP + pair];
+    if (ch != kNoChunk && lane < kNVpi) part_pi[(size_t)ch * kNVpi + lane] = out[kGroupPairsPP * kNVpp + pair * kNVpi + lane];
   }
-  for (int idx = tid; idx < kGroupPairsII * kNVii; idx += NT) {
-    const int pair = idx / kNVii;
-    const uint32_t ch = cii[pair];
-    if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + (idx - pair * kNVii)] = out[kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + idx];
+  for (int it = wave; it < 2 * kGroupPairsII; it += kGroupWaves) {
+    const int pair = it >> 1, e = 64 * (it & 1) + lane;
+    const uint32_t ch = chunk_ids[kGroupPairsPP + kGroupPairsPI + pair];
+    if (ch != kNoChunk && e < kNVii) part_ii[(size_t)ch * kNVii + e] = out[kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + pair * kNVii + e];
   }
   MVGX_GSTAMP(7);
   MVGX_GSTAMP_FLUSH();
@@ -4242,6 +4321,10 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
     static std::atomic<int> last_on{0};
     const int on = getenv("MVGX_BA_GROUP_DEBUG") ? 1 : 0;
     if (last_on.exchange(on) != on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_debug), &on, sizeof(on));
+    static std::atomic<int> last_compact{1};
+    const char* env_c = getenv("MVGX_BA_GROUP_COMPACT");
+    const int compact_on = env_c ? (atoi(env_c) != 0) : 1;
+    if (last_compact.exchange(compact_on) != compact_on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_group_compact), &compact_on, sizeof(compact_on));
   }
   if (const char* env = getenv("MVGX_BA_MODEL_COST")) c->model_cost_from_jacobian = !strcmp(env, "jacobian");
   if (const char* env = getenv("MVGX_BA_SOLVER")) {

@@ -271,6 +271,9 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   if (n_pairs == 0) return MVGX_OK;
   int rc = mvgx::select_device(device);
   if (rc) return rc;
+  // (declared BEFORE the stream guard - destroyed after it: on every exit the stream is drained before the slabs of this call go back
+  // to the process-wide cache, where a concurrent call could pick them up while kernels enqueued here still write - ADVICE r5)
+  mvgx::Arena arena;   // device memory of this call
   hipStream_t stream = nullptr;
   if ((rc = mvgx::acquire_stream(&stream))) return rc;
   int dev = 0;
@@ -278,7 +281,6 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   struct StreamGuard { int d; hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); mvgx::release_stream(d, s); } } guard{dev, stream};
 
   const int DW = (int)desc_bytes / 4;
-  mvgx::Arena arena;   // device memory of this call
   DevArray<double2> d_xy; DevArray<uint32_t> d_desc; DevArray<int> d_norm; DevArray<uint64_t> d_fs, d_ls, d_ms; DevArray<uint32_t> d_pairs, d_best, d_count, d_ij;
   DevArray<double> d_models, d_th; DevArray<uint2> d_work; DevArray<unsigned long long> d_ctr;
   if ((rc = d_xy.alloc(arena, n_feat)) || (rc = d_desc.alloc(arena, n_feat * DW)) || (rc = d_norm.alloc(arena, n_feat)) || (rc = d_fs.alloc(arena, n_images + 1)) || (rc = d_ls.alloc(arena, n_pairs + 1)) ||
@@ -347,7 +349,10 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
     if (e == hipSuccess) e = hipMemcpyAsync(pinned ? pinned : out, d_ij.p, 2 * total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess && pinned) std::memcpy(out, pinned, 2 * total * sizeof(uint32_t));
-    if (e != hipSuccess) { free(out); set_error("mvgx_guided_match_u8: %s", hipGetErrorString(e)); return MVGX_ERR_HIP; }
+    if (e != hipSuccess) {   // (drained before the page-locked staging block goes back to the cache: a copy into it may still be in flight)
+      (void)hipStreamSynchronize(stream);
+      free(out); set_error("mvgx_guided_match_u8: %s", hipGetErrorString(e)); return MVGX_ERR_HIP;
+    }
   }
   *matches_ij = out;
   if (stats) {

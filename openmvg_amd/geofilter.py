@@ -287,9 +287,12 @@ def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRa
                                                  models.ctypes.data, th.ctypes.data, len(pairs), int(kind), ratio_sq, ms.ctypes.data, C.byref(out), C.byref(st)))
     try:
         total = int(ms[-1])
-        ij = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(max(total, 1) * 2,))[:2 * total].reshape(-1, 2).copy()
+        if total and out:   # (no pair / no match: the library hands back NULL - as_array on it raises)
+            ij = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), shape=(total * 2,)).reshape(-1, 2).copy()
+        else:
+            ij = np.zeros((0, 2), np.uint32)
     finally:
-        _capi.lib().mvgx_host_free(out)
+        _capi.lib().mvgx_host_free(out)   # (free(NULL) is fine)
     res = {}
     for p in range(len(pairs)):
         lo, hi = int(ms[p]), int(ms[p + 1])

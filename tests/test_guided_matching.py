@@ -203,3 +203,12 @@ def test_adapter_guided_matching_injected_failure_takes_the_reference_member_fun
     lib.mvgx_adapter_counters(out, 1)
     assert on_device == 0 and on_host == len(got) and int(out[2]) == 1
     assert set(want) == set(got) and all(np.array_equal(want[k], got[k]) for k in want)
+
+
+
+#  main_GeometricFilter -g h passes ratio -1 with guided matching, which selects H_ACRobust.hpp:166-187's geometry-only matching.
+# The replacement TU leaves such a call to the functor's own member function (it used to run the descriptor-ratio kernel with ratio^2 = 1).
+# There is no test against the reference for it: the reference's own code for that branch cannot run - H_ACRobust.hpp:118-124 takes the
+# output matrix as Eigen::Ref<Mat> and resizes it (an assertion in a build with assertions, a write through a null pointer without:
+# python /tmp: "DenseBase::resize() does not actually allow to resize", observed with oracle/_ref's build of the file). What the adapter
+# does with a negative ratio is therefore exactly what the host application's functor does.
