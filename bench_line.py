@@ -112,6 +112,10 @@ def compact(out, side_file=None):
                      ("geometric_filter_homography", "geo_h"), ("geometric_filter_essential", "geo_e"), ("guided_matching", "guided")):
         if k in out:
             side[short] = _side(out[k])
+    amb = out.get("adapter_match_boundary")
+    if isinstance(amb, dict):
+        side["match_boundary"] = ({"status": str(amb["status"])[:80]} if "status" in amb else
+                                  _pick(amb, ("value", "first_call_s", "repeated_call_s", "device_failures", "fallback_pairs"), 4))
     # (the a / u / o functors are not rows of SURVEY 8: their records stay in the side file only - VERDICT r5 item 7)
     if side:
         line["side"] = side

@@ -26,8 +26,10 @@
 // regions are skipped but counted; regions of different Type_id are skipped; only non-empty match vectors are
 // inserted; insert() is called from the calling thread only; cancellation is polled between device batches.
 // Several GPUs: MVGX_DEVICES=all (or a list of ordinals) in the environment of the unchanged main_ComputeMatches.
+#include <cstddef>
 #include <cstdint>
 #include <map>
+#include <type_traits>
 #include <memory>
 #include <atomic>
 #include <chrono>
@@ -150,9 +152,11 @@ class ListBuilder {
       for (uint64_t k = c * kChunk, hi = std::min(j.nb, k + kChunk); k < hi; ++k) {
         const uint64_t lo = j.offset(k), n = j.offset(k + 1) - lo;
         if (!n) continue;
-        matching::IndMatches& v = j.lists[k];
-        v.reserve(n);
-        for (uint64_t m = 0; m < n; ++m) v.emplace_back(j.ij[2 * (lo + m)], j.ij[2 * (lo + m) + 1]);
+        // one allocation and one block copy per pair: IndMatch is two IndexT side by side (indMatch.hpp:25-46), the device's (i, j) words
+        static_assert(sizeof(matching::IndMatch) == 2 * sizeof(uint32_t) && std::is_trivially_copyable<matching::IndMatch>::value &&
+                      offsetof(matching::IndMatch, i_) == 0 && offsetof(matching::IndMatch, j_) == sizeof(uint32_t), "IndMatch is the (i, j) pair of the device lists");
+        const matching::IndMatch* first = reinterpret_cast<const matching::IndMatch*>(j.ij + 2 * lo);
+        j.lists[k].assign(first, first + n);
       }
     } catch (...) {
       j.error = std::current_exception();   // (any chunk's failure fails the job; rethrown on the calling thread)
@@ -183,6 +187,22 @@ class ListBuilder {
   bool stop_ = false;
   std::vector<std::thread> pool_;
 };
+
+// The SIFT context of the last Match() call is KEPT (round 6): its device scratch (two batch slots), its page-locked result buffers and
+// its streams are what create / destroy cost - 25 + 46 ms of a 0.6 s call at 1 000 x 2 000 - and none of it depends on the image set; the
+// next call uploads its own regions into it (mvgx_match_set_regions reuses what fits). One context per process, taken by one Match() at
+// a time (a concurrent call makes its own, as before); MVGX_ADAPTER_KEEP_CONTEXT=0 restores create / destroy per call, and
+// mvgx_adapter_match_release_context() hands the memory back (tests; a host that is done matching).
+struct KeptMatchContext {
+  std::mutex mu;
+  mvgx_match_ctx* ctx = nullptr;
+  bool busy = false;
+};
+KeptMatchContext& kept_match_context() { static KeptMatchContext* k = new KeptMatchContext(); return *k; }   // (never destroyed: no HIP call at process exit)
+bool keep_context_enabled() {
+  const char* env = std::getenv("MVGX_ADAPTER_KEEP_CONTEXT");
+  return !env || std::atoi(env) != 0;
+}
 
 unsigned builder_helpers() { return std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u); }
 
@@ -304,12 +324,21 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       mvgx_hamming_ctx* hm = nullptr;
       mvgx_l2f_ctx* lf = nullptr;
       mvgx_l2u8_ctx* lu = nullptr;
+      bool l2_kept = false;    // l2 is the process's kept context, held by this call
+      bool l2_healthy = true;  // ... and goes back to the holder (false after a failing device call: destroyed instead)
       void release() {
         if (hm) mvgx_hamming_destroy(hm);
         if (lf) mvgx_l2f_destroy(lf);
         if (lu) mvgx_l2u8_destroy(lu);
-        if (l2) mvgx_match_destroy(l2);
-        hm = nullptr; lf = nullptr; lu = nullptr; l2 = nullptr;
+        if (l2 && l2_kept) {
+          KeptMatchContext& k = kept_match_context();
+          std::lock_guard<std::mutex> lk(k.mu);
+          if (!l2_healthy) { mvgx_match_destroy(l2); k.ctx = nullptr; }
+          k.busy = false;
+        } else if (l2) {
+          mvgx_match_destroy(l2);
+        }
+        hm = nullptr; lf = nullptr; lu = nullptr; l2 = nullptr; l2_kept = false;
       }
       ~Contexts() { release(); }
     } ctx;
@@ -323,13 +352,43 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       if (!inj && rc_call == MVGX_OK) return true;
       mvgx_adapter::device_failure(mvgx_adapter::kMatch, "matching", stage, inj ? MVGX_ERR_NODEV : rc_call, inj);
       failed = true;
+      ctx.l2_healthy = false;   // (a kept context that failed is not kept)
       return false;
     };
     const uint32_t n_img = static_cast<uint32_t>(ids.size());
     int rc = MVGX_OK;
     bool inj = injected("match", "create");
-    if (!inj) rc = hamming ? mvgx_hamming_create(-1, &ctx.hm) : f32 ? mvgx_l2f_create(-1, &ctx.lf) : u8o ? mvgx_l2u8_create(-1, &ctx.lu)
-                                                                                                        : mvgx_match_create(-1, &ctx.l2);
+    const bool sift = !hamming && !f32 && !u8o;
+    if (!inj && sift && keep_context_enabled()) {   // the kept context, when no other call holds it
+      KeptMatchContext& k = kept_match_context();
+      std::lock_guard<std::mutex> lk(k.mu);
+      if (!k.busy) {
+        if (!k.ctx) rc = mvgx_match_create(-1, &k.ctx);
+        if (rc == MVGX_OK) { ctx.l2 = k.ctx; ctx.l2_kept = true; k.busy = true; }
+      }
+    }
+    if (!inj && !ctx.l2_kept && rc == MVGX_OK)
+      rc = hamming ? mvgx_hamming_create(-1, &ctx.hm) : f32 ? mvgx_l2f_create(-1, &ctx.lf) : u8o ? mvgx_l2u8_create(-1, &ctx.lu)
+                                                                                                 : mvgx_match_create(-1, &ctx.l2);
+    // (SIFT path) the page-locked result buffers of the stream are obtained on a helper thread WHILE the regions are uploaded: in the first
+    // call of a process they cost what the plain-memory copies they replace cost (~100 ms at 1 000 x 2 000), later calls find them in place
+    std::thread reserve_thread;
+    struct JoinReserve { std::thread& t; ~JoinReserve() { if (t.joinable()) t.join(); } } join_reserve{reserve_thread};
+    if (!inj && rc == MVGX_OK && ctx.l2) {
+      const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");
+      const char* envb = std::getenv("MVGX_ADAPTER_BATCH_PAIRS");
+      const int64_t batch_pairs = envb ? std::max(1, std::atoi(envb)) : (1 << 14);
+      mvgx_match_set_option(ctx.l2, "stream_hold", 1);
+      mvgx_match_set_option(ctx.l2, "pinned_stream", env ? std::atoi(env) : 1);
+      mvgx_match_set_option(ctx.l2, "batch_pairs", batch_pairs);
+      uint64_t sum_desc = 0;
+      for (uint32_t v : n_desc) sum_desc += v;
+      // a guess at a batch's lists: 0.4 matches per feature of the left image (dense synthetic sets reach 0.2, real image sets a tenth
+      // of that), capped at 128 MB per buffer; a batch that exceeds its buffer re-pins it with headroom (the library's rule)
+      const uint64_t words = std::min<uint64_t>((128u << 20) / 4, (uint64_t)(0.4 * 2.0 * (double)batch_pairs * (double)sum_desc / std::max<size_t>(n_desc.size(), 1)));
+      mvgx_match_ctx* l2 = ctx.l2;
+      reserve_thread = std::thread([l2, words]() { (void)mvgx_match_set_option(l2, "stream_reserve", (int64_t)words); });   // (a failure here: the run allocates itself)
+    }
     if (step("create", rc, inj)) {
       inj = injected("match", "set_regions");
       if (!inj)
@@ -339,15 +398,17 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
                      : mvgx_match_set_regions(ctx.l2, rows.data(), n_desc.data(), n_img, 128);
       step("set_regions", rc, inj);
     }
+    if (reserve_thread.joinable()) reserve_thread.join();
     tick("context + upload + tile build");
     if (!failed && ctx.l2) {
       // SIFT path: the lists arrive batch by batch on THIS thread (mvgx_match_run_stream) while the device(s) work on the
       // next batches; host memory beside the container itself is two batches per device. Cancellation is polled per batch.
       // "stream_hold": a batch's buffers outlive two further sink calls, so batch k is converted by the helper threads while
       // batches k + 1 and k + 2 arrive; the container takes batch k - 2 at call k (and the rest after the run) - on this thread.
-      mvgx_match_set_option(ctx.l2, "stream_hold", 1);
-      { const char* env = std::getenv("MVGX_ADAPTER_PINNED_RESULTS");   // one Match() per context: pinning the buffers rarely pays
-        mvgx_match_set_option(ctx.l2, "pinned_stream", env ? std::atoi(env) : 0); }
+      // (options set above, before the regions went up: "stream_hold" - a batch's buffers outlive two further sink calls -, the lists
+      // through page-locked buffers - round 6: into plain memory the runtime stages the copies itself, 976 MB of lists at 1 000 x 2 000
+      // took 130 ms longer than the device needs for the whole run (call r6_09: 336 against 208 ms with the sink switched off) -, batches
+      // of 16 384 pairs: four buffers of ~70 MB at that size)
       ListBuilder list_builder(builder_helpers());
       struct Stream {
         ListBuilder& builder; const Sink* sink; const uint32_t* pairs; system::ProgressInterface* progress; std::exception_ptr error;
@@ -411,7 +472,7 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
       tick("reference route after a device failure");
     }
     ctx.release();
-    tick("context destroy");
+    tick("context release");
   }
 
   if (!generic_pairs.empty())
@@ -420,3 +481,13 @@ void Matcher_Regions::Match(const std::shared_ptr<sfm::Regions_Provider>& region
 
 }  // namespace matching_image_collection
 }  // namespace openMVG
+
+// releases the kept SIFT context (device scratch, page-locked buffers); a Match() in flight keeps its hold: returns 0 then, 1 when released / nothing was kept
+extern "C" int mvgx_adapter_match_release_context() {
+  using openMVG::matching_image_collection::kept_match_context;
+  auto& k = kept_match_context();
+  std::lock_guard<std::mutex> lk(k.mu);
+  if (k.busy) return 0;
+  if (k.ctx) { mvgx_match_destroy(k.ctx); k.ctx = nullptr; }
+  return 1;
+}

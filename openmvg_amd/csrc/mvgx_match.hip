@@ -1693,6 +1693,20 @@ int mvgx_match_set_option(mvgx_match_ctx* c, const char* key, int64_t value) {
     c->stream_hold = value != 0;
   } else if (!strcmp(key, "pinned_stream")) {
     c->pinned_stream = value != 0;
+  } else if (!strcmp(key, "stream_reserve")) {
+    // Page-locks the host buffers of the stream mode ahead of the run (value: uint32 words per buffer; with "stream_hold" four
+    // buffers, else two): a caller does this on another thread while its regions are uploaded - pinning ~100 MB takes tens of
+    // milliseconds, which the first batches of a run would otherwise wait for. Only with "pinned_stream"; buffers that are larger stay.
+    MVGX_REQUIRE(value >= 0 && value <= (int64_t)1 << 31, MVGX_ERR_ARG, "stream_reserve: words per buffer in [0, 2^31]");
+    if (c->pinned_stream && value > 0) {
+      MVGX_HIP(hipSetDevice(c->device));
+      for (auto& sl : c->slot)
+        for (int set = 0; set < (c->stream_hold ? 2 : 1); ++set) {
+          PinnedBuf<uint32_t>& hb = sl.hp_ij[set];
+          if (!hb.p) hb.pageable = false;
+          if (!hb.pageable && (size_t)value > hb.cap) { hb.release(); const int rc = hb.grow_keep((size_t)value, 0); if (rc) return rc; }
+        }
+    }
   } else if (!strcmp(key, "double_buffer_results")) {
     c->double_buffer = value != 0;
   } else if (!strcmp(key, "pinned_results")) {
