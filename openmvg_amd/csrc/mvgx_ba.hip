@@ -2149,9 +2149,13 @@ __global__ __launch_bounds__(256) void chol_diag_inv_kernel(double* __restrict__
 // destination tile and walks its contributors in a fixed order: operands go straight from L2 into the f64 MFMA (the
 // tiles are stored so that an operand fragment is 16 consecutive doubles), no LDS, no barriers, no atomics.
 // ------------------------------------------------------------------------------------------------------
+constexpr long long kZNotYet = 0x7FF84D5647580001ll;   // a quiet NaN no arithmetic produces: "this entry of z has not been solved in this solve"
 __global__ __launch_bounds__(256) void sp_factor_kernel(SpSys s, int f0, int* fail) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int k = s.f_cols[f0 + blockIdx.x];
+  // (every column is factored once per solve, before the reverse sweep: its part of the solution starts as "not there yet" - see
+  // sp_backsolve_all_kernel - at no launch of its own)
+  if (threadIdx.x < 64) s.z[(size_t)k * 64 + threadIdx.x] = __longlong_as_double(kZNotYet);
   double* A = s.A + (size_t)s.tmap[(size_t)k * s.nT + k] * 4096;
   chol_diag_inv_body<false>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds);
 }
@@ -2374,6 +2378,7 @@ __global__ __launch_bounds__(kLevelThreads) void sp_level_kernel(SpSys s, int f0
   if ((int)blockIdx.x < nf) {
     if (threadIdx.x >= 256) return;   // (whole waves: the barriers of the factor count the four that stay)
     const int k = s.f_cols[f0 + blockIdx.x];
+    if (threadIdx.x < 64) s.z[(size_t)k * 64 + threadIdx.x] = __longlong_as_double(kZNotYet);   // (as sp_factor_kernel)
     double* A = s.A + (size_t)s.tmap[(size_t)k * s.nT + k] * 4096;
     if (pre) chol_diag_inv_body<false, true>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds, &s, k);
     else chol_diag_inv_body<false, false>(A, 64, 0, s.tile_kb[k], s.Linv + (size_t)k * 4096, fail, lds);
@@ -2455,20 +2460,38 @@ __global__ __launch_bounds__(256) void sp_backsolve_kernel(SpSys s, int f0) {
 // solve whose z it carries, written after the values with device-scope release, polled with device-scope acquire - and only then loads
 // those 64 doubles per entry. A level of the sweep then costs one flag hand-over and one trip to memory for z (~3.5 us) instead of a launch,
 // its drain and three trips (10 us). Same sums in the same order as sp_backsolve_col.
+// Round 6: the hand-over without cache maintenance. What made the round-5 form slow (a hand-over ~15 us) was not the distance between
+// the XCDs but the fences: a device-scope release writes the producer's whole L2 back (buffer_wbl2), an acquire invalidates the
+// consumer's (buffer_inv) - on every poll. Here every word that crosses workgroups - the flags AND the values - moves with RELAXED
+// agent-scope atomic accesses (sc1: they miss the per-CU cache and are coherent across the XCDs by themselves), the producer waits
+// for its stores to be acknowledged (s_waitcnt vmcnt(0): a workgroup-scope release fence) before it raises the flag, and nothing else is
+// fenced: tools/xcd_handoff.hip measures 0.8 - 1.2 us per hand-over of a 4 KB tile this way, on one XCD or across them (call r6_15).
 #ifdef __HIPCC__
-__device__ __forceinline__ unsigned flag_load_acquire(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flag_store_release(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ unsigned flag_load_relaxed(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store_relaxed(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double shared_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void shared_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_acknowledged() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 #else   // the HIP emulation runs the workgroups of a launch one after the other, in index order: a flag is always set when it is read
-__device__ __forceinline__ unsigned flag_load_acquire(const unsigned* p) { return *p; }
-__device__ __forceinline__ void flag_store_release(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ unsigned flag_load_relaxed(const unsigned* p) { return *p; }
+__device__ __forceinline__ void flag_store_relaxed(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ double shared_load(const double* p) { return *p; }
+__device__ __forceinline__ void shared_store(double* p, double v) { *p = v; }
+__device__ __forceinline__ void stores_acknowledged() {}
 __device__ __forceinline__ void spin_pause() {}
 #endif
 constexpr int kBsPrefetch = 4;   // entries whose tiles a workgroup holds in registers while it waits
+// Round 6: no flags. A column's part of z starts every solve as kZNotYet (written by the column's own factor workgroup) and turns into
+// the solution by 64 single 8-byte stores; a consumer polls THE VALUES (lane i of wave w polls element i of the w-th entry it needs,
+// into LDS) until none is kZNotYet: one store on the producer's side and one successful poll on the consumer's per level of the sweep,
+// where flag + values were two dependent trips each (store, acknowledge, flag | poll, load). A NaN in the solution (a failed
+// factorisation: the fail word is set anyway) can never equal kZNotYet; the polls are bounded all the same.
 __global__ __launch_bounds__(256) void sp_backsolve_all_kernel(SpSys s, unsigned epoch, int* fail) {
   __shared__ double w[64];
+  __shared__ double zsh[kBsPrefetch][64];
   __shared__ int give_up;
-  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3, lane = tid & 63;
+  const int tid = threadIdx.x, c = tid >> 2, part = tid & 3, lane = tid & 63, wave = tid >> 6;
   const int f = s.nT - 1 - (int)blockIdx.x;
   const int32_t* __restrict__ rec = s.bs_rec + (size_t)f * 16;
   const int k = rec[0], rhs_slot = rec[1], n = rec[2], e0 = rec[3];
@@ -2477,52 +2500,43 @@ __global__ __launch_bounds__(256) void sp_backsolve_all_kernel(SpSys s, unsigned
 #pragma unroll
   for (int q = 0; q < 16; ++q) lv[q] = li[q];
   const double yk = part == 0 ? s.L[(size_t)rhs_slot * 4096 + c * 64] : 0.0;
-  double tv[kBsPrefetch][16];
-#pragma unroll
-  for (int i = 0; i < kBsPrefetch; ++i)
-    if (i < n) {   // (uniform)
-      const double* __restrict__ tile = s.L + (size_t)rec[4 + 2 * i] * 4096 + c * 64 + part * 16;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) tv[i][q] = tile[q];
-    }
-  // wait for the rows this column needs: thread i of the first wave polls entry i (the lists beyond the record's six inline entries
-  // come from bs_row); bounded - a flag that never comes (it cannot, by construction) ends the solve with the failure word, not a hang
   if (tid == 0) give_up = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + tid;
-    if (tid < 64 && i < n) {
-      const int row = i < mvgx_sparse::kBsInline ? rec[5 + 2 * i] : s.bs_row[e0 + i];
-      int spins = 0;
-      while (flag_load_acquire(s.z_flag + row) != epoch) {
-        spin_pause();
-        if (++spins > (1 << 22)) { give_up = 1; break; }
-      }
-    }
-  }
-  __syncthreads();
-  if (give_up) { if (tid == 0) atomicExch(fail, 3); return; }   // (uniform)
-  __threadfence();   // acquire on behalf of every thread: the z values read below were written before the flags seen above
   double v = 0;
+  static_assert(kBsPrefetch == 4, "one polling wave per entry of a round");
+  for (int base = 0; base < n; base += kBsPrefetch) {   // (one round for almost every column: at most four tiles below it)
+    // the tile parts of this round's entries: they do not depend on the solution - in flight while the values are awaited
+    double tv[kBsPrefetch][16];
 #pragma unroll
-  for (int i = 0; i < kBsPrefetch; ++i)
-    if (i < n) {
-      const double* zi = s.z + (size_t)rec[5 + 2 * i] * 64 + part * 16;
-      double zv[16];
+    for (int i = 0; i < kBsPrefetch; ++i)
+      if (base + i < n) {   // (uniform)
+        const int e = base + i;
+        const int slot = e < mvgx_sparse::kBsInline ? rec[4 + 2 * e] : s.bs_slot[e0 + e];
+        const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) zv[q] = __builtin_nontemporal_load(zi + q);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += tv[i][q] * zv[q];
+        for (int q = 0; q < 16; ++q) tv[i][q] = tile[q];
+      }
+    __syncthreads();   // (zsh of the round before has been read; give_up is set)
+    if (base + wave < n) {   // wave w awaits entry base + w: 64 values, one per lane
+      const int e = base + wave;
+      const int row = e < mvgx_sparse::kBsInline ? rec[5 + 2 * e] : s.bs_row[e0 + e];
+      const double* src = s.z + (size_t)row * 64 + lane;
+      double val = shared_load(src);
+      int spins = 0;
+      while (__double_as_longlong(val) == kZNotYet) {
+        spin_pause();
+        if (++spins > (1 << 20)) { give_up = 1; break; }
+        val = shared_load(src);
+      }
+      zsh[wave][lane] = val;
     }
-  for (int i = kBsPrefetch; i < n; ++i) {   // (rare: more than four tiles below the column)
-    const int slot = i < mvgx_sparse::kBsInline ? rec[4 + 2 * i] : s.bs_slot[e0 + i], row = i < mvgx_sparse::kBsInline ? rec[5 + 2 * i] : s.bs_row[e0 + i];
-    const double* __restrict__ tile = s.L + (size_t)slot * 4096 + c * 64 + part * 16;
-    const double* zi = s.z + (size_t)row * 64 + part * 16;
-    double t2[16], z2[16];
+    __syncthreads();
+    if (give_up) { if (tid == 0) atomicExch(fail, 3); return; }   // (uniform)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { t2[q] = tile[q]; z2[q] = __builtin_nontemporal_load(zi + q); }
+    for (int i = 0; i < kBsPrefetch; ++i)
+      if (base + i < n) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v += t2[q] * z2[q];
+        for (int q = 0; q < 16; ++q) v += tv[i][q] * zsh[i][part * 16 + q];
+      }
   }
   v += __shfl_xor(v, 1);
   v += __shfl_xor(v, 2);
@@ -2533,10 +2547,8 @@ __global__ __launch_bounds__(256) void sp_backsolve_all_kernel(SpSys s, unsigned
   for (int q = 0; q < 16; ++q) u += lv[q] * w[part * 16 + q];
   u += __shfl_xor(u, 1);
   u += __shfl_xor(u, 2);
-  if (part == 0) { s.z[(size_t)k * 64 + c] = u; __threadfence(); }   // the value is visible device-wide before the column counts as solved
-  __syncthreads();
-  if (tid == 0) flag_store_release(s.z_flag + k, epoch);
-  (void)lane;
+  if (part == 0) shared_store(s.z + (size_t)k * 64 + c, u);
+  (void)epoch;
 }
 
 // The top of the elimination tree is a chain - one tile column per level, each depending on all the ones above it - and its part
@@ -3354,7 +3366,7 @@ struct mvgx_ba_ctx {
   // reverse sweep of the block-sparse solve in ONE launch, columns handed over through device-scope flags (MVGX_BA_BACKSOLVE_FLAGS=1). Built and
   // measured in round 5 (call r5_16): bit-identical, and SLOWER - C5 solve 0.474 against 0.409 ms, C3 0.246 against 0.245: a device-scope release on
   // this eight-XCD part writes the producer's whole L2 back, a hand-over costs ~15 us where a launch boundary costs 10. Off by default.
-  bool bs_one_launch = false;
+  bool bs_one_launch = true;    // the reverse sweep of the block-sparse solver as ONE launch (round 6: values polled, no flags - sp_backsolve_all_kernel); MVGX_BA_BACKSOLVE_FLAGS=0: a launch per level
   unsigned bs_epoch = 0;       // number of the solve whose solution the flags of that launch announce
   int chain_fuse_max_tasks = 4096;   // single-column levels with at most this many update tasks run panel + update as one launch (MVGX_BA_CHAIN_FUSE=0: never)
   bool fold_cand_now = false;   // this step: set by compute_step before the solve

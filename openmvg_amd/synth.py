@@ -101,11 +101,22 @@ def project(model, intr, pose, X):
     return np.stack([intr[:, 1] + intr[:, 0] * xd, intr[:, 2] + intr[:, 0] * yd], axis=1)
 
 
+def geometric_track_lengths(n_points, mean=6.0, lo=2, hi=40, seed=0x7AC4):
+    """track lengths of a scene with a realistic distribution: lo + geometric, mean `mean`, cut at `hi` (most tracks short, a long tail)"""
+    rng = np.random.default_rng(seed)
+    return np.minimum(lo + rng.geometric(1.0 / (mean - lo + 1.0), size=n_points) - 1, hi).astype(np.int64)
+
+
 def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1, seed=0xBA5E0000,
              noise_px=0.5, rot_deg=0.5, center_sigma=0.01, point_sigma=0.01, k_gt=(-0.05, 0.01, 0.0),
-             n_rings=4, outlier_frac=0.0):
-    """Returns a dict with ground truth and the perturbed initial problem (flat arrays, mvgx_ba_problem layout)."""
+             n_rings=4, outlier_frac=0.0, track_lens=None):
+    """Returns a dict with ground truth and the perturbed initial problem (flat arrays, mvgx_ba_problem layout).
+    track_lens: per-point track lengths (array of n_points) instead of the one `track_len` of every point."""
     rng = np.random.default_rng(seed)
+    if track_lens is not None:
+        track_lens = np.minimum(np.asarray(track_lens, np.int64), n_cams)
+        assert len(track_lens) == n_points and track_lens.min() >= 1
+        track_len = int(track_lens.max())
     track_len = min(track_len, n_cams)
     n_rings = max(1, min(n_rings, n_cams // max(1, track_len)))
     # cameras: ring-major order, radii 1.5..3, small height offsets, looking at the origin
@@ -142,8 +153,14 @@ def ba_scene(n_cams, n_points, track_len=10, model=CAM_PINHOLE, n_intr_groups=1,
     X_gt = rng.uniform(-0.3, 0.3, size=(n_points, 3))
     # visibility: `track_len` consecutive cameras (ring-major order, wrapping) from a random start
     start = rng.integers(0, n_cams, size=n_points)
-    obs_point = np.repeat(np.arange(n_points, dtype=np.uint32), track_len)
-    obs_pose = ((start[:, None] + np.arange(track_len)[None, :]) % n_cams).astype(np.uint32).reshape(-1)
+    if track_lens is None:
+        obs_point = np.repeat(np.arange(n_points, dtype=np.uint32), track_len)
+        obs_pose = ((start[:, None] + np.arange(track_len)[None, :]) % n_cams).astype(np.uint32).reshape(-1)
+    else:   # point p: track_lens[p] consecutive cameras from its start
+        obs_point = np.repeat(np.arange(n_points, dtype=np.uint32), track_lens)
+        first = np.concatenate([[0], np.cumsum(track_lens)[:-1]])
+        within = np.arange(int(track_lens.sum()), dtype=np.int64) - np.repeat(first, track_lens)
+        obs_pose = ((np.repeat(start, track_lens) + within) % n_cams).astype(np.uint32)
     obs_intr = cam_group[obs_pose].astype(np.uint32)
     xy = project(model, intr_gt[obs_intr], poses_gt[obs_pose], X_gt[obs_point])
     xy = xy + noise_px * rng.standard_normal(xy.shape)
