@@ -107,14 +107,26 @@ struct TripList {
 // Z blocks again (mode kGroupBacksub) instead of reading stored Z blocks: per LM iteration the points' observations are read twice
 // (24 bytes each), no per-observation record is written. Long tracks, constant points, poses seen twice by a point and points
 // with more intrinsics than kGroupIntr stay on the record-based path below (JA / JB / JC records, flat product lists).
-constexpr int kGroupCams = 10;                                    // local poses per group: 60 pose columns
+constexpr int kGroupCams = 16;                                    // local poses per group AT MOST (tables, pair numbering): the wide form
+constexpr int kNarrowCams = 10;                                   // ... of the usual form: 60 pose columns
 constexpr int kGroupIntr = 2;                                     // local intrinsics per group: 16 intrinsic columns
-constexpr int kGroupHCol = 6 * kGroupCams + 8 * kGroupIntr;       // the column of h_p (76)
+// The staged matrix has one of two forms, chosen per supergroup (round 6: points seen by 11 .. 16 poses used to leave the fused path):
+//   usual: up to kNarrowCams local poses - 60 pose columns | 16 intrinsic columns | h_p (column kGroupHCol = 76) in rows of kGroupCols = 80
+//          doubles (5 column tiles, 15 tiles of Z^T Z; the compact form of a pinhole-size single intrinsic: h_p in column 63, 10 tiles),
+//          up to kGroupPts points, the tiles accumulated in registers over the groups of the supergroup;
+//   wide:  a local pose beyond kNarrowCams in use - 96 pose columns | 16 | h_p (column kWideHCol = 112) in rows of kWideCols = 128 doubles
+//          (8 column tiles, 36 tiles), up to kWidePts points (the same LDS region), ONE group per supergroup, a wave's tiles formed one
+//          after the other and stored straight to the partial blocks.
+constexpr int kGroupHCol = 6 * kNarrowCams + 8 * kGroupIntr;      // the column of h_p (76)
 constexpr int kGroupCols = 80;                                    // 5 x 16: the columns 77..79 are padding (zero)
 constexpr int kGroupColTiles = kGroupCols / 16;
 constexpr int kGroupTiles = kGroupColTiles * (kGroupColTiles + 1) / 2;   // upper 16 x 16 tiles of Z^T Z (15)
-constexpr int kGroupPairsPP = kGroupCams * (kGroupCams + 1) / 2;  // destination blocks of a group: pose x pose (55)
-constexpr int kGroupPairsPI = kGroupCams * kGroupIntr;            // pose x intrinsic (20)
+constexpr int kWideHCol = 6 * kGroupCams + 8 * kGroupIntr;        // 112
+constexpr int kWideCols = 128;
+constexpr int kWideColTiles = kWideCols / 16;
+constexpr int kWideTiles = kWideColTiles * (kWideColTiles + 1) / 2;      // 36
+constexpr int kGroupPairsPP = kGroupCams * (kGroupCams + 1) / 2;  // destination blocks of a group: pose x pose (136)
+constexpr int kGroupPairsPI = kGroupCams * kGroupIntr;            // pose x intrinsic (32)
 constexpr int kGroupPairsII = kGroupIntr * (kGroupIntr + 1) / 2;  // intrinsic x intrinsic (3)
 constexpr int kNVpp = 6 * 6 + 6, kNVpi = 6 * 8 + 6, kNVii = 8 * 8 + 8;   // doubles per partial block (block | rhs) of the three product families
 #ifndef MVGX_GROUP_PTS
@@ -131,10 +143,12 @@ constexpr int kGroupTilesPerWave = (kGroupTiles + kGroupWaves - 1) / kGroupWaves
 // a row of its pose's columns are three 16-byte writes side by side with its neighbours' (the column-major form scattered 18 8-byte
 // writes of a thread over 18 columns, four distinct bank groups per half wave), and a half wave's MFMA operand - 16 consecutive
 // columns of two rows - is two contiguous 128-byte runs 640 bytes apart: every bank twice, the minimum for 64 x 8 bytes.
-constexpr int kGroupCS = kGroupCols;                              // doubles between rows
+constexpr int kGroupCS = kGroupCols;                              // doubles between rows (usual form; the wide form: kWideCols)
 constexpr int kGroupRows = 3 * kGroupPts;
+constexpr int kWidePts = kGroupRows * kGroupCols / kWideCols / 3; // 20: the wide form's rows fill the same region
 static_assert(kGroupPts % 4 == 0 && kGroupPts <= 255 && kGroupIntr == 2 && (kGroupCS * 8) % 256 == 128 && (6 * 8) % 16 == 0, "group tile layout (the slot ranges assume two local intrinsics)");
-static_assert(224 >= 128 + 6 * kGroupCams + 8 * kGroupIntr && kGroupThreads >= 224 + 8 * kGroupIntr, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128.., 224..");
+static_assert(kGroupThreads >= 128 + 6 * kGroupCams + 8 * kGroupIntr + 8 * kGroupIntr && kGroupCams <= 16, "the tables of a supergroup are staged by thread ranges 0.., 64.., 128.., 240..; four bits of local pose in an entry word");
+static_assert(kWidePts * 3 * kWideCols <= kGroupRows * kGroupCols && kWidePts * kGroupCams >= kGroupThreads, "the wide form in region M");
 constexpr int kGroupOut = kGroupPairsPP * kNVpp + kGroupPairsPI * kNVpi + kGroupPairsII * kNVii;   // partial blocks of a supergroup on their way out
 constexpr int kGroupM = kGroupRows * kGroupCS;                    // region M: the staged matrix; before that the per-observation terms (24 x threads)
 static_assert(kGroupM >= 24 * (kGroupThreads + 1) && kGroupM >= kGroupOut && kGroupM >= 3 * (kGroupThreads + 1) + 3 * kGroupPts * kGroupIntr * 8, "LDS region M");
@@ -144,7 +158,7 @@ constexpr int kGroupIntrRow = 8 + 8;                              // per local i
 constexpr int kGroupCandRow = 6 + kPoseTrig;                       // per local pose of the candidate x + delta: parameters | rotation terms
 constexpr int kGroupCand = kGroupCams * kGroupCandRow + kGroupIntr * 8 + 3 * kGroupPts;   // back-substitution with the candidate's cost: the candidate's cameras, the point threads' running sums
 constexpr int kGroupTabs = kGroupCams * kGroupCamRow + kGroupIntr * kGroupIntrRow + 6 * kGroupCams + 8 * kGroupIntr + kGroupCand;   // ... the solution's components, the candidate
-constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr + 2 + kGroupPairsPP + kGroupPairsPI + kGroupPairsII) * (int)sizeof(uint32_t);
+constexpr int kGroupLds = (kGroupM + kGroupSums + kGroupPtab + kGroupTabs) * (int)sizeof(double) + (kGroupThreads + 2 * (kGroupPts + 1) + kGroupIntr + 3 + kGroupPairsPP + kGroupPairsPI + kGroupPairsII) * (int)sizeof(uint32_t);
 // The norms and back-substitution modes never stage the matrix: their region M holds only the per-observation terms of the point
 // sums (18 x (threads + 1) doubles), which lets a third workgroup onto the CU (49 KB instead of 74 KB each).
 constexpr int kGroupMSmall = (18 * (kGroupThreads + 1) + 1) & ~1;
@@ -1007,7 +1021,7 @@ __device__ __forceinline__ void group_tile(int t, int& ti, int& tj, int n = kGro
 // of kGroupHCol - 64 columns, four column tiles, ten tiles of Z^T Z instead of fifteen. Same sums, same bits; the zero elements the
 // five dropped tiles used to deliver are written as zeros when the partial blocks go out.
 constexpr int kCompactIntr = 3;
-constexpr int kCompactHCol = 6 * kGroupCams + kCompactIntr;
+constexpr int kCompactHCol = 6 * kNarrowCams + kCompactIntr;
 constexpr int kCompactColTiles = (kCompactHCol + 16) / 16;
 constexpr int kCompactTiles = kCompactColTiles * (kCompactColTiles + 1) / 2;
 static_assert(kCompactHCol == 63 && kCompactColTiles == 4, "the compact form is sized for four column tiles");
@@ -1019,24 +1033,52 @@ static_assert(kCompactHCol == 63 && kCompactColTiles == 4, "the compact form is 
 __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk, int hcol = kGroupHCol) {
   double* __restrict__ out_pi = out + kGroupPairsPP * kNVpp;
   double* __restrict__ out_ii = out_pi + kGroupPairsPI * kNVpi;
+  constexpr int kPoseCols = 6 * kNarrowCams;   // (the usual form)
   const int J = 16 * tj + li;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int I = 16 * ti + lk + 4 * reg;
     if (I >= hcol || J > hcol || I > J) continue;
-    const bool i_pose = I < 6 * kGroupCams;
-    const int x = i_pose ? I / 6 : (I - 6 * kGroupCams) / 8;
-    const int r = i_pose ? I - 6 * x : (I - 6 * kGroupCams) - 8 * x;
+    const bool i_pose = I < kPoseCols;
+    const int x = i_pose ? I / 6 : (I - kPoseCols) / 8;
+    const int r = i_pose ? I - 6 * x : (I - kPoseCols) - 8 * x;
     if (J == hcol) {   // column of h_p: the rhs
       if (i_pose) out[group_pair_pp(x, x) * kNVpp + 36 + r] = acc[reg];
       else out_ii[group_pair_ii(x, x) * kNVii + 64 + r] = acc[reg];
-    } else if (J < 6 * kGroupCams) {   // I <= J: I is a pose column too
+    } else if (J < kPoseCols) {   // I <= J: I is a pose column too
       const int y = J / 6, c = J - 6 * y;
       out[group_pair_pp(x, y) * kNVpp + r * 6 + c] = acc[reg];
     } else {
-      const int l = (J - 6 * kGroupCams) / 8, c = (J - 6 * kGroupCams) - 8 * l;
+      const int l = (J - kPoseCols) / 8, c = (J - kPoseCols) - 8 * l;
       if (i_pose) out_pi[(x * kGroupIntr + l) * kNVpi + r * 8 + c] = acc[reg];
       else out_ii[group_pair_ii(x, l) * kNVii + r * 8 + c] = acc[reg];
+    }
+  }
+}
+
+// The wide form: a finished tile goes straight to the partial blocks in memory (chunk: the destination rows of the supergroup's blocks,
+// pp | pi | ii as in LDS; kNoChunk: the block has no destination).
+__device__ __forceinline__ void wide_store_tile(const d4_t& acc, int ti, int tj, const uint32_t* __restrict__ chunk, double* __restrict__ part_pp,
+                                                double* __restrict__ part_pi, double* __restrict__ part_ii, int li, int lk, int kPoseCols, int hcol) {
+  const int J = 16 * tj + li;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int I = 16 * ti + lk + 4 * reg;
+    if (I >= hcol || J > hcol || I > J) continue;
+    const bool i_pose = I < kPoseCols;
+    const int x = i_pose ? I / 6 : (I - kPoseCols) / 8;
+    const int r = i_pose ? I - 6 * x : (I - kPoseCols) - 8 * x;
+    if (J == hcol) {
+      if (i_pose) { const uint32_t ch = chunk[group_pair_pp(x, x)]; if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + 36 + r] = acc[reg]; }
+      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, x)]; if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + 64 + r] = acc[reg]; }
+    } else if (J < kPoseCols) {
+      const int y = J / 6, c = J - 6 * y;
+      const uint32_t ch = chunk[group_pair_pp(x, y)];
+      if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + r * 6 + c] = acc[reg];
+    } else {
+      const int l = (J - kPoseCols) / 8, c = (J - kPoseCols) - 8 * l;
+      if (i_pose) { const uint32_t ch = chunk[kGroupPairsPP + x * kGroupIntr + l]; if (ch != kNoChunk) part_pi[(size_t)ch * kNVpi + r * 8 + c] = acc[reg]; }
+      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, l)]; if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + r * 8 + c] = acc[reg]; }
     }
   }
 }
@@ -1109,12 +1151,17 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   int* const imodel = reinterpret_cast<int*>(pks + kGroupPts + 1);   // [local intrinsic]: camera model
   int* const ncam_used = imodel + kGroupIntr;                         // forward: local poses of the supergroup that carry observations
   uint32_t* const chunk_ids = reinterpret_cast<uint32_t*>(ncam_used + 2);   // forward: destination rows of the supergroup's partial blocks (pp | pi | ii), fetched at the start
-  int* const sg_flags = ncam_used + 1;                                // forward: bit 0 - only local intrinsic 0 is in use, bit 1 - the compact form (see kCompactIntr)
+  int* const sg_flags = ncam_used + 1;
+  int* const npose_cols = reinterpret_cast<int*>(chunk_ids + kGroupPairsPP + kGroupPairsPI + kGroupPairsII);   // forward: 6 x (the highest local pose in use + 1)                                // forward: bit 0 - only local intrinsic 0 is in use, bit 1 - the compact form (see kCompactIntr)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t sg = G.sg_order[blockIdx.x];
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
   const uint32_t* __restrict__ cams = G.cams + (size_t)sg * kGroupCams;
   const uint32_t* __restrict__ intrs = G.intrs + (size_t)sg * kGroupIntr;
+  // the wide form: a local pose beyond the usual form's columns is in use (uniform: six scalar loads)
+  bool wide = false;
+#pragma unroll
+  for (int x = kNarrowCams; x < kGroupCams; ++x) wide = wide || G.chunk_pp[(size_t)sg * kGroupPairsPP + group_pair_pp(x, x)] != kNoChunk;
   constexpr int NT = kGroupThreads;
   constexpr int NSUM = MODE == kGroupBacksub ? 18 : 15;   // per-observation terms summed per point (back-substitution: + Es^T (Fs z))
   constexpr int NS = kGroupThreads + 1;   // stride of the per-observation terms [value][thread]: odd, so that the readers of one observation's values hit distinct banks
@@ -1159,24 +1206,28 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     const int j = tid - 128;
     ztab[j] = j < 6 * kGroupCams ? d.zsol[6 * (size_t)cams[j / 6] + j % 6]
                                  : d.zsol[6 * (size_t)d.n_poses + 8 * (size_t)intrs[(j - 6 * kGroupCams) >> 3] + ((j - 6 * kGroupCams) & 7)];
-  } else if (with_cand && tid >= 224 && tid < 224 + 8 * kGroupIntr) {
-    const int j = tid - 224;
+  } else if (with_cand && tid >= 240 && tid < 240 + 8 * kGroupIntr) {
+    const int j = tid - 240;
     ccand[kGroupCams * kGroupCandRow + j] = d.cintr[(size_t)intrs[j >> 3] * 8 + (j & 7)];
   }
   if (MODE == kGroupForward && tid >= 192) {   // (wave 3: the waves 0..2 stage the tables above)
     const int x = tid - 192;
     const bool used = x < kGroupCams && G.chunk_pp[(size_t)sg * kGroupPairsPP + group_pair_pp(x, x)] != kNoChunk;
-    const int n_used = (int)__popcll(__ballot(used));
+    const unsigned long long used_mask = __ballot(used);
+    const int n_used = (int)__popcll(used_mask);
     if (x == 0) {
       *ncam_used = n_used;
+      *npose_cols = 0;
+      for (int b = 0; b < kGroupCams; ++b) if ((used_mask >> b) & 1ull) *npose_cols = 6 * (b + 1);   // pose columns up to the last local pose in use
       const bool single = G.chunk_ii[(size_t)sg * kGroupPairsII + group_pair_ii(1, 1)] == kNoChunk;   // no point of the supergroup sees local intrinsic 1
       const int pc = intr_param_count(d.model[intrs[0]]);
-      *sg_flags = (single ? 1 : 0) | (single && pc >= 0 && pc <= kCompactIntr && g_group_compact ? 2 : 0);
+      *sg_flags = (single ? 1 : 0) | (!wide && single && pc >= 0 && pc <= kCompactIntr && g_group_compact ? 2 : 0);
     }
   }
-  if (MODE == kGroupForward && tid >= 96 && tid < 96 + kGroupPairsPP + kGroupPairsPI + kGroupPairsII) {
+  if (MODE == kGroupForward && tid < kGroupPairsPP + kGroupPairsPI + kGroupPairsII) {
     // (the last phase used to fetch a block's destination element by element: fourteen dependent trips to memory per workgroup, 8 us)
-    const int j = tid - 96;
+    static_assert(kGroupPairsPP + kGroupPairsPI + kGroupPairsII <= kGroupThreads, "one destination row per thread");
+    const int j = tid;
     chunk_ids[j] = j < kGroupPairsPP ? G.chunk_pp[(size_t)sg * kGroupPairsPP + j]
                  : j < kGroupPairsPP + kGroupPairsPI ? G.chunk_pi[(size_t)sg * kGroupPairsPI + (j - kGroupPairsPP)]
                  : G.chunk_ii[(size_t)sg * kGroupPairsII + (j - kGroupPairsPP - kGroupPairsPI)];
@@ -1208,8 +1259,15 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
       for (int j = 0; j < kGroupTilesPerWave; ++j) group_tile(min(wave + j * kGroupWaves, kCompactTiles - 1), tti[j], ttj[j], kCompactColTiles);
     }
+    // (the wide form keeps its intrinsic columns and h_p right behind the pose columns IN USE: 11 poses are 83 columns - 6 column
+    // tiles, 21 tiles of Z^T Z - where the full width has 36)
+    if (wide) hcol = *npose_cols + 8 * kGroupIntr;
   }
-  const bool compact = hcol != kGroupHCol;
+  const bool compact = !wide && hcol == kCompactHCol;
+  const int cs = wide ? kWideCols : kGroupCS;                          // doubles between the rows of the staged matrix
+  const int icol0 = wide ? hcol - 8 * kGroupIntr : 6 * kNarrowCams;    // its first intrinsic column
+  const int wide_col_tiles = (hcol + 16) / 16;
+  const int ncap = wide ? kGroupCams : kNarrowCams;                    // entries a point can have
   uint32_t nx_e0 = G.obs_start[g0], nx_ne = G.obs_start[g0 + 1] - nx_e0, nx_p0 = G.pt_start[g0], nx_np = G.pt_start[g0 + 1] - nx_p0;
   uint32_t nx_qxk = (uint32_t)tid < nx_ne ? G.eq[nx_e0 + tid] : 0u;
   double2 nx_xy = (uint32_t)tid < nx_ne ? G.exy[nx_e0 + tid] : make_double2(0.0, 0.0);
@@ -1321,10 +1379,18 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       const double* __restrict__ src = M + v * NS;
       double term[kGroupCams];
 #pragma unroll
-      for (int j = 0; j < kGroupCams; ++j) term[j] = src[min(elo + (uint32_t)j, ehi - 1)];   // independent loads, all in flight
+      for (int j = 0; j < kNarrowCams; ++j) term[j] = src[min(elo + (uint32_t)j, ehi - 1)];   // independent loads, all in flight
+      if (wide) {   // (uniform)
+#pragma unroll
+        for (int j = kNarrowCams; j < kGroupCams; ++j) term[j] = src[min(elo + (uint32_t)j, ehi - 1)];
+      }
       double sum = 0.0;
 #pragma unroll
-      for (int j = 0; j < kGroupCams; ++j) sum += elo + (uint32_t)j < ehi ? term[j] : 0.0;
+      for (int j = 0; j < kNarrowCams; ++j) sum += elo + (uint32_t)j < ehi ? term[j] : 0.0;
+      if (wide) {
+#pragma unroll
+        for (int j = kNarrowCams; j < kGroupCams; ++j) sum += elo + (uint32_t)j < ehi ? term[j] : 0.0;
+      }
       sums[pq * 20 + v] = sum;
     }
     __syncthreads();
@@ -1447,22 +1513,25 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     const bool slot_item = slot_pq < (int)np && (!compact || slot_c < kCompactIntr);
     {
       const int pq = slot_pq, c = slot_c;
+      // the entries of a point in rounds of kSlotRound (all terms of a round fetched before its first sum): two rounds cover the usual
+      // form's ten entries, four the wide form's sixteen
+      constexpr int kSlotRound = 5;
+      const int n_rounds = wide ? (kGroupCams + kSlotRound - 1) / kSlotRound : (kNarrowCams + kSlotRound - 1) / kSlotRound;
       if (slot_item && single_intr) {
         // (uniform choice) every entry of the point belongs to local intrinsic 0: one range, its terms added in entry order behind a
         // 0 / 1 factor (y + t * 1 = y + t, y + t * 0 = y: the bits of the masked sums below)
         const uint32_t elo = pe[pq], ehi = pe[pq + 1];
         double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        for (int half = 0; half < n_rounds; ++half) {
+          double t0[kSlotRound], t1[kSlotRound], t2[kSlotRound];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          double t0[kGroupCams / 2], t1[kGroupCams / 2], t2[kGroupCams / 2];
-#pragma unroll
-          for (int j = 0; j < kGroupCams / 2; ++j) {
-            const uint32_t e = min(elo + (uint32_t)(half * (kGroupCams / 2) + j), ehi - 1);
+          for (int j = 0; j < kSlotRound; ++j) {
+            const uint32_t e = min(elo + (uint32_t)(half * kSlotRound + j), ehi - 1);
             t0[j] = M[c * NS + e]; t1[j] = M[(8 + c) * NS + e]; t2[j] = M[(16 + c) * NS + e];
           }
 #pragma unroll
-          for (int j = 0; j < kGroupCams / 2; ++j) {
-            const double m = elo + (uint32_t)(half * (kGroupCams / 2) + j) < ehi ? 1.0 : 0.0;
+          for (int j = 0; j < kSlotRound; ++j) {
+            const double m = elo + (uint32_t)(half * kSlotRound + j) < ehi ? 1.0 : 0.0;
             y0 = fma(t0[j], m, y0); y1 = fma(t1[j], m, y1); y2 = fma(t2[j], m, y2);
           }
         }
@@ -1473,17 +1542,16 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       } else if (slot_item) {
         const uint32_t elo = pe[pq], ehi = pe[pq + 1], esp = pks[pq];
         double y[kGroupIntr][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        for (int half = 0; half < n_rounds; ++half) {
+          double t0[kSlotRound], t1[kSlotRound], t2[kSlotRound];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          double t0[kGroupCams / 2], t1[kGroupCams / 2], t2[kGroupCams / 2];
-#pragma unroll
-          for (int j = 0; j < kGroupCams / 2; ++j) {
-            const uint32_t e = min(elo + (uint32_t)(half * (kGroupCams / 2) + j), ehi - 1);
+          for (int j = 0; j < kSlotRound; ++j) {
+            const uint32_t e = min(elo + (uint32_t)(half * kSlotRound + j), ehi - 1);
             t0[j] = M[c * NS + e]; t1[j] = M[(8 + c) * NS + e]; t2[j] = M[(16 + c) * NS + e];
           }
 #pragma unroll
-          for (int j = 0; j < kGroupCams / 2; ++j) {
-            const uint32_t e = elo + (uint32_t)(half * (kGroupCams / 2) + j);
+          for (int j = 0; j < kSlotRound; ++j) {
+            const uint32_t e = elo + (uint32_t)(half * kSlotRound + j);
             const bool in0 = e < esp, in1 = e >= esp && e < ehi;
             y[0][0] += in0 ? t0[j] : 0.0; y[0][1] += in0 ? t1[j] : 0.0; y[0][2] += in0 ? t2[j] : 0.0;
             y[1][0] += in1 ? t0[j] : 0.0; y[1][1] += in1 ? t1[j] : 0.0; y[1][2] += in1 ? t2[j] : 0.0;
@@ -1514,7 +1582,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       __syncthreads();
     } else {
       const int npad = rows - 3 * (int)np;   // 0..3 rows of zeros behind the last point
-      for (int i = tid; i < kGroupCS * npad; i += NT) M[3 * (int)np * kGroupCS + i] = 0.0;
+      for (int i = tid; i < cs * npad; i += NT) M[3 * (int)np * cs + i] = 0.0;
     }
     if (has) {
       // Z = L^-1 Es^T Fc_s as (L^-1 Es^T) Fc_s: the two columns a0, a1 of L^-1 Es^T (3 x 2) first - 12 operations - then two per element
@@ -1523,9 +1591,13 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       const double a1[3] = {ptq[0] * es1[0], ptq[1] * es1[0] + ptq[2] * es1[1], ptq[3] * es1[0] + ptq[4] * es1[1] + ptq[5] * es1[2]};
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        double2* __restrict__ dst = reinterpret_cast<double2*>(M + (3 * q + r) * kGroupCS + 6 * x);   // (16-byte aligned: 640 (3 q + r) + 48 x)
+        // (16-byte aligned: 640 or 1 024 (3 q + r) + 48 x; the wide form's rows are 1 024 bytes apart - every row on the same banks - so
+        // its odd rows keep their columns exchanged in blocks of 16, `swz`: an MFMA operand's two rows then meet different banks)
+        const int swz = wide ? (((3 * q + r) & 1) << 4) : 0;
+        double* __restrict__ dst = M + (3 * q + r) * cs;
 #pragma unroll
-        for (int c = 0; c < 6; c += 2) dst[c / 2] = make_double2(a0[r] * fc0[c] + a1[r] * fc1[c], a0[r] * fc0[c + 1] + a1[r] * fc1[c + 1]);
+        for (int c = 0; c < 6; c += 2)
+          *reinterpret_cast<double2*>(dst + ((6 * x + c) ^ swz)) = make_double2(a0[r] * fc0[c] + a1[r] * fc1[c], a0[r] * fc0[c + 1] + a1[r] * fc1[c + 1]);
       }
     }
     if (slot_item) {
@@ -1533,18 +1605,30 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
 #pragma unroll
       for (int k = 0; k < kGroupIntr; ++k) {   // column 8 k + c behind the pose columns (compact: local intrinsic 0 only)
         if (k == 0 || !compact) {
-          double* __restrict__ dst = M + 3 * pq * kGroupCS + (6 * kGroupCams + 8 * k + c);
-          dst[0] = zs[k][0]; dst[kGroupCS] = zs[k][1]; dst[2 * kGroupCS] = zs[k][2];
+          const int col = icol0 + 8 * k + c, r0 = 3 * pq;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) M[(r0 + r) * cs + (wide ? col ^ (((r0 + r) & 1) << 4) : col)] = zs[k][r];
         }
       }
     }
     if ((uint32_t)tid < np) {
-      double* __restrict__ dst = M + 3 * tid * kGroupCS + hcol;
-      dst[0] = ptab[tid * 12 + 6]; dst[kGroupCS] = ptab[tid * 12 + 7]; dst[2 * kGroupCS] = ptab[tid * 12 + 8];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) M[(3 * tid + r) * cs + (wide ? hcol ^ (((3 * tid + r) & 1) << 4) : hcol)] = ptab[tid * 12 + 6 + r];
     }
     __syncthreads();
     MVGX_GSTAMP(5);
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
+    if (wide) {   // (uniform) the wide form: 36 tiles, a wave's nine one after the other, each straight to the partial blocks - one group per supergroup
+      for (int t = wave; t < wide_col_tiles * (wide_col_tiles + 1) / 2; t += kGroupWaves) {
+        int ti, tj;
+        group_tile(t, ti, tj, wide_col_tiles);
+        const double* __restrict__ ca = M + lk * kWideCols + ((16 * ti + li) ^ ((lk & 1) << 4));   // (row k0 + lk: k0 is a multiple of four)
+        const double* __restrict__ cb = M + lk * kWideCols + ((16 * tj + li) ^ ((lk & 1) << 4));
+        d4_t a = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0 * kWideCols], cb[k0 * kWideCols], a, 0, 0, 0);
+        wide_store_tile(a, ti, tj, chunk_ids, part_pp, part_pi, part_ii, li, lk, icol0, hcol);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < kGroupTilesPerWave; ++j) {
       if (wave + j * kGroupWaves < n_tiles) {   // wave-uniform
@@ -1554,6 +1638,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0 * kGroupCS], cb[k0 * kGroupCS], a, 0, 0, 0);
         acc[j] = a;
       }
+    }
     }
     MVGX_GSTAMP(6);
   }
@@ -1567,6 +1652,13 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   if (MODE != kGroupForward) { MVGX_GSTAMP_FLUSH(); return; }
   // ---- 7. partial blocks out: tiles -> LDS -> contiguous runs in the three partial-sum buffers; max |g_pt| of the supergroup ----
   __syncthreads();
+  if (wide) {   // (uniform) its tiles are out already
+    const double gm = block_max(gmax, sums);
+    if (tid == 0) G.gmax_part[sg] = gm;
+    MVGX_GSTAMP(7);
+    MVGX_GSTAMP_FLUSH();
+    return;
+  }
   double* const out = M;
   if (compact) {   // (uniform) what the dropped tiles held: zero rows / columns of the intrinsic's blocks beyond kCompactIntr
     for (int i = tid; i < kGroupPairsPI * kNVpi + kGroupPairsII * kNVii; i += NT) out[kGroupPairsPP * kNVpp + i] = 0.0;
@@ -3791,7 +3883,10 @@ int plan_solver(mvgx_ba_ctx* c, const std::vector<std::pair<uint32_t, uint32_t>>
         [&](int cb) { return cb < (int)np ? 6 * cb : 6 * (int)np + 8 * (cb - (int)np); }, prm, (uint64_t)1 << 25, c->plan);
     const uint64_t nd = (uint64_t)((d.N + 63) / 64);
     c->plan_tried = true; c->plan_ok = ok;
-    sparse = ok && (c->solver_mode >= 2 || ((uint64_t)c->plan.n_levels < nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
+    // (round 6: "<=" - a camera graph without structure gives a plan of nd single-column levels, a dense factorisation run by the tile
+    // kernels: a level is then two launches where the dense solver's block step is three, and the reverse sweep one launch where it
+    // is nd - 0.59 against 0.93 ms at N = 1 203 on a scene with long tracks, call r6_14)
+    sparse = ok && (c->solver_mode >= 2 || ((uint64_t)c->plan.n_levels <= nd && c->plan.n_fill_tiles <= nd * (nd + 1) / 2));
     MVGX_REQUIRE(ok || c->solver_mode != 2, MVGX_ERR_UNSUPPORTED, "MVGX_BA_SOLVER=sparse: the reduced system fills too much for the task lists");
   }
   if (sparse && getenv("MVGX_BA_PLAN_DEBUG")) {
@@ -4694,9 +4789,24 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           B.pt_n.push_back((uint32_t)cur.size());
         };
         auto close_group = [&]() {
-          const bool continues = sg_open && cams == tail_cams && intrs == tail_intrs && B.sg_n.back() < (uint32_t)kMaxSgGroups;
-          if (cur.size() >= (size_t)kGroupMinPts || (continues && !cur.empty())) { emit_group(continues); sg_open = true; }
+          if (cams.size() > (size_t)kNarrowCams && !cur.empty()) {
+            // a wide group takes the EXACT union of its points' sets (a group inherits the sets of the one before it - that is what lets
+            // groups of one camera set form a supergroup - but a wide group never continues one, and its columns follow its poses in use)
+            std::vector<uint32_t> ec, ei;
+            for (uint32_t j : cur) {
+              for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) { ec.push_back(opose[o]); ei.push_back(ointr[o]); }
+            }
+            std::sort(ec.begin(), ec.end()); ec.erase(std::unique(ec.begin(), ec.end()), ec.end());
+            std::sort(ei.begin(), ei.end()); ei.erase(std::unique(ei.begin(), ei.end()), ei.end());
+            cams = ec; intrs = ei;
+            sg_open = false;
+          }
+          // (a wide group - more than kNarrowCams poses - is a supergroup of its own: its tiles leave the workgroup group by group)
+          const bool continues = sg_open && cams.size() <= (size_t)kNarrowCams && cams == tail_cams && intrs == tail_intrs && B.sg_n.back() < (uint32_t)kMaxSgGroups;
+          // (a wide group stays whatever its size: a handful of points left to the record-based path costs its dozen launches per iteration)
+          if (cur.size() >= (size_t)kGroupMinPts || (continues && !cur.empty()) || (cams.size() > (size_t)kNarrowCams && !cur.empty())) { emit_group(continues); sg_open = true; }
           else sg_open = false;
+          if (cams.size() > (size_t)kNarrowCams) { cams.clear(); intrs.clear(); sg_open = false; }   // (nothing continues a wide group: the next one starts from its own points)
           cur.clear(); cur_obs = 0;
         };
         for (uint32_t q = lo_start[bucket]; q < lo_start[bucket + 1]; ++q) {
@@ -4706,11 +4816,17 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
           for (uint32_t o = pt_start[j]; o < pt_start[j + 1]; ++o) pc[npc++] = opose[o];
           for (uint32_t sl = ptk_start[j]; sl < ptk_start[j + 1]; ++sl) pk[npk++] = slot_intr[sl];
           std::sort(pc, pc + npc); std::sort(pk, pk + npk);
-          if (cur.size() == (size_t)kGroupPts || cur_obs + (uint32_t)npc > (uint32_t)kGroupThreads) close_group();   // full: the next group starts from the same sets (and may continue the supergroup)
+          // the two forms (see kNarrowCams): a group is wide once it holds a point of more than kNarrowCams poses - then up to kGroupCams
+          // poses and kWidePts points; a group of short tracks never grows wide by union alone (it closes at kNarrowCams as before)
+          const bool cur_wide = cams.size() > (size_t)kNarrowCams;
+          const size_t max_pts = cur_wide ? (size_t)kWidePts : (size_t)kGroupPts;
+          if (cur.size() >= max_pts || cur_obs + (uint32_t)npc > (uint32_t)kGroupThreads) close_group();   // full: the next group starts from the same sets (and may continue the supergroup)
           mc.clear(); mi.clear();
           std::set_union(cams.begin(), cams.end(), pc, pc + npc, std::back_inserter(mc));
           std::set_union(intrs.begin(), intrs.end(), pk, pk + npk, std::back_inserter(mi));
-          if (mc.size() > (size_t)kGroupCams || mi.size() > (size_t)kGroupIntr) {
+          const bool to_wide = npc > kNarrowCams || cur_wide;
+          const size_t cam_limit = to_wide ? (size_t)kGroupCams : (size_t)kNarrowCams;
+          if (mc.size() > cam_limit || mi.size() > (size_t)kGroupIntr || (to_wide && !cur_wide && cur.size() >= (size_t)kWidePts)) {
             close_group();
             sg_open = false;
             mc.assign(pc, pc + npc); mi.assign(pk, pk + npk);

@@ -557,7 +557,9 @@ def test_multi_device_from_the_environment_only_for_large_problems(monkeypatch):
 @pytest.mark.parametrize("kw", [
     dict(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=2, seed=101),
     dict(n_cams=30, n_points=700, track_len=10, model=1, n_intr_groups=1, seed=102),      # ten poses per point: full groups
-    dict(n_cams=16, n_points=200, track_len=12, model=1, n_intr_groups=1, seed=103),      # tracks longer than a group: flat list only
+    dict(n_cams=16, n_points=200, track_len=12, model=1, n_intr_groups=1, seed=103),      # 11 .. 16 poses per point: the wide form of the groups (round 6)
+    dict(n_cams=20, n_points=150, track_len=14, model=3, n_intr_groups=2, seed=106),      # ... with two local intrinsics
+    dict(n_cams=20, n_points=120, track_len=18, model=1, n_intr_groups=1, seed=107),      # tracks longer than any group: flat list only
     dict(n_cams=10, n_points=260, track_len=10, model=3, n_intr_groups=2, seed=104),      # one camera set, two intrinsics: supergroups of several groups
     dict(n_cams=16, n_points=400, track_len=4, model=2, n_intr_groups=8, seed=105),       # many points with more than two intrinsics: both paths mixed
 ])
@@ -580,7 +582,7 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert info_f.n_point_groups == 0
     if kw["n_intr_groups"] > 2:
         assert 0 < info.n_grouped_points < 0.9 * kw["n_points"]
-    elif kw["track_len"] <= 10:
+    elif kw["track_len"] <= 16:
         assert info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]
     else:
         assert info.n_point_groups == 0

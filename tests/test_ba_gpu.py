@@ -355,20 +355,28 @@ def test_block_sparse_solver_is_chosen_for_a_sequential_capture_scene(monkeypatc
     assert s.termination == 0 and s.final_rmse < 0.6
 
 
-def test_dense_visibility_scene_keeps_the_dense_solver(monkeypatch):
-    """every camera sees every point: S is full, nothing to dissect -> the dense blocked Cholesky (the fallback and cross-check)"""
+def test_dense_visibility_scene_on_both_solvers(monkeypatch):
+    """every camera sees every point: S is full, nothing to dissect. Round 6: the plan of such a system is one tile column per level - a dense
+    factorisation run by the tile kernels, which is faster than the dense solver's three launches per block step and nd-launch reverse
+    sweep (0.59 against 0.93 ms at N = 1 203) - so the block-sparse solver is chosen; the dense blocked Cholesky stays the cross-check"""
     monkeypatch.delenv("MVGX_BA_SOLVER", raising=False)
     sc = synth.ba_scene(n_cams=40, n_points=1500, track_len=40, model=3, n_intr_groups=2, seed=77)
     rc, osum, *_ = _oracle.port_ba_solve(sc)
     ctx = ba.BaContext(sc); s = ctx.solve(); info = ctx.solver_info(); ctx.close()
-    assert info.sparse == 0
+    assert info.sparse == 1 and info.n_levels <= (info.n_columns + 63) // 64
     assert s.num_iterations == osum.num_iterations and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+    monkeypatch.setenv("MVGX_BA_SOLVER", "dense")
+    ctx = ba.BaContext(sc); sd = ctx.solve(); info_d = ctx.solver_info(); ctx.close()
+    assert info_d.sparse == 0
+    assert sd.num_iterations == osum.num_iterations and abs(sd.final_rmse - osum.final_rmse) < RMSE_TOL and abs(sd.final_rmse - s.final_rmse) < 1e-9
 
 
 @pytest.mark.parametrize("kw", [
     dict(n_cams=60, n_points=6000, track_len=10, model=3, n_intr_groups=4, seed=111),
     dict(n_cams=40, n_points=3000, track_len=6, model=1, n_intr_groups=1, seed=112, outlier_frac=0.02),
-    dict(n_cams=24, n_points=1500, track_len=14, model=1, n_intr_groups=1, seed=113),     # tracks too long for a group
+    dict(n_cams=24, n_points=1500, track_len=14, model=1, n_intr_groups=1, seed=113),     # 11 .. 16 poses per point: the wide form of the groups (round 6)
+    dict(n_cams=24, n_points=1500, track_len=12, model=3, n_intr_groups=2, seed=115),     # ... with two local intrinsics
+    dict(n_cams=30, n_points=1200, track_len=19, model=1, n_intr_groups=1, seed=114),     # tracks too long for a group
 ])
 def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkeypatch):
     """pose x pose Schur products formed group-wise on the f64 matrix cores (ba_schur_group_kernel) against the flat product
@@ -378,7 +386,7 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     monkeypatch.setenv("MVGX_BA_GROUPS", "0")
     c = ba.BaContext(sc); s_f = c.solve(); pf, if_, xf = c.read_params(); info_f = c.solver_info(); c.close()
     assert info_f.n_point_groups == 0
-    assert (info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]) if kw["track_len"] <= 10 else info.n_point_groups == 0
+    assert (info.n_point_groups > 0 and info.n_grouped_points > 0.8 * kw["n_points"]) if kw["track_len"] <= 16 else info.n_point_groups == 0
     assert s_g.num_iterations == s_f.num_iterations and abs(s_g.final_cost - s_f.final_cost) <= 1e-9 * s_f.final_cost
     assert np.allclose(pg, pf, atol=1e-8) and np.allclose(ig, if_, rtol=1e-8, atol=1e-8) and np.allclose(xg, xf, atol=1e-7)
     rc, osum, *_ = _oracle.port_ba_solve(sc)
