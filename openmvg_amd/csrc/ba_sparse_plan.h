@@ -468,7 +468,12 @@ inline bool build_plan(int n_cb, int N, const std::vector<std::pair<uint32_t, ui
   // ---- reverse sweep ----
   out.bs_start.assign(nT + 1, 0);
   for (int k = 0; k < nT; ++k) {
-    for (int i : below[k]) { out.bs_slot.push_back(out.tmap[(size_t)i * nT + k]); out.bs_row.push_back(i); }
+    // (round 6: highest level first. The one-launch reverse sweep - sp_backsolve_all_kernel - walks a column's list in rounds of four and
+    // waits for each round's parts of z: the part solved LAST - the lowest level - now comes last, so only the final round waits, with
+    // every other product done. The same order in every form of the sweep: the same sums.)
+    std::vector<int> ord(below[k].begin(), below[k].end());
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return out.level_of[a] > out.level_of[b]; });
+    for (int i : ord) { out.bs_slot.push_back(out.tmap[(size_t)i * nT + k]); out.bs_row.push_back(i); }
     out.bs_start[k + 1] = (int32_t)out.bs_slot.size();
   }
   out.bs_rec.assign((size_t)nT * 16, 0);

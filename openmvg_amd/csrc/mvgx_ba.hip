@@ -115,8 +115,8 @@ constexpr int kGroupIntr = 2;                                     // local intri
 //          doubles (5 column tiles, 15 tiles of Z^T Z; the compact form of a pinhole-size single intrinsic: h_p in column 63, 10 tiles),
 //          up to kGroupPts points, the tiles accumulated in registers over the groups of the supergroup;
 //   wide:  a local pose beyond kNarrowCams in use - 96 pose columns | 16 | h_p (column kWideHCol = 112) in rows of kWideCols = 128 doubles
-//          (8 column tiles, 36 tiles), up to kWidePts points (the same LDS region), ONE group per supergroup, a wave's tiles formed one
-//          after the other and stored straight to the partial blocks.
+//          (up to 8 column tiles, 36 tiles), up to kWidePts points (the same LDS region), a wave's tiles formed one
+//          after the other and added straight to the partial blocks in memory (a supergroup of several groups: read - add - write by the same lane).
 constexpr int kGroupHCol = 6 * kNarrowCams + 8 * kGroupIntr;      // the column of h_p (76)
 constexpr int kGroupCols = 80;                                    // 5 x 16: the columns 77..79 are padding (zero)
 constexpr int kGroupColTiles = kGroupCols / 16;
@@ -1056,29 +1056,31 @@ __device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj
   }
 }
 
-// The wide form: a finished tile goes straight to the partial blocks in memory (chunk: the destination rows of the supergroup's blocks,
-// pp | pi | ii as in LDS; kNoChunk: the block has no destination).
-__device__ __forceinline__ void wide_store_tile(const d4_t& acc, int ti, int tj, const uint32_t* __restrict__ chunk, double* __restrict__ part_pp,
-                                                double* __restrict__ part_pi, double* __restrict__ part_ii, int li, int lk, int kPoseCols, int hcol) {
+// The wide form: a tile's four elements of a lane go straight to the partial blocks in memory - where (chunk: the destination rows of
+// the supergroup's blocks, pp | pi | ii as in LDS; null: the element has no destination). A supergroup of several groups adds to what its
+// group before left there: the same lane owns the same elements in every group, the old values are fetched before the tile's k loop.
+__device__ __forceinline__ void wide_tile_dst(int ti, int tj, const uint32_t* __restrict__ chunk, double* __restrict__ part_pp, double* __restrict__ part_pi,
+                                              double* __restrict__ part_ii, int li, int lk, int kPoseCols, int hcol, double* (&dst)[4]) {
   const int J = 16 * tj + li;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
+    dst[reg] = nullptr;
     const int I = 16 * ti + lk + 4 * reg;
     if (I >= hcol || J > hcol || I > J) continue;
     const bool i_pose = I < kPoseCols;
     const int x = i_pose ? I / 6 : (I - kPoseCols) / 8;
     const int r = i_pose ? I - 6 * x : (I - kPoseCols) - 8 * x;
     if (J == hcol) {
-      if (i_pose) { const uint32_t ch = chunk[group_pair_pp(x, x)]; if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + 36 + r] = acc[reg]; }
-      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, x)]; if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + 64 + r] = acc[reg]; }
+      if (i_pose) { const uint32_t ch = chunk[group_pair_pp(x, x)]; if (ch != kNoChunk) dst[reg] = part_pp + (size_t)ch * kNVpp + 36 + r; }
+      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, x)]; if (ch != kNoChunk) dst[reg] = part_ii + (size_t)ch * kNVii + 64 + r; }
     } else if (J < kPoseCols) {
       const int y = J / 6, c = J - 6 * y;
       const uint32_t ch = chunk[group_pair_pp(x, y)];
-      if (ch != kNoChunk) part_pp[(size_t)ch * kNVpp + r * 6 + c] = acc[reg];
+      if (ch != kNoChunk) dst[reg] = part_pp + (size_t)ch * kNVpp + r * 6 + c;
     } else {
       const int l = (J - kPoseCols) / 8, c = (J - kPoseCols) - 8 * l;
-      if (i_pose) { const uint32_t ch = chunk[kGroupPairsPP + x * kGroupIntr + l]; if (ch != kNoChunk) part_pi[(size_t)ch * kNVpi + r * 8 + c] = acc[reg]; }
-      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, l)]; if (ch != kNoChunk) part_ii[(size_t)ch * kNVii + r * 8 + c] = acc[reg]; }
+      if (i_pose) { const uint32_t ch = chunk[kGroupPairsPP + x * kGroupIntr + l]; if (ch != kNoChunk) dst[reg] = part_pi + (size_t)ch * kNVpi + r * 8 + c; }
+      else { const uint32_t ch = chunk[kGroupPairsPP + kGroupPairsPI + group_pair_ii(x, l)]; if (ch != kNoChunk) dst[reg] = part_ii + (size_t)ch * kNVii + r * 8 + c; }
     }
   }
 }
@@ -1126,10 +1128,12 @@ __device__ int g_group_compact = 1;   // MVGX_BA_GROUP_COMPACT=0: every supergro
 // addresses slowed the stamped kernel by 60 % - round 6 - and the wait ended up in whichever phase came next)
 #define MVGX_GSTAMP(i) do { if (stamping) { const long long t_now = __builtin_amdgcn_s_memtime(); s_stamps[i] += (unsigned long long)(t_now - t_prev); t_prev = __builtin_amdgcn_s_memtime(); } } while (0)
 #define MVGX_GSTAMP_FLUSH() do { if (stamping) { for (int i_ = 0; i_ < 8; ++i_) if (s_stamps[i_]) atomicAdd(&g_group_stamps[MODE][i_], s_stamps[i_]); } } while (0)
-template <int MODE, bool kPinholeFamily = false>
+// WIDE: the launch covers the supergroups of the wide form (G.sg_order[sg_base ..]; a launch of its own - round 6: with the form a
+// run-time flag the usual form paid for it, 543 -> 603 us at C5 - so the form is a compile-time constant of each of the two launches).
+template <int MODE, bool kPinholeFamily = false, bool WIDE = false>
 __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (MODE == 2 && !kPinholeFamily)) ? 2 : 3) void ba_point_group_kernel(Dev d, GroupList G, double inv_radius, double dmin, double dmax,
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
-                                                                       double* __restrict__ part_ii, double* __restrict__ cand_part) {
+                                                                       double* __restrict__ part_ii, double* __restrict__ cand_part, uint32_t sg_base, int zero_system) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [row][kGroupCS] -> partial blocks
   double* const sums = lds + group_m_doubles<MODE>();   // [point][20]
@@ -1154,14 +1158,11 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   int* const sg_flags = ncam_used + 1;
   int* const npose_cols = reinterpret_cast<int*>(chunk_ids + kGroupPairsPP + kGroupPairsPI + kGroupPairsII);   // forward: 6 x (the highest local pose in use + 1)                                // forward: bit 0 - only local intrinsic 0 is in use, bit 1 - the compact form (see kCompactIntr)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const uint32_t sg = G.sg_order[blockIdx.x];
+  const uint32_t sg = G.sg_order[sg_base + blockIdx.x];
   const uint32_t g0 = G.sg_start[sg], g1 = G.sg_start[sg + 1];
   const uint32_t* __restrict__ cams = G.cams + (size_t)sg * kGroupCams;
   const uint32_t* __restrict__ intrs = G.intrs + (size_t)sg * kGroupIntr;
-  // the wide form: a local pose beyond the usual form's columns is in use (uniform: six scalar loads)
-  bool wide = false;
-#pragma unroll
-  for (int x = kNarrowCams; x < kGroupCams; ++x) wide = wide || G.chunk_pp[(size_t)sg * kGroupPairsPP + group_pair_pp(x, x)] != kNoChunk;
+  constexpr bool wide = WIDE;   // (the host sorts the supergroups by form: a supergroup is wide when its camera set has more than kNarrowCams poses)
   constexpr int NT = kGroupThreads;
   constexpr int NSUM = MODE == kGroupBacksub ? 18 : 15;   // per-observation terms summed per point (back-substitution: + Es^T (Fs z))
   constexpr int NS = kGroupThreads + 1;   // stride of the per-observation terms [value][thread]: odd, so that the readers of one observation's values hit distinct banks
@@ -1232,12 +1233,12 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
                  : j < kGroupPairsPP + kGroupPairsPI ? G.chunk_pi[(size_t)sg * kGroupPairsPI + (j - kGroupPairsPP)]
                  : G.chunk_ii[(size_t)sg * kGroupPairsII + (j - kGroupPairsPP - kGroupPairsPI)];
   }
-  if (MODE == kGroupForward) {
-    // The reduced system is zeroed here, a slice per workgroup - the assemble pass that follows this kernel writes only the blocks
-    // that exist, the tiles of the fill must start at zero - instead of by a memset launch in front of this kernel.
+  if (MODE == kGroupForward && zero_system) {
+    // The reduced system is zeroed here, a slice per workgroup (of the first forward launch) - the assemble pass that follows this kernel
+    // writes only the blocks that exist, the tiles of the fill must start at zero - instead of by a memset launch in front of this kernel.
     double2* const z2 = reinterpret_cast<double2*>(d.sp.enabled ? d.sp.A : d.S);
     const size_t n2 = (d.sp.enabled ? (size_t)d.sp.n_slots * 4096 : (size_t)d.N * d.LD) / 2;   // (N (N + 1) is even)
-    const size_t per = (n2 + gridDim.x - 1) / gridDim.x, lo = (size_t)sg * per, hi = lo + per < n2 ? lo + per : n2;
+    const size_t per = (n2 + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = lo + per < n2 ? lo + per : n2;
     for (size_t i = lo + tid; i < hi; i += kGroupThreads) z2[i] = make_double2(0.0, 0.0);
   }
   double gmax = 0.0;
@@ -1618,15 +1619,23 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     __syncthreads();
     MVGX_GSTAMP(5);
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
-    if (wide) {   // (uniform) the wide form: 36 tiles, a wave's nine one after the other, each straight to the partial blocks - one group per supergroup
+    if (wide) {   // (uniform) the wide form: 36 tiles, a wave's nine one after the other, each straight to the partial blocks
       for (int t = wave; t < wide_col_tiles * (wide_col_tiles + 1) / 2; t += kGroupWaves) {
         int ti, tj;
         group_tile(t, ti, tj, wide_col_tiles);
         const double* __restrict__ ca = M + lk * kWideCols + ((16 * ti + li) ^ ((lk & 1) << 4));   // (row k0 + lk: k0 is a multiple of four)
         const double* __restrict__ cb = M + lk * kWideCols + ((16 * tj + li) ^ ((lk & 1) << 4));
+        double* dst[4];
+        wide_tile_dst(ti, tj, chunk_ids, part_pp, part_pi, part_ii, li, lk, icol0, hcol, dst);
+        double old[4] = {0.0, 0.0, 0.0, 0.0};
+        if (g != g0) {   // (uniform) what the groups before left
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) if (dst[reg]) old[reg] = *dst[reg];
+        }
         d4_t a = d4_t{0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < rows; k0 += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[k0 * kWideCols], cb[k0 * kWideCols], a, 0, 0, 0);
-        wide_store_tile(a, ti, tj, chunk_ids, part_pp, part_pi, part_ii, li, lk, icol0, hcol);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) if (dst[reg]) *dst[reg] = old[reg] + a[reg];
       }
     } else {
 #pragma unroll
@@ -1675,9 +1684,18 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   // a wave per block, a lane per element (elements a block does not define - the rhs of an off-diagonal block, the lower triangle of a
   // diagonal one - carry whatever the region held: ba_schur_assemble never uses them)
   static_assert(kNVpp <= 64 && kNVpi <= 64 && kNVii <= 128, "a block is one or two rows of lanes");
-  for (int pair = wave; pair < kGroupPairsPP; pair += kGroupWaves) {
-    const uint32_t ch = chunk_ids[pair];
-    if (ch != kNoChunk && lane < kNVpp) part_pp[(size_t)ch * kNVpp + lane] = out[pair * kNVpp + lane];
+  {   // (pose x pose: 136 pair numbers, of which a supergroup of the usual form has at most 55 - a wave walks the LIVE ones of its quarter)
+    constexpr int kPer = (kGroupPairsPP + kGroupWaves - 1) / kGroupWaves;
+    static_assert(kPer <= 64, "a quarter of the pair numbers per wave, one per lane");
+    const int p0 = wave * kPer;
+    const uint32_t my_ch = lane < kPer && p0 + lane < kGroupPairsPP ? chunk_ids[p0 + lane] : kNoChunk;
+    unsigned long long live = __ballot(my_ch != kNoChunk);
+    while (live) {
+      const int b = __builtin_ctzll(live);
+      live &= live - 1;
+      const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)my_ch, b);
+      if (lane < kNVpp) part_pp[(size_t)ch * kNVpp + lane] = out[(p0 + b) * kNVpp + lane];
+    }
   }
   for (int pair = wave; pair < kGroupPairsPI; pair += kGroupWaves) {
     const uint32_t ch = chunk_ids[kGroupPairsPP + pair];
@@ -3440,6 +3458,7 @@ struct mvgx_ba_ctx {
   bool solver_ready = false;
   bool pinhole_family = false;       // every intrinsic is pinhole / radial K1 / radial K3 / Brown T2: the point-group kernels run without the spherical / fisheye branches
   bool diag_blocks_complete = false;   // every pose / intrinsic block has a diagonal destination block in the assemble lists
+  uint32_t n_sg_wide = 0;             // supergroups of the wide form: the tail of sg_order, a launch of their own
   std::vector<uint32_t> h_sg_order;   // (a member: the asynchronous upload may read it after mvgx_ba_create's locals are gone)
   // what mvgx_ba_update needs to re-bind the context to new values of the same structure
   mvgx::BaFingerprint fingerprint;            // of the problem the context was created from
@@ -3576,14 +3595,18 @@ int eval(mvgx_ba_ctx* c, const double* poses, const double* intr, const double* 
 template <int MODE>
 void launch_point_groups(mvgx_ba_ctx* c, double inv_radius, double dmin, double dmax, double* cand_part = nullptr) {
   Dev& d = c->d;
-  if (c->pinhole_family)   // every intrinsic is a polynomial model: the variant without the spherical / fisheye branches
-    hipLaunchKernelGGL((ba_point_group_kernel<MODE, true>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
-                       d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
-                       d.tii.part + (size_t)d.tii.n_chunks * kNVii, cand_part);
-  else
-    hipLaunchKernelGGL((ba_point_group_kernel<MODE, false>), dim3(d.grp.n_sg), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax,
-                       d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp, d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi,
-                       d.tii.part + (size_t)d.tii.n_chunks * kNVii, cand_part);
+  double* const ppp = d.tpp.part + (size_t)d.tpp.n_chunks * kNVpp;
+  double* const ppi = d.tpi.part + (size_t)d.tpi.n_chunks * kNVpi;
+  double* const pii = d.tii.part + (size_t)d.tii.n_chunks * kNVii;
+  // the supergroups of the usual form, then - a launch of its own - those of the wide form (G.sg_order lists them in that order)
+  const uint32_t n_narrow = d.grp.n_sg - c->n_sg_wide, n_wide = c->n_sg_wide;
+  if (c->pinhole_family) {   // every intrinsic is a polynomial model: the variant without the spherical / fisheye branches
+    if (n_narrow) hipLaunchKernelGGL((ba_point_group_kernel<MODE, true, false>), dim3(n_narrow), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax, ppp, ppi, pii, cand_part, 0u, 1);
+    if (n_wide) hipLaunchKernelGGL((ba_point_group_kernel<MODE, true, true>), dim3(n_wide), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax, ppp, ppi, pii, cand_part, n_narrow, n_narrow ? 0 : 1);
+  } else {
+    if (n_narrow) hipLaunchKernelGGL((ba_point_group_kernel<MODE, false, false>), dim3(n_narrow), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax, ppp, ppi, pii, cand_part, 0u, 1);
+    if (n_wide) hipLaunchKernelGGL((ba_point_group_kernel<MODE, false, true>), dim3(n_wide), dim3(kGroupThreads), group_lds_bytes<MODE>(), c->stream, d, d.grp, inv_radius, dmin, dmax, ppp, ppi, pii, cand_part, n_narrow, n_narrow ? 0 : 1);
+  }
 }
 
 // TrustRegionMinimizer::EvaluateGradientAndJacobian at the current x (its cost is known: c->x_cost - the cost pass of the
@@ -4799,14 +4822,12 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
             std::sort(ec.begin(), ec.end()); ec.erase(std::unique(ec.begin(), ec.end()), ec.end());
             std::sort(ei.begin(), ei.end()); ei.erase(std::unique(ei.begin(), ei.end()), ei.end());
             cams = ec; intrs = ei;
-            sg_open = false;
           }
-          // (a wide group - more than kNarrowCams poses - is a supergroup of its own: its tiles leave the workgroup group by group)
-          const bool continues = sg_open && cams.size() <= (size_t)kNarrowCams && cams == tail_cams && intrs == tail_intrs && B.sg_n.back() < (uint32_t)kMaxSgGroups;
+          const bool continues = sg_open && cams == tail_cams && intrs == tail_intrs && B.sg_n.back() < (uint32_t)kMaxSgGroups;
           // (a wide group stays whatever its size: a handful of points left to the record-based path costs its dozen launches per iteration)
           if (cur.size() >= (size_t)kGroupMinPts || (continues && !cur.empty()) || (cams.size() > (size_t)kNarrowCams && !cur.empty())) { emit_group(continues); sg_open = true; }
           else sg_open = false;
-          if (cams.size() > (size_t)kNarrowCams) { cams.clear(); intrs.clear(); sg_open = false; }   // (nothing continues a wide group: the next one starts from its own points)
+          if (cams.size() > (size_t)kNarrowCams) { cams.clear(); intrs.clear(); }   // (the next group starts from its own points: a wide group's sets are exact, and it continues the supergroup when they come out the same)
           cur.clear(); cur_obs = 0;
         };
         for (uint32_t q = lo_start[bucket]; q < lo_start[bucket + 1]; ++q) {
@@ -5042,6 +5063,15 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
         std::stable_sort(c->h_sg_order.begin(), c->h_sg_order.end(), [&](uint32_t a, uint32_t b) {
           return g_obs_start[sg_start[a + 1]] - g_obs_start[sg_start[a]] > g_obs_start[sg_start[b + 1]] - g_obs_start[sg_start[b]];
         });
+      // ... the supergroups of the usual form first, the wide ones (a local pose beyond kNarrowCams in use) behind them: two launches
+      auto sg_is_wide = [&](uint32_t sgi) {
+        for (int x = kNarrowCams; x < kGroupCams; ++x)
+          if (sg_pp[(size_t)sgi * kGroupPairsPP + x * kGroupCams - x * (x - 1) / 2]) return true;
+        return false;
+      };
+      std::stable_partition(c->h_sg_order.begin(), c->h_sg_order.end(), [&](uint32_t sgi) { return !sg_is_wide(sgi); });
+      c->n_sg_wide = 0;
+      for (uint32_t sgi = 0; sgi < (uint32_t)n_sg; ++sgi) c->n_sg_wide += sg_is_wide(sgi) ? 1u : 0u;
       if ((rc = dev_upload(c->pool, &d.grp.sg_order, c->h_sg_order, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.obs_start, g_obs_start, c->stream))) return rc;
       if ((rc = dev_upload(c->pool, &d.grp.pt_start, g_pt_start, c->stream))) return rc;
@@ -5080,12 +5110,12 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
 #undef HA
   MVGX_HIP(hipMemsetAsync(d.scalars, 0, kSCount * sizeof(double), c->stream));
   MVGX_HIP(hipMemsetAsync(d.zsol, 0, (size_t)std::max(d.N, 1) * sizeof(double), c->stream));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupForward>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupBacksub>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupNorms, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupForward, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
-  MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<kGroupBacksub, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds));
+#define MVGX_GROUP_ATTR(mode, fam, wide_) MVGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_point_group_kernel<mode, fam, wide_>), hipFuncAttributeMaxDynamicSharedMemorySize, kGroupLds))
+  MVGX_GROUP_ATTR(kGroupNorms, false, false); MVGX_GROUP_ATTR(kGroupForward, false, false); MVGX_GROUP_ATTR(kGroupBacksub, false, false);
+  MVGX_GROUP_ATTR(kGroupNorms, true, false); MVGX_GROUP_ATTR(kGroupForward, true, false); MVGX_GROUP_ATTR(kGroupBacksub, true, false);
+  MVGX_GROUP_ATTR(kGroupNorms, false, true); MVGX_GROUP_ATTR(kGroupForward, false, true); MVGX_GROUP_ATTR(kGroupBacksub, false, true);
+  MVGX_GROUP_ATTR(kGroupNorms, true, true); MVGX_GROUP_ATTR(kGroupForward, true, true); MVGX_GROUP_ATTR(kGroupBacksub, true, true);
+#undef MVGX_GROUP_ATTR
   c->pinhole_family = true;
   for (uint32_t k = 0; k < d.n_intr; ++k) {
     const int m = p->intr_model[k];
