@@ -418,6 +418,10 @@ def main():
             ba_rec = ba_bench_record(local_rank, world, cpu=not args.no_cpu_baseline, rehearsal=rehearsal)
             if world == 1 and not args.no_ba_c5 and not rehearsal:   # configs[4] fits one GPU: reported beside its sharded runs at N > 1
                 ba_c5 = ba_bench_record(local_rank, 1, cpu=not args.no_cpu_baseline, name="c5")
+                try:   # C3's size with a realistic track-length distribution (side record; the reference beside it on a short budget)
+                    out["ba_mixed_track_lengths"] = ba_bench_record(local_rank, 1, cpu=not args.no_cpu_baseline, cpu_budget_s=30.0, name="mixed")
+                except Exception as e:
+                    out["ba_mixed_track_lengths"] = {"status": f"failed: {e!r}"}
         except Exception as e:  # the BA leg is a side record: never lose the matching line
             ba_rec = ba_rec or {"status": f"failed: {e!r}"}
     if rank == 0 and world == 1 and not args.no_hamming and not rehearsal:

@@ -17,10 +17,13 @@ def _r(x, digits=6):
 
 
 def _pick(d, keys, digits=6):
-    return {k: _r(d[k], digits) for k in keys if isinstance(d, dict) and k in d}
+    o = {k: _r(d[k], digits) for k in keys if isinstance(d, dict) and k in d}
+    if isinstance(o.get("traffic_source"), str):   # the file only: the command it came from is in the side record
+        o["traffic_source"] = o["traffic_source"].replace("PMC pass ", "").split(" ")[0]
+    return o
 
 
-def _cpu(c, sample_chars=100):
+def _cpu(c, sample_chars=70):
     if not isinstance(c, dict):
         return None
     o = _pick(c, ("value", "unit", "cores", "kind"))
@@ -107,6 +110,11 @@ def compact(out, side_file=None):
         line["ba"] = _ba(out["ba"])
     if "ba_c5_single_gpu" in out:
         line["ba_c5_single_gpu"] = _ba(out["ba_c5_single_gpu"])
+    if isinstance(out.get("ba_mixed_track_lengths"), dict):   # digest only: iteration time, iterations, RMSE against the reference
+        m = out["ba_mixed_track_lengths"]
+        line["ba_mixed_tracks"] = ({"status": str(m["status"])[:80]} if "status" in m else
+                                   {**_pick(m, ("lm_iteration_ms", "iterations"), 6), "final_rmse": m.get("final_rmse"),
+                                    "rmse_diff_vs_reference": (m.get("cpu_baseline") or {}).get("rmse_diff_vs_reference")})
     side = {}
     for k, short in (("hamming", "hamming"), ("l2_float", "l2_float"), ("l2_uint8_144", "l2_u8_144"), ("geometric_filter", "geo_f"),
                      ("geometric_filter_homography", "geo_h"), ("geometric_filter_essential", "geo_e"), ("guided_matching", "guided")):

@@ -393,6 +393,26 @@ def test_point_groups_on_the_matrix_cores_equal_the_flat_product_list(kw, monkey
     assert s_g.num_iterations == osum.num_iterations and abs(s_g.final_rmse - osum.final_rmse) < RMSE_TOL
 
 
+def test_mixed_track_lengths_equal_the_reference():
+    """A scene with a realistic track-length distribution (2 + geometric, mean 6, tail to 40: synth.geometric_track_lengths) - points on
+    all three routes at once: the usual groups (up to 10 poses), the wide groups (11 .. 16, round 6) and the record-based path (longer) -
+    against the compiled reference (Ceres through Bundle_Adjustment_Ceres::Adjust): final RMSE (north_star: 1e-6), and iteration count + RMSE
+    against the restatement."""
+    if not _oracle.have_ref_ba():
+        pytest.skip("oracle/_ref BA library not built")
+    lens = synth.geometric_track_lengths(9000, mean=6.0, lo=2, hi=40, seed=5)
+    sc = synth.ba_scene(n_cams=60, n_points=len(lens), track_lens=lens, model=3, n_intr_groups=2, seed=0xBA5E0044)
+    ctx = ba.BaContext(sc); s = ctx.solve(); info = ctx.solver_info(); ctx.close()
+    n_long = int((lens > 16).sum()); n_wide = int(((lens > 10) & (lens <= 16)).sum())
+    assert n_long > 50 and n_wide > 300
+    assert info.n_point_groups > 0 and len(lens) - n_long - 200 <= info.n_grouped_points <= len(lens) - n_long   # (everything up to 16 poses grouped, a few small tail groups aside)
+    rc, st, *_ = _oracle.ref_ba_adjust(sc, num_threads=4)
+    assert rc == 0 and st[3] == 1.0
+    assert abs(s.final_rmse - float(st[1])) < RMSE_TOL, (s.final_rmse, float(st[1]))   # (stats: rmse before, rmse after, seconds, Adjust()'s return value)
+    rc, osum, *_ = _oracle.port_ba_solve(sc)
+    assert s.num_iterations == osum.num_iterations and abs(s.final_rmse - osum.final_rmse) < RMSE_TOL
+
+
 @pytest.mark.parametrize("kw", [
     dict(n_cams=60, n_points=6000, track_len=10, model=3, n_intr_groups=2, seed=121, outlier_frac=0.02),
     dict(n_cams=30, n_points=2500, track_len=6, model=7, n_intr_groups=1, seed=122),      # spherical: the generic kernel variants
