@@ -39,7 +39,7 @@ FLOP_PER_DESC_PAIR = 256.0          # 128 MAC
 # streams, MI355X_MICROARCH.md] + TCC_EA0_WRREQ x 64 B) / 499 500 pairs). Counters cannot be read inside this process; the
 # figure is scaled to this run's pairs per launch and the record names the file it came from. Algorithmic minimum (every image
 # read once) is ~0.1 GB per launch.
-MATCH_TRAFFIC_PROFILES = ("profiles/round5_match_traffic_pmc.json", "profiles/round4_match_traffic_pmc.json", "profiles/round2_match_traffic_pmc_call26.json")
+MATCH_TRAFFIC_PROFILES = ("profiles/round6_match_traffic_pmc.json", "profiles/round5_match_traffic_pmc.json", "profiles/round4_match_traffic_pmc.json", "profiles/round2_match_traffic_pmc_call26.json")
 
 
 def match_traffic_profile():
