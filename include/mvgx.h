@@ -86,7 +86,10 @@ int mvgx_match_destroy(mvgx_match_ctx* ctx);
  * "stream_hold" (mvgx_match_run_stream, default 0; 1: the buffers handed to the sink stay valid until TWO further sink
  * calls have returned or the run has returned - a second set of host buffers per batch slot - so that a caller can
  * convert batch k on its own threads while batches k + 1 and k + 2 arrive),
- * "pinned_stream" (default 1: the batch buffers of mvgx_match_run_stream are pinned; 0: plain memory, for one-shot use). */
+ * "pinned_stream" (default 1: the batch buffers of mvgx_match_run_stream are pinned; 0: plain memory, for one-shot use).
+ * "stream_reserve" (uint32 words per buffer): page-locks the stream's host buffers ahead of the run - callable from another thread
+ *   while mvgx_match_set_regions uploads (pinning ~100 MB takes tens of milliseconds the first batches would otherwise wait for).
+ * "batch_pairs" (default 32 768): image pairs per device batch. */
 int mvgx_match_set_option(mvgx_match_ctx* ctx, const char* key, int64_t value);
 
 /* Load the descriptor arrays of n_images images into HBM (replaces Regions_Provider::get +
