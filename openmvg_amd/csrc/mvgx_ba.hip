@@ -282,6 +282,7 @@ struct Dev {
   double* grp_part = nullptr;         // n_sg x 5: the supergroups' sums of the back-substitution pass with the candidate (ba_step_reduce_kernel)
   double* scalars = nullptr;          // kSCount
   int* fail = nullptr;
+  const int* gate = nullptr;          // non-null: a Jacobian evaluation launched AHEAD of the host's accept decision - its kernels leave at once unless *gate (the device's own decision, ba_publish_scalars_kernel)
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(256, kPinholeFamily ? 4 : 2) void ba_cam_gram_kerne
   __shared__ __attribute__((aligned(16))) double F[128 * kGramRow];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const uint32_t ch = blockIdx.x;
+  if (d.gate && !*d.gate) return;   // (launched ahead of a step the device itself did not accept: nothing has changed)
   if (ch == 0 && tid == 0) { *d.fail = 0; d.scalars[kSGmax] = 0.0; }   // every Jacobian evaluation leaves the fail word of the following step clear (one memset launch less per iteration) and the gradient maximum ready for ba_gram_finish_kernel's atomic max
   const uint32_t lo = d.pichunk_lo[ch], hi = d.pichunk_hi[ch];
   const uint32_t ip = d.pichunk_pose[ch], ii = d.pichunk_intr[ch];
@@ -724,6 +726,7 @@ __device__ __forceinline__ void finish_column(const Dev& d, int col, double cn, 
 __global__ __launch_bounds__(1024) void ba_gram_finish_kernel(Dev d, uint32_t wg_pi, uint32_t wg_pose, int fold_diag, double dmin, double dmax) {
   __shared__ double sh[16][kIntrGram];
   __shared__ unsigned s_last;
+  if (d.gate && !*d.gate) return;   // (as ba_cam_gram_kernel)
   const uint32_t wg = blockIdx.x;
   double gm = 0.0;   // fold_diag: max |gradient| over the active camera columns this thread finishes
   if (wg < wg_pi) {   // ---- (pose, intrinsic) pairs ----
@@ -3434,6 +3437,9 @@ struct mvgx_ba_ctx {
   unsigned long long publish_seq = 0;
   bool poll_scalars = true;
   int* h_fail = nullptr;               // the slot after h_scalars
+  int* d_accept = nullptr;             // device word: the accept decision of the step just computed (ba_publish_scalars_kernel)
+  bool speculate = true;               // MVGX_BA_SPECULATE=0: the next Jacobian evaluation is launched after the host's decision, as before round 6
+  bool spec_done = false;              // this step's Jacobian evaluation at x + delta is already enqueued, gated by d_accept
   mvgx_allreduce_f64 allreduce = nullptr;
   void* allreduce_user = nullptr;
   mvgx::RcclComm* rccl = nullptr;
@@ -3510,22 +3516,47 @@ namespace {
 // The scalars of a step reach the host through its page-locked, device-visible block: a one-wave kernel copies them there and then
 // raises a sequence number the host polls - the copy engine + hipStreamSynchronize pair it replaces woke the host 10 - 15 us after
 // the stream had drained (an LM iteration waits for exactly one such hand-over). MVGX_BA_POLL_SCALARS=0: the copy + synchronise form.
-__global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double* __restrict__ scalars, double* __restrict__ host, unsigned long long seq) {
+// Round 6: the kernel also takes the step's accept decision ITSELF (x_cost: the cost at x, known to the host when it launches the step; the
+// test of trust_region_minimizer.cc:640-700 on the same doubles with the same three operations) and leaves it in `accept` - the Jacobian
+// evaluation of the next iteration is launched right behind this kernel, before the host has seen the scalars, gated by that word
+// (Dev::gate): the 20-25 us between the last kernel of an iteration and the first of the next - the host's poll, decision and launch -
+// were 5 % of an iteration at C3. The host reads the same word with the scalars and follows it.
+__global__ __launch_bounds__(64) void ba_publish_scalars_kernel(const double* __restrict__ scalars, double* __restrict__ host, unsigned long long seq,
+                                                                int* __restrict__ accept, double x_cost, double min_relative_decrease, int decide,
+                                                                double parameter_tolerance, double function_tolerance, int x_norm_valid) {
   const int t = threadIdx.x;
   if (t <= kSCount) host[t] = scalars[t];   // (the fail word rides in slot kSCount)
+  if (t == 0 && decide) {
+    const double model = scalars[kSModelPt] + scalars[kSModelCam];
+    const int failed = *reinterpret_cast<const int*>(scalars + kSCount);
+    const bool ok = !failed && isfinite(model);
+    const double relative_decrease = (x_cost - scalars[kSCost]) / model;
+    const int a = (ok && model > 0.0 && relative_decrease > min_relative_decrease) ? 1 : 0;
+    // ... and the two tolerance tests that END the solve before the step is taken (lm_iteration): a solve of three iterations should not pay
+    // for an evaluation nobody uses. The gate is the conjunction; the host follows `a` and checks it, and launches the evaluation itself
+    // whenever the gate stayed shut.
+    const double step_norm = sqrt(scalars[kSCamStepSq] + scalars[kSStepSq]);
+    const double x_norm = x_norm_valid ? sqrt(scalars[kSCamXSq] + scalars[kSXSq]) : -1.0;
+    const bool ends = step_norm <= parameter_tolerance * (x_norm + parameter_tolerance) || fabs(x_cost - scalars[kSCost]) <= function_tolerance * x_cost;
+    const int g = a && !ends ? 1 : 0;
+    *accept = g;
+    host[kSCount + 2] = (double)(a + 2 * g);
+  }
   __threadfence_system();
   __syncthreads();
   if (t == 0) *reinterpret_cast<volatile unsigned long long*>(host + kSCount + 1) = seq;
 }
-int read_scalars(mvgx_ba_ctx* c) {
+int read_scalars(mvgx_ba_ctx* c, int decide = 0, const mvgx_ba_options* opt = nullptr, int (*between)(mvgx_ba_ctx*, void*) = nullptr, void* between_arg = nullptr) {
   if (!c->poll_scalars) {
     MVGX_HIP(hipMemcpyAsync(c->h_scalars, c->d.scalars, (kSCount + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     MVGX_HIP(hipStreamSynchronize(c->stream));
     return MVGX_OK;
   }
   const unsigned long long seq = ++c->publish_seq;
-  hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(64), 0, c->stream, c->d.scalars, c->h_scalars_dev, seq);
+  hipLaunchKernelGGL(ba_publish_scalars_kernel, dim3(1), dim3(64), 0, c->stream, c->d.scalars, c->h_scalars_dev, seq, c->d_accept, c->x_cost, opt ? opt->min_relative_decrease : 0.0, decide,
+                     opt ? opt->parameter_tolerance : 0.0, opt ? opt->function_tolerance : 0.0, c->x_norm_valid ? 1 : 0);
   BA_LAUNCH_CHECK();
+  if (between) { const int rc_b = between(c, between_arg); if (rc_b) return rc_b; }   // (work enqueued behind the publish kernel while the device still runs the step)
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->h_scalars + kSCount + 1);
   const auto t0 = std::chrono::steady_clock::now();
   for (uint64_t spins = 0; *flag != seq; ++spins) {
@@ -4047,7 +4078,26 @@ int enqueue_candidate_and_cost(mvgx_ba_ctx* c, bool candidate_done) {
 }
 
 // LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver::SolveImpl. ok=false <=> LINEAR_SOLVER_FAILURE.
-int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
+int evaluate_gradient_and_jacobian(mvgx_ba_ctx* c, const mvgx_ba_options* opt, bool iteration_zero);
+// The Jacobian evaluation of the NEXT iteration at x + delta, enqueued behind the publish kernel and gated by the device's accept word
+// (ba_publish_scalars_kernel): the pointers of x and the candidate are exchanged for the launches and exchanged back - the host accepts,
+// or does not, when it has read the scalars. Host-side flags the evaluation sets are restored: they become true only with the acceptance.
+int speculative_evaluation(mvgx_ba_ctx* c, void* arg) {
+  const mvgx_ba_options* opt = static_cast<const mvgx_ba_options*>(arg);
+  Dev& d = c->d;
+  const bool fail_clear = c->fail_clear, gmax_pending = c->gmax_pending;
+  const double dmin = c->dmin, dmax = c->dmax;
+  std::swap(d.poses, d.cposes); std::swap(d.intr, d.cintr); std::swap(d.pts, d.cpts);
+  d.gate = c->d_accept;
+  const int rc = evaluate_gradient_and_jacobian(c, opt, false);
+  d.gate = nullptr;
+  std::swap(d.poses, d.cposes); std::swap(d.intr, d.cintr); std::swap(d.pts, d.cpts);
+  c->fail_clear = fail_clear; c->gmax_pending = gmax_pending; c->dmin = dmin; c->dmax = dmax;
+  c->spec_done = rc == MVGX_OK;
+  return rc;
+}
+
+int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change, const mvgx_ba_options* opt) {
   Dev& d = c->d;
   const double inv_radius = 1.0 / c->radius;
   phase_begin(c);
@@ -4101,7 +4151,12 @@ int compute_step(mvgx_ba_ctx* c, bool* ok, double* model_cost_change) {
   }
   phase_end(c, kPhBacksub);
   if ((rc = enqueue_candidate_and_cost(c, !c->model_cost_from_jacobian))) return rc;
-  if ((rc = read_scalars(c))) return rc;
+  // the usual case - one rank, every point grouped, no priors, the candidate's cost from the back-substitution pass - launches the next
+  // iteration's Jacobian evaluation ahead of the decision (two gated kernels: Gram + finish)
+  c->spec_done = false;
+  const bool spec = c->speculate && c->poll_scalars && fold_cand && !multi_rank(c) && !d.n_priors && d.n_pichunks && !c->model_cost_from_jacobian &&
+                    c->iteration < opt->max_num_iterations;
+  if ((rc = read_scalars(c, spec ? 1 : 0, opt, spec ? &speculative_evaluation : nullptr, const_cast<mvgx_ba_options*>(opt)))) return rc;
   if (c->gmax_pending) {   // the Jacobian evaluation before this step left its max |gradient| on the device (see there)
     c->gradient_max_norm = std::max(c->h_scalars[kSGmax], c->h_scalars[kSGmaxGrp]);
     c->gmax_pending = false;
@@ -4177,7 +4232,7 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   bool ok = false;
   double model_cost_change = 0;
   c->gmax_resolved = false;
-  int rc = compute_step(c, &ok, &model_cost_change);
+  int rc = compute_step(c, &ok, &model_cost_change, opt);
   if (rc) return rc;
   // The gradient test of this iteration's start, made now that the max |gradient| of the last Jacobian evaluation has come back
   // with the step's scalars (one host round trip per iteration instead of two): the step just computed is dropped, as if the
@@ -4202,11 +4257,20 @@ int lm_iteration(mvgx_ba_ctx* c, const mvgx_ba_options* opt) {
   if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { c->termination = 0; c->finished = true; return MVGX_OK; }
   if (std::fabs(c->x_cost - cand) <= opt->function_tolerance * c->x_cost) { c->termination = 0; c->finished = true; return MVGX_OK; }
   const double relative_decrease = (c->x_cost - cand) / model_cost_change;
-  if (relative_decrease > opt->min_relative_decrease) {
+  const bool accept = relative_decrease > opt->min_relative_decrease;
+  // (a Jacobian evaluation launched ahead runs on the device's own decision: the two are the same test on the same doubles)
+  const int dev_word = c->spec_done ? (int)c->h_scalars[kSCount + 2] : 0;   // accept + 2 gate
+  MVGX_REQUIRE(!c->spec_done || accept == ((dev_word & 1) != 0), MVGX_ERR_NUMERIC, "internal error: the device's accept decision differs from the host's");
+  if (c->spec_done && !(dev_word & 2)) c->spec_done = false;   // (the gate stayed shut - the device saw the solve end here: the evaluation is launched below, as without the look-ahead)
+  if (accept) {
     if ((rc = accept_candidate(c))) return rc;
     c->x_cost = cand;   // the cost pass of the candidate IS the cost at the new x
     c->x_sqerr = c->h_scalars[kSSqErr];
-    if ((rc = evaluate_gradient_and_jacobian(c, opt, false))) return rc;
+    if (c->spec_done) {   // the evaluation at the new x is on its way: what it leaves on the host side
+      c->fail_clear = c->d.n_pichunks != 0;
+      c->dmin = opt->min_lm_diagonal; c->dmax = opt->max_lm_diagonal;
+      c->gmax_pending = true;
+    } else if ((rc = evaluate_gradient_and_jacobian(c, opt, false))) return rc;
     c->radius = c->radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
     c->radius = std::min(opt->max_radius, c->radius);
     c->decrease_factor = 2.0; c->reuse_diagonal = false;
@@ -4430,8 +4494,9 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   MVGX_HIP(hipEventCreate(&c->ev0));
   MVGX_HIP(hipEventCreate(&c->ev1));
   tick("events");
-  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 2) * sizeof(double), hipHostMallocDefault));
-  memset(c->h_scalars, 0, (kSCount + 2) * sizeof(double));
+  MVGX_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scalars), (kSCount + 3) * sizeof(double), hipHostMallocDefault));
+  memset(c->h_scalars, 0, (kSCount + 3) * sizeof(double));
+  if (const char* env = getenv("MVGX_BA_SPECULATE")) c->speculate = atoi(env) != 0;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_scalars_dev), c->h_scalars, 0) != hipSuccess) { (void)hipGetLastError(); c->poll_scalars = false; }
   if (const char* env = getenv("MVGX_BA_POLL_SCALARS")) c->poll_scalars = c->poll_scalars && atoi(env) != 0;
   if (const char* env = getenv("MVGX_BA_SEPARATE_COST")) c->fold_candidate = atoi(env) == 0;
@@ -5102,6 +5167,7 @@ int mvgx_ba_create(int device, const mvgx_ba_problem* p, mvgx_ba_ctx** out) {
   AL(part, (size_t)6 * std::max(c->grid_obs, c->grid_vec) + 16);   // up to six partial sums per workgroup (ba_step_scalars_kernel)
   AL(grp_part, (size_t)5 * d.grp.n_sg + 8);
   AL(scalars, kSCount + 1);   // the fail word lives in the slot after the scalars: one D2H copy fetches both
+  if ((rc = dev_alloc(c->pool, &c->d_accept, (size_t)2))) return rc;
   d.fail = reinterpret_cast<int*>(d.scalars + kSCount);
 #undef UP
 #undef UPN
