@@ -1024,6 +1024,13 @@ __device__ __forceinline__ void group_tile(int t, int& ti, int& tj, int n = kGro
 // of kGroupHCol - 64 columns, four column tiles, ten tiles of Z^T Z instead of fifteen. Same sums, same bits; the zero elements the
 // five dropped tiles used to deliver are written as zeros when the partial blocks go out.
 constexpr int kCompactIntr = 3;
+// The strip form (round 6): one local intrinsic of up to kStripIntr parameters. Columns: 60 pose columns | h_p (60) | the intrinsic's eight
+// columns (61 ..; those beyond 67 are zero and are not read). Z^T Z = the ten 16 x 16 tiles of columns 0 .. 63 + the products of columns
+// 64 .. 67 with columns 0 .. 67: five v_mfma_f64_4x4x4_4b_f64 per k-step (18 cycles each: 90) where the fifth column tile cost five
+// 16 x 16 x 4 instructions (320). Lane (li, lk) of strip instruction s holds the product of columns 64 + lk and 16 s + li.
+constexpr int kStripIntr = 7;
+constexpr int kStripHCol = 6 * kNarrowCams, kStripICol0 = kStripHCol + 1, kStripCol0 = 64, kStripInstr = 5;
+static_assert(kStripICol0 + kStripIntr <= kStripCol0 + 4, "the strip's four columns hold the intrinsic's last parameters");
 constexpr int kCompactHCol = 6 * kNarrowCams + kCompactIntr;
 constexpr int kCompactColTiles = (kCompactHCol + 16) / 16;
 constexpr int kCompactTiles = kCompactColTiles * (kCompactColTiles + 1) / 2;
@@ -1033,30 +1040,33 @@ static_assert(kCompactHCol == 63 && kCompactColTiles == 4, "the compact form is 
 //   out + 55 * 42                [x * kGroupIntr + k][54]  6 x 8 block
 //   out + 55 * 42 + 20 * 54      [pair (k <= l)][72]  8 x 8 block (+ the rhs of intrinsic k for k == l)
 // Only elements with global column I <= J are defined (the upper triangle of a diagonal block is the whole block).
-__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk, int hcol = kGroupHCol) {
+// (I <= J: columns of the staged matrix in its usual forms - pose columns below 6 kNarrowCams, 16 intrinsic columns from icol0, h_p in
+// column hcol: behind the intrinsic columns, or in front of them in the strip form)
+__device__ __forceinline__ void group_store_elem(int I, int J, double val, double* __restrict__ out, int icol0, int hcol) {
+  constexpr int kPoseCols = 6 * kNarrowCams;
   double* __restrict__ out_pi = out + kGroupPairsPP * kNVpp;
   double* __restrict__ out_ii = out_pi + kGroupPairsPI * kNVpi;
-  constexpr int kPoseCols = 6 * kNarrowCams;   // (the usual form)
+  if (I > J) return;
+  const bool i_pose = I < kPoseCols, j_pose = J < kPoseCols;   // (h_p first: in the compact form its column lies inside the intrinsic's range)
+  const bool i_intr = I != hcol && I >= icol0 && I < icol0 + 8 * kGroupIntr, j_intr = J != hcol && J >= icol0 && J < icol0 + 8 * kGroupIntr;
+  if (i_pose) {
+    const int x = I / 6, r = I - 6 * x;
+    if (j_pose) { const int y = J / 6, c = J - 6 * y; out[group_pair_pp(x, y) * kNVpp + r * 6 + c] = val; }
+    else if (J == hcol) out[group_pair_pp(x, x) * kNVpp + 36 + r] = val;
+    else if (j_intr) { const int l = (J - icol0) >> 3, c = (J - icol0) & 7; out_pi[(x * kGroupIntr + l) * kNVpi + r * 8 + c] = val; }
+  } else if (i_intr) {
+    const int k = (I - icol0) >> 3, r = (I - icol0) & 7;
+    if (j_intr) { const int l = (J - icol0) >> 3, c = (J - icol0) & 7; out_ii[group_pair_ii(k, l) * kNVii + r * 8 + c] = val; }
+    else if (J == hcol) out_ii[group_pair_ii(k, k) * kNVii + 64 + r] = val;
+  } else if (I == hcol && j_intr) {   // (the strip form: h_p in front of the intrinsic columns)
+    const int l = (J - icol0) >> 3, c = (J - icol0) & 7;
+    out_ii[group_pair_ii(l, l) * kNVii + 64 + c] = val;
+  }
+}
+__device__ __forceinline__ void group_store_tile(const d4_t& acc, int ti, int tj, double* __restrict__ out, int li, int lk, int icol0, int hcol) {
   const int J = 16 * tj + li;
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int I = 16 * ti + lk + 4 * reg;
-    if (I >= hcol || J > hcol || I > J) continue;
-    const bool i_pose = I < kPoseCols;
-    const int x = i_pose ? I / 6 : (I - kPoseCols) / 8;
-    const int r = i_pose ? I - 6 * x : (I - kPoseCols) - 8 * x;
-    if (J == hcol) {   // column of h_p: the rhs
-      if (i_pose) out[group_pair_pp(x, x) * kNVpp + 36 + r] = acc[reg];
-      else out_ii[group_pair_ii(x, x) * kNVii + 64 + r] = acc[reg];
-    } else if (J < kPoseCols) {   // I <= J: I is a pose column too
-      const int y = J / 6, c = J - 6 * y;
-      out[group_pair_pp(x, y) * kNVpp + r * 6 + c] = acc[reg];
-    } else {
-      const int l = (J - kPoseCols) / 8, c = (J - kPoseCols) - 8 * l;
-      if (i_pose) out_pi[(x * kGroupIntr + l) * kNVpi + r * 8 + c] = acc[reg];
-      else out_ii[group_pair_ii(x, l) * kNVii + r * 8 + c] = acc[reg];
-    }
-  }
+  for (int reg = 0; reg < 4; ++reg) group_store_elem(16 * ti + lk + 4 * reg, J, acc[reg], out, icol0, hcol);
 }
 
 // The wide form: a tile's four elements of a lane go straight to the partial blocks in memory - where (chunk: the destination rows of
@@ -1225,7 +1235,10 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       for (int b = 0; b < kGroupCams; ++b) if ((used_mask >> b) & 1ull) *npose_cols = 6 * (b + 1);   // pose columns up to the last local pose in use
       const bool single = G.chunk_ii[(size_t)sg * kGroupPairsII + group_pair_ii(1, 1)] == kNoChunk;   // no point of the supergroup sees local intrinsic 1
       const int pc = intr_param_count(d.model[intrs[0]]);
-      *sg_flags = (single ? 1 : 0) | (!wide && single && pc >= 0 && pc <= kCompactIntr && g_group_compact ? 2 : 0);
+      // (bit 2: the strip form - one local intrinsic of 4 .. kStripIntr parameters, radial K3 and its kin: h_p in column 60, the intrinsic
+      // columns behind it - 68 columns: the ten tiles of four column tiles, and columns 64 .. 67 on v_mfma_f64_4x4x4_4b_f64)
+      *sg_flags = (single ? 1 : 0) | (!wide && single && pc >= 0 && pc <= kCompactIntr && g_group_compact ? 2 : 0) |
+                  (!wide && single && pc > kCompactIntr && pc <= kStripIntr && g_group_compact ? 4 : 0);
     }
   }
   if (MODE == kGroupForward && tid < kGroupPairsPP + kGroupPairsPI + kGroupPairsII) {
@@ -1253,23 +1266,27 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
   // head the chains of dependent loads (entry -> ids -> parameters), which then start from registers.
   // forward: the form of the staged matrix (the flags were set by wave 3 above)
   int hcol = kGroupHCol, n_tiles = kGroupTiles;
-  bool single_intr = false;
+  bool single_intr = false, strip = false;
   if (MODE == kGroupForward) {
     __syncthreads();
     const int fl = *sg_flags;
     single_intr = (fl & 1) != 0;
-    if (fl & 2) {
-      hcol = kCompactHCol; n_tiles = kCompactTiles;
+    if (fl & 6) {   // compact or strip: the ten tiles of four column tiles
+      hcol = (fl & 2) ? kCompactHCol : kStripHCol; n_tiles = kCompactTiles;
 #pragma unroll
       for (int j = 0; j < kGroupTilesPerWave; ++j) group_tile(min(wave + j * kGroupWaves, kCompactTiles - 1), tti[j], ttj[j], kCompactColTiles);
     }
+    strip = !wide && (fl & 4) != 0;
     // (the wide form keeps its intrinsic columns and h_p right behind the pose columns IN USE: 11 poses are 83 columns - 6 column
     // tiles, 21 tiles of Z^T Z - where the full width has 36)
     if (wide) hcol = *npose_cols + 8 * kGroupIntr;
   }
   const bool compact = !wide && hcol == kCompactHCol;
   const int cs = wide ? kWideCols : kGroupCS;                          // doubles between the rows of the staged matrix
-  const int icol0 = wide ? hcol - 8 * kGroupIntr : 6 * kNarrowCams;    // its first intrinsic column
+  const int icol0 = wide ? hcol - 8 * kGroupIntr : strip ? kStripICol0 : 6 * kNarrowCams;    // its first intrinsic column
+  // the strip form's instructions: waves 0 / 1 carry three tiles, 2 / 3 two - the five strip instructions go 4 | - | 0, 1 | 2, 3
+  const int strip_s0 = wave == 0 ? 4 : wave == 2 ? 0 : wave == 3 ? 2 : -1, strip_n = !strip ? 0 : wave == 0 ? 1 : wave >= 2 ? 2 : 0;
+  double sacc[2] = {0.0, 0.0};
   const int wide_col_tiles = (hcol + 16) / 16;
   const int ncap = wide ? kGroupCams : kNarrowCams;                    // entries a point can have
   uint32_t nx_e0 = G.obs_start[g0], nx_ne = G.obs_start[g0 + 1] - nx_e0, nx_p0 = G.pt_start[g0], nx_np = G.pt_start[g0 + 1] - nx_p0;
@@ -1608,7 +1625,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       const int pq = slot_pq, c = slot_c;
 #pragma unroll
       for (int k = 0; k < kGroupIntr; ++k) {   // column 8 k + c behind the pose columns (compact: local intrinsic 0 only)
-        if (k == 0 || !compact) {
+        if (k == 0 || !(compact || strip)) {
           const int col = icol0 + 8 * k + c, r0 = 3 * pq;
 #pragma unroll
           for (int r = 0; r < 3; ++r) M[(r0 + r) * cs + (wide ? col ^ (((r0 + r) & 1) << 4) : col)] = zs[k][r];
@@ -1651,6 +1668,21 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
         acc[j] = a;
       }
     }
+    if (strip_n) {   // (wave-uniform) columns 64 .. 67 against the columns of this wave's strip instructions
+      const double* __restrict__ sa = M + lk * kGroupCS + kStripCol0 + (li & 3);
+      const double* __restrict__ sb = M + lk * kGroupCS + 16 * strip_s0 + li;
+      double s0 = sacc[0], s1 = sacc[1];
+      if (strip_n == 2) {
+        for (int k0 = 0; k0 < rows; k0 += 4) {
+          const double av = sa[k0 * kGroupCS];
+          s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, sb[k0 * kGroupCS], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, sb[k0 * kGroupCS + 16], s1, 0, 0, 0);
+        }
+      } else {
+        for (int k0 = 0; k0 < rows; k0 += 4) s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(sa[k0 * kGroupCS], sb[k0 * kGroupCS], s0, 0, 0, 0);
+      }
+      sacc[0] = s0; sacc[1] = s1;
+    }
     }
     MVGX_GSTAMP(6);
   }
@@ -1672,13 +1704,15 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     return;
   }
   double* const out = M;
-  if (compact) {   // (uniform) what the dropped tiles held: zero rows / columns of the intrinsic's blocks beyond kCompactIntr
+  if (compact || strip) {   // (uniform) what the dropped tiles / columns held: zero rows / columns of the intrinsic's blocks beyond its parameters
     for (int i = tid; i < kGroupPairsPI * kNVpi + kGroupPairsII * kNVii; i += NT) out[kGroupPairsPP * kNVpp + i] = 0.0;
     __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < kGroupTilesPerWave; ++j)
-    if (wave + j * kGroupWaves < n_tiles) group_store_tile(acc[j], tti[j], ttj[j], out, li, lk, hcol);
+    if (wave + j * kGroupWaves < n_tiles) group_store_tile(acc[j], tti[j], ttj[j], out, li, lk, icol0, hcol);
+  for (int q = 0; q < strip_n; ++q)   // lane (li, lk) of strip instruction s: the product of columns 16 s + li (row) and 64 + lk (column)
+    group_store_elem(16 * (strip_s0 + q) + li, kStripCol0 + lk, sacc[q], out, icol0, hcol);
   {
     const double gm = block_max(gmax, sums);   // (block_max synchronises: the tiles above are in LDS afterwards)
     if (tid == 0) G.gmax_part[sg] = gm;

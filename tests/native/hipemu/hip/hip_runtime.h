@@ -40,6 +40,7 @@ void site(int n);
 double shfl_f64(double v, int src_lane_of(int lane, int arg), int arg);
 typedef double d4 __attribute__((ext_vector_type(4)));
 d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int);
+double mfma_f64_4x4x4(double a, double b, double c, int, int, int);
 int readlane_i32(int v, int src_lane);
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
@@ -96,6 +97,7 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
   return c;
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu::mfma_f64_16x16x4
+#define __builtin_amdgcn_mfma_f64_4x4x4f64 hipemu::mfma_f64_4x4x4
 #define __builtin_amdgcn_readlane(v, l) hipemu::readlane_i32((v), (l))
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }

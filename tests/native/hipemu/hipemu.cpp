@@ -218,6 +218,21 @@ d4 mfma_f64_16x16x4(double a, double b, d4 c, int, int, int) {
   return out;
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products. Lane l feeds A_b[i = l & 3][k = l >> 4] and B_b[k = l >> 4][j = l & 3] of
+// block b = (l & 15) >> 2 and receives D_b[i = l >> 4][j = l & 3] of the same block - read off the device with tools/mfma_f64_4x4x4_probe.hip
+// (profiles/round6_mfma_f64_4x4x4_probe_call_r6_35.txt).
+double mfma_f64_4x4x4(double a, double b, double c, int, int, int) {
+  const int me = g_cur, w0 = me & ~63, lane = me & 63, par = g_parity[me];
+  g_parity[me] ^= 1;
+  g_slot[par][me] = a;
+  g_slot_b[par][me] = b;
+  wave_sync();
+  const int i = lane >> 4, blk = (lane & 15) >> 2, j = lane & 3;
+  double s = 0;
+  for (int k = 0; k < 4; ++k) s += g_slot[par][w0 + 16 * k + 4 * blk + i] * g_slot_b[par][w0 + 16 * k + 4 * blk + j];
+  return c + s;
+}
+
 // v_mfma_i32_32x32x32_i8 (gfx950): lane l feeds 16 bytes of A row i = l & 31 and of B column j = l & 31, covering
 // k = 16 (l >> 5) .. + 15; it receives D[i = 8 (r >> 2) + 4 (l >> 5) + (r & 3)][j = l & 31], r = 0..15
 // (MI355X_MICROARCH.md, 32x32 accumulator layout; the matching kernels were validated bit for bit on the device with it)

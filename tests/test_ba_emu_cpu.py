@@ -556,6 +556,8 @@ def test_multi_device_from_the_environment_only_for_large_problems(monkeypatch):
 
 @pytest.mark.parametrize("kw", [
     dict(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=2, seed=101),
+    dict(n_cams=12, n_points=300, track_len=6, model=3, n_intr_groups=1, seed=108),       # one radial-K3 intrinsic: the strip form (columns 64 .. 67 on the 4 x 4 x 4 MFMA)
+    dict(n_cams=14, n_points=260, track_len=10, model=2, n_intr_groups=1, seed=109),      # ... radial-K1 (four parameters), ten poses per point
     dict(n_cams=30, n_points=700, track_len=10, model=1, n_intr_groups=1, seed=102),      # ten poses per point: full groups
     dict(n_cams=16, n_points=200, track_len=12, model=1, n_intr_groups=1, seed=103),      # 11 .. 16 poses per point: the wide form of the groups (round 6)
     dict(n_cams=20, n_points=150, track_len=14, model=3, n_intr_groups=2, seed=106),      # ... with two local intrinsics
