@@ -36,7 +36,7 @@ int mvgx_device_count(int* count);
  * 3: mvgx_ba_get_solver_info; 4: multi-device contexts, mvgx_match_run_stream; 5: geometric filter; 6: indexed filter entry,
  * cascade hashing on the device; 7: homography model of the geometric filter; 8: iteration / clock counters in
  * mvgx_geofilter_stats, essential-matrix model of the geometric filter; 9: mvgx_host_parallel_for; 10: guided matching;
- * 11: mvgx_cascade_hash_regions_typed) */
+ * 11: mvgx_cascade_hash_regions_typed; 12: mvgx_guided_match for float and binary regions) */
 int mvgx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -576,7 +576,18 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
                          const uint32_t* pairs, const double* models /* 9 per pair, row-major */, const double* error_th /* per pair */,
                          uint64_t n_pairs, int kind, double dist_ratio_sq, uint64_t* match_start, uint32_t** matches_ij,
                          mvgx_guided_stats* stats /* may be NULL */);
-void mvgx_host_free(void* p);   /* releases an array the library allocated for the caller (mvgx_guided_match_u8) */
+/* The same for every region type the reference's functors can meet (ABI 12; Regions::SquaredDescriptorDistance is virtual,
+ * guided_matching.hpp:213): desc_type MVGX_DESC_U8 = mvgx_guided_match_u8; MVGX_DESC_F32 = float rows of 64 or 128 values (desc_bytes
+ * 256 / 512: AKAZE_Float_Regions, scalar_regions.hpp:107-116 + L2<float>, metric.hpp:95-131 - the reference's float sums in its order, no
+ * fused multiply-add, widened to double: equal lists, not a tolerance); MVGX_DESC_BINARY = rows of 32 or 64 bytes under the SQUARED
+ * Hamming distance (AKAZE_Binary_Regions, binary_regions.hpp:109-120). Everything else as above. */
+#define MVGX_DESC_U8 0
+#define MVGX_DESC_F32 1
+#define MVGX_DESC_BINARY 2
+int mvgx_guided_match(int device, const double* feat_xy, const void* desc, int desc_type, uint32_t desc_bytes, const uint64_t* feat_start,
+                      uint32_t n_images, const uint32_t* pairs, const double* models, const double* error_th, uint64_t n_pairs, int kind,
+                      double dist_ratio_sq, uint64_t* match_start, uint32_t** matches_ij, mvgx_guided_stats* stats /* may be NULL */);
+void mvgx_host_free(void* p);   /* releases an array the library allocated for the caller (mvgx_guided_match{,_u8}) */
 
 #ifdef __cplusplus
 }

@@ -220,6 +220,8 @@ PROTOTYPES = {
                                                             C.c_int, C.POINTER(GeofilterOptions), C.c_void_p, C.c_void_p, C.POINTER(GeofilterStats)]),
     "mvgx_guided_match_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GuidedStats)]),
+    "mvgx_guided_match": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_uint64, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GuidedStats)]),
     "mvgx_host_free": (None, [C.c_void_p]),
 }
 

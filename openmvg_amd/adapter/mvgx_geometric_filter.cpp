@@ -310,16 +310,26 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
   const bool guided_on_device = !(std::is_same<Functor, GeometricFilter_HMatrix_AC>::value && d_distance_ratio < 0);
   if constexpr (!M::angular && !kOrtho) {
     if (b_guided_matching && guided_on_device && n_dev_done > 0 && !my_progress_bar->hasBeenCanceled()) {
-      // the regions' descriptors, in the feature order of feat_start: uint8 scalar regions of one length only
+      // the regions' descriptors, in the feature order of feat_start: regions of ONE type and length - uint8 scalar rows (SIFT, LIOP:
+      // L2<uint8_t>), float scalar rows (AKAZE float: L2<float>) or binary rows (AKAZE binary: squared Hamming), the three metrics
+      // Regions::SquaredDescriptorDistance resolves to (scalar_regions.hpp:107-116, binary_regions.hpp:109-120; round 6)
       uint32_t desc_bytes = 0;
+      int desc_type = -1;
       bool usable = true;
       for (size_t v = 0; v < n_views && usable; ++v) {
         const std::shared_ptr<features::Regions> r = regions_provider_->get(slot_view[v]);
-        usable = r && r->IsScalar() && r->Type_id() == typeid(unsigned char).name() && (desc_bytes == 0 || r->DescriptorLength() == desc_bytes) &&
-                 r->RegionCount() == feat_start[v + 1] - feat_start[v];
-        if (usable) desc_bytes = (uint32_t)r->DescriptorLength();
+        usable = r && r->RegionCount() == feat_start[v + 1] - feat_start[v];
+        if (!usable) break;
+        const int t = r->IsBinary() ? MVGX_DESC_BINARY
+                      : r->IsScalar() && r->Type_id() == typeid(unsigned char).name() ? MVGX_DESC_U8
+                      : r->IsScalar() && r->Type_id() == typeid(float).name() ? MVGX_DESC_F32 : -1;
+        const uint32_t nb = (uint32_t)(r->DescriptorLength() * (t == MVGX_DESC_F32 ? sizeof(float) : 1));
+        usable = t >= 0 && (desc_type < 0 || (t == desc_type && nb == desc_bytes));
+        if (usable) { desc_type = t; desc_bytes = nb; }
       }
-      usable = usable && (desc_bytes == 64 || desc_bytes == 128 || desc_bytes == 144);
+      usable = usable && (desc_type == MVGX_DESC_U8 ? (desc_bytes == 64 || desc_bytes == 128 || desc_bytes == 144)
+                          : desc_type == MVGX_DESC_F32 ? (desc_bytes == 256 || desc_bytes == 512)
+                                                       : (desc_bytes == 32 || desc_bytes == 64));
       if (usable) {
         for (size_t k = 0; k < n_dev_done; ++k)
           if (res[k].ok) guided_pairs.push_back(k);
@@ -370,10 +380,10 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
           gb.start.assign(ng + 1, 0);
           const bool inj = mvgx_adapter::injected("geofilter", "guided");
           const int rc = inj ? MVGX_ERR_NODEV
-                             : mvgx_guided_match_u8(-1, feat_xy.data(), desc.data(), desc_bytes, feat_start.data(), (uint32_t)n_views, g_views.data(), g_model.data(),
-                                                    g_th.data(), (uint64_t)ng, std::is_same<Functor, GeometricFilter_HMatrix_AC>::value ? MVGX_GUIDED_HOMOGRAPHY
-                                                                                                                                       : MVGX_GUIDED_FUNDAMENTAL,
-                                                    Square(d_distance_ratio), gb.start.data(), &gb.ij, nullptr);
+                             : mvgx_guided_match(-1, feat_xy.data(), desc.data(), desc_type, desc_bytes, feat_start.data(), (uint32_t)n_views, g_views.data(),
+                                                 g_model.data(), g_th.data(), (uint64_t)ng,
+                                                 std::is_same<Functor, GeometricFilter_HMatrix_AC>::value ? MVGX_GUIDED_HOMOGRAPHY : MVGX_GUIDED_FUNDAMENTAL,
+                                                 Square(d_distance_ratio), gb.start.data(), &gb.ij, nullptr);
           if (rc == MVGX_OK) {
             for (size_t q = 0; q < ng; ++q) {
               guided_done[guided_pairs[q0 + q]] = 1;
@@ -382,7 +392,7 @@ void filter_container(const sfm::SfM_Data* sfm_data_, const std::shared_ptr<sfm:
             mvgx_adapter::counters().guided_device_pairs.fetch_add(ng);
           } else {
             // logged once; the pairs of this batch take the reference's own Geometry_guided_matching below (or the failure is thrown)
-            mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", "mvgx_guided_match_u8", rc, inj);
+            mvgx_adapter::device_failure(mvgx_adapter::kGeofilter, "geometric filter", "mvgx_guided_match", rc, inj);
           }
           q0 = q1;
         }

@@ -258,7 +258,7 @@ extern "C" {
 
 const char* mvgx_last_error(void) { return mvgx::last_error_ref().c_str(); }
 
-int mvgx_abi_version(void) { return 11; }
+int mvgx_abi_version(void) { return 12; }
 
 int mvgx_device_count(int* count) {
   if (!count) return MVGX_ERR_ARG;

@@ -13,6 +13,9 @@
 //   multiview/solver_fundamental_kernel.cpp:157-166    EpipolarDistanceError = (y~ . F x~)^2 / |(F x~)_xy|^2
 //   multiview/solver_homography_kernel.hpp:59-63       AsymmetricError = |y - hnormalized(H x~)|^2
 //   features/regions_factory.hpp (Scalar_Regions::SquaredDescriptorDistance) + matching/metric.hpp:55-93: L2<uint8_t>, exact int
+//   features/scalar_regions.hpp:107-116 + matching/metric.hpp:95-131: L2<float> (AKAZE_Float_Regions), float sums in groups of four -
+//                                                   result += ((d0 d0 + d1 d1) + d2 d2) + d3 d3, no fused multiply-add - widened to double
+//   features/binary_regions.hpp:109-120 + matching/metric_hamming.hpp: Hamming<unsigned char> SQUARED (AKAZE_Binary_Regions, 64 bytes)
 //
 // Device formulation: an O(nI nJ) predicate with a sparse descriptor stage - the brute-force matcher with a geometric mask. One lane
 // owns one left feature; the right features arrive through the scalar data path (wave-uniform position, norm and descriptor row), so
@@ -78,8 +81,15 @@ __global__ __launch_bounds__(256) void desc_norms_kernel(const uint32_t* __restr
 }
 
 // KIND 0: EpipolarDistanceError (model = F), 1: AsymmetricError (model = H)
-template <int KIND, int DW>
+// TYPE (round 6): 0 uint8 rows under L2<uint8_t> (int), 1 float rows under L2<float> (the reference's float sums, in its order), 2 binary rows
+// under the squared Hamming distance (int). distanceRatio<double> sees these values widened to double: comparing them in their own type is the
+// same comparison, and "no second best yet" (its numeric_limits<double>::max()) is INT_MAX / +infinity here - a value no distance takes
+// (a float distance that overflowed to +infinity fails `dist < max` in the reference as it fails `dist < infinity` here).
+template <int TYPE> struct GuidedDist { using type = int; static __device__ __forceinline__ int none() { return INT_MAX; } };
+template <> struct GuidedDist<1> { using type = float; static __device__ __forceinline__ float none() { return __builtin_inff(); } };
+template <int KIND, int DW, int TYPE = 0>
 __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) {
+  using dist_t = typename GuidedDist<TYPE>::type;
   const uint2 wk = P.work[blockIdx.x];
   const uint32_t p = wk.x;
   const uint32_t I = P.pairs[2 * p], J = P.pairs[2 * p + 1];
@@ -108,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
   // (this lane's descriptor row stays in memory: held in registers across the test loop - 32 of them - it halved the waves per SIMD, and
   // the test loop lives on occupancy; a drain step reads both rows 16 bytes at a time while the other waves run their tests)
   const uint4* __restrict__ lrow = reinterpret_cast<const uint4*>(P.desc + (fI + (active ? i : 0)) * DW);
-  const int na = P.norm[fI + (active ? i : 0)];
-  int bd = INT_MAX, sbd = INT_MAX;
+  const int na = TYPE == 0 ? P.norm[fI + (active ? i : 0)] : 0;
+  dist_t bd = GuidedDist<TYPE>::none(), sbd = GuidedDist<TYPE>::none();
   uint32_t idx = 0;
   unsigned long long n_pass = 0, n_stage = 0;
   const double2* __restrict__ xyJ = P.xy + fJ;
@@ -150,16 +160,38 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
       if (k < n_q) {
         const uint32_t j = q[64 * k];
         const uint4* __restrict__ rj = reinterpret_cast<const uint4*>(descJ + (size_t)j * DW);
-        unsigned dot = 0;
+        dist_t d;
+        if (TYPE == 0) {
+          unsigned dot = 0;
 #pragma unroll 2
-        for (int k4 = 0; k4 < DW / 4; ++k4) {
-          const uint4 l = lrow[k4], r = rj[k4];
-          dot = __builtin_amdgcn_udot4(l.x, r.x, dot, false);
-          dot = __builtin_amdgcn_udot4(l.y, r.y, dot, false);
-          dot = __builtin_amdgcn_udot4(l.z, r.z, dot, false);
-          dot = __builtin_amdgcn_udot4(l.w, r.w, dot, false);
+          for (int k4 = 0; k4 < DW / 4; ++k4) {
+            const uint4 l = lrow[k4], r = rj[k4];
+            dot = __builtin_amdgcn_udot4(l.x, r.x, dot, false);
+            dot = __builtin_amdgcn_udot4(l.y, r.y, dot, false);
+            dot = __builtin_amdgcn_udot4(l.z, r.z, dot, false);
+            dot = __builtin_amdgcn_udot4(l.w, r.w, dot, false);
+          }
+          d = (dist_t)(na + normJ[j] - 2 * (int)dot);
+        } else if (TYPE == 1) {   // metric.hpp:95-131: four differences, their squares summed left to right, added to the running float
+          float result = 0.f;
+#pragma unroll 2
+          for (int k4 = 0; k4 < DW / 4; ++k4) {
+            const uint4 l = lrow[k4], r = rj[k4];
+            const float d0 = __fsub_rn(__uint_as_float(l.x), __uint_as_float(r.x)), d1 = __fsub_rn(__uint_as_float(l.y), __uint_as_float(r.y));
+            const float d2 = __fsub_rn(__uint_as_float(l.z), __uint_as_float(r.z)), d3 = __fsub_rn(__uint_as_float(l.w), __uint_as_float(r.w));
+            const float g = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
+            result = __fadd_rn(result, g);
+          }
+          d = (dist_t)result;
+        } else {
+          int h = 0;
+#pragma unroll 2
+          for (int k4 = 0; k4 < DW / 4; ++k4) {
+            const uint4 l = lrow[k4], r = rj[k4];
+            h += __popc(l.x ^ r.x) + __popc(l.y ^ r.y) + __popc(l.z ^ r.z) + __popc(l.w ^ r.w);
+          }
+          d = (dist_t)(h * h);   // binary_regions.hpp:119: descDist * descDist
         }
-        const int d = na + normJ[j] - 2 * (int)dot;
         n_pass += 1;
         if (d < bd) { sbd = bd; bd = d; idx = j; }
         else if (d < sbd) sbd = d;
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void guided_match_kernel(GuidedParams P) 
     if (__ballot(n_q + 4 > (uint32_t)kQueue)) drain();
   }
   drain();
-  const bool valid = active && sbd != INT_MAX && (double)bd < P.ratio_sq * (double)sbd;
+  const bool valid = active && sbd != GuidedDist<TYPE>::none() && (double)bd < P.ratio_sq * (double)sbd;
   if (active) P.best[P.left_start[p] + i] = valid ? idx : kNone;
   const unsigned long long m = __ballot(valid);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&P.count[p], (unsigned)__popcll(m));
@@ -228,9 +260,9 @@ struct DevArray {
   int alloc(mvgx::Arena& a, size_t n) { return a.alloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
-template <int KIND, int DW>
+template <int KIND, int DW, int TYPE>
 void launch_match(const GuidedParams& P, uint32_t n_work, hipStream_t s) {
-  hipLaunchKernelGGL((guided_match_kernel<KIND, DW>), dim3(n_work), dim3(kThreads), 0, s, P);
+  hipLaunchKernelGGL((guided_match_kernel<KIND, DW, TYPE>), dim3(n_work), dim3(kThreads), 0, s, P);
 }
 
 }  // namespace
@@ -242,25 +274,37 @@ void mvgx_host_free(void* p) { free(p); }
 int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc, uint32_t desc_bytes, const uint64_t* feat_start, uint32_t n_images,
                          const uint32_t* pairs, const double* models, const double* error_th, uint64_t n_pairs, int kind, double dist_ratio_sq,
                          uint64_t* match_start, uint32_t** matches_ij, mvgx_guided_stats* stats) {
+  return mvgx_guided_match(device, feat_xy, desc, MVGX_DESC_U8, desc_bytes, feat_start, n_images, pairs, models, error_th, n_pairs, kind, dist_ratio_sq,
+                           match_start, matches_ij, stats);
+}
+
+int mvgx_guided_match(int device, const double* feat_xy, const void* desc, int desc_type, uint32_t desc_bytes, const uint64_t* feat_start, uint32_t n_images,
+                      const uint32_t* pairs, const double* models, const double* error_th, uint64_t n_pairs, int kind, double dist_ratio_sq,
+                      uint64_t* match_start, uint32_t** matches_ij, mvgx_guided_stats* stats) {
   const auto t_enter = std::chrono::steady_clock::now();
-  MVGX_REQUIRE(feat_start && match_start && matches_ij && (n_pairs == 0 || (pairs && models && error_th)), MVGX_ERR_ARG, "mvgx_guided_match_u8: NULL argument");
-  MVGX_REQUIRE(kind == MVGX_GUIDED_FUNDAMENTAL || kind == MVGX_GUIDED_HOMOGRAPHY, MVGX_ERR_ARG, "mvgx_guided_match_u8: kind must be 0 (fundamental) or 1 (homography)");
-  MVGX_REQUIRE(desc_bytes == 64 || desc_bytes == 128 || desc_bytes == 144, MVGX_ERR_UNSUPPORTED,
-               "mvgx_guided_match_u8: descriptors of %u bytes (64, 128 and 144 are built)", desc_bytes);
-  MVGX_REQUIRE(dist_ratio_sq >= 0.0 && std::isfinite(dist_ratio_sq), MVGX_ERR_ARG, "mvgx_guided_match_u8: distance ratio");
+  MVGX_REQUIRE(feat_start && match_start && matches_ij && (n_pairs == 0 || (pairs && models && error_th)), MVGX_ERR_ARG, "mvgx_guided_match: NULL argument");
+  MVGX_REQUIRE(kind == MVGX_GUIDED_FUNDAMENTAL || kind == MVGX_GUIDED_HOMOGRAPHY, MVGX_ERR_ARG, "mvgx_guided_match: kind must be 0 (fundamental) or 1 (homography)");
+  MVGX_REQUIRE(desc_type == MVGX_DESC_U8 || desc_type == MVGX_DESC_F32 || desc_type == MVGX_DESC_BINARY, MVGX_ERR_ARG, "mvgx_guided_match: descriptor type %d", desc_type);
+  MVGX_REQUIRE(desc_type != MVGX_DESC_U8 || desc_bytes == 64 || desc_bytes == 128 || desc_bytes == 144, MVGX_ERR_UNSUPPORTED,
+               "mvgx_guided_match: uint8 descriptors of %u bytes (64, 128 and 144 are built)", desc_bytes);
+  MVGX_REQUIRE(desc_type != MVGX_DESC_F32 || desc_bytes == 256 || desc_bytes == 512, MVGX_ERR_UNSUPPORTED,
+               "mvgx_guided_match: float descriptors of %u bytes (64 and 128 floats are built)", desc_bytes);
+  MVGX_REQUIRE(desc_type != MVGX_DESC_BINARY || desc_bytes == 32 || desc_bytes == 64, MVGX_ERR_UNSUPPORTED,
+               "mvgx_guided_match: binary descriptors of %u bytes (32 and 64 are built)", desc_bytes);
+  MVGX_REQUIRE(dist_ratio_sq >= 0.0 && std::isfinite(dist_ratio_sq), MVGX_ERR_ARG, "mvgx_guided_match: distance ratio");
   *matches_ij = nullptr;
   const uint64_t n_feat = n_images ? feat_start[n_images] : 0;
-  for (uint32_t k = 0; k < n_images; ++k) MVGX_REQUIRE(feat_start[k] <= feat_start[k + 1], MVGX_ERR_ARG, "mvgx_guided_match_u8: feat_start must ascend");
-  MVGX_REQUIRE(n_feat == 0 || (feat_xy && desc), MVGX_ERR_ARG, "mvgx_guided_match_u8: NULL feature arrays");
+  for (uint32_t k = 0; k < n_images; ++k) MVGX_REQUIRE(feat_start[k] <= feat_start[k + 1], MVGX_ERR_ARG, "mvgx_guided_match: feat_start must ascend");
+  MVGX_REQUIRE(n_feat == 0 || (feat_xy && desc), MVGX_ERR_ARG, "mvgx_guided_match: NULL feature arrays");
   // work list; a pair whose bound is not finite gives no match (the functors test m_dPrecision_robust != infinity), neither does an empty image
   std::vector<uint64_t> left_start(n_pairs + 1, 0);
   std::vector<uint2> work;
   for (uint64_t p = 0; p < n_pairs; ++p) {
     const uint32_t I = pairs[2 * p], J = pairs[2 * p + 1];
-    MVGX_REQUIRE(I < n_images && J < n_images, MVGX_ERR_ARG, "mvgx_guided_match_u8: pair %llu names image %u / %u of %u", (unsigned long long)p, I, J, n_images);
-    MVGX_REQUIRE(p < (uint64_t)UINT32_MAX, MVGX_ERR_ARG, "mvgx_guided_match_u8: more than 2^32 pairs in one call");
+    MVGX_REQUIRE(I < n_images && J < n_images, MVGX_ERR_ARG, "mvgx_guided_match: pair %llu names image %u / %u of %u", (unsigned long long)p, I, J, n_images);
+    MVGX_REQUIRE(p < (uint64_t)UINT32_MAX, MVGX_ERR_ARG, "mvgx_guided_match: more than 2^32 pairs in one call");
     const uint64_t nI = feat_start[I + 1] - feat_start[I], nJ = feat_start[J + 1] - feat_start[J];
-    MVGX_REQUIRE(nI < (1ull << 31) && nJ < (1ull << 31), MVGX_ERR_ARG, "mvgx_guided_match_u8: image with 2^31 or more features");
+    MVGX_REQUIRE(nI < (1ull << 31) && nJ < (1ull << 31), MVGX_ERR_ARG, "mvgx_guided_match: image with 2^31 or more features");
     left_start[p + 1] = left_start[p] + nI;
     if (!(error_th[p] > 0.0) || !std::isfinite(error_th[p]) || nI == 0 || nJ == 0) continue;
     for (uint64_t i0 = 0; i0 < nI; i0 += kThreads) work.push_back(make_uint2((uint32_t)p, (uint32_t)i0));
@@ -289,7 +333,7 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
     return rc;
   if (n_feat) {
     MVGX_HIP(hipMemcpyAsync(d_xy.p, feat_xy, n_feat * sizeof(double2), hipMemcpyHostToDevice, stream));
-    MVGX_HIP(hipMemcpyAsync(d_desc.p, desc, n_feat * desc_bytes, hipMemcpyHostToDevice, stream));
+    MVGX_HIP(hipMemcpyAsync(d_desc.p, desc, n_feat * (size_t)desc_bytes, hipMemcpyHostToDevice, stream));
   }
   MVGX_HIP(hipMemcpyAsync(d_fs.p, feat_start, (n_images + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
   MVGX_HIP(hipMemcpyAsync(d_ls.p, left_start.data(), (n_pairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -305,7 +349,7 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   MVGX_HIP(hipEventCreate(&e1));
   struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eguard{e0, e1};
   MVGX_HIP(hipEventRecord(e0, stream));
-  if (n_feat) {
+  if (n_feat && desc_type == MVGX_DESC_U8) {
     const unsigned nb = (unsigned)((n_feat + 255) / 256);
     const uint32_t* const pd = d_desc.p;
     int* const pn = d_norm.p;
@@ -318,8 +362,10 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   P.work = d_work.p; P.left_start = d_ls.p; P.best = d_best.p; P.count = d_count.p; P.counters = stats ? d_ctr.p : nullptr; P.ratio_sq = dist_ratio_sq;
   if (!work.empty()) {
     const uint32_t nw = (uint32_t)work.size();
-#define MVGX_GUIDED_CASE(K, D) if (kind == K && DW == D) launch_match<K, D>(P, nw, stream);
-    MVGX_GUIDED_CASE(0, 16) MVGX_GUIDED_CASE(0, 32) MVGX_GUIDED_CASE(0, 36) MVGX_GUIDED_CASE(1, 16) MVGX_GUIDED_CASE(1, 32) MVGX_GUIDED_CASE(1, 36)
+#define MVGX_GUIDED_CASE(K, D, TY) if (kind == K && DW == D && desc_type == TY) launch_match<K, D, TY>(P, nw, stream);
+    MVGX_GUIDED_CASE(0, 16, 0) MVGX_GUIDED_CASE(0, 32, 0) MVGX_GUIDED_CASE(0, 36, 0) MVGX_GUIDED_CASE(1, 16, 0) MVGX_GUIDED_CASE(1, 32, 0) MVGX_GUIDED_CASE(1, 36, 0)
+    MVGX_GUIDED_CASE(0, 64, 1) MVGX_GUIDED_CASE(0, 128, 1) MVGX_GUIDED_CASE(1, 64, 1) MVGX_GUIDED_CASE(1, 128, 1)
+    MVGX_GUIDED_CASE(0, 8, 2) MVGX_GUIDED_CASE(0, 16, 2) MVGX_GUIDED_CASE(1, 8, 2) MVGX_GUIDED_CASE(1, 16, 2)
 #undef MVGX_GUIDED_CASE
     MVGX_HIP(hipGetLastError());
   }
@@ -330,7 +376,7 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
   for (uint64_t p = 0; p < n_pairs; ++p) match_start[p + 1] = match_start[p] + count[p];
   const uint64_t total = match_start[n_pairs];
   uint32_t* out = static_cast<uint32_t*>(malloc(std::max<uint64_t>(total, 1) * 2 * sizeof(uint32_t)));
-  MVGX_REQUIRE(out, MVGX_ERR_HIP, "mvgx_guided_match_u8: out of host memory (%llu matches)", (unsigned long long)total);
+  MVGX_REQUIRE(out, MVGX_ERR_HIP, "mvgx_guided_match: out of host memory (%llu matches)", (unsigned long long)total);
   if (total) {
     if ((rc = d_ij.alloc(arena, 2 * total))) { free(out); return rc; }
     hipError_t e = hipMemcpyAsync(d_ms.p, match_start, (n_pairs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
@@ -351,7 +397,7 @@ int mvgx_guided_match_u8(int device, const double* feat_xy, const uint8_t* desc,
     if (e == hipSuccess && pinned) std::memcpy(out, pinned, 2 * total * sizeof(uint32_t));
     if (e != hipSuccess) {   // (drained before the page-locked staging block goes back to the cache: a copy into it may still be in flight)
       (void)hipStreamSynchronize(stream);
-      free(out); set_error("mvgx_guided_match_u8: %s", hipGetErrorString(e)); return MVGX_ERR_HIP;
+      free(out); set_error("mvgx_guided_match: %s", hipGetErrorString(e)); return MVGX_ERR_HIP;
     }
   }
   *matches_ij = out;

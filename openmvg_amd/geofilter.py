@@ -250,13 +250,16 @@ def Robust_model_estimation(putative_matches, feats_xy, image_sizes, functor=Non
 # Guided matching: robust_estimation/guided_matching.hpp:178-227 through {F,H,E}_ACRobust.hpp's Geometry_guided_matching
 # ---------------------------------------------------------------------------------------------------------------------------------
 GUIDED_FUNDAMENTAL, GUIDED_HOMOGRAPHY = 0, 1
+DESC_U8, DESC_F32, DESC_BINARY = 0, 1, 2
 
 
-def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRatio=0.6, kind=GUIDED_FUNDAMENTAL, device=-1):
-    """The functors' second stage for a list of image pairs on the device (mvgx_guided_match_u8).
+def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRatio=0.6, kind=GUIDED_FUNDAMENTAL, device=-1, desc_type=None):
+    """The functors' second stage for a list of image pairs on the device (mvgx_guided_match).
 
     feat_xy: per image an (n, 2) array of the positions the reference compares (cam->get_ud_pixel(position), or the position itself);
-    descs: per image an (n, 64 | 128 | 144) uint8 array; pairs: (P, 2) image indices; models: (P, 3, 3) - m_F (for the essential
+    descs: per image an (n, 64 | 128 | 144) uint8 array (SIFT / LIOP: L2<uint8_t>), an (n, 64 | 128) float32 array (AKAZE float: L2<float>)
+    or, with desc_type=DESC_BINARY, an (n, 32 | 64) uint8 array of bit rows (AKAZE binary: squared Hamming distance); desc_type None:
+    by dtype (float32 -> DESC_F32, else DESC_U8); pairs: (P, 2) image indices; models: (P, 3, 3) - m_F (for the essential
     functor F = K2^-T E K1^-1) or m_H; precision_robust: (P,) m_dPrecision_robust in pixels (infinity: no guided matching for that
     pair, as the reference). The reference passes Square(m_dPrecision_robust) and Square(dDistanceRatio): so does this function.
     Returns ({(I, J): (m, 2) uint32 array of (i, j)} for the pairs with at least one match, stats)."""
@@ -270,8 +273,12 @@ def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRa
     nb = {int(np.asarray(d).shape[1]) for d in descs if len(d)} or {128}
     if len(nb) != 1:
         raise ValueError("guided_matching: descriptors of different lengths")
-    desc_bytes = nb.pop()
-    dd = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, desc_bytes) for d in descs]) if n_images else np.zeros((0, desc_bytes), np.uint8))
+    desc_len = nb.pop()
+    if desc_type is None:
+        desc_type = DESC_F32 if any(np.asarray(d).dtype == np.float32 for d in descs if len(d)) else DESC_U8
+    dt = np.float32 if desc_type == DESC_F32 else np.uint8
+    desc_bytes = desc_len * np.dtype(dt).itemsize
+    dd = np.ascontiguousarray(np.concatenate([np.asarray(d, dt).reshape(-1, desc_len) for d in descs]) if n_images else np.zeros((0, desc_len), dt))
     pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
     models = np.ascontiguousarray(models, np.float64).reshape(-1, 9)
     prec = np.asarray(precision_robust, np.float64).reshape(-1)
@@ -283,8 +290,8 @@ def guided_matching(feat_xy, descs, pairs, models, precision_robust, dDistanceRa
     ms = np.zeros(len(pairs) + 1, np.uint64)
     out = C.c_void_p()
     st = _capi.GuidedStats()
-    _capi.check(_capi.lib().mvgx_guided_match_u8(device, xy.ctypes.data, dd.ctypes.data, desc_bytes, start.ctypes.data, n_images, pairs.ctypes.data,
-                                                 models.ctypes.data, th.ctypes.data, len(pairs), int(kind), ratio_sq, ms.ctypes.data, C.byref(out), C.byref(st)))
+    _capi.check(_capi.lib().mvgx_guided_match(device, xy.ctypes.data, dd.ctypes.data, int(desc_type), desc_bytes, start.ctypes.data, n_images, pairs.ctypes.data,
+                                              models.ctypes.data, th.ctypes.data, len(pairs), int(kind), ratio_sq, ms.ctypes.data, C.byref(out), C.byref(st)))
     try:
         total = int(ms[-1])
         if total and out:   # (no pair / no match: the library hands back NULL - as_array on it raises)

@@ -740,3 +740,58 @@ extern "C" uint64_t port_guided_match(int kind, const double* M, const double* x
   }
   return n_out;
 }
+
+// The same for the other region types (round 6): desc_type 0 = uint8 rows (L2<uint8_t>), 1 = float rows (L2<float>, metric.hpp:95-131:
+// float sums in groups of four, result += ((d0 d0 + d1 d1) + d2 d2) + d3 d3; this file is compiled with -ffp-contract=off), 2 = bit rows under
+// the SQUARED Hamming distance (binary_regions.hpp:109-120). desc_len: elements per row (bytes for types 0 and 2, floats for type 1).
+extern "C" uint64_t port_guided_match_typed(int kind, int desc_type, const double* M, const double* xyI, const void* descI_, uint64_t nI, const double* xyJ,
+                                             const void* descJ_, uint64_t nJ, uint32_t desc_len, double error_th, double dist_ratio, uint32_t* out_ij) {
+  uint64_t n_out = 0;
+  if (!(error_th < std::numeric_limits<double>::infinity())) return 0;
+  const uint8_t* bI = static_cast<const uint8_t*>(descI_); const uint8_t* bJ = static_cast<const uint8_t*>(descJ_);
+  const float* fI = static_cast<const float*>(descI_); const float* fJ = static_cast<const float*>(descJ_);
+  for (uint64_t i = 0; i < nI; ++i) {
+    const double x0 = xyI[2 * i], x1 = xyI[2 * i + 1];
+    const double v0 = (M[0] * x0 + M[1] * x1) + M[2], v1 = (M[3] * x0 + M[4] * x1) + M[5], v2 = (M[6] * x0 + M[7] * x1) + M[8];
+    double bd = std::numeric_limits<double>::max(), sbd = bd;
+    uint64_t idx = 0;
+    for (uint64_t j = 0; j < nJ; ++j) {
+      const double y0 = xyJ[2 * j], y1 = xyJ[2 * j + 1];
+      double err;
+      if (kind == 0) {
+        const double dt = v0 * y0 + (v1 * y1 + v2);
+        err = (dt * dt) / (v0 * v0 + v1 * v1);
+      } else {
+        const double dx = y0 - v0 / v2, dy = y1 - v1 / v2;
+        err = dx * dx + dy * dy;
+      }
+      if (!(err < error_th)) continue;
+      double dist;
+      if (desc_type == 0) {
+        int d = 0;
+        for (uint32_t k = 0; k < desc_len; ++k) { const int t = (int)bI[i * desc_len + k] - (int)bJ[j * desc_len + k]; d += t * t; }
+        dist = (double)d;
+      } else if (desc_type == 1) {
+        const float* a = fI + i * desc_len; const float* b = fJ + j * desc_len;
+        volatile float result = 0.f;
+        uint32_t k = 0;
+        for (; k + 3 < desc_len; k += 4) {
+          const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2], d3 = a[k + 3] - b[k + 3];
+          volatile float g = d0 * d0;
+          g = g + d1 * d1; g = g + d2 * d2; g = g + d3 * d3;
+          result = result + g;
+        }
+        for (; k < desc_len; ++k) { const float d0 = a[k] - b[k]; result = result + d0 * d0; }
+        dist = (double)result;
+      } else {
+        unsigned h = 0;
+        for (uint32_t k = 0; k < desc_len; ++k) h += (unsigned)__builtin_popcount((unsigned)(bI[i * desc_len + k] ^ bJ[j * desc_len + k]));
+        dist = (double)(h * h);
+      }
+      if (dist < bd) { idx = j; sbd = bd; bd = dist; }
+      else if (dist < sbd) sbd = dist;
+    }
+    if (sbd != std::numeric_limits<double>::max() && bd < dist_ratio * sbd) { out_ij[2 * n_out] = (uint32_t)i; out_ij[2 * n_out + 1] = (uint32_t)idx; ++n_out; }
+  }
+  return n_out;
+}

@@ -258,6 +258,26 @@ struct InMemoryRegionsProvider : public sfm::Regions_Provider {
 
 extern "C" typedef void (*geo_sink)(void* user, uint32_t I, uint32_t J, const uint32_t* ij, uint32_t n);
 
+// the region type the container entries below build: 0 SIFT_Regions (128 bytes per feature, the default), 1 AKAZE_Float_Regions (64 floats),
+// 2 AKAZE_Binary_Regions (64 bytes) - `descs` is read with that row size
+static int g_container_region_type = 0;
+extern "C" void ref_geofilter_container_region_type(int t) { g_container_region_type = t; }
+namespace {
+template <class RegionsT>
+std::shared_ptr<features::Regions> make_regions(const float* feat_xy, const uint8_t* descs, uint64_t lo, uint64_t n) {
+  auto r = std::make_shared<RegionsT>();
+  r->Features().resize(n);
+  r->Descriptors().resize(n);
+  constexpr size_t kRowBytes = sizeof(typename RegionsT::DescriptorT);
+  for (uint64_t i = 0; i < n; ++i) {
+    r->Features()[i] = features::SIOPointFeature(feat_xy[2 * (lo + i)], feat_xy[2 * (lo + i) + 1], 1.f, 0.f);
+    if (descs) std::memcpy(r->Descriptors()[i].data(), descs + (lo + i) * kRowBytes, kRowBytes);
+    else std::memset(r->Descriptors()[i].data(), 0, kRowBytes);
+  }
+  return r;
+}
+}  // namespace
+
 // images: feat_xy (2 floats per feature, image k owning [feat_start[k], feat_start[k + 1])), descs (128 bytes per feature or NULL),
 // image_wh (w, h per image); k1 != 0: all views share one Pinhole_Intrinsic_Radial_K1 (the positions are then undistorted by
 // MatchesPairToMat). putative matches: pairs_IJ, match_start, matches_ij (feature indices). The geometric matches are handed to
@@ -269,7 +289,9 @@ static uint64_t container_impl(const float* feat_xy, const uint8_t* descs, const
                                double pinhole_focal = 0.0) {
   sfm::SfM_Data scene;
   auto provider = std::make_shared<InMemoryRegionsProvider>();
-  provider->set_type(new features::SIFT_Regions());
+  if (g_container_region_type == 1) provider->set_type(new features::AKAZE_Float_Regions());
+  else if (g_container_region_type == 2) provider->set_type(new features::AKAZE_Binary_Regions());
+  else provider->set_type(new features::SIFT_Regions());
   for (uint32_t k = 0; k < n_images; ++k) {
     // pinhole_focal > 0: every view has its own Pinhole_Intrinsic (focal given, principal point at the centre) - except the LAST view, which
     // keeps no intrinsic, so that the essential functor's "no intrinsic information" branch is exercised by its pairs
@@ -277,16 +299,10 @@ static uint64_t container_impl(const float* feat_xy, const uint8_t* descs, const
     scene.views[k] = std::make_shared<sfm::View>("", k, k1 != 0.0 ? 0 : own_pinhole ? k : UndefinedIndexT, UndefinedIndexT, image_wh[2 * k], image_wh[2 * k + 1]);
     if (own_pinhole)
       scene.intrinsics[k] = std::make_shared<cameras::Pinhole_Intrinsic>(image_wh[2 * k], image_wh[2 * k + 1], pinhole_focal, image_wh[2 * k] / 2.0, image_wh[2 * k + 1] / 2.0);
-    auto r = std::make_shared<features::SIFT_Regions>();
     const uint64_t lo = feat_start[k], n = feat_start[k + 1] - lo;
-    r->Features().resize(n);
-    r->Descriptors().resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
-      r->Features()[i] = features::SIOPointFeature(feat_xy[2 * (lo + i)], feat_xy[2 * (lo + i) + 1], 1.f, 0.f);
-      if (descs) std::memcpy(r->Descriptors()[i].data(), descs + (lo + i) * 128, 128);
-      else std::memset(r->Descriptors()[i].data(), 0, 128);
-    }
-    provider->set(k, r);
+    provider->set(k, g_container_region_type == 1   ? make_regions<features::AKAZE_Float_Regions>(feat_xy, descs, lo, n)
+                     : g_container_region_type == 2 ? make_regions<features::AKAZE_Binary_Regions>(feat_xy, descs, lo, n)
+                                                    : make_regions<features::SIFT_Regions>(feat_xy, descs, lo, n));
   }
   if (k1 != 0.0)
     scene.intrinsics[0] = std::make_shared<cameras::Pinhole_Intrinsic_Radial_K1>(image_wh[0], image_wh[1], 0.9 * image_wh[0], image_wh[0] / 2.0, image_wh[1] / 2.0, k1);
@@ -378,4 +394,43 @@ extern "C" uint64_t ref_guided_match(int kind, const double* M, const float* xyI
     geometry_aware::GuidedMatching<Mat3, openMVG::homography::kernel::AsymmetricError>(mod, nullptr, *rI, nullptr, *rJ, error_th, dist_ratio, out);
   for (size_t k = 0; k < out.size(); ++k) { out_ij[2 * k] = out[k].i_; out_ij[2 * k + 1] = out[k].j_; }
   return out.size();
+}
+
+// ... and on the other region types the functors can meet (round 6): desc_type 1 = AKAZE_Float_Regions (64 floats per row), 2 =
+// AKAZE_Binary_Regions (64 bytes per row) - the regions' own virtual SquaredDescriptorDistance decides the metric (guided_matching.hpp:213).
+template <class RegionsT, class ElemT>
+static uint64_t ref_guided_match_on(int kind, const double* M, const float* xyI, const ElemT* descI, uint64_t nI, const float* xyJ, const ElemT* descJ, uint64_t nJ,
+                                    double error_th, double dist_ratio, uint32_t* out_ij) {
+  auto make = [](const float* xy, const ElemT* d, uint64_t n) {
+    auto r = std::make_shared<RegionsT>();
+    r->Features().resize(n);
+    r->Descriptors().resize(n);
+    constexpr size_t L = RegionsT::DescriptorT::static_size;
+    for (uint64_t i = 0; i < n; ++i) {
+      r->Features()[i] = features::SIOPointFeature(xy[2 * i], xy[2 * i + 1], 1.f, 0.f);
+      std::memcpy(r->Descriptors()[i].data(), d + i * L, L * sizeof(ElemT));
+    }
+    return r;
+  };
+  const auto rI = make(xyI, descI, nI), rJ = make(xyJ, descJ, nJ);
+  Mat3 mod;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mod(r, c) = M[3 * r + c];
+  matching::IndMatches out;
+  if (kind == 0)
+    geometry_aware::GuidedMatching<Mat3, openMVG::fundamental::kernel::EpipolarDistanceError>(mod, nullptr, *rI, nullptr, *rJ, error_th, dist_ratio, out);
+  else
+    geometry_aware::GuidedMatching<Mat3, openMVG::homography::kernel::AsymmetricError>(mod, nullptr, *rI, nullptr, *rJ, error_th, dist_ratio, out);
+  for (size_t k = 0; k < out.size(); ++k) { out_ij[2 * k] = out[k].i_; out_ij[2 * k + 1] = out[k].j_; }
+  return out.size();
+}
+extern "C" uint64_t ref_guided_match_typed(int kind, int desc_type, const double* M, const float* xyI, const void* descI, uint64_t nI, const float* xyJ,
+                                           const void* descJ, uint64_t nJ, double error_th, double dist_ratio, uint32_t* out_ij) {
+  if (desc_type == 1)
+    return ref_guided_match_on<features::AKAZE_Float_Regions, float>(kind, M, xyI, static_cast<const float*>(descI), nI, xyJ, static_cast<const float*>(descJ), nJ,
+                                                                     error_th, dist_ratio, out_ij);
+  if (desc_type == 2)
+    return ref_guided_match_on<features::AKAZE_Binary_Regions, unsigned char>(kind, M, xyI, static_cast<const unsigned char*>(descI), nI, xyJ,
+                                                                              static_cast<const unsigned char*>(descJ), nJ, error_th, dist_ratio, out_ij);
+  return ref_guided_match_on<features::SIFT_Regions, unsigned char>(kind, M, xyI, static_cast<const unsigned char*>(descI), nI, xyJ,
+                                                                    static_cast<const unsigned char*>(descJ), nJ, error_th, dist_ratio, out_ij);
 }

@@ -945,9 +945,13 @@ def geofilter_container_lib(kind):
     return lib
 
 
-def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None, model="f", focal=0.0):
-    """feats_xy: list of (n_k, 2) float32 positions; image_wh: (n_images, 2); putative: {(I, J): (n, 2) uint32}. -> {(I, J): (m, 2)}"""
+def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_iterations=2048, guided=False, ratio=0.6, k1=0.0, descs=None, model="f", focal=0.0,
+                        desc_type=0):
+    """feats_xy: list of (n_k, 2) float32 positions; image_wh: (n_images, 2); putative: {(I, J): (n, 2) uint32}. -> {(I, J): (m, 2)}
+    desc_type: the regions the caller code builds - 0 SIFT_Regions (descs: 128 bytes per feature), 1 AKAZE_Float_Regions (64 float32),
+    2 AKAZE_Binary_Regions (64 bytes)"""
     lib = geofilter_container_lib(kind)
+    lib.ref_geofilter_container_region_type(C.c_int(desc_type))
     fx = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float32).reshape(-1, 2) for f in feats_xy]), np.float32)
     fstart = np.cumsum([0] + [len(f) for f in feats_xy]).astype(np.uint64)
     wh = np.ascontiguousarray(image_wh, np.uint32).reshape(-1, 2)
@@ -955,7 +959,8 @@ def geofilter_container(kind, feats_xy, image_wh, putative, precision=4.0, max_i
     pij = np.ascontiguousarray(np.asarray(keys, np.uint32).reshape(-1, 2))
     mstart = np.cumsum([0] + [len(putative[k]) for k in keys]).astype(np.uint64)
     mij = np.ascontiguousarray(np.concatenate([np.asarray(putative[k], np.uint32).reshape(-1, 2) for k in keys]) if keys else np.zeros((0, 2), np.uint32))
-    dd = None if descs is None else np.ascontiguousarray(np.concatenate(descs), np.uint8)
+    dd = None if descs is None else np.ascontiguousarray(np.concatenate(descs), np.float32 if desc_type == 1 else np.uint8)
+    assert dd is None or dd.shape[1] == (128 if desc_type == 0 else 64)
     out = {}
 
     def sink(_u, I, J, p, n):
@@ -1000,6 +1005,47 @@ def port_guided_match(kind, M, xyI, descI, xyJ, descJ, error_th, dist_ratio):
     n = L.port_guided_match(C.c_int(kind), M.ctypes.data_as(C.c_void_p), xyI.ctypes.data_as(C.c_void_p), descI.ctypes.data_as(C.c_void_p), C.c_uint64(len(xyI)),
                             xyJ.ctypes.data_as(C.c_void_p), descJ.ctypes.data_as(C.c_void_p), C.c_uint64(len(xyJ)), C.c_uint32(nb), C.c_double(error_th),
                             C.c_double(dist_ratio), out.ctypes.data_as(C.c_void_p))
+    return out[:int(n)].copy()
+
+
+def _typed_desc(desc, desc_type):
+    """(rows as the C side reads them, elements per row) for desc_type 0 uint8 / 1 float32 / 2 bit rows"""
+    a = np.ascontiguousarray(desc, np.float32 if desc_type == 1 else np.uint8)
+    return a, (a.shape[1] if a.ndim == 2 else 0)
+
+
+def port_guided_match_typed(kind, desc_type, M, xyI, descI, xyJ, descJ, error_th, dist_ratio):
+    """oracle/geofilter_oracle.cpp::port_guided_match_typed (desc_type 0 uint8 L2, 1 float L2, 2 squared Hamming) -> (m, 2) uint32"""
+    L = port()
+    xyI = np.ascontiguousarray(xyI, np.float64).reshape(-1, 2); xyJ = np.ascontiguousarray(xyJ, np.float64).reshape(-1, 2)
+    dI, nI_ = _typed_desc(descI, desc_type); dJ, nJ_ = _typed_desc(descJ, desc_type)
+    n_el = nI_ or nJ_ or 64
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((max(len(xyI), 1), 2), np.uint32)
+    L.port_guided_match_typed.restype = C.c_uint64
+    n = L.port_guided_match_typed(C.c_int(kind), C.c_int(desc_type), M.ctypes.data_as(C.c_void_p), xyI.ctypes.data_as(C.c_void_p), dI.ctypes.data_as(C.c_void_p),
+                                  C.c_uint64(len(xyI)), xyJ.ctypes.data_as(C.c_void_p), dJ.ctypes.data_as(C.c_void_p), C.c_uint64(len(xyJ)), C.c_uint32(n_el),
+                                  C.c_double(error_th), C.c_double(dist_ratio), out.ctypes.data_as(C.c_void_p))
+    return out[:int(n)].copy()
+
+
+def ref_guided_match_typed(kind, desc_type, M, xyI, descI, xyJ, descJ, error_th, dist_ratio):
+    """the reference's GuidedMatching template on AKAZE_Float_Regions (desc_type 1: 64 floats per row) / AKAZE_Binary_Regions (2: 64 bytes)
+    / SIFT_Regions (0) built from the arrays -> (m, 2) uint32"""
+    global _refgeo
+    if _refgeo is None:
+        _refgeo = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_geofilter.so"))
+    xI = np.ascontiguousarray(xyI, np.float32).reshape(-1, 2); xJ = np.ascontiguousarray(xyJ, np.float32).reshape(-1, 2)
+    assert np.array_equal(xI.astype(np.float64), np.asarray(xyI, np.float64).reshape(-1, 2)) and np.array_equal(xJ.astype(np.float64), np.asarray(xyJ, np.float64).reshape(-1, 2))
+    dI, _ = _typed_desc(descI, desc_type); dJ, _ = _typed_desc(descJ, desc_type)
+    want_len = {0: 128, 1: 64, 2: 64}[desc_type]
+    assert (not len(dI) or dI.shape[1] == want_len) and (not len(dJ) or dJ.shape[1] == want_len)
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((max(len(xI), 1), 2), np.uint32)
+    _refgeo.ref_guided_match_typed.restype = C.c_uint64
+    n = _refgeo.ref_guided_match_typed(C.c_int(kind), C.c_int(desc_type), M.ctypes.data_as(C.c_void_p), xI.ctypes.data_as(C.c_void_p), dI.ctypes.data_as(C.c_void_p),
+                                       C.c_uint64(len(xI)), xJ.ctypes.data_as(C.c_void_p), dJ.ctypes.data_as(C.c_void_p), C.c_uint64(len(xJ)), C.c_double(error_th),
+                                       C.c_double(dist_ratio), out.ctypes.data_as(C.c_void_p))
     return out[:int(n)].copy()
 
 

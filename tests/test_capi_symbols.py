@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
 
 def test_library_loads_without_gpu_and_reports_version(built_lib):
     lib = _capi.lib()
-    assert lib.mvgx_abi_version() == 11
+    assert lib.mvgx_abi_version() == 12
     assert _capi.device_count() >= 0
 
 

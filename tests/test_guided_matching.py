@@ -132,13 +132,100 @@ def test_other_descriptor_lengths_and_argument_checks_emulated():
             geofilter.guided_matching([xi, xj], [di, dj], [(0, 1)], [M], [4.0], 0.8, 2)      # unknown kind
 
 
-# ---- through the replacement TU: ImageCollectionGeometricFilter::Robust_model_estimation(functor, putative, b_guided_matching = true) ----
-def _matching_descriptors(feats, putative, seed):
-    """descriptors under which the putative matches look alike (so that guided matching keeps many of them) and everything else is noise"""
+# ---- the other region types (round 6; VERDICT r5 "what's missing" 5): AKAZE float (L2<float>) and AKAZE binary (squared Hamming) ----
+def _typed_pair(rng, n_true, n_ci, n_cj, kind, desc_type, dup=0, n_el=64):
+    """_pair with float rows or bit rows derived from its uint8 descriptors (true matches look alike there): float = the bytes scaled and
+    normalised to unit length (AKAZE's M-SURF rows are unit vectors; near-ties in the last float bits are what the summation order decides),
+    bits = the four high bits of every byte (true matches differ in a few bits, everything else in half of them)"""
+    xi, bi, xj, bj, M = _pair(rng, n_true, n_ci, n_cj, kind, desc_bytes=n_el, dup=dup)
+    if desc_type == 1:
+        di = bi.astype(np.float32) / np.float32(255); dj = bj.astype(np.float32) / np.float32(255)
+        di = (di / np.maximum(np.linalg.norm(di, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+        dj = (dj / np.maximum(np.linalg.norm(dj, axis=1, keepdims=True), 1e-6)).astype(np.float32)
+    else:
+        di = bi & 0xF0; dj = bj & 0xF0
+    return xi, np.ascontiguousarray(di), xj, np.ascontiguousarray(dj), M
+
+
+@pytest.mark.skipif(not _oracle.have_ref_geofilter(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("desc_type", [1, 2])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_typed_restatement_equals_the_reference_template(kind, desc_type):
+    rng = np.random.default_rng(131 + 2 * kind + desc_type)
+    total = 0
+    for trial in range(4):
+        xi, di, xj, dj, M = _typed_pair(rng, 120, 150, 170, kind, desc_type, dup=3 if trial % 2 else 0)
+        for prec, ratio in ((4.0, 0.8), (60.0, 0.9), (30.0, 1.0)):
+            want = _oracle.ref_guided_match_typed(kind, desc_type, M, xi, di, xj, dj, prec * prec, ratio * ratio)
+            got = _oracle.port_guided_match_typed(kind, desc_type, M, xi, di, xj, dj, prec * prec, ratio * ratio)
+            assert np.array_equal(want, got), (trial, prec, ratio, len(want), len(got))
+            total += len(want)
+    assert total > 30
+
+
+def _typed_device_equals_restatement(emulated, n_pairs, sizes, seed):
     rng = np.random.default_rng(seed)
-    descs = [rng.integers(0, 256, (len(f), 128), dtype=np.uint8) for f in feats]
+    for desc_type, n_el in ((1, 64), (1, 128), (2, 64), (2, 32)):
+        for kind in (0, 1):
+            feats, descs, pairs, models, precs = [], [], [], [], []
+            for p in range(n_pairs):
+                xi, di, xj, dj, M = _typed_pair(rng, *sizes, kind, desc_type, dup=2 if p % 3 == 0 else 0, n_el=n_el)
+                feats += [xi, xj]; descs += [di, dj]
+                pairs.append((2 * p, 2 * p + 1)); models.append(M)
+                precs.append([4.0, 40.0, np.inf, 25.0][p % 4])
+            feats += [np.zeros((0, 2))]; descs += [np.zeros((0, n_el), descs[0].dtype)]
+            pairs += [(len(feats) - 1, 1), (0, len(feats) - 1)]; models += [models[0], models[0]]; precs += [4.0, 4.0]
+            ratio = 0.9
+            with (_emu.emulated() if emulated else contextlib.nullcontext()):
+                got, st = geofilter.guided_matching(feats, descs, pairs, models, precs, ratio, kind, desc_type=desc_type)
+            n = 0
+            for p, (I, J) in enumerate(pairs):
+                th = precs[p] * precs[p]
+                want = (_oracle.port_guided_match_typed(kind, desc_type, models[p], feats[I], descs[I], feats[J], descs[J], th, ratio * ratio)
+                        if np.isfinite(th) else np.zeros((0, 2), np.uint32))
+                have = got.get((I, J), np.zeros((0, 2), np.uint32))
+                assert np.array_equal(want, have), (desc_type, n_el, kind, p, len(want), len(have))
+                n += len(want)
+            assert n > 0 and st.n_matches == n and st.n_geometric_passed > 0
+
+
+def test_typed_device_code_equals_the_restatement_emulated():
+    _typed_device_equals_restatement(True, 4, (40, 50, 45), 15)
+
+
+@pytest.mark.gpu
+def test_typed_device_equals_the_restatement_on_the_mi355x():
+    _typed_device_equals_restatement(False, 12, (400, 900, 1100), 17)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _oracle.have_ref_geofilter(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("desc_type", [1, 2])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_typed_device_equals_the_reference_template_on_the_mi355x(kind, desc_type):
+    rng = np.random.default_rng(177 + 2 * kind + desc_type)
+    xi, di, xj, dj, M = _typed_pair(rng, 700, 1300, 1500, kind, desc_type, dup=5)
+    for prec, ratio in ((4.0, 0.8), (50.0, 0.9)):
+        want = _oracle.ref_guided_match_typed(kind, desc_type, M, xi, di, xj, dj, prec * prec, ratio * ratio)
+        got, _ = geofilter.guided_matching([xi, xj], [di, dj], [(0, 1)], [M], [prec], ratio, kind, desc_type=desc_type)
+        assert np.array_equal(want, got.get((0, 1), np.zeros((0, 2), np.uint32))), (prec, ratio, len(want))
+    assert len(want) > 3
+
+
+# ---- through the replacement TU: ImageCollectionGeometricFilter::Robust_model_estimation(functor, putative, b_guided_matching = true) ----
+def _matching_descriptors(feats, putative, seed, desc_type=0):
+    """descriptors under which the putative matches look alike (so that guided matching keeps many of them) and everything else is noise;
+    desc_type 1 / 2: 64 floats (unit rows) / 64 bytes of bits derived from such bytes as in _typed_pair"""
+    rng = np.random.default_rng(seed)
+    n_el = 128 if desc_type == 0 else 64
+    descs = [rng.integers(0, 256, (len(f), n_el), dtype=np.uint8) for f in feats]
     for (I, J), m in putative.items():
-        descs[J][m[:, 1]] = np.clip(descs[I][m[:, 0]].astype(int) + rng.integers(-10, 11, (len(m), 128)), 0, 255).astype(np.uint8)
+        descs[J][m[:, 1]] = np.clip(descs[I][m[:, 0]].astype(int) + rng.integers(-10, 11, (len(m), n_el)), 0, 255).astype(np.uint8)
+    if desc_type == 1:
+        descs = [d.astype(np.float32) / np.float32(255) for d in descs]
+        descs = [np.ascontiguousarray((d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6)).astype(np.float32)) for d in descs]
+    elif desc_type == 2:
+        descs = [d & 0xF0 for d in descs]
     return descs
 
 
@@ -149,15 +236,15 @@ def _guided_counters(lib, reset=True):
     return int(out[0]), int(out[1])
 
 
-def _adapter_guided_case(kind, model, n_pairs, n_max):
+def _adapter_guided_case(kind, model, n_pairs, n_max, desc_type=0):
     from tests import _geofilter_scene
     ref_lib, lib = _oracle.geofilter_container_lib("reference"), _oracle.geofilter_container_lib(kind)
     if ref_lib is None or lib is None:
         pytest.skip("needs the reference library and the adapter harness (tools/prep_gpu.sh)")
     kw = dict(homography=True, inlier_frac=(0.6, 0.9)) if model == "h" else dict(size=(1000, 1000)) if model == "e" else {}
     feats, wh, putative = _geofilter_scene.collection(n_pairs=n_pairs, seed=33, n_min=40, n_max=n_max, no_geometry_frac=0.2, **kw)
-    descs = _matching_descriptors(feats, putative, 5)
-    args = dict(max_iterations=512, guided=True, ratio=0.8, descs=descs, model=model, focal=900.0 if model == "e" else 0.0)
+    descs = _matching_descriptors(feats, putative, 5, desc_type)
+    args = dict(max_iterations=512, guided=True, ratio=0.8, descs=descs, model=model, focal=900.0 if model == "e" else 0.0, desc_type=desc_type)
     want = _oracle.geofilter_container("reference", feats, wh, putative, **args)
     _guided_counters(lib)
     got = _oracle.geofilter_container(kind, feats, wh, putative, **args)
@@ -182,6 +269,19 @@ def test_adapter_guided_matching_runs_the_device_code_emulated(model):
 @pytest.mark.parametrize("model", ["f", "h", "e"])
 def test_adapter_guided_matching_on_the_mi355x(model):
     _adapter_guided_case("adapter", model, 60, 250)
+
+
+# AKAZE float / AKAZE binary regions through the replacement TU (round 6): the regions' own metric on the device, no host pair
+@pytest.mark.parametrize("desc_type,model", [(1, "f"), (2, "f"), (2, "h")])
+def test_adapter_guided_matching_other_region_types_emulated(desc_type, model):
+    _adapter_guided_case("adapter_emu", model, 4, 60, desc_type)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("desc_type", [1, 2])
+@pytest.mark.parametrize("model", ["f", "h", "e"])
+def test_adapter_guided_matching_other_region_types_on_the_mi355x(model, desc_type):
+    _adapter_guided_case("adapter", model, 40, 250, desc_type)
 
 
 def test_adapter_guided_matching_injected_failure_takes_the_reference_member_function(monkeypatch, capfd):
