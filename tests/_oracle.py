@@ -646,6 +646,23 @@ def ref_ba_reject_loop(scene, px_threshold=4.0, count=0, max_rounds=8, num_threa
                 removed=rem[:2 * r].reshape(r, 2).astype(np.int64), rmse=float(rmse[0]))
 
 
+def ref_ba_adjust_growing(scene, n_new_tracks=0, max_iterations=0, num_threads=0, lib=None):
+    """oracle/ref_shim_ba.cpp::ref_ba_adjust_growing: Adjust() without the last pose's view, then the view + its observations + n_new_tracks
+    of its tracks are added to the same SfM_Data and Adjust() runs again (resection, then BA: sequential_SfM.cpp:206-210).
+    -> dict(rc, seconds[2], rmse[3], counts (obs, tracks, obs, tracks), poses, intrinsics, points)"""
+    L = lib if lib is not None else C.CDLL(REF_BA_SO)
+    fn = L.ref_ba_adjust_growing
+    fn.restype = C.c_int
+    fn.argtypes = ([C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 8 + [C.c_uint32, C.c_int, C.c_int] + [C.c_void_p] * 3)
+    poses, intr, model, pts, op, oi, ox, xy = _flat(scene)
+    poses = poses.copy(); intr = intr.copy(); pts = pts.copy()
+    sec = np.zeros(2); rmse = np.zeros(3); counts = np.zeros(4, np.uint64)
+    rc = fn(len(poses), len(intr), len(pts), len(op), poses.ctypes.data, intr.ctypes.data, model.ctypes.data, pts.ctypes.data, op.ctypes.data,
+            oi.ctypes.data, ox.ctypes.data, xy.ctypes.data, int(n_new_tracks), int(max_iterations), int(num_threads), sec.ctypes.data, rmse.ctypes.data,
+            counts.ctypes.data)
+    return dict(rc=rc, seconds=sec, rmse=rmse, counts=counts.astype(np.int64), poses=poses, intrinsics=intr, points=pts)
+
+
 def ref_save_baf(scene, path):
     """The reference's Save_BAF (sfm/sfm_data_io_baf.hpp) on the flat scene (oracle/ref_shim_ba.cpp::ref_save_baf)."""
     L = C.CDLL(REF_BA_SO)
@@ -737,7 +754,7 @@ def adapter():
                      "ref_cascade_matcher_regions_match_liop144", "ref_cascade_hash_u8", "mvgx_adapter_counters",
                      "mvgx_adapter_cascade_last_hash_check"):   # (the counters of the matcher half: which route produced a container)
             setattr(both, name, getattr(m, name))
-        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
+        for name in ("ref_ba_adjust", "ref_ba_adjust_ex", "ref_ba_prior_prepare", "ref_ba_filters", "ref_ba_filters_timed", "ref_ba_reject_loop", "ref_ba_adjust_growing", "mvgx_adapter_ba_context_stats", "mvgx_adapter_ba_context_stats3",
                      "mvgx_adapter_ba_release_context", "mvgx_adapter_ba_kept_solver_info"):
             setattr(both, name, getattr(b, name))
         both.ba_counters = b.mvgx_adapter_counters   # (the counters of the BA half)
