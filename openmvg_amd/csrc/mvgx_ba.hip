@@ -2040,9 +2040,10 @@ __device__ __forceinline__ void sp_strip_compute(const StripOperands& o, double 
 // block dg (lower triangle, row s at s (s + 1) / 2) and its own row a[0..7] of the same eight columns. Right-looking on unscaled columns,
 // exactly the recurrence of the rows themselves: x_t -= (x_j / d_j) dg[t][j] for t > j. Out: the multipliers lj[j] = a_j / d_j of the own
 // row, the pivots (1.0 where the block is not positive definite: ok turns false, uniformly - every lane sees the same dg).
-__device__ __forceinline__ bool panel8_factor(double (&dg)[36], double* __restrict__ a, double (&lj)[8], double* __restrict__ piv, bool ok) {
+template <int G>
+__device__ __forceinline__ bool panel_factor(double (&dg)[G * (G + 1) / 2], double* __restrict__ a, double (&lj)[G], double* __restrict__ piv, bool ok) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < G; ++j) {
     const double dj = dg[j * (j + 1) / 2 + j];
     ok = ok && (dj > 0.0) && isfinite(dj);
     const double dsafe = ok ? dj : 1.0;
@@ -2050,9 +2051,9 @@ __device__ __forceinline__ bool panel8_factor(double (&dg)[36], double* __restri
     const double r = fast_rcp(dsafe);
     lj[j] = a[j] * r;
 #pragma unroll
-    for (int t = j + 1; t < 8; ++t) a[t] -= lj[j] * dg[t * (t + 1) / 2 + j];
+    for (int t = j + 1; t < G; ++t) a[t] -= lj[j] * dg[t * (t + 1) / 2 + j];
 #pragma unroll
-    for (int s_ = j + 1; s_ < 8; ++s_) {
+    for (int s_ = j + 1; s_ < G; ++s_) {
       const double m = dg[s_ * (s_ + 1) / 2 + j] * r;
 #pragma unroll
       for (int t = j + 1; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] -= m * dg[t * (t + 1) / 2 + j];
@@ -2060,6 +2061,15 @@ __device__ __forceinline__ bool panel8_factor(double (&dg)[36], double* __restri
   }
   return ok;
 }
+// (round 6) The sub-panel width: 16 pivots as 16 / kPanelG sub-panels whose kPanelG x kPanelG diagonal block every lane factors redundantly.
+// The redundant block costs G^3 / 6 multiply-adds per sub-panel in every lane: 84 at G = 8 (two sub-panels: 168 + the two hand-overs),
+// 10 at G = 4 (four sub-panels: 40 + six hand-overs through the wave's scratch block). Same operations on the same values in the same order
+// for every G (a_rt -= (a_rj / d_j) a_pt, j ascending): same bits. -DMVGX_BA_PANEL_G=8: the round-5 form (A/B runs).
+#ifndef MVGX_BA_PANEL_G
+#define MVGX_BA_PANEL_G 4
+#endif
+constexpr int kPanelG = MVGX_BA_PANEL_G;
+static_assert(16 % kPanelG == 0 && kPanelG >= 2, "sub-panels of the 16-column panel");
 
 // Factor the kb x kb diagonal block (kb <= 64, identity-padded to 64) and invert the factor. One workgroup; the block is
 // processed as four 64 x 16 column panels: a register-resident panel factorisation by one wave, then a rank-16 update
@@ -2174,52 +2184,56 @@ __device__ __forceinline__ void chol_diag_inv_body(double* __restrict__ A, int l
     // barriers. Right-looking on UNscaled columns: a_rt -= (a_rj / d_j) a_pt for t > j, p = j0 + j; the 1 / sqrt(d)
     // scaling is applied when the panel is written back. Rows above the pivot compute garbage that is never stored.
     if (wave == 0) {
-      // Round 5: the 16 columns as two sub-panels of 8 whose 8 x 8 diagonal block every lane factors REDUNDANTLY in its own registers
-      // (panel8_factor): no pivot crosses a lane any more. The v_readlane-fed form (one pivot = 2 + 2 (15 - j) readlanes in front of the
+      // Round 5: the 16 columns as sub-panels (two of 8 then; four of 4 since round 6) whose diagonal block every lane factors REDUNDANTLY in its
+      // own registers (panel_factor): no pivot crosses a lane any more. The v_readlane-fed form (one pivot = 2 + 2 (15 - j) readlanes in front of the
       // multiply-adds, ~380 clocks) gave way to ~36 broadcast LDS reads per sub-panel; between the two sub-panels the eight rows
       // j0 + 8 .. j0 + 15 hand their entries to every lane through the wave's scratch block. Same operations on the same values in the
       // same order as the one-pivot-at-a-time form (a_rt -= (a_rj / d_j) a_pt, unscaled columns, 1 / sqrt(d) at the write-back): same bits.
-      double a[16], dg[36], lj[8], piv[16];
-      double* X = &T0[0][0];   // wave 0's scratch blocks (the inverse schedule never gives wave 0 a task): 64 doubles used
+      double a[16], dg[kPanelG * (kPanelG + 1) / 2], lj[kPanelG], piv[16];
+      double* X = &T0[0][0];   // wave 0's scratch blocks (the inverse schedule never gives wave 0 a task): (16 - G) G + G G doubles used
+      double* X2 = X + (16 - kPanelG) * kPanelG;
       MVGX_STAMP_W(10);
 #pragma unroll
       for (int t = 0; t < 16; ++t) a[t] = L[lane][j0 + t];
 #pragma unroll
-      for (int s_ = 0; s_ < 8; ++s_)
+      for (int s_ = 0; s_ < kPanelG; ++s_)
 #pragma unroll
         for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = L[j0 + s_][j0 + t];   // wave-uniform addresses: broadcast reads
       MVGX_STAMP_W(11);
-      bool ok = panel8_factor(dg, a, lj, piv, true);
-      MVGX_STAMP_W(12);
-      // columns 8 .. 15 of the panel: a[8 + t] -= sum_k (a_rk / d_k) U[t][k], U = the unscaled entries of rows j0 + 8 + t, k ascending
-      if ((unsigned)(lane - (j0 + 8)) < 8u) {
+      bool ok = true;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[(lane - (j0 + 8)) * 8 + k] = a[k];
+      for (int c0 = 0; c0 < 16; c0 += kPanelG) {
+        ok = panel_factor<kPanelG>(dg, a + c0, lj, piv + c0, ok);
+        if (c0 + kPanelG >= 16) break;
+        // the columns right of the sub-panel: a[c0 + G + t] -= sum_k (a_rk / d_k) U[t][k], U = the unscaled entries (columns c0 .. c0 + G - 1)
+        // of rows j0 + c0 + G + t, k ascending - handed to every lane through the wave's scratch block
+        const int nrem = 16 - (c0 + kPanelG);
+        const int row0 = j0 + c0 + kPanelG;
+        if ((unsigned)(lane - row0) < (unsigned)nrem) {
+#pragma unroll
+          for (int k = 0; k < kPanelG; ++k) X[(lane - row0) * kPanelG + k] = a[c0 + k];
+        }
+        lds_wave_sync();
+#pragma unroll
+        for (int t = 0; t < nrem; ++t) {
+          double u[kPanelG];
+#pragma unroll
+          for (int k = 0; k < kPanelG; ++k) u[k] = X[t * kPanelG + k];
+#pragma unroll
+          for (int k = 0; k < kPanelG; ++k) a[c0 + kPanelG + t] -= lj[k] * u[k];
+        }
+        // the next diagonal block: rows row0 .. row0 + G - 1 hand over their entries of columns c0 + G .. c0 + 2 G - 1
+        if ((unsigned)(lane - row0) < (unsigned)kPanelG) {
+#pragma unroll
+          for (int t = 0; t < kPanelG; ++t) X2[(lane - row0) * kPanelG + t] = a[c0 + kPanelG + t];
+        }
+        lds_wave_sync();   // (also: every lane has read U before the next sub-panel overwrites it)
+#pragma unroll
+        for (int s_ = 0; s_ < kPanelG; ++s_)
+#pragma unroll
+          for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = X2[s_ * kPanelG + t];
+        lds_wave_sync();   // (X2 is read before the next hand-over writes it)
       }
-      lds_wave_sync();
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        double u[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) u[q] = X[half * 32 + q];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int k = 0; k < 8; ++k) a[8 + 4 * half + t] -= lj[k] * u[t * 8 + k];
-      }
-      MVGX_STAMP_W(13);
-      lds_wave_sync();   // every lane has read U before the scratch is reused
-      if ((unsigned)(lane - (j0 + 8)) < 8u) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) X[(lane - (j0 + 8)) * 8 + t] = a[8 + t];
-      }
-      lds_wave_sync();
-#pragma unroll
-      for (int s_ = 0; s_ < 8; ++s_)
-#pragma unroll
-        for (int t = 0; t <= s_; ++t) dg[s_ * (s_ + 1) / 2 + t] = X[s_ * 8 + t];
-      MVGX_STAMP_W(14);
-      ok = panel8_factor(dg, a + 8, lj, piv + 8, ok);
       MVGX_STAMP_W(15);
       double dmine = 1.0;   // lane j keeps pivot j: the 16 square roots are taken once, in parallel, after the chain
 #pragma unroll
@@ -5252,9 +5266,9 @@ int mvgx_ba_destroy(mvgx_ba_ctx* c) {
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_factor_stamps), sizeof(st)) == hipSuccess) {
       fprintf(stderr, "[mvgx factor kernel, shader clocks] load %lld | panels (+ overlapped inverse) %lld %lld %lld %lld | inverse tail A %lld | tail B %lld | store %lld | total %lld\n",
               st[1] - st[0], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[9] - st[0]);
-      fprintf(stderr, "[mvgx factor kernel, second panel slot, wave 0] row + diagonal-block loads %lld | first 8 pivots %lld | hand-over + columns 8..15 %lld | second "
-              "diagonal block %lld | second 8 pivots %lld | square roots + write-back %lld | wait for the other waves %lld | rank-16 update + barrier %lld\n",
-              st[11] - st[10], st[12] - st[11], st[13] - st[12], st[14] - st[13], st[15] - st[14], st[16] - st[15], st[17] - st[16], st[18] - st[17]);
+      fprintf(stderr, "[mvgx factor kernel, second panel slot, wave 0] row + diagonal-block loads %lld | the sub-panels with their hand-overs %lld | "
+              "square roots + write-back %lld | wait for the other waves %lld | rank-16 update + barrier %lld\n",
+              st[11] - st[10], st[15] - st[11], st[16] - st[15], st[17] - st[16], st[18] - st[17]);
     }
   }
   if (getenv("MVGX_BA_GROUP_DEBUG")) {
