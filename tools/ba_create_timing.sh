@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r5_25
-MVGX_BA_CREATE_TIMING=1 python - > gpurun_out/r5_25/create_timing.txt 2>&1 <<'PY'
+mkdir -p gpurun_out/${CALL:-r6_41}
+MVGX_BA_CREATE_TIMING=1 python - > gpurun_out/${CALL:-r6_41}/create_timing.txt 2>&1 <<'PY'
 import sys, time
 sys.path.insert(0, '.')
 import bench_ba
@@ -12,4 +12,4 @@ for name in ("c3", "c5"):
         if rep == 0: c.solve(ba.default_options(max_num_iterations=2))
         c.close()
 PY
-tail -70 gpurun_out/r5_25/create_timing.txt
+tail -70 gpurun_out/${CALL:-r6_41}/create_timing.txt
