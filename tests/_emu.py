@@ -15,8 +15,13 @@ from openmvg_amd import _capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SRC = os.path.join(_HERE, "native", "hipemu")
-_OUT = os.path.join(_HERE, "native", "_build", "libmvgx_ba_emu.so")
 _CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+# MVGX_EMU_SANITIZE=1 (tools/sanitize_cpu.sh): the emulation libraries built with AddressSanitizer + UndefinedBehaviorSanitizer into files of
+# their own; the interpreter must then run with the ASan runtime preloaded. GPU sanitizers do not exist on this pool - the device source is
+# checked for out-of-bounds and undefined behaviour here, on the CPU build of the same code.
+_SAN = os.environ.get("MVGX_EMU_SANITIZE") == "1"
+_SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-shared-libsan", "-fno-omit-frame-pointer", "-g", "-O1"] if _SAN else ["-O2"]
+_OUT = os.path.join(_HERE, "native", "_build", "libmvgx_ba_emu_san.so" if _SAN else "libmvgx_ba_emu.so")
 
 
 def build(force=False):
@@ -28,7 +33,7 @@ def build(force=False):
         return _OUT
     os.makedirs(os.path.dirname(_OUT), exist_ok=True)
     cxx = _CLANG if os.path.exists(_CLANG) else "clang++"
-    subprocess.run([cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-psabi",
+    subprocess.run([cxx, "-x", "c++", "-std=c++17", *_SAN_FLAGS, "-fPIC", "-shared", "-Wno-psabi",
                     "-Wl,-Bsymbolic",   # never bind to same-named (weak, inline) symbols of libmvgx_hip.so loaded earlier
                     "-I" + _SRC,
                     "-I" + os.path.join(_ROOT, "include"), "-I" + csrc, os.path.join(_SRC, "hipemu.cpp"), "-o", _OUT], check=True)
@@ -81,7 +86,7 @@ def emulated():
 # ---------------------------------------------------------------------------------------------------------
 # the matching path (second emulation library)
 # ---------------------------------------------------------------------------------------------------------
-_OUT_MATCH = os.path.join(_HERE, "native", "_build", "libmvgx_match_emu.so")
+_OUT_MATCH = os.path.join(_HERE, "native", "_build", "libmvgx_match_emu_san.so" if _SAN else "libmvgx_match_emu.so")
 _GEN_MATCH = os.path.join(_HERE, "native", "_build", "mvgx_match_emu.hip")
 
 _HOST_STAGING = """
@@ -134,7 +139,7 @@ def build_match(force=False):
     if not force and os.path.exists(_OUT_MATCH) and all(os.path.getmtime(d) <= os.path.getmtime(_OUT_MATCH) for d in deps):
         return _OUT_MATCH
     cxx = _CLANG if os.path.exists(_CLANG) else "clang++"
-    subprocess.run([cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-psabi", "-Wl,-Bsymbolic", "-I" + _SRC,
+    subprocess.run([cxx, "-x", "c++", "-std=c++17", *_SAN_FLAGS, "-fPIC", "-shared", "-Wno-psabi", "-Wl,-Bsymbolic", "-I" + _SRC,
                     "-I" + os.path.dirname(gen), "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "openmvg_amd", "csrc"),
                     os.path.join(_SRC, "hipemu_match.cpp"), "-o", _OUT_MATCH], check=True)
     return _OUT_MATCH

@@ -102,6 +102,10 @@ print(json.dumps({'images': $n, 'descriptors_per_image': $dsc, 'value': r['value
   run:*)      # run:<script under tools/ or repo-relative python file with args, '+' for spaces>
     cmd=${mode#run:}; cmd=${cmd//+/ }
     timeout 1200 python $cmd 2>&1 | tee "$O/run_$(echo "$cmd" | tr -c 'A-Za-z0-9_.' '_' | cut -c1-60).log" | tail -15 ;;
+  fuzz:*)     # fuzz:<seconds match>:<seconds ba>[:seed] - randomised parity campaign against the compiled reference (tools/fuzz_gpu.py)
+    IFS=: read -r _ sm sb seed <<< "$mode"; seed=${seed:-1}
+    timeout $((sm + 600)) python tools/fuzz_gpu.py match "$sm" "$seed" 2>&1 | grep -v "^INFO" | tee "$O/fuzz_match_seed$seed.txt" | tail -5
+    timeout $((sb + 900)) python tools/fuzz_gpu.py ba "$sb" "$seed" 2>&1 | grep -v "^INFO" | tee "$O/fuzz_ba_seed$seed.txt" | tail -8 ;;
   *) echo "unknown mode $mode" ;;
   esac
 done
