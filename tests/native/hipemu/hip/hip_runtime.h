@@ -101,7 +101,7 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
 #define __builtin_amdgcn_readlane(v, l) hipemu::readlane_i32((v), (l))
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
-static inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &b, 8); return d; }
+static inline double __hiloint2double(int hi, int lo) { long long b = (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo); double d; memcpy(&d, &b, 8); return d; }
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))   /* v_rcp_f64: the device refines it with Newton steps */
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))   /* v_rsq_f64: refined on the device likewise */
 
