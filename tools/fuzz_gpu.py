@@ -4,6 +4,7 @@ Bundle_Adjustment_Ceres::Adjust): test infrastructure, not product.
     python tools/fuzz_gpu.py match <seconds> [seed]     ragged image sets (0 .. 6 000 descriptors per image, duplicated rows inside
                                                          and across images, every ratio the adapters pass) through mvgx_match_*; the
                                                          lists must EQUAL the reference's (regions_matcher.hpp:171-205)
+    python tools/fuzz_gpu.py other <seconds> [seed]     the Hamming / float L2 / 144-byte uint8 L2 matchers likewise
     python tools/fuzz_gpu.py ba <seconds> [seed]        random scenes (3 .. 120 views, every camera model, shared intrinsics, track
                                                          lengths from 2 to 40 so that the usual groups, the wide groups and the
                                                          record-based path meet in one scene, outliers under the Huber loss, every
@@ -64,6 +65,54 @@ def fuzz_match(seconds, seed):
             bad += 1
             print("MISMATCH match", sizes, mode, s, ratio, bp, flush=True)
     print(f"match: cases {n_cases} image pairs {n_pairs} matches {n_matches} mismatches {bad} ({time.time() - t0:.0f} s, seed {seed})", flush=True)
+    return bad
+
+
+def fuzz_other(seconds, seed):
+    """the other instantiations of ArrayMatcherBruteForce (mvgx_bruteforce.hip): 64-byte binary rows under Hamming, 64-float rows under L2<float>
+    (the reference's summation order: lists EQUAL), 144-byte uint8 rows under L2 - ragged sets, repeated rows, against the reference's own matcher"""
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); n = [0, 0, 0]; bad = 0; n_matches = 0
+    pools = [list(range(0, 20)), list(range(250, 270)), [63, 64, 65, 255, 256, 257, 1023, 1024, 1025], list(range(300, 2600, 53))]
+    while time.time() - t0 < seconds:
+        kind = int(rng.integers(0, 3))
+        k = int(rng.integers(2, 6))
+        sizes = [int(rng.choice(pools[int(rng.integers(0, len(pools)))])) for _ in range(k)]
+        s = int(rng.integers(1 << 30))
+        ratio = float(rng.choice([0.6, 0.8, 0.8, 0.95, 1.0]))
+        bp = int(rng.choice([0, 0, 1, 3]))
+        pairs = np.array([(i, j) for i in range(k) for j in range(k) if i != j], np.uint32)
+        if kind == 0:
+            imgs = synth.binary_descriptors(k, sizes, n_bytes=64, seed=s, flip_bits=int(rng.choice([8, 40, 120])))
+            ctx = matching.HammingContext(0); arg = ratio; ref_fn = _oracle.ref_matcher_regions_match_binary64; L = 64
+        elif kind == 1:
+            imgs = synth.float_descriptors(k, sizes, dim=64, seed=s, noise=float(rng.choice([0.01, 0.05, 0.3])))
+            ctx = matching.L2fContext(0); arg = np.float32(ratio) * np.float32(ratio); ref_fn = _oracle.ref_matcher_regions_match_float64; L = 64
+        else:
+            g = np.random.default_rng(s)
+            imgs = [g.integers(0, 256, (m, 144), dtype=np.uint8) for m in sizes]
+            for q in range(1, k):   # near-duplicates of the image before (matches exist), full byte range
+                m = min(sizes[q], sizes[q - 1])
+                if m:
+                    imgs[q][:m] = np.clip(imgs[q - 1][:m].astype(np.int16) + g.integers(-9, 10, (m, 144)), 0, 255).astype(np.uint8)
+            ctx = matching.L2u8Context(0); arg = np.float32(ratio) * np.float32(ratio); ref_fn = _oracle.ref_matcher_regions_match_liop144; L = 144
+        if sizes[0] > 3 and rng.random() < 0.5:   # a row twice in one image: a tie for the first place
+            imgs[0] = imgs[0].copy(); imgs[0][1] = imgs[0][3]
+        try:
+            if bp:
+                ctx.set_option("batch_pairs", bp)
+            ctx.set_regions(imgs, L)
+            _, off, ij = ctx.run(pairs, arg)
+        finally:
+            ctx.close()
+        ref = ref_fn(imgs, pairs, ratio)
+        got = _oracle.offsets_to_dict(pairs, off, ij)
+        ok = set(got) == set(ref) and all(np.array_equal(got[q], ref[q]) for q in ref)
+        n[kind] += 1; n_matches += int(sum(len(v) for v in ref.values()))
+        if not ok:
+            bad += 1
+            print("MISMATCH other", ["hamming", "l2_float", "l2_uint8_144"][kind], sizes, s, ratio, bp, flush=True)
+    print(f"other matchers: cases hamming {n[0]} / float L2 {n[1]} / uint8-144 L2 {n[2]} matches {n_matches} mismatches {bad} ({time.time() - t0:.0f} s, seed {seed})", flush=True)
     return bad
 
 
@@ -190,5 +239,5 @@ if __name__ == "__main__":
     if what == "ba-replay":   # ba-replay <seed> <s,s,...>
         replay_ba(int(sys.argv[2]), [int(x) for x in sys.argv[3].split(",")])
         sys.exit(0)
-    rc = (fuzz_match if what == "match" else fuzz_ba)(seconds, seed)
+    rc = {"match": fuzz_match, "other": fuzz_other, "ba": fuzz_ba}[what](seconds, seed)
     sys.exit(1 if rc else 0)

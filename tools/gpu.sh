@@ -102,6 +102,9 @@ print(json.dumps({'images': $n, 'descriptors_per_image': $dsc, 'value': r['value
   run:*)      # run:<script under tools/ or repo-relative python file with args, '+' for spaces>
     cmd=${mode#run:}; cmd=${cmd//+/ }
     timeout 1200 python $cmd 2>&1 | tee "$O/run_$(echo "$cmd" | tr -c 'A-Za-z0-9_.' '_' | cut -c1-60).log" | tail -15 ;;
+  fuzzother:*)  # fuzzother:<seconds>[:seed] - the Hamming / float / uint8-144 matchers against the reference's own
+    IFS=: read -r _ so seed <<< "$mode"; seed=${seed:-1}
+    timeout $((so + 600)) python tools/fuzz_gpu.py other "$so" "$seed" 2>&1 | grep -v "^INFO" | tee "$O/fuzz_other_seed$seed.txt" | tail -5 ;;
   fuzz:*)     # fuzz:<seconds match>:<seconds ba>[:seed] - randomised parity campaign against the compiled reference (tools/fuzz_gpu.py)
     IFS=: read -r _ sm sb seed <<< "$mode"; seed=${seed:-1}
     timeout $((sm + 600)) python tools/fuzz_gpu.py match "$sm" "$seed" 2>&1 | grep -v "^INFO" | tee "$O/fuzz_match_seed$seed.txt" | tail -5
