@@ -1148,6 +1148,12 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
                                                                        double* __restrict__ part_pp, double* __restrict__ part_pi,
                                                                        double* __restrict__ part_ii, double* __restrict__ cand_part, uint32_t sg_base, int zero_system) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // (round 6) issue priority: a forward workgroup's waves go FIRST on their SIMDs outside the Z^T Z phase and last inside it. The matrix
+  // instruction holds the SIMD's vector issue for 64 cycles (section 4.3 of DESIGN.md): a SIMD-mate in its evaluation / sum / factor phases -
+  // dependent chains - otherwise gets one instruction in between and crawls; with priority it issues whenever it can and the matrix stream
+  // takes what is left. C3 0.498 against 0.508 ms per iteration, C5 1.328 against 1.335 (calls r6_60 / r6_61, same box, three alternations;
+  // the reverse assignment: half of it; the same in the Gram kernel: nothing). Same results: only the order of issue changes.
+  if (MODE == kGroupForward) __builtin_amdgcn_s_setprio(3);
   double* const M = lds;                          // per-observation terms [value][thread] -> the staged matrix [row][kGroupCS] -> partial blocks
   double* const sums = lds + group_m_doubles<MODE>();   // [point][20]
   double* const ptab = sums + kGroupSums;         // [point][12]: L^-1 (6) | h (3)
@@ -1638,6 +1644,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
     }
     __syncthreads();
     MVGX_GSTAMP(5);
+    if (MODE == kGroupForward) __builtin_amdgcn_s_setprio(0);   // (see the head of the kernel)
     // ---- 6. Z^T Z: the upper tiles dealt round-robin to the waves, accumulated over the groups of the supergroup ----
     if (wide) {   // (uniform) the wide form: 36 tiles, a wave's nine one after the other, each straight to the partial blocks
       for (int t = wave; t < wide_col_tiles * (wide_col_tiles + 1) / 2; t += kGroupWaves) {
@@ -1684,6 +1691,7 @@ __global__ __launch_bounds__(kGroupThreads, (MODE == 1 /* kGroupForward */ || (M
       sacc[0] = s0; sacc[1] = s1;
     }
     }
+    if (MODE == kGroupForward) __builtin_amdgcn_s_setprio(3);
     MVGX_GSTAMP(6);
   }
   if (with_cand) {   // (uniform) the supergroup's five sums, in wave order

@@ -862,12 +862,18 @@ __global__ __launch_bounds__(256, 2) void l2_filter16_kernel(MatchParams p) {
     a0[1] = *reinterpret_cast<const v4i*>(wb + 2048);
     c0 = *reinterpret_cast<const v4i*>(wc);
     // (the first epilogue of a window folds accB = neutral into block class 1 of blocks 4..7: a no-op)
+    // (round 6) the wave is given issue priority over its SIMD-mate for the tile loop and hands it back for the window's fold: the mate in
+    // its MFMA stream then goes first while this wave is at a fold, a barrier, its start or its merge - 11.80 against 11.89 ms per launch at
+    // 2 000 descriptors, 3.53 against 3.57 at 1 000 (calls r6_58 / r6_59; priority over the whole run of windows: half the gain; priority
+    // in the OTHER phases instead: a little slower than none)
+    __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < nt; ++t) {
       const int tn = min(t + 1, nt - 1);   // the fetch past the window's last tile re-reads it (no branch around the loads)
       MVGX_BLOCK16(a0, c0, a1, c1, 0, t * kTileBytes + 256, t * (kTileRows * 4) + 64)
       MVGX_BLOCK16(a1, c1, a0, c0, 1, tn * kTileBytes, tn * (kTileRows * 4))
     }
     MVGX_EPI16(accB, 4, 1)   // drain: the second group of the window's last block
+    __builtin_amdgcn_s_setprio(0);
 #undef MVGX_GROUP16
 #undef MVGX_EPI16
 #undef MVGX_MIX16

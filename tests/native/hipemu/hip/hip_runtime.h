@@ -83,6 +83,7 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline float __int2float_rn(int v) { return (float)v; }
 #define __builtin_amdgcn_readfirstlane(v) hipemu::readlane_i32((int)(v), 0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp

@@ -82,6 +82,11 @@ for mode in "$@"; do
       echo "tree $s $(python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
       echo "prev $s $(MVGX_LIB_PATH=$R/tools/_build/libmvgx_prev.so python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_ab.txt"
     done; done ;;
+  balibab)    # same-box A/B of BA builds: LIBS = "tree <name> ..." (tools/_build/libmvgx_<name>.so), alternating, both scenes
+    for rep in 1 2 3; do for s in c3 c5; do for which in ${LIBS:-tree prev}; do
+      lib=""; [ $which != tree ] && lib=$R/tools/_build/libmvgx_$which.so
+      echo "$which $s $(MVGX_LIB_PATH=$lib python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_lib_ab.txt"
+    done; done; done ;;
   matchab)    # the filter kernel on the two MFMA shapes, alternating, headline leg only
     for rep in 1 2 3; do for shape in ${SHAPES:-16 32}; do
       python bench.py --filter-shape $shape --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
@@ -90,8 +95,8 @@ r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]
 print(json.dumps({'filter_shape': $shape, 'value': r['value'], 'frac': r['roofline']['frac'], 'mean_launch_ms': r['roofline']['mean_launch_ms'], 'ms_per_step': r['ms_per_step'], 'kernel': r['roofline']['kernel']}))" | tee -a "$O/match_filter_shape_ab.jsonl"
     done; done ;;
   matchlibab) # same-box A/B of a matching change: tools/_build/libmvgx_exp.so (an experimental build) against the tree, alternating, headline leg; DESC / IMAGES: the set
-    for rep in 1 2 3; do for which in tree exp; do
-      lib=""; [ $which = exp ] && lib=$R/tools/_build/libmvgx_exp.so
+    for rep in 1 2 3; do for which in ${LIBS:-tree exp}; do
+      lib=""; [ $which != tree ] && lib=$R/tools/_build/libmvgx_$which.so
       MVGX_LIB_PATH=$lib python bench.py --images ${IMAGES:-1000} --desc ${DESC:-2000} --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
 import json,sys
 r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
