@@ -97,10 +97,10 @@ print(json.dumps({'filter_shape': $shape, 'value': r['value'], 'frac': r['roofli
   matchlibab) # same-box A/B of a matching change: tools/_build/libmvgx_exp.so (an experimental build) against the tree, alternating, headline leg; DESC / IMAGES: the set
     for rep in 1 2 3; do for which in ${LIBS:-tree exp}; do
       lib=""; [ $which != tree ] && lib=$R/tools/_build/libmvgx_$which.so
-      MVGX_LIB_PATH=$lib python bench.py --images ${IMAGES:-1000} --desc ${DESC:-2000} --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
+      MVGX_LIB_PATH=$lib python bench.py ${FSHAPE:+--filter-shape $FSHAPE} --images ${IMAGES:-1000} --desc ${DESC:-2000} --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
 import json,sys
 r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
-print(json.dumps({'library': '$which', 'descriptors_per_image': ${DESC:-2000}, 'value': r['value'], 'frac': r['roofline']['frac'], 'mean_launch_ms': r['roofline']['mean_launch_ms'], 'ms_per_step': r['ms_per_step']}))" | tee -a "$O/match_lib_ab.jsonl"
+print(json.dumps({'library': '$which${FSHAPE:+ shape $FSHAPE}', 'descriptors_per_image': ${DESC:-2000}, 'value': r['value'], 'frac': r['roofline']['frac'], 'mean_launch_ms': r['roofline']['mean_launch_ms'], 'ms_per_step': r['ms_per_step']}))" | tee -a "$O/match_lib_ab.jsonl"
     done; done ;;
   descsweep)  # the filter kernel's fraction of the i8 peak by descriptors per image (the per-workgroup start and the per-image finish amortise)
     for dsc in 1000 2000 4000 8000; do
