@@ -87,6 +87,11 @@ for mode in "$@"; do
       lib=""; [ $which != tree ] && lib=$R/tools/_build/libmvgx_$which.so
       echo "$which $s $(MVGX_LIB_PATH=$lib python tools/ba_iterations.py $s 8 --warm 2>&1 | tail -1)" | tee -a "$O/ba_lib_ab.txt"
     done; done; done ;;
+  geolibab)   # same-box A/B of geometric-filter builds: LIBS = "tree <name> ...", the three models, alternating
+    for rep in 1 2 3; do for m in f h e; do for which in ${LIBS:-tree prev}; do
+      lib=""; [ $which != tree ] && lib=$R/tools/_build/libmvgx_$which.so
+      echo "$which $(MVGX_LIB_PATH=$lib python tools/geofilter_run.py 20000 250 $m 2>/dev/null | head -1)" | tee -a "$O/geo_lib_ab.txt"
+    done; done; done ;;
   matchab)    # the filter kernel on the two MFMA shapes, alternating, headline leg only
     for rep in 1 2 3; do for shape in ${SHAPES:-16 32}; do
       python bench.py --filter-shape $shape --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-hamming 2>/dev/null | python -c "
